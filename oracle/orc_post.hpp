@@ -1,0 +1,406 @@
+// ORACLE — test infrastructure only (see orc_core.hpp header).
+// mapping qualities, mapDirectly file plumbing, EM classification and its output files.
+#pragma once
+#include "orc_map.hpp"
+#include <fstream>
+#include <iostream>
+#include <regex>
+
+namespace orc {
+
+// meta/util.h:80-118
+static inline std::vector<std::string> split(const std::string& in, const std::string& d) {
+  std::vector<std::string> out;
+  if (in.empty()) return out;
+  size_t s = 0, p;
+  while ((p = in.find(d, s)) != std::string::npos) { out.push_back(in.substr(s, p - s)); s = p + d.size(); }
+  out.push_back(in.substr(s));
+  return out;
+}
+static inline std::string join(const std::vector<std::string>& v, const std::string& d) {   // util.h:57-71
+  std::string r;
+  for (size_t i = 0; i < v.size(); ++i) { if (i) r += d; r += v[i]; }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// A12 mapping qualities — map/mapWrap.h:215-323, :332-356
+// ---------------------------------------------------------------------------------------
+static inline double likelihood_set_sizes(int k, int nKmers, double ident, int sketch, int inter) {   // :332-356
+  double surv = std::pow(ident, k);
+  double eSurv = std::round(surv * nKmers);
+  double eUnion = nKmers + (nKmers - eSurv);
+  return binom_pmf(sketch, eSurv / eUnion, inter);
+}
+static inline void add_mapping_qualities(const Params& P, std::vector<std::string>& lines) {
+  if (lines.empty()) return;
+  std::vector<double> ids; std::vector<std::pair<int, int>> sizes;
+  double maxId = -1; int readLen = 0;
+  for (auto& ln : lines) {
+    auto f = split(ln, " ");
+    readLen = std::stoi(f.at(1));
+    double id = std::stod(f.at(9)) / 100.0;                      // :237 — re-parsed 6-digit text
+    int inter = std::stoi(f.at(10)), sk = std::stoi(f.at(11));
+    if (id > maxId) maxId = id;
+    ids.push_back(id); sizes.push_back({sk, inter});
+  }
+  maxId = std::exp(-(1 - maxId));                                // :261
+  int nK = readLen - P.k + 1;                                    // :266
+  std::vector<double> L; double sum = 0;
+  for (auto& p : sizes) { double l = likelihood_set_sizes(P.k, nK, maxId, p.first, p.second); L.push_back(l); sum += l; }
+  if (!(sum > 0)) throw std::runtime_error("likelihood_sum == 0 (reference aborts here, mapWrap.h:298)");
+  for (size_t i = 0; i < lines.size(); ++i) {
+    double mq = L[i] / sum;
+    float corrected = std::exp(-(1 - ids[i]));                   // :311 double exp → float
+    std::ostringstream add;
+    add << " " << corrected * 100 << " " << mq;                  // :318-320
+    lines[i] += add.str();
+  }
+}
+
+// prettyprint.hpp rendering of std::vector<std::string> as used by mapWrap.h:204-205
+static inline std::string pretty(const std::vector<std::string>& v) {
+  std::string r = "[";
+  for (size_t i = 0; i < v.size(); ++i) { if (i) r += ", "; r += v[i]; }
+  return r + "]";
+}
+
+// mapWrap.h:34-213 — merges the per-chunk files PREFIX.N in read order and writes the side files.
+static inline void unify_files(const std::string& prefix, const Params& P, const std::vector<std::string>& chunkFiles,
+                               const std::string& queryFile, const std::string& refFile) {
+  std::ofstream out(prefix);
+  std::vector<std::ifstream*> in;
+  for (auto& f : chunkFiles) in.push_back(new std::ifstream(f));
+  std::ofstream unm(prefix + ".meta.unmappedReadsLengths");
+  std::set<std::string> done;
+  size_t total = 0, mapped = 0, tooShort = 0, notMapped = 0;
+  auto pull = [&](size_t fi, const std::string& id) {
+    std::vector<std::string> got;
+    std::ifstream& s = *in[fi];
+    if (!s.good()) return got;
+    std::streampos keep = s.tellg();
+    std::string ln;
+    while (s.good()) {
+      std::getline(s, ln);
+      size_t sp = ln.find(' ');
+      if (sp == std::string::npos) break;
+      std::string rid = ln.substr(0, sp);
+      if (done.count(rid)) { std::cerr << "Seems that read ID " << rid << " has already been processed\n"; exit(1); }
+      if (rid == id) { got.push_back(ln); keep = s.tellg(); } else break;
+    }
+    s.seekg(keep);
+    return got;
+  };
+  SeqReader rd(queryFile);
+  long len;
+  while ((len = rd.next()) >= 0) {
+    ++total;
+    if (len < P.w || len < P.k || len < P.minReadLen) { ++tooShort; continue; }
+    std::vector<std::string> lines;
+    for (size_t fi = 0; fi < in.size(); ++fi) { auto g = pull(fi, rd.name); lines.insert(lines.end(), g.begin(), g.end()); }
+    if (lines.empty()) { ++notMapped; unm << (int)len << "\t" << rd.name << "\n"; } else ++mapped;
+    add_mapping_qualities(P, lines);
+    for (auto& l : lines) out << l << "\n";
+    done.insert(rd.name);
+  }
+  for (auto* s : in) { s->close(); delete s; }
+  std::ofstream meta(prefix + ".meta");
+  meta << "TotalReads " << total << "\nReadsTooShort " << tooShort << "\nReadsMapped " << mapped
+       << "\nReadsNotMapped " << notMapped << "\n";
+  for (auto& f : chunkFiles) std::remove(f.c_str());
+  std::ofstream ps(prefix + ".parameters");
+  ps << "kmerSize " << P.k << "\nwindowSize " << P.w << "\nminReadLength " << P.minReadLen << "\nalphabetSize "
+     << P.alphabet << "\nreferenceSize " << P.refSize << "\npercentageIdentity " << P.pi << "\np_value " << P.pval
+     << "\nrefSequences " << pretty({refFile}) << "\nquerySequences " << pretty({queryFile}) << "\noutFileName "
+     << prefix << "\nreportAll " << P.reportAll << "\nindex " << "" << "\nmaximumMemory " << P.maxMem << "\n";
+}
+
+struct MapCounters { uint64_t reads = 0, bases = 0, sketch = 0, hits = 0, cands = 0, stream = 0, evals = 0, maps = 0; };
+
+// computeMap.hpp:104-172 (single-threaded; the pool only preserves input order) writing PREFIX.N
+static inline void map_query_file(const RefSketch& R, const Params& P, const std::string& queryFile,
+                                  const std::string& outFile, MapCounters* C = nullptr) {
+  std::ofstream out(outFile);
+  SeqReader rd(queryFile);
+  long len;
+  while ((len = rd.next()) >= 0) {
+    if (len < P.w || len < P.k || len < P.minReadLen) continue;
+    Query Q; Q.name = rd.name; Q.seq = &rd.seq[0]; Q.len = (int)len;
+    std::vector<L1Cand> cands; std::vector<Mapping> ms; L1Debug dbg;
+    do_l1(R, P, Q, cands, &dbg);
+    uint64_t ev = 0, st = 0;
+    do_l2(R, P, Q, cands, ms, &ev, &st);
+    std::string lines;
+    report_lines(R, P, Q.name, ms, lines);
+    out << lines;
+    if (C) { C->reads++; C->bases += len; C->sketch += Q.sketch; C->hits += dbg.hits.size(); C->cands += cands.size();
+             C->stream += st; C->evals += ev; C->maps += ms.size(); }
+  }
+}
+
+// mapWrap.h:407-441 for one query/prefix pair
+static inline void map_directly(Params P, const std::string& refFile, const std::string& queryFile,
+                                const std::string& prefix, MapCounters* C = nullptr) {
+  std::vector<std::string> chunkFiles;
+  RefSketch R;
+  R.build({refFile}, P, [&](RefSketch& r, int n) {
+    std::string f = prefix + "." + std::to_string(n);
+    map_query_file(r, P, queryFile, f, C);
+    chunkFiles.push_back(f);
+  });
+  unify_files(prefix, P, chunkFiles, queryFile, refFile);
+}
+
+// ---------------------------------------------------------------------------------------
+// Taxonomy — meta/taxonomy.h:137-246, :51-135
+// ---------------------------------------------------------------------------------------
+struct TaxNode { std::string id, parent, rank, sci; };
+struct Taxonomy {
+  std::map<std::string, TaxNode> T;
+  static std::vector<std::string> fields(std::string ln) {
+    static const std::regex re("\\s*\\|\\s*");
+    ln = std::regex_replace(ln, re, "|");
+    return split(ln, "|");
+  }
+  explicit Taxonomy(const std::string& dir) {
+    std::map<std::string, std::string> sci;
+    std::ifstream nm(dir + "/names.dmp");
+    if (!nm.is_open()) { std::cerr << "Cannot open file " << dir << "/names.dmp\n"; exit(1); }
+    std::string ln;
+    while (std::getline(nm, ln)) {
+      if (ln.empty()) continue;
+      auto f = fields(ln);
+      if (f.size() > 3 && f[3] == "scientific name") sci[f[0]] = f[1];
+      else if (f.size() > 3 && f[3] == "genbank common name") sci[f[0]];   // entry exists, scientific name may stay empty
+    }
+    std::ifstream nd(dir + "/nodes.dmp");
+    if (!nd.is_open()) { std::cerr << "Cannot open file " << dir << "/nodes.dmp\n"; exit(1); }
+    while (std::getline(nd, ln)) {
+      if (ln.empty()) continue;
+      auto f = fields(ln);
+      if (!sci.count(f[0])) { std::cerr << "No name for taxon ID " << f[0] << "\n"; exit(1); }
+      T[f[0]] = TaxNode{f[0], f[1], f[2], sci[f[0]]};
+    }
+  }
+  std::vector<std::string> upward(std::string id) const {        // :113-129
+    std::vector<std::string> u{id};
+    while (id != "1") { id = T.at(id).parent; u.push_back(id); }
+    return u;
+  }
+  std::map<std::string, std::string> upward_by_ranks(const std::string& id, const std::set<std::string>& want) const {  // :76-111
+    std::map<std::string, std::string> r;
+    for (auto& n : upward(id)) {
+      const std::string& rank = T.at(n).rank;
+      if (!want.empty() && !want.count(rank)) continue;
+      if (rank != "no rank") {
+        if (r.count(rank)) { std::cerr << "Node " << id << " has multiple entries for rank " << rank << "\n"; exit(1); }
+        r[rank] = n;
+      }
+    }
+    for (auto& w : want) if (!r.count(w)) r[w] = "Undefined";
+    return r;
+  }
+  std::string first_non_x(const std::string& id) const {         // :51-74
+    std::string r = id;
+    while (r.find('x') != std::string::npos) r = T.at(r).parent;
+    return r;
+  }
+};
+
+// meta/fEM.h:1396-1415
+static inline std::string extract_taxon(const std::string& contig) {
+  static const std::regex re("kraken:taxid\\|(x?\\d+)");
+  std::smatch m;
+  if (!std::regex_search(contig, m, re)) throw std::runtime_error("Could not extract taxon ID from contig identifier '" + contig + "'");
+  return m[1];
+}
+
+struct Loc { std::string taxon, contig; double identity; size_t readLen, start, stop; double p, l; };   // fEM.h:39-50
+using TaxonInfo = std::map<std::string, std::map<std::string, size_t>>;
+
+// meta/fEM.h:234-373
+static inline std::vector<Loc> mapping_locations(const TaxonInfo& TI, const std::map<std::string, double>& f,
+                                                 const std::vector<std::string>& lines) {
+  std::set<std::string> sawContig, sawTaxon;
+  std::vector<Loc> locs;
+  long long readLen = -1;
+  for (auto& ln : lines) {
+    auto fld = split(ln, " ");
+    Loc l;
+    l.contig = fld.at(5);
+    l.start = std::stoull(fld.at(7)); l.stop = std::stoull(fld.at(8));
+    l.taxon = extract_taxon(l.contig);
+    if (!TI.count(l.taxon)) { std::cerr << "Unknown taxonID '" << l.taxon << "'\n"; exit(1); }
+    double mq;
+    try { mq = std::stod(fld.at(13)); }
+    catch (const std::out_of_range&) { if (fld.at(13).find("e-") != std::string::npos) mq = 0; else throw; }   // :269-281
+    if (readLen == -1) readLen = std::stoi(fld.at(1));
+    l.identity = std::stod(fld.at(9)) / 100.0;
+    l.p = mq; l.readLen = (size_t)readLen; l.l = 0;
+    sawTaxon.insert(l.taxon); sawContig.insert(l.contig);
+    locs.push_back(l);
+  }
+  std::map<std::string, size_t> nLoc;                            // :325-348
+  for (auto& t : sawTaxon) {
+    size_t n = 0;
+    for (auto& c : TI.at(t)) {
+      if ((long long)c.second >= readLen) n += c.second - readLen + 1;
+      else if (sawContig.count(c.first)) ++n;
+    }
+    nLoc[t] = n;
+  }
+  double tot = 0;
+  for (auto& l : locs) { l.l = f.at(l.taxon) * (1 / (double)nLoc.at(l.taxon)) * l.p; tot += l.l; }   // :353
+  for (auto& l : locs) l.p = l.l / tot;
+  return locs;
+}
+
+static inline std::vector<std::vector<std::string>> group_reads(const std::string& file) {   // fEM.h:1171-1214
+  std::vector<std::vector<std::string>> groups;
+  std::ifstream s(file);
+  std::string ln, curId; std::vector<std::string> cur;
+  while (std::getline(s, ln)) {
+    if (ln.empty()) continue;
+    std::string id = ln.substr(0, ln.find(' '));
+    if (id != curId) { if (!cur.empty()) groups.push_back(cur); curId = id; cur.clear(); }
+    cur.push_back(ln);
+  }
+  if (!cur.empty()) groups.push_back(cur);
+  return groups;
+}
+
+struct EMTrace { std::vector<double> ll; std::map<std::string, double> f; };
+
+// meta/fEM.h:52-215 (WIMP)
+static inline void write_wimp(const std::string& fn, const Taxonomy& T, std::map<std::string, double> freq,
+                              const std::map<std::string, size_t>& reads, size_t nTotal, size_t nUnmapped, size_t nTooShort) {
+  std::set<std::string> levels{"species", "genus", "family", "order", "phylum", "superkingdom"};   // :1417-1420
+  std::map<std::string, std::set<std::string>> keys;
+  std::map<std::string, std::map<std::string, double>> fL;
+  std::map<std::string, std::map<std::string, size_t>> rL;
+  for (auto& kv : freq) {
+    auto up = T.upward_by_ranks(kv.first, levels); up["definedGenomes"] = kv.first;
+    for (auto& u : up) {
+      fL[u.first][u.second] += kv.second; keys[u.first].insert(u.second);
+      if (fL[u.first][u.second] > 1) fL[u.first][u.second] = 1;  // :98-101
+    }
+  }
+  for (auto& kv : reads) {
+    auto up = T.upward_by_ranks(kv.first, levels); up["definedGenomes"] = kv.first;
+    for (auto& u : up) {
+      if (fL[u.first].count(u.second) == 0) rL[u.first][u.second] = 0;   // :108 (tests f_per_level; harmless)
+      rL[u.first][u.second] += kv.second; keys[u.first].insert(u.second);
+    }
+  }
+  long long nMappable = (long long)nTotal - (long long)nTooShort, nMapped = nMappable - (long long)nUnmapped;
+  std::ofstream o(fn);
+  o << "AnalysisLevel\ttaxonID\tName\tAbsolute\tEMFrequency\tPotFrequency\n";
+  for (auto& lv : keys) {
+    const std::string& L = lv.first;
+    std::map<std::string, double> emF;
+    double sumF = 0;
+    for (auto& t : lv.second) {
+      double f = fL[L].count(t) ? fL[L][t] : 0; size_t r = rL[L].count(t) ? rL[L][t] : 0;
+      sumF += f; fL[L][t] = f; rL[L][t] = r;
+    }
+    for (auto& t : lv.second) { fL[L][t] /= sumF; emF[t] = fL[L][t]; }
+    double propMapped = (double)nMapped / nMappable, propNot = (double)nUnmapped / nMappable;
+    for (auto& t : lv.second) fL[L][t] *= propMapped;
+    double emUnm = 0; size_t nUnmUndef = nUnmapped;
+    for (auto& t : lv.second) {
+      if (t != "Undefined")
+        o << L << "\t" << t << "\t" << T.T.at(t).sci << "\t" << rL[L][t] << "\t" << emF[t] << "\t" << fL[L][t] << "\n";
+      else { nUnmUndef += rL[L][t]; emUnm += emF[t]; propNot += fL[L][t]; }
+    }
+    o << L << "\t" << 0 << "\t" << "Unclassified" << "\t" << nUnmUndef << "\t" << emUnm << "\t" << propNot << "\n";
+    o << L << "\t" << -3 << "\t" << "totalReads" << "\t" << nTotal << "\t" << 0 << "\t" << 0 << "\n";
+    o << L << "\t" << -3 << "\t" << "readsLongEnough" << "\t" << nMappable << "\t" << 0 << "\t" << 0 << "\n";
+    o << L << "\t" << -3 << "\t" << "readsLongEnough_unmapped" << "\t" << nUnmapped << "\t" << 0 << "\t" << 0 << "\n";
+  }
+}
+
+// meta/fEM.h:466-803 (EM loop + .EM / .EM.reads2Taxon / .krona / .EM.WIMP).  Single summation order
+// (the reference sums per OpenMP thread chunk, then across threads; with -t 1 it is exactly this order).
+static inline EMTrace do_em(const std::string& mapped, const std::string& dbDir, bool writeFiles = true) {
+  EMTrace tr;
+  std::set<std::string> taxa;                                    // :1366-1394
+  {
+    std::ifstream s(mapped); std::string ln;
+    while (std::getline(s, ln)) if (!ln.empty()) taxa.insert(extract_taxon(split(ln, " ").at(5)));
+  }
+  if (taxa.empty()) throw std::runtime_error("No relevant taxon IDs found in your mappings file");
+  std::map<std::string, size_t> st;                              // :398-421
+  { std::ifstream s(mapped + ".meta"); std::string a; size_t b; while (s >> a >> b) st[a] = b; }
+  size_t nUnmapped = st.at("ReadsNotMapped"), nTooShort = st.at("ReadsTooShort"), nTotal = st.at("TotalReads");
+  TaxonInfo TI;                                                  // :1320-1364
+  {
+    std::ifstream s(dbDir + "/taxonInfo.txt"); std::string ln;
+    if (!s.is_open()) { std::cerr << "Could not open file " << dbDir << "/taxonInfo.txt\n"; exit(1); }
+    while (std::getline(s, ln)) {
+      if (ln.empty()) continue;
+      auto f = split(ln, " ");
+      for (auto& c : split(f.at(1), ";")) { auto kv = split(c, "="); TI[f.at(0)][kv.at(0)] = std::stoull(kv.at(1)); }
+    }
+  }
+  Taxonomy T(dbDir + "/taxonomy");
+  std::map<std::string, double> f;
+  for (auto& t : taxa) f[t] = 1 / (double)taxa.size();           // :491-495
+  auto groups = group_reads(mapped);
+  double llPrev = 0; size_t iter = 0; bool go = true;
+  while (go) {                                                   // :501-661
+    std::map<std::string, double> fn = f; for (auto& e : fn) e.second = 0;
+    double ll = 0;
+    for (auto& g : groups) {
+      auto locs = mapping_locations(TI, f, g);
+      double lr = 0;
+      for (auto& l : locs) { lr += l.l; fn.at(l.taxon) += l.p; }
+      ll += std::log(lr);
+    }
+    double sum = 0; for (auto& e : fn) sum += e.second;
+    for (auto& e : fn) e.second /= sum;
+    tr.ll.push_back(ll);
+    if (iter > 0) {
+      double diff = ll - llPrev, rel = 1 - ll / llPrev;
+      if (diff <= 1 && rel < 0.0001) go = false;                 // :636
+    }
+    f = fn; ++iter; llPrev = ll;
+  }
+  tr.f = f;
+  if (!writeFiles) return tr;
+  std::ofstream em(mapped + ".EM"), r2t(mapped + ".EM.reads2Taxon"), kr(mapped + ".EM.reads2Taxon.krona");
+  std::map<std::string, size_t> readsPer;
+  for (auto& g : groups) {                                       // :684-779
+    auto locs = mapping_locations(TI, f, g);
+    std::string rid;
+    for (size_t i = 0; i < g.size(); ++i) {
+      auto fld = split(g[i], " "); rid = fld.at(0);
+      fld.at(13) = std::to_string(locs[i].p);                    // :705
+      em << join(fld, " ") << "\n";
+    }
+    size_t best = 0;                                             // :217-232 first strict maximum
+    for (size_t i = 1; i < locs.size(); ++i) if (locs[i].p > locs[best].p) best = i;
+    r2t << rid << "\t" << locs[best].taxon << "\n";
+    kr << rid << "\t" << T.first_non_x(locs[best].taxon) << "\t" << locs[best].p << "\n";
+    readsPer[locs[best].taxon]++;
+  }
+  {                                                              // :785-790
+    std::ifstream s(mapped + ".meta.unmappedReadsLengths"); std::string ln;
+    while (std::getline(s, ln)) {
+      if (ln.empty()) continue;
+      auto fl = split(ln, "\t");
+      r2t << fl.at(1) << "\t" << 0 << "\n"; kr << fl.at(1) << "\t" << 0 << "\t" << 0 << "\n";
+    }
+  }
+  {                                                              // cleanF :1135-1163
+    double minF = 0.9 * (1.0 / (double)st.at("ReadsMapped"));
+    std::set<std::string> drop;
+    for (auto& e : f) if (e.second < minF && !readsPer.count(e.first)) drop.insert(e.first);
+    for (auto& d : drop) f.erase(d);
+    double s = 0; for (auto& e : f) s += e.second;
+    for (auto& e : f) e.second /= s;
+  }
+  write_wimp(mapped + ".EM.WIMP", T, f, readsPer, nTotal, nUnmapped, nTooShort);
+  return tr;
+}
+
+}  // namespace orc

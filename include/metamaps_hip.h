@@ -1,0 +1,190 @@
+/*
+ * metamaps_hip.h — C ABI of libmetamaps_hip.so, the MI355X (gfx950) implementation of the
+ * MetaMaps mapping + EM-classification hot path.
+ *
+ * The reference (DiltheyLab/MetaMaps) has no FFI/plugin seam: its hot path is reached through
+ * three in-process C++ interfaces (paths relative to /root/reference/src):
+ *   (i)   skch::Sketch(param, maxMem, callback)            map/include/winSketch.hpp:157  — index one chunk
+ *   (ii)  MapModuleOutput* skch::Map::mapModule(read)      map/include/computeMap.hpp:180 — map one read
+ *   (iii) meta::doEM  per-read callback + reduction        meta/fEM.h:466, :535-600       — one EM iteration
+ * Each entry point below names the interface (and the loops under it) that it replaces.  Handles are
+ * opaque; buffers are caller-owned plain arrays; every call returns 0 on success or a negative
+ * mm_status and leaves a message in mm_last_error().  No exceptions cross this boundary, no global
+ * state: one mm_ctx per device, used from one host thread at a time.  There is no CPU fallback:
+ * mm_ctx_create fails when no gfx950 device is present.
+ */
+#ifndef METAMAPS_HIP_H
+#define METAMAPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_ABI_VERSION 1
+
+typedef enum {
+  MM_OK = 0,
+  MM_ERR_ARG = -1,        /* bad argument / unsupported parameter value          */
+  MM_ERR_DEVICE = -2,     /* HIP runtime error (message has the HIP error string) */
+  MM_ERR_NOMEM = -3,      /* device or host allocation failed                     */
+  MM_ERR_STATE = -4,      /* call sequence violated                               */
+  MM_ERR_LIMIT = -5,      /* documented capacity limit exceeded       */
+  MM_ERR_NUMERIC = -6,    /* reference would abort here (e.g. likelihood sum 0, mapWrap.h:298) */
+  MM_ERR_COMM = -7        /* RCCL error                                           */
+} mm_status;
+
+typedef struct mm_ctx mm_ctx;          /* a device + streams + scratch allocator                  */
+typedef struct mm_seqset mm_seqset;    /* sequences resident in HBM as packed 2-bit + exceptions  */
+typedef struct mm_index mm_index;      /* reference sketch of one index chunk, resident in HBM     */
+typedef struct mm_mapping mm_mapping;  /* mapping results of one read batch, resident in HBM      */
+typedef struct mm_em mm_em;            /* EM state (mappings x taxa) resident in HBM              */
+
+/* ---- context -------------------------------------------------------------------------------- */
+int mm_abi_version(void);
+int mm_ctx_create(int device_id, mm_ctx** out);
+void mm_ctx_destroy(mm_ctx* ctx);
+const char* mm_last_error(const mm_ctx* ctx);            /* valid until the next call on ctx       */
+/* device name, CU count, total HBM bytes, free HBM bytes */
+int mm_ctx_device_info(mm_ctx* ctx, char* name, size_t name_cap, int* cus, uint64_t* hbm_total, uint64_t* hbm_free);
+int mm_ctx_synchronize(mm_ctx* ctx);
+/* raw hipStream_t the kernels are launched on (for event timing by the caller) */
+void* mm_ctx_stream(mm_ctx* ctx);
+
+/* ---- sequences -------------------------------------------------------------------------------
+ * Replaces the kseq buffers handed to addMinimizers (commonFunc.hpp:92; callers winSketch.hpp:269,
+ * computeMap.hpp:285).  Bytes are upper-cased exactly as makeUpperCase does (commonFunc.hpp:57);
+ * A/C/G/T are packed 2 bits/base, every other byte is kept verbatim in an exception run list so that
+ * hashing sees the same ASCII the reference hashes. */
+int mm_seqset_create(mm_ctx* ctx, mm_seqset** out);
+void mm_seqset_destroy(mm_seqset* s);
+int mm_seqset_add(mm_seqset* s, const char* ascii, int64_t len);   /* host staging, keeps input order */
+int mm_seqset_upload(mm_seqset* s);                                /* pack + copy to HBM; set is then frozen */
+int64_t mm_seqset_count(const mm_seqset* s);
+int64_t mm_seqset_total_bases(const mm_seqset* s);
+int mm_seqset_lengths(const mm_seqset* s, int32_t* len_out /* [count] */);
+/* read back sequence i as (upper-cased) ASCII — round-trip check for tests */
+int mm_seqset_fetch(mm_seqset* s, int64_t i, char* ascii_out, int64_t cap);
+
+/* Device-side synthetic inputs (bench.py; DESIGN.md "Synthetic workload").  The reference is a set of
+ * genomes grouped in species (strains = substituted copies of a species root), generated straight into
+ * packed HBM form; reads are sampled from it with ONT/PacBio-like sub/ins/del errors. */
+typedef struct {
+  uint64_t seed;
+  int32_t n_species;          /* species roots                                                     */
+  int32_t strains_per_species;
+  int32_t genome_len;         /* bases per genome (one contig per genome)                          */
+  float strain_divergence;    /* per-base substitution rate of a strain w.r.t. its species root    */
+  float genus_divergence;     /* roots of the same genus (4 species each) differ by this rate      */
+} mm_synth_ref_params;
+typedef struct {
+  uint64_t seed;
+  int64_t n_reads;
+  int32_t read_len;           /* template length taken from the genome                              */
+  float sub_rate, ins_rate, del_rate;
+  float frac_random;          /* reads made of random sequence (unmappable)                          */
+  int32_t n_abundant;         /* reads are drawn from this many genomes, lognormal abundances        */
+} mm_synth_read_params;
+int mm_synth_reference(mm_ctx* ctx, const mm_synth_ref_params* p, mm_seqset** out);
+/* truth_genome (optional, [n_reads]) receives the source genome index or -1 */
+int mm_synth_reads(mm_ctx* ctx, const mm_seqset* reference, const mm_synth_read_params* p, mm_seqset** out,
+                   int32_t* truth_genome);
+
+/* ---- A2 debug tap: winnowed minimizers of every sequence (commonFunc.hpp:92-175) -------------- */
+/* offsets[count+1]; records are (hash, wpos, strand) in winnowing order.  Pass NULL arrays to query sizes. */
+int mm_minimizers(mm_ctx* ctx, const mm_seqset* s, int k, int w, int64_t* offsets, uint32_t* hash, int32_t* wpos,
+                  int32_t* strand, int64_t cap);
+
+/* ---- index (replaces Sketch::build_and_store_index + computeFreqHist, winSketch.hpp:180-365, :452-494) */
+typedef struct {
+  int64_t n_contigs, n_entries, n_unique_hashes, n_dup_flagged;
+  int64_t hbm_bytes;
+} mm_index_info;
+int mm_index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index** out);
+void mm_index_destroy(mm_index* idx);
+int mm_index_get_info(const mm_index* idx, mm_index_info* out);
+/* Occurrence-count histogram of this chunk: pairs (count, number of hashes with that count), ascending.
+ * The caller accumulates it across chunks and derives freqThreshold exactly as winSketch.hpp:452-494 does
+ * (mm_freq_threshold_from_hist below) — the reference never clears the histogram between chunks. */
+int mm_index_freq_hist(mm_index* idx, int64_t* counts, int64_t* n_hashes, int64_t cap, int64_t* n_out);
+int mm_freq_threshold_from_hist(const int64_t* counts, const int64_t* n_hashes, int64_t n, int64_t n_unique_hashes,
+                                int prev_threshold);
+int mm_index_set_freq_threshold(mm_index* idx, int threshold);
+/* debug tap: position-ordered entries (hash, contig, wpos, strand) */
+int mm_index_entries(mm_index* idx, uint32_t* hash, int32_t* contig, int32_t* wpos, int32_t* strand, int64_t cap);
+
+/* ---- host statistics (float math of map_stats.hpp; Boost.Math binomial restated) -------------- */
+int mm_recommended_window(double p_value, int k, float pi, int min_read_len, uint64_t reference_size);   /* map_stats.hpp:226 */
+double mm_estimate_pvalue(int s, int k, float pi, int min_read_len, uint64_t reference_size);             /* map_stats.hpp:179 */
+int mm_min_hits_relaxed(int s, int k, float pi);                                                          /* map_stats.hpp:142 */
+void mm_identity(int shared, int s, int k, float* ident, float* ident_upper);                             /* computeMap.hpp:406-412 */
+
+/* ---- mapping (replaces Map::mapModule for a whole batch: computeMap.hpp:180-538) -------------- */
+typedef struct {
+  int32_t k, w;
+  float perc_identity;        /* --pi, default 80                                   */
+  int32_t min_read_len;       /* reads shorter than max(w,k,min_read_len) are skipped (computeMap.hpp:137) */
+} mm_map_params;
+
+typedef struct {              /* one L2 mapping that passed the identity filter (base_types.hpp:133) */
+  int32_t read;               /* index of the read in the seqset                      */
+  int32_t ref_contig;         /* chunk-local contig id                                */
+  int32_t ref_start;          /* meanOptimalPos; refEnd = ref_start + read_len - 1    */
+  int32_t shared;             /* conservedSketches                                    */
+  int32_t sketch;             /* sketchSize s                                         */
+  int32_t strand;             /* +1 / -1                                              */
+  double mapq;                /* mapping quality (mapWrap.h:215-323), filled by mm_mapping_add_qualities */
+} mm_map_record;
+
+typedef struct {
+  int64_t n_reads, n_reads_long_enough, n_reads_mapped, n_mappings;
+  int64_t bases_long_enough;
+  /* algorithmic-traffic counters */
+  int64_t sum_sketch, sum_hits, n_candidates, sum_l2_stream_entries, sum_l2_evals;
+  int64_t n_ambiguous_sketch_reads;   /* reads whose duplicate-hash strands needed the std::sort tie-break */
+} mm_map_stats;
+
+int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, mm_mapping** out);
+void mm_mapping_destroy(mm_mapping* m);
+int mm_mapping_get_stats(const mm_mapping* m, mm_map_stats* out);
+/* per-read first-record offsets [n_reads+1], records in (read, contig, position) order */
+int mm_mapping_fetch(mm_mapping* m, int64_t* offsets, mm_map_record* records, int64_t cap);
+/* K8: mapping qualities over the union of each read's records (mapWrap.h:215-323) */
+int mm_mapping_add_qualities(mm_ctx* ctx, mm_mapping* m, const mm_seqset* reads, int k);
+/* merge the records of several index chunks read-wise, chunk order preserved (unifyFiles, mapWrap.h:128-132) */
+int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* contig_base, int n_parts, mm_mapping** out);
+
+/* debug taps for one batch (parity tests).  Any output pointer may be NULL. */
+int mm_debug_sketch(mm_mapping* m, int64_t* offsets, uint32_t* hash, int32_t* strand, int64_t cap);          /* computeMap.hpp:292-298 */
+int mm_debug_hits(mm_mapping* m, int64_t* offsets, int32_t* contig, int32_t* wpos, int64_t cap);             /* :307-323, sorted :353 */
+int mm_debug_candidates(mm_mapping* m, int64_t* offsets, int32_t* triples /* contig,start,end */, int64_t cap);   /* :346-386 */
+int mm_debug_l2(mm_mapping* m, int64_t* per_cand /* contig, meanPos, shared, optBeg, optEnd */, int64_t cap);      /* :460-538 */
+int mm_debug_min_hits(mm_mapping* m, int32_t* min_hits /* [n_reads] */);
+
+/* ---- EM (replaces meta::doEM's iteration, fEM.h:501-661, and the per-read likelihood fEM.h:234-373) */
+/* Mappings are given read-wise: read r owns entries [read_off[r], read_off[r+1]).  For entry i:
+ * l_i = f[taxon[i]] * inv_nloc[i] * mapq[i]  (fEM.h:353), p_i = l_i / sum over the read.  */
+int mm_em_create(mm_ctx* ctx, int64_t n_reads, const int64_t* read_off, const int32_t* taxon, const double* mapq,
+                 const double* inv_nloc, int32_t n_taxa, mm_em** out);
+void mm_em_destroy(mm_em* em);
+/* one E+M step on this rank's reads: f_partial[t] = sum of p_i, *ll_partial = sum log(sum l_i) */
+int mm_em_iterate(mm_em* em, const double* f, double* f_partial, double* ll_partial);
+/* same, but leaves the partial sums on the device, all-reduces them over the communicator (RCCL) and
+ * returns the normalised next f and the global log-likelihood (identical on every rank) */
+int mm_em_iterate_allreduce(mm_em* em, const double* f, double* f_next, double* ll);
+/* final posteriors p_i for the current f (fEM.h:684-707) and the index of the best mapping per read (fEM.h:217) */
+int mm_em_posteriors(mm_em* em, const double* f, double* post /* [n_entries] */, int64_t* best /* [n_reads] */);
+
+/* ---- communicator (RCCL over xGMI; one process per GPU) --------------------------------------- */
+#define MM_COMM_ID_BYTES 128
+int mm_comm_unique_id(char id[MM_COMM_ID_BYTES]);                     /* rank 0 creates, caller broadcasts */
+int mm_comm_init(mm_ctx* ctx, const char id[MM_COMM_ID_BYTES], int rank, int nranks);
+int mm_comm_allreduce_f64(mm_ctx* ctx, double* host_inout, int64_t n);   /* staging helper for small vectors */
+void mm_comm_destroy(mm_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METAMAPS_HIP_H */

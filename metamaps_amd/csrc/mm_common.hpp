@@ -1,0 +1,167 @@
+// Shared host/device definitions of libmetamaps_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "../../include/metamaps_hip.h"
+
+namespace mm {
+
+// ---- error plumbing: internal code throws, the C ABI layer converts to a status + message ----------
+struct Error : std::runtime_error {
+  int status;
+  Error(int st, const std::string& m) : std::runtime_error(m), status(st) {}
+};
+#define MM_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      throw mm::Error(_e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE,              \
+                      std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+  } while (0)
+#define MM_REQUIRE(cond, st, msg) \
+  do { if (!(cond)) throw mm::Error((st), (msg)); } while (0)
+#define MM_KERNEL_CHECK() MM_HIP(hipGetLastError())
+
+// ---- device buffer ---------------------------------------------------------------------------------
+template <typename T>
+struct DBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DBuf() = default;
+  explicit DBuf(size_t count) { alloc(count); }
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  DBuf(DBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+  ~DBuf() { release(); }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    if (count) MM_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+  }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+  size_t bytes() const { return n * sizeof(T); }
+  void zero(hipStream_t st) { if (n) MM_HIP(hipMemsetAsync(p, 0, bytes(), st)); }
+  void upload(const T* h, size_t count, hipStream_t st) { if (count) MM_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, st)); }
+  void download(T* h, size_t count, hipStream_t st, size_t offset = 0) const {
+    if (count) MM_HIP(hipMemcpyAsync(h, p + offset, count * sizeof(T), hipMemcpyDeviceToHost, st));
+  }
+  std::vector<T> to_host(hipStream_t st, size_t count = (size_t)-1) const {
+    if (count == (size_t)-1) count = n;
+    std::vector<T> v(count);
+    download(v.data(), count, st);
+    MM_HIP(hipStreamSynchronize(st));
+    return v;
+  }
+};
+
+// ---- index / minimizer record ------------------------------------------------------------------------
+// One winnowed minimizer = 8 bytes: {hash, pw}.  pw packs window position, strand and two duplicate
+// flags the index builder fills in (DESIGN.md §Data layout):
+//   bit 0      strand (1 = FWD, 0 = REV)                      base_types.hpp:121-125
+//   bit 1      DP: an earlier entry of the same contig carries the same hash
+//   bit 2      DN: a later   entry of the same contig carries the same hash
+//   bits 3..31 wpos (< 2^29: contigs up to 536 Mbp)
+struct Rec { uint32_t hash; uint32_t pw; };
+constexpr uint32_t PW_STRAND = 1u, PW_DP = 2u, PW_DN = 4u;
+constexpr int PW_SHIFT = 3;
+constexpr int64_t MAX_SEQ_LEN = (1LL << 29) - 1;
+__host__ __device__ inline int32_t pw_wpos(uint32_t pw) { return (int32_t)(pw >> PW_SHIFT); }
+__host__ __device__ inline int32_t pw_strand(uint32_t pw) { return (pw & PW_STRAND) ? 1 : -1; }
+
+// ---- MurmurHash3_x64_128 low 32 bits, seed 42 (murmur3.h:226-303, commonFunc.hpp:33,71-81) -----------
+__host__ __device__ inline uint64_t rotl64(uint64_t v, int r) { return (v << r) | (v >> (64 - r)); }
+__host__ __device__ inline uint64_t fmix64(uint64_t v) {
+  v ^= v >> 33; v *= 0xff51afd7ed558ccdULL;
+  v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL;
+  v ^= v >> 33;
+  return v;
+}
+constexpr uint64_t MUR_C1 = 0x87c37b91114253d5ULL, MUR_C2 = 0x4cf5ad432745937fULL;
+constexpr uint32_t MUR_SEED = 42u;
+
+// k == 16: exactly one block (lo = bytes 0..7, hi = bytes 8..15, little endian), no tail
+__host__ __device__ inline uint32_t murmur16(uint64_t lo, uint64_t hi) {
+  uint64_t a = MUR_SEED, b = MUR_SEED;
+  lo *= MUR_C1; lo = rotl64(lo, 31); lo *= MUR_C2; a ^= lo;
+  a = rotl64(a, 27); a += b; a = a * 5 + 0x52dce729;
+  hi *= MUR_C2; hi = rotl64(hi, 33); hi *= MUR_C1; b ^= hi;
+  b = rotl64(b, 31); b += a; b = b * 5 + 0x38495ab5;
+  a ^= 16; b ^= 16;
+  a += b; b += a;
+  a = fmix64(a); b = fmix64(b);
+  a += b;
+  return (uint32_t)a;
+}
+// general k (bytes need not be aligned); `rev` reads the bytes backwards from p (p points at the LAST byte)
+template <bool REV>
+__host__ __device__ inline uint32_t murmur_bytes(const uint8_t* p, int k) {
+  auto at = [&](int i) -> uint64_t { return REV ? p[-i] : p[i]; };
+  uint64_t a = MUR_SEED, b = MUR_SEED;
+  int nb = k >> 4;
+  for (int blk = 0; blk < nb; ++blk) {
+    uint64_t lo = 0, hi = 0;
+    for (int j = 0; j < 8; ++j) { lo |= at(16 * blk + j) << (8 * j); hi |= at(16 * blk + 8 + j) << (8 * j); }
+    lo *= MUR_C1; lo = rotl64(lo, 31); lo *= MUR_C2; a ^= lo;
+    a = rotl64(a, 27); a += b; a = a * 5 + 0x52dce729;
+    hi *= MUR_C2; hi = rotl64(hi, 33); hi *= MUR_C1; b ^= hi;
+    b = rotl64(b, 31); b += a; b = b * 5 + 0x38495ab5;
+  }
+  int rem = k & 15, base = nb << 4;
+  uint64_t lo = 0, hi = 0;
+  for (int j = 8; j < rem; ++j) hi |= at(base + j) << (8 * (j - 8));
+  if (rem > 8) { hi *= MUR_C2; hi = rotl64(hi, 33); hi *= MUR_C1; b ^= hi; }
+  for (int j = 0; j < rem && j < 8; ++j) lo |= at(base + j) << (8 * j);
+  if (rem > 0) { lo *= MUR_C1; lo = rotl64(lo, 31); lo *= MUR_C2; a ^= lo; }
+  a ^= (uint64_t)k; b ^= (uint64_t)k;
+  a += b; b += a;
+  a = fmix64(a); b = fmix64(b);
+  a += b;
+  return (uint32_t)a;
+}
+
+__host__ __device__ inline uint8_t ascii_of_code(uint32_t c) {      // 0,1,2,3 -> A,C,G,T
+  return (uint8_t)(0x41 + 2 * (c & 1) + 6 * (c >> 1) + 11 * ((c & 1) & (c >> 1)));
+}
+__host__ __device__ inline uint8_t complement_ascii(uint8_t c) {    // commonFunc.hpp:38-55
+  return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace mm
+
+// ---- opaque handle bodies ----------------------------------------------------------------------------
+struct mm_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int cus = 0;
+  void* comm = nullptr;          // ncclComm_t
+  int comm_rank = 0, comm_size = 1;
+};
+
+struct mm_seqset {
+  mm_ctx* ctx = nullptr;
+  bool frozen = false;
+  // host staging (until upload)
+  std::vector<std::string> staged;
+  // host-side metadata (always valid after upload / synthesis)
+  std::vector<int32_t> len;            // per sequence
+  std::vector<uint64_t> base;          // [n+1] first base of sequence i in the packed stream (multiple of 16)
+  int64_t total_bases = 0;
+  // device
+  mm::DBuf<uint32_t> packed;           // 16 bases per word, base b at bits [2b, 2b+2)
+  mm::DBuf<uint64_t> d_base;           // [n+1]
+  mm::DBuf<int32_t> d_len;             // [n]
+  mm::DBuf<uint64_t> exc_start;        // exception runs, sorted by start (stream coordinates)
+  mm::DBuf<uint32_t> exc_len;
+  mm::DBuf<uint8_t> exc_byte;
+  int64_t n_exc = 0;
+  int64_t count() const { return (int64_t)len.size(); }
+};

@@ -1,0 +1,158 @@
+// Index construction on the device (replaces Sketch::build_and_store_index + computeFreqHist for one chunk,
+// winSketch.hpp:180-365, :452-494).  K1 sweep over the contigs, one global radix sort by hash (rocPRIM —
+// a plain library sort, run once per index, outside the per-read hot path), CSR + bucket table, duplicate
+// flags for the L2 sliding window, occurrence histogram.
+#include "mm_index.hpp"
+#include "mm_minimizer.hpp"
+#include <rocprim/rocprim.hpp>
+#include <algorithm>
+
+namespace mm {
+
+__global__ void split_records_kernel(const Rec* __restrict__ rec, const uint32_t* __restrict__ rec_seq, int64_t n,
+                                     uint32_t* __restrict__ key, uint64_t* __restrict__ val) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { Rec r = rec[i]; key[i] = r.hash; val[i] = ((uint64_t)rec_seq[i] << 32) | r.pw; }
+}
+
+__global__ void head_flags_kernel(const uint32_t* __restrict__ key, int64_t n, uint32_t* __restrict__ flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
+}
+
+__global__ void csr_fill_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ rank,
+                                int64_t n, uint32_t* __restrict__ uh, uint64_t* __restrict__ ustart) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flag[i]) { uint64_t u = rank[i]; uh[u] = key[i]; ustart[u] = (uint64_t)i; }
+  if (i == n) ustart[rank[n]] = (uint64_t)n;        // rank[n] = U (scan total)
+}
+
+__global__ void bucket_kernel(const uint32_t* __restrict__ uh, int64_t U, int bits, uint64_t* __restrict__ bkt) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t nb = 1LL << bits;
+  if (b > nb) return;
+  if (b == nb) { bkt[b] = (uint64_t)U; return; }
+  uint32_t target = (uint32_t)b << (32 - bits);
+  int64_t lo = 0, hi = U;
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (uh[mid] < target) lo = mid + 1; else hi = mid; }
+  bkt[b] = (uint64_t)lo;
+}
+
+// Duplicate flags: two entries of one contig with the same hash.  The hash-sorted table is stable, so such
+// entries are adjacent there.  DN on the earlier, DP on the later (slidingMap.hpp:139-214 needs "is another
+// occurrence of this hash inside the window?", which only same-contig neighbours can answer yes to).
+__global__ void dup_flags_kernel(const uint32_t* __restrict__ key, const uint64_t* __restrict__ val, int64_t n,
+                                 const uint64_t* __restrict__ cstart, Rec* __restrict__ pos, unsigned long long* __restrict__ ndup) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i + 1 >= n) return;
+  if (key[i] != key[i + 1]) return;
+  uint64_t a = val[i], b = val[i + 1];
+  if ((a >> 32) != (b >> 32)) return;
+  int32_t c = (int32_t)(a >> 32);
+  auto ordinal = [&](uint32_t pw) {
+    int32_t p = pw_wpos(pw);
+    int64_t lo = (int64_t)cstart[c], hi = (int64_t)cstart[c + 1];
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (pw_wpos(pos[mid].pw) < p) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  atomicOr(&pos[ordinal((uint32_t)a)].pw, PW_DN);
+  atomicOr(&pos[ordinal((uint32_t)b)].pw, PW_DP);
+  atomicAdd(ndup, 1ull);
+}
+
+constexpr int HIST_BINS = 4096;
+// occurrence-count histogram; counts >= HIST_BINS go to an overflow list (count per hash)
+__global__ void __launch_bounds__(256) count_hist_kernel(const uint64_t* __restrict__ ustart, int64_t U, unsigned long long* __restrict__ bins,
+                                                         unsigned long long* __restrict__ big, unsigned long long* __restrict__ nbig, int64_t big_cap) {
+  __shared__ unsigned int lb[HIST_BINS];
+  for (int i = threadIdx.x; i < HIST_BINS; i += 256) lb[i] = 0;
+  __syncthreads();
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < U; u += (int64_t)gridDim.x * 256) {
+    uint64_t c = ustart[u + 1] - ustart[u];
+    if (c < HIST_BINS) atomicAdd(&lb[c], 1u);
+    else { unsigned long long s = atomicAdd(nbig, 1ull); if ((int64_t)s < big_cap) big[s] = c; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HIST_BINS; i += 256) if (lb[i]) atomicAdd(&bins[i], (unsigned long long)lb[i]);
+}
+
+void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* I) {
+  hipStream_t st = ctx->stream;
+  I->ctx = ctx; I->k = k; I->w = w;
+  I->n_contigs = contigs->count();
+  I->contig_len = contigs->len;
+  I->d_contig_len.alloc(std::max<size_t>(I->contig_len.size(), 1));
+  I->d_contig_len.upload(I->contig_len.data(), I->contig_len.size(), st);
+
+  // K1 over every contig; contigs shorter than w or k contribute metadata only (winSketch.hpp:258-264)
+  MinimizerSet ms;
+  run_minimizers(ctx, contigs, k, w, {}, /*want_rec_seq=*/true, ms);
+  const int64_t N = ms.total;
+  I->N = N;
+  I->pos = std::move(ms.rec);
+  I->cstart = std::move(ms.off);
+  I->h_cstart = ms.h_off;
+  I->U = 0; I->n_dup = 0; I->hist.clear();
+  if (N == 0) {
+    I->bkt_bits = 4;
+    I->bkt.alloc((1u << I->bkt_bits) + 1); I->bkt.zero(st);
+    I->uh.alloc(1); I->ustart.alloc(1); I->ustart.zero(st); I->occ.alloc(1);
+    MM_HIP(hipStreamSynchronize(st));
+    return;
+  }
+  const unsigned nblk = (unsigned)ceil_div(N, 256);
+  // sort (hash -> contig<<32|pw) by hash, stable
+  DBuf<uint32_t> key_in((size_t)N), key_out((size_t)N);
+  DBuf<uint64_t> val_in((size_t)N);
+  I->occ.alloc((size_t)N);
+  split_records_kernel<<<dim3(nblk), dim3(256), 0, st>>>(I->pos.p, ms.rec_seq.p, N, key_in.p, val_in.p);
+  MM_KERNEL_CHECK();
+  ms.rec_seq.release();
+  {
+    size_t tmp_bytes = 0;
+    MM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in.p, key_out.p, val_in.p, I->occ.p, (size_t)N, 0, 32, st));
+    DBuf<uint8_t> tmp(tmp_bytes);
+    MM_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, key_in.p, key_out.p, val_in.p, I->occ.p, (size_t)N, 0, 32, st));
+    MM_HIP(hipStreamSynchronize(st));
+  }
+  key_in.release(); val_in.release();
+  // CSR over unique hashes
+  DBuf<uint32_t> flag((size_t)N);
+  DBuf<uint64_t> rank((size_t)N + 1), scan_tmp;
+  head_flags_kernel<<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, N, flag.p);
+  MM_KERNEL_CHECK();
+  exclusive_scan_u32_u64(flag.p, N, rank.p, scan_tmp, st);
+  uint64_t U = 0;
+  MM_HIP(hipMemcpyAsync(&U, rank.p + N, sizeof U, hipMemcpyDeviceToHost, st));
+  MM_HIP(hipStreamSynchronize(st));
+  I->U = (int64_t)U;
+  I->uh.alloc((size_t)U); I->ustart.alloc((size_t)U + 1);
+  csr_fill_kernel<<<dim3((unsigned)ceil_div(N + 1, 256)), dim3(256), 0, st>>>(key_out.p, flag.p, rank.p, N, I->uh.p, I->ustart.p);
+  MM_KERNEL_CHECK();
+  flag.release(); rank.release();
+  // bucket table over hash prefixes
+  int bits = 4; while (bits < 26 && (1LL << (bits + 1)) <= (int64_t)U) ++bits;
+  I->bkt_bits = bits;
+  I->bkt.alloc(((size_t)1 << bits) + 1);
+  bucket_kernel<<<dim3((unsigned)ceil_div((1LL << bits) + 1, 256)), dim3(256), 0, st>>>(I->uh.p, (int64_t)U, bits, I->bkt.p);
+  MM_KERNEL_CHECK();
+  // duplicate flags into pos[]
+  DBuf<unsigned long long> ndup(1); ndup.zero(st);
+  dup_flags_kernel<<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, I->occ.p, N, I->cstart.p, I->pos.p, ndup.p);
+  MM_KERNEL_CHECK();
+  // occurrence histogram (winSketch.hpp:456-459)
+  const int64_t big_cap = 1 << 20;
+  DBuf<unsigned long long> bins(HIST_BINS), big((size_t)big_cap), nbig(1);
+  bins.zero(st); nbig.zero(st);
+  count_hist_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div((int64_t)U, 256), 2048)), dim3(256), 0, st>>>(I->ustart.p, (int64_t)U, bins.p, big.p, nbig.p, big_cap);
+  MM_KERNEL_CHECK();
+  auto hb = bins.to_host(st);
+  auto hn = nbig.to_host(st);
+  auto hd = ndup.to_host(st);
+  I->n_dup = (int64_t)hd[0];
+  MM_REQUIRE((int64_t)hn[0] <= big_cap, MM_ERR_LIMIT, "more than 2^20 hashes occur >= 4096 times in one index chunk");
+  for (int i = 0; i < HIST_BINS; ++i) if (hb[i]) I->hist[i] += (int64_t)hb[i];
+  if (hn[0]) { auto hbig = big.to_host(st, (size_t)hn[0]); for (auto c : hbig) I->hist[(int64_t)c] += 1; }
+}
+
+}  // namespace mm

@@ -1,0 +1,86 @@
+// K5 core — the sliding MinHash window as O(1) integer updates on two small arrays
+// (replaces SlideMapper's ordered std::map: slidingMap.hpp:26-318).
+//
+// Let Q[0..s) be the read's sorted unique sketch.  For a window W of reference minimizers:
+//   matched rank r   : Q[r] occurs in W                                    -> bit r of mt[]
+//   W-only hash h    : h not in Q, gap g = #{Q < h}; D[g] = number of DISTINCT such hashes in W (g < s)
+// Q[r] belongs to the s smallest hashes of Q ∪ W  <=>  r + sum_{g<=r} D[g] < s   (it and everything below
+// it number at most s).  The left side is strictly increasing in r, so the counted ranks are exactly
+// r < R where R = min{ r : r + C(r) >= s } (R = s if none), C(r) = D[0]+..+D[r].  The reference's
+//   sharedSketchElements == popcount(mt[0..R))            (slidingMap.hpp:263-316 keeps the same count
+// incrementally around its `pivot` iterator).  Inserting/deleting one reference minimizer moves R by at
+// most one, so the state is {R, Cb = C(R-1), shared}; every event is a constant number of array accesses.
+//
+// Distinctness (slidingMap.hpp:148-157 REV / :186-209 NOOP): the caller tells whether another occurrence
+// of the same hash is inside the window; the index precomputes per-entry DP/DN flags so that this
+// question only needs work for hashes repeated within one contig.
+//
+// Compiles for host (unit tests: tests/test_l2_core.cpp via g++) and device.
+#pragma once
+#include <stdint.h>
+
+#ifndef MM_HD
+#if defined(__HIPCC__)
+#define MM_HD __host__ __device__ inline
+#else
+#define MM_HD inline
+#endif
+#endif
+
+namespace mm {
+
+struct L2State {
+  const uint32_t* Q;   // sorted unique sketch hashes
+  uint16_t* D;         // [s] distinct W-only hashes per gap (gap s is never needed)
+  uint32_t* mt;        // [(s+31)/32] matched-rank bitmap
+  int s;
+  int R;               // pivot rank: ranks < R are counted
+  int Cb;              // D[0] + ... + D[R-1]
+  int shared;
+};
+
+// code >= 0: matched rank; code < 0: W-only in gap g = -code-1 (g == s means "above every query hash")
+MM_HD int l2_classify(const uint32_t* Q, int s, uint32_t h) {
+  int lo = 0, hi = s;
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (Q[mid] < h) lo = mid + 1; else hi = mid; }
+  return (lo < s && Q[lo] == h) ? lo : -(lo + 1);
+}
+
+MM_HD void l2_reset(L2State& S) { S.R = S.s; S.Cb = 0; S.shared = 0; }   // arrays must be zeroed by the caller
+
+MM_HD bool l2_mt_test(const L2State& S, int r) { return (S.mt[r >> 5] >> (r & 31)) & 1u; }
+
+// a matched hash enters the window (first occurrence) / leaves it (last occurrence)
+MM_HD void l2_add_matched(L2State& S, int r) {
+  S.mt[r >> 5] |= 1u << (r & 31);
+  if (r < S.R) S.shared += 1;
+}
+MM_HD void l2_del_matched(L2State& S, int r) {
+  S.mt[r >> 5] &= ~(1u << (r & 31));
+  if (r < S.R) S.shared -= 1;
+}
+// a distinct W-only hash of gap g enters / leaves
+MM_HD void l2_add_wonly(L2State& S, int g) {
+  if (g >= S.s) return;
+  S.D[g] += 1;
+  if (g < S.R) {
+    S.Cb += 1;
+    if (S.R - 1 + S.Cb >= S.s) {                 // rank R-1 pushed out of the s smallest
+      S.R -= 1;
+      S.Cb -= S.D[S.R];
+      if (l2_mt_test(S, S.R)) S.shared -= 1;
+    }
+  }
+}
+MM_HD void l2_del_wonly(L2State& S, int g) {
+  if (g >= S.s) return;
+  S.D[g] -= 1;
+  if (g < S.R) S.Cb -= 1;
+  if (g <= S.R && S.R < S.s && S.R + S.Cb + S.D[S.R] < S.s) {   // rank R now fits among the s smallest
+    if (l2_mt_test(S, S.R)) S.shared += 1;
+    S.Cb += S.D[S.R];
+    S.R += 1;
+  }
+}
+
+}  // namespace mm

@@ -1,0 +1,267 @@
+// K1 — k-mer hashing + winnowing sweep (replaces CommonFunc::addMinimizers, commonFunc.hpp:92-175).
+//
+// Parallel restatement of the reference's monotone-deque loop.  Let NS be the positions i in
+// [0, len-k] whose forward and reverse-complement hashes differ (commonFunc.hpp:130: symmetric k-mers
+// take no part at all, not even in window expiry).  For every i in NS with i >= w-1:
+//     c(i) = argmin over q in NS ∩ (i-w, i] of the canonical hash, ties -> largest q   (:139-149)
+// The loop appends (hash[c(i)], wpos = i-w+1, strand[c(i)]) when c(i) differs from c at the previous
+// evaluated position (:157: the saved queue entry carries its wpos, an unsaved one carries 0), except
+// that right after the window-0 emission E0 (only if position w-1 is in NS) change points whose
+// (hash, strand) equal E0's are swallowed until the first one that differs (the 4-tuple compare
+// matches an unsaved entry with wpos 0).  `jstar` = position of that first differing change point,
+// found per sequence by a short serial walk (jstar_kernel); emissions in (w-1, jstar) are dropped.
+//
+// HBM traffic per position: 2 bits in, 8 bytes out per emitted minimizer (~2/(w+1) per position),
+// twice (count pass + write pass).  Everything else lives in LDS.
+#pragma once
+#include "mm_common.hpp"
+#include "mm_scan.hpp"
+
+namespace mm {
+
+constexpr int MZ_THREADS = 256;
+constexpr int MZ_TILE = 2048;          // positions per workgroup
+constexpr int MZ_MAX_W = 4096;
+constexpr int MZ_MAX_K = 64;
+
+struct SeqView {                       // device view of an mm_seqset
+  const uint32_t* packed;
+  const uint64_t* base;                // [n+1]
+  const int32_t* len;                  // [n]
+  const uint64_t* exc_start;
+  const uint32_t* exc_len;
+  const uint8_t* exc_byte;
+  int64_t n_exc;
+  int64_t n;
+};
+
+__device__ inline uint32_t code_at(const SeqView& S, uint64_t g) { return (S.packed[g >> 4] >> (2 * (g & 15))) & 3u; }
+
+// first exception run whose end is beyond g
+__device__ inline int64_t exc_lower(const SeqView& S, uint64_t g) {
+  int64_t lo = 0, hi = S.n_exc;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (S.exc_start[mid] + S.exc_len[mid] <= g) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ inline uint8_t ascii_at(const SeqView& S, uint64_t g) {
+  if (S.n_exc) {
+    int64_t r = exc_lower(S, g);
+    if (r < S.n_exc && S.exc_start[r] <= g) return S.exc_byte[r];
+  }
+  return ascii_of_code(code_at(S, g));
+}
+
+struct KmerInfo { uint32_t hash; bool ns; bool fwd; };
+// serial (one thread) evaluation of one position; used only by the jstar walk
+__device__ inline KmerInfo kmer_info_serial(const SeqView& S, uint64_t gbase, int p, int k) {
+  uint8_t f[MZ_MAX_K], c[MZ_MAX_K];
+  for (int j = 0; j < k; ++j) { f[j] = ascii_at(S, gbase + p + j); c[j] = complement_ascii(f[j]); }
+  uint32_t hf = murmur_bytes<false>(f, k), hb = murmur_bytes<true>(c + k - 1, k);
+  return KmerInfo{hf < hb ? hf : hb, hf != hb, hf < hb};
+}
+
+// One thread per sequence: position of the first change point after window 0 whose (hash,strand)
+// differs from the window-0 emission; w-1 when nothing can be swallowed.
+__global__ void jstar_kernel(SeqView S, const uint8_t* __restrict__ active, int k, int w, int32_t* __restrict__ jstar) {
+  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S.n) return;
+  int32_t res = w - 1;
+  int npos = S.len[s] - k + 1;
+  if ((active == nullptr || active[s]) && npos >= w) {
+    uint64_t gb = S.base[s];
+    KmerInfo e = kmer_info_serial(S, gb, w - 1, k);
+    if (e.ns) {
+      // c(w-1): argmin over NS positions 0..w-1, ties -> rightmost
+      int cpos = w - 1; uint32_t ch = e.hash; bool cf = e.fwd;
+      for (int q = w - 2; q >= 0; --q) {
+        KmerInfo t = kmer_info_serial(S, gb, q, k);
+        if (t.ns && t.hash < ch) { ch = t.hash; cpos = q; cf = t.fwd; }
+      }
+      const uint32_t h0 = ch; const bool f0 = cf;
+      res = npos;                                  // swallowed to the end unless a differing change point shows up
+      for (int p = w; p < npos; ++p) {
+        KmerInfo t = kmer_info_serial(S, gb, p, k);
+        if (!t.ns) continue;
+        int ncpos; uint32_t nch; bool ncf;
+        if (t.hash <= ch || cpos <= p - w) {
+          if (t.hash <= ch && cpos > p - w) { ncpos = p; nch = t.hash; ncf = t.fwd; }
+          else {                                   // previous minimum left the window: rescan
+            ncpos = p; nch = t.hash; ncf = t.fwd;
+            for (int q = p - 1; q > p - w; --q) {
+              KmerInfo u = kmer_info_serial(S, gb, q, k);
+              if (u.ns && u.hash < nch) { nch = u.hash; ncpos = q; ncf = u.fwd; }
+            }
+          }
+        } else { ncpos = cpos; nch = ch; ncf = cf; }
+        if (ncpos != cpos) {
+          if (nch != h0 || ncf != f0) { res = p; break; }
+        }
+        cpos = ncpos; ch = nch; cf = ncf;
+      }
+    }
+  }
+  jstar[s] = res;
+}
+
+// tile_first[s] = index of the first tile of sequence s (tile_first[n] = number of tiles)
+__device__ inline int64_t seq_of_tile(const uint64_t* __restrict__ tile_first, int64_t n, uint64_t tile) {
+  int64_t lo = 0, hi = n;                          // last s with tile_first[s] <= tile
+  while (hi - lo > 1) {
+    int64_t mid = (lo + hi) >> 1;
+    if (tile_first[mid] <= tile) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// WRITE=false: tile_count[tile] = number of emitted minimizers.  WRITE=true: records written at tile_out[tile]...
+template <bool WRITE>
+__global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const uint64_t* __restrict__ tile_first, int k, int w,
+                                                               const int32_t* __restrict__ jstar, uint32_t* __restrict__ tile_count,
+                                                               const uint64_t* __restrict__ tile_out, Rec* __restrict__ out,
+                                                               uint32_t* __restrict__ out_seq) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int halo = 2 * (w - 1);
+  const int NP = MZ_TILE + halo;                   // positions held
+  const int NB = ((NP + k - 1) + 15) & ~15;        // bytes held
+  uint8_t* fwd = smem;
+  uint8_t* cmp = fwd + NB;
+  uint32_t* hsh = (uint32_t*)(cmp + NB);
+  uint16_t* cps = (uint16_t*)(hsh + NP);
+  uint8_t* flg = (uint8_t*)(cps + NP);
+
+  const uint64_t tile = blockIdx.x;
+  const int64_t s = seq_of_tile(tile_first, S.n, tile);
+  const int len = S.len[s];
+  const int npos = len - k + 1;
+  const int P0 = (int)(tile - tile_first[s]) * MZ_TILE;
+  const int Pend = min(P0 + MZ_TILE, npos);
+  const int H0 = max(0, P0 - halo);
+  const uint64_t gb = S.base[s];
+  const int nbytes = (Pend - H0) + k - 1;
+  const int tid = threadIdx.x;
+
+  // 1. unpack 2-bit codes -> ASCII (+ complement) in LDS
+  {
+    const uint64_t g0 = gb + (uint64_t)H0;
+    const uint64_t w0 = g0 >> 4, w1 = (g0 + nbytes - 1) >> 4;
+    for (uint64_t wi = w0 + tid; wi <= w1; wi += MZ_THREADS) {
+      uint32_t word = S.packed[wi];
+      int64_t rel = (int64_t)(wi << 4) - (int64_t)g0;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        int64_t j = rel + b;
+        if (j >= 0 && j < nbytes) {
+          uint32_t c = (word >> (2 * b)) & 3u;
+          fwd[j] = ascii_of_code(c);
+          cmp[j] = ascii_of_code(3u - c);
+        }
+      }
+    }
+    __syncthreads();
+    if (S.n_exc) {                                 // patch non-ACGT bytes (self-complementary, commonFunc.hpp:50)
+      const uint64_t g1 = g0 + nbytes;
+      for (int64_t r = exc_lower(S, g0); r < S.n_exc && S.exc_start[r] < g1; ++r) {
+        uint64_t a = max(S.exc_start[r], g0), b = min(S.exc_start[r] + S.exc_len[r], g1);
+        uint8_t ch = S.exc_byte[r];
+        for (uint64_t g = a + tid; g < b; g += MZ_THREADS) { fwd[g - g0] = ch; cmp[g - g0] = ch; }
+      }
+      __syncthreads();
+    }
+  }
+  // 2. canonical hash / strand / non-symmetric flag per position
+  const int np = Pend - H0;
+  for (int j = tid; j < np; j += MZ_THREADS) {
+    uint32_t hf, hb;
+    if (k == 16) {
+      uint64_t lo = 0, hi = 0, rlo = 0, rhi = 0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        lo |= (uint64_t)fwd[j + b] << (8 * b);
+        hi |= (uint64_t)fwd[j + 8 + b] << (8 * b);
+        rlo |= (uint64_t)cmp[j + 15 - b] << (8 * b);
+        rhi |= (uint64_t)cmp[j + 7 - b] << (8 * b);
+      }
+      hf = murmur16(lo, hi);
+      hb = murmur16(rlo, rhi);
+    } else {
+      hf = murmur_bytes<false>(fwd + j, k);
+      hb = murmur_bytes<true>(cmp + j + k - 1, k);
+    }
+    hsh[j] = hf < hb ? hf : hb;
+    flg[j] = (uint8_t)((hf != hb ? 1 : 0) | (hf < hb ? 2 : 0));
+  }
+  __syncthreads();
+  // 3. window argmin c(p) for every evaluated position from P0-(w-1) on
+  const int jeval0 = max(max(P0 - (w - 1), w - 1), H0) - H0;
+  for (int j = jeval0 + tid; j < np; j += MZ_THREADS) {
+    uint16_t c = 0xFFFF;
+    if (flg[j] & 1) {
+      uint32_t best = hsh[j]; int bj = j;
+      const int qlo = max(j - w + 1, 0);           // j-w+1 >= 0 whenever p >= H0 + ... ; clamp for p < w-1+H0 cases
+      for (int q = j - 1; q >= qlo; --q)
+        if ((flg[q] & 1) && hsh[q] < best) { best = hsh[q]; bj = q; }
+      c = (uint16_t)bj;
+    }
+    cps[j] = c;
+  }
+  __syncthreads();
+  // 4. emission flags for the tile's own positions, 8 consecutive positions per thread
+  const int js = jstar[s];
+  const int j0 = (P0 - H0) + tid * (MZ_TILE / MZ_THREADS);
+  uint32_t mask = 0;
+#pragma unroll
+  for (int i = 0; i < MZ_TILE / MZ_THREADS; ++i) {
+    int j = j0 + i, p = H0 + j;
+    if (j < np && p >= w - 1 && (flg[j] & 1)) {
+      int pj = -1;
+      const int qlo = max(max(j - w + 1, 0), (w - 1) - H0);
+      for (int q = j - 1; q >= qlo; --q) if (flg[q] & 1) { pj = q; break; }
+      bool emit = (pj < 0) || (cps[pj] != cps[j]);
+      if (p > w - 1 && p < js) emit = false;
+      if (emit) mask |= 1u << i;
+    }
+  }
+  const uint32_t cnt = __popc(mask);
+  uint64_t tot;
+  uint64_t ex = block_excl_scan_u64(cnt, &tot);
+  if (!WRITE) {
+    if (tid == 0) tile_count[tile] = (uint32_t)tot;
+  } else {
+    uint64_t o = tile_out[tile] + ex;
+#pragma unroll
+    for (int i = 0; i < MZ_TILE / MZ_THREADS; ++i) {
+      if (mask & (1u << i)) {
+        int j = j0 + i, p = H0 + j, c = cps[j];
+        uint32_t pw = ((uint32_t)(p - w + 1) << PW_SHIFT) | ((flg[c] & 2) ? PW_STRAND : 0u);
+        out[o] = Rec{hsh[c], pw};
+        if (out_seq) out_seq[o] = (uint32_t)s;
+        ++o;
+      }
+    }
+  }
+}
+
+inline size_t minimizer_lds_bytes(int k, int w) {
+  int halo = 2 * (w - 1), NP = MZ_TILE + halo, NB = ((NP + k - 1) + 15) & ~15;
+  return (size_t)2 * NB + (size_t)NP * 4 + (size_t)NP * 2 + (size_t)NP;
+}
+
+// Result of a sweep over a sequence set
+struct MinimizerSet {
+  DBuf<Rec> rec;                 // all records, sequence-major, position order
+  DBuf<uint64_t> off;            // [n+1] first record of each sequence
+  DBuf<uint32_t> rec_seq;        // optional owner sequence per record
+  std::vector<uint64_t> h_off;   // host copy of off
+  int64_t total = 0;
+};
+
+// `active` (host, may be empty = all): sequences with active[i]==0 produce nothing.
+void run_minimizers(mm_ctx* ctx, const mm_seqset* S, int k, int w, const std::vector<uint8_t>& active, bool want_rec_seq,
+                    MinimizerSet& out);
+
+SeqView make_view(const mm_seqset* S);
+
+}  // namespace mm

@@ -1,0 +1,144 @@
+// Sequence sets in HBM (packed 2-bit + exception runs) and the K1 driver.
+#include "mm_minimizer.hpp"
+#include <algorithm>
+
+namespace mm {
+
+SeqView make_view(const mm_seqset* S) {
+  return SeqView{S->packed.p, S->d_base.p, S->d_len.p, S->exc_start.p, S->exc_len.p, S->exc_byte.p, S->n_exc, S->count()};
+}
+
+__global__ void gather_offsets_kernel(const uint64_t* __restrict__ tile_first, const uint64_t* __restrict__ tile_out, int64_t n,
+                                      uint64_t* __restrict__ off) {
+  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s <= n) off[s] = tile_out[tile_first[s]];
+}
+
+void run_minimizers(mm_ctx* ctx, const mm_seqset* S, int k, int w, const std::vector<uint8_t>& active, bool want_rec_seq,
+                    MinimizerSet& out) {
+  MM_REQUIRE(S->frozen, MM_ERR_STATE, "sequence set not uploaded");
+  MM_REQUIRE(k >= 1 && k <= MZ_MAX_K, MM_ERR_ARG, "k must be in [1,64]");
+  MM_REQUIRE(w >= 1 && w <= MZ_MAX_W, MM_ERR_ARG, "window size must be in [1,4096]");
+  hipStream_t st = ctx->stream;
+  const int64_t n = S->count();
+  std::vector<uint64_t> tf((size_t)n + 1, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t npos = (int64_t)S->len[i] - k + 1;
+    bool on = active.empty() || active[(size_t)i];
+    int64_t nt = (on && npos >= w) ? ceil_div(npos, MZ_TILE) : 0;   // no window fits => nothing can be emitted
+    tf[i + 1] = tf[i] + (uint64_t)nt;
+  }
+  const int64_t ntiles = (int64_t)tf[n];
+  out.off.alloc((size_t)n + 1);
+  out.h_off.assign((size_t)n + 1, 0);
+  out.total = 0;
+  if (ntiles == 0) { out.off.zero(st); out.rec.alloc(0); MM_HIP(hipStreamSynchronize(st)); return; }
+  MM_REQUIRE(ntiles < (1LL << 31), MM_ERR_LIMIT, "too many tiles for one launch");
+
+  DBuf<uint64_t> d_tf((size_t)n + 1);
+  d_tf.upload(tf.data(), tf.size(), st);
+  DBuf<uint8_t> d_act;
+  if (!active.empty()) { d_act.alloc(active.size()); d_act.upload(active.data(), active.size(), st); }
+  DBuf<int32_t> d_js((size_t)n);
+  SeqView V = make_view(S);
+  jstar_kernel<<<dim3((unsigned)ceil_div(n, 128)), dim3(128), 0, st>>>(V, d_act.p, k, w, d_js.p);
+  MM_KERNEL_CHECK();
+
+  const size_t lds = minimizer_lds_bytes(k, w);
+  if (lds > 64 * 1024) {
+    MM_HIP(hipFuncSetAttribute((const void*)minimizer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MM_HIP(hipFuncSetAttribute((const void*)minimizer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  DBuf<uint32_t> tcount((size_t)ntiles);
+  DBuf<uint64_t> tout((size_t)ntiles + 1), tmp;
+  minimizer_kernel<false><<<dim3((unsigned)ntiles), dim3(MZ_THREADS), lds, st>>>(V, d_tf.p, k, w, d_js.p, tcount.p, nullptr, nullptr, nullptr);
+  MM_KERNEL_CHECK();
+  exclusive_scan_u32_u64(tcount.p, ntiles, tout.p, tmp, st);
+  uint64_t total = 0;
+  MM_HIP(hipMemcpyAsync(&total, tout.p + ntiles, sizeof total, hipMemcpyDeviceToHost, st));
+  MM_HIP(hipStreamSynchronize(st));
+  out.total = (int64_t)total;
+  out.rec.alloc((size_t)total);
+  if (want_rec_seq) out.rec_seq.alloc((size_t)total);
+  if (total) {
+    minimizer_kernel<true><<<dim3((unsigned)ntiles), dim3(MZ_THREADS), lds, st>>>(V, d_tf.p, k, w, d_js.p, nullptr, tout.p, out.rec.p,
+                                                                                 want_rec_seq ? out.rec_seq.p : nullptr);
+    MM_KERNEL_CHECK();
+  }
+  gather_offsets_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(d_tf.p, tout.p, n, out.off.p);
+  MM_KERNEL_CHECK();
+  out.off.download(out.h_off.data(), (size_t)n + 1, st);
+  MM_HIP(hipStreamSynchronize(st));
+}
+
+// ---- host packing -----------------------------------------------------------------------------------
+static inline int code_of(uint8_t c) {
+  switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; }
+  return -1;
+}
+
+void seqset_upload(mm_seqset* s) {
+  MM_REQUIRE(!s->frozen, MM_ERR_STATE, "sequence set already uploaded");
+  hipStream_t st = s->ctx->stream;
+  const size_t n = s->staged.size();
+  s->len.resize(n);
+  s->base.assign(n + 1, 0);
+  s->total_bases = 0;
+  for (size_t i = 0; i < n; ++i) {
+    MM_REQUIRE((int64_t)s->staged[i].size() <= MAX_SEQ_LEN, MM_ERR_LIMIT, "sequence longer than 2^29-1 bases");
+    s->len[i] = (int32_t)s->staged[i].size();
+    s->base[i + 1] = s->base[i] + (((uint64_t)s->len[i] + 15) & ~15ull);
+    s->total_bases += s->len[i];
+  }
+  const size_t nwords = (size_t)(s->base[n] >> 4);
+  std::vector<uint32_t> words(nwords + 1, 0);
+  std::vector<uint64_t> es; std::vector<uint32_t> el; std::vector<uint8_t> eb;
+  for (size_t i = 0; i < n; ++i) {
+    const std::string& q = s->staged[i];
+    const uint64_t b0 = s->base[i];
+    bool open = false;
+    for (size_t j = 0; j < q.size(); ++j) {
+      uint8_t c = (uint8_t)q[j];
+      if (c > 96 && c < 123) c -= 32;                         // makeUpperCase, commonFunc.hpp:57-66
+      int code = code_of(c);
+      if (code >= 0) { words[(b0 + j) >> 4] |= (uint32_t)code << (2 * ((b0 + j) & 15)); open = false; }
+      else if (open && eb.back() == c && el.back() < 0xFFFFFFFFu) el.back()++;
+      else { es.push_back(b0 + j); el.push_back(1); eb.push_back(c); open = true; }
+    }
+  }
+  s->packed.alloc(words.size());
+  s->packed.upload(words.data(), words.size(), st);
+  s->d_base.alloc(n + 1); s->d_base.upload(s->base.data(), n + 1, st);
+  s->d_len.alloc(std::max<size_t>(n, 1)); s->d_len.upload(s->len.data(), n, st);
+  s->n_exc = (int64_t)es.size();
+  if (s->n_exc) {
+    s->exc_start.alloc(es.size()); s->exc_start.upload(es.data(), es.size(), st);
+    s->exc_len.alloc(el.size()); s->exc_len.upload(el.data(), el.size(), st);
+    s->exc_byte.alloc(eb.size()); s->exc_byte.upload(eb.data(), eb.size(), st);
+  }
+  MM_HIP(hipStreamSynchronize(st));
+  s->staged.clear(); s->staged.shrink_to_fit();
+  s->frozen = true;
+}
+
+void seqset_fetch(mm_seqset* s, int64_t i, char* out, int64_t cap) {
+  MM_REQUIRE(s->frozen, MM_ERR_STATE, "sequence set not uploaded");
+  MM_REQUIRE(i >= 0 && i < s->count(), MM_ERR_ARG, "sequence index out of range");
+  const int64_t L = s->len[(size_t)i];
+  MM_REQUIRE(cap >= L, MM_ERR_ARG, "output buffer too small");
+  hipStream_t st = s->ctx->stream;
+  const uint64_t b0 = s->base[(size_t)i];
+  const size_t nw = (size_t)((L + 15) >> 4);
+  std::vector<uint32_t> w(nw);
+  if (nw) MM_HIP(hipMemcpyAsync(w.data(), s->packed.p + (b0 >> 4), nw * 4, hipMemcpyDeviceToHost, st));
+  std::vector<uint64_t> es; std::vector<uint32_t> el; std::vector<uint8_t> eb;
+  if (s->n_exc) { es = s->exc_start.to_host(st); el = s->exc_len.to_host(st); eb = s->exc_byte.to_host(st); }
+  MM_HIP(hipStreamSynchronize(st));
+  for (int64_t j = 0; j < L; ++j) out[j] = (char)ascii_of_code((w[(size_t)(j >> 4)] >> (2 * (j & 15))) & 3u);
+  for (size_t r = 0; r < es.size(); ++r) {
+    if (es[r] + el[r] <= b0 || es[r] >= b0 + (uint64_t)L) continue;
+    for (uint64_t g = std::max(es[r], b0); g < std::min(es[r] + el[r], b0 + (uint64_t)L); ++g) out[g - b0] = (char)eb[r];
+  }
+}
+
+}  // namespace mm

@@ -1,0 +1,50 @@
+// CPU unit test of the K5 integer state machine (metamaps_amd/csrc/mm_l2_core.hpp) against the oracle's
+// ordered-map sliding window (oracle/orc_map.hpp SlideWindow, restating slidingMap.hpp) on random streams
+// with heavy hash duplication.  Built and run by tests/test_l2_core.py with g++ (no GPU needed).
+#include "../oracle/orc_map.hpp"
+#include "../metamaps_amd/csrc/mm_l2_core.hpp"
+#include <random>
+#include <cstdio>
+
+int main(int argc, char** argv) {
+  int rounds = argc > 1 ? atoi(argv[1]) : 300;
+  std::mt19937_64 rng(12345);
+  long long checked = 0, dups = 0;
+  for (int it = 0; it < rounds; ++it) {
+    int s = 1 + rng() % 200;
+    uint32_t space = s + 50 + rng() % 2000;                      // small hash space => many duplicates
+    std::set<uint32_t> qs; while ((int)qs.size() < s) qs.insert(rng() % space);
+    orc::Query Q; Q.sketch = s;
+    for (uint32_t h : qs) Q.mins.push_back(orc::Mz{h, 0, 0, 1});
+    std::vector<uint32_t> Qh(qs.begin(), qs.end());
+    int M = 50 + rng() % 1500;
+    std::vector<orc::Mz> X(M);
+    for (int i = 0; i < M; ++i) X[i] = orc::Mz{(uint32_t)(rng() % space), 0, i, 1};
+    std::vector<uint16_t> D(s, 0); std::vector<uint32_t> mt((s + 31) / 32, 0);
+    mm::L2State S{Qh.data(), D.data(), mt.data(), s, 0, 0, 0};
+    mm::l2_reset(S);
+    orc::SlideWindow ref(Q);
+    int b = 0, e = 0;                                          // window [b,e)
+    auto other_alive = [&](int j) { for (int i = b; i < e; ++i) if (i != j && X[i].hash == X[j].hash) return true; return false; };
+    for (int step = 0; step < 3 * M; ++step) {
+      bool ins = (e < M) && (b == e || (rng() % 100) < 55);
+      if (!ins && b == e) break;
+      if (ins) {
+        int code = mm::l2_classify(Qh.data(), s, X[e].hash);
+        bool dup = other_alive(e);                             // window is [b,e) here: e itself not inside yet
+        dups += dup;
+        if (!dup) { if (code >= 0) mm::l2_add_matched(S, code); else mm::l2_add_wonly(S, -code - 1); }
+        ref.insert(X[e]); ++e;
+      } else {
+        int code = mm::l2_classify(Qh.data(), s, X[b].hash);
+        bool dup = other_alive(b);
+        if (!dup) { if (code >= 0) mm::l2_del_matched(S, code); else mm::l2_del_wonly(S, -code - 1); }
+        ref.erase(X[b]); ++b;
+      }
+      ++checked;
+      if (S.shared != ref.shared) { printf("MISMATCH it=%d step=%d shared=%d ref=%d s=%d\n", it, step, S.shared, ref.shared, s); return 1; }
+    }
+  }
+  printf("ok %lld events, %lld duplicate inserts\n", checked, dups);
+  return 0;
+}

@@ -1,0 +1,407 @@
+"""ctypes binding of include/metamaps_hip.h (libmetamaps_hip.so).
+
+Thin and literal: every wrapper is one C-ABI call (plus buffer allocation), so the parity tests exercise
+exactly what a host program in another language would call.  There is no fallback: if the shared library
+is missing, loading raises; if no gfx950 GPU is present, Context() raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmetamaps_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "metamaps_hip.h")
+
+COMM_ID_BYTES = 128
+
+
+class MMError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"libmetamaps_hip status {status}: {msg}")
+        self.status = status
+
+
+class MapParams(C.Structure):
+    _fields_ = [("k", C.c_int32), ("w", C.c_int32), ("perc_identity", C.c_float), ("min_read_len", C.c_int32)]
+
+
+class MapRecord(C.Structure):
+    _fields_ = [("read", C.c_int32), ("ref_contig", C.c_int32), ("ref_start", C.c_int32), ("shared", C.c_int32),
+                ("sketch", C.c_int32), ("strand", C.c_int32), ("mapq", C.c_double)]
+
+
+RECORD_DTYPE = np.dtype([("read", "<i4"), ("ref_contig", "<i4"), ("ref_start", "<i4"), ("shared", "<i4"),
+                         ("sketch", "<i4"), ("strand", "<i4"), ("mapq", "<f8")])
+assert RECORD_DTYPE.itemsize == C.sizeof(MapRecord)
+
+
+class MapStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_reads", "n_reads_long_enough", "n_reads_mapped", "n_mappings",
+                                           "bases_long_enough", "sum_sketch", "sum_hits", "n_candidates",
+                                           "sum_l2_stream_entries", "sum_l2_evals", "n_ambiguous_sketch_reads")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_contigs", "n_entries", "n_unique_hashes", "n_dup_flagged", "hbm_bytes")]
+
+
+class SynthRefParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_species", C.c_int32), ("strains_per_species", C.c_int32),
+                ("genome_len", C.c_int32), ("strain_divergence", C.c_float), ("genus_divergence", C.c_float)]
+
+
+class SynthReadParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_reads", C.c_int64), ("read_len", C.c_int32), ("sub_rate", C.c_float),
+                ("ins_rate", C.c_float), ("del_rate", C.c_float), ("frac_random", C.c_float), ("n_abundant", C.c_int32)]
+
+
+def declared_symbols(header: str = HEADER_PATH) -> list[str]:
+    """Every function the public header declares (used by the CPU test that checks the exports)."""
+    txt = open(header).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mm_[a-z0-9_]+)\s*\(", txt)))
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
+        P = C.POINTER
+        sig = {
+            "mm_abi_version": (C.c_int, []),
+            "mm_ctx_create": (C.c_int, [C.c_int, P(vp)]),
+            "mm_ctx_destroy": (None, [vp]),
+            "mm_last_error": (C.c_char_p, [vp]),
+            "mm_ctx_device_info": (C.c_int, [vp, C.c_char_p, C.c_size_t, P(C.c_int), P(u64), P(u64)]),
+            "mm_ctx_synchronize": (C.c_int, [vp]),
+            "mm_ctx_stream": (vp, [vp]),
+            "mm_seqset_create": (C.c_int, [vp, P(vp)]),
+            "mm_seqset_destroy": (None, [vp]),
+            "mm_seqset_add": (C.c_int, [vp, C.c_char_p, i64]),
+            "mm_seqset_upload": (C.c_int, [vp]),
+            "mm_seqset_count": (i64, [vp]),
+            "mm_seqset_total_bases": (i64, [vp]),
+            "mm_seqset_lengths": (C.c_int, [vp, vp]),
+            "mm_seqset_fetch": (C.c_int, [vp, i64, C.c_char_p, i64]),
+            "mm_synth_reference": (C.c_int, [vp, P(SynthRefParams), P(vp)]),
+            "mm_synth_reads": (C.c_int, [vp, vp, P(SynthReadParams), P(vp), vp]),
+            "mm_minimizers": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, i64]),
+            "mm_index_build": (C.c_int, [vp, vp, C.c_int, C.c_int, P(vp)]),
+            "mm_index_destroy": (None, [vp]),
+            "mm_index_get_info": (C.c_int, [vp, P(IndexInfo)]),
+            "mm_index_freq_hist": (C.c_int, [vp, vp, vp, i64, P(i64)]),
+            "mm_freq_threshold_from_hist": (C.c_int, [vp, vp, i64, i64, C.c_int]),
+            "mm_index_set_freq_threshold": (C.c_int, [vp, C.c_int]),
+            "mm_index_entries": (C.c_int, [vp, vp, vp, vp, vp, i64]),
+            "mm_recommended_window": (C.c_int, [f64, C.c_int, f32, C.c_int, u64]),
+            "mm_estimate_pvalue": (f64, [C.c_int, C.c_int, f32, C.c_int, u64]),
+            "mm_min_hits_relaxed": (C.c_int, [C.c_int, C.c_int, f32]),
+            "mm_identity": (None, [C.c_int, C.c_int, C.c_int, P(f32), P(f32)]),
+            "mm_map_batch": (C.c_int, [vp, vp, vp, P(MapParams), P(vp)]),
+            "mm_mapping_destroy": (None, [vp]),
+            "mm_mapping_get_stats": (C.c_int, [vp, P(MapStats)]),
+            "mm_mapping_fetch": (C.c_int, [vp, vp, vp, i64]),
+            "mm_mapping_add_qualities": (C.c_int, [vp, vp, vp, C.c_int]),
+            "mm_mapping_concat": (C.c_int, [vp, P(vp), vp, C.c_int, P(vp)]),
+            "mm_debug_sketch": (C.c_int, [vp, vp, vp, vp, i64]),
+            "mm_debug_hits": (C.c_int, [vp, vp, vp, vp, i64]),
+            "mm_debug_candidates": (C.c_int, [vp, vp, vp, i64]),
+            "mm_debug_l2": (C.c_int, [vp, vp, i64]),
+            "mm_debug_min_hits": (C.c_int, [vp, vp]),
+            "mm_em_create": (C.c_int, [vp, i64, vp, vp, vp, vp, i32, P(vp)]),
+            "mm_em_destroy": (None, [vp]),
+            "mm_em_iterate": (C.c_int, [vp, vp, vp, P(f64)]),
+            "mm_em_iterate_allreduce": (C.c_int, [vp, vp, vp, P(f64)]),
+            "mm_em_posteriors": (C.c_int, [vp, vp, vp, vp]),
+            "mm_comm_unique_id": (C.c_int, [C.c_char_p]),
+            "mm_comm_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
+            "mm_comm_allreduce_f64": (C.c_int, [vp, vp, i64]),
+            "mm_comm_destroy": (None, [vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self.h = C.c_void_p()
+        st = lib().mm_ctx_create(device, C.byref(self.h))
+        if st != 0:
+            raise MMError(st, "mm_ctx_create failed (no gfx950 GPU visible? this library has no CPU fallback)")
+
+    def check(self, st: int):
+        if st != 0:
+            raise MMError(st, lib().mm_last_error(self.h).decode(errors="replace"))
+
+    def close(self):
+        if self.h:
+            lib().mm_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cus = C.c_int()
+        tot, free = C.c_uint64(), C.c_uint64()
+        self.check(lib().mm_ctx_device_info(self.h, name, 256, C.byref(cus), C.byref(tot), C.byref(free)))
+        return {"name": name.value.decode(), "cus": cus.value, "hbm_total": tot.value, "hbm_free": free.value}
+
+    def synchronize(self):
+        self.check(lib().mm_ctx_synchronize(self.h))
+
+    @property
+    def stream(self) -> int:
+        return lib().mm_ctx_stream(self.h) or 0
+
+    # ---- sequences
+    def seqset(self, seqs) -> "SeqSet":
+        h = C.c_void_p()
+        self.check(lib().mm_seqset_create(self.h, C.byref(h)))
+        s = SeqSet(self, h)
+        for q in seqs:
+            if isinstance(q, str):
+                q = q.encode()
+            q = bytes(q)
+            self.check(lib().mm_seqset_add(h, q, len(q)))
+        self.check(lib().mm_seqset_upload(h))
+        return s
+
+    def synth_reference(self, **kw) -> "SeqSet":
+        p = SynthRefParams(**kw)
+        h = C.c_void_p()
+        self.check(lib().mm_synth_reference(self.h, C.byref(p), C.byref(h)))
+        return SeqSet(self, h)
+
+    def synth_reads(self, ref: "SeqSet", **kw):
+        p = SynthReadParams(**kw)
+        h = C.c_void_p()
+        truth = np.zeros(p.n_reads, dtype=np.int32)
+        self.check(lib().mm_synth_reads(self.h, ref.h, C.byref(p), C.byref(h), _ptr(truth)))
+        return SeqSet(self, h), truth
+
+    def minimizers(self, s: "SeqSet", k: int, w: int):
+        n = s.count
+        off = np.zeros(n + 1, dtype=np.int64)
+        self.check(lib().mm_minimizers(self.h, s.h, k, w, _ptr(off), None, None, None, 0))
+        tot = int(off[-1])
+        hsh = np.zeros(tot, dtype=np.uint32)
+        wp = np.zeros(tot, dtype=np.int32)
+        st = np.zeros(tot, dtype=np.int32)
+        self.check(lib().mm_minimizers(self.h, s.h, k, w, _ptr(off), _ptr(hsh), _ptr(wp), _ptr(st), tot))
+        return off, hsh, wp, st
+
+    def index(self, contigs: "SeqSet", k: int, w: int, auto_threshold: bool = True) -> "Index":
+        h = C.c_void_p()
+        self.check(lib().mm_index_build(self.h, contigs.h, k, w, C.byref(h)))
+        idx = Index(self, h)
+        if auto_threshold:
+            counts, nh = idx.freq_hist()
+            thr = lib().mm_freq_threshold_from_hist(_ptr(counts), _ptr(nh), len(counts), idx.info()["n_unique_hashes"], 2**31 - 1)
+            idx.set_freq_threshold(thr)
+        return idx
+
+    def map_batch(self, idx: "Index", reads: "SeqSet", k: int, w: int, pi: float = 80.0, min_read_len: int = 1000) -> "Mapping":
+        p = MapParams(k, w, pi, min_read_len)
+        h = C.c_void_p()
+        self.check(lib().mm_map_batch(self.h, idx.h, reads.h, C.byref(p), C.byref(h)))
+        return Mapping(self, h, reads.count)
+
+    def em(self, read_off, taxon, mapq, inv_nloc, n_taxa: int) -> "EM":
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        taxon = np.ascontiguousarray(taxon, dtype=np.int32)
+        mapq = np.ascontiguousarray(mapq, dtype=np.float64)
+        inv_nloc = np.ascontiguousarray(inv_nloc, dtype=np.float64)
+        h = C.c_void_p()
+        self.check(lib().mm_em_create(self.h, len(read_off) - 1, _ptr(read_off), _ptr(taxon), _ptr(mapq), _ptr(inv_nloc), n_taxa, C.byref(h)))
+        return EM(self, h, n_taxa, len(read_off) - 1, len(taxon))
+
+    # ---- communicator
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        st = lib().mm_comm_unique_id(buf)
+        if st != 0:
+            raise MMError(st, "mm_comm_unique_id failed")
+        return buf.raw
+
+    def comm_init(self, uid: bytes, rank: int, nranks: int):
+        self.check(lib().mm_comm_init(self.h, uid, rank, nranks))
+
+    def comm_allreduce(self, arr: np.ndarray):
+        assert arr.dtype == np.float64 and arr.flags.c_contiguous
+        self.check(lib().mm_comm_allreduce_f64(self.h, _ptr(arr), arr.size))
+
+
+class SeqSet:
+    def __init__(self, ctx: Context, h):
+        self.ctx, self.h = ctx, h
+
+    @property
+    def count(self) -> int:
+        return int(lib().mm_seqset_count(self.h))
+
+    @property
+    def total_bases(self) -> int:
+        return int(lib().mm_seqset_total_bases(self.h))
+
+    def lengths(self) -> np.ndarray:
+        a = np.zeros(self.count, dtype=np.int32)
+        self.ctx.check(lib().mm_seqset_lengths(self.h, _ptr(a)))
+        return a
+
+    def fetch(self, i: int, length: int) -> bytes:
+        buf = C.create_string_buffer(length + 1)
+        self.ctx.check(lib().mm_seqset_fetch(self.h, i, buf, length))
+        return buf.raw[:length]
+
+    def close(self):
+        if self.h:
+            lib().mm_seqset_destroy(self.h)
+            self.h = None
+
+
+class Index:
+    def __init__(self, ctx: Context, h):
+        self.ctx, self.h = ctx, h
+        self.freq_threshold = 2**31 - 1
+
+    def info(self) -> dict:
+        i = IndexInfo()
+        self.ctx.check(lib().mm_index_get_info(self.h, C.byref(i)))
+        return {n: int(getattr(i, n)) for n, _ in i._fields_}
+
+    def freq_hist(self):
+        n = C.c_int64()
+        self.ctx.check(lib().mm_index_freq_hist(self.h, None, None, 0, C.byref(n)))
+        counts = np.zeros(n.value, dtype=np.int64)
+        nh = np.zeros(n.value, dtype=np.int64)
+        self.ctx.check(lib().mm_index_freq_hist(self.h, _ptr(counts), _ptr(nh), n.value, C.byref(n)))
+        return counts, nh
+
+    def set_freq_threshold(self, thr: int):
+        self.ctx.check(lib().mm_index_set_freq_threshold(self.h, int(thr)))
+        self.freq_threshold = int(thr)
+
+    def entries(self):
+        n = self.info()["n_entries"]
+        hsh = np.zeros(n, dtype=np.uint32)
+        ct = np.zeros(n, dtype=np.int32)
+        wp = np.zeros(n, dtype=np.int32)
+        st = np.zeros(n, dtype=np.int32)
+        self.ctx.check(lib().mm_index_entries(self.h, _ptr(hsh), _ptr(ct), _ptr(wp), _ptr(st), n))
+        return hsh, ct, wp, st
+
+    def close(self):
+        if self.h:
+            lib().mm_index_destroy(self.h)
+            self.h = None
+
+
+class Mapping:
+    def __init__(self, ctx: Context, h, n_reads: int):
+        self.ctx, self.h, self.n_reads = ctx, h, n_reads
+
+    def stats(self) -> dict:
+        s = MapStats()
+        self.ctx.check(lib().mm_mapping_get_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def add_qualities(self, k: int):
+        self.ctx.check(lib().mm_mapping_add_qualities(self.ctx.h, self.h, None, k))
+
+    def fetch(self):
+        off = np.zeros(self.n_reads + 1, dtype=np.int64)
+        self.ctx.check(lib().mm_mapping_fetch(self.h, _ptr(off), None, 0))
+        rec = np.zeros(int(off[-1]), dtype=RECORD_DTYPE)
+        self.ctx.check(lib().mm_mapping_fetch(self.h, _ptr(off), _ptr(rec), len(rec)))
+        return off, rec
+
+    def debug_sketch(self):
+        off = np.zeros(self.n_reads + 1, dtype=np.int64)
+        self.ctx.check(lib().mm_debug_sketch(self.h, _ptr(off), None, None, 0))
+        h = np.zeros(int(off[-1]), dtype=np.uint32)
+        s = np.zeros(int(off[-1]), dtype=np.int32)
+        self.ctx.check(lib().mm_debug_sketch(self.h, _ptr(off), _ptr(h), _ptr(s), len(h)))
+        return off, h, s
+
+    def debug_hits(self):
+        off = np.zeros(self.n_reads + 1, dtype=np.int64)
+        self.ctx.check(lib().mm_debug_hits(self.h, _ptr(off), None, None, 0))
+        c = np.zeros(int(off[-1]), dtype=np.int32)
+        w = np.zeros(int(off[-1]), dtype=np.int32)
+        self.ctx.check(lib().mm_debug_hits(self.h, _ptr(off), _ptr(c), _ptr(w), len(c)))
+        return off, c, w
+
+    def debug_candidates(self):
+        off = np.zeros(self.n_reads + 1, dtype=np.int64)
+        self.ctx.check(lib().mm_debug_candidates(self.h, _ptr(off), None, 0))
+        t = np.zeros((int(off[-1]), 3), dtype=np.int32)
+        self.ctx.check(lib().mm_debug_candidates(self.h, _ptr(off), _ptr(t), len(t)))
+        return off, t
+
+    def debug_l2(self, n_cand: int):
+        a = np.zeros((n_cand, 5), dtype=np.int64)
+        if n_cand:
+            self.ctx.check(lib().mm_debug_l2(self.h, _ptr(a), n_cand))
+        return a
+
+    def debug_min_hits(self):
+        a = np.zeros(self.n_reads, dtype=np.int32)
+        self.ctx.check(lib().mm_debug_min_hits(self.h, _ptr(a)))
+        return a
+
+    def close(self):
+        if self.h:
+            lib().mm_mapping_destroy(self.h)
+            self.h = None
+
+
+class EM:
+    def __init__(self, ctx: Context, h, n_taxa: int, n_reads: int, n_entries: int):
+        self.ctx, self.h, self.n_taxa, self.n_reads, self.n_entries = ctx, h, n_taxa, n_reads, n_entries
+
+    def iterate(self, f: np.ndarray):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        part = np.zeros(self.n_taxa, dtype=np.float64)
+        ll = C.c_double()
+        self.ctx.check(lib().mm_em_iterate(self.h, _ptr(f), _ptr(part), C.byref(ll)))
+        return part, ll.value
+
+    def iterate_allreduce(self, f: np.ndarray):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        nxt = np.zeros(self.n_taxa, dtype=np.float64)
+        ll = C.c_double()
+        self.ctx.check(lib().mm_em_iterate_allreduce(self.h, _ptr(f), _ptr(nxt), C.byref(ll)))
+        return nxt, ll.value
+
+    def posteriors(self, f: np.ndarray):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        post = np.zeros(self.n_entries, dtype=np.float64)
+        best = np.zeros(self.n_reads, dtype=np.int64)
+        self.ctx.check(lib().mm_em_posteriors(self.h, _ptr(f), _ptr(post), _ptr(best)))
+        return post, best
+
+    def close(self):
+        if self.h:
+            lib().mm_em_destroy(self.h)
+            self.h = None

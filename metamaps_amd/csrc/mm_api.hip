@@ -1,0 +1,387 @@
+// extern "C" surface of libmetamaps_hip.so (include/metamaps_hip.h).  Converts internal exceptions into
+// status codes + mm_last_error(); owns handle lifetimes.  No CPU fallback anywhere: without a gfx950
+// device mm_ctx_create fails and nothing else can be called.
+#include "mm_map.hpp"
+#include "mm_em.hpp"
+#include "mm_stats.hpp"
+#include "mm_synth.hpp"
+#include <new>
+
+namespace mm {
+void seqset_upload(mm_seqset* s);
+void seqset_fetch(mm_seqset* s, int64_t i, char* out, int64_t cap);
+}
+
+namespace {
+template <typename F>
+int guarded(mm_ctx* ctx, F&& f) {
+  try { f(); return MM_OK; }
+  catch (const mm::Error& e) { if (ctx) ctx->err = e.what(); return e.status; }
+  catch (const std::bad_alloc&) { if (ctx) ctx->err = "host allocation failed"; return MM_ERR_NOMEM; }
+  catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return MM_ERR_DEVICE; }
+}
+}  // namespace
+
+extern "C" {
+
+int mm_abi_version(void) { return MM_ABI_VERSION; }
+
+int mm_ctx_create(int device_id, mm_ctx** out) {
+  if (!out) return MM_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MM_ERR_DEVICE;   // no GPU: fail loudly, never fall back
+  if (device_id < 0 || device_id >= n) return MM_ERR_ARG;
+  mm_ctx* c = new (std::nothrow) mm_ctx;
+  if (!c) return MM_ERR_NOMEM;
+  c->device = device_id;
+  int st = guarded(c, [&] {
+    MM_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t p;
+    MM_HIP(hipGetDeviceProperties(&p, device_id));
+    MM_REQUIRE(std::string(p.gcnArchName).rfind("gfx950", 0) == 0, MM_ERR_DEVICE,
+               std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
+    c->cus = p.multiProcessorCount;
+    MM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  });
+  if (st != MM_OK) { delete c; return st; }
+  *out = c;
+  return MM_OK;
+}
+void mm_ctx_destroy(mm_ctx* ctx) {
+  if (!ctx) return;
+  mm::comm_destroy(ctx);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+const char* mm_last_error(const mm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int mm_ctx_device_info(mm_ctx* ctx, char* name, size_t name_cap, int* cus, uint64_t* hbm_total, uint64_t* hbm_free) {
+  if (!ctx) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
+    hipDeviceProp_t p;
+    MM_HIP(hipGetDeviceProperties(&p, ctx->device));
+    if (name && name_cap) { snprintf(name, name_cap, "%s (%s)", p.name, p.gcnArchName); }
+    if (cus) *cus = p.multiProcessorCount;
+    size_t f = 0, t = 0;
+    MM_HIP(hipMemGetInfo(&f, &t));
+    if (hbm_total) *hbm_total = t;
+    if (hbm_free) *hbm_free = f;
+  });
+}
+int mm_ctx_synchronize(mm_ctx* ctx) {
+  if (!ctx) return MM_ERR_ARG;
+  return guarded(ctx, [&] { MM_HIP(hipStreamSynchronize(ctx->stream)); });
+}
+void* mm_ctx_stream(mm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// ---- sequences ----------------------------------------------------------------------------------------
+int mm_seqset_create(mm_ctx* ctx, mm_seqset** out) {
+  if (!ctx || !out) return MM_ERR_ARG;
+  return guarded(ctx, [&] { auto* s = new mm_seqset; s->ctx = ctx; *out = s; });
+}
+void mm_seqset_destroy(mm_seqset* s) { delete s; }
+int mm_seqset_add(mm_seqset* s, const char* ascii, int64_t len) {
+  if (!s || (!ascii && len > 0) || len < 0) return MM_ERR_ARG;
+  return guarded(s->ctx, [&] {
+    MM_REQUIRE(!s->frozen, MM_ERR_STATE, "sequence set already uploaded");
+    s->staged.emplace_back(ascii ? ascii : "", (size_t)len);
+  });
+}
+int mm_seqset_upload(mm_seqset* s) {
+  if (!s) return MM_ERR_ARG;
+  return guarded(s->ctx, [&] { MM_HIP(hipSetDevice(s->ctx->device)); mm::seqset_upload(s); });
+}
+int64_t mm_seqset_count(const mm_seqset* s) { return s ? (s->frozen ? s->count() : (int64_t)s->staged.size()) : 0; }
+int64_t mm_seqset_total_bases(const mm_seqset* s) { return s ? s->total_bases : 0; }
+int mm_seqset_lengths(const mm_seqset* s, int32_t* len_out) {
+  if (!s || !len_out || !s->frozen) return MM_ERR_ARG;
+  memcpy(len_out, s->len.data(), s->len.size() * sizeof(int32_t));
+  return MM_OK;
+}
+int mm_seqset_fetch(mm_seqset* s, int64_t i, char* ascii_out, int64_t cap) {
+  if (!s || !ascii_out) return MM_ERR_ARG;
+  return guarded(s->ctx, [&] { mm::seqset_fetch(s, i, ascii_out, cap); });
+}
+
+int mm_synth_reference(mm_ctx* ctx, const mm_synth_ref_params* p, mm_seqset** out) {
+  if (!ctx || !p || !out) return MM_ERR_ARG;
+  return guarded(ctx, [&] { MM_HIP(hipSetDevice(ctx->device)); auto* s = new mm_seqset; s->ctx = ctx; try { mm::synth_reference(ctx, *p, s); } catch (...) { delete s; throw; } *out = s; });
+}
+int mm_synth_reads(mm_ctx* ctx, const mm_seqset* reference, const mm_synth_read_params* p, mm_seqset** out, int32_t* truth_genome) {
+  if (!ctx || !reference || !p || !out) return MM_ERR_ARG;
+  return guarded(ctx, [&] { MM_HIP(hipSetDevice(ctx->device)); auto* s = new mm_seqset; s->ctx = ctx; try { mm::synth_reads(ctx, reference, *p, s, truth_genome); } catch (...) { delete s; throw; } *out = s; });
+}
+
+// ---- minimizer tap ------------------------------------------------------------------------------------
+int mm_minimizers(mm_ctx* ctx, const mm_seqset* s, int k, int w, int64_t* offsets, uint32_t* hash, int32_t* wpos, int32_t* strand, int64_t cap) {
+  if (!ctx || !s) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
+    mm::MinimizerSet ms;
+    mm::run_minimizers(ctx, s, k, w, {}, false, ms);
+    if (offsets) for (size_t i = 0; i < ms.h_off.size(); ++i) offsets[i] = (int64_t)ms.h_off[i];
+    if (hash || wpos || strand) {
+      MM_REQUIRE(cap >= ms.total, MM_ERR_ARG, "output capacity too small");
+      auto h = ms.rec.to_host(ctx->stream, (size_t)ms.total);
+      for (int64_t i = 0; i < ms.total; ++i) {
+        if (hash) hash[i] = h[(size_t)i].hash;
+        if (wpos) wpos[i] = mm::pw_wpos(h[(size_t)i].pw);
+        if (strand) strand[i] = mm::pw_strand(h[(size_t)i].pw);
+      }
+    }
+  });
+}
+
+// ---- index --------------------------------------------------------------------------------------------
+int mm_index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index** out) {
+  if (!ctx || !contigs || !out) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
+    auto* I = new mm_index;
+    try { mm::index_build(ctx, contigs, k, w, I); } catch (...) { delete I; throw; }
+    *out = I;
+  });
+}
+void mm_index_destroy(mm_index* idx) { delete idx; }
+int mm_index_get_info(const mm_index* idx, mm_index_info* out) {
+  if (!idx || !out) return MM_ERR_ARG;
+  out->n_contigs = idx->n_contigs; out->n_entries = idx->N; out->n_unique_hashes = idx->U; out->n_dup_flagged = idx->n_dup;
+  out->hbm_bytes = idx->hbm_bytes();
+  return MM_OK;
+}
+int mm_index_freq_hist(mm_index* idx, int64_t* counts, int64_t* n_hashes, int64_t cap, int64_t* n_out) {
+  if (!idx || !n_out) return MM_ERR_ARG;
+  *n_out = (int64_t)idx->hist.size();
+  if (!counts || !n_hashes) return MM_OK;
+  if (cap < *n_out) return MM_ERR_ARG;
+  int64_t i = 0;
+  for (auto& kv : idx->hist) { counts[i] = kv.first; n_hashes[i] = kv.second; ++i; }
+  return MM_OK;
+}
+// winSketch.hpp:452-494 on an accumulated histogram.  `prev_threshold` is the threshold left by the previous
+// chunk (INT_MAX for the first): the reference keeps the old value when the loop breaks before assigning.
+int mm_freq_threshold_from_hist(const int64_t* counts, const int64_t* n_hashes, int64_t n, int64_t n_unique_hashes, int prev_threshold) {
+  int thr = prev_threshold;
+  if (n_unique_hashes <= 0) return thr;                        // :456 — empty lookup: nothing happens
+  float pct = 0.001f;                                          // :91
+  int64_t ignore = n_unique_hashes * pct / 100;                // :466 float arithmetic, truncated
+  int64_t sum = 0;
+  for (int64_t i = n - 1; i >= 0; --i) {                       // most frequent first
+    sum += n_hashes[i];
+    if (sum < ignore) thr = (int)counts[i];
+    else if (sum == ignore) { thr = (int)counts[i]; break; }
+    else break;
+  }
+  return thr;
+}
+int mm_index_set_freq_threshold(mm_index* idx, int threshold) {
+  if (!idx) return MM_ERR_ARG;
+  idx->freq_threshold = threshold;
+  return MM_OK;
+}
+int mm_index_entries(mm_index* idx, uint32_t* hash, int32_t* contig, int32_t* wpos, int32_t* strand, int64_t cap) {
+  if (!idx) return MM_ERR_ARG;
+  return guarded(idx->ctx, [&] {
+    MM_REQUIRE(cap >= idx->N, MM_ERR_ARG, "output capacity too small");
+    auto h = idx->pos.to_host(idx->ctx->stream, (size_t)idx->N);
+    int64_t c = 0;
+    for (int64_t i = 0; i < idx->N; ++i) {
+      while (c + 1 < (int64_t)idx->h_cstart.size() && (uint64_t)i >= idx->h_cstart[(size_t)c + 1]) ++c;
+      if (hash) hash[i] = h[(size_t)i].hash;
+      if (contig) contig[i] = (int32_t)c;
+      if (wpos) wpos[i] = mm::pw_wpos(h[(size_t)i].pw);
+      if (strand) strand[i] = mm::pw_strand(h[(size_t)i].pw);
+    }
+  });
+}
+
+// ---- statistics ---------------------------------------------------------------------------------------
+int mm_recommended_window(double p_value, int k, float pi, int min_read_len, uint64_t reference_size) {
+  return mm::stats::recommended_window(p_value, k, 4, pi, min_read_len, reference_size);
+}
+double mm_estimate_pvalue(int s, int k, float pi, int min_read_len, uint64_t reference_size) {
+  return mm::stats::estimate_pvalue(s, k, 4, pi, min_read_len, reference_size);
+}
+int mm_min_hits_relaxed(int s, int k, float pi) { return mm::stats::min_hits_relaxed(s, k, pi); }
+void mm_identity(int shared, int s, int k, float* ident, float* ident_upper) {
+  float a, b;
+  mm::stats::identity(shared, s, k, &a, &b);
+  if (ident) *ident = a;
+  if (ident_upper) *ident_upper = b;
+}
+
+// ---- mapping ------------------------------------------------------------------------------------------
+int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, mm_mapping** out) {
+  if (!ctx || !idx || !reads || !p || !out) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
+    auto* M = new mm_mapping;
+    try { mm::map_batch(ctx, idx, reads, *p, M); } catch (...) { delete M; throw; }
+    *out = M;
+  });
+}
+void mm_mapping_destroy(mm_mapping* m) { delete m; }
+int mm_mapping_get_stats(const mm_mapping* m, mm_map_stats* out) {
+  if (!m || !out) return MM_ERR_ARG;
+  *out = m->stats;
+  return MM_OK;
+}
+int mm_mapping_fetch(mm_mapping* m, int64_t* offsets, mm_map_record* records, int64_t cap) {
+  if (!m) return MM_ERR_ARG;
+  return guarded(m->ctx, [&] {
+    if (offsets) for (size_t i = 0; i < m->h_rec_off.size(); ++i) offsets[i] = (int64_t)m->h_rec_off[i];
+    if (records) {
+      MM_REQUIRE(cap >= m->n_rec, MM_ERR_ARG, "output capacity too small");
+      m->rec.download(records, (size_t)m->n_rec, m->ctx->stream);
+      MM_HIP(hipStreamSynchronize(m->ctx->stream));
+    }
+  });
+}
+int mm_mapping_add_qualities(mm_ctx* ctx, mm_mapping* m, const mm_seqset* reads, int k) {
+  if (!ctx || !m) return MM_ERR_ARG;
+  (void)reads;
+  return guarded(ctx, [&] { MM_HIP(hipSetDevice(ctx->device)); mm::mapping_add_qualities(ctx, m, k); });
+}
+int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* contig_base, int n_parts, mm_mapping** out) {
+  if (!ctx || !parts || n_parts <= 0 || !out) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    // read-wise concatenation in chunk order (unifyFiles, mapWrap.h:128-132); small, done on the host
+    const int64_t n = parts[0]->n_reads;
+    std::vector<std::vector<mm_map_record>> recs((size_t)n_parts);
+    for (int p = 0; p < n_parts; ++p) {
+      MM_REQUIRE(parts[p]->n_reads == n, MM_ERR_ARG, "chunk results cover different read sets");
+      recs[(size_t)p].resize((size_t)parts[p]->n_rec);
+      parts[p]->rec.download(recs[(size_t)p].data(), (size_t)parts[p]->n_rec, ctx->stream);
+    }
+    MM_HIP(hipStreamSynchronize(ctx->stream));
+    auto* M = new mm_mapping;
+    M->ctx = ctx; M->n_reads = n; M->params = parts[0]->params; M->read_len = parts[0]->read_len; M->active = parts[0]->active;
+    M->stats = parts[0]->stats;
+    std::vector<mm_map_record> all; std::vector<uint64_t> off((size_t)n + 1, 0);
+    for (int64_t r = 0; r < n; ++r) {
+      for (int p = 0; p < n_parts; ++p)
+        for (uint64_t i = parts[p]->h_rec_off[(size_t)r]; i < parts[p]->h_rec_off[(size_t)r + 1]; ++i) {
+          mm_map_record x = recs[(size_t)p][(size_t)i];
+          x.ref_contig += contig_base ? contig_base[p] : 0;
+          all.push_back(x);
+        }
+      off[(size_t)r + 1] = all.size();
+    }
+    M->n_rec = (int64_t)all.size();
+    M->rec.alloc(std::max<size_t>(all.size(), 1)); M->rec.upload(all.data(), all.size(), ctx->stream);
+    M->rec_off.alloc((size_t)n + 1); M->rec_off.upload(off.data(), off.size(), ctx->stream);
+    M->d_read_len.alloc((size_t)std::max<int64_t>(n, 1)); M->d_read_len.upload(M->read_len.data(), (size_t)n, ctx->stream);
+    M->h_rec_off = off;
+    M->stats.n_mappings = M->n_rec; M->stats.n_reads_mapped = 0;
+    for (int64_t r = 0; r < n; ++r) if (off[(size_t)r + 1] > off[(size_t)r]) M->stats.n_reads_mapped++;
+    for (int p = 1; p < n_parts; ++p) {
+      M->stats.sum_hits += parts[p]->stats.sum_hits; M->stats.n_candidates += parts[p]->stats.n_candidates;
+      M->stats.sum_l2_stream_entries += parts[p]->stats.sum_l2_stream_entries; M->stats.sum_l2_evals += parts[p]->stats.sum_l2_evals;
+    }
+    MM_HIP(hipStreamSynchronize(ctx->stream));
+    *out = M;
+  });
+}
+
+int mm_debug_sketch(mm_mapping* m, int64_t* offsets, uint32_t* hash, int32_t* strand, int64_t cap) {
+  if (!m) return MM_ERR_ARG;
+  return guarded(m->ctx, [&] {
+    hipStream_t st = m->ctx->stream;
+    int64_t tot = 0;
+    for (int64_t r = 0; r < m->n_reads; ++r) { if (offsets) offsets[r] = tot; tot += m->h_sk_n[(size_t)r]; }
+    if (offsets) offsets[m->n_reads] = tot;
+    if (!hash && !strand) return;
+    MM_REQUIRE(cap >= tot, MM_ERR_ARG, "output capacity too small");
+    auto hh = m->sk_hash.to_host(st); auto hs = m->sk_strand.to_host(st);
+    int64_t o = 0;
+    for (int64_t r = 0; r < m->n_reads; ++r)
+      for (int i = 0; i < m->h_sk_n[(size_t)r]; ++i, ++o) {
+        size_t src = (size_t)m->mz.h_off[(size_t)r] + (size_t)i;
+        if (hash) hash[o] = hh[src];
+        if (strand) strand[o] = hs[src] ? 1 : -1;
+      }
+  });
+}
+int mm_debug_hits(mm_mapping* m, int64_t* offsets, int32_t* contig, int32_t* wpos, int64_t cap) {
+  if (!m) return MM_ERR_ARG;
+  return guarded(m->ctx, [&] {
+    const int64_t tot = (int64_t)m->h_read_hit_off[(size_t)m->n_reads];
+    if (offsets) for (size_t i = 0; i < m->h_read_hit_off.size(); ++i) offsets[i] = (int64_t)m->h_read_hit_off[i];
+    if (!contig && !wpos) return;
+    MM_REQUIRE(cap >= tot, MM_ERR_ARG, "output capacity too small");
+    auto h = m->hits.to_host(m->ctx->stream, (size_t)tot);
+    for (int64_t i = 0; i < tot; ++i) {
+      if (contig) contig[i] = (int32_t)(h[(size_t)i] >> 32);
+      if (wpos) wpos[i] = mm::pw_wpos((uint32_t)h[(size_t)i]);
+    }
+  });
+}
+int mm_debug_candidates(mm_mapping* m, int64_t* offsets, int32_t* triples, int64_t cap) {
+  if (!m) return MM_ERR_ARG;
+  return guarded(m->ctx, [&] {
+    if (offsets) for (size_t i = 0; i < m->h_cand_off.size(); ++i) offsets[i] = (int64_t)m->h_cand_off[i];
+    if (!triples) return;
+    MM_REQUIRE(cap >= m->n_cand, MM_ERR_ARG, "output capacity too small");
+    m->cand.download(triples, (size_t)(3 * m->n_cand), m->ctx->stream);
+    MM_HIP(hipStreamSynchronize(m->ctx->stream));
+  });
+}
+int mm_debug_l2(mm_mapping* m, int64_t* per_cand, int64_t cap) {
+  if (!m || !per_cand) return MM_ERR_ARG;
+  return guarded(m->ctx, [&] {
+    MM_REQUIRE(cap >= m->n_cand, MM_ERR_ARG, "output capacity too small");
+    auto h = m->l2.to_host(m->ctx->stream, (size_t)m->n_cand);
+    for (int64_t i = 0; i < m->n_cand; ++i) {
+      per_cand[5 * i] = h[(size_t)i].contig; per_cand[5 * i + 1] = h[(size_t)i].mean_pos; per_cand[5 * i + 2] = h[(size_t)i].shared;
+      per_cand[5 * i + 3] = h[(size_t)i].opt_beg; per_cand[5 * i + 4] = h[(size_t)i].opt_end;
+    }
+  });
+}
+int mm_debug_min_hits(mm_mapping* m, int32_t* min_hits) {
+  if (!m || !min_hits) return MM_ERR_ARG;
+  memcpy(min_hits, m->h_min_hits.data(), m->h_min_hits.size() * sizeof(int32_t));
+  return MM_OK;
+}
+
+// ---- EM -----------------------------------------------------------------------------------------------
+int mm_em_create(mm_ctx* ctx, int64_t n_reads, const int64_t* read_off, const int32_t* taxon, const double* mapq, const double* inv_nloc,
+                 int32_t n_taxa, mm_em** out) {
+  if (!ctx || !read_off || !out || n_reads < 0 || n_taxa <= 0) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
+    auto* E = new mm_em;
+    try { mm::em_create(ctx, n_reads, read_off, taxon, mapq, inv_nloc, n_taxa, E); } catch (...) { delete E; throw; }
+    *out = E;
+  });
+}
+void mm_em_destroy(mm_em* em) { delete em; }
+int mm_em_iterate(mm_em* em, const double* f, double* f_partial, double* ll_partial) {
+  if (!em || !f || !f_partial || !ll_partial) return MM_ERR_ARG;
+  return guarded(em->ctx, [&] { MM_HIP(hipSetDevice(em->ctx->device)); mm::em_iterate(em, f, f_partial, ll_partial); });
+}
+int mm_em_iterate_allreduce(mm_em* em, const double* f, double* f_next, double* ll) {
+  if (!em || !f || !f_next || !ll) return MM_ERR_ARG;
+  return guarded(em->ctx, [&] { MM_HIP(hipSetDevice(em->ctx->device)); mm::em_iterate_allreduce(em, f, f_next, ll); });
+}
+int mm_em_posteriors(mm_em* em, const double* f, double* post, int64_t* best) {
+  if (!em || !f) return MM_ERR_ARG;
+  return guarded(em->ctx, [&] { MM_HIP(hipSetDevice(em->ctx->device)); mm::em_posteriors(em, f, post, best); });
+}
+
+// ---- communicator -------------------------------------------------------------------------------------
+int mm_comm_unique_id(char id[MM_COMM_ID_BYTES]) {
+  if (!id) return MM_ERR_ARG;
+  return guarded(nullptr, [&] { mm::comm_unique_id(id); });
+}
+int mm_comm_init(mm_ctx* ctx, const char id[MM_COMM_ID_BYTES], int rank, int nranks) {
+  if (!ctx || !id || rank < 0 || rank >= nranks) return MM_ERR_ARG;
+  return guarded(ctx, [&] { mm::comm_init(ctx, id, rank, nranks); });
+}
+int mm_comm_allreduce_f64(mm_ctx* ctx, double* host_inout, int64_t n) {
+  if (!ctx || (!host_inout && n > 0)) return MM_ERR_ARG;
+  return guarded(ctx, [&] { MM_HIP(hipSetDevice(ctx->device)); mm::comm_allreduce_f64(ctx, host_inout, n); });
+}
+void mm_comm_destroy(mm_ctx* ctx) { if (ctx) mm::comm_destroy(ctx); }
+
+}  // extern "C"

@@ -1,0 +1,26 @@
+// EM state resident in HBM: mappings grouped by read (E step) and indexed by taxon (M step).
+#pragma once
+#include "mm_common.hpp"
+
+struct mm_em {
+  mm_ctx* ctx = nullptr;
+  int64_t n_reads = 0, n_entries = 0;
+  int32_t n_taxa = 0;
+  mm::DBuf<int64_t> read_off;      // [n_reads+1]
+  mm::DBuf<int32_t> taxon;         // [n_entries]
+  mm::DBuf<double> mapq, inv_nloc; // [n_entries]
+  mm::DBuf<int64_t> tstart, perm;  // CSR by taxon: entries of taxon t are perm[tstart[t]..tstart[t+1]) in read order
+  mm::DBuf<double> post, ll_read, f, partial, block_sum;
+};
+
+namespace mm {
+void em_create(mm_ctx* ctx, int64_t n_reads, const int64_t* read_off, const int32_t* taxon, const double* mapq, const double* inv_nloc,
+               int32_t n_taxa, mm_em* E);
+void em_iterate(mm_em* E, const double* f, double* f_partial, double* ll_partial);
+void em_iterate_allreduce(mm_em* E, const double* f, double* f_next, double* ll);
+void em_posteriors(mm_em* E, const double* f, double* post, int64_t* best);
+void comm_unique_id(char* id);
+void comm_init(mm_ctx* ctx, const char* id, int rank, int nranks);
+void comm_allreduce_f64(mm_ctx* ctx, double* host, int64_t n);
+void comm_destroy(mm_ctx* ctx);
+}

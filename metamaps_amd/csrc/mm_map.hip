@@ -1,0 +1,550 @@
+// Per-batch mapping pipeline on the device (replaces Map::mapModule → mapSingleQuerySeq → doL1Mapping /
+// doL2Mapping, computeMap.hpp:180-538, for a whole batch of reads; output order == input order, which is
+// all the reference's ThreadPool guarantees, ThreadPool.hpp:13-17).
+//
+//   K1  minimizer sweep of the reads                         mm_minimizer.hpp
+//   K2  sketch = sort by hash + unique                       computeMap.hpp:292-298
+//   K3  index probe + seed-hit gather                        computeMap.hpp:307-323
+//   K4  hit sort + L1 candidate scan                         computeMap.hpp:346-386
+//   K5  L2 sliding MinHash window + K6 strand vote           computeMap.hpp:460-538, slidingMap.hpp
+//   K7  identity filter: a per-sketch-size integer threshold computed on the host (mm_stats.hpp)
+#include "mm_map.hpp"
+#include "mm_l2_core.hpp"
+#include "mm_stats.hpp"
+#include <algorithm>
+#include <numeric>
+
+namespace mm {
+
+// ---------------------------------------------------------------------------------------------------
+// workgroup bitonic sort of 64-bit keys (n a power of two), data in LDS or global memory
+// ---------------------------------------------------------------------------------------------------
+__device__ inline void bitonic_sort_u64(uint64_t* a, int n) {
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
+        int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        int p = i | j;
+        uint64_t x = a[i], y = a[p];
+        bool up = (i & k) == 0;
+        if ((x > y) == up) { a[i] = y; a[p] = x; }
+      }
+      __syncthreads();
+    }
+  }
+}
+static inline int pow2_at_least(int64_t n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+// ---------------------------------------------------------------------------------------------------
+// K2  sketch: one workgroup per read
+// ---------------------------------------------------------------------------------------------------
+template <bool IN_LDS>
+__global__ void __launch_bounds__(256) sketch_kernel(const Rec* __restrict__ rec, const uint64_t* __restrict__ off,
+                                                     const int32_t* __restrict__ read_list, int npow2, uint64_t* __restrict__ gscratch,
+                                                     uint32_t* __restrict__ sk_hash, uint8_t* __restrict__ sk_strand,
+                                                     int32_t* __restrict__ sk_n, uint8_t* __restrict__ amb) {
+  extern __shared__ __align__(16) uint64_t skeys[];
+  const int r = read_list[blockIdx.x];
+  const uint64_t o = off[r];
+  const int n = (int)(off[r + 1] - o);
+  uint64_t* a = IN_LDS ? skeys : gscratch + (size_t)blockIdx.x * npow2;
+  for (int i = threadIdx.x; i < npow2; i += 256) a[i] = i < n ? (((uint64_t)rec[o + i].hash << 32) | (uint32_t)i) : ~0ull;
+  __syncthreads();
+  bitonic_sort_u64(a, npow2);
+  __shared__ int s_amb;
+  if (threadIdx.x == 0) s_amb = 0;
+  __syncthreads();
+  uint64_t carry = 0;
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + threadIdx.x;
+    bool first = false; uint32_t h = 0; uint32_t st = 0;
+    if (i < n) {
+      uint64_t key = a[i];
+      h = (uint32_t)(key >> 32);
+      st = rec[o + (uint32_t)key].pw & PW_STRAND;
+      if (i == 0) first = true;
+      else {
+        uint64_t pk = a[i - 1];
+        first = (uint32_t)(pk >> 32) != h;
+        if (!first && (rec[o + (uint32_t)pk].pw & PW_STRAND) != st) s_amb = 1;   // same hash, different strands
+      }
+    }
+    uint64_t tot;
+    uint64_t ex = block_excl_scan_u64(first ? 1 : 0, &tot);
+    if (first) { sk_hash[o + carry + ex] = h; sk_strand[o + carry + ex] = (uint8_t)st; }
+    carry += tot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { sk_n[r] = (int32_t)carry; amb[r] = (uint8_t)s_amb; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3  probe (one workgroup per read) and gather
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) probe_kernel(IndexView I, const uint32_t* __restrict__ sk_hash, const uint64_t* __restrict__ off,
+                                                    const int32_t* __restrict__ sk_n, uint32_t* __restrict__ probe_cnt,
+                                                    uint64_t* __restrict__ probe_start) {
+  const int r = blockIdx.x;
+  const uint64_t o = off[r];
+  const int s = sk_n[r];
+  for (int i = threadIdx.x; i < s; i += 256) {
+    int64_t slot = index_find(I, sk_hash[o + i]);
+    uint32_t c = 0; uint64_t st = 0;
+    if (slot >= 0) {
+      st = I.ustart[slot];
+      uint64_t cnt = I.ustart[slot + 1] - st;
+      if (cnt < (uint64_t)(int64_t)I.freq_threshold) c = (uint32_t)cnt;   // computeMap.hpp:317
+    }
+    probe_cnt[o + i] = c;
+    probe_start[o + i] = st;
+  }
+}
+
+__global__ void __launch_bounds__(256) gather_hits_kernel(IndexView I, const uint64_t* __restrict__ off, const int32_t* __restrict__ sk_n,
+                                                          const uint32_t* __restrict__ probe_cnt, const uint64_t* __restrict__ probe_start,
+                                                          const uint64_t* __restrict__ hit_off, uint64_t* __restrict__ hits) {
+  const int r = blockIdx.x;
+  const uint64_t o = off[r];
+  const int s = sk_n[r];
+  for (int i = threadIdx.x; i < s; i += 256) {
+    uint32_t c = probe_cnt[o + i];
+    if (!c) continue;
+    const uint64_t* src = I.occ + probe_start[o + i];
+    uint64_t* dst = hits + hit_off[o + i];
+    for (uint32_t j = 0; j < c; ++j) dst[j] = src[j] & ~(uint64_t)(PW_DP | PW_DN);
+  }
+}
+
+__global__ void read_hit_bounds_kernel(const uint64_t* __restrict__ off, const uint64_t* __restrict__ hit_off, int64_t n,
+                                       uint64_t* __restrict__ read_hit_off) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r <= n) read_hit_off[r] = hit_off[off[r]];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4a  sort the seed hits of each read by (contig, wpos)          computeMap.hpp:353
+// ---------------------------------------------------------------------------------------------------
+template <bool IN_LDS>
+__global__ void __launch_bounds__(256) sort_hits_kernel(uint64_t* __restrict__ hits, const uint64_t* __restrict__ read_hit_off,
+                                                        const int32_t* __restrict__ read_list, int npow2, uint64_t* __restrict__ gscratch) {
+  extern __shared__ __align__(16) uint64_t skeys[];
+  const int r = read_list[blockIdx.x];
+  const uint64_t o = read_hit_off[r];
+  const int n = (int)(read_hit_off[r + 1] - o);
+  uint64_t* a = IN_LDS ? skeys : gscratch + (size_t)blockIdx.x * npow2;
+  for (int i = threadIdx.x; i < npow2; i += 256) a[i] = i < n ? hits[o + i] : ~0ull;
+  __syncthreads();
+  bitonic_sort_u64(a, npow2);
+  for (int i = threadIdx.x; i < n; i += 256) hits[o + i] = a[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4b  L1 candidate scan, one thread per read, the reference's loop verbatim in behaviour
+//      (computeL1CandidateRegions, computeMap.hpp:346-386).  WRITE=false counts, WRITE=true writes.
+// ---------------------------------------------------------------------------------------------------
+template <bool WRITE>
+__global__ void l1_scan_kernel(const uint64_t* __restrict__ hits, const uint64_t* __restrict__ read_hit_off, const int32_t* __restrict__ read_len,
+                               const int32_t* __restrict__ min_hits, int64_t n_reads, uint32_t* __restrict__ cand_n,
+                               const uint64_t* __restrict__ cand_off, int32_t* __restrict__ cand, int32_t* __restrict__ cand_read) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  const uint64_t o = read_hit_off[r];
+  const int64_t H = (int64_t)(read_hit_off[r + 1] - o);
+  const int len = read_len[r];
+  int m = min_hits[r]; if (m < 1) m = 1;                         // :349
+  uint32_t nc = 0;
+  int lseq = -1, lstart = 0, lend = 0;
+  uint64_t wbase = WRITE ? cand_off[r] : 0;
+  auto flush = [&]() {
+    if (lseq < 0) return;
+    if (WRITE) { int32_t* c = cand + 3 * (wbase + nc); c[0] = lseq; c[1] = lstart; c[2] = lend; cand_read[wbase + nc] = (int32_t)r; }
+    ++nc;
+  };
+  for (int64_t i = 0; i + m <= H; ++i) {
+    uint64_t a = hits[o + i], b = hits[o + i + m - 1];
+    int sa = (int)(a >> 32), sb = (int)(b >> 32);
+    int wa = pw_wpos((uint32_t)a), wb = pw_wpos((uint32_t)b);
+    if (sa != sb || wb - wa >= len) continue;                    // :365
+    int cs = max(0, wb - len + 1), ce = wa;                      // :368
+    if (lseq == sa && lend >= cs) lend = max(ce, lend);          // :374-380
+    else { flush(); lseq = sa; lstart = cs; lend = ce; }
+  }
+  flush();
+  if (!WRITE) cand_n[r] = nc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5 + K6  one wavefront per L1 candidate
+// ---------------------------------------------------------------------------------------------------
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// wave-parallel: does any entry of pos[lo,hi) carry hash h?
+__device__ inline bool wave_has_hash(const Rec* __restrict__ pos, int64_t lo, int64_t hi, uint32_t h, int lane) {
+  for (int64_t base = lo; base < hi; base += 64) {               // `base` is wave-uniform
+    const int64_t j = base + lane;
+    const bool hit = (j < hi) && pos[j].hash == h;
+    if (__ballot(hit) != 0ull) return true;
+  }
+  return false;
+}
+
+__global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restrict__ cand_read,
+                                                const uint32_t* __restrict__ sk_hash, const uint8_t* __restrict__ sk_strand,
+                                                const uint64_t* __restrict__ mz_off, const int32_t* __restrict__ sk_n,
+                                                const int32_t* __restrict__ read_len, const int32_t* __restrict__ accept_min,
+                                                int k, int w, int smax, L2Result* __restrict__ out,
+                                                unsigned long long* __restrict__ counters /* [0]=stream entries, [1]=evaluations */) {
+  extern __shared__ __align__(16) uint32_t lds[];
+  uint32_t* Q = lds;
+  uint16_t* D = (uint16_t*)(Q + smax);
+  uint32_t* mt = (uint32_t*)(D + ((smax + 1) & ~1));
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  const int r = cand_read[c];
+  const int s = sk_n[r];
+  const uint64_t qo = mz_off[r];
+  const int len = read_len[r];
+  for (int i = lane; i < s; i += 64) { Q[i] = sk_hash[qo + i]; D[i] = 0; }
+  for (int i = lane; i < (s + 31) / 32; i += 64) mt[i] = 0;
+  __syncthreads();
+
+  const int contig = cand[3 * c], rs = cand[3 * c + 1], re = cand[3 * c + 2];
+  const int cnt = len - (w - 1) - (k - 1);                       // computeMap.hpp:470
+  const Rec* __restrict__ pos = I.pos;
+  const int64_t first = index_search(I, contig, rs);             // :466
+  const int64_t first_end = index_search(I, contig, pw_wpos(pos[first].pw) + cnt);   // :473
+  const int64_t last_end = index_search(I, contig, re + len);    // :477
+  const int64_t nmax = I.N - 1;
+
+  L2State S{Q, D, mt, s, 0, 0, 0};
+  l2_reset(S);
+
+  // register-resident chunks of 64 consecutive index entries at the two ends of the window
+  int64_t baseB = first, baseE = first;
+  Rec rb = pos[min(baseB + lane, nmax)], rE = rb;
+  int codeB = l2_classify(Q, s, rb.hash), codeE = codeB;
+  auto loadB = [&](int64_t nb) { baseB = nb; rb = pos[min(nb + lane, nmax)]; codeB = l2_classify(Q, s, rb.hash); };
+  auto loadE = [&](int64_t ne) { baseE = ne; rE = pos[min(ne + lane, nmax)]; codeE = l2_classify(Q, s, rE.hash); };
+
+  int64_t b = first, e = first;
+  auto add_entry = [&](int64_t x) {                              // slidingMap.hpp:139-160
+    if (x - baseE >= 64) loadE(x);
+    int ln = (int)(x - baseE);
+    uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)rE.hash, ln);
+    uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)rE.pw, ln);
+    int code = __builtin_amdgcn_readlane(codeE, ln);
+    if (code == -(s + 1)) return;                                // above every query hash: never counted
+    if ((pw & PW_DP) && wave_has_hash(pos, b, x, h, lane)) return;   // REV: hash already in the window
+    if (code >= 0) l2_add_matched(S, code); else l2_add_wonly(S, -code - 1);
+  };
+  auto del_entry = [&](int64_t x, int64_t wend) {                // slidingMap.hpp:170-214
+    int ln = (int)(x - baseB);
+    uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)rb.hash, ln);
+    uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)rb.pw, ln);
+    int code = __builtin_amdgcn_readlane(codeB, ln);
+    if (code == -(s + 1)) return;
+    if ((pw & PW_DN) && wave_has_hash(pos, x + 1, wend, h, lane)) return;   // NOOP: a later occurrence stays
+    if (code >= 0) l2_del_matched(S, code); else l2_del_wonly(S, -code - 1);
+  };
+
+  for (; e < first_end; ++e) add_entry(e);                       // first super-window, :489
+
+  int wpos_b = pw_wpos(pos[first].pw);
+  int sw_pos = wpos_b;                                           // MIIteratorL2.hpp:62
+  int best = 0, bestR = 0, beg_pos = 0, last_pos = 0;
+  int64_t opt_b = 0, opt_e = 0;
+  unsigned long long evals = 0;
+  while (e < last_end) {                                         // :496
+    if (b + 1 - baseB >= 64) loadB(b);
+    if (e - baseE >= 64) loadE(e);
+    const int cur_wb = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rb.pw, (int)(b - baseB)));
+    if (S.shared > best) { best = S.shared; bestR = S.R; opt_b = b; opt_e = e; beg_pos = last_pos = cur_wb; }   // :510-518
+    else if (S.shared == best) last_pos = cur_wb;                // :520-524
+    ++evals;
+    // MIIteratorL2::next, MIIteratorL2.hpp:74-96
+    const int wb1 = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rb.pw, (int)(b + 1 - baseB)));
+    const int we = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rE.pw, (int)(e - baseE)));
+    const int d_beg = wb1 - sw_pos, d_end = we - (sw_pos + cnt - 1);
+    const int adv = min(d_beg, d_end);
+    sw_pos += adv;
+    if (adv == d_beg) { del_entry(b, e); ++b; }
+    if (adv == d_end) { add_entry(e); ++e; }
+  }
+
+  // K6 strand vote over the first optimal window (computeMap.hpp:424-433, slidingMap.hpp:232-254):
+  // sum over query ranks below the pivot that are present in the window of strandQ * strandR, where
+  // strandR comes from the LAST occurrence of the hash in the window (insert_ref overwrites, :155-156).
+  int amin = accept_min[r]; if (amin < 1) amin = 1;
+  int strand = -1, accepted = 0;
+  if (best >= amin) {
+    accepted = 1;
+    int votes = 0;
+    for (int64_t j = opt_b + lane; j < opt_e; j += 64) {
+      Rec x = pos[j];
+      int code = l2_classify(Q, s, x.hash);
+      if (code >= 0 && code < bestR) {
+        bool later = false;
+        if (x.pw & PW_DN) for (int64_t t = j + 1; t < opt_e; ++t) if (pos[t].hash == x.hash) { later = true; break; }
+        if (!later) votes += (sk_strand[qo + code] ? 1 : -1) * pw_strand(x.pw);
+      }
+    }
+    for (int d = 32; d > 0; d >>= 1) votes += __shfl_xor(votes, d, 64);
+    strand = votes > 0 ? 1 : -1;
+  }
+  if (lane == 0) {
+    L2Result o;
+    o.contig = contig; o.mean_pos = (beg_pos + last_pos) / 2;    // :537
+    o.shared = best; o.strand = strand; o.accepted = accepted; o.pad = 0;
+    o.opt_beg = opt_b; o.opt_end = opt_e;
+    out[c] = o;
+    atomicAdd(&counters[0], (unsigned long long)(last_end - first));
+    atomicAdd(&counters[1], evals);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// result compaction: accepted candidates -> mapping records, read order preserved
+// ---------------------------------------------------------------------------------------------------
+__global__ void accept_flags_kernel(const L2Result* __restrict__ l2, int64_t n, uint32_t* __restrict__ flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = l2[i].accepted ? 1u : 0u;
+}
+__global__ void write_records_kernel(const L2Result* __restrict__ l2, const int32_t* __restrict__ cand_read, const int32_t* __restrict__ sk_n,
+                                     const uint32_t* __restrict__ flag, const uint64_t* __restrict__ rank, int64_t n,
+                                     mm_map_record* __restrict__ rec) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  mm_map_record m;
+  m.read = cand_read[i]; m.ref_contig = l2[i].contig; m.ref_start = l2[i].mean_pos; m.shared = l2[i].shared;
+  m.sketch = sk_n[m.read]; m.strand = l2[i].strand; m.mapq = 0.0;
+  rec[rank[i]] = m;
+}
+__global__ void read_rec_bounds_kernel(const uint64_t* __restrict__ cand_off, const uint64_t* __restrict__ rank, int64_t n_reads,
+                                       uint64_t* __restrict__ rec_off) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r <= n_reads) rec_off[r] = rank[cand_off[r]];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct SizeClass { int npow2; std::vector<int32_t> reads; };
+
+// reads grouped by power-of-two capacity; entries beyond lds_cap elements use the global-memory variant
+std::vector<SizeClass> make_classes(const std::vector<int64_t>& count, int min_pow2) {
+  std::map<int, std::vector<int32_t>> m;
+  for (size_t r = 0; r < count.size(); ++r) {
+    if (count[r] <= 1) continue;                                // nothing to sort
+    m[std::max(min_pow2, pow2_at_least(count[r]))].push_back((int32_t)r);
+  }
+  std::vector<SizeClass> v;
+  for (auto& kv : m) v.push_back(SizeClass{kv.first, std::move(kv.second)});
+  return v;
+}
+constexpr int LDS_SORT_MAX = 16384;     // 128 KiB of 64-bit keys
+
+struct HostMz { uint32_t hash; int32_t wpos, strand; };
+static bool host_less_by_hash(const HostMz& a, const HostMz& b) { return a.hash < b.hash; }   // base_types.hpp:70
+static bool host_eq_by_hash(const HostMz& a, const HostMz& b) { return a.hash == b.hash; }    // base_types.hpp:66
+}  // namespace
+
+void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_map_params& P, mm_mapping* M) {
+  hipStream_t st = ctx->stream;
+  MM_REQUIRE(I->k == P.k && I->w == P.w, MM_ERR_ARG, "index was built with different k / window size");
+  const int64_t n = reads->count();
+  MM_REQUIRE(n < (1LL << 31), MM_ERR_LIMIT, "more than 2^31 reads in one batch");
+  M->ctx = ctx; M->n_reads = n; M->params = P; M->stats = mm_map_stats{};
+  M->stats.n_reads = n;
+  M->read_len = reads->len;
+  M->active.assign((size_t)n, 0);
+  for (int64_t r = 0; r < n; ++r) {
+    int L = reads->len[(size_t)r];
+    bool ok = !(L < P.w || L < P.k || L < P.min_read_len);      // computeMap.hpp:137
+    M->active[(size_t)r] = ok;
+    if (ok) { M->stats.n_reads_long_enough++; M->stats.bases_long_enough += L; }
+  }
+  // ---- K1
+  run_minimizers(ctx, reads, P.k, P.w, M->active, false, M->mz);
+  const int64_t total_mz = M->mz.total;
+  const std::vector<uint64_t>& hoff = M->mz.h_off;
+  M->sk_hash.alloc((size_t)std::max<int64_t>(total_mz, 1));
+  M->sk_strand.alloc((size_t)std::max<int64_t>(total_mz, 1));
+  M->sk_n.alloc((size_t)std::max<int64_t>(n, 1)); M->sk_n.zero(st);
+  M->amb.alloc((size_t)std::max<int64_t>(n, 1)); M->amb.zero(st);
+  // ---- K2
+  {
+    std::vector<int64_t> cnt((size_t)n);
+    for (int64_t r = 0; r < n; ++r) cnt[(size_t)r] = (int64_t)(hoff[(size_t)r + 1] - hoff[(size_t)r]);
+    // single-element lists are "sorted" already but still need their sketch written: force class >= 2 by min count 1
+    for (auto& c : cnt) if (c == 1) c = 2;
+    for (auto& cls : make_classes(cnt, 256)) {
+      DBuf<int32_t> list(cls.reads.size());
+      list.upload(cls.reads.data(), cls.reads.size(), st);
+      if (cls.npow2 <= LDS_SORT_MAX) {
+        size_t lds = (size_t)cls.npow2 * 8;
+        if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)sketch_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        sketch_kernel<true><<<dim3((unsigned)cls.reads.size()), dim3(256), lds, st>>>(M->mz.rec.p, M->mz.off.p, list.p, cls.npow2, nullptr,
+                                                                                     M->sk_hash.p, M->sk_strand.p, M->sk_n.p, M->amb.p);
+        MM_KERNEL_CHECK();
+      } else {
+        DBuf<uint64_t> scratch((size_t)cls.npow2 * cls.reads.size());
+        sketch_kernel<false><<<dim3((unsigned)cls.reads.size()), dim3(256), 0, st>>>(M->mz.rec.p, M->mz.off.p, list.p, cls.npow2, scratch.p,
+                                                                                    M->sk_hash.p, M->sk_strand.p, M->sk_n.p, M->amb.p);
+        MM_KERNEL_CHECK();
+        MM_HIP(hipStreamSynchronize(st));
+      }
+      MM_HIP(hipStreamSynchronize(st));                          // `list` must outlive the launch
+    }
+  }
+  M->h_sk_n = M->sk_n.to_host(st, (size_t)n);
+  std::vector<uint8_t> h_amb = M->amb.to_host(st, (size_t)n);
+  // ---- duplicate-hash strand tie-break (computeMap.hpp:292-295: std::sort is not stable, std::unique keeps
+  //      whichever equal-hash element introsort left first).  Only the strand of the survivor is observable
+  //      (slidingMap.hpp:247), so it is resolved here with the same library calls on the same input order.
+  for (int64_t r = 0; r < n; ++r) {
+    if (!h_amb[(size_t)r]) continue;
+    M->stats.n_ambiguous_sketch_reads++;
+    const uint64_t o = hoff[(size_t)r]; const size_t cntr = (size_t)(hoff[(size_t)r + 1] - o);
+    std::vector<Rec> hr(cntr);
+    M->mz.rec.download(hr.data(), cntr, st, (size_t)o);
+    MM_HIP(hipStreamSynchronize(st));
+    std::vector<HostMz> v(cntr);
+    for (size_t i = 0; i < cntr; ++i) v[i] = HostMz{hr[i].hash, pw_wpos(hr[i].pw), pw_strand(hr[i].pw)};
+    std::sort(v.begin(), v.end(), host_less_by_hash);
+    auto ue = std::unique(v.begin(), v.end(), host_eq_by_hash);
+    size_t s = (size_t)(ue - v.begin());
+    MM_REQUIRE((int64_t)s == M->h_sk_n[(size_t)r], MM_ERR_DEVICE, "sketch size disagrees between device and host tie-break");
+    std::vector<uint8_t> sv(s);
+    for (size_t i = 0; i < s; ++i) sv[i] = v[i].strand == 1 ? 1 : 0;
+    MM_HIP(hipMemcpyAsync(M->sk_strand.p + o, sv.data(), s, hipMemcpyHostToDevice, st));
+    MM_HIP(hipStreamSynchronize(st));
+  }
+  // ---- K7 host thresholds per distinct sketch size
+  {
+    stats::LutCache lut(P.k, P.perc_identity);
+    std::vector<int32_t> mh((size_t)n, 0), am((size_t)n, 0);
+    int smax = 0;
+    for (int64_t r = 0; r < n; ++r) {
+      int s = M->h_sk_n[(size_t)r];
+      if (s <= 0) continue;
+      auto L = lut.get(s);
+      mh[(size_t)r] = L.min_hits; am[(size_t)r] = L.accept_min;
+      smax = std::max(smax, s);
+      M->stats.sum_sketch += s;
+    }
+    M->smax = smax;
+    M->min_hits.alloc((size_t)std::max<int64_t>(n, 1)); M->min_hits.upload(mh.data(), (size_t)n, st);
+    M->accept_min.alloc((size_t)std::max<int64_t>(n, 1)); M->accept_min.upload(am.data(), (size_t)n, st);
+    M->h_min_hits = mh;
+    MM_HIP(hipStreamSynchronize(st));
+  }
+  M->d_read_len.alloc((size_t)std::max<int64_t>(n, 1));
+  M->d_read_len.upload(reads->len.data(), (size_t)n, st);
+  IndexView IV = make_view(I);
+  // ---- K3
+  DBuf<uint32_t> probe_cnt((size_t)total_mz + 1); probe_cnt.zero(st);
+  DBuf<uint64_t> probe_start((size_t)total_mz + 1);
+  DBuf<uint64_t> hit_off((size_t)total_mz + 2), scan_tmp;
+  if (n > 0 && total_mz > 0) {
+    probe_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p);
+    MM_KERNEL_CHECK();
+  }
+  exclusive_scan_u32_u64(probe_cnt.p, total_mz, hit_off.p, scan_tmp, st);
+  M->read_hit_off.alloc((size_t)n + 1);
+  read_hit_bounds_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(M->mz.off.p, hit_off.p, n, M->read_hit_off.p);
+  MM_KERNEL_CHECK();
+  M->h_read_hit_off = M->read_hit_off.to_host(st);
+  const int64_t total_hits = (int64_t)M->h_read_hit_off[(size_t)n];
+  M->stats.sum_hits = total_hits;
+  M->hits.alloc((size_t)std::max<int64_t>(total_hits, 1));
+  if (total_hits > 0) {
+    gather_hits_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, hit_off.p, M->hits.p);
+    MM_KERNEL_CHECK();
+    // ---- K4a
+    std::vector<int64_t> hc((size_t)n);
+    for (int64_t r = 0; r < n; ++r) hc[(size_t)r] = (int64_t)(M->h_read_hit_off[(size_t)r + 1] - M->h_read_hit_off[(size_t)r]);
+    for (auto& cls : make_classes(hc, 256)) {
+      DBuf<int32_t> list(cls.reads.size());
+      list.upload(cls.reads.data(), cls.reads.size(), st);
+      if (cls.npow2 <= LDS_SORT_MAX) {
+        size_t lds = (size_t)cls.npow2 * 8;
+        if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)sort_hits_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        sort_hits_kernel<true><<<dim3((unsigned)cls.reads.size()), dim3(256), lds, st>>>(M->hits.p, M->read_hit_off.p, list.p, cls.npow2, nullptr);
+        MM_KERNEL_CHECK();
+        MM_HIP(hipStreamSynchronize(st));
+      } else {
+        // large segments: a few reads at a time through a global scratch buffer
+        const size_t per = (size_t)cls.npow2;
+        const size_t group = std::max<size_t>(1, std::min<size_t>(cls.reads.size(), ((size_t)1 << 28) / per));
+        DBuf<uint64_t> scratch(per * group);
+        for (size_t g0 = 0; g0 < cls.reads.size(); g0 += group) {
+          size_t g = std::min(group, cls.reads.size() - g0);
+          sort_hits_kernel<false><<<dim3((unsigned)g), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, list.p + g0, cls.npow2, scratch.p);
+          MM_KERNEL_CHECK();
+        }
+        MM_HIP(hipStreamSynchronize(st));
+      }
+    }
+  }
+  // ---- K4b
+  DBuf<uint32_t> cand_n((size_t)n + 1); cand_n.zero(st);
+  M->cand_off.alloc((size_t)n + 2);
+  const unsigned rblk = (unsigned)ceil_div(std::max<int64_t>(n, 1), 128);
+  if (n > 0) {
+    l1_scan_kernel<false><<<dim3(rblk), dim3(128), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, cand_n.p, nullptr, nullptr, nullptr);
+    MM_KERNEL_CHECK();
+  }
+  exclusive_scan_u32_u64(cand_n.p, n, M->cand_off.p, scan_tmp, st);
+  M->h_cand_off = M->cand_off.to_host(st, (size_t)n + 1);
+  const int64_t ncand = (int64_t)M->h_cand_off[(size_t)n];
+  M->n_cand = ncand;
+  M->stats.n_candidates = ncand;
+  M->cand.alloc((size_t)std::max<int64_t>(3 * ncand, 1));
+  M->cand_read.alloc((size_t)std::max<int64_t>(ncand, 1));
+  M->l2.alloc((size_t)std::max<int64_t>(ncand, 1));
+  M->rec_off.alloc((size_t)n + 1);
+  if (ncand > 0) {
+    l1_scan_kernel<true><<<dim3(rblk), dim3(128), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, nullptr, M->cand_off.p, M->cand.p, M->cand_read.p);
+    MM_KERNEL_CHECK();
+    // ---- K5/K6
+    MM_REQUIRE(ncand < (1LL << 31), MM_ERR_LIMIT, "more than 2^31 L1 candidates in one batch");
+    const int smax = M->smax;
+    const size_t lds = (size_t)smax * 4 + (size_t)((smax + 1) & ~1) * 2 + (size_t)((smax + 31) / 32) * 4 + 16;
+    MM_REQUIRE(lds <= 160 * 1024, MM_ERR_LIMIT, "sketch too large for the L2 window state in LDS (read longer than ~115 kb at w=8)");
+    if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)l2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DBuf<unsigned long long> counters(2); counters.zero(st);
+    l2_kernel<<<dim3((unsigned)ncand), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p,
+                                                           M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p);
+    MM_KERNEL_CHECK();
+    auto hc = counters.to_host(st);
+    M->stats.sum_l2_stream_entries = (int64_t)hc[0];
+    M->stats.sum_l2_evals = (int64_t)hc[1];
+    // ---- compaction
+    DBuf<uint32_t> flag((size_t)ncand);
+    DBuf<uint64_t> rank((size_t)ncand + 1);
+    accept_flags_kernel<<<dim3((unsigned)ceil_div(ncand, 256)), dim3(256), 0, st>>>(M->l2.p, ncand, flag.p);
+    MM_KERNEL_CHECK();
+    exclusive_scan_u32_u64(flag.p, ncand, rank.p, scan_tmp, st);
+    uint64_t nrec = 0;
+    MM_HIP(hipMemcpyAsync(&nrec, rank.p + ncand, sizeof nrec, hipMemcpyDeviceToHost, st));
+    MM_HIP(hipStreamSynchronize(st));
+    M->n_rec = (int64_t)nrec;
+    M->rec.alloc((size_t)std::max<uint64_t>(nrec, 1));
+    write_records_kernel<<<dim3((unsigned)ceil_div(ncand, 256)), dim3(256), 0, st>>>(M->l2.p, M->cand_read.p, M->sk_n.p, flag.p, rank.p, ncand, M->rec.p);
+    MM_KERNEL_CHECK();
+    read_rec_bounds_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(M->cand_off.p, rank.p, n, M->rec_off.p);
+    MM_KERNEL_CHECK();
+    MM_HIP(hipStreamSynchronize(st));
+  } else {
+    M->n_rec = 0;
+    M->rec.alloc(1);
+    M->rec_off.zero(st);
+    MM_HIP(hipStreamSynchronize(st));
+  }
+  M->h_rec_off = M->rec_off.to_host(st, (size_t)n + 1);
+  M->stats.n_mappings = M->n_rec;
+  for (int64_t r = 0; r < n; ++r) if (M->h_rec_off[(size_t)r + 1] > M->h_rec_off[(size_t)r]) M->stats.n_reads_mapped++;
+}
+
+}  // namespace mm

@@ -65,7 +65,7 @@ __device__ inline KmerInfo kmer_info_serial(const SeqView& S, uint64_t gbase, in
 
 // One thread per sequence: position of the first change point after window 0 whose (hash,strand)
 // differs from the window-0 emission; w-1 when nothing can be swallowed.
-__global__ void jstar_kernel(SeqView S, const uint8_t* __restrict__ active, int k, int w, int32_t* __restrict__ jstar) {
+static __global__ void jstar_kernel(SeqView S, const uint8_t* __restrict__ active, int k, int w, int32_t* __restrict__ jstar) {
   int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S.n) return;
   int32_t res = w - 1;

@@ -1,0 +1,259 @@
+// K8 mapping qualities (replaces mapWrap::addMappingQualities, mapWrap.h:215-323, :332-356) and
+// K9 EM classification step (replaces the per-read callback + reduction of meta::doEM, fEM.h:501-615,
+// with getMappingLocations' likelihood, fEM.h:350-361) + the RCCL all-reduce of the sufficient statistics.
+#include "mm_map.hpp"
+#include "mm_em.hpp"
+#include <rccl/rccl.h>
+#include <cfloat>
+#include <numeric>
+
+namespace mm {
+
+// ---------------------------------------------------------------------------------------------------
+// Text round trips are part of the reference's numerics: identities and mapping qualities
+// are printed with 6 significant digits (ostream default) and parsed back with stod.  parse6() returns
+// the double that stod would return for the "%g" rendering of v.  For a float-valued v the scaling by a
+// power of ten is exact in double, so ties (…5 exactly) are detected exactly and rounded half-to-even as
+// glibc's printf does.
+// ---------------------------------------------------------------------------------------------------
+__host__ __device__ inline double pow10_int(int t) {
+  const double tab[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  if (t >= 0 && t <= 22) return tab[t];
+  return pow(10.0, (double)t);
+}
+__host__ __device__ inline double parse6(double v) {
+  if (v == 0.0 || !(v == v)) return v;
+  double a = fabs(v);
+  int e = (int)floor(log10(a));
+  {                                                              // fix log10 rounding at decade boundaries
+    double pe = e >= 0 ? pow10_int(e) : 1.0 / pow10_int(-e);
+    if (a < pe) --e; else if (a >= pe * 10.0) ++e;
+  }
+  int t = 5 - e;
+  double x = t >= 0 ? a * pow10_int(t) : a / pow10_int(-t);
+  double d = rint(x);
+  if (d >= 1e6) { d /= 10.0; t -= 1; }
+  double r = t >= 0 ? d / pow10_int(t) : d * pow10_int(-t);
+  if (r < DBL_MIN) r = 0.0;                                      // stod throws out_of_range → reference uses 0, fEM.h:269-275
+  return v < 0 ? -r : r;
+}
+
+// float math of Stat::j2md (map_stats.hpp:44) and the identity of computeMap.hpp:406,411
+__host__ __device__ inline float dev_identity(int shared, int s, int k) {
+  float j = (float)(1.0 * shared / s);
+  float md;
+  if (j == 0) md = 1.0f;
+  else if (j == 1) md = 0.0f;
+  else md = (float)((-1.0 / k) * log(2.0 * j / (double)(1 + j)));
+  return 100 * (1 - md);
+}
+
+__device__ inline double dev_binom_pmf(int n, double p, int k) {  // boost pdf(binomial), mapWrap.h:340
+  if (k < 0 || k > n) return 0.0;
+  if (p == 0) return k == 0 ? 1.0 : 0.0;
+  if (p == 1) return k == n ? 1.0 : 0.0;
+  if (n == 0) return 1.0;
+  if (k == 0) return pow(1 - p, (double)n);
+  if (k == n) return pow(p, (double)k);
+  return exp(lgamma((double)n + 1) - lgamma((double)k + 1) - lgamma((double)(n - k) + 1) + k * log(p) + (n - k) * log1p(-p));
+}
+
+__global__ void mapq_kernel(mm_map_record* __restrict__ rec, const uint64_t* __restrict__ rec_off, const int32_t* __restrict__ read_len,
+                            int64_t n_reads, int k, int* __restrict__ err) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  const uint64_t lo = rec_off[r], hi = rec_off[r + 1];
+  if (lo == hi) return;
+  double maxid = -1;
+  for (uint64_t i = lo; i < hi; ++i) {
+    double id = parse6((double)dev_identity(rec[i].shared, rec[i].sketch, k)) / 100.0;   // mapWrap.h:237
+    if (id > maxid) maxid = id;
+  }
+  maxid = exp(-(1 - maxid));                                      // :261
+  const int nk = read_len[r] - k + 1;                             // :266
+  const double surv = pow(maxid, (double)k);                      // :335
+  const double es = round(surv * nk);
+  const double eu = nk + (nk - es);
+  const double p = es / eu;
+  double sum = 0;
+  for (uint64_t i = lo; i < hi; ++i) { double l = dev_binom_pmf(rec[i].sketch, p, rec[i].shared); rec[i].mapq = l; sum += l; }
+  if (!(sum > 0)) { atomicExch(err, 1); return; }                 // reference asserts here, :298
+  for (uint64_t i = lo; i < hi; ++i) rec[i].mapq = rec[i].mapq / sum;
+}
+
+void mapping_add_qualities(mm_ctx* ctx, mm_mapping* M, int k) {
+  hipStream_t st = ctx->stream;
+  if (M->n_reads == 0 || M->n_rec == 0) { M->has_mapq = true; return; }
+  DBuf<int> err(1); err.zero(st);
+  mapq_kernel<<<dim3((unsigned)ceil_div(M->n_reads, 128)), dim3(128), 0, st>>>(M->rec.p, M->rec_off.p, M->d_read_len.p, M->n_reads, k, err.p);
+  MM_KERNEL_CHECK();
+  auto he = err.to_host(st);
+  MM_REQUIRE(he[0] == 0, MM_ERR_NUMERIC, "likelihood sum of a read is 0 (the reference aborts here, mapWrap.h:298)");
+  M->has_mapq = true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K9 EM
+// ---------------------------------------------------------------------------------------------------
+__global__ void em_estep_kernel(const int64_t* __restrict__ read_off, const int32_t* __restrict__ taxon, const double* __restrict__ mapq,
+                                const double* __restrict__ inv_nloc, const double* __restrict__ f, int64_t n_reads,
+                                double* __restrict__ post, double* __restrict__ ll_read) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  const int64_t lo = read_off[r], hi = read_off[r + 1];
+  double sum = 0;
+  for (int64_t i = lo; i < hi; ++i) { double l = f[taxon[i]] * inv_nloc[i] * mapq[i]; post[i] = l; sum += l; }   // fEM.h:353
+  for (int64_t i = lo; i < hi; ++i) post[i] = post[i] / sum;                                                      // :361
+  ll_read[r] = hi > lo ? log(sum) : 0.0;                                                                          // fEM.h:578
+}
+
+// fixed-shape sum of v[idx[lo..hi)]: 64 lanes stride the segment, then a butterfly.  The shape depends only on
+// the segment length, so two taxa with identical contribution sequences get bit-identical sums.
+__global__ void __launch_bounds__(64) em_taxon_sum_kernel(const double* __restrict__ post, const int64_t* __restrict__ tstart,
+                                                          const int64_t* __restrict__ perm, double* __restrict__ f_partial) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  double acc = 0;
+  for (int64_t j = tstart[t] + lane; j < tstart[t + 1]; j += 64) acc += post[perm[j]];
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if (lane == 0) f_partial[t] = acc;
+}
+__global__ void __launch_bounds__(256) sum_blocks_kernel(const double* __restrict__ v, int64_t n, double* __restrict__ block_sum) {
+  __shared__ double sh[256];
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  sh[threadIdx.x] = i < n ? v[i] : 0.0;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
+  if (threadIdx.x == 0) block_sum[blockIdx.x] = sh[0];
+}
+__global__ void __launch_bounds__(256) sum_final_kernel(const double* __restrict__ block_sum, int64_t nb, double* __restrict__ out) {
+  __shared__ double sh[256];
+  double acc = 0;
+  for (int64_t i = threadIdx.x; i < nb; i += 256) acc += block_sum[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
+  if (threadIdx.x == 0) *out = sh[0];
+}
+__global__ void em_best_kernel(const int64_t* __restrict__ read_off, const double* __restrict__ post, int64_t n_reads, int64_t* __restrict__ best) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  const int64_t lo = read_off[r], hi = read_off[r + 1];
+  int64_t b = lo;                                                 // first strict maximum, fEM.h:217-232
+  for (int64_t i = lo + 1; i < hi; ++i) if (post[i] > post[b]) b = i;
+  best[r] = hi > lo ? b : -1;
+}
+
+void em_create(mm_ctx* ctx, int64_t n_reads, const int64_t* read_off, const int32_t* taxon, const double* mapq, const double* inv_nloc,
+               int32_t n_taxa, mm_em* E) {
+  hipStream_t st = ctx->stream;
+  E->ctx = ctx; E->n_reads = n_reads; E->n_taxa = n_taxa;
+  const int64_t ne = n_reads > 0 ? read_off[n_reads] : 0;
+  E->n_entries = ne;
+  for (int64_t i = 0; i < ne; ++i) MM_REQUIRE(taxon[i] >= 0 && taxon[i] < n_taxa, MM_ERR_ARG, "taxon index out of range");
+  // CSR by taxon, entries kept in input (read) order inside each taxon
+  std::vector<int64_t> ts((size_t)n_taxa + 1, 0), perm((size_t)std::max<int64_t>(ne, 1));
+  for (int64_t i = 0; i < ne; ++i) ts[(size_t)taxon[i] + 1]++;
+  for (int32_t t = 0; t < n_taxa; ++t) ts[(size_t)t + 1] += ts[(size_t)t];
+  { std::vector<int64_t> cur(ts.begin(), ts.end() - 1); for (int64_t i = 0; i < ne; ++i) perm[(size_t)cur[(size_t)taxon[i]]++] = i; }
+  E->read_off.alloc((size_t)n_reads + 1); E->read_off.upload(read_off, (size_t)n_reads + 1, st);
+  E->taxon.alloc((size_t)std::max<int64_t>(ne, 1)); E->taxon.upload(taxon, (size_t)ne, st);
+  E->mapq.alloc((size_t)std::max<int64_t>(ne, 1)); E->mapq.upload(mapq, (size_t)ne, st);
+  E->inv_nloc.alloc((size_t)std::max<int64_t>(ne, 1)); E->inv_nloc.upload(inv_nloc, (size_t)ne, st);
+  E->tstart.alloc((size_t)n_taxa + 1); E->tstart.upload(ts.data(), ts.size(), st);
+  E->perm.alloc(perm.size()); E->perm.upload(perm.data(), (size_t)ne, st);
+  E->post.alloc((size_t)std::max<int64_t>(ne, 1));
+  E->ll_read.alloc((size_t)std::max<int64_t>(n_reads, 1));
+  E->f.alloc((size_t)n_taxa);
+  E->partial.alloc((size_t)n_taxa + 1);
+  E->block_sum.alloc((size_t)ceil_div(std::max<int64_t>(n_reads, 1), 256));
+  MM_HIP(hipStreamSynchronize(st));
+}
+
+// device part of one iteration: partial[0..T) = sum of posteriors per taxon, partial[T] = sum of log-likelihoods
+static void em_step_device(mm_em* E, const double* f_host) {
+  hipStream_t st = E->ctx->stream;
+  E->f.upload(f_host, (size_t)E->n_taxa, st);
+  if (E->n_reads > 0) {
+    em_estep_kernel<<<dim3((unsigned)ceil_div(E->n_reads, 128)), dim3(128), 0, st>>>(E->read_off.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->f.p,
+                                                                                 E->n_reads, E->post.p, E->ll_read.p);
+    MM_KERNEL_CHECK();
+  }
+  em_taxon_sum_kernel<<<dim3((unsigned)E->n_taxa), dim3(64), 0, st>>>(E->post.p, E->tstart.p, E->perm.p, E->partial.p);
+  MM_KERNEL_CHECK();
+  const int64_t nb = ceil_div(std::max<int64_t>(E->n_reads, 1), 256);
+  sum_blocks_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(E->ll_read.p, E->n_reads, E->block_sum.p);
+  MM_KERNEL_CHECK();
+  sum_final_kernel<<<dim3(1), dim3(256), 0, st>>>(E->block_sum.p, nb, E->partial.p + E->n_taxa);
+  MM_KERNEL_CHECK();
+}
+
+void em_iterate(mm_em* E, const double* f, double* f_partial, double* ll_partial) {
+  em_step_device(E, f);
+  std::vector<double> h = E->partial.to_host(E->ctx->stream);
+  memcpy(f_partial, h.data(), sizeof(double) * (size_t)E->n_taxa);
+  *ll_partial = h[(size_t)E->n_taxa];
+}
+
+void em_iterate_allreduce(mm_em* E, const double* f, double* f_next, double* ll) {
+  mm_ctx* ctx = E->ctx;
+  em_step_device(E, f);
+  if (ctx->comm) {                                                // fEM.h:583-600, across GPUs instead of OpenMP threads
+    ncclResult_t rc = ncclAllReduce(E->partial.p, E->partial.p, (size_t)E->n_taxa + 1, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
+    MM_REQUIRE(rc == ncclSuccess, MM_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
+  }
+  std::vector<double> h = E->partial.to_host(ctx->stream);
+  double sum = 0;
+  for (int32_t t = 0; t < E->n_taxa; ++t) sum += h[(size_t)t];    // fEM.h:606-615
+  for (int32_t t = 0; t < E->n_taxa; ++t) f_next[t] = h[(size_t)t] / sum;
+  *ll = h[(size_t)E->n_taxa];
+}
+
+void em_posteriors(mm_em* E, const double* f, double* post, int64_t* best) {
+  hipStream_t st = E->ctx->stream;
+  em_step_device(E, f);
+  if (post) E->post.download(post, (size_t)E->n_entries, st);
+  if (best && E->n_reads > 0) {
+    DBuf<int64_t> b((size_t)E->n_reads);
+    em_best_kernel<<<dim3((unsigned)ceil_div(E->n_reads, 128)), dim3(128), 0, st>>>(E->read_off.p, E->post.p, E->n_reads, b.p);
+    MM_KERNEL_CHECK();
+    b.download(best, (size_t)E->n_reads, st);
+    MM_HIP(hipStreamSynchronize(st));
+  }
+  MM_HIP(hipStreamSynchronize(st));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// communicator
+// ---------------------------------------------------------------------------------------------------
+void comm_unique_id(char* id) {
+  static_assert(sizeof(ncclUniqueId) <= MM_COMM_ID_BYTES, "ncclUniqueId larger than MM_COMM_ID_BYTES");
+  ncclUniqueId u;
+  ncclResult_t rc = ncclGetUniqueId(&u);
+  MM_REQUIRE(rc == ncclSuccess, MM_ERR_COMM, std::string("ncclGetUniqueId: ") + ncclGetErrorString(rc));
+  memset(id, 0, MM_COMM_ID_BYTES);
+  memcpy(id, &u, sizeof u);
+}
+void comm_init(mm_ctx* ctx, const char* id, int rank, int nranks) {
+  MM_REQUIRE(ctx->comm == nullptr, MM_ERR_STATE, "communicator already initialised");
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  ncclComm_t c;
+  MM_HIP(hipSetDevice(ctx->device));
+  ncclResult_t rc = ncclCommInitRank(&c, nranks, u, rank);
+  MM_REQUIRE(rc == ncclSuccess, MM_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(rc));
+  ctx->comm = c; ctx->comm_rank = rank; ctx->comm_size = nranks;
+}
+void comm_allreduce_f64(mm_ctx* ctx, double* host, int64_t n) {
+  if (!ctx->comm || n <= 0) return;
+  DBuf<double> d((size_t)n);
+  d.upload(host, (size_t)n, ctx->stream);
+  ncclResult_t rc = ncclAllReduce(d.p, d.p, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
+  MM_REQUIRE(rc == ncclSuccess, MM_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
+  d.download(host, (size_t)n, ctx->stream);
+  MM_HIP(hipStreamSynchronize(ctx->stream));
+}
+void comm_destroy(mm_ctx* ctx) {
+  if (ctx->comm) { ncclCommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; ctx->comm_size = 1; ctx->comm_rank = 0; }
+}
+
+}  // namespace mm

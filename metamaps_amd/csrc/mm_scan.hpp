@@ -34,7 +34,7 @@ __device__ inline uint64_t block_excl_scan_u64(uint64_t v, uint64_t* total) {
   return base + inc - v;
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_t* __restrict__ in, int64_t n, uint64_t* __restrict__ tile_sum) {
+static __global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_t* __restrict__ in, int64_t n, uint64_t* __restrict__ tile_sum) {
   int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
   uint64_t s = 0;
 #pragma unroll
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_
 }
 
 // single block: in-place exclusive scan of tile sums (any length), grand total to *grand
-__global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(uint64_t* __restrict__ tile_sum, int64_t ntiles, uint64_t* __restrict__ grand) {
+static __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(uint64_t* __restrict__ tile_sum, int64_t ntiles, uint64_t* __restrict__ grand) {
   uint64_t carry = 0;
   for (int64_t base = 0; base < ntiles; base += SCAN_THREADS) {
     int64_t j = base + threadIdx.x;
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(uint64_t* __re
   if (threadIdx.x == 0 && grand) *grand = carry;
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t* __restrict__ in, int64_t n, const uint64_t* __restrict__ tile_sum,
+static __global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t* __restrict__ in, int64_t n, const uint64_t* __restrict__ tile_sum,
                                                                   uint64_t* __restrict__ out) {
   // thread t owns SCAN_ITEMS consecutive items so that the output order is the input order
   int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;

@@ -144,6 +144,9 @@ typedef struct {
   /* algorithmic-traffic counters */
   int64_t sum_sketch, sum_hits, n_candidates, sum_l2_stream_entries, sum_l2_evals;
   int64_t n_ambiguous_sketch_reads;   /* reads whose duplicate-hash strands needed the std::sort tie-break */
+  /* device time of each stage of this batch, milliseconds, from hipEvents recorded on the ctx stream
+   * around the launches (bench.py's roofline uses ms_l2 = the K5/K6 kernel) */
+  double ms_minimizer, ms_sketch, ms_probe_gather, ms_sort_hits, ms_l1_scan, ms_l2, ms_compact, ms_total;
 } mm_map_stats;
 
 int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, mm_mapping** out);

@@ -349,8 +349,32 @@ static bool host_less_by_hash(const HostMz& a, const HostMz& b) { return a.hash 
 static bool host_eq_by_hash(const HostMz& a, const HostMz& b) { return a.hash == b.hash; }    // base_types.hpp:66
 }  // namespace
 
+namespace {
+// hipEvent pairs on the ctx stream; elapsed times are read once at the end of the batch
+struct StageTimer {
+  hipStream_t st;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  std::vector<double*> dst;
+  explicit StageTimer(hipStream_t s) : st(s) {}
+  ~StageTimer() { for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } }
+  size_t begin(double* target) {
+    hipEvent_t a, b;
+    MM_HIP(hipEventCreate(&a)); MM_HIP(hipEventCreate(&b));
+    ev.push_back({a, b}); dst.push_back(target);
+    MM_HIP(hipEventRecord(a, st));
+    return ev.size() - 1;
+  }
+  void end(size_t i) { MM_HIP(hipEventRecord(ev[i].second, st)); }
+  void collect() {
+    MM_HIP(hipStreamSynchronize(st));
+    for (size_t i = 0; i < ev.size(); ++i) { float ms = 0; MM_HIP(hipEventElapsedTime(&ms, ev[i].first, ev[i].second)); *dst[i] += ms; }
+  }
+};
+}  // namespace
+
 void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_map_params& P, mm_mapping* M) {
   hipStream_t st = ctx->stream;
+  StageTimer T(st);
   MM_REQUIRE(I->k == P.k && I->w == P.w, MM_ERR_ARG, "index was built with different k / window size");
   const int64_t n = reads->count();
   MM_REQUIRE(n < (1LL << 31), MM_ERR_LIMIT, "more than 2^31 reads in one batch");
@@ -364,8 +388,9 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     M->active[(size_t)r] = ok;
     if (ok) { M->stats.n_reads_long_enough++; M->stats.bases_long_enough += L; }
   }
+  const size_t t_total = T.begin(&M->stats.ms_total);
   // ---- K1
-  run_minimizers(ctx, reads, P.k, P.w, M->active, false, M->mz);
+  { size_t t = T.begin(&M->stats.ms_minimizer); run_minimizers(ctx, reads, P.k, P.w, M->active, false, M->mz); T.end(t); }
   const int64_t total_mz = M->mz.total;
   const std::vector<uint64_t>& hoff = M->mz.h_off;
   M->sk_hash.alloc((size_t)std::max<int64_t>(total_mz, 1));
@@ -374,6 +399,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   M->amb.alloc((size_t)std::max<int64_t>(n, 1)); M->amb.zero(st);
   // ---- K2
   {
+    size_t t_sk = T.begin(&M->stats.ms_sketch);
     std::vector<int64_t> cnt((size_t)n);
     for (int64_t r = 0; r < n; ++r) cnt[(size_t)r] = (int64_t)(hoff[(size_t)r + 1] - hoff[(size_t)r]);
     // single-element lists are "sorted" already but still need their sketch written: force class >= 2 by min count 1
@@ -396,6 +422,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       }
       MM_HIP(hipStreamSynchronize(st));                          // `list` must outlive the launch
     }
+    T.end(t_sk);
   }
   M->h_sk_n = M->sk_n.to_host(st, (size_t)n);
   std::vector<uint8_t> h_amb = M->amb.to_host(st, (size_t)n);
@@ -446,6 +473,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   DBuf<uint32_t> probe_cnt((size_t)total_mz + 1); probe_cnt.zero(st);
   DBuf<uint64_t> probe_start((size_t)total_mz + 1);
   DBuf<uint64_t> hit_off((size_t)total_mz + 2), scan_tmp;
+  const size_t t_pg = T.begin(&M->stats.ms_probe_gather);
   if (n > 0 && total_mz > 0) {
     probe_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p);
     MM_KERNEL_CHECK();
@@ -461,6 +489,10 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   if (total_hits > 0) {
     gather_hits_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, hit_off.p, M->hits.p);
     MM_KERNEL_CHECK();
+  }
+  T.end(t_pg);
+  if (total_hits > 0) {
+    const size_t t_sh = T.begin(&M->stats.ms_sort_hits);
     // ---- K4a
     std::vector<int64_t> hc((size_t)n);
     for (int64_t r = 0; r < n; ++r) hc[(size_t)r] = (int64_t)(M->h_read_hit_off[(size_t)r + 1] - M->h_read_hit_off[(size_t)r]);
@@ -486,8 +518,10 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         MM_HIP(hipStreamSynchronize(st));
       }
     }
+    T.end(t_sh);
   }
   // ---- K4b
+  const size_t t_l1 = T.begin(&M->stats.ms_l1_scan);
   DBuf<uint32_t> cand_n((size_t)n + 1); cand_n.zero(st);
   M->cand_off.alloc((size_t)n + 2);
   const unsigned rblk = (unsigned)ceil_div(std::max<int64_t>(n, 1), 128);
@@ -507,6 +541,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   if (ncand > 0) {
     l1_scan_kernel<true><<<dim3(rblk), dim3(128), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, nullptr, M->cand_off.p, M->cand.p, M->cand_read.p);
     MM_KERNEL_CHECK();
+    T.end(t_l1);
     // ---- K5/K6
     MM_REQUIRE(ncand < (1LL << 31), MM_ERR_LIMIT, "more than 2^31 L1 candidates in one batch");
     const int smax = M->smax;
@@ -514,13 +549,16 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     MM_REQUIRE(lds <= 160 * 1024, MM_ERR_LIMIT, "sketch too large for the L2 window state in LDS (read longer than ~115 kb at w=8)");
     if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)l2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     DBuf<unsigned long long> counters(2); counters.zero(st);
+    const size_t t_l2 = T.begin(&M->stats.ms_l2);
     l2_kernel<<<dim3((unsigned)ncand), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p,
                                                            M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p);
     MM_KERNEL_CHECK();
+    T.end(t_l2);
     auto hc = counters.to_host(st);
     M->stats.sum_l2_stream_entries = (int64_t)hc[0];
     M->stats.sum_l2_evals = (int64_t)hc[1];
     // ---- compaction
+    const size_t t_cp = T.begin(&M->stats.ms_compact);
     DBuf<uint32_t> flag((size_t)ncand);
     DBuf<uint64_t> rank((size_t)ncand + 1);
     accept_flags_kernel<<<dim3((unsigned)ceil_div(ncand, 256)), dim3(256), 0, st>>>(M->l2.p, ncand, flag.p);
@@ -535,14 +573,18 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     MM_KERNEL_CHECK();
     read_rec_bounds_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(M->cand_off.p, rank.p, n, M->rec_off.p);
     MM_KERNEL_CHECK();
+    T.end(t_cp);
     MM_HIP(hipStreamSynchronize(st));
   } else {
+    T.end(t_l1);
     M->n_rec = 0;
     M->rec.alloc(1);
     M->rec_off.zero(st);
     MM_HIP(hipStreamSynchronize(st));
   }
   M->h_rec_off = M->rec_off.to_host(st, (size_t)n + 1);
+  T.end(t_total);
+  T.collect();
   M->stats.n_mappings = M->n_rec;
   for (int64_t r = 0; r < n; ++r) if (M->h_rec_off[(size_t)r + 1] > M->h_rec_off[(size_t)r]) M->stats.n_reads_mapped++;
 }

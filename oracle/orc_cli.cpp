@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::cerr << "{\"oracle\":\"mapDirectly\",\"w\":" << P.w << ",\"reads\":" << C.reads << ",\"bases\":" << C.bases
               << ",\"sketch\":" << C.sketch << ",\"hits\":" << C.hits << ",\"cands\":" << C.cands << ",\"stream\":"
-              << C.stream << ",\"evals\":" << C.evals << ",\"mappings\":" << C.maps << ",\"seconds\":" << sec << "}\n";
+              << C.stream << ",\"evals\":" << C.evals << ",\"mappings\":" << C.maps << ",\"map_seconds\":" << C.map_seconds << ",\"seconds\":" << sec << "}\n";
   } else if (mode == "classify") {
     if (!opt.count("DB")) { std::cerr << "Provide path to DB.\n"; return 1; }
     if (!opt.count("mappings")) { std::cerr << "Provide path to mappings.\n"; return 1; }

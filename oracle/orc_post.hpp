@@ -5,6 +5,7 @@
 #include <fstream>
 #include <iostream>
 #include <regex>
+#include <chrono>
 
 namespace orc {
 
@@ -115,7 +116,7 @@ static inline void unify_files(const std::string& prefix, const Params& P, const
      << prefix << "\nreportAll " << P.reportAll << "\nindex " << "" << "\nmaximumMemory " << P.maxMem << "\n";
 }
 
-struct MapCounters { uint64_t reads = 0, bases = 0, sketch = 0, hits = 0, cands = 0, stream = 0, evals = 0, maps = 0; };
+struct MapCounters { uint64_t reads = 0, bases = 0, sketch = 0, hits = 0, cands = 0, stream = 0, evals = 0, maps = 0; double map_seconds = 0; };
 
 // computeMap.hpp:104-172 (single-threaded; the pool only preserves input order) writing PREFIX.N
 static inline void map_query_file(const RefSketch& R, const Params& P, const std::string& queryFile,
@@ -123,6 +124,7 @@ static inline void map_query_file(const RefSketch& R, const Params& P, const std
   std::ofstream out(outFile);
   SeqReader rd(queryFile);
   long len;
+  auto t0 = std::chrono::steady_clock::now();                    // "Time spent mapping the query", computeMap.hpp:91-96
   while ((len = rd.next()) >= 0) {
     if (len < P.w || len < P.k || len < P.minReadLen) continue;
     Query Q; Q.name = rd.name; Q.seq = &rd.seq[0]; Q.len = (int)len;
@@ -136,6 +138,7 @@ static inline void map_query_file(const RefSketch& R, const Params& P, const std
     if (C) { C->reads++; C->bases += len; C->sketch += Q.sketch; C->hits += dbg.hits.size(); C->cands += cands.size();
              C->stream += st; C->evals += ev; C->maps += ms.size(); }
   }
+  if (C) C->map_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 // mapWrap.h:407-441 for one query/prefix pair

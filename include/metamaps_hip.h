@@ -144,6 +144,7 @@ typedef struct {
   /* algorithmic-traffic counters */
   int64_t sum_sketch, sum_hits, n_candidates, sum_l2_stream_entries, sum_l2_evals;
   int64_t n_ambiguous_sketch_reads;   /* reads whose duplicate-hash strands needed the std::sort tie-break */
+  int64_t n_l2_rebuilds;              /* window states rebuilt from scratch by the exact skip-ahead of K5 */
   /* device time of each stage of this batch, milliseconds, from hipEvents recorded on the ctx stream
    * around the launches (bench.py's roofline uses ms_l2 = the K5/K6 kernel) */
   double ms_minimizer, ms_sketch, ms_probe_gather, ms_sort_hits, ms_l1_scan, ms_l2, ms_compact, ms_total;
@@ -163,7 +164,7 @@ int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* cont
 int mm_debug_sketch(mm_mapping* m, int64_t* offsets, uint32_t* hash, int32_t* strand, int64_t cap);          /* computeMap.hpp:292-298 */
 int mm_debug_hits(mm_mapping* m, int64_t* offsets, int32_t* contig, int32_t* wpos, int64_t cap);             /* :307-323, sorted :353 */
 int mm_debug_candidates(mm_mapping* m, int64_t* offsets, int32_t* triples /* contig,start,end */, int64_t cap);   /* :346-386 */
-int mm_debug_l2(mm_mapping* m, int64_t* per_cand /* contig, meanPos, shared, optBeg, optEnd */, int64_t cap);      /* :460-538 */
+int mm_debug_l2(mm_mapping* m, int64_t* per_cand /* contig, meanPos, shared, optBeg, optEnd, accepted */, int64_t cap);      /* :460-538 */
 int mm_debug_min_hits(mm_mapping* m, int32_t* min_hits /* [n_reads] */);
 
 /* ---- EM (replaces meta::doEM's iteration, fEM.h:501-661, and the per-read likelihood fEM.h:234-373) */

@@ -15,6 +15,7 @@ void seqset_fetch(mm_seqset* s, int64_t i, char* out, int64_t cap);
 namespace {
 template <typename F>
 int guarded(mm_ctx* ctx, F&& f) {
+  if (ctx) mm::current_stream() = ctx->stream;
   try { f(); return MM_OK; }
   catch (const mm::Error& e) { if (ctx) ctx->err = e.what(); return e.status; }
   catch (const std::bad_alloc&) { if (ctx) ctx->err = "host allocation failed"; return MM_ERR_NOMEM; }
@@ -43,6 +44,10 @@ int mm_ctx_create(int device_id, mm_ctx** out) {
                std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
     c->cus = p.multiProcessorCount;
     MM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    hipMemPool_t pool;                                          // keep freed blocks cached in the pool
+    MM_HIP(hipDeviceGetDefaultMemPool(&pool, device_id));
+    uint64_t keep = UINT64_MAX;
+    MM_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
   });
   if (st != MM_OK) { delete c; return st; }
   *out = c;
@@ -50,6 +55,7 @@ int mm_ctx_create(int device_id, mm_ctx** out) {
 }
 void mm_ctx_destroy(mm_ctx* ctx) {
   if (!ctx) return;
+  (void)hipStreamSynchronize(ctx->stream);
   mm::comm_destroy(ctx);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -80,7 +86,7 @@ int mm_seqset_create(mm_ctx* ctx, mm_seqset** out) {
   if (!ctx || !out) return MM_ERR_ARG;
   return guarded(ctx, [&] { auto* s = new mm_seqset; s->ctx = ctx; *out = s; });
 }
-void mm_seqset_destroy(mm_seqset* s) { delete s; }
+void mm_seqset_destroy(mm_seqset* s) { if (s) { mm::current_stream() = s->ctx->stream; delete s; } }
 int mm_seqset_add(mm_seqset* s, const char* ascii, int64_t len) {
   if (!s || (!ascii && len > 0) || len < 0) return MM_ERR_ARG;
   return guarded(s->ctx, [&] {
@@ -143,7 +149,7 @@ int mm_index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index
     *out = I;
   });
 }
-void mm_index_destroy(mm_index* idx) { delete idx; }
+void mm_index_destroy(mm_index* idx) { if (idx) { mm::current_stream() = idx->ctx->stream; delete idx; } }
 int mm_index_get_info(const mm_index* idx, mm_index_info* out) {
   if (!idx || !out) return MM_ERR_ARG;
   out->n_contigs = idx->n_contigs; out->n_entries = idx->N; out->n_unique_hashes = idx->U; out->n_dup_flagged = idx->n_dup;
@@ -221,7 +227,7 @@ int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const
     *out = M;
   });
 }
-void mm_mapping_destroy(mm_mapping* m) { delete m; }
+void mm_mapping_destroy(mm_mapping* m) { if (m) { mm::current_stream() = m->ctx->stream; delete m; } }
 int mm_mapping_get_stats(const mm_mapping* m, mm_map_stats* out) {
   if (!m || !out) return MM_ERR_ARG;
   *out = m->stats;
@@ -333,8 +339,8 @@ int mm_debug_l2(mm_mapping* m, int64_t* per_cand, int64_t cap) {
     MM_REQUIRE(cap >= m->n_cand, MM_ERR_ARG, "output capacity too small");
     auto h = m->l2.to_host(m->ctx->stream, (size_t)m->n_cand);
     for (int64_t i = 0; i < m->n_cand; ++i) {
-      per_cand[5 * i] = h[(size_t)i].contig; per_cand[5 * i + 1] = h[(size_t)i].mean_pos; per_cand[5 * i + 2] = h[(size_t)i].shared;
-      per_cand[5 * i + 3] = h[(size_t)i].opt_beg; per_cand[5 * i + 4] = h[(size_t)i].opt_end;
+      per_cand[6 * i] = h[(size_t)i].contig; per_cand[6 * i + 1] = h[(size_t)i].mean_pos; per_cand[6 * i + 2] = h[(size_t)i].shared;
+      per_cand[6 * i + 3] = h[(size_t)i].opt_beg; per_cand[6 * i + 4] = h[(size_t)i].opt_end; per_cand[6 * i + 5] = h[(size_t)i].accepted;
     }
   });
 }
@@ -355,7 +361,7 @@ int mm_em_create(mm_ctx* ctx, int64_t n_reads, const int64_t* read_off, const in
     *out = E;
   });
 }
-void mm_em_destroy(mm_em* em) { delete em; }
+void mm_em_destroy(mm_em* em) { if (em) { mm::current_stream() = em->ctx->stream; delete em; } }
 int mm_em_iterate(mm_em* em, const double* f, double* f_partial, double* ll_partial) {
   if (!em || !f || !f_partial || !ll_partial) return MM_ERR_ARG;
   return guarded(em->ctx, [&] { MM_HIP(hipSetDevice(em->ctx->device)); mm::em_iterate(em, f, f_partial, ll_partial); });

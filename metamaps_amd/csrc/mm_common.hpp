@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <stdexcept>
+#include <memory>
 #include "../../include/metamaps_hip.h"
 
 namespace mm {
@@ -28,6 +29,11 @@ struct Error : std::runtime_error {
 #define MM_KERNEL_CHECK() MM_HIP(hipGetLastError())
 
 // ---- device buffer ---------------------------------------------------------------------------------
+// Allocations are stream-ordered (hipMallocAsync on the context stream, pool kept warm), so that the dozens
+// of per-batch temporaries cost microseconds and never force a device-wide synchronisation the way
+// hipFree does.  The C ABI layer sets the current stream on entry (one ctx per host thread).
+inline hipStream_t& current_stream() { static thread_local hipStream_t s = nullptr; return s; }
+
 template <typename T>
 struct DBuf {
   T* p = nullptr;
@@ -42,9 +48,9 @@ struct DBuf {
   void alloc(size_t count) {
     release();
     n = count;
-    if (count) MM_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+    if (count) MM_HIP(hipMallocAsync((void**)&p, count * sizeof(T), current_stream()));
   }
-  void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+  void release() { if (p) { (void)hipFreeAsync(p, current_stream()); p = nullptr; } n = 0; }
   size_t bytes() const { return n * sizeof(T); }
   void zero(hipStream_t st) { if (n) MM_HIP(hipMemsetAsync(p, 0, bytes(), st)); }
   void upload(const T* h, size_t count, hipStream_t st) { if (count) MM_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, st)); }
@@ -144,6 +150,9 @@ struct mm_ctx {
   int cus = 0;
   void* comm = nullptr;          // ncclComm_t
   int comm_rank = 0, comm_size = 1;
+  // per-(k, pi) cache of the host statistics thresholds (pure functions of the sketch size), mm_stats.hpp
+  std::shared_ptr<void> lut_cache;
+  int lut_k = 0; float lut_pi = 0;
 };
 
 struct mm_seqset {

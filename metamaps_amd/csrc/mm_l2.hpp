@@ -1,0 +1,346 @@
+// K5 + K6 — L2 sliding MinHash window and strand vote, one wavefront per L1 candidate
+// (replaces Map::computeL2MappedRegions + the statistics part of doL2Mapping, computeMap.hpp:396-538;
+//  SlideMapper, slidingMap.hpp; MIIteratorL2::next, MIIteratorL2.hpp:74-96).
+//
+// Window sequence.  A window is the index range [b,e) with `sw_pos`; e is always the first entry with
+// wpos > sw_pos+cnt-1 and wpos[b] <= sw_pos < wpos[b+1].  Whenever b has just advanced, sw_pos == wpos[b]
+// and e == e_min(b) := lower_bound(wpos >= wpos[b]+cnt): every b is a re-entry point of the sequence.
+//
+// Exact skip-ahead (SKIP=true).  The reference evaluates ~1.16 windows per streamed index entry, each an
+// ordered-map update.  Only (max shared, first and last window reaching it, the first optimal window) are
+// outputs, so a window whose shared count provably stays below the best count found so far — or below the
+// acceptance threshold accept_min(s), since a candidate whose maximum is smaller is dropped by the identity
+// filter (computeMap.hpp:415) — cannot influence anything.  Upper bounds, per block of 64 consecutive b:
+//     shared(W) <= m_all(W)  = matched entries in W (query hash present, with multiplicity)
+//     if r0 + a(W) >= s  then pivot rank R(W) <= r0 and shared(W) <= m_lo(W) = matched entries of rank < r0,
+//         where a(W) = window-only entries below Q[r0] that are first occurrences in their contig (DP clear),
+//         a lower bound of the DISTINCT window-only hashes below Q[r0]  (mm_l2_core.hpp: R = min r with
+//         r + #distinct window-only hashes below Q[r] >= s).
+// All three are prefix-sum differences over per-entry class bits (ballot masks + block prefixes in LDS);
+// m is taken over the largest window of the block, a over the smallest, so the bound holds for every window
+// of the block.  r0 = pivot rank of the best window of the most promising block + 1/32 s.  Blocks that pass
+// are evaluated exactly by the serial slide, re-entering at (b, e_min(b)) with the state rebuilt in
+// parallel (LDS atomics; D and mt are order independent).  Everything skipped is provably below the final
+// maximum, so the result is bit-identical to the full slide (SKIP=false), which is kept as the fallback for
+// candidates with more than L2_MCAP streamed entries and as the cross-check in tests.
+#pragma once
+#include "mm_index.hpp"
+#include "mm_map.hpp"
+#include "mm_l2_core.hpp"
+
+namespace mm {
+
+constexpr int L2_MCAP = 8192;                      // max streamed entries handled by the skip path
+constexpr int L2_NBLK = L2_MCAP / 64;
+
+__device__ inline bool wave_has_hash(const Rec* __restrict__ pos, int64_t lo, int64_t hi, uint32_t h, int lane) {
+  for (int64_t base = lo; base < hi; base += 64) {               // `base` is wave-uniform
+    const int64_t j = base + lane;
+    const bool hit = (j < hi) && pos[j].hash == h;
+    if (__ballot(hit) != 0ull) return true;
+  }
+  return false;
+}
+__device__ inline int wave_sum(int v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return v; }
+__device__ inline int wave_min(int v) { for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64)); return v; }
+__device__ inline int wave_max(int v) { for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64)); return v; }
+__device__ inline int wave_excl_scan(int v, int lane) {
+  int inc = v;
+  for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+  return inc - v;
+}
+
+__host__ __device__ inline size_t l2_state_bytes(int smax) {      // Q | D | mt, rounded to 8 bytes
+  size_t b = (size_t)smax * 4 + (size_t)((smax + 1) & ~1) * 2 + (size_t)((smax + 31) / 32) * 4 + 16;
+  return (b + 7) & ~(size_t)7;
+}
+inline size_t l2_lds_bytes(int smax, bool skip) {
+  return l2_state_bytes(smax) + (skip ? (size_t)(L2_NBLK + 1) * (3 * 8 + 3 * 2) + 16 : 0);
+}
+
+template <bool SKIP>
+__global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restrict__ cand_read,
+                                                const uint32_t* __restrict__ sk_hash, const uint8_t* __restrict__ sk_strand,
+                                                const uint64_t* __restrict__ mz_off, const int32_t* __restrict__ sk_n,
+                                                const int32_t* __restrict__ read_len, const int32_t* __restrict__ accept_min,
+                                                int k, int w, int smax, L2Result* __restrict__ out,
+                                                unsigned long long* __restrict__ counters /* [0] streamed entries, [1] evaluated windows, [2] rebuilds */) {
+  extern __shared__ __align__(16) uint32_t lds[];
+  uint32_t* Q = lds;
+  uint16_t* D = (uint16_t*)(Q + smax);
+  uint32_t* mt = (uint32_t*)(D + ((smax + 1) & ~1));
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  const int r = cand_read[c];
+  const int s = sk_n[r];
+  const uint64_t qo = mz_off[r];
+  const int len = read_len[r];
+  for (int i = lane; i < s; i += 64) Q[i] = sk_hash[qo + i];
+  __syncthreads();
+
+  const int contig = cand[3 * c], rs = cand[3 * c + 1], re = cand[3 * c + 2];
+  const int cnt = len - (w - 1) - (k - 1);                       // computeMap.hpp:470
+  const Rec* __restrict__ pos = I.pos;
+  const int64_t first = index_search(I, contig, rs);             // :466
+  const int64_t last_end = index_search(I, contig, re + len);    // :477
+  const int64_t nmax = I.N - 1;
+  int amin = accept_min[r]; if (amin < 1) amin = 1;
+
+  L2State S{Q, D, mt, s, 0, 0, 0};
+
+  // e_min(b): first entry at or after b whose wpos >= wpos[b] + cnt (never beyond last_end)
+  auto e_min = [&](int64_t bb) -> int64_t {
+    const int target = pw_wpos(pos[bb].pw) + cnt;
+    int64_t lo = bb, hi = last_end;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (pw_wpos(pos[mid].pw) < target) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+
+  // ---- register-resident chunks of 64 consecutive entries at both window ends -------------------------
+  int64_t baseB = first, baseE = first;
+  Rec rb = pos[min(baseB + lane, nmax)], rE = rb;
+  int codeB = l2_classify(Q, s, rb.hash), codeE = codeB;
+  auto loadB = [&](int64_t nb) { baseB = nb; rb = pos[min(nb + lane, nmax)]; codeB = l2_classify(Q, s, rb.hash); };
+  auto loadE = [&](int64_t ne) { baseE = ne; rE = pos[min(ne + lane, nmax)]; codeE = l2_classify(Q, s, rE.hash); };
+
+  int64_t b = first, e = first;
+  int sw_pos = 0;
+  auto add_entry = [&](int64_t x) {                              // slidingMap.hpp:139-160
+    if (x - baseE >= 64 || x < baseE) loadE(x);
+    const int ln = (int)(x - baseE);
+    const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)rE.hash, ln);
+    const uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)rE.pw, ln);
+    const int code = __builtin_amdgcn_readlane(codeE, ln);
+    if (code == -(s + 1)) return;                                // above every query hash: never counted
+    if ((pw & PW_DP) && wave_has_hash(pos, b, x, h, lane)) return;   // REV: hash already in the window
+    if (code >= 0) l2_add_matched(S, code); else l2_add_wonly(S, -code - 1);
+  };
+  auto del_entry = [&](int64_t x, int64_t wend) {                // slidingMap.hpp:170-214
+    const int ln = (int)(x - baseB);
+    const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)rb.hash, ln);
+    const uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)rb.pw, ln);
+    const int code = __builtin_amdgcn_readlane(codeB, ln);
+    if (code == -(s + 1)) return;
+    if ((pw & PW_DN) && wave_has_hash(pos, x + 1, wend, h, lane)) return;   // NOOP: a later occurrence stays
+    if (code >= 0) l2_del_matched(S, code); else l2_del_wonly(S, -code - 1);
+  };
+
+  // ---- state of window [nb,ne) from scratch, all lanes (the arrays are order independent) ---------------
+  unsigned long long rebuilds = 0;
+  auto rebuild = [&](int64_t nb, int64_t ne) {
+    ++rebuilds;
+    for (int i = lane; i < s; i += 64) D[i] = 0;
+    for (int i = lane; i < (s + 31) / 32; i += 64) mt[i] = 0;
+    __syncthreads();
+    uint32_t* Dw = (uint32_t*)D;
+    for (int64_t base = nb; base < ne; base += 64) {
+      const int64_t j = base + lane;
+      if (j < ne) {
+        const Rec x = pos[j];
+        const int code = l2_classify(Q, s, x.hash);
+        if (code >= 0) atomicOr(&mt[code >> 5], 1u << (code & 31));
+        else {
+          const int g = -code - 1;
+          if (g < s) {
+            bool dup = false;
+            if (x.pw & PW_DP) for (int64_t t = j - 1; t >= nb; --t) if (pos[t].hash == x.hash) { dup = true; break; }
+            if (!dup) atomicAdd(&Dw[g >> 1], (g & 1) ? 0x10000u : 1u);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // pivot: R = min r with r + C(r) >= s
+    const int chunk = (s + 63) / 64;
+    const int r_lo = min(lane * chunk, s), r_hi = min(r_lo + chunk, s);
+    int local = 0;
+    for (int i = r_lo; i < r_hi; ++i) local += D[i];
+    const int basec = wave_excl_scan(local, lane);
+    int run = basec, myR = s;
+    for (int i = r_lo; i < r_hi; ++i) { run += D[i]; if (i + run >= s) { myR = i; break; } }
+    const int R = wave_min(myR);
+    int cb = 0;
+    for (int i = r_lo; i < r_hi && i < R; ++i) cb += D[i];
+    cb = wave_sum(cb);
+    int sh = 0;
+    for (int wd = lane; wd * 32 < R; wd += 64) {
+      uint32_t m = mt[wd];
+      const int rem = R - wd * 32;
+      if (rem < 32) m &= (1u << rem) - 1u;
+      sh += __popc(m);
+    }
+    sh = wave_sum(sh);
+    S.R = R; S.Cb = cb; S.shared = sh;
+    b = nb; e = ne;
+    sw_pos = pw_wpos(pos[nb].pw);
+    loadB(nb); loadE(ne);
+  };
+
+  // ---- the reference's loop body (computeMap.hpp:496-533): evaluate [b,e), then MIIteratorL2::next ------
+  int best = 0, bestR = 0, beg_pos = 0, last_pos = 0;
+  int64_t opt_b = 0, opt_e = 0;
+  unsigned long long evals = 0;
+  int probe_best = 0, probe_R = 0;
+  // slides while e < last_end and b < b_stop; TRACK=false only records the maximum (for the bound), it does
+  // not touch the reference-visible trackers
+  auto slide = [&](int64_t b_stop, bool track) {
+    while (e < last_end && b < b_stop) {
+      if (b + 1 - baseB >= 64 || b < baseB) loadB(b);
+      if (e - baseE >= 64 || e < baseE) loadE(e);
+      const int cur_wb = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rb.pw, (int)(b - baseB)));
+      if (track) {
+        if (S.shared > best) { best = S.shared; bestR = S.R; opt_b = b; opt_e = e; beg_pos = last_pos = cur_wb; }   // :510-518
+        else if (S.shared == best) last_pos = cur_wb;            // :520-524
+      } else if (S.shared > probe_best) { probe_best = S.shared; probe_R = S.R; }
+      ++evals;
+      const int wb1 = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rb.pw, (int)(b + 1 - baseB)));
+      const int we = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rE.pw, (int)(e - baseE)));
+      const int d_beg = wb1 - sw_pos, d_end = we - (sw_pos + cnt - 1);
+      const int adv = min(d_beg, d_end);                         // MIIteratorL2.hpp:83
+      sw_pos += adv;
+      if (adv == d_beg) { del_entry(b, e); ++b; }
+      if (adv == d_end) { add_entry(e); ++e; }
+    }
+  };
+
+  const int64_t M = last_end - first;
+  bool done = false;
+  if (SKIP && M <= L2_MCAP && M > 192) {
+    // ---- class bits of every streamed entry: ballot masks + block prefixes in LDS ----------------------
+    uint64_t* mAll = (uint64_t*)(lds + l2_state_bytes(smax) / 4);
+    uint64_t* mLo = mAll + (L2_NBLK + 1);
+    uint64_t* mA = mLo + (L2_NBLK + 1);
+    uint16_t* pAll = (uint16_t*)(mA + (L2_NBLK + 1));
+    uint16_t* pLo = pAll + (L2_NBLK + 1);
+    uint16_t* pA = pLo + (L2_NBLK + 1);
+    const int nblk = (int)((M + 63) >> 6);
+    auto pfx = [&](const uint64_t* m, const uint16_t* p, int64_t j) -> int {   // set bits among entries [first, j)
+      const int o = (int)(j - first), bk = o >> 6, bit = o & 63;
+      return (int)p[bk] + __popcll(m[bk] & ((1ull << bit) - 1ull));
+    };
+    auto classify_pass = [&](int r0, bool lo_pass) {
+      int runA = 0, runL = 0, runW = 0;
+      for (int bk = 0; bk < nblk; ++bk) {
+        const int64_t j = first + (int64_t)bk * 64 + lane;
+        bool all = false, lo = false, aw = false;
+        if (j < last_end) {
+          const Rec x = pos[j];
+          const int code = l2_classify(Q, s, x.hash);
+          all = code >= 0;
+          if (lo_pass) { lo = code >= 0 && code < r0; aw = code < 0 && (-code - 1) <= r0 && !(x.pw & PW_DP); }
+        }
+        const uint64_t ba = __ballot(all), bl = __ballot(lo), bw = __ballot(aw);
+        if (lane == 0) {
+          if (!lo_pass) { mAll[bk] = ba; pAll[bk] = (uint16_t)runA; }
+          else { mLo[bk] = bl; pLo[bk] = (uint16_t)runL; mA[bk] = bw; pA[bk] = (uint16_t)runW; }
+        }
+        runA += __popcll(ba); runL += __popcll(bl); runW += __popcll(bw);
+      }
+      if (lane == 0) {
+        if (!lo_pass) { mAll[nblk] = 0; pAll[nblk] = (uint16_t)runA; }
+        else { mLo[nblk] = 0; pLo[nblk] = (uint16_t)runL; mA[nblk] = 0; pA[nblk] = (uint16_t)runW; }
+      }
+      __syncthreads();
+    };
+    classify_pass(0, false);
+    // per block of 64 b's: largest window [bF, eHi), smallest window [bL, eLo)
+    // (lane l owns blocks l and l+64; L2_NBLK == 128)
+    int64_t eLo[2], eHi[2]; int ub_all[2];
+    for (int q = 0; q < 2; ++q) {
+      const int bk = lane + 64 * q;
+      eLo[q] = eHi[q] = last_end; ub_all[q] = -1;
+      if (bk < nblk) {
+        const int64_t bF = first + (int64_t)bk * 64, bL = min(bF + 63, last_end - 1);
+        eLo[q] = e_min(bF);
+        eHi[q] = (bL + 1 < last_end) ? e_min(bL + 1) : last_end;
+        if (eLo[q] < last_end) ub_all[q] = pfx(mAll, pAll, eHi[q]) - pfx(mAll, pAll, bF);
+      }
+    }
+    const int ubmax = wave_max(max(ub_all[0], ub_all[1]));
+    if (ubmax < amin) done = true;                               // no window can reach the acceptance threshold
+    else {
+      // most promising block first: its exact maximum is the initial bound, its pivot fixes r0
+      int key = max(ub_all[0], ub_all[1]) == ubmax ? ((ub_all[0] == ubmax) ? lane : lane + 64) : 1 << 20;
+      const int bk0 = wave_min(key);
+      {
+        const int64_t bF = first + (int64_t)bk0 * 64;
+        rebuild(bF, e_min(bF));
+        slide(bF + 64, false);
+      }
+      int lb = probe_best;
+      const int r0 = min(s, probe_R + max(8, s >> 5));
+      classify_pass(r0, true);
+      int ub2[2];
+      auto bound = [&](int q) -> int {
+        const int bk = lane + 64 * q;
+        if (bk >= nblk || eLo[q] >= last_end) return -1;
+        const int64_t bF = first + (int64_t)bk * 64, bL = min(bF + 63, last_end - 1);
+        const int a = eLo[q] > bL ? pfx(mA, pA, eLo[q]) - pfx(mA, pA, bL) : 0;
+        if (r0 + a >= s) return pfx(mLo, pLo, eHi[q]) - pfx(mLo, pLo, bF);
+        return ub_all[q];
+      };
+      ub2[0] = bound(0); ub2[1] = bound(1);
+      // sweep the blocks in order; exact evaluation only where the bound reaches max(best so far, amin)
+      bool live = false;                                         // state positioned at the first b of the next block
+      for (int bk = 0; bk < nblk; ++bk) {
+        const int u = __builtin_amdgcn_readlane(bk < 64 ? ub2[0] : ub2[1], bk & 63);
+        const int thr = max(max(lb, best), amin);
+        const int64_t bF = first + (int64_t)bk * 64;
+        if (u < thr) { live = false; continue; }
+        if (!(live && b == bF)) {
+          const int64_t em = e_min(bF);
+          if (em >= last_end) break;
+          rebuild(bF, em);
+        }
+        slide(bF + 64, true);
+        live = (b == bF + 64);
+        if (e >= last_end) break;
+      }
+      done = true;
+    }
+  }
+  if (!done) {                                                   // full slide, exactly the reference's order
+    for (int i = lane; i < s; i += 64) D[i] = 0;
+    for (int i = lane; i < (s + 31) / 32; i += 64) mt[i] = 0;
+    __syncthreads();
+    l2_reset(S);
+    const int64_t first_end = index_search(I, contig, pw_wpos(pos[first].pw) + cnt);   // :473
+    b = first; e = first;
+    loadB(first); loadE(first);
+    for (; e < first_end; ++e) add_entry(e);                     // first super-window, :489
+    sw_pos = pw_wpos(pos[first].pw);                             // MIIteratorL2.hpp:62
+    slide(last_end, true);
+  }
+
+  // K6 strand vote over the first optimal window (computeMap.hpp:424-433, slidingMap.hpp:232-254):
+  // sum over query ranks below the pivot that are present in the window of strandQ * strandR, where
+  // strandR comes from the LAST occurrence of the hash in the window (insert_ref overwrites, :155-156).
+  int strand = -1, accepted = 0;
+  if (best >= amin) {
+    accepted = 1;
+    int votes = 0;
+    for (int64_t j = opt_b + lane; j < opt_e; j += 64) {
+      const Rec x = pos[j];
+      const int code = l2_classify(Q, s, x.hash);
+      if (code >= 0 && code < bestR) {
+        bool later = false;
+        if (x.pw & PW_DN) for (int64_t t = j + 1; t < opt_e; ++t) if (pos[t].hash == x.hash) { later = true; break; }
+        if (!later) votes += (sk_strand[qo + code] ? 1 : -1) * pw_strand(x.pw);
+      }
+    }
+    votes = wave_sum(votes);
+    strand = votes > 0 ? 1 : -1;
+  }
+  if (lane == 0) {
+    L2Result o;
+    o.contig = contig; o.mean_pos = (beg_pos + last_pos) / 2;    // :537
+    o.shared = best; o.strand = strand; o.accepted = accepted; o.pad = 0;
+    o.opt_beg = opt_b; o.opt_end = opt_e;
+    out[c] = o;
+    atomicAdd(&counters[0], (unsigned long long)(last_end - first));
+    atomicAdd(&counters[1], evals);
+    atomicAdd(&counters[2], rebuilds);
+  }
+}
+
+}  // namespace mm

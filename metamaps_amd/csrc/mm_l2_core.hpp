@@ -50,37 +50,53 @@ MM_HD void l2_reset(L2State& S) { S.R = S.s; S.Cb = 0; S.shared = 0; }   // arra
 
 MM_HD bool l2_mt_test(const L2State& S, int r) { return (S.mt[r >> 5] >> (r & 31)) & 1u; }
 
-// a matched hash enters the window (first occurrence) / leaves it (last occurrence)
-MM_HD void l2_add_matched(L2State& S, int r) {
-  S.mt[r >> 5] |= 1u << (r & 31);
-  if (r < S.R) S.shared += 1;
+// Every event gathers all the array cells it can possibly need with INDEPENDENT loads first (on the device:
+// one LDS round trip instead of a chain of dependent ones), then decides in registers.
+
+// a matched hash enters the window (first occurrence, sign=+1) / leaves it (last occurrence, sign=-1)
+MM_HD void l2_matched_event(L2State& S, int r, int sign) {
+  const uint32_t bit = 1u << (r & 31);
+  uint32_t wd = S.mt[r >> 5];
+  wd = sign > 0 ? (wd | bit) : (wd & ~bit);
+  S.mt[r >> 5] = wd;
+  if (r < S.R) S.shared += sign;
 }
-MM_HD void l2_del_matched(L2State& S, int r) {
-  S.mt[r >> 5] &= ~(1u << (r & 31));
-  if (r < S.R) S.shared -= 1;
-}
-// a distinct W-only hash of gap g enters / leaves
-MM_HD void l2_add_wonly(L2State& S, int g) {
+MM_HD void l2_add_matched(L2State& S, int r) { l2_matched_event(S, r, +1); }
+MM_HD void l2_del_matched(L2State& S, int r) { l2_matched_event(S, r, -1); }
+
+// a distinct W-only hash of gap g enters (sign=+1) / leaves (sign=-1)
+MM_HD void l2_wonly_event(L2State& S, int g, int sign) {
   if (g >= S.s) return;
-  S.D[g] += 1;
-  if (g < S.R) {
-    S.Cb += 1;
-    if (S.R - 1 + S.Cb >= S.s) {                 // rank R-1 pushed out of the s smallest
-      S.R -= 1;
-      S.Cb -= S.D[S.R];
-      if (l2_mt_test(S, S.R)) S.shared -= 1;
+  const int R = S.R;
+  const int rm1 = R > 0 ? R - 1 : 0;            // rank just below the pivot (dummy 0 when R == 0)
+  const int rr = R < S.s ? R : S.s - 1;         // pivot rank (dummy s-1 when R == s)
+  int dg = S.D[g];
+  int dR = S.D[rr];
+  int dRm1 = S.D[rm1];
+  const uint32_t wR = S.mt[rr >> 5], wRm1 = S.mt[rm1 >> 5];
+  dg += sign;
+  S.D[g] = (uint16_t)dg;
+  if (g == rr) dR = dg;                         // the cells were read before the update
+  if (g == rm1) dRm1 = dg;
+  if (sign > 0) {
+    if (g < R) {
+      S.Cb += 1;
+      if (R - 1 + S.Cb >= S.s) {                // rank R-1 pushed out of the s smallest
+        S.R = R - 1;
+        S.Cb -= dRm1;
+        if ((wRm1 >> (rm1 & 31)) & 1u) S.shared -= 1;
+      }
+    }
+  } else {
+    if (g < R) S.Cb -= 1;
+    if (g <= R && R < S.s && R + S.Cb + dR < S.s) {   // rank R now fits among the s smallest
+      if ((wR >> (R & 31)) & 1u) S.shared += 1;
+      S.Cb += dR;
+      S.R = R + 1;
     }
   }
 }
-MM_HD void l2_del_wonly(L2State& S, int g) {
-  if (g >= S.s) return;
-  S.D[g] -= 1;
-  if (g < S.R) S.Cb -= 1;
-  if (g <= S.R && S.R < S.s && S.R + S.Cb + S.D[S.R] < S.s) {   // rank R now fits among the s smallest
-    if (l2_mt_test(S, S.R)) S.shared += 1;
-    S.Cb += S.D[S.R];
-    S.R += 1;
-  }
-}
+MM_HD void l2_add_wonly(L2State& S, int g) { l2_wonly_event(S, g, +1); }
+MM_HD void l2_del_wonly(L2State& S, int g) { l2_wonly_event(S, g, -1); }
 
 }  // namespace mm

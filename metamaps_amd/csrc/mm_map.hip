@@ -10,6 +10,8 @@
 //   K7  identity filter: a per-sketch-size integer threshold computed on the host (mm_stats.hpp)
 #include "mm_map.hpp"
 #include "mm_l2_core.hpp"
+#include "mm_l2.hpp"
+#include <cstdlib>
 #include "mm_stats.hpp"
 #include <algorithm>
 #include <numeric>
@@ -76,6 +78,20 @@ __global__ void __launch_bounds__(256) sketch_kernel(const Rec* __restrict__ rec
   }
   __syncthreads();
   if (threadIdx.x == 0) { sk_n[r] = (int32_t)carry; amb[r] = (uint8_t)s_amb; }
+}
+
+// compact copies for the host-side duplicate-hash tie-break (one workgroup per flagged read)
+__global__ void __launch_bounds__(256) gather_amb_kernel(const Rec* __restrict__ rec, const uint64_t* __restrict__ src_off,
+                                                         const uint64_t* __restrict__ dst_off, Rec* __restrict__ out) {
+  const uint64_t so = src_off[blockIdx.x], d0 = dst_off[blockIdx.x], n = dst_off[blockIdx.x + 1] - d0;
+  for (uint64_t i = threadIdx.x; i < n; i += 256) out[d0 + i] = rec[so + i];
+}
+__global__ void __launch_bounds__(256) scatter_strand_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ src_off,
+                                                             const uint64_t* __restrict__ dst_off, const int32_t* __restrict__ cnt,
+                                                             uint8_t* __restrict__ sk_strand) {
+  const uint64_t d0 = dst_off[blockIdx.x], so = src_off[blockIdx.x];
+  const int n = cnt[blockIdx.x];
+  for (int i = threadIdx.x; i < n; i += 256) sk_strand[so + i] = in[d0 + i];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -171,135 +187,6 @@ __global__ void l1_scan_kernel(const uint64_t* __restrict__ hits, const uint64_t
   }
   flush();
   if (!WRITE) cand_n[r] = nc;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// K5 + K6  one wavefront per L1 candidate
-// ---------------------------------------------------------------------------------------------------
-__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// wave-parallel: does any entry of pos[lo,hi) carry hash h?
-__device__ inline bool wave_has_hash(const Rec* __restrict__ pos, int64_t lo, int64_t hi, uint32_t h, int lane) {
-  for (int64_t base = lo; base < hi; base += 64) {               // `base` is wave-uniform
-    const int64_t j = base + lane;
-    const bool hit = (j < hi) && pos[j].hash == h;
-    if (__ballot(hit) != 0ull) return true;
-  }
-  return false;
-}
-
-__global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restrict__ cand_read,
-                                                const uint32_t* __restrict__ sk_hash, const uint8_t* __restrict__ sk_strand,
-                                                const uint64_t* __restrict__ mz_off, const int32_t* __restrict__ sk_n,
-                                                const int32_t* __restrict__ read_len, const int32_t* __restrict__ accept_min,
-                                                int k, int w, int smax, L2Result* __restrict__ out,
-                                                unsigned long long* __restrict__ counters /* [0]=stream entries, [1]=evaluations */) {
-  extern __shared__ __align__(16) uint32_t lds[];
-  uint32_t* Q = lds;
-  uint16_t* D = (uint16_t*)(Q + smax);
-  uint32_t* mt = (uint32_t*)(D + ((smax + 1) & ~1));
-  const int lane = threadIdx.x;
-  const int64_t c = blockIdx.x;
-  const int r = cand_read[c];
-  const int s = sk_n[r];
-  const uint64_t qo = mz_off[r];
-  const int len = read_len[r];
-  for (int i = lane; i < s; i += 64) { Q[i] = sk_hash[qo + i]; D[i] = 0; }
-  for (int i = lane; i < (s + 31) / 32; i += 64) mt[i] = 0;
-  __syncthreads();
-
-  const int contig = cand[3 * c], rs = cand[3 * c + 1], re = cand[3 * c + 2];
-  const int cnt = len - (w - 1) - (k - 1);                       // computeMap.hpp:470
-  const Rec* __restrict__ pos = I.pos;
-  const int64_t first = index_search(I, contig, rs);             // :466
-  const int64_t first_end = index_search(I, contig, pw_wpos(pos[first].pw) + cnt);   // :473
-  const int64_t last_end = index_search(I, contig, re + len);    // :477
-  const int64_t nmax = I.N - 1;
-
-  L2State S{Q, D, mt, s, 0, 0, 0};
-  l2_reset(S);
-
-  // register-resident chunks of 64 consecutive index entries at the two ends of the window
-  int64_t baseB = first, baseE = first;
-  Rec rb = pos[min(baseB + lane, nmax)], rE = rb;
-  int codeB = l2_classify(Q, s, rb.hash), codeE = codeB;
-  auto loadB = [&](int64_t nb) { baseB = nb; rb = pos[min(nb + lane, nmax)]; codeB = l2_classify(Q, s, rb.hash); };
-  auto loadE = [&](int64_t ne) { baseE = ne; rE = pos[min(ne + lane, nmax)]; codeE = l2_classify(Q, s, rE.hash); };
-
-  int64_t b = first, e = first;
-  auto add_entry = [&](int64_t x) {                              // slidingMap.hpp:139-160
-    if (x - baseE >= 64) loadE(x);
-    int ln = (int)(x - baseE);
-    uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)rE.hash, ln);
-    uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)rE.pw, ln);
-    int code = __builtin_amdgcn_readlane(codeE, ln);
-    if (code == -(s + 1)) return;                                // above every query hash: never counted
-    if ((pw & PW_DP) && wave_has_hash(pos, b, x, h, lane)) return;   // REV: hash already in the window
-    if (code >= 0) l2_add_matched(S, code); else l2_add_wonly(S, -code - 1);
-  };
-  auto del_entry = [&](int64_t x, int64_t wend) {                // slidingMap.hpp:170-214
-    int ln = (int)(x - baseB);
-    uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)rb.hash, ln);
-    uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)rb.pw, ln);
-    int code = __builtin_amdgcn_readlane(codeB, ln);
-    if (code == -(s + 1)) return;
-    if ((pw & PW_DN) && wave_has_hash(pos, x + 1, wend, h, lane)) return;   // NOOP: a later occurrence stays
-    if (code >= 0) l2_del_matched(S, code); else l2_del_wonly(S, -code - 1);
-  };
-
-  for (; e < first_end; ++e) add_entry(e);                       // first super-window, :489
-
-  int wpos_b = pw_wpos(pos[first].pw);
-  int sw_pos = wpos_b;                                           // MIIteratorL2.hpp:62
-  int best = 0, bestR = 0, beg_pos = 0, last_pos = 0;
-  int64_t opt_b = 0, opt_e = 0;
-  unsigned long long evals = 0;
-  while (e < last_end) {                                         // :496
-    if (b + 1 - baseB >= 64) loadB(b);
-    if (e - baseE >= 64) loadE(e);
-    const int cur_wb = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rb.pw, (int)(b - baseB)));
-    if (S.shared > best) { best = S.shared; bestR = S.R; opt_b = b; opt_e = e; beg_pos = last_pos = cur_wb; }   // :510-518
-    else if (S.shared == best) last_pos = cur_wb;                // :520-524
-    ++evals;
-    // MIIteratorL2::next, MIIteratorL2.hpp:74-96
-    const int wb1 = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rb.pw, (int)(b + 1 - baseB)));
-    const int we = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rE.pw, (int)(e - baseE)));
-    const int d_beg = wb1 - sw_pos, d_end = we - (sw_pos + cnt - 1);
-    const int adv = min(d_beg, d_end);
-    sw_pos += adv;
-    if (adv == d_beg) { del_entry(b, e); ++b; }
-    if (adv == d_end) { add_entry(e); ++e; }
-  }
-
-  // K6 strand vote over the first optimal window (computeMap.hpp:424-433, slidingMap.hpp:232-254):
-  // sum over query ranks below the pivot that are present in the window of strandQ * strandR, where
-  // strandR comes from the LAST occurrence of the hash in the window (insert_ref overwrites, :155-156).
-  int amin = accept_min[r]; if (amin < 1) amin = 1;
-  int strand = -1, accepted = 0;
-  if (best >= amin) {
-    accepted = 1;
-    int votes = 0;
-    for (int64_t j = opt_b + lane; j < opt_e; j += 64) {
-      Rec x = pos[j];
-      int code = l2_classify(Q, s, x.hash);
-      if (code >= 0 && code < bestR) {
-        bool later = false;
-        if (x.pw & PW_DN) for (int64_t t = j + 1; t < opt_e; ++t) if (pos[t].hash == x.hash) { later = true; break; }
-        if (!later) votes += (sk_strand[qo + code] ? 1 : -1) * pw_strand(x.pw);
-      }
-    }
-    for (int d = 32; d > 0; d >>= 1) votes += __shfl_xor(votes, d, 64);
-    strand = votes > 0 ? 1 : -1;
-  }
-  if (lane == 0) {
-    L2Result o;
-    o.contig = contig; o.mean_pos = (beg_pos + last_pos) / 2;    // :537
-    o.shared = best; o.strand = strand; o.accepted = accepted; o.pad = 0;
-    o.opt_beg = opt_b; o.opt_end = opt_e;
-    out[c] = o;
-    atomicAdd(&counters[0], (unsigned long long)(last_end - first));
-    atomicAdd(&counters[1], evals);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -418,9 +305,8 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         sketch_kernel<false><<<dim3((unsigned)cls.reads.size()), dim3(256), 0, st>>>(M->mz.rec.p, M->mz.off.p, list.p, cls.npow2, scratch.p,
                                                                                     M->sk_hash.p, M->sk_strand.p, M->sk_n.p, M->amb.p);
         MM_KERNEL_CHECK();
-        MM_HIP(hipStreamSynchronize(st));
       }
-      MM_HIP(hipStreamSynchronize(st));                          // `list` must outlive the launch
+      MM_HIP(hipStreamSynchronize(st));                          // cls.reads is the source of the async upload
     }
     T.end(t_sk);
   }
@@ -429,27 +315,52 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   // ---- duplicate-hash strand tie-break (computeMap.hpp:292-295: std::sort is not stable, std::unique keeps
   //      whichever equal-hash element introsort left first).  Only the strand of the survivor is observable
   //      (slidingMap.hpp:247), so it is resolved here with the same library calls on the same input order.
-  for (int64_t r = 0; r < n; ++r) {
-    if (!h_amb[(size_t)r]) continue;
-    M->stats.n_ambiguous_sketch_reads++;
-    const uint64_t o = hoff[(size_t)r]; const size_t cntr = (size_t)(hoff[(size_t)r + 1] - o);
-    std::vector<Rec> hr(cntr);
-    M->mz.rec.download(hr.data(), cntr, st, (size_t)o);
-    MM_HIP(hipStreamSynchronize(st));
-    std::vector<HostMz> v(cntr);
-    for (size_t i = 0; i < cntr; ++i) v[i] = HostMz{hr[i].hash, pw_wpos(hr[i].pw), pw_strand(hr[i].pw)};
-    std::sort(v.begin(), v.end(), host_less_by_hash);
-    auto ue = std::unique(v.begin(), v.end(), host_eq_by_hash);
-    size_t s = (size_t)(ue - v.begin());
-    MM_REQUIRE((int64_t)s == M->h_sk_n[(size_t)r], MM_ERR_DEVICE, "sketch size disagrees between device and host tie-break");
-    std::vector<uint8_t> sv(s);
-    for (size_t i = 0; i < s; ++i) sv[i] = v[i].strand == 1 ? 1 : 0;
-    MM_HIP(hipMemcpyAsync(M->sk_strand.p + o, sv.data(), s, hipMemcpyHostToDevice, st));
-    MM_HIP(hipStreamSynchronize(st));
+  {
+    std::vector<int64_t> amb_reads;
+    for (int64_t r = 0; r < n; ++r) if (h_amb[(size_t)r]) amb_reads.push_back(r);
+    M->stats.n_ambiguous_sketch_reads = (int64_t)amb_reads.size();
+    if (!amb_reads.empty()) {
+      const size_t na = amb_reads.size();
+      std::vector<uint64_t> so(na), dof(na + 1, 0);
+      for (size_t i = 0; i < na; ++i) {
+        int64_t r = amb_reads[i];
+        so[i] = hoff[(size_t)r];
+        dof[i + 1] = dof[i] + (hoff[(size_t)r + 1] - hoff[(size_t)r]);
+      }
+      DBuf<uint64_t> d_so(na), d_do(na + 1);
+      d_so.upload(so.data(), na, st); d_do.upload(dof.data(), na + 1, st);
+      DBuf<Rec> comp((size_t)dof[na]);
+      gather_amb_kernel<<<dim3((unsigned)na), dim3(256), 0, st>>>(M->mz.rec.p, d_so.p, d_do.p, comp.p);
+      MM_KERNEL_CHECK();
+      std::vector<Rec> hr = comp.to_host(st);
+      std::vector<uint8_t> sv((size_t)dof[na], 0);
+      std::vector<int32_t> scnt(na);
+      std::vector<HostMz> v;
+      for (size_t i = 0; i < na; ++i) {
+        const size_t cntr = (size_t)(dof[i + 1] - dof[i]);
+        v.resize(cntr);
+        for (size_t j = 0; j < cntr; ++j) { const Rec& x = hr[(size_t)dof[i] + j]; v[j] = HostMz{x.hash, pw_wpos(x.pw), pw_strand(x.pw)}; }
+        std::sort(v.begin(), v.end(), host_less_by_hash);
+        auto ue = std::unique(v.begin(), v.end(), host_eq_by_hash);
+        const size_t sN = (size_t)(ue - v.begin());
+        MM_REQUIRE((int64_t)sN == M->h_sk_n[(size_t)amb_reads[i]], MM_ERR_DEVICE, "sketch size disagrees between device and host tie-break");
+        for (size_t j = 0; j < sN; ++j) sv[(size_t)dof[i] + j] = v[j].strand == 1 ? 1 : 0;
+        scnt[i] = (int32_t)sN;
+      }
+      DBuf<uint8_t> d_sv(sv.size()); d_sv.upload(sv.data(), sv.size(), st);
+      DBuf<int32_t> d_cnt(na); d_cnt.upload(scnt.data(), na, st);
+      scatter_strand_kernel<<<dim3((unsigned)na), dim3(256), 0, st>>>(d_sv.p, d_so.p, d_do.p, d_cnt.p, M->sk_strand.p);
+      MM_KERNEL_CHECK();
+      MM_HIP(hipStreamSynchronize(st));                          // host vectors above are the H2D sources
+    }
   }
   // ---- K7 host thresholds per distinct sketch size
   {
-    stats::LutCache lut(P.k, P.perc_identity);
+    if (!ctx->lut_cache || ctx->lut_k != P.k || ctx->lut_pi != P.perc_identity) {
+      ctx->lut_cache = std::make_shared<stats::LutCache>(P.k, P.perc_identity);
+      ctx->lut_k = P.k; ctx->lut_pi = P.perc_identity;
+    }
+    stats::LutCache& lut = *static_cast<stats::LutCache*>(ctx->lut_cache.get());
     std::vector<int32_t> mh((size_t)n, 0), am((size_t)n, 0);
     int smax = 0;
     for (int64_t r = 0; r < n; ++r) {
@@ -545,18 +456,28 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     // ---- K5/K6
     MM_REQUIRE(ncand < (1LL << 31), MM_ERR_LIMIT, "more than 2^31 L1 candidates in one batch");
     const int smax = M->smax;
-    const size_t lds = (size_t)smax * 4 + (size_t)((smax + 1) & ~1) * 2 + (size_t)((smax + 31) / 32) * 4 + 16;
+    const char* full_env = getenv("MM_L2_FULL");                 // cross-check switch: evaluate every window
+    const bool skip = !(full_env && full_env[0] == '1');
+    const size_t lds = l2_lds_bytes(smax, skip);
     MM_REQUIRE(lds <= 160 * 1024, MM_ERR_LIMIT, "sketch too large for the L2 window state in LDS (read longer than ~115 kb at w=8)");
-    if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)l2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    DBuf<unsigned long long> counters(2); counters.zero(st);
+    if (lds > 64 * 1024) {
+      MM_HIP(hipFuncSetAttribute((const void*)l2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      MM_HIP(hipFuncSetAttribute((const void*)l2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    DBuf<unsigned long long> counters(3); counters.zero(st);
     const size_t t_l2 = T.begin(&M->stats.ms_l2);
-    l2_kernel<<<dim3((unsigned)ncand), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p,
-                                                           M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p);
+    if (skip)
+      l2_kernel<true><<<dim3((unsigned)ncand), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p,
+                                                                   M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p);
+    else
+      l2_kernel<false><<<dim3((unsigned)ncand), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p,
+                                                                    M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p);
     MM_KERNEL_CHECK();
     T.end(t_l2);
     auto hc = counters.to_host(st);
     M->stats.sum_l2_stream_entries = (int64_t)hc[0];
     M->stats.sum_l2_evals = (int64_t)hc[1];
+    M->stats.n_l2_rebuilds = (int64_t)hc[2];
     // ---- compaction
     const size_t t_cp = T.begin(&M->stats.ms_compact);
     DBuf<uint32_t> flag((size_t)ncand);

@@ -144,6 +144,7 @@ typedef struct {
   /* algorithmic-traffic counters */
   int64_t sum_sketch, sum_hits, n_candidates, sum_l2_stream_entries, sum_l2_evals;
   int64_t n_ambiguous_sketch_reads;   /* reads whose duplicate-hash strands needed the std::sort tie-break */
+  int64_t sum_hits_kept;              /* seed hits left after the exact run pre-filter (K3c) */
   int64_t n_l2_rebuilds;              /* window states rebuilt from scratch by the exact skip-ahead of K5 */
   /* device time of each stage of this batch, milliseconds, from hipEvents recorded on the ctx stream
    * around the launches (bench.py's roofline uses ms_l2 = the K5/K6 kernel) */

@@ -20,6 +20,12 @@ __global__ void head_flags_kernel(const uint32_t* __restrict__ key, int64_t n, u
   if (i < n) flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
 }
 
+// paranoia for > 2^32-element library sorts: number of adjacent inversions must be zero
+__global__ void count_inversions_kernel(const uint32_t* __restrict__ key, int64_t n, unsigned long long* __restrict__ bad) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i + 1 < n && key[i] > key[i + 1]) atomicAdd(bad, 1ull);
+}
+
 __global__ void csr_fill_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ rank,
                                 int64_t n, uint32_t* __restrict__ uh, uint64_t* __restrict__ ustart) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,6 +120,11 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
     DBuf<uint8_t> tmp(tmp_bytes);
     MM_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, key_in.p, key_out.p, val_in.p, I->occ.p, (size_t)N, 0, 32, st));
     MM_HIP(hipStreamSynchronize(st));
+    DBuf<unsigned long long> bad(1); bad.zero(st);
+    count_inversions_kernel<<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, N, bad.p);
+    MM_KERNEL_CHECK();
+    auto hb = bad.to_host(st);
+    MM_REQUIRE(hb[0] == 0, MM_ERR_DEVICE, "radix sort of the index left the hash keys unsorted");
   }
   key_in.release(); val_in.release();
   // CSR over unique hashes

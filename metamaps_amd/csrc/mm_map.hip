@@ -131,6 +131,70 @@ __global__ void __launch_bounds__(256) gather_hits_kernel(IndexView I, const uin
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K3c  exact seed-hit pre-filter.  At miniSeq+H density the 32-bit hash space is saturated:
+// a read draws ~10^4 chance hits scattered over the whole reference, and only hits that sit in a run of
+// `minimumHits` hits of one contig spanning less than the read length can ever produce or shape an L1
+// candidate (computeMap.hpp:357-385).  Such a run lies inside two adjacent position bins of width = read
+// length, so a hit can be dropped when both bin pairs around it hold fewer than minimumHits hits.  Bin
+// counts live in a hashed LDS counter table (collisions only over-count, so nothing needed is lost).
+// Dropping hits that belong to no qualifying run leaves every qualifying run intact and cannot create a
+// new one (a run that qualifies after dropping also qualifies before, so none of its members was dropped).
+// ---------------------------------------------------------------------------------------------------
+constexpr int HF_SLOTS = 8192;
+__device__ inline uint32_t hf_slot(uint32_t contig, uint32_t bin) {
+  uint32_t x = contig * 0x9E3779B1u ^ (bin + 0x7F4A7C15u) * 0x85EBCA77u;
+  x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
+  return x & (HF_SLOTS - 1);
+}
+template <bool WRITE>
+__global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint64_t* __restrict__ off, const int32_t* __restrict__ sk_n,
+                                                         const uint32_t* __restrict__ probe_cnt, const uint64_t* __restrict__ probe_start,
+                                                         const int32_t* __restrict__ read_len, const int32_t* __restrict__ min_hits,
+                                                         uint32_t* __restrict__ surv_n, const uint64_t* __restrict__ read_hit_off,
+                                                         uint64_t* __restrict__ hits) {
+  __shared__ uint32_t cnt[HF_SLOTS];
+  __shared__ uint32_t cursor;
+  const int r = blockIdx.x;
+  const uint64_t o = off[r];
+  const int s = sk_n[r];
+  const uint32_t len = (uint32_t)max(read_len[r], 1);
+  int m = min_hits[r]; if (m < 1) m = 1;
+  for (int i = threadIdx.x; i < HF_SLOTS; i += 256) cnt[i] = 0;
+  if (threadIdx.x == 0) cursor = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < s; i += 256) {
+    const uint32_t c = probe_cnt[o + i];
+    const uint64_t* src = I.occ + probe_start[o + i];
+    for (uint32_t j = 0; j < c; ++j) {
+      const uint64_t h = src[j];
+      atomicAdd(&cnt[hf_slot((uint32_t)(h >> 32), (uint32_t)pw_wpos((uint32_t)h) / len)], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t mine = 0;
+  const uint64_t wbase = WRITE ? read_hit_off[r] : 0;
+  for (int i = threadIdx.x; i < s; i += 256) {
+    const uint32_t c = probe_cnt[o + i];
+    const uint64_t* src = I.occ + probe_start[o + i];
+    for (uint32_t j = 0; j < c; ++j) {
+      const uint64_t h = src[j];
+      const uint32_t ct = (uint32_t)(h >> 32), bin = (uint32_t)pw_wpos((uint32_t)h) / len;
+      const uint32_t c0 = cnt[hf_slot(ct, bin)];
+      const uint32_t cl = bin > 0 ? cnt[hf_slot(ct, bin - 1)] : 0u, cr = cnt[hf_slot(ct, bin + 1)];
+      if (c0 + cl >= (uint32_t)m || c0 + cr >= (uint32_t)m) {
+        if (WRITE) hits[wbase + atomicAdd(&cursor, 1u)] = h & ~(uint64_t)(PW_DP | PW_DN);
+        else ++mine;
+      }
+    }
+  }
+  if (!WRITE) {
+    uint64_t tot;
+    block_excl_scan_u64(mine, &tot);
+    if (threadIdx.x == 0) surv_n[r] = (uint32_t)tot;
+  }
+}
+
 __global__ void read_hit_bounds_kernel(const uint64_t* __restrict__ off, const uint64_t* __restrict__ hit_off, int64_t n,
                                        uint64_t* __restrict__ read_hit_off) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -391,14 +455,31 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   }
   exclusive_scan_u32_u64(probe_cnt.p, total_mz, hit_off.p, scan_tmp, st);
   M->read_hit_off.alloc((size_t)n + 1);
-  read_hit_bounds_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(M->mz.off.p, hit_off.p, n, M->read_hit_off.p);
-  MM_KERNEL_CHECK();
+  uint64_t raw_hits = 0;
+  MM_HIP(hipMemcpyAsync(&raw_hits, hit_off.p + total_mz, sizeof raw_hits, hipMemcpyDeviceToHost, st));
+  const char* nf_env = getenv("MM_NO_HIT_FILTER");               // parity tests of the raw hit list
+  const bool use_filter = !(nf_env && nf_env[0] == '1');
+  if (use_filter && n > 0) {
+    DBuf<uint32_t> surv((size_t)n + 1); surv.zero(st);
+    hit_filter_kernel<false><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
+                                                                   M->min_hits.p, surv.p, nullptr, nullptr);
+    MM_KERNEL_CHECK();
+    exclusive_scan_u32_u64(surv.p, n, M->read_hit_off.p, scan_tmp, st);
+  } else {
+    read_hit_bounds_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(M->mz.off.p, hit_off.p, n, M->read_hit_off.p);
+    MM_KERNEL_CHECK();
+  }
   M->h_read_hit_off = M->read_hit_off.to_host(st);
   const int64_t total_hits = (int64_t)M->h_read_hit_off[(size_t)n];
-  M->stats.sum_hits = total_hits;
+  M->stats.sum_hits = (int64_t)raw_hits;
+  M->stats.sum_hits_kept = total_hits;
   M->hits.alloc((size_t)std::max<int64_t>(total_hits, 1));
   if (total_hits > 0) {
-    gather_hits_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, hit_off.p, M->hits.p);
+    if (use_filter)
+      hit_filter_kernel<true><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
+                                                                    M->min_hits.p, nullptr, M->read_hit_off.p, M->hits.p);
+    else
+      gather_hits_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, hit_off.p, M->hits.p);
     MM_KERNEL_CHECK();
   }
   T.end(t_pg);

@@ -123,8 +123,9 @@ def test_index_matches_oracle(ctx, oracle_lib, mini, k, w):
 
 
 @pytest.mark.parametrize("k,w,force_thr", [(16, 13, None), (16, 8, None), (16, 8, 3)])
-def test_mapping_stages_match_oracle(ctx, oracle_lib, mini, k, w, force_thr):
+def test_mapping_stages_match_oracle(ctx, oracle_lib, mini, k, w, force_thr, monkeypatch):
     from metamaps_amd import capi
+    monkeypatch.setenv("MM_NO_HIT_FILTER", "1")        # compare the raw seed-hit list; the filter has its own test below
     names, contigs = _read_fasta(mini["db"].fasta)
     rnames, reads = _read_fastq(mini["reads"])
     S = ctx.seqset(contigs)
@@ -235,4 +236,26 @@ def test_l2_skip_ahead_equals_full_slide(ctx, monkeypatch):
     s_skip, s_full = res["0"][2], res["1"][2]
     assert s_full["n_mappings"] > 5000 and s_skip["n_l2_rebuilds"] > 0
     assert s_skip["sum_l2_evals"] < s_full["sum_l2_evals"]
+    idx.close(); reads.close(); ref.close()
+
+
+def test_hit_prefilter_keeps_candidates_identical(ctx, monkeypatch):
+    """K3c drops seed hits that cannot belong to a qualifying run; candidates and mappings must not change."""
+    ref = ctx.synth_reference(seed=6, n_species=40, strains_per_species=4, genome_len=300_000, strain_divergence=0.02, genus_divergence=0.08)
+    reads, _ = ctx.synth_reads(ref, seed=10, n_reads=2000, read_len=6000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.1, n_abundant=30)
+    idx = ctx.index(ref, 16, 8)
+    idx.set_freq_threshold(2**31 - 1)                  # keep every hash: many chance hits
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MM_NO_HIT_FILTER", mode)
+        M = ctx.map_batch(idx, reads, 16, 8)
+        coff, cand = M.debug_candidates()
+        off, rec = M.fetch()
+        res[mode] = (coff.copy(), cand.copy(), off.copy(), rec.copy(), M.stats())
+        M.close()
+    monkeypatch.delenv("MM_NO_HIT_FILTER")
+    for i in range(4):
+        assert np.array_equal(res["0"][i], res["1"][i]), i
+    assert res["0"][4]["sum_hits_kept"] < res["1"][4]["sum_hits_kept"] == res["1"][4]["sum_hits"]
+    assert res["0"][4]["n_candidates"] > 2000
     idx.close(); reads.close(); ref.close()

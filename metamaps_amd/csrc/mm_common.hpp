@@ -34,23 +34,36 @@ struct Error : std::runtime_error {
 // hipFree does.  The C ABI layer sets the current stream on entry (one ctx per host thread).
 inline hipStream_t& current_stream() { static thread_local hipStream_t s = nullptr; return s; }
 
+constexpr size_t DIRECT_ALLOC_BYTES = (size_t)8 << 30;   // index-scale buffers bypass the pool (no fragmentation, exact accounting)
+
 template <typename T>
 struct DBuf {
   T* p = nullptr;
   size_t n = 0;
+  bool direct = false;
   DBuf() = default;
   explicit DBuf(size_t count) { alloc(count); }
   DBuf(const DBuf&) = delete;
   DBuf& operator=(const DBuf&) = delete;
-  DBuf(DBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
-  DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+  DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), direct(o.direct) { o.p = nullptr; o.n = 0; }
+  DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; direct = o.direct; o.p = nullptr; o.n = 0; } return *this; }
   ~DBuf() { release(); }
   void alloc(size_t count) {
     release();
     n = count;
-    if (count) MM_HIP(hipMallocAsync((void**)&p, count * sizeof(T), current_stream()));
+    if (!count) return;
+    direct = count * sizeof(T) >= DIRECT_ALLOC_BYTES;
+    if (direct) { MM_HIP(hipStreamSynchronize(current_stream())); MM_HIP(hipMalloc((void**)&p, count * sizeof(T))); }
+    else MM_HIP(hipMallocAsync((void**)&p, count * sizeof(T), current_stream()));
   }
-  void release() { if (p) { (void)hipFreeAsync(p, current_stream()); p = nullptr; } n = 0; }
+  void release() {
+    if (p) {
+      if (direct) { (void)hipStreamSynchronize(current_stream()); (void)hipFree(p); }
+      else (void)hipFreeAsync(p, current_stream());
+      p = nullptr;
+    }
+    n = 0;
+  }
   size_t bytes() const { return n * sizeof(T); }
   void zero(hipStream_t st) { if (n) MM_HIP(hipMemsetAsync(p, 0, bytes(), st)); }
   void upload(const T* h, size_t count, hipStream_t st) { if (count) MM_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, st)); }

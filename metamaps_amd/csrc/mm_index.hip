@@ -6,31 +6,74 @@
 #include "mm_minimizer.hpp"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
+#include <cstdlib>
 
 namespace mm {
 
 __global__ void split_records_kernel(const Rec* __restrict__ rec, const uint32_t* __restrict__ rec_seq, int64_t n,
                                      uint32_t* __restrict__ key, uint64_t* __restrict__ val) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { Rec r = rec[i]; key[i] = r.hash; val[i] = ((uint64_t)rec_seq[i] << 32) | r.pw; }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    Rec r = rec[i]; key[i] = r.hash; val[i] = ((uint64_t)rec_seq[i] << 32) | r.pw;
+  }
+}
+
+// ---- partitioned sort for indexes beyond the library sort's 32-bit element range -------------------------
+// 65536-bin histogram over the top 16 hash bits picks hash ranges of at most PART_MAX entries; each range is
+// selected in input order (stable: tile counts -> scan -> ordered tile writes), sorted by the library, and
+// lands at its final offset.
+constexpr int64_t PART_MAX_DEFAULT = 1500000000LL;
+constexpr int SEL_TILE = 2048;
+__global__ void __launch_bounds__(256) top16_hist_kernel(const Rec* __restrict__ rec, int64_t n, unsigned long long* __restrict__ hist) {
+  __shared__ unsigned int lh[65536 / 4];                          // four passes of 16384 bins keep LDS at 64 KiB
+  for (int pass = 0; pass < 4; ++pass) {
+    for (int i = threadIdx.x; i < 16384; i += 256) lh[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      uint32_t b = rec[i].hash >> 16;
+      if ((int)(b >> 14) == pass) atomicAdd(&lh[b & 16383], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16384; i += 256) if (lh[i]) atomicAdd(&hist[pass * 16384 + i], (unsigned long long)lh[i]);
+    __syncthreads();
+  }
+}
+template <bool WRITE>
+__global__ void __launch_bounds__(256) select_range_kernel(const Rec* __restrict__ rec, const uint32_t* __restrict__ rec_seq, int64_t n,
+                                                           uint32_t lo16, uint32_t hi16, uint32_t* __restrict__ tile_cnt,
+                                                           const uint64_t* __restrict__ tile_off, uint32_t* __restrict__ key, uint64_t* __restrict__ val) {
+  const int64_t base = (int64_t)blockIdx.x * SEL_TILE + (int64_t)threadIdx.x * (SEL_TILE / 256);
+  uint32_t mask = 0;
+#pragma unroll
+  for (int i = 0; i < SEL_TILE / 256; ++i) {
+    int64_t j = base + i;
+    if (j < n) { uint32_t b = rec[j].hash >> 16; if (b >= lo16 && b < hi16) mask |= 1u << i; }
+  }
+  uint64_t tot;
+  uint64_t ex = block_excl_scan_u64(__popc(mask), &tot);
+  if (!WRITE) { if (threadIdx.x == 0) tile_cnt[blockIdx.x] = (uint32_t)tot; return; }
+  uint64_t o = tile_off[blockIdx.x] + ex;
+#pragma unroll
+  for (int i = 0; i < SEL_TILE / 256; ++i)
+    if (mask & (1u << i)) { Rec r = rec[base + i]; key[o] = r.hash; val[o] = ((uint64_t)rec_seq[base + i] << 32) | r.pw; ++o; }
 }
 
 __global__ void head_flags_kernel(const uint32_t* __restrict__ key, int64_t n, uint32_t* __restrict__ flag) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
 }
 
 // paranoia for > 2^32-element library sorts: number of adjacent inversions must be zero
 __global__ void count_inversions_kernel(const uint32_t* __restrict__ key, int64_t n, unsigned long long* __restrict__ bad) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i + 1 < n && key[i] > key[i + 1]) atomicAdd(bad, 1ull);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (key[i] > key[i + 1]) atomicAdd(bad, 1ull);
 }
 
 __global__ void csr_fill_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ rank,
                                 int64_t n, uint32_t* __restrict__ uh, uint64_t* __restrict__ ustart) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && flag[i]) { uint64_t u = rank[i]; uh[u] = key[i]; ustart[u] = (uint64_t)i; }
-  if (i == n) ustart[rank[n]] = (uint64_t)n;        // rank[n] = U (scan total)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < n && flag[i]) { uint64_t u = rank[i]; uh[u] = key[i]; ustart[u] = (uint64_t)i; }
+    if (i == n) ustart[rank[n]] = (uint64_t)n;      // rank[n] = U (scan total)
+  }
 }
 
 __global__ void bucket_kernel(const uint32_t* __restrict__ uh, int64_t U, int bits, uint64_t* __restrict__ bkt) {
@@ -49,21 +92,21 @@ __global__ void bucket_kernel(const uint32_t* __restrict__ uh, int64_t U, int bi
 // occurrence of this hash inside the window?", which only same-contig neighbours can answer yes to).
 __global__ void dup_flags_kernel(const uint32_t* __restrict__ key, const uint64_t* __restrict__ val, int64_t n,
                                  const uint64_t* __restrict__ cstart, Rec* __restrict__ pos, unsigned long long* __restrict__ ndup) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i + 1 >= n) return;
-  if (key[i] != key[i + 1]) return;
-  uint64_t a = val[i], b = val[i + 1];
-  if ((a >> 32) != (b >> 32)) return;
-  int32_t c = (int32_t)(a >> 32);
-  auto ordinal = [&](uint32_t pw) {
-    int32_t p = pw_wpos(pw);
-    int64_t lo = (int64_t)cstart[c], hi = (int64_t)cstart[c + 1];
-    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (pw_wpos(pos[mid].pw) < p) lo = mid + 1; else hi = mid; }
-    return lo;
-  };
-  atomicOr(&pos[ordinal((uint32_t)a)].pw, PW_DN);
-  atomicOr(&pos[ordinal((uint32_t)b)].pw, PW_DP);
-  atomicAdd(ndup, 1ull);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (key[i] != key[i + 1]) continue;
+    uint64_t a = val[i], b = val[i + 1];
+    if ((a >> 32) != (b >> 32)) continue;
+    int32_t c = (int32_t)(a >> 32);
+    auto ordinal = [&](uint32_t pw) {
+      int32_t p = pw_wpos(pw);
+      int64_t lo = (int64_t)cstart[c], hi = (int64_t)cstart[c + 1];
+      while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (pw_wpos(pos[mid].pw) < p) lo = mid + 1; else hi = mid; }
+      return lo;
+    };
+    atomicOr(&pos[ordinal((uint32_t)a)].pw, PW_DN);
+    atomicOr(&pos[ordinal((uint32_t)b)].pw, PW_DP);
+    atomicAdd(ndup, 1ull);
+  }
 }
 
 constexpr int HIST_BINS = 4096;
@@ -84,6 +127,12 @@ __global__ void __launch_bounds__(256) count_hist_kernel(const uint64_t* __restr
 
 void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* I) {
   hipStream_t st = ctx->stream;
+  {                                                             // hand cached pool blocks back before the big allocations
+    hipMemPool_t pool;
+    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(hipDeviceGetDefaultMemPool(&pool, ctx->device));
+    MM_HIP(hipMemPoolTrimTo(pool, 0));
+  }
   I->ctx = ctx; I->k = k; I->w = w;
   I->n_contigs = contigs->count();
   I->contig_len = contigs->len;
@@ -106,20 +155,63 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
     MM_HIP(hipStreamSynchronize(st));
     return;
   }
-  const unsigned nblk = (unsigned)ceil_div(N, 256);
+  // HIP caps gridDim.x*blockDim.x below 2^32 threads: per-element kernels are grid-stride loops on a capped grid
+  const unsigned nblk = (unsigned)std::min<int64_t>(ceil_div(N, 256), 1 << 22);
   // sort (hash -> contig<<32|pw) by hash, stable
-  DBuf<uint32_t> key_in((size_t)N), key_out((size_t)N);
-  DBuf<uint64_t> val_in((size_t)N);
+  DBuf<uint32_t> key_in, key_out((size_t)N);
+  DBuf<uint64_t> val_in;
   I->occ.alloc((size_t)N);
-  split_records_kernel<<<dim3(nblk), dim3(256), 0, st>>>(I->pos.p, ms.rec_seq.p, N, key_in.p, val_in.p);
-  MM_KERNEL_CHECK();
-  ms.rec_seq.release();
-  {
+  auto library_sort = [&](uint32_t* kin, uint64_t* vin, uint32_t* kout, uint64_t* vout, size_t cnt) {
     size_t tmp_bytes = 0;
-    MM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in.p, key_out.p, val_in.p, I->occ.p, (size_t)N, 0, 32, st));
+    MM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, cnt, 0, 32, st));
     DBuf<uint8_t> tmp(tmp_bytes);
-    MM_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, key_in.p, key_out.p, val_in.p, I->occ.p, (size_t)N, 0, 32, st));
+    MM_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kin, kout, vin, vout, cnt, 0, 32, st));
     MM_HIP(hipStreamSynchronize(st));
+  };
+  const char* pm_env = getenv("MM_INDEX_PART_MAX");              // tests force the partitioned path on small inputs
+  const int64_t PART_MAX = pm_env ? std::max<int64_t>(atoll(pm_env), 1) : PART_MAX_DEFAULT;
+  if (N <= PART_MAX) {
+    key_in.alloc((size_t)N); val_in.alloc((size_t)N);
+    split_records_kernel<<<dim3(nblk), dim3(256), 0, st>>>(I->pos.p, ms.rec_seq.p, N, key_in.p, val_in.p);
+    MM_KERNEL_CHECK();
+    ms.rec_seq.release();
+    library_sort(key_in.p, val_in.p, key_out.p, I->occ.p, (size_t)N);
+  } else {
+    DBuf<unsigned long long> d_hist(65536); d_hist.zero(st);
+    top16_hist_kernel<<<dim3(2048), dim3(256), 0, st>>>(I->pos.p, N, d_hist.p);
+    MM_KERNEL_CHECK();
+    auto hist = d_hist.to_host(st);
+    std::vector<std::pair<uint32_t, uint32_t>> parts;            // [lo16, hi16)
+    std::vector<int64_t> part_cnt;
+    {
+      uint32_t lo = 0; int64_t acc = 0;
+      for (uint32_t b = 0; b < 65536; ++b) {
+        MM_REQUIRE((int64_t)hist[b] <= PART_MAX, MM_ERR_LIMIT, "one 16-bit hash prefix holds more than 1.5e9 index entries");
+        if (acc + (int64_t)hist[b] > PART_MAX) { parts.push_back({lo, b}); part_cnt.push_back(acc); lo = b; acc = 0; }
+        acc += (int64_t)hist[b];
+      }
+      parts.push_back({lo, 65536u}); part_cnt.push_back(acc);
+    }
+    const int64_t ntile = ceil_div(N, SEL_TILE);
+    DBuf<uint32_t> tcnt((size_t)ntile);
+    DBuf<uint64_t> toff((size_t)ntile + 1), scan_tmp2;
+    int64_t maxp = 0; for (auto c : part_cnt) maxp = std::max(maxp, c);
+    key_in.alloc((size_t)maxp); val_in.alloc((size_t)maxp);
+    int64_t done = 0;
+    for (size_t p = 0; p < parts.size(); ++p) {
+      if (part_cnt[p] == 0) continue;
+      select_range_kernel<false><<<dim3((unsigned)ntile), dim3(256), 0, st>>>(I->pos.p, ms.rec_seq.p, N, parts[p].first, parts[p].second, tcnt.p, nullptr, nullptr, nullptr);
+      MM_KERNEL_CHECK();
+      exclusive_scan_u32_u64(tcnt.p, ntile, toff.p, scan_tmp2, st);
+      select_range_kernel<true><<<dim3((unsigned)ntile), dim3(256), 0, st>>>(I->pos.p, ms.rec_seq.p, N, parts[p].first, parts[p].second, nullptr, toff.p, key_in.p, val_in.p);
+      MM_KERNEL_CHECK();
+      library_sort(key_in.p, val_in.p, key_out.p + done, I->occ.p + done, (size_t)part_cnt[p]);
+      done += part_cnt[p];
+    }
+    MM_REQUIRE(done == N, MM_ERR_DEVICE, "partitioned sort lost index entries");
+    ms.rec_seq.release();
+  }
+  {
     DBuf<unsigned long long> bad(1); bad.zero(st);
     count_inversions_kernel<<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, N, bad.p);
     MM_KERNEL_CHECK();
@@ -138,7 +230,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   MM_HIP(hipStreamSynchronize(st));
   I->U = (int64_t)U;
   I->uh.alloc((size_t)U); I->ustart.alloc((size_t)U + 1);
-  csr_fill_kernel<<<dim3((unsigned)ceil_div(N + 1, 256)), dim3(256), 0, st>>>(key_out.p, flag.p, rank.p, N, I->uh.p, I->ustart.p);
+  csr_fill_kernel<<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, flag.p, rank.p, N, I->uh.p, I->ustart.p);
   MM_KERNEL_CHECK();
   flag.release(); rank.release();
   // bucket table over hash prefixes

@@ -105,8 +105,10 @@ def mini(tmp_path_factory, oracle_lib):
     return {"dir": str(d), "db": db, "reads": rd["path"]}
 
 
-@pytest.mark.parametrize("k,w", [(16, 13), (16, 8)])
-def test_index_matches_oracle(ctx, oracle_lib, mini, k, w):
+@pytest.mark.parametrize("k,w,part_max", [(16, 13, None), (16, 8, None), (16, 8, 20000)])
+def test_index_matches_oracle(ctx, oracle_lib, mini, k, w, part_max, monkeypatch):
+    if part_max:                                       # force the partitioned (>2^31-entry) sort path
+        monkeypatch.setenv("MM_INDEX_PART_MAX", str(part_max))
     names, contigs = _read_fasta(mini["db"].fasta)
     S = ctx.seqset(contigs)
     idx = ctx.index(S, k, w)
@@ -119,6 +121,16 @@ def test_index_matches_oracle(ctx, oracle_lib, mini, k, w):
     oh, oc, ow, os_ = oi.dump()
     assert np.array_equal(h, oh) and np.array_equal(c, oc) and np.array_equal(wp, ow) and np.array_equal(st, os_)
     assert idx.freq_threshold == oi.freq_threshold
+    if part_max:                                       # the hash-ordered table must work too: map a few reads
+        rnames, reads = _read_fastq(mini["reads"])
+        R = ctx.seqset(reads[:40])
+        M = ctx.map_batch(idx, R, k, w)
+        off, rec = M.fetch()
+        for r, q in enumerate(reads[:40]):
+            if len(q) >= 1000:
+                m = oi.map_read(q)["map"]
+                assert np.array_equal(rec[off[r]:off[r + 1]]["ref_start"], m[:, 1]), r
+        M.close(); R.close()
     oi.close(); idx.close(); S.close()
 
 

@@ -1,0 +1,360 @@
+// `metamaps` — drop-in command line front end for the MI355X hot path.
+//
+// Keeps the reference's sub-commands, flags and on-disk formats (map/include/parseCmdArgs.hpp:33-117,
+// map/mash_map.cpp:257-317; files: map/mapWrap.h:39-211, meta/fEM.h:663-803) and drives the device
+// exclusively through the C ABI in include/metamaps_hip.h.  Host work here is what stays host work in the
+// reference too: argument parsing, FASTA/FASTQ(.gz) reading, text formatting, taxonomy bookkeeping.
+//
+//   metamaps mapDirectly --all -r DB.fa -q reads.fq -o PREFIX [-k 16] [-w W] [-m 1000] [--pi 80] [-p 1e-3] [-t N] [--mm G]
+//   metamaps classify --DB DBDIR --mappings PREFIX [--minreads N] [-t N]
+//
+// Not provided: index / mapAgainstIndex (Boost archives), classifyU (disabled upstream),
+// reporting without --all, the coverage / unknown-species side files of classify.  --maxmemory is accepted;
+// the index is built as one chunk (288 GB of HBM hold miniSeq+H whole).
+#include "../../../include/metamaps_hip.h"
+#include <zlib.h>
+#include <algorithm>
+#include <cctype>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <regex>
+#include <set>
+#include <sstream>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+namespace {
+
+[[noreturn]] void die(const std::string& m) { std::cerr << m << std::endl; exit(1); }
+void ck(mm_ctx* ctx, int st, const char* what) { if (st != MM_OK) die(std::string(what) + ": " + mm_last_error(ctx)); }
+
+// FASTA/FASTQ(.gz) records with kseq's observable behaviour (common/kseq.h:170-207)
+class SeqFile {
+  gzFile fp_; std::vector<unsigned char> buf_; size_t beg_ = 0, end_ = 0; bool eof_ = false; int pending_ = 0;
+  int get() {
+    if (beg_ >= end_) { if (eof_) return -1; int n = gzread(fp_, buf_.data(), (unsigned)buf_.size()); if (n <= 0) { eof_ = true; return -1; } beg_ = 0; end_ = (size_t)n; }
+    return buf_[beg_++];
+  }
+ public:
+  std::string name, seq;
+  explicit SeqFile(const std::string& path) : buf_(1 << 20) { fp_ = gzopen(path.c_str(), "r"); if (!fp_) die("Cannot open " + path); }
+  ~SeqFile() { gzclose(fp_); }
+  bool next() {
+    int c;
+    if (!pending_) { while ((c = get()) != -1 && c != '>' && c != '@') {} if (c == -1) return false; pending_ = c; }
+    name.clear(); seq.clear();
+    bool any = false;
+    while ((c = get()) != -1 && !isspace(c)) { name.push_back((char)c); any = true; }
+    if (c == -1 && !any) return false;
+    if (c != '\n') while (c != -1 && (c = get()) != -1 && c != '\n') {}
+    while ((c = get()) != -1 && c != '>' && c != '+' && c != '@') if (isgraph(c)) seq.push_back((char)c);
+    pending_ = (c == '>' || c == '@') ? c : 0;
+    if (c != '+') return true;
+    while ((c = get()) != -1 && c != '\n') {}
+    size_t got = 0;
+    while (got < seq.size() && (c = get()) != -1) if (c >= 33 && c <= 127) ++got;
+    pending_ = 0;
+    return true;
+  }
+};
+
+std::vector<std::string> split(const std::string& in, const std::string& d) {   // meta/util.h:80
+  std::vector<std::string> out;
+  if (in.empty()) return out;
+  size_t s = 0, p;
+  while ((p = in.find(d, s)) != std::string::npos) { out.push_back(in.substr(s, p - s)); s = p + d.size(); }
+  out.push_back(in.substr(s));
+  return out;
+}
+
+struct Options { std::map<std::string, std::string> v; bool all = false; };
+Options parse(int argc, char** argv) {
+  static const std::map<std::string, std::string> alias{{"-r", "reference"}, {"-q", "query"}, {"-o", "output"}, {"-k", "kmer"}, {"-p", "pval"},
+      {"-w", "window"}, {"-m", "minReadLen"}, {"-t", "threads"}, {"--mm", "maxmemory"}, {"--pi", "perc_identity"}, {"-i", "index"}};
+  Options o;
+  for (int i = 2; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a == "--all") { o.all = true; continue; }
+    if (a == "-h" || a == "--help") { std::cout << "see the header of metamaps_main.cpp / the reference's README\n"; exit(0); }
+    std::string key = alias.count(a) ? alias.at(a) : (a.rfind("--", 0) == 0 ? a.substr(2) : "");
+    if (key.empty() || i + 1 >= argc) die("Unknown or incomplete option " + a);
+    o.v[key] = argv[++i];
+  }
+  return o;
+}
+
+uint64_t file_size(const std::string& f) {                       // commonFunc.hpp:211-231
+  struct stat st; if (stat(f.c_str(), &st) != 0) die("Cannot open " + f + " for size determination.");
+  return (uint64_t)st.st_size;
+}
+
+// ------------------------------------------------------------------------------------------------------
+int map_directly(const Options& o) {
+  if (!o.v.count("reference")) die("Provide reference file (s)");
+  if (!o.v.count("query")) die("Provide query file (s)");
+  if (!o.v.count("output")) die("Provide output file");
+  if (!o.all) die("This build reports all mappings only: please pass --all (the mode MetaMaps' own pipelines use, simulate.pl:1626)");
+  const std::string ref = o.v.at("reference");
+  const uint64_t refSize = file_size(ref);
+  const uint64_t maxMem = o.v.count("maxmemory") ? (uint64_t)(std::pow(1024, 3) * std::stoull(o.v.at("maxmemory"))) : 0;
+  int k = o.v.count("kmer") ? std::stoi(o.v.at("kmer")) : 16;
+  double pval = o.v.count("pval") ? std::stod(o.v.at("pval")) : 1e-3;
+  int minLen = o.v.count("minReadLen") ? std::stoi(o.v.at("minReadLen")) : 1000;
+  float pi = o.v.count("perc_identity") ? std::stof(o.v.at("perc_identity")) : 80;
+  int w;
+  if (o.v.count("window")) {                                     // parseCmdArgs.hpp:363-374
+    w = std::stoi(o.v.at("window"));
+    pval = mm_estimate_pvalue(minLen * 2 / w, k, pi, minLen, refSize);
+  } else w = mm_recommended_window(pval, k, pi, minLen, refSize);
+  auto queries = split(o.v.at("query"), ","), prefixes = split(o.v.at("output"), ",");
+  if (queries.size() != prefixes.size()) die("Please specify an equal number of input and output files (as comma-separated lists)");
+  if (maxMem) std::cerr << "note: --maxmemory accepted; the index is built as a single chunk in HBM\n";
+
+  mm_ctx* ctx;
+  if (mm_ctx_create(0, &ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
+  // ---- index (winSketch.hpp:180-365)
+  mm_seqset* contigs; ck(ctx, mm_seqset_create(ctx, &contigs), "seqset");
+  std::vector<std::string> cname; std::vector<int> clen;
+  { SeqFile f(ref); while (f.next()) { ck(ctx, mm_seqset_add(contigs, f.seq.data(), (int64_t)f.seq.size()), "add contig"); cname.push_back(f.name); clen.push_back((int)f.seq.size()); } }
+  ck(ctx, mm_seqset_upload(contigs), "upload reference");
+  mm_index* idx; ck(ctx, mm_index_build(ctx, contigs, k, w, &idx), "index");
+  {
+    int64_t n = 0; mm_index_freq_hist(idx, nullptr, nullptr, 0, &n);
+    std::vector<int64_t> c((size_t)n), h((size_t)n); mm_index_freq_hist(idx, c.data(), h.data(), n, &n);
+    mm_index_info info; mm_index_get_info(idx, &info);
+    mm_index_set_freq_threshold(idx, mm_freq_threshold_from_hist(c.data(), h.data(), n, info.n_unique_hashes, INT_MAX));
+    std::cout << "INFO, index: " << info.n_contigs << " contigs, " << info.n_entries << " minimizers, " << info.n_unique_hashes << " unique hashes\n";
+  }
+  mm_seqset_destroy(contigs);
+  // ---- reads, batch by batch (computeMap.hpp:104-172 + unifyFiles mapWrap.h:34-213)
+  const int64_t BATCH_READS = 200000, BATCH_BASES = 3000000000LL;
+  for (size_t fi = 0; fi < queries.size(); ++fi) {
+    const std::string& prefix = prefixes[fi];
+    std::ofstream out(prefix), unm(prefix + ".meta.unmappedReadsLengths");
+    if (!out.is_open()) die("Cannot open output file " + prefix);
+    size_t total = 0, tooShort = 0, mapped = 0, notMapped = 0;
+    std::set<std::string> seen;
+    SeqFile f(queries[fi]);
+    bool more = true;
+    while (more) {
+      mm_seqset* reads; ck(ctx, mm_seqset_create(ctx, &reads), "seqset");
+      std::vector<std::string> names; std::vector<int> lens; int64_t bases = 0;
+      while ((int64_t)names.size() < BATCH_READS && bases < BATCH_BASES && (more = f.next())) {
+        ck(ctx, mm_seqset_add(reads, f.seq.data(), (int64_t)f.seq.size()), "add read");
+        names.push_back(f.name); lens.push_back((int)f.seq.size()); bases += (int64_t)f.seq.size();
+      }
+      if (names.empty()) { mm_seqset_destroy(reads); break; }
+      ck(ctx, mm_seqset_upload(reads), "upload reads");
+      mm_map_params mp{k, w, pi, minLen};
+      mm_mapping* m; ck(ctx, mm_map_batch(ctx, idx, reads, &mp, &m), "map");
+      ck(ctx, mm_mapping_add_qualities(ctx, m, reads, k), "mapping qualities");
+      std::vector<int64_t> off(names.size() + 1);
+      ck(ctx, mm_mapping_fetch(m, off.data(), nullptr, 0), "fetch");
+      std::vector<mm_map_record> rec((size_t)off.back());
+      ck(ctx, mm_mapping_fetch(m, off.data(), rec.data(), (int64_t)rec.size()), "fetch");
+      for (size_t r = 0; r < names.size(); ++r) {
+        ++total;
+        const int len = lens[r];
+        if (len < w || len < k || len < minLen) { ++tooShort; continue; }
+        if (!seen.insert(names[r]).second) die("Seems that read ID " + names[r] + " has already been processed");   // mapWrap.h:71-75
+        if (off[r] == off[r + 1]) { ++notMapped; unm << len << "\t" << names[r] << "\n"; continue; }
+        ++mapped;
+        for (int64_t i = off[r]; i < off[r + 1]; ++i) {
+          const mm_map_record& x = rec[(size_t)i];
+          float id, ub; mm_identity(x.shared, x.sketch, k, &id, &ub);
+          std::ostringstream ln;                                  // computeMap.hpp:565-581
+          ln << names[r] << " " << len << " " << "0" << " " << len - 1 << " " << (x.strand == 1 ? "+" : "-") << " "
+             << cname[(size_t)x.ref_contig] << " " << clen[(size_t)x.ref_contig] << " " << x.ref_start << " " << x.ref_start + len - 1 << " ";
+          std::ostringstream ids; ids << id;                      // printed, then re-parsed (mapWrap.h:237)
+          ln << ids.str() << " " << x.shared << " " << x.sketch;
+          const double reported = std::stod(ids.str()) / 100.0;
+          const float corrected = std::exp(-(1 - reported));      // mapWrap.h:311
+          ln << " " << corrected * 100 << " " << x.mapq << "\n";  // :318-320
+          out << ln.str();
+        }
+      }
+      mm_mapping_destroy(m); mm_seqset_destroy(reads);
+    }
+    std::ofstream meta(prefix + ".meta");                        // mapWrap.h:178-184
+    meta << "TotalReads " << total << "\nReadsTooShort " << tooShort << "\nReadsMapped " << mapped << "\nReadsNotMapped " << notMapped << "\n";
+    std::ofstream ps(prefix + ".parameters");                    // mapWrap.h:196-211
+    ps << "kmerSize " << k << "\nwindowSize " << w << "\nminReadLength " << minLen << "\nalphabetSize " << 4 << "\nreferenceSize " << refSize
+       << "\npercentageIdentity " << pi << "\np_value " << pval << "\nrefSequences [" << ref << "]\nquerySequences [" << queries[fi]
+       << "]\noutFileName " << prefix << "\nreportAll " << o.all << "\nindex " << "" << "\nmaximumMemory " << maxMem << "\n";
+    std::cout << "INFO, [count of mapped reads, reads qualified for mapping, total input reads] = [" << mapped << ", " << total - tooShort << ", " << total << "]\n";
+  }
+  mm_index_destroy(idx); mm_ctx_destroy(ctx);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+struct TaxNode { std::string parent, rank, sci; };
+struct Taxonomy {                                                // meta/taxonomy.h:137-246
+  std::map<std::string, TaxNode> T;
+  static std::vector<std::string> fields(std::string ln) { static const std::regex re("\\s*\\|\\s*"); return split(std::regex_replace(ln, re, "|"), "|"); }
+  explicit Taxonomy(const std::string& dir) {
+    std::map<std::string, std::string> sci; std::string ln;
+    std::ifstream nm(dir + "/names.dmp"); if (!nm.is_open()) die("Cannot open file " + dir + "/names.dmp -- is '" + dir + "' a valid NCBI taxonomy?");
+    while (std::getline(nm, ln)) { if (ln.empty()) continue; auto f = fields(ln); if (f.size() > 3 && f[3] == "scientific name") sci[f[0]] = f[1]; else if (f.size() > 3 && f[3] == "genbank common name") sci[f[0]]; }
+    std::ifstream nd(dir + "/nodes.dmp"); if (!nd.is_open()) die("Cannot open file " + dir + "/nodes.dmp");
+    while (std::getline(nd, ln)) { if (ln.empty()) continue; auto f = fields(ln); if (!sci.count(f[0])) die("No name for taxon ID " + f[0] + " in taxonomy directory " + dir); T[f[0]] = TaxNode{f[1], f[2], sci[f[0]]}; }
+    std::cout << "Read taxonomy from " << dir << " -- have " << T.size() << " nodes." << std::endl;
+  }
+  std::map<std::string, std::string> upward_by_ranks(std::string id, const std::set<std::string>& want) const {   // taxonomy.h:76-111
+    std::map<std::string, std::string> r;
+    std::vector<std::string> up{id};
+    while (id != "1") { id = T.at(id).parent; up.push_back(id); }
+    for (auto& n : up) { const std::string& rank = T.at(n).rank; if (!want.count(rank)) continue; if (rank != "no rank") { if (r.count(rank)) die("Node " + up[0] + " has multiple entries for rank " + rank); r[rank] = n; } }
+    for (auto& w : want) if (!r.count(w)) r[w] = "Undefined";
+    return r;
+  }
+  std::string first_non_x(std::string id) const { while (id.find('x') != std::string::npos) id = T.at(id).parent; return id; }   // :51-74
+};
+
+std::string extract_taxon(const std::string& contig) {           // fEM.h:1396
+  static const std::regex re("kraken:taxid\\|(x?\\d+)");
+  std::smatch m;
+  if (!std::regex_search(contig, m, re)) die("Could not extract taxon ID from contig identifier '" + contig + "' - did you use the MetMaps build scripts to construct your database?");
+  return m[1];
+}
+
+void write_wimp(const std::string& fn, const Taxonomy& T, const std::map<std::string, double>& freq, const std::map<std::string, size_t>& reads,
+                size_t nTotal, size_t nUnmapped, size_t nTooShort) {   // fEM.h:52-215
+  const std::set<std::string> levels{"species", "genus", "family", "order", "phylum", "superkingdom"};
+  std::map<std::string, std::set<std::string>> keys;
+  std::map<std::string, std::map<std::string, double>> fL; std::map<std::string, std::map<std::string, size_t>> rL;
+  for (auto& kv : freq) { auto up = T.upward_by_ranks(kv.first, levels); up["definedGenomes"] = kv.first;
+    for (auto& u : up) { fL[u.first][u.second] += kv.second; keys[u.first].insert(u.second); if (fL[u.first][u.second] > 1) fL[u.first][u.second] = 1; } }
+  for (auto& kv : reads) { auto up = T.upward_by_ranks(kv.first, levels); up["definedGenomes"] = kv.first;
+    for (auto& u : up) { rL[u.first][u.second] += kv.second; keys[u.first].insert(u.second); } }
+  const long long nMappable = (long long)nTotal - (long long)nTooShort, nMapped = nMappable - (long long)nUnmapped;
+  std::ofstream o(fn);
+  o << "AnalysisLevel\ttaxonID\tName\tAbsolute\tEMFrequency\tPotFrequency\n";
+  for (auto& lv : keys) {
+    const std::string& L = lv.first; std::map<std::string, double> emF; double sumF = 0;
+    for (auto& t : lv.second) { double f = fL[L].count(t) ? fL[L][t] : 0; size_t r = rL[L].count(t) ? rL[L][t] : 0; sumF += f; fL[L][t] = f; rL[L][t] = r; }
+    for (auto& t : lv.second) { fL[L][t] /= sumF; emF[t] = fL[L][t]; }
+    const double propMapped = (double)nMapped / nMappable; double propNot = (double)nUnmapped / nMappable;
+    for (auto& t : lv.second) fL[L][t] *= propMapped;
+    double emUnm = 0; size_t nUnmUndef = nUnmapped;
+    for (auto& t : lv.second) {
+      if (t != "Undefined") o << L << "\t" << t << "\t" << T.T.at(t).sci << "\t" << rL[L][t] << "\t" << emF[t] << "\t" << fL[L][t] << "\n";
+      else { nUnmUndef += rL[L][t]; emUnm += emF[t]; propNot += fL[L][t]; }
+    }
+    o << L << "\t" << 0 << "\tUnclassified\t" << nUnmUndef << "\t" << emUnm << "\t" << propNot << "\n";
+    o << L << "\t" << -3 << "\ttotalReads\t" << nTotal << "\t" << 0 << "\t" << 0 << "\n";
+    o << L << "\t" << -3 << "\treadsLongEnough\t" << nMappable << "\t" << 0 << "\t" << 0 << "\n";
+    o << L << "\t" << -3 << "\treadsLongEnough_unmapped\t" << nUnmapped << "\t" << 0 << "\t" << 0 << "\n";
+  }
+}
+
+int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db) {   // meta::doEM, fEM.h:466-803
+  // mappings grouped by read (fEM.h:1171-1214)
+  std::vector<std::vector<std::string>> groups;
+  { std::ifstream s(mapped); if (!s.is_open()) die("Cannot open mappings file " + mapped);
+    std::string ln, cur; std::vector<std::string> g;
+    while (std::getline(s, ln)) { if (ln.empty()) continue; std::string id = ln.substr(0, ln.find(' ')); if (id != cur) { if (!g.empty()) groups.push_back(g); cur = id; g.clear(); } g.push_back(ln); }
+    if (!g.empty()) groups.push_back(g); }
+  std::set<std::string> taxaSet;
+  for (auto& g : groups) for (auto& ln : g) { auto f = split(ln, " "); if (f.size() < 6) die("File " + mapped + " has weird format - is this a mappings file generated by MetaMap?"); taxaSet.insert(extract_taxon(f[5])); }
+  if (taxaSet.empty()) die("No relevant taxon IDs found in your mappings file - is it possible that none of your reads are mapped?");
+  std::map<std::string, size_t> st;
+  { std::ifstream s(mapped + ".meta"); if (!s.is_open()) die("The file " + mapped + ".meta is not present or could not be opened - this file is generated automatically as part of the mapping process, so please check whether the mapping process finished successfully.");
+    std::string a; size_t b; while (s >> a >> b) st[a] = b; }
+  const size_t nUnmapped = st.at("ReadsNotMapped"), nTooShort = st.at("ReadsTooShort"), nTotal = st.at("TotalReads");
+  std::map<std::string, std::map<std::string, size_t>> TI;       // fEM.h:1320-1364
+  { std::ifstream s(db + "/taxonInfo.txt"); if (!s.is_open()) die("Could not open file " + db + "/taxonInfo.txt -- perhaps you have specified an incomplete DB?");
+    std::string ln; while (std::getline(s, ln)) { if (ln.empty()) continue; auto f = split(ln, " "); for (auto& c : split(f.at(1), ";")) { auto kv = split(c, "="); TI[f.at(0)][kv.at(0)] = std::stoull(kv.at(1)); } } }
+  Taxonomy T(db + "/taxonomy");
+  std::vector<std::string> taxa(taxaSet.begin(), taxaSet.end());
+  std::map<std::string, int> tindex; for (size_t i = 0; i < taxa.size(); ++i) tindex[taxa[i]] = (int)i;
+  // per mapping: taxon, quality, 1/nLoc (getMappingLocations, fEM.h:234-353)
+  std::vector<int64_t> off{0}; std::vector<int32_t> taxon; std::vector<double> mapq, inv, ident; std::vector<std::string> contigOf; std::vector<size_t> rlen;
+  for (auto& g : groups) {
+    std::vector<std::vector<std::string>> F; std::set<std::string> sawC, sawT;
+    for (auto& ln : g) { F.push_back(split(ln, " ")); sawC.insert(F.back().at(5)); }
+    const long long L = std::stoi(F[0].at(1));
+    std::map<std::string, size_t> nLoc;
+    for (auto& f : F) { std::string t = extract_taxon(f[5]); if (!TI.count(t)) die("Unknown taxonID '" + t + "'; please check that your mappings file was mapped against the database now specified."); sawT.insert(t); }
+    for (auto& t : sawT) { size_t n = 0; for (auto& c : TI.at(t)) { if ((long long)c.second >= L) n += c.second - L + 1; else if (sawC.count(c.first)) ++n; } nLoc[t] = n; }
+    for (auto& f : F) {
+      std::string t = extract_taxon(f[5]); double q;
+      try { q = std::stod(f.at(13)); } catch (const std::out_of_range&) { if (f.at(13).find("e-") != std::string::npos) q = 0; else throw; }
+      taxon.push_back(tindex.at(t)); mapq.push_back(q); inv.push_back(1 / (double)nLoc.at(t)); ident.push_back(std::stod(f.at(9)) / 100.0); contigOf.push_back(f[5]); rlen.push_back((size_t)L);
+    }
+    off.push_back((int64_t)taxon.size());
+  }
+  mm_em* em; ck(ctx, mm_em_create(ctx, (int64_t)groups.size(), off.data(), taxon.data(), mapq.data(), inv.data(), (int32_t)taxa.size(), &em), "em");
+  std::vector<double> f(taxa.size(), 1 / (double)taxa.size()), fn(taxa.size());
+  std::cout << "Starting EM..." << std::endl;
+  double llPrev = 0; size_t iter = 0; bool go = true;
+  while (go) {                                                   // fEM.h:501-661
+    std::cout << "EM round " << iter << std::endl;
+    double ll; ck(ctx, mm_em_iterate_allreduce(em, f.data(), fn.data(), &ll), "em iterate");
+    std::cout << "\n\tLog likelihood: " << ll << std::endl;
+    if (iter > 0) { double diff = ll - llPrev, rel = ll / llPrev; std::cout << "\tImprovement: " << diff << "\n\tRelative   : " << rel << std::endl; if (diff <= 1 && (1 - rel) < 0.0001) go = false; }
+    f = fn; ++iter; llPrev = ll;
+  }
+  std::vector<double> post(taxon.size()); std::vector<int64_t> best(groups.size());
+  ck(ctx, mm_em_posteriors(em, f.data(), post.data(), best.data()), "posteriors");
+  mm_em_destroy(em);
+  std::cout << "Outputting mappings with adjusted alignment qualities." << std::endl;
+  std::ofstream emf(mapped + ".EM"), r2t(mapped + ".EM.reads2Taxon"), kr(mapped + ".EM.reads2Taxon.krona"), li(mapped + ".EM.lengthAndIdentitiesPerMappingUnit");
+  li << "AnalysisLevel\tID\treadI\tIdentity\tLength\n";
+  std::map<std::string, size_t> readsPer;
+  for (size_t r = 0; r < groups.size(); ++r) {                   // fEM.h:684-779
+    std::string rid;
+    for (size_t j = 0; j < groups[r].size(); ++j) {
+      auto fld = split(groups[r][j], " "); rid = fld.at(0);
+      fld.at(13) = std::to_string(post[(size_t)off[r] + j]);     // :705
+      for (size_t q = 0; q < fld.size(); ++q) emf << (q ? " " : "") << fld[q];
+      emf << "\n";
+    }
+    const size_t b = (size_t)best[r];
+    const std::string& tx = taxa[(size_t)taxon[b]];
+    li << "EqualCoverageUnit\t" << contigOf[b] << "\t" << r << "\t" << ident[b] << "\t" << rlen[b] << "\n";   // :711
+    r2t << rid << "\t" << tx << "\n";
+    kr << rid << "\t" << T.first_non_x(tx) << "\t" << post[b] << "\n";
+    readsPer[tx]++;
+  }
+  { std::ifstream s(mapped + ".meta.unmappedReadsLengths"); std::string ln;
+    while (std::getline(s, ln)) { if (ln.empty()) continue; auto fl = split(ln, "\t"); r2t << fl.at(1) << "\t" << 0 << "\n"; kr << fl.at(1) << "\t" << 0 << "\t" << 0 << "\n"; } }
+  std::map<std::string, double> fmap;
+  for (size_t i = 0; i < taxa.size(); ++i) fmap[taxa[i]] = f[i];
+  { const double minF = 0.9 * (1.0 / (double)st.at("ReadsMapped")); std::set<std::string> drop;   // cleanF, fEM.h:1135-1163
+    for (auto& e : fmap) if (e.second < minF && !readsPer.count(e.first)) drop.insert(e.first);
+    for (auto& d : drop) fmap.erase(d);
+    double s = 0; for (auto& e : fmap) s += e.second; for (auto& e : fmap) e.second /= s; }
+  write_wimp(mapped + ".EM.WIMP", T, fmap, readsPer, nTotal, nUnmapped, nTooShort);
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 2 || !(std::string(argv[1]) == "index" || std::string(argv[1]) == "mapDirectly" || std::string(argv[1]) == "mapAgainstIndex" ||
+                    std::string(argv[1]) == "classify" || std::string(argv[1]) == "classifyU")) {
+    std::cout << "\nMetaMaps (MI355X hot path)\n\n  Simultaneous metagenomic classification and mapping.\n\nUsage:\n\n  ./metamaps mapDirectly|classify\n\n";
+    return 1;
+  }
+  const std::string mode = argv[1];
+  Options o = parse(argc, argv);
+  if (mode == "mapDirectly") return map_directly(o);
+  if (mode == "classify") {
+    if (!o.v.count("DB")) die("Provide path to DB.");
+    if (!o.v.count("mappings")) die("Provide path to mappings.");
+    mm_ctx* ctx;
+    if (mm_ctx_create(0, &ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
+    for (auto& m : split(o.v.at("mappings"), ",")) classify_one(ctx, m, o.v.at("DB"));
+    mm_ctx_destroy(ctx);
+    return 0;
+  }
+  die("sub-command '" + mode + "' is outside the accelerated hot path (SURVEY.md §2: Boost-archive index files / disabled upstream)");
+}

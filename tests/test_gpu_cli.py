@@ -1,0 +1,55 @@
+"""End to end through the drop-in CLI (metamaps_amd/csrc/metamaps, which uses only the C ABI) against the
+oracle CLI on the same files: every output file of mapDirectly and classify.  Integers and text byte-exact;
+mapping qualities / posteriors / frequencies within 1e-5 (BASELINE.json north_star)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "metamaps_amd", "csrc", "metamaps")
+
+
+def _close(a: str, b: str, rel=1e-5, abs_=2e-6) -> bool:
+    if a == b:
+        return True
+    x, y = float(a), float(b)
+    return abs(x - y) <= abs_ + rel * max(abs(x), abs(y))
+
+
+def _cmp_table(fa, fb, sep, numeric_cols):
+    la, lb = open(fa).read().splitlines(), open(fb).read().splitlines()
+    assert len(la) == len(lb), (fa, len(la), len(lb))
+    for i, (x, y) in enumerate(zip(la, lb)):
+        fx, fy = x.split(sep), y.split(sep)
+        assert len(fx) == len(fy), (fa, i)
+        for c, (u, v) in enumerate(zip(fx, fy)):
+            if c in numeric_cols:
+                assert _close(u, v), (fa, i, c, u, v)
+            else:
+                assert u == v, (fa, i, c, u, v)
+
+
+@pytest.mark.parametrize("w_flag", [[], ["-w", "8"]])
+def test_cli_outputs_match_oracle(oracle_lib, tmp_path, w_flag):
+    import orc
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=10, genome_len=60_000, seed=7)
+    rd = synth.make_reads(db, str(tmp_path / "reads.fq"), n_reads=200, read_len=3000, seed=3)
+    pa, pb = str(tmp_path / "gpu"), str(tmp_path / "cpu")
+    for exe, pre in ((CLI, pa), (orc.CLI, pb)):
+        subprocess.run([exe, "mapDirectly", "--all", "-r", db.fasta, "-q", rd["path"], "-o", pre] + w_flag, check=True, capture_output=True, timeout=900)
+        subprocess.run([exe, "classify", "--DB", db.dir, "--mappings", pre], check=True, capture_output=True, timeout=900)
+    _cmp_table(pa, pb, " ", {13})
+    for suf in (".meta", ".meta.unmappedReadsLengths"):
+        assert open(pa + suf).read() == open(pb + suf).read(), suf
+    pa_par = [l for l in open(pa + ".parameters") if not l.startswith("outFileName")]
+    pb_par = [l for l in open(pb + ".parameters") if not l.startswith("outFileName")]
+    assert pa_par == pb_par
+    _cmp_table(pa + ".EM", pb + ".EM", " ", {13})
+    assert open(pa + ".EM.reads2Taxon").read() == open(pb + ".EM.reads2Taxon").read()
+    _cmp_table(pa + ".EM.reads2Taxon.krona", pb + ".EM.reads2Taxon.krona", "\t", {2})
+    _cmp_table(pa + ".EM.WIMP", pb + ".EM.WIMP", "\t", {4, 5})
+    assert sum(1 for _ in open(pa)) > 150

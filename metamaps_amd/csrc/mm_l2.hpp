@@ -50,6 +50,26 @@ __device__ inline int wave_excl_scan(int v, int lane) {
   return inc - v;
 }
 
+// Four independent lower_bound searches per lane with their steps interleaved: the four LDS reads of a step
+// are issued back to back, so one search step costs one LDS latency for four entries instead of one.
+__device__ inline void l2_classify4(const uint32_t* __restrict__ Q, int s, const uint32_t (&h)[4], int (&code)[4]) {
+  int lo0 = 0, lo1 = 0, lo2 = 0, lo3 = 0, hi0 = s, hi1 = s, hi2 = s, hi3 = s;
+  const int steps = 33 - __clz(s | 1);                            // >= ceil(log2(s+1))
+  for (int it = 0; it < steps; ++it) {
+    const int m0 = min((lo0 + hi0) >> 1, s - 1), m1 = min((lo1 + hi1) >> 1, s - 1), m2 = min((lo2 + hi2) >> 1, s - 1), m3 = min((lo3 + hi3) >> 1, s - 1);
+    const uint32_t v0 = Q[m0], v1 = Q[m1], v2 = Q[m2], v3 = Q[m3];
+    if (lo0 < hi0) { if (v0 < h[0]) lo0 = m0 + 1; else hi0 = m0; }
+    if (lo1 < hi1) { if (v1 < h[1]) lo1 = m1 + 1; else hi1 = m1; }
+    if (lo2 < hi2) { if (v2 < h[2]) lo2 = m2 + 1; else hi2 = m2; }
+    if (lo3 < hi3) { if (v3 < h[3]) lo3 = m3 + 1; else hi3 = m3; }
+  }
+  const uint32_t e0 = Q[min(lo0, s - 1)], e1 = Q[min(lo1, s - 1)], e2 = Q[min(lo2, s - 1)], e3 = Q[min(lo3, s - 1)];
+  code[0] = (lo0 < s && e0 == h[0]) ? lo0 : -(lo0 + 1);
+  code[1] = (lo1 < s && e1 == h[1]) ? lo1 : -(lo1 + 1);
+  code[2] = (lo2 < s && e2 == h[2]) ? lo2 : -(lo2 + 1);
+  code[3] = (lo3 < s && e3 == h[3]) ? lo3 : -(lo3 + 1);
+}
+
 __host__ __device__ inline size_t l2_state_bytes(int smax) {      // Q | D | mt, rounded to 8 bytes
   size_t b = (size_t)smax * 4 + (size_t)((smax + 1) & ~1) * 2 + (size_t)((smax + 31) / 32) * 4 + 16;
   return (b + 7) & ~(size_t)7;
@@ -87,6 +107,9 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
   int amin = accept_min[r]; if (amin < 1) amin = 1;
 
   L2State S{Q, D, mt, s, 0, 0, 0};
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};                // phase clocks: setup, passA, bounds, rebuild, slide, passB, vote, -
+  long long tmark = clock64();
+  auto lap = [&](int ph) { long long now = clock64(); tph[ph] += now - tmark; tmark = now; };
 
   // e_min(b): first entry at or after b whose wpos >= wpos[b] + cnt (never beyond last_end)
   auto e_min = [&](int64_t bb) -> int64_t {
@@ -133,19 +156,29 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
     for (int i = lane; i < (s + 31) / 32; i += 64) mt[i] = 0;
     __syncthreads();
     uint32_t* Dw = (uint32_t*)D;
-    for (int64_t base = nb; base < ne; base += 64) {
-      const int64_t j = base + lane;
-      if (j < ne) {
-        const Rec x = pos[j];
-        const int code = l2_classify(Q, s, x.hash);
-        if (code >= 0) atomicOr(&mt[code >> 5], 1u << (code & 31));
-        else {
-          const int g = -code - 1;
-          if (g < s) {
-            bool dup = false;
-            if (x.pw & PW_DP) for (int64_t t = j - 1; t >= nb; --t) if (pos[t].hash == x.hash) { dup = true; break; }
-            if (!dup) atomicAdd(&Dw[g >> 1], (g & 1) ? 0x10000u : 1u);
-          }
+    Rec nx[4];
+    for (int i = 0; i < 4; ++i) { const int64_t j = nb + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
+    for (int64_t base = nb; base < ne; base += 256) {
+      Rec x[4]; uint32_t hh[4]; int cd[4];
+      for (int i = 0; i < 4; ++i) { x[i] = nx[i]; hh[i] = x[i].hash; }
+      if (base + 256 < ne) for (int i = 0; i < 4; ++i) { const int64_t j = base + 256 + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }   // prefetch
+      l2_classify4(Q, s, hh, cd);
+      for (int i = 0; i < 4; ++i) {
+        const int64_t j = base + lane + 64 * i;
+        const int code = cd[i];
+        const int g = -code - 1;
+        const bool in = j < ne;
+        if (in && code >= 0) atomicOr(&mt[code >> 5], 1u << (code & 31));
+        const bool wonly = in && code < 0 && g < s;
+        const bool flagged = wonly && (x[i].pw & PW_DP);          // an earlier occurrence exists in the contig: inside the window?
+        if (wonly && !flagged) atomicAdd(&Dw[g >> 1], (g & 1) ? 0x10000u : 1u);
+        uint64_t fm = __ballot(flagged);                         // rare: resolved one by one with a wave-wide scan
+        while (fm) {
+          const int l = __ffsll((unsigned long long)fm) - 1;
+          fm &= fm - 1;
+          const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)x[i].hash, l);
+          const bool dup = wave_has_hash(pos, nb, base + l + 64 * i, hj, lane);
+          if (!dup && lane == l) atomicAdd(&Dw[g >> 1], (g & 1) ? 0x10000u : 1u);
         }
       }
     }
@@ -218,31 +251,53 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
       const int o = (int)(j - first), bk = o >> 6, bit = o & 63;
       return (int)p[bk] + __popcll(m[bk] & ((1ull << bit) - 1ull));
     };
-    auto classify_pass = [&](int r0, bool lo_pass) {
-      int runA = 0, runL = 0, runW = 0;
-      for (int bk = 0; bk < nblk; ++bk) {
-        const int64_t j = first + (int64_t)bk * 64 + lane;
-        bool all = false, lo = false, aw = false;
-        if (j < last_end) {
-          const Rec x = pos[j];
-          const int code = l2_classify(Q, s, x.hash);
-          all = code >= 0;
-          if (lo_pass) { lo = code >= 0 && code < r0; aw = code < 0 && (-code - 1) <= r0 && !(x.pw & PW_DP); }
+    // pass A: which entries carry a query hash (binary search, 256 entries per iteration, loads prefetched)
+    auto pass_matched = [&]() {
+      int run = 0;
+      Rec nx[4];
+      for (int i = 0; i < 4; ++i) { const int64_t j = first + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
+      for (int64_t base = first; base < last_end; base += 256) {
+        uint32_t hh[4]; int cd[4];
+        for (int i = 0; i < 4; ++i) hh[i] = nx[i].hash;
+        if (base + 256 < last_end) for (int i = 0; i < 4; ++i) { const int64_t j = base + 256 + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
+        l2_classify4(Q, s, hh, cd);
+        for (int i = 0; i < 4; ++i) {
+          const int64_t j = base + lane + 64 * i;
+          const int bk = (int)((base - first) >> 6) + i;
+          if (bk >= nblk) break;
+          const uint64_t ba = __ballot(j < last_end && cd[i] >= 0);
+          if (lane == 0) { mAll[bk] = ba; pAll[bk] = (uint16_t)run; }
+          run += __popcll(ba);
         }
-        const uint64_t ba = __ballot(all), bl = __ballot(lo), bw = __ballot(aw);
-        if (lane == 0) {
-          if (!lo_pass) { mAll[bk] = ba; pAll[bk] = (uint16_t)runA; }
-          else { mLo[bk] = bl; pLo[bk] = (uint16_t)runL; mA[bk] = bw; pA[bk] = (uint16_t)runW; }
-        }
-        runA += __popcll(ba); runL += __popcll(bl); runW += __popcll(bw);
       }
-      if (lane == 0) {
-        if (!lo_pass) { mAll[nblk] = 0; pAll[nblk] = (uint16_t)runA; }
-        else { mLo[nblk] = 0; pLo[nblk] = (uint16_t)runL; mA[nblk] = 0; pA[nblk] = (uint16_t)runW; }
-      }
+      if (lane == 0) { mAll[nblk] = 0; pAll[nblk] = (uint16_t)run; }
       __syncthreads();
     };
-    classify_pass(0, false);
+    // pass B: rank below r0  <=>  hash below Q[r0]; no search needed once the matched bits are known
+    auto pass_low = [&](int r0) {
+      const bool every = r0 >= s;
+      const uint32_t qr0 = every ? 0u : Q[r0];
+      int runL = 0, runW = 0;
+      for (int bk = 0; bk < nblk; ++bk) {
+        const int64_t j = first + (int64_t)bk * 64 + lane;
+        bool lo = false, aw = false;
+        if (j < last_end) {
+          const Rec x = pos[j];
+          const bool below = every || x.hash < qr0;
+          const bool matched = (mAll[bk] >> lane) & 1ull;
+          lo = matched && below;
+          aw = !matched && below && !(x.pw & PW_DP);
+        }
+        const uint64_t bl = __ballot(lo), bw = __ballot(aw);
+        if (lane == 0) { mLo[bk] = bl; pLo[bk] = (uint16_t)runL; mA[bk] = bw; pA[bk] = (uint16_t)runW; }
+        runL += __popcll(bl); runW += __popcll(bw);
+      }
+      if (lane == 0) { mLo[nblk] = 0; pLo[nblk] = (uint16_t)runL; mA[nblk] = 0; pA[nblk] = (uint16_t)runW; }
+      __syncthreads();
+    };
+    lap(0);
+    pass_matched();
+    lap(1);
     // per block of 64 b's: largest window [bF, eHi), smallest window [bL, eLo)
     // (lane l owns blocks l and l+64; L2_NBLK == 128)
     int64_t eLo[2], eHi[2]; int ub_all[2];
@@ -257,6 +312,7 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
       }
     }
     const int ubmax = wave_max(max(ub_all[0], ub_all[1]));
+    lap(2);
     if (ubmax < amin) done = true;                               // no window can reach the acceptance threshold
     else {
       // most promising block first: its exact maximum is the initial bound, its pivot fixes r0
@@ -265,11 +321,14 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
       {
         const int64_t bF = first + (int64_t)bk0 * 64;
         rebuild(bF, e_min(bF));
+        lap(3);
         slide(bF + 64, false);
+        lap(4);
       }
       int lb = probe_best;
-      const int r0 = min(s, probe_R + max(8, s >> 5));
-      classify_pass(r0, true);
+      const int r0 = min(s, probe_R + max(4, s >> 6));
+      pass_low(r0);
+      lap(5);
       int ub2[2];
       auto bound = [&](int q) -> int {
         const int bk = lane + 64 * q;
@@ -290,9 +349,12 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
         if (!(live && b == bF)) {
           const int64_t em = e_min(bF);
           if (em >= last_end) break;
+          lap(2);
           rebuild(bF, em);
+          lap(3);
         }
         slide(bF + 64, true);
+        lap(4);
         live = (b == bF + 64);
         if (e >= last_end) break;
       }
@@ -315,17 +377,26 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
   // K6 strand vote over the first optimal window (computeMap.hpp:424-433, slidingMap.hpp:232-254):
   // sum over query ranks below the pivot that are present in the window of strandQ * strandR, where
   // strandR comes from the LAST occurrence of the hash in the window (insert_ref overwrites, :155-156).
+  lap(4);
   int strand = -1, accepted = 0;
   if (best >= amin) {
     accepted = 1;
     int votes = 0;
-    for (int64_t j = opt_b + lane; j < opt_e; j += 64) {
-      const Rec x = pos[j];
-      const int code = l2_classify(Q, s, x.hash);
-      if (code >= 0 && code < bestR) {
-        bool later = false;
-        if (x.pw & PW_DN) for (int64_t t = j + 1; t < opt_e; ++t) if (pos[t].hash == x.hash) { later = true; break; }
-        if (!later) votes += (sk_strand[qo + code] ? 1 : -1) * pw_strand(x.pw);
+    for (int64_t base = opt_b; base < opt_e; base += 64) {
+      const int64_t j = base + lane;
+      Rec x{0, 0}; int code = -1;
+      if (j < opt_e) { x = pos[j]; code = l2_classify(Q, s, x.hash); }
+      const bool cnt_it = j < opt_e && code >= 0 && code < bestR;
+      const int contrib = cnt_it ? (sk_strand[qo + code] ? 1 : -1) * pw_strand(x.pw) : 0;
+      const bool flagged = cnt_it && (x.pw & PW_DN);              // a later occurrence exists in the contig: inside the window?
+      if (cnt_it && !flagged) votes += contrib;
+      uint64_t fm = __ballot(flagged);
+      while (fm) {
+        const int l = __ffsll((unsigned long long)fm) - 1;
+        fm &= fm - 1;
+        const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)x.hash, l);
+        const bool later = wave_has_hash(pos, base + l + 1, opt_e, hj, lane);
+        if (!later && lane == l) votes += contrib;
       }
     }
     votes = wave_sum(votes);
@@ -340,6 +411,8 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
     atomicAdd(&counters[0], (unsigned long long)(last_end - first));
     atomicAdd(&counters[1], evals);
     atomicAdd(&counters[2], rebuilds);
+    lap(6);
+    for (int i = 0; i < 8; ++i) atomicAdd(&counters[3 + i], (unsigned long long)tph[i]);
   }
 }
 

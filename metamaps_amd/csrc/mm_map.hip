@@ -12,6 +12,8 @@
 #include "mm_l2_core.hpp"
 #include "mm_l2.hpp"
 #include <cstdlib>
+#include <atomic>
+#include <thread>
 #include "mm_stats.hpp"
 #include <algorithm>
 #include <numeric>
@@ -147,15 +149,24 @@ __device__ inline uint32_t hf_slot(uint32_t contig, uint32_t bin) {
   x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
   return x & (HF_SLOTS - 1);
 }
+constexpr int HF_STAGE = 2048;     // survivors staged per read (8 B each); reads with more are re-filtered by the write kernel
 template <bool WRITE>
 __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint64_t* __restrict__ off, const int32_t* __restrict__ sk_n,
                                                          const uint32_t* __restrict__ probe_cnt, const uint64_t* __restrict__ probe_start,
                                                          const int32_t* __restrict__ read_len, const int32_t* __restrict__ min_hits,
                                                          uint32_t* __restrict__ surv_n, const uint64_t* __restrict__ read_hit_off,
-                                                         uint64_t* __restrict__ hits) {
+                                                         uint64_t* __restrict__ hits, uint64_t* __restrict__ stage) {
   __shared__ uint32_t cnt[HF_SLOTS];
   __shared__ uint32_t cursor;
   const int r = blockIdx.x;
+  if (WRITE) {                                                   // staged reads only need a copy
+    const uint32_t n_s = surv_n[r];
+    if (n_s <= HF_STAGE) {
+      const uint64_t wb = read_hit_off[r];
+      for (uint32_t i = threadIdx.x; i < n_s; i += 256) hits[wb + i] = stage[(size_t)r * HF_STAGE + i];
+      return;
+    }
+  }
   const uint64_t o = off[r];
   const int s = sk_n[r];
   const uint32_t len = (uint32_t)max(read_len[r], 1);
@@ -183,15 +194,16 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
       const uint32_t c0 = cnt[hf_slot(ct, bin)];
       const uint32_t cl = bin > 0 ? cnt[hf_slot(ct, bin - 1)] : 0u, cr = cnt[hf_slot(ct, bin + 1)];
       if (c0 + cl >= (uint32_t)m || c0 + cr >= (uint32_t)m) {
-        if (WRITE) hits[wbase + atomicAdd(&cursor, 1u)] = h & ~(uint64_t)(PW_DP | PW_DN);
-        else ++mine;
+        const uint32_t slot = atomicAdd(&cursor, 1u);
+        if (WRITE) hits[wbase + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
+        else if (slot < HF_STAGE) stage[(size_t)r * HF_STAGE + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
       }
     }
   }
+  (void)mine;
   if (!WRITE) {
-    uint64_t tot;
-    block_excl_scan_u64(mine, &tot);
-    if (threadIdx.x == 0) surv_n[r] = (uint32_t)tot;
+    __syncthreads();
+    if (threadIdx.x == 0) surv_n[r] = cursor;
   }
 }
 
@@ -399,18 +411,29 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       std::vector<Rec> hr = comp.to_host(st);
       std::vector<uint8_t> sv((size_t)dof[na], 0);
       std::vector<int32_t> scnt(na);
-      std::vector<HostMz> v;
-      for (size_t i = 0; i < na; ++i) {
-        const size_t cntr = (size_t)(dof[i + 1] - dof[i]);
-        v.resize(cntr);
-        for (size_t j = 0; j < cntr; ++j) { const Rec& x = hr[(size_t)dof[i] + j]; v[j] = HostMz{x.hash, pw_wpos(x.pw), pw_strand(x.pw)}; }
-        std::sort(v.begin(), v.end(), host_less_by_hash);
-        auto ue = std::unique(v.begin(), v.end(), host_eq_by_hash);
-        const size_t sN = (size_t)(ue - v.begin());
-        MM_REQUIRE((int64_t)sN == M->h_sk_n[(size_t)amb_reads[i]], MM_ERR_DEVICE, "sketch size disagrees between device and host tie-break");
-        for (size_t j = 0; j < sN; ++j) sv[(size_t)dof[i] + j] = v[j].strand == 1 ? 1 : 0;
-        scnt[i] = (int32_t)sN;
-      }
+      // the library sort of ~1 % of the reads is the only per-read host work of a batch: spread it over threads
+      std::atomic<size_t> next{0};
+      std::atomic<int> mismatch{0};
+      auto worker = [&]() {
+        std::vector<HostMz> v;
+        for (size_t i = next.fetch_add(1); i < na; i = next.fetch_add(1)) {
+          const size_t cntr = (size_t)(dof[i + 1] - dof[i]);
+          v.resize(cntr);
+          for (size_t j = 0; j < cntr; ++j) { const Rec& x = hr[(size_t)dof[i] + j]; v[j] = HostMz{x.hash, pw_wpos(x.pw), pw_strand(x.pw)}; }
+          std::sort(v.begin(), v.end(), host_less_by_hash);
+          auto ue = std::unique(v.begin(), v.end(), host_eq_by_hash);
+          const size_t sN = (size_t)(ue - v.begin());
+          if ((int64_t)sN != M->h_sk_n[(size_t)amb_reads[i]]) mismatch = 1;
+          for (size_t j = 0; j < sN; ++j) sv[(size_t)dof[i] + j] = v[j].strand == 1 ? 1 : 0;
+          scnt[i] = (int32_t)sN;
+        }
+      };
+      const unsigned nthr = std::max(1u, std::min(16u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)((na + 31) / 32))));
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
+      worker();
+      for (auto& t : pool) t.join();
+      MM_REQUIRE(mismatch == 0, MM_ERR_DEVICE, "sketch size disagrees between device and host tie-break");
       DBuf<uint8_t> d_sv(sv.size()); d_sv.upload(sv.data(), sv.size(), st);
       DBuf<int32_t> d_cnt(na); d_cnt.upload(scnt.data(), na, st);
       scatter_strand_kernel<<<dim3((unsigned)na), dim3(256), 0, st>>>(d_sv.p, d_so.p, d_do.p, d_cnt.p, M->sk_strand.p);
@@ -459,10 +482,13 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   MM_HIP(hipMemcpyAsync(&raw_hits, hit_off.p + total_mz, sizeof raw_hits, hipMemcpyDeviceToHost, st));
   const char* nf_env = getenv("MM_NO_HIT_FILTER");               // parity tests of the raw hit list
   const bool use_filter = !(nf_env && nf_env[0] == '1');
+  DBuf<uint32_t> surv;
+  DBuf<uint64_t> stage;
   if (use_filter && n > 0) {
-    DBuf<uint32_t> surv((size_t)n + 1); surv.zero(st);
+    surv.alloc((size_t)n + 1); surv.zero(st);
+    stage.alloc((size_t)n * HF_STAGE);
     hit_filter_kernel<false><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
-                                                                   M->min_hits.p, surv.p, nullptr, nullptr);
+                                                                   M->min_hits.p, surv.p, nullptr, nullptr, stage.p);
     MM_KERNEL_CHECK();
     exclusive_scan_u32_u64(surv.p, n, M->read_hit_off.p, scan_tmp, st);
   } else {
@@ -477,7 +503,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   if (total_hits > 0) {
     if (use_filter)
       hit_filter_kernel<true><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
-                                                                    M->min_hits.p, nullptr, M->read_hit_off.p, M->hits.p);
+                                                                    M->min_hits.p, surv.p, M->read_hit_off.p, M->hits.p, stage.p);
     else
       gather_hits_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, hit_off.p, M->hits.p);
     MM_KERNEL_CHECK();
@@ -545,7 +571,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       MM_HIP(hipFuncSetAttribute((const void*)l2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       MM_HIP(hipFuncSetAttribute((const void*)l2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    DBuf<unsigned long long> counters(3); counters.zero(st);
+    DBuf<unsigned long long> counters(11); counters.zero(st);
     const size_t t_l2 = T.begin(&M->stats.ms_l2);
     if (skip)
       l2_kernel<true><<<dim3((unsigned)ncand), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p,
@@ -559,6 +585,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     M->stats.sum_l2_stream_entries = (int64_t)hc[0];
     M->stats.sum_l2_evals = (int64_t)hc[1];
     M->stats.n_l2_rebuilds = (int64_t)hc[2];
+    if (getenv("MM_L2_PHASES")) { fprintf(stderr, "l2 phase clocks [setup passA bounds rebuild slide passB vote]:"); for (int i = 0; i < 7; ++i) fprintf(stderr, " %.3g", (double)hc[3 + i]); fprintf(stderr, "\n"); }
     // ---- compaction
     const size_t t_cp = T.begin(&M->stats.ms_compact);
     DBuf<uint32_t> flag((size_t)ncand);

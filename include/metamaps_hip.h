@@ -146,6 +146,7 @@ typedef struct {
   int64_t n_ambiguous_sketch_reads;   /* reads whose duplicate-hash strands needed the std::sort tie-break */
   int64_t sum_hits_kept;              /* seed hits left after the exact run pre-filter (K3c) */
   int64_t n_l2_rebuilds;              /* window states rebuilt from scratch by the exact skip-ahead of K5 */
+  int64_t n_l2_wide_redo;             /* candidates redone with 16-bit gap counters after an 8-bit counter saturated */
   /* device time of each stage of this batch, milliseconds, from hipEvents recorded on the ctx stream
    * around the launches (bench.py's roofline uses ms_l2 = the K5/K6 kernel) */
   double ms_minimizer, ms_sketch, ms_probe_gather, ms_sort_hits, ms_l1_scan, ms_l2, ms_compact, ms_total;

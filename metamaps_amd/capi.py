@@ -42,7 +42,7 @@ assert RECORD_DTYPE.itemsize == C.sizeof(MapRecord)
 class MapStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("n_reads", "n_reads_long_enough", "n_reads_mapped", "n_mappings",
                                            "bases_long_enough", "sum_sketch", "sum_hits", "n_candidates",
-                                           "sum_l2_stream_entries", "sum_l2_evals", "n_ambiguous_sketch_reads", "sum_hits_kept", "n_l2_rebuilds")] + \
+                                           "sum_l2_stream_entries", "sum_l2_evals", "n_ambiguous_sketch_reads", "sum_hits_kept", "n_l2_rebuilds", "n_l2_wide_redo")] + \
                [(n, C.c_double) for n in ("ms_minimizer", "ms_sketch", "ms_probe_gather", "ms_sort_hits", "ms_l1_scan",
                                           "ms_l2", "ms_compact", "ms_total")]
 

@@ -70,33 +70,56 @@ __device__ inline void l2_classify4(const uint32_t* __restrict__ Q, int s, const
   code[3] = (lo3 < s && e3 == h[3]) ? lo3 : -(lo3 + 1);
 }
 
-__host__ __device__ inline size_t l2_state_bytes(int smax) {      // Q | D | mt, rounded to 8 bytes
-  size_t b = (size_t)smax * 4 + (size_t)((smax + 1) & ~1) * 2 + (size_t)((smax + 31) / 32) * 4 + 16;
-  return (b + 7) & ~(size_t)7;
+// LDS layout: Q[smax] (shared by the waves of a workgroup) | per wave: D[smax] | mt | skip-ahead class arrays
+template <typename DT>
+__host__ __device__ inline size_t l2_wave_bytes(int smax, bool skip) {
+  size_t b = (((size_t)smax * sizeof(DT) + 3) & ~(size_t)3) + (size_t)((smax + 31) / 32) * 4;
+  b = (b + 7) & ~(size_t)7;
+  if (skip) b += (size_t)(L2_NBLK + 1) * (3 * 8 + 3 * 2);
+  return (b + 15) & ~(size_t)15;
 }
-inline size_t l2_lds_bytes(int smax, bool skip) {
-  return l2_state_bytes(smax) + (skip ? (size_t)(L2_NBLK + 1) * (3 * 8 + 3 * 2) + 16 : 0);
+__host__ __device__ inline size_t l2_q_bytes(int smax) { return ((size_t)smax * 4 + 15) & ~(size_t)15; }
+template <typename DT>
+inline size_t l2_lds_bytes(int smax, bool skip, int waves) { return l2_q_bytes(smax) + (size_t)waves * l2_wave_bytes<DT>(smax, skip); }
+
+// visibility of a wave's own LDS writes to its other lanes (workgroups may hold several independent waves)
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 }
 
-template <bool SKIP>
-__global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restrict__ cand_read,
+// SKIP: exact skip-ahead on/off.  DT: counter width of D (uint8_t compact / uint16_t wide).  WAVES: candidates per
+// workgroup; with WAVES > 1 the waves of a workgroup map candidates of ONE read and share its sketch Q in LDS.
+template <bool SKIP, typename DT, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restrict__ cand_read,
                                                 const uint32_t* __restrict__ sk_hash, const uint8_t* __restrict__ sk_strand,
                                                 const uint64_t* __restrict__ mz_off, const int32_t* __restrict__ sk_n,
                                                 const int32_t* __restrict__ read_len, const int32_t* __restrict__ accept_min,
                                                 int k, int w, int smax, L2Result* __restrict__ out,
-                                                unsigned long long* __restrict__ counters /* [0] streamed entries, [1] evaluated windows, [2] rebuilds */) {
+                                                unsigned long long* __restrict__ counters /* [0] streamed entries, [1] evaluated windows, [2] rebuilds */,
+                                                const int32_t* __restrict__ grp_cand0 /* WAVES>1: first candidate of the group */,
+                                                const int32_t* __restrict__ grp_n /* WAVES>1: candidates in the group */,
+                                                const int32_t* __restrict__ cand_list /* WAVES==1: optional indirection (fallback runs) */,
+                                                int32_t* __restrict__ ovf_list, unsigned int* __restrict__ ovf_n) {
   extern __shared__ __align__(16) uint32_t lds[];
   uint32_t* Q = lds;
-  uint16_t* D = (uint16_t*)(Q + smax);
-  uint32_t* mt = (uint32_t*)(D + ((smax + 1) & ~1));
-  const int lane = threadIdx.x;
-  const int64_t c = blockIdx.x;
-  const int r = cand_read[c];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t* wbase = (uint8_t*)lds + l2_q_bytes(smax) + (size_t)wave * l2_wave_bytes<DT>(smax, SKIP);
+  DT* D = (DT*)wbase;
+  uint32_t* mt = (uint32_t*)(wbase + (((size_t)smax * sizeof(DT) + 3) & ~(size_t)3));
+  const int64_t c0 = WAVES > 1 ? (int64_t)grp_cand0[blockIdx.x] : (cand_list ? (int64_t)cand_list[blockIdx.x] : (int64_t)blockIdx.x);
+  const int r = cand_read[c0];                                   // every wave of the workgroup serves this read
   const int s = sk_n[r];
   const uint64_t qo = mz_off[r];
   const int len = read_len[r];
-  for (int i = lane; i < s; i += 64) Q[i] = sk_hash[qo + i];
+  for (int i = threadIdx.x; i < s; i += 64 * WAVES) Q[i] = sk_hash[qo + i];
   __syncthreads();
+  if (WAVES > 1 && wave >= grp_n[blockIdx.x]) return;
+  const int64_t c = c0 + (WAVES > 1 ? wave : 0);
+  constexpr int DMAX = (int)(DT)~(DT)0;
+  constexpr int DPER = 4 / (int)sizeof(DT);                      // counters per 32-bit word
+  constexpr int DBITS = 8 * (int)sizeof(DT);
+  int overflow = 0;
 
   const int contig = cand[3 * c], rs = cand[3 * c + 1], re = cand[3 * c + 2];
   const int cnt = len - (w - 1) - (k - 1);                       // computeMap.hpp:470
@@ -106,7 +129,7 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
   const int64_t nmax = I.N - 1;
   int amin = accept_min[r]; if (amin < 1) amin = 1;
 
-  L2State S{Q, D, mt, s, 0, 0, 0};
+  L2StateT<DT> S{Q, D, mt, s, 0, 0, 0, 0};
   long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};                // phase clocks: setup, passA, bounds, rebuild, slide, passB, vote, -
   long long tmark = clock64();
   auto lap = [&](int ph) { long long now = clock64(); tph[ph] += now - tmark; tmark = now; };
@@ -152,10 +175,15 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
   unsigned long long rebuilds = 0;
   auto rebuild = [&](int64_t nb, int64_t ne) {
     ++rebuilds;
-    for (int i = lane; i < s; i += 64) D[i] = 0;
-    for (int i = lane; i < (s + 31) / 32; i += 64) mt[i] = 0;
-    __syncthreads();
     uint32_t* Dw = (uint32_t*)D;
+    for (int i = lane; i < (s + DPER - 1) / DPER; i += 64) Dw[i] = 0;
+    for (int i = lane; i < (s + 31) / 32; i += 64) mt[i] = 0;
+    wave_sync();
+    auto d_inc = [&](int g) {                                    // packed counter += 1 with overflow detection
+      const int sh = DBITS * (g % DPER);
+      const uint32_t old = atomicAdd(&Dw[g / DPER], 1u << sh);
+      if ((int)((old >> sh) & (uint32_t)DMAX) == DMAX) overflow = 1;
+    };
     Rec nx[4];
     for (int i = 0; i < 4; ++i) { const int64_t j = nb + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
     for (int64_t base = nb; base < ne; base += 256) {
@@ -171,18 +199,18 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
         if (in && code >= 0) atomicOr(&mt[code >> 5], 1u << (code & 31));
         const bool wonly = in && code < 0 && g < s;
         const bool flagged = wonly && (x[i].pw & PW_DP);          // an earlier occurrence exists in the contig: inside the window?
-        if (wonly && !flagged) atomicAdd(&Dw[g >> 1], (g & 1) ? 0x10000u : 1u);
+        if (wonly && !flagged) d_inc(g);
         uint64_t fm = __ballot(flagged);                         // rare: resolved one by one with a wave-wide scan
         while (fm) {
           const int l = __ffsll((unsigned long long)fm) - 1;
           fm &= fm - 1;
           const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)x[i].hash, l);
           const bool dup = wave_has_hash(pos, nb, base + l + 64 * i, hj, lane);
-          if (!dup && lane == l) atomicAdd(&Dw[g >> 1], (g & 1) ? 0x10000u : 1u);
+          if (!dup && lane == l) d_inc(g);
         }
       }
     }
-    __syncthreads();
+    wave_sync();
     // pivot: R = min r with r + C(r) >= s
     const int chunk = (s + 63) / 64;
     const int r_lo = min(lane * chunk, s), r_hi = min(r_lo + chunk, s);
@@ -240,7 +268,7 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
   bool done = false;
   if (SKIP && M <= L2_MCAP && M > 192) {
     // ---- class bits of every streamed entry: ballot masks + block prefixes in LDS ----------------------
-    uint64_t* mAll = (uint64_t*)(lds + l2_state_bytes(smax) / 4);
+    uint64_t* mAll = (uint64_t*)(wbase + l2_wave_bytes<DT>(smax, false));
     uint64_t* mLo = mAll + (L2_NBLK + 1);
     uint64_t* mA = mLo + (L2_NBLK + 1);
     uint16_t* pAll = (uint16_t*)(mA + (L2_NBLK + 1));
@@ -271,7 +299,7 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
         }
       }
       if (lane == 0) { mAll[nblk] = 0; pAll[nblk] = (uint16_t)run; }
-      __syncthreads();
+      wave_sync();
     };
     // pass B: rank below r0  <=>  hash below Q[r0]; no search needed once the matched bits are known
     auto pass_low = [&](int r0) {
@@ -293,7 +321,7 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
         runL += __popcll(bl); runW += __popcll(bw);
       }
       if (lane == 0) { mLo[nblk] = 0; pLo[nblk] = (uint16_t)runL; mA[nblk] = 0; pA[nblk] = (uint16_t)runW; }
-      __syncthreads();
+      wave_sync();
     };
     lap(0);
     pass_matched();
@@ -362,9 +390,9 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
     }
   }
   if (!done) {                                                   // full slide, exactly the reference's order
-    for (int i = lane; i < s; i += 64) D[i] = 0;
+    for (int i = lane; i < (s + DPER - 1) / DPER; i += 64) ((uint32_t*)D)[i] = 0;
     for (int i = lane; i < (s + 31) / 32; i += 64) mt[i] = 0;
-    __syncthreads();
+    wave_sync();
     l2_reset(S);
     const int64_t first_end = index_search(I, contig, pw_wpos(pos[first].pw) + cnt);   // :473
     b = first; e = first;
@@ -401,6 +429,10 @@ __global__ void __launch_bounds__(64) l2_kernel(IndexView I, const int32_t* __re
     }
     votes = wave_sum(votes);
     strand = votes > 0 ? 1 : -1;
+  }
+  if (__ballot(overflow || S.overflow)) {                        // a packed counter saturated: redo this candidate with wide counters
+    if (lane == 0 && ovf_list) ovf_list[atomicAdd(ovf_n, 1u)] = (int32_t)c;
+    accepted = 0; best = 0;
   }
   if (lane == 0) {
     L2Result o;

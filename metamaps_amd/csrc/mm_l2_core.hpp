@@ -29,15 +29,21 @@
 
 namespace mm {
 
-struct L2State {
+// DT = uint16_t (always sufficient: a window holds < 65536 entries for reads up to 64 kb; longer reads are rejected
+// by the caller) or uint8_t (compact variant; `overflow` is raised if a gap ever holds more than 255 distinct
+// hashes and the caller redoes the candidate with the wide type).
+template <typename DT>
+struct L2StateT {
   const uint32_t* Q;   // sorted unique sketch hashes
-  uint16_t* D;         // [s] distinct W-only hashes per gap (gap s is never needed)
+  DT* D;               // [s] distinct W-only hashes per gap (gap s is never needed)
   uint32_t* mt;        // [(s+31)/32] matched-rank bitmap
   int s;
   int R;               // pivot rank: ranks < R are counted
   int Cb;              // D[0] + ... + D[R-1]
   int shared;
+  int overflow;
 };
+using L2State = L2StateT<uint16_t>;
 
 // code >= 0: matched rank; code < 0: W-only in gap g = -code-1 (g == s means "above every query hash")
 MM_HD int l2_classify(const uint32_t* Q, int s, uint32_t h) {
@@ -46,26 +52,26 @@ MM_HD int l2_classify(const uint32_t* Q, int s, uint32_t h) {
   return (lo < s && Q[lo] == h) ? lo : -(lo + 1);
 }
 
-MM_HD void l2_reset(L2State& S) { S.R = S.s; S.Cb = 0; S.shared = 0; }   // arrays must be zeroed by the caller
+template <typename DT> MM_HD void l2_reset(L2StateT<DT>& S) { S.R = S.s; S.Cb = 0; S.shared = 0; S.overflow = 0; }   // arrays must be zeroed by the caller
 
-MM_HD bool l2_mt_test(const L2State& S, int r) { return (S.mt[r >> 5] >> (r & 31)) & 1u; }
+template <typename DT> MM_HD bool l2_mt_test(const L2StateT<DT>& S, int r) { return (S.mt[r >> 5] >> (r & 31)) & 1u; }
 
 // Every event gathers all the array cells it can possibly need with INDEPENDENT loads first (on the device:
 // one LDS round trip instead of a chain of dependent ones), then decides in registers.
 
 // a matched hash enters the window (first occurrence, sign=+1) / leaves it (last occurrence, sign=-1)
-MM_HD void l2_matched_event(L2State& S, int r, int sign) {
+template <typename DT> MM_HD void l2_matched_event(L2StateT<DT>& S, int r, int sign) {
   const uint32_t bit = 1u << (r & 31);
   uint32_t wd = S.mt[r >> 5];
   wd = sign > 0 ? (wd | bit) : (wd & ~bit);
   S.mt[r >> 5] = wd;
   if (r < S.R) S.shared += sign;
 }
-MM_HD void l2_add_matched(L2State& S, int r) { l2_matched_event(S, r, +1); }
-MM_HD void l2_del_matched(L2State& S, int r) { l2_matched_event(S, r, -1); }
+template <typename DT> MM_HD void l2_add_matched(L2StateT<DT>& S, int r) { l2_matched_event(S, r, +1); }
+template <typename DT> MM_HD void l2_del_matched(L2StateT<DT>& S, int r) { l2_matched_event(S, r, -1); }
 
 // a distinct W-only hash of gap g enters (sign=+1) / leaves (sign=-1)
-MM_HD void l2_wonly_event(L2State& S, int g, int sign) {
+template <typename DT> MM_HD void l2_wonly_event(L2StateT<DT>& S, int g, int sign) {
   if (g >= S.s) return;
   const int R = S.R;
   const int rm1 = R > 0 ? R - 1 : 0;            // rank just below the pivot (dummy 0 when R == 0)
@@ -75,7 +81,8 @@ MM_HD void l2_wonly_event(L2State& S, int g, int sign) {
   int dRm1 = S.D[rm1];
   const uint32_t wR = S.mt[rr >> 5], wRm1 = S.mt[rm1 >> 5];
   dg += sign;
-  S.D[g] = (uint16_t)dg;
+  if (dg > (int)(DT)~(DT)0) S.overflow = 1;
+  S.D[g] = (DT)dg;
   if (g == rr) dR = dg;                         // the cells were read before the update
   if (g == rm1) dRm1 = dg;
   if (sign > 0) {
@@ -96,7 +103,7 @@ MM_HD void l2_wonly_event(L2State& S, int g, int sign) {
     }
   }
 }
-MM_HD void l2_add_wonly(L2State& S, int g) { l2_wonly_event(S, g, +1); }
-MM_HD void l2_del_wonly(L2State& S, int g) { l2_wonly_event(S, g, -1); }
+template <typename DT> MM_HD void l2_add_wonly(L2StateT<DT>& S, int g) { l2_wonly_event(S, g, +1); }
+template <typename DT> MM_HD void l2_del_wonly(L2StateT<DT>& S, int g) { l2_wonly_event(S, g, -1); }
 
 }  // namespace mm

@@ -565,21 +565,49 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     const int smax = M->smax;
     const char* full_env = getenv("MM_L2_FULL");                 // cross-check switch: evaluate every window
     const bool skip = !(full_env && full_env[0] == '1');
-    const size_t lds = l2_lds_bytes(smax, skip);
-    MM_REQUIRE(lds <= 160 * 1024, MM_ERR_LIMIT, "sketch too large for the L2 window state in LDS (read longer than ~115 kb at w=8)");
-    if (lds > 64 * 1024) {
-      MM_HIP(hipFuncSetAttribute((const void*)l2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      MM_HIP(hipFuncSetAttribute((const void*)l2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    const size_t lds_wide = l2_lds_bytes<uint16_t>(smax, skip, 1);
+    const size_t lds_c4 = l2_lds_bytes<uint8_t>(smax, true, 4);
+    MM_REQUIRE(lds_wide <= 160 * 1024, MM_ERR_LIMIT, "sketch too large for the L2 window state in LDS (read longer than ~115 kb at w=8)");
+    auto set_lds = [&](const void* fn, size_t bytes) { if (bytes > 64 * 1024) MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); };
     DBuf<unsigned long long> counters(11); counters.zero(st);
+    DBuf<int32_t> ovf((size_t)ncand);
+    DBuf<unsigned int> ovf_n(1); ovf_n.zero(st);
     const size_t t_l2 = T.begin(&M->stats.ms_l2);
-    if (skip)
-      l2_kernel<true><<<dim3((unsigned)ncand), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p,
-                                                                   M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p);
-    else
-      l2_kernel<false><<<dim3((unsigned)ncand), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p,
-                                                                    M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p);
-    MM_KERNEL_CHECK();
+    if (!skip) {
+      set_lds((const void*)l2_kernel<false, uint16_t, 1>, lds_wide);
+      l2_kernel<false, uint16_t, 1><<<dim3((unsigned)ncand), dim3(64), lds_wide, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+          M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, nullptr, nullptr, nullptr);
+      MM_KERNEL_CHECK();
+    } else if (lds_c4 <= 160 * 1024) {
+      // compact path: four candidates of one read per workgroup share the sketch; 8-bit gap counters
+      std::vector<int32_t> g0, gn;
+      for (int64_t r = 0; r < n; ++r)
+        for (uint64_t c0 = M->h_cand_off[(size_t)r]; c0 < M->h_cand_off[(size_t)r + 1]; c0 += 4) {
+          g0.push_back((int32_t)c0);
+          gn.push_back((int32_t)std::min<uint64_t>(4, M->h_cand_off[(size_t)r + 1] - c0));
+        }
+      DBuf<int32_t> d_g0(g0.size()), d_gn(gn.size());
+      d_g0.upload(g0.data(), g0.size(), st); d_gn.upload(gn.data(), gn.size(), st);
+      set_lds((const void*)l2_kernel<true, uint8_t, 4>, lds_c4);
+      l2_kernel<true, uint8_t, 4><<<dim3((unsigned)g0.size()), dim3(256), lds_c4, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+          M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, d_g0.p, d_gn.p, nullptr, ovf.p, ovf_n.p);
+      MM_KERNEL_CHECK();
+      unsigned int h_ovf = 0;
+      MM_HIP(hipMemcpyAsync(&h_ovf, ovf_n.p, sizeof h_ovf, hipMemcpyDeviceToHost, st));
+      MM_HIP(hipStreamSynchronize(st));                          // also keeps g0/gn alive until the upload is done
+      if (h_ovf) {                                               // saturated 8-bit counters: redo those candidates with 16-bit ones
+        set_lds((const void*)l2_kernel<true, uint16_t, 1>, lds_wide);
+        l2_kernel<true, uint16_t, 1><<<dim3(h_ovf), dim3(64), lds_wide, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr);
+        MM_KERNEL_CHECK();
+      }
+      M->stats.n_l2_wide_redo = (int64_t)h_ovf;
+    } else {
+      set_lds((const void*)l2_kernel<true, uint16_t, 1>, lds_wide);
+      l2_kernel<true, uint16_t, 1><<<dim3((unsigned)ncand), dim3(64), lds_wide, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+          M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, nullptr, nullptr, nullptr);
+      MM_KERNEL_CHECK();
+    }
     T.end(t_l2);
     auto hc = counters.to_host(st);
     M->stats.sum_l2_stream_entries = (int64_t)hc[0];

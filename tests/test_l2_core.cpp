@@ -6,8 +6,13 @@
 #include <random>
 #include <cstdio>
 
+template <typename DT> int run(int rounds);
 int main(int argc, char** argv) {
   int rounds = argc > 1 ? atoi(argv[1]) : 300;
+  if (run<uint16_t>(rounds)) return 1;
+  return run<uint8_t>(rounds);
+}
+template <typename DT> int run(int rounds) {
   std::mt19937_64 rng(12345);
   long long checked = 0, dups = 0;
   for (int it = 0; it < rounds; ++it) {
@@ -20,8 +25,8 @@ int main(int argc, char** argv) {
     int M = 50 + rng() % 1500;
     std::vector<orc::Mz> X(M);
     for (int i = 0; i < M; ++i) X[i] = orc::Mz{(uint32_t)(rng() % space), 0, i, 1};
-    std::vector<uint16_t> D(s, 0); std::vector<uint32_t> mt((s + 31) / 32, 0);
-    mm::L2State S{Qh.data(), D.data(), mt.data(), s, 0, 0, 0};
+    std::vector<DT> D(s, 0); std::vector<uint32_t> mt((s + 31) / 32, 0);
+    mm::L2StateT<DT> S{Qh.data(), D.data(), mt.data(), s, 0, 0, 0, 0};
     mm::l2_reset(S);
     orc::SlideWindow ref(Q);
     int b = 0, e = 0;                                          // window [b,e)
@@ -42,9 +47,10 @@ int main(int argc, char** argv) {
         ref.erase(X[b]); ++b;
       }
       ++checked;
+      if (S.overflow) { printf("unexpected overflow\n"); return 1; }
       if (S.shared != ref.shared) { printf("MISMATCH it=%d step=%d shared=%d ref=%d s=%d\n", it, step, S.shared, ref.shared, s); return 1; }
     }
   }
-  printf("ok %lld events, %lld duplicate inserts\n", checked, dups);
+  printf("ok %lld events, %lld duplicate inserts (D width %d)\n", checked, dups, (int)sizeof(DT));
   return 0;
 }

@@ -107,13 +107,17 @@ def main():
     ctx.synchronize()
 
     agg = {"ms_l2": 0.0, "l2_launches": 0, "l2_stream": 0, "stats": None, "em_iters": 0}
+    rec_buf = np.empty(max(64 * args.reads, 1 << 16), dtype=capi.RECORD_DTYPE)   # host result buffer reused by every step
 
     def step():
+        tt = [time.perf_counter()]
         M = ctx.map_batch(idx, reads, k, w, pi=80.0, min_read_len=1000)
+        tt.append(time.perf_counter())
         M.add_qualities(k)
-        off, rec = M.fetch()
+        off, rec = M.fetch(rec_buf)
         st = M.stats()
         M.close()
+        tt.append(time.perf_counter())
         # ---- classify: host preparation of the EM problem (fEM.h:234-373), then device iterations
         n_reads = len(off) - 1
         taxon = rec["ref_contig"].astype(np.int32)            # one contig per genome = one taxon per contig
@@ -141,8 +145,12 @@ def main():
             f, ll_prev = f_next, ll
             if stop:
                 break
+        tt.append(time.perf_counter())
         post, best = em.posteriors(f)
         em.close()
+        tt.append(time.perf_counter())
+        agg["host_ms"] = {"map_batch": (tt[1] - tt[0]) * 1e3, "mapq_fetch": (tt[2] - tt[1]) * 1e3, "em_prepare_iterate": (tt[3] - tt[2]) * 1e3,
+                          "posteriors": (tt[4] - tt[3]) * 1e3}
         agg["ms_l2"] += st["ms_l2"]; agg["l2_launches"] += 1; agg["l2_stream"] += st["sum_l2_stream_entries"]
         agg["stats"] = st; agg["em_iters"] = len(lls)
         return st, f, best
@@ -196,6 +204,7 @@ def main():
                 "per_step": {kk: st[kk] for kk in ("n_reads_long_enough", "n_reads_mapped", "n_mappings", "sum_sketch", "sum_hits",
                                                    "n_candidates", "sum_l2_stream_entries", "sum_l2_evals", "n_ambiguous_sketch_reads")},
                 "stage_ms": {kk: round(st[kk], 3) for kk in st if kk.startswith("ms_")},
+                "host_wall_ms": {kk: round(v, 3) for kk, v in agg.get("host_ms", {}).items()},
             },
             "roofline": {"bound": "hbm", "kernel": "l2_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -331,11 +331,14 @@ class Mapping:
     def add_qualities(self, k: int):
         self.ctx.check(lib().mm_mapping_add_qualities(self.ctx.h, self.h, None, k))
 
-    def fetch(self):
-        off = np.zeros(self.n_reads + 1, dtype=np.int64)
+    def fetch(self, rec_buf: np.ndarray | None = None):
+        """offsets [n_reads+1] and the mm_map_record array.  `rec_buf` (RECORD_DTYPE, any capacity) lets a caller
+        that maps batch after batch reuse one host buffer instead of faulting in fresh pages every time."""
+        off = np.empty(self.n_reads + 1, dtype=np.int64)
         self.ctx.check(lib().mm_mapping_fetch(self.h, _ptr(off), None, 0))
-        rec = np.zeros(int(off[-1]), dtype=RECORD_DTYPE)
-        self.ctx.check(lib().mm_mapping_fetch(self.h, _ptr(off), _ptr(rec), len(rec)))
+        n = int(off[-1])
+        rec = rec_buf[:n] if rec_buf is not None and len(rec_buf) >= n else np.empty(n, dtype=RECORD_DTYPE)
+        self.ctx.check(lib().mm_mapping_fetch(self.h, _ptr(off), _ptr(rec), n))
         return off, rec
 
     def debug_sketch(self):

@@ -57,6 +57,7 @@ void mm_ctx_destroy(mm_ctx* ctx) {
   if (!ctx) return;
   (void)hipStreamSynchronize(ctx->stream);
   mm::comm_destroy(ctx);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -239,8 +240,13 @@ int mm_mapping_fetch(mm_mapping* m, int64_t* offsets, mm_map_record* records, in
     if (offsets) for (size_t i = 0; i < m->h_rec_off.size(); ++i) offsets[i] = (int64_t)m->h_rec_off[i];
     if (records) {
       MM_REQUIRE(cap >= m->n_rec, MM_ERR_ARG, "output capacity too small");
-      m->rec.download(records, (size_t)m->n_rec, m->ctx->stream);
-      MM_HIP(hipStreamSynchronize(m->ctx->stream));
+      const size_t bytes = (size_t)m->n_rec * sizeof(mm_map_record);
+      if (bytes) {                                               // device -> pinned bounce buffer -> caller memory
+        void* pin = m->ctx->pinned_at_least(bytes);
+        MM_HIP(hipMemcpyAsync(pin, m->rec.p, bytes, hipMemcpyDeviceToHost, m->ctx->stream));
+        MM_HIP(hipStreamSynchronize(m->ctx->stream));
+        memcpy(records, pin, bytes);
+      }
     }
   });
 }

@@ -166,6 +166,18 @@ struct mm_ctx {
   // per-(k, pi) cache of the host statistics thresholds (pure functions of the sketch size), mm_stats.hpp
   std::shared_ptr<void> lut_cache;
   int lut_k = 0; float lut_pi = 0;
+  // pinned bounce buffer for result downloads into caller-owned (pageable) memory
+  void* pinned = nullptr; size_t pinned_bytes = 0;
+  void* pinned_at_least(size_t bytes) {
+    if (bytes > pinned_bytes) {
+      if (pinned) (void)hipHostFree(pinned);
+      pinned = nullptr; pinned_bytes = 0;
+      size_t want = bytes + bytes / 2 + (1 << 20);
+      MM_HIP(hipHostMalloc(&pinned, want, hipHostMallocDefault));
+      pinned_bytes = want;
+    }
+    return pinned;
+  }
 };
 
 struct mm_seqset {

@@ -15,7 +15,7 @@ void seqset_fetch(mm_seqset* s, int64_t i, char* out, int64_t cap);
 namespace {
 template <typename F>
 int guarded(mm_ctx* ctx, F&& f) {
-  if (ctx) mm::current_stream() = ctx->stream;
+  if (ctx) { mm::current_stream() = ctx->stream; mm::current_alloc() = &ctx->alloc; }
   try { f(); return MM_OK; }
   catch (const mm::Error& e) { if (ctx) ctx->err = e.what(); return e.status; }
   catch (const std::bad_alloc&) { if (ctx) ctx->err = "host allocation failed"; return MM_ERR_NOMEM; }
@@ -44,10 +44,7 @@ int mm_ctx_create(int device_id, mm_ctx** out) {
                std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
     c->cus = p.multiProcessorCount;
     MM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    hipMemPool_t pool;                                          // keep freed blocks cached in the pool
-    MM_HIP(hipDeviceGetDefaultMemPool(&pool, device_id));
-    uint64_t keep = UINT64_MAX;
-    MM_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+    c->alloc.stream = c->stream;
   });
   if (st != MM_OK) { delete c; return st; }
   *out = c;
@@ -56,6 +53,7 @@ int mm_ctx_create(int device_id, mm_ctx** out) {
 void mm_ctx_destroy(mm_ctx* ctx) {
   if (!ctx) return;
   (void)hipStreamSynchronize(ctx->stream);
+  ctx->alloc.trim();
   mm::comm_destroy(ctx);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -87,7 +85,7 @@ int mm_seqset_create(mm_ctx* ctx, mm_seqset** out) {
   if (!ctx || !out) return MM_ERR_ARG;
   return guarded(ctx, [&] { auto* s = new mm_seqset; s->ctx = ctx; *out = s; });
 }
-void mm_seqset_destroy(mm_seqset* s) { if (s) { mm::current_stream() = s->ctx->stream; delete s; } }
+void mm_seqset_destroy(mm_seqset* s) { if (s) { mm::current_stream() = s->ctx->stream; mm::current_alloc() = &s->ctx->alloc; delete s; } }
 int mm_seqset_add(mm_seqset* s, const char* ascii, int64_t len) {
   if (!s || (!ascii && len > 0) || len < 0) return MM_ERR_ARG;
   return guarded(s->ctx, [&] {
@@ -150,7 +148,7 @@ int mm_index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index
     *out = I;
   });
 }
-void mm_index_destroy(mm_index* idx) { if (idx) { mm::current_stream() = idx->ctx->stream; delete idx; } }
+void mm_index_destroy(mm_index* idx) { if (idx) { mm::current_stream() = idx->ctx->stream; mm::current_alloc() = &idx->ctx->alloc; delete idx; } }
 int mm_index_get_info(const mm_index* idx, mm_index_info* out) {
   if (!idx || !out) return MM_ERR_ARG;
   out->n_contigs = idx->n_contigs; out->n_entries = idx->N; out->n_unique_hashes = idx->U; out->n_dup_flagged = idx->n_dup;
@@ -228,7 +226,7 @@ int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const
     *out = M;
   });
 }
-void mm_mapping_destroy(mm_mapping* m) { if (m) { mm::current_stream() = m->ctx->stream; delete m; } }
+void mm_mapping_destroy(mm_mapping* m) { if (m) { mm::current_stream() = m->ctx->stream; mm::current_alloc() = &m->ctx->alloc; delete m; } }
 int mm_mapping_get_stats(const mm_mapping* m, mm_map_stats* out) {
   if (!m || !out) return MM_ERR_ARG;
   *out = m->stats;
@@ -367,7 +365,7 @@ int mm_em_create(mm_ctx* ctx, int64_t n_reads, const int64_t* read_off, const in
     *out = E;
   });
 }
-void mm_em_destroy(mm_em* em) { if (em) { mm::current_stream() = em->ctx->stream; delete em; } }
+void mm_em_destroy(mm_em* em) { if (em) { mm::current_stream() = em->ctx->stream; mm::current_alloc() = &em->ctx->alloc; delete em; } }
 int mm_em_iterate(mm_em* em, const double* f, double* f_partial, double* ll_partial) {
   if (!em || !f || !f_partial || !ll_partial) return MM_ERR_ARG;
   return guarded(em->ctx, [&] { MM_HIP(hipSetDevice(em->ctx->device)); mm::em_iterate(em, f, f_partial, ll_partial); });

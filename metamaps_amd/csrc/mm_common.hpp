@@ -3,11 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 #include <stdexcept>
 #include <memory>
+#include <map>
 #include "../../include/metamaps_hip.h"
 
 namespace mm {
@@ -28,41 +30,84 @@ struct Error : std::runtime_error {
   do { if (!(cond)) throw mm::Error((st), (msg)); } while (0)
 #define MM_KERNEL_CHECK() MM_HIP(hipGetLastError())
 
-// ---- device buffer ---------------------------------------------------------------------------------
-// Allocations are stream-ordered (hipMallocAsync on the context stream, pool kept warm), so that the dozens
-// of per-batch temporaries cost microseconds and never force a device-wide synchronisation the way
-// hipFree does.  The C ABI layer sets the current stream on entry (one ctx per host thread).
+// ---- device memory -----------------------------------------------------------------------------------
+// Per-context caching allocator.  A batch needs dozens of temporaries; hipMalloc/hipFree synchronise the
+// device, and ROCm 7.2's stream-ordered pool (hipMallocAsync) gave wrong results here when the library ran
+// on the system HIP runtime (it only behaved under the older runtime that PyTorch bundles), so blocks are
+// recycled by hand: a context owns ONE stream, every kernel and copy is issued on it, and a freed block
+// handed to a later allocation is therefore only touched by work that is stream-ordered after its previous
+// user.  Index-scale buffers (>= 8 GiB) bypass the cache.
+struct DevAlloc {
+  hipStream_t stream = nullptr;
+  std::multimap<size_t, void*> cache;        // size -> free block
+  size_t cached_bytes = 0;
+  static size_t round_up(size_t b) {
+    if (b < 4096) return 4096;
+    int lg = 63 - __builtin_clzll((unsigned long long)b);
+    size_t gran = (size_t)1 << (lg > 3 ? lg - 3 : 0);           // <= 12.5 % slack
+    return (b + gran - 1) / gran * gran;
+  }
+  void trim() {
+    if (cache.empty()) return;
+    (void)hipStreamSynchronize(stream);
+    for (auto& kv : cache) (void)hipFree(kv.second);
+    cache.clear(); cached_bytes = 0;
+  }
+  void* get(size_t bytes, size_t* got) {
+    const size_t want = round_up(bytes);
+    auto it = cache.lower_bound(want);
+    if (it != cache.end() && it->first <= want + want / 4) {
+      void* p = it->second; *got = it->first; cached_bytes -= it->first; cache.erase(it); return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); trim(); e = hipMalloc(&p, want); }
+    if (e != hipSuccess) { (void)hipGetLastError(); throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    *got = want;
+    return p;
+  }
+  void put(void* p, size_t bytes) { cache.emplace(bytes, p); cached_bytes += bytes; }
+  ~DevAlloc() { trim(); }
+};
+inline DevAlloc*& current_alloc() { static thread_local DevAlloc* a = nullptr; return a; }
 inline hipStream_t& current_stream() { static thread_local hipStream_t s = nullptr; return s; }
-
-constexpr size_t DIRECT_ALLOC_BYTES = (size_t)8 << 30;   // index-scale buffers bypass the pool (no fragmentation, exact accounting)
+constexpr size_t DIRECT_ALLOC_BYTES = (size_t)8 << 30;
 
 template <typename T>
 struct DBuf {
   T* p = nullptr;
   size_t n = 0;
-  bool direct = false;
+  size_t block = 0;            // bytes of the underlying block (0 = direct hipMalloc)
+  DevAlloc* owner = nullptr;
   DBuf() = default;
   explicit DBuf(size_t count) { alloc(count); }
   DBuf(const DBuf&) = delete;
   DBuf& operator=(const DBuf&) = delete;
-  DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), direct(o.direct) { o.p = nullptr; o.n = 0; }
-  DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; direct = o.direct; o.p = nullptr; o.n = 0; } return *this; }
+  DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), block(o.block), owner(o.owner) { o.p = nullptr; o.n = 0; }
+  DBuf& operator=(DBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; n = o.n; block = o.block; owner = o.owner; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
   ~DBuf() { release(); }
   void alloc(size_t count) {
     release();
     n = count;
     if (!count) return;
-    direct = count * sizeof(T) >= DIRECT_ALLOC_BYTES;
-    if (direct) { MM_HIP(hipStreamSynchronize(current_stream())); MM_HIP(hipMalloc((void**)&p, count * sizeof(T))); }
-    else MM_HIP(hipMallocAsync((void**)&p, count * sizeof(T), current_stream()));
+    const size_t bytes = count * sizeof(T);
+    owner = current_alloc();
+    if (bytes >= DIRECT_ALLOC_BYTES || !owner) {
+      if (owner) owner->trim();
+      block = 0;
+      MM_HIP(hipMalloc((void**)&p, bytes));
+    } else p = (T*)owner->get(bytes, &block);
   }
   void release() {
     if (p) {
-      if (direct) { (void)hipStreamSynchronize(current_stream()); (void)hipFree(p); }
-      else (void)hipFreeAsync(p, current_stream());
+      if (block && owner) owner->put(p, block);
+      else { (void)hipDeviceSynchronize(); (void)hipFree(p); }
       p = nullptr;
     }
-    n = 0;
+    n = 0; block = 0;
   }
   size_t bytes() const { return n * sizeof(T); }
   void zero(hipStream_t st) { if (n) MM_HIP(hipMemsetAsync(p, 0, bytes(), st)); }
@@ -159,6 +204,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 struct mm_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
+  mm::DevAlloc alloc;
   std::string err;
   int cus = 0;
   void* comm = nullptr;          // ncclComm_t

@@ -127,12 +127,7 @@ __global__ void __launch_bounds__(256) count_hist_kernel(const uint64_t* __restr
 
 void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* I) {
   hipStream_t st = ctx->stream;
-  {                                                             // hand cached pool blocks back before the big allocations
-    hipMemPool_t pool;
-    MM_HIP(hipStreamSynchronize(st));
-    MM_HIP(hipDeviceGetDefaultMemPool(&pool, ctx->device));
-    MM_HIP(hipMemPoolTrimTo(pool, 0));
-  }
+  ctx->alloc.trim();                                            // hand cached blocks back before the big allocations
   I->ctx = ctx; I->k = k; I->w = w;
   I->n_contigs = contigs->count();
   I->contig_len = contigs->len;

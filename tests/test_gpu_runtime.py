@@ -1,0 +1,42 @@
+"""The library must give the same answers whether it runs on the system HIP runtime (plain process, e.g. the
+C++ CLI) or on the runtime PyTorch bundles and loads first (pytest / bench.py).  A stream-ordered-allocator
+problem once made the two differ; this test keeps them tied."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import sys, json
+sys.path.insert(0, sys.argv[1])
+if sys.argv[2] == "torch":
+    import torch; torch.cuda.set_device(0)
+from metamaps_amd import capi
+ctx = capi.Context(0)
+ref = ctx.synth_reference(seed=3, n_species=48, strains_per_species=4, genome_len=500000, strain_divergence=0.02, genus_divergence=0.2)
+idx = ctx.index(ref, 16, 8)
+reads, _ = ctx.synth_reads(ref, seed=4, n_reads=1500, read_len=9000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=50)
+out = []
+for it in range(2):
+    M = ctx.map_batch(idx, reads, 16, 8); M.add_qualities(16)
+    off, rec = M.fetch(); s = M.stats(); M.close()
+    out.append([int(off[-1]), int(rec["ref_start"].astype("int64").sum()), int(rec["shared"].sum()), s["sum_hits"], s["n_candidates"], idx.info()["n_unique_hashes"]])
+print(json.dumps(out))
+'''
+
+
+def test_same_results_with_and_without_pytorch_runtime(tmp_path):
+    p = tmp_path / "w.py"
+    p.write_text(SCRIPT)
+    res = {}
+    for mode in ("plain", "torch"):
+        r = subprocess.run([sys.executable, str(p), ROOT, mode], capture_output=True, timeout=900)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        res[mode] = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert res["plain"] == res["torch"]
+    assert res["plain"][0] == res["plain"][1] and res["plain"][0][0] > 3000

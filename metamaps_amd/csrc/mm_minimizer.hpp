@@ -22,6 +22,7 @@ namespace mm {
 constexpr int MZ_THREADS = 256;
 constexpr int MZ_TILE = 2048;          // positions per workgroup
 constexpr int MZ_MAX_W = 4096;
+constexpr int MZ_STAGE = 1024;         // staged records per tile in the single-pass scheme
 constexpr int MZ_MAX_K = 64;
 
 struct SeqView {                       // device view of an mm_seqset
@@ -116,16 +117,20 @@ __device__ inline int64_t seq_of_tile(const uint64_t* __restrict__ tile_first, i
   return lo;
 }
 
-// WRITE=false: tile_count[tile] = number of emitted minimizers.  WRITE=true: records written at tile_out[tile]...
-template <bool WRITE>
+// MODE 0: tile_count[tile] = number of emitted minimizers (count pass of the two-pass scheme, index scale).
+// MODE 1: records written at tile_out[tile]... (write pass).
+// MODE 2: single pass — records staged at tile*MZ_STAGE and counted; compact_tiles_kernel then packs them.  A tile
+//         normally emits ~2/(w+1) of its 2048 positions; if one exceeds MZ_STAGE (low-complexity sequence) the
+//         overflow flag is raised and the caller falls back to the two-pass scheme.  Used for read batches.
+template <int MODE>
 __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const uint64_t* __restrict__ tile_first, int k, int w,
                                                                const int32_t* __restrict__ jstar, uint32_t* __restrict__ tile_count,
                                                                const uint64_t* __restrict__ tile_out, Rec* __restrict__ out,
-                                                               uint32_t* __restrict__ out_seq) {
+                                                               uint32_t* __restrict__ out_seq, int* __restrict__ stage_overflow) {
   extern __shared__ __align__(16) uint8_t smem[];
-  const int halo = 2 * (w - 1);
+  const int halo = (2 * (w - 1) + 7) & ~7;         // rounded so that the tile's first byte is 8-byte aligned in LDS
   const int NP = MZ_TILE + halo;                   // positions held
-  const int NB = ((NP + k - 1) + 15) & ~15;        // bytes held
+  const int NB = ((NP + k - 1 + 8) + 15) & ~15;    // bytes held (+8: the k=16 path reads whole 8-byte words)
   uint8_t* fwd = smem;
   uint8_t* cmp = fwd + NB;
   uint32_t* hsh = (uint32_t*)(cmp + NB);
@@ -173,25 +178,35 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
   }
   // 2. canonical hash / strand / non-symmetric flag per position
   const int np = Pend - H0;
-  for (int j = tid; j < np; j += MZ_THREADS) {
-    uint32_t hf, hb;
-    if (k == 16) {
-      uint64_t lo = 0, hi = 0, rlo = 0, rhi = 0;
+  if (k == 16) {
+    // eight consecutive positions per thread from three aligned 8-byte words per strand: the k-mer at offset i
+    // is a funnel shift of (w0,w1,w2); its reverse complement is the byte-swapped complement words
+    const uint64_t* f64 = (const uint64_t*)fwd;
+    const uint64_t* c64 = (const uint64_t*)cmp;
+    for (int g = tid; g * 8 < np; g += MZ_THREADS) {
+      const uint64_t w0 = f64[g], w1 = f64[g + 1], w2 = f64[g + 2];
+      const uint64_t c0 = c64[g], c1 = c64[g + 1], c2 = c64[g + 2];
 #pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        lo |= (uint64_t)fwd[j + b] << (8 * b);
-        hi |= (uint64_t)fwd[j + 8 + b] << (8 * b);
-        rlo |= (uint64_t)cmp[j + 15 - b] << (8 * b);
-        rhi |= (uint64_t)cmp[j + 7 - b] << (8 * b);
+      for (int i = 0; i < 8; ++i) {
+        const int j = g * 8 + i;
+        if (j >= np) break;
+        const uint64_t lo = i ? (w0 >> (8 * i)) | (w1 << (64 - 8 * i)) : w0;
+        const uint64_t hi = i ? (w1 >> (8 * i)) | (w2 << (64 - 8 * i)) : w1;
+        const uint64_t clo = i ? (c0 >> (8 * i)) | (c1 << (64 - 8 * i)) : c0;
+        const uint64_t chi = i ? (c1 >> (8 * i)) | (c2 << (64 - 8 * i)) : c1;
+        const uint32_t hf = murmur16(lo, hi);
+        const uint32_t hb = murmur16(__builtin_bswap64(chi), __builtin_bswap64(clo));
+        hsh[j] = hf < hb ? hf : hb;
+        flg[j] = (uint8_t)((hf != hb ? 1 : 0) | (hf < hb ? 2 : 0));
       }
-      hf = murmur16(lo, hi);
-      hb = murmur16(rlo, rhi);
-    } else {
-      hf = murmur_bytes<false>(fwd + j, k);
-      hb = murmur_bytes<true>(cmp + j + k - 1, k);
     }
-    hsh[j] = hf < hb ? hf : hb;
-    flg[j] = (uint8_t)((hf != hb ? 1 : 0) | (hf < hb ? 2 : 0));
+  } else {
+    for (int j = tid; j < np; j += MZ_THREADS) {
+      const uint32_t hf = murmur_bytes<false>(fwd + j, k);
+      const uint32_t hb = murmur_bytes<true>(cmp + j + k - 1, k);
+      hsh[j] = hf < hb ? hf : hb;
+      flg[j] = (uint8_t)((hf != hb ? 1 : 0) | (hf < hb ? 2 : 0));
+    }
   }
   __syncthreads();
   // 3. window argmin c(p) for every evaluated position from P0-(w-1) on
@@ -227,10 +242,10 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
   const uint32_t cnt = __popc(mask);
   uint64_t tot;
   uint64_t ex = block_excl_scan_u64(cnt, &tot);
-  if (!WRITE) {
-    if (tid == 0) tile_count[tile] = (uint32_t)tot;
-  } else {
-    uint64_t o = tile_out[tile] + ex;
+  if (MODE != 1 && tid == 0) tile_count[tile] = (uint32_t)tot;
+  if (MODE == 2 && tot > MZ_STAGE) { if (tid == 0) atomicExch(stage_overflow, 1); return; }
+  if (MODE != 0) {
+    uint64_t o = (MODE == 1 ? tile_out[tile] : tile * (uint64_t)MZ_STAGE) + ex;
 #pragma unroll
     for (int i = 0; i < MZ_TILE / MZ_THREADS; ++i) {
       if (mask & (1u << i)) {
@@ -244,8 +259,17 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
   }
 }
 
+// packs the staged tiles of the single-pass scheme
+static __global__ void __launch_bounds__(256) compact_tiles_kernel(const Rec* __restrict__ stage, const uint32_t* __restrict__ tile_count,
+                                                                   const uint64_t* __restrict__ tile_out, Rec* __restrict__ out) {
+  const uint64_t tile = blockIdx.x;
+  const uint32_t n = tile_count[tile];
+  const uint64_t o = tile_out[tile];
+  for (uint32_t i = threadIdx.x; i < n; i += 256) out[o + i] = stage[tile * (uint64_t)MZ_STAGE + i];
+}
+
 inline size_t minimizer_lds_bytes(int k, int w) {
-  int halo = 2 * (w - 1), NP = MZ_TILE + halo, NB = ((NP + k - 1) + 15) & ~15;
+  int halo = (2 * (w - 1) + 7) & ~7, NP = MZ_TILE + halo, NB = ((NP + k - 1 + 8) + 15) & ~15;
   return (size_t)2 * NB + (size_t)NP * 4 + (size_t)NP * 2 + (size_t)NP;
 }
 

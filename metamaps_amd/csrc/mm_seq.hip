@@ -46,23 +46,39 @@ void run_minimizers(mm_ctx* ctx, const mm_seqset* S, int k, int w, const std::ve
 
   const size_t lds = minimizer_lds_bytes(k, w);
   if (lds > 64 * 1024) {
-    MM_HIP(hipFuncSetAttribute((const void*)minimizer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MM_HIP(hipFuncSetAttribute((const void*)minimizer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MM_HIP(hipFuncSetAttribute((const void*)minimizer_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MM_HIP(hipFuncSetAttribute((const void*)minimizer_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MM_HIP(hipFuncSetAttribute((const void*)minimizer_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   DBuf<uint32_t> tcount((size_t)ntiles);
   DBuf<uint64_t> tout((size_t)ntiles + 1), tmp;
-  minimizer_kernel<false><<<dim3((unsigned)ntiles), dim3(MZ_THREADS), lds, st>>>(V, d_tf.p, k, w, d_js.p, tcount.p, nullptr, nullptr, nullptr);
+  // hashing is the expensive part: do it once when a per-tile staging area (16 KiB per tile) is affordable
+  bool single_pass = !want_rec_seq && (size_t)ntiles * MZ_STAGE * sizeof(Rec) <= ((size_t)6 << 30);
+  DBuf<Rec> stage;
+  DBuf<int> d_ovf(1); d_ovf.zero(st);
+  if (single_pass) {
+    stage.alloc((size_t)ntiles * MZ_STAGE);
+    minimizer_kernel<2><<<dim3((unsigned)ntiles), dim3(MZ_THREADS), lds, st>>>(V, d_tf.p, k, w, d_js.p, tcount.p, nullptr, stage.p, nullptr, d_ovf.p);
+  } else {
+    minimizer_kernel<0><<<dim3((unsigned)ntiles), dim3(MZ_THREADS), lds, st>>>(V, d_tf.p, k, w, d_js.p, tcount.p, nullptr, nullptr, nullptr, nullptr);
+  }
   MM_KERNEL_CHECK();
   exclusive_scan_u32_u64(tcount.p, ntiles, tout.p, tmp, st);
   uint64_t total = 0;
+  int h_ovf = 0;
   MM_HIP(hipMemcpyAsync(&total, tout.p + ntiles, sizeof total, hipMemcpyDeviceToHost, st));
+  MM_HIP(hipMemcpyAsync(&h_ovf, d_ovf.p, sizeof h_ovf, hipMemcpyDeviceToHost, st));
   MM_HIP(hipStreamSynchronize(st));
+  if (h_ovf) single_pass = false;                                // some tile emitted more than MZ_STAGE records: counts are right, redo the write
   out.total = (int64_t)total;
   out.rec.alloc((size_t)total);
   if (want_rec_seq) out.rec_seq.alloc((size_t)total);
   if (total) {
-    minimizer_kernel<true><<<dim3((unsigned)ntiles), dim3(MZ_THREADS), lds, st>>>(V, d_tf.p, k, w, d_js.p, nullptr, tout.p, out.rec.p,
-                                                                                 want_rec_seq ? out.rec_seq.p : nullptr);
+    if (single_pass)
+      compact_tiles_kernel<<<dim3((unsigned)ntiles), dim3(256), 0, st>>>(stage.p, tcount.p, tout.p, out.rec.p);
+    else
+      minimizer_kernel<1><<<dim3((unsigned)ntiles), dim3(MZ_THREADS), lds, st>>>(V, d_tf.p, k, w, d_js.p, nullptr, tout.p, out.rec.p,
+                                                                               want_rec_seq ? out.rec_seq.p : nullptr, nullptr);
     MM_KERNEL_CHECK();
   }
   gather_offsets_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(d_tf.p, tout.p, n, out.off.p);

@@ -40,7 +40,8 @@ def adversarial_sequences(seed, n, kmax=21):
         else:
             s = bytes(rnd.choice(b"AC") for _ in range(L))
         out.append(s)
-    out += [b"ACGT", b"A" * 40, b"N" * 50, b"ACGTACGTACGTACGTA", bytes(random.Random(3).choice(b"ACGT") for _ in range(9000))]
+    out += [b"ACGT", b"A" * 40, b"N" * 50, b"ACGTACGTACGTACGTA", bytes(random.Random(3).choice(b"ACGT") for _ in range(9000)),
+            b"AC" * 3000, b"ACG" * 2500 + b"T" * 3000, b"A" * 6000]      # > 1024 minimizers per 2048-position tile (staging overflow path)
     return out
 
 

@@ -123,10 +123,13 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
 
   const int contig = cand[3 * c], rs = cand[3 * c + 1], re = cand[3 * c + 2];
   const int cnt = len - (w - 1) - (k - 1);                       // computeMap.hpp:470
-  const Rec* __restrict__ pos = I.pos;
-  const int64_t first = index_search(I, contig, rs);             // :466
-  const int64_t last_end = index_search(I, contig, re + len);    // :477
-  const int64_t nmax = I.N - 1;
+  // all window arithmetic below is 32-bit and relative to the first streamed entry of this candidate
+  const int64_t first0 = index_search(I, contig, rs);            // :466
+  const int64_t last0 = index_search(I, contig, re + len);       // :477
+  const Rec* __restrict__ pos = I.pos + first0;
+  const int first = 0;
+  const int last_end = (int)(last0 - first0);
+  const int nmax = (int)min((int64_t)0x7fffffff, I.N - 1 - first0);
   int amin = accept_min[r]; if (amin < 1) amin = 1;
 
   L2StateT<DT> S{Q, D, mt, s, 0, 0, 0, 0};
@@ -135,23 +138,23 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   auto lap = [&](int ph) { long long now = clock64(); tph[ph] += now - tmark; tmark = now; };
 
   // e_min(b): first entry at or after b whose wpos >= wpos[b] + cnt (never beyond last_end)
-  auto e_min = [&](int64_t bb) -> int64_t {
+  auto e_min = [&](int bb) -> int {
     const int target = pw_wpos(pos[bb].pw) + cnt;
-    int64_t lo = bb, hi = last_end;
-    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (pw_wpos(pos[mid].pw) < target) lo = mid + 1; else hi = mid; }
+    int lo = bb, hi = last_end;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (pw_wpos(pos[mid].pw) < target) lo = mid + 1; else hi = mid; }
     return lo;
   };
 
   // ---- register-resident chunks of 64 consecutive entries at both window ends -------------------------
-  int64_t baseB = first, baseE = first;
+  int baseB = first, baseE = first;
   Rec rb = pos[min(baseB + lane, nmax)], rE = rb;
   int codeB = l2_classify(Q, s, rb.hash), codeE = codeB;
-  auto loadB = [&](int64_t nb) { baseB = nb; rb = pos[min(nb + lane, nmax)]; codeB = l2_classify(Q, s, rb.hash); };
-  auto loadE = [&](int64_t ne) { baseE = ne; rE = pos[min(ne + lane, nmax)]; codeE = l2_classify(Q, s, rE.hash); };
+  auto loadB = [&](int nb) { baseB = nb; rb = pos[min(nb + lane, nmax)]; codeB = l2_classify(Q, s, rb.hash); };
+  auto loadE = [&](int ne) { baseE = ne; rE = pos[min(ne + lane, nmax)]; codeE = l2_classify(Q, s, rE.hash); };
 
-  int64_t b = first, e = first;
+  int b = first, e = first;
   int sw_pos = 0;
-  auto add_entry = [&](int64_t x) {                              // slidingMap.hpp:139-160
+  auto add_entry = [&](int x) {                              // slidingMap.hpp:139-160
     if (x - baseE >= 64 || x < baseE) loadE(x);
     const int ln = (int)(x - baseE);
     const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)rE.hash, ln);
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     if ((pw & PW_DP) && wave_has_hash(pos, b, x, h, lane)) return;   // REV: hash already in the window
     if (code >= 0) l2_add_matched(S, code); else l2_add_wonly(S, -code - 1);
   };
-  auto del_entry = [&](int64_t x, int64_t wend) {                // slidingMap.hpp:170-214
+  auto del_entry = [&](int x, int wend) {                // slidingMap.hpp:170-214
     const int ln = (int)(x - baseB);
     const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)rb.hash, ln);
     const uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)rb.pw, ln);
@@ -173,7 +176,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
 
   // ---- state of window [nb,ne) from scratch, all lanes (the arrays are order independent) ---------------
   unsigned long long rebuilds = 0;
-  auto rebuild = [&](int64_t nb, int64_t ne) {
+  auto rebuild = [&](int nb, int ne) {
     ++rebuilds;
     uint32_t* Dw = (uint32_t*)D;
     for (int i = lane; i < (s + DPER - 1) / DPER; i += 64) Dw[i] = 0;
@@ -185,14 +188,14 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       if ((int)((old >> sh) & (uint32_t)DMAX) == DMAX) overflow = 1;
     };
     Rec nx[4];
-    for (int i = 0; i < 4; ++i) { const int64_t j = nb + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
-    for (int64_t base = nb; base < ne; base += 256) {
+    for (int i = 0; i < 4; ++i) { const int j = nb + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
+    for (int base = nb; base < ne; base += 256) {
       Rec x[4]; uint32_t hh[4]; int cd[4];
       for (int i = 0; i < 4; ++i) { x[i] = nx[i]; hh[i] = x[i].hash; }
-      if (base + 256 < ne) for (int i = 0; i < 4; ++i) { const int64_t j = base + 256 + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }   // prefetch
+      if (base + 256 < ne) for (int i = 0; i < 4; ++i) { const int j = base + 256 + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }   // prefetch
       l2_classify4(Q, s, hh, cd);
       for (int i = 0; i < 4; ++i) {
-        const int64_t j = base + lane + 64 * i;
+        const int j = base + lane + 64 * i;
         const int code = cd[i];
         const int g = -code - 1;
         const bool in = j < ne;
@@ -239,12 +242,12 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
 
   // ---- the reference's loop body (computeMap.hpp:496-533): evaluate [b,e), then MIIteratorL2::next ------
   int best = 0, bestR = 0, beg_pos = 0, last_pos = 0;
-  int64_t opt_b = 0, opt_e = 0;
+  int opt_b = 0, opt_e = 0;
   unsigned long long evals = 0;
   int probe_best = 0, probe_R = 0;
   // slides while e < last_end and b < b_stop; TRACK=false only records the maximum (for the bound), it does
   // not touch the reference-visible trackers
-  auto slide = [&](int64_t b_stop, bool track) {
+  auto slide = [&](int b_stop, bool track) {
     while (e < last_end && b < b_stop) {
       if (b + 1 - baseB >= 64 || b < baseB) loadB(b);
       if (e - baseE >= 64 || e < baseE) loadE(e);
@@ -264,7 +267,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     }
   };
 
-  const int64_t M = last_end - first;
+  const int M = last_end - first;
   bool done = false;
   if (SKIP && M <= L2_MCAP && M > 192) {
     // ---- class bits of every streamed entry: ballot masks + block prefixes in LDS ----------------------
@@ -275,7 +278,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     uint16_t* pLo = pAll + (L2_NBLK + 1);
     uint16_t* pA = pLo + (L2_NBLK + 1);
     const int nblk = (int)((M + 63) >> 6);
-    auto pfx = [&](const uint64_t* m, const uint16_t* p, int64_t j) -> int {   // set bits among entries [first, j)
+    auto pfx = [&](const uint64_t* m, const uint16_t* p, int j) -> int {   // set bits among entries [first, j)
       const int o = (int)(j - first), bk = o >> 6, bit = o & 63;
       return (int)p[bk] + __popcll(m[bk] & ((1ull << bit) - 1ull));
     };
@@ -283,14 +286,14 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     auto pass_matched = [&]() {
       int run = 0;
       Rec nx[4];
-      for (int i = 0; i < 4; ++i) { const int64_t j = first + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
-      for (int64_t base = first; base < last_end; base += 256) {
+      for (int i = 0; i < 4; ++i) { const int j = first + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
+      for (int base = first; base < last_end; base += 256) {
         uint32_t hh[4]; int cd[4];
         for (int i = 0; i < 4; ++i) hh[i] = nx[i].hash;
-        if (base + 256 < last_end) for (int i = 0; i < 4; ++i) { const int64_t j = base + 256 + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
+        if (base + 256 < last_end) for (int i = 0; i < 4; ++i) { const int j = base + 256 + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
         l2_classify4(Q, s, hh, cd);
         for (int i = 0; i < 4; ++i) {
-          const int64_t j = base + lane + 64 * i;
+          const int j = base + lane + 64 * i;
           const int bk = (int)((base - first) >> 6) + i;
           if (bk >= nblk) break;
           const uint64_t ba = __ballot(j < last_end && cd[i] >= 0);
@@ -307,7 +310,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       const uint32_t qr0 = every ? 0u : Q[r0];
       int runL = 0, runW = 0;
       for (int bk = 0; bk < nblk; ++bk) {
-        const int64_t j = first + (int64_t)bk * 64 + lane;
+        const int j = first + (int)bk * 64 + lane;
         bool lo = false, aw = false;
         if (j < last_end) {
           const Rec x = pos[j];
@@ -328,12 +331,12 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     lap(1);
     // per block of 64 b's: largest window [bF, eHi), smallest window [bL, eLo)
     // (lane l owns blocks l and l+64; L2_NBLK == 128)
-    int64_t eLo[2], eHi[2]; int ub_all[2];
+    int eLo[2], eHi[2]; int ub_all[2];
     for (int q = 0; q < 2; ++q) {
       const int bk = lane + 64 * q;
       eLo[q] = eHi[q] = last_end; ub_all[q] = -1;
       if (bk < nblk) {
-        const int64_t bF = first + (int64_t)bk * 64, bL = min(bF + 63, last_end - 1);
+        const int bF = first + (int)bk * 64, bL = min(bF + 63, last_end - 1);
         eLo[q] = e_min(bF);
         eHi[q] = (bL + 1 < last_end) ? e_min(bL + 1) : last_end;
         if (eLo[q] < last_end) ub_all[q] = pfx(mAll, pAll, eHi[q]) - pfx(mAll, pAll, bF);
@@ -347,7 +350,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       int key = max(ub_all[0], ub_all[1]) == ubmax ? ((ub_all[0] == ubmax) ? lane : lane + 64) : 1 << 20;
       const int bk0 = wave_min(key);
       {
-        const int64_t bF = first + (int64_t)bk0 * 64;
+        const int bF = first + (int)bk0 * 64;
         rebuild(bF, e_min(bF));
         lap(3);
         slide(bF + 64, false);
@@ -361,7 +364,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       auto bound = [&](int q) -> int {
         const int bk = lane + 64 * q;
         if (bk >= nblk || eLo[q] >= last_end) return -1;
-        const int64_t bF = first + (int64_t)bk * 64, bL = min(bF + 63, last_end - 1);
+        const int bF = first + (int)bk * 64, bL = min(bF + 63, last_end - 1);
         const int a = eLo[q] > bL ? pfx(mA, pA, eLo[q]) - pfx(mA, pA, bL) : 0;
         if (r0 + a >= s) return pfx(mLo, pLo, eHi[q]) - pfx(mLo, pLo, bF);
         return ub_all[q];
@@ -372,10 +375,10 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       for (int bk = 0; bk < nblk; ++bk) {
         const int u = __builtin_amdgcn_readlane(bk < 64 ? ub2[0] : ub2[1], bk & 63);
         const int thr = max(max(lb, best), amin);
-        const int64_t bF = first + (int64_t)bk * 64;
+        const int bF = first + (int)bk * 64;
         if (u < thr) { live = false; continue; }
         if (!(live && b == bF)) {
-          const int64_t em = e_min(bF);
+          const int em = e_min(bF);
           if (em >= last_end) break;
           lap(2);
           rebuild(bF, em);
@@ -394,7 +397,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     for (int i = lane; i < (s + 31) / 32; i += 64) mt[i] = 0;
     wave_sync();
     l2_reset(S);
-    const int64_t first_end = index_search(I, contig, pw_wpos(pos[first].pw) + cnt);   // :473
+    const int first_end = (int)(index_search(I, contig, pw_wpos(pos[first].pw) + cnt) - first0);   // :473
     b = first; e = first;
     loadB(first); loadE(first);
     for (; e < first_end; ++e) add_entry(e);                     // first super-window, :489
@@ -410,21 +413,28 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   if (best >= amin) {
     accepted = 1;
     int votes = 0;
-    for (int64_t base = opt_b; base < opt_e; base += 64) {
-      const int64_t j = base + lane;
-      Rec x{0, 0}; int code = -1;
-      if (j < opt_e) { x = pos[j]; code = l2_classify(Q, s, x.hash); }
-      const bool cnt_it = j < opt_e && code >= 0 && code < bestR;
-      const int contrib = cnt_it ? (sk_strand[qo + code] ? 1 : -1) * pw_strand(x.pw) : 0;
-      const bool flagged = cnt_it && (x.pw & PW_DN);              // a later occurrence exists in the contig: inside the window?
-      if (cnt_it && !flagged) votes += contrib;
-      uint64_t fm = __ballot(flagged);
-      while (fm) {
-        const int l = __ffsll((unsigned long long)fm) - 1;
-        fm &= fm - 1;
-        const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)x.hash, l);
-        const bool later = wave_has_hash(pos, base + l + 1, opt_e, hj, lane);
-        if (!later && lane == l) votes += contrib;
+    Rec nx[4];
+    for (int i = 0; i < 4; ++i) { const int j = opt_b + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
+    for (int base = opt_b; base < opt_e; base += 256) {
+      Rec x[4]; uint32_t hh[4]; int cd[4];
+      for (int i = 0; i < 4; ++i) { x[i] = nx[i]; hh[i] = x[i].hash; }
+      if (base + 256 < opt_e) for (int i = 0; i < 4; ++i) { const int j = base + 256 + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
+      l2_classify4(Q, s, hh, cd);
+      for (int i = 0; i < 4; ++i) {
+        const int j = base + lane + 64 * i;
+        const int code = cd[i];
+        const bool cnt_it = j < opt_e && code >= 0 && code < bestR;
+        const int contrib = cnt_it ? (sk_strand[qo + code] ? 1 : -1) * pw_strand(x[i].pw) : 0;
+        const bool flagged = cnt_it && (x[i].pw & PW_DN);         // a later occurrence exists in the contig: inside the window?
+        if (cnt_it && !flagged) votes += contrib;
+        uint64_t fm = __ballot(flagged);
+        while (fm) {
+          const int l = __ffsll((unsigned long long)fm) - 1;
+          fm &= fm - 1;
+          const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)x[i].hash, l);
+          const bool later = wave_has_hash(pos, base + l + 64 * i + 1, opt_e, hj, lane);
+          if (!later && lane == l) votes += contrib;
+        }
       }
     }
     votes = wave_sum(votes);
@@ -438,7 +448,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     L2Result o;
     o.contig = contig; o.mean_pos = (beg_pos + last_pos) / 2;    // :537
     o.shared = best; o.strand = strand; o.accepted = accepted; o.pad = 0;
-    o.opt_beg = opt_b; o.opt_end = opt_e;
+    o.opt_beg = first0 + opt_b; o.opt_end = first0 + opt_e;
     out[c] = o;
     atomicAdd(&counters[0], (unsigned long long)(last_end - first));
     atomicAdd(&counters[1], evals);

@@ -76,15 +76,18 @@ __global__ void csr_fill_kernel(const uint32_t* __restrict__ key, const uint32_t
   }
 }
 
-__global__ void bucket_kernel(const uint32_t* __restrict__ uh, int64_t U, int bits, uint64_t* __restrict__ bkt) {
-  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t nb = 1LL << bits;
-  if (b > nb) return;
-  if (b == nb) { bkt[b] = (uint64_t)U; return; }
-  uint32_t target = (uint32_t)b << (32 - bits);
-  int64_t lo = 0, hi = U;
-  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (uh[mid] < target) lo = mid + 1; else hi = mid; }
-  bkt[b] = (uint64_t)lo;
+// open-addressing insert of every unique hash: slot word 0 = count<<32 | hash (non-zero: count >= 1), word 1 = start
+__global__ void table_insert_kernel(const uint32_t* __restrict__ uh, const uint64_t* __restrict__ ustart, int64_t U, int bits,
+                                    unsigned long long* __restrict__ tab) {
+  const uint64_t mask = ((uint64_t)1 << bits) - 1;
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t h = uh[u];
+    const uint64_t st = ustart[u], cnt = ustart[u + 1] - st;
+    const unsigned long long w0 = ((unsigned long long)(cnt > 0xFFFFFFFFull ? 0xFFFFFFFFull : cnt) << 32) | h;
+    uint64_t slot = tab_slot(h, bits);
+    while (atomicCAS(&tab[2 * slot], 0ull, w0) != 0ull) slot = (slot + 1) & mask;
+    tab[2 * slot + 1] = st;
+  }
 }
 
 // Duplicate flags: two entries of one contig with the same hash.  The hash-sorted table is stable, so such
@@ -144,9 +147,9 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   I->h_cstart = ms.h_off;
   I->U = 0; I->n_dup = 0; I->hist.clear();
   if (N == 0) {
-    I->bkt_bits = 4;
-    I->bkt.alloc((1u << I->bkt_bits) + 1); I->bkt.zero(st);
-    I->uh.alloc(1); I->ustart.alloc(1); I->ustart.zero(st); I->occ.alloc(1);
+    I->tab_bits = 8;
+    I->tab.alloc((size_t)2 << I->tab_bits); I->tab.zero(st);
+    I->occ.alloc(1);
     MM_HIP(hipStreamSynchronize(st));
     return;
   }
@@ -228,12 +231,6 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   csr_fill_kernel<<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, flag.p, rank.p, N, I->uh.p, I->ustart.p);
   MM_KERNEL_CHECK();
   flag.release(); rank.release();
-  // bucket table over hash prefixes
-  int bits = 4; while (bits < 26 && (1LL << (bits + 1)) <= (int64_t)U) ++bits;
-  I->bkt_bits = bits;
-  I->bkt.alloc(((size_t)1 << bits) + 1);
-  bucket_kernel<<<dim3((unsigned)ceil_div((1LL << bits) + 1, 256)), dim3(256), 0, st>>>(I->uh.p, (int64_t)U, bits, I->bkt.p);
-  MM_KERNEL_CHECK();
   // duplicate flags into pos[]
   DBuf<unsigned long long> ndup(1); ndup.zero(st);
   dup_flags_kernel<<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, I->occ.p, N, I->cstart.p, I->pos.p, ndup.p);
@@ -251,6 +248,17 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   MM_REQUIRE((int64_t)hn[0] <= big_cap, MM_ERR_LIMIT, "more than 2^20 hashes occur >= 4096 times in one index chunk");
   for (int i = 0; i < HIST_BINS; ++i) if (hb[i]) I->hist[i] += (int64_t)hb[i];
   if (hn[0]) { auto hbig = big.to_host(st, (size_t)hn[0]); for (auto c : hbig) I->hist[(int64_t)c] += 1; }
+  // lookup table (load factor <= 0.625), then the CSR arrays are no longer needed
+  key_out.release();
+  int bits = 8; while (((int64_t)1 << bits) * 5 < (int64_t)U * 8) ++bits;
+  I->tab_bits = bits;
+  I->tab.alloc((size_t)2 << bits);
+  I->tab.zero(st);
+  table_insert_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div((int64_t)U, 256), 1 << 20)), dim3(256), 0, st>>>(I->uh.p, I->ustart.p, (int64_t)U, bits,
+                                                                                                              (unsigned long long*)I->tab.p);
+  MM_KERNEL_CHECK();
+  MM_HIP(hipStreamSynchronize(st));
+  I->uh.release(); I->ustart.release();
 }
 
 }  // namespace mm

@@ -3,9 +3,10 @@
 //
 //   pos[N]      position-ordered minimizers {hash, pw}           == Sketch::minimizerIndex      (:129)
 //   cstart[C+1] entry range of every contig in pos[]
-//   uh[U], ustart[U+1], occ[N]   hash -> occurrence list (CSR)    == minimizerPosLookupIndex      (:119)
+//   occ[N]      occurrences grouped by hash                       == minimizerPosLookupIndex      (:119)
 //               occ entry = contig<<32 | pw  (8 bytes, directly usable as an L1 seed hit / sort key)
-//   bkt[2^B+1]  first uh index per top-B-bit hash prefix (one coalesced probe + short search per lookup)
+//   tab[2*cap]  open-addressing table hash -> (count, first occ): slot = {count<<32 | hash, start}; one 64-byte
+//               line per lookup on average (uh[]/ustart[] CSR arrays only live during the build)
 #pragma once
 #include "mm_common.hpp"
 #include <climits>
@@ -15,20 +16,20 @@ struct mm_index {
   mm_ctx* ctx = nullptr;
   int k = 0, w = 0;
   int64_t n_contigs = 0, N = 0, U = 0, n_dup = 0;
-  int bkt_bits = 0;
+  int tab_bits = 0;
   int freq_threshold = INT_MAX;              // winSketch.hpp:94
   mm::DBuf<mm::Rec> pos;
   mm::DBuf<uint64_t> cstart;
   mm::DBuf<uint32_t> uh;
   mm::DBuf<uint64_t> ustart;
   mm::DBuf<uint64_t> occ;
-  mm::DBuf<uint64_t> bkt;
+  mm::DBuf<uint64_t> tab;
   mm::DBuf<int32_t> d_contig_len;
   std::vector<int32_t> contig_len;
   std::vector<uint64_t> h_cstart;
   std::map<int64_t, int64_t> hist;           // occurrence count -> number of hashes (this chunk)
   int64_t hbm_bytes() const {
-    return (int64_t)(pos.bytes() + cstart.bytes() + uh.bytes() + ustart.bytes() + occ.bytes() + bkt.bytes() + d_contig_len.bytes());
+    return (int64_t)(pos.bytes() + cstart.bytes() + uh.bytes() + ustart.bytes() + occ.bytes() + tab.bytes() + d_contig_len.bytes());
   }
 };
 
@@ -37,28 +38,29 @@ namespace mm {
 struct IndexView {
   const Rec* pos;
   const uint64_t* cstart;
-  const uint32_t* uh;
-  const uint64_t* ustart;
   const uint64_t* occ;
-  const uint64_t* bkt;
+  const uint64_t* tab;
   int64_t N, U;
-  int bkt_bits;
+  int tab_bits;
   int freq_threshold;
 };
 inline IndexView make_view(const mm_index* I) {
-  return IndexView{I->pos.p, I->cstart.p, I->uh.p, I->ustart.p, I->occ.p, I->bkt.p, I->N, I->U, I->bkt_bits, I->freq_threshold};
+  return IndexView{I->pos.p, I->cstart.p, I->occ.p, I->tab.p, I->N, I->U, I->tab_bits, I->freq_threshold};
 }
 
-// hash -> slot in uh[] or -1  (minimizerPosLookupIndex.find, computeMap.hpp:310)
-__device__ inline int64_t index_find(const IndexView& I, uint32_t h) {
-  uint32_t b = h >> (32 - I.bkt_bits);            // bkt_bits in [4,26]
-  int64_t lo = (int64_t)I.bkt[b], hi = (int64_t)I.bkt[b + 1];
-  while (lo < hi) {
-    int64_t mid = (lo + hi) >> 1;
-    uint32_t v = I.uh[mid];
-    if (v < h) lo = mid + 1; else hi = mid;
+__host__ __device__ inline uint64_t tab_slot(uint32_t h, int bits) { return ((uint64_t)h * 0x9E3779B97F4A7C15ULL) >> (64 - bits); }
+
+// hash -> (occurrence count, first occurrence); false when the hash is not in the index
+// (minimizerPosLookupIndex.find, computeMap.hpp:310)
+__device__ inline bool index_find(const IndexView& I, uint32_t h, uint32_t* count, uint64_t* start) {
+  const uint64_t mask = ((uint64_t)1 << I.tab_bits) - 1;
+  uint64_t slot = tab_slot(h, I.tab_bits);
+  for (;;) {
+    const uint64_t w0 = I.tab[2 * slot];
+    if (w0 == 0) return false;
+    if ((uint32_t)w0 == h) { *count = (uint32_t)(w0 >> 32); *start = I.tab[2 * slot + 1]; return true; }
+    slot = (slot + 1) & mask;
   }
-  return (lo < (int64_t)I.bkt[b + 1] && I.uh[lo] == h) ? lo : -1;
 }
 
 // first entry of contig c with wpos >= p, as an ordinal into pos[]  (Sketch::searchIndex, winSketch.hpp:506)

@@ -106,12 +106,10 @@ __global__ void __launch_bounds__(256) probe_kernel(IndexView I, const uint32_t*
   const uint64_t o = off[r];
   const int s = sk_n[r];
   for (int i = threadIdx.x; i < s; i += 256) {
-    int64_t slot = index_find(I, sk_hash[o + i]);
-    uint32_t c = 0; uint64_t st = 0;
-    if (slot >= 0) {
-      st = I.ustart[slot];
-      uint64_t cnt = I.ustart[slot + 1] - st;
-      if (cnt < (uint64_t)(int64_t)I.freq_threshold) c = (uint32_t)cnt;   // computeMap.hpp:317
+    uint32_t c = 0, cnt = 0; uint64_t st = 0;
+    if (index_find(I, sk_hash[o + i], &cnt, &st)) {
+      if ((uint64_t)cnt < (uint64_t)(int64_t)I.freq_threshold) c = cnt;   // computeMap.hpp:317
+      else st = 0;
     }
     probe_cnt[o + i] = c;
     probe_start[o + i] = st;

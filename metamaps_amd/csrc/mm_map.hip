@@ -178,9 +178,13 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   for (int i = grp; i < s; i += 32) {
     const uint32_t c = probe_cnt[o + i];
     const uint64_t* src = I.occ + probe_start[o + i];
-    for (uint32_t j = sub; j < c; j += 8) {
-      const uint64_t h = src[j];
-      atomicAdd(&cnt[hf_slot((uint32_t)(h >> 32), (uint32_t)pw_wpos((uint32_t)h) / len)], 1u);
+    for (uint32_t j0 = 0; j0 < c; j0 += 32) {                     // up to four unconditional loads in flight per lane
+      uint64_t hq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hq[q] = src[min(j0 + sub + 8 * q, c - 1)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (j0 + sub + 8 * q < c) atomicAdd(&cnt[hf_slot((uint32_t)(hq[q] >> 32), (uint32_t)pw_wpos((uint32_t)hq[q]) / len)], 1u);
     }
   }
   __syncthreads();
@@ -189,15 +193,22 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   for (int i = grp; i < s; i += 32) {
     const uint32_t c = probe_cnt[o + i];
     const uint64_t* src = I.occ + probe_start[o + i];
-    for (uint32_t j = sub; j < c; j += 8) {
-      const uint64_t h = src[j];
-      const uint32_t ct = (uint32_t)(h >> 32), bin = (uint32_t)pw_wpos((uint32_t)h) / len;
-      const uint32_t c0 = cnt[hf_slot(ct, bin)];
-      const uint32_t cl = bin > 0 ? cnt[hf_slot(ct, bin - 1)] : 0u, cr = cnt[hf_slot(ct, bin + 1)];
-      if (c0 + cl >= (uint32_t)m || c0 + cr >= (uint32_t)m) {
-        const uint32_t slot = atomicAdd(&cursor, 1u);
-        if (WRITE) hits[wbase + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
-        else if (slot < HF_STAGE) stage[(size_t)r * HF_STAGE + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
+    for (uint32_t j0 = 0; j0 < c; j0 += 32) {
+      uint64_t hq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hq[q] = src[min(j0 + sub + 8 * q, c - 1)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (j0 + sub + 8 * q >= c) continue;
+        const uint64_t h = hq[q];
+        const uint32_t ct = (uint32_t)(h >> 32), bin = (uint32_t)pw_wpos((uint32_t)h) / len;
+        const uint32_t c0 = cnt[hf_slot(ct, bin)];
+        const uint32_t cl = bin > 0 ? cnt[hf_slot(ct, bin - 1)] : 0u, cr = cnt[hf_slot(ct, bin + 1)];
+        if (c0 + cl >= (uint32_t)m || c0 + cr >= (uint32_t)m) {
+          const uint32_t slot = atomicAdd(&cursor, 1u);
+          if (WRITE) hits[wbase + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
+          else if (slot < HF_STAGE) stage[(size_t)r * HF_STAGE + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
+        }
       }
     }
   }

@@ -174,32 +174,32 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   __syncthreads();
   // one occurrence list per group of 8 lanes: a list (~17 entries at miniSeq+H density) is read as a few
   // contiguous 64-byte requests instead of one 8-byte request per lane per step
-  const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
-  for (int i = grp; i < s; i += 32) {
+  const int grp = threadIdx.x >> 2, sub = threadIdx.x & 3;
+  for (int i = grp; i < s; i += 64) {
     const uint32_t c = probe_cnt[o + i];
     const uint64_t* src = I.occ + probe_start[o + i];
     for (uint32_t j0 = 0; j0 < c; j0 += 32) {                     // up to four unconditional loads in flight per lane
-      uint64_t hq[4];
+      uint64_t hq[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) hq[q] = src[min(j0 + sub + 8 * q, c - 1)];
+      for (int q = 0; q < 8; ++q) hq[q] = src[min(j0 + sub + 4 * q, c - 1)];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (j0 + sub + 8 * q < c) atomicAdd(&cnt[hf_slot((uint32_t)(hq[q] >> 32), (uint32_t)pw_wpos((uint32_t)hq[q]) / len)], 1u);
+      for (int q = 0; q < 8; ++q)
+        if (j0 + sub + 4 * q < c) atomicAdd(&cnt[hf_slot((uint32_t)(hq[q] >> 32), (uint32_t)pw_wpos((uint32_t)hq[q]) / len)], 1u);
     }
   }
   __syncthreads();
   uint32_t mine = 0;
   const uint64_t wbase = WRITE ? read_hit_off[r] : 0;
-  for (int i = grp; i < s; i += 32) {
+  for (int i = grp; i < s; i += 64) {
     const uint32_t c = probe_cnt[o + i];
     const uint64_t* src = I.occ + probe_start[o + i];
     for (uint32_t j0 = 0; j0 < c; j0 += 32) {
-      uint64_t hq[4];
+      uint64_t hq[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) hq[q] = src[min(j0 + sub + 8 * q, c - 1)];
+      for (int q = 0; q < 8; ++q) hq[q] = src[min(j0 + sub + 4 * q, c - 1)];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (j0 + sub + 8 * q >= c) continue;
+      for (int q = 0; q < 8; ++q) {
+        if (j0 + sub + 4 * q >= c) continue;
         const uint64_t h = hq[q];
         const uint32_t ct = (uint32_t)(h >> 32), bin = (uint32_t)pw_wpos((uint32_t)h) / len;
         const uint32_t c0 = cnt[hf_slot(ct, bin)];

@@ -50,6 +50,25 @@ __device__ inline int wave_excl_scan(int v, int lane) {
   return inc - v;
 }
 
+// Wave-cooperative lower_bound over wpos in pos[lo,hi): 64 pivots per step (one dependent memory round trip narrows
+// the range 64-fold) instead of one pivot per step.  All arguments wave-uniform; returns the first index whose
+// wpos >= target (hi if none).
+__device__ inline int64_t wave_lower_bound_wpos(const Rec* __restrict__ pos, int64_t lo, int64_t hi, int target, int lane) {
+  while (hi - lo > 64) {
+    const int64_t step = (hi - lo + 63) / 64;
+    const int64_t idx = lo + (int64_t)lane * step;                // lane 0 probes lo itself
+    const bool less = idx < hi && pw_wpos(pos[idx].pw) < target;
+    const int p = __popcll(__ballot(less));                      // `less` is monotone over lanes: p leading lanes are below target
+    if (p == 0) return lo;
+    const int64_t nlo = lo + (int64_t)(p - 1) * step + 1;
+    const int64_t nhi = min(hi, lo + (int64_t)p * step);
+    lo = nlo; hi = nhi;
+  }
+  const int64_t idx = lo + lane;
+  const bool less = idx < hi && pw_wpos(pos[idx].pw) < target;
+  return lo + __popcll(__ballot(less));
+}
+
 // Four independent lower_bound searches per lane with their steps interleaved: the four LDS reads of a step
 // are issued back to back, so one search step costs one LDS latency for four entries instead of one.
 __device__ inline void l2_classify4(const uint32_t* __restrict__ Q, int s, const uint32_t (&h)[4], int (&code)[4]) {
@@ -124,8 +143,9 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   const int contig = cand[3 * c], rs = cand[3 * c + 1], re = cand[3 * c + 2];
   const int cnt = len - (w - 1) - (k - 1);                       // computeMap.hpp:470
   // all window arithmetic below is 32-bit and relative to the first streamed entry of this candidate
-  const int64_t first0 = index_search(I, contig, rs);            // :466
-  const int64_t last0 = index_search(I, contig, re + len);       // :477
+  const int64_t cbeg = (int64_t)I.cstart[contig], cend = (int64_t)I.cstart[contig + 1];
+  const int64_t first0 = wave_lower_bound_wpos(I.pos, cbeg, cend, rs, lane);          // searchIndex, :466
+  const int64_t last0 = wave_lower_bound_wpos(I.pos, first0, cend, re + len, lane);   // :477
   const Rec* __restrict__ pos = I.pos + first0;
   const int first = 0;
   const int last_end = (int)(last0 - first0);
@@ -137,11 +157,28 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   long long tmark = clock64();
   auto lap = [&](int ph) { long long now = clock64(); tph[ph] += now - tmark; tmark = now; };
 
-  // e_min(b): first entry at or after b whose wpos >= wpos[b] + cnt (never beyond last_end)
+  // e_min(b): first entry at or after b whose wpos >= wpos[b] + cnt (never beyond last_end).  Wave-uniform argument.
   auto e_min = [&](int bb) -> int {
     const int target = pw_wpos(pos[bb].pw) + cnt;
-    int lo = bb, hi = last_end;
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (pw_wpos(pos[mid].pw) < target) lo = mid + 1; else hi = mid; }
+    return (int)wave_lower_bound_wpos(pos, bb, last_end, target, lane);
+  };
+  // per-lane variant (different bb per lane): windows hold a nearly constant number of entries, so gallop around
+  // bb + span0 (span0 = size of the first window) instead of bisecting the whole range
+  int span0 = 0;
+  auto e_min_lane = [&](int bb) -> int {
+    const int target = pw_wpos(pos[bb].pw) + cnt;
+    int lo, hi;
+    int g = min(bb + span0, last_end);
+    if (g >= last_end || pw_wpos(pos[g].pw) >= target) {         // answer <= g: gallop down
+      hi = g; int stepd = 16; lo = max(bb, hi - stepd);
+      while (lo > bb && pw_wpos(pos[lo].pw) >= target) { hi = lo; stepd <<= 1; lo = max(bb, hi - stepd); }
+      if (pw_wpos(pos[lo].pw) >= target) return lo;              // lo == bb only if cnt <= 0
+      lo = lo + 1;
+    } else {                                                     // answer > g: gallop up
+      lo = g + 1; int stepu = 16; hi = min(last_end, lo + stepu);
+      while (hi < last_end && pw_wpos(pos[hi].pw) < target) { lo = hi + 1; stepu <<= 1; hi = min(last_end, lo + stepu); }
+    }
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (pw_wpos(pos[mid].pw) < target) lo = mid + 1; else hi = mid; }
     return lo;
   };
 
@@ -310,7 +347,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       const uint32_t qr0 = every ? 0u : Q[r0];
       int runL = 0, runW = 0;
       for (int bk = 0; bk < nblk; ++bk) {
-        const int j = first + (int)bk * 64 + lane;
+        const int j = first + bk * 64 + lane;
         bool lo = false, aw = false;
         if (j < last_end) {
           const Rec x = pos[j];
@@ -328,6 +365,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     };
     lap(0);
     pass_matched();
+    span0 = e_min(first) - first;
     lap(1);
     // per block of 64 b's: largest window [bF, eHi), smallest window [bL, eLo)
     // (lane l owns blocks l and l+64; L2_NBLK == 128)
@@ -337,8 +375,8 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       eLo[q] = eHi[q] = last_end; ub_all[q] = -1;
       if (bk < nblk) {
         const int bF = first + (int)bk * 64, bL = min(bF + 63, last_end - 1);
-        eLo[q] = e_min(bF);
-        eHi[q] = (bL + 1 < last_end) ? e_min(bL + 1) : last_end;
+        eLo[q] = e_min_lane(bF);
+        eHi[q] = (bL + 1 < last_end) ? e_min_lane(bL + 1) : last_end;
         if (eLo[q] < last_end) ub_all[q] = pfx(mAll, pAll, eHi[q]) - pfx(mAll, pAll, bF);
       }
     }
@@ -397,7 +435,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     for (int i = lane; i < (s + 31) / 32; i += 64) mt[i] = 0;
     wave_sync();
     l2_reset(S);
-    const int first_end = (int)(index_search(I, contig, pw_wpos(pos[first].pw) + cnt) - first0);   // :473
+    const int first_end = e_min(first);                          // :473
     b = first; e = first;
     loadB(first); loadE(first);
     for (; e < first_end; ++e) add_entry(e);                     // first super-window, :489

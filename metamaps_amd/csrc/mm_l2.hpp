@@ -32,6 +32,9 @@ namespace mm {
 
 constexpr int L2_MCAP = 8192;                      // max streamed entries handled by the skip path
 constexpr int L2_NBLK = L2_MCAP / 64;
+constexpr int L2_TBITS = 10;                     // bucket table over the top hash bits of the sketch
+constexpr int L2_TSHIFT = 32 - L2_TBITS;
+constexpr int L2_TSIZE = (1 << L2_TBITS) + 1;
 
 __device__ inline bool wave_has_hash(const Rec* __restrict__ pos, int64_t lo, int64_t hi, uint32_t h, int lane) {
   for (int64_t base = lo; base < hi; base += 64) {               // `base` is wave-uniform
@@ -71,9 +74,11 @@ __device__ inline int64_t wave_lower_bound_wpos(const Rec* __restrict__ pos, int
 
 // Four independent lower_bound searches per lane with their steps interleaved: the four LDS reads of a step
 // are issued back to back, so one search step costs one LDS latency for four entries instead of one.
-__device__ inline void l2_classify4(const uint32_t* __restrict__ Q, int s, const uint32_t (&h)[4], int (&code)[4]) {
-  int lo0 = 0, lo1 = 0, lo2 = 0, lo3 = 0, hi0 = s, hi1 = s, hi2 = s, hi3 = s;
-  const int steps = 33 - __clz(s | 1);                            // >= ceil(log2(s+1))
+__device__ inline void l2_classify4(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int steps, int s,
+                                    const uint32_t (&h)[4], int (&code)[4]) {
+  // T[b] = lower_bound(Q, b << L2_TSHIFT): the top hash bits give a short search range; `steps` covers the longest one
+  int lo0 = T[h[0] >> L2_TSHIFT], lo1 = T[h[1] >> L2_TSHIFT], lo2 = T[h[2] >> L2_TSHIFT], lo3 = T[h[3] >> L2_TSHIFT];
+  int hi0 = T[(h[0] >> L2_TSHIFT) + 1], hi1 = T[(h[1] >> L2_TSHIFT) + 1], hi2 = T[(h[2] >> L2_TSHIFT) + 1], hi3 = T[(h[3] >> L2_TSHIFT) + 1];
   for (int it = 0; it < steps; ++it) {
     const int m0 = min((lo0 + hi0) >> 1, s - 1), m1 = min((lo1 + hi1) >> 1, s - 1), m2 = min((lo2 + hi2) >> 1, s - 1), m3 = min((lo3 + hi3) >> 1, s - 1);
     const uint32_t v0 = Q[m0], v1 = Q[m1], v2 = Q[m2], v3 = Q[m3];
@@ -88,6 +93,15 @@ __device__ inline void l2_classify4(const uint32_t* __restrict__ Q, int s, const
   code[2] = (lo2 < s && e2 == h[2]) ? lo2 : -(lo2 + 1);
   code[3] = (lo3 < s && e3 == h[3]) ? lo3 : -(lo3 + 1);
 }
+__device__ inline int l2_classify1(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int steps, int s, uint32_t h) {
+  int lo = T[h >> L2_TSHIFT], hi = T[(h >> L2_TSHIFT) + 1];
+  for (int it = 0; it < steps; ++it) {
+    const int m = min((lo + hi) >> 1, s - 1);
+    const uint32_t v = Q[m];
+    if (lo < hi) { if (v < h) lo = m + 1; else hi = m; }
+  }
+  return (lo < s && Q[min(lo, s - 1)] == h) ? lo : -(lo + 1);
+}
 
 // LDS layout: Q[smax] (shared by the waves of a workgroup) | per wave: D[smax] | mt | skip-ahead class arrays
 template <typename DT>
@@ -97,7 +111,7 @@ __host__ __device__ inline size_t l2_wave_bytes(int smax, bool skip) {
   if (skip) b += (size_t)(L2_NBLK + 1) * (3 * 8 + 3 * 2);
   return (b + 15) & ~(size_t)15;
 }
-__host__ __device__ inline size_t l2_q_bytes(int smax) { return ((size_t)smax * 4 + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t l2_q_bytes(int smax) { return (((size_t)smax * 4 + 15) & ~(size_t)15) + (((size_t)L2_TSIZE * 2 + 4 + 15) & ~(size_t)15); }
 template <typename DT>
 inline size_t l2_lds_bytes(int smax, bool skip, int waves) { return l2_q_bytes(smax) + (size_t)waves * l2_wave_bytes<DT>(smax, skip); }
 
@@ -131,8 +145,21 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   const int s = sk_n[r];
   const uint64_t qo = mz_off[r];
   const int len = read_len[r];
+  uint16_t* T = (uint16_t*)((uint8_t*)lds + (((size_t)smax * 4 + 15) & ~(size_t)15));
+  int* tmaxp = (int*)(T + ((L2_TSIZE + 1) & ~1));
   for (int i = threadIdx.x; i < s; i += 64 * WAVES) Q[i] = sk_hash[qo + i];
+  if (threadIdx.x == 0) *tmaxp = 0;
   __syncthreads();
+  for (int bkt = threadIdx.x; bkt < L2_TSIZE; bkt += 64 * WAVES) {  // T[b] = first rank whose hash >= b << L2_TSHIFT
+    int lo = 0, hi = s;
+    if (bkt >= (1 << L2_TBITS)) lo = s;
+    else { const uint32_t tv = (uint32_t)bkt << L2_TSHIFT; while (lo < hi) { const int mid = (lo + hi) >> 1; if (Q[mid] < tv) lo = mid + 1; else hi = mid; } }
+    T[bkt] = (uint16_t)lo;
+  }
+  __syncthreads();
+  for (int bkt = threadIdx.x; bkt < (1 << L2_TBITS); bkt += 64 * WAVES) atomicMax(tmaxp, (int)T[bkt + 1] - (int)T[bkt]);
+  __syncthreads();
+  const int tsteps = *tmaxp ? 32 - __clz(*tmaxp) : 0;
   if (WAVES > 1 && wave >= grp_n[blockIdx.x]) return;
   const int64_t c = c0 + (WAVES > 1 ? wave : 0);
   constexpr int DMAX = (int)(DT)~(DT)0;
@@ -185,9 +212,9 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   // ---- register-resident chunks of 64 consecutive entries at both window ends -------------------------
   int baseB = first, baseE = first;
   Rec rb = pos[min(baseB + lane, nmax)], rE = rb;
-  int codeB = l2_classify(Q, s, rb.hash), codeE = codeB;
-  auto loadB = [&](int nb) { baseB = nb; rb = pos[min(nb + lane, nmax)]; codeB = l2_classify(Q, s, rb.hash); };
-  auto loadE = [&](int ne) { baseE = ne; rE = pos[min(ne + lane, nmax)]; codeE = l2_classify(Q, s, rE.hash); };
+  int codeB = l2_classify1(Q, T, tsteps, s, rb.hash), codeE = codeB;
+  auto loadB = [&](int nb) { baseB = nb; rb = pos[min(nb + lane, nmax)]; codeB = l2_classify1(Q, T, tsteps, s, rb.hash); };
+  auto loadE = [&](int ne) { baseE = ne; rE = pos[min(ne + lane, nmax)]; codeE = l2_classify1(Q, T, tsteps, s, rE.hash); };
 
   int b = first, e = first;
   int sw_pos = 0;
@@ -230,7 +257,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       Rec x[4]; uint32_t hh[4]; int cd[4];
       for (int i = 0; i < 4; ++i) { x[i] = nx[i]; hh[i] = x[i].hash; }
       if (base + 256 < ne) for (int i = 0; i < 4; ++i) { const int j = base + 256 + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }   // prefetch
-      l2_classify4(Q, s, hh, cd);
+      l2_classify4(Q, T, tsteps, s, hh, cd);
       for (int i = 0; i < 4; ++i) {
         const int j = base + lane + 64 * i;
         const int code = cd[i];
@@ -328,7 +355,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
         uint32_t hh[4]; int cd[4];
         for (int i = 0; i < 4; ++i) hh[i] = nx[i].hash;
         if (base + 256 < last_end) for (int i = 0; i < 4; ++i) { const int j = base + 256 + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
-        l2_classify4(Q, s, hh, cd);
+        l2_classify4(Q, T, tsteps, s, hh, cd);
         for (int i = 0; i < 4; ++i) {
           const int j = base + lane + 64 * i;
           const int bk = (int)((base - first) >> 6) + i;
@@ -457,7 +484,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       Rec x[4]; uint32_t hh[4]; int cd[4];
       for (int i = 0; i < 4; ++i) { x[i] = nx[i]; hh[i] = x[i].hash; }
       if (base + 256 < opt_e) for (int i = 0; i < 4; ++i) { const int j = base + 256 + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
-      l2_classify4(Q, s, hh, cd);
+      l2_classify4(Q, T, tsteps, s, hh, cd);
       for (int i = 0; i < 4; ++i) {
         const int j = base + lane + 64 * i;
         const int code = cd[i];

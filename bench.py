@@ -188,14 +188,15 @@ def main():
         l2_bytes = 8.0 * agg["l2_stream"] / max(agg["l2_launches"], 1)
         l2_ms = agg["ms_l2"] / max(agg["l2_launches"], 1)
         achieved = l2_bytes / (l2_ms * 1e-3) / 1e9 if l2_ms > 0 else 0.0
+        out_workload = (f"{args.reads} synthetic {args.read_len} bp ONT-error reads per GPU vs synthetic miniSeq+H-shaped index "
+                        f"({args.species} species x {args.strains} strains x {args.genome_len} bp = {G * args.genome_len / 1e9:.2f} Gbp), k=16 w={w}, --all")
         out = {
             "metric": "Gbp long reads mapped+classified per sec (whole node), miniSeq+H DB",
             "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {
-                "workload": f"{args.reads} synthetic {args.read_len} bp ONT-error reads per GPU vs synthetic miniSeq+H-shaped index "
-                            f"({args.species} species x {args.strains} strains x {args.genome_len} bp = {G * args.genome_len / 1e9:.2f} Gbp), k=16 w={w}, --all",
+                "workload": out_workload,
                 "reads_per_gpu": args.reads, "read_len": args.read_len, "reference_bp": G * args.genome_len,
                 "index_entries": info["n_entries"], "index_unique_hashes": info["n_unique_hashes"], "index_hbm_bytes": info["hbm_bytes"],
                 "freq_threshold": idx.freq_threshold, "reference_synth_s": round(t_ref, 3), "index_build_s": round(t_index, 3),
@@ -207,7 +208,7 @@ def main():
                 "host_wall_ms": {kk: round(v, 3) for kk, v in agg.get("host_ms", {}).items()},
             },
             "roofline": {"bound": "hbm", "kernel": "l2_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(out_workload),
                          "algorithmic_bytes_per_launch": l2_bytes, "ms_per_launch": l2_ms},
         }
         if not args.no_cpu_baseline:
@@ -220,6 +221,17 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def measured_traffic(workload: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+    collected and corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes; profiles/r01_pmc_hbm_traffic.txt).
+    bench.py cannot run the profiler itself, so the number is reported only for the workload it was measured on."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        return t["traffic_bytes_per_launch"] if t.get("workload") == workload else None
+    except Exception:
+        return None
 
 
 def cpu_baseline(args, ctx, ref, reads, truth, k, w):

@@ -1,0 +1,148 @@
+"""Edge cases and size-independent properties of the HIP path (through the C ABI)."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from metamaps_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _rand(rnd, n):
+    return bytes(rnd.choice(b"ACGT") for _ in range(n))
+
+
+def _mutate(rnd, s, rate):
+    out = bytearray()
+    for c in s:
+        u = rnd.random()
+        if u < rate / 3:
+            continue
+        if u < 2 * rate / 3:
+            out.append(rnd.choice(b"ACGT")); continue
+        out.append(c)
+        if u < rate:
+            out.append(rnd.choice(b"ACGT"))
+    return bytes(out)
+
+
+@pytest.fixture(scope="module")
+def small_world(ctx, oracle_lib, tmp_path_factory):
+    rnd = random.Random(77)
+    genomes = [_rand(rnd, 120_000) for _ in range(4)]
+    d = tmp_path_factory.mktemp("edge")
+    fa = d / "ref.fa"
+    with open(fa, "wb") as f:
+        for i, g in enumerate(genomes):
+            f.write(b">C%d|kraken:taxid|%d|X\n" % (i, 100 + i) + g + b"\n")
+        f.write(b">tiny|kraken:taxid|9|X\nACGTAC\n")            # shorter than k: metadata only
+    S = ctx.seqset(genomes + [b"ACGTAC"])
+    idx = ctx.index(S, 16, 10)
+    oi = oracle_lib.index(str(fa), 16, 10)
+    return {"genomes": genomes, "idx": idx, "oi": oi, "rnd": rnd}
+
+
+def _check_against_oracle(ctx, world, reads, min_read_len=1000):
+    R = ctx.seqset(reads)
+    M = ctx.map_batch(world["idx"], R, 16, 10, pi=80.0, min_read_len=min_read_len)
+    off, rec = M.fetch()
+    for r, q in enumerate(reads):
+        got = rec[off[r]:off[r + 1]]
+        if len(q) < max(min_read_len, 16, 10):
+            assert len(got) == 0
+            continue
+        m = world["oi"].map_read(q, 80.0)["map"]
+        assert len(got) == len(m), (r, len(q))
+        assert np.array_equal(got["ref_contig"], m[:, 0]) and np.array_equal(got["ref_start"], m[:, 1]), r
+        assert np.array_equal(got["shared"], m[:, 3]) and np.array_equal(got["sketch"], m[:, 4]) and np.array_equal(got["strand"], m[:, 5]), r
+    st = M.stats()
+    M.close(); R.close()
+    return st
+
+
+def test_ragged_and_degenerate_reads(ctx, small_world):
+    g, rnd = small_world["genomes"], small_world["rnd"]
+    reads = [
+        b"",                                              # empty record
+        b"ACGT",                                          # shorter than k
+        g[0][1000:1900],                                  # below --minReadLen
+        b"N" * 3000,                                      # every k-mer symmetric: sketch size 0 (computeMap.hpp:302)
+        b"A" * 4000,                                      # homopolymer: one hash
+        b"ACGT" * 1000,                                   # palindromic tandem repeat
+        g[1][5000:9000],                                  # exact copy
+        g[1][5000:9000].lower(),                          # lower case is upper-cased first
+        _mutate(rnd, g[2][20000:32000], 0.12),            # ONT-like
+        g[3][100:3100][:1500] + b"N" * 200 + g[3][1800:3100],   # N run inside
+        g[0][-2500:],                                     # hangs over the contig end
+        g[0][:2500],                                      # at the contig start
+        _rand(rnd, 5000),                                 # unrelated
+        _mutate(rnd, g[2][40000:90000], 0.10),            # 50 kb read: large sketch (LDS size classes, compact L2 limits)
+    ]
+    st = _check_against_oracle(ctx, small_world, reads)
+    assert st["n_reads"] == len(reads) and st["n_reads_mapped"] >= 6
+
+
+def test_all_reads_too_short_and_empty_batch(ctx, small_world):
+    st = _check_against_oracle(ctx, small_world, [b"ACGT", b"", small_world["genomes"][0][:900]])
+    assert st["n_reads_long_enough"] == 0 and st["n_mappings"] == 0
+    R = ctx.seqset([])
+    M = ctx.map_batch(small_world["idx"], R, 16, 10)
+    off, rec = M.fetch()
+    assert len(off) == 1 and len(rec) == 0
+    M.add_qualities(16)
+    M.close(); R.close()
+
+
+def test_min_read_len_and_identity_threshold_flags(ctx, small_world):
+    g, rnd = small_world["genomes"], small_world["rnd"]
+    reads = [_mutate(rnd, g[i % 4][3000 * i:3000 * i + 2200], 0.1) for i in range(12)]
+    _check_against_oracle(ctx, small_world, reads, min_read_len=2000)
+    R = ctx.seqset(reads)
+    for pi in (70.0, 90.0, 99.0):                        # threshold only changes which candidates survive
+        M = ctx.map_batch(small_world["idx"], R, 16, 10, pi=pi, min_read_len=1000)
+        off, rec = M.fetch()
+        for r, q in enumerate(reads):
+            m = small_world["oi"].map_read(q, pi)["map"]
+            assert np.array_equal(rec[off[r]:off[r + 1]]["ref_start"], m[:, 1]), (pi, r)
+        M.close()
+    R.close()
+
+
+def test_results_do_not_depend_on_batching(ctx):
+    """Size-independent property at a larger scale: mapping a batch == mapping its parts (reads are independent,
+    computeMap.hpp:180-200), and mapping twice is bit-identical."""
+    ref = ctx.synth_reference(seed=11, n_species=64, strains_per_species=4, genome_len=400_000, strain_divergence=0.02, genus_divergence=0.1)
+    idx = ctx.index(ref, 16, 8)
+    parts, recs = [], []
+    for i, n in enumerate((3000, 1700)):
+        r, _ = ctx.synth_reads(ref, seed=50 + i, n_reads=n, read_len=7000 + 2500 * i, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=60)
+        parts.append(r)
+    whole = ctx.seqset([p.fetch(i, int(L)) for p in parts for i, L in enumerate(p.lengths())])
+    Mw = ctx.map_batch(idx, whole, 16, 8); Mw.add_qualities(16)
+    offw, recw = Mw.fetch()
+    Mw2 = ctx.map_batch(idx, whole, 16, 8); Mw2.add_qualities(16)
+    offw2, recw2 = Mw2.fetch()
+    assert np.array_equal(offw, offw2) and recw.tobytes() == recw2.tobytes()
+    base = 0
+    for p in parts:
+        M = ctx.map_batch(idx, p, 16, 8); M.add_qualities(16)
+        off, rec = M.fetch()
+        n = p.count
+        a, b = int(offw[base]), int(offw[base + n])
+        assert np.array_equal(off, offw[base:base + n + 1] - a)
+        sub = recw[a:b].copy(); sub["read"] -= base
+        assert sub.tobytes() == rec.tobytes()
+        # mapping qualities of a read sum to one (mapWrap.h:300-306)
+        sums = np.add.reduceat(rec["mapq"], off[:-1][np.diff(off) > 0])
+        assert np.allclose(sums, 1.0, atol=1e-9)
+        base += n
+        M.close()
+    assert len(recw) > 10_000
+    Mw.close(); Mw2.close(); whole.close(); idx.close(); ref.close()

@@ -104,6 +104,12 @@ typedef struct {
 } mm_index_info;
 int mm_index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index** out);
 void mm_index_destroy(mm_index* idx);
+/* --maxmemory chunk rule (Sketch::build flush test winSketch.hpp:274-329, memory model :165-178), evaluated on the
+ * index of the WHOLE reference: returns the first contig of every chunk the reference would create under the
+ * given limit (n_chunks == 1, first_contig[0] == 0 when everything fits or max_memory_bytes == 0).  The caller then
+ * builds one mm_index per contig range, maps every read against each, and merges with mm_mapping_concat.
+ * MM_ERR_LIMIT if a single contig exceeds the limit (the reference throws there, :318-322). */
+int mm_index_plan_chunks(mm_ctx* ctx, const mm_index* whole, uint64_t max_memory_bytes, int32_t* first_contig, int32_t cap, int32_t* n_chunks);
 int mm_index_get_info(const mm_index* idx, mm_index_info* out);
 /* Occurrence-count histogram of this chunk: pairs (count, number of hashes with that count), ascending.
  * The caller accumulates it across chunks and derives freqThreshold exactly as winSketch.hpp:452-494 does
@@ -159,6 +165,9 @@ int mm_mapping_get_stats(const mm_mapping* m, mm_map_stats* out);
 int mm_mapping_fetch(mm_mapping* m, int64_t* offsets, mm_map_record* records, int64_t cap);
 /* K8: mapping qualities over the union of each read's records (mapWrap.h:215-323) */
 int mm_mapping_add_qualities(mm_ctx* ctx, mm_mapping* m, const mm_seqset* reads, int k);
+/* default (non --all) reporting: per read keep the records whose identity is >= best - 1.0
+ * (reportReadMappings, computeMap.hpp:546-587).  Apply per index chunk, before mm_mapping_concat / add_qualities. */
+int mm_mapping_keep_best(mm_ctx* ctx, mm_mapping* m, int k);
 /* merge the records of several index chunks read-wise, chunk order preserved (unifyFiles, mapWrap.h:128-132) */
 int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* contig_base, int n_parts, mm_mapping** out);
 

@@ -118,6 +118,8 @@ def lib() -> C.CDLL:
             "mm_mapping_fetch": (C.c_int, [vp, vp, vp, i64]),
             "mm_mapping_add_qualities": (C.c_int, [vp, vp, vp, C.c_int]),
             "mm_mapping_concat": (C.c_int, [vp, P(vp), vp, C.c_int, P(vp)]),
+            "mm_mapping_keep_best": (C.c_int, [vp, vp, C.c_int]),
+            "mm_index_plan_chunks": (C.c_int, [vp, vp, u64, vp, i32, P(i32)]),
             "mm_debug_sketch": (C.c_int, [vp, vp, vp, vp, i64]),
             "mm_debug_hits": (C.c_int, [vp, vp, vp, vp, i64]),
             "mm_debug_candidates": (C.c_int, [vp, vp, vp, i64]),
@@ -304,6 +306,14 @@ class Index:
         self.ctx.check(lib().mm_index_set_freq_threshold(self.h, int(thr)))
         self.freq_threshold = int(thr)
 
+    def plan_chunks(self, max_memory_bytes: int) -> list[int]:
+        """first contig of every --maxmemory chunk (this index must cover the whole reference)"""
+        n = C.c_int32()
+        self.ctx.check(lib().mm_index_plan_chunks(self.ctx.h, self.h, int(max_memory_bytes), None, 0, C.byref(n)))
+        fc = np.zeros(n.value, dtype=np.int32)
+        self.ctx.check(lib().mm_index_plan_chunks(self.ctx.h, self.h, int(max_memory_bytes), _ptr(fc), n.value, C.byref(n)))
+        return [int(x) for x in fc]
+
     def entries(self):
         n = self.info()["n_entries"]
         hsh = np.zeros(n, dtype=np.uint32)
@@ -330,6 +340,18 @@ class Mapping:
 
     def add_qualities(self, k: int):
         self.ctx.check(lib().mm_mapping_add_qualities(self.ctx.h, self.h, None, k))
+
+    def keep_best(self, k: int):
+        """default (non --all) reporting: per read keep identity >= best - 1.0"""
+        self.ctx.check(lib().mm_mapping_keep_best(self.ctx.h, self.h, k))
+
+    @staticmethod
+    def concat(ctx: "Context", parts: list["Mapping"], contig_base: list[int]) -> "Mapping":
+        arr = (C.c_void_p * len(parts))(*[p.h for p in parts])
+        base = np.asarray(contig_base, dtype=np.int32)
+        out = C.c_void_p()
+        ctx.check(lib().mm_mapping_concat(ctx.h, arr, _ptr(base), len(parts), C.byref(out)))
+        return Mapping(ctx, out, parts[0].n_reads)
 
     def fetch(self, rec_buf: np.ndarray | None = None):
         """offsets [n_reads+1] and the mm_map_record array.  `rec_buf` (RECORD_DTYPE, any capacity) lets a caller

@@ -5,12 +5,15 @@
 // exclusively through the C ABI in include/metamaps_hip.h.  Host work here is what stays host work in the
 // reference too: argument parsing, FASTA/FASTQ(.gz) reading, text formatting, taxonomy bookkeeping.
 //
-//   metamaps mapDirectly --all -r DB.fa -q reads.fq -o PREFIX [-k 16] [-w W] [-m 1000] [--pi 80] [-p 1e-3] [-t N] [--mm G]
+//   metamaps mapDirectly [--all] -r DB.fa -q reads.fq -o PREFIX [-k 16] [-w W] [-m 1000] [--pi 80] [-p 1e-3] [-t N] [--mm G]
 //   metamaps classify --DB DBDIR --mappings PREFIX [--minreads N] [-t N]
 //
+// --mm G splits the reference into the same index chunks the reference would build under that limit
+// (mm_index_plan_chunks); all chunk indexes stay resident in HBM and every read batch is mapped against each.
+// (--maxmemory-bytes N gives the limit in bytes: a test hook, sub-GiB limits make small references chunk.)
+//
 // Not provided: index / mapAgainstIndex (Boost archives), classifyU (disabled upstream),
-// reporting without --all, the coverage / unknown-species side files of classify.  --maxmemory is accepted;
-// the index is built as one chunk (288 GB of HBM hold miniSeq+H whole).
+// the coverage / unknown-species side files of classify.
 #include "../../../include/metamaps_hip.h"
 #include <zlib.h>
 #include <algorithm>
@@ -100,10 +103,10 @@ int map_directly(const Options& o) {
   if (!o.v.count("reference")) die("Provide reference file (s)");
   if (!o.v.count("query")) die("Provide query file (s)");
   if (!o.v.count("output")) die("Provide output file");
-  if (!o.all) die("This build reports all mappings only: please pass --all (the mode MetaMaps' own pipelines use, simulate.pl:1626)");
   const std::string ref = o.v.at("reference");
   const uint64_t refSize = file_size(ref);
-  const uint64_t maxMem = o.v.count("maxmemory") ? (uint64_t)(std::pow(1024, 3) * std::stoull(o.v.at("maxmemory"))) : 0;
+  uint64_t maxMem = o.v.count("maxmemory") ? (uint64_t)(std::pow(1024, 3) * std::stoull(o.v.at("maxmemory"))) : 0;
+  if (o.v.count("maxmemory-bytes")) maxMem = std::stoull(o.v.at("maxmemory-bytes"));
   int k = o.v.count("kmer") ? std::stoi(o.v.at("kmer")) : 16;
   double pval = o.v.count("pval") ? std::stod(o.v.at("pval")) : 1e-3;
   int minLen = o.v.count("minReadLen") ? std::stoi(o.v.at("minReadLen")) : 1000;
@@ -115,24 +118,63 @@ int map_directly(const Options& o) {
   } else w = mm_recommended_window(pval, k, pi, minLen, refSize);
   auto queries = split(o.v.at("query"), ","), prefixes = split(o.v.at("output"), ",");
   if (queries.size() != prefixes.size()) die("Please specify an equal number of input and output files (as comma-separated lists)");
-  if (maxMem) std::cerr << "note: --maxmemory accepted; the index is built as a single chunk in HBM\n";
-
   mm_ctx* ctx;
   if (mm_ctx_create(0, &ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
-  // ---- index (winSketch.hpp:180-365)
-  mm_seqset* contigs; ck(ctx, mm_seqset_create(ctx, &contigs), "seqset");
-  std::vector<std::string> cname; std::vector<int> clen;
-  { SeqFile f(ref); while (f.next()) { ck(ctx, mm_seqset_add(contigs, f.seq.data(), (int64_t)f.seq.size()), "add contig"); cname.push_back(f.name); clen.push_back((int)f.seq.size()); } }
-  ck(ctx, mm_seqset_upload(contigs), "upload reference");
-  mm_index* idx; ck(ctx, mm_index_build(ctx, contigs, k, w, &idx), "index");
+  // ---- index (winSketch.hpp:180-365): the whole reference first; under --maxmemory it only serves to evaluate the
+  // chunk rule and is then replaced by one index per chunk
+  std::vector<std::string> cname, cseq; std::vector<int> clen;
+  struct Chunk { int first, count; mm_index* idx; };
+  std::vector<Chunk> chunks;
   {
-    int64_t n = 0; mm_index_freq_hist(idx, nullptr, nullptr, 0, &n);
-    std::vector<int64_t> c((size_t)n), h((size_t)n); mm_index_freq_hist(idx, c.data(), h.data(), n, &n);
-    mm_index_info info; mm_index_get_info(idx, &info);
-    mm_index_set_freq_threshold(idx, mm_freq_threshold_from_hist(c.data(), h.data(), n, info.n_unique_hashes, INT_MAX));
-    std::cout << "INFO, index: " << info.n_contigs << " contigs, " << info.n_entries << " minimizers, " << info.n_unique_hashes << " unique hashes\n";
+    mm_seqset* contigs; ck(ctx, mm_seqset_create(ctx, &contigs), "seqset");
+    SeqFile f(ref);
+    while (f.next()) {
+      ck(ctx, mm_seqset_add(contigs, f.seq.data(), (int64_t)f.seq.size()), "add contig");
+      cname.push_back(f.name); clen.push_back((int)f.seq.size());
+      if (maxMem) cseq.push_back(f.seq);
+    }
+    ck(ctx, mm_seqset_upload(contigs), "upload reference");
+    mm_index* whole; ck(ctx, mm_index_build(ctx, contigs, k, w, &whole), "index");
+    mm_seqset_destroy(contigs);
+    std::vector<int32_t> first(1, 0);
+    if (maxMem) {
+      int32_t n = 0;
+      ck(ctx, mm_index_plan_chunks(ctx, whole, maxMem, nullptr, 0, &n), "chunk plan");
+      first.resize((size_t)n);
+      ck(ctx, mm_index_plan_chunks(ctx, whole, maxMem, first.data(), n, &n), "chunk plan");
+    }
+    if (first.size() == 1) chunks.push_back(Chunk{0, (int)cname.size(), whole});
+    else {
+      mm_index_destroy(whole);
+      for (size_t c = 0; c < first.size(); ++c) {
+        const int a = first[c], b = c + 1 < first.size() ? first[c + 1] : (int)cname.size();
+        mm_seqset* part; ck(ctx, mm_seqset_create(ctx, &part), "seqset");
+        for (int i = a; i < b; ++i) ck(ctx, mm_seqset_add(part, cseq[(size_t)i].data(), (int64_t)cseq[(size_t)i].size()), "add contig");
+        ck(ctx, mm_seqset_upload(part), "upload reference chunk");
+        mm_index* idx; ck(ctx, mm_index_build(ctx, part, k, w, &idx), "index chunk");
+        mm_seqset_destroy(part);
+        chunks.push_back(Chunk{a, b - a, idx});
+      }
+    }
+    cseq.clear(); cseq.shrink_to_fit();
   }
-  mm_seqset_destroy(contigs);
+  {
+    // freqThreshold per chunk from the histogram accumulated over the chunks so far (never cleared, winSketch.hpp:452-494)
+    std::map<int64_t, int64_t> acc; int thr = INT_MAX;
+    for (size_t c = 0; c < chunks.size(); ++c) {
+      int64_t n = 0; mm_index_freq_hist(chunks[c].idx, nullptr, nullptr, 0, &n);
+      std::vector<int64_t> cc((size_t)n), hh((size_t)n); mm_index_freq_hist(chunks[c].idx, cc.data(), hh.data(), n, &n);
+      for (int64_t i = 0; i < n; ++i) acc[cc[(size_t)i]] += hh[(size_t)i];
+      mm_index_info info; mm_index_get_info(chunks[c].idx, &info);
+      if (info.n_unique_hashes > 0) {
+        std::vector<int64_t> ac, ah; for (auto& kv : acc) { ac.push_back(kv.first); ah.push_back(kv.second); }
+        thr = mm_freq_threshold_from_hist(ac.data(), ah.data(), (int64_t)ac.size(), info.n_unique_hashes, thr);
+      }
+      mm_index_set_freq_threshold(chunks[c].idx, thr);
+      std::cout << "INFO, index chunk " << c + 1 << "/" << chunks.size() << ": contigs " << chunks[c].first << ".." << chunks[c].first + chunks[c].count - 1
+                << ", " << info.n_entries << " minimizers, " << info.n_unique_hashes << " unique hashes\n";
+    }
+  }
   // ---- reads, batch by batch (computeMap.hpp:104-172 + unifyFiles mapWrap.h:34-213)
   const int64_t BATCH_READS = 200000, BATCH_BASES = 3000000000LL;
   for (size_t fi = 0; fi < queries.size(); ++fi) {
@@ -153,7 +195,17 @@ int map_directly(const Options& o) {
       if (names.empty()) { mm_seqset_destroy(reads); break; }
       ck(ctx, mm_seqset_upload(reads), "upload reads");
       mm_map_params mp{k, w, pi, minLen};
-      mm_mapping* m; ck(ctx, mm_map_batch(ctx, idx, reads, &mp, &m), "map");
+      std::vector<mm_mapping*> parts; std::vector<int32_t> base;
+      for (auto& ch : chunks) {                                   // one "PREFIX.N" per chunk in the reference (mapWrap.h:419-437)
+        mm_mapping* pm; ck(ctx, mm_map_batch(ctx, ch.idx, reads, &mp, &pm), "map");
+        if (!o.all) ck(ctx, mm_mapping_keep_best(ctx, pm, k), "best mappings");
+        parts.push_back(pm); base.push_back(ch.first);
+      }
+      mm_mapping* m = parts[0];
+      if (parts.size() > 1) {                                     // unifyFiles: read-wise concatenation in chunk order
+        ck(ctx, mm_mapping_concat(ctx, parts.data(), base.data(), (int)parts.size(), &m), "merge chunks");
+        for (auto* pm : parts) mm_mapping_destroy(pm);
+      }
       ck(ctx, mm_mapping_add_qualities(ctx, m, reads, k), "mapping qualities");
       std::vector<int64_t> off(names.size() + 1);
       ck(ctx, mm_mapping_fetch(m, off.data(), nullptr, 0), "fetch");
@@ -190,7 +242,8 @@ int map_directly(const Options& o) {
        << "]\noutFileName " << prefix << "\nreportAll " << o.all << "\nindex " << "" << "\nmaximumMemory " << maxMem << "\n";
     std::cout << "INFO, [count of mapped reads, reads qualified for mapping, total input reads] = [" << mapped << ", " << total - tooShort << ", " << total << "]\n";
   }
-  mm_index_destroy(idx); mm_ctx_destroy(ctx);
+  for (auto& ch : chunks) mm_index_destroy(ch.idx);
+  mm_ctx_destroy(ctx);
   return 0;
 }
 

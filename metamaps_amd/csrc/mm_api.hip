@@ -148,6 +148,19 @@ int mm_index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index
     *out = I;
   });
 }
+int mm_index_plan_chunks(mm_ctx* ctx, const mm_index* whole, uint64_t max_memory_bytes, int32_t* first_contig, int32_t cap, int32_t* n_chunks) {
+  if (!ctx || !whole || !n_chunks) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
+    std::vector<int32_t> fc;
+    mm::index_plan_chunks(ctx, whole, max_memory_bytes, fc);
+    *n_chunks = (int32_t)fc.size();
+    if (first_contig) {
+      MM_REQUIRE(cap >= (int32_t)fc.size(), MM_ERR_ARG, "output capacity too small");
+      for (size_t i = 0; i < fc.size(); ++i) first_contig[i] = fc[i];
+    }
+  });
+}
 void mm_index_destroy(mm_index* idx) { if (idx) { mm::current_stream() = idx->ctx->stream; mm::current_alloc() = &idx->ctx->alloc; delete idx; } }
 int mm_index_get_info(const mm_index* idx, mm_index_info* out) {
   if (!idx || !out) return MM_ERR_ARG;
@@ -291,6 +304,37 @@ int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* cont
     }
     MM_HIP(hipStreamSynchronize(ctx->stream));
     *out = M;
+  });
+}
+
+int mm_mapping_keep_best(mm_ctx* ctx, mm_mapping* m, int k) {
+  if (!ctx || !m) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    // default (non --all) reporting, computeMap.hpp:546-587: per read keep the mappings whose (float) identity is
+    // >= best - 1.0; the comparison happens in double exactly as there.  Record lists are small: host side.
+    std::vector<mm_map_record> recs((size_t)m->n_rec), kept;
+    m->rec.download(recs.data(), recs.size(), ctx->stream);
+    MM_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> off((size_t)m->n_reads + 1, 0);
+    int64_t mapped = 0;
+    for (int64_t r = 0; r < m->n_reads; ++r) {
+      const uint64_t a = m->h_rec_off[(size_t)r], b = m->h_rec_off[(size_t)r + 1];
+      float best = 0;
+      std::vector<float> id((size_t)(b - a));
+      for (uint64_t i = a; i < b; ++i) {
+        float ub; mm::stats::identity(recs[(size_t)i].shared, recs[(size_t)i].sketch, k, &id[(size_t)(i - a)], &ub);
+        if (id[(size_t)(i - a)] > best) best = id[(size_t)(i - a)];
+      }
+      for (uint64_t i = a; i < b; ++i) if (id[(size_t)(i - a)] >= best - 1.0) kept.push_back(recs[(size_t)i]);
+      off[(size_t)r + 1] = kept.size();
+      if (off[(size_t)r + 1] > off[(size_t)r]) ++mapped;
+    }
+    m->n_rec = (int64_t)kept.size();
+    m->rec.alloc(std::max<size_t>(kept.size(), 1)); m->rec.upload(kept.data(), kept.size(), ctx->stream);
+    m->rec_off.upload(off.data(), off.size(), ctx->stream);
+    m->h_rec_off = off;
+    m->stats.n_mappings = m->n_rec; m->stats.n_reads_mapped = mapped;
+    MM_HIP(hipStreamSynchronize(ctx->stream));
   });
 }
 

@@ -261,4 +261,69 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   I->uh.release(); I->ustart.release();
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// --maxmemory chunk rule (winSketch.hpp:180-365, memory model :165-178) evaluated on the whole-reference index.
+//
+// The reference streams contigs and, before adding contig c, asks whether
+//   memory( hashes so far in this chunk + hashes of c not yet in the chunk's table , minimizers so far + |c| )
+// exceeds the limit; if so it flushes the chunk and c opens the next one.  With c0 = first contig of the current
+// chunk, "hashes of c not yet in the table" = #{h : the first occurrence of h at or after contig c0 lies in c}.
+// Every hash group in occ[] is sorted by contig, so one pass over the table finds that first occurrence by a
+// lower bound inside the group — one pass per chunk, no per-contig set arithmetic.
+__global__ void __launch_bounds__(256) novel_hashes_kernel(const uint64_t* __restrict__ tab, int64_t slots, const uint64_t* __restrict__ occ,
+                                                           uint32_t c0, unsigned int* __restrict__ novel) {
+  for (int64_t sl = (int64_t)blockIdx.x * 256 + threadIdx.x; sl < slots; sl += (int64_t)gridDim.x * 256) {
+    const uint64_t w0 = tab[2 * sl];
+    if (w0 == 0) continue;
+    const uint64_t start = tab[2 * sl + 1];
+    int64_t lo = 0, hi = (int64_t)(w0 >> 32);
+    const uint64_t key = (uint64_t)c0 << 32;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (occ[start + mid] < key) lo = mid + 1; else hi = mid; }
+    if (lo < (int64_t)(w0 >> 32)) atomicAdd(&novel[(uint32_t)(occ[start + lo] >> 32)], 1u);
+  }
+}
+
+static size_t chunk_memory(size_t hashes, size_t mins) {           // Sketch::estimateMemory, winSketch.hpp:165-178 (LP64 sizes)
+  size_t buckets = hashes / 10;
+  size_t table = buckets * (8 + 8) + hashes * 8 + hashes * 24 + mins * 12;
+  table *= 1.2;                                                    // size_t *= double, as there
+  size_t vec = 24 + mins * 16;
+  return table + vec;
+}
+
+void index_plan_chunks(mm_ctx* ctx, const mm_index* I, uint64_t max_memory, std::vector<int32_t>& first_contig) {
+  hipStream_t st = ctx->stream;
+  first_contig.assign(1, 0);
+  if (max_memory == 0 || I->n_contigs == 0) return;
+  const int64_t C = I->n_contigs, slots = (int64_t)1 << I->tab_bits;
+  DBuf<unsigned int> novel((size_t)C);
+  std::vector<unsigned int> h((size_t)C);
+  int64_t c0 = 0;
+  for (;;) {
+    novel.zero(st);
+    novel_hashes_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(slots, 256), 1 << 20)), dim3(256), 0, st>>>(I->tab.p, slots, I->occ.p, (uint32_t)c0, novel.p);
+    MM_KERNEL_CHECK();
+    novel.download(h.data(), (size_t)C, st);
+    MM_HIP(hipStreamSynchronize(st));
+    size_t runH = 0, runM = 0;
+    int64_t c = c0;
+    for (; c < C; ++c) {
+      const int len = I->contig_len[(size_t)c];
+      if (len < I->w || len < I->k) continue;                      // metadata only (:258-264)
+      const size_t addM = (size_t)(I->h_cstart[(size_t)c + 1] - I->h_cstart[(size_t)c]);
+      const size_t mem = chunk_memory(runH + h[(size_t)c], runM + addM);
+      if (mem > max_memory) {
+        // nothing in the chunk yet: the contig alone is over the limit (:318-322)
+        MM_REQUIRE(runH != 0 || runM != 0, MM_ERR_LIMIT, "Can't index the reference within current memory limits - a contig is too large");
+        break;
+      }
+      runH += h[(size_t)c]; runM += addM;
+    }
+    if (c >= C) break;
+    first_contig.push_back((int32_t)c);
+    c0 = c;
+  }
+}
+
 }  // namespace mm

@@ -39,7 +39,9 @@ int main(int argc, char** argv) {
     P.pval = opt.count("pval") ? std::stod(opt["pval"]) : 1e-3;
     P.minReadLen = opt.count("minReadLen") ? std::stoi(opt["minReadLen"]) : 1000;
     P.pi = opt.count("perc_identity") ? std::stof(opt["perc_identity"]) : 80;
+    if (opt.count("maxmemory-bytes")) P.maxMem = std::stoull(opt["maxmemory-bytes"]);   // test hook: sub-GiB limits
     P.reportAll = all;
+    P.threads = opt.count("threads") ? std::max(1, std::stoi(opt["threads"])) : 1;
     if (opt.count("window")) {                                   // parseCmdArgs.hpp:363-374
       P.w = std::stoi(opt["window"]);
       int s = P.minReadLen * 2 / P.w;
@@ -56,7 +58,7 @@ int main(int argc, char** argv) {
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::cerr << "{\"oracle\":\"mapDirectly\",\"w\":" << P.w << ",\"reads\":" << C.reads << ",\"bases\":" << C.bases
               << ",\"sketch\":" << C.sketch << ",\"hits\":" << C.hits << ",\"cands\":" << C.cands << ",\"stream\":"
-              << C.stream << ",\"evals\":" << C.evals << ",\"mappings\":" << C.maps << ",\"map_seconds\":" << C.map_seconds << ",\"seconds\":" << sec << "}\n";
+              << C.stream << ",\"evals\":" << C.evals << ",\"mappings\":" << C.maps << ",\"chunks\":" << C.chunks << ",\"threads\":" << P.threads << ",\"map_seconds\":" << C.map_seconds << ",\"seconds\":" << sec << "}\n";
   } else if (mode == "classify") {
     if (!opt.count("DB")) { std::cerr << "Provide path to DB.\n"; return 1; }
     if (!opt.count("mappings")) { std::cerr << "Provide path to mappings.\n"; return 1; }

@@ -6,6 +6,7 @@
 #include <iostream>
 #include <regex>
 #include <chrono>
+#include <thread>
 
 namespace orc {
 
@@ -116,29 +117,53 @@ static inline void unify_files(const std::string& prefix, const Params& P, const
      << prefix << "\nreportAll " << P.reportAll << "\nindex " << "" << "\nmaximumMemory " << P.maxMem << "\n";
 }
 
-struct MapCounters { uint64_t reads = 0, bases = 0, sketch = 0, hits = 0, cands = 0, stream = 0, evals = 0, maps = 0; double map_seconds = 0; };
+struct MapCounters { uint64_t reads = 0, bases = 0, sketch = 0, hits = 0, cands = 0, stream = 0, evals = 0, maps = 0, chunks = 0; double map_seconds = 0; };
 
-// computeMap.hpp:104-172 (single-threaded; the pool only preserves input order) writing PREFIX.N
+// computeMap.hpp:104-172 writing PREFIX.N.  The reference's thread pool only guarantees that output order equals
+// input order (ThreadPool.hpp:13-17); here `threads` workers take contiguous read ranges and the ranges are
+// written in order, which gives the same file.
 static inline void map_query_file(const RefSketch& R, const Params& P, const std::string& queryFile,
                                   const std::string& outFile, MapCounters* C = nullptr) {
   std::ofstream out(outFile);
-  SeqReader rd(queryFile);
-  long len;
-  auto t0 = std::chrono::steady_clock::now();                    // "Time spent mapping the query", computeMap.hpp:91-96
-  while ((len = rd.next()) >= 0) {
-    if (len < P.w || len < P.k || len < P.minReadLen) continue;
-    Query Q; Q.name = rd.name; Q.seq = &rd.seq[0]; Q.len = (int)len;
-    std::vector<L1Cand> cands; std::vector<Mapping> ms; L1Debug dbg;
-    do_l1(R, P, Q, cands, &dbg);
-    uint64_t ev = 0, st = 0;
-    do_l2(R, P, Q, cands, ms, &ev, &st);
-    std::string lines;
-    report_lines(R, P, Q.name, ms, lines);
-    out << lines;
-    if (C) { C->reads++; C->bases += len; C->sketch += Q.sketch; C->hits += dbg.hits.size(); C->cands += cands.size();
-             C->stream += st; C->evals += ev; C->maps += ms.size(); }
+  struct Item { std::string name, seq; };
+  std::vector<Item> items;
+  {
+    SeqReader rd(queryFile);
+    long len;
+    while ((len = rd.next()) >= 0) {
+      if (len < P.w || len < P.k || len < P.minReadLen) continue;
+      items.push_back(Item{rd.name, rd.seq});
+    }
   }
-  if (C) C->map_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  auto t0 = std::chrono::steady_clock::now();                    // "Time spent mapping the query", computeMap.hpp:91-96
+  const int nthr = std::max(1, std::min<int>(P.threads, (int)items.size()));
+  std::vector<std::string> chunks((size_t)nthr);
+  std::vector<MapCounters> cs((size_t)nthr);
+  auto work = [&](int t) {
+    const size_t lo = items.size() * (size_t)t / (size_t)nthr, hi = items.size() * (size_t)(t + 1) / (size_t)nthr;
+    for (size_t i = lo; i < hi; ++i) {
+      Query Q; Q.name = items[i].name; Q.seq = &items[i].seq[0]; Q.len = (int)items[i].seq.size();
+      std::vector<L1Cand> cands; std::vector<Mapping> ms; L1Debug dbg;
+      do_l1(R, P, Q, cands, &dbg);
+      uint64_t ev = 0, st = 0;
+      do_l2(R, P, Q, cands, ms, &ev, &st);
+      report_lines(R, P, Q.name, ms, chunks[(size_t)t]);
+      MapCounters& c = cs[(size_t)t];
+      c.reads++; c.bases += Q.len; c.sketch += Q.sketch; c.hits += dbg.hits.size(); c.cands += cands.size();
+      c.stream += st; c.evals += ev; c.maps += ms.size();
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nthr; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (auto& th : pool) th.join();
+  for (auto& ch : chunks) out << ch;
+  if (C) {
+    C->chunks++;
+    for (auto& c : cs) { C->reads += c.reads; C->bases += c.bases; C->sketch += c.sketch; C->hits += c.hits; C->cands += c.cands;
+                         C->stream += c.stream; C->evals += c.evals; C->maps += c.maps; }
+    C->map_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
 }
 
 // mapWrap.h:407-441 for one query/prefix pair

@@ -53,3 +53,52 @@ def test_cli_outputs_match_oracle(oracle_lib, tmp_path, w_flag):
     _cmp_table(pa + ".EM.reads2Taxon.krona", pb + ".EM.reads2Taxon.krona", "\t", {2})
     _cmp_table(pa + ".EM.WIMP", pb + ".EM.WIMP", "\t", {4, 5})
     assert sum(1 for _ in open(pa)) > 150
+
+
+def _run_pair(tmp_path, extra, n_reads=200):
+    import json
+    import orc
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=10, genome_len=60_000, seed=7)
+    rd = synth.make_reads(db, str(tmp_path / "reads.fq"), n_reads=n_reads, read_len=3000, seed=3)
+    pa, pb = str(tmp_path / "gpu"), str(tmp_path / "cpu")
+    info = {}
+    for exe, pre in ((CLI, pa), (orc.CLI, pb)):
+        p = subprocess.run([exe, "mapDirectly", "-r", db.fasta, "-q", rd["path"], "-o", pre] + extra, check=True, capture_output=True, timeout=900)
+        info[pre] = p
+    n_gpu_chunks = sum(1 for l in info[pa].stdout.decode().splitlines() if l.startswith("INFO, index chunk"))
+    n_cpu_chunks = json.loads(info[pb].stderr.decode().strip().splitlines()[-1])["chunks"]
+    _cmp_table(pa, pb, " ", {13})
+    for suf in (".meta", ".meta.unmappedReadsLengths"):
+        assert open(pa + suf).read() == open(pb + suf).read(), suf
+    pa_par = [l for l in open(pa + ".parameters") if not l.startswith("outFileName")]
+    pb_par = [l for l in open(pb + ".parameters") if not l.startswith("outFileName")]
+    assert pa_par == pb_par
+    return pa, n_gpu_chunks, n_cpu_chunks
+
+
+def test_cli_best_only_reporting(oracle_lib, tmp_path):
+    """without --all only mappings within 1.0 of the read's best identity are reported (computeMap.hpp:546-587)"""
+    pa, g, c = _run_pair(tmp_path, [])
+    assert g == c == 1
+    pall = str(tmp_path / "gpu_all")
+    subprocess.run([CLI, "mapDirectly", "--all", "-r", str(tmp_path / "db" / "DB.fa"), "-q", str(tmp_path / "reads.fq"), "-o", pall],
+                   check=True, capture_output=True, timeout=900)
+    assert sum(1 for _ in open(pa)) < sum(1 for _ in open(pall))          # the filter removed something
+
+
+@pytest.mark.parametrize("limit,all_flag", [(4_000_000, ["--all"]), (2_000_000, ["--all"]), (1_000_000, ["--all"]), (1_000_000, [])])
+def test_cli_maxmemory_chunks(oracle_lib, tmp_path, limit, all_flag):
+    """--maxmemory: same chunk boundaries as the reference's streaming rule (winSketch.hpp:274-329), per-chunk
+    freqThreshold from the accumulated histogram, read-wise merge in chunk order, mapQ over the union."""
+    pa, g, c = _run_pair(tmp_path, all_flag + ["--maxmemory-bytes", str(limit)])
+    assert g == c and g >= 2, (g, c)
+
+
+def test_cli_maxmemory_contig_too_large(tmp_path):
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=4, genome_len=60_000, seed=7)
+    rd = synth.make_reads(db, str(tmp_path / "reads.fq"), n_reads=10, read_len=3000, seed=3)
+    p = subprocess.run([CLI, "mapDirectly", "--all", "-r", db.fasta, "-q", rd["path"], "-o", str(tmp_path / "x"), "--maxmemory-bytes", "300000"],
+                       capture_output=True, timeout=900)
+    assert p.returncode != 0 and b"too large" in p.stderr

@@ -44,9 +44,10 @@ __device__ inline bool wave_has_hash(const Rec* __restrict__ pos, int64_t lo, in
   }
   return false;
 }
-__device__ inline int wave_sum(int v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return v; }
-__device__ inline int wave_min(int v) { for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64)); return v; }
-__device__ inline int wave_max(int v) { for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64)); return v; }
+// the results of the wave reductions are uniform; readfirstlane tells the compiler so (SGPRs, scalar branches)
+__device__ inline int wave_sum(int v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline int wave_min(int v) { for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64)); return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline int wave_max(int v) { for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64)); return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline int wave_excl_scan(int v, int lane) {
   int inc = v;
   for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
@@ -103,12 +104,14 @@ __device__ inline int l2_classify1(const uint32_t* __restrict__ Q, const uint16_
   return (lo < s && Q[min(lo, s - 1)] == h) ? lo : -(lo + 1);
 }
 
-// LDS layout: Q[smax] (shared by the waves of a workgroup) | per wave: D[smax] | mt | skip-ahead class arrays
+// LDS layout: Q[smax] (shared by the waves of a workgroup) | per wave: D[smax] | mt | skip-ahead class arrays | slide scratch
+constexpr int L2_SCRATCH_BYTES = 64 * 4 + 64 + 64;             // step times, step-has-deletion, step-has-addition
+__host__ __device__ inline size_t l2_skip_bytes() { return (((size_t)(L2_NBLK + 1) * (3 * 8 + 3 * 2)) + 15) & ~(size_t)15; }
 template <typename DT>
 __host__ __device__ inline size_t l2_wave_bytes(int smax, bool skip) {
   size_t b = (((size_t)smax * sizeof(DT) + 3) & ~(size_t)3) + (size_t)((smax + 31) / 32) * 4;
-  b = (b + 7) & ~(size_t)7;
-  if (skip) b += (size_t)(L2_NBLK + 1) * (3 * 8 + 3 * 2);
+  b = (b + 15) & ~(size_t)15;
+  if (skip) b += l2_skip_bytes() + L2_SCRATCH_BYTES;
   return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t l2_q_bytes(int smax) { return (((size_t)smax * 4 + 15) & ~(size_t)15) + (((size_t)L2_TSIZE * 2 + 4 + 15) & ~(size_t)15); }
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
                                                 int32_t* __restrict__ ovf_list, unsigned int* __restrict__ ovf_n) {
   extern __shared__ __align__(16) uint32_t lds[];
   uint32_t* Q = lds;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint8_t* wbase = (uint8_t*)lds + l2_q_bytes(smax) + (size_t)wave * l2_wave_bytes<DT>(smax, SKIP);
   DT* D = (DT*)wbase;
   uint32_t* mt = (uint32_t*)(wbase + (((size_t)smax * sizeof(DT) + 3) & ~(size_t)3));
@@ -240,7 +243,16 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
 
   // ---- state of window [nb,ne) from scratch, all lanes (the arrays are order independent) ---------------
   unsigned long long rebuilds = 0;
-  auto rebuild = [&](int nb, int ne) {
+  // Pivot zone (SKIP path).  The serial slide keeps no LDS state at all: lane l owns rank r = z0 + l and holds
+  //   fz = r + D[z0] + ... + D[r]                  (VGPR; huge for r >= s so that lane r == s acts as the "R = s" sentinel)
+  // next to the wave-uniform scalars cbase = D[0] + ... + D[z0-1], sb = matched ranks below z0 present in the window and
+  // pm = presence mask of the zone's ranks.  Then R = z0 + ctz(ballot(fz >= s - cbase)) and
+  // shared = sb + popcount(pm below R): one compare + scalar bit operations per window instead of LDS round trips.
+  // An event outside the zone only touches a scalar; inside it is one predicated vector add.  When the pivot reaches a
+  // zone edge the state is rebuilt from the window's entries, re-centred on the new pivot.
+  int z0 = 0, cbase = 0, sb = 0, fz = 0;
+  uint64_t pm = 0;
+  auto rebuild_state = [&](int nb, int ne) __attribute__((always_inline)) {
     ++rebuilds;
     uint32_t* Dw = (uint32_t*)D;
     for (int i = lane; i < (s + DPER - 1) / DPER; i += 64) Dw[i] = 0;
@@ -299,6 +311,29 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     }
     sh = wave_sum(sh);
     S.R = R; S.Cb = cb; S.shared = sh;
+    if (SKIP) {
+      z0 = max(0, min(R - 32, s - 63));
+      int below = 0;
+      for (int i = r_lo; i < r_hi && i < z0; ++i) below += D[i];
+      cbase = wave_sum(below);
+      const int rz = z0 + lane;
+      const int dz = rz < s ? (int)D[rz] : 0;
+      int inc = dz;
+      for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+      fz = rz < s ? rz + inc : (1 << 29);
+      int sbl = 0;
+      for (int wd = lane; wd * 32 < z0; wd += 64) {
+        uint32_t m = mt[wd];
+        const int rem = z0 - wd * 32;
+        if (rem < 32) m &= (1u << rem) - 1u;
+        sbl += __popc(m);
+      }
+      sb = wave_sum(sbl);
+      pm = __ballot(rz < s && ((mt[rz >> 5] >> (rz & 31)) & 1u));
+    }
+  };
+  auto rebuild = [&](int nb, int ne) __attribute__((always_inline)) {
+    rebuild_state(nb, ne);
     b = nb; e = ne;
     sw_pos = pw_wpos(pos[nb].pw);
     loadB(nb); loadE(ne);
@@ -311,7 +346,206 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   int probe_best = 0, probe_R = 0;
   // slides while e < last_end and b < b_stop; TRACK=false only records the maximum (for the bound), it does
   // not touch the reference-visible trackers
-  auto slide = [&](int b_stop, bool track) {
+  auto zone_apply = [&](int code, int sign) {                   // code, sign wave-uniform
+    if (code >= 0) {                                             // a matched rank enters / leaves
+      if (code < z0) sb += sign;
+      else if (code < z0 + 64) pm ^= 1ull << (code - z0);
+    } else {                                                     // a distinct window-only hash of gap g (g < s)
+      const int g = -code - 1;
+      if (g < z0) cbase += sign;
+      else if (g < z0 + 64) fz += (lane >= g - z0) ? sign : 0;
+    }
+  };
+  auto zone_slide = [&](int b_stop, bool track) __attribute__((always_inline)) {
+    while (e < last_end && b < b_stop) {
+      if (b + 1 - baseB >= 64 || b < baseB) loadB(b);
+      if (e - baseE >= 64 || e < baseE) loadE(e);
+      const uint32_t pwb = (uint32_t)__builtin_amdgcn_readlane((int)rb.pw, (int)(b - baseB));
+      const int cur_wb = pw_wpos(pwb);
+      if (track) {
+        if (S.shared > best) { best = S.shared; bestR = S.R; opt_b = b; opt_e = e; beg_pos = last_pos = cur_wb; }   // :510-518
+        else if (S.shared == best) last_pos = cur_wb;            // :520-524
+      } else if (S.shared > probe_best) { probe_best = S.shared; probe_R = S.R; }
+      ++evals;
+      const uint32_t pwe = (uint32_t)__builtin_amdgcn_readlane((int)rE.pw, (int)(e - baseE));
+      const int wb1 = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rb.pw, (int)(b + 1 - baseB)));
+      const int d_beg = wb1 - sw_pos, d_end = pw_wpos(pwe) - (sw_pos + cnt - 1);
+      const int adv = min(d_beg, d_end);                         // MIIteratorL2.hpp:83
+      sw_pos += adv;
+      if (adv == d_beg) {                                        // the first entry leaves (slidingMap.hpp:170-214)
+        const int code = __builtin_amdgcn_readlane(codeB, (int)(b - baseB));
+        if (code != -(s + 1)) {
+          bool stays = false;                                    // NOOP: a later occurrence of the hash stays inside
+          if (pwb & PW_DN) stays = wave_has_hash(pos, b + 1, e, (uint32_t)__builtin_amdgcn_readlane((int)rb.hash, (int)(b - baseB)), lane);
+          if (!stays) zone_apply(code, -1);
+        }
+        ++b;
+      }
+      if (adv == d_end) {                                        // the next entry enters (slidingMap.hpp:139-160)
+        const int code = __builtin_amdgcn_readlane(codeE, (int)(e - baseE));
+        if (code != -(s + 1)) {
+          bool dup = false;                                      // REV: the hash is already inside
+          if (pwe & PW_DP) dup = wave_has_hash(pos, b, e, (uint32_t)__builtin_amdgcn_readlane((int)rE.hash, (int)(e - baseE)), lane);
+          if (!dup) zone_apply(code, +1);
+        }
+        ++e;
+      }
+      const uint64_t ge = __ballot(fz >= s - cbase);
+      if (ge == 0ull || ((ge & 1ull) && z0 > 0)) rebuild_state(b, e);   // pivot at a zone edge: re-centre
+      else {
+        const int p = __builtin_ctzll(ge);
+        S.R = z0 + p;
+        S.shared = sb + __popcll(pm & ((1ull << p) - 1ull));
+      }
+    }
+  };
+  // ---- 64 consecutive windows per round, one lane per window (SKIP path) ---------------------------------
+  // The window sequence is the merge of two sorted time lists: entry b+i leaves when sw_pos reaches A_i = wpos[b+i+1],
+  // entry e+i enters at B_i = wpos[e+i]-(cnt-1); equal times are one step (deletion, then addition).  Step indices by
+  // cross-ranking the two lists (wave-wide binary searches through ds_bpermute), window j = state after the first j steps
+  // = [b+d_j, e+a_j).  Its pivot-zone state follows from prefix sums over the per-entry indicators: cbase_j and sb_j by
+  // one packed scan per side, then R_j by a per-lane binary search over the zone's fz (rank-indexed lanes, read with
+  // ds_bpermute) and shared_j = sb_j + popcount(pm_j below R_j).  Events inside the zone are rare and applied one by one.
+  // Only times up to min(A_63, B_63) are certain (later entries of the other list could interleave), the rest of the
+  // chunk is redone by the next round.
+  int* tst = (int*)(wbase + l2_wave_bytes<DT>(smax, false) + l2_skip_bytes());
+  uint8_t* fdel = (uint8_t*)(tst + 64);
+  uint8_t* fadd = fdel + 64;
+  auto rank_search = [&](int arr, int v) -> int {                // number of leading lanes whose (ascending) arr < v
+    int lo = 0;
+    for (int st = 32; st >= 1; st >>= 1) { const int x = __shfl(arr, lo + st - 1, 64); if (x < v) lo += st; }
+    const int x = __shfl(arr, lo, 64);
+    return lo + (x < v ? 1 : 0);
+  };
+  auto block_slide = [&](int b_stop, bool track) __attribute__((always_inline)) {
+    constexpr int INF = 0x7fffffff;
+    while (e < last_end && b < b_stop) {
+      const Rec xb = pos[min(b + lane, nmax)];
+      const Rec xe = pos[min(e + lane, nmax)];
+      const int w64 = pw_wpos(pos[min(b + 64, nmax)].pw);
+      const int cB = l2_classify1(Q, T, tsteps, s, xb.hash), cE = l2_classify1(Q, T, tsteps, s, xe.hash);
+      const int wpb = pw_wpos(xb.pw);
+      int nextw = __shfl_down(wpb, 1, 64);
+      if (lane == 63) nextw = w64;
+      const int tA = (b + lane + 1 < last_end) ? nextw : INF;
+      const int tB = (e + lane < last_end) ? pw_wpos(xe.pw) - (cnt - 1) : INF;
+      // cross ranks and ties
+      const int nB = rank_search(tB, tA), nA = rank_search(tA, tB);
+      const int tB_at = __shfl(tB, min(nB, 63), 64);               // (shuffles are executed by all lanes, never under a branch)
+      const bool tie = tA != INF && tB_at == tA && nB < 64;
+      const int tie_ex = wave_excl_scan(tie ? 1 : 0, lane);
+      const int ties_all = __builtin_amdgcn_readlane(tie_ex, 63) + (__builtin_amdgcn_readlane((int)tie, 63) ? 1 : 0);
+      const int tie_at = __shfl(tie_ex, min(nA, 63), 64);
+      const int t_lim = min(__builtin_amdgcn_readlane(tA, 63), __builtin_amdgcn_readlane(tB, 63));
+      const bool okA = tA != INF && tA <= t_lim, okB = tB != INF && tB <= t_lim;
+      const int kA = okA ? lane + nB - tie_ex : (1 << 20);
+      const int kB = okB ? lane + nA - (nA < 64 ? tie_at : ties_all) : (1 << 20);
+      const int ksteps = wave_max(max(okA ? kA + 1 : 0, okB ? kB + 1 : 0));
+      // step table: which steps delete / add, and their times
+      fdel[lane] = 0; fadd[lane] = 0;
+      wave_sync();
+      if (kA < 64) { fdel[kA] = 1; tst[kA] = tA; }
+      if (kB < 64) { fadd[kB] = 1; tst[kB] = tB; }
+      wave_sync();
+      const int hasDel = fdel[lane], hasAdd = fadd[lane];
+      const int dj = wave_excl_scan(hasDel, lane), aj = wave_excl_scan(hasAdd, lane);   // lane j: window j = [b+dj, e+aj)
+      const bool cond = lane < ksteps && (e + aj < last_end) && (b + dj < b_stop);
+      const uint64_t cm = __ballot(cond);
+      int n_eval = (~cm == 0ull) ? 64 : __builtin_ctzll(~cm);    // windows 0 .. n_eval-1 are evaluated (n_eval >= 1)
+      // events that count: not "above every query hash", and distinct inside their window (flagged entries are rare)
+      bool vE = cE != -(s + 1) && kB < n_eval, vB = cB != -(s + 1) && kA < n_eval;
+      {
+        uint64_t fm = __ballot(vE && (xe.pw & PW_DP));           // REV: the hash is already inside [b', x)
+        while (fm) {
+          const int l = __builtin_ctzll(fm); fm &= fm - 1;
+          const int kk = __builtin_amdgcn_readlane(kB, l);
+          const int hb = b + __builtin_amdgcn_readlane(dj, kk) + __builtin_amdgcn_readlane(hasDel, kk);
+          const bool dup = wave_has_hash(pos, hb, e + l, (uint32_t)__builtin_amdgcn_readlane((int)xe.hash, l), lane);
+          if (dup && lane == l) vE = false;
+        }
+        fm = __ballot(vB && (xb.pw & PW_DN));                    // NOOP: a later occurrence stays inside (x, e')
+        while (fm) {
+          const int l = __builtin_ctzll(fm); fm &= fm - 1;
+          const int kk = __builtin_amdgcn_readlane(kA, l);
+          const int we = e + __builtin_amdgcn_readlane(aj, kk);
+          const bool stays = wave_has_hash(pos, b + l + 1, we, (uint32_t)__builtin_amdgcn_readlane((int)xb.hash, l), lane);
+          if (stays && lane == l) vB = false;
+        }
+      }
+      // below-zone indicators, packed (window-only | matched << 16), inclusive prefix per side
+      const int gE = -cE - 1, gB = -cB - 1;
+      const int indE = vE ? ((cE < 0 && gE < z0 ? 1 : 0) | (cE >= 0 && cE < z0 ? 1 << 16 : 0)) : 0;
+      const int indB = vB ? ((cB < 0 && gB < z0 ? 1 : 0) | (cB >= 0 && cB < z0 ? 1 << 16 : 0)) : 0;
+      const int pE = wave_excl_scan(indE, lane) + indE, pB = wave_excl_scan(indB, lane) + indB;
+      const int gE_ = __shfl(pE, max(aj - 1, 0), 64), gB_ = __shfl(pB, max(dj - 1, 0), 64);
+      const int accE = aj > 0 ? gE_ : 0, accB = dj > 0 ? gB_ : 0;
+      const int cbase_j = cbase + (accE & 0xffff) - (accB & 0xffff);
+      const int sb_j = sb + (accE >> 16) - (accB >> 16);
+      const int thr = s - cbase_j;
+      // pivot per window; zone events in step order (each one changes the windows after its step)
+      auto pivot_of = [&]() -> int { return rank_search(fz, thr); };
+      int pj = pivot_of();
+      uint64_t pm_j = pm;
+      uint64_t zE = __ballot(vE && ((cE >= 0) ? (cE >= z0 && cE < z0 + 64) : (gE >= z0 && gE < z0 + 64)));
+      uint64_t zB = __ballot(vB && ((cB >= 0) ? (cB >= z0 && cB < z0 + 64) : (gB >= z0 && gB < z0 + 64)));
+      while (zE | zB) {
+        const int lE = zE ? __builtin_ctzll(zE) : 0, lB = zB ? __builtin_ctzll(zB) : 0;
+        const int kE_ = zE ? __builtin_amdgcn_readlane(kB, lE) : INF, kB_ = zB ? __builtin_amdgcn_readlane(kA, lB) : INF;
+        const bool takeB = kB_ <= kE_;                           // the deletion of a step comes first
+        const int code = takeB ? __builtin_amdgcn_readlane(cB, lB) : __builtin_amdgcn_readlane(cE, lE);
+        const int kk = takeB ? kB_ : kE_;
+        const int sign = takeB ? -1 : 1;
+        if (takeB) zB &= zB - 1; else zE &= zE - 1;
+        if (code >= 0) {
+          const uint64_t bit = 1ull << (code - z0);
+          pm ^= bit;
+          if (lane > kk) pm_j ^= bit;
+        } else {
+          const int g = -code - 1;
+          fz += (lane >= g - z0) ? sign : 0;
+          const int p2 = pivot_of();
+          if (lane > kk) pj = p2;
+        }
+      }
+      // pivot at a zone edge in some window: evaluate the windows before it, then re-centre there
+      const uint64_t xm = __ballot(lane < n_eval && (pj >= 64 || (pj == 0 && z0 > 0)));
+      const bool zone_exit = xm != 0ull;
+      if (zone_exit) n_eval = __builtin_ctzll(xm);
+      const int sh_j = lane < n_eval ? sb_j + __popcll(pm_j & ((1ull << (pj & 63)) - 1ull)) : -1;
+      if (n_eval > 0) {
+        const int m = wave_max(sh_j);
+        const uint64_t at = __ballot(sh_j == m);
+        const int j1 = __builtin_ctzll(at), jl = 63 - __builtin_clzll(at);
+        if (track) {
+          if (m > best) {                                        // :510-518 — the first window reaching the new maximum
+            best = m; bestR = z0 + __builtin_amdgcn_readlane(pj, j1);
+            const int d1 = __builtin_amdgcn_readlane(dj, j1);
+            opt_b = b + d1; opt_e = e + __builtin_amdgcn_readlane(aj, j1);
+            beg_pos = __builtin_amdgcn_readlane(wpb, d1);
+            last_pos = __builtin_amdgcn_readlane(wpb, __builtin_amdgcn_readlane(dj, jl));
+          } else if (m == best) last_pos = __builtin_amdgcn_readlane(wpb, __builtin_amdgcn_readlane(dj, jl));   // :520-524
+        } else if (m > probe_best) { probe_best = m; probe_R = z0 + __builtin_amdgcn_readlane(pj, j1); }
+        evals += (unsigned long long)n_eval;
+      }
+      // state of window n_eval
+      int dn, an;
+      if (n_eval < 64) { dn = __builtin_amdgcn_readlane(dj, n_eval); an = __builtin_amdgcn_readlane(aj, n_eval); }
+      else { dn = __builtin_amdgcn_readlane(dj, 63) + __builtin_amdgcn_readlane(hasDel, 63); an = __builtin_amdgcn_readlane(aj, 63) + __builtin_amdgcn_readlane(hasAdd, 63); }
+      if (n_eval > 0) sw_pos = tst[n_eval - 1];
+      b += dn; e += an;
+      if (zone_exit) rebuild_state(b, e);
+      else {
+        const int fE = an > 0 ? __builtin_amdgcn_readlane(pE, an - 1) : 0, fB = dn > 0 ? __builtin_amdgcn_readlane(pB, dn - 1) : 0;
+        cbase += (fE & 0xffff) - (fB & 0xffff);
+        sb += (fE >> 16) - (fB >> 16);
+        const uint64_t ge = __ballot(fz >= s - cbase);           // the pivot of the next round's first window must be inside too
+        if (ge == 0ull || ((ge & 1ull) && z0 > 0)) rebuild_state(b, e);
+        else { const int p = __builtin_ctzll(ge); S.R = z0 + p; S.shared = sb + __popcll(pm & ((1ull << p) - 1ull)); }
+      }
+    }
+  };
+  auto slide = [&](int b_stop, bool track) __attribute__((always_inline)) {
+    if (SKIP) { if (cnt >= 2) block_slide(b_stop, track); else zone_slide(b_stop, track); return; }
     while (e < last_end && b < b_stop) {
       if (b + 1 - baseB >= 64 || b < baseB) loadB(b);
       if (e - baseE >= 64 || e < baseE) loadE(e);
@@ -457,7 +691,10 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       done = true;
     }
   }
-  if (!done) {                                                   // full slide, exactly the reference's order
+  if (SKIP && !done) {                                           // every window, state of the first one built in parallel
+    rebuild(first, e_min(first));                                // :473, :489, MIIteratorL2.hpp:62
+    slide(last_end, true);
+  } else if (!done) {                                            // full slide, exactly the reference's order
     for (int i = lane; i < (s + DPER - 1) / DPER; i += 64) ((uint32_t*)D)[i] = 0;
     for (int i = lane; i < (s + 31) / 32; i += 64) mt[i] = 0;
     wave_sync();

@@ -163,8 +163,11 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   for (int bkt = threadIdx.x; bkt < (1 << L2_TBITS); bkt += 64 * WAVES) atomicMax(tmaxp, (int)T[bkt + 1] - (int)T[bkt]);
   __syncthreads();
   const int tsteps = *tmaxp ? 32 - __clz(*tmaxp) : 0;
+  const int dbg_flags = (int)counters[11];                       // timing aids: low byte MM_L2_STOP, bit 8 MM_L2_PHASES; 0 in normal operation
+  const int dbg_stop = dbg_flags & 0xff;
   if (WAVES > 1 && wave >= grp_n[blockIdx.x]) return;
   const int64_t c = c0 + (WAVES > 1 ? wave : 0);
+  if (dbg_stop) { if (lane == 0) { L2Result z{}; out[c] = z; } if (dbg_stop == 1) return; }
   constexpr int DMAX = (int)(DT)~(DT)0;
   constexpr int DPER = 4 / (int)sizeof(DT);                      // counters per 32-bit word
   constexpr int DBITS = 8 * (int)sizeof(DT);
@@ -192,26 +195,6 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     const int target = pw_wpos(pos[bb].pw) + cnt;
     return (int)wave_lower_bound_wpos(pos, bb, last_end, target, lane);
   };
-  // per-lane variant (different bb per lane): windows hold a nearly constant number of entries, so gallop around
-  // bb + span0 (span0 = size of the first window) instead of bisecting the whole range
-  int span0 = 0;
-  auto e_min_lane = [&](int bb) -> int {
-    const int target = pw_wpos(pos[bb].pw) + cnt;
-    int lo, hi;
-    int g = min(bb + span0, last_end);
-    if (g >= last_end || pw_wpos(pos[g].pw) >= target) {         // answer <= g: gallop down
-      hi = g; int stepd = 16; lo = max(bb, hi - stepd);
-      while (lo > bb && pw_wpos(pos[lo].pw) >= target) { hi = lo; stepd <<= 1; lo = max(bb, hi - stepd); }
-      if (pw_wpos(pos[lo].pw) >= target) return lo;              // lo == bb only if cnt <= 0
-      lo = lo + 1;
-    } else {                                                     // answer > g: gallop up
-      lo = g + 1; int stepu = 16; hi = min(last_end, lo + stepu);
-      while (hi < last_end && pw_wpos(pos[hi].pw) < target) { lo = hi + 1; stepu <<= 1; hi = min(last_end, lo + stepu); }
-    }
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (pw_wpos(pos[mid].pw) < target) lo = mid + 1; else hi = mid; }
-    return lo;
-  };
-
   // ---- register-resident chunks of 64 consecutive entries at both window ends -------------------------
   int baseB = first, baseE = first;
   Rec rb = pos[min(baseB + lane, nmax)], rE = rb;
@@ -263,15 +246,21 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       const uint32_t old = atomicAdd(&Dw[g / DPER], 1u << sh);
       if ((int)((old >> sh) & (uint32_t)DMAX) == DMAX) overflow = 1;
     };
-    Rec nx[4];
-    for (int i = 0; i < 4; ++i) { const int j = nb + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
-    for (int base = nb; base < ne; base += 256) {
-      Rec x[4]; uint32_t hh[4]; int cd[4];
-      for (int i = 0; i < 4; ++i) { x[i] = nx[i]; hh[i] = x[i].hash; }
-      if (base + 256 < ne) for (int i = 0; i < 4; ++i) { const int j = base + 256 + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }   // prefetch
-      l2_classify4(Q, T, tsteps, s, hh, cd);
-      for (int i = 0; i < 4; ++i) {
+    for (int base = nb; base < ne; base += 512) {                // eight loads in flight per wait
+      Rec x[8]; int cd[8];
+      for (int i = 0; i < 8; ++i) { const int j = base + lane + 64 * i; x[i] = pos[min(j, nmax)]; }
+      {
+        uint32_t hh[4]; int c4[4];
+        for (int i = 0; i < 4; ++i) hh[i] = x[i].hash;
+        l2_classify4(Q, T, tsteps, s, hh, c4);
+        for (int i = 0; i < 4; ++i) cd[i] = c4[i];
+        for (int i = 0; i < 4; ++i) hh[i] = x[4 + i].hash;
+        l2_classify4(Q, T, tsteps, s, hh, c4);
+        for (int i = 0; i < 4; ++i) cd[4 + i] = c4[i];
+      }
+      for (int i = 0; i < 8; ++i) {
         const int j = base + lane + 64 * i;
+        if (base + 64 * i >= ne) break;
         const int code = cd[i];
         const int g = -code - 1;
         const bool in = j < ne;
@@ -580,26 +569,53 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       const int o = (int)(j - first), bk = o >> 6, bit = o & 63;
       return (int)p[bk] + __popcll(m[bk] & ((1ull << bit) - 1ull));
     };
-    // pass A: which entries carry a query hash (binary search, 256 entries per iteration, loads prefetched)
+    // pass A: which entries carry a query hash (512 entries per iteration: eight loads in flight per wait), and on the
+    // way e_min of every block start.  The targets wpos[block start]+cnt increase with the block, and so do the streamed
+    // positions: one two-pointer walk, a ballot per resolved block, instead of a dependent-load search per block.
+    // (w0/eArr live in the space of mLo, which is only written by pass B.)
+    int* w0 = (int*)mLo;
+    uint16_t* eArr = (uint16_t*)(w0 + L2_NBLK + 1);
     auto pass_matched = [&]() {
-      int run = 0;
-      Rec nx[4];
-      for (int i = 0; i < 4; ++i) { const int j = first + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
-      for (int base = first; base < last_end; base += 256) {
-        uint32_t hh[4]; int cd[4];
-        for (int i = 0; i < 4; ++i) hh[i] = nx[i].hash;
-        if (base + 256 < last_end) for (int i = 0; i < 4; ++i) { const int j = base + 256 + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
-        l2_classify4(Q, T, tsteps, s, hh, cd);
-        for (int i = 0; i < 4; ++i) {
-          const int j = base + lane + 64 * i;
-          const int bk = (int)((base - first) >> 6) + i;
+      int run = 0, tk = 0;
+      for (int base = first; base < last_end; base += 512) {
+        Rec x[8];
+        for (int i = 0; i < 8; ++i) { const int j = base + lane + 64 * i; x[i] = pos[min(j, nmax)]; }
+        int cd[8];
+        {
+          uint32_t hh[4]; int c4[4];
+          for (int i = 0; i < 4; ++i) hh[i] = x[i].hash;
+          l2_classify4(Q, T, tsteps, s, hh, c4);
+          for (int i = 0; i < 4; ++i) cd[i] = c4[i];
+          for (int i = 0; i < 4; ++i) hh[i] = x[4 + i].hash;
+          l2_classify4(Q, T, tsteps, s, hh, c4);
+          for (int i = 0; i < 4; ++i) cd[4 + i] = c4[i];
+        }
+        const int bk0 = (int)((base - first) >> 6);
+        for (int i = 0; i < 8; ++i) {
+          const int bk = bk0 + i;
           if (bk >= nblk) break;
+          const int j = base + lane + 64 * i;
           const uint64_t ba = __ballot(j < last_end && cd[i] >= 0);
-          if (lane == 0) { mAll[bk] = ba; pAll[bk] = (uint16_t)run; }
+          if (lane == 0) { mAll[bk] = ba; pAll[bk] = (uint16_t)run; w0[bk] = pw_wpos(x[i].pw); }
           run += __popcll(ba);
+        }
+        wave_sync();
+        for (int i = 0; i < 8; ++i) {
+          const int bk = bk0 + i;
+          if (bk >= nblk) break;
+          const int j = base + lane + 64 * i;
+          const int nvalid = min(64, last_end - (base + 64 * i));
+          while (tk <= bk) {
+            const int tgt = w0[tk] + cnt;
+            const int below = __popcll(__ballot(j < last_end && pw_wpos(x[i].pw) < tgt));
+            if (below >= nvalid) break;                          // e_min(block tk) lies in a later chunk
+            if (lane == 0) eArr[tk] = (uint16_t)(base + 64 * i + below - first);
+            ++tk;
+          }
         }
       }
       if (lane == 0) { mAll[nblk] = 0; pAll[nblk] = (uint16_t)run; }
+      for (int t = tk + lane; t <= nblk; t += 64) eArr[t] = (uint16_t)(last_end - first);
       wave_sync();
     };
     // pass B: rank below r0  <=>  hash below Q[r0]; no search needed once the matched bits are known
@@ -607,27 +623,28 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       const bool every = r0 >= s;
       const uint32_t qr0 = every ? 0u : Q[r0];
       int runL = 0, runW = 0;
-      for (int bk = 0; bk < nblk; ++bk) {
-        const int j = first + bk * 64 + lane;
-        bool lo = false, aw = false;
-        if (j < last_end) {
-          const Rec x = pos[j];
-          const bool below = every || x.hash < qr0;
+      for (int bk0 = 0; bk0 < nblk; bk0 += 8) {
+        Rec x[8];
+        for (int i = 0; i < 8; ++i) { const int j = first + (bk0 + i) * 64 + lane; x[i] = pos[min(j, nmax)]; }
+        for (int i = 0; i < 8; ++i) {
+          const int bk = bk0 + i;
+          if (bk >= nblk) break;
+          const int j = first + bk * 64 + lane;
+          const bool in = j < last_end;
+          const bool below = every || x[i].hash < qr0;
           const bool matched = (mAll[bk] >> lane) & 1ull;
-          lo = matched && below;
-          aw = !matched && below && !(x.pw & PW_DP);
+          const uint64_t bl = __ballot(in && matched && below), bw = __ballot(in && !matched && below && !(x[i].pw & PW_DP));
+          if (lane == 0) { mLo[bk] = bl; pLo[bk] = (uint16_t)runL; mA[bk] = bw; pA[bk] = (uint16_t)runW; }
+          runL += __popcll(bl); runW += __popcll(bw);
         }
-        const uint64_t bl = __ballot(lo), bw = __ballot(aw);
-        if (lane == 0) { mLo[bk] = bl; pLo[bk] = (uint16_t)runL; mA[bk] = bw; pA[bk] = (uint16_t)runW; }
-        runL += __popcll(bl); runW += __popcll(bw);
       }
       if (lane == 0) { mLo[nblk] = 0; pLo[nblk] = (uint16_t)runL; mA[nblk] = 0; pA[nblk] = (uint16_t)runW; }
       wave_sync();
     };
     lap(0);
     pass_matched();
-    span0 = e_min(first) - first;
     lap(1);
+    if (dbg_stop == 2) return;
     // per block of 64 b's: largest window [bF, eHi), smallest window [bL, eLo)
     // (lane l owns blocks l and l+64; L2_NBLK == 128)
     int eLo[2], eHi[2]; int ub_all[2];
@@ -636,8 +653,8 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       eLo[q] = eHi[q] = last_end; ub_all[q] = -1;
       if (bk < nblk) {
         const int bF = first + (int)bk * 64, bL = min(bF + 63, last_end - 1);
-        eLo[q] = e_min_lane(bF);
-        eHi[q] = (bL + 1 < last_end) ? e_min_lane(bL + 1) : last_end;
+        eLo[q] = first + (int)eArr[bk];
+        eHi[q] = (bL + 1 < last_end) ? first + (int)eArr[bk + 1] : last_end;
         if (eLo[q] < last_end) ub_all[q] = pfx(mAll, pAll, eHi[q]) - pfx(mAll, pAll, bF);
       }
     }
@@ -650,15 +667,17 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       const int bk0 = wave_min(key);
       {
         const int bF = first + (int)bk0 * 64;
-        rebuild(bF, e_min(bF));
+        rebuild(bF, __builtin_amdgcn_readlane(bk0 < 64 ? eLo[0] : eLo[1], bk0 & 63));
         lap(3);
         slide(bF + 64, false);
         lap(4);
       }
+      if (dbg_stop == 3) return;
       int lb = probe_best;
       const int r0 = min(s, probe_R + max(4, s >> 6));
       pass_low(r0);
       lap(5);
+      if (dbg_stop == 4) return;
       int ub2[2];
       auto bound = [&](int q) -> int {
         const int bk = lane + 64 * q;
@@ -677,7 +696,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
         const int bF = first + (int)bk * 64;
         if (u < thr) { live = false; continue; }
         if (!(live && b == bF)) {
-          const int em = e_min(bF);
+          const int em = __builtin_amdgcn_readlane(bk < 64 ? eLo[0] : eLo[1], bk & 63);
           if (em >= last_end) break;
           lap(2);
           rebuild(bF, em);
@@ -711,19 +730,26 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   // sum over query ranks below the pivot that are present in the window of strandQ * strandR, where
   // strandR comes from the LAST occurrence of the hash in the window (insert_ref overwrites, :155-156).
   lap(4);
+  if (dbg_stop == 5) return;
   int strand = -1, accepted = 0;
   if (best >= amin) {
     accepted = 1;
     int votes = 0;
-    Rec nx[4];
-    for (int i = 0; i < 4; ++i) { const int j = opt_b + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
-    for (int base = opt_b; base < opt_e; base += 256) {
-      Rec x[4]; uint32_t hh[4]; int cd[4];
-      for (int i = 0; i < 4; ++i) { x[i] = nx[i]; hh[i] = x[i].hash; }
-      if (base + 256 < opt_e) for (int i = 0; i < 4; ++i) { const int j = base + 256 + lane + 64 * i; nx[i] = pos[min(j, nmax)]; }
-      l2_classify4(Q, T, tsteps, s, hh, cd);
-      for (int i = 0; i < 4; ++i) {
+    for (int base = opt_b; base < opt_e; base += 512) {
+      Rec x[8]; int cd[8];
+      for (int i = 0; i < 8; ++i) { const int j = base + lane + 64 * i; x[i] = pos[min(j, nmax)]; }
+      {
+        uint32_t hh[4]; int c4[4];
+        for (int i = 0; i < 4; ++i) hh[i] = x[i].hash;
+        l2_classify4(Q, T, tsteps, s, hh, c4);
+        for (int i = 0; i < 4; ++i) cd[i] = c4[i];
+        for (int i = 0; i < 4; ++i) hh[i] = x[4 + i].hash;
+        l2_classify4(Q, T, tsteps, s, hh, c4);
+        for (int i = 0; i < 4; ++i) cd[4 + i] = c4[i];
+      }
+      for (int i = 0; i < 8; ++i) {
         const int j = base + lane + 64 * i;
+        if (base + 64 * i >= opt_e) break;
         const int code = cd[i];
         const bool cnt_it = j < opt_e && code >= 0 && code < bestR;
         const int contrib = cnt_it ? (sk_strand[qo + code] ? 1 : -1) * pw_strand(x[i].pw) : 0;
@@ -751,12 +777,12 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     o.contig = contig; o.mean_pos = (beg_pos + last_pos) / 2;    // :537
     o.shared = best; o.strand = strand; o.accepted = accepted; o.pad = 0;
     o.opt_beg = first0 + opt_b; o.opt_end = first0 + opt_e;
+    // work counters travel with the result: hundreds of thousands of waves adding to the same few words would
+    // serialise in one L2 channel (measured: half of the kernel's time)
+    o.n_stream = (uint32_t)(last_end - first); o.n_evals = (uint32_t)evals; o.n_rebuilds = (uint32_t)rebuilds; o.pad2 = 0;
     out[c] = o;
-    atomicAdd(&counters[0], (unsigned long long)(last_end - first));
-    atomicAdd(&counters[1], evals);
-    atomicAdd(&counters[2], rebuilds);
     lap(6);
-    for (int i = 0; i < 8; ++i) atomicAdd(&counters[3 + i], (unsigned long long)tph[i]);
+    if (dbg_flags & 0x100) for (int i = 0; i < 8; ++i) atomicAdd(&counters[3 + i], (unsigned long long)tph[i]);   // MM_L2_PHASES only
   }
 }
 

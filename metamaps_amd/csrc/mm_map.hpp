@@ -8,6 +8,7 @@ namespace mm {
 struct L2Result {
   int32_t contig, mean_pos, shared, strand, accepted, pad;
   int64_t opt_beg, opt_end;
+  uint32_t n_stream, n_evals, n_rebuilds, pad2;                  // per-candidate work counters (summed by l2_stats_kernel)
 };
 }
 

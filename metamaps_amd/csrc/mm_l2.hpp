@@ -569,17 +569,44 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       const int o = (int)(j - first), bk = o >> 6, bit = o & 63;
       return (int)p[bk] + __popcll(m[bk] & ((1ull << bit) - 1ull));
     };
-    // pass A: which entries carry a query hash (512 entries per iteration: eight loads in flight per wait), and on the
-    // way e_min of every block start.  The targets wpos[block start]+cnt increase with the block, and so do the streamed
-    // positions: one two-pointer walk, a ballot per resolved block, instead of a dependent-load search per block.
-    // (w0/eArr live in the space of mLo, which is only written by pass B.)
-    int* w0 = (int*)mLo;
-    uint16_t* eArr = (uint16_t*)(w0 + L2_NBLK + 1);
+    // The kernel is bound by instruction issue (one wave instruction per cycle and CU), not by HBM, so the streaming
+    // passes keep per-chunk work minimal: eight 512-byte loads off one address, masks handled as scalar bit sets
+    // (ballots combined with s_and/s_andn2), per-block results parked in lane (block & 63) of a register with
+    // v_writelane and written to LDS once at the end, prefix counts by one wave scan afterwards.
+    auto load8 = [&](Rec (&x)[8], int base) {
+      if (base + 512 <= last_end) { const Rec* __restrict__ pp = pos + base + lane; for (int i = 0; i < 8; ++i) x[i] = pp[64 * i]; }
+      else for (int i = 0; i < 8; ++i) x[i] = pos[min(base + lane + 64 * i, nmax)];
+    };
+    auto valid_mask = [&](int chunk_base) -> uint64_t {           // lanes of a 64-entry chunk that lie below last_end
+      const int nv = last_end - chunk_base;
+      return nv >= 64 ? ~0ull : (nv <= 0 ? 0ull : (1ull << nv) - 1ull);
+    };
+    auto store_masks = [&](uint64_t* m, uint16_t* pf, const uint64_t (&reg)[2]) {   // lane l holds blocks l and l+64
+      const int c0 = __popcll(reg[0]), c1 = __popcll(reg[1]);
+      const int e0 = wave_excl_scan(c0, lane);
+      const int t0 = __builtin_amdgcn_readlane(e0, 63) + __builtin_amdgcn_readlane(c0, 63);
+      const int e1 = t0 + wave_excl_scan(c1, lane);
+      m[lane] = reg[0]; pf[lane] = (uint16_t)e0;
+      m[lane + 64] = reg[1]; pf[lane + 64] = (uint16_t)e1;
+      if (lane == 0) { m[L2_NBLK] = 0; pf[L2_NBLK] = (uint16_t)(__builtin_amdgcn_readlane(e1, 63) + __builtin_amdgcn_readlane(c1, 63)); }
+    };
+    auto park = [&](uint64_t (&reg)[2], int bk, uint64_t v) {      // reg[bk >> 6] of lane bk & 63 = v   (bk, v wave-uniform)
+      const bool mine = lane == (bk & 63);
+      if (bk < 64) reg[0] = mine ? v : reg[0]; else reg[1] = mine ? v : reg[1];
+    };
+    // pass A: which entries carry a query hash, and on the way e_min of every block start.  The targets
+    // wpos[block start]+cnt increase with the block, and so do the streamed positions: one two-pointer walk, a ballot per
+    // resolved block, instead of a dependent-load search per block.  Lane l keeps the results of blocks l and l+64.
+    int w0r[2] = {0, 0}, eLo[2] = {last_end, last_end};
+    uint64_t rAll[2] = {0, 0};
     auto pass_matched = [&]() {
-      int run = 0, tk = 0;
+      int tk = 0;
+      Rec nx[8];
+      load8(nx, first);
       for (int base = first; base < last_end; base += 512) {
         Rec x[8];
-        for (int i = 0; i < 8; ++i) { const int j = base + lane + 64 * i; x[i] = pos[min(j, nmax)]; }
+        for (int i = 0; i < 8; ++i) x[i] = nx[i];
+        if (base + 512 < last_end) load8(nx, base + 512);
         int cd[8];
         {
           uint32_t hh[4]; int c4[4];
@@ -594,51 +621,45 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
         for (int i = 0; i < 8; ++i) {
           const int bk = bk0 + i;
           if (bk >= nblk) break;
-          const int j = base + lane + 64 * i;
-          const uint64_t ba = __ballot(j < last_end && cd[i] >= 0);
-          if (lane == 0) { mAll[bk] = ba; pAll[bk] = (uint16_t)run; w0[bk] = pw_wpos(x[i].pw); }
-          run += __popcll(ba);
-        }
-        wave_sync();
-        for (int i = 0; i < 8; ++i) {
-          const int bk = bk0 + i;
-          if (bk >= nblk) break;
-          const int j = base + lane + 64 * i;
-          const int nvalid = min(64, last_end - (base + 64 * i));
+          const uint64_t vm = valid_mask(base + 64 * i);
+          park(rAll, bk, __ballot(cd[i] >= 0) & vm);
+          const int wfirst = pw_wpos((uint32_t)__builtin_amdgcn_readfirstlane((int)x[i].pw));
+          if (bk < 64) w0r[0] = lane == (bk & 63) ? wfirst : w0r[0]; else w0r[1] = lane == (bk & 63) ? wfirst : w0r[1];
+          const int nvalid = __popcll(vm);
           while (tk <= bk) {
-            const int tgt = w0[tk] + cnt;
-            const int below = __popcll(__ballot(j < last_end && pw_wpos(x[i].pw) < tgt));
+            const int tgt = __builtin_amdgcn_readlane(tk < 64 ? w0r[0] : w0r[1], tk & 63) + cnt;
+            const int below = __popcll(__ballot(pw_wpos(x[i].pw) < tgt) & vm);
             if (below >= nvalid) break;                          // e_min(block tk) lies in a later chunk
-            if (lane == 0) eArr[tk] = (uint16_t)(base + 64 * i + below - first);
+            if (tk < 64) eLo[0] = lane == (tk & 63) ? base + 64 * i + below : eLo[0]; else eLo[1] = lane == (tk & 63) ? base + 64 * i + below : eLo[1];
             ++tk;
           }
         }
       }
-      if (lane == 0) { mAll[nblk] = 0; pAll[nblk] = (uint16_t)run; }
-      for (int t = tk + lane; t <= nblk; t += 64) eArr[t] = (uint16_t)(last_end - first);
+      store_masks(mAll, pAll, rAll);
       wave_sync();
     };
     // pass B: rank below r0  <=>  hash below Q[r0]; no search needed once the matched bits are known
     auto pass_low = [&](int r0) {
       const bool every = r0 >= s;
-      const uint32_t qr0 = every ? 0u : Q[r0];
-      int runL = 0, runW = 0;
+      const uint32_t qr0 = every ? 0xffffffffu : Q[r0];
+      uint64_t rLo[2] = {0, 0}, rA[2] = {0, 0};
       for (int bk0 = 0; bk0 < nblk; bk0 += 8) {
         Rec x[8];
-        for (int i = 0; i < 8; ++i) { const int j = first + (bk0 + i) * 64 + lane; x[i] = pos[min(j, nmax)]; }
+        load8(x, first + bk0 * 64);
         for (int i = 0; i < 8; ++i) {
           const int bk = bk0 + i;
           if (bk >= nblk) break;
-          const int j = first + bk * 64 + lane;
-          const bool in = j < last_end;
-          const bool below = every || x[i].hash < qr0;
-          const bool matched = (mAll[bk] >> lane) & 1ull;
-          const uint64_t bl = __ballot(in && matched && below), bw = __ballot(in && !matched && below && !(x[i].pw & PW_DP));
-          if (lane == 0) { mLo[bk] = bl; pLo[bk] = (uint16_t)runL; mA[bk] = bw; pA[bk] = (uint16_t)runW; }
-          runL += __popcll(bl); runW += __popcll(bw);
+          const uint64_t vm = valid_mask(first + bk * 64);
+          const uint64_t mk = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rAll[bk >> 6] >> 32), bk & 63) << 32) |
+                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rAll[bk >> 6], bk & 63);
+          const uint64_t below = __ballot(every || x[i].hash < qr0) & vm;
+          const uint64_t first_occ = __ballot(!(x[i].pw & PW_DP));
+          park(rLo, bk, below & mk);
+          park(rA, bk, below & ~mk & first_occ);
         }
       }
-      if (lane == 0) { mLo[nblk] = 0; pLo[nblk] = (uint16_t)runL; mA[nblk] = 0; pA[nblk] = (uint16_t)runW; }
+      store_masks(mLo, pLo, rLo);
+      store_masks(mA, pA, rA);
       wave_sync();
     };
     lap(0);
@@ -647,16 +668,21 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     if (dbg_stop == 2) return;
     // per block of 64 b's: largest window [bF, eHi), smallest window [bL, eLo)
     // (lane l owns blocks l and l+64; L2_NBLK == 128)
-    int eLo[2], eHi[2]; int ub_all[2];
+    int eHi[2]; int ub_all[2];
+    {
+      const int up0 = __shfl_down(eLo[0], 1, 64), up1 = __shfl_down(eLo[1], 1, 64);   // e_min of the next block start
+      const int e64 = __builtin_amdgcn_readlane(eLo[1], 0);
+      eHi[0] = lane == 63 ? e64 : up0;
+      eHi[1] = lane == 63 ? last_end : up1;
+    }
     for (int q = 0; q < 2; ++q) {
       const int bk = lane + 64 * q;
-      eLo[q] = eHi[q] = last_end; ub_all[q] = -1;
+      ub_all[q] = -1;
       if (bk < nblk) {
         const int bF = first + (int)bk * 64, bL = min(bF + 63, last_end - 1);
-        eLo[q] = first + (int)eArr[bk];
-        eHi[q] = (bL + 1 < last_end) ? first + (int)eArr[bk + 1] : last_end;
+        if (!(bL + 1 < last_end)) eHi[q] = last_end;
         if (eLo[q] < last_end) ub_all[q] = pfx(mAll, pAll, eHi[q]) - pfx(mAll, pAll, bF);
-      }
+      } else eLo[q] = eHi[q] = last_end;
     }
     const int ubmax = wave_max(max(ub_all[0], ub_all[1]));
     lap(2);

@@ -73,35 +73,56 @@ __device__ inline int64_t wave_lower_bound_wpos(const Rec* __restrict__ pos, int
   return lo + __popcll(__ballot(less));
 }
 
-// Four independent lower_bound searches per lane with their steps interleaved: the four LDS reads of a step
-// are issued back to back, so one search step costs one LDS latency for four entries instead of one.
+// Rank of a hash in the sorted sketch Q (lower bound).  T[b] = first rank whose hash >= b << L2_TSHIFT, so the answer lies
+// in a run of fewer than 2^steps elements starting at T[b]; because all of Q is sorted, the branch-free doubling search
+// below needs no upper limit (elements behind the bucket are larger than h anyway; Q is padded with 16 x 0xffffffff).
+// Four independent searches are interleaved so that one step costs one LDS latency for four entries.
+constexpr int L2_QPAD = 16;
 __device__ inline void l2_classify4(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int steps, int s,
                                     const uint32_t (&h)[4], int (&code)[4]) {
-  // T[b] = lower_bound(Q, b << L2_TSHIFT): the top hash bits give a short search range; `steps` covers the longest one
   int lo0 = T[h[0] >> L2_TSHIFT], lo1 = T[h[1] >> L2_TSHIFT], lo2 = T[h[2] >> L2_TSHIFT], lo3 = T[h[3] >> L2_TSHIFT];
-  int hi0 = T[(h[0] >> L2_TSHIFT) + 1], hi1 = T[(h[1] >> L2_TSHIFT) + 1], hi2 = T[(h[2] >> L2_TSHIFT) + 1], hi3 = T[(h[3] >> L2_TSHIFT) + 1];
-  for (int it = 0; it < steps; ++it) {
-    const int m0 = min((lo0 + hi0) >> 1, s - 1), m1 = min((lo1 + hi1) >> 1, s - 1), m2 = min((lo2 + hi2) >> 1, s - 1), m3 = min((lo3 + hi3) >> 1, s - 1);
-    const uint32_t v0 = Q[m0], v1 = Q[m1], v2 = Q[m2], v3 = Q[m3];
-    if (lo0 < hi0) { if (v0 < h[0]) lo0 = m0 + 1; else hi0 = m0; }
-    if (lo1 < hi1) { if (v1 < h[1]) lo1 = m1 + 1; else hi1 = m1; }
-    if (lo2 < hi2) { if (v2 < h[2]) lo2 = m2 + 1; else hi2 = m2; }
-    if (lo3 < hi3) { if (v3 < h[3]) lo3 = m3 + 1; else hi3 = m3; }
+  if (steps <= 4) {
+#define MM_L2_STEP(ST)                                                                                              \
+    { const uint32_t v0 = Q[lo0 + ST - 1], v1 = Q[lo1 + ST - 1], v2 = Q[lo2 + ST - 1], v3 = Q[lo3 + ST - 1];         \
+      lo0 += v0 < h[0] ? ST : 0; lo1 += v1 < h[1] ? ST : 0; lo2 += v2 < h[2] ? ST : 0; lo3 += v3 < h[3] ? ST : 0; }
+    if (steps > 3) MM_L2_STEP(8)
+    if (steps > 2) MM_L2_STEP(4)
+    if (steps > 1) MM_L2_STEP(2)
+    if (steps > 0) MM_L2_STEP(1)
+#undef MM_L2_STEP
+  } else {
+    int hi0 = T[(h[0] >> L2_TSHIFT) + 1], hi1 = T[(h[1] >> L2_TSHIFT) + 1], hi2 = T[(h[2] >> L2_TSHIFT) + 1], hi3 = T[(h[3] >> L2_TSHIFT) + 1];
+    for (int it = 0; it < steps; ++it) {
+      const int m0 = min((lo0 + hi0) >> 1, s - 1), m1 = min((lo1 + hi1) >> 1, s - 1), m2 = min((lo2 + hi2) >> 1, s - 1), m3 = min((lo3 + hi3) >> 1, s - 1);
+      const uint32_t v0 = Q[m0], v1 = Q[m1], v2 = Q[m2], v3 = Q[m3];
+      if (lo0 < hi0) { if (v0 < h[0]) lo0 = m0 + 1; else hi0 = m0; }
+      if (lo1 < hi1) { if (v1 < h[1]) lo1 = m1 + 1; else hi1 = m1; }
+      if (lo2 < hi2) { if (v2 < h[2]) lo2 = m2 + 1; else hi2 = m2; }
+      if (lo3 < hi3) { if (v3 < h[3]) lo3 = m3 + 1; else hi3 = m3; }
+    }
   }
-  const uint32_t e0 = Q[min(lo0, s - 1)], e1 = Q[min(lo1, s - 1)], e2 = Q[min(lo2, s - 1)], e3 = Q[min(lo3, s - 1)];
+  const uint32_t e0 = Q[lo0], e1 = Q[lo1], e2 = Q[lo2], e3 = Q[lo3];   // lo <= s: the padding is readable
   code[0] = (lo0 < s && e0 == h[0]) ? lo0 : -(lo0 + 1);
   code[1] = (lo1 < s && e1 == h[1]) ? lo1 : -(lo1 + 1);
   code[2] = (lo2 < s && e2 == h[2]) ? lo2 : -(lo2 + 1);
   code[3] = (lo3 < s && e3 == h[3]) ? lo3 : -(lo3 + 1);
 }
 __device__ inline int l2_classify1(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int steps, int s, uint32_t h) {
-  int lo = T[h >> L2_TSHIFT], hi = T[(h >> L2_TSHIFT) + 1];
-  for (int it = 0; it < steps; ++it) {
-    const int m = min((lo + hi) >> 1, s - 1);
-    const uint32_t v = Q[m];
-    if (lo < hi) { if (v < h) lo = m + 1; else hi = m; }
+  int lo = T[h >> L2_TSHIFT];
+  if (steps <= 4) {
+    if (steps > 3) lo += Q[lo + 7] < h ? 8 : 0;
+    if (steps > 2) lo += Q[lo + 3] < h ? 4 : 0;
+    if (steps > 1) lo += Q[lo + 1] < h ? 2 : 0;
+    if (steps > 0) lo += Q[lo] < h ? 1 : 0;
+  } else {
+    int hi = T[(h >> L2_TSHIFT) + 1];
+    for (int it = 0; it < steps; ++it) {
+      const int m = min((lo + hi) >> 1, s - 1);
+      const uint32_t v = Q[m];
+      if (lo < hi) { if (v < h) lo = m + 1; else hi = m; }
+    }
   }
-  return (lo < s && Q[min(lo, s - 1)] == h) ? lo : -(lo + 1);
+  return (lo < s && Q[lo] == h) ? lo : -(lo + 1);
 }
 
 // LDS layout: Q[smax] (shared by the waves of a workgroup) | per wave: D[smax] | mt | skip-ahead class arrays | slide scratch
@@ -114,7 +135,8 @@ __host__ __device__ inline size_t l2_wave_bytes(int smax, bool skip) {
   if (skip) b += l2_skip_bytes() + L2_SCRATCH_BYTES;
   return (b + 15) & ~(size_t)15;
 }
-__host__ __device__ inline size_t l2_q_bytes(int smax) { return (((size_t)smax * 4 + 15) & ~(size_t)15) + (((size_t)L2_TSIZE * 2 + 4 + 15) & ~(size_t)15); }
+__host__ __device__ inline size_t l2_qpart_bytes(int smax) { return ((size_t)(smax + L2_QPAD) * 4 + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t l2_q_bytes(int smax) { return l2_qpart_bytes(smax) + (((size_t)L2_TSIZE * 2 + 4 + 15) & ~(size_t)15); }
 template <typename DT>
 inline size_t l2_lds_bytes(int smax, bool skip, int waves) { return l2_q_bytes(smax) + (size_t)waves * l2_wave_bytes<DT>(smax, skip); }
 
@@ -148,9 +170,10 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   const int s = sk_n[r];
   const uint64_t qo = mz_off[r];
   const int len = read_len[r];
-  uint16_t* T = (uint16_t*)((uint8_t*)lds + (((size_t)smax * 4 + 15) & ~(size_t)15));
+  uint16_t* T = (uint16_t*)((uint8_t*)lds + l2_qpart_bytes(smax));
   int* tmaxp = (int*)(T + ((L2_TSIZE + 1) & ~1));
   for (int i = threadIdx.x; i < s; i += 64 * WAVES) Q[i] = sk_hash[qo + i];
+  if (threadIdx.x < L2_QPAD) Q[s + threadIdx.x] = 0xffffffffu;
   if (threadIdx.x == 0) *tmaxp = 0;
   __syncthreads();
   for (int bkt = threadIdx.x; bkt < L2_TSIZE; bkt += 64 * WAVES) {  // T[b] = first rank whose hash >= b << L2_TSHIFT
@@ -248,6 +271,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     };
     for (int base = nb; base < ne; base += 512) {                // eight loads in flight per wait
       Rec x[8]; int cd[8];
+#pragma unroll
       for (int i = 0; i < 8; ++i) { const int j = base + lane + 64 * i; x[i] = pos[min(j, nmax)]; }
       {
         uint32_t hh[4]; int c4[4];
@@ -258,9 +282,10 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
         l2_classify4(Q, T, tsteps, s, hh, c4);
         for (int i = 0; i < 4; ++i) cd[4 + i] = c4[i];
       }
+#pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int j = base + lane + 64 * i;
-        if (base + 64 * i >= ne) break;
+        if (base + 64 * i >= ne) continue;
         const int code = cd[i];
         const int g = -code - 1;
         const bool in = j < ne;
@@ -321,12 +346,6 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       pm = __ballot(rz < s && ((mt[rz >> 5] >> (rz & 31)) & 1u));
     }
   };
-  auto rebuild = [&](int nb, int ne) __attribute__((always_inline)) {
-    rebuild_state(nb, ne);
-    b = nb; e = ne;
-    sw_pos = pw_wpos(pos[nb].pw);
-    loadB(nb); loadE(ne);
-  };
 
   // ---- the reference's loop body (computeMap.hpp:496-533): evaluate [b,e), then MIIteratorL2::next ------
   int best = 0, bestR = 0, beg_pos = 0, last_pos = 0;
@@ -335,59 +354,6 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   int probe_best = 0, probe_R = 0;
   // slides while e < last_end and b < b_stop; TRACK=false only records the maximum (for the bound), it does
   // not touch the reference-visible trackers
-  auto zone_apply = [&](int code, int sign) {                   // code, sign wave-uniform
-    if (code >= 0) {                                             // a matched rank enters / leaves
-      if (code < z0) sb += sign;
-      else if (code < z0 + 64) pm ^= 1ull << (code - z0);
-    } else {                                                     // a distinct window-only hash of gap g (g < s)
-      const int g = -code - 1;
-      if (g < z0) cbase += sign;
-      else if (g < z0 + 64) fz += (lane >= g - z0) ? sign : 0;
-    }
-  };
-  auto zone_slide = [&](int b_stop, bool track) __attribute__((always_inline)) {
-    while (e < last_end && b < b_stop) {
-      if (b + 1 - baseB >= 64 || b < baseB) loadB(b);
-      if (e - baseE >= 64 || e < baseE) loadE(e);
-      const uint32_t pwb = (uint32_t)__builtin_amdgcn_readlane((int)rb.pw, (int)(b - baseB));
-      const int cur_wb = pw_wpos(pwb);
-      if (track) {
-        if (S.shared > best) { best = S.shared; bestR = S.R; opt_b = b; opt_e = e; beg_pos = last_pos = cur_wb; }   // :510-518
-        else if (S.shared == best) last_pos = cur_wb;            // :520-524
-      } else if (S.shared > probe_best) { probe_best = S.shared; probe_R = S.R; }
-      ++evals;
-      const uint32_t pwe = (uint32_t)__builtin_amdgcn_readlane((int)rE.pw, (int)(e - baseE));
-      const int wb1 = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rb.pw, (int)(b + 1 - baseB)));
-      const int d_beg = wb1 - sw_pos, d_end = pw_wpos(pwe) - (sw_pos + cnt - 1);
-      const int adv = min(d_beg, d_end);                         // MIIteratorL2.hpp:83
-      sw_pos += adv;
-      if (adv == d_beg) {                                        // the first entry leaves (slidingMap.hpp:170-214)
-        const int code = __builtin_amdgcn_readlane(codeB, (int)(b - baseB));
-        if (code != -(s + 1)) {
-          bool stays = false;                                    // NOOP: a later occurrence of the hash stays inside
-          if (pwb & PW_DN) stays = wave_has_hash(pos, b + 1, e, (uint32_t)__builtin_amdgcn_readlane((int)rb.hash, (int)(b - baseB)), lane);
-          if (!stays) zone_apply(code, -1);
-        }
-        ++b;
-      }
-      if (adv == d_end) {                                        // the next entry enters (slidingMap.hpp:139-160)
-        const int code = __builtin_amdgcn_readlane(codeE, (int)(e - baseE));
-        if (code != -(s + 1)) {
-          bool dup = false;                                      // REV: the hash is already inside
-          if (pwe & PW_DP) dup = wave_has_hash(pos, b, e, (uint32_t)__builtin_amdgcn_readlane((int)rE.hash, (int)(e - baseE)), lane);
-          if (!dup) zone_apply(code, +1);
-        }
-        ++e;
-      }
-      const uint64_t ge = __ballot(fz >= s - cbase);
-      if (ge == 0ull || ((ge & 1ull) && z0 > 0)) rebuild_state(b, e);   // pivot at a zone edge: re-centre
-      else {
-        const int p = __builtin_ctzll(ge);
-        S.R = z0 + p;
-        S.shared = sb + __popcll(pm & ((1ull << p) - 1ull));
-      }
-    }
-  };
   // ---- 64 consecutive windows per round, one lane per window (SKIP path) ---------------------------------
   // The window sequence is the merge of two sorted time lists: entry b+i leaves when sw_pos reaches A_i = wpos[b+i+1],
   // entry e+i enters at B_i = wpos[e+i]-(cnt-1); equal times are one step (deletion, then addition).  Step indices by
@@ -406,9 +372,11 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     const int x = __shfl(arr, lo, 64);
     return lo + (x < v ? 1 : 0);
   };
+  bool pending_rebuild = false;
   auto block_slide = [&](int b_stop, bool track) __attribute__((always_inline)) {
     constexpr int INF = 0x7fffffff;
     while (e < last_end && b < b_stop) {
+      if (pending_rebuild) { rebuild_state(b, e); pending_rebuild = false; }   // the only instance of the rebuild code
       const Rec xb = pos[min(b + lane, nmax)];
       const Rec xe = pos[min(e + lane, nmax)];
       const int w64 = pw_wpos(pos[min(b + 64, nmax)].pw);
@@ -522,19 +490,17 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       else { dn = __builtin_amdgcn_readlane(dj, 63) + __builtin_amdgcn_readlane(hasDel, 63); an = __builtin_amdgcn_readlane(aj, 63) + __builtin_amdgcn_readlane(hasAdd, 63); }
       if (n_eval > 0) sw_pos = tst[n_eval - 1];
       b += dn; e += an;
-      if (zone_exit) rebuild_state(b, e);
+      if (zone_exit) pending_rebuild = true;
       else {
         const int fE = an > 0 ? __builtin_amdgcn_readlane(pE, an - 1) : 0, fB = dn > 0 ? __builtin_amdgcn_readlane(pB, dn - 1) : 0;
         cbase += (fE & 0xffff) - (fB & 0xffff);
         sb += (fE >> 16) - (fB >> 16);
         const uint64_t ge = __ballot(fz >= s - cbase);           // the pivot of the next round's first window must be inside too
-        if (ge == 0ull || ((ge & 1ull) && z0 > 0)) rebuild_state(b, e);
-        else { const int p = __builtin_ctzll(ge); S.R = z0 + p; S.shared = sb + __popcll(pm & ((1ull << p) - 1ull)); }
+        if (ge == 0ull || ((ge & 1ull) && z0 > 0)) pending_rebuild = true;
       }
     }
   };
   auto slide = [&](int b_stop, bool track) __attribute__((always_inline)) {
-    if (SKIP) { if (cnt >= 2) block_slide(b_stop, track); else zone_slide(b_stop, track); return; }
     while (e < last_end && b < b_stop) {
       if (b + 1 - baseB >= 64 || b < baseB) loadB(b);
       if (e - baseE >= 64 || e < baseE) loadE(e);
@@ -555,9 +521,13 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   };
 
   const int M = last_end - first;
-  bool done = false;
-  if (SKIP && M <= L2_MCAP && M > 192) {
-    // ---- class bits of every streamed entry: ballot masks + block prefixes in LDS ----------------------
+  // cnt < 2 (reads shorter than w+k): the literal serial automaton; the parallel window sequence assumes that an entry
+  // enters before it leaves
+  const bool classic = !SKIP || cnt < 2;
+  if (!classic) {
+    // phase 0: probe of the most promising block, 1: sweep over the blocks whose bound passes, 2: every window
+    int phase = (M <= L2_MCAP && M > 192) ? 0 : 2;
+    bool finished = false;
     uint64_t* mAll = (uint64_t*)(wbase + l2_wave_bytes<DT>(smax, false));
     uint64_t* mLo = mAll + (L2_NBLK + 1);
     uint64_t* mA = mLo + (L2_NBLK + 1);
@@ -574,8 +544,14 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     // (ballots combined with s_and/s_andn2), per-block results parked in lane (block & 63) of a register with
     // v_writelane and written to LDS once at the end, prefix counts by one wave scan afterwards.
     auto load8 = [&](Rec (&x)[8], int base) {
-      if (base + 512 <= last_end) { const Rec* __restrict__ pp = pos + base + lane; for (int i = 0; i < 8; ++i) x[i] = pp[64 * i]; }
-      else for (int i = 0; i < 8; ++i) x[i] = pos[min(base + lane + 64 * i, nmax)];
+      if (base + 512 <= last_end) {
+        const Rec* __restrict__ pp = pos + base + lane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = pp[64 * i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = pos[min(base + lane + 64 * i, nmax)];
+      }
     };
     auto valid_mask = [&](int chunk_base) -> uint64_t {           // lanes of a 64-entry chunk that lie below last_end
       const int nv = last_end - chunk_base;
@@ -605,6 +581,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       load8(nx, first);
       for (int base = first; base < last_end; base += 512) {
         Rec x[8];
+#pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = nx[i];
         if (base + 512 < last_end) load8(nx, base + 512);
         int cd[8];
@@ -618,9 +595,10 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
           for (int i = 0; i < 4; ++i) cd[4 + i] = c4[i];
         }
         const int bk0 = (int)((base - first) >> 6);
-        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                            // (fully unrolled: x[] and cd[] must stay in registers)
           const int bk = bk0 + i;
-          if (bk >= nblk) break;
+          if (bk >= nblk) continue;
           const uint64_t vm = valid_mask(base + 64 * i);
           park(rAll, bk, __ballot(cd[i] >= 0) & vm);
           const int wfirst = pw_wpos((uint32_t)__builtin_amdgcn_readfirstlane((int)x[i].pw));
@@ -646,9 +624,10 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       for (int bk0 = 0; bk0 < nblk; bk0 += 8) {
         Rec x[8];
         load8(x, first + bk0 * 64);
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int bk = bk0 + i;
-          if (bk >= nblk) break;
+          if (bk >= nblk) continue;
           const uint64_t vm = valid_mask(first + bk * 64);
           const uint64_t mk = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rAll[bk >> 6] >> 32), bk & 63) << 32) |
                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rAll[bk >> 6], bk & 63);
@@ -662,84 +641,87 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       store_masks(mA, pA, rA);
       wave_sync();
     };
-    lap(0);
-    pass_matched();
-    lap(1);
-    if (dbg_stop == 2) return;
-    // per block of 64 b's: largest window [bF, eHi), smallest window [bL, eLo)
-    // (lane l owns blocks l and l+64; L2_NBLK == 128)
-    int eHi[2]; int ub_all[2];
-    {
-      const int up0 = __shfl_down(eLo[0], 1, 64), up1 = __shfl_down(eLo[1], 1, 64);   // e_min of the next block start
-      const int e64 = __builtin_amdgcn_readlane(eLo[1], 0);
-      eHi[0] = lane == 63 ? e64 : up0;
-      eHi[1] = lane == 63 ? last_end : up1;
-    }
-    for (int q = 0; q < 2; ++q) {
-      const int bk = lane + 64 * q;
-      ub_all[q] = -1;
-      if (bk < nblk) {
-        const int bF = first + (int)bk * 64, bL = min(bF + 63, last_end - 1);
-        if (!(bL + 1 < last_end)) eHi[q] = last_end;
-        if (eLo[q] < last_end) ub_all[q] = pfx(mAll, pAll, eHi[q]) - pfx(mAll, pAll, bF);
-      } else eLo[q] = eHi[q] = last_end;
-    }
-    const int ubmax = wave_max(max(ub_all[0], ub_all[1]));
-    lap(2);
-    if (ubmax < amin) done = true;                               // no window can reach the acceptance threshold
-    else {
-      // most promising block first: its exact maximum is the initial bound, its pivot fixes r0
-      int key = max(ub_all[0], ub_all[1]) == ubmax ? ((ub_all[0] == ubmax) ? lane : lane + 64) : 1 << 20;
-      const int bk0 = wave_min(key);
+    int eHi[2] = {0, 0}, ub_all[2] = {-1, -1}, ub2[2] = {-1, -1};
+    int bk0 = 0, r0 = 0, lb = 0;
+    if (phase == 0) {
+      lap(0);
+      pass_matched();
+      lap(1);
+      if (dbg_stop == 2) return;
+      // per block of 64 b's: largest window [bF, eHi), smallest window [bL, eLo)
+      // (lane l owns blocks l and l+64; L2_NBLK == 128)
       {
-        const int bF = first + (int)bk0 * 64;
-        rebuild(bF, __builtin_amdgcn_readlane(bk0 < 64 ? eLo[0] : eLo[1], bk0 & 63));
-        lap(3);
-        slide(bF + 64, false);
-        lap(4);
+        const int up0 = __shfl_down(eLo[0], 1, 64), up1 = __shfl_down(eLo[1], 1, 64);   // e_min of the next block start
+        const int e64 = __builtin_amdgcn_readlane(eLo[1], 0);
+        eHi[0] = lane == 63 ? e64 : up0;
+        eHi[1] = lane == 63 ? last_end : up1;
       }
-      if (dbg_stop == 3) return;
-      int lb = probe_best;
-      const int r0 = min(s, probe_R + max(4, s >> 6));
-      pass_low(r0);
-      lap(5);
-      if (dbg_stop == 4) return;
-      int ub2[2];
-      auto bound = [&](int q) -> int {
+      for (int q = 0; q < 2; ++q) {
         const int bk = lane + 64 * q;
-        if (bk >= nblk || eLo[q] >= last_end) return -1;
-        const int bF = first + (int)bk * 64, bL = min(bF + 63, last_end - 1);
-        const int a = eLo[q] > bL ? pfx(mA, pA, eLo[q]) - pfx(mA, pA, bL) : 0;
-        if (r0 + a >= s) return pfx(mLo, pLo, eHi[q]) - pfx(mLo, pLo, bF);
-        return ub_all[q];
-      };
-      ub2[0] = bound(0); ub2[1] = bound(1);
-      // sweep the blocks in order; exact evaluation only where the bound reaches max(best so far, amin)
-      bool live = false;                                         // state positioned at the first b of the next block
-      for (int bk = 0; bk < nblk; ++bk) {
-        const int u = __builtin_amdgcn_readlane(bk < 64 ? ub2[0] : ub2[1], bk & 63);
-        const int thr = max(max(lb, best), amin);
-        const int bF = first + (int)bk * 64;
-        if (u < thr) { live = false; continue; }
-        if (!(live && b == bF)) {
-          const int em = __builtin_amdgcn_readlane(bk < 64 ? eLo[0] : eLo[1], bk & 63);
-          if (em >= last_end) break;
-          lap(2);
-          rebuild(bF, em);
-          lap(3);
-        }
-        slide(bF + 64, true);
-        lap(4);
-        live = (b == bF + 64);
-        if (e >= last_end) break;
+        ub_all[q] = -1;
+        if (bk < nblk) {
+          const int bF = first + (int)bk * 64, bL = min(bF + 63, last_end - 1);
+          if (!(bL + 1 < last_end)) eHi[q] = last_end;
+          if (eLo[q] < last_end) ub_all[q] = pfx(mAll, pAll, eHi[q]) - pfx(mAll, pAll, bF);
+        } else eLo[q] = eHi[q] = last_end;
       }
-      done = true;
+      const int ubmax = wave_max(max(ub_all[0], ub_all[1]));
+      lap(2);
+      if (ubmax < amin) finished = true;                         // no window can reach the acceptance threshold
+      else {                                                     // most promising block first: its exact maximum is the initial bound, its pivot fixes r0
+        const int key = max(ub_all[0], ub_all[1]) == ubmax ? ((ub_all[0] == ubmax) ? lane : lane + 64) : 1 << 20;
+        bk0 = wave_min(key);
+      }
     }
-  }
-  if (SKIP && !done) {                                           // every window, state of the first one built in parallel
-    rebuild(first, e_min(first));                                // :473, :489, MIIteratorL2.hpp:62
-    slide(last_end, true);
-  } else if (!done) {                                            // full slide, exactly the reference's order
+    int bk = 0;
+    bool live = false;                                           // sweep: the state stands at the first b of block bk
+    while (!finished) {
+      int b_stop = last_end, nb = first, ne = first;
+      bool track = true, need_rb = true;
+      if (phase == 0) {
+        nb = first + bk0 * 64; ne = __builtin_amdgcn_readlane(bk0 < 64 ? eLo[0] : eLo[1], bk0 & 63);
+        b_stop = nb + 64; track = false;
+      } else if (phase == 1) {
+        // the next block whose bound reaches max(best so far, amin); everything else is provably below the maximum
+        for (; bk < nblk; ++bk) {
+          const int u = __builtin_amdgcn_readlane(bk < 64 ? ub2[0] : ub2[1], bk & 63);
+          if (u >= max(max(lb, best), amin)) break;
+          live = false;
+        }
+        if (bk >= nblk) break;
+        nb = first + bk * 64; b_stop = nb + 64;
+        need_rb = !(live && b == nb);
+        if (need_rb) { ne = __builtin_amdgcn_readlane(bk < 64 ? eLo[0] : eLo[1], bk & 63); if (ne >= last_end) break; }
+      } else ne = e_min(first);                                  // :473, :489, MIIteratorL2.hpp:62
+      if (need_rb) { b = nb; e = ne; sw_pos = pw_wpos(pos[nb].pw); pending_rebuild = true; }
+      lap(2);
+      block_slide(b_stop, track);                                // the only instance of the slide code
+      lap(4);
+      if (phase == 0) {
+        if (dbg_stop == 3) return;
+        lb = probe_best;
+        r0 = min(s, probe_R + max(4, s >> 6));
+        pass_low(r0);
+        lap(5);
+        if (dbg_stop == 4) return;
+        for (int q = 0; q < 2; ++q) {
+          const int bq = lane + 64 * q;
+          int u = -1;
+          if (bq < nblk && eLo[q] < last_end) {
+            const int bF = first + (int)bq * 64, bL = min(bF + 63, last_end - 1);
+            const int a = eLo[q] > bL ? pfx(mA, pA, eLo[q]) - pfx(mA, pA, bL) : 0;
+            u = (r0 + a >= s) ? pfx(mLo, pLo, eHi[q]) - pfx(mLo, pLo, bF) : ub_all[q];
+          }
+          ub2[q] = u;
+        }
+        phase = 1; bk = 0; live = false;
+      } else if (phase == 1) {
+        live = (b == first + bk * 64 + 64);
+        ++bk;
+        if (e >= last_end) break;
+      } else break;
+    }
+  } else {                                                       // full slide, exactly the reference's order
     for (int i = lane; i < (s + DPER - 1) / DPER; i += 64) ((uint32_t*)D)[i] = 0;
     for (int i = lane; i < (s + 31) / 32; i += 64) mt[i] = 0;
     wave_sync();
@@ -763,6 +745,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     int votes = 0;
     for (int base = opt_b; base < opt_e; base += 512) {
       Rec x[8]; int cd[8];
+#pragma unroll
       for (int i = 0; i < 8; ++i) { const int j = base + lane + 64 * i; x[i] = pos[min(j, nmax)]; }
       {
         uint32_t hh[4]; int c4[4];
@@ -773,9 +756,10 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
         l2_classify4(Q, T, tsteps, s, hh, c4);
         for (int i = 0; i < 4; ++i) cd[4 + i] = c4[i];
       }
+#pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int j = base + lane + 64 * i;
-        if (base + 64 * i >= opt_e) break;
+        if (base + 64 * i >= opt_e) continue;
         const int code = cd[i];
         const bool cnt_it = j < opt_e && code >= 0 && code < bestR;
         const int contrib = cnt_it ? (sk_strand[qo + code] ? 1 : -1) * pw_strand(x[i].pw) : 0;

@@ -27,6 +27,7 @@
 #include "mm_index.hpp"
 #include "mm_map.hpp"
 #include "mm_l2_core.hpp"
+#include <type_traits>
 
 namespace mm {
 
@@ -106,6 +107,34 @@ __device__ inline void l2_classify4(const uint32_t* __restrict__ Q, const uint16
   code[1] = (lo1 < s && e1 == h[1]) ? lo1 : -(lo1 + 1);
   code[2] = (lo2 < s && e2 == h[2]) ? lo2 : -(lo2 + 1);
   code[3] = (lo3 < s && e3 == h[3]) ? lo3 : -(lo3 + 1);
+}
+// Eight at a time (the streaming passes hold eight chunks in registers): twice the LDS reads in flight per step.
+__device__ inline void l2_classify8(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int steps, int s,
+                                    const uint32_t (&h)[8], int (&code)[8]) {
+  if (steps > 4) {
+    uint32_t a[4], b[4]; int ca[4], cb[4];
+    for (int i = 0; i < 4; ++i) { a[i] = h[i]; b[i] = h[4 + i]; }
+    l2_classify4(Q, T, steps, s, a, ca); l2_classify4(Q, T, steps, s, b, cb);
+    for (int i = 0; i < 4; ++i) { code[i] = ca[i]; code[4 + i] = cb[i]; }
+    return;
+  }
+  int lo[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lo[i] = T[h[i] >> L2_TSHIFT];
+#define MM_L2_STEP8(ST)                                                                   \
+  { uint32_t v[8];                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) v[i] = Q[lo[i] + ST - 1];               \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) lo[i] += v[i] < h[i] ? ST : 0; }
+  if (steps > 3) MM_L2_STEP8(8)
+  if (steps > 2) MM_L2_STEP8(4)
+  if (steps > 1) MM_L2_STEP8(2)
+  if (steps > 0) MM_L2_STEP8(1)
+#undef MM_L2_STEP8
+  uint32_t ev[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ev[i] = Q[lo[i]];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) code[i] = (lo[i] < s && ev[i] == h[i]) ? lo[i] : -(lo[i] + 1);
 }
 __device__ inline int l2_classify1(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int steps, int s, uint32_t h) {
   int lo = T[h >> L2_TSHIFT];
@@ -191,7 +220,6 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   if (WAVES > 1 && wave >= grp_n[blockIdx.x]) return;
   const int64_t c = c0 + (WAVES > 1 ? wave : 0);
   if (dbg_stop) { if (lane == 0) { L2Result z{}; out[c] = z; } if (dbg_stop == 1) return; }
-  constexpr int DMAX = (int)(DT)~(DT)0;
   constexpr int DPER = 4 / (int)sizeof(DT);                      // counters per 32-bit word
   constexpr int DBITS = 8 * (int)sizeof(DT);
   int overflow = 0;
@@ -264,23 +292,22 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     for (int i = lane; i < (s + DPER - 1) / DPER; i += 64) Dw[i] = 0;
     for (int i = lane; i < (s + 31) / 32; i += 64) mt[i] = 0;
     wave_sync();
-    auto d_inc = [&](int g) {                                    // packed counter += 1 with overflow detection
-      const int sh = DBITS * (g % DPER);
-      const uint32_t old = atomicAdd(&Dw[g / DPER], 1u << sh);
-      if ((int)((old >> sh) & (uint32_t)DMAX) == DMAX) overflow = 1;
+    // packed counter += 1, fire and forget.  A saturated counter carries into its neighbour, which lowers the sum of
+    // all counters by DMAX per carry: comparing that sum with the number of increments detects it exactly.
+    int n_inc = 0;
+    auto d_inc = [&](int g) {
+      atomicAdd(&Dw[g / DPER], 1u << (DBITS * (g % DPER)));
+      ++n_inc;
     };
     for (int base = nb; base < ne; base += 512) {                // eight loads in flight per wait
       Rec x[8]; int cd[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) { const int j = base + lane + 64 * i; x[i] = pos[min(j, nmax)]; }
       {
-        uint32_t hh[4]; int c4[4];
-        for (int i = 0; i < 4; ++i) hh[i] = x[i].hash;
-        l2_classify4(Q, T, tsteps, s, hh, c4);
-        for (int i = 0; i < 4; ++i) cd[i] = c4[i];
-        for (int i = 0; i < 4; ++i) hh[i] = x[4 + i].hash;
-        l2_classify4(Q, T, tsteps, s, hh, c4);
-        for (int i = 0; i < 4; ++i) cd[4 + i] = c4[i];
+        uint32_t hh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hh[i] = x[i].hash;
+        l2_classify8(Q, T, tsteps, s, hh, cd);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -304,47 +331,49 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       }
     }
     wave_sync();
-    // pivot: R = min r with r + C(r) >= s
-    const int chunk = (s + 63) / 64;
-    const int r_lo = min(lane * chunk, s), r_hi = min(r_lo + chunk, s);
+    // pivot: R = min r with r + C(r) >= s.  Lane l sums the counters of its share of D word-wise; the first lane whose
+    // last rank satisfies the condition holds the pivot, and its share is resolved rank by rank with one wave scan.
+    const int NW = (s + DPER - 1) / DPER, wch = (NW + 63) / 64, rch = wch * DPER;
+    const int r_lo = min(lane * rch, s), r_hi = min(r_lo + rch, s);
     int local = 0;
-    for (int i = r_lo; i < r_hi; ++i) local += D[i];
+    for (int wi = 0; wi < wch; ++wi) {
+      const int wd = lane * wch + wi;
+      const uint32_t v = wd < NW ? Dw[wd] : 0u;
+      local += sizeof(DT) == 1 ? (int)__builtin_amdgcn_sad_u8(v, 0u, 0u) : (int)((v & 0xffffu) + (v >> 16));
+    }
     const int basec = wave_excl_scan(local, lane);
-    int run = basec, myR = s;
-    for (int i = r_lo; i < r_hi; ++i) { run += D[i]; if (i + run >= s) { myR = i; break; } }
-    const int R = wave_min(myR);
-    int cb = 0;
-    for (int i = r_lo; i < r_hi && i < R; ++i) cb += D[i];
-    cb = wave_sum(cb);
-    int sh = 0;
-    for (int wd = lane; wd * 32 < R; wd += 64) {
-      uint32_t m = mt[wd];
-      const int rem = R - wd * 32;
-      if (rem < 32) m &= (1u << rem) - 1u;
-      sh += __popc(m);
-    }
-    sh = wave_sum(sh);
-    S.R = R; S.Cb = cb; S.shared = sh;
-    if (SKIP) {
-      z0 = max(0, min(R - 32, s - 63));
-      int below = 0;
-      for (int i = r_lo; i < r_hi && i < z0; ++i) below += D[i];
-      cbase = wave_sum(below);
-      const int rz = z0 + lane;
-      const int dz = rz < s ? (int)D[rz] : 0;
-      int inc = dz;
-      for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-      fz = rz < s ? rz + inc : (1 << 29);
-      int sbl = 0;
-      for (int wd = lane; wd * 32 < z0; wd += 64) {
-        uint32_t m = mt[wd];
-        const int rem = z0 - wd * 32;
-        if (rem < 32) m &= (1u << rem) - 1u;
-        sbl += __popc(m);
+    const int total = __builtin_amdgcn_readlane(basec, 63) + __builtin_amdgcn_readlane(local, 63);
+    if (wave_sum(n_inc) != total) overflow = 1;
+    const uint64_t hm = __ballot(r_lo < s && r_hi - 1 + basec + local >= s);
+    int R = s, cb = total;
+    if (hm) {
+      const int P = __builtin_ctzll(hm), rP = P * rch;
+      int acc = __builtin_amdgcn_readlane(basec, P);
+      for (int t0 = 0; t0 < rch; t0 += 64) {
+        const int r = rP + t0 + lane;
+        const bool in = r < s && t0 + lane < rch;
+        const int d = in ? (int)D[r] : 0;
+        const int ex = wave_excl_scan(d, lane);
+        const uint64_t m = __ballot(in && r + acc + ex + d >= s);
+        if (m) { const int l = __builtin_ctzll(m); R = rP + t0 + l; cb = acc + __builtin_amdgcn_readlane(ex, l); break; }
+        acc += __builtin_amdgcn_readlane(ex, 63) + __builtin_amdgcn_readlane(d, 63);
       }
-      sb = wave_sum(sbl);
-      pm = __ballot(rz < s && ((mt[rz >> 5] >> (rz & 31)) & 1u));
     }
+    z0 = max(0, min(R - 32, s - 63));
+    const int rz = z0 + lane;
+    const int dz = rz < s ? (int)D[rz] : 0;
+    const int exz = wave_excl_scan(dz, lane);
+    fz = rz < s ? rz + exz + dz : (1 << 29);
+    cbase = cb - __builtin_amdgcn_readlane(exz, R - z0);          // D[0..z0) = D[0..R) - D[z0..R)
+    int sbl = 0;
+    for (int wd = lane; wd * 32 < z0; wd += 64) {
+      uint32_t m = mt[wd];
+      const int rem = z0 - wd * 32;
+      if (rem < 32) m &= (1u << rem) - 1u;
+      sbl += __popc(m);
+    }
+    sb = wave_sum(sbl);
+    pm = __ballot(rz < s && ((mt[rz >> 5] >> (rz & 31)) & 1u));
   };
 
   // ---- the reference's loop body (computeMap.hpp:496-533): evaluate [b,e), then MIIteratorL2::next ------
@@ -566,17 +595,12 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       m[lane + 64] = reg[1]; pf[lane + 64] = (uint16_t)e1;
       if (lane == 0) { m[L2_NBLK] = 0; pf[L2_NBLK] = (uint16_t)(__builtin_amdgcn_readlane(e1, 63) + __builtin_amdgcn_readlane(c1, 63)); }
     };
-    auto park = [&](uint64_t (&reg)[2], int bk, uint64_t v) {      // reg[bk >> 6] of lane bk & 63 = v   (bk, v wave-uniform)
-      const bool mine = lane == (bk & 63);
-      if (bk < 64) reg[0] = mine ? v : reg[0]; else reg[1] = mine ? v : reg[1];
-    };
-    // pass A: which entries carry a query hash, and on the way e_min of every block start.  The targets
-    // wpos[block start]+cnt increase with the block, and so do the streamed positions: one two-pointer walk, a ballot per
-    // resolved block, instead of a dependent-load search per block.  Lane l keeps the results of blocks l and l+64.
-    int w0r[2] = {0, 0}, eLo[2] = {last_end, last_end};
+    // pass A: which entries carry a query hash; lane l keeps the masks of blocks l and l+64 and the position of their
+    // first entry.  e_min of every block start (first entry with wpos >= wpos[block start] + cnt) afterwards, all blocks at
+    // once: the chunk by ranking the target among the chunk starts, the entry by a binary search inside that chunk.
+    int w0r[2] = {0x7fffffff, 0x7fffffff}, eLo[2] = {last_end, last_end};
     uint64_t rAll[2] = {0, 0};
     auto pass_matched = [&]() {
-      int tk = 0;
       Rec nx[8];
       load8(nx, first);
       for (int base = first; base < last_end; base += 512) {
@@ -586,34 +610,49 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
         if (base + 512 < last_end) load8(nx, base + 512);
         int cd[8];
         {
-          uint32_t hh[4]; int c4[4];
-          for (int i = 0; i < 4; ++i) hh[i] = x[i].hash;
-          l2_classify4(Q, T, tsteps, s, hh, c4);
-          for (int i = 0; i < 4; ++i) cd[i] = c4[i];
-          for (int i = 0; i < 4; ++i) hh[i] = x[4 + i].hash;
-          l2_classify4(Q, T, tsteps, s, hh, c4);
-          for (int i = 0; i < 4; ++i) cd[4 + i] = c4[i];
+          uint32_t hh[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) hh[i] = x[i].hash;
+          l2_classify8(Q, T, tsteps, s, hh, cd);
         }
         const int bk0 = (int)((base - first) >> 6);
+        // per-chunk bookkeeping specialised on (register half, group entirely below last_end): a handful of instructions
+        auto group = [&](auto qtag, auto fulltag) {
+          constexpr int QH = decltype(qtag)::value;
+          constexpr bool FULL = decltype(fulltag)::value;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {                            // (fully unrolled: x[] and cd[] must stay in registers)
-          const int bk = bk0 + i;
-          if (bk >= nblk) continue;
-          const uint64_t vm = valid_mask(base + 64 * i);
-          park(rAll, bk, __ballot(cd[i] >= 0) & vm);
-          const int wfirst = pw_wpos((uint32_t)__builtin_amdgcn_readfirstlane((int)x[i].pw));
-          if (bk < 64) w0r[0] = lane == (bk & 63) ? wfirst : w0r[0]; else w0r[1] = lane == (bk & 63) ? wfirst : w0r[1];
-          const int nvalid = __popcll(vm);
-          while (tk <= bk) {
-            const int tgt = __builtin_amdgcn_readlane(tk < 64 ? w0r[0] : w0r[1], tk & 63) + cnt;
-            const int below = __popcll(__ballot(pw_wpos(x[i].pw) < tgt) & vm);
-            if (below >= nvalid) break;                          // e_min(block tk) lies in a later chunk
-            if (tk < 64) eLo[0] = lane == (tk & 63) ? base + 64 * i + below : eLo[0]; else eLo[1] = lane == (tk & 63) ? base + 64 * i + below : eLo[1];
-            ++tk;
+          for (int i = 0; i < 8; ++i) {                          // (fully unrolled: x[] and cd[] must stay in registers)
+            const int bk = bk0 + i;
+            if (!FULL && bk >= nblk) continue;
+            uint64_t m = __ballot(cd[i] >= 0);
+            if (!FULL) m &= valid_mask(base + 64 * i);
+            const bool mine = lane == (bk & 63);
+            rAll[QH] = mine ? m : rAll[QH];
+            const int wfirst = pw_wpos((uint32_t)__builtin_amdgcn_readfirstlane((int)x[i].pw));
+            w0r[QH] = mine ? wfirst : w0r[QH];
           }
-        }
+        };
+        const bool full = base + 512 <= last_end;
+        if (bk0 < 64) { if (full) group(std::integral_constant<int, 0>{}, std::true_type{}); else group(std::integral_constant<int, 0>{}, std::false_type{}); }
+        else { if (full) group(std::integral_constant<int, 1>{}, std::true_type{}); else group(std::integral_constant<int, 1>{}, std::false_type{}); }
       }
       store_masks(mAll, pAll, rAll);
+      {
+        const int tg0 = w0r[0] + cnt, tg1 = w0r[1] + cnt;        // (cnt >= 2 on this path; unused lanes hold INT_MAX and are masked below)
+        const bool v0 = lane < nblk, v1 = lane + 64 < nblk;
+        const int c0 = rank_search(w0r[0], tg0) + rank_search(w0r[1], tg0) - 1;
+        const int c1 = rank_search(w0r[0], tg1) + rank_search(w0r[1], tg1) - 1;
+        int lo0 = first + 64 * max(c0, 0), lo1 = first + 64 * max(c1, 0);
+        int hi0 = min(lo0 + 64, last_end), hi1 = min(lo1 + 64, last_end);
+        for (int it = 0; it < 7; ++it) {                         // two independent searches per lane, steps interleaved
+          const int m0 = min((lo0 + hi0) >> 1, nmax), m1 = min((lo1 + hi1) >> 1, nmax);
+          const int p0 = pw_wpos(pos[m0].pw), p1 = pw_wpos(pos[m1].pw);
+          if (lo0 < hi0) { if (p0 < tg0) lo0 = m0 + 1; else hi0 = m0; }
+          if (lo1 < hi1) { if (p1 < tg1) lo1 = m1 + 1; else hi1 = m1; }
+        }
+        eLo[0] = v0 ? lo0 : last_end;
+        eLo[1] = v1 ? lo1 : last_end;
+      }
       wave_sync();
     };
     // pass B: rank below r0  <=>  hash below Q[r0]; no search needed once the matched bits are known
@@ -624,18 +663,27 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       for (int bk0 = 0; bk0 < nblk; bk0 += 8) {
         Rec x[8];
         load8(x, first + bk0 * 64);
+        auto group = [&](auto qtag, auto fulltag) {
+          constexpr int QH = decltype(qtag)::value;
+          constexpr bool FULL = decltype(fulltag)::value;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int bk = bk0 + i;
-          if (bk >= nblk) continue;
-          const uint64_t vm = valid_mask(first + bk * 64);
-          const uint64_t mk = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rAll[bk >> 6] >> 32), bk & 63) << 32) |
-                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rAll[bk >> 6], bk & 63);
-          const uint64_t below = __ballot(every || x[i].hash < qr0) & vm;
-          const uint64_t first_occ = __ballot(!(x[i].pw & PW_DP));
-          park(rLo, bk, below & mk);
-          park(rA, bk, below & ~mk & first_occ);
-        }
+          for (int i = 0; i < 8; ++i) {
+            const int bk = bk0 + i;
+            if (!FULL && bk >= nblk) continue;
+            const int l = bk & 63;
+            const uint64_t mk = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rAll[QH] >> 32), l) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rAll[QH], l);
+            uint64_t below = __ballot(every || x[i].hash < qr0);
+            if (!FULL) below &= valid_mask(first + bk * 64);
+            const uint64_t first_occ = __ballot(!(x[i].pw & PW_DP));
+            const bool mine = lane == l;
+            rLo[QH] = mine ? (below & mk) : rLo[QH];
+            rA[QH] = mine ? (below & ~mk & first_occ) : rA[QH];
+          }
+        };
+        const bool full = first + bk0 * 64 + 512 <= last_end;
+        if (bk0 < 64) { if (full) group(std::integral_constant<int, 0>{}, std::true_type{}); else group(std::integral_constant<int, 0>{}, std::false_type{}); }
+        else { if (full) group(std::integral_constant<int, 1>{}, std::true_type{}); else group(std::integral_constant<int, 1>{}, std::false_type{}); }
       }
       store_masks(mLo, pLo, rLo);
       store_masks(mA, pA, rA);
@@ -748,13 +796,10 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
 #pragma unroll
       for (int i = 0; i < 8; ++i) { const int j = base + lane + 64 * i; x[i] = pos[min(j, nmax)]; }
       {
-        uint32_t hh[4]; int c4[4];
-        for (int i = 0; i < 4; ++i) hh[i] = x[i].hash;
-        l2_classify4(Q, T, tsteps, s, hh, c4);
-        for (int i = 0; i < 4; ++i) cd[i] = c4[i];
-        for (int i = 0; i < 4; ++i) hh[i] = x[4 + i].hash;
-        l2_classify4(Q, T, tsteps, s, hh, c4);
-        for (int i = 0; i < 4; ++i) cd[4 + i] = c4[i];
+        uint32_t hh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hh[i] = x[i].hash;
+        l2_classify8(Q, T, tsteps, s, hh, cd);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {

@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   };
 
   // ---- state of window [nb,ne) from scratch, all lanes (the arrays are order independent) ---------------
-  unsigned long long rebuilds = 0;
+  unsigned long long rebuilds = 0, rounds = 0;
   // Pivot zone (SKIP path).  The serial slide keeps no LDS state at all: lane l owns rank r = z0 + l and holds
   //   fz = r + D[z0] + ... + D[r]                  (VGPR; huge for r >= s so that lane r == s acts as the "R = s" sentinel)
   // next to the wave-uniform scalars cbase = D[0] + ... + D[z0-1], sb = matched ranks below z0 present in the window and
@@ -378,9 +378,8 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
 
   // ---- the reference's loop body (computeMap.hpp:496-533): evaluate [b,e), then MIIteratorL2::next ------
   int best = 0, bestR = 0, beg_pos = 0, last_pos = 0;
-  int opt_b = 0, opt_e = 0;
+  int opt_b = 0, opt_e = 0, last_b = 0;
   unsigned long long evals = 0;
-  int probe_best = 0, probe_R = 0;
   // slides while e < last_end and b < b_stop; TRACK=false only records the maximum (for the bound), it does
   // not touch the reference-visible trackers
   // ---- 64 consecutive windows per round, one lane per window (SKIP path) ---------------------------------
@@ -402,10 +401,17 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     return lo + (x < v ? 1 : 0);
   };
   bool pending_rebuild = false;
-  auto block_slide = [&](int b_stop, bool track) __attribute__((always_inline)) {
+  // sweep state (phase 1): the slide runs on across block boundaries as long as the next block's bound still passes
+  int ub2[2] = {-1, -1};
+  int bk = 0, j0 = 0, stage = 0, blk_end = 0x7fffffff, nblk_s = 0;
+  bool run_stop = false;
+  auto lane2 = [&](const int (&v)[2], int k) -> int { return __builtin_amdgcn_readlane(k < 64 ? v[0] : v[1], k & 63); };
+  auto block_slide = [&](int b_stop) __attribute__((always_inline)) {
     constexpr int INF = 0x7fffffff;
     while (e < last_end && b < b_stop) {
-      if (pending_rebuild) { rebuild_state(b, e); pending_rebuild = false; }   // the only instance of the rebuild code
+      if (pending_rebuild) { rebuild_state(b, e); pending_rebuild = false; if (dbg_stop == 8) break; }   // the only instance of the rebuild code
+      if (dbg_stop == 9 && rounds >= 1) break;
+      ++rounds;
       const Rec xb = pos[min(b + lane, nmax)];
       const Rec xe = pos[min(e + lane, nmax)];
       const int w64 = pw_wpos(pos[min(b + 64, nmax)].pw);
@@ -502,15 +508,23 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
         const int m = wave_max(sh_j);
         const uint64_t at = __ballot(sh_j == m);
         const int j1 = __builtin_ctzll(at), jl = 63 - __builtin_clzll(at);
-        if (track) {
-          if (m > best) {                                        // :510-518 — the first window reaching the new maximum
-            best = m; bestR = z0 + __builtin_amdgcn_readlane(pj, j1);
-            const int d1 = __builtin_amdgcn_readlane(dj, j1);
-            opt_b = b + d1; opt_e = e + __builtin_amdgcn_readlane(aj, j1);
-            beg_pos = __builtin_amdgcn_readlane(wpb, d1);
-            last_pos = __builtin_amdgcn_readlane(wpb, __builtin_amdgcn_readlane(dj, jl));
-          } else if (m == best) last_pos = __builtin_amdgcn_readlane(wpb, __builtin_amdgcn_readlane(dj, jl));   // :520-524
-        } else if (m > probe_best) { probe_best = m; probe_R = z0 + __builtin_amdgcn_readlane(pj, j1); }
+        // trackers by position, not by evaluation order (the sweep visits the most promising run first):
+        // the first window reaching the maximum (:510-518) and the last one equal to it (:520-524)
+        auto set_first = [&]() {
+          bestR = z0 + __builtin_amdgcn_readlane(pj, j1);
+          const int d1 = __builtin_amdgcn_readlane(dj, j1);
+          opt_b = b + d1; opt_e = e + __builtin_amdgcn_readlane(aj, j1);
+          beg_pos = __builtin_amdgcn_readlane(wpb, d1);
+        };
+        auto set_last = [&]() {
+          const int dl = __builtin_amdgcn_readlane(dj, jl);
+          last_b = b + dl; last_pos = __builtin_amdgcn_readlane(wpb, dl);
+        };
+        if (m > best) { best = m; set_first(); set_last(); }
+        else if (m == best && best > 0) {
+          if (b + __builtin_amdgcn_readlane(dj, j1) < opt_b) set_first();
+          if (b + __builtin_amdgcn_readlane(dj, jl) > last_b) set_last();
+        }
         evals += (unsigned long long)n_eval;
       }
       // state of window n_eval
@@ -519,6 +533,12 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       else { dn = __builtin_amdgcn_readlane(dj, 63) + __builtin_amdgcn_readlane(hasDel, 63); an = __builtin_amdgcn_readlane(aj, 63) + __builtin_amdgcn_readlane(hasAdd, 63); }
       if (n_eval > 0) sw_pos = tst[n_eval - 1];
       b += dn; e += an;
+      while (b >= blk_end) {                                     // entered the next block: does its bound still pass?
+        ++bk;
+        if (bk >= nblk_s || (stage == 1 && bk == j0) || lane2(ub2, bk) < max(best, amin)) { run_stop = true; break; }
+        blk_end += 64;
+      }
+      if (run_stop) break;
       if (zone_exit) pending_rebuild = true;
       else {
         const int fE = an > 0 ? __builtin_amdgcn_readlane(pE, an - 1) : 0, fB = dn > 0 ? __builtin_amdgcn_readlane(pB, dn - 1) : 0;
@@ -529,15 +549,13 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       }
     }
   };
-  auto slide = [&](int b_stop, bool track) __attribute__((always_inline)) {
+  auto slide = [&](int b_stop) __attribute__((always_inline)) {
     while (e < last_end && b < b_stop) {
       if (b + 1 - baseB >= 64 || b < baseB) loadB(b);
       if (e - baseE >= 64 || e < baseE) loadE(e);
       const int cur_wb = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rb.pw, (int)(b - baseB)));
-      if (track) {
-        if (S.shared > best) { best = S.shared; bestR = S.R; opt_b = b; opt_e = e; beg_pos = last_pos = cur_wb; }   // :510-518
-        else if (S.shared == best) last_pos = cur_wb;            // :520-524
-      } else if (S.shared > probe_best) { probe_best = S.shared; probe_R = S.R; }
+      if (S.shared > best) { best = S.shared; bestR = S.R; opt_b = b; opt_e = e; beg_pos = last_pos = cur_wb; }   // :510-518
+      else if (S.shared == best) last_pos = cur_wb;              // :520-524
       ++evals;
       const int wb1 = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rb.pw, (int)(b + 1 - baseB)));
       const int we = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rE.pw, (int)(e - baseE)));
@@ -554,7 +572,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   // enters before it leaves
   const bool classic = !SKIP || cnt < 2;
   if (!classic) {
-    // phase 0: probe of the most promising block, 1: sweep over the blocks whose bound passes, 2: every window
+    // phase 0: bounds first (becomes 1: sweep over the blocks whose bound passes), 2: every window
     int phase = (M <= L2_MCAP && M > 192) ? 0 : 2;
     bool finished = false;
     uint64_t* mAll = (uint64_t*)(wbase + l2_wave_bytes<DT>(smax, false));
@@ -689,8 +707,9 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       store_masks(mA, pA, rA);
       wave_sync();
     };
-    int eHi[2] = {0, 0}, ub_all[2] = {-1, -1}, ub2[2] = {-1, -1};
-    int bk0 = 0, r0 = 0, lb = 0;
+    int eHi[2] = {0, 0}, ub_all[2] = {-1, -1};
+    int bkmax = 0;
+    nblk_s = nblk;
     if (phase == 0) {
       lap(0);
       pass_matched();
@@ -716,39 +735,18 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       const int ubmax = wave_max(max(ub_all[0], ub_all[1]));
       lap(2);
       if (ubmax < amin) finished = true;                         // no window can reach the acceptance threshold
-      else {                                                     // most promising block first: its exact maximum is the initial bound, its pivot fixes r0
+      else {
+        // r0 without a probe: the pivot rank of a window is the number of query hashes among the s smallest of
+        // query + window-only hashes.  For the most promising block (fewest window-only hashes, so the largest
+        // pivot) that is hypergeometric with mean s*s/(s+wo); r0 = mean + 2.5 sigma (tuned on the bench workload).  A wrong guess costs only
+        // tightness: validity (r0 + a >= s) is checked per block below.
         const int key = max(ub_all[0], ub_all[1]) == ubmax ? ((ub_all[0] == ubmax) ? lane : lane + 64) : 1 << 20;
-        bk0 = wave_min(key);
-      }
-    }
-    int bk = 0;
-    bool live = false;                                           // sweep: the state stands at the first b of block bk
-    while (!finished) {
-      int b_stop = last_end, nb = first, ne = first;
-      bool track = true, need_rb = true;
-      if (phase == 0) {
-        nb = first + bk0 * 64; ne = __builtin_amdgcn_readlane(bk0 < 64 ? eLo[0] : eLo[1], bk0 & 63);
-        b_stop = nb + 64; track = false;
-      } else if (phase == 1) {
-        // the next block whose bound reaches max(best so far, amin); everything else is provably below the maximum
-        for (; bk < nblk; ++bk) {
-          const int u = __builtin_amdgcn_readlane(bk < 64 ? ub2[0] : ub2[1], bk & 63);
-          if (u >= max(max(lb, best), amin)) break;
-          live = false;
-        }
-        if (bk >= nblk) break;
-        nb = first + bk * 64; b_stop = nb + 64;
-        need_rb = !(live && b == nb);
-        if (need_rb) { ne = __builtin_amdgcn_readlane(bk < 64 ? eLo[0] : eLo[1], bk & 63); if (ne >= last_end) break; }
-      } else ne = e_min(first);                                  // :473, :489, MIIteratorL2.hpp:62
-      if (need_rb) { b = nb; e = ne; sw_pos = pw_wpos(pos[nb].pw); pending_rebuild = true; }
-      lap(2);
-      block_slide(b_stop, track);                                // the only instance of the slide code
-      lap(4);
-      if (phase == 0) {
-        if (dbg_stop == 3) return;
-        lb = probe_best;
-        r0 = min(s, probe_R + max(4, s >> 6));
+        const int bkb = wave_min(key);
+        const int bLb = min(first + bkb * 64 + 63, last_end - 1);
+        const int wo = max(lane2(eLo, bkb) - bLb - ubmax, 0);
+        const float pq = (float)s / (float)(s + wo);
+        const float sigma = sqrtf((float)s * pq * (1.0f - pq) * (1.0f - pq));
+        const int r0 = min(s, (int)((float)s * pq) + max(8, (int)(2.5f * sigma) + 4));
         pass_low(r0);
         lap(5);
         if (dbg_stop == 4) return;
@@ -762,12 +760,51 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
           }
           ub2[q] = u;
         }
-        phase = 1; bk = 0; live = false;
-      } else if (phase == 1) {
-        live = (b == first + bk * 64 + 64);
-        ++bk;
-        if (e >= last_end) break;
-      } else break;
+        // the sweep starts a little before the block with the largest bound, so that the maximum is known early and
+        // the rest (left flank afterwards, right flank on the way) is pruned against it
+        const int u2max = wave_max(max(ub2[0], ub2[1]));
+        const int key2 = max(ub2[0], ub2[1]) == u2max ? ((ub2[0] == u2max) ? lane : lane + 64) : 1 << 20;
+        bkmax = wave_min(key2);
+        j0 = bkmax;
+        while (j0 > 0 && bkmax - j0 < 3 && 100 * lane2(ub2, j0 - 1) >= 95 * u2max) --j0;
+        phase = 1;
+      }
+    }
+    int done_hi = nblk;
+    bk = j0;
+    bool live = false;                                           // sweep: the state stands at the first b of block bk
+    while (!finished) {
+      int nb = first, ne = first;
+      bool need_rb = true;
+      if (phase == 1) {
+        // the next block whose bound reaches max(best so far, amin); everything else is provably below the maximum.
+        // stage 0: from j0 to the first failing block behind bkmax; stage 1: all other blocks in index order.
+        bool found = false;
+        for (;;) {
+          if (stage == 1 && bk == j0) { bk = done_hi; live = false; }
+          if (bk >= nblk) { if (stage == 0) { done_hi = nblk; stage = 1; bk = 0; live = false; continue; } break; }
+          if (lane2(ub2, bk) >= max(best, amin)) { found = true; break; }
+          live = false;
+          if (stage == 0 && bk >= bkmax) { done_hi = bk + 1; stage = 1; bk = 0; continue; }
+          ++bk;
+        }
+        if (!found) break;
+        nb = first + bk * 64; blk_end = nb + 64; run_stop = false;
+        need_rb = !(live && b == nb);
+        if (need_rb) ne = lane2(eLo, bk);
+      } else ne = e_min(first);                                  // :473, :489, MIIteratorL2.hpp:62
+      if (need_rb) { b = nb; e = ne; sw_pos = pw_wpos(pos[nb].pw); pending_rebuild = true; }
+      lap(2);
+      block_slide(last_end);                                     // the only instance of the slide code
+      lap(4);
+      if (dbg_stop == 8 || dbg_stop == 9) return;
+      if (phase != 1) break;
+      // the slide stopped inside block bk, whose bound failed (or at the right end of the candidate)
+      live = false;
+      if (e >= last_end || bk >= nblk) {
+        if (stage == 1) break;
+        done_hi = nblk; stage = 1; bk = 0;
+      }
     }
   } else {                                                       // full slide, exactly the reference's order
     for (int i = lane; i < (s + DPER - 1) / DPER; i += 64) ((uint32_t*)D)[i] = 0;
@@ -779,7 +816,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     loadB(first); loadE(first);
     for (; e < first_end; ++e) add_entry(e);                     // first super-window, :489
     sw_pos = pw_wpos(pos[first].pw);                             // MIIteratorL2.hpp:62
-    slide(last_end, true);
+    slide(last_end);
   }
 
   // K6 strand vote over the first optimal window (computeMap.hpp:424-433, slidingMap.hpp:232-254):
@@ -834,7 +871,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     o.opt_beg = first0 + opt_b; o.opt_end = first0 + opt_e;
     // work counters travel with the result: hundreds of thousands of waves adding to the same few words would
     // serialise in one L2 channel (measured: half of the kernel's time)
-    o.n_stream = (uint32_t)(last_end - first); o.n_evals = (uint32_t)evals; o.n_rebuilds = (uint32_t)rebuilds; o.pad2 = 0;
+    o.n_stream = (uint32_t)(last_end - first); o.n_evals = (uint32_t)evals; o.n_rebuilds = (uint32_t)rebuilds; o.pad2 = (uint32_t)rounds;
     out[c] = o;
     lap(6);
     if (dbg_flags & 0x100) for (int i = 0; i < 8; ++i) atomicAdd(&counters[3 + i], (unsigned long long)tph[i]);   // MM_L2_PHASES only

@@ -282,14 +282,15 @@ __global__ void l1_scan_kernel(const uint64_t* __restrict__ hits, const uint64_t
 // ---------------------------------------------------------------------------------------------------
 // sums of the per-candidate work counters: one atomic per counter per block
 __global__ void __launch_bounds__(256) l2_stats_kernel(const L2Result* __restrict__ l2, int64_t n, unsigned long long* __restrict__ counters) {
-  __shared__ unsigned long long acc[3];
-  if (threadIdx.x < 3) acc[threadIdx.x] = 0;
+  __shared__ unsigned long long acc[4];
+  if (threadIdx.x < 4) acc[threadIdx.x] = 0;
   __syncthreads();
-  unsigned long long a = 0, b = 0, c = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { a += l2[i].n_stream; b += l2[i].n_evals; c += l2[i].n_rebuilds; }
-  atomicAdd(&acc[0], a); atomicAdd(&acc[1], b); atomicAdd(&acc[2], c);
+  unsigned long long a = 0, b = 0, c = 0, d = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { a += l2[i].n_stream; b += l2[i].n_evals; c += l2[i].n_rebuilds; d += l2[i].pad2; }
+  atomicAdd(&acc[0], a); atomicAdd(&acc[1], b); atomicAdd(&acc[2], c); atomicAdd(&acc[3], d);
   __syncthreads();
   if (threadIdx.x < 3) atomicAdd(&counters[threadIdx.x], acc[threadIdx.x]);
+  if (threadIdx.x == 3) atomicAdd(&counters[15], acc[3]);   // slide rounds (diagnostic)
 }
 
 __global__ void accept_flags_kernel(const L2Result* __restrict__ l2, int64_t n, uint32_t* __restrict__ flag) {
@@ -593,7 +594,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     const size_t lds_c4 = l2_lds_bytes<uint8_t>(smax, true, 4);
     MM_REQUIRE(lds_wide <= 160 * 1024, MM_ERR_LIMIT, "sketch too large for the L2 window state in LDS (read longer than ~115 kb at w=8)");
     auto set_lds = [&](const void* fn, size_t bytes) { if (bytes > 64 * 1024) MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); };
-    DBuf<unsigned long long> counters(12); counters.zero(st);
+    DBuf<unsigned long long> counters(16); counters.zero(st);
     if (getenv("MM_L2_STOP") || getenv("MM_L2_PHASES")) {
       const char* ds = getenv("MM_L2_STOP"); unsigned long long v = (unsigned long long)((ds ? atoi(ds) & 0xff : 0) | (getenv("MM_L2_PHASES") ? 0x100 : 0)); MM_HIP(hipMemcpyAsync(counters.p + 11, &v, sizeof v, hipMemcpyHostToDevice, st)); MM_HIP(hipStreamSynchronize(st)); }   // timing aid: leave the kernel after phase n (results are then meaningless)
     DBuf<int32_t> ovf((size_t)ncand);
@@ -641,7 +642,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     M->stats.sum_l2_stream_entries = (int64_t)hc[0];
     M->stats.sum_l2_evals = (int64_t)hc[1];
     M->stats.n_l2_rebuilds = (int64_t)hc[2];
-    if (getenv("MM_L2_PHASES")) { fprintf(stderr, "l2 phase clocks [setup passA bounds rebuild slide passB vote]:"); for (int i = 0; i < 7; ++i) fprintf(stderr, " %.3g", (double)hc[3 + i]); fprintf(stderr, "\n"); }
+    if (getenv("MM_L2_PHASES")) { fprintf(stderr, "l2 rounds %llu; ", hc[15]); fprintf(stderr, "l2 phase clocks [setup passA bounds rebuild slide passB vote]:"); for (int i = 0; i < 7; ++i) fprintf(stderr, " %.3g", (double)hc[3 + i]); fprintf(stderr, "\n"); }
     // ---- compaction
     const size_t t_cp = T.begin(&M->stats.ms_compact);
     DBuf<uint32_t> flag((size_t)ncand);

@@ -158,7 +158,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   // sort (hash -> contig<<32|pw) by hash, stable
   DBuf<uint32_t> key_in, key_out((size_t)N);
   DBuf<uint64_t> val_in;
-  I->occ.alloc((size_t)N);
+  I->occ.alloc((size_t)N + 2);                                  // +2: the seed-hit filter reads lists in aligned 16-byte pieces
   auto library_sort = [&](uint32_t* kin, uint64_t* vin, uint32_t* kout, uint64_t* vout, size_t cnt) {
     size_t tmp_bytes = 0;
     MM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, cnt, 0, 32, st));

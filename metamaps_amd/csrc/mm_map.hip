@@ -135,25 +135,28 @@ __global__ void __launch_bounds__(256) gather_hits_kernel(IndexView I, const uin
 // K3c  exact seed-hit pre-filter.  At miniSeq+H density the 32-bit hash space is saturated:
 // a read draws ~10^4 chance hits scattered over the whole reference, and only hits that sit in a run of
 // `minimumHits` hits of one contig spanning less than the read length can ever produce or shape an L1
-// candidate (computeMap.hpp:357-385).  Such a run lies inside two adjacent position bins of width = read
+// candidate (computeMap.hpp:357-385).  Such a run lies inside two adjacent position bins of width >= read
 // length, so a hit can be dropped when both bin pairs around it hold fewer than minimumHits hits.  Bin
 // counts live in a hashed LDS counter table (collisions only over-count, so nothing needed is lost).
 // Dropping hits that belong to no qualifying run leaves every qualifying run intact and cannot create a
 // new one (a run that qualifies after dropping also qualifies before, so none of its members was dropped).
 // ---------------------------------------------------------------------------------------------------
 constexpr int HF_SLOTS = 8192;
-__device__ inline uint32_t hf_slot(uint32_t contig, uint32_t bin) {
-  uint32_t x = contig * 0x9E3779B1u ^ (bin + 0x7F4A7C15u) * 0x85EBCA77u;
-  x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
-  return x & (HF_SLOTS - 1);
-}
+constexpr int HF_BITS = 13;
+// bin(wpos) = floor(wpos * floor(2^32 / len) / 2^32): a monotone step function whose steps are at least `len` apart, so
+// two hits less than `len` apart still fall into the same or adjacent bins (all the proof needs) — one v_mul_hi instead of
+// an integer division.  The counter slot is the top bits of contig*K1 + bin*K2: the slots of bin-1 / bin+1 are one
+// addition away.
+constexpr uint32_t HF_K1 = 0x9E3779B1u, HF_K2 = 0x85EBCA77u;
+__device__ inline uint32_t hf_base(uint32_t contig, uint32_t bin) { return contig * HF_K1 + bin * HF_K2; }
+__device__ inline uint32_t hf_slot_of(uint32_t base) { return base >> (32 - HF_BITS); }
 constexpr int HF_STAGE = 2048;     // survivors staged per read (8 B each); reads with more are re-filtered by the write kernel
 template <bool WRITE>
 __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint64_t* __restrict__ off, const int32_t* __restrict__ sk_n,
                                                          const uint32_t* __restrict__ probe_cnt, const uint64_t* __restrict__ probe_start,
                                                          const int32_t* __restrict__ read_len, const int32_t* __restrict__ min_hits,
                                                          uint32_t* __restrict__ surv_n, const uint64_t* __restrict__ read_hit_off,
-                                                         uint64_t* __restrict__ hits, uint64_t* __restrict__ stage) {
+                                                         uint64_t* __restrict__ hits, uint64_t* __restrict__ stage, int dbg) {
   __shared__ uint32_t cnt[HF_SLOTS];
   __shared__ uint32_t cursor;
   const int r = blockIdx.x;
@@ -168,50 +171,80 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   const uint64_t o = off[r];
   const int s = sk_n[r];
   const uint32_t len = (uint32_t)max(read_len[r], 1);
+  const uint32_t inv_len = len > 1 ? (uint32_t)(0x100000000ull / len) : 0xffffffffu;
   int m = min_hits[r]; if (m < 1) m = 1;
   for (int i = threadIdx.x; i < HF_SLOTS; i += 256) cnt[i] = 0;
   if (threadIdx.x == 0) cursor = 0;
   __syncthreads();
-  // one occurrence list per group of 8 lanes: a list (~17 entries at miniSeq+H density) is read as a few
-  // contiguous 64-byte requests instead of one 8-byte request per lane per step
+  // One occurrence list per group of 4 lanes, 16 bytes per lane and load: a list (~17 entries at miniSeq+H density) is
+  // a few 64-byte requests, all in flight together.  The random-access rate of HBM is bound by requests, not bytes (tools/ubench/randread:
+  // 48 G requests/s whether they carry 8 or 64 bytes), so fewer, wider requests is what counts here.  Lists start at
+  // any 8-byte offset; reading starts at the even element below (occ[] is padded by two entries).
+  // A group's lists are software-pipelined (count/start and list data several lists ahead): without that every
+  // list costs two dependent memory latencies and the kernel waits instead of streaming.
   const int grp = threadIdx.x >> 2, sub = threadIdx.x & 3;
-  for (int i = grp; i < s; i += 64) {
-    const uint32_t c = probe_cnt[o + i];
-    const uint64_t* src = I.occ + probe_start[o + i];
-    for (uint32_t j0 = 0; j0 < c; j0 += 32) {                     // up to four unconditional loads in flight per lane
-      uint64_t hq[8];
+  auto for_each_hit = [&](auto&& fn) {
+    auto meta = [&](int i, uint32_t& c, uint64_t& st0) { c = 0; st0 = 0; if (i < s) { c = probe_cnt[o + i]; st0 = probe_start[o + i]; } };
+    auto issue = [&](uint32_t c, uint64_t st0, ulonglong2 (&v)[4]) {   // the first 32 elements, counted from the even element at or below the start
+      const uint32_t skip = (uint32_t)(st0 & 1ull), tot = skip + c;
+      const ulonglong2* src = reinterpret_cast<const ulonglong2*>(I.occ + (st0 - skip));
 #pragma unroll
-      for (int q = 0; q < 8; ++q) hq[q] = src[min(j0 + sub + 4 * q, c - 1)];
+      for (int q = 0; q < 4; ++q) { const uint32_t e = 2 * sub + 8 * q; if (c) v[q] = src[min(e, tot - 1) >> 1]; }
+    };
+    uint32_t c0, c1, c2; uint64_t s0, s1, s2;
+    ulonglong2 v0[4], v1[4];
+    meta(grp, c0, s0); meta(grp + 64, c1, s1);
+    issue(c0, s0, v0);
+    for (int i = grp; i < s; i += 64) {                          // (a third list in flight costs occupancy and is slower)
+      meta(i + 128, c2, s2);
+      issue(c1, s1, v1);
+      if (c0) {
+        const uint32_t skip = (uint32_t)(s0 & 1ull), tot = skip + c0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (j0 + sub + 4 * q < c) atomicAdd(&cnt[hf_slot((uint32_t)(hq[q] >> 32), (uint32_t)pw_wpos((uint32_t)hq[q]) / len)], 1u);
-    }
-  }
-  __syncthreads();
-  uint32_t mine = 0;
-  const uint64_t wbase = WRITE ? read_hit_off[r] : 0;
-  for (int i = grp; i < s; i += 64) {
-    const uint32_t c = probe_cnt[o + i];
-    const uint64_t* src = I.occ + probe_start[o + i];
-    for (uint32_t j0 = 0; j0 < c; j0 += 32) {
-      uint64_t hq[8];
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t e = 2 * sub + 8 * q;
+          if (e >= skip && e < tot) fn(v0[q].x);
+          if (e + 1 < tot) fn(v0[q].y);
+        }
+        if (tot > 32) {                                           // long lists: the rest, 32 elements at a time
+          const ulonglong2* src = reinterpret_cast<const ulonglong2*>(I.occ + (s0 - skip));
+          for (uint32_t j0 = 32; j0 < tot; j0 += 32) {
+            ulonglong2 v[4];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) hq[q] = src[min(j0 + sub + 4 * q, c - 1)];
+            for (int q = 0; q < 4; ++q) { const uint32_t e = j0 + 2 * sub + 8 * q; v[q] = src[min(e, tot - 1) >> 1]; }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        if (j0 + sub + 4 * q >= c) continue;
-        const uint64_t h = hq[q];
-        const uint32_t ct = (uint32_t)(h >> 32), bin = (uint32_t)pw_wpos((uint32_t)h) / len;
-        const uint32_t c0 = cnt[hf_slot(ct, bin)];
-        const uint32_t cl = bin > 0 ? cnt[hf_slot(ct, bin - 1)] : 0u, cr = cnt[hf_slot(ct, bin + 1)];
-        if (c0 + cl >= (uint32_t)m || c0 + cr >= (uint32_t)m) {
-          const uint32_t slot = atomicAdd(&cursor, 1u);
-          if (WRITE) hits[wbase + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
-          else if (slot < HF_STAGE) stage[(size_t)r * HF_STAGE + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t e = j0 + 2 * sub + 8 * q;
+              if (e < tot) fn(v[q].x);
+              if (e + 1 < tot) fn(v[q].y);
+            }
+          }
         }
       }
+      c0 = c1; s0 = s1; c1 = c2; s1 = s2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v0[q] = v1[q];
     }
-  }
+  };
+  if (dbg == 2) { uint64_t a = 0; for_each_hit([&](uint64_t h) { a += h; }); if (a == 0x123456789ull) cnt[0] = 1; }
+  else for_each_hit([&](uint64_t h) {
+    atomicAdd(&cnt[hf_slot_of(hf_base((uint32_t)(h >> 32), __umulhi((uint32_t)pw_wpos((uint32_t)h), inv_len)))], 1u);
+  });
+  __syncthreads();
+  if (dbg) { if (!WRITE && threadIdx.x == 0) surv_n[r] = 0; return; }   // timing aid (MM_HF_DBG): pass 1 only
+  uint32_t mine = 0;
+  const uint64_t wbase = WRITE ? read_hit_off[r] : 0;
+  for_each_hit([&](uint64_t h) {
+    const uint32_t ct = (uint32_t)(h >> 32), bin = __umulhi((uint32_t)pw_wpos((uint32_t)h), inv_len);
+    const uint32_t hb = hf_base(ct, bin);
+    const uint32_t c0 = cnt[hf_slot_of(hb)];
+    const uint32_t cl = bin > 0 ? cnt[hf_slot_of(hb - HF_K2)] : 0u, cr = cnt[hf_slot_of(hb + HF_K2)];
+    if (c0 + cl >= (uint32_t)m || c0 + cr >= (uint32_t)m) {
+      const uint32_t slot = atomicAdd(&cursor, 1u);
+      if (WRITE) hits[wbase + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
+      else if (slot < HF_STAGE) stage[(size_t)r * HF_STAGE + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
+    }
+  });
   (void)mine;
   if (!WRITE) {
     __syncthreads();
@@ -513,7 +546,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     surv.alloc((size_t)n + 1); surv.zero(st);
     stage.alloc((size_t)n * HF_STAGE);
     hit_filter_kernel<false><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
-                                                                   M->min_hits.p, surv.p, nullptr, nullptr, stage.p);
+                                                                   M->min_hits.p, surv.p, nullptr, nullptr, stage.p, getenv("MM_HF_DBG") ? atoi(getenv("MM_HF_DBG")) : 0);
     MM_KERNEL_CHECK();
     exclusive_scan_u32_u64(surv.p, n, M->read_hit_off.p, scan_tmp, st);
   } else {
@@ -528,7 +561,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   if (total_hits > 0) {
     if (use_filter)
       hit_filter_kernel<true><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
-                                                                    M->min_hits.p, surv.p, M->read_hit_off.p, M->hits.p, stage.p);
+                                                                    M->min_hits.p, surv.p, M->read_hit_off.p, M->hits.p, stage.p, 0);
     else
       gather_hits_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, hit_off.p, M->hits.p);
     MM_KERNEL_CHECK();

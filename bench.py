@@ -107,6 +107,8 @@ def main():
     read_len = reads.lengths().astype(np.int64)
     ctx.synchronize()
 
+    contig_taxon = np.arange(G, dtype=np.int32)                  # one contig per genome = one taxon per contig
+    contig_len = ref.lengths().astype(np.int32)
     agg = {"ms_l2": 0.0, "l2_launches": 0, "l2_stream": 0, "stats": None, "em_iters": 0}
     rec_buf = np.empty(max(64 * args.reads, 1 << 16), dtype=capi.RECORD_DTYPE)   # host result buffer reused by every step
 
@@ -117,21 +119,15 @@ def main():
         M.add_qualities(k)
         off, rec = M.fetch(rec_buf)
         st = M.stats()
-        M.close()
         tt.append(time.perf_counter())
-        # ---- classify: host preparation of the EM problem (fEM.h:234-373), then device iterations
-        n_reads = len(off) - 1
-        taxon = rec["ref_contig"].astype(np.int32)            # one contig per genome = one taxon per contig
-        mapq = parse6(rec["mapq"].astype(np.float64))
-        rl = np.repeat(read_len, np.diff(off))
-        inv = 1.0 / (args.genome_len - rl + 1).astype(np.float64)   # nLoc: contigs >= read length (fEM.h:334)
-        seen = np.zeros(G, dtype=np.float64)
-        seen[np.unique(taxon)] = 1.0
+        # ---- classify: the EM problem built on the device from the records (fEM.h:234-373), then device iterations
+        em = ctx.em_from_mapping(M, contig_taxon, contig_len, G)
+        M.close()
+        seen = (em.taxon_counts() > 0).astype(np.float64)
         if world > 1:
             ctx.comm_allreduce(seen)
         present = seen > 0
         n_seen = int(present.sum())
-        em = ctx.em(off, taxon, mapq, inv, G)
         f0 = np.where(present, 1.0 / max(n_seen, 1), 0.0)
 
         def em_step(f):

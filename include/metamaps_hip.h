@@ -183,6 +183,16 @@ int mm_debug_min_hits(mm_mapping* m, int32_t* min_hits /* [n_reads] */);
  * l_i = f[taxon[i]] * inv_nloc[i] * mapq[i]  (fEM.h:353), p_i = l_i / sum over the read.  */
 int mm_em_create(mm_ctx* ctx, int64_t n_reads, const int64_t* read_off, const int32_t* taxon, const double* mapq,
                  const double* inv_nloc, int32_t n_taxa, mm_em** out);
+/* map -> classify without the text file in between: the same EM problem `classify` would read from PREFIX, built on
+ * the device from the records of `m` (after mm_mapping_add_qualities): taxon = contig_taxon[contig]; the mapping
+ * quality rounded to the 6 significant digits the file carries (mapWrap.h:318-320 -> fEM.h:262); 1/nLoc with
+ * nLoc = sum over the taxon's contigs of (len - readLen + 1) when len >= readLen, else 1 if the read maps to that
+ * contig (getMappingLocations, fEM.h:322-346). */
+int mm_em_create_from_mapping(mm_ctx* ctx, const mm_mapping* m, const int32_t* contig_taxon, const int32_t* contig_len, int32_t n_contigs,
+                              int32_t n_taxa, mm_em** out);
+/* mappings per taxon (taxa without any start the iteration at frequency 0, fEM.h:494) */
+int mm_em_taxon_counts(mm_em* em, int64_t* counts);
+int mm_em_sizes(const mm_em* em, int64_t* n_reads, int64_t* n_entries, int32_t* n_taxa);
 void mm_em_destroy(mm_em* em);
 /* one E+M step on this rank's reads: f_partial[t] = sum of p_i, *ll_partial = sum log(sum l_i) */
 int mm_em_iterate(mm_em* em, const double* f, double* f_partial, double* ll_partial);

@@ -126,6 +126,9 @@ def lib() -> C.CDLL:
             "mm_debug_l2": (C.c_int, [vp, vp, i64]),
             "mm_debug_min_hits": (C.c_int, [vp, vp]),
             "mm_em_create": (C.c_int, [vp, i64, vp, vp, vp, vp, i32, P(vp)]),
+            "mm_em_create_from_mapping": (C.c_int, [vp, vp, vp, vp, i32, i32, P(vp)]),
+            "mm_em_taxon_counts": (C.c_int, [vp, vp]),
+            "mm_em_sizes": (C.c_int, [vp, P(i64), P(i64), P(i32)]),
             "mm_em_destroy": (None, [vp]),
             "mm_em_iterate": (C.c_int, [vp, vp, vp, P(f64)]),
             "mm_em_iterate_allreduce": (C.c_int, [vp, vp, vp, P(f64)]),
@@ -238,6 +241,16 @@ class Context:
         h = C.c_void_p()
         self.check(lib().mm_em_create(self.h, len(read_off) - 1, _ptr(read_off), _ptr(taxon), _ptr(mapq), _ptr(inv_nloc), n_taxa, C.byref(h)))
         return EM(self, h, n_taxa, len(read_off) - 1, len(taxon))
+
+    def em_from_mapping(self, mapping: "Mapping", contig_taxon, contig_len, n_taxa: int) -> "EM":
+        """the EM problem of `classify` built on the device from the mapping's records (after add_qualities)"""
+        contig_taxon = np.ascontiguousarray(contig_taxon, dtype=np.int32)
+        contig_len = np.ascontiguousarray(contig_len, dtype=np.int32)
+        h = C.c_void_p()
+        self.check(lib().mm_em_create_from_mapping(self.h, mapping.h, _ptr(contig_taxon), _ptr(contig_len), len(contig_taxon), n_taxa, C.byref(h)))
+        nr, ne, nt = C.c_int64(), C.c_int64(), C.c_int32()
+        self.check(lib().mm_em_sizes(h, C.byref(nr), C.byref(ne), C.byref(nt)))
+        return EM(self, h, n_taxa, nr.value, ne.value)
 
     # ---- communicator
     @staticmethod
@@ -420,6 +433,11 @@ class EM:
         ll = C.c_double()
         self.ctx.check(lib().mm_em_iterate_allreduce(self.h, _ptr(f), _ptr(nxt), C.byref(ll)))
         return nxt, ll.value
+
+    def taxon_counts(self) -> np.ndarray:
+        c = np.zeros(self.n_taxa, dtype=np.int64)
+        self.ctx.check(lib().mm_em_taxon_counts(self.h, _ptr(c)))
+        return c
 
     def posteriors(self, f: np.ndarray):
         f = np.ascontiguousarray(f, dtype=np.float64)

@@ -409,6 +409,30 @@ int mm_em_create(mm_ctx* ctx, int64_t n_reads, const int64_t* read_off, const in
     *out = E;
   });
 }
+int mm_em_create_from_mapping(mm_ctx* ctx, const mm_mapping* m, const int32_t* contig_taxon, const int32_t* contig_len, int32_t n_contigs,
+                              int32_t n_taxa, mm_em** out) {
+  if (!ctx || !m || !contig_taxon || !contig_len || !out || n_contigs < 0 || n_taxa <= 0) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
+    auto* E = new mm_em;
+    try { mm::em_create_from_mapping(ctx, m, contig_taxon, contig_len, n_contigs, n_taxa, E); } catch (...) { delete E; throw; }
+    *out = E;
+  });
+}
+int mm_em_taxon_counts(mm_em* em, int64_t* counts) {
+  if (!em || !counts) return MM_ERR_ARG;
+  return guarded(em->ctx, [&] {
+    auto ts = em->tstart.to_host(em->ctx->stream, (size_t)em->n_taxa + 1);
+    for (int32_t t = 0; t < em->n_taxa; ++t) counts[t] = ts[(size_t)t + 1] - ts[(size_t)t];
+  });
+}
+int mm_em_sizes(const mm_em* em, int64_t* n_reads, int64_t* n_entries, int32_t* n_taxa) {
+  if (!em) return MM_ERR_ARG;
+  if (n_reads) *n_reads = em->n_reads;
+  if (n_entries) *n_entries = em->n_entries;
+  if (n_taxa) *n_taxa = em->n_taxa;
+  return MM_OK;
+}
 void mm_em_destroy(mm_em* em) { if (em) { mm::current_stream() = em->ctx->stream; mm::current_alloc() = &em->ctx->alloc; delete em; } }
 int mm_em_iterate(mm_em* em, const double* f, double* f_partial, double* ll_partial) {
   if (!em || !f || !f_partial || !ll_partial) return MM_ERR_ARG;

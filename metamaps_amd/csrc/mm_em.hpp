@@ -2,6 +2,7 @@
 #pragma once
 #include "mm_common.hpp"
 
+struct mm_mapping;
 struct mm_em {
   mm_ctx* ctx = nullptr;
   int64_t n_reads = 0, n_entries = 0;
@@ -16,6 +17,8 @@ struct mm_em {
 namespace mm {
 void em_create(mm_ctx* ctx, int64_t n_reads, const int64_t* read_off, const int32_t* taxon, const double* mapq, const double* inv_nloc,
                int32_t n_taxa, mm_em* E);
+void em_create_from_mapping(mm_ctx* ctx, const ::mm_mapping* M, const int32_t* contig_taxon, const int32_t* contig_len, int32_t n_contigs,
+                            int32_t n_taxa, mm_em* E);
 void em_iterate(mm_em* E, const double* f, double* f_partial, double* ll_partial);
 void em_iterate_allreduce(mm_em* E, const double* f, double* f_next, double* ll);
 void em_posteriors(mm_em* E, const double* f, double* post, int64_t* best);

@@ -4,6 +4,7 @@
 #include "mm_map.hpp"
 #include "mm_em.hpp"
 #include <rccl/rccl.h>
+#include <rocprim/rocprim.hpp>
 #include <cfloat>
 #include <numeric>
 
@@ -162,6 +163,100 @@ void em_create(mm_ctx* ctx, int64_t n_reads, const int64_t* read_off, const int3
   E->tstart.alloc((size_t)n_taxa + 1); E->tstart.upload(ts.data(), ts.size(), st);
   E->perm.alloc(perm.size()); E->perm.upload(perm.data(), (size_t)ne, st);
   E->post.alloc((size_t)std::max<int64_t>(ne, 1));
+  E->ll_read.alloc((size_t)std::max<int64_t>(n_reads, 1));
+  E->f.alloc((size_t)n_taxa);
+  E->partial.alloc((size_t)n_taxa + 1);
+  E->block_sum.alloc((size_t)ceil_div(std::max<int64_t>(n_reads, 1), 256));
+  MM_HIP(hipStreamSynchronize(st));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// EM problem straight from device-resident mapping records (map -> classify without the text file in between)
+// ---------------------------------------------------------------------------------------------------
+// per record: taxon of its contig, the mapping quality as the file would carry it (6 significant digits,
+// mapWrap.h:318-320 -> fEM.h:262), 1/nLoc with nLoc = sum over the taxon's contigs of (len - L + 1) if len >= L, else 1 if the
+// read has a mapping on that contig (getMappingLocations, fEM.h:322-346)
+__global__ void __launch_bounds__(256) em_entries_kernel(const mm_map_record* __restrict__ rec, const uint64_t* __restrict__ rec_off, int64_t ne,
+                                                         const int32_t* __restrict__ read_len, const int32_t* __restrict__ contig_taxon,
+                                                         const int32_t* __restrict__ contig_len, const int64_t* __restrict__ tl_off,
+                                                         const int32_t* __restrict__ tl_len /* ascending per taxon */,
+                                                         const int64_t* __restrict__ tl_suffix /* sum of tl_len[i..end of taxon) */,
+                                                         int32_t* __restrict__ taxon, uint32_t* __restrict__ key, uint32_t* __restrict__ val,
+                                                         double* __restrict__ mapq, double* __restrict__ inv) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ne) return;
+  const mm_map_record x = rec[i];
+  const int t = contig_taxon[x.ref_contig];
+  const int64_t L = read_len[x.read];
+  int64_t lo = tl_off[t], hi = tl_off[t + 1];
+  const int64_t end = hi;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (tl_len[mid] < L) lo = mid + 1; else hi = mid; }
+  int64_t n = (lo < end ? tl_suffix[lo] : 0) - (end - lo) * (L - 1);
+  int prev = -1;                                                   // shorter contigs of the taxon the read maps to, each once
+  for (uint64_t j = rec_off[x.read]; j < rec_off[x.read + 1]; ++j) {
+    const int c = rec[j].ref_contig;
+    if (c != prev && contig_taxon[c] == t && contig_len[c] < L) ++n;
+    prev = c;
+  }
+  taxon[i] = t; key[i] = (uint32_t)t; val[i] = (uint32_t)i;
+  mapq[i] = parse6(x.mapq);
+  inv[i] = 1.0 / (double)n;
+}
+__global__ void em_perm_kernel(const uint32_t* __restrict__ val_sorted, int64_t ne, int64_t* __restrict__ perm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ne) perm[i] = (int64_t)val_sorted[i];
+}
+__global__ void em_tstart_kernel(const uint32_t* __restrict__ key_sorted, int64_t ne, int32_t n_taxa, int64_t* __restrict__ tstart) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > n_taxa) return;
+  int64_t lo = 0, hi = ne;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)key_sorted[mid] < t) lo = mid + 1; else hi = mid; }
+  tstart[t] = lo;
+}
+
+void em_create_from_mapping(mm_ctx* ctx, const mm_mapping* M, const int32_t* contig_taxon, const int32_t* contig_len, int32_t n_contigs,
+                            int32_t n_taxa, mm_em* E) {
+  hipStream_t st = ctx->stream;
+  const int64_t n_reads = M->n_reads, ne = M->n_rec;
+  MM_REQUIRE(ne < (1LL << 32), MM_ERR_LIMIT, "more than 2^32 mapping records in one EM problem");
+  E->ctx = ctx; E->n_reads = n_reads; E->n_taxa = n_taxa; E->n_entries = ne;
+  // contig lengths per taxon, ascending, with suffix sums
+  std::vector<int64_t> tl_off((size_t)n_taxa + 1, 0);
+  for (int32_t c = 0; c < n_contigs; ++c) { MM_REQUIRE(contig_taxon[c] >= 0 && contig_taxon[c] < n_taxa, MM_ERR_ARG, "taxon index out of range"); tl_off[(size_t)contig_taxon[c] + 1]++; }
+  for (int32_t t = 0; t < n_taxa; ++t) tl_off[(size_t)t + 1] += tl_off[(size_t)t];
+  std::vector<int32_t> tl_len((size_t)std::max(n_contigs, 1));
+  { std::vector<int64_t> cur(tl_off.begin(), tl_off.end() - 1); for (int32_t c = 0; c < n_contigs; ++c) tl_len[(size_t)cur[(size_t)contig_taxon[c]]++] = contig_len[c]; }
+  std::vector<int64_t> tl_suf((size_t)std::max(n_contigs, 1), 0);
+  for (int32_t t = 0; t < n_taxa; ++t) {
+    std::sort(tl_len.begin() + tl_off[(size_t)t], tl_len.begin() + tl_off[(size_t)t + 1]);
+    int64_t run = 0;
+    for (int64_t i = tl_off[(size_t)t + 1] - 1; i >= tl_off[(size_t)t]; --i) { run += tl_len[(size_t)i]; tl_suf[(size_t)i] = run; }
+  }
+  DBuf<int32_t> d_ct((size_t)std::max(n_contigs, 1)), d_cl((size_t)std::max(n_contigs, 1)), d_tl(tl_len.size());
+  DBuf<int64_t> d_toff(tl_off.size()), d_tsuf(tl_suf.size());
+  d_ct.upload(contig_taxon, (size_t)n_contigs, st); d_cl.upload(contig_len, (size_t)n_contigs, st);
+  d_tl.upload(tl_len.data(), tl_len.size(), st); d_toff.upload(tl_off.data(), tl_off.size(), st); d_tsuf.upload(tl_suf.data(), tl_suf.size(), st);
+  const size_t cap = (size_t)std::max<int64_t>(ne, 1);
+  E->read_off.alloc((size_t)n_reads + 1);
+  MM_HIP(hipMemcpyAsync(E->read_off.p, M->rec_off.p, sizeof(int64_t) * ((size_t)n_reads + 1), hipMemcpyDeviceToDevice, st));
+  E->taxon.alloc(cap); E->mapq.alloc(cap); E->inv_nloc.alloc(cap); E->perm.alloc(cap); E->post.alloc(cap);
+  E->tstart.alloc((size_t)n_taxa + 1);
+  DBuf<uint32_t> key(cap), val(cap), key2(cap), val2(cap);
+  if (ne > 0) {
+    em_entries_kernel<<<dim3((unsigned)ceil_div(ne, 256)), dim3(256), 0, st>>>(M->rec.p, M->rec_off.p, ne, M->d_read_len.p, d_ct.p, d_cl.p, d_toff.p, d_tl.p,
+                                                                          d_tsuf.p, E->taxon.p, key.p, val.p, E->mapq.p, E->inv_nloc.p);
+    MM_KERNEL_CHECK();
+    // CSR by taxon, entries in read order inside each taxon (stable sort)
+    int bits = 1; while ((1LL << bits) < (int64_t)n_taxa) ++bits;
+    size_t tmp_bytes = 0;
+    MM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key.p, key2.p, val.p, val2.p, (size_t)ne, 0, bits, st));
+    DBuf<uint8_t> tmp(tmp_bytes);
+    MM_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, key.p, key2.p, val.p, val2.p, (size_t)ne, 0, bits, st));
+    em_perm_kernel<<<dim3((unsigned)ceil_div(ne, 256)), dim3(256), 0, st>>>(val2.p, ne, E->perm.p);
+    MM_KERNEL_CHECK();
+  }
+  em_tstart_kernel<<<dim3((unsigned)ceil_div((int64_t)n_taxa + 1, 256)), dim3(256), 0, st>>>(key2.p, ne, n_taxa, E->tstart.p);
+  MM_KERNEL_CHECK();
   E->ll_read.alloc((size_t)std::max<int64_t>(n_reads, 1));
   E->f.alloc((size_t)n_taxa);
   E->partial.alloc((size_t)n_taxa + 1);

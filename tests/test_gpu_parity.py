@@ -272,3 +272,52 @@ def test_hit_prefilter_keeps_candidates_identical(ctx, monkeypatch):
     assert res["0"][4]["sum_hits_kept"] < res["1"][4]["sum_hits_kept"] == res["1"][4]["sum_hits"]
     assert res["0"][4]["n_candidates"] > 2000
     idx.close(); reads.close(); ref.close()
+
+
+def test_em_from_mapping_equals_host_built_problem(ctx):
+    """mm_em_create_from_mapping (device) against the same EM problem assembled on the host from fetched records with the
+    reference's rules (fEM.h:234-353): multi-contig taxa, contigs shorter than the read, 6-digit mapping qualities."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    ref = ctx.synth_reference(seed=8, n_species=24, strains_per_species=4, genome_len=150_000, strain_divergence=0.02, genus_divergence=0.08)
+    reads, _ = ctx.synth_reads(ref, seed=12, n_reads=1500, read_len=5000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.1, n_abundant=30)
+    idx = ctx.index(ref, 16, 8)
+    M = ctx.map_batch(idx, reads, 16, 8)
+    M.add_qualities(16)
+    off, rec = M.fetch()
+    C = ref.count
+    contig_taxon = (np.arange(C) // 2).astype(np.int32)          # two contigs per taxon
+    contig_len = ref.lengths().astype(np.int32).copy()
+    contig_len[::5] = 3000                                        # pretend every fifth contig is shorter than the reads
+    T = int(contig_taxon.max()) + 1
+    rl = reads.lengths().astype(np.int64)
+    # host construction
+    taxon = contig_taxon[rec["ref_contig"]]
+    mapq = bench.parse6(rec["mapq"].astype(np.float64))
+    inv = np.zeros(len(rec))
+    for r in range(len(off) - 1):
+        a, b = int(off[r]), int(off[r + 1])
+        L = int(rl[r])
+        cs = set(int(c) for c in rec["ref_contig"][a:b])
+        for i in range(a, b):
+            t = int(taxon[i]); n = 0
+            for c in np.nonzero(contig_taxon == t)[0]:
+                if contig_len[c] >= L: n += int(contig_len[c]) - L + 1
+                elif int(c) in cs: n += 1
+            inv[i] = 1.0 / n
+    e_host = ctx.em(off, taxon, mapq, inv, T)
+    e_dev = ctx.em_from_mapping(M, contig_taxon, contig_len, T)
+    assert e_dev.n_entries == len(rec) and e_dev.n_reads == len(off) - 1
+    assert np.array_equal(e_dev.taxon_counts(), np.bincount(taxon, minlength=T))
+    f = np.where(np.bincount(taxon, minlength=T) > 0, 1.0, 0.0); f /= f.sum()
+    for _ in range(3):
+        ph, lh = e_host.iterate(f)
+        pd_, ld = e_dev.iterate(f)
+        assert np.array_equal(ph, pd_) and lh == ld
+        f = ph / ph.sum()
+    p1, b1 = e_host.posteriors(f); p2, b2 = e_dev.posteriors(f)
+    assert np.array_equal(b1, b2)
+    # (mapping qualities around 1e-35 round differently in numpy's and the device's 6-digit rounding: posteriors that small only)
+    assert np.allclose(p1, p2, rtol=1e-12, atol=1e-30)
+    e_host.close(); e_dev.close(); M.close(); idx.close(); reads.close(); ref.close()

@@ -9,6 +9,8 @@
 //   K5  L2 sliding MinHash window + K6 strand vote           computeMap.hpp:460-538, slidingMap.hpp
 //   K7  identity filter: a per-sketch-size integer threshold computed on the host (mm_stats.hpp)
 #include "mm_map.hpp"
+#include <functional>
+#include <memory>
 #include <rocprim/rocprim.hpp>
 #include "mm_l2_core.hpp"
 #include "mm_l2.hpp"
@@ -440,6 +442,8 @@ struct StageTimer {
 };
 }  // namespace
 
+struct AmbState { std::vector<int64_t> reads; std::vector<uint64_t> dof; DBuf<uint64_t> d_so, d_do; };
+
 void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_map_params& P, mm_mapping* M) {
   hipStream_t st = ctx->stream;
   StageTimer T(st);
@@ -499,6 +503,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   }
   M->h_sk_n = M->sk_n.to_host(st, (size_t)n);
   std::vector<uint8_t> h_amb = M->amb.to_host(st, (size_t)n);
+  std::function<void()> amb_finish;
   // ---- duplicate-hash strand tie-break (computeMap.hpp:292-295: std::sort is not stable, std::unique keeps
   //      whichever equal-hash element introsort left first).  Only the strand of the survivor is observable
   //      (slidingMap.hpp:247), so it is resolved here with the same library calls on the same input order.
@@ -519,37 +524,46 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       DBuf<Rec> comp((size_t)dof[na]);
       gather_amb_kernel<<<dim3((unsigned)na), dim3(256), 0, st>>>(M->mz.rec.p, d_so.p, d_do.p, comp.p);
       MM_KERNEL_CHECK();
-      std::vector<Rec> hr = comp.to_host(st);
-      std::vector<uint8_t> sv((size_t)dof[na], 0);
-      std::vector<int32_t> scnt(na);
-      // the library sort of ~1 % of the reads is the only per-read host work of a batch: spread it over threads
-      std::atomic<size_t> next{0};
-      std::atomic<int> mismatch{0};
-      auto worker = [&]() {
-        std::vector<HostMz> v;
-        for (size_t i = next.fetch_add(1); i < na; i = next.fetch_add(1)) {
-          const size_t cntr = (size_t)(dof[i + 1] - dof[i]);
-          v.resize(cntr);
-          for (size_t j = 0; j < cntr; ++j) { const Rec& x = hr[(size_t)dof[i] + j]; v[j] = HostMz{x.hash, pw_wpos(x.pw), pw_strand(x.pw)}; }
-          std::sort(v.begin(), v.end(), host_less_by_hash);
-          auto ue = std::unique(v.begin(), v.end(), host_eq_by_hash);
-          const size_t sN = (size_t)(ue - v.begin());
-          if ((int64_t)sN != M->h_sk_n[(size_t)amb_reads[i]]) mismatch = 1;
-          for (size_t j = 0; j < sN; ++j) sv[(size_t)dof[i] + j] = v[j].strand == 1 ? 1 : 0;
-          scnt[i] = (int32_t)sN;
-        }
+      // The library sort of ~1 % of the reads is the only per-read host work of a batch.  Only the L2 strand vote needs its
+      // result, so it runs (spread over threads) while the device is busy with the probe and the seed-hit filter.
+      auto hr = std::make_shared<std::vector<Rec>>(comp.to_host(st));
+      auto st_amb = std::make_shared<AmbState>();
+      st_amb->reads = amb_reads; st_amb->dof = dof; st_amb->d_so = std::move(d_so); st_amb->d_do = std::move(d_do);
+      amb_finish = [this_M = M, hr, st_amb, st]() {
+        mm_mapping* M = this_M;
+        const std::vector<int64_t>& amb_reads = st_amb->reads;
+        const std::vector<uint64_t>& dof = st_amb->dof;
+        const size_t na = amb_reads.size();
+        std::vector<uint8_t> sv((size_t)dof[na], 0);
+        std::vector<int32_t> scnt(na);
+        std::atomic<size_t> next{0};
+        std::atomic<int> mismatch{0};
+        auto worker = [&]() {
+          std::vector<HostMz> v;
+          for (size_t i = next.fetch_add(1); i < na; i = next.fetch_add(1)) {
+            const size_t cntr = (size_t)(dof[i + 1] - dof[i]);
+            v.resize(cntr);
+            for (size_t j = 0; j < cntr; ++j) { const Rec& x = (*hr)[(size_t)dof[i] + j]; v[j] = HostMz{x.hash, pw_wpos(x.pw), pw_strand(x.pw)}; }
+            std::sort(v.begin(), v.end(), host_less_by_hash);
+            auto ue = std::unique(v.begin(), v.end(), host_eq_by_hash);
+            const size_t sN = (size_t)(ue - v.begin());
+            if ((int64_t)sN != M->h_sk_n[(size_t)amb_reads[i]]) mismatch = 1;
+            for (size_t j = 0; j < sN; ++j) sv[(size_t)dof[i] + j] = v[j].strand == 1 ? 1 : 0;
+            scnt[i] = (int32_t)sN;
+          }
+        };
+        const unsigned nthr = std::max(1u, std::min(16u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)((na + 31) / 32))));
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto& t : pool) t.join();
+        MM_REQUIRE(mismatch == 0, MM_ERR_DEVICE, "sketch size disagrees between device and host tie-break");
+        DBuf<uint8_t> d_sv(sv.size()); d_sv.upload(sv.data(), sv.size(), st);
+        DBuf<int32_t> d_cnt(na); d_cnt.upload(scnt.data(), na, st);
+        scatter_strand_kernel<<<dim3((unsigned)na), dim3(256), 0, st>>>(d_sv.p, st_amb->d_so.p, st_amb->d_do.p, d_cnt.p, M->sk_strand.p);
+        MM_KERNEL_CHECK();
+        MM_HIP(hipStreamSynchronize(st));                        // host vectors above are the H2D sources
       };
-      const unsigned nthr = std::max(1u, std::min(16u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)((na + 31) / 32))));
-      std::vector<std::thread> pool;
-      for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
-      worker();
-      for (auto& t : pool) t.join();
-      MM_REQUIRE(mismatch == 0, MM_ERR_DEVICE, "sketch size disagrees between device and host tie-break");
-      DBuf<uint8_t> d_sv(sv.size()); d_sv.upload(sv.data(), sv.size(), st);
-      DBuf<int32_t> d_cnt(na); d_cnt.upload(scnt.data(), na, st);
-      scatter_strand_kernel<<<dim3((unsigned)na), dim3(256), 0, st>>>(d_sv.p, d_so.p, d_do.p, d_cnt.p, M->sk_strand.p);
-      MM_KERNEL_CHECK();
-      MM_HIP(hipStreamSynchronize(st));                          // host vectors above are the H2D sources
     }
   }
   // ---- K7 host thresholds per distinct sketch size
@@ -606,6 +620,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     read_hit_bounds_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(M->mz.off.p, hit_off.p, n, M->read_hit_off.p);
     MM_KERNEL_CHECK();
   }
+  if (amb_finish) { amb_finish(); amb_finish = nullptr; }          // overlaps with the kernels queued above
   M->h_read_hit_off = M->read_hit_off.to_host(st);
   const int64_t total_hits = (int64_t)M->h_read_hit_off[(size_t)n];
   M->stats.sum_hits = (int64_t)raw_hits;

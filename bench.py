@@ -270,7 +270,9 @@ def cpu_baseline(args, ctx, ref, reads, truth, k, w):
             for r in pick_reads:
                 s = reads.fetch(r, int(rl[r])); nb += len(s)
                 f.write(f"@r{r}\n".encode() + s + b"\n+\n" + b"I" * len(s) + b"\n")
-        cores = args.cpu_threads or len(os.sched_getaffinity(0))
+        # the GPU boxes show 256 cores but the oracle stops scaling at ~16 threads there (tools/cpu_scaling.sh: 0.072 Gbp/s at 16,
+        # 0.077 at 64, 0.061 at 256), so more than 64 threads only adds scheduling noise
+        cores = args.cpu_threads or min(len(os.sched_getaffinity(0)), 64)
         p = subprocess.run([exe, "mapDirectly", "--all", "-r", fa, "-q", fq, "-o", os.path.join(d, "out"), "-w", str(w), "-t", str(cores)],
                            capture_output=True, check=True, timeout=1200)
         js = json.loads(p.stderr.decode().strip().splitlines()[-1])

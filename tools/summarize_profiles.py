@@ -1,0 +1,41 @@
+"""Turns the rocprofv3 CSV output of tools/collect_profiles.sh into the text/json summaries kept under profiles/."""
+import collections, csv, glob, json, os, sys
+
+out = sys.argv[1]
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "")
+    if "rocprim" in n:
+        n = "rocprim::" + ("radix_sort_onesweep" if "onesweep" in name else "radix_sort_histogram" if "histogram" in name else "other")
+    return n[:60]
+
+f = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+with open(os.path.join(out, "kernel_stats.txt"), "w") as w:
+    w.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (setup kernels: index build, synthetic data; per-step kernels: 4 calls)\n")
+    w.write(f"{'calls':>7} {'total_ms':>12} {'avg_ms':>12} {'%':>7}  kernel\n")
+    for r in rows:
+        w.write(f"{int(r['Calls']):>7} {float(r['TotalDurationNs'])/1e6:>12.3f} {float(r['AverageNs'])/1e6:>12.3f} {float(r['Percentage']):>7.3f}  {short(r['Name'])}\n")
+
+def pmc(kind):
+    f = glob.glob(os.path.join(out, kind, "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"]); acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
+    return acc
+
+fe, wr = pmc("fetch"), pmc("write")
+with open(os.path.join(out, "pmc_hbm_traffic.txt"), "w") as w:
+    w.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE   and   --pmc WRITE_SIZE   (separate passes), bench.py --steps 1 --warmup 0 --no-cpu-baseline\n")
+    w.write("# counter unit: KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (fetch_GB_x2).\n")
+    w.write(f"{'kernel':<62} {'launches':>8} {'FETCH_KiB':>14} {'fetch_GB_x2':>12} {'WRITE_KiB':>14} {'write_GB':>9}\n")
+    for k in sorted(fe, key=lambda k: -fe[k][1]):
+        w.write(f"{k:<62} {fe[k][0]:>8} {fe[k][1]:>14.0f} {fe[k][1]*1024*2/1e9:>12.2f} {wr.get(k,[0,0])[1]:>14.0f} {wr.get(k,[0,0])[1]*1024/1e9:>9.2f}\n")
+traffic = {}
+for k in fe:
+    if "l2_kernel" in k or "hit_filter_kernel<false>" in k:
+        traffic[k] = (fe[k][1] * 1024 * 2 + wr.get(k, [0, 0])[1] * 1024) / max(fe[k][0], 1)
+json.dump(traffic, open(os.path.join(out, "traffic_by_kernel.json"), "w"), indent=1)
+print(open(os.path.join(out, "kernel_stats.txt")).read()[:3000])
+print(open(os.path.join(out, "pmc_hbm_traffic.txt")).read()[:3000])
+print(traffic)

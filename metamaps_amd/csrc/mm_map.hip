@@ -359,6 +359,53 @@ __global__ void l1_scan_kernel(const uint64_t* __restrict__ hits, const uint64_t
   if (!WRITE) cand_n[r] = nc;
 }
 
+// The same loop, one wavefront per read.  Hits are sorted by (contig, position), so the merged region so far ends at the
+// position of the latest qualifying hit: hit i opens a new candidate iff the previous qualifying hit lies on another contig
+// or before max(0, wpos[i+m-1]-len+1).  That makes every decision local (ballot + one shuffle); a candidate's end is written
+// by the last qualifying hit before the next opening one, later chunks of the same candidate simply overwrite it.
+template <bool WRITE>
+__global__ void __launch_bounds__(256) l1_wave_kernel(const uint64_t* __restrict__ hits, const uint64_t* __restrict__ read_hit_off,
+                                                      const int32_t* __restrict__ read_len, const int32_t* __restrict__ min_hits, int64_t n_reads,
+                                                      uint32_t* __restrict__ cand_n, const uint64_t* __restrict__ cand_off, int32_t* __restrict__ cand,
+                                                      int32_t* __restrict__ cand_read) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= n_reads) return;
+  const uint64_t o = read_hit_off[r];
+  const int64_t H = (int64_t)(read_hit_off[r + 1] - o);
+  const int len = read_len[r];
+  int m = min_hits[r]; if (m < 1) m = 1;                         // :349
+  const uint64_t wbase = WRITE ? cand_off[r] : 0;
+  int count = 0, prev_seq = -1, prev_wa = 0;
+  for (int64_t base = 0; base + m <= H; base += 64) {
+    const int64_t i = base + lane;
+    const bool valid = i + m <= H;
+    uint64_t a = 0, b = 0;
+    if (valid) { a = hits[o + i]; b = hits[o + i + m - 1]; }
+    const int sa = (int)(a >> 32), sb = (int)(b >> 32), wa = pw_wpos((uint32_t)a), wb = pw_wpos((uint32_t)b);
+    const bool q = valid && sa == sb && wb - wa < len;           // :365
+    const int cs = max(0, wb - len + 1);                         // :368
+    const uint64_t qm = __ballot(q);
+    const uint64_t below = qm & ((1ull << lane) - 1ull);
+    const int pl = below ? 63 - __builtin_clzll(below) : 0;
+    const int p_seq_l = __shfl(sa, pl, 64), p_wa_l = __shfl(wa, pl, 64);
+    const int p_seq = below ? p_seq_l : prev_seq, p_wa = below ? p_wa_l : prev_wa;
+    const bool brk = q && !(p_seq == sa && p_wa >= cs);          // :374-380
+    const uint64_t bm = __ballot(brk);
+    if (WRITE && q) {
+      const int k = count + __popcll(bm & ((2ull << lane) - 1ull)) - 1;
+      const uint64_t above = lane < 63 ? qm & ~((2ull << lane) - 1ull) : 0ull;
+      const bool last = above == 0ull || ((bm >> (__builtin_ctzll(above))) & 1ull);
+      int32_t* c = cand + 3 * (wbase + (uint64_t)k);
+      if (brk) { c[0] = sa; c[1] = cs; cand_read[wbase + (uint64_t)k] = (int32_t)r; }
+      if (last) c[2] = wa;
+    }
+    count += __popcll(bm);
+    if (qm) { const int ll = 63 - __builtin_clzll(qm); prev_seq = __shfl(sa, ll, 64); prev_wa = __shfl(wa, ll, 64); }
+  }
+  if (!WRITE && lane == 0) cand_n[r] = (uint32_t)count;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // result compaction: accepted candidates -> mapping records, read order preserved
 // ---------------------------------------------------------------------------------------------------
@@ -666,11 +713,13 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   }
   // ---- K4b
   const size_t t_l1 = T.begin(&M->stats.ms_l1_scan);
+  const bool l1_serial = getenv("MM_L1_SERIAL") != nullptr;       // cross-check switch: the one-thread-per-read loop
   DBuf<uint32_t> cand_n((size_t)n + 1); cand_n.zero(st);
   M->cand_off.alloc((size_t)n + 2);
   const unsigned rblk = (unsigned)ceil_div(std::max<int64_t>(n, 1), 128);
   if (n > 0) {
-    l1_scan_kernel<false><<<dim3(rblk), dim3(128), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, cand_n.p, nullptr, nullptr, nullptr);
+    if (l1_serial) l1_scan_kernel<false><<<dim3(rblk), dim3(128), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, cand_n.p, nullptr, nullptr, nullptr);
+    else l1_wave_kernel<false><<<dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, cand_n.p, nullptr, nullptr, nullptr);
     MM_KERNEL_CHECK();
   }
   exclusive_scan_u32_u64(cand_n.p, n, M->cand_off.p, scan_tmp, st);
@@ -683,7 +732,8 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   M->l2.alloc((size_t)std::max<int64_t>(ncand, 1));
   M->rec_off.alloc((size_t)n + 1);
   if (ncand > 0) {
-    l1_scan_kernel<true><<<dim3(rblk), dim3(128), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, nullptr, M->cand_off.p, M->cand.p, M->cand_read.p);
+    if (l1_serial) l1_scan_kernel<true><<<dim3(rblk), dim3(128), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, nullptr, M->cand_off.p, M->cand.p, M->cand_read.p);
+    else l1_wave_kernel<true><<<dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, nullptr, M->cand_off.p, M->cand.p, M->cand_read.p);
     MM_KERNEL_CHECK();
     T.end(t_l1);
     // ---- K5/K6

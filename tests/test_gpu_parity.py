@@ -321,3 +321,22 @@ def test_em_from_mapping_equals_host_built_problem(ctx):
     # (mapping qualities around 1e-35 round differently in numpy's and the device's 6-digit rounding: posteriors that small only)
     assert np.allclose(p1, p2, rtol=1e-12, atol=1e-30)
     e_host.close(); e_dev.close(); M.close(); idx.close(); reads.close(); ref.close()
+
+
+def test_l1_wave_scan_equals_serial_loop(ctx, monkeypatch):
+    """K4b one wavefront per read against the literal one-thread-per-read loop (MM_L1_SERIAL=1)."""
+    ref = ctx.synth_reference(seed=6, n_species=40, strains_per_species=4, genome_len=300_000, strain_divergence=0.02, genus_divergence=0.08)
+    reads, _ = ctx.synth_reads(ref, seed=10, n_reads=2000, read_len=6000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.1, n_abundant=30)
+    idx = ctx.index(ref, 16, 8)
+    res = {}
+    for mode in ("wave", "serial"):
+        if mode == "serial":
+            monkeypatch.setenv("MM_L1_SERIAL", "1")
+        M = ctx.map_batch(idx, reads, 16, 8)
+        off, cand = M.debug_candidates()
+        res[mode] = (off.copy(), cand.copy())
+        M.close()
+    monkeypatch.delenv("MM_L1_SERIAL")
+    assert np.array_equal(res["wave"][0], res["serial"][0]) and np.array_equal(res["wave"][1], res["serial"][1])
+    assert len(res["wave"][1]) > 3000
+    idx.close(); reads.close(); ref.close()

@@ -205,14 +205,20 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   if (threadIdx.x < L2_QPAD) Q[s + threadIdx.x] = 0xffffffffu;
   if (threadIdx.x == 0) *tmaxp = 0;
   __syncthreads();
-  for (int bkt = threadIdx.x; bkt < L2_TSIZE; bkt += 64 * WAVES) {  // T[b] = first rank whose hash >= b << L2_TSHIFT
-    int lo = 0, hi = s;
-    if (bkt >= (1 << L2_TBITS)) lo = s;
-    else { const uint32_t tv = (uint32_t)bkt << L2_TSHIFT; while (lo < hi) { const int mid = (lo + hi) >> 1; if (Q[mid] < tv) lo = mid + 1; else hi = mid; } }
-    T[bkt] = (uint16_t)lo;
+  // T[b] = first rank whose hash >= b << L2_TSHIFT: element i is the answer for the buckets after Q[i-1]'s up to its own
+  // (i == s closes the table), so every T entry is written exactly once, without searching
+  for (int i = threadIdx.x; i <= s; i += 64 * WAVES) {
+    const int lo = i ? (int)(Q[i - 1] >> L2_TSHIFT) + 1 : 0;
+    const int hi = i < s ? (int)(Q[i] >> L2_TSHIFT) : (1 << L2_TBITS);
+    for (int bb = lo; bb <= hi; ++bb) T[bb] = (uint16_t)i;
   }
   __syncthreads();
-  for (int bkt = threadIdx.x; bkt < (1 << L2_TBITS); bkt += 64 * WAVES) atomicMax(tmaxp, (int)T[bkt + 1] - (int)T[bkt]);
+  {                                                              // longest bucket: wave maximum first, one LDS atomic per wave
+    int tm = 0;
+    for (int bkt = threadIdx.x; bkt < (1 << L2_TBITS); bkt += 64 * WAVES) tm = max(tm, (int)T[bkt + 1] - (int)T[bkt]);
+    tm = wave_max(tm);
+    if ((threadIdx.x & 63) == 0) atomicMax(tmaxp, tm);
+  }
   __syncthreads();
   const int tsteps = *tmaxp ? 32 - __clz(*tmaxp) : 0;
   const int dbg_flags = (int)counters[11];                       // timing aids: low byte MM_L2_STOP, bit 8 MM_L2_PHASES; 0 in normal operation

@@ -200,7 +200,8 @@ def main():
                 "parallelism": f"reads sharded x{world}, index replicated, RCCL all-reduce of EM sums",
                 "em_iterations": agg["em_iters"],
                 "per_step": {kk: st[kk] for kk in ("n_reads_long_enough", "n_reads_mapped", "n_mappings", "sum_sketch", "sum_hits",
-                                                   "n_candidates", "sum_l2_stream_entries", "sum_l2_evals", "n_ambiguous_sketch_reads")},
+                                                   "n_candidates", "sum_l2_stream_entries", "sum_l2_evals", "n_ambiguous_sketch_reads",
+                                                   "sum_hits_kept", "n_l2_rebuilds", "n_l2_wide_redo")},
                 "stage_ms": {kk: round(st[kk], 3) for kk in st if kk.startswith("ms_")},
                 "host_wall_ms": {kk: round(v, 3) for kk, v in agg.get("host_ms", {}).items()},
             },

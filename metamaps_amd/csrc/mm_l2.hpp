@@ -31,8 +31,10 @@
 
 namespace mm {
 
-constexpr int L2_MCAP = 8192;                      // max streamed entries handled by the skip path
-constexpr int L2_NBLK = L2_MCAP / 64;
+// The skip path keeps one mask word per 64 streamed entries ("word"); NWQ = words / 64 is a template parameter
+// (2: up to 8 192 streamed entries, reads up to ~18 kb at w=8; 8: 32 768 entries).  Bounds are taken per block of BW words,
+// BW the smallest power of two with at most 128 blocks (two per lane).
+constexpr int L2_NBLK_MAX = 128;
 constexpr int L2_TBITS = 10;                     // bucket table over the top hash bits of the sketch
 constexpr int L2_TSHIFT = 32 - L2_TBITS;
 constexpr int L2_TSIZE = (1 << L2_TBITS) + 1;
@@ -156,18 +158,18 @@ __device__ inline int l2_classify1(const uint32_t* __restrict__ Q, const uint16_
 
 // LDS layout: Q[smax] (shared by the waves of a workgroup) | per wave: D[smax] | mt | skip-ahead class arrays | slide scratch
 constexpr int L2_SCRATCH_BYTES = 64 * 4 + 64 + 64;             // step times, step-has-deletion, step-has-addition
-__host__ __device__ inline size_t l2_skip_bytes() { return (((size_t)(L2_NBLK + 1) * (3 * 8 + 3 * 2)) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t l2_skip_bytes(int nwq) { return (((size_t)(64 * nwq + 1) * (3 * 8 + 3 * 2)) + 15) & ~(size_t)15; }
 template <typename DT>
-__host__ __device__ inline size_t l2_wave_bytes(int smax, bool skip) {
+__host__ __device__ inline size_t l2_wave_bytes(int smax, bool skip, int nwq) {
   size_t b = (((size_t)smax * sizeof(DT) + 3) & ~(size_t)3) + (size_t)((smax + 31) / 32) * 4;
   b = (b + 15) & ~(size_t)15;
-  if (skip) b += l2_skip_bytes() + L2_SCRATCH_BYTES;
+  if (skip) b += l2_skip_bytes(nwq) + L2_SCRATCH_BYTES;
   return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t l2_qpart_bytes(int smax) { return ((size_t)(smax + L2_QPAD) * 4 + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t l2_q_bytes(int smax) { return l2_qpart_bytes(smax) + (((size_t)L2_TSIZE * 2 + 4 + 15) & ~(size_t)15); }
 template <typename DT>
-inline size_t l2_lds_bytes(int smax, bool skip, int waves) { return l2_q_bytes(smax) + (size_t)waves * l2_wave_bytes<DT>(smax, skip); }
+inline size_t l2_lds_bytes(int smax, bool skip, int waves, int nwq) { return l2_q_bytes(smax) + (size_t)waves * l2_wave_bytes<DT>(smax, skip, nwq); }
 
 // visibility of a wave's own LDS writes to its other lanes (workgroups may hold several independent waves)
 __device__ inline void wave_sync() {
@@ -177,7 +179,7 @@ __device__ inline void wave_sync() {
 
 // SKIP: exact skip-ahead on/off.  DT: counter width of D (uint8_t compact / uint16_t wide).  WAVES: candidates per
 // workgroup; with WAVES > 1 the waves of a workgroup map candidates of ONE read and share its sketch Q in LDS.
-template <bool SKIP, typename DT, int WAVES>
+template <bool SKIP, typename DT, int WAVES, int NWQ>
 __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restrict__ cand_read,
                                                 const uint32_t* __restrict__ sk_hash, const uint8_t* __restrict__ sk_strand,
                                                 const uint64_t* __restrict__ mz_off, const int32_t* __restrict__ sk_n,
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   extern __shared__ __align__(16) uint32_t lds[];
   uint32_t* Q = lds;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint8_t* wbase = (uint8_t*)lds + l2_q_bytes(smax) + (size_t)wave * l2_wave_bytes<DT>(smax, SKIP);
+  uint8_t* wbase = (uint8_t*)lds + l2_q_bytes(smax) + (size_t)wave * l2_wave_bytes<DT>(smax, SKIP, NWQ);
   DT* D = (DT*)wbase;
   uint32_t* mt = (uint32_t*)(wbase + (((size_t)smax * sizeof(DT) + 3) & ~(size_t)3));
   const int64_t c0 = WAVES > 1 ? (int64_t)grp_cand0[blockIdx.x] : (cand_list ? (int64_t)cand_list[blockIdx.x] : (int64_t)blockIdx.x);
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   // ds_bpermute) and shared_j = sb_j + popcount(pm_j below R_j).  Events inside the zone are rare and applied one by one.
   // Only times up to min(A_63, B_63) are certain (later entries of the other list could interleave), the rest of the
   // chunk is redone by the next round.
-  int* tst = (int*)(wbase + l2_wave_bytes<DT>(smax, false) + l2_skip_bytes());
+  int* tst = (int*)(wbase + l2_wave_bytes<DT>(smax, false, NWQ) + l2_skip_bytes(NWQ));
   uint8_t* fdel = (uint8_t*)(tst + 64);
   uint8_t* fadd = fdel + 64;
   auto rank_search = [&](int arr, int v) -> int {                // number of leading lanes whose (ascending) arr < v
@@ -409,7 +411,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   bool pending_rebuild = false;
   // sweep state (phase 1): the slide runs on across block boundaries as long as the next block's bound still passes
   int ub2[2] = {-1, -1};
-  int bk = 0, j0 = 0, stage = 0, blk_end = 0x7fffffff, nblk_s = 0;
+  int bk = 0, j0 = 0, stage = 0, blk_end = 0x7fffffff, nblk_s = 0, bspan = 64;
   bool run_stop = false;
   auto lane2 = [&](const int (&v)[2], int k) -> int { return __builtin_amdgcn_readlane(k < 64 ? v[0] : v[1], k & 63); };
   auto block_slide = [&](int b_stop) __attribute__((always_inline)) {
@@ -542,7 +544,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       while (b >= blk_end) {                                     // entered the next block: does its bound still pass?
         ++bk;
         if (bk >= nblk_s || (stage == 1 && bk == j0) || lane2(ub2, bk) < max(best, amin)) { run_stop = true; break; }
-        blk_end += 64;
+        blk_end += bspan;
       }
       if (run_stop) break;
       if (zone_exit) pending_rebuild = true;
@@ -579,23 +581,28 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   const bool classic = !SKIP || cnt < 2;
   if (!classic) {
     // phase 0: bounds first (becomes 1: sweep over the blocks whose bound passes), 2: every window
-    int phase = (M <= L2_MCAP && M > 192) ? 0 : 2;
+    constexpr int NWORDS_MAX = 64 * NWQ;
+    int phase = (M <= 64 * NWORDS_MAX && M > 192) ? 0 : 2;
     bool finished = false;
-    uint64_t* mAll = (uint64_t*)(wbase + l2_wave_bytes<DT>(smax, false));
-    uint64_t* mLo = mAll + (L2_NBLK + 1);
-    uint64_t* mA = mLo + (L2_NBLK + 1);
-    uint16_t* pAll = (uint16_t*)(mA + (L2_NBLK + 1));
-    uint16_t* pLo = pAll + (L2_NBLK + 1);
-    uint16_t* pA = pLo + (L2_NBLK + 1);
-    const int nblk = (int)((M + 63) >> 6);
+    uint64_t* mAll = (uint64_t*)(wbase + l2_wave_bytes<DT>(smax, false, NWQ));
+    uint64_t* mLo = mAll + (NWORDS_MAX + 1);
+    uint64_t* mA = mLo + (NWORDS_MAX + 1);
+    uint16_t* pAll = (uint16_t*)(mA + (NWORDS_MAX + 1));
+    uint16_t* pLo = pAll + (NWORDS_MAX + 1);
+    uint16_t* pA = pLo + (NWORDS_MAX + 1);
+    const int nwords = (int)((M + 63) >> 6);
+    int bwl = 0;                                                 // log2 of the words per block
+    while (((nwords + (1 << bwl) - 1) >> bwl) > L2_NBLK_MAX) ++bwl;
+    const int nblk = (nwords + (1 << bwl) - 1) >> bwl;
+    bspan = 64 << bwl;                                           // entries per block
     auto pfx = [&](const uint64_t* m, const uint16_t* p, int j) -> int {   // set bits among entries [first, j)
-      const int o = (int)(j - first), bk = o >> 6, bit = o & 63;
-      return (int)p[bk] + __popcll(m[bk] & ((1ull << bit) - 1ull));
+      const int o = (int)(j - first), wd = o >> 6, bit = o & 63;
+      return (int)p[wd] + __popcll(m[wd] & ((1ull << bit) - 1ull));
     };
     // The kernel is bound by instruction issue (one wave instruction per cycle and CU), not by HBM, so the streaming
-    // passes keep per-chunk work minimal: eight 512-byte loads off one address, masks handled as scalar bit sets
-    // (ballots combined with s_and/s_andn2), per-block results parked in lane (block & 63) of a register with
-    // v_writelane and written to LDS once at the end, prefix counts by one wave scan afterwards.
+    // passes keep per-word work minimal: eight 512-byte loads off one address, masks handled as scalar bit sets
+    // (ballots combined with s_and/s_andn2), per-word results parked in lane (word & 63) of register (word >> 6) and
+    // written to LDS once at the end, prefix counts by wave scans afterwards.
     auto load8 = [&](Rec (&x)[8], int base) {
       if (base + 512 <= last_end) {
         const Rec* __restrict__ pp = pos + base + lane;
@@ -606,24 +613,38 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
         for (int i = 0; i < 8; ++i) x[i] = pos[min(base + lane + 64 * i, nmax)];
       }
     };
-    auto valid_mask = [&](int chunk_base) -> uint64_t {           // lanes of a 64-entry chunk that lie below last_end
+    auto valid_mask = [&](int chunk_base) -> uint64_t {           // lanes of a 64-entry word that lie below last_end
       const int nv = last_end - chunk_base;
       return nv >= 64 ? ~0ull : (nv <= 0 ? 0ull : (1ull << nv) - 1ull);
     };
-    auto store_masks = [&](uint64_t* m, uint16_t* pf, const uint64_t (&reg)[2]) {   // lane l holds blocks l and l+64
-      const int c0 = __popcll(reg[0]), c1 = __popcll(reg[1]);
-      const int e0 = wave_excl_scan(c0, lane);
-      const int t0 = __builtin_amdgcn_readlane(e0, 63) + __builtin_amdgcn_readlane(c0, 63);
-      const int e1 = t0 + wave_excl_scan(c1, lane);
-      m[lane] = reg[0]; pf[lane] = (uint16_t)e0;
-      m[lane + 64] = reg[1]; pf[lane + 64] = (uint16_t)e1;
-      if (lane == 0) { m[L2_NBLK] = 0; pf[L2_NBLK] = (uint16_t)(__builtin_amdgcn_readlane(e1, 63) + __builtin_amdgcn_readlane(c1, 63)); }
+    auto store_masks = [&](uint64_t* m, uint16_t* pf, const uint64_t (&reg)[NWQ]) {   // lane l holds words l, l+64, ...
+      int carry = 0;
+#pragma unroll
+      for (int q = 0; q < NWQ; ++q) {
+        const int c = __popcll(reg[q]);
+        const int ex = carry + wave_excl_scan(c, lane);
+        m[lane + 64 * q] = reg[q]; pf[lane + 64 * q] = (uint16_t)ex;
+        carry = __builtin_amdgcn_readlane(ex, 63) + __builtin_amdgcn_readlane(c, 63);
+      }
+      if (lane == 0) { m[NWORDS_MAX] = 0; pf[NWORDS_MAX] = (uint16_t)carry; }
     };
-    // pass A: which entries carry a query hash; lane l keeps the masks of blocks l and l+64 and the position of their
+    // a group of eight words lives in one register set q = word >> 6 (groups never straddle): run `body` with q and
+    // "group entirely below last_end" as compile-time constants
+    auto dispatch = [&](int q, bool full, auto&& body) {
+#define MM_L2_CASE(QV)                                                                                                  \
+      if constexpr (NWQ > QV) if (q == QV) { if (full) body(std::integral_constant<int, QV>{}, std::true_type{});        \
+                                             else body(std::integral_constant<int, QV>{}, std::false_type{}); return; }
+      MM_L2_CASE(0) MM_L2_CASE(1) MM_L2_CASE(2) MM_L2_CASE(3) MM_L2_CASE(4) MM_L2_CASE(5) MM_L2_CASE(6) MM_L2_CASE(7)
+#undef MM_L2_CASE
+    };
+    static_assert(NWQ <= 8, "dispatch covers eight register sets");
+    // pass A: which entries carry a query hash; lane l keeps the masks of words l, l+64, ... and the position of their
     // first entry.  e_min of every block start (first entry with wpos >= wpos[block start] + cnt) afterwards, all blocks at
-    // once: the chunk by ranking the target among the chunk starts, the entry by a binary search inside that chunk.
-    int w0r[2] = {0x7fffffff, 0x7fffffff}, eLo[2] = {last_end, last_end};
-    uint64_t rAll[2] = {0, 0};
+    // once: the word by ranking the target among the word starts, the entry by a binary search inside that word.
+    int w0r[NWQ], eLo[2] = {last_end, last_end};
+    uint64_t rAll[NWQ];
+#pragma unroll
+    for (int q = 0; q < NWQ; ++q) { w0r[q] = 0x7fffffff; rAll[q] = 0; }
     auto pass_matched = [&]() {
       Rec nx[8];
       load8(nx, first);
@@ -639,43 +660,47 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
           for (int i = 0; i < 8; ++i) hh[i] = x[i].hash;
           l2_classify8(Q, T, tsteps, s, hh, cd);
         }
-        const int bk0 = (int)((base - first) >> 6);
-        // per-chunk bookkeeping specialised on (register half, group entirely below last_end): a handful of instructions
-        auto group = [&](auto qtag, auto fulltag) {
+        const int wd0 = (int)((base - first) >> 6);
+        dispatch(wd0 >> 6, base + 512 <= last_end, [&](auto qtag, auto fulltag) {
           constexpr int QH = decltype(qtag)::value;
           constexpr bool FULL = decltype(fulltag)::value;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {                          // (fully unrolled: x[] and cd[] must stay in registers)
-            const int bk = bk0 + i;
-            if (!FULL && bk >= nblk) continue;
+            const int wd = wd0 + i;
+            if (!FULL && wd >= nwords) continue;
             uint64_t m = __ballot(cd[i] >= 0);
             if (!FULL) m &= valid_mask(base + 64 * i);
-            const bool mine = lane == (bk & 63);
+            const bool mine = lane == (wd & 63);
             rAll[QH] = mine ? m : rAll[QH];
             const int wfirst = pw_wpos((uint32_t)__builtin_amdgcn_readfirstlane((int)x[i].pw));
             w0r[QH] = mine ? wfirst : w0r[QH];
           }
-        };
-        const bool full = base + 512 <= last_end;
-        if (bk0 < 64) { if (full) group(std::integral_constant<int, 0>{}, std::true_type{}); else group(std::integral_constant<int, 0>{}, std::false_type{}); }
-        else { if (full) group(std::integral_constant<int, 1>{}, std::true_type{}); else group(std::integral_constant<int, 1>{}, std::false_type{}); }
+        });
       }
       store_masks(mAll, pAll, rAll);
       {
-        const int tg0 = w0r[0] + cnt, tg1 = w0r[1] + cnt;        // (cnt >= 2 on this path; unused lanes hold INT_MAX and are masked below)
-        const bool v0 = lane < nblk, v1 = lane + 64 < nblk;
-        const int c0 = rank_search(w0r[0], tg0) + rank_search(w0r[1], tg0) - 1;
-        const int c1 = rank_search(w0r[0], tg1) + rank_search(w0r[1], tg1) - 1;
-        int lo0 = first + 64 * max(c0, 0), lo1 = first + 64 * max(c1, 0);
-        int hi0 = min(lo0 + 64, last_end), hi1 = min(lo1 + 64, last_end);
-        for (int it = 0; it < 7; ++it) {                         // two independent searches per lane, steps interleaved
-          const int m0 = min((lo0 + hi0) >> 1, nmax), m1 = min((lo1 + hi1) >> 1, nmax);
-          const int p0 = pw_wpos(pos[m0].pw), p1 = pw_wpos(pos[m1].pw);
-          if (lo0 < hi0) { if (p0 < tg0) lo0 = m0 + 1; else hi0 = m0; }
-          if (lo1 < hi1) { if (p1 < tg1) lo1 = m1 + 1; else hi1 = m1; }
+        // lane l owns blocks l and l+64; their first words are (l << bwl) and ((l + 64) << bwl)
+        int tg[2], lo[2], hi[2];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const int wd = (lane + 64 * qq) << bwl;
+          int v = 0x7fffffff;
+#pragma unroll
+          for (int q = 0; q < NWQ; ++q) { const int t = __shfl(w0r[q], wd & 63, 64); if ((wd >> 6) == q) v = t; }
+          tg[qq] = v == 0x7fffffff ? v : v + cnt;                // (cnt >= 2 on this path; unused blocks hold INT_MAX and are masked below)
+          int c = -1;
+#pragma unroll
+          for (int q = 0; q < NWQ; ++q) c += rank_search(w0r[q], tg[qq]);
+          lo[qq] = first + 64 * max(c, 0); hi[qq] = min(lo[qq] + 64, last_end);
         }
-        eLo[0] = v0 ? lo0 : last_end;
-        eLo[1] = v1 ? lo1 : last_end;
+        for (int it = 0; it < 7; ++it) {                         // two independent searches per lane, steps interleaved
+          const int m0 = min((lo[0] + hi[0]) >> 1, nmax), m1 = min((lo[1] + hi[1]) >> 1, nmax);
+          const int p0 = pw_wpos(pos[m0].pw), p1 = pw_wpos(pos[m1].pw);
+          if (lo[0] < hi[0]) { if (p0 < tg[0]) lo[0] = m0 + 1; else hi[0] = m0; }
+          if (lo[1] < hi[1]) { if (p1 < tg[1]) lo[1] = m1 + 1; else hi[1] = m1; }
+        }
+        eLo[0] = lane < nblk ? lo[0] : last_end;
+        eLo[1] = lane + 64 < nblk ? lo[1] : last_end;
       }
       wave_sync();
     };
@@ -683,31 +708,30 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     auto pass_low = [&](int r0) {
       const bool every = r0 >= s;
       const uint32_t qr0 = every ? 0xffffffffu : Q[r0];
-      uint64_t rLo[2] = {0, 0}, rA[2] = {0, 0};
-      for (int bk0 = 0; bk0 < nblk; bk0 += 8) {
+      uint64_t rLo[NWQ], rA[NWQ];
+#pragma unroll
+      for (int q = 0; q < NWQ; ++q) { rLo[q] = 0; rA[q] = 0; }
+      for (int wd0 = 0; wd0 < nwords; wd0 += 8) {
         Rec x[8];
-        load8(x, first + bk0 * 64);
-        auto group = [&](auto qtag, auto fulltag) {
+        load8(x, first + wd0 * 64);
+        dispatch(wd0 >> 6, first + wd0 * 64 + 512 <= last_end, [&](auto qtag, auto fulltag) {
           constexpr int QH = decltype(qtag)::value;
           constexpr bool FULL = decltype(fulltag)::value;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const int bk = bk0 + i;
-            if (!FULL && bk >= nblk) continue;
-            const int l = bk & 63;
+            const int wd = wd0 + i;
+            if (!FULL && wd >= nwords) continue;
+            const int l = wd & 63;
             const uint64_t mk = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rAll[QH] >> 32), l) << 32) |
                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rAll[QH], l);
             uint64_t below = __ballot(every || x[i].hash < qr0);
-            if (!FULL) below &= valid_mask(first + bk * 64);
+            if (!FULL) below &= valid_mask(first + wd * 64);
             const uint64_t first_occ = __ballot(!(x[i].pw & PW_DP));
             const bool mine = lane == l;
             rLo[QH] = mine ? (below & mk) : rLo[QH];
             rA[QH] = mine ? (below & ~mk & first_occ) : rA[QH];
           }
-        };
-        const bool full = first + bk0 * 64 + 512 <= last_end;
-        if (bk0 < 64) { if (full) group(std::integral_constant<int, 0>{}, std::true_type{}); else group(std::integral_constant<int, 0>{}, std::false_type{}); }
-        else { if (full) group(std::integral_constant<int, 1>{}, std::true_type{}); else group(std::integral_constant<int, 1>{}, std::false_type{}); }
+        });
       }
       store_masks(mLo, pLo, rLo);
       store_masks(mA, pA, rA);
@@ -721,8 +745,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       pass_matched();
       lap(1);
       if (dbg_stop == 2) return;
-      // per block of 64 b's: largest window [bF, eHi), smallest window [bL, eLo)
-      // (lane l owns blocks l and l+64; L2_NBLK == 128)
+      // per block of `bspan` b's: largest window [bF, eHi), smallest window [bL, eLo)   (lane l owns blocks l and l+64)
       {
         const int up0 = __shfl_down(eLo[0], 1, 64), up1 = __shfl_down(eLo[1], 1, 64);   // e_min of the next block start
         const int e64 = __builtin_amdgcn_readlane(eLo[1], 0);
@@ -730,10 +753,10 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
         eHi[1] = lane == 63 ? last_end : up1;
       }
       for (int q = 0; q < 2; ++q) {
-        const int bk = lane + 64 * q;
+        const int bq = lane + 64 * q;
         ub_all[q] = -1;
-        if (bk < nblk) {
-          const int bF = first + (int)bk * 64, bL = min(bF + 63, last_end - 1);
+        if (bq < nblk) {
+          const int bF = first + bq * bspan, bL = min(bF + bspan - 1, last_end - 1);
           if (!(bL + 1 < last_end)) eHi[q] = last_end;
           if (eLo[q] < last_end) ub_all[q] = pfx(mAll, pAll, eHi[q]) - pfx(mAll, pAll, bF);
         } else eLo[q] = eHi[q] = last_end;
@@ -744,11 +767,11 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       else {
         // r0 without a probe: the pivot rank of a window is the number of query hashes among the s smallest of
         // query + window-only hashes.  For the most promising block (fewest window-only hashes, so the largest
-        // pivot) that is hypergeometric with mean s*s/(s+wo); r0 = mean + 2.5 sigma (tuned on the bench workload).  A wrong guess costs only
-        // tightness: validity (r0 + a >= s) is checked per block below.
+        // pivot) that is hypergeometric with mean s*s/(s+wo); r0 = mean + 2.5 sigma (tuned on the bench workload).
+        // A wrong guess costs only tightness: validity (r0 + a >= s) is checked per block below.
         const int key = max(ub_all[0], ub_all[1]) == ubmax ? ((ub_all[0] == ubmax) ? lane : lane + 64) : 1 << 20;
         const int bkb = wave_min(key);
-        const int bLb = min(first + bkb * 64 + 63, last_end - 1);
+        const int bLb = min(first + bkb * bspan + bspan - 1, last_end - 1);
         const int wo = max(lane2(eLo, bkb) - bLb - ubmax, 0);
         const float pq = (float)s / (float)(s + wo);
         const float sigma = sqrtf((float)s * pq * (1.0f - pq) * (1.0f - pq));
@@ -760,7 +783,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
           const int bq = lane + 64 * q;
           int u = -1;
           if (bq < nblk && eLo[q] < last_end) {
-            const int bF = first + (int)bq * 64, bL = min(bF + 63, last_end - 1);
+            const int bF = first + bq * bspan, bL = min(bF + bspan - 1, last_end - 1);
             const int a = eLo[q] > bL ? pfx(mA, pA, eLo[q]) - pfx(mA, pA, bL) : 0;
             u = (r0 + a >= s) ? pfx(mLo, pLo, eHi[q]) - pfx(mLo, pLo, bF) : ub_all[q];
           }
@@ -795,7 +818,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
           ++bk;
         }
         if (!found) break;
-        nb = first + bk * 64; blk_end = nb + 64; run_stop = false;
+        nb = first + bk * bspan; blk_end = nb + bspan; run_stop = false;
         need_rb = !(live && b == nb);
         if (need_rb) ne = lane2(eLo, bk);
       } else ne = e_min(first);                                  // :473, :489, MIIteratorL2.hpp:62

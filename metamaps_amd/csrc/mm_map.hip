@@ -94,7 +94,9 @@ __global__ void __launch_bounds__(256) sketch_radix_kernel(const Rec* __restrict
                                                            uint8_t* __restrict__ sk_strand, int32_t* __restrict__ sk_n, uint8_t* __restrict__ amb) {
   using Sort = rocprim::block_radix_sort<uint32_t, 256, IPT, uint16_t>;
   using Scan = rocprim::block_scan<int, 256>;
-  __shared__ union { typename Sort::storage_type sort; typename Scan::storage_type scan; } tmp;
+  union Tmp { typename Sort::storage_type sort; typename Scan::storage_type scan; };
+  extern __shared__ __align__(16) unsigned char sketch_dyn[];    // dynamic: 64 elements per thread need more than 64 KB
+  Tmp& tmp = *reinterpret_cast<Tmp*>(sketch_dyn);
   __shared__ uint32_t last_key[256];
   __shared__ uint8_t last_st[256];
   __shared__ int s_amb;
@@ -199,21 +201,21 @@ constexpr int HF_BITS = 13;
 constexpr uint32_t HF_K1 = 0x9E3779B1u, HF_K2 = 0x85EBCA77u;
 __device__ inline uint32_t hf_base(uint32_t contig, uint32_t bin) { return contig * HF_K1 + bin * HF_K2; }
 __device__ inline uint32_t hf_slot_of(uint32_t base) { return base >> (32 - HF_BITS); }
-constexpr int HF_STAGE = 2048;     // survivors staged per read (8 B each); reads with more are re-filtered by the write kernel
+// survivors are staged per read (8 B each, capacity 1024 + 2 x sketch size: stage_off); reads with more are re-filtered by the write kernel
 template <bool WRITE>
 __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint64_t* __restrict__ off, const int32_t* __restrict__ sk_n,
                                                          const uint32_t* __restrict__ probe_cnt, const uint64_t* __restrict__ probe_start,
                                                          const int32_t* __restrict__ read_len, const int32_t* __restrict__ min_hits,
                                                          uint32_t* __restrict__ surv_n, const uint64_t* __restrict__ read_hit_off,
-                                                         uint64_t* __restrict__ hits, uint64_t* __restrict__ stage, int dbg) {
+                                                         uint64_t* __restrict__ hits, uint64_t* __restrict__ stage, const uint64_t* __restrict__ stage_off, int dbg) {
   __shared__ uint32_t cnt[HF_SLOTS];
   __shared__ uint32_t cursor;
   const int r = blockIdx.x;
   if (WRITE) {                                                   // staged reads only need a copy
     const uint32_t n_s = surv_n[r];
-    if (n_s <= HF_STAGE) {
+    if (n_s <= (uint32_t)(stage_off[r + 1] - stage_off[r])) {
       const uint64_t wb = read_hit_off[r];
-      for (uint32_t i = threadIdx.x; i < n_s; i += 256) hits[wb + i] = stage[(size_t)r * HF_STAGE + i];
+      for (uint32_t i = threadIdx.x; i < n_s; i += 256) hits[wb + i] = stage[stage_off[r] + i];
       return;
     }
   }
@@ -283,6 +285,8 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   if (dbg) { if (!WRITE && threadIdx.x == 0) surv_n[r] = 0; return; }   // timing aid (MM_HF_DBG): pass 1 only
   uint32_t mine = 0;
   const uint64_t wbase = WRITE ? read_hit_off[r] : 0;
+  const uint64_t stage_base = stage_off[r];
+  const uint32_t stage_cap = (uint32_t)(stage_off[r + 1] - stage_base);
   for_each_hit([&](uint64_t h) {
     const uint32_t ct = (uint32_t)(h >> 32), bin = __umulhi((uint32_t)pw_wpos((uint32_t)h), inv_len);
     const uint32_t hb = hf_base(ct, bin);
@@ -291,7 +295,7 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
     if (c0 + cl >= (uint32_t)m || c0 + cr >= (uint32_t)m) {
       const uint32_t slot = atomicAdd(&cursor, 1u);
       if (WRITE) hits[wbase + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
-      else if (slot < HF_STAGE) stage[(size_t)r * HF_STAGE + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
+      else if (slot < stage_cap) stage[stage_base + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
     }
   });
   (void)mine;
@@ -526,11 +530,21 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     for (auto& cls : make_classes(cnt, 256)) {
       DBuf<int32_t> list(cls.reads.size());
       list.upload(cls.reads.data(), cls.reads.size(), st);
-      if (cls.npow2 <= 4096) {                                   // radix sort in LDS: 4 / 8 / 16 elements per thread
+      if (cls.npow2 <= 16384) {                                  // radix sort in LDS: 4 ... 64 elements per thread
         const unsigned nb = (unsigned)cls.reads.size();
-        if (cls.npow2 <= 1024) sketch_radix_kernel<4><<<dim3(nb), dim3(256), 0, st>>>(M->mz.rec.p, M->mz.off.p, list.p, M->sk_hash.p, M->sk_strand.p, M->sk_n.p, M->amb.p);
-        else if (cls.npow2 <= 2048) sketch_radix_kernel<8><<<dim3(nb), dim3(256), 0, st>>>(M->mz.rec.p, M->mz.off.p, list.p, M->sk_hash.p, M->sk_strand.p, M->sk_n.p, M->amb.p);
-        else sketch_radix_kernel<16><<<dim3(nb), dim3(256), 0, st>>>(M->mz.rec.p, M->mz.off.p, list.p, M->sk_hash.p, M->sk_strand.p, M->sk_n.p, M->amb.p);
+        auto launch = [&](auto ipt_tag) {
+          constexpr int IPT = decltype(ipt_tag)::value;
+          using SortT = rocprim::block_radix_sort<uint32_t, 256, IPT, uint16_t>;
+          using ScanT = rocprim::block_scan<int, 256>;
+          const size_t lds = std::max(sizeof(typename SortT::storage_type), sizeof(typename ScanT::storage_type)) + 16;
+          if (lds > 48 * 1024) MM_HIP(hipFuncSetAttribute((const void*)sketch_radix_kernel<IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          sketch_radix_kernel<IPT><<<dim3(nb), dim3(256), lds, st>>>(M->mz.rec.p, M->mz.off.p, list.p, M->sk_hash.p, M->sk_strand.p, M->sk_n.p, M->amb.p);
+        };
+        if (cls.npow2 <= 1024) launch(std::integral_constant<int, 4>{});
+        else if (cls.npow2 <= 2048) launch(std::integral_constant<int, 8>{});
+        else if (cls.npow2 <= 4096) launch(std::integral_constant<int, 16>{});
+        else if (cls.npow2 <= 8192) launch(std::integral_constant<int, 32>{});
+        else launch(std::integral_constant<int, 64>{});
         MM_KERNEL_CHECK();
       } else if (cls.npow2 <= LDS_SORT_MAX) {
         size_t lds = (size_t)cls.npow2 * 8;
@@ -655,12 +669,17 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   const char* nf_env = getenv("MM_NO_HIT_FILTER");               // parity tests of the raw hit list
   const bool use_filter = !(nf_env && nf_env[0] == '1');
   DBuf<uint32_t> surv;
-  DBuf<uint64_t> stage;
+  DBuf<uint64_t> stage, stage_off;
   if (use_filter && n > 0) {
     surv.alloc((size_t)n + 1); surv.zero(st);
-    stage.alloc((size_t)n * HF_STAGE);
+    std::vector<uint64_t> h_stage_off((size_t)n + 1, 0);
+    const char* cap_env = getenv("MM_HF_STAGE_CAP");              // tests: a tiny capacity forces the re-filtering write path
+    for (int64_t r = 0; r < n; ++r)
+      h_stage_off[(size_t)r + 1] = h_stage_off[(size_t)r] + (M->h_sk_n[(size_t)r] > 0 ? (cap_env ? (uint64_t)atoi(cap_env) : 1024 + 2 * (uint64_t)M->h_sk_n[(size_t)r]) : 0);
+    stage_off.alloc((size_t)n + 1); stage_off.upload(h_stage_off.data(), h_stage_off.size(), st);
+    stage.alloc((size_t)std::max<uint64_t>(h_stage_off[(size_t)n], 1));
     hit_filter_kernel<false><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
-                                                                   M->min_hits.p, surv.p, nullptr, nullptr, stage.p, getenv("MM_HF_DBG") ? atoi(getenv("MM_HF_DBG")) : 0);
+                                                                   M->min_hits.p, surv.p, nullptr, nullptr, stage.p, stage_off.p, getenv("MM_HF_DBG") ? atoi(getenv("MM_HF_DBG")) : 0);
     MM_KERNEL_CHECK();
     exclusive_scan_u32_u64(surv.p, n, M->read_hit_off.p, scan_tmp, st);
   } else {
@@ -676,7 +695,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   if (total_hits > 0) {
     if (use_filter)
       hit_filter_kernel<true><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
-                                                                    M->min_hits.p, surv.p, M->read_hit_off.p, M->hits.p, stage.p, 0);
+                                                                    M->min_hits.p, surv.p, M->read_hit_off.p, M->hits.p, stage.p, stage_off.p, 0);
     else
       gather_hits_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, hit_off.p, M->hits.p);
     MM_KERNEL_CHECK();
@@ -741,8 +760,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     const int smax = M->smax;
     const char* full_env = getenv("MM_L2_FULL");                 // cross-check switch: evaluate every window
     const bool skip = !(full_env && full_env[0] == '1');
-    const size_t lds_wide = l2_lds_bytes<uint16_t>(smax, skip, 1);
-    const size_t lds_c4 = l2_lds_bytes<uint8_t>(smax, true, 4);
+    const size_t lds_wide = l2_lds_bytes<uint16_t>(smax, skip, 1, 8);
     MM_REQUIRE(lds_wide <= 160 * 1024, MM_ERR_LIMIT, "sketch too large for the L2 window state in LDS (read longer than ~115 kb at w=8)");
     auto set_lds = [&](const void* fn, size_t bytes) { if (bytes > 64 * 1024) MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); };
     DBuf<unsigned long long> counters(16); counters.zero(st);
@@ -752,39 +770,82 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     DBuf<unsigned int> ovf_n(1); ovf_n.zero(st);
     const size_t t_l2 = T.begin(&M->stats.ms_l2);
     if (!skip) {
-      set_lds((const void*)l2_kernel<false, uint16_t, 1>, lds_wide);
-      l2_kernel<false, uint16_t, 1><<<dim3((unsigned)ncand), dim3(64), lds_wide, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+      set_lds((const void*)l2_kernel<false, uint16_t, 1, 8>, lds_wide);
+      l2_kernel<false, uint16_t, 1, 8><<<dim3((unsigned)ncand), dim3(64), lds_wide, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
           M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, nullptr, nullptr, nullptr);
       MM_KERNEL_CHECK();
-    } else if (lds_c4 <= 160 * 1024) {
-      // compact path: four candidates of one read per workgroup share the sketch; 8-bit gap counters
-      std::vector<int32_t> g0, gn;
-      for (int64_t r = 0; r < n; ++r)
-        for (uint64_t c0 = M->h_cand_off[(size_t)r]; c0 < M->h_cand_off[(size_t)r + 1]; c0 += 4) {
-          g0.push_back((int32_t)c0);
-          gn.push_back((int32_t)std::min<uint64_t>(4, M->h_cand_off[(size_t)r + 1] - c0));
+    } else {
+      // Reads are grouped by sketch size so that one long read does not size the LDS state (and the occupancy) of all:
+      //   A  s <= 3072   (reads up to ~14 kb at w=8)  compact: 4 candidates of a read per workgroup share the sketch,
+      //                                                8-bit gap counters, masks for 8 192 streamed entries
+      //   B  s <= 7168   (~32 kb)                      the same with masks for 32 768 entries
+      //   D  s <= 16384  (~74 kb)                      two candidates per workgroup, otherwise as B
+      //   C  larger                                    one wave per workgroup, 16-bit counters, 32 768 entries
+      // Candidates whose 8-bit counters saturate are redone by the C kernel.
+      std::vector<int32_t> gA0, gAn, gB0, gBn, gD0, gDn, listC;
+      int smA = 0, smB = 0, smC = 0, smD = 0;
+      for (int64_t r = 0; r < n; ++r) {
+        const uint64_t c_lo = M->h_cand_off[(size_t)r], c_hi = M->h_cand_off[(size_t)r + 1];
+        if (c_lo == c_hi) continue;
+        const int sr = M->h_sk_n[(size_t)r];
+        if (sr <= 7168) {
+          auto& g0 = sr <= 3072 ? gA0 : gB0; auto& gn = sr <= 3072 ? gAn : gBn;
+          (sr <= 3072 ? smA : smB) = std::max(sr <= 3072 ? smA : smB, sr);
+          for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 4) { g0.push_back((int32_t)c0); gn.push_back((int32_t)std::min<uint64_t>(4, c_hi - c0)); }
+        } else if (sr <= 16384) {
+          smD = std::max(smD, sr);
+          for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 2) { gD0.push_back((int32_t)c0); gDn.push_back((int32_t)std::min<uint64_t>(2, c_hi - c0)); }
+        } else {
+          smC = std::max(smC, sr);
+          for (uint64_t c0 = c_lo; c0 < c_hi; ++c0) listC.push_back((int32_t)c0);
         }
-      DBuf<int32_t> d_g0(g0.size()), d_gn(gn.size());
-      d_g0.upload(g0.data(), g0.size(), st); d_gn.upload(gn.data(), gn.size(), st);
-      set_lds((const void*)l2_kernel<true, uint8_t, 4>, lds_c4);
-      l2_kernel<true, uint8_t, 4><<<dim3((unsigned)g0.size()), dim3(256), lds_c4, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-          M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, d_g0.p, d_gn.p, nullptr, ovf.p, ovf_n.p);
-      MM_KERNEL_CHECK();
+      }
+      DBuf<int32_t> d_gA0(gA0.size()), d_gAn(gAn.size()), d_gB0(gB0.size()), d_gBn(gBn.size()), d_listC(listC.size());
+      if (!gA0.empty()) {
+        d_gA0.upload(gA0.data(), gA0.size(), st); d_gAn.upload(gAn.data(), gAn.size(), st);
+        const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 4, 2);
+        set_lds((const void*)l2_kernel<true, uint8_t, 4, 2>, lds);
+        l2_kernel<true, uint8_t, 4, 2><<<dim3((unsigned)gA0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p);
+        MM_KERNEL_CHECK();
+      }
+      if (!gB0.empty()) {
+        d_gB0.upload(gB0.data(), gB0.size(), st); d_gBn.upload(gBn.data(), gBn.size(), st);
+        const size_t lds = l2_lds_bytes<uint8_t>(smB, true, 4, 8);
+        set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
+        l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gB0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smB, M->l2.p, counters.p, d_gB0.p, d_gBn.p, nullptr, ovf.p, ovf_n.p);
+        MM_KERNEL_CHECK();
+      }
+      DBuf<int32_t> d_gD0(gD0.size()), d_gDn(gDn.size());
+      if (!gD0.empty()) {
+        d_gD0.upload(gD0.data(), gD0.size(), st); d_gDn.upload(gDn.data(), gDn.size(), st);
+        const size_t lds = l2_lds_bytes<uint8_t>(smD, true, 2, 8);
+        set_lds((const void*)l2_kernel<true, uint8_t, 2, 8>, lds);
+        l2_kernel<true, uint8_t, 2, 8><<<dim3((unsigned)gD0.size()), dim3(128), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p);
+        MM_KERNEL_CHECK();
+      }
+      if (!listC.empty()) {
+        d_listC.upload(listC.data(), listC.size(), st);
+        const size_t lds = l2_lds_bytes<uint16_t>(smC, true, 1, 8);
+        set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
+        l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)listC.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smC, M->l2.p, counters.p, nullptr, nullptr, d_listC.p, nullptr, nullptr);
+        MM_KERNEL_CHECK();
+      }
       unsigned int h_ovf = 0;
       MM_HIP(hipMemcpyAsync(&h_ovf, ovf_n.p, sizeof h_ovf, hipMemcpyDeviceToHost, st));
-      MM_HIP(hipStreamSynchronize(st));                          // also keeps g0/gn alive until the upload is done
+      MM_HIP(hipStreamSynchronize(st));                          // also keeps the host lists alive until the uploads are done
       if (h_ovf) {                                               // saturated 8-bit counters: redo those candidates with 16-bit ones
-        set_lds((const void*)l2_kernel<true, uint16_t, 1>, lds_wide);
-        l2_kernel<true, uint16_t, 1><<<dim3(h_ovf), dim3(64), lds_wide, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr);
+        const int smO = std::max(std::max(smA, smB), smD);
+        const size_t lds = l2_lds_bytes<uint16_t>(smO, true, 1, 8);
+        set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
+        l2_kernel<true, uint16_t, 1, 8><<<dim3(h_ovf), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smO, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr);
         MM_KERNEL_CHECK();
       }
       M->stats.n_l2_wide_redo = (int64_t)h_ovf;
-    } else {
-      set_lds((const void*)l2_kernel<true, uint16_t, 1>, lds_wide);
-      l2_kernel<true, uint16_t, 1><<<dim3((unsigned)ncand), dim3(64), lds_wide, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-          M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, nullptr, nullptr, nullptr);
-      MM_KERNEL_CHECK();
     }
     l2_stats_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(ncand, 256), 1024)), dim3(256), 0, st>>>(M->l2.p, ncand, counters.p);
     MM_KERNEL_CHECK();

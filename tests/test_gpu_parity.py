@@ -323,6 +323,26 @@ def test_em_from_mapping_equals_host_built_problem(ctx):
     e_host.close(); e_dev.close(); M.close(); idx.close(); reads.close(); ref.close()
 
 
+def test_hit_filter_staging_overflow_path(ctx, monkeypatch):
+    """survivors beyond the per-read staging capacity are re-filtered by the write kernel: same hits either way"""
+    ref = ctx.synth_reference(seed=6, n_species=40, strains_per_species=4, genome_len=300_000, strain_divergence=0.02, genus_divergence=0.08)
+    reads, _ = ctx.synth_reads(ref, seed=10, n_reads=1000, read_len=6000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.1, n_abundant=30)
+    idx = ctx.index(ref, 16, 8)
+    res = {}
+    for cap in (None, "16"):
+        if cap:
+            monkeypatch.setenv("MM_HF_STAGE_CAP", cap)
+        M = ctx.map_batch(idx, reads, 16, 8)
+        off, c, w = M.debug_hits()
+        ro, rec = M.fetch()
+        res[cap] = (off.copy(), np.sort(c.astype(np.int64) << 32 | w), ro.copy(), rec.copy())   # hits per read are sorted later: compare as sets per batch
+        M.close()
+    monkeypatch.delenv("MM_HF_STAGE_CAP")
+    assert np.array_equal(res[None][0], res["16"][0]) and np.array_equal(res[None][1], res["16"][1])
+    assert np.array_equal(res[None][2], res["16"][2]) and np.array_equal(res[None][3], res["16"][3])
+    idx.close(); reads.close(); ref.close()
+
+
 def test_l1_wave_scan_equals_serial_loop(ctx, monkeypatch):
     """K4b one wavefront per read against the literal one-thread-per-read loop (MM_L1_SERIAL=1)."""
     ref = ctx.synth_reference(seed=6, n_species=40, strains_per_species=4, genome_len=300_000, strain_divergence=0.02, genus_divergence=0.08)

@@ -493,7 +493,11 @@ struct StageTimer {
 };
 }  // namespace
 
-struct AmbState { std::vector<int64_t> reads; std::vector<uint64_t> dof; DBuf<uint64_t> d_so, d_do; };
+struct AmbState {
+  std::vector<int64_t> reads; std::vector<uint64_t> dof; DBuf<uint64_t> d_so, d_do;
+  std::vector<uint8_t> sv; std::vector<int32_t> scnt; std::atomic<int> mismatch{0}; std::thread bg;
+  ~AmbState() { if (bg.joinable()) bg.join(); }
+};
 
 void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_map_params& P, mm_mapping* M) {
   hipStream_t st = ctx->stream;
@@ -586,19 +590,19 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       gather_amb_kernel<<<dim3((unsigned)na), dim3(256), 0, st>>>(M->mz.rec.p, d_so.p, d_do.p, comp.p);
       MM_KERNEL_CHECK();
       // The library sort of ~1 % of the reads is the only per-read host work of a batch.  Only the L2 strand vote needs its
-      // result, so it runs (spread over threads) while the device is busy with the probe and the seed-hit filter.
+      // result, so it runs on host threads while the device goes through K3 and K4.
       auto hr = std::make_shared<std::vector<Rec>>(comp.to_host(st));
       auto st_amb = std::make_shared<AmbState>();
       st_amb->reads = amb_reads; st_amb->dof = dof; st_amb->d_so = std::move(d_so); st_amb->d_do = std::move(d_do);
-      amb_finish = [this_M = M, hr, st_amb, st]() {
-        mm_mapping* M = this_M;
+      // host part (no device calls): starts now on its own threads; joined right before the L2 launch
+      st_amb->sv.assign((size_t)dof[na], 0);
+      st_amb->scnt.assign(na, 0);
+      st_amb->bg = std::thread([this_M = M, hr, st_amb]() {
+        const mm_mapping* M = this_M;
         const std::vector<int64_t>& amb_reads = st_amb->reads;
         const std::vector<uint64_t>& dof = st_amb->dof;
         const size_t na = amb_reads.size();
-        std::vector<uint8_t> sv((size_t)dof[na], 0);
-        std::vector<int32_t> scnt(na);
         std::atomic<size_t> next{0};
-        std::atomic<int> mismatch{0};
         auto worker = [&]() {
           std::vector<HostMz> v;
           for (size_t i = next.fetch_add(1); i < na; i = next.fetch_add(1)) {
@@ -608,19 +612,24 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
             std::sort(v.begin(), v.end(), host_less_by_hash);
             auto ue = std::unique(v.begin(), v.end(), host_eq_by_hash);
             const size_t sN = (size_t)(ue - v.begin());
-            if ((int64_t)sN != M->h_sk_n[(size_t)amb_reads[i]]) mismatch = 1;
-            for (size_t j = 0; j < sN; ++j) sv[(size_t)dof[i] + j] = v[j].strand == 1 ? 1 : 0;
-            scnt[i] = (int32_t)sN;
+            if ((int64_t)sN != M->h_sk_n[(size_t)amb_reads[i]]) st_amb->mismatch = 1;
+            for (size_t j = 0; j < sN; ++j) st_amb->sv[(size_t)dof[i] + j] = v[j].strand == 1 ? 1 : 0;
+            st_amb->scnt[i] = (int32_t)sN;
           }
         };
-        const unsigned nthr = std::max(1u, std::min(16u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)((na + 31) / 32))));
+        const unsigned nthr = std::max(1u, std::min(32u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)((na + 15) / 16))));
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
         worker();
         for (auto& t : pool) t.join();
-        MM_REQUIRE(mismatch == 0, MM_ERR_DEVICE, "sketch size disagrees between device and host tie-break");
-        DBuf<uint8_t> d_sv(sv.size()); d_sv.upload(sv.data(), sv.size(), st);
-        DBuf<int32_t> d_cnt(na); d_cnt.upload(scnt.data(), na, st);
+      });
+      amb_finish = [this_M = M, st_amb, st]() {
+        mm_mapping* M = this_M;
+        st_amb->bg.join();
+        MM_REQUIRE(st_amb->mismatch == 0, MM_ERR_DEVICE, "sketch size disagrees between device and host tie-break");
+        const size_t na = st_amb->reads.size();
+        DBuf<uint8_t> d_sv(st_amb->sv.size()); d_sv.upload(st_amb->sv.data(), st_amb->sv.size(), st);
+        DBuf<int32_t> d_cnt(na); d_cnt.upload(st_amb->scnt.data(), na, st);
         scatter_strand_kernel<<<dim3((unsigned)na), dim3(256), 0, st>>>(d_sv.p, st_amb->d_so.p, st_amb->d_do.p, d_cnt.p, M->sk_strand.p);
         MM_KERNEL_CHECK();
         MM_HIP(hipStreamSynchronize(st));                        // host vectors above are the H2D sources
@@ -686,7 +695,6 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     read_hit_bounds_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(M->mz.off.p, hit_off.p, n, M->read_hit_off.p);
     MM_KERNEL_CHECK();
   }
-  if (amb_finish) { amb_finish(); amb_finish = nullptr; }          // overlaps with the kernels queued above
   M->h_read_hit_off = M->read_hit_off.to_host(st);
   const int64_t total_hits = (int64_t)M->h_read_hit_off[(size_t)n];
   M->stats.sum_hits = (int64_t)raw_hits;
@@ -768,6 +776,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       const char* ds = getenv("MM_L2_STOP"); unsigned long long v = (unsigned long long)((ds ? atoi(ds) & 0xff : 0) | (getenv("MM_L2_PHASES") ? 0x100 : 0)); MM_HIP(hipMemcpyAsync(counters.p + 11, &v, sizeof v, hipMemcpyHostToDevice, st)); MM_HIP(hipStreamSynchronize(st)); }   // timing aid: leave the kernel after phase n (results are then meaningless)
     DBuf<int32_t> ovf((size_t)ncand);
     DBuf<unsigned int> ovf_n(1); ovf_n.zero(st);
+    if (amb_finish) { amb_finish(); amb_finish = nullptr; }        // strands of ambiguous sketches: needed by the vote only
     const size_t t_l2 = T.begin(&M->stats.ms_l2);
     if (!skip) {
       set_lds((const void*)l2_kernel<false, uint16_t, 1, 8>, lds_wide);
@@ -856,6 +865,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     M->stats.n_l2_rebuilds = (int64_t)hc[2];
     if (getenv("MM_L2_PHASES")) { fprintf(stderr, "l2 rounds %llu; ", hc[15]); fprintf(stderr, "l2 phase clocks [setup passA bounds rebuild slide passB vote]:"); for (int i = 0; i < 7; ++i) fprintf(stderr, " %.3g", (double)hc[3 + i]); fprintf(stderr, "\n"); }
     // ---- compaction
+    if (amb_finish) { amb_finish(); amb_finish = nullptr; }
     const size_t t_cp = T.begin(&M->stats.ms_compact);
     DBuf<uint32_t> flag((size_t)ncand);
     DBuf<uint64_t> rank((size_t)ncand + 1);

@@ -353,7 +353,7 @@ int mm_debug_sketch(mm_mapping* m, int64_t* offsets, uint32_t* hash, int32_t* st
       for (int i = 0; i < m->h_sk_n[(size_t)r]; ++i, ++o) {
         size_t src = (size_t)m->mz.h_off[(size_t)r] + (size_t)i;
         if (hash) hash[o] = hh[src];
-        if (strand) strand[o] = hs[src] ? 1 : -1;
+        if (strand) strand[o] = (hs[src] & 1) ? 1 : -1;       // (bit 1: duplicate of the other strand not resolved, mm_map.hip K2)
       }
   });
 }

@@ -189,7 +189,8 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
                                                 const int32_t* __restrict__ grp_cand0 /* WAVES>1: first candidate of the group */,
                                                 const int32_t* __restrict__ grp_n /* WAVES>1: candidates in the group */,
                                                 const int32_t* __restrict__ cand_list /* WAVES==1: optional indirection (fallback runs) */,
-                                                int32_t* __restrict__ ovf_list, unsigned int* __restrict__ ovf_n) {
+                                                int32_t* __restrict__ ovf_list, unsigned int* __restrict__ ovf_n,
+                                                uint8_t* __restrict__ amb_used /* optional: set per read when a vote read an unresolved strand */) {
   extern __shared__ __align__(16) uint32_t lds[];
   uint32_t* Q = lds;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -856,7 +857,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   int strand = -1, accepted = 0;
   if (best >= amin) {
     accepted = 1;
-    int votes = 0;
+    int votes = 0, amb_votes = 0;                                 // votes of resolved strands / number of votes whose query strand is unresolved
     for (int base = opt_b; base < opt_e; base += 512) {
       Rec x[8]; int cd[8];
 #pragma unroll
@@ -873,20 +874,25 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
         if (base + 64 * i >= opt_e) continue;
         const int code = cd[i];
         const bool cnt_it = j < opt_e && code >= 0 && code < bestR;
-        const int contrib = cnt_it ? (sk_strand[qo + code] ? 1 : -1) * pw_strand(x[i].pw) : 0;
+        const uint8_t sq = cnt_it ? sk_strand[qo + code] : (uint8_t)0;   // bit 0 strand, bit 1 unresolved duplicate (mm_map.hip, K2)
+        const bool unres = (sq & 2) && amb_used != nullptr;       // (after the host resolved the read, amb_used is null and bit 1 is gone)
+        const int contrib = cnt_it ? ((sq & 1) ? 1 : -1) * pw_strand(x[i].pw) : 0;
         const bool flagged = cnt_it && (x[i].pw & PW_DN);         // a later occurrence exists in the contig: inside the window?
-        if (cnt_it && !flagged) votes += contrib;
+        if (cnt_it && !flagged) { if (unres) ++amb_votes; else votes += contrib; }
         uint64_t fm = __ballot(flagged);
         while (fm) {
           const int l = __ffsll((unsigned long long)fm) - 1;
           fm &= fm - 1;
           const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)x[i].hash, l);
           const bool later = wave_has_hash(pos, base + l + 64 * i + 1, opt_e, hj, lane);
-          if (!later && lane == l) votes += contrib;
+          if (!later && lane == l) { if (unres) ++amb_votes; else votes += contrib; }
         }
       }
     }
     votes = wave_sum(votes);
+    amb_votes = wave_sum(amb_votes);
+    // each unresolved vote is +1 or -1: the sign of the total is already decided unless the resolved votes are that close
+    if (amb_votes > 0 && ((votes - amb_votes <= 0 && votes + amb_votes > 0) || (dbg_flags & 0x200)) && lane == 0) amb_used[r] = 1;   // (0x200: tests force the resolution path)
     strand = votes > 0 ? 1 : -1;
   }
   if (__ballot(overflow || S.overflow)) {                        // a packed counter saturated: redo this candidate with wide counters

@@ -127,10 +127,25 @@ __global__ void __launch_bounds__(256) sketch_radix_kernel(const Rec* __restrict
   if (ambig) s_amb = 1;
   int ex = 0, total = 0;
   Scan().exclusive_scan(nfirst, ex, 0, total, tmp.scan);
+  const int ex0 = ex;
 #pragma unroll
   for (int i = 0; i < IPT; ++i) if (first[i]) { sk_hash[o + ex] = key[i]; sk_strand[o + ex] = stv[i]; ++ex; }
+  __threadfence_block();
   __syncthreads();
-  if (t == 0) { sk_n[r] = total; amb[r] = (uint8_t)s_amb; }
+  // bit 1 of the strand byte: some duplicate of this hash has the other strand, i.e. the strand the reference would keep
+  // depends on libstdc++'s sort (resolved on the host, and only if a strand vote ever reads this entry)
+  if (s_amb) {
+    int ex2 = ex0;
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+      const int pos = t * IPT + i;
+      if (first[i]) ++ex2;
+      const uint32_t pk = i ? key[i - 1] : (t ? last_key[t - 1] : 0u);
+      const uint8_t ps = i ? stv[i - 1] : (t ? last_st[t - 1] : 0);
+      if (pos < n && pos > 0 && pk == key[i] && ps != stv[i]) sk_strand[o + ex2 - 1] |= 2;
+    }
+  }
+  if (t == 0) { sk_n[r] = total; amb[r] = (uint8_t)(s_amb ? 2 : 0); }   // 2: ambiguous entries are marked
 }
 
 // compact copies for the host-side duplicate-hash tie-break (one workgroup per flagged read)
@@ -572,11 +587,19 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   // ---- duplicate-hash strand tie-break (computeMap.hpp:292-295: std::sort is not stable, std::unique keeps
   //      whichever equal-hash element introsort left first).  Only the strand of the survivor is observable
   //      (slidingMap.hpp:247), so it is resolved here with the same library calls on the same input order.
+  //      Entries whose strand depends on that are marked by K2 (bit 1 of the strand byte); the library sort is only run for
+  //      reads whose strand vote actually read such an entry (found out by K6, amb_used[]), and those few candidates are
+  //      then redone.  Reads sorted by the bitonic kernel (> 16 384 minimizers) carry no marks and are resolved up front.
+  std::vector<int64_t> eager_reads, lazy_reads;
   {
-    std::vector<int64_t> amb_reads;
-    for (int64_t r = 0; r < n; ++r) if (h_amb[(size_t)r]) amb_reads.push_back(r);
-    M->stats.n_ambiguous_sketch_reads = (int64_t)amb_reads.size();
-    if (!amb_reads.empty()) {
+    const bool all_eager = getenv("MM_EAGER_TIEBREAK") != nullptr;   // tests that compare every sketch strand with the oracle
+    for (int64_t r = 0; r < n; ++r) if (h_amb[(size_t)r]) ((h_amb[(size_t)r] == 2 && !all_eager) ? lazy_reads : eager_reads).push_back(r);
+    M->stats.n_ambiguous_sketch_reads = (int64_t)(eager_reads.size() + lazy_reads.size());
+  }
+  // starts the host work for `amb_reads` on background threads and returns the closure that joins it and patches the strands
+  auto start_tiebreak = [&](const std::vector<int64_t>& amb_reads) -> std::function<void()> {
+    std::function<void()> amb_finish;
+    {
       const size_t na = amb_reads.size();
       std::vector<uint64_t> so(na), dof(na + 1, 0);
       for (size_t i = 0; i < na; ++i) {
@@ -635,7 +658,9 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         MM_HIP(hipStreamSynchronize(st));                        // host vectors above are the H2D sources
       };
     }
-  }
+    return amb_finish;
+  };
+  if (!eager_reads.empty()) amb_finish = start_tiebreak(eager_reads);
   // ---- K7 host thresholds per distinct sketch size
   {
     if (!ctx->lut_cache || ctx->lut_k != P.k || ctx->lut_pi != P.perc_identity) {
@@ -772,16 +797,19 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     MM_REQUIRE(lds_wide <= 160 * 1024, MM_ERR_LIMIT, "sketch too large for the L2 window state in LDS (read longer than ~115 kb at w=8)");
     auto set_lds = [&](const void* fn, size_t bytes) { if (bytes > 64 * 1024) MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); };
     DBuf<unsigned long long> counters(16); counters.zero(st);
-    if (getenv("MM_L2_STOP") || getenv("MM_L2_PHASES")) {
-      const char* ds = getenv("MM_L2_STOP"); unsigned long long v = (unsigned long long)((ds ? atoi(ds) & 0xff : 0) | (getenv("MM_L2_PHASES") ? 0x100 : 0)); MM_HIP(hipMemcpyAsync(counters.p + 11, &v, sizeof v, hipMemcpyHostToDevice, st)); MM_HIP(hipStreamSynchronize(st)); }   // timing aid: leave the kernel after phase n (results are then meaningless)
+    if (getenv("MM_L2_STOP") || getenv("MM_L2_PHASES") || getenv("MM_FORCE_AMB_REDO")) {
+      const char* ds = getenv("MM_L2_STOP"); unsigned long long v = (unsigned long long)((ds ? atoi(ds) & 0xff : 0) | (getenv("MM_L2_PHASES") ? 0x100 : 0) | (getenv("MM_FORCE_AMB_REDO") ? 0x200 : 0)); MM_HIP(hipMemcpyAsync(counters.p + 11, &v, sizeof v, hipMemcpyHostToDevice, st)); MM_HIP(hipStreamSynchronize(st)); }   // timing aid: leave the kernel after phase n (results are then meaningless)
     DBuf<int32_t> ovf((size_t)ncand);
     DBuf<unsigned int> ovf_n(1); ovf_n.zero(st);
+    DBuf<uint8_t> amb_used;
+    if (!lazy_reads.empty()) { amb_used.alloc((size_t)n); amb_used.zero(st); }
+    uint8_t* const amb_used_p = lazy_reads.empty() ? nullptr : amb_used.p;
     if (amb_finish) { amb_finish(); amb_finish = nullptr; }        // strands of ambiguous sketches: needed by the vote only
     const size_t t_l2 = T.begin(&M->stats.ms_l2);
     if (!skip) {
       set_lds((const void*)l2_kernel<false, uint16_t, 1, 8>, lds_wide);
       l2_kernel<false, uint16_t, 1, 8><<<dim3((unsigned)ncand), dim3(64), lds_wide, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-          M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, nullptr, nullptr, nullptr);
+          M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, nullptr, nullptr, nullptr, amb_used_p);
       MM_KERNEL_CHECK();
     } else {
       // Reads are grouped by sketch size so that one long read does not size the LDS state (and the occupancy) of all:
@@ -815,7 +843,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 4, 2);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 2>, lds);
         l2_kernel<true, uint8_t, 4, 2><<<dim3((unsigned)gA0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p);
         MM_KERNEL_CHECK();
       }
       if (!gB0.empty()) {
@@ -823,7 +851,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smB, true, 4, 8);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
         l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gB0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smB, M->l2.p, counters.p, d_gB0.p, d_gBn.p, nullptr, ovf.p, ovf_n.p);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smB, M->l2.p, counters.p, d_gB0.p, d_gBn.p, nullptr, ovf.p, ovf_n.p, amb_used_p);
         MM_KERNEL_CHECK();
       }
       DBuf<int32_t> d_gD0(gD0.size()), d_gDn(gDn.size());
@@ -832,7 +860,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smD, true, 2, 8);
         set_lds((const void*)l2_kernel<true, uint8_t, 2, 8>, lds);
         l2_kernel<true, uint8_t, 2, 8><<<dim3((unsigned)gD0.size()), dim3(128), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p, amb_used_p);
         MM_KERNEL_CHECK();
       }
       if (!listC.empty()) {
@@ -840,7 +868,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint16_t>(smC, true, 1, 8);
         set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
         l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)listC.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smC, M->l2.p, counters.p, nullptr, nullptr, d_listC.p, nullptr, nullptr);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smC, M->l2.p, counters.p, nullptr, nullptr, d_listC.p, nullptr, nullptr, amb_used_p);
         MM_KERNEL_CHECK();
       }
       unsigned int h_ovf = 0;
@@ -851,10 +879,31 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint16_t>(smO, true, 1, 8);
         set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
         l2_kernel<true, uint16_t, 1, 8><<<dim3(h_ovf), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smO, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smO, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr, amb_used_p);
         MM_KERNEL_CHECK();
       }
       M->stats.n_l2_wide_redo = (int64_t)h_ovf;
+      if (!lazy_reads.empty()) {                                 // votes that read an unresolved strand: resolve those reads, redo their candidates
+        std::vector<uint8_t> used = amb_used.to_host(st, (size_t)n);
+        std::vector<int64_t> fix;
+        for (int64_t r : lazy_reads) if (used[(size_t)r]) fix.push_back(r);
+        if (!fix.empty()) {
+          start_tiebreak(fix)();
+          std::vector<int32_t> redo; int smR = 0;
+          for (int64_t r : fix) {
+            smR = std::max(smR, M->h_sk_n[(size_t)r]);
+            for (uint64_t c0 = M->h_cand_off[(size_t)r]; c0 < M->h_cand_off[(size_t)r + 1]; ++c0) redo.push_back((int32_t)c0);
+          }
+          DBuf<int32_t> d_redo(redo.size()); d_redo.upload(redo.data(), redo.size(), st);
+          const size_t lds = l2_lds_bytes<uint16_t>(smR, true, 1, 8);
+          set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
+          l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)redo.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smR, M->l2.p, counters.p, nullptr, nullptr, d_redo.p, nullptr, nullptr, nullptr);
+          MM_KERNEL_CHECK();
+          MM_HIP(hipStreamSynchronize(st));
+          M->stats.n_l2_wide_redo += (int64_t)redo.size();
+        }
+      }
     }
     l2_stats_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(ncand, 256), 1024)), dim3(256), 0, st>>>(M->l2.p, ncand, counters.p);
     MM_KERNEL_CHECK();

@@ -135,9 +135,13 @@ def test_index_matches_oracle(ctx, oracle_lib, mini, k, w, part_max, monkeypatch
     oi.close(); idx.close(); S.close()
 
 
-@pytest.mark.parametrize("k,w,force_thr", [(16, 13, None), (16, 8, None), (16, 8, 3)])
-def test_mapping_stages_match_oracle(ctx, oracle_lib, mini, k, w, force_thr, monkeypatch):
+@pytest.mark.parametrize("k,w,force_thr,eager", [(16, 13, None, True), (16, 8, None, True), (16, 8, 3, True), (16, 8, None, False), (16, 8, None, "redo")])
+def test_mapping_stages_match_oracle(ctx, oracle_lib, mini, k, w, force_thr, eager, monkeypatch):
     from metamaps_amd import capi
+    if eager is True:   # resolve every duplicated-hash strand up front so that the whole sketch can be compared; the default
+        monkeypatch.setenv("MM_EAGER_TIEBREAK", "1")   # resolves only reads whose strand vote is undecided without it
+    elif eager == "redo":   # ... which is rare: force that path (host resolution after L2, candidates redone)
+        monkeypatch.setenv("MM_FORCE_AMB_REDO", "1")
     monkeypatch.setenv("MM_NO_HIT_FILTER", "1")        # compare the raw seed-hit list; the filter has its own test below
     names, contigs = _read_fasta(mini["db"].fasta)
     rnames, reads = _read_fastq(mini["reads"])
@@ -152,6 +156,7 @@ def test_mapping_stages_match_oracle(ctx, oracle_lib, mini, k, w, force_thr, mon
     M = ctx.map_batch(idx, R, k, w, pi=80.0, min_read_len=1000)
     M.add_qualities(k)
     st = M.stats()
+    print("tie-break mode", eager, "ambiguous reads", st["n_ambiguous_sketch_reads"], "candidates redone", st["n_l2_wide_redo"])
     sk_off, sk_h, sk_s = M.debug_sketch()
     hit_off, hit_c, hit_w = M.debug_hits()
     cand_off, cand = M.debug_candidates()
@@ -166,7 +171,8 @@ def test_mapping_stages_match_oracle(ctx, oracle_lib, mini, k, w, force_thr, mon
         o = oi.map_read(q, 80.0)
         a, b = int(sk_off[r]), int(sk_off[r + 1])
         assert np.array_equal(sk_h[a:b], o["sketch_hash"]), r
-        assert np.array_equal(sk_s[a:b], o["sketch_strand"]), r
+        if eager is True:
+            assert np.array_equal(sk_s[a:b], o["sketch_strand"]), r
         assert mh[r] == o["min_hits"] or b == a, r
         if force_thr is None:
             a, b = int(hit_off[r]), int(hit_off[r + 1])
@@ -359,4 +365,27 @@ def test_l1_wave_scan_equals_serial_loop(ctx, monkeypatch):
     monkeypatch.delenv("MM_L1_SERIAL")
     assert np.array_equal(res["wave"][0], res["serial"][0]) and np.array_equal(res["wave"][1], res["serial"][1])
     assert len(res["wave"][1]) > 3000
+    idx.close(); reads.close(); ref.close()
+
+
+def test_tiebreak_modes_agree(ctx, monkeypatch):
+    """Duplicated hashes with differing strands (computeMap.hpp:292-295): resolving all of them up front, only those
+    an undecided strand vote needs (default), or every one a vote reads (forced) must give the same records."""
+    ref = ctx.synth_reference(seed=5, n_species=48, strains_per_species=4, genome_len=400_000, strain_divergence=0.02, genus_divergence=0.08)
+    reads, _ = ctx.synth_reads(ref, seed=9, n_reads=4000, read_len=12000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=40)
+    idx = ctx.index(ref, 16, 8)
+    res = {}
+    for mode, env in (("default", None), ("eager", "MM_EAGER_TIEBREAK"), ("redo", "MM_FORCE_AMB_REDO")):
+        if env:
+            monkeypatch.setenv(env, "1")
+        M = ctx.map_batch(idx, reads, 16, 8)
+        off, rec = M.fetch()
+        res[mode] = (off.copy(), rec.copy(), M.stats())
+        M.close()
+        if env:
+            monkeypatch.delenv(env)
+    assert res["default"][2]["n_ambiguous_sketch_reads"] > 10
+    assert res["redo"][2]["n_l2_wide_redo"] > 0                  # the host-resolution path really ran
+    for mode in ("eager", "redo"):
+        assert np.array_equal(res["default"][0], res[mode][0]) and np.array_equal(res["default"][1], res[mode][1]), mode
     idx.close(); reads.close(); ref.close()

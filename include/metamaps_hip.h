@@ -62,6 +62,11 @@ int mm_seqset_create(mm_ctx* ctx, mm_seqset** out);
 void mm_seqset_destroy(mm_seqset* s);
 int mm_seqset_add(mm_seqset* s, const char* ascii, int64_t len);   /* host staging, keeps input order */
 int mm_seqset_upload(mm_seqset* s);                                /* pack + copy to HBM; set is then frozen */
+/* Persistent packed form of an uploaded sequence set (2-bit bases, exception runs, lengths): what `metamaps index` stores
+ * per index chunk in place of the reference's Boost archive of the sketch (createIndex, mapWrap.h:358-405;
+ * winSketch.hpp:73-83).  The device index is rebuilt from it in seconds (mm_index_build), nothing derived is stored. */
+int mm_seqset_save(mm_seqset* set, const char* path);
+int mm_seqset_load(mm_ctx* ctx, const char* path, mm_seqset** out);
 int64_t mm_seqset_count(const mm_seqset* s);
 int64_t mm_seqset_total_bases(const mm_seqset* s);
 int mm_seqset_lengths(const mm_seqset* s, int32_t* len_out /* [count] */);

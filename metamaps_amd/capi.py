@@ -93,6 +93,8 @@ def lib() -> C.CDLL:
             "mm_seqset_create": (C.c_int, [vp, P(vp)]),
             "mm_seqset_destroy": (None, [vp]),
             "mm_seqset_add": (C.c_int, [vp, C.c_char_p, i64]),
+            "mm_seqset_save": (C.c_int, [vp, C.c_char_p]),
+            "mm_seqset_load": (C.c_int, [vp, C.c_char_p, P(vp)]),
             "mm_seqset_upload": (C.c_int, [vp]),
             "mm_seqset_count": (i64, [vp]),
             "mm_seqset_total_bases": (i64, [vp]),
@@ -193,6 +195,11 @@ class Context:
         self.check(lib().mm_seqset_upload(h))
         return s
 
+    def load_seqset(self, path: str) -> "SeqSet":
+        h = C.c_void_p()
+        self.check(lib().mm_seqset_load(self.h, path.encode(), C.byref(h)))
+        return SeqSet(self, h)
+
     def synth_reference(self, **kw) -> "SeqSet":
         p = SynthRefParams(**kw)
         h = C.c_void_p()
@@ -285,6 +292,9 @@ class SeqSet:
         a = np.zeros(self.count, dtype=np.int32)
         self.ctx.check(lib().mm_seqset_lengths(self.h, _ptr(a)))
         return a
+
+    def save(self, path: str):
+        self.ctx.check(lib().mm_seqset_save(self.h, path.encode()))
 
     def fetch(self, i: int, length: int) -> bytes:
         buf = C.create_string_buffer(length + 1)

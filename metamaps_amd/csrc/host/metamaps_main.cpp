@@ -6,14 +6,17 @@
 // reference too: argument parsing, FASTA/FASTQ(.gz) reading, text formatting, taxonomy bookkeeping.
 //
 //   metamaps mapDirectly [--all] -r DB.fa -q reads.fq -o PREFIX [-k 16] [-w W] [-m 1000] [--pi 80] [-p 1e-3] [-t N] [--mm G]
+//   metamaps index -r DB.fa -i IDX [same reference options]          metamaps mapAgainstIndex [--all] -i IDX -q reads.fq -o PREFIX
 //   metamaps classify --DB DBDIR --mappings PREFIX [--minreads N] [-t N]
 //
 // --mm G splits the reference into the same index chunks the reference would build under that limit
 // (mm_index_plan_chunks); all chunk indexes stay resident in HBM and every read batch is mapped against each.
 // (--maxmemory-bytes N gives the limit in bytes: a test hook, sub-GiB limits make small references chunk.)
 //
-// Not provided: index / mapAgainstIndex (Boost archives), classifyU (disabled upstream),
-// the coverage / unknown-species side files of classify.
+// `index` stores the packed reference per chunk (own versioned format, include/metamaps_hip.h: mm_seqset_save) instead of
+// the reference's Boost archives of the sketch; the device index is rebuilt from it in seconds.
+//
+// Not provided: classifyU (disabled upstream), the coverage / unknown-species side files of classify.
 #include "../../../include/metamaps_hip.h"
 #include <zlib.h>
 #include <algorithm>
@@ -99,33 +102,57 @@ uint64_t file_size(const std::string& f) {                       // commonFunc.h
 }
 
 // ------------------------------------------------------------------------------------------------------
-int map_directly(const Options& o) {
-  if (!o.v.count("reference")) die("Provide reference file (s)");
-  if (!o.v.count("query")) die("Provide query file (s)");
-  if (!o.v.count("output")) die("Provide output file");
-  const std::string ref = o.v.at("reference");
-  const uint64_t refSize = file_size(ref);
-  uint64_t maxMem = o.v.count("maxmemory") ? (uint64_t)(std::pow(1024, 3) * std::stoull(o.v.at("maxmemory"))) : 0;
-  if (o.v.count("maxmemory-bytes")) maxMem = std::stoull(o.v.at("maxmemory-bytes"));
-  int k = o.v.count("kmer") ? std::stoi(o.v.at("kmer")) : 16;
-  double pval = o.v.count("pval") ? std::stod(o.v.at("pval")) : 1e-3;
-  int minLen = o.v.count("minReadLen") ? std::stoi(o.v.at("minReadLen")) : 1000;
-  float pi = o.v.count("perc_identity") ? std::stof(o.v.at("perc_identity")) : 80;
-  int w;
-  if (o.v.count("window")) {                                     // parseCmdArgs.hpp:363-374
-    w = std::stoi(o.v.at("window"));
-    pval = mm_estimate_pvalue(minLen * 2 / w, k, pi, minLen, refSize);
-  } else w = mm_recommended_window(pval, k, pi, minLen, refSize);
-  auto queries = split(o.v.at("query"), ","), prefixes = split(o.v.at("output"), ",");
-  if (queries.size() != prefixes.size()) die("Please specify an equal number of input and output files (as comma-separated lists)");
+// mapDirectly, index and mapAgainstIndex share everything but where the reference comes from:
+//   index            FASTA -> chunk plan -> PREFIX.N.seqset per chunk (+ PREFIX.index / .arguments / .contigs)   mapWrap.h:358-405
+//   mapAgainstIndex  those files -> device indexes -> map                                                         mapWrap.h:443-554
+//   mapDirectly      FASTA -> chunk plan -> device indexes -> map                                                 mapWrap.h:407-441
+// The stored form is the packed reference, not the reference's Boost archive of the sketch: rebuilding the device
+// index takes seconds and the file stays a third of the FASTA's size.
+int map_mode(const Options& o, const std::string& mode) {
+  const bool from_index = mode == "mapAgainstIndex", only_index = mode == "index";
+  if (!from_index && !o.v.count("reference")) die("Provide reference file (s)");
+  if ((from_index || only_index) && !o.v.count("index")) die("Please provide index");
+  if (!only_index && !o.v.count("query")) die("Provide query file (s)");
+  if (!only_index && !o.v.count("output")) die("Provide output file");
+  std::string ref; uint64_t refSize = 0, maxMem = 0; int k = 16, w = 0, minLen = 1000; double pval = 1e-3; float pi = 80;
+  const std::string ipre = o.v.count("index") ? o.v.at("index") : "";
+  if (!from_index) {
+    ref = o.v.at("reference");
+    refSize = file_size(ref);
+    maxMem = o.v.count("maxmemory") ? (uint64_t)(std::pow(1024, 3) * std::stoull(o.v.at("maxmemory"))) : 0;
+    if (o.v.count("maxmemory-bytes")) maxMem = std::stoull(o.v.at("maxmemory-bytes"));
+    k = o.v.count("kmer") ? std::stoi(o.v.at("kmer")) : 16;
+    pval = o.v.count("pval") ? std::stod(o.v.at("pval")) : 1e-3;
+    minLen = o.v.count("minReadLen") ? std::stoi(o.v.at("minReadLen")) : 1000;
+    pi = o.v.count("perc_identity") ? std::stof(o.v.at("perc_identity")) : 80;
+    if (o.v.count("window")) {                                   // parseCmdArgs.hpp:363-374
+      w = std::stoi(o.v.at("window"));
+      pval = mm_estimate_pvalue(minLen * 2 / w, k, pi, minLen, refSize);
+    } else w = mm_recommended_window(pval, k, pi, minLen, refSize);
+  } else {                                                       // the parameters travel with the index (mapWrap.h:447-461)
+    std::ifstream a(ipre + ".arguments");
+    if (!a.is_open()) die("Cannot open file " + ipre + ".arguments for deserialization.");
+    std::string key, val; std::map<std::string, std::string> kv;
+    while (a >> key && std::getline(a, val)) { while (!val.empty() && val[0] == ' ') val.erase(0, 1); kv[key] = val; }
+    for (const char* need : {"kmerSize", "windowSize", "minReadLength", "percentageIdentity", "p_value", "referenceSize", "maximumMemory", "reference"})
+      if (!kv.count(need)) die("Index " + ipre + " is incomplete (" + need + " missing in .arguments)");
+    k = std::stoi(kv["kmerSize"]); w = std::stoi(kv["windowSize"]); minLen = std::stoi(kv["minReadLength"]); pi = std::stof(kv["percentageIdentity"]);
+    pval = std::stod(kv["p_value"]); refSize = std::stoull(kv["referenceSize"]); maxMem = std::stoull(kv["maximumMemory"]); ref = kv["reference"];
+  }
+  std::vector<std::string> queries, prefixes;
+  if (!only_index) {
+    queries = split(o.v.at("query"), ","); prefixes = split(o.v.at("output"), ",");
+    if (queries.size() != prefixes.size()) die("Please specify an equal number of input and output files (as comma-separated lists)");
+  }
   mm_ctx* ctx;
   if (mm_ctx_create(0, &ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
-  // ---- index (winSketch.hpp:180-365): the whole reference first; under --maxmemory it only serves to evaluate the
-  // chunk rule and is then replaced by one index per chunk
-  std::vector<std::string> cname, cseq; std::vector<int> clen;
+  std::vector<std::string> cname; std::vector<int> clen;
   struct Chunk { int first, count; mm_index* idx; };
   std::vector<Chunk> chunks;
-  {
+  if (!from_index) {
+    // ---- index (winSketch.hpp:180-365): the whole reference first; under --maxmemory it only serves to evaluate the
+    // chunk rule and is then replaced by one index per chunk
+    std::vector<std::string> cseq;
     mm_seqset* contigs; ck(ctx, mm_seqset_create(ctx, &contigs), "seqset");
     SeqFile f(ref);
     while (f.next()) {
@@ -135,7 +162,6 @@ int map_directly(const Options& o) {
     }
     ck(ctx, mm_seqset_upload(contigs), "upload reference");
     mm_index* whole; ck(ctx, mm_index_build(ctx, contigs, k, w, &whole), "index");
-    mm_seqset_destroy(contigs);
     std::vector<int32_t> first(1, 0);
     if (maxMem) {
       int32_t n = 0;
@@ -143,20 +169,66 @@ int map_directly(const Options& o) {
       first.resize((size_t)n);
       ck(ctx, mm_index_plan_chunks(ctx, whole, maxMem, first.data(), n, &n), "chunk plan");
     }
-    if (first.size() == 1) chunks.push_back(Chunk{0, (int)cname.size(), whole});
-    else {
+    std::vector<std::string> chunk_files;
+    if (only_index) { std::ofstream flag(ipre + ".index"); if (!flag.is_open()) die("Cannot open " + ipre + ".index"); flag << 0 << "\n"; }   // mapWrap.h:363-366
+    if (first.size() == 1) {
+      if (only_index) { chunk_files.push_back(ipre + ".1.seqset"); ck(ctx, mm_seqset_save(contigs, chunk_files.back().c_str()), "store index chunk"); }
+      chunks.push_back(Chunk{0, (int)cname.size(), whole});
+    } else {
       mm_index_destroy(whole);
       for (size_t c = 0; c < first.size(); ++c) {
         const int a = first[c], b = c + 1 < first.size() ? first[c + 1] : (int)cname.size();
         mm_seqset* part; ck(ctx, mm_seqset_create(ctx, &part), "seqset");
         for (int i = a; i < b; ++i) ck(ctx, mm_seqset_add(part, cseq[(size_t)i].data(), (int64_t)cseq[(size_t)i].size()), "add contig");
         ck(ctx, mm_seqset_upload(part), "upload reference chunk");
-        mm_index* idx; ck(ctx, mm_index_build(ctx, part, k, w, &idx), "index chunk");
+        mm_index* idx = nullptr;
+        if (only_index) { chunk_files.push_back(ipre + "." + std::to_string(c + 1) + ".seqset"); ck(ctx, mm_seqset_save(part, chunk_files.back().c_str()), "store index chunk"); }
+        else ck(ctx, mm_index_build(ctx, part, k, w, &idx), "index chunk");
         mm_seqset_destroy(part);
         chunks.push_back(Chunk{a, b - a, idx});
       }
     }
-    cseq.clear(); cseq.shrink_to_fit();
+    mm_seqset_destroy(contigs);
+    if (only_index) {
+      for (auto& ch : chunks) if (ch.idx) mm_index_destroy(ch.idx);
+      std::ofstream args(ipre + ".arguments");
+      if (!args.is_open()) die("Cannot open file " + ipre + ".arguments for serialization.");
+      args.precision(17);
+      args << "kmerSize " << k << "\nwindowSize " << w << "\nminReadLength " << minLen << "\npercentageIdentity " << pi << "\np_value " << pval
+           << "\nreferenceSize " << refSize << "\nmaximumMemory " << maxMem << "\nreference " << ref << "\n";
+      std::ofstream cf(ipre + ".contigs");
+      for (size_t c = 0; c < chunks.size(); ++c)
+        for (int i = chunks[c].first; i < chunks[c].first + chunks[c].count; ++i) cf << cname[(size_t)i] << "\t" << clen[(size_t)i] << "\t" << c + 1 << "\n";
+      std::ofstream flag(ipre + ".index");                       // mapWrap.h:395-402
+      flag << 1 << "\n";
+      for (auto& fn : chunk_files) { flag << fn << "\n"; std::cout << "Stored state in file " << fn << "\n"; }
+      mm_ctx_destroy(ctx);
+      return 0;
+    }
+  } else {
+    std::ifstream flag(ipre + ".index");
+    if (!flag.is_open()) die("Index " + ipre + " not found (" + ipre + ".index)");
+    int done = 0; flag >> done;
+    if (done != 1) die("Index " + ipre + " is not complete.");    // mapWrap.h:466-470
+    std::vector<std::string> chunk_files; std::string fn;
+    while (flag >> fn) chunk_files.push_back(fn);
+    std::ifstream cf(ipre + ".contigs");
+    if (!cf.is_open()) die("Cannot open " + ipre + ".contigs");
+    std::vector<int> chunk_of; std::string line;
+    while (std::getline(cf, line)) {
+      auto fl = split(line, "\t");
+      if (fl.size() != 3) die("Weird line in " + ipre + ".contigs");
+      cname.push_back(fl[0]); clen.push_back(std::stoi(fl[1])); chunk_of.push_back(std::stoi(fl[2]));
+    }
+    for (size_t c = 0; c < chunk_files.size(); ++c) {
+      mm_seqset* part; ck(ctx, mm_seqset_load(ctx, chunk_files[c].c_str(), &part), "load index chunk");
+      int first = -1, count = 0;
+      for (size_t i = 0; i < chunk_of.size(); ++i) if (chunk_of[i] == (int)c + 1) { if (first < 0) first = (int)i; ++count; }
+      if ((int64_t)count != mm_seqset_count(part)) die("Index chunk " + chunk_files[c] + " does not match " + ipre + ".contigs");
+      mm_index* idx; ck(ctx, mm_index_build(ctx, part, k, w, &idx), "index chunk");
+      mm_seqset_destroy(part);
+      chunks.push_back(Chunk{first < 0 ? 0 : first, count, idx});
+    }
   }
   {
     // freqThreshold per chunk from the histogram accumulated over the chunks so far (never cleared, winSketch.hpp:452-494)
@@ -394,12 +466,12 @@ int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db) 
 int main(int argc, char** argv) {
   if (argc < 2 || !(std::string(argv[1]) == "index" || std::string(argv[1]) == "mapDirectly" || std::string(argv[1]) == "mapAgainstIndex" ||
                     std::string(argv[1]) == "classify" || std::string(argv[1]) == "classifyU")) {
-    std::cout << "\nMetaMaps (MI355X hot path)\n\n  Simultaneous metagenomic classification and mapping.\n\nUsage:\n\n  ./metamaps mapDirectly|classify\n\n";
+    std::cout << "\nMetaMaps (MI355X hot path)\n\n  Simultaneous metagenomic classification and mapping.\n\nUsage:\n\n  ./metamaps mapDirectly|classify|mapAgainstIndex|index\n\n";
     return 1;
   }
   const std::string mode = argv[1];
   Options o = parse(argc, argv);
-  if (mode == "mapDirectly") return map_directly(o);
+  if (mode == "mapDirectly" || mode == "index" || mode == "mapAgainstIndex") return map_mode(o, mode);
   if (mode == "classify") {
     if (!o.v.count("DB")) die("Provide path to DB.");
     if (!o.v.count("mappings")) die("Provide path to mappings.");

@@ -9,6 +9,8 @@
 
 namespace mm {
 void seqset_upload(mm_seqset* s);
+void seqset_save(mm_seqset* s, const char* path);
+void seqset_load(mm_seqset* s, const char* path);
 void seqset_fetch(mm_seqset* s, int64_t i, char* out, int64_t cap);
 }
 
@@ -96,6 +98,19 @@ int mm_seqset_add(mm_seqset* s, const char* ascii, int64_t len) {
 int mm_seqset_upload(mm_seqset* s) {
   if (!s) return MM_ERR_ARG;
   return guarded(s->ctx, [&] { MM_HIP(hipSetDevice(s->ctx->device)); mm::seqset_upload(s); });
+}
+int mm_seqset_save(mm_seqset* s, const char* path) {
+  if (!s || !path) return MM_ERR_ARG;
+  return guarded(s->ctx, [&] { MM_HIP(hipSetDevice(s->ctx->device)); mm::seqset_save(s, path); });
+}
+int mm_seqset_load(mm_ctx* ctx, const char* path, mm_seqset** out) {
+  if (!ctx || !path || !out) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
+    auto* S = new mm_seqset; S->ctx = ctx;
+    try { mm::seqset_load(S, path); } catch (...) { delete S; throw; }
+    *out = S;
+  });
 }
 int64_t mm_seqset_count(const mm_seqset* s) { return s ? (s->frozen ? s->count() : (int64_t)s->staged.size()) : 0; }
 int64_t mm_seqset_total_bases(const mm_seqset* s) { return s ? s->total_bases : 0; }

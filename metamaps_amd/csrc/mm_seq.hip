@@ -1,6 +1,8 @@
 // Sequence sets in HBM (packed 2-bit + exception runs) and the K1 driver.
 #include "mm_minimizer.hpp"
 #include <algorithm>
+#include <cstdio>
+#include <cstring>
 
 namespace mm {
 
@@ -134,6 +136,86 @@ void seqset_upload(mm_seqset* s) {
   }
   MM_HIP(hipStreamSynchronize(st));
   s->staged.clear(); s->staged.shrink_to_fit();
+  s->frozen = true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Persistent packed form (what `metamaps index` writes instead of the reference's Boost archives of the sketch,
+// mapWrap.h:358-405): the 2-bit stream, the exception runs and the lengths.  The device index is rebuilt from it in
+// seconds, so nothing derived is stored.  Little endian, versioned:
+//   "MMSEQSET" u32 version=1 u32 reserved  i64 n  i64 total_bases  i64 n_words  i64 n_exc
+//   i32 len[n]  u32 words[n_words]  u64 exc_start[n_exc]  u32 exc_len[n_exc]  u8 exc_byte[n_exc]
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct FileCloser { FILE* f; ~FileCloser() { if (f) fclose(f); } };
+template <typename T> void write_all(FILE* f, const T* p, size_t n, const char* what) {
+  MM_REQUIRE(n == 0 || fwrite(p, sizeof(T), n, f) == n, MM_ERR_ARG, std::string("short write (") + what + ")");
+}
+template <typename T> void read_all(FILE* f, T* p, size_t n, const char* what) {
+  MM_REQUIRE(n == 0 || fread(p, sizeof(T), n, f) == n, MM_ERR_ARG, std::string("truncated sequence-set file (") + what + ")");
+}
+}  // namespace
+
+void seqset_save(mm_seqset* s, const char* path) {
+  MM_REQUIRE(s->frozen, MM_ERR_STATE, "sequence set not uploaded yet");
+  hipStream_t st = s->ctx->stream;
+  FileCloser fc{fopen(path, "wb")};
+  MM_REQUIRE(fc.f != nullptr, MM_ERR_ARG, std::string("cannot open ") + path + " for writing");
+  const int64_t n = s->count(), nwords = (int64_t)s->packed.n, nexc = s->n_exc;
+  const char magic[8] = {'M', 'M', 'S', 'E', 'Q', 'S', 'E', 'T'};
+  const uint32_t ver[2] = {1u, 0u};
+  const int64_t hdr[4] = {n, s->total_bases, nwords, nexc};
+  write_all(fc.f, magic, 8, "magic"); write_all(fc.f, ver, 2, "version"); write_all(fc.f, hdr, 4, "header");
+  write_all(fc.f, s->len.data(), (size_t)n, "lengths");
+  {
+    std::vector<uint32_t> w = s->packed.to_host(st);
+    write_all(fc.f, w.data(), (size_t)nwords, "bases");
+  }
+  if (nexc) {
+    auto es = s->exc_start.to_host(st); auto el = s->exc_len.to_host(st); auto eb = s->exc_byte.to_host(st);
+    write_all(fc.f, es.data(), (size_t)nexc, "exception starts"); write_all(fc.f, el.data(), (size_t)nexc, "exception lengths");
+    write_all(fc.f, eb.data(), (size_t)nexc, "exception bytes");
+  }
+}
+
+void seqset_load(mm_seqset* s, const char* path) {
+  hipStream_t st = s->ctx->stream;
+  FileCloser fc{fopen(path, "rb")};
+  MM_REQUIRE(fc.f != nullptr, MM_ERR_ARG, std::string("cannot open ") + path);
+  char magic[8]; uint32_t ver[2]; int64_t hdr[4];
+  read_all(fc.f, magic, 8, "magic"); read_all(fc.f, ver, 2, "version"); read_all(fc.f, hdr, 4, "header");
+  MM_REQUIRE(memcmp(magic, "MMSEQSET", 8) == 0 && ver[0] == 1u, MM_ERR_ARG, std::string(path) + " is not a sequence-set file of this version");
+  const int64_t n = hdr[0], nwords = hdr[2], nexc = hdr[3];
+  MM_REQUIRE(n >= 0 && nwords >= 1 && nexc >= 0, MM_ERR_ARG, "corrupt sequence-set header");
+  s->len.resize((size_t)n);
+  read_all(fc.f, s->len.data(), (size_t)n, "lengths");
+  s->base.assign((size_t)n + 1, 0);
+  s->total_bases = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    MM_REQUIRE(s->len[(size_t)i] >= 0 && (int64_t)s->len[(size_t)i] <= MAX_SEQ_LEN, MM_ERR_ARG, "corrupt sequence length");
+    s->base[(size_t)i + 1] = s->base[(size_t)i] + (((uint64_t)s->len[(size_t)i] + 15) & ~15ull);
+    s->total_bases += s->len[(size_t)i];
+  }
+  MM_REQUIRE(s->total_bases == hdr[1] && (int64_t)(s->base[(size_t)n] >> 4) + 1 == nwords, MM_ERR_ARG, "sequence-set file is inconsistent");
+  {
+    std::vector<uint32_t> w((size_t)nwords);
+    read_all(fc.f, w.data(), (size_t)nwords, "bases");
+    s->packed.alloc((size_t)nwords); s->packed.upload(w.data(), (size_t)nwords, st);
+    MM_HIP(hipStreamSynchronize(st));
+  }
+  s->d_base.alloc((size_t)n + 1); s->d_base.upload(s->base.data(), (size_t)n + 1, st);
+  s->d_len.alloc(std::max<size_t>((size_t)n, 1)); s->d_len.upload(s->len.data(), (size_t)n, st);
+  s->n_exc = nexc;
+  if (nexc) {
+    std::vector<uint64_t> es((size_t)nexc); std::vector<uint32_t> el((size_t)nexc); std::vector<uint8_t> eb((size_t)nexc);
+    read_all(fc.f, es.data(), (size_t)nexc, "exception starts"); read_all(fc.f, el.data(), (size_t)nexc, "exception lengths");
+    read_all(fc.f, eb.data(), (size_t)nexc, "exception bytes");
+    s->exc_start.alloc(es.size()); s->exc_start.upload(es.data(), es.size(), st);
+    s->exc_len.alloc(el.size()); s->exc_len.upload(el.data(), el.size(), st);
+    s->exc_byte.alloc(eb.size()); s->exc_byte.upload(eb.data(), eb.size(), st);
+    MM_HIP(hipStreamSynchronize(st));
+  }
+  MM_HIP(hipStreamSynchronize(st));
   s->frozen = true;
 }
 

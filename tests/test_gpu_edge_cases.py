@@ -146,3 +146,24 @@ def test_results_do_not_depend_on_batching(ctx):
         M.close()
     assert len(recw) > 10_000
     Mw.close(); Mw2.close(); whole.close(); idx.close(); ref.close()
+
+
+def test_seqset_save_load_round_trip(tmp_path):
+    """packed reference file: every base, exception run (N, lower case handled at upload) and length survives"""
+    from metamaps_amd import capi
+    ctx = capi.Context(0)
+    rng = np.random.default_rng(3)
+    seqs = [bytes(rng.choice(list(b"ACGT"), size=n).astype(np.uint8)) for n in (1, 15, 16, 17, 1000, 40_001)]
+    seqs[4] = seqs[4][:100] + b"N" * 50 + b"RYK" + seqs[4][153:]
+    seqs.append(b"")
+    S = ctx.seqset(seqs)
+    path = str(tmp_path / "s.seqset")
+    S.save(path)
+    T = ctx.load_seqset(path)
+    assert T.count == S.count and T.total_bases == S.total_bases and np.array_equal(T.lengths(), S.lengths())
+    for i, q in enumerate(seqs):
+        assert T.fetch(i, len(q)) == S.fetch(i, len(q)) == q.upper()
+    open(path, "r+b").write(b"XX")                      # a damaged file is refused
+    with pytest.raises(Exception):
+        ctx.load_seqset(path)
+    S.close(); T.close(); ctx.close()

@@ -130,7 +130,7 @@ int mm_index_entries(mm_index* idx, uint32_t* hash, int32_t* contig, int32_t* wp
 int mm_recommended_window(double p_value, int k, float pi, int min_read_len, uint64_t reference_size);   /* map_stats.hpp:226 */
 double mm_estimate_pvalue(int s, int k, float pi, int min_read_len, uint64_t reference_size);             /* map_stats.hpp:179 */
 int mm_min_hits_relaxed(int s, int k, float pi);                                                          /* map_stats.hpp:142 */
-void mm_identity(int shared, int s, int k, float* ident, float* ident_upper);                             /* computeMap.hpp:406-412 */
+void mm_identity(int shared, int s, int k, float* ident, float* ident_upper /* may be NULL */);         /* computeMap.hpp:406-412 */
 
 /* ---- mapping (replaces Map::mapModule for a whole batch: computeMap.hpp:180-538) -------------- */
 typedef struct {

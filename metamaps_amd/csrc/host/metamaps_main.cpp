@@ -25,10 +25,16 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <thread>
+#include <mutex>
+#include <memory>
 #include <regex>
 #include <set>
 #include <sstream>
@@ -37,6 +43,13 @@
 #include <vector>
 
 namespace {
+
+// MM_CLI_TIMING=1: wall time per phase on stderr at exit
+struct PhaseClock {
+  std::map<std::string, double> acc; std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char* name) { auto n = std::chrono::steady_clock::now(); acc[name] += std::chrono::duration<double>(n - t).count(); t = n; }
+  ~PhaseClock() { if (getenv("MM_CLI_TIMING")) for (auto& kv : acc) std::cerr << "INFO, time " << kv.first << " " << kv.second << " s\n"; }
+};
 
 [[noreturn]] void die(const std::string& m) { std::cerr << m << std::endl; exit(1); }
 void ck(mm_ctx* ctx, int st, const char* what) { if (st != MM_OK) die(std::string(what) + ": " + mm_last_error(ctx)); }
@@ -60,12 +73,40 @@ class SeqFile {
     while ((c = get()) != -1 && !isspace(c)) { name.push_back((char)c); any = true; }
     if (c == -1 && !any) return false;
     if (c != '\n') while (c != -1 && (c = get()) != -1 && c != '\n') {}
-    while ((c = get()) != -1 && c != '>' && c != '+' && c != '@') if (isgraph(c)) seq.push_back((char)c);
+    // sequence: everything up to the next '>', '+' or '@', graphic characters only — in bulk over the read buffer
+    // (class table: 0 keep, 1 skip, 2 stop) instead of one call per character
+    static const struct Cls { uint8_t t[256]; Cls() { for (int i = 0; i < 256; ++i) t[i] = (i == '>' || i == '+' || i == '@') ? 2 : (isgraph(i) ? 0 : 1); } } cls;
+    c = -1;
+    for (;;) {
+      if (beg_ >= end_) { const int ch = get(); if (ch == -1) break; --beg_; }      // refill
+      const unsigned char* p = buf_.data() + beg_;
+      const unsigned char* const e = p + std::min<size_t>(end_ - beg_, 16384);   // (resize zero-fills: keep the pieces small)
+      const size_t old = seq.size();
+      seq.resize(old + (size_t)(e - p));
+      char* o = &seq[old];
+      uint8_t k = 0;
+      while (p < e && (k = cls.t[*p]) != 2) { *o = (char)*p; o += (k == 0); ++p; }
+      seq.resize((size_t)(o - seq.data()));
+      beg_ = (size_t)(p - buf_.data());
+      if (p < e) { c = *p; ++beg_; break; }                       // the stop character is consumed, as get() would
+    }
     pending_ = (c == '>' || c == '@') ? c : 0;
     if (c != '+') return true;
     while ((c = get()) != -1 && c != '\n') {}
-    size_t got = 0;
-    while (got < seq.size() && (c = get()) != -1) if (c >= 33 && c <= 127) ++got;
+    size_t got = 0;                                              // qualities: as many characters in [33,127] as there are bases
+    while (got < seq.size()) {
+      if (beg_ >= end_) { const int ch = get(); if (ch == -1) break; --beg_; }
+      const unsigned char* p = buf_.data() + beg_; const unsigned char* const e = buf_.data() + end_;
+      const size_t want = seq.size() - got, avail = (size_t)(e - p);
+      if (avail <= want) {                                       // the whole rest of the buffer cannot overshoot
+        size_t cnt = 0;
+        for (const unsigned char* q = p; q < e; ++q) cnt += (unsigned)(*q - 33u) <= 94u;
+        got += cnt; beg_ = end_;
+      } else {
+        while (p < e && got < seq.size()) { got += (unsigned)(*p - 33u) <= 94u; ++p; }
+        beg_ = (size_t)(p - buf_.data());
+      }
+    }
     pending_ = 0;
     return true;
   }
@@ -144,8 +185,10 @@ int map_mode(const Options& o, const std::string& mode) {
     queries = split(o.v.at("query"), ","); prefixes = split(o.v.at("output"), ",");
     if (queries.size() != prefixes.size()) die("Please specify an equal number of input and output files (as comma-separated lists)");
   }
+  PhaseClock pc;
   mm_ctx* ctx;
   if (mm_ctx_create(0, &ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
+  pc.lap("0 context");
   std::vector<std::string> cname; std::vector<int> clen;
   struct Chunk { int first, count; mm_index* idx; };
   std::vector<Chunk> chunks;
@@ -160,8 +203,11 @@ int map_mode(const Options& o, const std::string& mode) {
       cname.push_back(f.name); clen.push_back((int)f.seq.size());
       if (maxMem) cseq.push_back(f.seq);
     }
+    pc.lap("1 reference parse");
     ck(ctx, mm_seqset_upload(contigs), "upload reference");
+    pc.lap("2 reference pack+upload");
     mm_index* whole; ck(ctx, mm_index_build(ctx, contigs, k, w, &whole), "index");
+    pc.lap("3 index build");
     std::vector<int32_t> first(1, 0);
     if (maxMem) {
       int32_t n = 0;
@@ -248,24 +294,51 @@ int map_mode(const Options& o, const std::string& mode) {
     }
   }
   // ---- reads, batch by batch (computeMap.hpp:104-172 + unifyFiles mapWrap.h:34-213)
-  const int64_t BATCH_READS = 200000, BATCH_BASES = 3000000000LL;
+  const int64_t BATCH_READS = 100000, BATCH_BASES = 1000000000LL;   // ~1 Gbp per device batch; the next one is parsed meanwhile
   for (size_t fi = 0; fi < queries.size(); ++fi) {
     const std::string& prefix = prefixes[fi];
     std::ofstream out(prefix), unm(prefix + ".meta.unmappedReadsLengths");
     if (!out.is_open()) die("Cannot open output file " + prefix);
     size_t total = 0, tooShort = 0, mapped = 0, notMapped = 0;
     std::set<std::string> seen;
-    SeqFile f(queries[fi]);
-    bool more = true;
-    while (more) {
-      mm_seqset* reads; ck(ctx, mm_seqset_create(ctx, &reads), "seqset");
-      std::vector<std::string> names; std::vector<int> lens; int64_t bases = 0;
-      while ((int64_t)names.size() < BATCH_READS && bases < BATCH_BASES && (more = f.next())) {
-        ck(ctx, mm_seqset_add(reads, f.seq.data(), (int64_t)f.seq.size()), "add read");
-        names.push_back(f.name); lens.push_back((int)f.seq.size()); bases += (int64_t)f.seq.size();
+    // a reader thread parses the next batches (bounded queue) while this thread packs, maps and writes the current one
+    struct Batch { std::vector<std::string> names, seqs; std::vector<int> lens; };
+    std::mutex qm; std::condition_variable qcv; std::deque<std::unique_ptr<Batch>> queue; bool reader_done = false;
+    std::thread reader([&]() {
+      SeqFile f(queries[fi]);
+      bool more = true;
+      while (more) {
+        auto b = std::make_unique<Batch>();
+        int64_t bases = 0;
+        while ((int64_t)b->names.size() < BATCH_READS && bases < BATCH_BASES && (more = f.next())) {
+          b->names.push_back(f.name); b->lens.push_back((int)f.seq.size()); bases += (int64_t)f.seq.size();
+          b->seqs.emplace_back(); b->seqs.back().swap(f.seq);
+        }
+        if (b->names.empty()) break;
+        std::unique_lock<std::mutex> lk(qm);
+        qcv.wait(lk, [&] { return queue.size() < 2; });
+        queue.push_back(std::move(b));
+        qcv.notify_all();
       }
-      if (names.empty()) { mm_seqset_destroy(reads); break; }
+      std::lock_guard<std::mutex> lk(qm); reader_done = true; qcv.notify_all();
+    });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{reader};
+    for (;;) {
+      std::unique_ptr<Batch> bt;
+      {
+        std::unique_lock<std::mutex> lk(qm);
+        qcv.wait(lk, [&] { return !queue.empty() || reader_done; });
+        if (queue.empty()) break;
+        bt = std::move(queue.front()); queue.pop_front();
+        qcv.notify_all();
+      }
+      std::vector<std::string>& names = bt->names; std::vector<int>& lens = bt->lens;
+      mm_seqset* reads; ck(ctx, mm_seqset_create(ctx, &reads), "seqset");
+      for (auto& q : bt->seqs) ck(ctx, mm_seqset_add(reads, q.data(), (int64_t)q.size()), "add read");
+      bt->seqs.clear(); bt->seqs.shrink_to_fit();
+      pc.lap("4 reads parse");
       ck(ctx, mm_seqset_upload(reads), "upload reads");
+      pc.lap("5 reads pack+upload");
       mm_map_params mp{k, w, pi, minLen};
       std::vector<mm_mapping*> parts; std::vector<int32_t> base;
       for (auto& ch : chunks) {                                   // one "PREFIX.N" per chunk in the reference (mapWrap.h:419-437)
@@ -283,6 +356,7 @@ int map_mode(const Options& o, const std::string& mode) {
       ck(ctx, mm_mapping_fetch(m, off.data(), nullptr, 0), "fetch");
       std::vector<mm_map_record> rec((size_t)off.back());
       ck(ctx, mm_mapping_fetch(m, off.data(), rec.data(), (int64_t)rec.size()), "fetch");
+      pc.lap("6 map+mapq+fetch");
       for (size_t r = 0; r < names.size(); ++r) {
         ++total;
         const int len = lens[r];
@@ -292,7 +366,7 @@ int map_mode(const Options& o, const std::string& mode) {
         ++mapped;
         for (int64_t i = off[r]; i < off[r + 1]; ++i) {
           const mm_map_record& x = rec[(size_t)i];
-          float id, ub; mm_identity(x.shared, x.sketch, k, &id, &ub);
+          float id; mm_identity(x.shared, x.sketch, k, &id, nullptr);
           std::ostringstream ln;                                  // computeMap.hpp:565-581
           ln << names[r] << " " << len << " " << "0" << " " << len - 1 << " " << (x.strand == 1 ? "+" : "-") << " "
              << cname[(size_t)x.ref_contig] << " " << clen[(size_t)x.ref_contig] << " " << x.ref_start << " " << x.ref_start + len - 1 << " ";
@@ -305,6 +379,7 @@ int map_mode(const Options& o, const std::string& mode) {
         }
       }
       mm_mapping_destroy(m); mm_seqset_destroy(reads);
+      pc.lap("7 format+write");
     }
     std::ofstream meta(prefix + ".meta");                        // mapWrap.h:178-184
     meta << "TotalReads " << total << "\nReadsTooShort " << tooShort << "\nReadsMapped " << mapped << "\nReadsNotMapped " << notMapped << "\n";

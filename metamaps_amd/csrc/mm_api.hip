@@ -238,10 +238,14 @@ double mm_estimate_pvalue(int s, int k, float pi, int min_read_len, uint64_t ref
 }
 int mm_min_hits_relaxed(int s, int k, float pi) { return mm::stats::min_hits_relaxed(s, k, pi); }
 void mm_identity(int shared, int s, int k, float* ident, float* ident_upper) {
+  if (!ident_upper) {                                            // the estimate alone needs no binomial quantile
+    if (ident) *ident = 100 * (1 - mm::stats::j2md(1.0 * shared / s, k));
+    return;
+  }
   float a, b;
   mm::stats::identity(shared, s, k, &a, &b);
   if (ident) *ident = a;
-  if (ident_upper) *ident_upper = b;
+  *ident_upper = b;
 }
 
 // ---- mapping ------------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 // Sequence sets in HBM (packed 2-bit + exception runs) and the K1 driver.
 #include "mm_minimizer.hpp"
 #include <algorithm>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 
@@ -111,18 +112,50 @@ void seqset_upload(mm_seqset* s) {
   const size_t nwords = (size_t)(s->base[n] >> 4);
   std::vector<uint32_t> words(nwords + 1, 0);
   std::vector<uint64_t> es; std::vector<uint32_t> el; std::vector<uint8_t> eb;
-  for (size_t i = 0; i < n; ++i) {
-    const std::string& q = s->staged[i];
-    const uint64_t b0 = s->base[i];
-    bool open = false;
-    for (size_t j = 0; j < q.size(); ++j) {
-      uint8_t c = (uint8_t)q[j];
-      if (c > 96 && c < 123) c -= 32;                         // makeUpperCase, commonFunc.hpp:57-66
-      int code = code_of(c);
-      if (code >= 0) { words[(b0 + j) >> 4] |= (uint32_t)code << (2 * ((b0 + j) & 15)); open = false; }
-      else if (open && eb.back() == c && el.back() < 0xFFFFFFFFu) el.back()++;
-      else { es.push_back(b0 + j); el.push_back(1); eb.push_back(c); open = true; }
-    }
+  {
+    // 16 bases per step through a byte table (code, or 0x80 for anything but ACGT after upper-casing, commonFunc.hpp:57-66);
+    // only words with such a base take the per-base path.  Sequences start on word boundaries, so threads own disjoint
+    // word ranges; their exception runs are concatenated in sequence order afterwards.
+    static const struct Lut { uint8_t t[256]; Lut() { for (int c = 0; c < 256; ++c) { int u = (c > 96 && c < 123) ? c - 32 : c; int k = code_of((uint8_t)u); t[c] = k >= 0 ? (uint8_t)k : 0x80; } } } lut;
+    struct Runs { std::vector<uint64_t> es; std::vector<uint32_t> el; std::vector<uint8_t> eb; };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nthr = (size_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)hw, 16, (uint64_t)(s->total_bases >> 22) + 1, (uint64_t)std::max<size_t>(n, 1)}));
+    std::vector<Runs> runs(nthr);
+    std::vector<size_t> cut(nthr + 1, n);                         // sequence ranges of about equal bases
+    cut[0] = 0;
+    { size_t t = 1; for (size_t i = 0; i < n && t < nthr; ++i) if (s->base[i] >= s->base[n] / nthr * t) cut[t++] = i; }
+    auto work = [&](size_t t) {
+      Runs& R = runs[t];
+      for (size_t i = cut[t]; i < cut[t + 1]; ++i) {
+        const std::string& q = s->staged[i];
+        const uint8_t* p = (const uint8_t*)q.data();
+        const size_t L = q.size();
+        uint32_t* wp = words.data() + (s->base[i] >> 4);
+        const uint64_t b0 = s->base[i];
+        bool open = false;
+        for (size_t j0 = 0; j0 < L; j0 += 16) {
+          const size_t m = std::min<size_t>(16, L - j0);
+          uint32_t wv = 0; uint8_t bad = 0;
+          for (size_t j = 0; j < m; ++j) { const uint8_t k = lut.t[p[j0 + j]]; bad |= k; wv |= (uint32_t)(k & 3) << (2 * j); }
+          if (!(bad & 0x80)) { wp[j0 >> 4] = wv; open = false; continue; }
+          wv = 0;
+          for (size_t j = 0; j < m; ++j) {
+            uint8_t c = p[j0 + j];
+            if (c > 96 && c < 123) c -= 32;
+            const uint8_t k = lut.t[c];
+            if (!(k & 0x80)) { wv |= (uint32_t)k << (2 * j); open = false; }
+            else if (open && R.eb.back() == c && R.el.back() < 0xFFFFFFFFu) R.el.back()++;
+            else { R.es.push_back(b0 + j0 + j); R.el.push_back(1); R.eb.push_back(c); open = true; }
+          }
+          wp[j0 >> 4] = wv;
+        }
+      }
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nthr; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    for (auto& R : runs) { es.insert(es.end(), R.es.begin(), R.es.end()); el.insert(el.end(), R.el.begin(), R.el.end()); eb.insert(eb.end(), R.eb.begin(), R.eb.end()); }
   }
   s->packed.alloc(words.size());
   s->packed.upload(words.data(), words.size(), st);

@@ -16,7 +16,8 @@
 // `index` stores the packed reference per chunk (own versioned format, include/metamaps_hip.h: mm_seqset_save) instead of
 // the reference's Boost archives of the sketch; the device index is rebuilt from it in seconds.
 //
-// Not provided: classifyU (disabled upstream), the coverage / unknown-species side files of classify.
+// Not provided: classifyU (disabled upstream), the unknown-species side file of classify
+// (.EM.evidenceUnknownSpecies needs the DB's contigNstats file and Boost's chi-square / Poisson / binomial cdfs).
 #include "../../../include/metamaps_hip.h"
 #include <zlib.h>
 #include <algorithm>
@@ -455,6 +456,52 @@ void write_wimp(const std::string& fn, const Taxonomy& T, const std::map<std::st
   }
 }
 
+// overlap of two closed intervals as computed by meta/util.h:118-172
+size_t iv_overlap_big_small(size_t bigL, size_t bigR, size_t smL, size_t smR) {
+  if (bigL <= smL && bigR >= smR) return smR - smL + 1;
+  if (smL >= bigL && smL <= bigR) return bigR - smL + 1;
+  if (smR >= bigL && smR <= bigR) return smR - bigL + 1;
+  return 0;
+}
+size_t iv_overlap(size_t aL, size_t aR, size_t bL, size_t bR) {
+  return (aR - aL + 1 > bR - bL + 1) ? iv_overlap_big_small(aL, aR, bL, bR) : iv_overlap_big_small(bL, bR, aL, aR);
+}
+// .EM.contigCoverage: bases of best mappings per 1000-bp window of every contig that carries one (fEM.h:684, :730-776,
+// :805-845).  Kept as the reference computes it, including the length it assigns to the last window of a contig that is
+// not a multiple of the window size (:744 subtracts after incrementing the window count, so the unsigned value wraps).
+struct ContigCoverage {
+  const size_t W = 1000;
+  std::map<std::string, std::map<std::string, std::vector<size_t>>> cov;
+  std::map<std::string, std::map<std::string, size_t>> last;
+  void add(const std::string& tx, const std::string& cg, size_t L, size_t start, size_t stop_in) {
+    auto& per = cov[tx];
+    if (!per.count(cg)) {
+      size_t n = L / W;
+      if (n == 0) { n = 1; last[tx][cg] = L; }
+      else if (n * W != L) { ++n; last[tx][cg] = L - n * W; }
+      else last[tx][cg] = W;
+      per[cg].assign(n, 0);
+    }
+    const size_t stop = stop_in >= L ? L - 1 : stop_in;
+    std::vector<size_t>& v = per[cg];
+    for (size_t p = start; p <= stop; p += W) {
+      const size_t wi = p / W, ws = wi * W;
+      size_t we = (wi + 1) * W - 1;
+      if (we > L) we = L - 1;
+      v.at(wi) += iv_overlap(ws, we, start, stop);
+    }
+  }
+  void write(const std::string& fn, const Taxonomy& T) const {
+    std::ofstream o(fn);
+    o << "taxonID\tequalCoverageUnitLabel\tcontigID\tstart\tstop\tnBases\treadCoverage\n";
+    for (auto& t : cov) for (auto& c : t.second) for (size_t wi = 0; wi < c.second.size(); ++wi) {
+      const size_t wl = wi + 1 == c.second.size() ? last.at(t.first).at(c.first) : W;
+      o << t.first << "\t" << T.T.at(t.first).sci << "\t" << c.first << "\t" << wi * W << "\t" << (wi + 1) * W - 1 << "\t" << c.second[wi] << "\t"
+        << (double)c.second[wi] / (double)wl << "\n";
+    }
+  }
+};
+
 int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db) {   // meta::doEM, fEM.h:466-803
   // mappings grouped by read (fEM.h:1171-1214)
   std::vector<std::vector<std::string>> groups;
@@ -476,7 +523,7 @@ int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db) 
   std::vector<std::string> taxa(taxaSet.begin(), taxaSet.end());
   std::map<std::string, int> tindex; for (size_t i = 0; i < taxa.size(); ++i) tindex[taxa[i]] = (int)i;
   // per mapping: taxon, quality, 1/nLoc (getMappingLocations, fEM.h:234-353)
-  std::vector<int64_t> off{0}; std::vector<int32_t> taxon; std::vector<double> mapq, inv, ident; std::vector<std::string> contigOf; std::vector<size_t> rlen;
+  std::vector<int64_t> off{0}; std::vector<int32_t> taxon; std::vector<double> mapq, inv, ident; std::vector<std::string> contigOf; std::vector<size_t> rlen, mstart, mstop;
   for (auto& g : groups) {
     std::vector<std::vector<std::string>> F; std::set<std::string> sawC, sawT;
     for (auto& ln : g) { F.push_back(split(ln, " ")); sawC.insert(F.back().at(5)); }
@@ -487,7 +534,7 @@ int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db) 
     for (auto& f : F) {
       std::string t = extract_taxon(f[5]); double q;
       try { q = std::stod(f.at(13)); } catch (const std::out_of_range&) { if (f.at(13).find("e-") != std::string::npos) q = 0; else throw; }
-      taxon.push_back(tindex.at(t)); mapq.push_back(q); inv.push_back(1 / (double)nLoc.at(t)); ident.push_back(std::stod(f.at(9)) / 100.0); contigOf.push_back(f[5]); rlen.push_back((size_t)L);
+      taxon.push_back(tindex.at(t)); mapq.push_back(q); inv.push_back(1 / (double)nLoc.at(t)); ident.push_back(std::stod(f.at(9)) / 100.0); contigOf.push_back(f[5]); rlen.push_back((size_t)L); mstart.push_back(std::stoull(f.at(7))); mstop.push_back(std::stoull(f.at(8)));
     }
     off.push_back((int64_t)taxon.size());
   }
@@ -509,6 +556,7 @@ int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db) 
   std::ofstream emf(mapped + ".EM"), r2t(mapped + ".EM.reads2Taxon"), kr(mapped + ".EM.reads2Taxon.krona"), li(mapped + ".EM.lengthAndIdentitiesPerMappingUnit");
   li << "AnalysisLevel\tID\treadI\tIdentity\tLength\n";
   std::map<std::string, size_t> readsPer;
+  ContigCoverage coverage;
   for (size_t r = 0; r < groups.size(); ++r) {                   // fEM.h:684-779
     std::string rid;
     for (size_t j = 0; j < groups[r].size(); ++j) {
@@ -523,6 +571,7 @@ int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db) 
     r2t << rid << "\t" << tx << "\n";
     kr << rid << "\t" << T.first_non_x(tx) << "\t" << post[b] << "\n";
     readsPer[tx]++;
+    coverage.add(tx, contigOf[b], TI.at(tx).at(contigOf[b]), mstart[b], mstop[b]);
   }
   { std::ifstream s(mapped + ".meta.unmappedReadsLengths"); std::string ln;
     while (std::getline(s, ln)) { if (ln.empty()) continue; auto fl = split(ln, "\t"); r2t << fl.at(1) << "\t" << 0 << "\n"; kr << fl.at(1) << "\t" << 0 << "\t" << 0 << "\n"; } }
@@ -533,6 +582,7 @@ int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db) 
     for (auto& d : drop) fmap.erase(d);
     double s = 0; for (auto& e : fmap) s += e.second; for (auto& e : fmap) e.second /= s; }
   write_wimp(mapped + ".EM.WIMP", T, fmap, readsPer, nTotal, nUnmapped, nTooShort);
+  coverage.write(mapped + ".EM.contigCoverage", T);
   return 0;
 }
 

@@ -297,6 +297,54 @@ static inline std::vector<std::vector<std::string>> group_reads(const std::strin
   return groups;
 }
 
+// meta/util.h:118-172
+static inline size_t overlap_first_larger(size_t aL, size_t aR, size_t bL, size_t bR) {
+  size_t bLen = bR - bL + 1;
+  if (aL <= bL && aR >= bR) return bLen;
+  else if (bL >= aL && bL <= aR) return aR - bL + 1;
+  else if (bR >= aL && bR <= aR) return bR - aL + 1;
+  return 0;
+}
+static inline size_t overlap(size_t aL, size_t aR, size_t bL, size_t bR) {
+  return (aR - aL + 1 > bR - bL + 1) ? overlap_first_larger(aL, aR, bL, bR) : overlap_first_larger(bL, bR, aL, aR);
+}
+// read coverage in 1000-bp windows of the contigs carrying best mappings — meta/fEM.h:684 (window size), :730-776
+// (accumulation, including the unsigned wrap of the last window's length when the contig is not a multiple of the
+// window: :744 subtracts after incrementing n_windows), :805-845 (output)
+struct Coverage {
+  size_t W = 1000;
+  std::map<std::string, std::map<std::string, std::vector<size_t>>> cov;
+  std::map<std::string, std::map<std::string, size_t>> lastWin;
+  void add(const TaxonInfo& TI, const Loc& b) {
+    const size_t L = TI.at(b.taxon).at(b.contig);
+    if (!cov[b.taxon].count(b.contig)) {
+      size_t n = L / W;
+      if (n == 0) { n++; lastWin[b.taxon][b.contig] = L; }
+      else if (n * W != L) { n++; lastWin[b.taxon][b.contig] = L - n * W; }
+      else lastWin[b.taxon][b.contig] = W;
+      cov[b.taxon][b.contig].resize(n, 0);
+    }
+    const size_t stop = b.stop >= L ? L - 1 : b.stop;
+    for (size_t pos = b.start; pos <= stop; pos += W) {
+      const size_t wi = pos / W, ws = wi * W;
+      size_t we = (wi + 1) * W - 1;
+      if (we > L) we = L - 1;
+      cov.at(b.taxon).at(b.contig).at(wi) += overlap(ws, we, b.start, stop);
+    }
+  }
+  template <typename TaxT> void write(const std::string& file, const TaxT& T) const {
+    std::ofstream o(file);
+    o << "taxonID\tequalCoverageUnitLabel\tcontigID\tstart\tstop\tnBases\treadCoverage\n";
+    for (auto& t : cov) for (auto& c : t.second)
+      for (size_t wi = 0; wi < c.second.size(); ++wi) {
+        size_t wl = W;
+        if (wi == c.second.size() - 1) wl = lastWin.at(t.first).at(c.first);
+        o << t.first << "\t" << T.T.at(t.first).sci << "\t" << c.first << "\t" << wi * W << "\t" << (wi + 1) * W - 1 << "\t" << c.second[wi] << "\t"
+          << (double)c.second[wi] / (double)wl << "\n";
+      }
+  }
+};
+
 struct EMTrace { std::vector<double> ll; std::map<std::string, double> f; };
 
 // meta/fEM.h:52-215 (WIMP)
@@ -395,8 +443,11 @@ static inline EMTrace do_em(const std::string& mapped, const std::string& dbDir,
   }
   tr.f = f;
   if (!writeFiles) return tr;
-  std::ofstream em(mapped + ".EM"), r2t(mapped + ".EM.reads2Taxon"), kr(mapped + ".EM.reads2Taxon.krona");
+  std::ofstream em(mapped + ".EM"), r2t(mapped + ".EM.reads2Taxon"), kr(mapped + ".EM.reads2Taxon.krona"), li(mapped + ".EM.lengthAndIdentitiesPerMappingUnit");
+  li << "AnalysisLevel\tID\treadI\tIdentity\tLength\n";     // :686
   std::map<std::string, size_t> readsPer;
+  Coverage coverage;
+  size_t readI = 0;
   for (auto& g : groups) {                                       // :684-779
     auto locs = mapping_locations(TI, f, g);
     std::string rid;
@@ -410,6 +461,8 @@ static inline EMTrace do_em(const std::string& mapped, const std::string& dbDir,
     r2t << rid << "\t" << locs[best].taxon << "\n";
     kr << rid << "\t" << T.first_non_x(locs[best].taxon) << "\t" << locs[best].p << "\n";
     readsPer[locs[best].taxon]++;
+    li << "EqualCoverageUnit\t" << locs[best].contig << "\t" << readI++ << "\t" << locs[best].identity << "\t" << locs[best].readLen << "\n";   // :711
+    coverage.add(TI, locs[best]);
   }
   {                                                              // :785-790
     std::ifstream s(mapped + ".meta.unmappedReadsLengths"); std::string ln;
@@ -428,6 +481,7 @@ static inline EMTrace do_em(const std::string& mapped, const std::string& dbDir,
     for (auto& e : f) e.second /= s;
   }
   write_wimp(mapped + ".EM.WIMP", T, f, readsPer, nTotal, nUnmapped, nTooShort);
+  coverage.write(mapped + ".EM.contigCoverage", T);
   return tr;
 }
 

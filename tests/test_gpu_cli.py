@@ -52,6 +52,9 @@ def test_cli_outputs_match_oracle(oracle_lib, tmp_path, w_flag):
     assert open(pa + ".EM.reads2Taxon").read() == open(pb + ".EM.reads2Taxon").read()
     _cmp_table(pa + ".EM.reads2Taxon.krona", pb + ".EM.reads2Taxon.krona", "\t", {2})
     _cmp_table(pa + ".EM.WIMP", pb + ".EM.WIMP", "\t", {4, 5})
+    _cmp_table(pa + ".EM.lengthAndIdentitiesPerMappingUnit", pb + ".EM.lengthAndIdentitiesPerMappingUnit", "\t", {3})
+    _cmp_table(pa + ".EM.contigCoverage", pb + ".EM.contigCoverage", "\t", {6})
+    assert sum(1 for _ in open(pa + ".EM.contigCoverage")) > 50
     assert sum(1 for _ in open(pa)) > 150
 
 

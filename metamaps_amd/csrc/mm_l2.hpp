@@ -51,11 +51,18 @@ __device__ inline bool wave_has_hash(const Rec* __restrict__ pos, int64_t lo, in
 __device__ inline int wave_sum(int v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline int wave_min(int v) { for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64)); return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline int wave_max(int v) { for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64)); return __builtin_amdgcn_readfirstlane(v); }
-__device__ inline int wave_excl_scan(int v, int lane) {
-  int inc = v;
-  for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-  return inc - v;
+// wave64 prefix sum with DPP row shifts and row broadcasts: six adds, no LDS traffic (the __shfl_up form is 6 x (ds_bpermute
+// + compare + add))
+__device__ inline int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+  return v;
 }
+__device__ inline int wave_excl_scan(int v, int lane) { (void)lane; return wave_incl_scan(v) - v; }
 
 // Wave-cooperative lower_bound over wpos in pos[lo,hi): 64 pivots per step (one dependent memory round trip narrows
 // the range 64-fold) instead of one pivot per step.  All arguments wave-uniform; returns the first index whose

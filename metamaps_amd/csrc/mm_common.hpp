@@ -212,6 +212,17 @@ struct mm_ctx {
   // per-(k, pi) cache of the host statistics thresholds (pure functions of the sketch size), mm_stats.hpp
   std::shared_ptr<void> lut_cache;
   int lut_k = 0; float lut_pi = 0;
+  // K5 scratch kept across batches: the per-entry code words of pass A (4 B per streamed entry slot, mm_l2.hpp)
+  void* l2_codes = nullptr; size_t l2_codes_bytes = 0;
+  void* l2_codes_at_least(size_t bytes) {
+    if (bytes > l2_codes_bytes) {
+      if (l2_codes) { MM_HIP(hipStreamSynchronize(stream)); (void)hipFree(l2_codes); }
+      l2_codes = nullptr; l2_codes_bytes = 0;
+      MM_HIP(hipMalloc(&l2_codes, bytes));
+      l2_codes_bytes = bytes;
+    }
+    return l2_codes;
+  }
   // pinned bounce buffer for result downloads into caller-owned (pageable) memory
   void* pinned = nullptr; size_t pinned_bytes = 0;
   void* pinned_at_least(size_t bytes) {

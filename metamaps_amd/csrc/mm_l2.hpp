@@ -197,7 +197,8 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
                                                 const int32_t* __restrict__ grp_n /* WAVES>1: candidates in the group */,
                                                 const int32_t* __restrict__ cand_list /* WAVES==1: optional indirection (fallback runs) */,
                                                 int32_t* __restrict__ ovf_list, unsigned int* __restrict__ ovf_n,
-                                                uint8_t* __restrict__ amb_used /* optional: set per read when a vote read an unresolved strand */) {
+                                                uint8_t* __restrict__ amb_used /* optional: set per read when a vote read an unresolved strand */,
+                                                uint32_t* __restrict__ code_buf /* optional: 64*64*NWQ words per wave of the launch */) {
   extern __shared__ __align__(16) uint32_t lds[];
   uint32_t* Q = lds;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -239,6 +240,12 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   constexpr int DPER = 4 / (int)sizeof(DT);                      // counters per 32-bit word
   constexpr int DBITS = 8 * (int)sizeof(DT);
   int overflow = 0;
+  // Pass A classifies every streamed entry once; its result (rank / gap code in the low 16 bits, strand and duplicate
+  // flags above) is parked in global memory, 4 bytes per entry, and read back by the rebuilds, the slide rounds and the
+  // vote instead of searching the sketch again.
+  uint32_t* const cw = code_buf ? code_buf + (size_t)(WAVES > 1 ? blockIdx.x * WAVES + wave : blockIdx.x) * (size_t)(64 * 64 * NWQ) : nullptr;
+  bool have_codes = false;                                       // set once pass A has run
+  auto code_of_word = [](uint32_t ew) -> int { return (int)(int16_t)(uint16_t)(ew & 0xffffu); };
 
   const int contig = cand[3 * c], rs = cand[3 * c + 1], re = cand[3 * c + 2];
   const int cnt = len - (w - 1) - (k - 1);                       // computeMap.hpp:470
@@ -316,13 +323,18 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       ++n_inc;
     };
     for (int base = nb; base < ne; base += 512) {                // eight loads in flight per wait
-      Rec x[8]; int cd[8];
+      int cd[8]; uint32_t fl[8];
+      if (have_codes) {
+        const uint32_t* __restrict__ pc = cw + (base - first) + lane;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int j = base + lane + 64 * i; x[i] = pos[min(j, nmax)]; }
-      {
+        for (int i = 0; i < 8; ++i) { const uint32_t ew = pc[min(64 * i, 64 * 64 * NWQ - 1 - (base - first) - lane)]; cd[i] = code_of_word(ew); fl[i] = ew >> 16; }
+      } else {
+        Rec x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int j = base + lane + 64 * i; x[i] = pos[min(j, nmax)]; }
         uint32_t hh[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) hh[i] = x[i].hash;
+        for (int i = 0; i < 8; ++i) { hh[i] = x[i].hash; fl[i] = x[i].pw & 7u; }
         l2_classify8(Q, T, tsteps, s, hh, cd);
       }
 #pragma unroll
@@ -334,13 +346,13 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
         const bool in = j < ne;
         if (in && code >= 0) atomicOr(&mt[code >> 5], 1u << (code & 31));
         const bool wonly = in && code < 0 && g < s;
-        const bool flagged = wonly && (x[i].pw & PW_DP);          // an earlier occurrence exists in the contig: inside the window?
+        const bool flagged = wonly && (fl[i] & PW_DP);            // an earlier occurrence exists in the contig: inside the window?
         if (wonly && !flagged) d_inc(g);
         uint64_t fm = __ballot(flagged);                         // rare: resolved one by one with a wave-wide scan
         while (fm) {
           const int l = __ffsll((unsigned long long)fm) - 1;
           fm &= fm - 1;
-          const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)x[i].hash, l);
+          const uint32_t hj = pos[base + l + 64 * i].hash;
           const bool dup = wave_has_hash(pos, nb, base + l + 64 * i, hj, lane);
           if (!dup && lane == l) d_inc(g);
         }
@@ -431,7 +443,9 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
       const Rec xb = pos[min(b + lane, nmax)];
       const Rec xe = pos[min(e + lane, nmax)];
       const int w64 = pw_wpos(pos[min(b + 64, nmax)].pw);
-      const int cB = l2_classify1(Q, T, tsteps, s, xb.hash), cE = l2_classify1(Q, T, tsteps, s, xe.hash);
+      int cB, cE;
+      if (have_codes) { cB = code_of_word(cw[min(b - first + lane, 64 * 64 * NWQ - 1)]); cE = code_of_word(cw[min(e - first + lane, 64 * 64 * NWQ - 1)]); }
+      else { cB = l2_classify1(Q, T, tsteps, s, xb.hash); cE = l2_classify1(Q, T, tsteps, s, xe.hash); }
       const int wpb = pw_wpos(xb.pw);
       int nextw = __shfl_down(wpb, 1, 64);
       if (lane == 63) nextw = w64;
@@ -668,6 +682,11 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
           for (int i = 0; i < 8; ++i) hh[i] = x[i].hash;
           l2_classify8(Q, T, tsteps, s, hh, cd);
         }
+        if (cw) {
+          uint32_t* __restrict__ pc = cw + (base - first) + lane;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) if (base + 64 * i < last_end) pc[64 * i] = (uint32_t)(uint16_t)(int16_t)cd[i] | ((x[i].pw & 7u) << 16);
+        }
         const int wd0 = (int)((base - first) >> 6);
         dispatch(wd0 >> 6, base + 512 <= last_end, [&](auto qtag, auto fulltag) {
           constexpr int QH = decltype(qtag)::value;
@@ -751,6 +770,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     if (phase == 0) {
       lap(0);
       pass_matched();
+      have_codes = cw != nullptr;
       lap(1);
       if (dbg_stop == 2) return;
       // per block of `bspan` b's: largest window [bF, eHi), smallest window [bL, eLo)   (lane l owns blocks l and l+64)
@@ -866,13 +886,18 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     accepted = 1;
     int votes = 0, amb_votes = 0;                                 // votes of resolved strands / number of votes whose query strand is unresolved
     for (int base = opt_b; base < opt_e; base += 512) {
-      Rec x[8]; int cd[8];
+      int cd[8]; uint32_t fl[8];
+      if (have_codes) {
+        const uint32_t* __restrict__ pc = cw + (base - first) + lane;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int j = base + lane + 64 * i; x[i] = pos[min(j, nmax)]; }
-      {
+        for (int i = 0; i < 8; ++i) { const uint32_t ew = pc[min(64 * i, 64 * 64 * NWQ - 1 - (base - first) - lane)]; cd[i] = code_of_word(ew); fl[i] = ew >> 16; }
+      } else {
+        Rec x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int j = base + lane + 64 * i; x[i] = pos[min(j, nmax)]; }
         uint32_t hh[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) hh[i] = x[i].hash;
+        for (int i = 0; i < 8; ++i) { hh[i] = x[i].hash; fl[i] = x[i].pw & 7u; }
         l2_classify8(Q, T, tsteps, s, hh, cd);
       }
 #pragma unroll
@@ -883,14 +908,14 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
         const bool cnt_it = j < opt_e && code >= 0 && code < bestR;
         const uint8_t sq = cnt_it ? sk_strand[qo + code] : (uint8_t)0;   // bit 0 strand, bit 1 unresolved duplicate (mm_map.hip, K2)
         const bool unres = (sq & 2) && amb_used != nullptr;       // (after the host resolved the read, amb_used is null and bit 1 is gone)
-        const int contrib = cnt_it ? ((sq & 1) ? 1 : -1) * pw_strand(x[i].pw) : 0;
-        const bool flagged = cnt_it && (x[i].pw & PW_DN);         // a later occurrence exists in the contig: inside the window?
+        const int contrib = cnt_it ? ((sq & 1) ? 1 : -1) * pw_strand(fl[i]) : 0;
+        const bool flagged = cnt_it && (fl[i] & PW_DN);           // a later occurrence exists in the contig: inside the window?
         if (cnt_it && !flagged) { if (unres) ++amb_votes; else votes += contrib; }
         uint64_t fm = __ballot(flagged);
         while (fm) {
           const int l = __ffsll((unsigned long long)fm) - 1;
           fm &= fm - 1;
-          const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)x[i].hash, l);
+          const uint32_t hj = pos[base + l + 64 * i].hash;
           const bool later = wave_has_hash(pos, base + l + 64 * i + 1, opt_e, hj, lane);
           if (!later && lane == l) { if (unres) ++amb_votes; else votes += contrib; }
         }

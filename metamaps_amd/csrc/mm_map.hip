@@ -809,7 +809,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     if (!skip) {
       set_lds((const void*)l2_kernel<false, uint16_t, 1, 8>, lds_wide);
       l2_kernel<false, uint16_t, 1, 8><<<dim3((unsigned)ncand), dim3(64), lds_wide, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-          M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, nullptr, nullptr, nullptr, amb_used_p);
+          M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, nullptr, nullptr, nullptr, amb_used_p, nullptr);
       MM_KERNEL_CHECK();
     } else {
       // Reads are grouped by sketch size so that one long read does not size the LDS state (and the occupancy) of all:
@@ -819,6 +819,12 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       //   D  s <= 16384  (~74 kb)                      two candidates per workgroup, otherwise as B
       //   C  larger                                    one wave per workgroup, 16-bit counters, 32 768 entries
       // Candidates whose 8-bit counters saturate are redone by the C kernel.
+      // per-entry code words of pass A: one slot range per wave of a launch (the launches of a batch run one after the other
+      // on the stream, so they share the buffer); classes whose ranks do not fit 16 bits (C) search the sketch instead
+      auto codes_for = [&](size_t n_waves, int nwq) -> uint32_t* {
+        if (getenv("MM_L2_NO_CODES")) return nullptr;              // cross-check switch
+        return (uint32_t*)ctx->l2_codes_at_least(n_waves * (size_t)(64 * 64 * nwq) * sizeof(uint32_t));
+      };
       std::vector<int32_t> gA0, gAn, gB0, gBn, gD0, gDn, listC;
       int smA = 0, smB = 0, smC = 0, smD = 0;
       for (int64_t r = 0; r < n; ++r) {
@@ -843,7 +849,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 4, 2);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 2>, lds);
         l2_kernel<true, uint8_t, 4, 2><<<dim3((unsigned)gA0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gA0.size() * 4, 2));
         MM_KERNEL_CHECK();
       }
       if (!gB0.empty()) {
@@ -851,7 +857,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smB, true, 4, 8);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
         l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gB0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smB, M->l2.p, counters.p, d_gB0.p, d_gBn.p, nullptr, ovf.p, ovf_n.p, amb_used_p);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smB, M->l2.p, counters.p, d_gB0.p, d_gBn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gB0.size() * 4, 8));
         MM_KERNEL_CHECK();
       }
       DBuf<int32_t> d_gD0(gD0.size()), d_gDn(gDn.size());
@@ -860,7 +866,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smD, true, 2, 8);
         set_lds((const void*)l2_kernel<true, uint8_t, 2, 8>, lds);
         l2_kernel<true, uint8_t, 2, 8><<<dim3((unsigned)gD0.size()), dim3(128), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p, amb_used_p);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gD0.size() * 2, 8));
         MM_KERNEL_CHECK();
       }
       if (!listC.empty()) {
@@ -868,7 +874,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint16_t>(smC, true, 1, 8);
         set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
         l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)listC.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smC, M->l2.p, counters.p, nullptr, nullptr, d_listC.p, nullptr, nullptr, amb_used_p);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smC, M->l2.p, counters.p, nullptr, nullptr, d_listC.p, nullptr, nullptr, amb_used_p, nullptr);
         MM_KERNEL_CHECK();
       }
       unsigned int h_ovf = 0;
@@ -879,7 +885,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint16_t>(smO, true, 1, 8);
         set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
         l2_kernel<true, uint16_t, 1, 8><<<dim3(h_ovf), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smO, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr, amb_used_p);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smO, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr, amb_used_p, nullptr);
         MM_KERNEL_CHECK();
       }
       M->stats.n_l2_wide_redo = (int64_t)h_ovf;
@@ -898,7 +904,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           const size_t lds = l2_lds_bytes<uint16_t>(smR, true, 1, 8);
           set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
           l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)redo.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smR, M->l2.p, counters.p, nullptr, nullptr, d_redo.p, nullptr, nullptr, nullptr);
+              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smR, M->l2.p, counters.p, nullptr, nullptr, d_redo.p, nullptr, nullptr, nullptr, nullptr);
           MM_KERNEL_CHECK();
           MM_HIP(hipStreamSynchronize(st));
           M->stats.n_l2_wide_redo += (int64_t)redo.size();

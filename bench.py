@@ -109,7 +109,7 @@ def main():
 
     contig_taxon = np.arange(G, dtype=np.int32)                  # one contig per genome = one taxon per contig
     contig_len = ref.lengths().astype(np.int32)
-    agg = {"ms_l2": 0.0, "l2_launches": 0, "l2_stream": 0, "stats": None, "em_iters": 0}
+    agg = {"ms_l2": 0.0, "ms_hf": 0.0, "l2_launches": 0, "l2_stream": 0, "hf_hits": 0, "stats": None, "em_iters": 0}
     rec_buf = np.empty(max(64 * args.reads, 1 << 16), dtype=capi.RECORD_DTYPE)   # host result buffer reused by every step
 
     def step():
@@ -149,6 +149,7 @@ def main():
         agg["host_ms"] = {"map_batch": (tt[1] - tt[0]) * 1e3, "mapq_fetch": (tt[2] - tt[1]) * 1e3, "em_prepare_iterate": (tt[3] - tt[2]) * 1e3,
                           "posteriors": (tt[4] - tt[3]) * 1e3}
         agg["ms_l2"] += st["ms_l2"]; agg["l2_launches"] += 1; agg["l2_stream"] += st["sum_l2_stream_entries"]
+        agg["ms_hf"] += st["ms_hit_filter"]; agg["hf_hits"] += st["sum_hits"]
         agg["stats"] = st; agg["em_iters"] = len(lls)
         return st, f, best
 
@@ -160,7 +161,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    agg.update({"ms_l2": 0.0, "l2_launches": 0, "l2_stream": 0})
+    agg.update({"ms_l2": 0.0, "ms_hf": 0.0, "l2_launches": 0, "l2_stream": 0, "hf_hits": 0})
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -180,11 +181,15 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = bases_all * args.steps / dt / 1e9
-        # roofline of the dominant kernel (K5/K6): algorithmic bytes = 8 B per streamed index entry
-        # (8·Σ_c M_{r,c}) per launch ÷ its mean duration from hipEvents on the ctx stream
-        l2_bytes = 8.0 * agg["l2_stream"] / max(agg["l2_launches"], 1)
-        l2_ms = agg["ms_l2"] / max(agg["l2_launches"], 1)
-        achieved = l2_bytes / (l2_ms * 1e-3) / 1e9 if l2_ms > 0 else 0.0
+        # roofline of the dominant kernel — whichever of the two big kernels took longer per launch (hipEvents on the ctx
+        # stream around each).  Algorithmic bytes per launch, SURVEY.md §8 D3:
+        #   K5/K6  l2_kernel                  8 B per streamed index entry   (8·Σ_c M_{r,c})
+        #   K3c    hit_filter_kernel<false>   8 B per seed hit               (8·H_r)
+        nl = max(agg["l2_launches"], 1)
+        cands = [("l2_kernel", 8.0 * agg["l2_stream"] / nl, agg["ms_l2"] / nl),
+                 ("hit_filter_kernel<false>", 8.0 * agg["hf_hits"] / nl, agg["ms_hf"] / nl)]
+        dom_name, dom_bytes, dom_ms = max(cands, key=lambda c: c[2])
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         out_workload = (f"{args.reads} synthetic {args.read_len} bp ONT-error reads per GPU vs synthetic miniSeq+H-shaped index "
                         f"({args.species} species x {args.strains} strains x {args.genome_len} bp = {G * args.genome_len / 1e9:.2f} Gbp), k=16 w={w}, --all")
         out = {
@@ -205,9 +210,11 @@ def main():
                 "stage_ms": {kk: round(st[kk], 3) for kk in st if kk.startswith("ms_")},
                 "host_wall_ms": {kk: round(v, 3) for kk, v in agg.get("host_ms", {}).items()},
             },
-            "roofline": {"bound": "hbm", "kernel": "l2_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(out_workload),
-                         "algorithmic_bytes_per_launch": l2_bytes, "ms_per_launch": l2_ms},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(out_workload, dom_name),
+                         "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms,
+                         "other_kernels": {n: {"ms_per_launch": m, "algorithmic_bytes_per_launch": b, "achieved": (b / (m * 1e-3) / 1e9 if m > 0 else 0.0)}
+                                           for n, b, m in cands if n != dom_name}},
         }
         if not args.no_cpu_baseline:
             try:
@@ -221,13 +228,18 @@ def main():
     ctx.close()
 
 
-def measured_traffic(workload: str):
+def measured_traffic(workload: str, kernel: str = "l2_kernel"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     collected and corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes; profiles/r01_pmc_hbm_traffic.txt).
     bench.py cannot run the profiler itself, so the number is reported only for the workload it was measured on."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        return t["traffic_bytes_per_launch"] if t.get("workload") == workload else None
+        if t.get("workload") != workload:
+            return None
+        for name, v in t.get("by_kernel", {}).items():
+            if kernel.split("<")[0] in name and ("<false>" in name) == ("<false>" in kernel):
+                return v
+        return t["traffic_bytes_per_launch"] if kernel == t.get("kernel") else None
     except Exception:
         return None
 

@@ -159,8 +159,9 @@ typedef struct {
   int64_t n_l2_rebuilds;              /* window states rebuilt from scratch by the exact skip-ahead of K5 */
   int64_t n_l2_wide_redo;             /* candidates redone with 16-bit gap counters after an 8-bit counter saturated */
   /* device time of each stage of this batch, milliseconds, from hipEvents recorded on the ctx stream
-   * around the launches (bench.py's roofline uses ms_l2 = the K5/K6 kernel) */
-  double ms_minimizer, ms_sketch, ms_probe_gather, ms_sort_hits, ms_l1_scan, ms_l2, ms_compact, ms_total;
+   * around the launches; ms_l2 (the K5/K6 kernel) and ms_hit_filter (the counting+filtering K3c kernel, part of
+   * ms_probe_gather) are single kernels: bench.py's roofline uses whichever is larger */
+  double ms_minimizer, ms_sketch, ms_probe_gather, ms_sort_hits, ms_l1_scan, ms_l2, ms_compact, ms_total, ms_hit_filter;
 } mm_map_stats;
 
 int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, mm_mapping** out);

@@ -712,9 +712,11 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       h_stage_off[(size_t)r + 1] = h_stage_off[(size_t)r] + (M->h_sk_n[(size_t)r] > 0 ? (cap_env ? (uint64_t)atoi(cap_env) : 1024 + 2 * (uint64_t)M->h_sk_n[(size_t)r]) : 0);
     stage_off.alloc((size_t)n + 1); stage_off.upload(h_stage_off.data(), h_stage_off.size(), st);
     stage.alloc((size_t)std::max<uint64_t>(h_stage_off[(size_t)n], 1));
+    const size_t t_hf = T.begin(&M->stats.ms_hit_filter);
     hit_filter_kernel<false><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
                                                                    M->min_hits.p, surv.p, nullptr, nullptr, stage.p, stage_off.p, getenv("MM_HF_DBG") ? atoi(getenv("MM_HF_DBG")) : 0);
     MM_KERNEL_CHECK();
+    T.end(t_hf);
     exclusive_scan_u32_u64(surv.p, n, M->read_hit_off.p, scan_tmp, st);
   } else {
     read_hit_bounds_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(M->mz.off.p, hit_off.p, n, M->read_hit_off.p);

@@ -216,7 +216,7 @@ def main():
                          "other_kernels": {n: {"ms_per_launch": m, "algorithmic_bytes_per_launch": b, "achieved": (b / (m * 1e-3) / 1e9 if m > 0 else 0.0)}
                                            for n, b, m in cands if n != dom_name}},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:              # (the contract asks for it at N=1 only)
             try:
                 out["cpu_baseline"] = cpu_baseline(args, ctx, ref, reads, truth, k, w)
             except Exception as e:  # the baseline is a reported side number; never let it kill the bench line

@@ -40,6 +40,7 @@ def parse_args():
     # workload: BASELINE configs[1] shape; scale knobs exist so that smaller boxes / quick checks can run
     ap.add_argument("--reads", type=int, default=int(os.environ.get("MM_BENCH_READS", 100_000)), help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=10_000)
+    ap.add_argument("--read-len-min", type=int, default=0, help="mixed lengths, log-uniform in [read-len-min, read-len] (BASELINE config 3 shape); 0 = fixed")
     ap.add_argument("--species", type=int, default=int(os.environ.get("MM_BENCH_SPECIES", 3000)))
     ap.add_argument("--strains", type=int, default=int(os.environ.get("MM_BENCH_STRAINS", 4)))
     ap.add_argument("--genome-len", type=int, default=int(os.environ.get("MM_BENCH_GENOME_LEN", 2_200_000)))
@@ -102,7 +103,7 @@ def main():
     ctx.synchronize()
     t_index = time.time() - t0
     info = idx.info()
-    reads, truth = ctx.synth_reads(ref, seed=1000 + rank, n_reads=args.reads, read_len=args.read_len,
+    reads, truth = ctx.synth_reads(ref, seed=1000 + rank, n_reads=args.reads, read_len=args.read_len, read_len_min=args.read_len_min,
                                    sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=100)
     read_len = reads.lengths().astype(np.int64)
     ctx.synchronize()
@@ -190,7 +191,8 @@ def main():
                  ("hit_filter_kernel<false>", 8.0 * agg["hf_hits"] / nl, agg["ms_hf"] / nl)]
         dom_name, dom_bytes, dom_ms = max(cands, key=lambda c: c[2])
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        out_workload = (f"{args.reads} synthetic {args.read_len} bp ONT-error reads per GPU vs synthetic miniSeq+H-shaped index "
+        len_txt = f"{args.read_len}" if not args.read_len_min else f"{args.read_len_min}-{args.read_len}"
+        out_workload = (f"{args.reads} synthetic {len_txt} bp ONT-error reads per GPU vs synthetic miniSeq+H-shaped index "
                         f"({args.species} species x {args.strains} strains x {args.genome_len} bp = {G * args.genome_len / 1e9:.2f} Gbp), k=16 w={w}, --all")
         out = {
             "metric": "Gbp long reads mapped+classified per sec (whole node), miniSeq+H DB",

@@ -91,6 +91,7 @@ typedef struct {
   float sub_rate, ins_rate, del_rate;
   float frac_random;          /* reads made of random sequence (unmappable)                          */
   int32_t n_abundant;         /* reads are drawn from this many genomes, lognormal abundances        */
+  int32_t read_len_min;       /* 0: every read has read_len bases; else lengths log-uniform in [read_len_min, read_len] */
 } mm_synth_read_params;
 int mm_synth_reference(mm_ctx* ctx, const mm_synth_ref_params* p, mm_seqset** out);
 /* truth_genome (optional, [n_reads]) receives the source genome index or -1 */

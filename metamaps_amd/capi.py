@@ -61,7 +61,7 @@ class SynthRefParams(C.Structure):
 
 class SynthReadParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_reads", C.c_int64), ("read_len", C.c_int32), ("sub_rate", C.c_float),
-                ("ins_rate", C.c_float), ("del_rate", C.c_float), ("frac_random", C.c_float), ("n_abundant", C.c_int32)]
+                ("ins_rate", C.c_float), ("del_rate", C.c_float), ("frac_random", C.c_float), ("n_abundant", C.c_int32), ("read_len_min", C.c_int32)]
 
 
 def declared_symbols(header: str = HEADER_PATH) -> list[str]:

@@ -75,13 +75,16 @@ void synth_reference(mm_ctx* ctx, const mm_synth_ref_params& p, mm_seqset* S) {
 // one thread per read: walk the template, apply deletions / substitutions / insertions, pack as we go
 __global__ void synth_reads_kernel(const uint32_t* __restrict__ ref, const uint64_t* __restrict__ ref_base_off, int ref_len,
                                    const int32_t* __restrict__ pick_genome, const float* __restrict__ pick_cum, int n_pick,
-                                   int64_t n_reads, int read_len, int64_t stride_words, uint64_t seed, float sub, float ins, float del,
+                                   int64_t n_reads, int read_len_max, int read_len_min, int64_t stride_words, uint64_t seed, float sub, float ins, float del,
                                    float frac_random, uint32_t* __restrict__ out, int32_t* __restrict__ out_len, int32_t* __restrict__ truth) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_reads) return;
   const uint64_t s0 = 0x400000000ull + (uint64_t)r;
   uint64_t h = rnd(seed, s0, 0);
   const bool random_read = u01(h) < frac_random;
+  int read_len = read_len_max;
+  if (read_len_min > 0 && read_len_min < read_len_max)          // log-uniform lengths
+    read_len = min(read_len_max, (int)((float)read_len_min * expf(u01(rnd(seed, s0, 4)) * logf((float)read_len_max / (float)read_len_min))));
   int g = -1; int64_t start = 0; bool rev = false;
   if (!random_read) {
     float u = u01(rnd(seed, s0, 1));
@@ -157,7 +160,7 @@ void synth_reads(mm_ctx* ctx, const mm_seqset* ref, const mm_synth_read_params& 
   DBuf<int32_t> d_truth((size_t)p.n_reads);
   S->d_len.alloc((size_t)p.n_reads);
   synth_reads_kernel<<<dim3((unsigned)ceil_div(p.n_reads, 128)), dim3(128), 0, st>>>(ref->packed.p, ref->d_base.p, ref_len, d_ids.p, d_cum.p, npick,
-      p.n_reads, p.read_len, sw, p.seed, p.sub_rate, p.ins_rate, p.del_rate, p.frac_random, S->packed.p, S->d_len.p, d_truth.p);
+      p.n_reads, p.read_len, p.read_len_min, sw, p.seed, p.sub_rate, p.ins_rate, p.del_rate, p.frac_random, S->packed.p, S->d_len.p, d_truth.p);
   MM_KERNEL_CHECK();
   S->len = S->d_len.to_host(st, (size_t)p.n_reads);
   if (truth_genome) { auto t = d_truth.to_host(st); memcpy(truth_genome, t.data(), sizeof(int32_t) * (size_t)p.n_reads); }

@@ -409,3 +409,24 @@ def test_l2_long_read_classes_equal_full_slide(ctx, monkeypatch, read_len, n_rea
     assert np.array_equal(res["0"][0], res["1"][0]) and np.array_equal(res["0"][1], res["1"][1])
     assert res["0"][2]["n_mappings"] > n_reads and res["0"][2]["sum_l2_evals"] < res["1"][2]["sum_l2_evals"]
     idx.close(); reads.close(); ref.close()
+
+
+def test_mixed_read_lengths_one_batch_equal_full_slide(ctx, monkeypatch):
+    """reads of 1-60 kb in one batch (BASELINE config 3 shape): every K5 class is launched in the same map_batch and shares
+    the code-word scratch; records must equal the literal full slide"""
+    ref = ctx.synth_reference(seed=25, n_species=12, strains_per_species=4, genome_len=600_000, strain_divergence=0.02, genus_divergence=0.08)
+    reads, _ = ctx.synth_reads(ref, seed=29, n_reads=1200, read_len=60_000, read_len_min=1_000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=10)
+    lens = reads.lengths()
+    assert lens.min() < 2_500 and lens.max() > 40_000 and ((lens > 14_000) & (lens < 30_000)).sum() > 50
+    idx = ctx.index(ref, 16, 8)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MM_L2_FULL", mode)
+        M = ctx.map_batch(idx, reads, 16, 8)
+        off, rec = M.fetch()
+        res[mode] = (off.copy(), rec.copy(), M.stats())
+        M.close()
+    monkeypatch.delenv("MM_L2_FULL")
+    assert np.array_equal(res["0"][0], res["1"][0]) and np.array_equal(res["0"][1], res["1"][1])
+    assert res["0"][2]["n_mappings"] > 1500
+    idx.close(); reads.close(); ref.close()

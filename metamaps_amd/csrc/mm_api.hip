@@ -59,6 +59,7 @@ void mm_ctx_destroy(mm_ctx* ctx) {
   mm::comm_destroy(ctx);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->l2_codes) (void)hipFree(ctx->l2_codes);
+  if (ctx->l2_masks) (void)hipFree(ctx->l2_masks);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -223,6 +223,16 @@ struct mm_ctx {
     }
     return l2_codes;
   }
+  void* l2_masks = nullptr; size_t l2_masks_bytes = 0;           // class masks of the long-read K5 classes
+  void* l2_masks_at_least(size_t bytes) {
+    if (bytes > l2_masks_bytes) {
+      if (l2_masks) { MM_HIP(hipStreamSynchronize(stream)); (void)hipFree(l2_masks); }
+      l2_masks = nullptr; l2_masks_bytes = 0;
+      MM_HIP(hipMalloc(&l2_masks, bytes));
+      l2_masks_bytes = bytes;
+    }
+    return l2_masks;
+  }
   // pinned bounce buffer for result downloads into caller-owned (pageable) memory
   void* pinned = nullptr; size_t pinned_bytes = 0;
   void* pinned_at_least(size_t bytes) {

@@ -170,7 +170,7 @@ template <typename DT>
 __host__ __device__ inline size_t l2_wave_bytes(int smax, bool skip, int nwq) {
   size_t b = (((size_t)smax * sizeof(DT) + 3) & ~(size_t)3) + (size_t)((smax + 31) / 32) * 4;
   b = (b + 15) & ~(size_t)15;
-  if (skip) b += l2_skip_bytes(nwq) + L2_SCRATCH_BYTES;
+  if (skip) b += (nwq > 2 ? 0 : l2_skip_bytes(nwq)) + L2_SCRATCH_BYTES;   // the long-read classes keep their masks in global memory
   return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t l2_qpart_bytes(int smax) { return ((size_t)(smax + L2_QPAD) * 4 + 15) & ~(size_t)15; }
@@ -198,7 +198,8 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
                                                 const int32_t* __restrict__ cand_list /* WAVES==1: optional indirection (fallback runs) */,
                                                 int32_t* __restrict__ ovf_list, unsigned int* __restrict__ ovf_n,
                                                 uint8_t* __restrict__ amb_used /* optional: set per read when a vote read an unresolved strand */,
-                                                uint32_t* __restrict__ code_buf /* optional: 64*64*NWQ words per wave of the launch */) {
+                                                uint32_t* __restrict__ code_buf /* optional: 64*64*NWQ words per wave of the launch */,
+                                                uint8_t* __restrict__ mask_buf /* NWQ > 2: l2_skip_bytes(NWQ) per wave of the launch */) {
   extern __shared__ __align__(16) uint32_t lds[];
   uint32_t* Q = lds;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -419,7 +420,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   // ds_bpermute) and shared_j = sb_j + popcount(pm_j below R_j).  Events inside the zone are rare and applied one by one.
   // Only times up to min(A_63, B_63) are certain (later entries of the other list could interleave), the rest of the
   // chunk is redone by the next round.
-  int* tst = (int*)(wbase + l2_wave_bytes<DT>(smax, false, NWQ) + l2_skip_bytes(NWQ));
+  int* tst = (int*)(wbase + l2_wave_bytes<DT>(smax, false, NWQ) + (NWQ > 2 ? 0 : l2_skip_bytes(NWQ)));
   uint8_t* fdel = (uint8_t*)(tst + 64);
   uint8_t* fadd = fdel + 64;
   auto rank_search = [&](int arr, int v) -> int {                // number of leading lanes whose (ascending) arr < v
@@ -606,7 +607,10 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     constexpr int NWORDS_MAX = 64 * NWQ;
     int phase = (M <= 64 * NWORDS_MAX && M > 192) ? 0 : 2;
     bool finished = false;
-    uint64_t* mAll = (uint64_t*)(wbase + l2_wave_bytes<DT>(smax, false, NWQ));
+    // class masks and their prefix counts: LDS for the 10 kb class; for the long-read classes (NWQ > 2) they are written once
+    // and read a few times per block, so they live in global memory and the LDS they would take buys resident waves instead
+    uint64_t* mAll = NWQ > 2 ? (uint64_t*)(mask_buf + (size_t)(WAVES > 1 ? blockIdx.x * WAVES + wave : blockIdx.x) * l2_skip_bytes(NWQ))
+                             : (uint64_t*)(wbase + l2_wave_bytes<DT>(smax, false, NWQ));
     uint64_t* mLo = mAll + (NWORDS_MAX + 1);
     uint64_t* mA = mLo + (NWORDS_MAX + 1);
     uint16_t* pAll = (uint16_t*)(mA + (NWORDS_MAX + 1));

@@ -811,18 +811,19 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     if (!skip) {
       set_lds((const void*)l2_kernel<false, uint16_t, 1, 8>, lds_wide);
       l2_kernel<false, uint16_t, 1, 8><<<dim3((unsigned)ncand), dim3(64), lds_wide, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-          M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, nullptr, nullptr, nullptr, amb_used_p, nullptr);
+          M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, nullptr, nullptr, nullptr, amb_used_p, nullptr, nullptr);
       MM_KERNEL_CHECK();
     } else {
       // Reads are grouped by sketch size so that one long read does not size the LDS state (and the occupancy) of all:
       //   A  s <= 3072   (reads up to ~14 kb at w=8)  compact: 4 candidates of a read per workgroup share the sketch,
       //                                                8-bit gap counters, masks for 8 192 streamed entries
-      //   B  s <= 7168   (~32 kb)                      the same with masks for 32 768 entries
+      //   B  s <= 7168   (~32 kb)                      the same with masks for 32 768 entries, kept in global memory
       //   D  s <= 16384  (~74 kb)                      two candidates per workgroup, otherwise as B
       //   C  larger                                    one wave per workgroup, 16-bit counters, 32 768 entries
       // Candidates whose 8-bit counters saturate are redone by the C kernel.
       // per-entry code words of pass A: one slot range per wave of a launch (the launches of a batch run one after the other
       // on the stream, so they share the buffer); classes whose ranks do not fit 16 bits (C) search the sketch instead
+      auto masks_for = [&](size_t n_waves) -> uint8_t* { return (uint8_t*)ctx->l2_masks_at_least(std::max<size_t>(n_waves, 1) * l2_skip_bytes(8)); };
       auto codes_for = [&](size_t n_waves, int nwq) -> uint32_t* {
         if (getenv("MM_L2_NO_CODES")) return nullptr;              // cross-check switch
         return (uint32_t*)ctx->l2_codes_at_least(n_waves * (size_t)(64 * 64 * nwq) * sizeof(uint32_t));
@@ -851,7 +852,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 4, 2);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 2>, lds);
         l2_kernel<true, uint8_t, 4, 2><<<dim3((unsigned)gA0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gA0.size() * 4, 2));
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gA0.size() * 4, 2), nullptr);
         MM_KERNEL_CHECK();
       }
       if (!gB0.empty()) {
@@ -859,7 +860,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smB, true, 4, 8);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
         l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gB0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smB, M->l2.p, counters.p, d_gB0.p, d_gBn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gB0.size() * 4, 8));
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smB, M->l2.p, counters.p, d_gB0.p, d_gBn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gB0.size() * 4, 8), masks_for(gB0.size() * 4));
         MM_KERNEL_CHECK();
       }
       DBuf<int32_t> d_gD0(gD0.size()), d_gDn(gDn.size());
@@ -868,7 +869,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smD, true, 2, 8);
         set_lds((const void*)l2_kernel<true, uint8_t, 2, 8>, lds);
         l2_kernel<true, uint8_t, 2, 8><<<dim3((unsigned)gD0.size()), dim3(128), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gD0.size() * 2, 8));
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gD0.size() * 2, 8), masks_for(gD0.size() * 2));
         MM_KERNEL_CHECK();
       }
       if (!listC.empty()) {
@@ -876,7 +877,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint16_t>(smC, true, 1, 8);
         set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
         l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)listC.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smC, M->l2.p, counters.p, nullptr, nullptr, d_listC.p, nullptr, nullptr, amb_used_p, nullptr);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smC, M->l2.p, counters.p, nullptr, nullptr, d_listC.p, nullptr, nullptr, amb_used_p, nullptr, masks_for(listC.size()));
         MM_KERNEL_CHECK();
       }
       unsigned int h_ovf = 0;
@@ -887,7 +888,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint16_t>(smO, true, 1, 8);
         set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
         l2_kernel<true, uint16_t, 1, 8><<<dim3(h_ovf), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smO, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr, amb_used_p, nullptr);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smO, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr, amb_used_p, nullptr, masks_for(h_ovf));
         MM_KERNEL_CHECK();
       }
       M->stats.n_l2_wide_redo = (int64_t)h_ovf;
@@ -906,7 +907,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           const size_t lds = l2_lds_bytes<uint16_t>(smR, true, 1, 8);
           set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
           l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)redo.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smR, M->l2.p, counters.p, nullptr, nullptr, d_redo.p, nullptr, nullptr, nullptr, nullptr);
+              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smR, M->l2.p, counters.p, nullptr, nullptr, d_redo.p, nullptr, nullptr, nullptr, nullptr, masks_for(redo.size()));
           MM_KERNEL_CHECK();
           MM_HIP(hipStreamSynchronize(st));
           M->stats.n_l2_wide_redo += (int64_t)redo.size();

@@ -170,7 +170,7 @@ template <typename DT>
 __host__ __device__ inline size_t l2_wave_bytes(int smax, bool skip, int nwq) {
   size_t b = (((size_t)smax * sizeof(DT) + 3) & ~(size_t)3) + (size_t)((smax + 31) / 32) * 4;
   b = (b + 15) & ~(size_t)15;
-  if (skip) b += (nwq > 2 ? 0 : l2_skip_bytes(nwq)) + L2_SCRATCH_BYTES;   // the long-read classes keep their masks in global memory
+  if (skip) b += (nwq >= 1 ? 0 : l2_skip_bytes(nwq)) + L2_SCRATCH_BYTES;   // the long-read classes keep their masks in global memory
   return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t l2_qpart_bytes(int smax) { return ((size_t)(smax + L2_QPAD) * 4 + 15) & ~(size_t)15; }
@@ -187,7 +187,7 @@ __device__ inline void wave_sync() {
 // SKIP: exact skip-ahead on/off.  DT: counter width of D (uint8_t compact / uint16_t wide).  WAVES: candidates per
 // workgroup; with WAVES > 1 the waves of a workgroup map candidates of ONE read and share its sketch Q in LDS.
 template <bool SKIP, typename DT, int WAVES, int NWQ>
-__global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restrict__ cand_read,
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(NWQ == 2 ? 6 : 2))) l2_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restrict__ cand_read,
                                                 const uint32_t* __restrict__ sk_hash, const uint8_t* __restrict__ sk_strand,
                                                 const uint64_t* __restrict__ mz_off, const int32_t* __restrict__ sk_n,
                                                 const int32_t* __restrict__ read_len, const int32_t* __restrict__ accept_min,
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
   // ds_bpermute) and shared_j = sb_j + popcount(pm_j below R_j).  Events inside the zone are rare and applied one by one.
   // Only times up to min(A_63, B_63) are certain (later entries of the other list could interleave), the rest of the
   // chunk is redone by the next round.
-  int* tst = (int*)(wbase + l2_wave_bytes<DT>(smax, false, NWQ) + (NWQ > 2 ? 0 : l2_skip_bytes(NWQ)));
+  int* tst = (int*)(wbase + l2_wave_bytes<DT>(smax, false, NWQ) + (NWQ >= 1 ? 0 : l2_skip_bytes(NWQ)));
   uint8_t* fdel = (uint8_t*)(tst + 64);
   uint8_t* fadd = fdel + 64;
   auto rank_search = [&](int arr, int v) -> int {                // number of leading lanes whose (ascending) arr < v
@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(64 * WAVES) l2_kernel(IndexView I, const int32
     bool finished = false;
     // class masks and their prefix counts: LDS for the 10 kb class; for the long-read classes (NWQ > 2) they are written once
     // and read a few times per block, so they live in global memory and the LDS they would take buys resident waves instead
-    uint64_t* mAll = NWQ > 2 ? (uint64_t*)(mask_buf + (size_t)(WAVES > 1 ? blockIdx.x * WAVES + wave : blockIdx.x) * l2_skip_bytes(NWQ))
+    uint64_t* mAll = NWQ >= 1 ? (uint64_t*)(mask_buf + (size_t)(WAVES > 1 ? blockIdx.x * WAVES + wave : blockIdx.x) * l2_skip_bytes(NWQ))
                              : (uint64_t*)(wbase + l2_wave_bytes<DT>(smax, false, NWQ));
     uint64_t* mLo = mAll + (NWORDS_MAX + 1);
     uint64_t* mA = mLo + (NWORDS_MAX + 1);

@@ -823,7 +823,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       // Candidates whose 8-bit counters saturate are redone by the C kernel.
       // per-entry code words of pass A: one slot range per wave of a launch (the launches of a batch run one after the other
       // on the stream, so they share the buffer); classes whose ranks do not fit 16 bits (C) search the sketch instead
-      auto masks_for = [&](size_t n_waves) -> uint8_t* { return (uint8_t*)ctx->l2_masks_at_least(std::max<size_t>(n_waves, 1) * l2_skip_bytes(8)); };
+      auto masks_for = [&](size_t n_waves, int nwq = 8) -> uint8_t* { return (uint8_t*)ctx->l2_masks_at_least(std::max<size_t>(n_waves, 1) * l2_skip_bytes(nwq)); };
       auto codes_for = [&](size_t n_waves, int nwq) -> uint32_t* {
         if (getenv("MM_L2_NO_CODES")) return nullptr;              // cross-check switch
         return (uint32_t*)ctx->l2_codes_at_least(n_waves * (size_t)(64 * 64 * nwq) * sizeof(uint32_t));
@@ -852,7 +852,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 4, 2);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 2>, lds);
         l2_kernel<true, uint8_t, 4, 2><<<dim3((unsigned)gA0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gA0.size() * 4, 2), nullptr);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gA0.size() * 4, 2), masks_for(gA0.size() * 4, 2));
         MM_KERNEL_CHECK();
       }
       if (!gB0.empty()) {

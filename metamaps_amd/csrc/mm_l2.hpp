@@ -16,13 +16,24 @@
 //         where a(W) = window-only entries below Q[r0] that are first occurrences in their contig (DP clear),
 //         a lower bound of the DISTINCT window-only hashes below Q[r0]  (mm_l2_core.hpp: R = min r with
 //         r + #distinct window-only hashes below Q[r] >= s).
-// All three are prefix-sum differences over per-entry class bits (ballot masks + block prefixes in LDS);
+// All three are prefix-sum differences over per-entry class bits (ballot masks + word prefixes);
 // m is taken over the largest window of the block, a over the smallest, so the bound holds for every window
-// of the block.  r0 = pivot rank of the best window of the most promising block + 1/32 s.  Blocks that pass
-// are evaluated exactly by the serial slide, re-entering at (b, e_min(b)) with the state rebuilt in
-// parallel (LDS atomics; D and mt are order independent).  Everything skipped is provably below the final
-// maximum, so the result is bit-identical to the full slide (SKIP=false), which is kept as the fallback for
-// candidates with more than L2_MCAP streamed entries and as the cross-check in tests.
+// of the block.  r0 = expected pivot rank of the most promising block + 2.5 sigma (no probe; validity is checked per
+// block).  Blocks that pass are evaluated exactly, re-entering at (b, e_min(b)) with the state rebuilt in parallel
+// (LDS atomics; D and mt are order independent); the sweep starts near the largest bound and its trackers compare
+// positions, so the visiting order is free.  Everything skipped is provably below the final maximum, so the result is
+// bit-identical to the full slide (SKIP=false: the literal serial automaton, kept for reads shorter than w+k and as the
+// cross-check in tests).
+//
+// Exact evaluation, 64 windows per round.  The window sequence is the merge of two sorted time lists (leave / enter);
+// step indices come from cross-ranking two 64-entry chunks, window j is the state after j steps, and its shared count
+// follows from prefix sums over per-entry indicators plus a per-lane binary search of the pivot inside a 64-rank
+// "pivot zone" held in registers (block_slide below).  Pass A parks the rank code of every streamed entry in global
+// memory (4 B per entry) for the rebuilds, the rounds and the vote.
+//
+// Launch shapes (mm_map.hip): reads are grouped by sketch size; the 10 kb class runs 4 candidates of a read per
+// workgroup sharing the sketch in LDS, 8-bit gap counters, 80 VGPRs (24 waves per CU); longer reads get masks for
+// 32 768 streamed entries and blocks of 2^j words.
 #pragma once
 #include "mm_index.hpp"
 #include "mm_map.hpp"

@@ -158,7 +158,7 @@ typedef struct {
   int64_t n_ambiguous_sketch_reads;   /* reads whose duplicate-hash strands needed the std::sort tie-break */
   int64_t sum_hits_kept;              /* seed hits left after the exact run pre-filter (K3c) */
   int64_t n_l2_rebuilds;              /* window states rebuilt from scratch by the exact skip-ahead of K5 */
-  int64_t n_l2_wide_redo;             /* candidates redone with 16-bit gap counters after an 8-bit counter saturated */
+  int64_t n_l2_wide_redo;             /* candidates done again: by the literal full slide (reads shorter than w+k) or after a strand tie-break */
   /* device time of each stage of this batch, milliseconds, from hipEvents recorded on the ctx stream
    * around the launches; ms_l2 (the K5/K6 kernel) and ms_hit_filter (the counting+filtering K3c kernel, part of
    * ms_probe_gather) are single kernels: bench.py's roofline uses whichever is larger */

@@ -177,11 +177,15 @@ __device__ inline int l2_classify1(const uint32_t* __restrict__ Q, const uint16_
 // LDS layout: Q[smax] (shared by the waves of a workgroup) | per wave: D[smax] | mt | skip-ahead class arrays | slide scratch
 constexpr int L2_SCRATCH_BYTES = 64 * 4 + 64 + 64;             // step times, step-has-deletion, step-has-addition
 __host__ __device__ inline size_t l2_skip_bytes(int nwq) { return (((size_t)(64 * nwq + 1) * (3 * 8 + 3 * 2)) + 15) & ~(size_t)15; }
+constexpr int L2_HBUCKETS = 1024;                              // coarse gap histogram of a rebuild (16-bit counters)
 template <typename DT>
 __host__ __device__ inline size_t l2_wave_bytes(int smax, bool skip, int nwq) {
-  size_t b = (((size_t)smax * sizeof(DT) + 3) & ~(size_t)3) + (size_t)((smax + 31) / 32) * 4;
-  b = (b + 15) & ~(size_t)15;
-  if (skip) b += (nwq >= 1 ? 0 : l2_skip_bytes(nwq)) + L2_SCRATCH_BYTES;   // the long-read classes keep their masks in global memory
+  if (skip && nwq > 2) return ((size_t)L2_HBUCKETS * 2 + L2_SCRATCH_BYTES + 15) & ~(size_t)15;   // long-read classes: histogram | slide scratch
+  if (skip) {                                                    // 10 kb class: D[smax] | mt | slide scratch
+    size_t b = (((size_t)smax * sizeof(DT) + 3) & ~(size_t)3) + (size_t)((smax + 31) / 32) * 4;
+    return (((b + 15) & ~(size_t)15) + L2_SCRATCH_BYTES + 15) & ~(size_t)15;
+  }
+  size_t b = (((size_t)smax * sizeof(DT) + 3) & ~(size_t)3) + (size_t)((smax + 31) / 32) * 4;   // full slide: D[smax] | mt
   return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t l2_qpart_bytes(int smax) { return ((size_t)(smax + L2_QPAD) * 4 + 15) & ~(size_t)15; }
@@ -215,7 +219,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   uint32_t* Q = lds;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint8_t* wbase = (uint8_t*)lds + l2_q_bytes(smax) + (size_t)wave * l2_wave_bytes<DT>(smax, SKIP, NWQ);
-  DT* D = (DT*)wbase;
+  DT* D = (DT*)wbase;                                            // (full slide only; the skip kernels keep a histogram here)
   uint32_t* mt = (uint32_t*)(wbase + (((size_t)smax * sizeof(DT) + 3) & ~(size_t)3));
   const int64_t c0 = WAVES > 1 ? (int64_t)grp_cand0[blockIdx.x] : (cand_list ? (int64_t)cand_list[blockIdx.x] : (int64_t)blockIdx.x);
   const int r = cand_read[c0];                                   // every wave of the workgroup serves this read
@@ -250,8 +254,6 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   const int64_t c = c0 + (WAVES > 1 ? wave : 0);
   if (dbg_stop) { if (lane == 0) { L2Result z{}; out[c] = z; } if (dbg_stop == 1) return; }
   constexpr int DPER = 4 / (int)sizeof(DT);                      // counters per 32-bit word
-  constexpr int DBITS = 8 * (int)sizeof(DT);
-  int overflow = 0;
   // Pass A classifies every streamed entry once; its result (rank / gap code in the low 16 bits, strand and duplicate
   // flags above) is parked in global memory, 4 bytes per entry, and read back by the rebuilds, the slide rounds and the
   // vote instead of searching the sketch again.
@@ -261,6 +263,10 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 
   const int contig = cand[3 * c], rs = cand[3 * c + 1], re = cand[3 * c + 2];
   const int cnt = len - (w - 1) - (k - 1);                       // computeMap.hpp:470
+  if (SKIP && cnt < 2) {                                         // reads shorter than w+k: left to the literal full slide (host launches it on this list)
+    if (lane == 0) { L2Result z{}; out[c] = z; ovf_list[atomicAdd(ovf_n, 1u)] = (int32_t)c; }
+    return;
+  }
   // all window arithmetic below is 32-bit and relative to the first streamed entry of this candidate
   const int64_t cbeg = (int64_t)I.cstart[contig], cend = (int64_t)I.cstart[contig + 1];
   const int64_t first0 = wave_lower_bound_wpos(I.pos, cbeg, cend, rs, lane);          // searchIndex, :466
@@ -321,7 +327,10 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   // zone edge the state is rebuilt from the window's entries, re-centred on the new pivot.
   int z0 = 0, cbase = 0, sb = 0, fz = 0;
   uint64_t pm = 0;
-  auto rebuild_state = [&](int nb, int ne) __attribute__((always_inline)) {
+  // 10 kb class (NWQ == 2): one gap counter per rank in LDS (D, packed 8-bit) and the matched bitmap, filled with LDS atomics
+  int overflow = 0;
+  constexpr int DBITS = 8 * (int)sizeof(DT);
+  auto rebuild_dense = [&](int nb, int ne) __attribute__((always_inline)) {
     ++rebuilds;
     uint32_t* Dw = (uint32_t*)D;
     for (int i = lane; i < (s + DPER - 1) / DPER; i += 64) Dw[i] = 0;
@@ -415,6 +424,115 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     sb = wave_sum(sbl);
     pm = __ballot(rz < s && ((mt[rz >> 5] >> (rz & 31)) & 1u));
   };
+  // State of window [nb, ne) from scratch, in two passes over its entries (their rank codes come from pass A's parked
+  // words, or from a search where pass A did not run):
+  //   1. a coarse histogram of the distinct window-only hashes by gap (L2_HBUCKETS 16-bit LDS counters, fire and
+  //      forget); its prefix sums locate the bucket of the pivot R = min r with r + C(r) >= s;
+  //   2. with the zone centred on that bucket: window-only hashes between the bucket-aligned zone start and z0 (-> cbase),
+  //      matched ranks below z0 (-> sb), and the zone's own entries (-> fz, pm).
+  // Duplicates inside the window (entries flagged DP) are resolved one by one as everywhere else.
+  int bsh = 0;
+  while ((s >> bsh) >= L2_HBUCKETS) ++bsh;
+  auto rebuild_hist = [&](int nb, int ne) __attribute__((always_inline)) {
+    ++rebuilds;
+    uint32_t* Hw = (uint32_t*)wbase;                             // two 16-bit counters per word
+    for (int i = lane; i < L2_HBUCKETS / 2; i += 64) Hw[i] = 0;
+    wave_sync();
+    auto fetch8 = [&](int base, int (&cd)[8], uint32_t (&fl)[8]) {
+      if (have_codes) {
+        const uint32_t* __restrict__ pc = cw + (base - first) + lane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const uint32_t ew = pc[min(64 * i, 64 * 64 * NWQ - 1 - (base - first) - lane)]; cd[i] = code_of_word(ew); fl[i] = ew >> 16; }
+      } else {
+        Rec x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int j = base + lane + 64 * i; x[i] = pos[min(j, nmax)]; }
+        uint32_t hh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { hh[i] = x[i].hash; fl[i] = x[i].pw & 7u; }
+        l2_classify8(Q, T, tsteps, s, hh, cd);
+      }
+    };
+    // an entry flagged DP counts only if no earlier occurrence of its hash lies inside the window
+    auto first_in_window = [&](int j) -> bool { return !wave_has_hash(pos, nb, j, pos[j].hash, lane); };
+    for (int base = nb; base < ne; base += 512) {                // pass 1
+      int cd[8]; uint32_t fl[8];
+      fetch8(base, cd, fl);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = base + lane + 64 * i;
+        if (base + 64 * i >= ne) continue;
+        const int g = -cd[i] - 1;
+        const bool wonly = j < ne && cd[i] < 0 && g < s;
+        const bool flagged = wonly && (fl[i] & PW_DP);
+        bool count_it = wonly && !flagged;
+        uint64_t fm = __ballot(flagged);
+        while (fm) {
+          const int l = __builtin_ctzll(fm); fm &= fm - 1;
+          const bool ok = first_in_window(base + l + 64 * i);
+          if (ok && lane == l) count_it = true;
+        }
+        if (count_it) { const int bq = g >> bsh; atomicAdd(&Hw[bq >> 1], 1u << (16 * (bq & 1))); }
+      }
+    }
+    wave_sync();
+    // prefix sums over the buckets (16 per lane); the first bucket whose last rank satisfies r + C(r) >= s holds the pivot
+    constexpr int BPL = L2_HBUCKETS / 64;
+    int hv[BPL], hsum = 0;
+#pragma unroll
+    for (int t = 0; t < BPL / 2; ++t) { const uint32_t v = Hw[lane * (BPL / 2) + t]; hv[2 * t] = (int)(v & 0xffffu); hv[2 * t + 1] = (int)(v >> 16); hsum += hv[2 * t] + hv[2 * t + 1]; }
+    int run = wave_excl_scan(hsum, lane);
+    int myJ = 1 << 30;
+    wave_sync();                                                 // all lanes have read their counters: the words now take the exclusive prefixes
+#pragma unroll
+    for (int t = 0; t < BPL; ++t) {
+      const int bq = lane * BPL + t;
+      const int rend = min(((bq + 1) << bsh) - 1, s - 1);        // last rank of the bucket
+      if (t & 1) Hw[lane * (BPL / 2) + (t >> 1)] = (uint32_t)(uint16_t)(run - hv[t - 1]) | ((uint32_t)(uint16_t)run << 16);
+      run += hv[t];
+      if (myJ == (1 << 30) && (bq << bsh) < s && rend + run >= s) myJ = bq;
+    }
+    const int jst = wave_min(myJ);
+    wave_sync();
+    const int r_est = jst == (1 << 30) ? s : min(s, (jst << bsh) + ((1 << bsh) >> 1));
+    z0 = max(0, min(r_est - 32, s - 63));
+    const int zb = (z0 >> bsh) << bsh;                           // bucket-aligned rank at or below z0
+    const uint32_t pw_ = Hw[(z0 >> bsh) >> 1];
+    cbase = (int)(((z0 >> bsh) & 1) ? (pw_ >> 16) : (pw_ & 0xffffu));   // distinct window-only hashes in the buckets below
+    const int rz = z0 + lane;
+    fz = rz < s ? rz : (1 << 29);
+    sb = 0; pm = 0;
+    for (int base = nb; base < ne; base += 512) {                // pass 2
+      int cd[8]; uint32_t fl[8];
+      fetch8(base, cd, fl);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = base + lane + 64 * i;
+        if (base + 64 * i >= ne) continue;
+        const int code = cd[i], g = -code - 1;
+        const bool in = j < ne;
+        const bool wonly = in && code < 0 && g < s;
+        bool part_w = wonly && g >= zb && g < z0, zone_w = wonly && g >= z0 && g < z0 + 64;
+        bool low_m = in && code >= 0 && code < z0, zone_m = in && code >= z0 && code < z0 + 64;
+        uint64_t fm = __ballot((part_w || zone_w || low_m) && (fl[i] & PW_DP));
+        while (fm) {
+          const int l = __builtin_ctzll(fm); fm &= fm - 1;
+          const bool ok = first_in_window(base + l + 64 * i);
+          if (!ok && lane == l) { part_w = false; zone_w = false; low_m = false; }
+        }
+        cbase += __popcll(__ballot(part_w));
+        sb += __popcll(__ballot(low_m));
+        uint64_t zm = __ballot(zone_m);
+        while (zm) { const int l = __builtin_ctzll(zm); zm &= zm - 1; pm |= 1ull << (__builtin_amdgcn_readlane(code, l) - z0); }
+        uint64_t zw = __ballot(zone_w);
+        while (zw) { const int l = __builtin_ctzll(zw); zw &= zw - 1; const int gg = __builtin_amdgcn_readlane(g, l) - z0; fz += (lane >= gg) ? 1 : 0; }
+      }
+    }
+  };
+
+  auto rebuild_state = [&](int nb, int ne) __attribute__((always_inline)) {
+    if constexpr (NWQ == 2) rebuild_dense(nb, ne); else rebuild_hist(nb, ne);
+  };
 
   // ---- the reference's loop body (computeMap.hpp:496-533): evaluate [b,e), then MIIteratorL2::next ------
   int best = 0, bestR = 0, beg_pos = 0, last_pos = 0;
@@ -431,7 +549,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   // ds_bpermute) and shared_j = sb_j + popcount(pm_j below R_j).  Events inside the zone are rare and applied one by one.
   // Only times up to min(A_63, B_63) are certain (later entries of the other list could interleave), the rest of the
   // chunk is redone by the next round.
-  int* tst = (int*)(wbase + l2_wave_bytes<DT>(smax, false, NWQ) + (NWQ >= 1 ? 0 : l2_skip_bytes(NWQ)));
+  int* tst = (int*)(wbase + (NWQ > 2 ? (size_t)L2_HBUCKETS * 2 : (((((size_t)smax * sizeof(DT) + 3) & ~(size_t)3) + (size_t)((smax + 31) / 32) * 4 + 15) & ~(size_t)15)));
   uint8_t* fdel = (uint8_t*)(tst + 64);
   uint8_t* fadd = fdel + 64;
   auto rank_search = [&](int arr, int v) -> int {                // number of leading lanes whose (ascending) arr < v
@@ -620,8 +738,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     bool finished = false;
     // class masks and their prefix counts: LDS for the 10 kb class; for the long-read classes (NWQ > 2) they are written once
     // and read a few times per block, so they live in global memory and the LDS they would take buys resident waves instead
-    uint64_t* mAll = NWQ >= 1 ? (uint64_t*)(mask_buf + (size_t)(WAVES > 1 ? blockIdx.x * WAVES + wave : blockIdx.x) * l2_skip_bytes(NWQ))
-                             : (uint64_t*)(wbase + l2_wave_bytes<DT>(smax, false, NWQ));
+    uint64_t* mAll = (uint64_t*)(mask_buf + (size_t)(WAVES > 1 ? blockIdx.x * WAVES + wave : blockIdx.x) * l2_skip_bytes(NWQ));
     uint64_t* mLo = mAll + (NWORDS_MAX + 1);
     uint64_t* mA = mLo + (NWORDS_MAX + 1);
     uint16_t* pAll = (uint16_t*)(mA + (NWORDS_MAX + 1));
@@ -942,8 +1059,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     if (amb_votes > 0 && ((votes - amb_votes <= 0 && votes + amb_votes > 0) || (dbg_flags & 0x200)) && lane == 0) amb_used[r] = 1;   // (0x200: tests force the resolution path)
     strand = votes > 0 ? 1 : -1;
   }
-  if (__ballot(overflow || S.overflow)) {                        // a packed counter saturated: redo this candidate with wide counters
-    if (lane == 0 && ovf_list) ovf_list[atomicAdd(ovf_n, 1u)] = (int32_t)c;
+  if (NWQ == 2 && __ballot(overflow) != 0ull) {                   // a packed 8-bit counter saturated: hand the candidate to the full slide
+    if (lane == 0) ovf_list[atomicAdd(ovf_n, 1u)] = (int32_t)c;
     accepted = 0; best = 0;
   }
   if (lane == 0) {

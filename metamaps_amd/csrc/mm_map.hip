@@ -820,7 +820,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       //   B  s <= 7168   (~32 kb)                      the same with masks for 32 768 entries, kept in global memory
       //   D  s <= 16384  (~74 kb)                      two candidates per workgroup, otherwise as B
       //   C  larger                                    one wave per workgroup, 16-bit counters, 32 768 entries
-      // Candidates whose 8-bit counters saturate are redone by the C kernel.
+      // Reads shorter than w+k are handed back by these kernels and go through the literal full slide.
       // per-entry code words of pass A: one slot range per wave of a launch (the launches of a batch run one after the other
       // on the stream, so they share the buffer); classes whose ranks do not fit 16 bits (C) search the sketch instead
       auto masks_for = [&](size_t n_waves, int nwq = 8) -> uint8_t* { return (uint8_t*)ctx->l2_masks_at_least(std::max<size_t>(n_waves, 1) * l2_skip_bytes(nwq)); };
@@ -877,21 +877,26 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint16_t>(smC, true, 1, 8);
         set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
         l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)listC.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smC, M->l2.p, counters.p, nullptr, nullptr, d_listC.p, nullptr, nullptr, amb_used_p, nullptr, masks_for(listC.size()));
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smC, M->l2.p, counters.p, nullptr, nullptr, d_listC.p, ovf.p, ovf_n.p, amb_used_p, nullptr, masks_for(listC.size()));
         MM_KERNEL_CHECK();
       }
-      unsigned int h_ovf = 0;
-      MM_HIP(hipMemcpyAsync(&h_ovf, ovf_n.p, sizeof h_ovf, hipMemcpyDeviceToHost, st));
-      MM_HIP(hipStreamSynchronize(st));                          // also keeps the host lists alive until the uploads are done
-      if (h_ovf) {                                               // saturated 8-bit counters: redo those candidates with 16-bit ones
-        const int smO = std::max(std::max(smA, smB), smD);
-        const size_t lds = l2_lds_bytes<uint16_t>(smO, true, 1, 8);
-        set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
-        l2_kernel<true, uint16_t, 1, 8><<<dim3(h_ovf), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smO, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr, amb_used_p, nullptr, masks_for(h_ovf));
+      // candidates the skip kernels hand back (reads shorter than w+k): the literal full slide
+      int64_t n_fallback = 0;
+      auto run_fallback = [&](uint8_t* amb_ptr) {
+        unsigned int h_ovf = 0;
+        MM_HIP(hipMemcpyAsync(&h_ovf, ovf_n.p, sizeof h_ovf, hipMemcpyDeviceToHost, st));
+        MM_HIP(hipStreamSynchronize(st));                        // also keeps the host lists alive until the uploads are done
+        if (!h_ovf) return;
+        const size_t lds = l2_lds_bytes<uint16_t>(smax, false, 1, 8);
+        set_lds((const void*)l2_kernel<false, uint16_t, 1, 8>, lds);
+        l2_kernel<false, uint16_t, 1, 8><<<dim3(h_ovf), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr, amb_ptr, nullptr, nullptr);
         MM_KERNEL_CHECK();
-      }
-      M->stats.n_l2_wide_redo = (int64_t)h_ovf;
+        ovf_n.zero(st);
+        n_fallback += h_ovf;
+      };
+      run_fallback(amb_used_p);
+      int64_t n_redo = 0;
       if (!lazy_reads.empty()) {                                 // votes that read an unresolved strand: resolve those reads, redo their candidates
         std::vector<uint8_t> used = amb_used.to_host(st, (size_t)n);
         std::vector<int64_t> fix;
@@ -907,12 +912,14 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           const size_t lds = l2_lds_bytes<uint16_t>(smR, true, 1, 8);
           set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
           l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)redo.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smR, M->l2.p, counters.p, nullptr, nullptr, d_redo.p, nullptr, nullptr, nullptr, nullptr, masks_for(redo.size()));
+              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smR, M->l2.p, counters.p, nullptr, nullptr, d_redo.p, ovf.p, ovf_n.p, nullptr, nullptr, masks_for(redo.size()));
           MM_KERNEL_CHECK();
+          run_fallback(nullptr);
           MM_HIP(hipStreamSynchronize(st));
-          M->stats.n_l2_wide_redo += (int64_t)redo.size();
+          n_redo += (int64_t)redo.size();
         }
       }
+      M->stats.n_l2_wide_redo = n_redo + n_fallback;
     }
     l2_stats_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(ncand, 256), 1024)), dim3(256), 0, st>>>(M->l2.p, ncand, counters.p);
     MM_KERNEL_CHECK();

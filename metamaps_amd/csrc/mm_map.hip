@@ -818,7 +818,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       //   A  s <= 3072   (reads up to ~14 kb at w=8)  compact: 4 candidates of a read per workgroup share the sketch,
       //                                                8-bit gap counters, masks for 8 192 streamed entries
       //   B  s <= 7168   (~32 kb)                      the same with masks for 32 768 entries, kept in global memory
-      //   D  s <= 16384  (~74 kb)                      two candidates per workgroup, otherwise as B
+      //   D  s <= 16384  (~74 kb)                      as B, launched separately so that B keeps its smaller sketch area
       //   C  larger                                    one wave per workgroup, 16-bit counters, 32 768 entries
       // Reads shorter than w+k are handed back by these kernels and go through the literal full slide.
       // per-entry code words of pass A: one slot range per wave of a launch (the launches of a batch run one after the other
@@ -840,7 +840,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 4) { g0.push_back((int32_t)c0); gn.push_back((int32_t)std::min<uint64_t>(4, c_hi - c0)); }
         } else if (sr <= 16384) {
           smD = std::max(smD, sr);
-          for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 2) { gD0.push_back((int32_t)c0); gDn.push_back((int32_t)std::min<uint64_t>(2, c_hi - c0)); }
+          for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 4) { gD0.push_back((int32_t)c0); gDn.push_back((int32_t)std::min<uint64_t>(4, c_hi - c0)); }
         } else {
           smC = std::max(smC, sr);
           for (uint64_t c0 = c_lo; c0 < c_hi; ++c0) listC.push_back((int32_t)c0);
@@ -866,10 +866,10 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       DBuf<int32_t> d_gD0(gD0.size()), d_gDn(gDn.size());
       if (!gD0.empty()) {
         d_gD0.upload(gD0.data(), gD0.size(), st); d_gDn.upload(gDn.data(), gDn.size(), st);
-        const size_t lds = l2_lds_bytes<uint8_t>(smD, true, 2, 8);
-        set_lds((const void*)l2_kernel<true, uint8_t, 2, 8>, lds);
-        l2_kernel<true, uint8_t, 2, 8><<<dim3((unsigned)gD0.size()), dim3(128), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gD0.size() * 2, 8), masks_for(gD0.size() * 2));
+        const size_t lds = l2_lds_bytes<uint8_t>(smD, true, 4, 8);
+        set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
+        l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gD0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gD0.size() * 4, 8), masks_for(gD0.size() * 4));
         MM_KERNEL_CHECK();
       }
       if (!listC.empty()) {

@@ -130,3 +130,22 @@ def test_cli_index_then_map_against_index(tmp_path, extra):
     open(str(tmp_path / "idx.index"), "w").write("0\n")
     q = subprocess.run([CLI, "mapAgainstIndex", "--all", "-i", str(tmp_path / "idx"), "-q", rd["path"], "-o", via], capture_output=True, timeout=900)
     assert q.returncode != 0 and b"not complete" in q.stderr
+
+
+def test_cli_midscale_matches_oracle(oracle_lib, tmp_path):
+    """a larger case than the plumbing ones: 24 genomes x 1 Mbp (related pairs), 1500 reads of 10 kb with ONT-like errors,
+    mapDirectly + classify against the oracle CLI"""
+    import orc
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=24, genome_len=1_000_000, seed=11, contigs_per_genome=3)
+    rd = synth.make_reads(db, str(tmp_path / "reads.fq"), n_reads=1500, read_len=10_000, seed=5)
+    pa, pb = str(tmp_path / "gpu"), str(tmp_path / "cpu")
+    for exe, pre, extra in ((CLI, pa, []), (orc.CLI, pb, ["-t", "16"])):
+        subprocess.run([exe, "mapDirectly", "--all", "-r", db.fasta, "-q", rd["path"], "-o", pre] + extra, check=True, capture_output=True, timeout=1500)
+        subprocess.run([exe, "classify", "--DB", db.dir, "--mappings", pre], check=True, capture_output=True, timeout=1500)
+    _cmp_table(pa, pb, " ", {13})
+    assert open(pa + ".meta").read() == open(pb + ".meta").read()
+    _cmp_table(pa + ".EM", pb + ".EM", " ", {13})
+    assert open(pa + ".EM.reads2Taxon").read() == open(pb + ".EM.reads2Taxon").read()
+    _cmp_table(pa + ".EM.WIMP", pb + ".EM.WIMP", "\t", {4, 5})
+    assert sum(1 for _ in open(pa)) > 2000

@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                                                 const int32_t* __restrict__ cand_list /* WAVES==1: optional indirection (fallback runs) */,
                                                 int32_t* __restrict__ ovf_list, unsigned int* __restrict__ ovf_n,
                                                 uint8_t* __restrict__ amb_used /* optional: set per read when a vote read an unresolved strand */,
-                                                uint32_t* __restrict__ code_buf /* optional: 64*64*NWQ words per wave of the launch */,
+                                                void* __restrict__ code_buf /* optional: 64*64*NWQ code words per wave of the launch (2 bytes each for NWQ == 2, else 4) */,
                                                 uint8_t* __restrict__ mask_buf /* NWQ > 2: l2_skip_bytes(NWQ) per wave of the launch */) {
   extern __shared__ __align__(16) uint32_t lds[];
   uint32_t* Q = lds;
@@ -257,9 +257,19 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   // Pass A classifies every streamed entry once; its result (rank / gap code in the low 16 bits, strand and duplicate
   // flags above) is parked in global memory, 4 bytes per entry, and read back by the rebuilds, the slide rounds and the
   // vote instead of searching the sketch again.
-  uint32_t* const cw = code_buf ? code_buf + (size_t)(WAVES > 1 ? blockIdx.x * WAVES + wave : blockIdx.x) * (size_t)(64 * 64 * NWQ) : nullptr;
+  // 10 kb class (NWQ == 2, sketch <= 3072): 13-bit code + 3 flag bits in 16 bits; other classes: 16-bit code + flags in 32 bits
+  using CW = std::conditional_t<NWQ == 2, uint16_t, uint32_t>;
+  CW* const cw = code_buf ? (CW*)code_buf + (size_t)(WAVES > 1 ? blockIdx.x * WAVES + wave : blockIdx.x) * (size_t)(64 * 64 * NWQ) : nullptr;
   bool have_codes = false;                                       // set once pass A has run
-  auto code_of_word = [](uint32_t ew) -> int { return (int)(int16_t)(uint16_t)(ew & 0xffffu); };
+  auto cw_make = [](int code, uint32_t flags) -> CW {
+    if constexpr (NWQ == 2) return (CW)(((uint32_t)code & 0x1fffu) | (flags << 13));
+    else return (CW)((uint32_t)(uint16_t)(int16_t)code | (flags << 16));
+  };
+  auto cw_code = [](CW ew) -> int {
+    if constexpr (NWQ == 2) return ((int)((uint32_t)ew << 19)) >> 19;
+    else return (int)(int16_t)(uint16_t)((uint32_t)ew & 0xffffu);
+  };
+  auto cw_flags = [](CW ew) -> uint32_t { if constexpr (NWQ == 2) return (uint32_t)ew >> 13; else return (uint32_t)ew >> 16; };
 
   const int contig = cand[3 * c], rs = cand[3 * c + 1], re = cand[3 * c + 2];
   const int cnt = len - (w - 1) - (k - 1);                       // computeMap.hpp:470
@@ -346,9 +356,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     for (int base = nb; base < ne; base += 512) {                // eight loads in flight per wait
       int cd[8]; uint32_t fl[8];
       if (have_codes) {
-        const uint32_t* __restrict__ pc = cw + (base - first) + lane;
+        const CW* __restrict__ pc = cw + (base - first) + lane;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const uint32_t ew = pc[min(64 * i, 64 * 64 * NWQ - 1 - (base - first) - lane)]; cd[i] = code_of_word(ew); fl[i] = ew >> 16; }
+        for (int i = 0; i < 8; ++i) { const CW ew = pc[min(64 * i, 64 * 64 * NWQ - 1 - (base - first) - lane)]; cd[i] = cw_code(ew); fl[i] = cw_flags(ew); }
       } else {
         Rec x[8];
 #pragma unroll
@@ -440,9 +450,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     wave_sync();
     auto fetch8 = [&](int base, int (&cd)[8], uint32_t (&fl)[8]) {
       if (have_codes) {
-        const uint32_t* __restrict__ pc = cw + (base - first) + lane;
+        const CW* __restrict__ pc = cw + (base - first) + lane;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const uint32_t ew = pc[min(64 * i, 64 * 64 * NWQ - 1 - (base - first) - lane)]; cd[i] = code_of_word(ew); fl[i] = ew >> 16; }
+        for (int i = 0; i < 8; ++i) { const CW ew = pc[min(64 * i, 64 * 64 * NWQ - 1 - (base - first) - lane)]; cd[i] = cw_code(ew); fl[i] = cw_flags(ew); }
       } else {
         Rec x[8];
 #pragma unroll
@@ -574,7 +584,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
       const Rec xe = pos[min(e + lane, nmax)];
       const int w64 = pw_wpos(pos[min(b + 64, nmax)].pw);
       int cB, cE;
-      if (have_codes) { cB = code_of_word(cw[min(b - first + lane, 64 * 64 * NWQ - 1)]); cE = code_of_word(cw[min(e - first + lane, 64 * 64 * NWQ - 1)]); }
+      if (have_codes) { cB = cw_code(cw[min(b - first + lane, 64 * 64 * NWQ - 1)]); cE = cw_code(cw[min(e - first + lane, 64 * 64 * NWQ - 1)]); }
       else { cB = l2_classify1(Q, T, tsteps, s, xb.hash); cE = l2_classify1(Q, T, tsteps, s, xe.hash); }
       const int wpb = pw_wpos(xb.pw);
       int nextw = __shfl_down(wpb, 1, 64);
@@ -815,9 +825,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
           l2_classify8(Q, T, tsteps, s, hh, cd);
         }
         if (cw) {
-          uint32_t* __restrict__ pc = cw + (base - first) + lane;
+          CW* __restrict__ pc = cw + (base - first) + lane;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) if (base + 64 * i < last_end) pc[64 * i] = (uint32_t)(uint16_t)(int16_t)cd[i] | ((x[i].pw & 7u) << 16);
+          for (int i = 0; i < 8; ++i) if (base + 64 * i < last_end) pc[64 * i] = cw_make(cd[i], x[i].pw & 7u);
         }
         const int wd0 = (int)((base - first) >> 6);
         dispatch(wd0 >> 6, base + 512 <= last_end, [&](auto qtag, auto fulltag) {
@@ -871,6 +881,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
       for (int q = 0; q < NWQ; ++q) { rLo[q] = 0; rA[q] = 0; }
       for (int wd0 = 0; wd0 < nwords; wd0 += 8) {
+        // (reads the entries, not the parked code words: half the bytes, but this pass is also what pulls the stream into
+        // L2/MALL for the sweep, whose scattered entry reads otherwise cost 1.3 ms more than the 0.3 ms saved here)
         Rec x[8];
         load8(x, first + wd0 * 64);
         dispatch(wd0 >> 6, first + wd0 * 64 + 512 <= last_end, [&](auto qtag, auto fulltag) {
@@ -1020,9 +1032,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     for (int base = opt_b; base < opt_e; base += 512) {
       int cd[8]; uint32_t fl[8];
       if (have_codes) {
-        const uint32_t* __restrict__ pc = cw + (base - first) + lane;
+        const CW* __restrict__ pc = cw + (base - first) + lane;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const uint32_t ew = pc[min(64 * i, 64 * 64 * NWQ - 1 - (base - first) - lane)]; cd[i] = code_of_word(ew); fl[i] = ew >> 16; }
+        for (int i = 0; i < 8; ++i) { const CW ew = pc[min(64 * i, 64 * 64 * NWQ - 1 - (base - first) - lane)]; cd[i] = cw_code(ew); fl[i] = cw_flags(ew); }
       } else {
         Rec x[8];
 #pragma unroll

@@ -824,9 +824,9 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       // per-entry code words of pass A: one slot range per wave of a launch (the launches of a batch run one after the other
       // on the stream, so they share the buffer); classes whose ranks do not fit 16 bits (C) search the sketch instead
       auto masks_for = [&](size_t n_waves, int nwq = 8) -> uint8_t* { return (uint8_t*)ctx->l2_masks_at_least(std::max<size_t>(n_waves, 1) * l2_skip_bytes(nwq)); };
-      auto codes_for = [&](size_t n_waves, int nwq) -> uint32_t* {
+      auto codes_for = [&](size_t n_waves, int nwq) -> void* {
         if (getenv("MM_L2_NO_CODES")) return nullptr;              // cross-check switch
-        return (uint32_t*)ctx->l2_codes_at_least(n_waves * (size_t)(64 * 64 * nwq) * sizeof(uint32_t));
+        return ctx->l2_codes_at_least(n_waves * (size_t)(64 * 64 * nwq) * (nwq == 2 ? sizeof(uint16_t) : sizeof(uint32_t)));
       };
       std::vector<int32_t> gA0, gAn, gB0, gBn, gD0, gDn, listC;
       int smA = 0, smB = 0, smC = 0, smD = 0;

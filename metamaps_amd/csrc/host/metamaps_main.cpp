@@ -16,8 +16,8 @@
 // `index` stores the packed reference per chunk (own versioned format, include/metamaps_hip.h: mm_seqset_save) instead of
 // the reference's Boost archives of the sketch; the device index is rebuilt from it in seconds.
 //
-// Not provided: classifyU (disabled upstream), the unknown-species side file of classify
-// (.EM.evidenceUnknownSpecies needs the DB's contigNstats file and Boost's chi-square / Poisson / binomial cdfs).
+// Not provided: classifyU (disabled upstream).
+
 #include "../../../include/metamaps_hip.h"
 #include <zlib.h>
 #include <algorithm>
@@ -471,7 +471,7 @@ size_t iv_overlap(size_t aL, size_t aR, size_t bL, size_t bR) {
 // not a multiple of the window size (:744 subtracts after incrementing the window count, so the unsigned value wraps).
 struct ContigCoverage {
   const size_t W = 1000;
-  std::map<std::string, std::map<std::string, std::vector<size_t>>> cov;
+  std::map<std::string, std::map<std::string, std::vector<size_t>>> cov, reads;   // bases / best mappings per window
   std::map<std::string, std::map<std::string, size_t>> last;
   void add(const std::string& tx, const std::string& cg, size_t L, size_t start, size_t stop_in) {
     auto& per = cov[tx];
@@ -481,14 +481,17 @@ struct ContigCoverage {
       else if (n * W != L) { ++n; last[tx][cg] = L - n * W; }
       else last[tx][cg] = W;
       per[cg].assign(n, 0);
+      reads[tx][cg].assign(n, 0);
     }
     const size_t stop = stop_in >= L ? L - 1 : stop_in;
     std::vector<size_t>& v = per[cg];
+    std::vector<size_t>& nr = reads[tx][cg];
     for (size_t p = start; p <= stop; p += W) {
       const size_t wi = p / W, ws = wi * W;
       size_t we = (wi + 1) * W - 1;
       if (we > L) we = L - 1;
       v.at(wi) += iv_overlap(ws, we, start, stop);
+      nr.at(wi)++;
     }
   }
   void write(const std::string& fn, const Taxonomy& T) const {
@@ -502,7 +505,125 @@ struct ContigCoverage {
   }
 };
 
-int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db) {   // meta::doEM, fEM.h:466-803
+// Regularised incomplete beta I_x(a, b) by the continued fraction (modified Lentz), used for the binomial tail below.
+double reg_inc_beta(double a, double b, double x) {
+  if (x <= 0) return 0;
+  if (x >= 1) return 1;
+  if (x > (a + 1) / (a + b + 2)) return 1 - reg_inc_beta(b, a, 1 - x);
+  const double lead = std::exp(std::lgamma(a + b) - std::lgamma(a) - std::lgamma(b) + a * std::log(x) + b * std::log1p(-x)) / a;
+  const double tiny = 1e-300;
+  double f = 1, c = 1, d = 0;
+  for (int i = 0; i <= 100000; ++i) {
+    const int m = i / 2;
+    double num;
+    if (i == 0) num = 1;
+    else if (i % 2 == 0) num = (m * (b - m) * x) / ((a + 2.0 * m - 1) * (a + 2.0 * m));
+    else num = -((a + m) * (a + b + m) * x) / ((a + 2.0 * m) * (a + 2.0 * m + 1));
+    d = 1 + num * d; if (std::fabs(d) < tiny) d = tiny; d = 1 / d;
+    c = 1 + num / c; if (std::fabs(c) < tiny) c = tiny;
+    const double cd = c * d;
+    f *= cd;
+    if (std::fabs(1 - cd) < 1e-16) break;
+  }
+  return lead * (f - 1);
+}
+// P(X <= k), X ~ Binomial(n, p)  (boost::math::cdf(binomial_distribution, k), fEM.h:1107)
+double binomial_cdf(double n, double p, double k) {
+  if (k >= n || p <= 0) return 1;
+  if (p >= 1) return 0;
+  return reg_inc_beta(n - k, k + 1, 1 - p);
+}
+
+// .EM.evidenceUnknownSpecies (fEM.h:846-1132): per taxon with best mappings, (1) a one-degree-of-freedom chi-square test of
+// the share of its reads whose identity lies in the bottom third of the best-identity taxon's distribution, (2) the
+// number of zero-coverage windows among the "usable" ones (at least a maximum read length of N-poor windows on both
+// sides; N counts per 1000-bp window come from DBDIR/contigNstats_windowSize_1000.txt, :1421-1470) against a Poisson
+// expectation.  Integer arithmetic as in the reference (size_t, including the wrapped last-window length kept by
+// ContigCoverage).  The reference asserts when the contigNstats file is missing (:1427) or an expected count is zero
+// (:1049-1050): here the file is skipped with a warning, respectively the row's identity columns are "NA".
+bool write_unknown_species(const std::string& fn, const std::string& db, const Taxonomy& T, const ContigCoverage& C,
+                           const std::map<std::string, std::vector<double>>& idents, long long maxReadLen, size_t minReads) {
+  std::ifstream ns(db + "/contigNstats_windowSize_" + std::to_string(C.W) + ".txt");
+  if (!ns.is_open()) return false;
+  struct PerTaxon { size_t windows = 0, usable = 0, usableReads = 0, usableZero = 0; };
+  std::map<std::string, PerTaxon> G;
+  std::set<std::string> seenContigs;
+  const size_t need = (size_t)maxReadLen;
+  std::string ln;
+  while (std::getline(ns, ln)) {
+    while (!ln.empty() && (ln.back() == '\r' || ln.back() == '\n')) ln.pop_back();
+    if (ln.empty()) continue;
+    auto fl = split(ln, "\t");
+    if (fl.size() != 3) die("Format error " + db + "/contigNstats_windowSize_1000.txt; wrong number of fields:\n" + ln);
+    auto ct = C.cov.find(fl[0]);
+    if (ct == C.cov.end() || !ct->second.count(fl[1])) continue;
+    if (!seenContigs.insert(fl[1]).second) die("contigNstats: duplicate contig " + fl[1]);
+    const std::vector<size_t>& nreads = C.reads.at(fl[0]).at(fl[1]);
+    auto nf = split(fl[2], ";");
+    if (nf.size() != nreads.size()) die("contigNstats: " + fl[1] + " has " + std::to_string(nf.size()) + " windows, expected " + std::to_string(nreads.size()));
+    const size_t nw = nf.size(), lastLen = C.last.at(fl[0]).at(fl[1]);
+    std::vector<uint8_t> poor(nw);                               // window has <= 2 % N
+    for (size_t i = 0; i < nw; ++i) poor[i] = (double)std::stoull(nf[i]) / (double)(i + 1 == nw ? lastLen : C.W) <= 0.02;
+    std::vector<size_t> before(nw), after(nw);                   // N-poor bases running up to / following each window
+    size_t run = 0;
+    for (size_t i = 0; i < nw; ++i) { before[i] = run; if (poor[i]) run += i + 1 == nw ? lastLen : C.W; else run = 0; }
+    run = 0;
+    for (size_t i = nw; i-- > 0;) { after[i] = run; if (poor[i]) run += i + 1 == nw ? lastLen : C.W; else run = 0; }
+    PerTaxon& g = G[fl[0]];
+    g.windows += nw;
+    for (size_t i = 0; i < nw; ++i) if (before[i] >= need && after[i] >= need) { ++g.usable; g.usableReads += nreads[i]; g.usableZero += nreads[i] == 0; }
+  }
+  for (auto& t : C.cov) for (auto& c : t.second) if (!seenContigs.count(c.first)) die("Missing entry " + c.first + " in " + db + "/contigNstats_windowSize_1000.txt");
+
+  // reference distribution: the taxon with the highest median identity among those with enough reads (:846-890)
+  bool haveRef = false; double refMedian = 0, cut = 0, cutP = 0;
+  for (auto& e : idents) {
+    if (e.second.size() < 3 || e.second.size() < minReads) continue;
+    std::vector<double> v = e.second; std::sort(v.begin(), v.end());
+    const double med = v[v.size() / 2];
+    if (haveRef && !(med > refMedian)) continue;
+    haveRef = true; refMedian = med;
+    cut = v.at((size_t)(v.size() * (1.0 / 3.0)));
+    cutP = (double)(std::upper_bound(v.begin(), v.end(), cut) - v.begin()) / (double)v.size();
+  }
+
+  std::ofstream o(fn);
+  o << "taxonID\tspecies\tgenus\tnReads\tpropBottomThirdReadIdentities\texpectedPropBottomThirdReadIdentities\tpValue_BottomThirdReadIdentities\t"
+       "coverageWindows_totalGenome\tcoverageWindows_usable\tcoverageWindows_usable_averageCoverage\tcoverageWindows_usable_coverageIsZero\t"
+       "coverageWindows_usable_coverageIsZero_expected\tcoverageWindows_usable_coverageIsZero_P\n";
+  for (auto& e : idents) {
+    const size_t n = e.second.size();
+    std::string c5 = "NA", c6 = "NA", c7 = "NA", c10 = "NA", c12 = "NA", c13 = "NA";
+    if (haveRef) {
+      size_t low = 0; for (double v : e.second) low += v <= cut;
+      const double expLow = cutP * n, expRest = n - expLow;
+      if (expLow > 0 && expRest > 0) {
+        const double dl = (double)low - expLow, dr = (double)(n - low) - expRest;
+        const double stat = dl * dl / expLow + dr * dr / expRest;
+        c5 = std::to_string((double)low / (double)n);
+        c6 = std::to_string(cutP);
+        c7 = std::to_string(1 - std::erf(std::sqrt(stat / 2)));   // 1 - cdf(chi_squared(1), stat)
+      } else std::cerr << "evidenceUnknownSpecies: expected count of zero for taxon " << e.first << " (the reference asserts here); identity columns NA\n";
+    }
+    const PerTaxon& g = G.at(e.first);
+    if (g.usable > 0) {
+      const double avg = (double)g.usableReads / (double)g.usable;
+      c10 = std::to_string(avg);
+      if (avg == 0) { c12 = std::to_string(g.usable); c13 = std::to_string(1); }
+      else {
+        const double p0 = std::exp(-avg);                        // Poisson(avg) mass at zero
+        c12 = std::to_string(g.usable * p0);
+        c13 = std::to_string(g.usableZero > 0 ? 1 - binomial_cdf((double)g.usable, p0, (double)(g.usableZero - 1)) : 1.0);
+      }
+    }
+    auto up = T.upward_by_ranks(e.first, {"species", "genus"});
+    o << e.first << "\t" << up.at("species") << "\t" << up.at("genus") << "\t" << n << "\t" << c5 << "\t" << c6 << "\t" << c7 << "\t" << g.windows << "\t"
+      << g.usable << "\t" << c10 << "\t" << g.usableZero << "\t" << c12 << "\t" << c13 << "\n";
+  }
+  return true;
+}
+
+int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db, size_t minReadsU) {   // meta::doEM, fEM.h:466-803
   // mappings grouped by read (fEM.h:1171-1214)
   std::vector<std::vector<std::string>> groups;
   { std::ifstream s(mapped); if (!s.is_open()) die("Cannot open mappings file " + mapped);
@@ -557,6 +678,8 @@ int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db) 
   li << "AnalysisLevel\tID\treadI\tIdentity\tLength\n";
   std::map<std::string, size_t> readsPer;
   ContigCoverage coverage;
+  std::map<std::string, std::vector<double>> identsPerTaxon;     // :691, :718
+  long long maxReadLen = -1;                                     // :692, :719-722
   for (size_t r = 0; r < groups.size(); ++r) {                   // fEM.h:684-779
     std::string rid;
     for (size_t j = 0; j < groups[r].size(); ++j) {
@@ -571,6 +694,8 @@ int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db) 
     r2t << rid << "\t" << tx << "\n";
     kr << rid << "\t" << T.first_non_x(tx) << "\t" << post[b] << "\n";
     readsPer[tx]++;
+    identsPerTaxon[tx].push_back(ident[b]);
+    maxReadLen = std::max(maxReadLen, (long long)rlen[b]);
     coverage.add(tx, contigOf[b], TI.at(tx).at(contigOf[b]), mstart[b], mstop[b]);
   }
   { std::ifstream s(mapped + ".meta.unmappedReadsLengths"); std::string ln;
@@ -583,6 +708,8 @@ int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db) 
     double s = 0; for (auto& e : fmap) s += e.second; for (auto& e : fmap) e.second /= s; }
   write_wimp(mapped + ".EM.WIMP", T, fmap, readsPer, nTotal, nUnmapped, nTooShort);
   coverage.write(mapped + ".EM.contigCoverage", T);
+  if (!write_unknown_species(mapped + ".EM.evidenceUnknownSpecies", db, T, coverage, identsPerTaxon, maxReadLen, minReadsU))
+    std::cerr << "Warning: " << db << "/contigNstats_windowSize_1000.txt not found - " << mapped << ".EM.evidenceUnknownSpecies is not written." << std::endl;
   return 0;
 }
 
@@ -602,7 +729,8 @@ int main(int argc, char** argv) {
     if (!o.v.count("mappings")) die("Provide path to mappings.");
     mm_ctx* ctx;
     if (mm_ctx_create(0, &ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
-    for (auto& m : split(o.v.at("mappings"), ",")) classify_one(ctx, m, o.v.at("DB"));
+    const size_t minReadsU = o.v.count("minreads") ? std::stoull(o.v.at("minreads")) : 10000;   // parseCmdArgs.hpp:462-471
+    for (auto& m : split(o.v.at("mappings"), ",")) classify_one(ctx, m, o.v.at("DB"), minReadsU);
     mm_ctx_destroy(ctx);
     return 0;
   }

@@ -20,6 +20,8 @@ long orc_minimizers(const char* seq, int len, int k, int w, uint32_t* hash, int3
 double orc_binom_pmf(int n, double p, int k) { return binom_pmf(n, p, k); }
 double orc_binom_sf(int n, double p, int x) { return binom_sf(n, p, x); }
 int orc_binom_quantile_upper(int n, double p, double q) { return binom_quantile_upper(n, p, q); }
+double orc_binom_cdf_sum(uint64_t n, double p, uint64_t k) { return binom_cdf_sum((size_t)n, p, (size_t)k); }   // evidenceUnknownSpecies columns
+double orc_chi2_1df_cdf(double x) { return chi2_1df_cdf(x); }
 int orc_min_hits_relaxed(int s, int k, float pi) { return estimate_min_hits_relaxed(s, k, pi); }
 int orc_recommended_window(double pval, int k, float pi, int qlen, uint64_t rlen) { return recommended_window(pval, k, 4, pi, qlen, rlen); }
 void orc_identity(int shared, int s, int k, float* ident, float* identUB) {

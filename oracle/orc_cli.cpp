@@ -63,7 +63,7 @@ int main(int argc, char** argv) {
     if (!opt.count("DB")) { std::cerr << "Provide path to DB.\n"; return 1; }
     if (!opt.count("mappings")) { std::cerr << "Provide path to mappings.\n"; return 1; }
     for (auto& m : split(opt["mappings"], ",")) {
-      EMTrace tr = do_em(m, opt["DB"]);
+      EMTrace tr = do_em(m, opt["DB"], true, opt.count("minreads") ? std::stoull(opt["minreads"]) : 10000);   // parseCmdArgs.hpp:462-471
       std::cerr << "{\"oracle\":\"classify\",\"iterations\":" << tr.ll.size() << ",\"ll\":[";
       for (size_t i = 0; i < tr.ll.size(); ++i) { char b[64]; snprintf(b, sizeof b, "%s%.17g", i ? "," : "", tr.ll[i]); std::cerr << b; }
       double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

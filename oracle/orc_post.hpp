@@ -313,7 +313,7 @@ static inline size_t overlap(size_t aL, size_t aR, size_t bL, size_t bR) {
 // window: :744 subtracts after incrementing n_windows), :805-845 (output)
 struct Coverage {
   size_t W = 1000;
-  std::map<std::string, std::map<std::string, std::vector<size_t>>> cov;
+  std::map<std::string, std::map<std::string, std::vector<size_t>>> cov, cnt;   // bases / reads per window (:685-686)
   std::map<std::string, std::map<std::string, size_t>> lastWin;
   void add(const TaxonInfo& TI, const Loc& b) {
     const size_t L = TI.at(b.taxon).at(b.contig);
@@ -323,6 +323,7 @@ struct Coverage {
       else if (n * W != L) { n++; lastWin[b.taxon][b.contig] = L - n * W; }
       else lastWin[b.taxon][b.contig] = W;
       cov[b.taxon][b.contig].resize(n, 0);
+      cnt[b.taxon][b.contig].resize(n, 0);
     }
     const size_t stop = b.stop >= L ? L - 1 : b.stop;
     for (size_t pos = b.start; pos <= stop; pos += W) {
@@ -330,6 +331,7 @@ struct Coverage {
       size_t we = (wi + 1) * W - 1;
       if (we > L) we = L - 1;
       cov.at(b.taxon).at(b.contig).at(wi) += overlap(ws, we, b.start, stop);
+      cnt.at(b.taxon).at(b.contig).at(wi)++;
     }
   }
   template <typename TaxT> void write(const std::string& file, const TaxT& T) const {
@@ -344,6 +346,133 @@ struct Coverage {
       }
   }
 };
+
+// Distribution functions the unknown-species table takes from Boost.Math (fEM.h:1014, :1064, :1101, :1107); the version
+// is unpinned, values only reach the file through std::to_string's six decimals.
+// chi-squared, one degree of freedom: P(X <= x) = P(|Z| <= sqrt(x)) = erf(sqrt(x/2))
+static inline double chi2_1df_cdf(double x) { return x <= 0 ? 0.0 : std::erf(std::sqrt(x / 2)); }
+// binomial P(X <= k), summed term by term in extended precision from the mode outwards being unnecessary here: k+1 terms
+static inline double binom_cdf_sum(size_t n, double p, size_t k) {
+  if (k >= n) return 1.0;
+  if (p <= 0) return 1.0;
+  if (p >= 1) return 0.0;
+  const long double lp = std::log((long double)p), lq = log1pl(-(long double)p);
+  long double acc = 0;
+  for (size_t i = 0; i <= k; ++i)
+    acc += expl(lgammal((long double)n + 1) - lgammal((long double)i + 1) - lgammal((long double)(n - i) + 1) + (long double)i * lp + (long double)(n - i) * lq);
+  return (double)(acc > 1 ? 1.0L : acc);
+}
+
+// PREFIX.EM.evidenceUnknownSpecies — meta/fEM.h:846-1132, Ns per window from DBDIR/contigNstats_windowSize_1000.txt (:1421-1470).
+// All size_t arithmetic is kept as written there, including running sums fed by the wrapped length of a last partial
+// window (Coverage above).  Where the reference would stop on an assert (:1049-1050, an expected count of zero), the
+// identity columns of that row are "NA" and a warning goes to stderr.  Returns false (nothing written) when the DB has no
+// contigNstats file — the reference asserts there (:1427).
+template <typename TaxT>
+static inline bool write_unknown_species(const std::string& file, const std::string& dbDir, const TaxT& T, const Coverage& C,
+                                         const std::map<std::string, std::vector<double>>& identPerTaxon, long long maxReadLen, size_t minReads) {
+  std::map<std::string, std::vector<size_t>> Ns;                 // by contig ID (:1421-1470)
+  {
+    std::ifstream s(dbDir + "/contigNstats_windowSize_" + std::to_string(C.W) + ".txt");
+    if (!s.is_open()) return false;
+    std::string ln;
+    while (std::getline(s, ln)) {
+      while (!ln.empty() && (ln.back() == '\n' || ln.back() == '\r')) ln.pop_back();
+      if (ln.empty()) continue;
+      auto fl = split(ln, "\t");
+      if (fl.size() != 3) throw std::runtime_error("Format error contigNstats; wrong number of fields: " + ln);
+      if (!C.cov.count(fl[0]) || !C.cov.at(fl[0]).count(fl[1])) continue;
+      auto nf = split(fl[2], ";");
+      if (nf.size() != C.cov.at(fl[0]).at(fl[1]).size()) throw std::runtime_error("contigNstats: window count mismatch for " + fl[1]);
+      std::vector<size_t> v; for (auto& e : nf) v.push_back(std::stoull(e));
+      Ns[fl[1]] = v;
+    }
+    for (auto& t : C.cov) for (auto& c : t.second) if (!Ns.count(c.first)) throw std::runtime_error("Missing entry " + c.first + " in contigNstats");
+  }
+  std::map<std::string, std::string> contigTaxon;
+  for (auto& t : C.cov) for (auto& c : t.second) contigTaxon[c.first] = t.first;
+
+  // taxon with the highest median identity and the bottom-third quantile of its identities (:846-890)
+  std::string bestTaxon; double bestMedian = 0, oneThird = 0, oneThirdP = 0;
+  for (auto& e : identPerTaxon) {
+    std::vector<double> id = e.second;
+    if (id.size() >= 3 && id.size() >= minReads) {
+      std::sort(id.begin(), id.end());
+      const double med = id.at(id.size() / 2);
+      if (bestTaxon.empty() || med > bestMedian) {
+        bestMedian = med; bestTaxon = e.first;
+        oneThird = id.at((size_t)(id.size() * (1.0 / 3.0)));
+        size_t n13 = 0; for (double v : id) if (v <= oneThird) ++n13;
+        oneThirdP = (double)n13 / (double)id.size();
+      }
+    }
+  }
+
+  // usable windows: at least maxReadLen bases of N-poor (<= 2 % N) windows on either side (:893-996)
+  const size_t need = (size_t)maxReadLen;
+  std::map<std::string, size_t> nWin, nUsable, nUsableReads, nUsableZero;
+  for (auto& cd : Ns) {
+    const std::string& tx = contigTaxon.at(cd.first);
+    const std::vector<size_t>& n = cd.second;
+    const size_t lastLen = C.lastWin.at(tx).at(cd.first);
+    std::vector<size_t> fwd(n.size(), 0), bwd(n.size(), 0);
+    size_t run = 0;
+    for (size_t i = 0; i < n.size(); ++i) {
+      fwd[i] = run;
+      const size_t wl = i == n.size() - 1 ? lastLen : C.W;
+      if ((double)n[i] / (double)wl <= 0.02) run += wl; else run = 0;
+    }
+    run = 0;
+    for (long long i = (long long)n.size() - 1; i >= 0; --i) {
+      bwd[(size_t)i] = run;
+      const size_t wl = i == (long long)n.size() - 1 ? lastLen : C.W;
+      if ((double)n[(size_t)i] / (double)wl <= 0.02) run += wl; else run = 0;
+    }
+    size_t use = 0, useReads = 0, useZero = 0;
+    const std::vector<size_t>& reads = C.cnt.at(tx).at(cd.first);
+    for (size_t i = 0; i < n.size(); ++i)
+      if (fwd[i] >= need && bwd[i] >= need) { ++use; useReads += reads.at(i); if (reads.at(i) == 0) ++useZero; }
+    nWin[tx] += n.size(); nUsable[tx] += use; nUsableReads[tx] += useReads; nUsableZero[tx] += useZero;
+  }
+
+  std::ofstream o(file);
+  o << "taxonID\tspecies\tgenus\tnReads\tpropBottomThirdReadIdentities\texpectedPropBottomThirdReadIdentities\tpValue_BottomThirdReadIdentities"
+       "\tcoverageWindows_totalGenome\tcoverageWindows_usable\tcoverageWindows_usable_averageCoverage\tcoverageWindows_usable_coverageIsZero"
+       "\tcoverageWindows_usable_coverageIsZero_expected\tcoverageWindows_usable_coverageIsZero_P\n";
+  for (auto& e : identPerTaxon) {
+    const std::string& tx = e.first;
+    const std::vector<double>& id = e.second;
+    std::string prop = "NA", pId = "NA", exp13 = "NA";
+    if (!bestTaxon.empty()) {                                    // :1026-1068
+      size_t obs = 0; for (double v : id) if (v <= oneThird) ++obs;
+      const size_t obsRest = id.size() - obs;
+      const double ex = oneThirdP * id.size(), exRest = id.size() - ex;
+      if (ex > 0 && exRest > 0) {
+        exp13 = std::to_string(oneThirdP);
+        const double stat = std::pow(obs - ex, 2) / ex + std::pow(obsRest - exRest, 2) / exRest;
+        prop = std::to_string((double)obs / (double)id.size());
+        pId = std::to_string(1 - chi2_1df_cdf(stat));
+      } else std::cerr << "evidenceUnknownSpecies: expected count of zero for taxon " << tx << " (the reference asserts here); identity columns NA\n";
+    }
+    std::string avg = "NA", zeroExp = "NA", zeroP = "NA";        // :1070-1114
+    if (nUsable.at(tx) > 0) {
+      const double a = (double)nUsableReads.at(tx) / (double)nUsable.at(tx);
+      avg = std::to_string(a);
+      if (a == 0) { zeroExp = std::to_string(nUsable.at(tx)); zeroP = std::to_string(1); }
+      else {
+        const double p0 = std::exp(-a);                          // Poisson(a) at 0
+        zeroExp = std::to_string(nUsable.at(tx) * p0);
+        double pv = 1;
+        if (nUsableZero.at(tx) > 0) pv = 1 - binom_cdf_sum(nUsable.at(tx), p0, nUsableZero.at(tx) - 1);
+        zeroP = std::to_string(pv);
+      }
+    }
+    auto up = T.upward_by_ranks(tx, {"species", "genus"});
+    o << tx << "\t" << up.at("species") << "\t" << up.at("genus") << "\t" << id.size() << "\t" << prop << "\t" << exp13 << "\t" << pId << "\t"
+      << nWin.at(tx) << "\t" << nUsable.at(tx) << "\t" << avg << "\t" << nUsableZero.at(tx) << "\t" << zeroExp << "\t" << zeroP << "\n";
+  }
+  return true;
+}
 
 struct EMTrace { std::vector<double> ll; std::map<std::string, double> f; };
 
@@ -397,7 +526,7 @@ static inline void write_wimp(const std::string& fn, const Taxonomy& T, std::map
 
 // meta/fEM.h:466-803 (EM loop + .EM / .EM.reads2Taxon / .krona / .EM.WIMP).  Single summation order
 // (the reference sums per OpenMP thread chunk, then across threads; with -t 1 it is exactly this order).
-static inline EMTrace do_em(const std::string& mapped, const std::string& dbDir, bool writeFiles = true) {
+static inline EMTrace do_em(const std::string& mapped, const std::string& dbDir, bool writeFiles = true, size_t minReadsU = 10000) {
   EMTrace tr;
   std::set<std::string> taxa;                                    // :1366-1394
   {
@@ -447,6 +576,8 @@ static inline EMTrace do_em(const std::string& mapped, const std::string& dbDir,
   li << "AnalysisLevel\tID\treadI\tIdentity\tLength\n";     // :686
   std::map<std::string, size_t> readsPer;
   Coverage coverage;
+  std::map<std::string, std::vector<double>> identPerTaxon;      // :691
+  long long maxReadLen = -1;                                     // :692
   size_t readI = 0;
   for (auto& g : groups) {                                       // :684-779
     auto locs = mapping_locations(TI, f, g);
@@ -462,6 +593,8 @@ static inline EMTrace do_em(const std::string& mapped, const std::string& dbDir,
     kr << rid << "\t" << T.first_non_x(locs[best].taxon) << "\t" << locs[best].p << "\n";
     readsPer[locs[best].taxon]++;
     li << "EqualCoverageUnit\t" << locs[best].contig << "\t" << readI++ << "\t" << locs[best].identity << "\t" << locs[best].readLen << "\n";   // :711
+    identPerTaxon[locs[best].taxon].push_back(locs[best].identity);   // :718-722
+    if ((long long)locs[best].readLen > maxReadLen) maxReadLen = (long long)locs[best].readLen;
     coverage.add(TI, locs[best]);
   }
   {                                                              // :785-790
@@ -482,6 +615,8 @@ static inline EMTrace do_em(const std::string& mapped, const std::string& dbDir,
   }
   write_wimp(mapped + ".EM.WIMP", T, f, readsPer, nTotal, nUnmapped, nTooShort);
   coverage.write(mapped + ".EM.contigCoverage", T);
+  if (!write_unknown_species(mapped + ".EM.evidenceUnknownSpecies", dbDir, T, coverage, identPerTaxon, maxReadLen, minReadsU))
+    std::cerr << "no contigNstats_windowSize_1000.txt in " << dbDir << ": .EM.evidenceUnknownSpecies not written\n";
   return tr;
 }
 

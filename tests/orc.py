@@ -24,6 +24,10 @@ class Oracle:
         L.orc_binom_pmf.argtypes = [C.c_int, C.c_double, C.c_int]
         L.orc_binom_sf.restype = C.c_double
         L.orc_binom_sf.argtypes = [C.c_int, C.c_double, C.c_int]
+        L.orc_binom_cdf_sum.restype = C.c_double
+        L.orc_binom_cdf_sum.argtypes = [C.c_uint64, C.c_double, C.c_uint64]
+        L.orc_chi2_1df_cdf.restype = C.c_double
+        L.orc_chi2_1df_cdf.argtypes = [C.c_double]
         L.orc_binom_quantile_upper.argtypes = [C.c_int, C.c_double, C.c_double]
         L.orc_min_hits_relaxed.argtypes = [C.c_int, C.c_int, C.c_float]
         L.orc_recommended_window.argtypes = [C.c_double, C.c_int, C.c_float, C.c_int, C.c_uint64]

@@ -41,7 +41,7 @@ def test_cli_outputs_match_oracle(oracle_lib, tmp_path, w_flag):
     pa, pb = str(tmp_path / "gpu"), str(tmp_path / "cpu")
     for exe, pre in ((CLI, pa), (orc.CLI, pb)):
         subprocess.run([exe, "mapDirectly", "--all", "-r", db.fasta, "-q", rd["path"], "-o", pre] + w_flag, check=True, capture_output=True, timeout=900)
-        subprocess.run([exe, "classify", "--DB", db.dir, "--mappings", pre], check=True, capture_output=True, timeout=900)
+        subprocess.run([exe, "classify", "--DB", db.dir, "--mappings", pre, "--minreads", "3"], check=True, capture_output=True, timeout=900)
     _cmp_table(pa, pb, " ", {13})
     for suf in (".meta", ".meta.unmappedReadsLengths"):
         assert open(pa + suf).read() == open(pb + suf).read(), suf
@@ -56,6 +56,23 @@ def test_cli_outputs_match_oracle(oracle_lib, tmp_path, w_flag):
     _cmp_table(pa + ".EM.contigCoverage", pb + ".EM.contigCoverage", "\t", {6})
     assert sum(1 for _ in open(pa + ".EM.contigCoverage")) > 50
     assert sum(1 for _ in open(pa)) > 150
+    _cmp_unknown_species(pa, pb)
+
+
+def _cmp_unknown_species(pa, pb, expect_tests=True):
+    # NA and integer columns as text, the six std::to_string doubles numerically
+    suf = ".EM.evidenceUnknownSpecies"
+    rows_a = [l.rstrip("\n").split("\t") for l in open(pa + suf)]
+    rows_b = [l.rstrip("\n").split("\t") for l in open(pb + suf)]
+    assert len(rows_a) == len(rows_b) > 1 and rows_a[0] == rows_b[0] and len(rows_a[0]) == 13
+    for ra, rb in zip(rows_a[1:], rows_b[1:]):
+        for c, (u, v) in enumerate(zip(ra, rb)):
+            if c in (4, 5, 6, 9, 11, 12) and u != "NA" and v != "NA":
+                assert abs(float(u) - float(v)) <= 2e-6, (ra, rb, c)
+            else:
+                assert u == v, (ra, rb, c)
+    if expect_tests:                                             # the run exercised both tests, not only the NA branches
+        assert any(r[6] != "NA" for r in rows_a[1:]) and any(r[12] not in ("NA", "1") for r in rows_a[1:])
 
 
 def _run_pair(tmp_path, extra, n_reads=200):
@@ -142,10 +159,11 @@ def test_cli_midscale_matches_oracle(oracle_lib, tmp_path):
     pa, pb = str(tmp_path / "gpu"), str(tmp_path / "cpu")
     for exe, pre, extra in ((CLI, pa, []), (orc.CLI, pb, ["-t", "16"])):
         subprocess.run([exe, "mapDirectly", "--all", "-r", db.fasta, "-q", rd["path"], "-o", pre] + extra, check=True, capture_output=True, timeout=1500)
-        subprocess.run([exe, "classify", "--DB", db.dir, "--mappings", pre], check=True, capture_output=True, timeout=1500)
+        subprocess.run([exe, "classify", "--DB", db.dir, "--mappings", pre, "--minreads", "20"], check=True, capture_output=True, timeout=1500)
     _cmp_table(pa, pb, " ", {13})
     assert open(pa + ".meta").read() == open(pb + ".meta").read()
     _cmp_table(pa + ".EM", pb + ".EM", " ", {13})
     assert open(pa + ".EM.reads2Taxon").read() == open(pb + ".EM.reads2Taxon").read()
     _cmp_table(pa + ".EM.WIMP", pb + ".EM.WIMP", "\t", {4, 5})
+    _cmp_unknown_species(pa, pb)
     assert sum(1 for _ in open(pa)) > 2000

@@ -6,6 +6,7 @@
 CPU only."""
 import ctypes as C
 import json
+import math
 import os
 import random
 import re
@@ -152,3 +153,41 @@ def test_mapq_text_roundtrip_matches_reference_format(oracle_lib):
     assert [x[12] for x in f] == ["85.5956", "82.8927", "85.5956"]        # the example file's field 13 for these identities
     q = [float(x[13]) for x in f]
     assert abs(sum(q) - 1) < 1e-5 and q[0] == q[2] and q[1] < q[0]
+
+
+def test_unknown_species_coverage_columns_of_example(oracle_lib):
+    """The coverage columns of the reference's own example.EM.evidenceUnknownSpecies (fEM.h:1070-1114): average reads per
+    usable window, expected zero-coverage windows (Poisson) and the binomial tail — known answers from a real run, i.e.
+    from the Boost.Math the reference was built with.  The file prints six decimals; the read count behind the printed
+    average is recovered as the integer that reproduces it."""
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(EX, "example.EM.evidenceUnknownSpecies"))]
+    assert rows[0][9:] == ["coverageWindows_usable_averageCoverage", "coverageWindows_usable_coverageIsZero",
+                           "coverageWindows_usable_coverageIsZero_expected", "coverageWindows_usable_coverageIsZero_P"]
+    checked = 0
+    for r in rows[1:]:
+        usable, avg_s, zero, exp_s, p_s = int(r[8]), r[9], int(r[10]), r[11], r[12]
+        if avg_s == "NA":
+            continue
+        reads = round(float(avg_s) * usable)
+        assert "%f" % (reads / usable) == avg_s
+        if reads == 0:
+            assert (exp_s, p_s) == (str(usable), "1")
+            continue
+        p0 = math.exp(-reads / usable)
+        assert "%f" % (usable * p0) == exp_s
+        pv = 1.0 if zero == 0 else 1 - oracle_lib.L.orc_binom_cdf_sum(usable, p0, zero - 1)
+        assert "%f" % pv == p_s, (r[0], pv, p_s)
+        checked += 1
+    assert checked >= 10
+
+
+def test_unknown_species_distribution_functions_vs_scipy(oracle_lib):
+    """chi-square(1) cdf and binomial cdf against scipy (which embeds Boost.Math) over the reachable domain."""
+    from scipy import stats
+    rng = np.random.default_rng(5)
+    for x in list(rng.uniform(0, 40, 200)) + [0.0, 1e-12, 3.841458820694124, 700.0]:
+        assert oracle_lib.L.orc_chi2_1df_cdf(x) == pytest.approx(stats.chi2.cdf(x, 1), rel=1e-12, abs=1e-300)
+    for _ in range(300):
+        n = int(rng.integers(1, 20000)); lam = float(10 ** rng.uniform(-4, 1.5)); p = math.exp(-lam)
+        k = int(min(n, max(0, rng.normal(n * p, 3 * math.sqrt(n * p * (1 - p)) + 1))))
+        assert oracle_lib.L.orc_binom_cdf_sum(n, p, k) == pytest.approx(stats.binom.cdf(k, n, p), rel=1e-9, abs=1e-14)

@@ -48,10 +48,13 @@ inline IndexView make_view(const mm_index* I) {
   return IndexView{I->pos.p, I->cstart.p, I->occ.p, I->tab.p, I->N, I->U, I->tab_bits, I->freq_threshold};
 }
 
-__host__ __device__ inline uint64_t tab_slot(uint32_t h, int bits) { return ((uint64_t)h * 0x9E3779B97F4A7C15ULL) >> (64 - bits); }
+// Home slot of a hash: the first slot of a 4-slot bucket (4 x 16 B = one 64-byte sector), linear probing from there.  A lookup
+// reads whole sectors: at load factor <= 0.625 nearly every hash is resolved (found, or an empty slot seen) by its home sector,
+// i.e. by one memory request — random requests, not bytes, are what the probe stage pays for (tools/ubench/randread).
+__host__ __device__ inline uint64_t tab_slot(uint32_t h, int bits) { return (((uint64_t)h * 0x9E3779B97F4A7C15ULL) >> (64 - (bits - 2))) << 2; }
 
 // hash -> (occurrence count, first occurrence); false when the hash is not in the index
-// (minimizerPosLookupIndex.find, computeMap.hpp:310)
+// (minimizerPosLookupIndex.find, computeMap.hpp:310).  One lane per lookup; probe_kernel has the 4-lanes-per-sector form.
 __device__ inline bool index_find(const IndexView& I, uint32_t h, uint32_t* count, uint64_t* start) {
   const uint64_t mask = ((uint64_t)1 << I.tab_bits) - 1;
   uint64_t slot = tab_slot(h, I.tab_bits);

@@ -168,17 +168,41 @@ __global__ void __launch_bounds__(256) scatter_strand_kernel(const uint8_t* __re
 __global__ void __launch_bounds__(256) probe_kernel(IndexView I, const uint32_t* __restrict__ sk_hash, const uint64_t* __restrict__ off,
                                                     const int32_t* __restrict__ sk_n, uint32_t* __restrict__ probe_cnt,
                                                     uint64_t* __restrict__ probe_start) {
+  // Four lanes per lookup, each reading one 16-byte slot of the hash's home sector (mm_index.hpp: tab_slot): one 64-byte
+  // request resolves nearly every lookup; NP lookups per group in flight.
   const int r = blockIdx.x;
   const uint64_t o = off[r];
   const int s = sk_n[r];
-  for (int i = threadIdx.x; i < s; i += 256) {
-    uint32_t c = 0, cnt = 0; uint64_t st = 0;
-    if (index_find(I, sk_hash[o + i], &cnt, &st)) {
-      if ((uint64_t)cnt < (uint64_t)(int64_t)I.freq_threshold) c = cnt;   // computeMap.hpp:317
-      else st = 0;
-    }
-    probe_cnt[o + i] = c;
-    probe_start[o + i] = st;
+  const int grp = threadIdx.x >> 2, sub = threadIdx.x & 3, gshift = (threadIdx.x & 63) & ~3;
+  const ulonglong2* __restrict__ tab = reinterpret_cast<const ulonglong2*>(I.tab);
+  const uint64_t mask = ((uint64_t)1 << I.tab_bits) - 1;
+  constexpr int NP = 4;                                          // lookups in flight per group
+  for (int i0 = grp; i0 < s; i0 += 64 * NP) {
+    uint32_t hq[NP]; uint64_t sq[NP]; ulonglong2 vq[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) { hq[u] = i0 + 64 * u < s ? sk_hash[o + i0 + 64 * u] : 0u; sq[u] = tab_slot(hq[u], I.tab_bits); }
+#pragma unroll
+    for (int u = 0; u < NP; ++u) vq[u] = tab[sq[u] + sub];
+    auto resolve = [&](uint32_t h, uint64_t slot, ulonglong2 v, bool active, int i) {
+      bool pending = active;
+      while (__any(pending)) {                                   // (wave-wide loop: the ballots below need every lane)
+        const bool match = pending && v.x != 0 && (uint32_t)v.x == h, empty = pending && v.x == 0;
+        const uint32_t gm = (uint32_t)(__ballot(match) >> gshift) & 0xfu, ge = (uint32_t)(__ballot(empty) >> gshift) & 0xfu;
+        if (pending && (gm | ge)) {
+          // slots are filled in probing order and never emptied: a match is the key's slot, an empty slot without one means absent
+          if (match) {
+            const uint32_t cnt = (uint32_t)(v.x >> 32);
+            const bool keep = (uint64_t)cnt < (uint64_t)(int64_t)I.freq_threshold;   // computeMap.hpp:317
+            probe_cnt[o + i] = keep ? cnt : 0u;
+            probe_start[o + i] = keep ? v.y : 0ull;
+          } else if (!gm && sub == 0) { probe_cnt[o + i] = 0u; probe_start[o + i] = 0ull; }
+          pending = false;
+        }
+        if (pending) { slot = (slot + 4) & mask; v = tab[slot + sub]; }
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < NP; ++u) resolve(hq[u], sq[u], vq[u], i0 + 64 * u < s, i0 + 64 * u);
   }
 }
 

@@ -25,16 +25,22 @@ def pmc(kind):
     return acc
 
 fe, wr = pmc("fetch"), pmc("write")
+
+def fetch_corr(kernel):
+    return 1.0 if ("hit_filter_kernel" in kernel or "probe_kernel" in kernel) else 2.0
+
 with open(os.path.join(out, "pmc_hbm_traffic.txt"), "w") as w:
     w.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE   and   --pmc WRITE_SIZE   (separate passes), bench.py --steps 1 --warmup 0 --no-cpu-baseline\n")
-    w.write("# counter unit: KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (fetch_GB_x2).\n")
-    w.write(f"{'kernel':<62} {'launches':>8} {'FETCH_KiB':>14} {'fetch_GB_x2':>12} {'WRITE_KiB':>14} {'write_GB':>9}\n")
+    w.write("# counter unit: KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> x2;\n")
+    w.write("# kernels whose reads are random pieces of <= 64 bytes (hit filter, probe: 4 lanes x 16 B) are counted exactly -> x1\n")
+    w.write("# (calibration on a known byte count in that access pattern: profiles/r01_fetch_size_calibration.txt).\n")
+    w.write(f"{'kernel':<62} {'launches':>8} {'FETCH_KiB':>14} {'corr':>5} {'fetch_GB':>10} {'WRITE_KiB':>14} {'write_GB':>9}\n")
     for k in sorted(fe, key=lambda k: -fe[k][1]):
-        w.write(f"{k:<62} {fe[k][0]:>8} {fe[k][1]:>14.0f} {fe[k][1]*1024*2/1e9:>12.2f} {wr.get(k,[0,0])[1]:>14.0f} {wr.get(k,[0,0])[1]*1024/1e9:>9.2f}\n")
+        w.write(f"{k:<62} {fe[k][0]:>8} {fe[k][1]:>14.0f} {fetch_corr(k):>5.0f} {fe[k][1]*1024*fetch_corr(k)/1e9:>10.2f} {wr.get(k,[0,0])[1]:>14.0f} {wr.get(k,[0,0])[1]*1024/1e9:>9.2f}\n")
 traffic = {}
 for k in fe:
     if "l2_kernel" in k or "hit_filter_kernel<false>" in k:
-        traffic[k] = (fe[k][1] * 1024 * 2 + wr.get(k, [0, 0])[1] * 1024) / max(fe[k][0], 1)
+        traffic[k] = (fe[k][1] * 1024 * fetch_corr(k) + wr.get(k, [0, 0])[1] * 1024) / max(fe[k][0], 1)
 json.dump(traffic, open(os.path.join(out, "traffic_by_kernel.json"), "w"), indent=1)
 print(open(os.path.join(out, "kernel_stats.txt")).read()[:3000])
 print(open(os.path.join(out, "pmc_hbm_traffic.txt")).read()[:3000])

@@ -76,13 +76,32 @@ __global__ void csr_fill_kernel(const uint32_t* __restrict__ key, const uint32_t
   }
 }
 
+// Occurrence lists are laid out on 64-byte sector boundaries: the seed-hit filter reads every list of every read twice and
+// pays per 64-byte sector touched; a list that starts mid-sector touches one sector more than it needs.
+// Cost: each list is padded to a multiple of 8 entries (~3.5 entries per unique hash).
+__global__ void padded_counts_kernel(const uint64_t* __restrict__ ustart, int64_t U, uint32_t* __restrict__ pc) {
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t c = ustart[u + 1] - ustart[u];
+    pc[u] = (uint32_t)((c + 7) & ~7ull);                         // (a list of >= 2^32 entries cannot exist: N < 2^32 per contig set is checked by the caller's limits)
+  }
+}
+// eight lanes per list: entry j of list u moves from occ[ustart[u] + j] to out[pstart[u] + j]
+__global__ void __launch_bounds__(256) pad_lists_kernel(const uint64_t* __restrict__ occ, const uint64_t* __restrict__ ustart,
+                                                        const uint64_t* __restrict__ pstart, int64_t U, uint64_t* __restrict__ out) {
+  const int sub = threadIdx.x & 7;
+  for (int64_t u = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; u < U; u += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+    const uint64_t a = ustart[u], c = ustart[u + 1] - a, b = pstart[u];
+    for (uint64_t j = sub; j < c; j += 8) out[b + j] = occ[a + j];
+  }
+}
+
 // open-addressing insert of every unique hash: slot word 0 = count<<32 | hash (non-zero: count >= 1), word 1 = start
-__global__ void table_insert_kernel(const uint32_t* __restrict__ uh, const uint64_t* __restrict__ ustart, int64_t U, int bits,
-                                    unsigned long long* __restrict__ tab) {
+__global__ void table_insert_kernel(const uint32_t* __restrict__ uh, const uint64_t* __restrict__ ustart, const uint64_t* __restrict__ pstart,
+                                    int64_t U, int bits, unsigned long long* __restrict__ tab) {
   const uint64_t mask = ((uint64_t)1 << bits) - 1;
   for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t h = uh[u];
-    const uint64_t st = ustart[u], cnt = ustart[u + 1] - st;
+    const uint64_t st = pstart[u], cnt = ustart[u + 1] - ustart[u];
     const unsigned long long w0 = ((unsigned long long)(cnt > 0xFFFFFFFFull ? 0xFFFFFFFFull : cnt) << 32) | h;
     uint64_t slot = tab_slot(h, bits);
     while (atomicCAS(&tab[2 * slot], 0ull, w0) != 0ull) slot = (slot + 1) & mask;
@@ -248,13 +267,30 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   MM_REQUIRE((int64_t)hn[0] <= big_cap, MM_ERR_LIMIT, "more than 2^20 hashes occur >= 4096 times in one index chunk");
   for (int i = 0; i < HIST_BINS; ++i) if (hb[i]) I->hist[i] += (int64_t)hb[i];
   if (hn[0]) { auto hbig = big.to_host(st, (size_t)hn[0]); for (auto c : hbig) I->hist[(int64_t)c] += 1; }
-  // lookup table (load factor <= 0.625), then the CSR arrays are no longer needed
   key_out.release();
+  // sector-aligned occurrence lists (see padded_counts_kernel)
+  DBuf<uint64_t> pstart((size_t)U + 1);
+  {
+    DBuf<uint32_t> pc((size_t)U + 1); pc.zero(st);
+    padded_counts_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div((int64_t)U, 256), 1 << 20)), dim3(256), 0, st>>>(I->ustart.p, (int64_t)U, pc.p);
+    MM_KERNEL_CHECK();
+    DBuf<uint64_t> scan_tmp3;
+    exclusive_scan_u32_u64(pc.p, (int64_t)U, pstart.p, scan_tmp3, st);
+    uint64_t P = 0;
+    MM_HIP(hipMemcpyAsync(&P, pstart.p + U, sizeof P, hipMemcpyDeviceToHost, st));
+    MM_HIP(hipStreamSynchronize(st));
+    DBuf<uint64_t> padded((size_t)P + 2);                        // +2: the filter's 16-byte loads may read one pair past a list
+    pad_lists_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div((int64_t)U * 8, 256), 1 << 20)), dim3(256), 0, st>>>(I->occ.p, I->ustart.p, pstart.p, (int64_t)U, padded.p);
+    MM_KERNEL_CHECK();
+    MM_HIP(hipStreamSynchronize(st));
+    I->occ = std::move(padded);
+  }
+  // lookup table (load factor <= 0.625), then the CSR arrays are no longer needed
   int bits = 8; while (((int64_t)1 << bits) * 5 < (int64_t)U * 8) ++bits;
   I->tab_bits = bits;
   I->tab.alloc((size_t)2 << bits);
   I->tab.zero(st);
-  table_insert_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div((int64_t)U, 256), 1 << 20)), dim3(256), 0, st>>>(I->uh.p, I->ustart.p, (int64_t)U, bits,
+  table_insert_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div((int64_t)U, 256), 1 << 20)), dim3(256), 0, st>>>(I->uh.p, I->ustart.p, pstart.p, (int64_t)U, bits,
                                                                                                               (unsigned long long*)I->tab.p);
   MM_KERNEL_CHECK();
   MM_HIP(hipStreamSynchronize(st));

@@ -3,7 +3,8 @@
 //
 //   pos[N]      position-ordered minimizers {hash, pw}           == Sketch::minimizerIndex      (:129)
 //   cstart[C+1] entry range of every contig in pos[]
-//   occ[N]      occurrences grouped by hash                       == minimizerPosLookupIndex      (:119)
+//   occ[P]      occurrences grouped by hash, every group starting on a 64-byte boundary (padded to 8 entries)
+//                                                                 == minimizerPosLookupIndex      (:119)
 //               occ entry = contig<<32 | pw  (8 bytes, directly usable as an L1 seed hit / sort key)
 //   tab[2*cap]  open-addressing table hash -> (count, first occ): slot = {count<<32 | hash, start}; one 64-byte
 //               line per lookup on average (uh[]/ustart[] CSR arrays only live during the build)

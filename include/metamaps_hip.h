@@ -61,6 +61,9 @@ void* mm_ctx_stream(mm_ctx* ctx);
 int mm_seqset_create(mm_ctx* ctx, mm_seqset** out);
 void mm_seqset_destroy(mm_seqset* s);
 int mm_seqset_add(mm_seqset* s, const char* ascii, int64_t len);   /* host staging, keeps input order */
+/* same, without the copy: the caller keeps `ascii` valid and unchanged until mm_seqset_upload has returned (a parser that
+ * fills one arena per batch hands its records over this way) */
+int mm_seqset_add_view(mm_seqset* s, const char* ascii, int64_t len);
 int mm_seqset_upload(mm_seqset* s);                                /* pack + copy to HBM; set is then frozen */
 /* Persistent packed form of an uploaded sequence set (2-bit bases, exception runs, lengths): what `metamaps index` stores
  * per index chunk in place of the reference's Boost archive of the sketch (createIndex, mapWrap.h:358-405;

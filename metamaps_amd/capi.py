@@ -93,6 +93,7 @@ def lib() -> C.CDLL:
             "mm_seqset_create": (C.c_int, [vp, P(vp)]),
             "mm_seqset_destroy": (None, [vp]),
             "mm_seqset_add": (C.c_int, [vp, C.c_char_p, i64]),
+            "mm_seqset_add_view": (C.c_int, [vp, C.c_char_p, i64]),
             "mm_seqset_save": (C.c_int, [vp, C.c_char_p]),
             "mm_seqset_load": (C.c_int, [vp, C.c_char_p, P(vp)]),
             "mm_seqset_upload": (C.c_int, [vp]),

@@ -19,6 +19,7 @@
 // Not provided: classifyU (disabled upstream).
 
 #include "../../../include/metamaps_hip.h"
+#include <sys/mman.h>
 #include <zlib.h>
 #include <algorithm>
 #include <cctype>
@@ -47,8 +48,9 @@ namespace {
 
 // MM_CLI_TIMING=1: wall time per phase on stderr at exit
 struct PhaseClock {
-  std::map<std::string, double> acc; std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-  void lap(const char* name) { auto n = std::chrono::steady_clock::now(); acc[name] += std::chrono::duration<double>(n - t).count(); t = n; }
+  std::map<std::string, double> acc; std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now(), t0 = t;
+  void lap(const char* name) { auto n = std::chrono::steady_clock::now(); acc[name] += std::chrono::duration<double>(n - t).count(); t = n;
+                               if (getenv("MM_CLI_TIMING")) std::cerr << "INFO, lap " << name << " at +" << std::chrono::duration<double>(n - t0).count() << " s\n"; }
   ~PhaseClock() { if (getenv("MM_CLI_TIMING")) for (auto& kv : acc) std::cerr << "INFO, time " << kv.first << " " << kv.second << " s\n"; }
 };
 
@@ -81,6 +83,13 @@ class SeqFile {
     for (;;) {
       if (beg_ >= end_) { const int ch = get(); if (ch == -1) break; --beg_; }      // refill
       const unsigned char* p = buf_.data() + beg_;
+      {                                                          // fast path: a whole line of plain sequence characters
+        const unsigned char* const nl = (const unsigned char*)memchr(p, '\n', end_ - beg_);
+        const unsigned char* const le = nl ? nl : buf_.data() + end_;
+        unsigned char bad = 0;                                   // (byte-wise OR reduction: vectorises)
+        for (const unsigned char* q = p; q < le; ++q) { const unsigned char b = *q; bad |= (unsigned char)((unsigned char)(b - 33) > 93) | (unsigned char)(b == '+') | (unsigned char)(b == '>') | (unsigned char)(b == '@'); }
+        if (!bad && le > p) { seq.append((const char*)p, (size_t)(le - p)); beg_ = (size_t)(le - buf_.data()) + (nl ? 1 : 0); continue; }
+      }
       const unsigned char* const e = p + std::min<size_t>(end_ - beg_, 16384);   // (resize zero-fills: keep the pieces small)
       const size_t old = seq.size();
       seq.resize(old + (size_t)(e - p));
@@ -104,8 +113,10 @@ class SeqFile {
         for (const unsigned char* q = p; q < e; ++q) cnt += (unsigned)(*q - 33u) <= 94u;
         got += cnt; beg_ = end_;
       } else {
-        while (p < e && got < seq.size()) { got += (unsigned)(*p - 33u) <= 94u; ++p; }
-        beg_ = (size_t)(p - buf_.data());
+        unsigned char bad = 0;                                   // usual case: the next `want` bytes are the quality line
+        for (const unsigned char* q = p; q < p + want; ++q) bad |= (unsigned char)((unsigned char)(*q - 33) > 94);
+        if (!bad) { got += want; beg_ += want; }
+        else { while (p < e && got < seq.size()) { got += (unsigned)(*p - 33u) <= 94u; ++p; } beg_ = (size_t)(p - buf_.data()); }
       }
     }
     pending_ = 0;
@@ -295,7 +306,7 @@ int map_mode(const Options& o, const std::string& mode) {
     }
   }
   // ---- reads, batch by batch (computeMap.hpp:104-172 + unifyFiles mapWrap.h:34-213)
-  const int64_t BATCH_READS = 100000, BATCH_BASES = 1000000000LL;   // ~1 Gbp per device batch; the next one is parsed meanwhile
+  const int64_t BATCH_READS = 100000, BATCH_BASES = 256000000LL;   // ~0.25 Gbp per device batch (16 ms of mapping); the next ones are parsed meanwhile
   for (size_t fi = 0; fi < queries.size(); ++fi) {
     const std::string& prefix = prefixes[fi];
     std::ofstream out(prefix), unm(prefix + ".meta.unmappedReadsLengths");
@@ -303,19 +314,40 @@ int map_mode(const Options& o, const std::string& mode) {
     size_t total = 0, tooShort = 0, mapped = 0, notMapped = 0;
     std::set<std::string> seen;
     // a reader thread parses the next batches (bounded queue) while this thread packs, maps and writes the current one
-    struct Batch { std::vector<std::string> names, seqs; std::vector<int> lens; };
-    std::mutex qm; std::condition_variable qcv; std::deque<std::unique_ptr<Batch>> queue; bool reader_done = false;
+    // A batch keeps its sequences back to back in one arena (huge pages when the system grants them) that is handed to
+    // the library by reference (mm_seqset_add_view) and recycled: no allocation, copy or page fault per read.
+    struct Batch {
+      std::vector<std::string> names; std::vector<int> lens; std::vector<size_t> off;
+      char* arena = nullptr; size_t cap = 0, used = 0;
+      ~Batch() { free(arena); }
+      void reserve(size_t want) {
+        if (want <= cap) return;
+        const size_t HP = (size_t)2 << 20, ncap = (std::max(want, cap + cap / 2) + HP - 1) / HP * HP;
+        char* na = (char*)aligned_alloc(HP, ncap);
+        if (!na) die("out of host memory for the read batch");
+        madvise(na, ncap, MADV_HUGEPAGE);
+        if (used) memcpy(na, arena, used);
+        free(arena); arena = na; cap = ncap;
+      }
+      void put(const std::string& q) { reserve(used + q.size() + 1); memcpy(arena + used, q.data(), q.size()); off.push_back(used); used += q.size(); }
+      void reset() { names.clear(); lens.clear(); off.clear(); used = 0; }
+    };
+    std::mutex qm; std::condition_variable qcv; std::deque<std::unique_ptr<Batch>> queue; std::vector<std::unique_ptr<Batch>> spare; bool reader_done = false;
     std::thread reader([&]() {
       SeqFile f(queries[fi]);
       bool more = true;
       while (more) {
-        auto b = std::make_unique<Batch>();
+        std::unique_ptr<Batch> b;
+        { std::lock_guard<std::mutex> lk(qm); if (!spare.empty()) { b = std::move(spare.back()); spare.pop_back(); } }
+        if (!b) b = std::make_unique<Batch>();
         int64_t bases = 0;
         while ((int64_t)b->names.size() < BATCH_READS && bases < BATCH_BASES && (more = f.next())) {
+          if (b->names.empty()) b->reserve((size_t)std::min<int64_t>(BATCH_BASES, (int64_t)f.seq.size() * BATCH_READS) + ((size_t)64 << 20));
           b->names.push_back(f.name); b->lens.push_back((int)f.seq.size()); bases += (int64_t)f.seq.size();
-          b->seqs.emplace_back(); b->seqs.back().swap(f.seq);
+          b->put(f.seq);
         }
         if (b->names.empty()) break;
+        if (getenv("MM_CLI_TIMING")) std::cerr << "INFO, reader: batch of " << b->names.size() << " reads parsed at +" << std::chrono::duration<double>(std::chrono::steady_clock::now() - pc.t0).count() << " s\n";
         std::unique_lock<std::mutex> lk(qm);
         qcv.wait(lk, [&] { return queue.size() < 2; });
         queue.push_back(std::move(b));
@@ -335,8 +367,7 @@ int map_mode(const Options& o, const std::string& mode) {
       }
       std::vector<std::string>& names = bt->names; std::vector<int>& lens = bt->lens;
       mm_seqset* reads; ck(ctx, mm_seqset_create(ctx, &reads), "seqset");
-      for (auto& q : bt->seqs) ck(ctx, mm_seqset_add(reads, q.data(), (int64_t)q.size()), "add read");
-      bt->seqs.clear(); bt->seqs.shrink_to_fit();
+      for (size_t r = 0; r < names.size(); ++r) ck(ctx, mm_seqset_add_view(reads, bt->arena + bt->off[r], (int64_t)lens[r]), "add read");
       pc.lap("4 reads parse");
       ck(ctx, mm_seqset_upload(reads), "upload reads");
       pc.lap("5 reads pack+upload");
@@ -380,6 +411,8 @@ int map_mode(const Options& o, const std::string& mode) {
         }
       }
       mm_mapping_destroy(m); mm_seqset_destroy(reads);
+      bt->reset();
+      { std::lock_guard<std::mutex> lk(qm); spare.push_back(std::move(bt)); }
       pc.lap("7 format+write");
     }
     std::ofstream meta(prefix + ".meta");                        // mapWrap.h:178-184

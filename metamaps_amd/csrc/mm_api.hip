@@ -94,7 +94,15 @@ int mm_seqset_add(mm_seqset* s, const char* ascii, int64_t len) {
   if (!s || (!ascii && len > 0) || len < 0) return MM_ERR_ARG;
   return guarded(s->ctx, [&] {
     MM_REQUIRE(!s->frozen, MM_ERR_STATE, "sequence set already uploaded");
-    s->staged.emplace_back(ascii ? ascii : "", (size_t)len);
+    s->owned.emplace_back(ascii ? ascii : "", (size_t)len);
+    s->staged.emplace_back(s->owned.back().data(), (size_t)len);
+  });
+}
+int mm_seqset_add_view(mm_seqset* s, const char* ascii, int64_t len) {
+  if (!s || (!ascii && len > 0) || len < 0) return MM_ERR_ARG;
+  return guarded(s->ctx, [&] {
+    MM_REQUIRE(!s->frozen, MM_ERR_STATE, "sequence set already uploaded");
+    s->staged.emplace_back(ascii, (size_t)len);
   });
 }
 int mm_seqset_upload(mm_seqset* s) {

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <deque>
 #include <vector>
 #include <stdexcept>
 #include <memory>
@@ -251,7 +252,8 @@ struct mm_seqset {
   mm_ctx* ctx = nullptr;
   bool frozen = false;
   // host staging (until upload)
-  std::vector<std::string> staged;
+  std::deque<std::string> owned;                                // copies made by mm_seqset_add (stable addresses)
+  std::vector<std::pair<const char*, size_t>> staged;           // what upload packs: views into `owned` or into caller memory (mm_seqset_add_view)
   // host-side metadata (always valid after upload / synthesis)
   std::vector<int32_t> len;            // per sequence
   std::vector<uint64_t> base;          // [n+1] first base of sequence i in the packed stream (multiple of 16)

@@ -104,8 +104,8 @@ void seqset_upload(mm_seqset* s) {
   s->base.assign(n + 1, 0);
   s->total_bases = 0;
   for (size_t i = 0; i < n; ++i) {
-    MM_REQUIRE((int64_t)s->staged[i].size() <= MAX_SEQ_LEN, MM_ERR_LIMIT, "sequence longer than 2^29-1 bases");
-    s->len[i] = (int32_t)s->staged[i].size();
+    MM_REQUIRE((int64_t)s->staged[i].second <= MAX_SEQ_LEN, MM_ERR_LIMIT, "sequence longer than 2^29-1 bases");
+    s->len[i] = (int32_t)s->staged[i].second;
     s->base[i + 1] = s->base[i] + (((uint64_t)s->len[i] + 15) & ~15ull);
     s->total_bases += s->len[i];
   }
@@ -127,9 +127,8 @@ void seqset_upload(mm_seqset* s) {
     auto work = [&](size_t t) {
       Runs& R = runs[t];
       for (size_t i = cut[t]; i < cut[t + 1]; ++i) {
-        const std::string& q = s->staged[i];
-        const uint8_t* p = (const uint8_t*)q.data();
-        const size_t L = q.size();
+        const uint8_t* p = (const uint8_t*)s->staged[i].first;
+        const size_t L = s->staged[i].second;
         uint32_t* wp = words.data() + (s->base[i] >> 4);
         const uint64_t b0 = s->base[i];
         bool open = false;
@@ -168,7 +167,7 @@ void seqset_upload(mm_seqset* s) {
     s->exc_byte.alloc(eb.size()); s->exc_byte.upload(eb.data(), eb.size(), st);
   }
   MM_HIP(hipStreamSynchronize(st));
-  s->staged.clear(); s->staged.shrink_to_fit();
+  s->staged.clear(); s->staged.shrink_to_fit(); s->owned.clear(); s->owned.shrink_to_fit();
   s->frozen = true;
 }
 

@@ -167,3 +167,40 @@ def test_cli_midscale_matches_oracle(oracle_lib, tmp_path):
     _cmp_table(pa + ".EM.WIMP", pb + ".EM.WIMP", "\t", {4, 5})
     _cmp_unknown_species(pa, pb)
     assert sum(1 for _ in open(pa)) > 2000
+
+
+_RANDOM_CASES = [
+    # k, w, --pi, -m, read_len, len_jitter, sub, ins, del, --all
+    (11, 5, 80, 500, 1500, 0.5, 0.03, 0.02, 0.03, True),
+    (14, 3, 85, 1000, 2500, 0.3, 0.02, 0.02, 0.02, True),
+    (19, 10, 75, 1000, 4000, 0.6, 0.05, 0.04, 0.05, False),
+    (24, 16, 90, 2000, 6000, 0.2, 0.01, 0.01, 0.01, True),
+    (16, 25, 80, 600, 3000, 0.8, 0.04, 0.03, 0.05, False),
+    (12, 1, 82, 1000, 2000, 0.4, 0.03, 0.03, 0.03, True),
+]
+
+
+@pytest.mark.parametrize("case", _RANDOM_CASES, ids=lambda c: f"k{c[0]}w{c[1]}pi{c[2]}m{c[3]}")
+def test_cli_parameter_sweep_matches_oracle(oracle_lib, tmp_path, case):
+    """mapDirectly + classify with k / w / identity threshold / minimum read length / read length spread / error rates
+    away from the defaults (k above and below the 16-base fast path of K1, w = 1, sketches of very different sizes)"""
+    import orc
+    from metamaps_amd import synth
+    k, w, pi, m, rl, jit, sub, ins, dele, all_ = case
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=8, genome_len=40_000, seed=100 + k)
+    rd = synth.make_reads(db, str(tmp_path / "reads.fq"), n_reads=150, read_len=rl, seed=w, len_jitter=jit, sub=sub, ins=ins, dele=dele)
+    pa, pb = str(tmp_path / "gpu"), str(tmp_path / "cpu")
+    opts = ["-k", str(k), "-w", str(w), "--pi", str(pi), "-m", str(m)] + (["--all"] if all_ else [])
+    for exe, pre in ((CLI, pa), (orc.CLI, pb)):
+        subprocess.run([exe, "mapDirectly", "-r", db.fasta, "-q", rd["path"], "-o", pre] + opts, check=True, capture_output=True, timeout=900)
+        subprocess.run([exe, "classify", "--DB", db.dir, "--mappings", pre, "--minreads", "3"], check=True, capture_output=True, timeout=900)
+    _cmp_table(pa, pb, " ", {13})
+    for suf in (".meta", ".meta.unmappedReadsLengths"):
+        assert open(pa + suf).read() == open(pb + suf).read(), suf
+    assert [l for l in open(pa + ".parameters") if not l.startswith("outFileName")] == [l for l in open(pb + ".parameters") if not l.startswith("outFileName")]
+    _cmp_table(pa + ".EM", pb + ".EM", " ", {13})
+    assert open(pa + ".EM.reads2Taxon").read() == open(pb + ".EM.reads2Taxon").read()
+    _cmp_table(pa + ".EM.WIMP", pb + ".EM.WIMP", "\t", {4, 5})
+    _cmp_table(pa + ".EM.contigCoverage", pb + ".EM.contigCoverage", "\t", {6})
+    _cmp_unknown_species(pa, pb, expect_tests=False)
+    assert sum(1 for _ in open(pa)) > 30

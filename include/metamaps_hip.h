@@ -171,6 +171,10 @@ typedef struct {
 int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, mm_mapping** out);
 void mm_mapping_destroy(mm_mapping* m);
 int mm_mapping_get_stats(const mm_mapping* m, mm_map_stats* out);
+/* frees everything of a batch result but its records, offsets and read lengths (what fetch, keep_best, concat, add_qualities and
+ * the EM builder use); the debug taps return empty afterwards.  For callers that hold the results of many batches, e.g. while
+ * the chunks of a reference larger than HBM are indexed and mapped one after the other (mapWrap.h:417-437 keeps them as files). */
+int mm_mapping_release_intermediates(mm_mapping* m);
 /* per-read first-record offsets [n_reads+1], records in (read, contig, position) order */
 int mm_mapping_fetch(mm_mapping* m, int64_t* offsets, mm_map_record* records, int64_t cap);
 /* K8: mapping qualities over the union of each read's records (mapWrap.h:215-323) */

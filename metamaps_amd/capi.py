@@ -118,6 +118,7 @@ def lib() -> C.CDLL:
             "mm_map_batch": (C.c_int, [vp, vp, vp, P(MapParams), P(vp)]),
             "mm_mapping_destroy": (None, [vp]),
             "mm_mapping_get_stats": (C.c_int, [vp, P(MapStats)]),
+            "mm_mapping_release_intermediates": (C.c_int, [vp]),
             "mm_mapping_fetch": (C.c_int, [vp, vp, vp, i64]),
             "mm_mapping_add_qualities": (C.c_int, [vp, vp, vp, C.c_int]),
             "mm_mapping_concat": (C.c_int, [vp, P(vp), vp, C.c_int, P(vp)]),

@@ -12,6 +12,9 @@
 // --mm G splits the reference into the same index chunks the reference would build under that limit
 // (mm_index_plan_chunks); all chunk indexes stay resident in HBM and every read batch is mapped against each.
 // (--maxmemory-bytes N gives the limit in bytes: a test hook, sub-GiB limits make small references chunk.)
+// --stream-chunks (automatic when the chunk indexes cannot all be resident): one chunk index on the device at a time,
+// every read batch (kept packed on the device) mapped against it, merge at the end — mapWrap.h:417-437 with HBM in
+// place of the PREFIX.N files.  (--stream-range-bases N: test hook, size of the contig ranges the chunk rule is evaluated on.)
 //
 // `index` stores the packed reference per chunk (own versioned format, include/metamaps_hip.h: mm_seqset_save) instead of
 // the reference's Boost archives of the sketch; the device index is rebuilt from it in seconds.
@@ -22,6 +25,7 @@
 #include <sys/mman.h>
 #include <zlib.h>
 #include <algorithm>
+#include <functional>
 #include <cctype>
 #include <climits>
 #include <cmath>
@@ -133,7 +137,7 @@ std::vector<std::string> split(const std::string& in, const std::string& d) {   
   return out;
 }
 
-struct Options { std::map<std::string, std::string> v; bool all = false; };
+struct Options { std::map<std::string, std::string> v; bool all = false, stream = false; };
 Options parse(int argc, char** argv) {
   static const std::map<std::string, std::string> alias{{"-r", "reference"}, {"-q", "query"}, {"-o", "output"}, {"-k", "kmer"}, {"-p", "pval"},
       {"-w", "window"}, {"-m", "minReadLen"}, {"-t", "threads"}, {"--mm", "maxmemory"}, {"--pi", "perc_identity"}, {"-i", "index"}};
@@ -141,6 +145,7 @@ Options parse(int argc, char** argv) {
   for (int i = 2; i < argc; ++i) {
     std::string a = argv[i];
     if (a == "--all") { o.all = true; continue; }
+    if (a == "--stream-chunks") { o.stream = true; continue; }
     if (a == "-h" || a == "--help") { std::cout << "see the header of metamaps_main.cpp / the reference's README\n"; exit(0); }
     std::string key = alias.count(a) ? alias.at(a) : (a.rfind("--", 0) == 0 ? a.substr(2) : "");
     if (key.empty() || i + 1 >= argc) die("Unknown or incomplete option " + a);
@@ -202,51 +207,100 @@ int map_mode(const Options& o, const std::string& mode) {
   if (mm_ctx_create(0, &ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
   pc.lap("0 context");
   std::vector<std::string> cname; std::vector<int> clen;
-  struct Chunk { int first, count; mm_index* idx; };
+  struct Chunk { int first, count; mm_index* idx; std::string file; };   // idx == nullptr: built when its pass starts (streamed chunks)
   std::vector<Chunk> chunks;
+  std::deque<std::string> cseq;                                  // contig sequences, kept while chunk indexes are still to be built from them
+  bool stream_chunks = o.stream;                                 // one chunk index in HBM at a time (also chosen automatically below)
+  uint64_t hbm_free = 0;
+  { char nm[8]; int cus; uint64_t tot; mm_ctx_device_info(ctx, nm, sizeof nm, &cus, &tot, &hbm_free); }
+  const double INDEX_BYTES_PER_BASE = 5.5;                       // pos + padded occ + table at w = 8; denser for smaller w
+  auto make_part = [&](int a, int bnd) {
+    mm_seqset* part; ck(ctx, mm_seqset_create(ctx, &part), "seqset");
+    for (int i = a; i < bnd; ++i) ck(ctx, mm_seqset_add_view(part, cseq[(size_t)i].data(), (int64_t)cseq[(size_t)i].size()), "add contig");
+    ck(ctx, mm_seqset_upload(part), "upload reference chunk");
+    return part;
+  };
   if (!from_index) {
     // ---- index (winSketch.hpp:180-365): the whole reference first; under --maxmemory it only serves to evaluate the
     // chunk rule and is then replaced by one index per chunk
-    std::vector<std::string> cseq;
     mm_seqset* contigs; ck(ctx, mm_seqset_create(ctx, &contigs), "seqset");
     SeqFile f(ref);
+    uint64_t ref_bases = 0;
     while (f.next()) {
-      ck(ctx, mm_seqset_add(contigs, f.seq.data(), (int64_t)f.seq.size()), "add contig");
-      cname.push_back(f.name); clen.push_back((int)f.seq.size());
-      if (maxMem) cseq.push_back(f.seq);
+      cname.push_back(f.name); clen.push_back((int)f.seq.size()); ref_bases += f.seq.size();
+      if (maxMem) { cseq.push_back(f.seq); ck(ctx, mm_seqset_add_view(contigs, cseq.back().data(), (int64_t)cseq.back().size()), "add contig"); }
+      else ck(ctx, mm_seqset_add(contigs, f.seq.data(), (int64_t)f.seq.size()), "add contig");
     }
     pc.lap("1 reference parse");
-    ck(ctx, mm_seqset_upload(contigs), "upload reference");
-    pc.lap("2 reference pack+upload");
-    mm_index* whole; ck(ctx, mm_index_build(ctx, contigs, k, w, &whole), "index");
-    pc.lap("3 index build");
+    if (maxMem && !stream_chunks && (double)ref_bases * INDEX_BYTES_PER_BASE * 1.2 > 0.8 * (double)hbm_free) {
+      stream_chunks = true;
+      std::cout << "INFO, the index of " << ref_bases << " reference bases does not fit the device's " << (hbm_free >> 30) << " GiB: chunk indexes are built and mapped one after the other\n";
+    }
     std::vector<int32_t> first(1, 0);
-    if (maxMem) {
-      int32_t n = 0;
-      ck(ctx, mm_index_plan_chunks(ctx, whole, maxMem, nullptr, 0, &n), "chunk plan");
-      first.resize((size_t)n);
-      ck(ctx, mm_index_plan_chunks(ctx, whole, maxMem, first.data(), n, &n), "chunk plan");
+    mm_index* whole = nullptr;
+    if (!stream_chunks) {
+      ck(ctx, mm_seqset_upload(contigs), "upload reference");
+      pc.lap("2 reference pack+upload");
+      ck(ctx, mm_index_build(ctx, contigs, k, w, &whole), "index");
+      pc.lap("3 index build");
+      if (maxMem) {
+        int32_t n = 0;
+        ck(ctx, mm_index_plan_chunks(ctx, whole, maxMem, nullptr, 0, &n), "chunk plan");
+        first.resize((size_t)n);
+        ck(ctx, mm_index_plan_chunks(ctx, whole, maxMem, first.data(), n, &n), "chunk plan");
+      }
+    } else {
+      // The chunk rule without an index of the whole reference: it decides to close a chunk from the chunk's own content
+      // and the next contig only, so it can be evaluated on the index of a contig range that fits the device.  Every cut
+      // inside the range is final; the range's last chunk is not (it may go on), so the next range starts there.
+      if (!maxMem) die("--stream-chunks needs --maxmemory (the chunk rule of the reference, winSketch.hpp:274-329)");
+      mm_seqset_destroy(contigs); contigs = nullptr;
+      const int C = (int)cname.size();
+      uint64_t range_bases = o.v.count("stream-range-bases") ? std::stoull(o.v.at("stream-range-bases")) : (uint64_t)(0.5 * (double)hbm_free / INDEX_BYTES_PER_BASE);
+      int c0 = 0;
+      while (c0 < C) {
+        int c1 = c0; uint64_t bases = 0;
+        while (c1 < C && (bases < range_bases || c1 == c0)) bases += (uint64_t)clen[(size_t)c1++];
+        mm_seqset* part = make_part(c0, c1);
+        mm_index* ri; ck(ctx, mm_index_build(ctx, part, k, w, &ri), "index (chunk planning range)");
+        mm_seqset_destroy(part);
+        int32_t n = 0;
+        ck(ctx, mm_index_plan_chunks(ctx, ri, maxMem, nullptr, 0, &n), "chunk plan");
+        std::vector<int32_t> loc((size_t)n);
+        ck(ctx, mm_index_plan_chunks(ctx, ri, maxMem, loc.data(), n, &n), "chunk plan");
+        mm_index_destroy(ri);
+        if (n == 1 && c1 < C) {                                   // the chunk that starts at c0 is longer than the range
+          if ((double)bases * 2 * INDEX_BYTES_PER_BASE > 0.8 * (double)hbm_free && !o.v.count("stream-range-bases"))
+            die("--maxmemory describes index chunks larger than this device can hold one at a time");
+          range_bases = bases * 2; continue;
+        }
+        for (int32_t j = 1; j < n; ++j) first.push_back(c0 + loc[(size_t)j]);
+        if (c1 == C) break;
+        c0 += loc[(size_t)n - 1];
+      }
+      pc.lap("3 index build");
     }
     std::vector<std::string> chunk_files;
     if (only_index) { std::ofstream flag(ipre + ".index"); if (!flag.is_open()) die("Cannot open " + ipre + ".index"); flag << 0 << "\n"; }   // mapWrap.h:363-366
-    if (first.size() == 1) {
+    if (first.size() == 1 && !stream_chunks) {
       if (only_index) { chunk_files.push_back(ipre + ".1.seqset"); ck(ctx, mm_seqset_save(contigs, chunk_files.back().c_str()), "store index chunk"); }
-      chunks.push_back(Chunk{0, (int)cname.size(), whole});
+      chunks.push_back(Chunk{0, (int)cname.size(), whole, ""});
     } else {
-      mm_index_destroy(whole);
+      if (whole) mm_index_destroy(whole);
       for (size_t c = 0; c < first.size(); ++c) {
         const int a = first[c], b = c + 1 < first.size() ? first[c + 1] : (int)cname.size();
-        mm_seqset* part; ck(ctx, mm_seqset_create(ctx, &part), "seqset");
-        for (int i = a; i < b; ++i) ck(ctx, mm_seqset_add(part, cseq[(size_t)i].data(), (int64_t)cseq[(size_t)i].size()), "add contig");
-        ck(ctx, mm_seqset_upload(part), "upload reference chunk");
         mm_index* idx = nullptr;
-        if (only_index) { chunk_files.push_back(ipre + "." + std::to_string(c + 1) + ".seqset"); ck(ctx, mm_seqset_save(part, chunk_files.back().c_str()), "store index chunk"); }
-        else ck(ctx, mm_index_build(ctx, part, k, w, &idx), "index chunk");
-        mm_seqset_destroy(part);
-        chunks.push_back(Chunk{a, b - a, idx});
+        if (only_index || !stream_chunks) {
+          mm_seqset* part = make_part(a, b);
+          if (only_index) { chunk_files.push_back(ipre + "." + std::to_string(c + 1) + ".seqset"); ck(ctx, mm_seqset_save(part, chunk_files.back().c_str()), "store index chunk"); }
+          else ck(ctx, mm_index_build(ctx, part, k, w, &idx), "index chunk");
+          mm_seqset_destroy(part);
+        }
+        chunks.push_back(Chunk{a, b - a, idx, ""});
       }
     }
-    mm_seqset_destroy(contigs);
+    if (contigs) mm_seqset_destroy(contigs);
+    if (!stream_chunks) cseq.clear();
     if (only_index) {
       for (auto& ch : chunks) if (ch.idx) mm_index_destroy(ch.idx);
       std::ofstream args(ipre + ".arguments");
@@ -273,68 +327,74 @@ int map_mode(const Options& o, const std::string& mode) {
     std::ifstream cf(ipre + ".contigs");
     if (!cf.is_open()) die("Cannot open " + ipre + ".contigs");
     std::vector<int> chunk_of; std::string line;
+    uint64_t ref_bases = 0;
     while (std::getline(cf, line)) {
       auto fl = split(line, "\t");
       if (fl.size() != 3) die("Weird line in " + ipre + ".contigs");
-      cname.push_back(fl[0]); clen.push_back(std::stoi(fl[1])); chunk_of.push_back(std::stoi(fl[2]));
+      cname.push_back(fl[0]); clen.push_back(std::stoi(fl[1])); chunk_of.push_back(std::stoi(fl[2])); ref_bases += (uint64_t)clen.back();
+    }
+    if (!stream_chunks && chunk_files.size() > 1 && (double)ref_bases * INDEX_BYTES_PER_BASE * 1.2 > 0.8 * (double)hbm_free) {
+      stream_chunks = true;
+      std::cout << "INFO, the index of " << ref_bases << " reference bases does not fit the device's " << (hbm_free >> 30) << " GiB: chunk indexes are built and mapped one after the other\n";
     }
     for (size_t c = 0; c < chunk_files.size(); ++c) {
-      mm_seqset* part; ck(ctx, mm_seqset_load(ctx, chunk_files[c].c_str(), &part), "load index chunk");
       int first = -1, count = 0;
       for (size_t i = 0; i < chunk_of.size(); ++i) if (chunk_of[i] == (int)c + 1) { if (first < 0) first = (int)i; ++count; }
-      if ((int64_t)count != mm_seqset_count(part)) die("Index chunk " + chunk_files[c] + " does not match " + ipre + ".contigs");
-      mm_index* idx; ck(ctx, mm_index_build(ctx, part, k, w, &idx), "index chunk");
+      chunks.push_back(Chunk{first < 0 ? 0 : first, count, nullptr, chunk_files[c]});
+    }
+  }
+  // Builds the index of chunk c if it is not resident yet and sets its freqThreshold from the histogram accumulated
+  // over the chunks so far (never cleared, winSketch.hpp:452-494): call once per chunk, in chunk order.
+  std::map<int64_t, int64_t> thr_acc; int thr = INT_MAX;
+  auto prepare_chunk = [&](size_t c) {
+    Chunk& ch = chunks[c];
+    if (!ch.idx) {
+      mm_seqset* part;
+      if (!ch.file.empty()) {
+        ck(ctx, mm_seqset_load(ctx, ch.file.c_str(), &part), "load index chunk");
+        if ((int64_t)ch.count != mm_seqset_count(part)) die("Index chunk " + ch.file + " does not match " + ipre + ".contigs");
+      } else part = make_part(ch.first, ch.first + ch.count);
+      ck(ctx, mm_index_build(ctx, part, k, w, &ch.idx), "index chunk");
       mm_seqset_destroy(part);
-      chunks.push_back(Chunk{first < 0 ? 0 : first, count, idx});
     }
-  }
-  {
-    // freqThreshold per chunk from the histogram accumulated over the chunks so far (never cleared, winSketch.hpp:452-494)
-    std::map<int64_t, int64_t> acc; int thr = INT_MAX;
-    for (size_t c = 0; c < chunks.size(); ++c) {
-      int64_t n = 0; mm_index_freq_hist(chunks[c].idx, nullptr, nullptr, 0, &n);
-      std::vector<int64_t> cc((size_t)n), hh((size_t)n); mm_index_freq_hist(chunks[c].idx, cc.data(), hh.data(), n, &n);
-      for (int64_t i = 0; i < n; ++i) acc[cc[(size_t)i]] += hh[(size_t)i];
-      mm_index_info info; mm_index_get_info(chunks[c].idx, &info);
-      if (info.n_unique_hashes > 0) {
-        std::vector<int64_t> ac, ah; for (auto& kv : acc) { ac.push_back(kv.first); ah.push_back(kv.second); }
-        thr = mm_freq_threshold_from_hist(ac.data(), ah.data(), (int64_t)ac.size(), info.n_unique_hashes, thr);
-      }
-      mm_index_set_freq_threshold(chunks[c].idx, thr);
-      std::cout << "INFO, index chunk " << c + 1 << "/" << chunks.size() << ": contigs " << chunks[c].first << ".." << chunks[c].first + chunks[c].count - 1
-                << ", " << info.n_entries << " minimizers, " << info.n_unique_hashes << " unique hashes\n";
+    int64_t n = 0; mm_index_freq_hist(ch.idx, nullptr, nullptr, 0, &n);
+    std::vector<int64_t> cc((size_t)n), hh((size_t)n); mm_index_freq_hist(ch.idx, cc.data(), hh.data(), n, &n);
+    for (int64_t i = 0; i < n; ++i) thr_acc[cc[(size_t)i]] += hh[(size_t)i];
+    mm_index_info info; mm_index_get_info(ch.idx, &info);
+    if (info.n_unique_hashes > 0) {
+      std::vector<int64_t> ac, ah; for (auto& kv : thr_acc) { ac.push_back(kv.first); ah.push_back(kv.second); }
+      thr = mm_freq_threshold_from_hist(ac.data(), ah.data(), (int64_t)ac.size(), info.n_unique_hashes, thr);
     }
-  }
+    mm_index_set_freq_threshold(ch.idx, thr);
+    std::cout << "INFO, index chunk " << c + 1 << "/" << chunks.size() << ": contigs " << ch.first << ".." << ch.first + ch.count - 1
+              << ", " << info.n_entries << " minimizers, " << info.n_unique_hashes << " unique hashes\n";
+  };
+  if (!stream_chunks) for (size_t c = 0; c < chunks.size(); ++c) prepare_chunk(c);
   // ---- reads, batch by batch (computeMap.hpp:104-172 + unifyFiles mapWrap.h:34-213)
   const int64_t BATCH_READS = 100000, BATCH_BASES = 256000000LL;   // ~0.25 Gbp per device batch (16 ms of mapping); the next ones are parsed meanwhile
-  for (size_t fi = 0; fi < queries.size(); ++fi) {
-    const std::string& prefix = prefixes[fi];
-    std::ofstream out(prefix), unm(prefix + ".meta.unmappedReadsLengths");
-    if (!out.is_open()) die("Cannot open output file " + prefix);
-    size_t total = 0, tooShort = 0, mapped = 0, notMapped = 0;
-    std::set<std::string> seen;
-    // a reader thread parses the next batches (bounded queue) while this thread packs, maps and writes the current one
-    // A batch keeps its sequences back to back in one arena (huge pages when the system grants them) that is handed to
-    // the library by reference (mm_seqset_add_view) and recycled: no allocation, copy or page fault per read.
-    struct Batch {
-      std::vector<std::string> names; std::vector<int> lens; std::vector<size_t> off;
-      char* arena = nullptr; size_t cap = 0, used = 0;
-      ~Batch() { free(arena); }
-      void reserve(size_t want) {
-        if (want <= cap) return;
-        const size_t HP = (size_t)2 << 20, ncap = (std::max(want, cap + cap / 2) + HP - 1) / HP * HP;
-        char* na = (char*)aligned_alloc(HP, ncap);
-        if (!na) die("out of host memory for the read batch");
-        madvise(na, ncap, MADV_HUGEPAGE);
-        if (used) memcpy(na, arena, used);
-        free(arena); arena = na; cap = ncap;
-      }
-      void put(const std::string& q) { reserve(used + q.size() + 1); memcpy(arena + used, q.data(), q.size()); off.push_back(used); used += q.size(); }
-      void reset() { names.clear(); lens.clear(); off.clear(); used = 0; }
-    };
+  // A batch keeps its sequences back to back in one arena (huge pages when the system grants them) that is handed to
+  // the library by reference (mm_seqset_add_view) and recycled: no allocation, copy or page fault per read.
+  struct Batch {
+    std::vector<std::string> names; std::vector<int> lens; std::vector<size_t> off;
+    char* arena = nullptr; size_t cap = 0, used = 0;
+    ~Batch() { free(arena); }
+    void reserve(size_t want) {
+      if (want <= cap) return;
+      const size_t HP = (size_t)2 << 20, ncap = (std::max(want, cap + cap / 2) + HP - 1) / HP * HP;
+      char* na = (char*)aligned_alloc(HP, ncap);
+      if (!na) die("out of host memory for the read batch");
+      madvise(na, ncap, MADV_HUGEPAGE);
+      if (used) memcpy(na, arena, used);
+      free(arena); arena = na; cap = ncap;
+    }
+    void put(const std::string& q) { reserve(used + q.size() + 1); memcpy(arena + used, q.data(), q.size()); off.push_back(used); used += q.size(); }
+    void reset() { names.clear(); lens.clear(); off.clear(); used = 0; }
+  };
+  // a reader thread parses the next batches of one query file (bounded queue) while the caller handles the current one
+  auto for_each_batch = [&](const std::string& query, const std::function<void(Batch&)>& handle) {
     std::mutex qm; std::condition_variable qcv; std::deque<std::unique_ptr<Batch>> queue; std::vector<std::unique_ptr<Batch>> spare; bool reader_done = false;
     std::thread reader([&]() {
-      SeqFile f(queries[fi]);
+      SeqFile f(query);
       bool more = true;
       while (more) {
         std::unique_ptr<Batch> b;
@@ -365,65 +425,119 @@ int map_mode(const Options& o, const std::string& mode) {
         bt = std::move(queue.front()); queue.pop_front();
         qcv.notify_all();
       }
-      std::vector<std::string>& names = bt->names; std::vector<int>& lens = bt->lens;
-      mm_seqset* reads; ck(ctx, mm_seqset_create(ctx, &reads), "seqset");
-      for (size_t r = 0; r < names.size(); ++r) ck(ctx, mm_seqset_add_view(reads, bt->arena + bt->off[r], (int64_t)lens[r]), "add read");
-      pc.lap("4 reads parse");
-      ck(ctx, mm_seqset_upload(reads), "upload reads");
-      pc.lap("5 reads pack+upload");
-      mm_map_params mp{k, w, pi, minLen};
-      std::vector<mm_mapping*> parts; std::vector<int32_t> base;
-      for (auto& ch : chunks) {                                   // one "PREFIX.N" per chunk in the reference (mapWrap.h:419-437)
-        mm_mapping* pm; ck(ctx, mm_map_batch(ctx, ch.idx, reads, &mp, &pm), "map");
-        if (!o.all) ck(ctx, mm_mapping_keep_best(ctx, pm, k), "best mappings");
-        parts.push_back(pm); base.push_back(ch.first);
-      }
-      mm_mapping* m = parts[0];
-      if (parts.size() > 1) {                                     // unifyFiles: read-wise concatenation in chunk order
-        ck(ctx, mm_mapping_concat(ctx, parts.data(), base.data(), (int)parts.size(), &m), "merge chunks");
-        for (auto* pm : parts) mm_mapping_destroy(pm);
-      }
-      ck(ctx, mm_mapping_add_qualities(ctx, m, reads, k), "mapping qualities");
-      std::vector<int64_t> off(names.size() + 1);
-      ck(ctx, mm_mapping_fetch(m, off.data(), nullptr, 0), "fetch");
-      std::vector<mm_map_record> rec((size_t)off.back());
-      ck(ctx, mm_mapping_fetch(m, off.data(), rec.data(), (int64_t)rec.size()), "fetch");
-      pc.lap("6 map+mapq+fetch");
-      for (size_t r = 0; r < names.size(); ++r) {
-        ++total;
-        const int len = lens[r];
-        if (len < w || len < k || len < minLen) { ++tooShort; continue; }
-        if (!seen.insert(names[r]).second) die("Seems that read ID " + names[r] + " has already been processed");   // mapWrap.h:71-75
-        if (off[r] == off[r + 1]) { ++notMapped; unm << len << "\t" << names[r] << "\n"; continue; }
-        ++mapped;
-        for (int64_t i = off[r]; i < off[r + 1]; ++i) {
-          const mm_map_record& x = rec[(size_t)i];
-          float id; mm_identity(x.shared, x.sketch, k, &id, nullptr);
-          std::ostringstream ln;                                  // computeMap.hpp:565-581
-          ln << names[r] << " " << len << " " << "0" << " " << len - 1 << " " << (x.strand == 1 ? "+" : "-") << " "
-             << cname[(size_t)x.ref_contig] << " " << clen[(size_t)x.ref_contig] << " " << x.ref_start << " " << x.ref_start + len - 1 << " ";
-          std::ostringstream ids; ids << id;                      // printed, then re-parsed (mapWrap.h:237)
-          ln << ids.str() << " " << x.shared << " " << x.sketch;
-          const double reported = std::stod(ids.str()) / 100.0;
-          const float corrected = std::exp(-(1 - reported));      // mapWrap.h:311
-          ln << " " << corrected * 100 << " " << x.mapq << "\n";  // :318-320
-          out << ln.str();
-        }
-      }
-      mm_mapping_destroy(m); mm_seqset_destroy(reads);
+      handle(*bt);
       bt->reset();
       { std::lock_guard<std::mutex> lk(qm); spare.push_back(std::move(bt)); }
-      pc.lap("7 format+write");
     }
-    std::ofstream meta(prefix + ".meta");                        // mapWrap.h:178-184
-    meta << "TotalReads " << total << "\nReadsTooShort " << tooShort << "\nReadsMapped " << mapped << "\nReadsNotMapped " << notMapped << "\n";
-    std::ofstream ps(prefix + ".parameters");                    // mapWrap.h:196-211
+  };
+  auto upload_batch = [&](Batch& bt) {
+    mm_seqset* reads; ck(ctx, mm_seqset_create(ctx, &reads), "seqset");
+    for (size_t r = 0; r < bt.names.size(); ++r) ck(ctx, mm_seqset_add_view(reads, bt.arena + bt.off[r], (int64_t)bt.lens[r]), "add read");
+    pc.lap("4 reads parse");
+    ck(ctx, mm_seqset_upload(reads), "upload reads");
+    pc.lap("5 reads pack+upload");
+    return reads;
+  };
+  const mm_map_params mp{k, w, pi, minLen};
+  auto map_chunk = [&](const Chunk& ch, mm_seqset* reads) {     // one "PREFIX.N" per chunk in the reference (mapWrap.h:419-437)
+    mm_mapping* pm; ck(ctx, mm_map_batch(ctx, ch.idx, reads, &mp, &pm), "map");
+    if (!o.all) ck(ctx, mm_mapping_keep_best(ctx, pm, k), "best mappings");
+    return pm;
+  };
+  // the output files of one query file (mapWrap.h:34-213)
+  struct FileOut {
+    std::string prefix; std::ofstream out, unm; size_t total = 0, tooShort = 0, mapped = 0, notMapped = 0; std::set<std::string> seen;
+    explicit FileOut(const std::string& p) : prefix(p), out(p), unm(p + ".meta.unmappedReadsLengths") { if (!out.is_open()) die("Cannot open output file " + p); }
+  };
+  // unifyFiles + mapping qualities + text for one batch; consumes `parts`
+  auto finish_batch = [&](FileOut& F, const std::vector<std::string>& names, const std::vector<int>& lens, mm_seqset* reads, std::vector<mm_mapping*>& parts) {
+    std::vector<int32_t> base; for (auto& ch : chunks) base.push_back(ch.first);
+    mm_mapping* m = parts[0];
+    if (parts.size() > 1) {                                       // unifyFiles: read-wise concatenation in chunk order
+      ck(ctx, mm_mapping_concat(ctx, parts.data(), base.data(), (int)parts.size(), &m), "merge chunks");
+      for (auto* pm : parts) mm_mapping_destroy(pm);
+    }
+    parts.clear();
+    ck(ctx, mm_mapping_add_qualities(ctx, m, reads, k), "mapping qualities");
+    std::vector<int64_t> off(names.size() + 1);
+    ck(ctx, mm_mapping_fetch(m, off.data(), nullptr, 0), "fetch");
+    std::vector<mm_map_record> rec((size_t)off.back());
+    ck(ctx, mm_mapping_fetch(m, off.data(), rec.data(), (int64_t)rec.size()), "fetch");
+    pc.lap("6 map+mapq+fetch");
+    for (size_t r = 0; r < names.size(); ++r) {
+      ++F.total;
+      const int len = lens[r];
+      if (len < w || len < k || len < minLen) { ++F.tooShort; continue; }
+      if (!F.seen.insert(names[r]).second) die("Seems that read ID " + names[r] + " has already been processed");   // mapWrap.h:71-75
+      if (off[r] == off[r + 1]) { ++F.notMapped; F.unm << len << "\t" << names[r] << "\n"; continue; }
+      ++F.mapped;
+      for (int64_t i = off[r]; i < off[r + 1]; ++i) {
+        const mm_map_record& x = rec[(size_t)i];
+        float id; mm_identity(x.shared, x.sketch, k, &id, nullptr);
+        std::ostringstream ln;                                    // computeMap.hpp:565-581
+        ln << names[r] << " " << len << " " << "0" << " " << len - 1 << " " << (x.strand == 1 ? "+" : "-") << " "
+           << cname[(size_t)x.ref_contig] << " " << clen[(size_t)x.ref_contig] << " " << x.ref_start << " " << x.ref_start + len - 1 << " ";
+        std::ostringstream ids; ids << id;                        // printed, then re-parsed (mapWrap.h:237)
+        ln << ids.str() << " " << x.shared << " " << x.sketch;
+        const double reported = std::stod(ids.str()) / 100.0;
+        const float corrected = std::exp(-(1 - reported));        // mapWrap.h:311
+        ln << " " << corrected * 100 << " " << x.mapq << "\n";    // :318-320
+        F.out << ln.str();
+      }
+    }
+    mm_mapping_destroy(m);
+    pc.lap("7 format+write");
+  };
+  auto finish_file = [&](FileOut& F, const std::string& query) {
+    std::ofstream meta(F.prefix + ".meta");                      // mapWrap.h:178-184
+    meta << "TotalReads " << F.total << "\nReadsTooShort " << F.tooShort << "\nReadsMapped " << F.mapped << "\nReadsNotMapped " << F.notMapped << "\n";
+    std::ofstream ps(F.prefix + ".parameters");                  // mapWrap.h:196-211
     ps << "kmerSize " << k << "\nwindowSize " << w << "\nminReadLength " << minLen << "\nalphabetSize " << 4 << "\nreferenceSize " << refSize
-       << "\npercentageIdentity " << pi << "\np_value " << pval << "\nrefSequences [" << ref << "]\nquerySequences [" << queries[fi]
-       << "]\noutFileName " << prefix << "\nreportAll " << o.all << "\nindex " << "" << "\nmaximumMemory " << maxMem << "\n";
-    std::cout << "INFO, [count of mapped reads, reads qualified for mapping, total input reads] = [" << mapped << ", " << total - tooShort << ", " << total << "]\n";
+       << "\npercentageIdentity " << pi << "\np_value " << pval << "\nrefSequences [" << ref << "]\nquerySequences [" << query
+       << "]\noutFileName " << F.prefix << "\nreportAll " << o.all << "\nindex " << "" << "\nmaximumMemory " << maxMem << "\n";
+    std::cout << "INFO, [count of mapped reads, reads qualified for mapping, total input reads] = [" << F.mapped << ", " << F.total - F.tooShort << ", " << F.total << "]\n";
+  };
+  if (!stream_chunks) {
+    for (size_t fi = 0; fi < queries.size(); ++fi) {
+      FileOut F(prefixes[fi]);
+      for_each_batch(queries[fi], [&](Batch& bt) {
+        mm_seqset* reads = upload_batch(bt);
+        std::vector<mm_mapping*> parts;
+        for (auto& ch : chunks) parts.push_back(map_chunk(ch, reads));
+        finish_batch(F, bt.names, bt.lens, reads, parts);
+        mm_seqset_destroy(reads);
+      });
+      finish_file(F, queries[fi]);
+    }
+  } else {
+    // Chunks that do not fit HBM together (mapWrap.h:417-437 does the same with files): every read batch is packed and
+    // kept on the device (2 bits per base), then one chunk index at a time is built, every batch is mapped against it
+    // and only the records of that pass are kept; the merge, the mapping qualities and the text follow at the end.
+    struct Held { size_t file; std::vector<std::string> names; std::vector<int> lens; mm_seqset* reads; std::vector<mm_mapping*> parts; };
+    std::vector<Held> held;
+    for (size_t fi = 0; fi < queries.size(); ++fi)
+      for_each_batch(queries[fi], [&](Batch& bt) { held.push_back(Held{fi, bt.names, bt.lens, upload_batch(bt), {}}); });
+    for (size_t c = 0; c < chunks.size(); ++c) {
+      prepare_chunk(c);
+      for (auto& h : held) {
+        mm_mapping* pm = map_chunk(chunks[c], h.reads);
+        ck(ctx, mm_mapping_release_intermediates(pm), "trim batch result");
+        h.parts.push_back(pm);
+      }
+      mm_index_destroy(chunks[c].idx); chunks[c].idx = nullptr;
+      pc.lap("6 map+mapq+fetch");
+    }
+    size_t hi = 0;
+    for (size_t fi = 0; fi < queries.size(); ++fi) {
+      FileOut F(prefixes[fi]);
+      for (; hi < held.size() && held[hi].file == fi; ++hi) {
+        finish_batch(F, held[hi].names, held[hi].lens, held[hi].reads, held[hi].parts);
+        mm_seqset_destroy(held[hi].reads);
+      }
+      finish_file(F, queries[fi]);
+    }
   }
-  for (auto& ch : chunks) mm_index_destroy(ch.idx);
+  for (auto& ch : chunks) if (ch.idx) mm_index_destroy(ch.idx);
   mm_ctx_destroy(ctx);
   return 0;
 }

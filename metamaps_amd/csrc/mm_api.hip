@@ -269,6 +269,19 @@ int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const
   });
 }
 void mm_mapping_destroy(mm_mapping* m) { if (m) { mm::current_stream() = m->ctx->stream; mm::current_alloc() = &m->ctx->alloc; delete m; } }
+int mm_mapping_release_intermediates(mm_mapping* m) {
+  if (!m) return MM_ERR_ARG;
+  return guarded(m->ctx, [&] {
+    MM_HIP(hipSetDevice(m->ctx->device));
+    m->mz = mm::MinimizerSet{};
+    m->sk_hash.release(); m->sk_strand.release(); m->sk_n.release(); m->amb.release();
+    m->min_hits.release(); m->accept_min.release();
+    m->read_hit_off.release(); m->hits.release(); m->cand_off.release(); m->cand.release(); m->cand_read.release(); m->l2.release();
+    std::vector<int32_t>().swap(m->h_sk_n); std::vector<int32_t>().swap(m->h_min_hits);
+    std::vector<uint64_t>().swap(m->h_read_hit_off); std::vector<uint64_t>().swap(m->h_cand_off);
+    m->n_cand = 0; m->released = true;
+  });
+}
 int mm_mapping_get_stats(const mm_mapping* m, mm_map_stats* out) {
   if (!m || !out) return MM_ERR_ARG;
   *out = m->stats;
@@ -368,6 +381,7 @@ int mm_mapping_keep_best(mm_ctx* ctx, mm_mapping* m, int k) {
 }
 
 int mm_debug_sketch(mm_mapping* m, int64_t* offsets, uint32_t* hash, int32_t* strand, int64_t cap) {
+  if (m && m->released) return MM_ERR_STATE;
   if (!m) return MM_ERR_ARG;
   return guarded(m->ctx, [&] {
     hipStream_t st = m->ctx->stream;
@@ -387,6 +401,7 @@ int mm_debug_sketch(mm_mapping* m, int64_t* offsets, uint32_t* hash, int32_t* st
   });
 }
 int mm_debug_hits(mm_mapping* m, int64_t* offsets, int32_t* contig, int32_t* wpos, int64_t cap) {
+  if (m && m->released) return MM_ERR_STATE;
   if (!m) return MM_ERR_ARG;
   return guarded(m->ctx, [&] {
     const int64_t tot = (int64_t)m->h_read_hit_off[(size_t)m->n_reads];
@@ -401,6 +416,7 @@ int mm_debug_hits(mm_mapping* m, int64_t* offsets, int32_t* contig, int32_t* wpo
   });
 }
 int mm_debug_candidates(mm_mapping* m, int64_t* offsets, int32_t* triples, int64_t cap) {
+  if (m && m->released) return MM_ERR_STATE;
   if (!m) return MM_ERR_ARG;
   return guarded(m->ctx, [&] {
     if (offsets) for (size_t i = 0; i < m->h_cand_off.size(); ++i) offsets[i] = (int64_t)m->h_cand_off[i];
@@ -411,6 +427,7 @@ int mm_debug_candidates(mm_mapping* m, int64_t* offsets, int32_t* triples, int64
   });
 }
 int mm_debug_l2(mm_mapping* m, int64_t* per_cand, int64_t cap) {
+  if (m && m->released) return MM_ERR_STATE;
   if (!m || !per_cand) return MM_ERR_ARG;
   return guarded(m->ctx, [&] {
     MM_REQUIRE(cap >= m->n_cand, MM_ERR_ARG, "output capacity too small");
@@ -422,6 +439,7 @@ int mm_debug_l2(mm_mapping* m, int64_t* per_cand, int64_t cap) {
   });
 }
 int mm_debug_min_hits(mm_mapping* m, int32_t* min_hits) {
+  if (m && m->released) return MM_ERR_STATE;
   if (!m || !min_hits) return MM_ERR_ARG;
   memcpy(min_hits, m->h_min_hits.data(), m->h_min_hits.size() * sizeof(int32_t));
   return MM_OK;

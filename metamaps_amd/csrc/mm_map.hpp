@@ -44,6 +44,7 @@ struct mm_mapping {
   mm::DBuf<uint64_t> rec_off;                // [n+1]
   std::vector<uint64_t> h_rec_off;
   bool has_mapq = false;
+  bool released = false;                     // mm_mapping_release_intermediates: only the records are left
 };
 
 namespace mm {

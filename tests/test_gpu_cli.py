@@ -75,7 +75,7 @@ def _cmp_unknown_species(pa, pb, expect_tests=True):
         assert any(r[6] != "NA" for r in rows_a[1:]) and any(r[12] not in ("NA", "1") for r in rows_a[1:])
 
 
-def _run_pair(tmp_path, extra, n_reads=200):
+def _run_pair(tmp_path, extra, n_reads=200, gpu_only=()):
     import json
     import orc
     from metamaps_amd import synth
@@ -84,7 +84,8 @@ def _run_pair(tmp_path, extra, n_reads=200):
     pa, pb = str(tmp_path / "gpu"), str(tmp_path / "cpu")
     info = {}
     for exe, pre in ((CLI, pa), (orc.CLI, pb)):
-        p = subprocess.run([exe, "mapDirectly", "-r", db.fasta, "-q", rd["path"], "-o", pre] + extra, check=True, capture_output=True, timeout=900)
+        p = subprocess.run([exe, "mapDirectly", "-r", db.fasta, "-q", rd["path"], "-o", pre] + extra + (list(gpu_only) if exe == CLI else []),
+                           check=True, capture_output=True, timeout=900)
         info[pre] = p
     n_gpu_chunks = sum(1 for l in info[pa].stdout.decode().splitlines() if l.startswith("INFO, index chunk"))
     n_cpu_chunks = json.loads(info[pb].stderr.decode().strip().splitlines()[-1])["chunks"]
@@ -204,3 +205,37 @@ def test_cli_parameter_sweep_matches_oracle(oracle_lib, tmp_path, case):
     _cmp_table(pa + ".EM.contigCoverage", pb + ".EM.contigCoverage", "\t", {6})
     _cmp_unknown_species(pa, pb, expect_tests=False)
     assert sum(1 for _ in open(pa)) > 30
+
+
+@pytest.mark.parametrize("limit,range_bases,all_flag", [(1_000_000, 100_000, ["--all"]), (1_000_000, 30_000, []), (2_000_000, 10_000_000, ["--all"]), (4_000_000, 150_000, ["--all"])])
+def test_cli_stream_chunks(oracle_lib, tmp_path, limit, range_bases, all_flag):
+    """references whose chunk indexes do not fit HBM together (BASELINE config 5): --stream-chunks keeps one chunk index
+    on the device at a time (all read batches are mapped against it, only the records are kept) and evaluates the chunk
+    rule on contig ranges instead of an index of the whole reference; `--stream-range-bases` makes the ranges tiny here
+    (smaller than a chunk, so that the range has to grow; several chunks per range; everything in one range).
+    Same files as the oracle under the same --maxmemory, and as `index` + `mapAgainstIndex --stream-chunks`."""
+    opts = all_flag + ["--maxmemory-bytes", str(limit)]
+    pa, g, c = _run_pair(tmp_path, opts, gpu_only=["--stream-chunks", "--stream-range-bases", str(range_bases)])
+    assert g == c and g >= 2, (g, c)
+    db_fa, reads = str(tmp_path / "db" / "DB.fa"), str(tmp_path / "reads.fq")
+    subprocess.run([CLI, "index", "-r", db_fa, "-i", str(tmp_path / "idx"), "--maxmemory-bytes", str(limit), "--stream-chunks", "--stream-range-bases", str(range_bases)],
+                   check=True, capture_output=True, timeout=900)
+    via = str(tmp_path / "via")
+    subprocess.run([CLI, "mapAgainstIndex", "-i", str(tmp_path / "idx"), "-q", reads, "-o", via, "--stream-chunks"] + all_flag, check=True, capture_output=True, timeout=900)
+    assert open(pa).read() == open(via).read()
+    assert open(pa + ".meta").read() == open(via + ".meta").read()
+
+
+def test_cli_stream_chunks_two_query_files(tmp_path):
+    """several query files share each chunk pass (mapWrap.h:417-430): same output as the resident mode"""
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=10, genome_len=60_000, seed=7)
+    r1 = synth.make_reads(db, str(tmp_path / "r1.fq"), n_reads=120, read_len=3000, seed=3)
+    r2 = synth.make_reads(db, str(tmp_path / "r2.fq"), n_reads=80, read_len=2500, seed=4)
+    outs = {}
+    for tag, extra in (("res", []), ("str", ["--stream-chunks", "--stream-range-bases", "120000"])):
+        o1, o2 = str(tmp_path / f"{tag}1"), str(tmp_path / f"{tag}2")
+        subprocess.run([CLI, "mapDirectly", "--all", "-r", db.fasta, "-q", r1["path"] + "," + r2["path"], "-o", o1 + "," + o2, "--maxmemory-bytes", "1000000"] + extra,
+                       check=True, capture_output=True, timeout=900)
+        outs[tag] = (open(o1).read(), open(o2).read(), open(o1 + ".meta").read(), open(o2 + ".meta").read())
+    assert outs["res"] == outs["str"] and len(outs["res"][0]) > 1000 and len(outs["res"][1]) > 1000

@@ -86,12 +86,18 @@ __global__ void padded_counts_kernel(const uint64_t* __restrict__ ustart, int64_
   }
 }
 // eight lanes per list: entry j of list u moves from occ[ustart[u] + j] to out[pstart[u] + j]
+// (also fills occ16[]: the filter's position bin of every entry, cbase[c] = first base of contig c in the concatenated reference)
 __global__ void __launch_bounds__(256) pad_lists_kernel(const uint64_t* __restrict__ occ, const uint64_t* __restrict__ ustart,
-                                                        const uint64_t* __restrict__ pstart, int64_t U, uint64_t* __restrict__ out) {
+                                                        const uint64_t* __restrict__ pstart, int64_t U, const uint64_t* __restrict__ cbase,
+                                                        uint64_t* __restrict__ out, uint16_t* __restrict__ out16) {
   const int sub = threadIdx.x & 7;
   for (int64_t u = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; u < U; u += ((int64_t)gridDim.x * blockDim.x) >> 3) {
     const uint64_t a = ustart[u], c = ustart[u + 1] - a, b = pstart[u];
-    for (uint64_t j = sub; j < c; j += 8) out[b + j] = occ[a + j];
+    for (uint64_t j = sub; j < c; j += 8) {
+      const uint64_t e = occ[a + j];
+      out[b + j] = e;
+      out16[b + j] = (uint16_t)(((cbase[e >> 32] + (uint64_t)pw_wpos((uint32_t)e)) >> HF_BIN_SHIFT) & (HF_SLOTS - 1));
+    }
   }
 }
 
@@ -168,7 +174,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   if (N == 0) {
     I->tab_bits = 8;
     I->tab.alloc((size_t)2 << I->tab_bits); I->tab.zero(st);
-    I->occ.alloc(1);
+    I->occ.alloc(1); I->occ16.alloc(16);
     MM_HIP(hipStreamSynchronize(st));
     return;
   }
@@ -279,8 +285,13 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
     uint64_t P = 0;
     MM_HIP(hipMemcpyAsync(&P, pstart.p + U, sizeof P, hipMemcpyDeviceToHost, st));
     MM_HIP(hipStreamSynchronize(st));
-    DBuf<uint64_t> padded((size_t)P + 2);                        // +2: the filter's 16-byte loads may read one pair past a list
-    pad_lists_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div((int64_t)U * 8, 256), 1 << 20)), dim3(256), 0, st>>>(I->occ.p, I->ustart.p, pstart.p, (int64_t)U, padded.p);
+    DBuf<uint64_t> padded((size_t)P + 2);
+    I->occ16.alloc((size_t)P + 16);
+    std::vector<uint64_t> h_cbase((size_t)I->n_contigs + 1, 0);
+    for (int64_t c = 0; c < I->n_contigs; ++c) h_cbase[(size_t)c + 1] = h_cbase[(size_t)c] + (uint64_t)I->contig_len[(size_t)c];
+    DBuf<uint64_t> d_cbase(h_cbase.size()); d_cbase.upload(h_cbase.data(), h_cbase.size(), st);
+    pad_lists_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div((int64_t)U * 8, 256), 1 << 20)), dim3(256), 0, st>>>(I->occ.p, I->ustart.p, pstart.p, (int64_t)U, d_cbase.p,
+                                                                                                               padded.p, I->occ16.p);
     MM_KERNEL_CHECK();
     MM_HIP(hipStreamSynchronize(st));
     I->occ = std::move(padded);

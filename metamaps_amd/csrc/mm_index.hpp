@@ -6,6 +6,8 @@
 //   occ[P]      occurrences grouped by hash, every group starting on a 64-byte boundary (padded to 8 entries)
 //                                                                 == minimizerPosLookupIndex      (:119)
 //               occ entry = contig<<32 | pw  (8 bytes, directly usable as an L1 seed hit / sort key)
+//   occ16[P]    per occ entry (same index) the 13-bit position bin the seed-hit filter counts in:
+//               ((first base of the contig in the concatenated reference + wpos) >> 13) & 8191
 //   tab[2*cap]  open-addressing table hash -> (count, first occ): slot = {count<<32 | hash, start}; one 64-byte
 //               line per lookup on average (uh[]/ustart[] CSR arrays only live during the build)
 #pragma once
@@ -24,29 +26,33 @@ struct mm_index {
   mm::DBuf<uint32_t> uh;
   mm::DBuf<uint64_t> ustart;
   mm::DBuf<uint64_t> occ;
+  mm::DBuf<uint16_t> occ16;
   mm::DBuf<uint64_t> tab;
   mm::DBuf<int32_t> d_contig_len;
   std::vector<int32_t> contig_len;
   std::vector<uint64_t> h_cstart;
   std::map<int64_t, int64_t> hist;           // occurrence count -> number of hashes (this chunk)
   int64_t hbm_bytes() const {
-    return (int64_t)(pos.bytes() + cstart.bytes() + uh.bytes() + ustart.bytes() + occ.bytes() + tab.bytes() + d_contig_len.bytes());
+    return (int64_t)(pos.bytes() + cstart.bytes() + uh.bytes() + ustart.bytes() + occ.bytes() + occ16.bytes() + tab.bytes() + d_contig_len.bytes());
   }
 };
 
 namespace mm {
 
+constexpr int HF_BIN_SHIFT = 13, HF_SLOTS = 8192;              // seed-hit filter: 8192-base position bins, counted modulo 8192 bins
+
 struct IndexView {
   const Rec* pos;
   const uint64_t* cstart;
   const uint64_t* occ;
+  const uint16_t* occ16;
   const uint64_t* tab;
   int64_t N, U;
   int tab_bits;
   int freq_threshold;
 };
 inline IndexView make_view(const mm_index* I) {
-  return IndexView{I->pos.p, I->cstart.p, I->occ.p, I->tab.p, I->N, I->U, I->tab_bits, I->freq_threshold};
+  return IndexView{I->pos.p, I->cstart.p, I->occ.p, I->occ16.p, I->tab.p, I->N, I->U, I->tab_bits, I->freq_threshold};
 }
 
 // Home slot of a hash: the first slot of a 4-slot bucket (4 x 16 B = one 64-byte sector), linear probing from there.  A lookup

@@ -225,21 +225,15 @@ __global__ void __launch_bounds__(256) gather_hits_kernel(IndexView I, const uin
 // K3c  exact seed-hit pre-filter.  At miniSeq+H density the 32-bit hash space is saturated:
 // a read draws ~10^4 chance hits scattered over the whole reference, and only hits that sit in a run of
 // `minimumHits` hits of one contig spanning less than the read length can ever produce or shape an L1
-// candidate (computeMap.hpp:357-385).  Such a run lies inside two adjacent position bins of width >= read
-// length, so a hit can be dropped when both bin pairs around it hold fewer than minimumHits hits.  Bin
-// counts live in a hashed LDS counter table (collisions only over-count, so nothing needed is lost).
-// Dropping hits that belong to no qualifying run leaves every qualifying run intact and cannot create a
-// new one (a run that qualifies after dropping also qualifies before, so none of its members was dropped).
+// candidate (computeMap.hpp:357-385).  Positions are binned in 8192-base bins of the concatenated reference; a
+// run shorter than the read touches at most nb = (len-1)/8192 + 2 consecutive bins, so a hit can be dropped when no
+// window of nb consecutive bins around it holds minimumHits hits.  Bins are counted modulo 8192 bins in LDS
+// (aliasing and contig borders only over-count, so nothing needed is lost).  Dropping hits that belong to no
+// qualifying run leaves every qualifying run intact and cannot create a new one (a run that qualifies after
+// dropping also qualifies before, so none of its members was dropped).
+// The bin of every index entry is precomputed (occ16[], 2 bytes per entry, same layout as occ[]): both passes
+// read a quarter of the list bytes, mostly one 64-byte sector per list, and only survivors touch occ[] itself.
 // ---------------------------------------------------------------------------------------------------
-constexpr int HF_SLOTS = 8192;
-constexpr int HF_BITS = 13;
-// bin(wpos) = floor(wpos * floor(2^32 / len) / 2^32): a monotone step function whose steps are at least `len` apart, so
-// two hits less than `len` apart still fall into the same or adjacent bins (all the proof needs) — one v_mul_hi instead of
-// an integer division.  The counter slot is the top bits of contig*K1 + bin*K2: the slots of bin-1 / bin+1 are one
-// addition away.
-constexpr uint32_t HF_K1 = 0x9E3779B1u, HF_K2 = 0x85EBCA77u;
-__device__ inline uint32_t hf_base(uint32_t contig, uint32_t bin) { return contig * HF_K1 + bin * HF_K2; }
-__device__ inline uint32_t hf_slot_of(uint32_t base) { return base >> (32 - HF_BITS); }
 // survivors are staged per read (8 B each, capacity 1024 + 2 x sketch size: stage_off); reads with more are re-filtered by the write kernel
 template <bool WRITE>
 __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint64_t* __restrict__ off, const int32_t* __restrict__ sk_n,
@@ -248,6 +242,7 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
                                                          uint32_t* __restrict__ surv_n, const uint64_t* __restrict__ read_hit_off,
                                                          uint64_t* __restrict__ hits, uint64_t* __restrict__ stage, const uint64_t* __restrict__ stage_off, int dbg) {
   __shared__ uint32_t cnt[HF_SLOTS];
+  __shared__ uint32_t good[HF_SLOTS / 32], alive[HF_SLOTS / 32];
   __shared__ uint32_t cursor;
   const int r = blockIdx.x;
   if (WRITE) {                                                   // staged reads only need a copy
@@ -261,87 +256,84 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   const uint64_t o = off[r];
   const int s = sk_n[r];
   const uint32_t len = (uint32_t)max(read_len[r], 1);
-  const uint32_t inv_len = len > 1 ? (uint32_t)(0x100000000ull / len) : 0xffffffffu;
+  const int nb = min((int)((len - 1) >> HF_BIN_SHIFT) + 2, HF_SLOTS);
   int m = min_hits[r]; if (m < 1) m = 1;
   for (int i = threadIdx.x; i < HF_SLOTS; i += 256) cnt[i] = 0;
   if (threadIdx.x == 0) cursor = 0;
   __syncthreads();
-  // One occurrence list per group of 4 lanes, 16 bytes per lane and load: a list (~17 entries at miniSeq+H density) is
-  // a few 64-byte requests, all in flight together.  The random-access rate of HBM is bound by requests, not bytes (tools/ubench/randread:
-  // 48 G requests/s whether they carry 8 or 64 bytes), so fewer, wider requests is what counts here.  Lists start at
-  // any 8-byte offset; reading starts at the even element below (occ[] is padded by two entries).
-  // A group's lists are software-pipelined (count/start and list data several lists ahead): without that every
-  // list costs two dependent memory latencies and the kernel waits instead of streaming.
+  // One occurrence list per group of 4 lanes, one 16-byte load (8 bin codes) per lane: a list of up to 32 entries is a
+  // single request of at most 64 bytes.  Random reads are bound by requests, not bytes (tools/ubench/randread), so the
+  // lists of a group are software-pipelined: count/start three lists ahead, codes two ahead.
   const int grp = threadIdx.x >> 2, sub = threadIdx.x & 3;
-  auto for_each_hit = [&](auto&& fn) {
+  auto for_each_hit = [&](auto&& fn) {                           // fn(bin code, index of the entry in occ[])
     auto meta = [&](int i, uint32_t& c, uint64_t& st0) { c = 0; st0 = 0; if (i < s) { c = probe_cnt[o + i]; st0 = probe_start[o + i]; } };
-    auto issue = [&](uint32_t c, uint64_t st0, ulonglong2 (&v)[4]) {   // the first 32 elements, counted from the even element at or below the start
-      const uint32_t skip = (uint32_t)(st0 & 1ull), tot = skip + c;
-      const ulonglong2* src = reinterpret_cast<const ulonglong2*>(I.occ + (st0 - skip));
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const uint32_t e = 2 * sub + 8 * q; if (c) v[q] = src[min(e, tot - 1) >> 1]; }
+    auto issue = [&](uint32_t c, uint64_t st0, uint32_t j0, ulonglong2& v) {   // codes j0 + 8*sub .. +7 (clamped into the padded list)
+      if (c) v = *reinterpret_cast<const ulonglong2*>(I.occ16 + st0 + min(j0 + 8u * sub, (c - 1) & ~7u));
     };
-    uint32_t c0, c1, c2; uint64_t s0, s1, s2;
-    ulonglong2 v0[4], v1[4];
-    meta(grp, c0, s0); meta(grp + 64, c1, s1);
-    issue(c0, s0, v0);
-    for (int i = grp; i < s; i += 64) {                          // (a third list in flight costs occupancy and is slower)
-      meta(i + 128, c2, s2);
-      issue(c1, s1, v1);
-      if (c0) {
-        const uint32_t skip = (uint32_t)(s0 & 1ull), tot = skip + c0;
+    auto consume = [&](uint32_t c, uint64_t st0, uint32_t j0, const ulonglong2& v) {
+      const uint32_t e0 = j0 + 8u * sub;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint32_t e = 2 * sub + 8 * q;
-          if (e >= skip && e < tot) fn(v0[q].x);
-          if (e + 1 < tot) fn(v0[q].y);
-        }
-        if (tot > 32) {                                           // long lists: the rest, 32 elements at a time
-          const ulonglong2* src = reinterpret_cast<const ulonglong2*>(I.occ + (s0 - skip));
-          for (uint32_t j0 = 32; j0 < tot; j0 += 32) {
-            ulonglong2 v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const uint32_t e = j0 + 2 * sub + 8 * q; v[q] = src[min(e, tot - 1) >> 1]; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const uint32_t e = j0 + 2 * sub + 8 * q;
-              if (e < tot) fn(v[q].x);
-              if (e + 1 < tot) fn(v[q].y);
-            }
-          }
-        }
+      for (int t = 0; t < 8; ++t) {
+        const uint32_t code = (uint32_t)((t < 4 ? v.x : v.y) >> (16 * (t & 3))) & 0xffffu;
+        if (e0 + t < c) fn(code, st0 + e0 + t);
       }
-      c0 = c1; s0 = s1; c1 = c2; s1 = s2;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v0[q] = v1[q];
+    };
+    uint32_t c0, c1, c2, c3; uint64_t s0, s1, s2, s3;
+    ulonglong2 v0, v1, v2;
+    meta(grp, c0, s0); meta(grp + 64, c1, s1); meta(grp + 128, c2, s2);
+    issue(c0, s0, 0, v0); issue(c1, s1, 0, v1);
+    for (int i = grp; i < s; i += 64) {
+      meta(i + 192, c3, s3);
+      issue(c2, s2, 0, v2);
+      if (c0) {
+        consume(c0, s0, 0, v0);
+        for (uint32_t j0 = 32; j0 < c0; j0 += 32) { ulonglong2 v; issue(c0, s0, j0, v); consume(c0, s0, j0, v); }   // long lists: the rest
+      }
+      c0 = c1; s0 = s1; v0 = v1; c1 = c2; s1 = s2; v1 = v2; c2 = c3; s2 = s3;
     }
   };
-  if (dbg == 2) { uint64_t a = 0; for_each_hit([&](uint64_t h) { a += h; }); if (a == 0x123456789ull) cnt[0] = 1; }
-  else for_each_hit([&](uint64_t h) {
-    atomicAdd(&cnt[hf_slot_of(hf_base((uint32_t)(h >> 32), __umulhi((uint32_t)pw_wpos((uint32_t)h), inv_len)))], 1u);
-  });
+  if (dbg == 2) { uint32_t a = 0; for_each_hit([&](uint32_t code, uint64_t) { a += code; }); if (a == 0x12345678u) cnt[0] = 1; }
+  else for_each_hit([&](uint32_t code, uint64_t) { atomicAdd(&cnt[code & (HF_SLOTS - 1)], 1u); });
   __syncthreads();
   if (dbg) { if (!WRITE && threadIdx.x == 0) surv_n[r] = 0; return; }   // timing aid (MM_HF_DBG): pass 1 only
-  uint32_t mine = 0;
+  {
+    // good[b]: the window of nb bins starting at b holds >= m hits (sliding sum over this thread's 32 window starts);
+    // alive[b]: some good window contains b, i.e. good dilated by nb positions (all modulo 8192 bins)
+    const int b0 = threadIdx.x * 32;
+    uint32_t sum = 0, bits = 0;
+    for (int i = 0; i < nb; ++i) sum += cnt[(b0 + i) & (HF_SLOTS - 1)];
+    for (int t = 0; t < 32; ++t) {
+      bits |= (sum >= (uint32_t)m ? 1u : 0u) << t;
+      sum += cnt[(b0 + t + nb) & (HF_SLOTS - 1)] - cnt[(b0 + t) & (HF_SLOTS - 1)];
+    }
+    good[threadIdx.x] = bits;
+    __syncthreads();
+    uint32_t al = 0;
+    for (int j = 0; j < nb; ++j) {                               // bit b of alive = OR over j < nb of good bit (b - j)
+      const int wsh = j >> 5, bsh = j & 31;
+      const uint32_t g0 = good[(threadIdx.x - wsh) & 255], g1 = good[(threadIdx.x - wsh - 1) & 255];
+      al |= bsh ? (g0 << bsh) | (g1 >> (32 - bsh)) : g0;
+    }
+    alive[threadIdx.x] = al;
+    __syncthreads();
+  }
   const uint64_t wbase = WRITE ? read_hit_off[r] : 0;
   const uint64_t stage_base = stage_off[r];
   const uint32_t stage_cap = (uint32_t)(stage_off[r + 1] - stage_base);
-  for_each_hit([&](uint64_t h) {
-    const uint32_t ct = (uint32_t)(h >> 32), bin = __umulhi((uint32_t)pw_wpos((uint32_t)h), inv_len);
-    const uint32_t hb = hf_base(ct, bin);
-    const uint32_t c0 = cnt[hf_slot_of(hb)];
-    const uint32_t cl = bin > 0 ? cnt[hf_slot_of(hb - HF_K2)] : 0u, cr = cnt[hf_slot_of(hb + HF_K2)];
-    if (c0 + cl >= (uint32_t)m || c0 + cr >= (uint32_t)m) {
+  uint64_t* const dst = WRITE ? hits + wbase : stage + stage_base;
+  const uint32_t dst_cap = WRITE ? 0xffffffffu : stage_cap;
+  // second pass: survivors (a few per cent) park the index of their entry, which is then replaced by the entry itself
+  for_each_hit([&](uint32_t code, uint64_t idx) {
+    const uint32_t b = code & (HF_SLOTS - 1);
+    if ((alive[b >> 5] >> (b & 31)) & 1u) {
       const uint32_t slot = atomicAdd(&cursor, 1u);
-      if (WRITE) hits[wbase + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
-      else if (slot < stage_cap) stage[stage_base + slot] = h & ~(uint64_t)(PW_DP | PW_DN);
+      if (slot < dst_cap) dst[slot] = idx;
     }
   });
-  (void)mine;
-  if (!WRITE) {
-    __syncthreads();
-    if (threadIdx.x == 0) surv_n[r] = cursor;
-  }
+  __syncthreads();
+  const uint32_t n_s = min(cursor, dst_cap);
+  for (uint32_t j = threadIdx.x; j < n_s; j += 256) dst[j] = I.occ[dst[j]] & ~(uint64_t)(PW_DP | PW_DN);
+  if (!WRITE && threadIdx.x == 0) surv_n[r] = cursor;
 }
 
 __global__ void read_hit_bounds_kernel(const uint64_t* __restrict__ off, const uint64_t* __restrict__ hit_off, int64_t n,

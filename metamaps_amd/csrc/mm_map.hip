@@ -265,37 +265,39 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   // single request of at most 64 bytes.  Random reads are bound by requests, not bytes (tools/ubench/randread), so the
   // lists of a group are software-pipelined: count/start three lists ahead, codes two ahead.
   const int grp = threadIdx.x >> 2, sub = threadIdx.x & 3;
-  auto for_each_hit = [&](auto&& fn) {                           // fn(bin code, index of the entry in occ[])
+  // fn(c, st0, j0, v): lane `sub` of the group holds the codes of entries j0 + 8*sub .. +7 of a list of c entries that starts
+  // at occ[st0]; called by all lanes of the wave together (c == 0: nothing), so that fn may use wave-wide operations
+  auto for_each_chunk = [&](auto&& fn) {
     auto meta = [&](int i, uint32_t& c, uint64_t& st0) { c = 0; st0 = 0; if (i < s) { c = probe_cnt[o + i]; st0 = probe_start[o + i]; } };
-    auto issue = [&](uint32_t c, uint64_t st0, uint32_t j0, ulonglong2& v) {   // codes j0 + 8*sub .. +7 (clamped into the padded list)
+    auto issue = [&](uint32_t c, uint64_t st0, uint32_t j0, ulonglong2& v) {   // (clamped into the padded list)
       if (c) v = *reinterpret_cast<const ulonglong2*>(I.occ16 + st0 + min(j0 + 8u * sub, (c - 1) & ~7u));
     };
-    auto consume = [&](uint32_t c, uint64_t st0, uint32_t j0, const ulonglong2& v) {
-      const uint32_t e0 = j0 + 8u * sub;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const uint32_t code = (uint32_t)((t < 4 ? v.x : v.y) >> (16 * (t & 3))) & 0xffffu;
-        if (e0 + t < c) fn(code, st0 + e0 + t);
-      }
-    };
     uint32_t c0, c1, c2, c3; uint64_t s0, s1, s2, s3;
-    ulonglong2 v0, v1, v2;
+    ulonglong2 v0 = make_ulonglong2(0, 0), v1 = v0, v2 = v0;
     meta(grp, c0, s0); meta(grp + 64, c1, s1); meta(grp + 128, c2, s2);
     issue(c0, s0, 0, v0); issue(c1, s1, 0, v1);
-    for (int i = grp; i < s; i += 64) {
-      meta(i + 192, c3, s3);
+    for (int ib = 0; ib < s; ib += 64) {                         // (wave-uniform trip count)
+      meta(ib + grp + 192, c3, s3);
       issue(c2, s2, 0, v2);
-      if (c0) {
-        consume(c0, s0, 0, v0);
-        for (uint32_t j0 = 32; j0 < c0; j0 += 32) { ulonglong2 v; issue(c0, s0, j0, v); consume(c0, s0, j0, v); }   // long lists: the rest
+      fn(c0, s0, 0u, v0);
+      for (uint32_t j0 = 32; __any(j0 < c0); j0 += 32) {         // long lists: the rest
+        const uint32_t cl = j0 < c0 ? c0 : 0u;
+        ulonglong2 v = make_ulonglong2(0, 0); issue(cl, s0, j0, v); fn(cl, s0, j0, v);
       }
       c0 = c1; s0 = s1; v0 = v1; c1 = c2; s1 = s2; v1 = v2; c2 = c3; s2 = s3;
     }
   };
-  if (dbg == 2) { uint32_t a = 0; for_each_hit([&](uint32_t code, uint64_t) { a += code; }); if (a == 0x12345678u) cnt[0] = 1; }
-  else for_each_hit([&](uint32_t code, uint64_t) { atomicAdd(&cnt[code & (HF_SLOTS - 1)], 1u); });
+  auto code_of = [](const ulonglong2& v, int t) { return (uint32_t)((t < 4 ? v.x : v.y) >> (16 * (t & 3))) & (uint32_t)(HF_SLOTS - 1); };
+  if (dbg == 2) {
+    uint32_t a = 0;
+    for_each_chunk([&](uint32_t c, uint64_t, uint32_t j0, const ulonglong2& v) { for (int t = 0; t < 8; ++t) if (j0 + 8u * sub + t < c) a += code_of(v, t); });
+    if (a == 0x12345678u) cnt[0] = 1;
+  } else for_each_chunk([&](uint32_t c, uint64_t, uint32_t j0, const ulonglong2& v) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) if (j0 + 8u * sub + t < c) atomicAdd(&cnt[code_of(v, t)], 1u);
+  });
   __syncthreads();
-  if (dbg) { if (!WRITE && threadIdx.x == 0) surv_n[r] = 0; return; }   // timing aid (MM_HF_DBG): pass 1 only
+  if (dbg == 1 || dbg == 2) { if (!WRITE && threadIdx.x == 0) surv_n[r] = 0; return; }   // timing aid (MM_HF_DBG): pass 1 only
   {
     // good[b]: the window of nb bins starting at b holds >= m hits (sliding sum over this thread's 32 window starts);
     // alive[b]: some good window contains b, i.e. good dilated by nb positions (all modulo 8192 bins)
@@ -322,16 +324,33 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   const uint32_t stage_cap = (uint32_t)(stage_off[r + 1] - stage_base);
   uint64_t* const dst = WRITE ? hits + wbase : stage + stage_base;
   const uint32_t dst_cap = WRITE ? 0xffffffffu : stage_cap;
-  // second pass: survivors (a few per cent) park the index of their entry, which is then replaced by the entry itself
-  for_each_hit([&](uint32_t code, uint64_t idx) {
-    const uint32_t b = code & (HF_SLOTS - 1);
-    if ((alive[b >> 5] >> (b & 31)) & 1u) {
-      const uint32_t slot = atomicAdd(&cursor, 1u);
-      if (slot < dst_cap) dst[slot] = idx;
+  // second pass: survivors (a few per cent) park the index of their entry, which is then replaced by the entry itself.
+  // Per chunk the wave reserves its slots with one atomic (bit mask per lane, prefix sum across the wave) — a branch and
+  // an atomic per surviving entry would serialise the wave on LDS round trips.
+  const int lane = threadIdx.x & 63;
+  for_each_chunk([&](uint32_t c, uint64_t st0, uint32_t j0, const ulonglong2& v) {
+    const uint32_t e0 = j0 + 8u * sub;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { const uint32_t b = code_of(v, t); mask |= ((e0 + t < c) ? (alive[b >> 5] >> (b & 31)) & 1u : 0u) << t; }
+    if (dbg == 4) { if (mask == 0xdeadu) cnt[1] = 1; return; }   // timing aid: reads and bit tests only
+    const int mine = __popc(mask);
+    const int incl = wave_incl_scan(mine);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total == 0) return;
+    uint32_t base = 0;
+    if (lane == 63) base = atomicAdd(&cursor, (uint32_t)total);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+    uint32_t pos = base + (uint32_t)(incl - mine);
+    while (mask) {
+      const int t = __ffs(mask) - 1; mask &= mask - 1;
+      if (pos < dst_cap) dst[pos] = st0 + e0 + t;
+      ++pos;
     }
   });
   __syncthreads();
   const uint32_t n_s = min(cursor, dst_cap);
+  if (dbg == 3 || dbg == 4) { if (!WRITE && threadIdx.x == 0) surv_n[r] = 0; return; }   // timing aid: without the fetch of the survivors
   for (uint32_t j = threadIdx.x; j < n_s; j += 256) dst[j] = I.occ[dst[j]] & ~(uint64_t)(PW_DP | PW_DN);
   if (!WRITE && threadIdx.x == 0) surv_n[r] = cursor;
 }

@@ -355,6 +355,14 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   if (!WRITE && threadIdx.x == 0) surv_n[r] = cursor;
 }
 
+// sum of the probe counts (= raw seed hits of the batch); the filter path needs no per-list offsets, only this total
+__global__ void __launch_bounds__(256) sum_u32_kernel(const uint32_t* __restrict__ v, int64_t n, unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += v[i];
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
 __global__ void read_hit_bounds_kernel(const uint64_t* __restrict__ off, const uint64_t* __restrict__ hit_off, int64_t n,
                                        uint64_t* __restrict__ read_hit_off) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -725,18 +733,26 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   // ---- K3
   DBuf<uint32_t> probe_cnt((size_t)total_mz + 1); probe_cnt.zero(st);
   DBuf<uint64_t> probe_start((size_t)total_mz + 1);
-  DBuf<uint64_t> hit_off((size_t)total_mz + 2), scan_tmp;
+  DBuf<uint64_t> hit_off, scan_tmp;
   const size_t t_pg = T.begin(&M->stats.ms_probe_gather);
   if (n > 0 && total_mz > 0) {
     probe_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p);
     MM_KERNEL_CHECK();
   }
-  exclusive_scan_u32_u64(probe_cnt.p, total_mz, hit_off.p, scan_tmp, st);
-  M->read_hit_off.alloc((size_t)n + 1);
-  uint64_t raw_hits = 0;
-  MM_HIP(hipMemcpyAsync(&raw_hits, hit_off.p + total_mz, sizeof raw_hits, hipMemcpyDeviceToHost, st));
   const char* nf_env = getenv("MM_NO_HIT_FILTER");               // parity tests of the raw hit list
   const bool use_filter = !(nf_env && nf_env[0] == '1');
+  M->read_hit_off.alloc((size_t)n + 1);
+  uint64_t raw_hits = 0;
+  DBuf<unsigned long long> raw_sum(1);
+  if (use_filter && n > 0) {                                      // only the total is needed
+    raw_sum.zero(st);
+    if (total_mz > 0) { sum_u32_kernel<<<dim3(2048), dim3(256), 0, st>>>(probe_cnt.p, total_mz, raw_sum.p); MM_KERNEL_CHECK(); }
+    MM_HIP(hipMemcpyAsync(&raw_hits, raw_sum.p, sizeof raw_hits, hipMemcpyDeviceToHost, st));
+  } else {
+    hit_off.alloc((size_t)total_mz + 2);
+    exclusive_scan_u32_u64(probe_cnt.p, total_mz, hit_off.p, scan_tmp, st);
+    MM_HIP(hipMemcpyAsync(&raw_hits, hit_off.p + total_mz, sizeof raw_hits, hipMemcpyDeviceToHost, st));
+  }
   DBuf<uint32_t> surv;
   DBuf<uint64_t> stage, stage_off;
   if (use_filter && n > 0) {

@@ -546,7 +546,23 @@ int map_mode(const Options& o, const std::string& mode) {
 struct TaxNode { std::string parent, rank, sci; };
 struct Taxonomy {                                                // meta/taxonomy.h:137-246
   std::map<std::string, TaxNode> T;
-  static std::vector<std::string> fields(std::string ln) { static const std::regex re("\\s*\\|\\s*"); return split(std::regex_replace(ln, re, "|"), "|"); }
+  // split(regex_replace(line, "\\s*\\|\\s*", "|"), "|") of taxonomy.h:150-175 without std::regex: cut at every '|', drop the white space
+  // that touches a '|' (not the one at the very start or end of the line)
+  static std::vector<std::string> fields(const std::string& ln) {
+    std::vector<std::string> out;
+    if (ln.empty()) return out;
+    size_t a = 0;
+    for (bool first = true;; first = false) {
+      const size_t bar = ln.find('|', a);
+      size_t lo = a, hi = bar == std::string::npos ? ln.size() : bar;
+      if (!first) while (lo < hi && isspace((unsigned char)ln[lo])) ++lo;
+      if (bar != std::string::npos) while (hi > lo && isspace((unsigned char)ln[hi - 1])) --hi;
+      out.push_back(ln.substr(lo, hi - lo));
+      if (bar == std::string::npos) break;
+      a = bar + 1;
+    }
+    return out;
+  }
   explicit Taxonomy(const std::string& dir) {
     std::map<std::string, std::string> sci; std::string ln;
     std::ifstream nm(dir + "/names.dmp"); if (!nm.is_open()) die("Cannot open file " + dir + "/names.dmp -- is '" + dir + "' a valid NCBI taxonomy?");
@@ -566,11 +582,17 @@ struct Taxonomy {                                                // meta/taxonom
   std::string first_non_x(std::string id) const { while (id.find('x') != std::string::npos) id = T.at(id).parent; return id; }   // :51-74
 };
 
-std::string extract_taxon(const std::string& contig) {           // fEM.h:1396
-  static const std::regex re("kraken:taxid\\|(x?\\d+)");
-  std::smatch m;
-  if (!std::regex_search(contig, m, re)) die("Could not extract taxon ID from contig identifier '" + contig + "' - did you use the MetMaps build scripts to construct your database?");
-  return m[1];
+// first match of the reference's regex  kraken:taxid\|(x?\d+)  (fEM.h:1396), without std::regex (called per mapping line)
+std::string extract_taxon(const std::string& contig) {
+  static const std::string key = "kraken:taxid|";
+  for (size_t p = contig.find(key); p != std::string::npos; p = contig.find(key, p + 1)) {
+    size_t a = p + key.size(), b = a;
+    if (b < contig.size() && contig[b] == 'x') ++b;
+    const size_t d0 = b;
+    while (b < contig.size() && contig[b] >= '0' && contig[b] <= '9') ++b;
+    if (b > d0) return contig.substr(a, b - a);
+  }
+  die("Could not extract taxon ID from contig identifier '" + contig + "' - did you use the MetMaps build scripts to construct your database?");
 }
 
 void write_wimp(const std::string& fn, const Taxonomy& T, const std::map<std::string, double>& freq, const std::map<std::string, size_t>& reads,
@@ -771,6 +793,7 @@ bool write_unknown_species(const std::string& fn, const std::string& db, const T
 }
 
 int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db, size_t minReadsU) {   // meta::doEM, fEM.h:466-803
+  PhaseClock pc;
   // mappings grouped by read (fEM.h:1171-1214)
   std::vector<std::vector<std::string>> groups;
   { std::ifstream s(mapped); if (!s.is_open()) die("Cannot open mappings file " + mapped);
@@ -787,7 +810,9 @@ int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db, 
   std::map<std::string, std::map<std::string, size_t>> TI;       // fEM.h:1320-1364
   { std::ifstream s(db + "/taxonInfo.txt"); if (!s.is_open()) die("Could not open file " + db + "/taxonInfo.txt -- perhaps you have specified an incomplete DB?");
     std::string ln; while (std::getline(s, ln)) { if (ln.empty()) continue; auto f = split(ln, " "); for (auto& c : split(f.at(1), ";")) { auto kv = split(c, "="); TI[f.at(0)][kv.at(0)] = std::stoull(kv.at(1)); } } }
+  pc.lap("c1 read mappings + taxonInfo");
   Taxonomy T(db + "/taxonomy");
+  pc.lap("c2 taxonomy");
   std::vector<std::string> taxa(taxaSet.begin(), taxaSet.end());
   std::map<std::string, int> tindex; for (size_t i = 0; i < taxa.size(); ++i) tindex[taxa[i]] = (int)i;
   // per mapping: taxon, quality, 1/nLoc (getMappingLocations, fEM.h:234-353)
@@ -806,6 +831,7 @@ int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db, 
     }
     off.push_back((int64_t)taxon.size());
   }
+  pc.lap("c3 per-mapping fields");
   mm_em* em; ck(ctx, mm_em_create(ctx, (int64_t)groups.size(), off.data(), taxon.data(), mapq.data(), inv.data(), (int32_t)taxa.size(), &em), "em");
   std::vector<double> f(taxa.size(), 1 / (double)taxa.size()), fn(taxa.size());
   std::cout << "Starting EM..." << std::endl;
@@ -820,6 +846,7 @@ int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db, 
   std::vector<double> post(taxon.size()); std::vector<int64_t> best(groups.size());
   ck(ctx, mm_em_posteriors(em, f.data(), post.data(), best.data()), "posteriors");
   mm_em_destroy(em);
+  pc.lap("c4 EM");
   std::cout << "Outputting mappings with adjusted alignment qualities." << std::endl;
   std::ofstream emf(mapped + ".EM"), r2t(mapped + ".EM.reads2Taxon"), kr(mapped + ".EM.reads2Taxon.krona"), li(mapped + ".EM.lengthAndIdentitiesPerMappingUnit");
   li << "AnalysisLevel\tID\treadI\tIdentity\tLength\n";
@@ -853,6 +880,7 @@ int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db, 
     for (auto& e : fmap) if (e.second < minF && !readsPer.count(e.first)) drop.insert(e.first);
     for (auto& d : drop) fmap.erase(d);
     double s = 0; for (auto& e : fmap) s += e.second; for (auto& e : fmap) e.second /= s; }
+  pc.lap("c5 output files");
   write_wimp(mapped + ".EM.WIMP", T, fmap, readsPer, nTotal, nUnmapped, nTooShort);
   coverage.write(mapped + ".EM.contigCoverage", T);
   if (!write_unknown_species(mapped + ".EM.evidenceUnknownSpecies", db, T, coverage, identsPerTaxon, maxReadLen, minReadsU))

@@ -5,7 +5,7 @@ from metamaps_amd import capi
 ctx = capi.Context(0)
 ref = ctx.synth_reference(seed=20260928, n_species=3000, strains_per_species=4, genome_len=2_200_000, strain_divergence=0.02, genus_divergence=0.2)
 idx = ctx.index(ref, 16, 8)
-reads, truth = ctx.synth_reads(ref, seed=1000, n_reads=100000, read_len=10000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=100)
+reads, truth = ctx.synth_reads(ref, seed=1000, n_reads=int(os.environ.get("NR", "100000")), read_len=int(os.environ.get("RL", "10000")), sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=100)
 for stop in sys.argv[1:]:
     os.environ["MM_L2_STOP"] = stop
     best = 1e9

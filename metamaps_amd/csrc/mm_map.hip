@@ -847,7 +847,9 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     const char* full_env = getenv("MM_L2_FULL");                 // cross-check switch: evaluate every window
     const bool skip = !(full_env && full_env[0] == '1');
     const size_t lds_wide = l2_lds_bytes<uint16_t>(smax, skip, 1, 8);
-    MM_REQUIRE(lds_wide <= 160 * 1024, MM_ERR_LIMIT, "sketch too large for the L2 window state in LDS (read longer than ~115 kb at w=8)");
+    // (>= 32768 sketch hashes: the rebuild's 1024-bucket histogram would be as coarse as the 64-rank pivot zone, and the window
+    //  state of the full slide no longer fits LDS either)
+    MM_REQUIRE(lds_wide <= 160 * 1024 && smax < 32768, MM_ERR_LIMIT, "sketch too large for the L2 window state in LDS (read longer than ~145 kb at w=8)");
     auto set_lds = [&](const void* fn, size_t bytes) { if (bytes > 64 * 1024) MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); };
     DBuf<unsigned long long> counters(16); counters.zero(st);
     if (getenv("MM_L2_STOP") || getenv("MM_L2_PHASES") || getenv("MM_FORCE_AMB_REDO")) {

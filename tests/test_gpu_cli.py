@@ -239,3 +239,71 @@ def test_cli_stream_chunks_two_query_files(tmp_path):
                        check=True, capture_output=True, timeout=900)
         outs[tag] = (open(o1).read(), open(o2).read(), open(o1 + ".meta").read(), open(o2 + ".meta").read())
     assert outs["res"] == outs["str"] and len(outs["res"][0]) > 1000 and len(outs["res"][1]) > 1000
+
+
+def test_cli_mixed_long_reads_match_oracle(oracle_lib, tmp_path):
+    """BASELINE config 3's read shape at oracle scale: lengths spread over 1-60 kb with PacBio-like errors (2 % del, 8 % ins,
+    2 % sub; simulate.pl:57), so that every sketch-size class of K5 (3 072 / 7 168 / 16 384 and beyond) and the multi-bin windows
+    of the seed-hit filter meet the oracle directly, not only the GPU's own full slide"""
+    import orc
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=12, genome_len=400_000, seed=23, contigs_per_genome=2)
+    rd = synth.make_reads(db, str(tmp_path / "reads.fq"), n_reads=260, read_len=9000, seed=9, len_jitter=1.0, sub=0.02, ins=0.08, dele=0.02)
+    # (reads beyond ~145 kb are refused, test_long_read_limit_is_an_error: keep this set below 100 kb)
+    recs = open(rd["path"]).read().split("\n")
+    with open(rd["path"], "w") as f:
+        for i in range(0, len(recs) - 3, 4):
+            if len(recs[i + 1]) <= 100_000:
+                f.write("\n".join(recs[i:i + 4]) + "\n")
+    lens = [len(l) for i, l in enumerate(open(rd["path"])) if i % 4 == 1]
+    assert 50_000 < max(lens) <= 100_000 and sum(1 for x in lens if x > 20_000) > 25 and min(lens) < 1500
+    pa, pb = str(tmp_path / "gpu"), str(tmp_path / "cpu")
+    for exe, pre, extra in ((CLI, pa, []), (orc.CLI, pb, ["-t", "16"])):
+        subprocess.run([exe, "mapDirectly", "--all", "-r", db.fasta, "-q", rd["path"], "-o", pre, "-w", "8"] + extra, check=True, capture_output=True, timeout=240)
+        subprocess.run([exe, "classify", "--DB", db.dir, "--mappings", pre, "--minreads", "5"], check=True, capture_output=True, timeout=240)
+    _cmp_table(pa, pb, " ", {13})
+    assert open(pa + ".meta").read() == open(pb + ".meta").read()
+    _cmp_table(pa + ".EM", pb + ".EM", " ", {13})
+    assert open(pa + ".EM.reads2Taxon").read() == open(pb + ".EM.reads2Taxon").read()
+    _cmp_table(pa + ".EM.WIMP", pb + ".EM.WIMP", "\t", {4, 5})
+    assert sum(1 for _ in open(pa)) > 300
+
+
+def test_longest_supported_reads_match_oracle(oracle_lib, tmp_path):
+    """just below the limit: 120-140 kb reads (sketches of 26-31 thousand hashes, streams beyond the mask capacity of K5)"""
+    import orc
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=4, genome_len=400_000, seed=5, contigs_per_genome=1)
+    seq = open(db.fasta).read().split("\n")
+    genomes, cur = [], []
+    for l in seq:
+        if l.startswith(">"):
+            if cur: genomes.append("".join(cur)); cur = []
+        elif l: cur.append(l)
+    if cur: genomes.append("".join(cur))
+    import random
+    rng = random.Random(3)
+    with open(str(tmp_path / "long.fq"), "w") as f:
+        for i, (g, L) in enumerate(((0, 140_000), (1, 120_000), (2, 131_000))):
+            s0 = rng.randrange(0, len(genomes[g]) - L)
+            r = list(genomes[g][s0:s0 + L])
+            for j in range(0, L, 23): r[j] = "ACGT"[rng.randrange(4)]          # ~3 % substitutions
+            f.write(f"@long{i}\n" + "".join(r) + "\n+\n" + "I" * L + "\n")
+    pa, pb = str(tmp_path / "gpu"), str(tmp_path / "cpu")
+    for exe, pre in ((CLI, pa), (orc.CLI, pb)):
+        subprocess.run([exe, "mapDirectly", "--all", "-r", db.fasta, "-q", str(tmp_path / "long.fq"), "-o", pre, "-w", "8"], check=True, capture_output=True, timeout=200)
+    _cmp_table(pa, pb, " ", {13})
+    assert sum(1 for _ in open(pa)) >= 3
+
+
+def test_long_read_limit_is_an_error(tmp_path):
+    """a read whose sketch has >= 32768 hashes (~145 kb at w = 8) is beyond the LDS-resident window state: refused with a
+    message, not mapped wrongly and not left spinning"""
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=4, genome_len=400_000, seed=5, contigs_per_genome=1)
+    seq = open(db.fasta).read().split("\n")
+    genome = "".join(l for l in seq[1:] if l and not l.startswith(">"))[:180_000]
+    with open(str(tmp_path / "long.fq"), "w") as f:
+        f.write("@long\n" + genome + "\n+\n" + "I" * len(genome) + "\n")
+    p = subprocess.run([CLI, "mapDirectly", "--all", "-r", db.fasta, "-q", str(tmp_path / "long.fq"), "-o", str(tmp_path / "x"), "-w", "8"], capture_output=True, timeout=120)
+    assert p.returncode != 0 and b"sketch too large" in p.stderr

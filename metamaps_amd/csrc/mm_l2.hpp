@@ -178,6 +178,7 @@ __device__ inline int l2_classify1(const uint32_t* __restrict__ Q, const uint16_
 constexpr int L2_SCRATCH_BYTES = 64 * 4 + 64 + 64;             // step times, step-has-deletion, step-has-addition
 __host__ __device__ inline size_t l2_skip_bytes(int nwq) { return (((size_t)(64 * nwq + 1) * (3 * 8 + 3 * 2)) + 15) & ~(size_t)15; }
 constexpr int L2_HBUCKETS = 1024;                              // coarse gap histogram of a rebuild (16-bit counters)
+constexpr int L2_SKETCH_LIMIT = 32 * L2_HBUCKETS;              // sketch sizes below this keep a histogram bucket narrower than the 64-rank zone
 template <typename DT>
 __host__ __device__ inline size_t l2_wave_bytes(int smax, bool skip, int nwq) {
   if (skip && nwq > 2) return ((size_t)L2_HBUCKETS * 2 + L2_SCRATCH_BYTES + 15) & ~(size_t)15;   // long-read classes: histogram | slide scratch

@@ -626,6 +626,14 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   }
   M->h_sk_n = M->sk_n.to_host(st, (size_t)n);
   std::vector<uint8_t> h_amb = M->amb.to_host(st, (size_t)n);
+  {
+    // Reads whose sketch has >= 32768 hashes (~145 kb at w = 8) are beyond the LDS-resident window state of K5 (below): they
+    // are left without a sketch, i.e. reported as not mapped, and counted in stats.n_reads_over_limit for the caller to flag.
+    int64_t over = 0;
+    for (int64_t r = 0; r < n; ++r) if (M->h_sk_n[(size_t)r] >= L2_SKETCH_LIMIT) { M->h_sk_n[(size_t)r] = 0; h_amb[(size_t)r] = 0; ++over; }
+    M->stats.n_reads_over_limit = over;
+    if (over) { M->sk_n.upload(M->h_sk_n.data(), (size_t)n, st); MM_HIP(hipStreamSynchronize(st)); }
+  }
   std::function<void()> amb_finish;
   // ---- duplicate-hash strand tie-break (computeMap.hpp:292-295: std::sort is not stable, std::unique keeps
   //      whichever equal-hash element introsort left first).  Only the strand of the survivor is observable
@@ -849,7 +857,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     const size_t lds_wide = l2_lds_bytes<uint16_t>(smax, skip, 1, 8);
     // (>= 32768 sketch hashes: the rebuild's 1024-bucket histogram would be as coarse as the 64-rank pivot zone, and the window
     //  state of the full slide no longer fits LDS either)
-    MM_REQUIRE(lds_wide <= 160 * 1024 && smax < 32768, MM_ERR_LIMIT, "sketch too large for the L2 window state in LDS (read longer than ~145 kb at w=8)");
+    MM_REQUIRE(lds_wide <= 160 * 1024 && smax < L2_SKETCH_LIMIT, MM_ERR_LIMIT, "sketch too large for the L2 window state in LDS (read longer than ~145 kb at w=8)");
     auto set_lds = [&](const void* fn, size_t bytes) { if (bytes > 64 * 1024) MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); };
     DBuf<unsigned long long> counters(16); counters.zero(st);
     if (getenv("MM_L2_STOP") || getenv("MM_L2_PHASES") || getenv("MM_FORCE_AMB_REDO")) {

@@ -296,14 +296,19 @@ def test_longest_supported_reads_match_oracle(oracle_lib, tmp_path):
     assert sum(1 for _ in open(pa)) >= 3
 
 
-def test_long_read_limit_is_an_error(tmp_path):
-    """a read whose sketch has >= 32768 hashes (~145 kb at w = 8) is beyond the LDS-resident window state: refused with a
-    message, not mapped wrongly and not left spinning"""
+def test_reads_over_the_sketch_limit_are_flagged(tmp_path):
+    """a read whose sketch has >= 32768 hashes (~145 kb at w = 8) is beyond the LDS-resident window state: reported as not
+    mapped with a warning (and counted in mm_map_stats.n_reads_over_limit), the other reads of the batch are unaffected"""
     from metamaps_amd import synth
     db = synth.make_db(str(tmp_path / "db"), n_genomes=4, genome_len=400_000, seed=5, contigs_per_genome=1)
     seq = open(db.fasta).read().split("\n")
-    genome = "".join(l for l in seq[1:] if l and not l.startswith(">"))[:180_000]
+    genome = "".join(l for l in seq[1:] if l and not l.startswith(">"))
     with open(str(tmp_path / "long.fq"), "w") as f:
-        f.write("@long\n" + genome + "\n+\n" + "I" * len(genome) + "\n")
-    p = subprocess.run([CLI, "mapDirectly", "--all", "-r", db.fasta, "-q", str(tmp_path / "long.fq"), "-o", str(tmp_path / "x"), "-w", "8"], capture_output=True, timeout=120)
-    assert p.returncode != 0 and b"sketch too large" in p.stderr
+        f.write("@long\n" + genome[:180_000] + "\n+\n" + "I" * 180_000 + "\n")
+        f.write("@ok\n" + genome[1000:9000] + "\n+\n" + "I" * 8000 + "\n")
+    out = str(tmp_path / "x")
+    p = subprocess.run([CLI, "mapDirectly", "--all", "-r", db.fasta, "-q", str(tmp_path / "long.fq"), "-o", out, "-w", "8"], capture_output=True, timeout=120)
+    assert p.returncode == 0 and b"exceed the device limit" in p.stderr
+    assert open(out + ".meta.unmappedReadsLengths").read() == "180000\tlong\n"
+    assert all(l.startswith("ok ") for l in open(out)) and sum(1 for _ in open(out)) >= 1
+    assert "ReadsNotMapped 1" in open(out + ".meta").read()

@@ -50,10 +50,16 @@ constexpr int L2_TBITS = 10;                     // bucket table over the top ha
 constexpr int L2_TSHIFT = 32 - L2_TBITS;
 constexpr int L2_TSIZE = (1 << L2_TBITS) + 1;
 
+// does [lo, hi) of pos[] hold hash h?  512 entries per step, the eight loads of a step in flight together: one load per step
+// made every duplicate-flagged entry of a 50 kb window cost ~200 dependent memory latencies (two thirds of the rebuild time).
 __device__ inline bool wave_has_hash(const Rec* __restrict__ pos, int64_t lo, int64_t hi, uint32_t h, int lane) {
-  for (int64_t base = lo; base < hi; base += 64) {               // `base` is wave-uniform
-    const int64_t j = base + lane;
-    const bool hit = (j < hi) && pos[j].hash == h;
+  for (int64_t base = lo; base < hi; base += 512) {              // `base` is wave-uniform
+    uint32_t x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int64_t j = base + lane + 64 * i; x[i] = pos[j < hi ? j : lo].hash; }
+    bool hit = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hit |= (base + lane + 64 * i < hi) && x[i] == h;
     if (__ballot(hit) != 0ull) return true;
   }
   return false;
@@ -466,9 +472,31 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     };
     // an entry flagged DP counts only if no earlier occurrence of its hash lies inside the window
     auto first_in_window = [&](int j) -> bool { return !wave_has_hash(pos, nb, j, pos[j].hash, lane); };
-    for (int base = nb; base < ne; base += 512) {                // pass 1
-      int cd[8]; uint32_t fl[8];
-      fetch8(base, cd, fl);
+    // the parked code words of [nb, ne), 512 entries per step; the loads of the next step are issued before the current one is
+    // processed (the long-read classes keep only 8-12 waves per CU: nothing else would cover the latency of each step)
+    auto stream_codes = [&](auto&& body) __attribute__((always_inline)) {
+      if (have_codes) {
+        auto load_raw = [&](int base, CW (&raw)[8]) {
+          const CW* __restrict__ pc = cw + (base - first) + lane;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) raw[i] = pc[min(64 * i, 64 * 64 * NWQ - 1 - (base - first) - lane)];
+        };
+        CW cur[8], nxt[8];
+        load_raw(nb, cur);
+        for (int base = nb; base < ne; base += 512) {
+          if (base + 512 < ne) load_raw(base + 512, nxt);
+          int cd[8]; uint32_t fl[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { cd[i] = cw_code(cur[i]); fl[i] = cw_flags(cur[i]); }
+          body(base, cd, fl);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+        }
+      } else {
+        for (int base = nb; base < ne; base += 512) { int cd[8]; uint32_t fl[8]; fetch8(base, cd, fl); body(base, cd, fl); }
+      }
+    };
+    stream_codes([&](int base, int (&cd)[8], uint32_t (&fl)[8]) __attribute__((always_inline)) {   // pass 1
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int j = base + lane + 64 * i;
@@ -485,7 +513,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         }
         if (count_it) { const int bq = g >> bsh; atomicAdd(&Hw[bq >> 1], 1u << (16 * (bq & 1))); }
       }
-    }
+    });
     wave_sync();
     // prefix sums over the buckets (16 per lane); the first bucket whose last rank satisfies r + C(r) >= s holds the pivot
     constexpr int BPL = L2_HBUCKETS / 64;
@@ -513,9 +541,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     const int rz = z0 + lane;
     fz = rz < s ? rz : (1 << 29);
     sb = 0; pm = 0;
-    for (int base = nb; base < ne; base += 512) {                // pass 2
-      int cd[8]; uint32_t fl[8];
-      fetch8(base, cd, fl);
+    stream_codes([&](int base, int (&cd)[8], uint32_t (&fl)[8]) __attribute__((always_inline)) {   // pass 2
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int j = base + lane + 64 * i;
@@ -538,7 +564,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         uint64_t zw = __ballot(zone_w);
         while (zw) { const int l = __builtin_ctzll(zw); zw &= zw - 1; const int gg = __builtin_amdgcn_readlane(g, l) - z0; fz += (lane >= gg) ? 1 : 0; }
       }
-    }
+    });
   };
 
   auto rebuild_state = [&](int nb, int ne) __attribute__((always_inline)) {
@@ -578,7 +604,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   auto block_slide = [&](int b_stop) __attribute__((always_inline)) {
     constexpr int INF = 0x7fffffff;
     while (e < last_end && b < b_stop) {
-      if (pending_rebuild) { rebuild_state(b, e); pending_rebuild = false; if (dbg_stop == 8) break; }   // the only instance of the rebuild code
+      if (pending_rebuild) { if (dbg_flags & 0x100) lap(4); rebuild_state(b, e); pending_rebuild = false; if (dbg_flags & 0x100) lap(3); if (dbg_stop == 8) break; }   // the only instance of the rebuild code
       if (dbg_stop == 9 && rounds >= 1) break;
       ++rounds;
       const Rec xb = pos[min(b + lane, nmax)];

@@ -196,7 +196,9 @@ __host__ __device__ inline size_t l2_wave_bytes(int smax, bool skip, int nwq) {
   return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t l2_qpart_bytes(int smax) { return ((size_t)(smax + L2_QPAD) * 4 + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t l2_q_bytes(int smax) { return l2_qpart_bytes(smax) + (((size_t)L2_TSIZE * 2 + 4 + 15) & ~(size_t)15); }
+__host__ __device__ inline size_t l2_tpart_bytes() { return ((size_t)L2_TSIZE * 2 + 4 + 15) & ~(size_t)15; }
+// sketch | search table | strand bits of the sketch (two 64-bit words per 64 ranks: strand, unresolved duplicate)
+__host__ __device__ inline size_t l2_q_bytes(int smax) { return l2_qpart_bytes(smax) + l2_tpart_bytes() + (size_t)((smax + 63) / 64) * 16; }
 template <typename DT>
 inline size_t l2_lds_bytes(int smax, bool skip, int waves, int nwq) { return l2_q_bytes(smax) + (size_t)waves * l2_wave_bytes<DT>(smax, skip, nwq); }
 
@@ -236,6 +238,14 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   uint16_t* T = (uint16_t*)((uint8_t*)lds + l2_qpart_bytes(smax));
   int* tmaxp = (int*)(T + ((L2_TSIZE + 1) & ~1));
   for (int i = threadIdx.x; i < s; i += 64 * WAVES) Q[i] = sk_hash[qo + i];
+  // strand byte of every sketch entry (bit 0 strand, bit 1 unresolved duplicate: mm_map.hip, K2) as two bit sets: the vote
+  // looks them up per matched entry, and a global load there is a second dependent memory latency in every step
+  uint64_t* const SB = (uint64_t*)((uint8_t*)lds + l2_qpart_bytes(smax) + l2_tpart_bytes());
+  for (int i0 = 64 * wave; i0 < s; i0 += 64 * WAVES) {
+    const uint8_t sbyte = i0 + lane < s ? sk_strand[qo + i0 + lane] : (uint8_t)0;
+    const uint64_t b0 = __ballot(sbyte & 1), b1 = __ballot(sbyte & 2);
+    if (lane == 0) { SB[2 * (i0 >> 6)] = b0; SB[2 * (i0 >> 6) + 1] = b1; }
+  }
   if (threadIdx.x < L2_QPAD) Q[s + threadIdx.x] = 0xffffffffu;
   if (threadIdx.x == 0) *tmaxp = 0;
   __syncthreads();
@@ -1077,7 +1087,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         if (base + 64 * i >= opt_e) continue;
         const int code = cd[i];
         const bool cnt_it = j < opt_e && code >= 0 && code < bestR;
-        const uint8_t sq = cnt_it ? sk_strand[qo + code] : (uint8_t)0;   // bit 0 strand, bit 1 unresolved duplicate (mm_map.hip, K2)
+        const int cq = cnt_it ? code : 0;
+        const uint32_t sq = cnt_it ? (uint32_t)((SB[2 * (cq >> 6)] >> (cq & 63)) & 1ull) | (uint32_t)(((SB[2 * (cq >> 6) + 1] >> (cq & 63)) & 1ull) << 1) : 0u;
         const bool unres = (sq & 2) && amb_used != nullptr;       // (after the host resolved the read, amb_used is null and bit 1 is gone)
         const int contrib = cnt_it ? ((sq & 1) ? 1 : -1) * pw_strand(fl[i]) : 0;
         const bool flagged = cnt_it && (fl[i] & PW_DN);           // a later occurrence exists in the contig: inside the window?

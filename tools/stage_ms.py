@@ -1,0 +1,16 @@
+"""Timing aid: stage times of one batch of the bench workload (NR reads of RL bases)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from metamaps_amd import capi
+ctx = capi.Context(0)
+ref = ctx.synth_reference(seed=20260928, n_species=int(os.environ.get("NS", "3000")), strains_per_species=4, genome_len=2_200_000, strain_divergence=0.02, genus_divergence=0.2)
+idx = ctx.index(ref, 16, 8)
+reads, truth = ctx.synth_reads(ref, seed=1000, n_reads=int(os.environ.get("NR", "100000")), read_len=int(os.environ.get("RL", "10000")), sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=100)
+best = None
+for it in range(3):
+    M = ctx.map_batch(idx, reads, 16, 8)
+    st = M.stats()
+    M.close()
+    if best is None or st["ms_total"] < best["ms_total"]:
+        best = st
+print({k: round(v, 2) for k, v in best.items() if k.startswith("ms_")}, flush=True)

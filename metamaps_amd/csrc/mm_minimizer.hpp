@@ -14,6 +14,7 @@
 // HBM traffic per position: 2 bits in, 8 bytes out per emitted minimizer (~2/(w+1) per position),
 // twice (count pass + write pass).  Everything else lives in LDS.
 #pragma once
+#include <type_traits>
 #include "mm_common.hpp"
 #include "mm_scan.hpp"
 
@@ -117,6 +118,7 @@ __device__ inline int64_t seq_of_tile(const uint64_t* __restrict__ tile_first, i
   return lo;
 }
 
+static __device__ int mz_dbg_stop = 0;   // timing aid (MM_MZ_DBG=n: the read kernel leaves after step n and reports no minimizers; tools/stage_ms.py)
 // MODE 0: tile_count[tile] = number of emitted minimizers (count pass of the two-pass scheme, index scale).
 // MODE 1: records written at tile_out[tile]... (write pass).
 // MODE 2: single pass — records staged at tile*MZ_STAGE and counted; compact_tiles_kernel then packs them.  A tile
@@ -176,6 +178,8 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
       __syncthreads();
     }
   }
+  const int dbgs = mz_dbg_stop;
+  if (dbgs == 1) { if (MODE != 1 && tid == 0) tile_count[tile] = 0; return; }
   // 2. canonical hash / strand / non-symmetric flag per position
   const int np = Pend - H0;
   if (k == 16) {
@@ -186,19 +190,22 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
     for (int g = tid; g * 8 < np; g += MZ_THREADS) {
       const uint64_t w0 = f64[g], w1 = f64[g + 1], w2 = f64[g + 2];
       const uint64_t c0 = c64[g], c1 = c64[g + 1], c2 = c64[g + 2];
+      uint32_t hq[8]; uint64_t fq = 0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int j = g * 8 + i;
-        if (j >= np) break;
         const uint64_t lo = i ? (w0 >> (8 * i)) | (w1 << (64 - 8 * i)) : w0;
         const uint64_t hi = i ? (w1 >> (8 * i)) | (w2 << (64 - 8 * i)) : w1;
         const uint64_t clo = i ? (c0 >> (8 * i)) | (c1 << (64 - 8 * i)) : c0;
         const uint64_t chi = i ? (c1 >> (8 * i)) | (c2 << (64 - 8 * i)) : c1;
         const uint32_t hf = murmur16(lo, hi);
         const uint32_t hb = murmur16(__builtin_bswap64(chi), __builtin_bswap64(clo));
-        hsh[j] = hf < hb ? hf : hb;
-        flg[j] = (uint8_t)((hf != hb ? 1 : 0) | (hf < hb ? 2 : 0));
+        hq[i] = hf < hb ? hf : hb;
+        fq |= (uint64_t)((hf != hb ? 1u : 0u) | (hf < hb ? 2u : 0u)) << (8 * i);
       }
+      // (positions at or beyond np inside the last group hold bytes past the sequence: written, never read)
+      *reinterpret_cast<uint4*>(hsh + 8 * g) = make_uint4(hq[0], hq[1], hq[2], hq[3]);
+      *reinterpret_cast<uint4*>(hsh + 8 * g + 4) = make_uint4(hq[4], hq[5], hq[6], hq[7]);
+      *reinterpret_cast<uint64_t*>(flg + 8 * g) = fq;
     }
   } else {
     for (int j = tid; j < np; j += MZ_THREADS) {
@@ -209,8 +216,71 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
     }
   }
   __syncthreads();
+  if (dbgs == 2) { if (MODE != 1 && tid == 0) tile_count[tile] = 0; return; }
   // 3. window argmin c(p) for every evaluated position from P0-(w-1) on
   const int jeval0 = max(max(P0 - (w - 1), w - 1), H0) - H0;
+  if (w <= 9) {
+    // eight consecutive positions per thread: the 16 (hash, flag) pairs they can look at are read once with vector loads and
+    // the eight arg-mins are found in registers (same scan order: from the position itself down, strictly smaller wins)
+    for (int g = tid; g * 8 < np; g += MZ_THREADS) {
+      uint32_t h[16]; uint8_t f[16];
+      {
+        const uint4 a = g ? *reinterpret_cast<const uint4*>(hsh + 8 * g - 8) : make_uint4(0, 0, 0, 0);
+        const uint4 b = g ? *reinterpret_cast<const uint4*>(hsh + 8 * g - 4) : make_uint4(0, 0, 0, 0);
+        const uint4 c = *reinterpret_cast<const uint4*>(hsh + 8 * g), d = *reinterpret_cast<const uint4*>(hsh + 8 * g + 4);
+        h[0] = a.x; h[1] = a.y; h[2] = a.z; h[3] = a.w; h[4] = b.x; h[5] = b.y; h[6] = b.z; h[7] = b.w;
+        h[8] = c.x; h[9] = c.y; h[10] = c.z; h[11] = c.w; h[12] = d.x; h[13] = d.y; h[14] = d.z; h[15] = d.w;
+        const uint64_t fa = g ? *reinterpret_cast<const uint64_t*>(flg + 8 * g - 8) : 0ull, fb = *reinterpret_cast<const uint64_t*>(flg + 8 * g);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { f[t] = (uint8_t)(fa >> (8 * t)); f[8 + t] = (uint8_t)(fb >> (8 * t)); }
+      }
+      // key = hash << 8 | (255 - slot) for non-symmetric positions, all ones otherwise: the minimum over a window is its
+      // smallest hash, the rightmost one among equals — found for all eight windows at once by doubling (windows of 2, 4, 8)
+      uint64_t key[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) key[t] = (f[t] & 1) ? ((uint64_t)h[t] << 8) | (uint64_t)(255 - t) : ~0ull;
+      uint64_t res[8];
+      auto mn = [](uint64_t a, uint64_t b) { return a < b ? a : b; };
+      auto windows = [&](auto wtag) {
+        constexpr int W = decltype(wtag)::value;
+        uint64_t m1[16], m2[16], m4[16];
+#pragma unroll
+        for (int t = 1; t < 16; ++t) m1[t] = mn(key[t], key[t - 1]);
+#pragma unroll
+        for (int t = 3; t < 16; ++t) m2[t] = mn(m1[t], m1[t - 2]);
+#pragma unroll
+        for (int t = 7; t < 16; ++t) m4[t] = mn(m2[t], m2[t - 4]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int t = 8 + i;
+          if constexpr (W == 1) res[i] = key[t];
+          else if constexpr (W == 2) res[i] = m1[t];
+          else if constexpr (W == 3) res[i] = mn(m1[t], m1[t - 1]);
+          else if constexpr (W == 4) res[i] = m2[t];
+          else if constexpr (W < 8) res[i] = mn(m2[t], m2[t - (W - 4)]);
+          else if constexpr (W == 8) res[i] = m4[t];
+          else res[i] = mn(m4[t], m4[t - 1]);
+        }
+      };
+      switch (w) {
+        case 1: windows(std::integral_constant<int, 1>{}); break;
+        case 2: windows(std::integral_constant<int, 2>{}); break;
+        case 3: windows(std::integral_constant<int, 3>{}); break;
+        case 4: windows(std::integral_constant<int, 4>{}); break;
+        case 5: windows(std::integral_constant<int, 5>{}); break;
+        case 6: windows(std::integral_constant<int, 6>{}); break;
+        case 7: windows(std::integral_constant<int, 7>{}); break;
+        case 8: windows(std::integral_constant<int, 8>{}); break;
+        default: windows(std::integral_constant<int, 9>{}); break;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = 8 * g + i;
+        if (j < jeval0 || j >= np) continue;
+        cps[j] = (f[8 + i] & 1) ? (uint16_t)(8 * g - 8 + 255 - (int)(res[i] & 0xffu)) : (uint16_t)0xFFFF;
+      }
+    }
+  } else
   for (int j = jeval0 + tid; j < np; j += MZ_THREADS) {
     uint16_t c = 0xFFFF;
     if (flg[j] & 1) {
@@ -223,6 +293,7 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
     cps[j] = c;
   }
   __syncthreads();
+  if (dbgs == 3) { if (MODE != 1 && tid == 0) tile_count[tile] = 0; return; }
   // 4. emission flags for the tile's own positions, 8 consecutive positions per thread
   const int js = jstar[s];
   const int j0 = (P0 - H0) + tid * (MZ_TILE / MZ_THREADS);
@@ -242,6 +313,7 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
   const uint32_t cnt = __popc(mask);
   uint64_t tot;
   uint64_t ex = block_excl_scan_u64(cnt, &tot);
+  if (dbgs == 4) { if (MODE != 1 && tid == 0) tile_count[tile] = 0; return; }
   if (MODE != 1 && tid == 0) tile_count[tile] = (uint32_t)tot;
   if (MODE == 2 && tot > MZ_STAGE) { if (tid == 0) atomicExch(stage_overflow, 1); return; }
   if (MODE != 0) {

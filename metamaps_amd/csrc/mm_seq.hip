@@ -61,6 +61,7 @@ void run_minimizers(mm_ctx* ctx, const mm_seqset* S, int k, int w, const std::ve
   DBuf<int> d_ovf(1); d_ovf.zero(st);
   if (single_pass) {
     stage.alloc((size_t)ntiles * MZ_STAGE);
+    { const char* e = getenv("MM_MZ_DBG"); int v = e ? atoi(e) : 0; MM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(mz_dbg_stop), &v, sizeof v, 0, hipMemcpyHostToDevice, st)); }   // timing aid, see mm_minimizer.hpp
     minimizer_kernel<2><<<dim3((unsigned)ntiles), dim3(MZ_THREADS), lds, st>>>(V, d_tf.p, k, w, d_js.p, tcount.p, nullptr, stage.p, nullptr, d_ovf.p);
   } else {
     minimizer_kernel<0><<<dim3((unsigned)ntiles), dim3(MZ_THREADS), lds, st>>>(V, d_tf.p, k, w, d_js.p, tcount.p, nullptr, nullptr, nullptr, nullptr);

@@ -7,7 +7,7 @@ ref = ctx.synth_reference(seed=20260928, n_species=int(os.environ.get("NS", "300
 idx = ctx.index(ref, 16, 8)
 reads, truth = ctx.synth_reads(ref, seed=1000, n_reads=int(os.environ.get("NR", "100000")), read_len=int(os.environ.get("RL", "10000")), sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=100)
 best = None
-for it in range(3):
+for it in range(int(os.environ.get("ITERS", "3"))):
     M = ctx.map_batch(idx, reads, 16, 8)
     st = M.stats()
     M.close()

@@ -154,17 +154,28 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
   {
     const uint64_t g0 = gb + (uint64_t)H0;
     const uint64_t w0 = g0 >> 4, w1 = (g0 + nbytes - 1) >> 4;
+    // sixteen bases per packed word -> two 8-byte ASCII words per strand: the four 2-bit codes of a byte are spread into the
+    // selector bytes of a byte permute over the table "ACGT" (its complement: selector ^ 3).  The tile starts on a multiple of 8
+    // bases, so both halves of a packed word land on 8-byte boundaries of the LDS strings; the last word may run past the
+    // sequence into the 8 spare bytes, which no evaluated position reads.
     for (uint64_t wi = w0 + tid; wi <= w1; wi += MZ_THREADS) {
-      uint32_t word = S.packed[wi];
-      int64_t rel = (int64_t)(wi << 4) - (int64_t)g0;
+      const uint32_t word = S.packed[wi];
+      const int64_t rel = (int64_t)(wi << 4) - (int64_t)g0;    // 0 mod 8
+      uint32_t fq[4], cq[4];
 #pragma unroll
-      for (int b = 0; b < 16; ++b) {
-        int64_t j = rel + b;
-        if (j >= 0 && j < nbytes) {
-          uint32_t c = (word >> (2 * b)) & 3u;
-          fwd[j] = ascii_of_code(c);
-          cmp[j] = ascii_of_code(3u - c);
-        }
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t x = (word >> (8 * q)) & 0xffu;
+        const uint32_t sel = (x | (x << 6) | (x << 12) | (x << 18)) & 0x03030303u;
+        fq[q] = __builtin_amdgcn_perm(0u, 0x54474341u, sel);
+        cq[q] = __builtin_amdgcn_perm(0u, 0x54474341u, sel ^ 0x03030303u);
+      }
+      if (rel >= 0 && rel < nbytes) {
+        *reinterpret_cast<uint64_t*>(fwd + rel) = (uint64_t)fq[0] | ((uint64_t)fq[1] << 32);
+        *reinterpret_cast<uint64_t*>(cmp + rel) = (uint64_t)cq[0] | ((uint64_t)cq[1] << 32);
+      }
+      if (rel + 8 >= 0 && rel + 8 < nbytes) {
+        *reinterpret_cast<uint64_t*>(fwd + rel + 8) = (uint64_t)fq[2] | ((uint64_t)fq[3] << 32);
+        *reinterpret_cast<uint64_t*>(cmp + rel + 8) = (uint64_t)cq[2] | ((uint64_t)cq[3] << 32);
       }
     }
     __syncthreads();

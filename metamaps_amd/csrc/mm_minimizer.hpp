@@ -58,7 +58,23 @@ __device__ inline uint8_t ascii_at(const SeqView& S, uint64_t g) {
 
 struct KmerInfo { uint32_t hash; bool ns; bool fwd; };
 // serial (one thread) evaluation of one position; used only by the jstar walk
+// eight 2-bit codes (low 16 bits of x) -> eight ASCII bytes; comp: the complementary bases
+__device__ inline uint64_t ascii8_of_codes(uint32_t x, bool comp) {
+  const uint32_t flip = comp ? 0x03030303u : 0u;
+  const uint32_t a = x & 0xffu, b = (x >> 8) & 0xffu;
+  const uint32_t sa = ((a | (a << 6) | (a << 12) | (a << 18)) & 0x03030303u) ^ flip, sb = ((b | (b << 6) | (b << 12) | (b << 18)) & 0x03030303u) ^ flip;
+  return (uint64_t)__builtin_amdgcn_perm(0u, 0x54474341u, sa) | ((uint64_t)__builtin_amdgcn_perm(0u, 0x54474341u, sb) << 32);
+}
 __device__ inline KmerInfo kmer_info_serial(const SeqView& S, uint64_t gbase, int p, int k) {
+  if (k == 16 && S.n_exc == 0) {                                // sixteen codes straddle at most two packed words
+    const uint64_t g = gbase + (uint64_t)p;
+    const uint32_t off = (uint32_t)(g & 15), w0 = S.packed[g >> 4], w1 = off ? S.packed[(g >> 4) + 1] : 0u;
+    const uint32_t codes = off ? (w0 >> (2 * off)) | (w1 << (32 - 2 * off)) : w0;
+    const uint64_t lo = ascii8_of_codes(codes, false), hi = ascii8_of_codes(codes >> 16, false);
+    const uint64_t clo = ascii8_of_codes(codes, true), chi = ascii8_of_codes(codes >> 16, true);
+    const uint32_t hf = murmur16(lo, hi), hb = murmur16(__builtin_bswap64(chi), __builtin_bswap64(clo));
+    return KmerInfo{hf < hb ? hf : hb, hf != hb, hf < hb};
+  }
   uint8_t f[MZ_MAX_K], c[MZ_MAX_K];
   for (int j = 0; j < k; ++j) { f[j] = ascii_at(S, gbase + p + j); c[j] = complement_ascii(f[j]); }
   uint32_t hf = murmur_bytes<false>(f, k), hb = murmur_bytes<true>(c + k - 1, k);

@@ -591,24 +591,49 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     for (auto& c : cnt) if (c == 1) c = 2;
     for (auto& cls : make_classes(cnt, 256)) {
       DBuf<int32_t> list(cls.reads.size());
-      list.upload(cls.reads.data(), cls.reads.size(), st);
       if (cls.npow2 <= 16384) {                                  // radix sort in LDS: 4 ... 64 elements per thread
-        const unsigned nb = (unsigned)cls.reads.size();
-        auto launch = [&](auto ipt_tag) {
-          constexpr int IPT = decltype(ipt_tag)::value;
-          using SortT = rocprim::block_radix_sort<uint32_t, 256, IPT, uint16_t>;
-          using ScanT = rocprim::block_scan<int, 256>;
-          const size_t lds = std::max(sizeof(typename SortT::storage_type), sizeof(typename ScanT::storage_type)) + 16;
-          if (lds > 48 * 1024) MM_HIP(hipFuncSetAttribute((const void*)sketch_radix_kernel<IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          sketch_radix_kernel<IPT><<<dim3(nb), dim3(256), lds, st>>>(M->mz.rec.p, M->mz.off.p, list.p, M->sk_hash.p, M->sk_strand.p, M->sk_n.p, M->amb.p);
-        };
-        if (cls.npow2 <= 1024) launch(std::integral_constant<int, 4>{});
-        else if (cls.npow2 <= 2048) launch(std::integral_constant<int, 8>{});
-        else if (cls.npow2 <= 4096) launch(std::integral_constant<int, 16>{});
-        else if (cls.npow2 <= 8192) launch(std::integral_constant<int, 32>{});
-        else launch(std::integral_constant<int, 64>{});
-        MM_KERNEL_CHECK();
-      } else if (cls.npow2 <= LDS_SORT_MAX) {
+        // the sort's cost follows the elements per thread, so the reads of a power-of-two class are split by the
+        // capacity they really need (a 10 kb read has ~2 200 minimizers: 10 per thread instead of 16)
+        static const int ipts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48, 64};
+        std::map<int, std::vector<int32_t>> by_ipt;
+        for (int32_t r : cls.reads) { int need = (int)((cnt[(size_t)r] + 255) / 256), ip = 64; for (int v : ipts) if (v >= need) { ip = v; break; } by_ipt[ip].push_back(r); }
+        std::vector<int32_t> ordered; std::vector<std::pair<int, size_t>> runs;   // (IPT, number of reads), lists back to back in `list`
+        for (auto& kv : by_ipt) { runs.emplace_back(kv.first, kv.second.size()); ordered.insert(ordered.end(), kv.second.begin(), kv.second.end()); }
+        list.upload(ordered.data(), ordered.size(), st);
+        size_t at = 0;
+        for (auto& run : runs) {
+          const unsigned nb = (unsigned)run.second;
+          const int32_t* lp = list.p + at;
+          auto launch = [&](auto ipt_tag) {
+            constexpr int IPT = decltype(ipt_tag)::value;
+            using SortT = rocprim::block_radix_sort<uint32_t, 256, IPT, uint16_t>;
+            using ScanT = rocprim::block_scan<int, 256>;
+            const size_t lds = std::max(sizeof(typename SortT::storage_type), sizeof(typename ScanT::storage_type)) + 16;
+            if (lds > 48 * 1024) MM_HIP(hipFuncSetAttribute((const void*)sketch_radix_kernel<IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            sketch_radix_kernel<IPT><<<dim3(nb), dim3(256), lds, st>>>(M->mz.rec.p, M->mz.off.p, lp, M->sk_hash.p, M->sk_strand.p, M->sk_n.p, M->amb.p);
+          };
+          switch (run.first) {
+            case 4: launch(std::integral_constant<int, 4>{}); break;
+            case 6: launch(std::integral_constant<int, 6>{}); break;
+            case 8: launch(std::integral_constant<int, 8>{}); break;
+            case 10: launch(std::integral_constant<int, 10>{}); break;
+            case 12: launch(std::integral_constant<int, 12>{}); break;
+            case 16: launch(std::integral_constant<int, 16>{}); break;
+            case 20: launch(std::integral_constant<int, 20>{}); break;
+            case 24: launch(std::integral_constant<int, 24>{}); break;
+            case 32: launch(std::integral_constant<int, 32>{}); break;
+            case 40: launch(std::integral_constant<int, 40>{}); break;
+            case 48: launch(std::integral_constant<int, 48>{}); break;
+            default: launch(std::integral_constant<int, 64>{}); break;
+          }
+          MM_KERNEL_CHECK();
+          at += run.second;
+        }
+        MM_HIP(hipStreamSynchronize(st));                        // `ordered` is the source of the async upload
+        continue;
+      }
+      list.upload(cls.reads.data(), cls.reads.size(), st);
+      if (cls.npow2 <= LDS_SORT_MAX) {
         size_t lds = (size_t)cls.npow2 * 8;
         if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)sketch_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         sketch_kernel<true><<<dim3((unsigned)cls.reads.size()), dim3(256), lds, st>>>(M->mz.rec.p, M->mz.off.p, list.p, cls.npow2, nullptr,

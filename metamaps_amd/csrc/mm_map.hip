@@ -355,6 +355,10 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   if (!WRITE && threadIdx.x == 0) surv_n[r] = cursor;
 }
 
+__global__ void __launch_bounds__(256) copy_ranges_kernel(const uint64_t* __restrict__ src, const uint64_t* __restrict__ rb, const uint64_t* __restrict__ re,
+                                                          uint64_t* __restrict__ dst) {
+  for (uint64_t i = rb[blockIdx.x] + threadIdx.x; i < re[blockIdx.x]; i += 256) dst[i] = src[i];
+}
 // sum of the probe counts (= raw seed hits of the batch); the filter path needs no per-list offsets, only this total
 __global__ void __launch_bounds__(256) sum_u32_kernel(const uint32_t* __restrict__ v, int64_t n, unsigned long long* __restrict__ out) {
   unsigned long long acc = 0;
@@ -834,8 +838,23 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         sort_hits_kernel<true><<<dim3((unsigned)cls.reads.size()), dim3(256), lds, st>>>(M->hits.p, M->read_hit_off.p, list.p, cls.npow2, nullptr);
         MM_KERNEL_CHECK();
         MM_HIP(hipStreamSynchronize(st));
+      } else if (total_hits < (int64_t)0xffffffffll && !getenv("MM_HITS_BITONIC")) {
+        // large segments (more than 16 384 surviving hits: reads beyond ~70 kb): the device's segmented radix sort over exactly
+        // these reads' ranges of hits[], through a scratch copy (the bitonic network through global memory took 0.5 s for a
+        // few hundred such reads)
+        std::vector<uint64_t> hb, he;
+        for (int32_t r : cls.reads) { hb.push_back(M->h_read_hit_off[(size_t)r]); he.push_back(M->h_read_hit_off[(size_t)r + 1]); }
+        DBuf<uint64_t> d_hb(hb.size()), d_he(he.size()), sorted((size_t)total_hits);
+        d_hb.upload(hb.data(), hb.size(), st); d_he.upload(he.data(), he.size(), st);
+        size_t tmp_bytes = 0;
+        MM_HIP(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, M->hits.p, sorted.p, (unsigned int)total_hits, (unsigned int)hb.size(), d_hb.p, d_he.p, 0, 64, st));
+        DBuf<uint8_t> tmp(std::max<size_t>(tmp_bytes, 16));
+        MM_HIP(rocprim::segmented_radix_sort_keys((void*)tmp.p, tmp_bytes, M->hits.p, sorted.p, (unsigned int)total_hits, (unsigned int)hb.size(), d_hb.p, d_he.p, 0, 64, st));
+        copy_ranges_kernel<<<dim3((unsigned)hb.size()), dim3(256), 0, st>>>(sorted.p, d_hb.p, d_he.p, M->hits.p);
+        MM_KERNEL_CHECK();
+        MM_HIP(hipStreamSynchronize(st));
       } else {
-        // large segments: a few reads at a time through a global scratch buffer
+        // (fallback) a few reads at a time through a global scratch buffer
         const size_t per = (size_t)cls.npow2;
         const size_t group = std::max<size_t>(1, std::min<size_t>(cls.reads.size(), ((size_t)1 << 28) / per));
         DBuf<uint64_t> scratch(per * group);

@@ -832,14 +832,14 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     for (auto& cls : make_classes(hc, 256)) {
       DBuf<int32_t> list(cls.reads.size());
       list.upload(cls.reads.data(), cls.reads.size(), st);
-      if (cls.npow2 <= LDS_SORT_MAX) {
+      if (cls.npow2 <= (getenv("MM_SEGSORT_FROM") ? atoi(getenv("MM_SEGSORT_FROM")) : 4096)) {   // beyond 4096 hits the device's segmented radix sort is faster (50 kb reads: 7.9 -> 7.0 ms); below, the LDS network (10 kb: 2.2 vs 3.9 ms)
         size_t lds = (size_t)cls.npow2 * 8;
         if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)sort_hits_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         sort_hits_kernel<true><<<dim3((unsigned)cls.reads.size()), dim3(256), lds, st>>>(M->hits.p, M->read_hit_off.p, list.p, cls.npow2, nullptr);
         MM_KERNEL_CHECK();
         MM_HIP(hipStreamSynchronize(st));
       } else if (total_hits < (int64_t)0xffffffffll && !getenv("MM_HITS_BITONIC")) {
-        // large segments (more than 16 384 surviving hits: reads beyond ~70 kb): the device's segmented radix sort over exactly
+        // large segments (more than 4 096 surviving hits: reads beyond ~30 kb): the device's segmented radix sort over exactly
         // these reads' ranges of hits[], through a scratch copy (the bitonic network through global memory took 0.5 s for a
         // few hundred such reads)
         std::vector<uint64_t> hb, he;

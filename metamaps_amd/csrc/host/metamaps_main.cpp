@@ -124,7 +124,7 @@ class SeqFile {
       }
     }
     pending_ = 0;
-    return true;
+    return got == seq.size();                                    // truncated quality string: kseq returns -2 and the callers' loops end (kseq.h:204)
   }
 };
 
@@ -476,8 +476,10 @@ int map_mode(const Options& o, const std::string& mode) {
       ++F.total;
       const int len = lens[r];
       if (len < w || len < k || len < minLen) { ++F.tooShort; continue; }
-      if (!F.seen.insert(names[r]).second) die("Seems that read ID " + names[r] + " has already been processed");   // mapWrap.h:71-75
-      if (off[r] == off[r + 1]) { ++F.notMapped; F.unm << len << "\t" << names[r] << "\n"; continue; }
+      // mapWrap.h:71-75 checks the IDs of mapping LINES against the reads already handled: a repeated ID only stops the run
+      // when the repeat carries mappings; every handled read's ID is remembered (:154-157)
+      if (off[r] == off[r + 1]) { ++F.notMapped; F.unm << len << "\t" << names[r] << "\n"; F.seen.insert(names[r]); continue; }
+      if (!F.seen.insert(names[r]).second) die("Seems that read ID " + names[r] + " has already been processed");
       ++F.mapped;
       for (int64_t i = off[r]; i < off[r + 1]; ++i) {
         const mm_map_record& x = rec[(size_t)i];

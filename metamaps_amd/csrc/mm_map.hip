@@ -355,9 +355,11 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   if (!WRITE && threadIdx.x == 0) surv_n[r] = cursor;
 }
 
-__global__ void __launch_bounds__(256) copy_ranges_kernel(const uint64_t* __restrict__ src, const uint64_t* __restrict__ rb, const uint64_t* __restrict__ re,
-                                                          uint64_t* __restrict__ dst) {
-  for (uint64_t i = rb[blockIdx.x] + threadIdx.x; i < re[blockIdx.x]; i += 256) dst[i] = src[i];
+// range blockIdx.x of src, [sb, se), goes to dst starting at db
+__global__ void __launch_bounds__(256) move_ranges_kernel(const uint64_t* __restrict__ src, const uint64_t* __restrict__ sb, const uint64_t* __restrict__ se,
+                                                          uint64_t* __restrict__ dst, const uint64_t* __restrict__ db) {
+  const uint64_t s0 = sb[blockIdx.x], n = se[blockIdx.x] - s0, d0 = db[blockIdx.x];
+  for (uint64_t i = threadIdx.x; i < n; i += 256) dst[d0 + i] = src[s0 + i];
 }
 // sum of the probe counts (= raw seed hits of the batch); the filter path needs no per-list offsets, only this total
 __global__ void __launch_bounds__(256) sum_u32_kernel(const uint32_t* __restrict__ v, int64_t n, unsigned long long* __restrict__ out) {
@@ -555,9 +557,11 @@ struct StageTimer {
 };
 }  // namespace
 
+// one host-side duplicate-hash tie-break in flight (owned by map_batch's frame, never by its worker thread)
 struct AmbState {
-  std::vector<int64_t> reads; std::vector<uint64_t> dof; DBuf<uint64_t> d_so, d_do;
-  std::vector<uint8_t> sv; std::vector<int32_t> scnt; std::atomic<int> mismatch{0}; std::thread bg;
+  std::thread bg;                          // (the destructor body joins it before any member is destroyed)
+  std::vector<Rec> hr; std::vector<uint64_t> dof; std::vector<int32_t> expect; DBuf<uint64_t> d_so, d_do;
+  std::vector<uint8_t> sv; std::vector<int32_t> scnt; std::atomic<int> mismatch{0};
   ~AmbState() { if (bg.joinable()) bg.join(); }
 };
 
@@ -676,69 +680,66 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     for (int64_t r = 0; r < n; ++r) if (h_amb[(size_t)r]) ((h_amb[(size_t)r] == 2 && !all_eager) ? lazy_reads : eager_reads).push_back(r);
     M->stats.n_ambiguous_sketch_reads = (int64_t)(eager_reads.size() + lazy_reads.size());
   }
+  // The tie-break states live in this frame: whatever way map_batch is left (return, MM_REQUIRE, a failed allocation), their
+  // destructors join the worker first and release the device buffers on this thread.  The worker only sees a raw pointer and
+  // its own copies of the host data it reads.
+  std::vector<std::unique_ptr<AmbState>> amb_states;
   // starts the host work for `amb_reads` on background threads and returns the closure that joins it and patches the strands
   auto start_tiebreak = [&](const std::vector<int64_t>& amb_reads) -> std::function<void()> {
-    std::function<void()> amb_finish;
-    {
-      const size_t na = amb_reads.size();
-      std::vector<uint64_t> so(na), dof(na + 1, 0);
-      for (size_t i = 0; i < na; ++i) {
-        int64_t r = amb_reads[i];
-        so[i] = hoff[(size_t)r];
-        dof[i + 1] = dof[i] + (hoff[(size_t)r + 1] - hoff[(size_t)r]);
-      }
-      DBuf<uint64_t> d_so(na), d_do(na + 1);
-      d_so.upload(so.data(), na, st); d_do.upload(dof.data(), na + 1, st);
-      DBuf<Rec> comp((size_t)dof[na]);
-      gather_amb_kernel<<<dim3((unsigned)na), dim3(256), 0, st>>>(M->mz.rec.p, d_so.p, d_do.p, comp.p);
-      MM_KERNEL_CHECK();
-      // The library sort of ~1 % of the reads is the only per-read host work of a batch.  Only the L2 strand vote needs its
-      // result, so it runs on host threads while the device goes through K3 and K4.
-      auto hr = std::make_shared<std::vector<Rec>>(comp.to_host(st));
-      auto st_amb = std::make_shared<AmbState>();
-      st_amb->reads = amb_reads; st_amb->dof = dof; st_amb->d_so = std::move(d_so); st_amb->d_do = std::move(d_do);
-      // host part (no device calls): starts now on its own threads; joined right before the L2 launch
-      st_amb->sv.assign((size_t)dof[na], 0);
-      st_amb->scnt.assign(na, 0);
-      st_amb->bg = std::thread([this_M = M, hr, st_amb]() {
-        const mm_mapping* M = this_M;
-        const std::vector<int64_t>& amb_reads = st_amb->reads;
-        const std::vector<uint64_t>& dof = st_amb->dof;
-        const size_t na = amb_reads.size();
-        std::atomic<size_t> next{0};
-        auto worker = [&]() {
-          std::vector<HostMz> v;
-          for (size_t i = next.fetch_add(1); i < na; i = next.fetch_add(1)) {
-            const size_t cntr = (size_t)(dof[i + 1] - dof[i]);
-            v.resize(cntr);
-            for (size_t j = 0; j < cntr; ++j) { const Rec& x = (*hr)[(size_t)dof[i] + j]; v[j] = HostMz{x.hash, pw_wpos(x.pw), pw_strand(x.pw)}; }
-            std::sort(v.begin(), v.end(), host_less_by_hash);
-            auto ue = std::unique(v.begin(), v.end(), host_eq_by_hash);
-            const size_t sN = (size_t)(ue - v.begin());
-            if ((int64_t)sN != M->h_sk_n[(size_t)amb_reads[i]]) st_amb->mismatch = 1;
-            for (size_t j = 0; j < sN; ++j) st_amb->sv[(size_t)dof[i] + j] = v[j].strand == 1 ? 1 : 0;
-            st_amb->scnt[i] = (int32_t)sN;
-          }
-        };
-        const unsigned nthr = std::max(1u, std::min(32u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)((na + 15) / 16))));
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
-        worker();
-        for (auto& t : pool) t.join();
-      });
-      amb_finish = [this_M = M, st_amb, st]() {
-        mm_mapping* M = this_M;
-        st_amb->bg.join();
-        MM_REQUIRE(st_amb->mismatch == 0, MM_ERR_DEVICE, "sketch size disagrees between device and host tie-break");
-        const size_t na = st_amb->reads.size();
-        DBuf<uint8_t> d_sv(st_amb->sv.size()); d_sv.upload(st_amb->sv.data(), st_amb->sv.size(), st);
-        DBuf<int32_t> d_cnt(na); d_cnt.upload(st_amb->scnt.data(), na, st);
-        scatter_strand_kernel<<<dim3((unsigned)na), dim3(256), 0, st>>>(d_sv.p, st_amb->d_so.p, st_amb->d_do.p, d_cnt.p, M->sk_strand.p);
-        MM_KERNEL_CHECK();
-        MM_HIP(hipStreamSynchronize(st));                        // host vectors above are the H2D sources
-      };
+    const size_t na = amb_reads.size();
+    std::vector<uint64_t> so(na), dof(na + 1, 0);
+    std::vector<int32_t> expect(na);
+    for (size_t i = 0; i < na; ++i) {
+      int64_t r = amb_reads[i];
+      so[i] = hoff[(size_t)r];
+      dof[i + 1] = dof[i] + (hoff[(size_t)r + 1] - hoff[(size_t)r]);
+      expect[i] = M->h_sk_n[(size_t)r];
     }
-    return amb_finish;
+    DBuf<uint64_t> d_so(na), d_do(na + 1);
+    d_so.upload(so.data(), na, st); d_do.upload(dof.data(), na + 1, st);
+    DBuf<Rec> comp((size_t)dof[na]);
+    gather_amb_kernel<<<dim3((unsigned)na), dim3(256), 0, st>>>(M->mz.rec.p, d_so.p, d_do.p, comp.p);
+    MM_KERNEL_CHECK();
+    // The library sort of ~1 % of the reads is the only per-read host work of a batch.  Only the L2 strand vote needs its
+    // result, so it runs on host threads while the device goes through K3 and K4.
+    amb_states.push_back(std::make_unique<AmbState>());
+    AmbState* const A = amb_states.back().get();
+    A->hr = comp.to_host(st);
+    A->dof = dof; A->expect = std::move(expect); A->d_so = std::move(d_so); A->d_do = std::move(d_do);
+    A->sv.assign((size_t)dof[na], 0);
+    A->scnt.assign(na, 0);
+    // host part (no device calls): starts now on its own threads; joined right before the L2 launch
+    A->bg = std::thread([A, na]() {
+      std::atomic<size_t> next{0};
+      auto worker = [&]() {
+        std::vector<HostMz> v;
+        for (size_t i = next.fetch_add(1); i < na; i = next.fetch_add(1)) {
+          const size_t cntr = (size_t)(A->dof[i + 1] - A->dof[i]);
+          v.resize(cntr);
+          for (size_t j = 0; j < cntr; ++j) { const Rec& x = A->hr[(size_t)A->dof[i] + j]; v[j] = HostMz{x.hash, pw_wpos(x.pw), pw_strand(x.pw)}; }
+          std::sort(v.begin(), v.end(), host_less_by_hash);
+          auto ue = std::unique(v.begin(), v.end(), host_eq_by_hash);
+          const size_t sN = (size_t)(ue - v.begin());
+          if ((int64_t)sN != A->expect[i]) A->mismatch = 1;
+          for (size_t j = 0; j < sN; ++j) A->sv[(size_t)A->dof[i] + j] = v[j].strand == 1 ? 1 : 0;
+          A->scnt[i] = (int32_t)sN;
+        }
+      };
+      const unsigned nthr = std::max(1u, std::min(32u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)((na + 15) / 16))));
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
+      worker();
+      for (auto& t : pool) t.join();
+    });
+    return [M, A, na, st]() {
+      if (A->bg.joinable()) A->bg.join();
+      MM_REQUIRE(A->mismatch == 0, MM_ERR_DEVICE, "sketch size disagrees between device and host tie-break");
+      DBuf<uint8_t> d_sv(A->sv.size()); d_sv.upload(A->sv.data(), A->sv.size(), st);
+      DBuf<int32_t> d_cnt(na); d_cnt.upload(A->scnt.data(), na, st);
+      scatter_strand_kernel<<<dim3((unsigned)na), dim3(256), 0, st>>>(d_sv.p, A->d_so.p, A->d_do.p, d_cnt.p, M->sk_strand.p);
+      MM_KERNEL_CHECK();
+      MM_HIP(hipStreamSynchronize(st));                          // host vectors above are the H2D sources
+    };
   };
   if (!eager_reads.empty()) amb_finish = start_tiebreak(eager_reads);
   // ---- K7 host thresholds per distinct sketch size
@@ -829,28 +830,19 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     // ---- K4a
     std::vector<int64_t> hc((size_t)n);
     for (int64_t r = 0; r < n; ++r) hc[(size_t)r] = (int64_t)(M->h_read_hit_off[(size_t)r + 1] - M->h_read_hit_off[(size_t)r]);
+    // beyond 4096 hits the device's segmented radix sort is faster (50 kb reads: 7.9 -> 7.0 ms); below, the LDS network (10 kb: 2.2 vs 3.9 ms)
+    const char* ss_env = getenv("MM_SEGSORT_FROM");
+    const int segsort_from = std::min(ss_env ? atoi(ss_env) : 4096, LDS_SORT_MAX);
+    const bool seg_ok = total_hits < (int64_t)0xffffffffll && !getenv("MM_HITS_BITONIC");
+    std::vector<int32_t> seg_reads;                               // reads of every class handled by the segmented sort: one call for all
     for (auto& cls : make_classes(hc, 256)) {
+      if (cls.npow2 > segsort_from && seg_ok) { seg_reads.insert(seg_reads.end(), cls.reads.begin(), cls.reads.end()); continue; }
       DBuf<int32_t> list(cls.reads.size());
       list.upload(cls.reads.data(), cls.reads.size(), st);
-      if (cls.npow2 <= (getenv("MM_SEGSORT_FROM") ? atoi(getenv("MM_SEGSORT_FROM")) : 4096)) {   // beyond 4096 hits the device's segmented radix sort is faster (50 kb reads: 7.9 -> 7.0 ms); below, the LDS network (10 kb: 2.2 vs 3.9 ms)
+      if (cls.npow2 <= LDS_SORT_MAX) {
         size_t lds = (size_t)cls.npow2 * 8;
         if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)sort_hits_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         sort_hits_kernel<true><<<dim3((unsigned)cls.reads.size()), dim3(256), lds, st>>>(M->hits.p, M->read_hit_off.p, list.p, cls.npow2, nullptr);
-        MM_KERNEL_CHECK();
-        MM_HIP(hipStreamSynchronize(st));
-      } else if (total_hits < (int64_t)0xffffffffll && !getenv("MM_HITS_BITONIC")) {
-        // large segments (more than 4 096 surviving hits: reads beyond ~30 kb): the device's segmented radix sort over exactly
-        // these reads' ranges of hits[], through a scratch copy (the bitonic network through global memory took 0.5 s for a
-        // few hundred such reads)
-        std::vector<uint64_t> hb, he;
-        for (int32_t r : cls.reads) { hb.push_back(M->h_read_hit_off[(size_t)r]); he.push_back(M->h_read_hit_off[(size_t)r + 1]); }
-        DBuf<uint64_t> d_hb(hb.size()), d_he(he.size()), sorted((size_t)total_hits);
-        d_hb.upload(hb.data(), hb.size(), st); d_he.upload(he.data(), he.size(), st);
-        size_t tmp_bytes = 0;
-        MM_HIP(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, M->hits.p, sorted.p, (unsigned int)total_hits, (unsigned int)hb.size(), d_hb.p, d_he.p, 0, 64, st));
-        DBuf<uint8_t> tmp(std::max<size_t>(tmp_bytes, 16));
-        MM_HIP(rocprim::segmented_radix_sort_keys((void*)tmp.p, tmp_bytes, M->hits.p, sorted.p, (unsigned int)total_hits, (unsigned int)hb.size(), d_hb.p, d_he.p, 0, 64, st));
-        copy_ranges_kernel<<<dim3((unsigned)hb.size()), dim3(256), 0, st>>>(sorted.p, d_hb.p, d_he.p, M->hits.p);
         MM_KERNEL_CHECK();
         MM_HIP(hipStreamSynchronize(st));
       } else {
@@ -863,6 +855,45 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           sort_hits_kernel<false><<<dim3((unsigned)g), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, list.p + g0, cls.npow2, scratch.p);
           MM_KERNEL_CHECK();
         }
+        MM_HIP(hipStreamSynchronize(st));
+      }
+    }
+    if (!seg_reads.empty()) {
+      // large segments (reads beyond ~30 kb): the device's segmented radix sort over exactly these reads' ranges (the bitonic
+      // network through global memory took 0.5 s for a few hundred such reads).  When they are a minority of the batch their
+      // ranges are gathered into a compact buffer first, so that the scratch is twice their hits instead of a copy of all hits.
+      std::sort(seg_reads.begin(), seg_reads.end());
+      const size_t ns = seg_reads.size();
+      std::vector<uint64_t> hb(ns), he(ns), cb(ns), ce(ns);
+      uint64_t run = 0;
+      for (size_t i = 0; i < ns; ++i) {
+        const int32_t r = seg_reads[i];
+        hb[i] = M->h_read_hit_off[(size_t)r]; he[i] = M->h_read_hit_off[(size_t)r + 1];
+        cb[i] = run; run += he[i] - hb[i]; ce[i] = run;
+      }
+      const bool compact = 2 * run <= (uint64_t)total_hits;
+      DBuf<uint64_t> d_hb(ns), d_he(ns), d_cb(ns), d_ce(ns);
+      d_hb.upload(hb.data(), ns, st); d_he.upload(he.data(), ns, st);
+      auto seg_sort = [&](uint64_t* in, uint64_t* out, uint64_t count, uint64_t* begins, uint64_t* ends) {
+        size_t tmp_bytes = 0;
+        MM_HIP(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, in, out, (unsigned int)count, (unsigned int)ns, begins, ends, 0, 64, st));
+        DBuf<uint8_t> tmp(std::max<size_t>(tmp_bytes, 16));
+        MM_HIP(rocprim::segmented_radix_sort_keys((void*)tmp.p, tmp_bytes, in, out, (unsigned int)count, (unsigned int)ns, begins, ends, 0, 64, st));
+      };
+      if (compact) {
+        d_cb.upload(cb.data(), ns, st); d_ce.upload(ce.data(), ns, st);
+        DBuf<uint64_t> packed((size_t)run), sorted((size_t)run);
+        move_ranges_kernel<<<dim3((unsigned)ns), dim3(256), 0, st>>>(M->hits.p, d_hb.p, d_he.p, packed.p, d_cb.p);
+        MM_KERNEL_CHECK();
+        seg_sort(packed.p, sorted.p, run, d_cb.p, d_ce.p);
+        move_ranges_kernel<<<dim3((unsigned)ns), dim3(256), 0, st>>>(sorted.p, d_cb.p, d_ce.p, M->hits.p, d_hb.p);
+        MM_KERNEL_CHECK();
+        MM_HIP(hipStreamSynchronize(st));
+      } else {
+        DBuf<uint64_t> sorted((size_t)total_hits);
+        seg_sort(M->hits.p, sorted.p, (uint64_t)total_hits, d_hb.p, d_he.p);
+        move_ranges_kernel<<<dim3((unsigned)ns), dim3(256), 0, st>>>(sorted.p, d_hb.p, d_he.p, M->hits.p, d_hb.p);
+        MM_KERNEL_CHECK();
         MM_HIP(hipStreamSynchronize(st));
       }
     }
@@ -1055,6 +1086,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     MM_HIP(hipStreamSynchronize(st));
   } else {
     T.end(t_l1);
+    if (amb_finish) { amb_finish(); amb_finish = nullptr; }
     M->n_rec = 0;
     M->rec.alloc(1);
     M->rec_off.zero(st);

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 1
+#define MM_ABI_VERSION 2
 
 typedef enum {
   MM_OK = 0,
@@ -166,9 +166,9 @@ typedef struct {
    * around the launches; ms_l2 (the K5/K6 kernel) and ms_hit_filter (the counting+filtering K3c kernel, part of
    * ms_probe_gather) are single kernels: bench.py's roofline uses whichever is larger */
   double ms_minimizer, ms_sketch, ms_probe_gather, ms_sort_hits, ms_l1_scan, ms_l2, ms_compact, ms_total, ms_hit_filter;
-  /* reads whose sketch has >= 32768 hashes (longer than ~145 kb at w = 8): beyond the LDS-resident window state of K5, left
-   * unmapped (the reference has no such limit — callers should flag them) */
-  int64_t n_reads_over_limit;
+  /* reads whose sketch has >= 32768 hashes (longer than ~145 kb at w = 8): mapped like every other read, but by the slow
+   * K5 class that keeps its window state in global memory (informational) */
+  int64_t n_reads_giant;
 } mm_map_stats;
 
 int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, mm_mapping** out);

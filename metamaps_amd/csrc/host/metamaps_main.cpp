@@ -439,16 +439,8 @@ int map_mode(const Options& o, const std::string& mode) {
     return reads;
   };
   const mm_map_params mp{k, w, pi, minLen};
-  bool warned_over_limit = false;
   auto map_chunk = [&](const Chunk& ch, mm_seqset* reads) {     // one "PREFIX.N" per chunk in the reference (mapWrap.h:419-437)
     mm_mapping* pm; ck(ctx, mm_map_batch(ctx, ch.idx, reads, &mp, &pm), "map");
-    mm_map_stats ms; mm_mapping_get_stats(pm, &ms);
-    if (ms.n_reads_over_limit > 0 && !warned_over_limit) {
-      warned_over_limit = true;
-      std::cerr << "Warning: reads with 32768 or more sketch hashes (longer than about " << (long long)16384 * (w + 1) / 1000
-                << " kb at window size " << w << ") exceed the device limit of this build and are reported as not mapped ("
-                << ms.n_reads_over_limit << " in the current batch)." << std::endl;
-    }
     if (!o.all) ck(ctx, mm_mapping_keep_best(ctx, pm, k), "best mappings");
     return pm;
   };

@@ -1127,4 +1127,131 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Reads whose sketch does not fit the LDS-resident classes above (>= L2_SKETCH_LIMIT hashes: ~145 kb at w = 8, shorter at
+// smaller w).  The reference sizes its map from the read (computeMap.hpp:228-263, slidingMap.hpp:114-131) and knows no
+// limit, so these take the literal serial automaton (the SKIP=false path above: add_entry / del_entry / slide, exactly the
+// reference's order) with every array in global memory: Q is the read's sketch where K2 left it, D (32-bit gap counters) and
+// the matched bitmap live in a per-wave scratch slot, rank codes come from a plain binary search over Q.  One wave per
+// candidate, a fixed number of resident waves looping over the candidate list.  Slow (one L2 round trip per window step) but
+// exact; such reads are rare.  Their sketches come from the bitonic K2 kernel, so duplicate-hash strands were resolved on the
+// host before this runs (mm_map.hip: eager tie-break) and the vote needs no "unresolved" bookkeeping.
+// ---------------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t l2_giant_slot_words(int smax) { return (size_t)smax + (size_t)((smax + 31) / 32) + 16; }
+
+__global__ void __launch_bounds__(64) l2_giant_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restrict__ cand_read,
+                                                      const uint32_t* __restrict__ sk_hash, const uint8_t* __restrict__ sk_strand,
+                                                      const uint64_t* __restrict__ mz_off, const int32_t* __restrict__ sk_n,
+                                                      const int32_t* __restrict__ read_len, const int32_t* __restrict__ accept_min,
+                                                      int k, int w, int smax, L2Result* __restrict__ out,
+                                                      const int32_t* __restrict__ cand_list, int n_list, uint32_t* __restrict__ scratch) {
+  const int lane = threadIdx.x & 63;
+  uint32_t* const D = scratch + (size_t)blockIdx.x * l2_giant_slot_words(smax);
+  uint32_t* const mt = D + smax;
+  for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+    const int64_t c = cand_list[li];
+    const int r = cand_read[c];
+    const int s = sk_n[r];
+    const uint64_t qo = mz_off[r];
+    const uint32_t* __restrict__ Q = sk_hash + qo;
+    const int len = read_len[r];
+    const int contig = cand[3 * c], rs = cand[3 * c + 1], re = cand[3 * c + 2];
+    const int cnt = len - (w - 1) - (k - 1);                     // computeMap.hpp:470
+    const int64_t cbeg = (int64_t)I.cstart[contig], cend = (int64_t)I.cstart[contig + 1];
+    const int64_t first0 = wave_lower_bound_wpos(I.pos, cbeg, cend, rs, lane);          // searchIndex, :466
+    const int64_t last0 = wave_lower_bound_wpos(I.pos, first0, cend, re + len, lane);   // :477
+    const Rec* __restrict__ pos = I.pos + first0;
+    const int last_end = (int)(last0 - first0);
+    const int nmax = (int)min((int64_t)0x7fffffff, I.N - 1 - first0);
+    int amin = accept_min[r]; if (amin < 1) amin = 1;
+    for (int i = lane; i < s; i += 64) D[i] = 0;
+    for (int i = lane; i < (s + 31) / 32; i += 64) mt[i] = 0;
+    wave_sync();
+    L2StateT<uint32_t> S{Q, D, mt, s, 0, 0, 0, 0};
+    l2_reset(S);
+    int baseB = 0, baseE = 0;
+    Rec rb = pos[min(lane, nmax)], rE = rb;
+    int codeB = l2_classify(Q, s, rb.hash), codeE = codeB;
+    auto loadB = [&](int nb) { baseB = nb; rb = pos[min(nb + lane, nmax)]; codeB = l2_classify(Q, s, rb.hash); };
+    auto loadE = [&](int ne) { baseE = ne; rE = pos[min(ne + lane, nmax)]; codeE = l2_classify(Q, s, rE.hash); };
+    int b = 0, e = 0, sw_pos = 0;
+    auto add_entry = [&](int x) {                                // slidingMap.hpp:139-160
+      if (x - baseE >= 64 || x < baseE) loadE(x);
+      const int ln = x - baseE;
+      const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)rE.hash, ln);
+      const uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)rE.pw, ln);
+      const int code = __builtin_amdgcn_readlane(codeE, ln);
+      if (code == -(s + 1)) return;                              // above every query hash: never counted
+      if ((pw & PW_DP) && wave_has_hash(pos, b, x, h, lane)) return;   // REV: hash already in the window
+      if (code >= 0) l2_add_matched(S, code); else l2_add_wonly(S, -code - 1);
+    };
+    auto del_entry = [&](int x, int wend) {                      // slidingMap.hpp:170-214
+      const int ln = x - baseB;
+      const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)rb.hash, ln);
+      const uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)rb.pw, ln);
+      const int code = __builtin_amdgcn_readlane(codeB, ln);
+      if (code == -(s + 1)) return;
+      if ((pw & PW_DN) && wave_has_hash(pos, x + 1, wend, h, lane)) return;   // NOOP: a later occurrence stays
+      if (code >= 0) l2_del_matched(S, code); else l2_del_wonly(S, -code - 1);
+    };
+    int best = 0, bestR = 0, beg_pos = 0, last_pos = 0, opt_b = 0, opt_e = 0;
+    unsigned long long evals = 0;
+    {
+      const int first_end = (int)wave_lower_bound_wpos(pos, 0, last_end, pw_wpos(pos[0].pw) + cnt, lane);   // :473
+      loadB(0); loadE(0);
+      for (; e < first_end; ++e) add_entry(e);                   // first super-window, :489
+      sw_pos = pw_wpos(pos[0].pw);                               // MIIteratorL2.hpp:62
+      while (e < last_end) {                                     // computeMap.hpp:496-533 + MIIteratorL2::next
+        if (b + 1 - baseB >= 64 || b < baseB) loadB(b);
+        if (e - baseE >= 64 || e < baseE) loadE(e);
+        const int cur_wb = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rb.pw, b - baseB));
+        if (S.shared > best) { best = S.shared; bestR = S.R; opt_b = b; opt_e = e; beg_pos = last_pos = cur_wb; }   // :510-518
+        else if (S.shared == best) last_pos = cur_wb;            // :520-524
+        ++evals;
+        const int wb1 = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rb.pw, b + 1 - baseB));
+        const int we = pw_wpos((uint32_t)__builtin_amdgcn_readlane((int)rE.pw, e - baseE));
+        const int d_beg = wb1 - sw_pos, d_end = we - (sw_pos + cnt - 1);
+        const int adv = min(d_beg, d_end);                       // MIIteratorL2.hpp:83
+        sw_pos += adv;
+        if (adv == d_beg) { del_entry(b, e); ++b; }
+        if (adv == d_end) { add_entry(e); ++e; }
+      }
+    }
+    // K6 strand vote over the first optimal window (computeMap.hpp:424-433, slidingMap.hpp:232-254)
+    int strand = -1, accepted = 0;
+    if (best >= amin) {
+      accepted = 1;
+      int votes = 0;
+      for (int base = opt_b; base < opt_e; base += 64) {
+        const int j = base + lane;
+        const Rec x = pos[min(j, nmax)];
+        const int code = l2_classify(Q, s, x.hash);
+        const bool cnt_it = j < opt_e && code >= 0 && code < bestR;
+        const int contrib = cnt_it ? ((sk_strand[qo + code] & 1) ? 1 : -1) * pw_strand(x.pw) : 0;
+        const bool flagged = cnt_it && (x.pw & PW_DN);           // a later occurrence exists in the contig: inside the window?
+        if (cnt_it && !flagged) votes += contrib;
+        uint64_t fm = __ballot(flagged);
+        while (fm) {
+          const int l = __ffsll((unsigned long long)fm) - 1;
+          fm &= fm - 1;
+          const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)x.hash, l);
+          const bool later = wave_has_hash(pos, base + l + 1, opt_e, hj, lane);
+          if (!later && lane == l) votes += contrib;
+        }
+      }
+      votes = wave_sum(votes);
+      strand = votes > 0 ? 1 : -1;
+    }
+    if (lane == 0) {
+      L2Result o;
+      o.contig = contig; o.mean_pos = (beg_pos + last_pos) / 2;  // :537
+      o.shared = best; o.strand = strand; o.accepted = accepted; o.pad = 0;
+      o.opt_beg = first0 + opt_b; o.opt_end = first0 + opt_e;
+      o.n_stream = (uint32_t)last_end; o.n_evals = (uint32_t)evals; o.n_rebuilds = 0; o.pad2 = 0;
+      out[c] = o;
+    }
+    wave_sync();
+  }
+}
+
 }  // namespace mm

@@ -81,7 +81,7 @@ template <typename DT> MM_HD void l2_wonly_event(L2StateT<DT>& S, int g, int sig
   int dRm1 = S.D[rm1];
   const uint32_t wR = S.mt[rr >> 5], wRm1 = S.mt[rm1 >> 5];
   dg += sign;
-  if (dg > (int)(DT)~(DT)0) S.overflow = 1;
+  if ((long long)dg > (long long)(DT)~(DT)0) S.overflow = 1;
   S.D[g] = (DT)dg;
   if (g == rr) dR = dg;                         // the cells were read before the update
   if (g == rm1) dRm1 = dg;

@@ -660,12 +660,11 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   M->h_sk_n = M->sk_n.to_host(st, (size_t)n);
   std::vector<uint8_t> h_amb = M->amb.to_host(st, (size_t)n);
   {
-    // Reads whose sketch has >= 32768 hashes (~145 kb at w = 8) are beyond the LDS-resident window state of K5 (below): they
-    // are left without a sketch, i.e. reported as not mapped, and counted in stats.n_reads_over_limit for the caller to flag.
-    int64_t over = 0;
-    for (int64_t r = 0; r < n; ++r) if (M->h_sk_n[(size_t)r] >= L2_SKETCH_LIMIT) { M->h_sk_n[(size_t)r] = 0; h_amb[(size_t)r] = 0; ++over; }
-    M->stats.n_reads_over_limit = over;
-    if (over) { M->sk_n.upload(M->h_sk_n.data(), (size_t)n, st); MM_HIP(hipStreamSynchronize(st)); }
+    // Reads whose sketch has >= 32768 hashes (~145 kb at w = 8) are beyond the LDS-resident window state of the K5 classes:
+    // their candidates go through l2_giant_kernel (state in global memory); counted for the caller's information only.
+    int64_t giant = 0;
+    for (int64_t r = 0; r < n; ++r) if (M->h_sk_n[(size_t)r] >= L2_SKETCH_LIMIT) ++giant;
+    M->stats.n_reads_giant = giant;
   }
   std::function<void()> amb_finish;
   // ---- duplicate-hash strand tie-break (computeMap.hpp:292-295: std::sort is not stable, std::unique keeps
@@ -756,7 +755,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       if (s <= 0) continue;
       auto L = lut.get(s);
       mh[(size_t)r] = L.min_hits; am[(size_t)r] = L.accept_min;
-      smax = std::max(smax, s);
+      if (s < L2_SKETCH_LIMIT) smax = std::max(smax, s);         // (LDS sizing of the K5 classes; larger sketches never enter them)
       M->stats.sum_sketch += s;
     }
     M->smax = smax;
@@ -930,9 +929,16 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     const char* full_env = getenv("MM_L2_FULL");                 // cross-check switch: evaluate every window
     const bool skip = !(full_env && full_env[0] == '1');
     const size_t lds_wide = l2_lds_bytes<uint16_t>(smax, skip, 1, 8);
-    // (>= 32768 sketch hashes: the rebuild's 1024-bucket histogram would be as coarse as the 64-rank pivot zone, and the window
-    //  state of the full slide no longer fits LDS either)
-    MM_REQUIRE(lds_wide <= 160 * 1024 && smax < L2_SKETCH_LIMIT, MM_ERR_LIMIT, "sketch too large for the L2 window state in LDS (read longer than ~145 kb at w=8)");
+    // Sketches of >= 32768 hashes (L2_SKETCH_LIMIT): the rebuild's 1024-bucket histogram would be as coarse as the 64-rank pivot
+    // zone, and the window state of the full slide no longer fits LDS either -> l2_giant_kernel, state in global memory.
+    std::vector<int32_t> listG; int smG = 0;
+    for (int64_t r = 0; r < n; ++r) {
+      const int sr = M->h_sk_n[(size_t)r];
+      if (sr < L2_SKETCH_LIMIT) continue;
+      smG = std::max(smG, sr);
+      for (uint64_t c0 = M->h_cand_off[(size_t)r]; c0 < M->h_cand_off[(size_t)r + 1]; ++c0) listG.push_back((int32_t)c0);
+    }
+    MM_REQUIRE(lds_wide <= 160 * 1024, MM_ERR_LIMIT, "L2 window state does not fit LDS");
     auto set_lds = [&](const void* fn, size_t bytes) { if (bytes > 64 * 1024) MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); };
     DBuf<unsigned long long> counters(16); counters.zero(st);
     if (getenv("MM_L2_STOP") || getenv("MM_L2_PHASES") || getenv("MM_FORCE_AMB_REDO")) {
@@ -944,11 +950,29 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     uint8_t* const amb_used_p = lazy_reads.empty() ? nullptr : amb_used.p;
     if (amb_finish) { amb_finish(); amb_finish = nullptr; }        // strands of ambiguous sketches: needed by the vote only
     const size_t t_l2 = T.begin(&M->stats.ms_l2);
-    if (!skip) {
-      set_lds((const void*)l2_kernel<false, uint16_t, 1, 8>, lds_wide);
-      l2_kernel<false, uint16_t, 1, 8><<<dim3((unsigned)ncand), dim3(64), lds_wide, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-          M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, nullptr, nullptr, nullptr, amb_used_p, nullptr, nullptr);
+    DBuf<int32_t> d_listG(listG.size());
+    DBuf<uint32_t> giant_scratch;
+    if (!listG.empty()) {
+      d_listG.upload(listG.data(), listG.size(), st);
+      const unsigned slots = (unsigned)std::min<size_t>(listG.size(), (size_t)ctx->cus * 8);
+      giant_scratch.alloc((size_t)slots * l2_giant_slot_words(smG));
+      l2_giant_kernel<<<dim3(slots), dim3(64), 0, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p,
+                                                      M->accept_min.p, P.k, P.w, smG, M->l2.p, d_listG.p, (int)listG.size(), giant_scratch.p);
       MM_KERNEL_CHECK();
+    }
+    if (!skip) {
+      std::vector<int32_t> listF;
+      for (int64_t r = 0; r < n; ++r) if (M->h_sk_n[(size_t)r] < L2_SKETCH_LIMIT)
+        for (uint64_t c0 = M->h_cand_off[(size_t)r]; c0 < M->h_cand_off[(size_t)r + 1]; ++c0) listF.push_back((int32_t)c0);
+      DBuf<int32_t> d_listF(listF.size());
+      if (!listF.empty()) {
+        d_listF.upload(listF.data(), listF.size(), st);
+        set_lds((const void*)l2_kernel<false, uint16_t, 1, 8>, lds_wide);
+        l2_kernel<false, uint16_t, 1, 8><<<dim3((unsigned)listF.size()), dim3(64), lds_wide, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, d_listF.p, nullptr, nullptr, amb_used_p, nullptr, nullptr);
+        MM_KERNEL_CHECK();
+      }
+      MM_HIP(hipStreamSynchronize(st));                          // listF is the source of the async upload
     } else {
       // Reads are grouped by sketch size so that one long read does not size the LDS state (and the occupancy) of all:
       //   A  s <= 3072   (reads up to ~14 kb at w=8)  compact: 4 candidates of a read per workgroup share the sketch,
@@ -977,10 +1001,10 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         } else if (sr <= 16384) {
           smD = std::max(smD, sr);
           for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 4) { gD0.push_back((int32_t)c0); gDn.push_back((int32_t)std::min<uint64_t>(4, c_hi - c0)); }
-        } else {
+        } else if (sr < L2_SKETCH_LIMIT) {
           smC = std::max(smC, sr);
           for (uint64_t c0 = c_lo; c0 < c_hi; ++c0) listC.push_back((int32_t)c0);
-        }
+        }                                                        // (larger: listG above)
       }
       DBuf<int32_t> d_gA0(gA0.size()), d_gAn(gAn.size()), d_gB0(gB0.size()), d_gBn(gBn.size()), d_listC(listC.size());
       if (!gA0.empty()) {

@@ -296,19 +296,40 @@ def test_longest_supported_reads_match_oracle(oracle_lib, tmp_path):
     assert sum(1 for _ in open(pa)) >= 3
 
 
-def test_reads_over_the_sketch_limit_are_flagged(tmp_path):
-    """a read whose sketch has >= 32768 hashes (~145 kb at w = 8) is beyond the LDS-resident window state: reported as not
-    mapped with a warning (and counted in mm_map_stats.n_reads_over_limit), the other reads of the batch are unaffected"""
+def _genomes_of(fasta):
+    genomes, cur = [], []
+    for l in open(fasta).read().split("\n"):
+        if l.startswith(">"):
+            if cur: genomes.append("".join(cur)); cur = []
+        elif l: cur.append(l)
+    if cur: genomes.append("".join(cur))
+    return genomes
+
+
+@pytest.mark.parametrize("w_flag", [["-w", "8"], ["-w", "3"]])
+def test_reads_of_any_length_match_oracle(oracle_lib, tmp_path, w_flag):
+    """The reference sizes its sliding map from the read (computeMap.hpp:228-263, slidingMap.hpp:114-131): no length limit.
+    Reads of 180 kb and 500 kb (sketches of 40 000 and 110 000 hashes at w = 8, beyond the LDS-resident K5 classes) map through the
+    global-memory class exactly like the oracle, next to ordinary reads of the same batch; with w = 3 already the 60 kb read
+    is in that class."""
+    import orc, random
     from metamaps_amd import synth
-    db = synth.make_db(str(tmp_path / "db"), n_genomes=4, genome_len=400_000, seed=5, contigs_per_genome=1)
-    seq = open(db.fasta).read().split("\n")
-    genome = "".join(l for l in seq[1:] if l and not l.startswith(">"))
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=3, genome_len=700_000, seed=9, contigs_per_genome=1)
+    genomes = [g for g in _genomes_of(db.fasta) if len(g) > 600_000]   # (make_db also writes a few-base contig)
+    rng = random.Random(5)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
     with open(str(tmp_path / "long.fq"), "w") as f:
-        f.write("@long\n" + genome[:180_000] + "\n+\n" + "I" * 180_000 + "\n")
-        f.write("@ok\n" + genome[1000:9000] + "\n+\n" + "I" * 8000 + "\n")
-    out = str(tmp_path / "x")
-    p = subprocess.run([CLI, "mapDirectly", "--all", "-r", db.fasta, "-q", str(tmp_path / "long.fq"), "-o", out, "-w", "8"], capture_output=True, timeout=120)
-    assert p.returncode == 0 and b"exceed the device limit" in p.stderr
-    assert open(out + ".meta.unmappedReadsLengths").read() == "180000\tlong\n"
-    assert all(l.startswith("ok ") for l in open(out)) and sum(1 for _ in open(out)) >= 1
-    assert "ReadsNotMapped 1" in open(out + ".meta").read()
+        for i, (g, L, rc) in enumerate(((0, 180_000, False), (1, 8_000, False), (2, 500_000, True), (1, 60_000, False), (0, 33_000, True))):
+            s0 = rng.randrange(0, len(genomes[g]) - L)
+            r = list(genomes[g][s0:s0 + L])
+            for j in range(0, L, 19): r[j] = "ACGT"[rng.randrange(4)]          # ~4 % substitutions
+            if rc: r = [comp[c] for c in reversed(r)]
+            f.write(f"@long{i}\n" + "".join(r) + "\n+\n" + "I" * L + "\n")
+    pa, pb = str(tmp_path / "gpu"), str(tmp_path / "cpu")
+    for exe, pre in ((CLI, pa), (orc.CLI, pb)):
+        subprocess.run([exe, "mapDirectly", "--all", "-r", db.fasta, "-q", str(tmp_path / "long.fq"), "-o", pre] + w_flag, check=True, capture_output=True, timeout=900)
+    _cmp_table(pa, pb, " ", {13})
+    for suf in (".meta", ".meta.unmappedReadsLengths"):
+        assert open(pa + suf).read() == open(pb + suf).read(), suf
+    mapped = {l.split(" ")[0] for l in open(pa)}
+    assert mapped == {f"long{i}" for i in range(5)}

@@ -85,10 +85,11 @@ def main():
 
     from metamaps_amd import capi, emhost
     ctx = capi.Context(local)
+    # the EM all-reduce always goes through the RCCL communicator, also with one rank (the same code path at every N)
+    uid = [capi.Context.comm_unique_id() if rank == 0 else None]
     if world > 1:
-        uid = [capi.Context.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], rank, world)
+    ctx.comm_init(uid[0], rank, world)
 
     k, w = 16, args.window
     G = args.species * args.strains
@@ -125,8 +126,7 @@ def main():
         em = ctx.em_from_mapping(M, contig_taxon, contig_len, G)
         M.close()
         seen = (em.taxon_counts() > 0).astype(np.float64)
-        if world > 1:
-            ctx.comm_allreduce(seen)
+        ctx.comm_allreduce(seen)
         present = seen > 0
         n_seen = int(present.sum())
         f0 = np.where(present, 1.0 / max(n_seen, 1), 0.0)

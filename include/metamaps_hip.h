@@ -10,8 +10,10 @@
  * Each entry point below names the interface (and the loops under it) that it replaces.  Handles are
  * opaque; buffers are caller-owned plain arrays; every call returns 0 on success or a negative
  * mm_status and leaves a message in mm_last_error().  No exceptions cross this boundary, no global
- * state: one mm_ctx per device, used from one host thread at a time.  There is no CPU fallback:
- * mm_ctx_create fails when no gfx950 device is present.
+ * state.  A mm_ctx is one device + one stream + a scratch allocator; it and the objects created from it are used
+ * from one host thread at a time, different contexts (one per GPU of a node, or several on one GPU) may be
+ * driven from different threads concurrently, and an index may be read by mm_map_batch through any context of
+ * the device it lives on.  There is no CPU fallback: mm_ctx_create fails when no gfx950 device is present.
  */
 #ifndef METAMAPS_HIP_H
 #define METAMAPS_HIP_H
@@ -44,6 +46,7 @@ typedef struct mm_em mm_em;            /* EM state (mappings x taxa) resident in
 
 /* ---- context -------------------------------------------------------------------------------- */
 int mm_abi_version(void);
+int mm_device_count(void);                               /* visible HIP devices (0 when there is none or the runtime fails) */
 int mm_ctx_create(int device_id, mm_ctx** out);
 void mm_ctx_destroy(mm_ctx* ctx);
 const char* mm_last_error(const mm_ctx* ctx);            /* valid until the next call on ctx       */
@@ -187,6 +190,13 @@ int mm_mapping_add_qualities(mm_ctx* ctx, mm_mapping* m, const mm_seqset* reads,
 int mm_mapping_keep_best(mm_ctx* ctx, mm_mapping* m, int k);
 /* merge the records of several index chunks read-wise, chunk order preserved (unifyFiles, mapWrap.h:128-132) */
 int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* contig_base, int n_parts, mm_mapping** out);
+/* the same from host-side parts, i.e. what mm_mapping_fetch returned for index chunks that live on OTHER GPUs (SURVEY §8 E1:
+ * "records gathered to the read's owner"; the reference gathers them through its PREFIX.N files, mapWrap.h:417-437):
+ * offsets[p][n_reads+1] and records[p][...] of chunk p, contig_base[p] = first contig of chunk p in the whole reference.
+ * The result carries records only (as after mm_mapping_release_intermediates) and takes mm_mapping_add_qualities,
+ * mm_mapping_fetch and mm_em_create_from_mapping. */
+int mm_mapping_from_parts(mm_ctx* ctx, int64_t n_reads, const int32_t* read_len, const mm_map_params* p, int n_parts,
+                          const int64_t* const* offsets, const mm_map_record* const* records, const int32_t* contig_base, mm_mapping** out);
 
 /* debug taps for one batch (parity tests).  Any output pointer may be NULL. */
 int mm_debug_sketch(mm_mapping* m, int64_t* offsets, uint32_t* hash, int32_t* strand, int64_t cap);          /* computeMap.hpp:292-298 */

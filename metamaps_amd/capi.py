@@ -85,6 +85,7 @@ def lib() -> C.CDLL:
         P = C.POINTER
         sig = {
             "mm_abi_version": (C.c_int, []),
+            "mm_device_count": (C.c_int, []),
             "mm_ctx_create": (C.c_int, [C.c_int, P(vp)]),
             "mm_ctx_destroy": (None, [vp]),
             "mm_last_error": (C.c_char_p, [vp]),
@@ -124,6 +125,7 @@ def lib() -> C.CDLL:
             "mm_mapping_add_qualities": (C.c_int, [vp, vp, vp, C.c_int]),
             "mm_mapping_concat": (C.c_int, [vp, P(vp), vp, C.c_int, P(vp)]),
             "mm_mapping_keep_best": (C.c_int, [vp, vp, C.c_int]),
+            "mm_mapping_from_parts": (C.c_int, [vp, i64, vp, P(MapParams), C.c_int, P(vp), P(vp), vp, P(vp)]),
             "mm_index_plan_chunks": (C.c_int, [vp, vp, u64, vp, i32, P(i32)]),
             "mm_debug_sketch": (C.c_int, [vp, vp, vp, vp, i64]),
             "mm_debug_hits": (C.c_int, [vp, vp, vp, vp, i64]),
@@ -378,6 +380,20 @@ class Mapping:
         out = C.c_void_p()
         ctx.check(lib().mm_mapping_concat(ctx.h, arr, _ptr(base), len(parts), C.byref(out)))
         return Mapping(ctx, out, parts[0].n_reads)
+
+    @staticmethod
+    def from_parts(ctx: "Context", read_len, parts: list, contig_base: list[int], k: int, w: int, pi: float = 80.0, min_read_len: int = 1000) -> "Mapping":
+        """parts = [(offsets, records)] as returned by fetch() for index chunks mapped on other GPUs"""
+        rl = np.ascontiguousarray(read_len, dtype=np.int32)
+        offs = [np.ascontiguousarray(o, dtype=np.int64) for o, _ in parts]
+        recs = [np.ascontiguousarray(r, dtype=RECORD_DTYPE) for _, r in parts]
+        oarr = (C.c_void_p * len(parts))(*[o.ctypes.data for o in offs])
+        rarr = (C.c_void_p * len(parts))(*[(r.ctypes.data if len(r) else None) for r in recs])
+        base = np.asarray(contig_base, dtype=np.int32)
+        mp = MapParams(k, w, pi, min_read_len)
+        out = C.c_void_p()
+        ctx.check(lib().mm_mapping_from_parts(ctx.h, len(rl), _ptr(rl), C.byref(mp), len(parts), oarr, rarr, _ptr(base), C.byref(out)))
+        return Mapping(ctx, out, len(rl))
 
     def fetch(self, rec_buf: np.ndarray | None = None):
         """offsets [n_reads+1] and the mm_map_record array.  `rec_buf` (RECORD_DTYPE, any capacity) lets a caller

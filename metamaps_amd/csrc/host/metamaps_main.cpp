@@ -5,9 +5,15 @@
 // exclusively through the C ABI in include/metamaps_hip.h.  Host work here is what stays host work in the
 // reference too: argument parsing, FASTA/FASTQ(.gz) reading, text formatting, taxonomy bookkeeping.
 //
-//   metamaps mapDirectly [--all] -r DB.fa -q reads.fq -o PREFIX [-k 16] [-w W] [-m 1000] [--pi 80] [-p 1e-3] [-t N] [--mm G]
-//   metamaps index -r DB.fa -i IDX [same reference options]          metamaps mapAgainstIndex [--all] -i IDX -q reads.fq -o PREFIX
-//   metamaps classify --DB DBDIR --mappings PREFIX [--minreads N] [-t N]
+//   metamaps mapDirectly [--all] -r DB.fa -q reads.fq -o PREFIX [-k 16] [-w W] [-m 1000] [--pi 80] [-p 1e-3] [-t N] [--mm G] [--gpus N]
+//   metamaps index -r DB.fa -i IDX [same reference options]          metamaps mapAgainstIndex [--all] -i IDX -q reads.fq -o PREFIX [--gpus N]
+//   metamaps classify --DB DBDIR --mappings PREFIX [--minreads N] [-t N] [--gpus N]
+//
+// --gpus N uses devices 0..N-1 of the node, one context per device on its own host thread (where the reference has -t N worker
+// threads, computeMap.hpp:104-176 / fEM.h:1229): mapping shards the read batches (index replicated) or the index chunks
+// (--shard-index / --stream-chunks) over the devices and writes the output in input order; classify shards the reads and
+// all-reduces the per-taxon EM sums over RCCL every iteration.  (--devices a,b,c names the devices explicitly; a device may
+// repeat — several contexts on one GPU — which is how the multi-device paths are tested on a one-GPU box.)
 //
 // --mm G splits the reference into the same index chunks the reference would build under that limit
 // (mm_index_plan_chunks); all chunk indexes stay resident in HBM and every read batch is mapped against each.
@@ -52,8 +58,9 @@ namespace {
 
 // MM_CLI_TIMING=1: wall time per phase on stderr at exit
 struct PhaseClock {
-  std::map<std::string, double> acc; std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now(), t0 = t;
-  void lap(const char* name) { auto n = std::chrono::steady_clock::now(); acc[name] += std::chrono::duration<double>(n - t).count(); t = n;
+  std::map<std::string, double> acc; std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now(), t0 = t; std::mutex m;
+  void add(const char* name, double seconds) { std::lock_guard<std::mutex> lk(m); acc[name] += seconds; }   // worker threads: summed over the workers
+  void lap(const char* name) { auto n = std::chrono::steady_clock::now(); add(name, std::chrono::duration<double>(n - t).count()); t = n;
                                if (getenv("MM_CLI_TIMING")) std::cerr << "INFO, lap " << name << " at +" << std::chrono::duration<double>(n - t0).count() << " s\n"; }
   ~PhaseClock() { if (getenv("MM_CLI_TIMING")) for (auto& kv : acc) std::cerr << "INFO, time " << kv.first << " " << kv.second << " s\n"; }
 };
@@ -137,7 +144,7 @@ std::vector<std::string> split(const std::string& in, const std::string& d) {   
   return out;
 }
 
-struct Options { std::map<std::string, std::string> v; bool all = false, stream = false; };
+struct Options { std::map<std::string, std::string> v; bool all = false, stream = false, shard = false; };
 Options parse(int argc, char** argv) {
   static const std::map<std::string, std::string> alias{{"-r", "reference"}, {"-q", "query"}, {"-o", "output"}, {"-k", "kmer"}, {"-p", "pval"},
       {"-w", "window"}, {"-m", "minReadLen"}, {"-t", "threads"}, {"--mm", "maxmemory"}, {"--pi", "perc_identity"}, {"-i", "index"}};
@@ -146,6 +153,7 @@ Options parse(int argc, char** argv) {
     std::string a = argv[i];
     if (a == "--all") { o.all = true; continue; }
     if (a == "--stream-chunks") { o.stream = true; continue; }
+    if (a == "--shard-index") { o.shard = true; continue; }
     if (a == "-h" || a == "--help") { std::cout << "see the header of metamaps_main.cpp / the reference's README\n"; exit(0); }
     std::string key = alias.count(a) ? alias.at(a) : (a.rfind("--", 0) == 0 ? a.substr(2) : "");
     if (key.empty() || i + 1 >= argc) die("Unknown or incomplete option " + a);
@@ -166,6 +174,82 @@ uint64_t file_size(const std::string& f) {                       // commonFunc.h
 //   mapDirectly      FASTA -> chunk plan -> device indexes -> map                                                 mapWrap.h:407-441
 // The stored form is the packed reference, not the reference's Boost archive of the sketch: rebuilding the device
 // index takes seconds and the file stays a third of the FASTA's size.
+//
+// Several GPUs (--gpus N; the reference's -t N worker pool, computeMap.hpp:104-176, becomes one context per device):
+//   replicated   every device holds every chunk index; read batches go to whichever worker is free and the output is written
+//                in batch order (= input order, all ThreadPool.hpp:13-17 guarantees).  No exchange between devices.
+//   sharded      (--shard-index, or automatic when the chunk indexes fit the devices together but not one of them) chunk c
+//                lives on device c mod N, every read batch visits every device, the records go to the batch's owner device
+//                through the host (mm_mapping_fetch -> mm_mapping_from_parts) for the merge in chunk order and the mapping
+//                qualities — what the reference does with its PREFIX.N files (mapWrap.h:417-437, :128-145).
+//   streamed     (--stream-chunks, or automatic when not even that fits) rounds of N chunks, one per device, built, mapped
+//                against every (device-resident) read batch and dropped.
+// A batch's sequences live back to back in one arena (huge pages when the system grants them) that is handed to the library by
+// reference (mm_seqset_add_view) and recycled: no allocation, copy or page fault per read.
+struct Batch {
+  std::vector<std::string> names; std::vector<int> lens; std::vector<size_t> off;
+  char* arena = nullptr; size_t cap = 0, used = 0;
+  size_t seq = 0, file = 0;
+  ~Batch() { free(arena); }
+  void reserve(size_t want) {
+    if (want <= cap) return;
+    const size_t HP = (size_t)2 << 20, ncap = (std::max(want, cap + cap / 2) + HP - 1) / HP * HP;
+    char* na = (char*)aligned_alloc(HP, ncap);
+    if (!na) die("out of host memory for the read batch");
+    madvise(na, ncap, MADV_HUGEPAGE);
+    if (used) memcpy(na, arena, used);
+    free(arena); arena = na; cap = ncap;
+  }
+  void put(const std::string& q) { reserve(used + q.size() + 1); memcpy(arena + used, q.data(), q.size()); off.push_back(used); used += q.size(); }
+  void reset() { names.clear(); lens.clear(); off.clear(); used = 0; }
+};
+
+// one logical GPU: a context (stream + allocator) on a physical device, and the chunk indexes that live there
+struct Dev { int phys = 0; mm_ctx* ctx = nullptr; std::vector<mm_index*> idx; };
+
+template <typename F> void on_each(size_t n, F&& fn) {           // fn(i) for i < n, concurrently
+  if (n == 1) { fn(0); return; }
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < n; ++i) th.emplace_back([&fn, i] { fn(i); });
+  for (auto& t : th) t.join();
+}
+
+std::vector<int> device_list(const Options& o) {                 // --gpus N: devices 0..N-1; --devices a,b,..: explicit (a device may repeat: test hook)
+  std::vector<int> phys;
+  if (o.v.count("devices")) for (auto& s : split(o.v.at("devices"), ",")) phys.push_back(std::stoi(s));
+  else { const int g = o.v.count("gpus") ? std::stoi(o.v.at("gpus")) : 1; for (int i = 0; i < g; ++i) phys.push_back(i); }
+  if (phys.empty()) die("--gpus must be at least 1");
+  const int n = mm_device_count();
+  if (n <= 0) die("No MI355X (gfx950) device available — this build has no CPU path");
+  for (int p : phys) if (p < 0 || p >= n) die("device " + std::to_string(p) + " requested but only " + std::to_string(n) + " visible");
+  return phys;
+}
+
+// records of one batch -> the text of PREFIX (computeMap.hpp:565-581 + the two fields of mapWrap.h:311-320), reads in order
+void format_records(const std::vector<std::string>& names, const std::vector<int>& lens, const std::vector<int64_t>& off,
+                    const std::vector<mm_map_record>& rec, const std::vector<std::string>& cname, const std::vector<int>& clen, int k, std::string& out) {
+  out.clear();
+  out.reserve(rec.size() * 160);
+  char num[256];
+  for (size_t r = 0; r < names.size(); ++r) {
+    const int len = lens[r];
+    for (int64_t i = off[r]; i < off[r + 1]; ++i) {
+      const mm_map_record& x = rec[(size_t)i];
+      float id; mm_identity(x.shared, x.sketch, k, &id, nullptr);
+      char ids[48]; snprintf(ids, sizeof ids, "%g", (double)id);   // operator<<(float): %g with 6 significant digits; printed, then re-parsed (mapWrap.h:237)
+      const double reported = strtod(ids, nullptr) / 100.0;
+      const float corrected = std::exp(-(1 - reported));          // mapWrap.h:311
+      out += names[r];
+      int n = snprintf(num, sizeof num, " %d 0 %d %c ", len, len - 1, x.strand == 1 ? '+' : '-');
+      out.append(num, (size_t)n);
+      out += cname[(size_t)x.ref_contig];
+      n = snprintf(num, sizeof num, " %d %d %d %s %d %d %g %g\n", clen[(size_t)x.ref_contig], x.ref_start, x.ref_start + len - 1, ids, x.shared, x.sketch,
+                   (double)(corrected * 100), x.mapq);              // :318-320
+      out.append(num, (size_t)n);
+    }
+  }
+}
+
 int map_mode(const Options& o, const std::string& mode) {
   const bool from_index = mode == "mapAgainstIndex", only_index = mode == "index";
   if (!from_index && !o.v.count("reference")) die("Provide reference file (s)");
@@ -203,71 +287,68 @@ int map_mode(const Options& o, const std::string& mode) {
     if (queries.size() != prefixes.size()) die("Please specify an equal number of input and output files (as comma-separated lists)");
   }
   PhaseClock pc;
-  mm_ctx* ctx;
-  if (mm_ctx_create(0, &ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
+  std::vector<Dev> devs;
+  for (int p : device_list(o)) { Dev d; d.phys = p; devs.push_back(d); }
+  if (only_index) devs.resize(1);
+  const size_t G = devs.size();
+  for (auto& d : devs) if (mm_ctx_create(d.phys, &d.ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
+  mm_ctx* const ctx0 = devs[0].ctx;
   pc.lap("0 context");
   std::vector<std::string> cname; std::vector<int> clen;
-  struct Chunk { int first, count; mm_index* idx; std::string file; };   // idx == nullptr: built when its pass starts (streamed chunks)
+  struct Chunk { int first, count; std::string file; };
   std::vector<Chunk> chunks;
   std::deque<std::string> cseq;                                  // contig sequences, kept while chunk indexes are still to be built from them
-  bool stream_chunks = o.stream;                                 // one chunk index in HBM at a time (also chosen automatically below)
   uint64_t hbm_free = 0;
-  { char nm[8]; int cus; uint64_t tot; mm_ctx_device_info(ctx, nm, sizeof nm, &cus, &tot, &hbm_free); }
+  { char nm[8]; int cus; uint64_t tot; mm_ctx_device_info(ctx0, nm, sizeof nm, &cus, &tot, &hbm_free); }
   const double INDEX_BYTES_PER_BASE = 5.5;                       // pos + padded occ + table at w = 8; denser for smaller w
-  auto make_part = [&](int a, int bnd) {
+  auto fits = [&](uint64_t bases, double share) { return (double)bases * INDEX_BYTES_PER_BASE * 1.2 * share <= 0.8 * (double)hbm_free; };
+  auto make_part = [&](mm_ctx* ctx, int a, int bnd) {
     mm_seqset* part; ck(ctx, mm_seqset_create(ctx, &part), "seqset");
     for (int i = a; i < bnd; ++i) ck(ctx, mm_seqset_add_view(part, cseq[(size_t)i].data(), (int64_t)cseq[(size_t)i].size()), "add contig");
     ck(ctx, mm_seqset_upload(part), "upload reference chunk");
     return part;
   };
+  uint64_t ref_bases = 0;
+  mm_index* whole = nullptr;                                     // index of the whole reference on device 0, when one was built for the chunk plan
   if (!from_index) {
-    // ---- index (winSketch.hpp:180-365): the whole reference first; under --maxmemory it only serves to evaluate the
-    // chunk rule and is then replaced by one index per chunk
-    mm_seqset* contigs; ck(ctx, mm_seqset_create(ctx, &contigs), "seqset");
+    // ---- reference (winSketch.hpp:180-365)
     SeqFile f(ref);
-    uint64_t ref_bases = 0;
-    while (f.next()) {
-      cname.push_back(f.name); clen.push_back((int)f.seq.size()); ref_bases += f.seq.size();
-      if (maxMem) { cseq.push_back(f.seq); ck(ctx, mm_seqset_add_view(contigs, cseq.back().data(), (int64_t)cseq.back().size()), "add contig"); }
-      else ck(ctx, mm_seqset_add(contigs, f.seq.data(), (int64_t)f.seq.size()), "add contig");
-    }
+    while (f.next()) { cname.push_back(f.name); clen.push_back((int)f.seq.size()); ref_bases += f.seq.size(); cseq.push_back(std::move(f.seq)); f.seq.clear(); }
     pc.lap("1 reference parse");
-    if (maxMem && !stream_chunks && (double)ref_bases * INDEX_BYTES_PER_BASE * 1.2 > 0.8 * (double)hbm_free) {
-      stream_chunks = true;
-      std::cout << "INFO, the index of " << ref_bases << " reference bases does not fit the device's " << (hbm_free >> 30) << " GiB: chunk indexes are built and mapped one after the other\n";
-    }
     std::vector<int32_t> first(1, 0);
-    mm_index* whole = nullptr;
-    if (!stream_chunks) {
-      ck(ctx, mm_seqset_upload(contigs), "upload reference");
+    if (!maxMem || fits(ref_bases, 1.0)) {
+      // the index of the whole reference: the only chunk, or what the chunk rule of --maxmemory is evaluated on
+      if (!maxMem && o.stream) die("--stream-chunks needs --maxmemory (the chunk rule of the reference, winSketch.hpp:274-329)");
+      mm_seqset* contigs = make_part(ctx0, 0, (int)cname.size());
       pc.lap("2 reference pack+upload");
-      ck(ctx, mm_index_build(ctx, contigs, k, w, &whole), "index");
+      ck(ctx0, mm_index_build(ctx0, contigs, k, w, &whole), "index");
       pc.lap("3 index build");
       if (maxMem) {
         int32_t n = 0;
-        ck(ctx, mm_index_plan_chunks(ctx, whole, maxMem, nullptr, 0, &n), "chunk plan");
+        ck(ctx0, mm_index_plan_chunks(ctx0, whole, maxMem, nullptr, 0, &n), "chunk plan");
         first.resize((size_t)n);
-        ck(ctx, mm_index_plan_chunks(ctx, whole, maxMem, first.data(), n, &n), "chunk plan");
+        ck(ctx0, mm_index_plan_chunks(ctx0, whole, maxMem, first.data(), n, &n), "chunk plan");
       }
+      if (only_index && first.size() == 1) ck(ctx0, mm_seqset_save(contigs, (ipre + ".1.seqset").c_str()), "store index chunk");
+      mm_seqset_destroy(contigs);
     } else {
       // The chunk rule without an index of the whole reference: it decides to close a chunk from the chunk's own content
       // and the next contig only, so it can be evaluated on the index of a contig range that fits the device.  Every cut
       // inside the range is final; the range's last chunk is not (it may go on), so the next range starts there.
-      if (!maxMem) die("--stream-chunks needs --maxmemory (the chunk rule of the reference, winSketch.hpp:274-329)");
-      mm_seqset_destroy(contigs); contigs = nullptr;
+      std::cout << "INFO, the index of " << ref_bases << " reference bases does not fit one device's " << (hbm_free >> 30) << " GiB: the chunk rule is evaluated on contig ranges\n";
       const int C = (int)cname.size();
       uint64_t range_bases = o.v.count("stream-range-bases") ? std::stoull(o.v.at("stream-range-bases")) : (uint64_t)(0.5 * (double)hbm_free / INDEX_BYTES_PER_BASE);
       int c0 = 0;
       while (c0 < C) {
         int c1 = c0; uint64_t bases = 0;
         while (c1 < C && (bases < range_bases || c1 == c0)) bases += (uint64_t)clen[(size_t)c1++];
-        mm_seqset* part = make_part(c0, c1);
-        mm_index* ri; ck(ctx, mm_index_build(ctx, part, k, w, &ri), "index (chunk planning range)");
+        mm_seqset* part = make_part(ctx0, c0, c1);
+        mm_index* ri; ck(ctx0, mm_index_build(ctx0, part, k, w, &ri), "index (chunk planning range)");
         mm_seqset_destroy(part);
         int32_t n = 0;
-        ck(ctx, mm_index_plan_chunks(ctx, ri, maxMem, nullptr, 0, &n), "chunk plan");
+        ck(ctx0, mm_index_plan_chunks(ctx0, ri, maxMem, nullptr, 0, &n), "chunk plan");
         std::vector<int32_t> loc((size_t)n);
-        ck(ctx, mm_index_plan_chunks(ctx, ri, maxMem, loc.data(), n, &n), "chunk plan");
+        ck(ctx0, mm_index_plan_chunks(ctx0, ri, maxMem, loc.data(), n, &n), "chunk plan");
         mm_index_destroy(ri);
         if (n == 1 && c1 < C) {                                   // the chunk that starts at c0 is longer than the range
           if ((double)bases * 2 * INDEX_BYTES_PER_BASE > 0.8 * (double)hbm_free && !o.v.count("stream-range-bases"))
@@ -280,29 +361,21 @@ int map_mode(const Options& o, const std::string& mode) {
       }
       pc.lap("3 index build");
     }
-    std::vector<std::string> chunk_files;
-    if (only_index) { std::ofstream flag(ipre + ".index"); if (!flag.is_open()) die("Cannot open " + ipre + ".index"); flag << 0 << "\n"; }   // mapWrap.h:363-366
-    if (first.size() == 1 && !stream_chunks) {
-      if (only_index) { chunk_files.push_back(ipre + ".1.seqset"); ck(ctx, mm_seqset_save(contigs, chunk_files.back().c_str()), "store index chunk"); }
-      chunks.push_back(Chunk{0, (int)cname.size(), whole, ""});
-    } else {
-      if (whole) mm_index_destroy(whole);
-      for (size_t c = 0; c < first.size(); ++c) {
-        const int a = first[c], b = c + 1 < first.size() ? first[c + 1] : (int)cname.size();
-        mm_index* idx = nullptr;
-        if (only_index || !stream_chunks) {
-          mm_seqset* part = make_part(a, b);
-          if (only_index) { chunk_files.push_back(ipre + "." + std::to_string(c + 1) + ".seqset"); ck(ctx, mm_seqset_save(part, chunk_files.back().c_str()), "store index chunk"); }
-          else ck(ctx, mm_index_build(ctx, part, k, w, &idx), "index chunk");
-          mm_seqset_destroy(part);
-        }
-        chunks.push_back(Chunk{a, b - a, idx, ""});
-      }
+    for (size_t c = 0; c < first.size(); ++c) {
+      const int a = first[c], b = c + 1 < first.size() ? first[c + 1] : (int)cname.size();
+      chunks.push_back(Chunk{a, b - a, ""});
     }
-    if (contigs) mm_seqset_destroy(contigs);
-    if (!stream_chunks) cseq.clear();
     if (only_index) {
-      for (auto& ch : chunks) if (ch.idx) mm_index_destroy(ch.idx);
+      { std::ofstream flag(ipre + ".index"); if (!flag.is_open()) die("Cannot open " + ipre + ".index"); flag << 0 << "\n"; }   // mapWrap.h:363-366
+      std::vector<std::string> chunk_files;
+      for (size_t c = 0; c < chunks.size(); ++c) {
+        chunk_files.push_back(ipre + "." + std::to_string(c + 1) + ".seqset");
+        if (chunks.size() == 1 && whole) continue;                // stored above, from the set the index was built on
+        mm_seqset* part = make_part(ctx0, chunks[c].first, chunks[c].first + chunks[c].count);
+        ck(ctx0, mm_seqset_save(part, chunk_files.back().c_str()), "store index chunk");
+        mm_seqset_destroy(part);
+      }
+      if (whole) mm_index_destroy(whole);
       std::ofstream args(ipre + ".arguments");
       if (!args.is_open()) die("Cannot open file " + ipre + ".arguments for serialization.");
       args.precision(17);
@@ -314,7 +387,7 @@ int map_mode(const Options& o, const std::string& mode) {
       std::ofstream flag(ipre + ".index");                       // mapWrap.h:395-402
       flag << 1 << "\n";
       for (auto& fn : chunk_files) { flag << fn << "\n"; std::cout << "Stored state in file " << fn << "\n"; }
-      mm_ctx_destroy(ctx);
+      mm_ctx_destroy(ctx0);
       return 0;
     }
   } else {
@@ -327,78 +400,98 @@ int map_mode(const Options& o, const std::string& mode) {
     std::ifstream cf(ipre + ".contigs");
     if (!cf.is_open()) die("Cannot open " + ipre + ".contigs");
     std::vector<int> chunk_of; std::string line;
-    uint64_t ref_bases = 0;
     while (std::getline(cf, line)) {
       auto fl = split(line, "\t");
       if (fl.size() != 3) die("Weird line in " + ipre + ".contigs");
       cname.push_back(fl[0]); clen.push_back(std::stoi(fl[1])); chunk_of.push_back(std::stoi(fl[2])); ref_bases += (uint64_t)clen.back();
     }
-    if (!stream_chunks && chunk_files.size() > 1 && (double)ref_bases * INDEX_BYTES_PER_BASE * 1.2 > 0.8 * (double)hbm_free) {
-      stream_chunks = true;
-      std::cout << "INFO, the index of " << ref_bases << " reference bases does not fit the device's " << (hbm_free >> 30) << " GiB: chunk indexes are built and mapped one after the other\n";
-    }
     for (size_t c = 0; c < chunk_files.size(); ++c) {
       int first = -1, count = 0;
       for (size_t i = 0; i < chunk_of.size(); ++i) if (chunk_of[i] == (int)c + 1) { if (first < 0) first = (int)i; ++count; }
-      chunks.push_back(Chunk{first < 0 ? 0 : first, count, nullptr, chunk_files[c]});
+      chunks.push_back(Chunk{first < 0 ? 0 : first, count, chunk_files[c]});
     }
   }
-  // Builds the index of chunk c if it is not resident yet and sets its freqThreshold from the histogram accumulated
-  // over the chunks so far (never cleared, winSketch.hpp:452-494): call once per chunk, in chunk order.
-  std::map<int64_t, int64_t> thr_acc; int thr = INT_MAX;
-  auto prepare_chunk = [&](size_t c) {
-    Chunk& ch = chunks[c];
-    if (!ch.idx) {
-      mm_seqset* part;
-      if (!ch.file.empty()) {
-        ck(ctx, mm_seqset_load(ctx, ch.file.c_str(), &part), "load index chunk");
-        if ((int64_t)ch.count != mm_seqset_count(part)) die("Index chunk " + ch.file + " does not match " + ipre + ".contigs");
-      } else part = make_part(ch.first, ch.first + ch.count);
-      ck(ctx, mm_index_build(ctx, part, k, w, &ch.idx), "index chunk");
-      mm_seqset_destroy(part);
-    }
-    int64_t n = 0; mm_index_freq_hist(ch.idx, nullptr, nullptr, 0, &n);
-    std::vector<int64_t> cc((size_t)n), hh((size_t)n); mm_index_freq_hist(ch.idx, cc.data(), hh.data(), n, &n);
+  const size_t NC = chunks.size();
+  // ---- where the chunk indexes live
+  enum class Place { Replicated, Sharded, Streamed } place = Place::Replicated;
+  if (o.stream) place = Place::Streamed;
+  else if (o.shard) place = Place::Sharded;
+  else if (!fits(ref_bases, 1.0) && NC > 1) {
+    place = (G > 1 && fits(ref_bases, 1.3 / (double)G)) ? Place::Sharded : Place::Streamed;
+    std::cout << "INFO, the index of " << ref_bases << " reference bases does not fit one device's " << (hbm_free >> 30) << " GiB: "
+              << (place == Place::Sharded ? "the chunk indexes are spread over the devices" : "chunk indexes are built and mapped one after the other") << "\n";
+  }
+  if (place != Place::Replicated && NC == 1 && !from_index && !maxMem) die("--stream-chunks / --shard-index need --maxmemory (the chunk rule of the reference, winSketch.hpp:274-329)");
+  for (auto& d : devs) d.idx.assign(NC, nullptr);
+  std::vector<int> thr_of(NC, INT_MAX);
+  std::map<int64_t, int64_t> thr_acc; int thr = INT_MAX;          // occurrence histogram accumulated over the chunks, never cleared (winSketch.hpp:452-494)
+  auto build_chunk = [&](Dev& d, size_t c) {                     // the index of chunk c on device d
+    const Chunk& ch = chunks[c];
+    if (d.idx[c]) return;
+    if (whole && NC == 1 && &d == &devs[0]) { d.idx[c] = whole; whole = nullptr; return; }
+    mm_seqset* part;
+    if (!ch.file.empty()) {
+      ck(d.ctx, mm_seqset_load(d.ctx, ch.file.c_str(), &part), "load index chunk");
+      if ((int64_t)ch.count != mm_seqset_count(part)) die("Index chunk " + ch.file + " does not match " + ipre + ".contigs");
+    } else part = make_part(d.ctx, ch.first, ch.first + ch.count);
+    ck(d.ctx, mm_index_build(d.ctx, part, k, w, &d.idx[c]), "index chunk");
+    mm_seqset_destroy(part);
+  };
+  // freqThreshold of chunk c from the histogram accumulated over chunks 0..c: call once per chunk, in chunk order, after some
+  // device has built it; the value is then set on every copy of that chunk
+  auto settle_threshold = [&](size_t c) {
+    mm_index* any = nullptr;
+    for (auto& d : devs) if (d.idx[c]) { any = d.idx[c]; break; }
+    int64_t n = 0; mm_index_freq_hist(any, nullptr, nullptr, 0, &n);
+    std::vector<int64_t> cc((size_t)n), hh((size_t)n); mm_index_freq_hist(any, cc.data(), hh.data(), n, &n);
     for (int64_t i = 0; i < n; ++i) thr_acc[cc[(size_t)i]] += hh[(size_t)i];
-    mm_index_info info; mm_index_get_info(ch.idx, &info);
+    mm_index_info info; mm_index_get_info(any, &info);
     if (info.n_unique_hashes > 0) {
       std::vector<int64_t> ac, ah; for (auto& kv : thr_acc) { ac.push_back(kv.first); ah.push_back(kv.second); }
       thr = mm_freq_threshold_from_hist(ac.data(), ah.data(), (int64_t)ac.size(), info.n_unique_hashes, thr);
     }
-    mm_index_set_freq_threshold(ch.idx, thr);
-    std::cout << "INFO, index chunk " << c + 1 << "/" << chunks.size() << ": contigs " << ch.first << ".." << ch.first + ch.count - 1
+    thr_of[c] = thr;
+    for (auto& d : devs) if (d.idx[c]) mm_index_set_freq_threshold(d.idx[c], thr);
+    std::cout << "INFO, index chunk " << c + 1 << "/" << NC << ": contigs " << chunks[c].first << ".." << chunks[c].first + chunks[c].count - 1
               << ", " << info.n_entries << " minimizers, " << info.n_unique_hashes << " unique hashes\n";
   };
-  if (!stream_chunks) for (size_t c = 0; c < chunks.size(); ++c) prepare_chunk(c);
-  // ---- reads, batch by batch (computeMap.hpp:104-172 + unifyFiles mapWrap.h:34-213)
-  const int64_t BATCH_READS = 100000, BATCH_BASES = 256000000LL;   // ~0.25 Gbp per device batch (16 ms of mapping); the next ones are parsed meanwhile
-  // A batch keeps its sequences back to back in one arena (huge pages when the system grants them) that is handed to
-  // the library by reference (mm_seqset_add_view) and recycled: no allocation, copy or page fault per read.
-  struct Batch {
-    std::vector<std::string> names; std::vector<int> lens; std::vector<size_t> off;
-    char* arena = nullptr; size_t cap = 0, used = 0;
-    ~Batch() { free(arena); }
-    void reserve(size_t want) {
-      if (want <= cap) return;
-      const size_t HP = (size_t)2 << 20, ncap = (std::max(want, cap + cap / 2) + HP - 1) / HP * HP;
-      char* na = (char*)aligned_alloc(HP, ncap);
-      if (!na) die("out of host memory for the read batch");
-      madvise(na, ncap, MADV_HUGEPAGE);
-      if (used) memcpy(na, arena, used);
-      free(arena); arena = na; cap = ncap;
+  if (whole && !(NC == 1 && place == Place::Replicated)) { mm_index_destroy(whole); whole = nullptr; }
+  if (place == Place::Replicated) {
+    on_each(G, [&](size_t d) { for (size_t c = 0; c < NC; ++c) build_chunk(devs[d], c); });
+    for (size_t c = 0; c < NC; ++c) settle_threshold(c);
+    cseq.clear();
+    pc.lap("3 index build");
+  }
+  // ---- reads (computeMap.hpp:104-172 + unifyFiles mapWrap.h:34-213)
+  // ~0.25 Gbp per device batch (16 ms of mapping); the next ones are parsed meanwhile.  (MM_CLI_BATCH_READS: test hook, small batches)
+  const int64_t BATCH_READS = getenv("MM_CLI_BATCH_READS") ? std::max(1, atoi(getenv("MM_CLI_BATCH_READS"))) : 100000, BATCH_BASES = 256000000LL;
+  const mm_map_params mp{k, w, pi, minLen};
+  std::vector<int32_t> chunk_base; for (auto& ch : chunks) chunk_base.push_back(ch.first);
+  // a reader thread parses the query files into batches (bounded queue); `take` hands them out in order, nullptr at the end
+  struct Reader {
+    std::mutex m; std::condition_variable cv; std::deque<std::unique_ptr<Batch>> queue, spare; bool done = false; size_t max_queued = 2;
+    std::vector<size_t> file_end;                                // file_end[f] = number of batches of files 0..f (set when file f has been read to its end)
+    std::thread th;
+    std::unique_ptr<Batch> take() {
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return !queue.empty() || done; });
+      if (queue.empty()) return nullptr;
+      auto b = std::move(queue.front()); queue.pop_front();
+      cv.notify_all();
+      return b;
     }
-    void put(const std::string& q) { reserve(used + q.size() + 1); memcpy(arena + used, q.data(), q.size()); off.push_back(used); used += q.size(); }
-    void reset() { names.clear(); lens.clear(); off.clear(); used = 0; }
-  };
-  // a reader thread parses the next batches of one query file (bounded queue) while the caller handles the current one
-  auto for_each_batch = [&](const std::string& query, const std::function<void(Batch&)>& handle) {
-    std::mutex qm; std::condition_variable qcv; std::deque<std::unique_ptr<Batch>> queue; std::vector<std::unique_ptr<Batch>> spare; bool reader_done = false;
-    std::thread reader([&]() {
-      SeqFile f(query);
+    void recycle(std::unique_ptr<Batch> b) { b->reset(); std::lock_guard<std::mutex> lk(m); spare.push_back(std::move(b)); }
+    ~Reader() { if (th.joinable()) th.join(); }
+  } reader;
+  reader.max_queued = std::max<size_t>(2, 2 * G);
+  reader.th = std::thread([&]() {
+    size_t seq = 0;
+    for (size_t fi = 0; fi < queries.size(); ++fi) {
+      SeqFile f(queries[fi]);
       bool more = true;
       while (more) {
         std::unique_ptr<Batch> b;
-        { std::lock_guard<std::mutex> lk(qm); if (!spare.empty()) { b = std::move(spare.back()); spare.pop_back(); } }
+        { std::lock_guard<std::mutex> lk(reader.m); if (!reader.spare.empty()) { b = std::move(reader.spare.back()); reader.spare.pop_back(); } }
         if (!b) b = std::make_unique<Batch>();
         int64_t bases = 0;
         while ((int64_t)b->names.size() < BATCH_READS && bases < BATCH_BASES && (more = f.next())) {
@@ -406,141 +499,186 @@ int map_mode(const Options& o, const std::string& mode) {
           b->names.push_back(f.name); b->lens.push_back((int)f.seq.size()); bases += (int64_t)f.seq.size();
           b->put(f.seq);
         }
-        if (b->names.empty()) break;
+        if (b->names.empty()) { std::lock_guard<std::mutex> lk(reader.m); reader.spare.push_back(std::move(b)); break; }
+        b->seq = seq++; b->file = fi;
         if (getenv("MM_CLI_TIMING")) std::cerr << "INFO, reader: batch of " << b->names.size() << " reads parsed at +" << std::chrono::duration<double>(std::chrono::steady_clock::now() - pc.t0).count() << " s\n";
-        std::unique_lock<std::mutex> lk(qm);
-        qcv.wait(lk, [&] { return queue.size() < 2; });
-        queue.push_back(std::move(b));
-        qcv.notify_all();
+        std::unique_lock<std::mutex> lk(reader.m);
+        reader.cv.wait(lk, [&] { return reader.queue.size() < reader.max_queued; });
+        reader.queue.push_back(std::move(b));
+        reader.cv.notify_all();
       }
-      std::lock_guard<std::mutex> lk(qm); reader_done = true; qcv.notify_all();
-    });
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{reader};
-    for (;;) {
-      std::unique_ptr<Batch> bt;
-      {
-        std::unique_lock<std::mutex> lk(qm);
-        qcv.wait(lk, [&] { return !queue.empty() || reader_done; });
-        if (queue.empty()) break;
-        bt = std::move(queue.front()); queue.pop_front();
-        qcv.notify_all();
-      }
-      handle(*bt);
-      bt->reset();
-      { std::lock_guard<std::mutex> lk(qm); spare.push_back(std::move(bt)); }
+      std::lock_guard<std::mutex> lk(reader.m); reader.file_end.push_back(seq); reader.cv.notify_all();
     }
-  };
-  auto upload_batch = [&](Batch& bt) {
+    std::lock_guard<std::mutex> lk(reader.m); reader.done = true; reader.cv.notify_all();
+  });
+  auto upload_batch = [&](mm_ctx* ctx, const Batch& bt) {
     mm_seqset* reads; ck(ctx, mm_seqset_create(ctx, &reads), "seqset");
     for (size_t r = 0; r < bt.names.size(); ++r) ck(ctx, mm_seqset_add_view(reads, bt.arena + bt.off[r], (int64_t)bt.lens[r]), "add read");
-    pc.lap("4 reads parse");
     ck(ctx, mm_seqset_upload(reads), "upload reads");
-    pc.lap("5 reads pack+upload");
     return reads;
   };
-  const mm_map_params mp{k, w, pi, minLen};
-  auto map_chunk = [&](const Chunk& ch, mm_seqset* reads) {     // one "PREFIX.N" per chunk in the reference (mapWrap.h:419-437)
-    mm_mapping* pm; ck(ctx, mm_map_batch(ctx, ch.idx, reads, &mp, &pm), "map");
+  auto map_chunk = [&](mm_ctx* ctx, mm_index* idx, mm_seqset* reads) {   // one "PREFIX.N" per chunk in the reference (mapWrap.h:419-437)
+    mm_mapping* pm; ck(ctx, mm_map_batch(ctx, idx, reads, &mp, &pm), "map");
     if (!o.all) ck(ctx, mm_mapping_keep_best(ctx, pm, k), "best mappings");
     return pm;
   };
-  // the output files of one query file (mapWrap.h:34-213)
-  struct FileOut {
-    std::string prefix; std::ofstream out, unm; size_t total = 0, tooShort = 0, mapped = 0, notMapped = 0; std::set<std::string> seen;
-    explicit FileOut(const std::string& p) : prefix(p), out(p), unm(p + ".meta.unmappedReadsLengths") { if (!out.is_open()) die("Cannot open output file " + p); }
-  };
-  // unifyFiles + mapping qualities + text for one batch; consumes `parts`
-  auto finish_batch = [&](FileOut& F, const std::vector<std::string>& names, const std::vector<int>& lens, mm_seqset* reads, std::vector<mm_mapping*>& parts) {
-    std::vector<int32_t> base; for (auto& ch : chunks) base.push_back(ch.first);
-    mm_mapping* m = parts[0];
-    if (parts.size() > 1) {                                       // unifyFiles: read-wise concatenation in chunk order
-      ck(ctx, mm_mapping_concat(ctx, parts.data(), base.data(), (int)parts.size(), &m), "merge chunks");
-      for (auto* pm : parts) mm_mapping_destroy(pm);
-    }
-    parts.clear();
-    ck(ctx, mm_mapping_add_qualities(ctx, m, reads, k), "mapping qualities");
-    std::vector<int64_t> off(names.size() + 1);
-    ck(ctx, mm_mapping_fetch(m, off.data(), nullptr, 0), "fetch");
-    std::vector<mm_map_record> rec((size_t)off.back());
-    ck(ctx, mm_mapping_fetch(m, off.data(), rec.data(), (int64_t)rec.size()), "fetch");
-    pc.lap("6 map+mapq+fetch");
-    for (size_t r = 0; r < names.size(); ++r) {
-      ++F.total;
-      const int len = lens[r];
-      if (len < w || len < k || len < minLen) { ++F.tooShort; continue; }
-      // mapWrap.h:71-75 checks the IDs of mapping LINES against the reads already handled: a repeated ID only stops the run
-      // when the repeat carries mappings; every handled read's ID is remembered (:154-157)
-      if (off[r] == off[r + 1]) { ++F.notMapped; F.unm << len << "\t" << names[r] << "\n"; F.seen.insert(names[r]); continue; }
-      if (!F.seen.insert(names[r]).second) die("Seems that read ID " + names[r] + " has already been processed");
-      ++F.mapped;
-      for (int64_t i = off[r]; i < off[r + 1]; ++i) {
-        const mm_map_record& x = rec[(size_t)i];
-        float id; mm_identity(x.shared, x.sketch, k, &id, nullptr);
-        std::ostringstream ln;                                    // computeMap.hpp:565-581
-        ln << names[r] << " " << len << " " << "0" << " " << len - 1 << " " << (x.strand == 1 ? "+" : "-") << " "
-           << cname[(size_t)x.ref_contig] << " " << clen[(size_t)x.ref_contig] << " " << x.ref_start << " " << x.ref_start + len - 1 << " ";
-        std::ostringstream ids; ids << id;                        // printed, then re-parsed (mapWrap.h:237)
-        ln << ids.str() << " " << x.shared << " " << x.sketch;
-        const double reported = std::stod(ids.str()) / 100.0;
-        const float corrected = std::exp(-(1 - reported));        // mapWrap.h:311
-        ln << " " << corrected * 100 << " " << x.mapq << "\n";    // :318-320
-        F.out << ln.str();
-      }
-    }
+  // what a worker hands to the writer: the finished text of one batch
+  struct Done { size_t file = 0; std::vector<std::string> names; std::vector<int> lens; std::vector<int64_t> off; std::string text; };
+  auto finish_mapping = [&](mm_ctx* ctx, mm_mapping* m, std::vector<std::string>&& names, std::vector<int>&& lens, size_t file) {   // mapping qualities + text; consumes m
+    auto dn = std::make_unique<Done>();
+    dn->file = file; dn->names = std::move(names); dn->lens = std::move(lens);
+    ck(ctx, mm_mapping_add_qualities(ctx, m, nullptr, k), "mapping qualities");
+    dn->off.resize(dn->names.size() + 1);
+    ck(ctx, mm_mapping_fetch(m, dn->off.data(), nullptr, 0), "fetch");
+    std::vector<mm_map_record> rec((size_t)dn->off.back());
+    ck(ctx, mm_mapping_fetch(m, dn->off.data(), rec.data(), (int64_t)rec.size()), "fetch");
     mm_mapping_destroy(m);
-    pc.lap("7 format+write");
+    format_records(dn->names, dn->lens, dn->off, rec, cname, clen, k, dn->text);
+    return dn;
   };
-  auto finish_file = [&](FileOut& F, const std::string& query) {
-    std::ofstream meta(F.prefix + ".meta");                      // mapWrap.h:178-184
-    meta << "TotalReads " << F.total << "\nReadsTooShort " << F.tooShort << "\nReadsMapped " << F.mapped << "\nReadsNotMapped " << F.notMapped << "\n";
-    std::ofstream ps(F.prefix + ".parameters");                  // mapWrap.h:196-211
-    ps << "kmerSize " << k << "\nwindowSize " << w << "\nminReadLength " << minLen << "\nalphabetSize " << 4 << "\nreferenceSize " << refSize
-       << "\npercentageIdentity " << pi << "\np_value " << pval << "\nrefSequences [" << ref << "]\nquerySequences [" << query
-       << "]\noutFileName " << F.prefix << "\nreportAll " << o.all << "\nindex " << "" << "\nmaximumMemory " << maxMem << "\n";
-    std::cout << "INFO, [count of mapped reads, reads qualified for mapping, total input reads] = [" << F.mapped << ", " << F.total - F.tooShort << ", " << F.total << "]\n";
-  };
-  if (!stream_chunks) {
+  // the writer: batches in input order -> PREFIX, .meta.unmappedReadsLengths, .meta, .parameters of every query file (mapWrap.h:34-213)
+  struct Writer {
+    std::mutex m; std::condition_variable cv; std::map<size_t, std::unique_ptr<Done>> ready;
+    void put(size_t seq, std::unique_ptr<Done> d) { std::lock_guard<std::mutex> lk(m); ready[seq] = std::move(d); cv.notify_all(); }
+  } writer;
+  auto write_all = [&](const std::function<std::unique_ptr<Done>(size_t, size_t)>& next /* (file, seq): batch `seq` if it belongs to that file, nullptr once the file has ended */) {
+    size_t seq = 0;
     for (size_t fi = 0; fi < queries.size(); ++fi) {
-      FileOut F(prefixes[fi]);
-      for_each_batch(queries[fi], [&](Batch& bt) {
-        mm_seqset* reads = upload_batch(bt);
+      const std::string& prefix = prefixes[fi];
+      std::ofstream out(prefix), unm(prefix + ".meta.unmappedReadsLengths");
+      if (!out.is_open()) die("Cannot open output file " + prefix);
+      size_t total = 0, tooShort = 0, mapped = 0, notMapped = 0; std::set<std::string> seen;
+      for (;;) {
+        std::unique_ptr<Done> d = next(fi, seq);
+        if (!d) break;
+        if (d->file != fi) die("internal error: batch order");
+        ++seq;
+        for (size_t r = 0; r < d->names.size(); ++r) {
+          ++total;
+          const int len = d->lens[r];
+          if (len < w || len < k || len < minLen) { ++tooShort; continue; }
+          // mapWrap.h:71-75 checks the IDs of mapping LINES against the reads already handled: a repeated ID only stops the run
+          // when the repeat carries mappings; every handled read's ID is remembered (:154-157)
+          if (d->off[r] == d->off[r + 1]) { ++notMapped; unm << len << "\t" << d->names[r] << "\n"; seen.insert(d->names[r]); continue; }
+          if (!seen.insert(d->names[r]).second) die("Seems that read ID " + d->names[r] + " has already been processed");
+          ++mapped;
+        }
+        out << d->text;
+      }
+      std::ofstream meta(prefix + ".meta");                      // mapWrap.h:178-184
+      meta << "TotalReads " << total << "\nReadsTooShort " << tooShort << "\nReadsMapped " << mapped << "\nReadsNotMapped " << notMapped << "\n";
+      std::ofstream ps(prefix + ".parameters");                  // mapWrap.h:196-211
+      ps << "kmerSize " << k << "\nwindowSize " << w << "\nminReadLength " << minLen << "\nalphabetSize " << 4 << "\nreferenceSize " << refSize
+         << "\npercentageIdentity " << pi << "\np_value " << pval << "\nrefSequences [" << ref << "]\nquerySequences [" << queries[fi]
+         << "]\noutFileName " << prefix << "\nreportAll " << o.all << "\nindex " << "" << "\nmaximumMemory " << maxMem << "\n";
+      std::cout << "INFO, [count of mapped reads, reads qualified for mapping, total input reads] = [" << mapped << ", " << total - tooShort << ", " << total << "]\n";
+    }
+  };
+  if (place == Place::Replicated) {
+    // ---- workers: two contexts per device, so that packing, result download and text formatting of one batch overlap the
+    // kernels of the other; the device's chunk indexes are shared (read-only) by its contexts
+    const size_t WPD = o.v.count("workers-per-gpu") ? (size_t)std::max(1, std::stoi(o.v.at("workers-per-gpu"))) : 2;
+    std::vector<std::thread> workers;
+    for (size_t d = 0; d < G; ++d) for (size_t wi = 0; wi < WPD; ++wi) workers.emplace_back([&, d, wi]() {
+      mm_ctx* ctx = devs[d].ctx;
+      if (wi > 0 && mm_ctx_create(devs[d].phys, &ctx) != MM_OK) die("cannot create a worker context");
+      while (std::unique_ptr<Batch> bt = reader.take()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        mm_seqset* reads = upload_batch(ctx, *bt);
+        const auto t1 = std::chrono::steady_clock::now();
         std::vector<mm_mapping*> parts;
-        for (auto& ch : chunks) parts.push_back(map_chunk(ch, reads));
-        finish_batch(F, bt.names, bt.lens, reads, parts);
+        for (size_t c = 0; c < NC; ++c) parts.push_back(map_chunk(ctx, devs[d].idx[c], reads));
+        mm_mapping* m = parts[0];
+        if (parts.size() > 1) {                                   // unifyFiles: read-wise concatenation in chunk order
+          ck(ctx, mm_mapping_concat(ctx, parts.data(), chunk_base.data(), (int)parts.size(), &m), "merge chunks");
+          for (auto* pm : parts) mm_mapping_destroy(pm);
+        }
         mm_seqset_destroy(reads);
-      });
-      finish_file(F, queries[fi]);
-    }
+        const auto t2 = std::chrono::steady_clock::now();
+        const size_t seq = bt->seq;
+        auto dn = finish_mapping(ctx, m, std::move(bt->names), std::move(bt->lens), bt->file);
+        const auto t3 = std::chrono::steady_clock::now();
+        pc.add("5 reads pack+upload", std::chrono::duration<double>(t1 - t0).count());
+        pc.add("6 map", std::chrono::duration<double>(t2 - t1).count());
+        pc.add("7 mapq+fetch+format", std::chrono::duration<double>(t3 - t2).count());
+        reader.recycle(std::move(bt));
+        writer.put(seq, std::move(dn));
+      }
+      if (wi > 0) mm_ctx_destroy(ctx);
+    });
+    write_all([&](size_t fi, size_t seq) -> std::unique_ptr<Done> {
+      std::unique_lock<std::mutex> lk(writer.m);
+      for (;;) {
+        { std::lock_guard<std::mutex> rl(reader.m); if (reader.file_end.size() > fi && reader.file_end[fi] == seq) return nullptr; }   // file fi ended before batch `seq`
+        auto it = writer.ready.find(seq);
+        if (it != writer.ready.end()) { auto d = std::move(it->second); writer.ready.erase(it); return d; }
+        writer.cv.wait_for(lk, std::chrono::milliseconds(20));
+      }
+    });
+    for (auto& t : workers) t.join();
   } else {
-    // Chunks that do not fit HBM together (mapWrap.h:417-437 does the same with files): every read batch is packed and
-    // kept on the device (2 bits per base), then one chunk index at a time is built, every batch is mapped against it
-    // and only the records of that pass are kept; the merge, the mapping qualities and the text follow at the end.
-    struct Held { size_t file; std::vector<std::string> names; std::vector<int> lens; mm_seqset* reads; std::vector<mm_mapping*> parts; };
+    // ---- sharded / streamed: every read batch is packed onto every device and stays there (2 bits per base) ...
+    struct Held { size_t file = 0; std::vector<std::string> names; std::vector<int> lens; std::vector<mm_seqset*> reads;
+                  std::vector<std::vector<int64_t>> poff; std::vector<std::vector<mm_map_record>> prec; };
     std::vector<Held> held;
-    for (size_t fi = 0; fi < queries.size(); ++fi)
-      for_each_batch(queries[fi], [&](Batch& bt) { held.push_back(Held{fi, bt.names, bt.lens, upload_batch(bt), {}}); });
-    for (size_t c = 0; c < chunks.size(); ++c) {
-      prepare_chunk(c);
-      for (auto& h : held) {
-        mm_mapping* pm = map_chunk(chunks[c], h.reads);
-        ck(ctx, mm_mapping_release_intermediates(pm), "trim batch result");
-        h.parts.push_back(pm);
-      }
-      mm_index_destroy(chunks[c].idx); chunks[c].idx = nullptr;
-      pc.lap("6 map+mapq+fetch");
+    while (std::unique_ptr<Batch> bt = reader.take()) {
+      held.emplace_back();
+      Held& h = held.back();
+      h.file = bt->file; h.reads.assign(G, nullptr); h.poff.resize(NC); h.prec.resize(NC);
+      on_each(G, [&](size_t d) { h.reads[d] = upload_batch(devs[d].ctx, *bt); });
+      h.names = std::move(bt->names); h.lens = std::move(bt->lens);
+      reader.recycle(std::move(bt));
     }
-    size_t hi = 0;
-    for (size_t fi = 0; fi < queries.size(); ++fi) {
-      FileOut F(prefixes[fi]);
-      for (; hi < held.size() && held[hi].file == fi; ++hi) {
-        finish_batch(F, held[hi].names, held[hi].lens, held[hi].reads, held[hi].parts);
-        mm_seqset_destroy(held[hi].reads);
-      }
-      finish_file(F, queries[fi]);
+    pc.lap("5 reads pack+upload");
+    // ... then the chunks in rounds: chunk c on device c mod N — all of them at once when they fit together (sharded), N at a time
+    // otherwise (streamed: built, mapped, dropped).  A round's indexes are built concurrently, their thresholds follow in chunk
+    // order from the accumulated histogram, then every device maps every batch against its chunks; the records of a pass go to the
+    // host, where the reference keeps its PREFIX.N files (mapWrap.h:417-437).
+    const size_t per_round = place == Place::Streamed ? G : NC;
+    for (size_t c0 = 0; c0 < NC; c0 += per_round) {
+      const size_t c1 = std::min(NC, c0 + per_round);
+      on_each(G, [&](size_t d) { for (size_t c = c0; c < c1; ++c) if (c % G == d) build_chunk(devs[d], c); });
+      for (size_t c = c0; c < c1; ++c) settle_threshold(c);
+      pc.lap("3 index build");
+      on_each(G, [&](size_t d) {
+        for (size_t c = c0; c < c1; ++c) {
+          if (c % G != d) continue;
+          for (auto& h : held) {
+            mm_mapping* pm = map_chunk(devs[d].ctx, devs[d].idx[c], h.reads[d]);
+            h.poff[c].resize(h.names.size() + 1);
+            ck(devs[d].ctx, mm_mapping_fetch(pm, h.poff[c].data(), nullptr, 0), "fetch");
+            h.prec[c].resize((size_t)h.poff[c].back());
+            ck(devs[d].ctx, mm_mapping_fetch(pm, h.poff[c].data(), h.prec[c].data(), (int64_t)h.prec[c].size()), "fetch");
+            mm_mapping_destroy(pm);
+          }
+          if (place == Place::Streamed) { mm_index_destroy(devs[d].idx[c]); devs[d].idx[c] = nullptr; }
+        }
+      });
+      pc.lap("6 map");
     }
+    // merge in chunk order (unifyFiles), mapping qualities over the union and text: batch b on device b mod N
+    std::vector<std::unique_ptr<Done>> results(held.size());
+    on_each(G, [&](size_t d) {
+      for (auto& h : held) mm_seqset_destroy(h.reads[d]);
+      for (size_t b = d; b < held.size(); b += G) {
+        Held& h = held[b];
+        std::vector<const int64_t*> op; std::vector<const mm_map_record*> rp;
+        for (size_t c = 0; c < NC; ++c) { op.push_back(h.poff[c].data()); rp.push_back(h.prec[c].data()); }
+        mm_mapping* m;
+        ck(devs[d].ctx, mm_mapping_from_parts(devs[d].ctx, (int64_t)h.names.size(), h.lens.data(), &mp, (int)NC, op.data(), rp.data(), chunk_base.data(), &m), "merge chunks");
+        results[b] = finish_mapping(devs[d].ctx, m, std::move(h.names), std::move(h.lens), h.file);
+        std::vector<std::vector<int64_t>>().swap(h.poff); std::vector<std::vector<mm_map_record>>().swap(h.prec);
+      }
+    });
+    pc.lap("7 mapq+fetch+format");
+    write_all([&](size_t fi, size_t seq) -> std::unique_ptr<Done> {
+      if (seq >= results.size() || results[seq]->file != fi) return nullptr;
+      return std::move(results[seq]);
+    });
   }
-  for (auto& ch : chunks) if (ch.idx) mm_index_destroy(ch.idx);
-  mm_ctx_destroy(ctx);
+  pc.lap("8 write");
+  cseq.clear();
+  for (auto& d : devs) { for (auto* ix : d.idx) if (ix) mm_index_destroy(ix); mm_ctx_destroy(d.ctx); }
   return 0;
 }
 
@@ -794,7 +932,7 @@ bool write_unknown_species(const std::string& fn, const std::string& db, const T
   return true;
 }
 
-int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db, size_t minReadsU) {   // meta::doEM, fEM.h:466-803
+int classify_one(const std::vector<Dev>& devs, bool use_comm, const std::string& mapped, const std::string& db, size_t minReadsU) {   // meta::doEM, fEM.h:466-803
   PhaseClock pc;
   // mappings grouped by read (fEM.h:1171-1214)
   std::vector<std::vector<std::string>> groups;
@@ -834,20 +972,43 @@ int classify_one(mm_ctx* ctx, const std::string& mapped, const std::string& db, 
     off.push_back((int64_t)taxon.size());
   }
   pc.lap("c3 per-mapping fields");
-  mm_em* em; ck(ctx, mm_em_create(ctx, (int64_t)groups.size(), off.data(), taxon.data(), mapq.data(), inv.data(), (int32_t)taxa.size(), &em), "em");
-  std::vector<double> f(taxa.size(), 1 / (double)taxa.size()), fn(taxa.size());
+  // The EM loop (fEM.h:501-661).  With several GPUs the reads are sharded contiguously (the reference shards them over OpenMP
+  // threads, :1229); every rank computes the per-taxon posterior sums and the log-likelihood of its reads, one RCCL all-reduce
+  // per iteration (mm_em_iterate_allreduce) replaces the merge of the per-thread sums (:583-600), and every rank normalises and
+  // evaluates the stop rule on identical values.
+  const size_t G = devs.size(), NT = taxa.size(), NR = groups.size();
+  std::vector<double> f(NT, 1 / (double)NT);
+  std::vector<double> post(taxon.size()); std::vector<int64_t> best(NR);
+  char comm_id[MM_COMM_ID_BYTES];
+  if (use_comm && mm_comm_unique_id(comm_id) != MM_OK) die("RCCL: cannot create a communicator id");
   std::cout << "Starting EM..." << std::endl;
-  double llPrev = 0; size_t iter = 0; bool go = true;
-  while (go) {                                                   // fEM.h:501-661
-    std::cout << "EM round " << iter << std::endl;
-    double ll; ck(ctx, mm_em_iterate_allreduce(em, f.data(), fn.data(), &ll), "em iterate");
-    std::cout << "\n\tLog likelihood: " << ll << std::endl;
-    if (iter > 0) { double diff = ll - llPrev, rel = ll / llPrev; std::cout << "\tImprovement: " << diff << "\n\tRelative   : " << rel << std::endl; if (diff <= 1 && (1 - rel) < 0.0001) go = false; }
-    f = fn; ++iter; llPrev = ll;
-  }
-  std::vector<double> post(taxon.size()); std::vector<int64_t> best(groups.size());
-  ck(ctx, mm_em_posteriors(em, f.data(), post.data(), best.data()), "posteriors");
-  mm_em_destroy(em);
+  on_each(G, [&](size_t d) {
+    mm_ctx* ctx = devs[d].ctx;
+    if (use_comm) ck(ctx, mm_comm_init(ctx, comm_id, (int)d, (int)G), "RCCL communicator");
+    const size_t base = NR / G, rem = NR % G, lo = d * base + std::min(d, rem), hi = lo + base + (d < rem ? 1 : 0);   // contiguous shard, rank order = read order
+    std::vector<int64_t> soff(hi - lo + 1);
+    for (size_t i = 0; i <= hi - lo; ++i) soff[i] = off[lo + i] - off[lo];
+    const size_t e0 = (size_t)off[lo];
+    mm_em* em; ck(ctx, mm_em_create(ctx, (int64_t)(hi - lo), soff.data(), taxon.data() + e0, mapq.data() + e0, inv.data() + e0, (int32_t)NT, &em), "em");
+    std::vector<double> fl(f), fn(NT);
+    double llPrev = 0; size_t iter = 0; bool go = true;
+    while (go) {
+      if (d == 0) std::cout << "EM round " << iter << std::endl;
+      double ll; ck(ctx, mm_em_iterate_allreduce(em, fl.data(), fn.data(), &ll), "em iterate");
+      if (d == 0) std::cout << "\n\tLog likelihood: " << ll << std::endl;
+      if (iter > 0) {
+        const double diff = ll - llPrev, rel = ll / llPrev;
+        if (d == 0) std::cout << "\tImprovement: " << diff << "\n\tRelative   : " << rel << std::endl;
+        if (diff <= 1 && (1 - rel) < 0.0001) go = false;
+      }
+      fl = fn; ++iter; llPrev = ll;
+    }
+    std::vector<int64_t> bl(hi - lo);
+    ck(ctx, mm_em_posteriors(em, fl.data(), post.data() + e0, bl.data()), "posteriors");
+    for (size_t i = 0; i < hi - lo; ++i) best[lo + i] = bl[i] < 0 ? -1 : bl[i] + (int64_t)e0;
+    if (d == 0) f = fl;
+    mm_em_destroy(em);
+  });
   pc.lap("c4 EM");
   std::cout << "Outputting mappings with adjusted alignment qualities." << std::endl;
   std::ofstream emf(mapped + ".EM"), r2t(mapped + ".EM.reads2Taxon"), kr(mapped + ".EM.reads2Taxon.krona"), li(mapped + ".EM.lengthAndIdentitiesPerMappingUnit");
@@ -904,11 +1065,16 @@ int main(int argc, char** argv) {
   if (mode == "classify") {
     if (!o.v.count("DB")) die("Provide path to DB.");
     if (!o.v.count("mappings")) die("Provide path to mappings.");
-    mm_ctx* ctx;
-    if (mm_ctx_create(0, &ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
+    std::vector<Dev> devs;
+    for (int p : device_list(o)) { Dev d; d.phys = p; devs.push_back(d); }
+    for (auto& d : devs) if (mm_ctx_create(d.phys, &d.ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
+    const bool use_comm = devs.size() > 1 || o.v.count("gpus") || o.v.count("devices");   // an explicit --gpus 1 also goes through RCCL (one rank)
     const size_t minReadsU = o.v.count("minreads") ? std::stoull(o.v.at("minreads")) : 10000;   // parseCmdArgs.hpp:462-471
-    for (auto& m : split(o.v.at("mappings"), ",")) classify_one(ctx, m, o.v.at("DB"), minReadsU);
-    mm_ctx_destroy(ctx);
+    for (auto& m : split(o.v.at("mappings"), ",")) {
+      classify_one(devs, use_comm, m, o.v.at("DB"), minReadsU);
+      for (auto& d : devs) mm_comm_destroy(d.ctx);
+    }
+    for (auto& d : devs) mm_ctx_destroy(d.ctx);
     return 0;
   }
   die("sub-command '" + mode + "' is outside the accelerated hot path (SURVEY.md §2: Boost-archive index files / disabled upstream)");

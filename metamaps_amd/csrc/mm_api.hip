@@ -17,7 +17,9 @@ void seqset_fetch(mm_seqset* s, int64_t i, char* out, int64_t cap);
 namespace {
 template <typename F>
 int guarded(mm_ctx* ctx, F&& f) {
-  if (ctx) { mm::current_stream() = ctx->stream; mm::current_alloc() = &ctx->alloc; }
+  // a context is bound to the calling thread for the duration of the call: its device (hipSetDevice is per thread), its
+  // stream and its allocator.  Several contexts — one per GPU, or several on one GPU — may be driven from different threads.
+  if (ctx) { if (ctx->device >= 0 && ctx->stream) (void)hipSetDevice(ctx->device); mm::current_stream() = ctx->stream; mm::current_alloc() = &ctx->alloc; }
   try { f(); return MM_OK; }
   catch (const mm::Error& e) { if (ctx) ctx->err = e.what(); return e.status; }
   catch (const std::bad_alloc&) { if (ctx) ctx->err = "host allocation failed"; return MM_ERR_NOMEM; }
@@ -29,6 +31,11 @@ extern "C" {
 
 int mm_abi_version(void) { return MM_ABI_VERSION; }
 
+int mm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
 int mm_ctx_create(int device_id, mm_ctx** out) {
   if (!out) return MM_ERR_ARG;
   *out = nullptr;
@@ -54,6 +61,7 @@ int mm_ctx_create(int device_id, mm_ctx** out) {
 }
 void mm_ctx_destroy(mm_ctx* ctx) {
   if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->alloc.trim();
   mm::comm_destroy(ctx);
@@ -89,7 +97,7 @@ int mm_seqset_create(mm_ctx* ctx, mm_seqset** out) {
   if (!ctx || !out) return MM_ERR_ARG;
   return guarded(ctx, [&] { auto* s = new mm_seqset; s->ctx = ctx; *out = s; });
 }
-void mm_seqset_destroy(mm_seqset* s) { if (s) { mm::current_stream() = s->ctx->stream; mm::current_alloc() = &s->ctx->alloc; delete s; } }
+void mm_seqset_destroy(mm_seqset* s) { if (s) { (void)hipSetDevice(s->ctx->device); mm::current_stream() = s->ctx->stream; mm::current_alloc() = &s->ctx->alloc; delete s; } }
 int mm_seqset_add(mm_seqset* s, const char* ascii, int64_t len) {
   if (!s || (!ascii && len > 0) || len < 0) return MM_ERR_ARG;
   return guarded(s->ctx, [&] {
@@ -186,7 +194,7 @@ int mm_index_plan_chunks(mm_ctx* ctx, const mm_index* whole, uint64_t max_memory
     }
   });
 }
-void mm_index_destroy(mm_index* idx) { if (idx) { mm::current_stream() = idx->ctx->stream; mm::current_alloc() = &idx->ctx->alloc; delete idx; } }
+void mm_index_destroy(mm_index* idx) { if (idx) { (void)hipSetDevice(idx->ctx->device); mm::current_stream() = idx->ctx->stream; mm::current_alloc() = &idx->ctx->alloc; delete idx; } }
 int mm_index_get_info(const mm_index* idx, mm_index_info* out) {
   if (!idx || !out) return MM_ERR_ARG;
   out->n_contigs = idx->n_contigs; out->n_entries = idx->N; out->n_unique_hashes = idx->U; out->n_dup_flagged = idx->n_dup;
@@ -268,7 +276,7 @@ int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const
     *out = M;
   });
 }
-void mm_mapping_destroy(mm_mapping* m) { if (m) { mm::current_stream() = m->ctx->stream; mm::current_alloc() = &m->ctx->alloc; delete m; } }
+void mm_mapping_destroy(mm_mapping* m) { if (m) { (void)hipSetDevice(m->ctx->device); mm::current_stream() = m->ctx->stream; mm::current_alloc() = &m->ctx->alloc; delete m; } }
 int mm_mapping_release_intermediates(mm_mapping* m) {
   if (!m) return MM_ERR_ARG;
   return guarded(m->ctx, [&] {
@@ -308,26 +316,26 @@ int mm_mapping_add_qualities(mm_ctx* ctx, mm_mapping* m, const mm_seqset* reads,
   (void)reads;
   return guarded(ctx, [&] { MM_HIP(hipSetDevice(ctx->device)); mm::mapping_add_qualities(ctx, m, k); });
 }
-int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* contig_base, int n_parts, mm_mapping** out) {
-  if (!ctx || !parts || n_parts <= 0 || !out) return MM_ERR_ARG;
-  return guarded(ctx, [&] {
-    // read-wise concatenation in chunk order (unifyFiles, mapWrap.h:128-132); small, done on the host
-    const int64_t n = parts[0]->n_reads;
-    std::vector<std::vector<mm_map_record>> recs((size_t)n_parts);
-    for (int p = 0; p < n_parts; ++p) {
-      MM_REQUIRE(parts[p]->n_reads == n, MM_ERR_ARG, "chunk results cover different read sets");
-      recs[(size_t)p].resize((size_t)parts[p]->n_rec);
-      parts[p]->rec.download(recs[(size_t)p].data(), (size_t)parts[p]->n_rec, ctx->stream);
+// read-wise concatenation of per-chunk record lists in chunk order (unifyFiles, mapWrap.h:128-132); small, done on the host
+static mm_mapping* merge_parts(mm_ctx* ctx, int64_t n, const std::vector<int32_t>& read_len, const mm_map_params& params, int n_parts,
+                               const int64_t* const* offsets, const mm_map_record* const* records, const int32_t* contig_base) {
+  auto* M = new mm_mapping;
+  try {
+    M->ctx = ctx; M->n_reads = n; M->params = params; M->read_len = read_len;
+    M->active.assign((size_t)n, 0);
+    M->stats = mm_map_stats{};
+    M->stats.n_reads = n;
+    for (int64_t r = 0; r < n; ++r) {
+      const int L = read_len[(size_t)r];
+      const bool ok = !(L < params.w || L < params.k || L < params.min_read_len);   // computeMap.hpp:137
+      M->active[(size_t)r] = ok;
+      if (ok) { M->stats.n_reads_long_enough++; M->stats.bases_long_enough += L; }
     }
-    MM_HIP(hipStreamSynchronize(ctx->stream));
-    auto* M = new mm_mapping;
-    M->ctx = ctx; M->n_reads = n; M->params = parts[0]->params; M->read_len = parts[0]->read_len; M->active = parts[0]->active;
-    M->stats = parts[0]->stats;
     std::vector<mm_map_record> all; std::vector<uint64_t> off((size_t)n + 1, 0);
     for (int64_t r = 0; r < n; ++r) {
       for (int p = 0; p < n_parts; ++p)
-        for (uint64_t i = parts[p]->h_rec_off[(size_t)r]; i < parts[p]->h_rec_off[(size_t)r + 1]; ++i) {
-          mm_map_record x = recs[(size_t)p][(size_t)i];
+        for (int64_t i = offsets[p][r]; i < offsets[p][r + 1]; ++i) {
+          mm_map_record x = records[p][i];
           x.ref_contig += contig_base ? contig_base[p] : 0;
           all.push_back(x);
         }
@@ -338,14 +346,45 @@ int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* cont
     M->rec_off.alloc((size_t)n + 1); M->rec_off.upload(off.data(), off.size(), ctx->stream);
     M->d_read_len.alloc((size_t)std::max<int64_t>(n, 1)); M->d_read_len.upload(M->read_len.data(), (size_t)n, ctx->stream);
     M->h_rec_off = off;
-    M->stats.n_mappings = M->n_rec; M->stats.n_reads_mapped = 0;
+    M->stats.n_mappings = M->n_rec;
     for (int64_t r = 0; r < n; ++r) if (off[(size_t)r + 1] > off[(size_t)r]) M->stats.n_reads_mapped++;
-    for (int p = 1; p < n_parts; ++p) {
-      M->stats.sum_hits += parts[p]->stats.sum_hits; M->stats.n_candidates += parts[p]->stats.n_candidates;
-      M->stats.sum_l2_stream_entries += parts[p]->stats.sum_l2_stream_entries; M->stats.sum_l2_evals += parts[p]->stats.sum_l2_evals;
+    M->released = true;                                          // records only: the debug taps have nothing to show
+    MM_HIP(hipStreamSynchronize(ctx->stream));
+  } catch (...) { delete M; throw; }
+  return M;
+}
+int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* contig_base, int n_parts, mm_mapping** out) {
+  if (!ctx || !parts || n_parts <= 0 || !out) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    const int64_t n = parts[0]->n_reads;
+    std::vector<std::vector<mm_map_record>> recs((size_t)n_parts);
+    std::vector<std::vector<int64_t>> offs((size_t)n_parts);
+    std::vector<const int64_t*> op; std::vector<const mm_map_record*> rp;
+    for (int p = 0; p < n_parts; ++p) {
+      MM_REQUIRE(parts[p]->n_reads == n, MM_ERR_ARG, "chunk results cover different read sets");
+      MM_REQUIRE(parts[p]->ctx->device == ctx->device, MM_ERR_ARG, "mm_mapping_concat: parts of another device go through mm_mapping_fetch + mm_mapping_from_parts");
+      recs[(size_t)p].resize((size_t)parts[p]->n_rec);
+      parts[p]->rec.download(recs[(size_t)p].data(), (size_t)parts[p]->n_rec, ctx->stream);
+      offs[(size_t)p].assign(parts[p]->h_rec_off.begin(), parts[p]->h_rec_off.end());
     }
     MM_HIP(hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p < n_parts; ++p) { op.push_back(offs[(size_t)p].data()); rp.push_back(recs[(size_t)p].data()); }
+    mm_mapping* M = merge_parts(ctx, n, parts[0]->read_len, parts[0]->params, n_parts, op.data(), rp.data(), contig_base);
+    for (int p = 0; p < n_parts; ++p) {
+      M->stats.sum_hits += parts[p]->stats.sum_hits; M->stats.n_candidates += parts[p]->stats.n_candidates;
+      M->stats.sum_l2_stream_entries += parts[p]->stats.sum_l2_stream_entries; M->stats.sum_l2_evals += parts[p]->stats.sum_l2_evals;
+      M->stats.sum_sketch = parts[p]->stats.sum_sketch;
+    }
     *out = M;
+  });
+}
+int mm_mapping_from_parts(mm_ctx* ctx, int64_t n_reads, const int32_t* read_len, const mm_map_params* p, int n_parts,
+                          const int64_t* const* offsets, const mm_map_record* const* records, const int32_t* contig_base, mm_mapping** out) {
+  if (!ctx || n_reads < 0 || (!read_len && n_reads > 0) || !p || n_parts <= 0 || !offsets || !records || !out) return MM_ERR_ARG;
+  for (int i = 0; i < n_parts; ++i) if (!offsets[i] || (!records[i] && offsets[i][n_reads] > 0)) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    std::vector<int32_t> len(read_len, read_len + n_reads);
+    *out = merge_parts(ctx, n_reads, len, *p, n_parts, offsets, records, contig_base);
   });
 }
 
@@ -480,7 +519,7 @@ int mm_em_sizes(const mm_em* em, int64_t* n_reads, int64_t* n_entries, int32_t* 
   if (n_taxa) *n_taxa = em->n_taxa;
   return MM_OK;
 }
-void mm_em_destroy(mm_em* em) { if (em) { mm::current_stream() = em->ctx->stream; mm::current_alloc() = &em->ctx->alloc; delete em; } }
+void mm_em_destroy(mm_em* em) { if (em) { (void)hipSetDevice(em->ctx->device); mm::current_stream() = em->ctx->stream; mm::current_alloc() = &em->ctx->alloc; delete em; } }
 int mm_em_iterate(mm_em* em, const double* f, double* f_partial, double* ll_partial) {
   if (!em || !f || !f_partial || !ll_partial) return MM_ERR_ARG;
   return guarded(em->ctx, [&] { MM_HIP(hipSetDevice(em->ctx->device)); mm::em_iterate(em, f, f_partial, ll_partial); });

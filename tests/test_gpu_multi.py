@@ -1,0 +1,170 @@
+"""Several GPUs through the drop-in CLI and the RCCL path of the library.
+
+The GPU test box has one MI355X, so:
+  * the RCCL code path runs with a one-rank communicator (ncclCommInitRank + ncclAllReduce are really executed);
+  * the multi-device orchestration of the CLI (order-preserving batch hand-out, chunk indexes spread over devices, records
+    gathered to a batch's owner, rounds of streamed chunks) runs with several LOGICAL devices on the one physical GPU
+    (`--devices 0,0,0`: one context each — exactly the code a real `--gpus 3` runs, minus peer hardware);
+  * `--gpus 2` on two physical devices runs wherever two are visible and is skipped otherwise.
+Every result is compared with the oracle CLI (bit-exact text, floats 1e-5)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_gpu_cli import CLI, _cmp_table
+
+pytestmark = pytest.mark.gpu
+
+
+def _classify_files_equal(pa, pb):
+    _cmp_table(pa + ".EM", pb + ".EM", " ", {13})
+    assert open(pa + ".EM.reads2Taxon").read() == open(pb + ".EM.reads2Taxon").read()
+    _cmp_table(pa + ".EM.reads2Taxon.krona", pb + ".EM.reads2Taxon.krona", "\t", {2})
+    _cmp_table(pa + ".EM.WIMP", pb + ".EM.WIMP", "\t", {4, 5})
+    _cmp_table(pa + ".EM.lengthAndIdentitiesPerMappingUnit", pb + ".EM.lengthAndIdentitiesPerMappingUnit", "\t", {3})
+    _cmp_table(pa + ".EM.contigCoverage", pb + ".EM.contigCoverage", "\t", {6})
+
+
+def _map_files_equal(pa, pb):
+    _cmp_table(pa, pb, " ", {13})
+    for suf in (".meta", ".meta.unmappedReadsLengths"):
+        assert open(pa + suf).read() == open(pb + suf).read(), suf
+
+
+@pytest.fixture(scope="module")
+def small_run(tmp_path_factory, oracle_lib):
+    """a 10-genome DB, 400 reads in two query files (so that batches, files and chunk passes all have borders), oracle outputs"""
+    import orc
+    from metamaps_amd import synth
+    d = tmp_path_factory.mktemp("multi")
+    db = synth.make_db(str(d / "db"), n_genomes=10, genome_len=60_000, seed=7)
+    r1 = synth.make_reads(db, str(d / "r1.fq"), n_reads=260, read_len=3000, seed=3)
+    r2 = synth.make_reads(db, str(d / "r2.fq"), n_reads=140, read_len=2500, seed=4)
+    ora = {}
+    for tag, extra in (("plain", []), ("chunks", ["--maxmemory-bytes", "1000000"])):
+        o1, o2 = str(d / f"cpu_{tag}1"), str(d / f"cpu_{tag}2")
+        subprocess.run([orc.CLI, "mapDirectly", "--all", "-r", db.fasta, "-q", r1["path"] + "," + r2["path"], "-o", o1 + "," + o2] + extra,
+                       check=True, capture_output=True, timeout=900)
+        ora[tag] = (o1, o2)
+    subprocess.run([orc.CLI, "classify", "--DB", db.dir, "--mappings", ora["plain"][0], "--minreads", "3"], check=True, capture_output=True, timeout=900)
+    return {"dir": d, "db": db, "queries": r1["path"] + "," + r2["path"], "oracle": ora}
+
+
+def _gpu_map(run, tag, extra):
+    d = run["dir"]
+    o1, o2 = str(d / f"gpu_{tag}1"), str(d / f"gpu_{tag}2")
+    # MM_CLI_BATCH_READS: batches of 64 reads, so that several batches are in flight on every worker
+    env = dict(os.environ, MM_CLI_BATCH_READS="64")
+    p = subprocess.run([CLI, "mapDirectly", "--all", "-r", run["db"].fasta, "-q", run["queries"], "-o", o1 + "," + o2] + extra,
+                       capture_output=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return o1, o2, p.stdout.decode()
+
+
+@pytest.mark.parametrize("devices", ["0", "0,0", "0,0,0"])
+def test_replicated_index_batches_over_devices(small_run, devices):
+    """index replicated per device, read batches handed to whichever worker is free, output in input order"""
+    o1, o2, _ = _gpu_map(small_run, "rep" + devices.replace(",", ""), ["--devices", devices])
+    _map_files_equal(o1, small_run["oracle"]["plain"][0])
+    _map_files_equal(o2, small_run["oracle"]["plain"][1])
+
+
+@pytest.mark.parametrize("devices,mode", [("0,0", "--shard-index"), ("0,0,0", "--shard-index"), ("0,0", "--stream-chunks"), ("0,0,0", "--stream-chunks"), ("0", "--shard-index")])
+def test_chunk_indexes_spread_over_devices(small_run, devices, mode):
+    """--maxmemory chunks, chunk c on device c mod N (all resident, or N at a time), every batch visits every device, records
+    gathered on the batch's owner: same files as the oracle under the same --maxmemory"""
+    o1, o2, out = _gpu_map(small_run, mode.strip("-")[:5] + devices.replace(",", ""), ["--devices", devices, mode, "--maxmemory-bytes", "1000000"])
+    assert sum(1 for l in out.splitlines() if l.startswith("INFO, index chunk")) >= 3
+    _map_files_equal(o1, small_run["oracle"]["chunks"][0])
+    _map_files_equal(o2, small_run["oracle"]["chunks"][1])
+
+
+def test_replicated_chunks_over_devices(small_run):
+    """--maxmemory with every chunk index on every device (BASELINE config 4's shape: miniSeq+H chunks all fit one GPU)"""
+    o1, o2, _ = _gpu_map(small_run, "repchunks", ["--devices", "0,0", "--maxmemory-bytes", "1000000"])
+    _map_files_equal(o1, small_run["oracle"]["chunks"][0])
+    _map_files_equal(o2, small_run["oracle"]["chunks"][1])
+
+
+def test_classify_through_rccl_one_rank(small_run):
+    """`classify --gpus 1`: the EM loop goes through ncclCommInitRank / ncclAllReduce (one rank) and writes the oracle's files"""
+    o1, _, _ = _gpu_map(small_run, "cls", [])
+    p = subprocess.run([CLI, "classify", "--DB", small_run["db"].dir, "--mappings", o1, "--minreads", "3", "--gpus", "1"], capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    _classify_files_equal(o1, small_run["oracle"]["plain"][0])
+
+
+def test_two_physical_gpus(small_run):
+    """--gpus 2: mapDirectly (replicated and sharded) and classify (reads sharded, RCCL all-reduce over xGMI) == --gpus 1 == oracle"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    for tag, extra, ref in (("g2", ["--gpus", "2"], "plain"), ("g2s", ["--gpus", "2", "--shard-index", "--maxmemory-bytes", "1000000"], "chunks")):
+        o1, o2, _ = _gpu_map(small_run, tag, extra)
+        _map_files_equal(o1, small_run["oracle"][ref][0])
+        _map_files_equal(o2, small_run["oracle"][ref][1])
+    o1, _, _ = _gpu_map(small_run, "g2c", ["--gpus", "2"])
+    p = subprocess.run([CLI, "classify", "--DB", small_run["db"].dir, "--mappings", o1, "--minreads", "3", "--gpus", "2"], capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    _classify_files_equal(o1, small_run["oracle"]["plain"][0])
+
+
+def test_allreduce_iteration_equals_local_iteration():
+    """mm_comm_init(nranks = 1), then mm_em_iterate_allreduce (device partial sums -> ncclAllReduce -> normalise) must equal
+    mm_em_iterate + the same normalisation on the host, bit for bit; mm_comm_allreduce_f64 is the identity"""
+    from metamaps_amd import capi
+    rng = np.random.default_rng(11)
+    n_reads, n_taxa = 5000, 37
+    per = rng.integers(1, 9, size=n_reads)
+    off = np.concatenate([[0], np.cumsum(per)]).astype(np.int64)
+    ne = int(off[-1])
+    taxon = rng.integers(0, n_taxa, size=ne).astype(np.int32)
+    mapq = rng.random(ne)
+    inv = 1.0 / rng.integers(1000, 5_000_000, size=ne).astype(np.float64)
+    f = np.full(n_taxa, 1.0 / n_taxa)
+    ctx_a, ctx_b = capi.Context(0), capi.Context(0)
+    ctx_b.comm_init(capi.Context.comm_unique_id(), 0, 1)
+    ea, eb = ctx_a.em(off, taxon, mapq, inv, n_taxa), ctx_b.em(off, taxon, mapq, inv, n_taxa)
+    v = rng.random(n_taxa + 1)
+    w = v.copy(); ctx_b.comm_allreduce(w)
+    assert np.array_equal(v, w)
+    for _ in range(6):
+        part, ll_a = ea.iterate(f)
+        tot = 0.0
+        for x in part:                                            # the library normalises with a sequential sum (fEM.h:606-615)
+            tot += float(x)
+        f_a = part / tot
+        f_b, ll_b = eb.iterate_allreduce(f)
+        assert np.array_equal(f_a, f_b) and ll_a == ll_b
+        f = f_b
+    ea.close(); eb.close(); ctx_a.close(); ctx_b.close()
+
+
+def test_records_gathered_from_parts_equal_device_concat(oracle_lib):
+    """mm_mapping_from_parts (host-side parts of chunks mapped elsewhere) == mm_mapping_concat, incl. mapping qualities"""
+    from metamaps_amd import capi, synth
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        db = synth.make_db(os.path.join(d, "db"), n_genomes=8, genome_len=50_000, seed=3)
+        rd = synth.make_reads(db, os.path.join(d, "r.fq"), n_reads=150, read_len=3000, seed=2)
+        reads = [l.strip() for i, l in enumerate(open(rd["path"], "rb")) if i % 4 == 1]
+        contigs = [s.tobytes() for s in db.contig_seqs]
+    ctx, ctx2 = capi.Context(0), capi.Context(0)
+    k, w = 16, 10
+    half = len(contigs) // 2
+    R = ctx.seqset(reads)
+    parts, host = [], []
+    for a, b in ((0, half), (half, len(contigs))):
+        S = ctx.seqset(contigs[a:b]); idx = ctx.index(S, k, w)
+        M = ctx.map_batch(idx, R, k, w)
+        parts.append(M); host.append(M.fetch())
+    U = capi.Mapping.concat(ctx, parts, [0, half]); U.add_qualities(k)
+    lens = R.lengths()
+    V = capi.Mapping.from_parts(ctx2, lens, host, [0, half], k, w); V.add_qualities(k)
+    (oa, ra), (ob, rb) = U.fetch(), V.fetch()
+    assert np.array_equal(oa, ob) and len(ra) > 100
+    for fld in ("read", "ref_contig", "ref_start", "shared", "sketch", "strand", "mapq"):
+        assert np.array_equal(ra[fld], rb[fld]), fld
+    ctx.close(); ctx2.close()

@@ -54,6 +54,7 @@ void orc_index_free(void* h) { delete (OrcIndex*)h; }
 long orc_index_entries(void* h) { return (long)((OrcIndex*)h)->R.byPos.size(); }
 long orc_index_contigs(void* h) { return (long)((OrcIndex*)h)->R.meta.size(); }
 int orc_index_freq_threshold(void* h) { return ((OrcIndex*)h)->R.freqThreshold; }
+void orc_index_set_freq_threshold(void* h, int thr) { ((OrcIndex*)h)->R.freqThreshold = thr; }   // tests: hit lists under a forced threshold
 long orc_index_unique_hashes(void* h) { return (long)((OrcIndex*)h)->R.lookup.size(); }
 void orc_index_dump(void* h, uint32_t* hash, int32_t* seq, int32_t* wpos, int32_t* strand) {
   auto& v = ((OrcIndex*)h)->R.byPos;

@@ -41,6 +41,7 @@ class Oracle:
             getattr(L, n).restype = C.c_long
             getattr(L, n).argtypes = [C.c_void_p]
         L.orc_index_freq_threshold.argtypes = [C.c_void_p]
+        L.orc_index_set_freq_threshold.argtypes = [C.c_void_p, C.c_int]
         L.orc_index_dump.argtypes = [C.c_void_p] * 5
         L.orc_index_contig_len.argtypes = [C.c_void_p, C.c_long]
         L.orc_map_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
@@ -83,6 +84,10 @@ class OracleIndex:
         self.n_unique = orc.L.orc_index_unique_hashes(self.h)
         self.freq_threshold = orc.L.orc_index_freq_threshold(self.h)
 
+    def set_freq_threshold(self, thr: int):
+        self.o.L.orc_index_set_freq_threshold(self.h, int(thr))
+        self.freq_threshold = int(thr)
+
     def dump(self):
         h = np.zeros(self.n, dtype=np.uint32); s = np.zeros(self.n, dtype=np.int32)
         w = np.zeros(self.n, dtype=np.int32); st = np.zeros(self.n, dtype=np.int32)
@@ -93,7 +98,7 @@ class OracleIndex:
         cap = len(seq) + 16
         n = np.zeros(5, dtype=np.int32)
         skh = np.zeros(cap, dtype=np.uint32); sks = np.zeros(cap, dtype=np.int32)
-        hcap = 1 << 20
+        hcap = 1 << 23
         hs = np.zeros(hcap, dtype=np.int32); hw = np.zeros(hcap, dtype=np.int32)
         ccap = 4096
         cand = np.zeros((ccap, 3), dtype=np.int32); l2 = np.zeros((ccap, 5), dtype=np.int64); mp = np.zeros((ccap, 6), dtype=np.int32)

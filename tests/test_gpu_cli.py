@@ -333,3 +333,24 @@ def test_reads_of_any_length_match_oracle(oracle_lib, tmp_path, w_flag):
         assert open(pa + suf).read() == open(pb + suf).read(), suf
     mapped = {l.split(" ")[0] for l in open(pa)}
     assert mapped == {f"long{i}" for i in range(5)}
+
+
+def test_cli_at_bench_hit_density_matches_oracle(oracle_lib, tmp_path):
+    """mapDirectly + classify with k = 10 on a 24 Mbp reference: the 32-bit hash space is saturated as at miniSeq+H scale
+    (tens of thousands of chance seed hits per read, the pre-filter drops > 90 %), every output file equal to the oracle's"""
+    import orc
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=24, genome_len=1_000_000, seed=33, contigs_per_genome=2)
+    rd = synth.make_reads(db, str(tmp_path / "reads.fq"), n_reads=260, read_len=6000, seed=12, len_jitter=0.4)
+    pa, pb = str(tmp_path / "gpu"), str(tmp_path / "cpu")
+    for exe, pre in ((CLI, pa), (orc.CLI, pb)):
+        subprocess.run([exe, "mapDirectly", "--all", "-k", "10", "-w", "8", "-r", db.fasta, "-q", rd["path"], "-o", pre], check=True, capture_output=True, timeout=1800)
+        subprocess.run([exe, "classify", "--DB", db.dir, "--mappings", pre, "--minreads", "3"], check=True, capture_output=True, timeout=900)
+    _cmp_table(pa, pb, " ", {13})
+    for suf in (".meta", ".meta.unmappedReadsLengths"):
+        assert open(pa + suf).read() == open(pb + suf).read(), suf
+    _cmp_table(pa + ".EM", pb + ".EM", " ", {13})
+    assert open(pa + ".EM.reads2Taxon").read() == open(pb + ".EM.reads2Taxon").read()
+    _cmp_table(pa + ".EM.WIMP", pb + ".EM.WIMP", "\t", {4, 5})
+    _cmp_table(pa + ".EM.contigCoverage", pb + ".EM.contigCoverage", "\t", {6})
+    assert sum(1 for _ in open(pa)) > 300

@@ -430,3 +430,85 @@ def test_mixed_read_lengths_one_batch_equal_full_slide(ctx, monkeypatch):
     assert np.array_equal(res["0"][0], res["1"][0]) and np.array_equal(res["0"][1], res["1"][1])
     assert res["0"][2]["n_mappings"] > 1500
     idx.close(); reads.close(); ref.close()
+
+
+@pytest.fixture(scope="module")
+def dense(tmp_path_factory, oracle_lib):
+    """The bench's regime at oracle size: a 30 Mbp reference under k = 10 saturates the hash space (a few hundred thousand distinct
+    minimizer hashes for ~7 million index entries, ~20 occurrences per hash), so that a read draws tens of thousands of chance
+    seed hits of which only the few per cent around its true locations matter — what K3 / K3c / K4 see at miniSeq+H density."""
+    from metamaps_amd import synth
+    d = tmp_path_factory.mktemp("dense")
+    db = synth.make_db(str(d / "db"), n_genomes=30, genome_len=1_000_000, seed=21, contigs_per_genome=2)
+    rd = synth.make_reads(db, str(d / "reads.fq"), n_reads=220, read_len=5000, seed=8, len_jitter=0.3)
+    return {"dir": str(d), "db": db, "reads": rd["path"]}
+
+
+@pytest.mark.parametrize("k,w,force_thr", [(10, 8, None), (10, 8, "cut30"), (11, 6, None)])
+def test_mapping_at_bench_hit_density_matches_oracle(ctx, oracle_lib, dense, k, w, force_thr, monkeypatch):
+    """Every stage against the oracle where the seed-hit filter has real work: > 90 % of the raw hits dropped, long occurrence
+    lists, and (force_thr) a frequency threshold that actually cuts lists (computeMap.hpp:307-385, winSketch.hpp:452-494)."""
+    names, contigs = _read_fasta(dense["db"].fasta)
+    rnames, reads = _read_fastq(dense["reads"])
+    S = ctx.seqset(contigs); R = ctx.seqset(reads)
+    idx = ctx.index(S, k, w)
+    oi = oracle_lib.index(dense["db"].fasta, k, w)
+    info = idx.info()
+    assert info["n_entries"] == oi.n and info["n_unique_hashes"] == oi.n_unique and idx.freq_threshold == oi.freq_threshold
+    assert info["n_entries"] > 5 * info["n_unique_hashes"]        # saturated: more than five occurrences per hash on average
+    if force_thr is not None:                                      # the threshold that cuts the lists holding ~30 % of the index entries
+        cnt, nh = idx.freq_hist()
+        cut = np.cumsum((cnt * nh)[::-1])[::-1] / float((cnt * nh).sum())       # share of the entries in lists of >= cnt[i] occurrences
+        force_thr = int(cnt[np.argmax(cut <= 0.3)])
+        idx.set_freq_threshold(force_thr); oi.set_freq_threshold(force_thr)
+    monkeypatch.setenv("MM_EAGER_TIEBREAK", "1")
+    exp = [oi.map_read(q, 80.0) if len(q) >= max(1000, k, w) else None for q in reads]
+    out = {}
+    for mode in ("filter", "raw"):
+        if mode == "raw":
+            monkeypatch.setenv("MM_NO_HIT_FILTER", "1")
+        M = ctx.map_batch(idx, R, k, w, pi=80.0, min_read_len=1000)
+        M.add_qualities(k)
+        out[mode] = dict(st=M.stats(), sk=M.debug_sketch(), hits=M.debug_hits(), cand=M.debug_candidates(), mh=M.debug_min_hits(), rec=M.fetch())
+        out[mode]["l2"] = M.debug_l2(len(out[mode]["cand"][1]))
+        M.close()
+    monkeypatch.delenv("MM_NO_HIT_FILTER")
+    st = out["filter"]["st"]
+    print("density", k, w, force_thr, {kk: st[kk] for kk in ("sum_sketch", "sum_hits", "sum_hits_kept", "n_candidates", "n_mappings")})
+    if force_thr is None:
+        assert st["sum_hits"] > 2_000_000 and st["sum_hits_kept"] * 10 < st["sum_hits"], st  # the filter drops > 90 %
+    else:                                                          # most lists are cut by the threshold, the filter still drops most of the rest
+        assert 1_000_000 < st["sum_hits"] and st["sum_hits_kept"] * 5 < st["sum_hits"], st
+    for mode in ("filter", "raw"):
+        sk_off, sk_h, sk_s = out[mode]["sk"]; hit_off, hit_c, hit_w = out[mode]["hits"]; cand_off, cand = out[mode]["cand"]
+        rec_off, rec = out[mode]["rec"]; l2 = out[mode]["l2"]; mh = out[mode]["mh"]
+        n_mapped = 0
+        for r, q in enumerate(reads):
+            o = exp[r]
+            if o is None:
+                assert rec_off[r + 1] == rec_off[r]
+                continue
+            a, b = int(sk_off[r]), int(sk_off[r + 1])
+            assert np.array_equal(sk_h[a:b], o["sketch_hash"]) and np.array_equal(sk_s[a:b], o["sketch_strand"]), r
+            assert mh[r] == o["min_hits"], r
+            a, b = int(hit_off[r]), int(hit_off[r + 1])
+            if mode == "raw":                                     # the complete seed-hit list, also under the forced threshold
+                assert np.array_equal(hit_c[a:b], o["hit_contig"]) and np.array_equal(hit_w[a:b], o["hit_wpos"]), r
+            else:                                                 # what the filter keeps is a sub-list of it, in order
+                key_all = o["hit_contig"].astype(np.int64) << 32 | o["hit_wpos"]
+                key_kept = hit_c[a:b].astype(np.int64) << 32 | hit_w[a:b]
+                assert np.all(np.diff(key_kept) >= 0) and np.all(np.isin(key_kept, key_all)), r
+            a, b = int(cand_off[r]), int(cand_off[r + 1])
+            assert np.array_equal(cand[a:b], o["cand"]), r
+            got, ex = l2[a:b], o["l2"]
+            ok = got[:, 5] == 1
+            assert np.array_equal(got[:, 0], ex[:, 0]) and np.array_equal(got[ok][:, [1, 2, 3, 4]], ex[ok][:, [1, 2, 3, 4]]), r
+            assert np.all(got[~ok][:, 2] <= ex[~ok][:, 2]) and int(ok.sum()) == len(o["map"]), r
+            a, b = int(rec_off[r]), int(rec_off[r + 1])
+            m, rr = o["map"], rec[a:b]
+            assert b - a == len(m), r
+            assert np.array_equal(rr["ref_contig"], m[:, 0]) and np.array_equal(rr["ref_start"], m[:, 1]) and np.array_equal(rr["shared"], m[:, 3]), r
+            assert np.array_equal(rr["sketch"], m[:, 4]) and np.array_equal(rr["strand"], m[:, 5]), r
+            n_mapped += len(m) > 0
+        assert n_mapped > 150, n_mapped
+    oi.close(); idx.close(); R.close(); S.close()

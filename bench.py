@@ -90,6 +90,8 @@ def main():
     if world > 1:
         dist.broadcast_object_list(uid, src=0)
     ctx.comm_init(uid[0], rank, world)
+    import ctypes
+    ctypes.CDLL(None).fflush(None)                                # RCCL prints a version banner through C stdio: out before the JSON line
 
     k, w = 16, args.window
     G = args.species * args.strains

@@ -167,10 +167,11 @@ __global__ void __launch_bounds__(256) scatter_strand_kernel(const uint8_t* __re
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) probe_kernel(IndexView I, const uint32_t* __restrict__ sk_hash, const uint64_t* __restrict__ off,
                                                     const int32_t* __restrict__ sk_n, uint32_t* __restrict__ probe_cnt,
-                                                    uint64_t* __restrict__ probe_start) {
+                                                    uint64_t* __restrict__ probe_start, const uint8_t* __restrict__ only /* optional: reads to do */) {
   // Four lanes per lookup, each reading one 16-byte slot of the hash's home sector (mm_index.hpp: tab_slot): one 64-byte
   // request resolves nearly every lookup; NP lookups per group in flight.
   const int r = blockIdx.x;
+  if (only && !only[r]) return;
   const uint64_t o = off[r];
   const int s = sk_n[r];
   const int grp = threadIdx.x >> 2, sub = threadIdx.x & 3, gshift = (threadIdx.x & 63) & ~3;
@@ -240,11 +241,14 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
                                                          const uint32_t* __restrict__ probe_cnt, const uint64_t* __restrict__ probe_start,
                                                          const int32_t* __restrict__ read_len, const int32_t* __restrict__ min_hits,
                                                          uint32_t* __restrict__ surv_n, const uint64_t* __restrict__ read_hit_off,
-                                                         uint64_t* __restrict__ hits, uint64_t* __restrict__ stage, const uint64_t* __restrict__ stage_off, int dbg) {
+                                                         uint64_t* __restrict__ hits, uint64_t* __restrict__ stage, const uint64_t* __restrict__ stage_off, int dbg,
+                                                         const uint8_t* __restrict__ only /* optional (WRITE = false): reads to do */,
+                                                         uint32_t* __restrict__ raw_hits /* optional (WRITE = false): seed hits of the read before filtering */) {
   __shared__ uint32_t cnt[HF_SLOTS];
   __shared__ uint32_t good[HF_SLOTS / 32], alive[HF_SLOTS / 32];
   __shared__ uint32_t cursor;
   const int r = blockIdx.x;
+  if (!WRITE && only && !only[r]) return;
   if (WRITE) {                                                   // staged reads only need a copy
     const uint32_t n_s = surv_n[r];
     if (n_s <= (uint32_t)(stage_off[r + 1] - stage_off[r])) {
@@ -353,6 +357,249 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   if (dbg == 3 || dbg == 4) { if (!WRITE && threadIdx.x == 0) surv_n[r] = 0; return; }   // timing aid: without the fetch of the survivors
   for (uint32_t j = threadIdx.x; j < n_s; j += 256) dst[j] = I.occ[dst[j]] & ~(uint64_t)(PW_DP | PW_DN);
   if (!WRITE && threadIdx.x == 0) surv_n[r] = cursor;
+  if (!WRITE && raw_hits) {                                      // (the bin counters still hold every hit of the read)
+    __syncthreads();
+    uint32_t acc = 0;
+    for (int i = threadIdx.x; i < HF_SLOTS; i += 256) acc += cnt[i];
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&raw_hits[r], acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3 + K3c fused for reads whose sketch and seed hits fit LDS (the 10 kb class): probe, count, filter in ONE launch.
+// hit_filter_kernel above reads every occurrence list twice (count pass, then the pass that tests each entry against the
+// surviving bins) and takes its list heads from arrays probe_kernel wrote to global memory.  Random requests, not bytes, are
+// what these kernels pay for (tools/ubench/randread), so here every list is requested ONCE: one workgroup of 1024 threads per
+// read keeps in LDS
+//     the list heads (first occurrence, count) of the sketch          phase 0: table lookups, 4 lanes per hash
+//     the 13-bit bin codes of every seed hit, 8 per 16-byte chunk      phase 1: one 16-byte load per lane, all lists of a lane
+//                                                                      group in flight together; bins counted as they arrive
+// and the second pass (phase 2) is bit tests over LDS; only survivors (a few per cent) touch occ[].  Results, staging and
+// overflow protocol are those of hit_filter_kernel<false>: survivors staged per read, surv_n[r] their number.  A read that does
+// not fit (sketch > SF_SMAX, more than SF_CHUNKS code chunks, a bin count that would not fit 16 bits, or a full stage) is
+// flagged in need_old[] and redone by probe_kernel + hit_filter_kernel, which skip every other read.
+// ---------------------------------------------------------------------------------------------------
+constexpr int SF_THREADS = 1024, SF_GROUPS = SF_THREADS / 4;
+constexpr int SF_LPG = 11;                                      // lists per lane group
+constexpr int SF_SMAX = SF_GROUPS * SF_LPG;                     // 2816 sketch hashes (reads up to ~12.5 kb at w = 8)
+constexpr int SF_CHUNKS = 6144;                                 // parked code chunks (8 codes, 16 bytes each): 49 152 seed hits incl. padding
+constexpr int SF_EXTRA = 1024;                                  // pieces of 32 entries beyond the first of a list (lists longer than 32 entries)
+struct SeedFilterLds {
+  uint32_t cnt16[HF_SLOTS / 2];                                 // two 16-bit bin counters per word
+  uint32_t good[HF_SLOTS / 32], alive[HF_SLOTS / 32];
+  uint64_t lstart[SF_SMAX];
+  uint16_t lcnt[SF_SMAX];
+  uint16_t coff8[SF_SMAX + 8];                                  // first code chunk of every list (+ total)
+  uint32_t extra[SF_EXTRA];                                     // 32-entry pieces beyond a list's first: list << 11 | piece
+  uint32_t wsum[SF_THREADS / 64], wsum2[SF_THREADS / 64];
+  uint32_t cursor, fallback, total8, hraw, n_extra, pad_[3];
+  ulonglong2 codes[SF_CHUNKS];
+};
+__global__ void __launch_bounds__(SF_THREADS) seed_filter_kernel(IndexView I, const uint32_t* __restrict__ sk_hash, const uint64_t* __restrict__ off,
+                                                                 const int32_t* __restrict__ sk_n, const int32_t* __restrict__ read_len,
+                                                                 const int32_t* __restrict__ min_hits, uint32_t* __restrict__ surv_n,
+                                                                 uint64_t* __restrict__ stage, const uint64_t* __restrict__ stage_off,
+                                                                 uint8_t* __restrict__ need_old, uint32_t* __restrict__ raw_hits, int dbg /* timing aid (MM_SF_DBG): leave after phase n */) {
+  extern __shared__ __align__(16) unsigned char sf_dyn[];
+  SeedFilterLds& L = *reinterpret_cast<SeedFilterLds*>(sf_dyn);
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int s = sk_n[r];
+  if (need_old[r]) return;                                       // not of this class (set by the host): the two-pass kernels take it
+  if (s <= 0) { if (tid == 0) { surv_n[r] = 0; raw_hits[r] = 0; } return; }
+  const uint64_t o = off[r];
+  const int grp = tid >> 2, sub = tid & 3, gshift = lane & ~3;
+  for (int i = tid; i < HF_SLOTS / 2; i += SF_THREADS) L.cnt16[i] = 0;
+  if (tid == 0) { L.cursor = 0; L.fallback = 0; }
+  __syncthreads();
+  // ---- phase 0: table lookups (probe_kernel's scheme: 4 lanes read the four 16-byte slots of the hash's home sector).  All hashes
+  // of a lane group are loaded first, then all home sectors requested, then resolved: two memory latencies for the whole sketch.
+  {
+    const ulonglong2* __restrict__ tab = reinterpret_cast<const ulonglong2*>(I.tab);
+    const uint64_t mask = ((uint64_t)1 << I.tab_bits) - 1;
+    uint32_t hq[SF_LPG]; ulonglong2 vq[SF_LPG];
+#pragma unroll
+    for (int u = 0; u < SF_LPG; ++u) { const int i = grp + SF_GROUPS * u; hq[u] = i < s ? sk_hash[o + i] : 0u; }
+#pragma unroll
+    for (int u = 0; u < SF_LPG; ++u) vq[u] = tab[tab_slot(hq[u], I.tab_bits) + sub];
+#pragma unroll
+    for (int u = 0; u < SF_LPG; ++u) {
+      const int i = grp + SF_GROUPS * u;
+      const uint32_t h = hq[u]; uint64_t slot = tab_slot(h, I.tab_bits); ulonglong2 v = vq[u];
+      bool pending = i < s;
+      while (__any(pending)) {
+        const bool match = pending && v.x != 0 && (uint32_t)v.x == h, empty = pending && v.x == 0;
+        const uint32_t gm = (uint32_t)(__ballot(match) >> gshift) & 0xfu, ge = (uint32_t)(__ballot(empty) >> gshift) & 0xfu;
+        if (pending && (gm | ge)) {
+          if (match) {
+            const uint32_t cnt = (uint32_t)(v.x >> 32);
+            const bool keep = (uint64_t)cnt < (uint64_t)(int64_t)I.freq_threshold;   // computeMap.hpp:317
+            if (keep && cnt > 0xffffu) L.fallback = 1;              // (a list this long overflows the code area anyway)
+            L.lcnt[i] = keep ? (uint16_t)cnt : (uint16_t)0; L.lstart[i] = keep ? v.y : 0ull;
+          } else if (!gm && sub == 0) { L.lcnt[i] = 0; L.lstart[i] = 0ull; }
+          pending = false;
+        }
+        if (pending) { slot = (slot + 4) & mask; v = tab[slot + sub]; }
+      }
+    }
+  }
+  __syncthreads();
+  if (dbg == 1) { if (tid == 0) { surv_n[r] = 0; raw_hits[r] = L.lcnt[0]; } return; }
+  // ---- code chunk offsets: exclusive scan of ceil(count / 8) over the lists (three lists per thread)
+  {
+    uint32_t c8[3], hr = 0, mine = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const int i = tid * 3 + j; const uint32_t c = i < s ? L.lcnt[i] : 0u; c8[j] = (c + 7) >> 3; mine += c8[j]; hr += c; }
+    const uint32_t inc = (uint32_t)wave_incl_scan((int)mine), inc2 = (uint32_t)wave_incl_scan((int)hr);
+    if (lane == 63) { L.wsum[wid] = inc; L.wsum2[wid] = inc2; }
+    __syncthreads();
+    uint32_t basew = 0, tot = 0, tot2 = 0;
+#pragma unroll
+    for (int q = 0; q < SF_THREADS / 64; ++q) { const uint32_t x = L.wsum[q]; if (q < wid) basew += x; tot += x; tot2 += L.wsum2[q]; }
+    uint32_t ex = basew + inc - mine;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const int i = tid * 3 + j; if (i <= s) L.coff8[i] = (uint16_t)min(ex, 0xffffu); ex += c8[j]; }
+    if (tid == 0) { L.total8 = tot; L.hraw = tot2; L.n_extra = 0; if (tot > (uint32_t)SF_CHUNKS || tot2 > 65535u) L.fallback = 1; }
+  }
+  __syncthreads();
+  // 32-entry pieces beyond the first of a list get their own table, so that they are requested together, too
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int i = tid * 3 + j;
+    const uint32_t c = i < s ? (uint32_t)L.lcnt[i] : 0u;
+    if (c > 32) {
+      const uint32_t np = (c - 1) >> 5;                           // pieces 1 .. np
+      const uint32_t at = atomicAdd(&L.n_extra, np);
+      for (uint32_t p = 0; p < np; ++p) if (at + p < (uint32_t)SF_EXTRA) L.extra[at + p] = ((uint32_t)i << 11) | (p + 1);
+    }
+  }
+  __syncthreads();
+  if (L.n_extra > (uint32_t)SF_EXTRA) L.fallback = 1;             // (every thread writes the same value)
+  __syncthreads();
+  if (L.fallback) { if (tid == 0) { need_old[r] = 1; surv_n[r] = 0; raw_hits[r] = 0; } return; }
+  if (dbg == 2) { if (tid == 0) { surv_n[r] = 0; raw_hits[r] = L.hraw; } return; }
+  const uint32_t len = (uint32_t)max(read_len[r], 1);
+  const int nb = min((int)((len - 1) >> HF_BIN_SHIFT) + 2, HF_SLOTS);
+  int m = min_hits[r]; if (m < 1) m = 1;
+  // ---- phase 1: every list once.  A lane group owns lists grp, grp + 256, ...; the first 32 entries of all of them are requested
+  // before any is used (up to 11 x 16 bytes per lane in flight); the further pieces of long lists follow the same way.
+  {
+    auto code_of = [](const ulonglong2& v, int t) { return (uint32_t)((t < 4 ? v.x : v.y) >> (16 * (t & 3))) & 0xffffu; };
+    // a parked chunk: eight 16-bit slots, bin code in the low 13 bits; the 3 spare bits of the slots together hold the list the chunk
+    // belongs to (12 bits) and its number of valid entries - 1 (3 bits), so that the second pass needs no search
+    auto take = [&](uint32_t cc, uint32_t li, uint32_t chunk0, uint32_t j0, const ulonglong2& x) {   // lane `sub` holds entries j0 + 8 sub .. + 7 of list li (cc entries)
+      const uint32_t e0 = j0 + 8u * sub;
+      if (e0 >= cc) return;
+      const uint32_t nv = min(8u, cc - e0), meta = li | ((nv - 1u) << 12);
+      uint64_t w0 = 0, w1 = 0;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const uint32_t code = code_of(x, t) & (uint32_t)(HF_SLOTS - 1);
+        if ((uint32_t)t < nv) atomicAdd(&L.cnt16[code >> 1], 1u << (16 * (code & 1)));
+        const uint64_t slot = code | (((meta >> (3 * t)) & 7u) << 13);
+        if (t < 4) w0 |= slot << (16 * t); else w1 |= slot << (16 * (t - 4));
+      }
+      L.codes[chunk0 + (e0 >> 3)] = make_ulonglong2(w0, w1);
+    };
+    {
+      uint32_t c[SF_LPG]; ulonglong2 v[SF_LPG];
+#pragma unroll
+      for (int u = 0; u < SF_LPG; ++u) {
+        const int i = grp + SF_GROUPS * u;
+        c[u] = i < s ? (uint32_t)L.lcnt[i] : 0u;
+        v[u] = make_ulonglong2(0, 0);
+        if (c[u]) v[u] = *reinterpret_cast<const ulonglong2*>(I.occ16 + L.lstart[i] + min(8u * sub, (c[u] - 1) & ~7u));
+      }
+#pragma unroll
+      for (int u = 0; u < SF_LPG; ++u) { const int i = grp + SF_GROUPS * u; if (c[u]) take(c[u], (uint32_t)i, (uint32_t)L.coff8[i], 0u, v[u]); }
+    }
+    {
+      constexpr int EPG = SF_EXTRA / SF_GROUPS;                   // extra pieces per lane group
+      const uint32_t ne = L.n_extra;
+      uint32_t c[EPG], ch0[EPG], j0[EPG], li[EPG]; ulonglong2 v[EPG];
+#pragma unroll
+      for (int u = 0; u < EPG; ++u) {
+        const uint32_t k = (uint32_t)(grp + SF_GROUPS * u);
+        c[u] = 0; v[u] = make_ulonglong2(0, 0); ch0[u] = 0; j0[u] = 0; li[u] = 0;
+        if (k < ne) {
+          const uint32_t e = L.extra[k], i = e >> 11;
+          li[u] = i; c[u] = (uint32_t)L.lcnt[i]; ch0[u] = (uint32_t)L.coff8[i]; j0[u] = (e & 0x7ffu) << 5;
+          v[u] = *reinterpret_cast<const ulonglong2*>(I.occ16 + L.lstart[i] + min(j0[u] + 8u * sub, (c[u] - 1) & ~7u));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < EPG; ++u) if (c[u]) take(c[u], li[u], ch0[u], j0[u], v[u]);
+    }
+  }
+  __syncthreads();
+  if (dbg == 3) { if (tid == 0) { surv_n[r] = 0; raw_hits[r] = L.cnt16[0]; } return; }
+  {
+    // good[b]: the window of nb bins starting at b holds >= m hits (eight window starts per thread, one byte of the bit set);
+    // alive[b]: some good window contains b, i.e. good dilated by nb positions (hit_filter_kernel)
+    const uint16_t* cnt = reinterpret_cast<const uint16_t*>(L.cnt16);
+    const int b0 = tid * 8;
+    uint32_t sum = 0, bits = 0;
+    for (int i = 0; i < nb; ++i) sum += cnt[(b0 + i) & (HF_SLOTS - 1)];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      bits |= (sum >= (uint32_t)m ? 1u : 0u) << t;
+      sum += (uint32_t)cnt[(b0 + t + nb) & (HF_SLOTS - 1)] - (uint32_t)cnt[(b0 + t) & (HF_SLOTS - 1)];
+    }
+    reinterpret_cast<uint8_t*>(L.good)[tid] = (uint8_t)bits;
+  }
+  __syncthreads();
+  if (tid < HF_SLOTS / 32) {
+    uint32_t al = 0;
+    for (int j = 0; j < nb; ++j) {
+      const int wsh = j >> 5, bsh = j & 31;
+      const uint32_t g0 = L.good[(tid - wsh) & 255], g1 = L.good[(tid - wsh - 1) & 255];
+      al |= bsh ? (g0 << bsh) | (g1 >> (32 - bsh)) : g0;
+    }
+    L.alive[tid] = al;
+  }
+  __syncthreads();
+  // ---- phase 2: bit tests over the parked codes; a survivor is the occurrence (list start + position in the list)
+  const uint64_t stage_base = stage_off[r];
+  const uint32_t stage_cap = (uint32_t)(stage_off[r + 1] - stage_base);
+  uint64_t* const dst = stage + stage_base;
+  const uint32_t T8 = L.total8;
+  for (uint32_t q0 = 0; q0 < T8; q0 += SF_THREADS) {             // (wave-uniform trip count)
+    const uint32_t q = q0 + tid;
+    uint32_t mask = 0, meta = 0;
+    if (q < T8) {
+      const ulonglong2 x = L.codes[q];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const uint32_t slot = (uint32_t)((t < 4 ? x.x : x.y) >> (16 * (t & 3))) & 0xffffu, code = slot & (uint32_t)(HF_SLOTS - 1);
+        meta |= (slot >> 13) << (3 * t);
+        mask |= ((L.alive[code >> 5] >> (code & 31)) & 1u) << t;
+      }
+      mask &= (2u << (meta >> 12 & 7u)) - 1u;                     // valid entries only
+    }
+    const int mine = __popc(mask);
+    const int incl = wave_incl_scan(mine);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total == 0) continue;
+    uint32_t base = 0;
+    if (lane == 63) base = atomicAdd(&L.cursor, (uint32_t)total);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+    uint32_t pos = base + (uint32_t)(incl - mine);
+    if (mask) {
+      const uint32_t li = meta & 0xfffu;
+      const uint64_t first = L.lstart[li] + (uint64_t)(q - (uint32_t)L.coff8[li]) * 8u;
+      while (mask) {
+        const int t = __ffs(mask) - 1; mask &= mask - 1;
+        if (pos < stage_cap) dst[pos] = first + (uint32_t)t;
+        ++pos;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t n_s = L.cursor;
+  if (dbg == 4) { if (tid == 0) { surv_n[r] = 0; raw_hits[r] = n_s; } return; }
+  if (n_s > stage_cap) { if (tid == 0) { need_old[r] = 1; surv_n[r] = 0; raw_hits[r] = 0; } return; }   // stage too small: the two-pass kernels redo the read
+  for (uint32_t j = tid; j < n_s; j += SF_THREADS) dst[j] = I.occ[dst[j]] & ~(uint64_t)(PW_DP | PW_DN);
+  if (tid == 0) { surv_n[r] = n_s; raw_hits[r] = L.hraw; }
 }
 
 // range blockIdx.x of src, [sb, se), goes to dst starting at db
@@ -768,28 +1015,27 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   M->d_read_len.upload(reads->len.data(), (size_t)n, st);
   IndexView IV = make_view(I);
   // ---- K3
-  DBuf<uint32_t> probe_cnt((size_t)total_mz + 1); probe_cnt.zero(st);
+  DBuf<uint32_t> probe_cnt((size_t)total_mz + 1);
   DBuf<uint64_t> probe_start((size_t)total_mz + 1);
   DBuf<uint64_t> hit_off, scan_tmp;
-  const size_t t_pg = T.begin(&M->stats.ms_probe_gather);
-  if (n > 0 && total_mz > 0) {
-    probe_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p);
-    MM_KERNEL_CHECK();
-  }
   const char* nf_env = getenv("MM_NO_HIT_FILTER");               // parity tests of the raw hit list
   const bool use_filter = !(nf_env && nf_env[0] == '1');
+  // the fused probe + filter kernel takes the reads whose sketch fits its LDS layout (MM_NO_FUSED_FILTER=1: cross-check switch)
+  const bool use_fused = use_filter && !getenv("MM_NO_FUSED_FILTER");
+  DBuf<uint8_t> need_old; DBuf<uint32_t> raw_per_read;
+  int64_t n_fused = 0;
+  if (use_filter && n > 0) { raw_per_read.alloc((size_t)n); raw_per_read.zero(st); }
+  else if (total_mz > 0) probe_cnt.zero(st);                     // (unfiltered path: the offsets come from a scan over every slot)
+  if (use_fused && n > 0) {
+    std::vector<uint8_t> h_need((size_t)n, 0);
+    for (int64_t r = 0; r < n; ++r) { h_need[(size_t)r] = M->h_sk_n[(size_t)r] > SF_SMAX ? 1 : 0; n_fused += !h_need[(size_t)r]; }
+    need_old.alloc((size_t)n); need_old.upload(h_need.data(), (size_t)n, st);
+    MM_HIP(hipStreamSynchronize(st));                            // h_need is the source of the async upload
+  }
+  const size_t t_pg = T.begin(&M->stats.ms_probe_gather);
   M->read_hit_off.alloc((size_t)n + 1);
   uint64_t raw_hits = 0;
   DBuf<unsigned long long> raw_sum(1);
-  if (use_filter && n > 0) {                                      // only the total is needed
-    raw_sum.zero(st);
-    if (total_mz > 0) { sum_u32_kernel<<<dim3(2048), dim3(256), 0, st>>>(probe_cnt.p, total_mz, raw_sum.p); MM_KERNEL_CHECK(); }
-    MM_HIP(hipMemcpyAsync(&raw_hits, raw_sum.p, sizeof raw_hits, hipMemcpyDeviceToHost, st));
-  } else {
-    hit_off.alloc((size_t)total_mz + 2);
-    exclusive_scan_u32_u64(probe_cnt.p, total_mz, hit_off.p, scan_tmp, st);
-    MM_HIP(hipMemcpyAsync(&raw_hits, hit_off.p + total_mz, sizeof raw_hits, hipMemcpyDeviceToHost, st));
-  }
   DBuf<uint32_t> surv;
   DBuf<uint64_t> stage, stage_off;
   if (use_filter && n > 0) {
@@ -800,11 +1046,38 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       h_stage_off[(size_t)r + 1] = h_stage_off[(size_t)r] + (M->h_sk_n[(size_t)r] > 0 ? (cap_env ? (uint64_t)atoi(cap_env) : 1024 + 2 * (uint64_t)M->h_sk_n[(size_t)r]) : 0);
     stage_off.alloc((size_t)n + 1); stage_off.upload(h_stage_off.data(), h_stage_off.size(), st);
     stage.alloc((size_t)std::max<uint64_t>(h_stage_off[(size_t)n], 1));
-    const size_t t_hf = T.begin(&M->stats.ms_hit_filter);
-    hit_filter_kernel<false><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
-                                                                   M->min_hits.p, surv.p, nullptr, nullptr, stage.p, stage_off.p, getenv("MM_HF_DBG") ? atoi(getenv("MM_HF_DBG")) : 0);
+    MM_HIP(hipStreamSynchronize(st));                            // h_stage_off is the source of the async upload
+    if (use_fused && n_fused > 0) {
+      const size_t lds = sizeof(SeedFilterLds);
+      MM_HIP(hipFuncSetAttribute((const void*)seed_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const size_t t_sf = T.begin(&M->stats.ms_hit_filter);
+      seed_filter_kernel<<<dim3((unsigned)n), dim3(SF_THREADS), lds, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->min_hits.p, surv.p,
+                                                                         stage.p, stage_off.p, need_old.p, raw_per_read.p, getenv("MM_SF_DBG") ? atoi(getenv("MM_SF_DBG")) : 0);
+      MM_KERNEL_CHECK();
+      T.end(t_sf);
+    }
+  }
+  const uint8_t* const only = use_fused ? need_old.p : nullptr;
+  if (n > 0 && total_mz > 0) {                                     // (reads the fused kernel flagged are only known on the device: the two-pass kernels always run and skip the rest)
+    probe_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, only);
     MM_KERNEL_CHECK();
-    T.end(t_hf);
+  }
+  if (!use_filter || n == 0) {
+    hit_off.alloc((size_t)total_mz + 2);
+    exclusive_scan_u32_u64(probe_cnt.p, total_mz, hit_off.p, scan_tmp, st);
+    MM_HIP(hipMemcpyAsync(&raw_hits, hit_off.p + total_mz, sizeof raw_hits, hipMemcpyDeviceToHost, st));
+  }
+  if (use_filter && n > 0) {
+    const bool time_old = !(use_fused && n_fused > 0);            // ms_hit_filter: the kernel that handles the bulk of the reads
+    const size_t t_hf = time_old ? T.begin(&M->stats.ms_hit_filter) : 0;
+    hit_filter_kernel<false><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
+                                                                   M->min_hits.p, surv.p, nullptr, nullptr, stage.p, stage_off.p, getenv("MM_HF_DBG") ? atoi(getenv("MM_HF_DBG")) : 0, only, raw_per_read.p);
+    MM_KERNEL_CHECK();
+    if (time_old) T.end(t_hf);
+    raw_sum.zero(st);                                            // only the total of the raw seed hits is needed
+    sum_u32_kernel<<<dim3(256), dim3(256), 0, st>>>(raw_per_read.p, n, raw_sum.p);
+    MM_KERNEL_CHECK();
+    MM_HIP(hipMemcpyAsync(&raw_hits, raw_sum.p, sizeof raw_hits, hipMemcpyDeviceToHost, st));
     exclusive_scan_u32_u64(surv.p, n, M->read_hit_off.p, scan_tmp, st);
   } else {
     read_hit_bounds_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(M->mz.off.p, hit_off.p, n, M->read_hit_off.p);
@@ -818,7 +1091,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   if (total_hits > 0) {
     if (use_filter)
       hit_filter_kernel<true><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
-                                                                    M->min_hits.p, surv.p, M->read_hit_off.p, M->hits.p, stage.p, stage_off.p, 0);
+                                                                    M->min_hits.p, surv.p, M->read_hit_off.p, M->hits.p, stage.p, stage_off.p, 0, nullptr, nullptr);
     else
       gather_hits_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, hit_off.p, M->hits.p);
     MM_KERNEL_CHECK();

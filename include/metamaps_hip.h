@@ -100,7 +100,29 @@ typedef struct {
   int32_t read_len_min;       /* 0: every read has read_len bases; else lengths log-uniform in [read_len_min, read_len] */
 } mm_synth_read_params;
 int mm_synth_reference(mm_ctx* ctx, const mm_synth_ref_params* p, mm_seqset** out);
-/* truth_genome (optional, [n_reads]) receives the source genome index or -1 */
+/* The miniSeq+H-shaped community of SURVEY.md §8 D1: microbial genomes of lognormal length grouped in species of 1..12 strains
+ * (substitutions at a per-strain rate + a few block insertions / deletions against the species root), species roots grouped in
+ * genera; plus "human-like" contigs: `repeat_fraction` of their 256-base granules are copies (2-20 % diverged, either strand) of
+ * granules of a Zipf-weighted repeat family library, and `n_fraction` of their bases are runs of N.  Contig order is shuffled.
+ * contig_genome[n_contigs] (optional) receives the genome of every contig: 0 .. n_genomes-1 microbial (one contig each), n_genomes
+ * for every human-like contig.  n_contigs = n_genomes + human_contigs. */
+typedef struct {
+  uint64_t seed;
+  int32_t n_genomes, n_species, n_genera;      /* microbial genomes (= contigs), species (1..12 strains each), genera        */
+  double median_len, sigma_len;                /* lognormal genome length, clipped to [min_len, max_len]                    */
+  int32_t min_len, max_len;
+  float strain_div_min, strain_div_max;        /* substitution rate of a strain against its species root                    */
+  float genus_div_min, genus_div_max;          /* substitution rate of a species root against its genus root                */
+  int32_t strain_indel_events;                 /* up to this many block insertions / deletions (50 - 5000 bases) per strain  */
+  int32_t human_contigs;                       /* 0: none                                                                    */
+  int64_t human_bases;                         /* total length of the human-like contigs                                     */
+  float repeat_fraction, n_fraction;
+  int32_t n_repeat_families;
+  int64_t total_bases_target;                  /* > 0: microbial lengths are scaled so that everything sums to this          */
+} mm_synth_community_params;
+int mm_synth_community(mm_ctx* ctx, const mm_synth_community_params* p, mm_seqset** out, int32_t* contig_genome);
+/* truth_genome (optional, [n_reads]) receives the source contig index or -1.  Reads are drawn from `n_abundant` contigs among
+ * those long enough for the longest read (exception runs — N — of the reference read as A). */
 int mm_synth_reads(mm_ctx* ctx, const mm_seqset* reference, const mm_synth_read_params* p, mm_seqset** out,
                    int32_t* truth_genome);
 

@@ -65,6 +65,14 @@ class SynthReadParams(C.Structure):
                 ("ins_rate", C.c_float), ("del_rate", C.c_float), ("frac_random", C.c_float), ("n_abundant", C.c_int32), ("read_len_min", C.c_int32)]
 
 
+class SynthCommunityParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_genomes", C.c_int32), ("n_species", C.c_int32), ("n_genera", C.c_int32),
+                ("median_len", C.c_double), ("sigma_len", C.c_double), ("min_len", C.c_int32), ("max_len", C.c_int32),
+                ("strain_div_min", C.c_float), ("strain_div_max", C.c_float), ("genus_div_min", C.c_float), ("genus_div_max", C.c_float),
+                ("strain_indel_events", C.c_int32), ("human_contigs", C.c_int32), ("human_bases", C.c_int64),
+                ("repeat_fraction", C.c_float), ("n_fraction", C.c_float), ("n_repeat_families", C.c_int32), ("total_bases_target", C.c_int64)]
+
+
 def declared_symbols(header: str = HEADER_PATH) -> list[str]:
     """Every function the public header declares (used by the CPU test that checks the exports)."""
     txt = open(header).read()
@@ -105,6 +113,7 @@ def lib() -> C.CDLL:
             "mm_seqset_fetch": (C.c_int, [vp, i64, C.c_char_p, i64]),
             "mm_synth_reference": (C.c_int, [vp, P(SynthRefParams), P(vp)]),
             "mm_synth_reads": (C.c_int, [vp, vp, P(SynthReadParams), P(vp), vp]),
+            "mm_synth_community": (C.c_int, [vp, P(SynthCommunityParams), P(vp), vp]),
             "mm_minimizers": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, i64]),
             "mm_index_build": (C.c_int, [vp, vp, C.c_int, C.c_int, P(vp)]),
             "mm_index_destroy": (None, [vp]),
@@ -210,6 +219,14 @@ class Context:
         h = C.c_void_p()
         self.check(lib().mm_synth_reference(self.h, C.byref(p), C.byref(h)))
         return SeqSet(self, h)
+
+    def synth_community(self, **kw):
+        """(reference, contig -> genome) of the SURVEY D1 community; genome n_genomes is the human-like one"""
+        p = SynthCommunityParams(**kw)
+        h = C.c_void_p()
+        genome = np.zeros(p.n_genomes + p.human_contigs, dtype=np.int32)
+        self.check(lib().mm_synth_community(self.h, C.byref(p), C.byref(h), _ptr(genome)))
+        return SeqSet(self, h), genome
 
     def synth_reads(self, ref: "SeqSet", **kw):
         p = SynthReadParams(**kw)

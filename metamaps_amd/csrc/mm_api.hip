@@ -146,6 +146,10 @@ int mm_synth_reference(mm_ctx* ctx, const mm_synth_ref_params* p, mm_seqset** ou
   if (!ctx || !p || !out) return MM_ERR_ARG;
   return guarded(ctx, [&] { MM_HIP(hipSetDevice(ctx->device)); auto* s = new mm_seqset; s->ctx = ctx; try { mm::synth_reference(ctx, *p, s); } catch (...) { delete s; throw; } *out = s; });
 }
+int mm_synth_community(mm_ctx* ctx, const mm_synth_community_params* p, mm_seqset** out, int32_t* contig_genome) {
+  if (!ctx || !p || !out) return MM_ERR_ARG;
+  return guarded(ctx, [&] { auto* s = new mm_seqset; s->ctx = ctx; try { mm::synth_community(ctx, *p, s, contig_genome); } catch (...) { delete s; throw; } *out = s; });
+}
 int mm_synth_reads(mm_ctx* ctx, const mm_seqset* reference, const mm_synth_read_params* p, mm_seqset** out, int32_t* truth_genome) {
   if (!ctx || !reference || !p || !out) return MM_ERR_ARG;
   return guarded(ctx, [&] { MM_HIP(hipSetDevice(ctx->device)); auto* s = new mm_seqset; s->ctx = ctx; try { mm::synth_reads(ctx, reference, *p, s, truth_genome); } catch (...) { delete s; throw; } *out = s; });

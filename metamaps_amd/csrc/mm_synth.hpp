@@ -4,5 +4,6 @@
 #include "mm_common.hpp"
 namespace mm {
 void synth_reference(mm_ctx* ctx, const mm_synth_ref_params& p, mm_seqset* out);
+void synth_community(mm_ctx* ctx, const mm_synth_community_params& p, mm_seqset* out, int32_t* contig_genome);
 void synth_reads(mm_ctx* ctx, const mm_seqset* ref, const mm_synth_read_params& p, mm_seqset* out, int32_t* truth_genome);
 }

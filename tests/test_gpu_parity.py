@@ -512,3 +512,47 @@ def test_mapping_at_bench_hit_density_matches_oracle(ctx, oracle_lib, dense, k, 
             n_mapped += len(m) > 0
         assert n_mapped > 150, n_mapped
     oi.close(); idx.close(); R.close(); S.close()
+
+
+def test_community_generator_and_parity_on_it(ctx, oracle_lib, tmp_path):
+    """The SURVEY D1 community at toy size (lognormal genome lengths, 1-12 strains per species with block indels, human-like
+    contigs with 45 % library repeats and N runs, shuffled contig order): structure checks, then the mapper against the oracle on
+    the very sequences the device generated — repeats (long occurrence lists, duplicate hashes inside windows) and N runs included."""
+    ref, genome = ctx.synth_community(seed=5, n_genomes=40, n_species=12, n_genera=4, median_len=120_000.0, sigma_len=0.6, min_len=5_000, max_len=600_000,
+                                      strain_div_min=0.001, strain_div_max=0.05, genus_div_min=0.15, genus_div_max=0.25, strain_indel_events=6,
+                                      human_contigs=3, human_bases=1_500_000, repeat_fraction=0.45, n_fraction=0.01, n_repeat_families=40, total_bases_target=0)
+    lens = ref.lengths()
+    assert len(lens) == 43 and len(genome) == 43 and int((genome == 40).sum()) == 3 and set(genome[genome < 40]) == set(range(40))
+    assert lens.min() >= 4_000 and len(set(lens.tolist())) > 20                     # lognormal lengths (+- block indels), not a constant
+    seqs = [ref.fetch(i, int(lens[i])) for i in range(len(lens))]
+    human = [s for s, g in zip(seqs, genome) if g == 40]
+    n_frac = sum(s.count(b"N") for s in human) / sum(len(s) for s in human)
+    assert 0.008 < n_frac < 0.012 and all(s.startswith(b"N") and s.endswith(b"N") for s in human)
+    assert all(set(s) <= set(b"ACGT") for s, g in zip(seqs, genome) if g < 40)
+    fa = str(tmp_path / "DB.fa")
+    with open(fa, "wb") as f:
+        for i, s in enumerate(seqs):
+            f.write(f">C{i}|kraken:taxid|{int(genome[i]) + 1}|x\n".encode() + s + b"\n")
+    k, w = 16, 8
+    idx = ctx.index(ref, k, w)
+    oi = oracle_lib.index(fa, k, w)
+    h, c, wp, st = idx.entries(); oh, oc, ow, os_ = oi.dump()
+    assert np.array_equal(h, oh) and np.array_equal(c, oc) and np.array_equal(wp, ow) and np.array_equal(st, os_)
+    cnt, nh = idx.freq_hist()
+    assert cnt.max() > 30                                                             # repeat granules: hashes with dozens of occurrences
+    reads, truth = ctx.synth_reads(ref, seed=3, n_reads=300, read_len=4000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=43)
+    assert int((genome[truth[truth >= 0]] == 40).sum()) > 5                            # some reads come from the human-like contigs
+    M = ctx.map_batch(idx, reads, k, w); M.add_qualities(k)
+    off, rec = M.fetch()
+    rl = reads.lengths()
+    n_map = 0
+    for r in range(300):
+        q = reads.fetch(r, int(rl[r]))
+        m = oi.map_read(q)["map"] if len(q) >= 1000 else np.zeros((0, 6), dtype=np.int32)
+        got = rec[off[r]:off[r + 1]]
+        assert len(got) == len(m), (r, len(got), len(m))
+        assert np.array_equal(got["ref_contig"], m[:, 0]) and np.array_equal(got["ref_start"], m[:, 1]) and np.array_equal(got["shared"], m[:, 3]), r
+        assert np.array_equal(got["strand"], m[:, 5]), r
+        n_map += len(m) > 0
+    assert n_map > 250
+    oi.close(); M.close(); idx.close(); reads.close(); ref.close()

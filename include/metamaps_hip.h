@@ -248,6 +248,12 @@ int mm_em_iterate(mm_em* em, const double* f, double* f_partial, double* ll_part
 /* same, but leaves the partial sums on the device, all-reduces them over the communicator (RCCL) and
  * returns the normalised next f and the global log-likelihood (identical on every rank) */
 int mm_em_iterate_allreduce(mm_em* em, const double* f, double* f_next, double* ll);
+/* The whole loop of meta::doEM (fEM.h:501-661) without a host round trip per iteration: starting from f0, iterate (E step, per-taxon
+ * sums, all-reduce over the communicator if there is one, normalise) until the reference's stop rule fires (log-likelihood gain <= 1
+ * and relative gain < 1e-4, from the second iteration on) or max_iter iterations.  f_out[n_taxa] = final frequencies, ll_trace
+ * (optional, up to ll_cap <= 1024 values) = log-likelihood of every iteration, *n_iter = iterations done.  Every rank of the
+ * communicator calls it together and gets the same result. */
+int mm_em_run(mm_em* em, const double* f0, int max_iter, double* f_out, double* ll_trace, int ll_cap, int* n_iter);
 /* final posteriors p_i for the current f (fEM.h:684-707) and the index of the best mapping per read (fEM.h:217) */
 int mm_em_posteriors(mm_em* em, const double* f, double* post /* [n_entries] */, int64_t* best /* [n_reads] */);
 

@@ -149,6 +149,7 @@ def lib() -> C.CDLL:
             "mm_em_iterate": (C.c_int, [vp, vp, vp, P(f64)]),
             "mm_em_iterate_allreduce": (C.c_int, [vp, vp, vp, P(f64)]),
             "mm_em_posteriors": (C.c_int, [vp, vp, vp, vp]),
+            "mm_em_run": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, P(C.c_int)]),
             "mm_comm_unique_id": (C.c_int, [C.c_char_p]),
             "mm_comm_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
             "mm_comm_allreduce_f64": (C.c_int, [vp, vp, i64]),
@@ -479,6 +480,15 @@ class EM:
         ll = C.c_double()
         self.ctx.check(lib().mm_em_iterate_allreduce(self.h, _ptr(f), _ptr(nxt), C.byref(ll)))
         return nxt, ll.value
+
+    def run(self, f0: np.ndarray, max_iter: int = 1000):
+        """the whole EM loop on the device: (final f, log-likelihood of every iteration)"""
+        f0 = np.ascontiguousarray(f0, dtype=np.float64)
+        f = np.zeros(self.n_taxa, dtype=np.float64)
+        ll = np.zeros(1024, dtype=np.float64)
+        n = C.c_int()
+        self.ctx.check(lib().mm_em_run(self.h, _ptr(f0), max_iter, _ptr(f), _ptr(ll), len(ll), C.byref(n)))
+        return f, ll[:min(n.value, len(ll))]
 
     def taxon_counts(self) -> np.ndarray:
         c = np.zeros(self.n_taxa, dtype=np.int64)

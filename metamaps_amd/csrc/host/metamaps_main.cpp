@@ -990,18 +990,14 @@ int classify_one(const std::vector<Dev>& devs, bool use_comm, const std::string&
     for (size_t i = 0; i <= hi - lo; ++i) soff[i] = off[lo + i] - off[lo];
     const size_t e0 = (size_t)off[lo];
     mm_em* em; ck(ctx, mm_em_create(ctx, (int64_t)(hi - lo), soff.data(), taxon.data() + e0, mapq.data() + e0, inv.data() + e0, (int32_t)NT, &em), "em");
-    std::vector<double> fl(f), fn(NT);
-    double llPrev = 0; size_t iter = 0; bool go = true;
-    while (go) {
-      if (d == 0) std::cout << "EM round " << iter << std::endl;
-      double ll; ck(ctx, mm_em_iterate_allreduce(em, fl.data(), fn.data(), &ll), "em iterate");
-      if (d == 0) std::cout << "\n\tLog likelihood: " << ll << std::endl;
-      if (iter > 0) {
-        const double diff = ll - llPrev, rel = ll / llPrev;
-        if (d == 0) std::cout << "\tImprovement: " << diff << "\n\tRelative   : " << rel << std::endl;
-        if (diff <= 1 && (1 - rel) < 0.0001) go = false;
-      }
-      fl = fn; ++iter; llPrev = ll;
+    // the loop itself runs on the device (mm_em_run: E step, sums, all-reduce, normalisation and the stop rule of fEM.h:624-639 per
+    // iteration, no host round trip); the per-round lines of the reference's log follow from the log-likelihood trace
+    std::vector<double> fl(NT), lls(1024);
+    int n_iter = 0;
+    ck(ctx, mm_em_run(em, f.data(), 100000, fl.data(), lls.data(), (int)lls.size(), &n_iter), "em");
+    if (d == 0) for (int it = 0; it < n_iter && it < (int)lls.size(); ++it) {
+      std::cout << "EM round " << it << std::endl << "\n\tLog likelihood: " << lls[(size_t)it] << std::endl;
+      if (it > 0) std::cout << "\tImprovement: " << lls[(size_t)it] - lls[(size_t)it - 1] << "\n\tRelative   : " << lls[(size_t)it] / lls[(size_t)it - 1] << std::endl;
     }
     std::vector<int64_t> bl(hi - lo);
     ck(ctx, mm_em_posteriors(em, fl.data(), post.data() + e0, bl.data()), "posteriors");

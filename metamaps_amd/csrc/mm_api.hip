@@ -532,6 +532,10 @@ int mm_em_iterate_allreduce(mm_em* em, const double* f, double* f_next, double* 
   if (!em || !f || !f_next || !ll) return MM_ERR_ARG;
   return guarded(em->ctx, [&] { MM_HIP(hipSetDevice(em->ctx->device)); mm::em_iterate_allreduce(em, f, f_next, ll); });
 }
+int mm_em_run(mm_em* em, const double* f0, int max_iter, double* f_out, double* ll_trace, int ll_cap, int* n_iter) {
+  if (!em || !f0 || max_iter <= 0 || !n_iter) return MM_ERR_ARG;
+  return guarded(em->ctx, [&] { *n_iter = mm::em_run(em, f0, max_iter, f_out, ll_trace, ll_cap); });
+}
 int mm_em_posteriors(mm_em* em, const double* f, double* post, int64_t* best) {
   if (!em || !f) return MM_ERR_ARG;
   return guarded(em->ctx, [&] { MM_HIP(hipSetDevice(em->ctx->device)); mm::em_posteriors(em, f, post, best); });

@@ -12,6 +12,10 @@ struct mm_em {
   mm::DBuf<double> mapq, inv_nloc; // [n_entries]
   mm::DBuf<int64_t> tstart, perm;  // CSR by taxon: entries of taxon t are perm[tstart[t]..tstart[t+1]) in read order
   mm::DBuf<double> post, ll_read, f, partial, block_sum;
+  // device-resident loop (mm_em_run): taxa with mappings on this rank, their partial sums, loop control, log-likelihood trace
+  mm::DBuf<int32_t> present; int32_t n_present = -1;
+  mm::DBuf<double> local_partial, ll_trace;
+  mm::DBuf<long long> ctrl;
 };
 
 namespace mm {
@@ -21,6 +25,7 @@ void em_create_from_mapping(mm_ctx* ctx, const ::mm_mapping* M, const int32_t* c
                             int32_t n_taxa, mm_em* E);
 void em_iterate(mm_em* E, const double* f, double* f_partial, double* ll_partial);
 void em_iterate_allreduce(mm_em* E, const double* f, double* f_next, double* ll);
+int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_trace, int ll_cap);
 void em_posteriors(mm_em* E, const double* f, double* post, int64_t* best);
 void comm_unique_id(char* id);
 void comm_init(mm_ctx* ctx, const char* id, int rank, int nranks);

@@ -303,6 +303,135 @@ void em_iterate_allreduce(mm_em* E, const double* f, double* f_next, double* ll)
   *ll = h[(size_t)E->n_taxa];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The whole EM loop on the device (meta::doEM's while loop, fEM.h:501-661): an iteration is E step, per-taxon sums, log-likelihood,
+// the RCCL all-reduce, normalisation and the stop rule — all stream ordered, no host round trip.  The host enqueues iterations in
+// groups and only looks at the control word afterwards; iterations enqueued past the stop are no-ops (every rank sees the same
+// all-reduced values, so every rank stops at the same iteration and the collectives stay matched).
+// ctrl[0] = iterations done, ctrl[1] = stopped, ctrl[2] = bits of the previous log-likelihood.
+// ---------------------------------------------------------------------------------------------------
+__global__ void em_estep_loop_kernel(const int64_t* __restrict__ read_off, const int32_t* __restrict__ taxon, const double* __restrict__ mapq,
+                                     const double* __restrict__ inv_nloc, const double* __restrict__ f, int64_t n_reads,
+                                     double* __restrict__ post, double* __restrict__ ll_read, const long long* __restrict__ ctrl) {
+  if (ctrl[1]) return;
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  const int64_t lo = read_off[r], hi = read_off[r + 1];
+  double sum = 0;
+  for (int64_t i = lo; i < hi; ++i) { double l = f[taxon[i]] * inv_nloc[i] * mapq[i]; post[i] = l; sum += l; }   // fEM.h:353
+  for (int64_t i = lo; i < hi; ++i) post[i] = post[i] / sum;                                                      // :361
+  ll_read[r] = hi > lo ? log(sum) : 0.0;                                                                          // fEM.h:578
+}
+// per-taxon sums for the taxa that have mappings on this rank (same fixed-shape sum as em_taxon_sum_kernel); 4 taxa per block
+__global__ void __launch_bounds__(256) em_taxon_sum_present_kernel(const double* __restrict__ post, const int64_t* __restrict__ tstart, const int64_t* __restrict__ perm,
+                                                                   const int32_t* __restrict__ present, int n_present, double* __restrict__ local_partial,
+                                                                   const long long* __restrict__ ctrl) {
+  if (ctrl[1]) return;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= n_present) return;
+  const int t = present[k];
+  double acc = 0;
+  for (int64_t j = tstart[t] + lane; j < tstart[t + 1]; j += 64) acc += post[perm[j]];
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if (lane == 0) local_partial[t] = acc;
+}
+__global__ void __launch_bounds__(256) em_ll_sum_kernel(const double* __restrict__ ll_read, int64_t n, double* __restrict__ block_sum, const long long* __restrict__ ctrl) {
+  if (ctrl[1]) return;
+  __shared__ double sh[256];
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  sh[threadIdx.x] = i < n ? ll_read[i] : 0.0;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
+  if (threadIdx.x == 0) block_sum[blockIdx.x] = sh[0];
+}
+__global__ void __launch_bounds__(256) em_ll_final_kernel(const double* __restrict__ block_sum, int64_t nb, double* __restrict__ out, const long long* __restrict__ ctrl) {
+  if (ctrl[1]) return;
+  __shared__ double sh[256];
+  double acc = 0;
+  for (int64_t i = threadIdx.x; i < nb; i += 256) acc += block_sum[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
+  if (threadIdx.x == 0) *out = sh[0];
+}
+// normalise (fEM.h:606-615; fixed-shape sum over the taxa, the same on every rank), log-likelihood trace, stop rule (:624-639)
+__global__ void __launch_bounds__(256) em_finalize_kernel(const double* __restrict__ partial, int32_t n_taxa, double* __restrict__ f, long long* __restrict__ ctrl,
+                                                          double* __restrict__ ll_trace, int ll_cap) {
+  if (ctrl[1]) return;
+  __shared__ double sh[256];
+  double acc = 0;
+  for (int t = threadIdx.x; t < n_taxa; t += 256) acc += partial[t];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
+  const double sum = sh[0];
+  for (int t = threadIdx.x; t < n_taxa; t += 256) f[t] = partial[t] / sum;
+  if (threadIdx.x == 0) {
+    const long long it = ctrl[0];
+    const double ll = partial[n_taxa], ll_prev = __longlong_as_double(ctrl[2]);
+    if (it < ll_cap) ll_trace[it] = ll;
+    if (it > 0 && (ll - ll_prev) <= 1 && (1 - ll / ll_prev) < 0.0001) ctrl[1] = 1;
+    ctrl[2] = __double_as_longlong(ll);
+    ctrl[0] = it + 1;
+  }
+}
+
+int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_trace, int ll_cap) {
+  mm_ctx* ctx = E->ctx;
+  hipStream_t st = ctx->stream;
+  const int32_t T = E->n_taxa;
+  if (E->n_present < 0) {                                        // taxa with mappings on this rank
+    std::vector<int64_t> ts = E->tstart.to_host(st, (size_t)T + 1);
+    std::vector<int32_t> pr;
+    for (int32_t t = 0; t < T; ++t) if (ts[(size_t)t + 1] > ts[(size_t)t]) pr.push_back(t);
+    E->n_present = (int32_t)pr.size();
+    E->present.alloc(std::max<size_t>(pr.size(), 1)); E->present.upload(pr.data(), pr.size(), st);
+    E->local_partial.alloc((size_t)T + 1);
+    E->ll_trace.alloc(1024);
+    E->ctrl.alloc(4);
+    MM_HIP(hipStreamSynchronize(st));
+  }
+  const int cap = 1024;
+  E->f.upload(f0, (size_t)T, st);
+  E->local_partial.zero(st);
+  E->ctrl.zero(st);
+  const int64_t nb = ceil_div(std::max<int64_t>(E->n_reads, 1), 256);
+  long long h_ctrl[4] = {0, 0, 0, 0};
+  const int GROUP = 8;
+  while (true) {
+    for (int g = 0; g < GROUP; ++g) {
+      if (E->n_reads > 0) {
+        em_estep_loop_kernel<<<dim3((unsigned)ceil_div(E->n_reads, 128)), dim3(128), 0, st>>>(E->read_off.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->f.p,
+                                                                                         E->n_reads, E->post.p, E->ll_read.p, E->ctrl.p);
+        MM_KERNEL_CHECK();
+      }
+      if (E->n_present > 0) {
+        em_taxon_sum_present_kernel<<<dim3((unsigned)ceil_div(E->n_present, 4)), dim3(256), 0, st>>>(E->post.p, E->tstart.p, E->perm.p, E->present.p, E->n_present,
+                                                                                               E->local_partial.p, E->ctrl.p);
+        MM_KERNEL_CHECK();
+      }
+      em_ll_sum_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(E->ll_read.p, E->n_reads, E->block_sum.p, E->ctrl.p);
+      MM_KERNEL_CHECK();
+      em_ll_final_kernel<<<dim3(1), dim3(256), 0, st>>>(E->block_sum.p, nb, E->local_partial.p + T, E->ctrl.p);
+      MM_KERNEL_CHECK();
+      if (ctx->comm) {                                           // fEM.h:583-600, across GPUs instead of OpenMP threads
+        ncclResult_t rc = ncclAllReduce(E->local_partial.p, E->partial.p, (size_t)T + 1, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, st);
+        MM_REQUIRE(rc == ncclSuccess, MM_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
+      } else MM_HIP(hipMemcpyAsync(E->partial.p, E->local_partial.p, sizeof(double) * ((size_t)T + 1), hipMemcpyDeviceToDevice, st));
+      em_finalize_kernel<<<dim3(1), dim3(256), 0, st>>>(E->partial.p, T, E->f.p, E->ctrl.p, E->ll_trace.p, cap);
+      MM_KERNEL_CHECK();
+    }
+    MM_HIP(hipMemcpyAsync(h_ctrl, E->ctrl.p, sizeof h_ctrl, hipMemcpyDeviceToHost, st));
+    MM_HIP(hipStreamSynchronize(st));
+    if (h_ctrl[1] || h_ctrl[0] >= max_iter) break;
+  }
+  const int n_iter = (int)h_ctrl[0];
+  if (f_out) E->f.download(f_out, (size_t)T, st);
+  if (ll_trace && ll_cap > 0) E->ll_trace.download(ll_trace, (size_t)std::min(std::min(n_iter, ll_cap), cap), st);
+  MM_HIP(hipStreamSynchronize(st));
+  return n_iter;
+}
+
 void em_posteriors(mm_em* E, const double* f, double* post, int64_t* best) {
   hipStream_t st = E->ctx->stream;
   em_step_device(E, f);

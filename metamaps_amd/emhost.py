@@ -115,3 +115,23 @@ def run_em(step, n_taxa: int, max_iter: int = 10_000):
         if stop:
             break
     return f, lls
+
+
+def parse6(v: np.ndarray) -> np.ndarray:
+    """The double that std::stod returns for the 6-significant-digit text of v (mapWrap.h:318 → fEM.h:265)."""
+    out = np.zeros_like(v)
+    nz = v > 0
+    a = v[nz]
+    e = np.floor(np.log10(a)).astype(np.int64)
+    pe = np.power(10.0, e.astype(np.float64))
+    e = np.where(a < pe, e - 1, np.where(a >= pe * 10, e + 1, e))
+    t = 5 - e
+    x = a * np.power(10.0, t.astype(np.float64))
+    d = np.rint(x)
+    bump = d >= 1e6
+    d = np.where(bump, d / 10, d)
+    t = np.where(bump, t - 1, t)
+    r = d / np.power(10.0, t.astype(np.float64))
+    r[r < _DBL_MIN] = 0.0
+    out[nz] = r
+    return out

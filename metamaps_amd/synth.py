@@ -180,3 +180,39 @@ def make_reads(db: SynthDB, path: str, n_reads: int = 1000, read_len: int = 5000
             truth.append((name, src, int(s.size)))
             f.write(b"@" + name.encode() + b" len=" + str(s.size).encode() + b"\n" + s.tobytes() + b"\n+\n" + b"I" * s.size + b"\n")
     return {"path": path, "truth": truth}
+
+
+def write_db_dir(out_dir: str, contigs: list) -> dict:
+    """A database directory (DB.fa, taxonInfo.txt, taxonomy/*.dmp, contigNstats_windowSize_1000.txt) around given sequences:
+    contigs = [(genome id, ASCII sequence bytes)] in DB.fa order; genome g becomes taxon 1000000 + g under species 500000 + g // 4,
+    genus 100000 + g // 16 (bench.py's CPU / CLI sample of the device-generated reference)."""
+    os.makedirs(os.path.join(out_dir, "taxonomy"), exist_ok=True)
+    nodes = {"1": ("1", "no rank", "root"), "2": ("1", "superkingdom", "Bacteria"), "100": ("2", "phylum", "Synthphyla"), "200": ("100", "order", "Synthales"),
+             "300": ("200", "family", "Synthaceae")}
+    per_taxon: dict = {}
+    fasta = os.path.join(out_dir, "DB.fa")
+    with open(fasta, "wb") as f, open(os.path.join(out_dir, "contigNstats_windowSize_1000.txt"), "w") as ns:
+        for ci, (g, seq) in enumerate(contigs):
+            tid, sp, ge = str(1000000 + g), str(500000 + g // 4), str(100000 + g // 16)
+            nodes.setdefault(ge, ("300", "genus", f"Synthus{g // 16}"))
+            nodes.setdefault(sp, (ge, "species", f"Synthus{g // 16} species{g // 4}"))
+            nodes.setdefault(tid, (sp, "no rank", f"Synthus{g // 16} species{g // 4} strain{g}"))
+            cid = f"C{ci}|kraken:taxid|{tid}|SYN{ci:05d}.1"
+            f.write(b">" + cid.encode() + b"\n" + seq + b"\n")
+            per_taxon.setdefault(tid, []).append(f"{cid}={len(seq)}")
+            a = np.frombuffer(seq, dtype=np.uint8)
+            isn = ((a == ord("N")) | (a == ord("n"))).astype(np.int64)
+            nwin = -(-len(seq) // 1000)
+            counts = np.add.reduceat(isn, np.arange(0, len(seq), 1000)) if len(seq) else np.zeros(0, dtype=np.int64)
+            ns.write(f"{tid}\t{cid}\t" + ";".join(map(str, counts[:nwin].tolist())) + "\n")
+    with open(os.path.join(out_dir, "taxonInfo.txt"), "w") as f:
+        for tid, lst in per_taxon.items():
+            f.write(tid + " " + ";".join(lst) + "\n")
+    with open(os.path.join(out_dir, "taxonomy", "nodes.dmp"), "w") as f:
+        for tid, (par, rank, _) in nodes.items():
+            f.write(f"{tid}\t|\t{par}\t|\t{rank}\t|\n")
+    with open(os.path.join(out_dir, "taxonomy", "names.dmp"), "w") as f:
+        for tid, (_, _, name) in nodes.items():
+            f.write(f"{tid}\t|\t{name}\t|\t\t|\tscientific name\t|\n")
+    open(os.path.join(out_dir, "taxonomy", "merged.dmp"), "w").close()
+    return {"dir": out_dir, "fasta": fasta}

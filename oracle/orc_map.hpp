@@ -4,6 +4,9 @@
 #include "orc_core.hpp"
 #include "orc_io.hpp"
 #include <functional>
+#include <atomic>
+#include <thread>
+#include <algorithm>
 #include <climits>
 
 namespace orc {
@@ -71,24 +74,52 @@ struct RefSketch {
              const std::function<void(RefSketch&, int)>& onChunk) {
     size_t runHashes = 0, runMins = 0, seen = 0;
     int chunkNo = 1;
-    std::vector<Mz> cur;
+    // distinct hashes of `cur` that the lookup does not hold yet (the reference walks a std::set, :274-282; same number)
+    auto count_novel = [&](const std::vector<Mz>& cur, bool against_lookup) {
+      std::vector<uint32_t> hs(cur.size());
+      for (size_t i = 0; i < cur.size(); ++i) hs[i] = cur[i].hash;
+      std::sort(hs.begin(), hs.end());
+      hs.erase(std::unique(hs.begin(), hs.end()), hs.end());
+      if (!against_lookup) return hs.size();
+      size_t n = 0;
+      for (uint32_t h : hs) if (!lookup.count(h)) ++n;
+      return n;
+    };
     for (const auto& fn : fastas) {
-      SeqReader rd(fn);
-      long len;
-      while ((len = rd.next()) >= 0) {
+      // The winnowing of a contig does not depend on anything else, so with -t N the contigs are read first and winnowed by N
+      // threads (seqId patched in when the contig is consumed); everything stateful below stays the reference's serial loop.
+      struct Pre { std::string name, seq; long len = 0; std::vector<Mz> mz; };
+      std::vector<Pre> pre;
+      {
+        SeqReader rd(fn);
+        long len;
+        while ((len = rd.next()) >= 0) { pre.emplace_back(); pre.back().name = rd.name; pre.back().len = len; if (!(len < P.w || len < P.k)) pre.back().seq = rd.seq; }
+      }
+      {
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+          for (size_t i = next.fetch_add(1); i < pre.size(); i = next.fetch_add(1)) {
+            Pre& x = pre[i];
+            if (x.len < P.w || x.len < P.k) continue;
+            add_minimizers(x.mz, &x.seq[0], (int)x.len, P.k, P.w, 0);   // :269 (seqId follows below)
+            std::string().swap(x.seq);
+          }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < std::max(1, P.threads); ++t) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+      }
+      for (auto& x : pre) {
+        const long len = x.len;
         if (len < P.w || len < P.k) {                            // :258-264 metadata only
-          meta.push_back(Contig{rd.name, (int32_t)len});
+          meta.push_back(Contig{x.name, (int32_t)len});
           ++seen;
           continue;
         }
-        cur.clear();
-        add_minimizers(cur, &rd.seq[0], (int)len, P.k, P.w, (int)seen);   // :269
-        size_t addHashes = 0, addMins = cur.size();
-        {
-          std::set<uint32_t> novel;                              // :274-282
-          for (auto& e : cur)
-            if (!novel.count(e.hash) && !lookup.count(e.hash)) { ++addHashes; novel.insert(e.hash); }
-        }
+        std::vector<Mz>& cur = x.mz;
+        for (auto& e : cur) e.seq = (int)seen;
+        size_t addHashes = count_novel(cur, true), addMins = cur.size();   // :274-282
         size_t totH = runHashes + addHashes, totM = runMins + addMins;
         size_t mem = memory_of(totH, totM);
         if (P.maxMem > 0 && mem > P.maxMem) {                    // :298-329 flush before adding
@@ -97,20 +128,20 @@ struct RefSketch {
           clear_chunk();
           runHashes = runMins = seen = 0;
           ++chunkNo;
-          std::set<uint32_t> novel;
-          for (auto& e : cur) { novel.insert(e.hash); e.seq = 0; }
-          addHashes = novel.size();
+          for (auto& e : cur) e.seq = 0;
+          addHashes = count_novel(cur, false);
           totH = addHashes; totM = addMins;
           mem = memory_of(totH, totM);
           if (mem > P.maxMem)
             throw std::runtime_error("Can't index file " + fn + " within current memory limits - contig " +
-                                     rd.name + " is too large");
+                                     x.name + " is too large");
         }
         for (auto& e : cur) lookup[e.hash].push_back(Hit{e.seq, e.wpos, e.strand});   // :331-336
         byPos.insert(byPos.end(), cur.begin(), cur.end());       // :338
-        meta.push_back(Contig{rd.name, (int32_t)len});
+        meta.push_back(Contig{x.name, (int32_t)len});
         runHashes = totH; runMins = totM;
         ++seen;
+        std::vector<Mz>().swap(cur);
       }
     }
     compute_freq_hist();                                         // :359 → processCurrentState

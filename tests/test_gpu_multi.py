@@ -139,6 +139,13 @@ def test_allreduce_iteration_equals_local_iteration():
         f_b, ll_b = eb.iterate_allreduce(f)
         assert np.array_equal(f_a, f_b) and ll_a == ll_b
         f = f_b
+    # the device-resident loop (mm_em_run), with and without the communicator, against the host-driven loop above
+    from metamaps_amd import emhost
+    f_ref, lls_ref = emhost.run_em(lambda x: ea.iterate_allreduce(x), n_taxa)
+    for e in (ea, eb):
+        f_run, lls_run = e.run(np.full(n_taxa, 1.0 / n_taxa))
+        assert len(lls_run) == len(lls_ref) and np.allclose(lls_run, lls_ref, rtol=1e-13, atol=0)
+        assert np.allclose(f_run, f_ref, rtol=1e-12, atol=1e-300)
     ea.close(); eb.close(); ctx_a.close(); ctx_b.close()
 
 

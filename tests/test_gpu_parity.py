@@ -283,9 +283,7 @@ def test_hit_prefilter_keeps_candidates_identical(ctx, monkeypatch):
 def test_em_from_mapping_equals_host_built_problem(ctx):
     """mm_em_create_from_mapping (device) against the same EM problem assembled on the host from fetched records with the
     reference's rules (fEM.h:234-353): multi-contig taxa, contigs shorter than the read, 6-digit mapping qualities."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
-    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    from metamaps_amd import emhost
     ref = ctx.synth_reference(seed=8, n_species=24, strains_per_species=4, genome_len=150_000, strain_divergence=0.02, genus_divergence=0.08)
     reads, _ = ctx.synth_reads(ref, seed=12, n_reads=1500, read_len=5000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.1, n_abundant=30)
     idx = ctx.index(ref, 16, 8)
@@ -300,7 +298,7 @@ def test_em_from_mapping_equals_host_built_problem(ctx):
     rl = reads.lengths().astype(np.int64)
     # host construction
     taxon = contig_taxon[rec["ref_contig"]]
-    mapq = bench.parse6(rec["mapq"].astype(np.float64))
+    mapq = emhost.parse6(rec["mapq"].astype(np.float64))
     inv = np.zeros(len(rec))
     for r in range(len(off) - 1):
         a, b = int(off[r]), int(off[r + 1])

@@ -54,6 +54,11 @@ def parse_args():
     ap.add_argument("--pacbio", action="store_true", help="PacBio-like errors (2/8/2 percent del/ins/sub) instead of ONT-like (5/3/4)")
     ap.add_argument("--scale", type=float, default=float(os.environ.get("MM_BENCH_SCALE", 1.0)), help="scales the number of genomes of the reference (quick checks)")
     ap.add_argument("--window", type=int, default=8, help="w the CLI derives for a 26.76 GB DB.fa at default flags")
+    ap.add_argument("--workers", type=int, default=int(os.environ.get("MM_BENCH_WORKERS", 2)),
+                    help="host threads / contexts per GPU that take the steps in turn: while one runs the EM iterations, result download and host "
+                         "bookkeeping of its step, the next step's mapping kernels run (the mapping sections themselves are serialised, so that "
+                         "kernel durations — the roofline — are those of kernels that own the GPU)")
+    ap.add_argument("--free-overlap", action="store_true", help="do not serialise the mapping sections of the workers (higher throughput, kernel durations inflated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-shape", action="store_true", help="skip the second reference shape (config.other_shape)")
     ap.add_argument("--cpu-sample-reads", type=int, default=20000)
@@ -92,12 +97,19 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from metamaps_amd import capi
-    ctx = capi.Context(local)
-    # the EM all-reduce always goes through the RCCL communicator, also with one rank (the same code path at every N)
+    import threading
+    W = max(1, args.workers)
+    ctxs = [capi.Context(local) for _ in range(W)]               # one context (stream + allocator + communicator) per worker thread
+    ctx = ctxs[0]
+    # the EM all-reduce always goes through the RCCL communicator, also with one rank (the same code path at every N).  The worker
+    # contexts of a rank share ONE communicator and run their classify sections in step order, so that every rank issues the same
+    # sequence of collectives
     uid = [capi.Context.comm_unique_id() if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(uid, src=0)
     ctx.comm_init(uid[0], rank, world)
+    for c in ctxs[1:]:
+        c.comm_share(ctx)
     import ctypes
     ctypes.CDLL(None).fflush(None)                                # RCCL prints a version banner through C stdio: out before the JSON line
 
@@ -108,7 +120,8 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        ctx.synchronize()
+        for c in ctxs:
+            c.synchronize()
 
     def run_shape(shape, steps, warmup):
         """setup (untimed) + warm-up + `steps` timed steps on one reference shape; returns everything the report needs"""
@@ -121,49 +134,90 @@ def main():
         ctx.synchronize()
         t_index = time.time() - t0
         info = idx.info()
-        reads, truth = ctx.synth_reads(ref, seed=1000 + rank, n_reads=args.reads, read_len=args.read_len, read_len_min=args.read_len_min,
-                                       frac_random=0.05, n_abundant=100, **err)
+        reads_w, truth = [], None
+        for c in ctxs:                                           # every worker context holds the batch (the same reads)
+            rd, truth = c.synth_reads(ref, seed=1000 + rank, n_reads=args.reads, read_len=args.read_len, read_len_min=args.read_len_min,
+                                      frac_random=0.05, n_abundant=100, **err)
+            reads_w.append(rd)
+        reads = reads_w[0]
         ctx.synchronize()
         contig_len = ref.lengths().astype(np.int32)
         agg = {"ms_l2": 0.0, "ms_hf": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0, "stats": None, "em_iters": 0}
-        rec_buf = np.empty(max(64 * args.reads, 1 << 16), dtype=capi.RECORD_DTYPE)   # host result buffer reused by every step
+        rec_bufs = [np.empty(max(64 * args.reads, 1 << 16), dtype=capi.RECORD_DTYPE) for _ in ctxs]   # host result buffers reused by every step
+        map_lock, agg_lock = threading.Lock(), threading.Lock()
+        em_turn = {"next": 0, "cv": threading.Condition()}
 
-        def step():
+        def step(wi, serialise=True, ticket=0):
+            c = ctxs[wi]
             tt = [time.perf_counter()]
-            M = ctx.map_batch(idx, reads, k, w, pi=80.0, min_read_len=1000)
-            tt.append(time.perf_counter())
-            M.add_qualities(k)
-            off, rec = M.fetch(rec_buf)
+            if serialise:
+                map_lock.acquire()
+            try:
+                M = c.map_batch(idx, reads_w[wi], k, w, pi=80.0, min_read_len=1000)
+                tt.append(time.perf_counter())
+                M.add_qualities(k)
+            finally:
+                if serialise:
+                    map_lock.release()
+            off, rec = M.fetch(rec_bufs[wi])
             st = M.stats()
             tt.append(time.perf_counter())
-            # ---- classify: the EM problem built on the device from the records (fEM.h:234-373), then device iterations
-            em = ctx.em_from_mapping(M, contig_taxon, contig_len, n_taxa)
+            # ---- classify: the EM problem built on the device from the records (fEM.h:234-373), then device iterations; the classify
+            # sections of the workers run in step order (one communicator, the same order of collectives on every rank)
+            em = c.em_from_mapping(M, contig_taxon, contig_len, n_taxa)
             M.close()
-            seen = (em.taxon_counts() > 0).astype(np.float64)
-            ctx.comm_allreduce(seen)
-            present = seen > 0
-            f = np.where(present, 1.0 / max(int(present.sum()), 1), 0.0)
-            f, lls = em.run(f)                                      # the EM loop, device resident (fEM.h:501-661)
+            with em_turn["cv"]:
+                em_turn["cv"].wait_for(lambda: em_turn["next"] == ticket)
+            try:
+                seen = (em.taxon_counts() > 0).astype(np.float64)
+                c.comm_allreduce(seen)
+                present = seen > 0
+                f = np.where(present, 1.0 / max(int(present.sum()), 1), 0.0)
+                f, lls = em.run(f)                                  # the EM loop, device resident (fEM.h:501-661)
+            finally:
+                with em_turn["cv"]:
+                    em_turn["next"] = ticket + 1
+                    em_turn["cv"].notify_all()
             tt.append(time.perf_counter())
             post, best = em.posteriors(f)
             em.close()
             tt.append(time.perf_counter())
-            agg["host_ms"] = {"map_batch": (tt[1] - tt[0]) * 1e3, "mapq_fetch": (tt[2] - tt[1]) * 1e3, "em_prepare_iterate": (tt[3] - tt[2]) * 1e3,
-                              "posteriors": (tt[4] - tt[3]) * 1e3}
-            agg["ms_l2"] += st["ms_l2"]; agg["launches"] += 1; agg["l2_stream"] += st["sum_l2_stream_entries"]
-            agg["ms_hf"] += st["ms_hit_filter"]; agg["hf_units"] += st["sum_hits"] + st["sum_sketch"]
-            agg["stats"] = st; agg["em_iters"] = len(lls)
+            with agg_lock:
+                agg["host_ms"] = {"map_batch": (tt[1] - tt[0]) * 1e3, "mapq_fetch": (tt[2] - tt[1]) * 1e3, "em_prepare_iterate": (tt[3] - tt[2]) * 1e3,
+                                  "posteriors": (tt[4] - tt[3]) * 1e3}
+                agg["ms_l2"] += st["ms_l2"]; agg["launches"] += 1; agg["l2_stream"] += st["sum_l2_stream_entries"]
+                agg["ms_hf"] += st["ms_hit_filter"]; agg["hf_units"] += st["sum_hits"] + st["sum_sketch"]
+                agg["stats"] = st; agg["em_iters"] = len(lls)
             return st
 
-        for _ in range(warmup):
-            step()
+        def run_steps(n, serialise=True):
+            """n steps, taken in turn by the worker threads (every rank runs the same schedule, so the collectives of communicator i match)"""
+            em_turn["next"] = 0
+            def work(wi):
+                for s_i in range(wi, n, W):
+                    step(wi, serialise, s_i)
+            th = [threading.Thread(target=work, args=(wi,)) for wi in range(1, W)]
+            for t in th:
+                t.start()
+            work(0)
+            for t in th:
+                t.join()
+
+        run_steps(max(warmup, 0))
         agg.update({"ms_l2": 0.0, "ms_hf": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0})
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            st = step()
+        run_steps(steps, not args.free_overlap)
         barrier()
         dt = time.perf_counter() - t0
+        st = agg["stats"]
+        free = None
+        if W > 1 and not args.free_overlap and world == 1 and shape == args.shape:   # beside the headline: the same steps with nothing serialised
+            keep = dict(agg)
+            barrier(); t1 = time.perf_counter(); run_steps(6, False); barrier()
+            d1 = time.perf_counter() - t1
+            free = {"ms_per_step": d1 / 6 * 1e3, "value": float(st["bases_long_enough"]) * 6 / d1 / 1e9, "steps": 6}
+            agg.clear(); agg.update(keep)
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -173,7 +227,7 @@ def main():
             bases_all = float(bb.item())
         else:
             bases_all = float(st["bases_long_enough"])
-        return dict(ref=ref, idx=idx, reads=reads, truth=truth, contig_taxon=contig_taxon, info=info, desc=desc, t_ref=t_ref, t_index=t_index,
+        return dict(ref=ref, idx=idx, reads=reads, reads_w=reads_w, truth=truth, contig_taxon=contig_taxon, info=info, desc=desc, t_ref=t_ref, t_index=t_index, free=free,
                     agg=agg, st=st, dt=dt, steps=steps, bases_all=bases_all, value=bases_all * steps / dt / 1e9, ms_step=dt / steps * 1e3,
                     freq_threshold=idx.freq_threshold, reference_bp=int(ref.total_bases))
 
@@ -204,7 +258,9 @@ def main():
                 "reads_per_gpu": args.reads, "read_len": args.read_len, "reference_bp": R["reference_bp"], "reference_contigs": info["n_contigs"],
                 "index_entries": info["n_entries"], "index_unique_hashes": info["n_unique_hashes"], "index_hbm_bytes": info["hbm_bytes"],
                 "freq_threshold": R["freq_threshold"], "reference_synth_s": round(R["t_ref"], 3), "index_build_s": round(R["t_index"], 3),
-                "parallelism": f"reads sharded x{world}, index replicated, RCCL all-reduce of EM sums",
+                "parallelism": f"reads sharded x{world}, index replicated, RCCL all-reduce of EM sums; {W} worker contexts per GPU take the steps in turn"
+                               + (" (mapping sections serialised)" if W > 1 and not args.free_overlap else ""),
+                "workers_per_gpu": W, "free_overlap": R["free"],
                 "em_iterations": agg["em_iters"],
                 "per_step": {kk: st[kk] for kk in ("n_reads_long_enough", "n_reads_mapped", "n_mappings", "sum_sketch", "sum_hits",
                                                    "n_candidates", "sum_l2_stream_entries", "sum_l2_evals", "n_ambiguous_sketch_reads",
@@ -225,7 +281,9 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
     # the other reference shape, beside the headline (one GPU only: it costs a second index build)
     if world == 1 and not args.no_other_shape:
-        for kk in ("reads", "idx", "ref"):
+        for rd in R["reads_w"]:
+            rd.close()
+        for kk in ("idx", "ref"):
             R[kk].close()
         other = "uniform" if args.shape == "community" else "community"
         try:
@@ -241,7 +299,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 def measured_traffic(args, kernel: str):

@@ -261,6 +261,10 @@ int mm_em_posteriors(mm_em* em, const double* f, double* post /* [n_entries] */,
 #define MM_COMM_ID_BYTES 128
 int mm_comm_unique_id(char id[MM_COMM_ID_BYTES]);                     /* rank 0 creates, caller broadcasts */
 int mm_comm_init(mm_ctx* ctx, const char id[MM_COMM_ID_BYTES], int rank, int nranks);
+/* Several contexts of one device (e.g. two host threads that take read batches in turn) use ONE communicator: `ctx` borrows the
+ * communicator of `owner` (same device; the owner outlives it).  The caller issues the collectives of the sharing contexts in
+ * the same order on every rank. */
+int mm_comm_share(mm_ctx* ctx, mm_ctx* owner);
 int mm_comm_allreduce_f64(mm_ctx* ctx, double* host_inout, int64_t n);   /* staging helper for small vectors */
 void mm_comm_destroy(mm_ctx* ctx);
 

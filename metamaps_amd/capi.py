@@ -153,6 +153,7 @@ def lib() -> C.CDLL:
             "mm_comm_unique_id": (C.c_int, [C.c_char_p]),
             "mm_comm_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
             "mm_comm_allreduce_f64": (C.c_int, [vp, vp, i64]),
+            "mm_comm_share": (C.c_int, [vp, vp]),
             "mm_comm_destroy": (None, [vp]),
         }
         for name, (res, args) in sig.items():
@@ -293,6 +294,10 @@ class Context:
 
     def comm_init(self, uid: bytes, rank: int, nranks: int):
         self.check(lib().mm_comm_init(self.h, uid, rank, nranks))
+
+    def comm_share(self, owner: "Context"):
+        """use the communicator of another context of the same device (collectives then go out in the caller's order)"""
+        self.check(lib().mm_comm_share(self.h, owner.h))
 
     def comm_allreduce(self, arr: np.ndarray):
         assert arr.dtype == np.float64 and arr.flags.c_contiguous

@@ -550,6 +550,14 @@ int mm_comm_init(mm_ctx* ctx, const char id[MM_COMM_ID_BYTES], int rank, int nra
   if (!ctx || !id || rank < 0 || rank >= nranks) return MM_ERR_ARG;
   return guarded(ctx, [&] { mm::comm_init(ctx, id, rank, nranks); });
 }
+int mm_comm_share(mm_ctx* ctx, mm_ctx* owner) {
+  if (!ctx || !owner || ctx == owner) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    MM_REQUIRE(ctx->comm == nullptr, MM_ERR_STATE, "communicator already initialised");
+    MM_REQUIRE(owner->comm != nullptr && !owner->comm_shared && owner->device == ctx->device, MM_ERR_ARG, "mm_comm_share: the owner must hold a communicator on the same device");
+    ctx->comm = owner->comm; ctx->comm_shared = true; ctx->comm_rank = owner->comm_rank; ctx->comm_size = owner->comm_size;
+  });
+}
 int mm_comm_allreduce_f64(mm_ctx* ctx, double* host_inout, int64_t n) {
   if (!ctx || (!host_inout && n > 0)) return MM_ERR_ARG;
   return guarded(ctx, [&] { MM_HIP(hipSetDevice(ctx->device)); mm::comm_allreduce_f64(ctx, host_inout, n); });

@@ -209,6 +209,7 @@ struct mm_ctx {
   std::string err;
   int cus = 0;
   void* comm = nullptr;          // ncclComm_t
+  bool comm_shared = false;      // the communicator belongs to another context of this device (mm_comm_share)
   int comm_rank = 0, comm_size = 1;
   // per-(k, pi) cache of the host statistics thresholds (pure functions of the sketch size), mm_stats.hpp
   std::shared_ptr<void> lut_cache;

@@ -477,7 +477,7 @@ void comm_allreduce_f64(mm_ctx* ctx, double* host, int64_t n) {
   MM_HIP(hipStreamSynchronize(ctx->stream));
 }
 void comm_destroy(mm_ctx* ctx) {
-  if (ctx->comm) { ncclCommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; ctx->comm_size = 1; ctx->comm_rank = 0; }
+  if (ctx->comm) { if (!ctx->comm_shared) ncclCommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; ctx->comm_shared = false; ctx->comm_size = 1; ctx->comm_rank = 0; }
 }
 
 }  // namespace mm

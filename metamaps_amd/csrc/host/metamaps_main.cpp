@@ -29,6 +29,9 @@
 
 #include "../../../include/metamaps_hip.h"
 #include <sys/mman.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <atomic>
 #include <zlib.h>
 #include <algorithm>
 #include <functional>
@@ -69,24 +72,61 @@ struct PhaseClock {
 void ck(mm_ctx* ctx, int st, const char* what) { if (st != MM_OK) die(std::string(what) + ": " + mm_last_error(ctx)); }
 
 // FASTA/FASTQ(.gz) records with kseq's observable behaviour (common/kseq.h:170-207)
+// Two sources: a (gz) file read through zlib in 1 MiB pieces, or a byte range of a memory-mapped plain file (MemView: the parallel
+// block parser below).  In memory mode `rec_start` is the file offset of the header character of the record just returned, `tell`
+// the offset of the first byte the next call will look at, and a record whose sequence sits on one line of a 4-line FASTQ record
+// is returned as a view into the mapping (view != nullptr, seq empty) instead of a copy.
 class SeqFile {
-  gzFile fp_; std::vector<unsigned char> buf_; size_t beg_ = 0, end_ = 0; bool eof_ = false; int pending_ = 0;
+  struct Buf { const unsigned char* p; const unsigned char* data() const { return p; } } buf_{nullptr};
+  gzFile fp_ = nullptr; std::vector<unsigned char> own_; size_t beg_ = 0, end_ = 0; bool eof_ = false; int pending_ = 0; size_t pending_pos_ = 0; bool mem_ = false;
   int get() {
-    if (beg_ >= end_) { if (eof_) return -1; int n = gzread(fp_, buf_.data(), (unsigned)buf_.size()); if (n <= 0) { eof_ = true; return -1; } beg_ = 0; end_ = (size_t)n; }
-    return buf_[beg_++];
+    if (beg_ >= end_) { if (eof_) return -1; int n = gzread(fp_, own_.data(), (unsigned)own_.size()); if (n <= 0) { eof_ = true; return -1; } beg_ = 0; end_ = (size_t)n; }
+    return buf_.p[beg_++];
   }
  public:
   std::string name, seq;
-  explicit SeqFile(const std::string& path) : buf_(1 << 20) { fp_ = gzopen(path.c_str(), "r"); if (!fp_) die("Cannot open " + path); }
-  ~SeqFile() { gzclose(fp_); }
+  const char* view = nullptr; size_t view_len = 0;               // memory mode: the sequence where it lies in the file
+  size_t rec_start = 0;
+  explicit SeqFile(const std::string& path) : own_(1 << 20) { fp_ = gzopen(path.c_str(), "r"); if (!fp_) die("Cannot open " + path); buf_.p = own_.data(); }
+  SeqFile(const unsigned char* data, size_t begin, size_t size) : beg_(begin), end_(size), eof_(true), mem_(true) { buf_.p = data; }   // memory mode: parses from `begin` on
+  ~SeqFile() { if (fp_) gzclose(fp_); }
+  SeqFile(const SeqFile&) = delete;
+  // memory mode: offset of the header character of the record the next call would return, (size_t)-1 if there is none
+  size_t peek_start() const {
+    if (pending_) return pending_pos_;
+    for (size_t q = beg_; q < end_; ++q) if (buf_.p[q] == '>' || buf_.p[q] == '@') return q;
+    return (size_t)-1;
+  }
+  size_t length() const { return view ? view_len : seq.size(); }
   bool next() {
     int c;
-    if (!pending_) { while ((c = get()) != -1 && c != '>' && c != '@') {} if (c == -1) return false; pending_ = c; }
+    view = nullptr; view_len = 0;
+    if (!pending_) { while ((c = get()) != -1 && c != '>' && c != '@') {} if (c == -1) return false; pending_ = c; pending_pos_ = beg_ - 1; }
+    rec_start = pending_pos_;
     name.clear(); seq.clear();
     bool any = false;
     while ((c = get()) != -1 && !isspace(c)) { name.push_back((char)c); any = true; }
     if (c == -1 && !any) return false;
     if (c != '\n') while (c != -1 && (c = get()) != -1 && c != '\n') {}
+    if (mem_ && pending_ == '@' && c == '\n') {
+      // the usual FASTQ record — sequence on one line, '+' line, as many quality characters on one line — straight from the mapping:
+      // validated in place, nothing copied.  Anything else (wrapped lines, odd characters, a short quality line) takes the general path.
+      const unsigned char* const base = buf_.p; const unsigned char* const fe = base + end_;
+      const unsigned char* p = base + beg_;
+      const unsigned char* nl = (const unsigned char*)memchr(p, '\n', (size_t)(fe - p));
+      if (nl && nl > p && nl + 1 < fe && nl[1] == '+') {
+        const size_t L = (size_t)(nl - p);
+        unsigned char bad = 0;
+        for (const unsigned char* q = p; q < nl; ++q) { const unsigned char b = *q; bad |= (unsigned char)((unsigned char)(b - 33) > 93) | (unsigned char)(b == '+') | (unsigned char)(b == '>') | (unsigned char)(b == '@'); }
+        const unsigned char* pl = (const unsigned char*)memchr(nl + 1, '\n', (size_t)(fe - nl - 1));
+        if (!bad && pl && (size_t)(fe - pl - 1) >= L && (pl + 1 + L == fe || pl[1 + L] == '\n')) {
+          const unsigned char* ql = pl + 1;
+          unsigned char qb = 0;
+          for (const unsigned char* q = ql; q < ql + L; ++q) qb |= (unsigned char)((unsigned char)(*q - 33) > 94);
+          if (!qb) { view = (const char*)p; view_len = L; beg_ = (size_t)(ql + L - base); pending_ = 0; return true; }
+        }
+      }
+    }
     // sequence: everything up to the next '>', '+' or '@', graphic characters only — in bulk over the read buffer
     // (class table: 0 keep, 1 skip, 2 stop) instead of one call per character
     static const struct Cls { uint8_t t[256]; Cls() { for (int i = 0; i < 256; ++i) t[i] = (i == '>' || i == '+' || i == '@') ? 2 : (isgraph(i) ? 0 : 1); } } cls;
@@ -111,7 +151,7 @@ class SeqFile {
       beg_ = (size_t)(p - buf_.data());
       if (p < e) { c = *p; ++beg_; break; }                       // the stop character is consumed, as get() would
     }
-    pending_ = (c == '>' || c == '@') ? c : 0;
+    pending_ = (c == '>' || c == '@') ? c : 0; pending_pos_ = beg_ - 1;
     if (c != '+') return true;
     while ((c = get()) != -1 && c != '\n') {}
     size_t got = 0;                                              // qualities: as many characters in [33,127] as there are bases
@@ -188,6 +228,7 @@ uint64_t file_size(const std::string& f) {                       // commonFunc.h
 // reference (mm_seqset_add_view) and recycled: no allocation, copy or page fault per read.
 struct Batch {
   std::vector<std::string> names; std::vector<int> lens; std::vector<size_t> off;
+  std::vector<const char*> view;                                 // per read: where the sequence lies in a mapped query file, or nullptr (then arena + off)
   char* arena = nullptr; size_t cap = 0, used = 0;
   size_t seq = 0, file = 0;
   ~Batch() { free(arena); }
@@ -200,8 +241,64 @@ struct Batch {
     if (used) memcpy(na, arena, used);
     free(arena); arena = na; cap = ncap;
   }
-  void put(const std::string& q) { reserve(used + q.size() + 1); memcpy(arena + used, q.data(), q.size()); off.push_back(used); used += q.size(); }
-  void reset() { names.clear(); lens.clear(); off.clear(); used = 0; }
+  void put(const std::string& q) { reserve(used + q.size() + 1); memcpy(arena + used, q.data(), q.size()); off.push_back(used); view.push_back(nullptr); used += q.size(); }
+  void put_view(const char* p) { off.push_back(0); view.push_back(p); }
+  const char* seq_of(size_t r) const { return view[r] ? view[r] : arena + off[r]; }
+  void add(SeqFile& f) {                                         // the record `f` just returned
+    names.push_back(f.name); lens.push_back((int)f.length());
+    if (f.view) put_view(f.view); else put(f.seq);
+  }
+  void reset() { names.clear(); lens.clear(); off.clear(); view.clear(); used = 0; }
+};
+
+// A plain (not gzip) query file, memory mapped.  Parsed in blocks by several threads; what makes that exact is that the state of
+// the sequential parser between two records is just a file offset: a block parser that starts on a record start the previous
+// block's parser also ends on reproduces the sequential parse (SeqFile, memory mode).
+struct MappedFile {
+  const unsigned char* data = nullptr; size_t size = 0;
+  bool open(const std::string& path) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 4) { ::close(fd); return false; }
+    unsigned char magic[2] = {0, 0};
+    if (pread(fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b)) { ::close(fd); return false; }   // gzip: zlib reads it
+    void* p = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (p == MAP_FAILED) return false;
+    madvise(p, (size_t)st.st_size, MADV_WILLNEED);
+    data = (const unsigned char*)p; size = (size_t)st.st_size;
+    return true;
+  }
+  ~MappedFile() { if (data) munmap((void*)data, size); }
+  // first offset >= x that is certainly a record start, or `limit` if none is found before it: a FASTA header ('>' at the start of
+  // a line; any '>' ends a sequence for kseq), or a FASTQ record whose four lines and whose successor's first line check out
+  size_t sync(size_t x, size_t limit) const {
+    const bool fasta = data[0] == '>';
+    for (size_t p = x; p < limit; ++p) {
+      if (p > 0 && data[p - 1] != '\n') { const void* q = memchr(data + p, '\n', limit - p); if (!q) return limit; p = (size_t)((const unsigned char*)q - data); continue; }
+      if (fasta) { if (data[p] == '>') return p; continue; }
+      if (data[p] != '@') continue;
+      size_t a = p; bool ok = true;
+      const unsigned char* const fe = data + size;
+      for (int rec = 0; rec < 2 && ok && a < size; ++rec) {
+        if (data[a] != '@') { ok = false; break; }
+        const unsigned char* l1 = (const unsigned char*)memchr(data + a, '\n', size - a);             // end of the header line
+        if (!l1 || l1 + 1 >= fe) { ok = false; break; }
+        const unsigned char* l2 = (const unsigned char*)memchr(l1 + 1, '\n', (size_t)(fe - l1 - 1));   // end of the sequence line
+        if (!l2 || l2 + 1 >= fe || l2[1] != '+' || l2 == l1 + 1) { ok = false; break; }
+        const unsigned char* l3 = (const unsigned char*)memchr(l2 + 1, '\n', (size_t)(fe - l2 - 1));   // end of the '+' line
+        if (!l3) { ok = false; break; }
+        const size_t L = (size_t)(l2 - l1 - 1);
+        if ((size_t)(fe - l3 - 1) < L) { ok = false; break; }
+        const unsigned char* e = l3 + 1 + L;                                                          // just behind the qualities
+        if (e < fe && *e != '\n') { ok = false; break; }
+        a = (size_t)(e - data) + 1;
+      }
+      if (ok) return p;
+    }
+    return limit;
+  }
 };
 
 // one logical GPU: a context (stream + allocator) on a physical device, and the chunk indexes that live there
@@ -484,28 +581,105 @@ int map_mode(const Options& o, const std::string& mode) {
     ~Reader() { if (th.joinable()) th.join(); }
   } reader;
   reader.max_queued = std::max<size_t>(2, 2 * G);
+  std::deque<MappedFile> mapped;                                 // query files whose sequences the batches point into: alive until the end
   reader.th = std::thread([&]() {
     size_t seq = 0;
-    for (size_t fi = 0; fi < queries.size(); ++fi) {
-      SeqFile f(queries[fi]);
-      bool more = true;
+    auto fresh = [&]() {
+      std::unique_ptr<Batch> b;
+      { std::lock_guard<std::mutex> lk(reader.m); if (!reader.spare.empty()) { b = std::move(reader.spare.back()); reader.spare.pop_back(); } }
+      if (!b) b = std::make_unique<Batch>();
+      return b;
+    };
+    auto enqueue = [&](std::unique_ptr<Batch> b, size_t fi) {
+      b->seq = seq++; b->file = fi;
+      if (getenv("MM_CLI_TIMING")) std::cerr << "INFO, reader: batch of " << b->names.size() << " reads parsed at +" << std::chrono::duration<double>(std::chrono::steady_clock::now() - pc.t0).count() << " s\n";
+      std::unique_lock<std::mutex> lk(reader.m);
+      reader.cv.wait(lk, [&] { return reader.queue.size() < reader.max_queued; });
+      reader.queue.push_back(std::move(b));
+      reader.cv.notify_all();
+    };
+    // records of `f` while they start before `stop` (memory mode; (size_t)-1: all) -> batches handed to `emit`; false if the reader
+    // gave up on the file (a truncated quality string ends the file for kseq, kseq.h:204)
+    auto parse_into = [&](SeqFile& f, size_t stop, const std::function<void(std::unique_ptr<Batch>)>& emit) -> bool {
+      bool more = true, gave_up = false;
       while (more) {
-        std::unique_ptr<Batch> b;
-        { std::lock_guard<std::mutex> lk(reader.m); if (!reader.spare.empty()) { b = std::move(reader.spare.back()); reader.spare.pop_back(); } }
-        if (!b) b = std::make_unique<Batch>();
+        std::unique_ptr<Batch> b = fresh();
         int64_t bases = 0;
-        while ((int64_t)b->names.size() < BATCH_READS && bases < BATCH_BASES && (more = f.next())) {
-          if (b->names.empty()) b->reserve((size_t)std::min<int64_t>(BATCH_BASES, (int64_t)f.seq.size() * BATCH_READS) + ((size_t)64 << 20));
-          b->names.push_back(f.name); b->lens.push_back((int)f.seq.size()); bases += (int64_t)f.seq.size();
-          b->put(f.seq);
+        while ((int64_t)b->names.size() < BATCH_READS && bases < BATCH_BASES) {
+          if (stop != (size_t)-1) { const size_t ps = f.peek_start(); if (ps == (size_t)-1 || ps >= stop) { more = false; break; } }
+          if (!(more = f.next())) { gave_up = stop != (size_t)-1; break; }
+          if (b->names.empty() && !f.view) b->reserve((size_t)std::min<int64_t>(BATCH_BASES, (int64_t)f.length() * BATCH_READS) + ((size_t)64 << 20));
+          bases += (int64_t)f.length();
+          b->add(f);
         }
         if (b->names.empty()) { std::lock_guard<std::mutex> lk(reader.m); reader.spare.push_back(std::move(b)); break; }
-        b->seq = seq++; b->file = fi;
-        if (getenv("MM_CLI_TIMING")) std::cerr << "INFO, reader: batch of " << b->names.size() << " reads parsed at +" << std::chrono::duration<double>(std::chrono::steady_clock::now() - pc.t0).count() << " s\n";
-        std::unique_lock<std::mutex> lk(reader.m);
-        reader.cv.wait(lk, [&] { return reader.queue.size() < reader.max_queued; });
-        reader.queue.push_back(std::move(b));
-        reader.cv.notify_all();
+        emit(std::move(b));
+      }
+      return !gave_up;
+    };
+    for (size_t fi = 0; fi < queries.size(); ++fi) {
+      mapped.emplace_back();
+      MappedFile& mf = mapped.back();
+      if (getenv("MM_CLI_NO_MMAP") || !mf.open(queries[fi])) {   // gzip, pipes, ...: the sequential reader
+        mapped.pop_back();
+        SeqFile f(queries[fi]);
+        parse_into(f, (size_t)-1, [&](std::unique_ptr<Batch> b) { enqueue(std::move(b), fi); });
+      } else {
+        // blocks of the mapped file, parsed by several threads, handed on in file order; a block's batches only go out once the
+        // block before it has been seen to end exactly where this one starts
+        const size_t blk = getenv("MM_CLI_BLOCK_BYTES") ? (size_t)std::max(1, atoi(getenv("MM_CLI_BLOCK_BYTES"))) : (size_t)128 << 20;
+        const size_t nb = std::max<size_t>(1, (mf.size + blk - 1) / blk);
+        std::vector<size_t> start(nb + 1, mf.size);
+        start[0] = 0;
+        struct Block { std::vector<std::unique_ptr<Batch>> out; size_t next = 0; bool done = false, empty = false, over = false; };   // next: first record start behind the block's records
+        std::vector<Block> blocks(nb);
+        std::mutex bm; std::condition_variable bcv; size_t next_block = 0, consumed = 0; bool abandon = false;
+        const unsigned P = (unsigned)std::max<size_t>(1, std::min<size_t>({nb, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4)}));
+        auto worker = [&]() {
+          for (;;) {
+            size_t j;
+            {
+              std::unique_lock<std::mutex> lk(bm);
+              bcv.wait(lk, [&] { return abandon || next_block >= nb || next_block < consumed + P + 2; });   // not too far ahead of the consumer
+              if (abandon || next_block >= nb) return;
+              j = next_block++;
+            }
+            if (j > 0) start[j] = mf.sync(j * blk, std::min(mf.size, (j + 1) * blk));   // (only this thread writes start[j]; read after `done`)
+            Block& B = blocks[j];
+            const size_t lim = std::min(mf.size, (j + 1) * blk);
+            if (j == 0 || start[j] < lim) {                        // records that start in [start[j], lim)
+              SeqFile f(mf.data, j == 0 ? 0 : start[j], mf.size);
+              B.over = !parse_into(f, lim, [&](std::unique_ptr<Batch> b) { B.out.push_back(std::move(b)); });
+              B.next = f.peek_start();
+            } else B.empty = true;                                 // no record start was recognised in this block
+            { std::lock_guard<std::mutex> lk(bm); B.done = true; }
+            bcv.notify_all();
+          }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < P; ++t) pool.emplace_back(worker);
+        // `expect`: where the parse stands = the start of the first record not handed on yet.  A block continues the parse iff it
+        // starts exactly there (block 0 starts at the file's first record by construction).
+        size_t expect = 0; bool chain_ok = true, file_over = false;
+        for (size_t j = 0; j < nb && chain_ok && !file_over; ++j) {
+          { std::unique_lock<std::mutex> lk(bm); bcv.wait(lk, [&] { return blocks[j].done; }); }
+          Block& B = blocks[j];
+          if (!B.empty) {
+            if (j > 0 && start[j] != expect) { chain_ok = false; break; }
+            for (auto& b : B.out) enqueue(std::move(b), fi);
+            B.out.clear();
+            if (B.over || B.next == (size_t)-1) { file_over = true; break; }
+            expect = B.next;
+          } else if (expect < std::min(mf.size, (j + 1) * blk)) { chain_ok = false; break; }   // a record starts in this block, but none was recognised
+          { std::lock_guard<std::mutex> lk(bm); consumed = j + 1; } bcv.notify_all();
+        }
+        { std::lock_guard<std::mutex> lk(bm); abandon = true; } bcv.notify_all();
+        for (auto& t : pool) t.join();
+        if (!chain_ok) {                                           // a block did not start where the parse stood: the rest sequentially, from there
+          for (auto& B : blocks) for (auto& b : B.out) reader.recycle(std::move(b));
+          SeqFile f(mf.data, expect, mf.size);
+          parse_into(f, (size_t)-1, [&](std::unique_ptr<Batch> b) { enqueue(std::move(b), fi); });
+        }
       }
       std::lock_guard<std::mutex> lk(reader.m); reader.file_end.push_back(seq); reader.cv.notify_all();
     }
@@ -513,7 +687,7 @@ int map_mode(const Options& o, const std::string& mode) {
   });
   auto upload_batch = [&](mm_ctx* ctx, const Batch& bt) {
     mm_seqset* reads; ck(ctx, mm_seqset_create(ctx, &reads), "seqset");
-    for (size_t r = 0; r < bt.names.size(); ++r) ck(ctx, mm_seqset_add_view(reads, bt.arena + bt.off[r], (int64_t)bt.lens[r]), "add read");
+    for (size_t r = 0; r < bt.names.size(); ++r) ck(ctx, mm_seqset_add_view(reads, bt.seq_of(r), (int64_t)bt.lens[r]), "add read");
     ck(ctx, mm_seqset_upload(reads), "upload reads");
     return reads;
   };

@@ -354,3 +354,50 @@ def test_cli_at_bench_hit_density_matches_oracle(oracle_lib, tmp_path):
     _cmp_table(pa + ".EM.WIMP", pb + ".EM.WIMP", "\t", {4, 5})
     _cmp_table(pa + ".EM.contigCoverage", pb + ".EM.contigCoverage", "\t", {6})
     assert sum(1 for _ in open(pa)) > 300
+
+
+def _rewrite_fastq(src, dst, mode):
+    """the reads of `src` in another layout: 'wrapped' (sequence and qualities over several lines, every third record), 'nasty'
+    (quality lines that start with '@' or '>' or contain '+'), 'fasta' (no qualities, 70 columns)"""
+    import random
+    rng = random.Random(7)
+    recs, lines = [], open(src).read().split("\n")
+    for i in range(0, len(lines) - 3, 4):
+        recs.append((lines[i], lines[i + 1]))
+    with open(dst, "w") as f:
+        for n, (h, s) in enumerate(recs):
+            if mode == "fasta":
+                f.write(">" + h[1:] + "\n" + "\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + "\n")
+                continue
+            q = "".join(rng.choice("@>+IIIIIIIIIIIIIIIII5?") for _ in s) if mode == "nasty" else "I" * len(s)
+            if mode == "nasty" and n % 2 == 0:
+                q = "@" + q[1:]
+            if mode == "wrapped" and n % 3 == 0:
+                cut = [0] + sorted(rng.sample(range(1, len(s)), 3)) + [len(s)]
+                f.write(h + "\n" + "\n".join(s[a:b] for a, b in zip(cut[:-1], cut[1:])) + "\n+\n" + "\n".join(q[a:b] for a, b in zip(cut[:-1], cut[1:])) + "\n")
+            else:
+                f.write(h + "\n" + s + "\n+" + (h[1:] if n % 5 == 0 else "") + "\n" + q + "\n")
+
+
+@pytest.mark.parametrize("mode", ["plain", "wrapped", "nasty", "fasta", "truncated"])
+def test_cli_parallel_block_parser_equals_sequential_reader(tmp_path, mode):
+    """query files are memory mapped and parsed in blocks by several threads; whatever the layout, the records must be those of the
+    sequential kseq-like reader (blocks of 30 kB here, so that hundreds of block borders fall into records of every kind)"""
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=6, genome_len=60_000, seed=7)
+    rd = synth.make_reads(db, str(tmp_path / "reads.fq"), n_reads=300, read_len=2500, seed=3)
+    q = rd["path"]
+    if mode in ("wrapped", "nasty", "fasta"):
+        q = str(tmp_path / f"{mode}.fq"); _rewrite_fastq(rd["path"], q, mode)
+    elif mode == "truncated":                                    # the file ends inside a quality string: kseq stops there (kseq.h:204)
+        q = str(tmp_path / "trunc.fq")
+        data = open(rd["path"], "rb").read()
+        open(q, "wb").write(data[:len(data) * 2 // 3])
+    outs = {}
+    for tag, env in (("seq", {"MM_CLI_NO_MMAP": "1"}), ("one", {}), ("blocks", {"MM_CLI_BLOCK_BYTES": "30000", "MM_CLI_BATCH_READS": "17"})):
+        pre = str(tmp_path / tag)
+        p = subprocess.run([CLI, "mapDirectly", "--all", "-r", db.fasta, "-q", q, "-o", pre], capture_output=True, timeout=600, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr.decode()[-1500:]
+        outs[tag] = (open(pre).read(), open(pre + ".meta").read(), open(pre + ".meta.unmappedReadsLengths").read())
+    assert outs["seq"] == outs["one"] == outs["blocks"]
+    assert len(outs["seq"][0]) > 10_000

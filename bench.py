@@ -354,11 +354,19 @@ def cpu_baseline_and_cli(args, R, k, w):
     with tempfile.TemporaryDirectory() as d:
         t0 = time.time()
         db = synth.write_db_dir(os.path.join(d, "db"), [(int(contig_taxon[ci]), ref.fetch(ci, int(cl[ci]))) for ci in contigs])
-        fq, nb = os.path.join(d, "reads.fq"), 0
-        with open(fq, "wb") as f:
-            for r in pick_reads:
-                s = reads.fetch(r, int(rl[r])); nb += len(s)
-                f.write(f"@r{r}\n".encode() + s + b"\n+\n" + b"I" * len(s) + b"\n")
+        # two FASTQ files: the CPU sample, and every bench read that stems from the slice (or from nowhere) for the CLI's throughput
+        fq, fq_all, n_all, bases_all = os.path.join(d, "reads.fq"), os.path.join(d, "reads_all.fq"), 0, 0
+        in_slice = np.zeros(len(cl) + 1, dtype=bool); in_slice[contigs] = True; in_slice[-1] = True   # (truth -1: random reads)
+        small = set(pick_reads)
+        with open(fq, "wb") as f, open(fq_all, "wb") as fa:
+            for r in range(len(rl)):
+                if not in_slice[int(truth[r])]:
+                    continue
+                s = reads.fetch(r, int(rl[r]))
+                rec = f"@r{r}\n".encode() + s + b"\n+\n" + b"I" * len(s) + b"\n"
+                fa.write(rec); n_all += 1; bases_all += len(s) if len(s) >= 1000 else 0
+                if r in small:
+                    f.write(rec)
         t_files = time.time() - t0
         ref_bp = int(sum(int(cl[ci]) for ci in contigs))
         # ---- oracle: mapDirectly (index build single-threaded apart from the winnowing, excluded) + classify
@@ -388,11 +396,23 @@ def cpu_baseline_and_cli(args, R, k, w):
         subprocess.run([cli, "classify", "--DB", db["dir"], "--mappings", os.path.join(d, "gpu")], capture_output=True, check=True, timeout=900)
         t_cli_cls = time.time() - t0
         same = open(os.path.join(d, "gpu.EM.reads2Taxon")).read() == open(os.path.join(d, "cpu.EM.reads2Taxon")).read()
-        e2e = {"value": bases / max(t_map_all - t_setup + t_cli_cls, 1e-9) / 1e9, "unit": "Gbp/s",
+        small_run = {"map_seconds": t_map_all - t_setup, "classify_seconds": t_cli_cls, "reads": len(pick_reads)}
+        # ... and on every bench read of the slice (fixed costs of two process starts weigh less)
+        t0 = time.time()
+        p = subprocess.run([cli, "mapDirectly", "--all", "-r", db["fasta"], "-q", fq_all, "-o", os.path.join(d, "gpuall"), "-w", str(w)], capture_output=True, check=True, timeout=900, env=env)
+        t_map_all = time.time() - t0
+        for ln in p.stderr.decode().splitlines():
+            if ln.startswith("INFO, lap 3 index build"):
+                t_setup = float(ln.split(" at +")[1].split()[0])
+        t0 = time.time()
+        subprocess.run([cli, "classify", "--DB", db["dir"], "--mappings", os.path.join(d, "gpuall")], capture_output=True, check=True, timeout=900)
+        t_cli_cls = time.time() - t0
+        e2e = {"value": bases_all / max(t_map_all - t_setup + t_cli_cls, 1e-9) / 1e9, "unit": "Gbp/s",
                "what": "metamaps mapDirectly (reads FASTQ -> PREFIX, .meta) + metamaps classify (-> .EM.*), wall clock of the two processes minus "
-                       "context + reference parse + index build; same files as cpu_baseline",
-               "map_seconds": t_map_all - t_setup, "setup_seconds": t_setup, "classify_seconds": t_cli_cls, "mapping_only_value": bases / max(t_map_all - t_setup, 1e-9) / 1e9,
-               "reads2taxon_identical_to_oracle": same, "sample_files_written_s": round(t_files, 2)}
+                       "context + reference parse + index build, on every bench read that stems from the cpu_baseline's reference slice",
+               "reads": n_all, "bases": bases_all, "map_seconds": t_map_all - t_setup, "setup_seconds": t_setup, "classify_seconds": t_cli_cls,
+               "mapping_only_value": bases_all / max(t_map_all - t_setup, 1e-9) / 1e9,
+               "on_the_cpu_sample": small_run, "reads2taxon_identical_to_oracle": same, "sample_files_written_s": round(t_files, 2)}
     return cpu, e2e
 
 

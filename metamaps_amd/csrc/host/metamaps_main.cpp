@@ -47,6 +47,8 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <unordered_map>
+#include <cerrno>
 #include <thread>
 #include <mutex>
 #include <memory>
@@ -1108,14 +1110,47 @@ bool write_unknown_species(const std::string& fn, const std::string& db, const T
 
 int classify_one(const std::vector<Dev>& devs, bool use_comm, const std::string& mapped, const std::string& db, size_t minReadsU) {   // meta::doEM, fEM.h:466-803
   PhaseClock pc;
-  // mappings grouped by read (fEM.h:1171-1214)
-  std::vector<std::vector<std::string>> groups;
-  { std::ifstream s(mapped); if (!s.is_open()) die("Cannot open mappings file " + mapped);
-    std::string ln, cur; std::vector<std::string> g;
-    while (std::getline(s, ln)) { if (ln.empty()) continue; std::string id = ln.substr(0, ln.find(' ')); if (id != cur) { if (!g.empty()) groups.push_back(g); cur = id; g.clear(); } g.push_back(ln); }
-    if (!g.empty()) groups.push_back(g); }
+  // The mappings file once through: every line is tokenised where it lies (the reference splits every line again in every EM round,
+  // fEM.h:1171-1214, :234-373), lines of one read are consecutive (mapWrap.h:128-149), contig IDs are interned.
+  std::string text;
+  { std::ifstream s(mapped, std::ios::binary); if (!s.is_open()) die("Cannot open mappings file " + mapped);
+    s.seekg(0, std::ios::end); const std::streamoff n = s.tellg(); s.seekg(0); text.resize((size_t)std::max<std::streamoff>(n, 0)); if (n > 0) s.read(&text[0], n); }
+  struct MapLine { size_t beg, last_space, end; int contig; long long len; size_t start, stop; double ident, mapq; };   // [beg, end): the line; last_space: the blank before field 14
+  std::vector<MapLine> lines; std::vector<int64_t> off{0};       // read r owns lines [off[r], off[r+1])
+  std::vector<std::string> contig_id; std::unordered_map<std::string, int> contig_index;
+  {
+    const char* const T0 = text.c_str();
+    size_t cur_beg = 0, cur_len = (size_t)-1;                    // the current read's ID, as a span of `text`
+    for (size_t p = 0; p < text.size();) {
+      const char* nl = (const char*)memchr(T0 + p, '\n', text.size() - p);
+      const size_t e = nl ? (size_t)(nl - T0) : text.size();
+      if (e == p) { p = e + 1; continue; }                       // empty line
+      size_t fb[16], fe[16]; int nf = 0;                         // fields (single blanks, util.h:80)
+      for (size_t q = p; nf < 16;) { const char* sp = (const char*)memchr(T0 + q, ' ', e - q); fb[nf] = q; fe[nf] = sp ? (size_t)(sp - T0) : e; ++nf; if (!sp) break; q = fe[nf - 1] + 1; }
+      if (nf < 6) die("File " + mapped + " has weird format - is this a mappings file generated by MetaMap?");
+      if (nf < 14) die("File " + mapped + " has lines with fewer than 14 fields - is this a mappings file generated by MetaMap?");
+      if (fe[0] - fb[0] != cur_len || memcmp(T0 + fb[0], T0 + cur_beg, cur_len) != 0) { if (!lines.empty()) off.push_back((int64_t)lines.size()); cur_beg = fb[0]; cur_len = fe[0] - fb[0]; }
+      MapLine L{};
+      L.beg = p; L.end = e; L.last_space = fb[13] - 1;
+      std::string cid(T0 + fb[5], fe[5] - fb[5]);
+      auto it = contig_index.find(cid);
+      if (it == contig_index.end()) { it = contig_index.emplace(cid, (int)contig_id.size()).first; contig_id.push_back(cid); }
+      L.contig = it->second;
+      L.len = std::stoi(std::string(T0 + fb[1], fe[1] - fb[1]));
+      L.start = std::stoull(std::string(T0 + fb[7], fe[7] - fb[7])); L.stop = std::stoull(std::string(T0 + fb[8], fe[8] - fb[8]));
+      L.ident = strtod(T0 + fb[9], nullptr) / 100.0;
+      { errno = 0; char* endp = nullptr; L.mapq = strtod(T0 + fb[13], &endp);   // std::stod: out of range (also a denormal) throws; the reference then takes 0 for "…e-…" (fEM.h:269-275)
+        if (errno == ERANGE) { if (std::string(T0 + fb[13], fe[13] - fb[13]).find("e-") != std::string::npos) L.mapq = 0; else die("mapping quality out of range in " + mapped); }
+        if (endp == T0 + fb[13]) die("File " + mapped + " has a mapping quality that is not a number"); }
+      lines.push_back(L);
+      p = e + 1;
+    }
+    if (!lines.empty()) off.push_back((int64_t)lines.size());
+  }
+  const size_t NRD = off.size() - 1;
+  std::vector<std::string> contig_taxon_id(contig_id.size());
   std::set<std::string> taxaSet;
-  for (auto& g : groups) for (auto& ln : g) { auto f = split(ln, " "); if (f.size() < 6) die("File " + mapped + " has weird format - is this a mappings file generated by MetaMap?"); taxaSet.insert(extract_taxon(f[5])); }
+  for (size_t c = 0; c < contig_id.size(); ++c) { contig_taxon_id[c] = extract_taxon(contig_id[c]); taxaSet.insert(contig_taxon_id[c]); }
   if (taxaSet.empty()) die("No relevant taxon IDs found in your mappings file - is it possible that none of your reads are mapped?");
   std::map<std::string, size_t> st;
   { std::ifstream s(mapped + ".meta"); if (!s.is_open()) die("The file " + mapped + ".meta is not present or could not be opened - this file is generated automatically as part of the mapping process, so please check whether the mapping process finished successfully.");
@@ -1129,28 +1164,48 @@ int classify_one(const std::vector<Dev>& devs, bool use_comm, const std::string&
   pc.lap("c2 taxonomy");
   std::vector<std::string> taxa(taxaSet.begin(), taxaSet.end());
   std::map<std::string, int> tindex; for (size_t i = 0; i < taxa.size(); ++i) tindex[taxa[i]] = (int)i;
-  // per mapping: taxon, quality, 1/nLoc (getMappingLocations, fEM.h:234-353)
-  std::vector<int64_t> off{0}; std::vector<int32_t> taxon; std::vector<double> mapq, inv, ident; std::vector<std::string> contigOf; std::vector<size_t> rlen, mstart, mstop;
-  for (auto& g : groups) {
-    std::vector<std::vector<std::string>> F; std::set<std::string> sawC, sawT;
-    for (auto& ln : g) { F.push_back(split(ln, " ")); sawC.insert(F.back().at(5)); }
-    const long long L = std::stoi(F[0].at(1));
-    std::map<std::string, size_t> nLoc;
-    for (auto& f : F) { std::string t = extract_taxon(f[5]); if (!TI.count(t)) die("Unknown taxonID '" + t + "'; please check that your mappings file was mapped against the database now specified."); sawT.insert(t); }
-    for (auto& t : sawT) { size_t n = 0; for (auto& c : TI.at(t)) { if ((long long)c.second >= L) n += c.second - L + 1; else if (sawC.count(c.first)) ++n; } nLoc[t] = n; }
-    for (auto& f : F) {
-      std::string t = extract_taxon(f[5]); double q;
-      try { q = std::stod(f.at(13)); } catch (const std::out_of_range&) { if (f.at(13).find("e-") != std::string::npos) q = 0; else throw; }
-      taxon.push_back(tindex.at(t)); mapq.push_back(q); inv.push_back(1 / (double)nLoc.at(t)); ident.push_back(std::stod(f.at(9)) / 100.0); contigOf.push_back(f[5]); rlen.push_back((size_t)L); mstart.push_back(std::stoull(f.at(7))); mstop.push_back(std::stoull(f.at(8)));
+  // per mapping: taxon, quality, 1/nLoc (getMappingLocations, fEM.h:234-353).  nLoc(read, taxon) = sum over the taxon's contigs of
+  // (len - L + 1) if len >= L, else 1 if the read has a mapping on that contig (:325-348): sorted lengths + suffix sums per taxon
+  std::vector<int> contig_tx(contig_id.size()); std::vector<long long> contig_len_ti(contig_id.size(), -1);   // taxon index; length per taxonInfo (-1: not listed)
+  struct TaxLens { std::vector<long long> len, suffix; };
+  std::vector<TaxLens> tl(taxa.size());
+  for (size_t t = 0; t < taxa.size(); ++t) {
+    auto it = TI.find(taxa[t]);
+    if (it == TI.end()) die("Unknown taxonID '" + taxa[t] + "'; please check that your mappings file was mapped against the database now specified.");
+    for (auto& c : it->second) tl[t].len.push_back((long long)c.second);
+    std::sort(tl[t].len.begin(), tl[t].len.end());
+    tl[t].suffix.assign(tl[t].len.size() + 1, 0);
+    for (size_t i = tl[t].len.size(); i-- > 0;) tl[t].suffix[i] = tl[t].suffix[i + 1] + tl[t].len[i];
+  }
+  for (size_t c = 0; c < contig_id.size(); ++c) {
+    contig_tx[c] = tindex.at(contig_taxon_id[c]);
+    auto& m = TI.at(contig_taxon_id[c]); auto it = m.find(contig_id[c]);
+    if (it != m.end()) contig_len_ti[c] = (long long)it->second;
+  }
+  std::vector<int32_t> taxon(lines.size()); std::vector<double> mapq(lines.size()), inv(lines.size());
+  {
+    std::vector<int> seen_c;                                     // distinct contigs of the current read
+    for (size_t r = 0; r < NRD; ++r) {
+      const size_t a0 = (size_t)off[r], b0 = (size_t)off[r + 1];
+      const long long L = lines[a0].len;
+      seen_c.clear();
+      for (size_t i = a0; i < b0; ++i) if (std::find(seen_c.begin(), seen_c.end(), lines[i].contig) == seen_c.end()) seen_c.push_back(lines[i].contig);
+      for (size_t i = a0; i < b0; ++i) {
+        const int t = contig_tx[(size_t)lines[i].contig];
+        const TaxLens& X = tl[(size_t)t];
+        const size_t k0 = (size_t)(std::lower_bound(X.len.begin(), X.len.end(), L) - X.len.begin());
+        long long n = X.suffix[k0] - (long long)(X.len.size() - k0) * (L - 1);
+        for (int c : seen_c) if (contig_tx[(size_t)c] == t && contig_len_ti[(size_t)c] >= 0 && contig_len_ti[(size_t)c] < L) ++n;
+        taxon[i] = t; mapq[i] = lines[i].mapq; inv[i] = 1 / (double)(size_t)n;
+      }
     }
-    off.push_back((int64_t)taxon.size());
   }
   pc.lap("c3 per-mapping fields");
   // The EM loop (fEM.h:501-661).  With several GPUs the reads are sharded contiguously (the reference shards them over OpenMP
   // threads, :1229); every rank computes the per-taxon posterior sums and the log-likelihood of its reads, one RCCL all-reduce
   // per iteration (mm_em_iterate_allreduce) replaces the merge of the per-thread sums (:583-600), and every rank normalises and
   // evaluates the stop rule on identical values.
-  const size_t G = devs.size(), NT = taxa.size(), NR = groups.size();
+  const size_t G = devs.size(), NT = taxa.size(), NR = NRD;
   std::vector<double> f(NT, 1 / (double)NT);
   std::vector<double> post(taxon.size()); std::vector<int64_t> best(NR);
   char comm_id[MM_COMM_ID_BYTES];
@@ -1187,23 +1242,35 @@ int classify_one(const std::vector<Dev>& devs, bool use_comm, const std::string&
   ContigCoverage coverage;
   std::map<std::string, std::vector<double>> identsPerTaxon;     // :691, :718
   long long maxReadLen = -1;                                     // :692, :719-722
-  for (size_t r = 0; r < groups.size(); ++r) {                   // fEM.h:684-779
-    std::string rid;
-    for (size_t j = 0; j < groups[r].size(); ++j) {
-      auto fld = split(groups[r][j], " "); rid = fld.at(0);
-      fld.at(13) = std::to_string(post[(size_t)off[r] + j]);     // :705
-      for (size_t q = 0; q < fld.size(); ++q) emf << (q ? " " : "") << fld[q];
-      emf << "\n";
+  {
+    std::string emtxt; emtxt.reserve(text.size() + lines.size() * 8);
+    std::string r2txt, krtxt, litxt;
+    char num[64];
+    std::vector<std::string> tax_nonx(taxa.size());              // getFirstNonXNode per taxon (taxonomy.h:51-74), once
+    for (size_t t = 0; t < taxa.size(); ++t) tax_nonx[t] = T.first_non_x(taxa[t]);
+    for (size_t r = 0; r < NRD; ++r) {                           // fEM.h:684-779
+      for (size_t i = (size_t)off[r]; i < (size_t)off[r + 1]; ++i) {   // the line with field 14 replaced by std::to_string(posterior) (:705)
+        emtxt.append(text, lines[i].beg, lines[i].last_space + 1 - lines[i].beg);
+        emtxt += std::to_string(post[i]);
+        emtxt += '\n';
+      }
+      const size_t b = (size_t)best[r];
+      const MapLine& B = lines[b];
+      const std::string& tx = taxa[(size_t)taxon[b]];
+      const std::string& cg = contig_id[(size_t)B.contig];
+      const size_t rid_end = (size_t)((const char*)memchr(text.c_str() + B.beg, ' ', B.end - B.beg) - text.c_str());
+      litxt += "EqualCoverageUnit\t"; litxt += cg; litxt += '\t';
+      snprintf(num, sizeof num, "%zu\t%g\t%lld\n", r, B.ident, B.len); litxt += num;                   // :711
+      r2txt.append(text, B.beg, rid_end - B.beg); r2txt += '\t'; r2txt += tx; r2txt += '\n';
+      krtxt.append(text, B.beg, rid_end - B.beg); krtxt += '\t'; krtxt += tax_nonx[(size_t)taxon[b]];
+      snprintf(num, sizeof num, "\t%g\n", post[b]); krtxt += num;
+      readsPer[tx]++;
+      identsPerTaxon[tx].push_back(B.ident);
+      maxReadLen = std::max(maxReadLen, B.len);
+      if (contig_len_ti[(size_t)B.contig] < 0) die("contig " + cg + " is not listed for taxon " + tx + " in " + db + "/taxonInfo.txt");
+      coverage.add(tx, cg, (size_t)contig_len_ti[(size_t)B.contig], B.start, B.stop);
     }
-    const size_t b = (size_t)best[r];
-    const std::string& tx = taxa[(size_t)taxon[b]];
-    li << "EqualCoverageUnit\t" << contigOf[b] << "\t" << r << "\t" << ident[b] << "\t" << rlen[b] << "\n";   // :711
-    r2t << rid << "\t" << tx << "\n";
-    kr << rid << "\t" << T.first_non_x(tx) << "\t" << post[b] << "\n";
-    readsPer[tx]++;
-    identsPerTaxon[tx].push_back(ident[b]);
-    maxReadLen = std::max(maxReadLen, (long long)rlen[b]);
-    coverage.add(tx, contigOf[b], TI.at(tx).at(contigOf[b]), mstart[b], mstop[b]);
+    emf << emtxt; r2t << r2txt; kr << krtxt; li << litxt;
   }
   { std::ifstream s(mapped + ".meta.unmappedReadsLengths"); std::string ln;
     while (std::getline(s, ln)) { if (ln.empty()) continue; auto fl = split(ln, "\t"); r2t << fl.at(1) << "\t" << 0 << "\n"; kr << fl.at(1) << "\t" << 0 << "\t" << 0 << "\n"; } }

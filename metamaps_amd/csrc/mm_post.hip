@@ -322,18 +322,21 @@ __global__ void em_estep_loop_kernel(const int64_t* __restrict__ read_off, const
   for (int64_t i = lo; i < hi; ++i) post[i] = post[i] / sum;                                                      // :361
   ll_read[r] = hi > lo ? log(sum) : 0.0;                                                                          // fEM.h:578
 }
-// per-taxon sums for the taxa that have mappings on this rank (same fixed-shape sum as em_taxon_sum_kernel); 4 taxa per block
+// per-taxon sums for the taxa that have mappings on this rank: one workgroup per taxon (an abundant genome owns tens of thousands of
+// entries; one wavefront walking them is what an iteration then waits for).  Fixed shape: 256 strided partial sums, butterfly per
+// wavefront, the four wavefront sums added in order — it depends on the segment length only, so exactly tied taxa stay tied.
 __global__ void __launch_bounds__(256) em_taxon_sum_present_kernel(const double* __restrict__ post, const int64_t* __restrict__ tstart, const int64_t* __restrict__ perm,
                                                                    const int32_t* __restrict__ present, int n_present, double* __restrict__ local_partial,
                                                                    const long long* __restrict__ ctrl) {
   if (ctrl[1]) return;
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (k >= n_present) return;
-  const int t = present[k];
+  __shared__ double ws[4];
+  const int t = present[blockIdx.x];
   double acc = 0;
-  for (int64_t j = tstart[t] + lane; j < tstart[t + 1]; j += 64) acc += post[perm[j]];
+  for (int64_t j = tstart[t] + threadIdx.x; j < tstart[t + 1]; j += 256) acc += post[perm[j]];
   for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
-  if (lane == 0) local_partial[t] = acc;
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) local_partial[t] = ((ws[0] + ws[1]) + ws[2]) + ws[3];
 }
 __global__ void __launch_bounds__(256) em_ll_sum_kernel(const double* __restrict__ ll_read, int64_t n, double* __restrict__ block_sum, const long long* __restrict__ ctrl) {
   if (ctrl[1]) return;
@@ -406,7 +409,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
         MM_KERNEL_CHECK();
       }
       if (E->n_present > 0) {
-        em_taxon_sum_present_kernel<<<dim3((unsigned)ceil_div(E->n_present, 4)), dim3(256), 0, st>>>(E->post.p, E->tstart.p, E->perm.p, E->present.p, E->n_present,
+        em_taxon_sum_present_kernel<<<dim3((unsigned)E->n_present), dim3(256), 0, st>>>(E->post.p, E->tstart.p, E->perm.p, E->present.p, E->n_present,
                                                                                                E->local_partial.p, E->ctrl.p);
         MM_KERNEL_CHECK();
       }

@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--pacbio", action="store_true", help="PacBio-like errors (2/8/2 percent del/ins/sub) instead of ONT-like (5/3/4)")
     ap.add_argument("--scale", type=float, default=float(os.environ.get("MM_BENCH_SCALE", 1.0)), help="scales the number of genomes of the reference (quick checks)")
     ap.add_argument("--window", type=int, default=8, help="w the CLI derives for a 26.76 GB DB.fa at default flags")
-    ap.add_argument("--workers", type=int, default=int(os.environ.get("MM_BENCH_WORKERS", 2)),
+    ap.add_argument("--workers", type=int, default=int(os.environ.get("MM_BENCH_WORKERS", 3)),
                     help="host threads / contexts per GPU that take the steps in turn: while one runs the EM iterations, result download and host "
                          "bookkeeping of its step, the next step's mapping kernels run (the mapping sections themselves are serialised, so that "
                          "kernel durations — the roofline — are those of kernels that own the GPU)")
@@ -99,6 +99,7 @@ def main():
 
     from metamaps_amd import capi
     import threading
+    sys.setswitchinterval(1e-4)                                   # worker threads hand the GPU over at lock releases: do not let one sit on the interpreter
     W = max(1, args.workers)
     ctxs = [capi.Context(local) for _ in range(W)]               # one context (stream + allocator + communicator) per worker thread
     ctx = ctxs[0]

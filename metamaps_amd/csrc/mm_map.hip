@@ -639,6 +639,25 @@ __global__ void __launch_bounds__(256) sort_hits_kernel(uint64_t* __restrict__ h
   for (int i = threadIdx.x; i < n; i += 256) hits[o + i] = a[i];
 }
 
+// The same with an LDS radix sort over the significant key bits (contig in the high word, position and strand below it):
+// fewer instructions than the bitonic network and no padding to a power of two.  256 * IPT >= hits of the longest read of the class.
+template <int IPT>
+__global__ void __launch_bounds__(256) sort_hits_radix_kernel(uint64_t* __restrict__ hits, const uint64_t* __restrict__ read_hit_off,
+                                                              const int32_t* __restrict__ read_list, int end_bit) {
+  using Sort = rocprim::block_radix_sort<uint64_t, 256, IPT>;
+  extern __shared__ __align__(16) unsigned char sort_dyn[];
+  typename Sort::storage_type& tmp = *reinterpret_cast<typename Sort::storage_type*>(sort_dyn);
+  const int r = read_list[blockIdx.x];
+  const uint64_t o = read_hit_off[r];
+  const int n = (int)(read_hit_off[r + 1] - o);
+  uint64_t key[IPT];
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) { const int idx = threadIdx.x * IPT + i; key[i] = idx < n ? hits[o + idx] : ~0ull; }
+  Sort().sort(key, tmp, 0, end_bit);                             // blocked: thread t holds sorted positions t*IPT ..  (padding keys sort last)
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) { const int idx = threadIdx.x * IPT + i; if (idx < n) hits[o + idx] = key[i]; }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K4b  L1 candidate scan, one thread per read, the reference's loop verbatim in behaviour
 //      (computeL1CandidateRegions, computeMap.hpp:346-386).  WRITE=false counts, WRITE=true writes.
@@ -1107,6 +1126,48 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     const int segsort_from = std::min(ss_env ? atoi(ss_env) : 4096, LDS_SORT_MAX);
     const bool seg_ok = total_hits < (int64_t)0xffffffffll && !getenv("MM_HITS_BITONIC");
     std::vector<int32_t> seg_reads;                               // reads of every class handled by the segmented sort: one call for all
+    // up to 4096 hits per read: LDS radix sort, the reads grouped by the elements per thread they need
+    int key_bits = 32; while (key_bits < 64 && ((int64_t)1 << (key_bits - 32)) < I->n_contigs) ++key_bits;
+    const bool use_radix = !getenv("MM_HITS_BITONIC");
+    if (use_radix) {
+      static const int ipts[] = {1, 2, 3, 4, 6, 8, 12, 16};
+      std::map<int, std::vector<int32_t>> by_ipt;
+      for (int64_t r = 0; r < n; ++r) {
+        const int64_t c = hc[(size_t)r];
+        if (c <= 1 || c > 4096) continue;
+        const int need = (int)((c + 255) / 256); int ip = 16; for (int v : ipts) if (v >= need) { ip = v; break; }
+        by_ipt[ip].push_back((int32_t)r);
+      }
+      std::vector<int32_t> ordered; std::vector<std::pair<int, size_t>> runs;
+      for (auto& kv : by_ipt) { runs.emplace_back(kv.first, kv.second.size()); ordered.insert(ordered.end(), kv.second.begin(), kv.second.end()); }
+      DBuf<int32_t> list(std::max<size_t>(ordered.size(), 1));
+      list.upload(ordered.data(), ordered.size(), st);
+      size_t at = 0;
+      for (auto& run : runs) {
+        const int32_t* lp = list.p + at;
+        auto launch = [&](auto tag) {
+          constexpr int IPT = decltype(tag)::value;
+          using SortT = rocprim::block_radix_sort<uint64_t, 256, IPT>;
+          const size_t lds = sizeof(typename SortT::storage_type) + 16;
+          if (lds > 48 * 1024) MM_HIP(hipFuncSetAttribute((const void*)sort_hits_radix_kernel<IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          sort_hits_radix_kernel<IPT><<<dim3((unsigned)run.second), dim3(256), lds, st>>>(M->hits.p, M->read_hit_off.p, lp, key_bits);
+        };
+        switch (run.first) {
+          case 1: launch(std::integral_constant<int, 1>{}); break;
+          case 2: launch(std::integral_constant<int, 2>{}); break;
+          case 3: launch(std::integral_constant<int, 3>{}); break;
+          case 4: launch(std::integral_constant<int, 4>{}); break;
+          case 6: launch(std::integral_constant<int, 6>{}); break;
+          case 8: launch(std::integral_constant<int, 8>{}); break;
+          case 12: launch(std::integral_constant<int, 12>{}); break;
+          default: launch(std::integral_constant<int, 16>{}); break;
+        }
+        MM_KERNEL_CHECK();
+        at += run.second;
+      }
+      MM_HIP(hipStreamSynchronize(st));                          // `ordered` is the source of the async upload
+      for (auto& c : hc) if (c <= 4096) c = 0;                   // done: the loops below only see the longer lists
+    }
     for (auto& cls : make_classes(hc, 256)) {
       if (cls.npow2 > segsort_from && seg_ok) { seg_reads.insert(seg_reads.end(), cls.reads.begin(), cls.reads.end()); continue; }
       DBuf<int32_t> list(cls.reads.size());
@@ -1261,7 +1322,8 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         if (getenv("MM_L2_NO_CODES")) return nullptr;              // cross-check switch
         return ctx->l2_codes_at_least(n_waves * (size_t)(64 * 64 * nwq) * (nwq == 2 ? sizeof(uint16_t) : sizeof(uint32_t)));
       };
-      std::vector<int32_t> gA0, gAn, gB0, gBn, gD0, gDn, listC;
+      const bool no_small_groups = getenv("MM_L2_NO_SMALL_GROUPS") != nullptr;   // cross-check / timing switch
+      std::vector<int32_t> gA0, gAn, gB0, gBn, gD0, gDn, listC, gS0, gSn;   // gS: groups of one or two candidates of the 10 kb class (two-wave workgroups)
       int smA = 0, smB = 0, smC = 0, smD = 0;
       for (int64_t r = 0; r < n; ++r) {
         const uint64_t c_lo = M->h_cand_off[(size_t)r], c_hi = M->h_cand_off[(size_t)r + 1];
@@ -1270,7 +1332,13 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         if (sr <= 7168) {
           auto& g0 = sr <= 3072 ? gA0 : gB0; auto& gn = sr <= 3072 ? gAn : gBn;
           (sr <= 3072 ? smA : smB) = std::max(sr <= 3072 ? smA : smB, sr);
-          for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 4) { g0.push_back((int32_t)c0); gn.push_back((int32_t)std::min<uint64_t>(4, c_hi - c0)); }
+          for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 4) {
+            const int32_t cnt = (int32_t)std::min<uint64_t>(4, c_hi - c0);
+            // a workgroup holds the read's sketch once: four-wave workgroups with one or two candidates leave half of their waves'
+            // LDS share idle (species of 1-12 strains: every candidate count occurs), those go to two-wave workgroups
+            if (sr <= 3072 && cnt <= 2 && !no_small_groups) { gS0.push_back((int32_t)c0); gSn.push_back(cnt); }
+            else { g0.push_back((int32_t)c0); gn.push_back(cnt); }
+          }
         } else if (sr <= 16384) {
           smD = std::max(smD, sr);
           for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 4) { gD0.push_back((int32_t)c0); gDn.push_back((int32_t)std::min<uint64_t>(4, c_hi - c0)); }
@@ -1286,6 +1354,15 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 2>, lds);
         l2_kernel<true, uint8_t, 4, 2><<<dim3((unsigned)gA0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
             M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gA0.size() * 4, 2), masks_for(gA0.size() * 4, 2));
+        MM_KERNEL_CHECK();
+      }
+      DBuf<int32_t> d_gS0(gS0.size()), d_gSn(gSn.size());
+      if (!gS0.empty()) {
+        d_gS0.upload(gS0.data(), gS0.size(), st); d_gSn.upload(gSn.data(), gSn.size(), st);
+        const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 2, 2);
+        set_lds((const void*)l2_kernel<true, uint8_t, 2, 2>, lds);
+        l2_kernel<true, uint8_t, 2, 2><<<dim3((unsigned)gS0.size()), dim3(128), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gS0.p, d_gSn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gS0.size() * 2, 2), masks_for(gS0.size() * 2, 2));
         MM_KERNEL_CHECK();
       }
       if (!gB0.empty()) {

@@ -14,6 +14,7 @@
 #include <rocprim/rocprim.hpp>
 #include "mm_l2_core.hpp"
 #include "mm_l2.hpp"
+#include "mm_l2_dense.hpp"
 #include <cstdlib>
 #include <atomic>
 #include <thread>
@@ -1284,9 +1285,46 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     uint8_t* const amb_used_p = lazy_reads.empty() ? nullptr : amb_used.p;
     if (amb_finish) { amb_finish(); amb_finish = nullptr; }        // strands of ambiguous sketches: needed by the vote only
     const size_t t_l2 = T.begin(&M->stats.ms_l2);
+    // Long reads: the window state in global memory, one wave per candidate (mm_l2_dense.hpp).  `list`: candidates, those of a read
+    // consecutive; smax_l: largest sketch among them.
+    auto run_dense = [&](const std::vector<int32_t>& list, int smax_l) {
+      if (list.empty()) return;
+      const size_t nl = list.size();
+      DBuf<int32_t> d_list(nl); d_list.upload(list.data(), nl, st);
+      DBuf<L2Range> d_rng(nl);
+      l2_range_kernel<<<dim3((unsigned)ceil_div((int64_t)nl, 4)), dim3(256), 0, st>>>(IV, M->cand.p, M->cand_read.p, M->d_read_len.p, d_list.p, (int)nl, d_rng.p);
+      MM_KERNEL_CHECK();
+      std::vector<L2Range> rng = d_rng.to_host(st);               // (also keeps `list` alive until its upload is done)
+      std::vector<uint64_t> coff(nl + 1, 0);
+      for (size_t i = 0; i < nl; ++i) coff[i + 1] = coff[i] + (uint64_t)std::max(rng[i].m, 0);
+      std::vector<int32_t> cr = M->cand_read.to_host(st, (size_t)ncand);
+      std::vector<int32_t> gfirst;                               // one classification workgroup per read
+      for (size_t i = 0; i < nl; ++i) if (i == 0 || cr[(size_t)list[i]] != cr[(size_t)list[i - 1]]) gfirst.push_back((int32_t)i);
+      gfirst.push_back((int32_t)nl);
+      DBuf<uint64_t> d_coff(nl + 1); d_coff.upload(coff.data(), nl + 1, st);
+      DBuf<int32_t> d_gf(gfirst.size()); d_gf.upload(gfirst.data(), gfirst.size(), st);
+      DBuf<uint32_t> codes((size_t)std::max<uint64_t>(coff[nl], 1));
+      const int q_in_lds = smax_l <= LD_Q_LDS_MAX ? 1 : 0;
+      const size_t lds = ((size_t)((LD_TSIZE + 3) & ~3) + (q_in_lds ? (size_t)smax_l + 4 : 0)) * 4;
+      set_lds((const void*)l2_codes_kernel, lds);
+      l2_codes_kernel<<<dim3((unsigned)(gfirst.size() - 1)), dim3(256), lds, st>>>(IV, M->cand_read.p, M->sk_hash.p, M->mz.off.p, M->sk_n.p, d_list.p, d_gf.p,
+                                                                                  d_rng.p, d_coff.p, codes.p, q_in_lds);
+      MM_KERNEL_CHECK();
+      const unsigned slots = (unsigned)std::min<size_t>(nl, (size_t)ctx->cus * 12);
+      DBuf<uint32_t> scratch((size_t)slots * l2_dense_slot_words(smax_l));
+      DBuf<unsigned int> next(1); next.zero(st);
+      l2_dense_kernel<<<dim3(slots), dim3(64), 0, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p,
+                                                      P.k, P.w, smax_l, M->l2.p, d_list.p, (int)nl, d_rng.p, d_coff.p, codes.p, scratch.p, next.p);
+      MM_KERNEL_CHECK();
+      MM_HIP(hipStreamSynchronize(st));                          // host vectors above are upload sources; the buffers die with this scope
+    };
+    // sketches from this size on take the dense path (MM_L2_DENSE_FROM: experiments; MM_L2_NO_DENSE=1: the LDS classes / literal automaton)
+    const bool use_dense = !getenv("MM_L2_NO_DENSE");
+    const int dense_from = getenv("MM_L2_DENSE_FROM") ? atoi(getenv("MM_L2_DENSE_FROM")) : 16385;
     DBuf<int32_t> d_listG(listG.size());
     DBuf<uint32_t> giant_scratch;
-    if (!listG.empty()) {
+    if (!listG.empty() && use_dense) run_dense(listG, smG);
+    else if (!listG.empty()) {
       d_listG.upload(listG.data(), listG.size(), st);
       const unsigned slots = (unsigned)std::min<size_t>(listG.size(), (size_t)ctx->cus * 8);
       giant_scratch.alloc((size_t)slots * l2_giant_slot_words(smG));
@@ -1325,10 +1363,16 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       const bool no_small_groups = getenv("MM_L2_NO_SMALL_GROUPS") != nullptr;   // cross-check / timing switch
       std::vector<int32_t> gA0, gAn, gB0, gBn, gD0, gDn, listC, gS0, gSn;   // gS: groups of one or two candidates of the 10 kb class (two-wave workgroups)
       int smA = 0, smB = 0, smC = 0, smD = 0;
+      std::vector<int32_t> listL; int smL = 0;                    // long reads below the giant class that take the dense path
       for (int64_t r = 0; r < n; ++r) {
         const uint64_t c_lo = M->h_cand_off[(size_t)r], c_hi = M->h_cand_off[(size_t)r + 1];
         if (c_lo == c_hi) continue;
         const int sr = M->h_sk_n[(size_t)r];
+        if (use_dense && sr >= dense_from && sr < L2_SKETCH_LIMIT && M->read_len[(size_t)r] >= P.w + P.k + 1) {
+          smL = std::max(smL, sr);
+          for (uint64_t c0 = c_lo; c0 < c_hi; ++c0) listL.push_back((int32_t)c0);
+          continue;
+        }
         if (sr <= 7168) {
           auto& g0 = sr <= 3072 ? gA0 : gB0; auto& gn = sr <= 3072 ? gAn : gBn;
           (sr <= 3072 ? smA : smB) = std::max(sr <= 3072 ? smA : smB, sr);
@@ -1347,6 +1391,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           for (uint64_t c0 = c_lo; c0 < c_hi; ++c0) listC.push_back((int32_t)c0);
         }                                                        // (larger: listG above)
       }
+      run_dense(listL, smL);
       DBuf<int32_t> d_gA0(gA0.size()), d_gAn(gAn.size()), d_gB0(gB0.size()), d_gBn(gBn.size()), d_listC(listC.size());
       if (!gA0.empty()) {
         d_gA0.upload(gA0.data(), gA0.size(), st); d_gAn.upload(gAn.data(), gAn.size(), st);

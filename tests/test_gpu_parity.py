@@ -554,3 +554,27 @@ def test_community_generator_and_parity_on_it(ctx, oracle_lib, tmp_path):
         n_map += len(m) > 0
     assert n_map > 250
     oi.close(); M.close(); idx.close(); reads.close(); ref.close()
+
+
+def test_l2_dense_path_equals_lds_classes(ctx, monkeypatch):
+    """The long-read K5 path (window state in global memory, every window evaluated in the reference's order: mm_l2_dense.hpp) forced
+    onto reads of every length (MM_L2_DENSE_FROM=1) against the LDS classes with their exact skip-ahead — which the tests above pin to
+    the oracle — on a workload with thousands of candidates, zone shifts and duplicated hashes inside windows."""
+    ref, genome = ctx.synth_community(seed=11, n_genomes=60, n_species=15, n_genera=5, median_len=300_000.0, sigma_len=0.5, min_len=20_000, max_len=900_000,
+                                      strain_div_min=0.001, strain_div_max=0.05, genus_div_min=0.15, genus_div_max=0.25, strain_indel_events=6,
+                                      human_contigs=2, human_bases=3_000_000, repeat_fraction=0.45, n_fraction=0.01, n_repeat_families=30, total_bases_target=0)
+    reads, truth = ctx.synth_reads(ref, seed=9, n_reads=2500, read_len=12000, read_len_min=1500, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=62)
+    idx = ctx.index(ref, 16, 8)
+    res = {}
+    for mode in ("lds", "dense"):
+        if mode == "dense":
+            monkeypatch.setenv("MM_L2_DENSE_FROM", "1")
+        M = ctx.map_batch(idx, reads, 16, 8)
+        off, rec = M.fetch()
+        res[mode] = (off.copy(), rec.copy(), M.stats())
+        M.close()
+    monkeypatch.delenv("MM_L2_DENSE_FROM")
+    assert np.array_equal(res["lds"][0], res["dense"][0]) and np.array_equal(res["lds"][1], res["dense"][1])
+    assert res["lds"][2]["n_mappings"] > 4000
+    assert res["dense"][2]["sum_l2_evals"] > 3 * res["lds"][2]["sum_l2_evals"]      # every window against the skip-ahead's few
+    idx.close(); reads.close(); ref.close()

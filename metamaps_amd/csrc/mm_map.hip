@@ -1210,9 +1210,9 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       d_hb.upload(hb.data(), ns, st); d_he.upload(he.data(), ns, st);
       auto seg_sort = [&](uint64_t* in, uint64_t* out, uint64_t count, uint64_t* begins, uint64_t* ends) {
         size_t tmp_bytes = 0;
-        MM_HIP(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, in, out, (unsigned int)count, (unsigned int)ns, begins, ends, 0, 64, st));
+        MM_HIP(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, in, out, (unsigned int)count, (unsigned int)ns, begins, ends, 0, key_bits, st));
         DBuf<uint8_t> tmp(std::max<size_t>(tmp_bytes, 16));
-        MM_HIP(rocprim::segmented_radix_sort_keys((void*)tmp.p, tmp_bytes, in, out, (unsigned int)count, (unsigned int)ns, begins, ends, 0, 64, st));
+        MM_HIP(rocprim::segmented_radix_sort_keys((void*)tmp.p, tmp_bytes, in, out, (unsigned int)count, (unsigned int)ns, begins, ends, 0, key_bits, st));
       };
       if (compact) {
         d_cb.upload(cb.data(), ns, st); d_ce.upload(ce.data(), ns, st);
@@ -1320,7 +1320,9 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     };
     // sketches from this size on take the dense path (MM_L2_DENSE_FROM: experiments; MM_L2_NO_DENSE=1: the LDS classes / literal automaton)
     const bool use_dense = !getenv("MM_L2_NO_DENSE");
-    const int dense_from = getenv("MM_L2_DENSE_FROM") ? atoi(getenv("MM_L2_DENSE_FROM")) : 16385;
+    // (from ~58 kb reads on the streamed range of a candidate outgrows the 32 768-entry masks of the LDS classes' exact skip-ahead, which
+    //  then evaluate every window with a rebuild per zone exit: 6 000 reads of 60-73 kb: 171 ms there, 83 ms here)
+    const int dense_from = getenv("MM_L2_DENSE_FROM") ? atoi(getenv("MM_L2_DENSE_FROM")) : 13000;
     DBuf<int32_t> d_listG(listG.size());
     DBuf<uint32_t> giant_scratch;
     if (!listG.empty() && use_dense) run_dense(listG, smG);

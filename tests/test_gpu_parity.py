@@ -392,7 +392,7 @@ def test_tiebreak_modes_agree(ctx, monkeypatch):
 @pytest.mark.parametrize("read_len,n_reads", [(20_000, 300), (45_000, 150), (90_000, 60)])
 def test_l2_long_read_classes_equal_full_slide(ctx, monkeypatch, read_len, n_reads):
     """the sketch-size classes of K5 beyond the 10 kb case (masks for 32 768 streamed entries, blocks of several words,
-    two candidates per workgroup, the one-wave 16-bit kernel) against the literal full slide"""
+    two candidates per workgroup; from ~58 kb on the long-read path of mm_l2_dense.hpp) against the literal full slide"""
     ref = ctx.synth_reference(seed=15, n_species=12, strains_per_species=4, genome_len=600_000, strain_divergence=0.02, genus_divergence=0.08)
     reads, _ = ctx.synth_reads(ref, seed=19, n_reads=n_reads, read_len=read_len, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=10)
     idx = ctx.index(ref, 16, 8)
@@ -405,7 +405,11 @@ def test_l2_long_read_classes_equal_full_slide(ctx, monkeypatch, read_len, n_rea
         M.close()
     monkeypatch.delenv("MM_L2_FULL")
     assert np.array_equal(res["0"][0], res["1"][0]) and np.array_equal(res["0"][1], res["1"][1])
-    assert res["0"][2]["n_mappings"] > n_reads and res["0"][2]["sum_l2_evals"] < res["1"][2]["sum_l2_evals"]
+    assert res["0"][2]["n_mappings"] > n_reads
+    if read_len < 58_000:                                         # the LDS classes skip most windows ...
+        assert res["0"][2]["sum_l2_evals"] < res["1"][2]["sum_l2_evals"]
+    else:                                                         # ... the long-read path (state in global memory) evaluates every window, like the full slide
+        assert res["0"][2]["sum_l2_evals"] == res["1"][2]["sum_l2_evals"]
     idx.close(); reads.close(); ref.close()
 
 

@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   if (WRITE) {                                                   // staged reads only need a copy
     const uint32_t n_s = surv_n[r];
     if (n_s <= (uint32_t)(stage_off[r + 1] - stage_off[r])) {
+      if (dbg == 100 && n_s >= 2u && n_s <= 4096u) return;        // (dbg 100: the LDS radix sort takes these straight from the stage)
       const uint64_t wb = read_hit_off[r];
       for (uint32_t i = threadIdx.x; i < n_s; i += 256) hits[wb + i] = stage[stage_off[r] + i];
       return;
@@ -644,16 +645,20 @@ __global__ void __launch_bounds__(256) sort_hits_kernel(uint64_t* __restrict__ h
 // fewer instructions than the bitonic network and no padding to a power of two.  256 * IPT >= hits of the longest read of the class.
 template <int IPT>
 __global__ void __launch_bounds__(256) sort_hits_radix_kernel(uint64_t* __restrict__ hits, const uint64_t* __restrict__ read_hit_off,
-                                                              const int32_t* __restrict__ read_list, int end_bit) {
+                                                              const int32_t* __restrict__ read_list, int end_bit,
+                                                              const uint64_t* __restrict__ stage /* optional: staged survivors of the filter ... */,
+                                                              const uint64_t* __restrict__ stage_off /* ... which hold a read's hits whenever they fit its stage */) {
   using Sort = rocprim::block_radix_sort<uint64_t, 256, IPT>;
   extern __shared__ __align__(16) unsigned char sort_dyn[];
   typename Sort::storage_type& tmp = *reinterpret_cast<typename Sort::storage_type*>(sort_dyn);
   const int r = read_list[blockIdx.x];
   const uint64_t o = read_hit_off[r];
   const int n = (int)(read_hit_off[r + 1] - o);
+  const uint64_t* __restrict__ src = hits + o;
+  if (stage) { const uint64_t sb = stage_off[r]; if ((uint64_t)n <= stage_off[r + 1] - sb) src = stage + sb; }   // (then the filter's write kernel left hits[] alone)
   uint64_t key[IPT];
 #pragma unroll
-  for (int i = 0; i < IPT; ++i) { const int idx = threadIdx.x * IPT + i; key[i] = idx < n ? hits[o + idx] : ~0ull; }
+  for (int i = 0; i < IPT; ++i) { const int idx = threadIdx.x * IPT + i; key[i] = idx < n ? src[idx] : ~0ull; }
   Sort().sort(key, tmp, 0, end_bit);                             // blocked: thread t holds sorted positions t*IPT ..  (padding keys sort last)
 #pragma unroll
   for (int i = 0; i < IPT; ++i) { const int idx = threadIdx.x * IPT + i; if (idx < n) hits[o + idx] = key[i]; }
@@ -1111,7 +1116,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   if (total_hits > 0) {
     if (use_filter)
       hit_filter_kernel<true><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
-                                                                    M->min_hits.p, surv.p, M->read_hit_off.p, M->hits.p, stage.p, stage_off.p, 0, nullptr, nullptr);
+                                                                    M->min_hits.p, surv.p, M->read_hit_off.p, M->hits.p, stage.p, stage_off.p, getenv("MM_HITS_BITONIC") ? 0 : 100, nullptr, nullptr);
     else
       gather_hits_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, hit_off.p, M->hits.p);
     MM_KERNEL_CHECK();
@@ -1151,7 +1156,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           using SortT = rocprim::block_radix_sort<uint64_t, 256, IPT>;
           const size_t lds = sizeof(typename SortT::storage_type) + 16;
           if (lds > 48 * 1024) MM_HIP(hipFuncSetAttribute((const void*)sort_hits_radix_kernel<IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          sort_hits_radix_kernel<IPT><<<dim3((unsigned)run.second), dim3(256), lds, st>>>(M->hits.p, M->read_hit_off.p, lp, key_bits);
+          sort_hits_radix_kernel<IPT><<<dim3((unsigned)run.second), dim3(256), lds, st>>>(M->hits.p, M->read_hit_off.p, lp, key_bits, use_filter ? stage.p : nullptr, use_filter ? stage_off.p : nullptr);
         };
         switch (run.first) {
           case 1: launch(std::integral_constant<int, 1>{}); break;

@@ -560,6 +560,7 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_kernel(IndexView I, co
     L.alive[tid] = al;
   }
   __syncthreads();
+  if (dbg == 5) { if (tid == 0) { surv_n[r] = 0; raw_hits[r] = L.alive[0]; } return; }
   // ---- phase 2: bit tests over the parked codes; a survivor is the occurrence (list start + position in the list)
   const uint64_t stage_base = stage_off[r];
   const uint32_t stage_cap = (uint32_t)(stage_off[r + 1] - stage_base);

@@ -403,18 +403,24 @@ def cpu_baseline_and_cli(args, R, k, w):
         t0 = time.time()
         p = subprocess.run([cli, "mapDirectly", "--all", "-r", db["fasta"], "-q", fq_all, "-o", os.path.join(d, "gpuall"), "-w", str(w)], capture_output=True, check=True, timeout=900, env=env)
         t_map_all = time.time() - t0
+        map_phases = {}
         for ln in p.stderr.decode().splitlines():
             if ln.startswith("INFO, lap 3 index build"):
                 t_setup = float(ln.split(" at +")[1].split()[0])
+            if ln.startswith("INFO, time "):
+                map_phases[" ".join(ln.split()[2:-2])] = float(ln.split()[-2])
+        map_phases["process wall"] = t_map_all
         t0 = time.time()
-        subprocess.run([cli, "classify", "--DB", db["dir"], "--mappings", os.path.join(d, "gpuall")], capture_output=True, check=True, timeout=900)
+        pc = subprocess.run([cli, "classify", "--DB", db["dir"], "--mappings", os.path.join(d, "gpuall")], capture_output=True, check=True, timeout=900, env=env)
         t_cli_cls = time.time() - t0
+        cls_phases = {ln.split()[2] + " " + " ".join(ln.split()[3:-2]): float(ln.split()[-2]) for ln in pc.stderr.decode().splitlines() if ln.startswith("INFO, time c")}
+        cls_phases.update({"main: " + ln.split(" at +")[0][12:]: float(ln.split(" at +")[1].split()[0]) for ln in pc.stderr.decode().splitlines() if ln.startswith("INFO, main: ")})
         e2e = {"value": bases_all / max(t_map_all - t_setup + t_cli_cls, 1e-9) / 1e9, "unit": "Gbp/s",
                "what": "metamaps mapDirectly (reads FASTQ -> PREFIX, .meta) + metamaps classify (-> .EM.*), wall clock of the two processes minus "
                        "context + reference parse + index build, on every bench read that stems from the cpu_baseline's reference slice",
                "reads": n_all, "bases": bases_all, "map_seconds": t_map_all - t_setup, "setup_seconds": t_setup, "classify_seconds": t_cli_cls,
                "mapping_only_value": bases_all / max(t_map_all - t_setup, 1e-9) / 1e9,
-               "on_the_cpu_sample": small_run, "reads2taxon_identical_to_oracle": same, "sample_files_written_s": round(t_files, 2)}
+               "map_phases_s": map_phases, "classify_phases_s": cls_phases, "on_the_cpu_sample": small_run, "reads2taxon_identical_to_oracle": same, "sample_files_written_s": round(t_files, 2)}
     return cpu, e2e
 
 

@@ -624,6 +624,8 @@ int map_mode(const Options& o, const std::string& mode) {
         pc.add("5 reads pack+upload", std::chrono::duration<double>(t1 - t0).count());
         pc.add("6 map", std::chrono::duration<double>(t2 - t1).count());
         pc.add("7 mapq+fetch+format", std::chrono::duration<double>(t3 - t2).count());
+        if (getenv("MM_CLI_TIMING")) { std::ostringstream os; os << "INFO, worker " << d << "." << wi << " batch " << seq << ": upload " << std::chrono::duration<double>(t1 - t0).count() << " map "
+          << std::chrono::duration<double>(t2 - t1).count() << " finish " << std::chrono::duration<double>(t3 - t2).count() << " done at +" << std::chrono::duration<double>(t3 - pc.t0).count() << " s\n"; std::cerr << os.str(); }
         reader.recycle(std::move(bt));
         writer.put(seq, std::move(dn));
       }
@@ -1149,16 +1151,21 @@ int main(int argc, char** argv) {
   if (mode == "classify") {
     if (!o.v.count("DB")) die("Provide path to DB.");
     if (!o.v.count("mappings")) die("Provide path to mappings.");
+    const auto m0 = std::chrono::steady_clock::now();
+    auto since = [&](const char* what) { if (getenv("MM_CLI_TIMING")) std::cerr << "INFO, main: " << what << " at +" << std::chrono::duration<double>(std::chrono::steady_clock::now() - m0).count() << " s\n"; };
     std::vector<Dev> devs;
     for (int p : device_list(o)) { Dev d; d.phys = p; devs.push_back(d); }
     for (auto& d : devs) if (mm_ctx_create(d.phys, &d.ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
+    since("contexts created");
     const bool use_comm = devs.size() > 1 || o.v.count("gpus") || o.v.count("devices");   // an explicit --gpus 1 also goes through RCCL (one rank)
     const size_t minReadsU = o.v.count("minreads") ? std::stoull(o.v.at("minreads")) : 10000;   // parseCmdArgs.hpp:462-471
     for (auto& m : split(o.v.at("mappings"), ",")) {
       classify_one(devs, use_comm, m, o.v.at("DB"), minReadsU);
       for (auto& d : devs) mm_comm_destroy(d.ctx);
+      since("mappings file done");
     }
     for (auto& d : devs) mm_ctx_destroy(d.ctx);
+    since("contexts destroyed");
     return 0;
   }
   die("sub-command '" + mode + "' is outside the accelerated hot path (SURVEY.md §2: Boost-archive index files / disabled upstream)");

@@ -10,6 +10,7 @@
 #include <vector>
 #include <stdexcept>
 #include <memory>
+#include <chrono>
 #include <map>
 #include "../../include/metamaps_hip.h"
 
@@ -61,7 +62,10 @@ struct DevAlloc {
       void* p = it->second; *got = it->first; cached_bytes -= it->first; cache.erase(it); return p;
     }
     void* p = nullptr;
+    static const bool trace = getenv("MM_ALLOC_TRACE") != nullptr;     // every block that comes from the driver, with its cost
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, want);
+    if (trace) fprintf(stderr, "MM_ALLOC_TRACE hipMalloc %zu bytes %.3f ms\n", want, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); trim(); e = hipMalloc(&p, want); }
     if (e != hipSuccess) { (void)hipGetLastError(); throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     *got = want;

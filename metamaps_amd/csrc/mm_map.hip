@@ -1017,16 +1017,21 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   // ---- K7 host thresholds per distinct sketch size
   {
     if (!ctx->lut_cache || ctx->lut_k != P.k || ctx->lut_pi != P.perc_identity) {
-      ctx->lut_cache = std::make_shared<stats::LutCache>(P.k, P.perc_identity);
+      ctx->lut_cache = stats::LutCache::for_params(P.k, P.perc_identity);
       ctx->lut_k = P.k; ctx->lut_pi = P.perc_identity;
     }
     stats::LutCache& lut = *static_cast<stats::LutCache*>(ctx->lut_cache.get());
     std::vector<int32_t> mh((size_t)n, 0), am((size_t)n, 0);
-    int smax = 0;
+    int smax = 0, s_hi = 0;
+    for (int64_t r = 0; r < n; ++r) s_hi = std::max(s_hi, (int)M->h_sk_n[(size_t)r]);
+    std::vector<int32_t> slot((size_t)s_hi + 1, -1);             // sketch size -> place in `sizes`
+    std::vector<int> sizes;
+    for (int64_t r = 0; r < n; ++r) { const int s = M->h_sk_n[(size_t)r]; if (s > 0 && slot[(size_t)s] < 0) { slot[(size_t)s] = (int32_t)sizes.size(); sizes.push_back(s); } }
+    const std::vector<stats::SketchLut> luts = lut.get_many(sizes);
     for (int64_t r = 0; r < n; ++r) {
       int s = M->h_sk_n[(size_t)r];
       if (s <= 0) continue;
-      auto L = lut.get(s);
+      const stats::SketchLut L = luts[(size_t)slot[(size_t)s]];
       mh[(size_t)r] = L.min_hits; am[(size_t)r] = L.accept_min;
       if (s < L2_SKETCH_LIMIT) smax = std::max(smax, s);         // (LDS sizing of the K5 classes; larger sketches never enter them)
       M->stats.sum_sketch += s;

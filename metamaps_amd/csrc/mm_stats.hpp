@@ -8,6 +8,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -129,12 +133,9 @@ inline int recommended_window(double pcut, int k, int alphabet, float pi, int ql
 struct SketchLut { int min_hits; int accept_min; };
 class LutCache {
   int k_; float pi_;
+  std::mutex m_;
   std::unordered_map<int, SketchLut> memo_;
- public:
-  LutCache(int k, float pi) : k_(k), pi_(pi) {}
-  SketchLut get(int s) {
-    auto it = memo_.find(s);
-    if (it != memo_.end()) return it->second;
+  SketchLut compute(int s) const {
     SketchLut L{0, 0};
     if (s > 0) {
       L.min_hits = min_hits_relaxed(s, k_, pi_);
@@ -146,8 +147,36 @@ class LutCache {
         L.accept_min = lo;
       }
     }
-    memo_[s] = L;
     return L;
+  }
+ public:
+  LutCache(int k, float pi) : k_(k), pi_(pi) {}
+  // thresholds of the given (distinct) sketch sizes; sizes not seen before are computed on a few host threads.  One cache per
+  // (k, pi) serves every context of the process (for()), so a second context never recomputes what the first one has.
+  std::vector<SketchLut> get_many(const std::vector<int>& sizes) {
+    std::lock_guard<std::mutex> lk(m_);
+    std::vector<int> missing;
+    for (int s : sizes) if (!memo_.count(s)) missing.push_back(s);
+    if (!missing.empty()) {
+      std::vector<SketchLut> out(missing.size());
+      const size_t nt = std::min<size_t>({missing.size() / 8 + 1, 16, std::max(1u, std::thread::hardware_concurrency())});
+      std::vector<std::thread> th;
+      for (size_t t = 1; t < nt; ++t) th.emplace_back([&, t]() { for (size_t i = t; i < missing.size(); i += nt) out[i] = compute(missing[i]); });
+      for (size_t i = 0; i < missing.size(); i += nt) out[i] = compute(missing[i]);
+      for (auto& x : th) x.join();
+      for (size_t i = 0; i < missing.size(); ++i) memo_[missing[i]] = out[i];
+    }
+    std::vector<SketchLut> r; r.reserve(sizes.size());
+    for (int s : sizes) r.push_back(memo_.at(s));
+    return r;
+  }
+  SketchLut get(int s) { return get_many({s})[0]; }
+  static std::shared_ptr<LutCache> for_params(int k, float pi) {
+    static std::mutex gm; static std::map<std::pair<int, float>, std::shared_ptr<LutCache>> all;
+    std::lock_guard<std::mutex> lk(gm);
+    auto& p = all[{k, pi}];
+    if (!p) p = std::make_shared<LutCache>(k, pi);
+    return p;
   }
 };
 

@@ -22,3 +22,6 @@ print("files written")
 PY
 MM_CLI_TIMING=1 metamaps_amd/csrc/metamaps mapDirectly --all -r /tmp/clit/DB.fa -q /tmp/clit/reads.fq -o /tmp/clit/out 2>&1 | grep -E "INFO|rror"
 wc -l /tmp/clit/out
+if [ -n "$SMALL_BATCH" ]; then
+MM_CLI_BATCH_READS=$SMALL_BATCH MM_CLI_TIMING=1 metamaps_amd/csrc/metamaps mapDirectly --all -r /tmp/clit/DB.fa -q /tmp/clit/reads.fq -o /tmp/clit/out2 2>&1 | grep -E "worker" | head -12
+fi

@@ -153,6 +153,37 @@ __global__ void __launch_bounds__(256) count_hist_kernel(const uint64_t* __restr
   for (int i = threadIdx.x; i < HIST_BINS; i += 256) if (lb[i]) atomicAdd(&bins[i], (unsigned long long)lb[i]);
 }
 
+// directory entry g: contig by binary search over dir_off, then the lower bound of (b << shift) among the contig's positions
+__global__ void __launch_bounds__(256) dir_build_kernel(const Rec* __restrict__ pos, const uint64_t* __restrict__ cstart, const uint64_t* __restrict__ dir_off,
+                                                        int64_t n_contigs, int shift, uint64_t total, uint32_t* __restrict__ dir) {
+  const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= total) return;
+  int64_t lo = 0, hi = n_contigs;                                // last c with dir_off[c] <= g
+  while (hi - lo > 1) { const int64_t m = (lo + hi) >> 1; if (dir_off[m] <= g) lo = m; else hi = m; }
+  const int64_t c = lo;
+  const int64_t target = (int64_t)(g - dir_off[c]) << shift;
+  int64_t a = (int64_t)cstart[c], b = (int64_t)cstart[c + 1];
+  const int64_t base = a;
+  while (a < b) { const int64_t m = (a + b) >> 1; if ((int64_t)pw_wpos(pos[m].pw) < target) a = m + 1; else b = m; }
+  dir[g] = (uint32_t)(a - base);
+}
+
+static void build_directory(mm_index* I, hipStream_t st) {
+  // about 128 entries per directory bucket at the expected density 2 / (w + 1)
+  int shift = 4; while ((128.0 * (I->w + 1) / 2.0) >= (double)((int64_t)2 << shift) && shift < 20) ++shift;
+  I->dir_shift = shift;
+  std::vector<uint64_t> off((size_t)I->n_contigs + 1, 0);
+  for (int64_t c = 0; c < I->n_contigs; ++c) off[(size_t)c + 1] = off[(size_t)c] + ((uint64_t)std::max(I->contig_len[(size_t)c], 0) >> shift) + 2;
+  const uint64_t total = off.back();
+  I->dir_off.alloc(off.size()); I->dir_off.upload(off.data(), off.size(), st);
+  I->dir.alloc(std::max<size_t>((size_t)total, 1));
+  if (total && I->n_contigs) {
+    dir_build_kernel<<<dim3((unsigned)ceil_div((int64_t)total, 256)), dim3(256), 0, st>>>(I->pos.p, I->cstart.p, I->dir_off.p, I->n_contigs, shift, total, I->dir.p);
+    MM_KERNEL_CHECK();
+  }
+  MM_HIP(hipStreamSynchronize(st));                              // `off` is the upload source
+}
+
 void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* I) {
   hipStream_t st = ctx->stream;
   ctx->alloc.trim();                                            // hand cached blocks back before the big allocations
@@ -171,6 +202,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   I->cstart = std::move(ms.off);
   I->h_cstart = ms.h_off;
   I->U = 0; I->n_dup = 0; I->hist.clear();
+  build_directory(I, st);
   if (N == 0) {
     I->tab_bits = 8;
     I->tab.alloc((size_t)2 << I->tab_bits); I->tab.zero(st);

@@ -29,11 +29,17 @@ struct mm_index {
   mm::DBuf<uint16_t> occ16;
   mm::DBuf<uint64_t> tab;
   mm::DBuf<int32_t> d_contig_len;
+  // position directory: dir[dir_off[c] + b] = number of entries of contig c with wpos < (b << dir_shift), b = 0 .. (len >> dir_shift) + 1
+  // (the last one is the contig's entry count): a range search of K5 starts from one directory read instead of log64(contig) rounds
+  // of 64 scattered 128-byte lines each
+  mm::DBuf<uint32_t> dir;
+  mm::DBuf<uint64_t> dir_off;
+  int dir_shift = 9;
   std::vector<int32_t> contig_len;
   std::vector<uint64_t> h_cstart;
   std::map<int64_t, int64_t> hist;           // occurrence count -> number of hashes (this chunk)
   int64_t hbm_bytes() const {
-    return (int64_t)(pos.bytes() + cstart.bytes() + uh.bytes() + ustart.bytes() + occ.bytes() + occ16.bytes() + tab.bytes() + d_contig_len.bytes());
+    return (int64_t)(pos.bytes() + cstart.bytes() + uh.bytes() + ustart.bytes() + occ.bytes() + occ16.bytes() + tab.bytes() + d_contig_len.bytes() + dir.bytes() + dir_off.bytes());
   }
 };
 
@@ -50,9 +56,12 @@ struct IndexView {
   int64_t N, U;
   int tab_bits;
   int freq_threshold;
+  const uint32_t* dir;
+  const uint64_t* dir_off;
+  int dir_shift;
 };
 inline IndexView make_view(const mm_index* I) {
-  return IndexView{I->pos.p, I->cstart.p, I->occ.p, I->occ16.p, I->tab.p, I->N, I->U, I->tab_bits, I->freq_threshold};
+  return IndexView{I->pos.p, I->cstart.p, I->occ.p, I->occ16.p, I->tab.p, I->N, I->U, I->tab_bits, I->freq_threshold, I->dir.p, I->dir_off.p, I->dir_shift};
 }
 
 // Home slot of a hash: the first slot of a 4-slot bucket (4 x 16 B = one 64-byte sector), linear probing from there.  A lookup

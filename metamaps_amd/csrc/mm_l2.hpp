@@ -100,6 +100,18 @@ __device__ inline int64_t wave_lower_bound_wpos(const Rec* __restrict__ pos, int
   return lo + __popcll(__ballot(less));
 }
 
+// The same over a whole contig, entered through the index's position directory (mm_index.hpp): one directory read bounds the
+// answer to one bucket (~128 entries, part of the range that is streamed afterwards anyway).
+__device__ inline int64_t contig_lower_bound_wpos(const IndexView& I, int contig, int target, int lane) {
+  const int64_t cbeg = (int64_t)I.cstart[contig];
+  const uint64_t d0 = I.dir_off[contig], nb = I.dir_off[contig + 1] - d0 - 1;   // buckets 0 .. nb-1, entry nb = the contig's entry count
+  const uint64_t b = min((uint64_t)max(target, 0) >> I.dir_shift, nb - 1);
+  const int64_t lo = cbeg + (int64_t)I.dir[d0 + b], hi = cbeg + (int64_t)I.dir[d0 + b + 1];
+  // entries before lo lie below b << shift <= target; the entry at hi (if any) lies at or beyond (b + 1) << shift > target, or
+  // b is the last bucket and hi is the contig's end
+  return wave_lower_bound_wpos(I.pos, lo, hi, target, lane);
+}
+
 // Rank of a hash in the sorted sketch Q (lower bound).  T[b] = first rank whose hash >= b << L2_TSHIFT, so the answer lies
 // in a run of fewer than 2^steps elements starting at T[b]; because all of Q is sorted, the branch-free doubling search
 // below needs no upper limit (elements behind the bucket are larger than h anyway; Q is padded with 16 x 0xffffffff).
@@ -295,14 +307,14 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     return;
   }
   // all window arithmetic below is 32-bit and relative to the first streamed entry of this candidate
-  const int64_t cbeg = (int64_t)I.cstart[contig], cend = (int64_t)I.cstart[contig + 1];
-  const int64_t first0 = wave_lower_bound_wpos(I.pos, cbeg, cend, rs, lane);          // searchIndex, :466
-  const int64_t last0 = wave_lower_bound_wpos(I.pos, first0, cend, re + len, lane);   // :477
+  const int64_t first0 = contig_lower_bound_wpos(I, contig, rs, lane);                // searchIndex, :466
+  const int64_t last0 = max(first0, contig_lower_bound_wpos(I, contig, re + len, lane));   // :477
   const Rec* __restrict__ pos = I.pos + first0;
   const int first = 0;
   const int last_end = (int)(last0 - first0);
   const int nmax = (int)min((int64_t)0x7fffffff, I.N - 1 - first0);
   int amin = accept_min[r]; if (amin < 1) amin = 1;
+  if (dbg_stop == 3) return;                                     // (timing aid: the two range searches alone)
 
   L2StateT<DT> S{Q, D, mt, s, 0, 0, 0, 0};
   long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};                // phase clocks: setup, passA, bounds, rebuild, slide, passB, vote, -
@@ -1157,9 +1169,8 @@ __global__ void __launch_bounds__(64) l2_giant_kernel(IndexView I, const int32_t
     const int len = read_len[r];
     const int contig = cand[3 * c], rs = cand[3 * c + 1], re = cand[3 * c + 2];
     const int cnt = len - (w - 1) - (k - 1);                     // computeMap.hpp:470
-    const int64_t cbeg = (int64_t)I.cstart[contig], cend = (int64_t)I.cstart[contig + 1];
-    const int64_t first0 = wave_lower_bound_wpos(I.pos, cbeg, cend, rs, lane);          // searchIndex, :466
-    const int64_t last0 = wave_lower_bound_wpos(I.pos, first0, cend, re + len, lane);   // :477
+      const int64_t first0 = contig_lower_bound_wpos(I, contig, rs, lane);                // searchIndex, :466
+    const int64_t last0 = max(first0, contig_lower_bound_wpos(I, contig, re + len, lane));   // :477
     const Rec* __restrict__ pos = I.pos + first0;
     const int last_end = (int)(last0 - first0);
     const int nmax = (int)min((int64_t)0x7fffffff, I.N - 1 - first0);

@@ -38,9 +38,8 @@ __global__ void __launch_bounds__(256) l2_range_kernel(IndexView I, const int32_
   if (li >= n_list) return;
   const int64_t c = cand_list[li];
   const int contig = cand[3 * c], rs = cand[3 * c + 1], re = cand[3 * c + 2], len = read_len[cand_read[c]];
-  const int64_t cbeg = (int64_t)I.cstart[contig], cend = (int64_t)I.cstart[contig + 1];
-  const int64_t first0 = wave_lower_bound_wpos(I.pos, cbeg, cend, rs, lane);          // searchIndex, computeMap.hpp:466
-  const int64_t last0 = wave_lower_bound_wpos(I.pos, first0, cend, re + len, lane);   // :477
+  const int64_t first0 = contig_lower_bound_wpos(I, contig, rs, lane);                // searchIndex, computeMap.hpp:466
+  const int64_t last0 = max(first0, contig_lower_bound_wpos(I, contig, re + len, lane));   // :477
   if (lane == 0) ranges[li] = L2Range{first0, (int32_t)min<int64_t>(last0 - first0, 0x7fffffff), 0};
 }
 

@@ -7,11 +7,11 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 __device__ inline uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
 template <int B>
-__global__ void __launch_bounds__(256) st(const uint64_t* __restrict__ buf, uint64_t words, int chunks, uint64_t* __restrict__ sink) {
+__global__ void __launch_bounds__(256) st(const uint64_t* __restrict__ buf, uint64_t words, int chunks, uint64_t* __restrict__ sink, uint64_t align_mask) {
   extern __shared__ uint32_t lds[];
   const int lane = threadIdx.x & 63;
   const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const uint64_t start = (mix(wid) % (words - (uint64_t)chunks * 64 - 64)) & ~7ull;
+  const uint64_t start = (mix(wid) % (words - (uint64_t)chunks * 64 - 64)) & align_mask;
   const uint64_t* p = buf + start;
   uint64_t acc = 0;
   for (int c = 0; c < chunks; c += B) {
@@ -24,15 +24,15 @@ __global__ void __launch_bounds__(256) st(const uint64_t* __restrict__ buf, uint
   if (acc == 0x1234567) { sink[0] = acc; lds[0] = 1; }
 }
 template <int B>
-void run(const uint64_t* buf, uint64_t words, uint64_t* sink, int waves, int chunks, int lds_bytes) {
+void run(const uint64_t* buf, uint64_t words, uint64_t* sink, int waves, int chunks, int lds_bytes, uint64_t align_mask = ~7ull) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   if (lds_bytes > 65536) CK(hipFuncSetAttribute((const void*)st<B>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-  st<B><<<waves / 4, 256, lds_bytes>>>(buf, words, chunks, sink);
+  st<B><<<waves / 4, 256, lds_bytes>>>(buf, words, chunks, sink, align_mask);
   CK(hipEventRecord(a));
-  st<B><<<waves / 4, 256, lds_bytes>>>(buf, words, chunks, sink);
+  st<B><<<waves / 4, 256, lds_bytes>>>(buf, words, chunks, sink, align_mask);
   CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b));
-  printf("B=%2d chunks=%d (%d KB/wave) lds=%d KB/WG: %.2f ms, %.2f TB/s\n", B, chunks, chunks / 2, lds_bytes >> 10, ms, (double)waves * chunks * 512 / ms / 1e9);
+  printf("B=%2d chunks=%d (%d KB/wave) lds=%d KB/WG align %d B: %.2f ms, %.2f TB/s\n", B, chunks, chunks / 2, lds_bytes >> 10, (int)(8 * (~align_mask + 1)), ms, (double)waves * chunks * 512 / ms / 1e9);
 }
 int main(int argc, char** argv) {
   const uint64_t gib = argc > 1 ? atoll(argv[1]) : 44;
@@ -48,5 +48,7 @@ int main(int argc, char** argv) {
   run<1>(buf, words, sink, waves, 96, 39 * 1024);
   run<8>(buf, words, sink, waves, 96, 78 * 1024);
   run<8>(buf, words, sink, waves, 32, 39 * 1024);
+  run<8>(buf, words, sink, waves, 96, 39 * 1024, ~0ull);      // starts at any 8-byte offset (the K5 candidates)
+  run<8>(buf, words, sink, waves, 96, 39 * 1024, ~15ull);     // 128-byte aligned
   return 0;
 }

@@ -249,7 +249,11 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   const int len = read_len[r];
   uint16_t* T = (uint16_t*)((uint8_t*)lds + l2_qpart_bytes(smax));
   int* tmaxp = (int*)(T + ((L2_TSIZE + 1) & ~1));
+  const int dbg_early = (int)counters[11] & 0xff;
+  auto early_out = [&]() { if (!(WAVES > 1 && wave >= grp_n[blockIdx.x]) && lane == 0) { L2Result z{}; out[c0 + (WAVES > 1 ? wave : 0)] = z; } };
+  if (dbg_early == 6) { early_out(); return; }
   for (int i = threadIdx.x; i < s; i += 64 * WAVES) Q[i] = sk_hash[qo + i];
+  if (dbg_early == 7) { __syncthreads(); early_out(); return; }
   // strand byte of every sketch entry (bit 0 strand, bit 1 unresolved duplicate: mm_map.hip, K2) as two bit sets: the vote
   // looks them up per matched entry, and a global load there is a second dependent memory latency in every step
   uint64_t* const SB = (uint64_t*)((uint8_t*)lds + l2_qpart_bytes(smax) + l2_tpart_bytes());

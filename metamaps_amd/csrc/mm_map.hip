@@ -751,6 +751,44 @@ __global__ void __launch_bounds__(256) l1_wave_kernel(const uint64_t* __restrict
 // result compaction: accepted candidates -> mapping records, read order preserved
 // ---------------------------------------------------------------------------------------------------
 // sums of the per-candidate work counters: one atomic per counter per block
+// K5 workgroups of the 10 kb class (sketch <= 3072), made on the device: per read, its candidates in groups of four (four-wave
+// workgroups); a remainder of one or two goes to a two-wave workgroup.  The same lists came from a host loop before, ~0.85 ms per
+// 10^5 reads of branch mispredictions with the device waiting.  Group order across workgroups of this kernel is arbitrary (results are
+// indexed by candidate).  ctr: [0] four-wave groups, [1] two-wave groups, [2] reads with candidates left to the host's classes,
+// [3] largest sketch among the grouped reads.
+__global__ void __launch_bounds__(256) l2_group_kernel(const uint64_t* __restrict__ cand_off, const int32_t* __restrict__ sk_n, const int32_t* __restrict__ read_len,
+                                                       int64_t n, int min_len_dense, int dense_from, int no_small,
+                                                       int32_t* __restrict__ gA0, int32_t* __restrict__ gAn, int32_t* __restrict__ gS0, int32_t* __restrict__ gSn,
+                                                       unsigned int* __restrict__ ctr) {
+  __shared__ unsigned int bA, bS, bOther, bMax, baseA, baseS;
+  if (threadIdx.x == 0) { bA = 0; bS = 0; bOther = 0; bMax = 0; }
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t c_lo = 0, c_hi = 0; int sr = 0; bool mine = false;
+  if (r < n) {
+    c_lo = cand_off[r]; c_hi = cand_off[r + 1]; sr = sk_n[r];
+    const bool dense = sr >= dense_from && sr < L2_SKETCH_LIMIT && read_len[r] >= min_len_dense;
+    mine = c_hi > c_lo && sr <= 3072 && !dense;
+    if (c_hi > c_lo && !mine) atomicAdd(&bOther, 1u);
+  }
+  const unsigned ncr = mine ? (unsigned)(c_hi - c_lo) : 0u, nfull = ncr >> 2, rem = ncr & 3u;
+  const bool rem_small = rem != 0 && rem <= 2 && !no_small;
+  const unsigned a = nfull + ((rem != 0 && !rem_small) ? 1u : 0u), b = rem_small ? 1u : 0u;
+  unsigned la = 0, ls = 0;
+  if (a) la = atomicAdd(&bA, a);
+  if (b) ls = atomicAdd(&bS, b);
+  if (mine) atomicMax(&bMax, (unsigned)sr);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    baseA = bA ? atomicAdd(&ctr[0], bA) : 0u; baseS = bS ? atomicAdd(&ctr[1], bS) : 0u;
+    if (bOther) atomicAdd(&ctr[2], bOther);
+    if (bMax) atomicMax(&ctr[3], bMax);
+  }
+  __syncthreads();
+  for (unsigned g = 0; g < a; ++g) { gA0[baseA + la + g] = (int32_t)(c_lo + 4u * g); gAn[baseA + la + g] = (int32_t)min(4u, ncr - 4u * g); }
+  if (b) { gS0[baseS + ls] = (int32_t)(c_lo + 4u * nfull); gSn[baseS + ls] = (int32_t)rem; }
+}
+
 __global__ void __launch_bounds__(256) l2_stats_kernel(const L2Result* __restrict__ l2, int64_t n, unsigned long long* __restrict__ counters) {
   __shared__ unsigned long long acc[4];
   if (threadIdx.x < 4) acc[threadIdx.x] = 0;
@@ -801,6 +839,31 @@ std::vector<SizeClass> make_classes(const std::vector<int64_t>& count, int min_p
   return v;
 }
 constexpr int LDS_SORT_MAX = 16384;     // 128 KiB of 64-bit keys
+
+// MM_HOST_TIMING=1: wall time of the host sections between kernels (stderr)
+struct HostLap {
+  const bool on = getenv("MM_HOST_TIMING") != nullptr; std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void operator()(const char* what) { if (!on) return; const auto n = std::chrono::steady_clock::now(); fprintf(stderr, "host %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(n - t).count()); t = n; }
+};
+
+// Reads grouped by a small class id (n_classes: left out), input order kept inside a class: a counting sort without data-dependent
+// branches, because these host loops sit between two kernels of a batch with the device waiting (std::map + push_back, or a branchy
+// class function on mixed counts, cost ~0.6 ms per 10^5 reads in mispredictions).
+struct ReadBins { std::vector<int32_t> order; std::vector<std::pair<int, size_t>> runs; };   // runs: (class, number of reads), ascending class, back to back in `order`
+template <typename F>
+ReadBins bin_reads(int64_t n, int n_classes, F&& class_of) {
+  ReadBins b;
+  std::vector<size_t> start((size_t)n_classes + 2, 0);
+  std::vector<uint8_t> cls((size_t)std::max<int64_t>(n, 0));
+  for (int64_t r = 0; r < n; ++r) { const unsigned c = (unsigned)class_of(r); cls[(size_t)r] = (uint8_t)c; ++start[(size_t)c + 1]; }
+  for (int c = 0; c <= n_classes; ++c) start[(size_t)c + 1] += start[(size_t)c];
+  b.order.resize((size_t)std::max<int64_t>(n, 0));               // the left-out reads land behind the classes and are cut off
+  std::vector<size_t> at(start.begin(), start.end() - 1);
+  for (int64_t r = 0; r < n; ++r) b.order[at[cls[(size_t)r]]++] = (int32_t)r;
+  b.order.resize(start[(size_t)n_classes]);
+  for (int c = 0; c < n_classes; ++c) if (start[(size_t)c + 1] > start[(size_t)c]) b.runs.emplace_back(c, start[(size_t)c + 1] - start[(size_t)c]);
+  return b;
+}
 
 struct HostMz { uint32_t hash; int32_t wpos, strand; };
 static bool host_less_by_hash(const HostMz& a, const HostMz& b) { return a.hash < b.hash; }   // base_types.hpp:70
@@ -866,53 +929,63 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   // ---- K2
   {
     size_t t_sk = T.begin(&M->stats.ms_sketch);
-    std::vector<int64_t> cnt((size_t)n);
-    for (int64_t r = 0; r < n; ++r) cnt[(size_t)r] = (int64_t)(hoff[(size_t)r + 1] - hoff[(size_t)r]);
-    // single-element lists are "sorted" already but still need their sketch written: force class >= 2 by min count 1
-    for (auto& c : cnt) if (c == 1) c = 2;
+    // up to 16384 minimizers: radix sort in LDS, 4 ... 64 elements per thread.  The sort's cost follows the elements per thread, so the
+    // reads are grouped by the capacity they really need (a 10 kb read has ~2 200 minimizers: 10 per thread instead of 16).
+    // Single-element lists are "sorted" already but still need their sketch written.
+    static const int ipts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48, 64};
+    uint8_t cls_of_need[66];                                      // elements per thread needed -> index into ipts; [0]: empty, [65]: beyond the LDS sort
+    for (int need = 0, i = 0; need <= 64; ++need) { while (ipts[i] < need) ++i; cls_of_need[need] = (uint8_t)i; }
+    cls_of_need[0] = 12; cls_of_need[65] = 12;
+    uint64_t big_seen = 0;
+    HostLap hl;
+    const ReadBins RB = bin_reads(n, 12, [&](int64_t r) -> int {
+      const uint64_t c = hoff[(size_t)r + 1] - hoff[(size_t)r];
+      big_seen |= (uint64_t)(c > 16384);
+      return cls_of_need[std::min<uint64_t>((c + 255) / 256, 65)];
+    });
+    const bool any_big = big_seen != 0;
+    {
+      hl("K2 bin");
+      DBuf<int32_t> list(std::max<size_t>(RB.order.size(), 1));
+      list.upload(RB.order.data(), RB.order.size(), st);
+      hl("K2 list upload");
+      size_t at = 0;
+      for (auto& run : RB.runs) {
+        const unsigned nb = (unsigned)run.second;
+        const int32_t* lp = list.p + at;
+        auto launch = [&](auto ipt_tag) {
+          constexpr int IPT = decltype(ipt_tag)::value;
+          using SortT = rocprim::block_radix_sort<uint32_t, 256, IPT, uint16_t>;
+          using ScanT = rocprim::block_scan<int, 256>;
+          const size_t lds = std::max(sizeof(typename SortT::storage_type), sizeof(typename ScanT::storage_type)) + 16;
+          if (lds > 48 * 1024) MM_HIP(hipFuncSetAttribute((const void*)sketch_radix_kernel<IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          sketch_radix_kernel<IPT><<<dim3(nb), dim3(256), lds, st>>>(M->mz.rec.p, M->mz.off.p, lp, M->sk_hash.p, M->sk_strand.p, M->sk_n.p, M->amb.p);
+        };
+        switch (ipts[run.first]) {
+          case 4: launch(std::integral_constant<int, 4>{}); break;
+          case 6: launch(std::integral_constant<int, 6>{}); break;
+          case 8: launch(std::integral_constant<int, 8>{}); break;
+          case 10: launch(std::integral_constant<int, 10>{}); break;
+          case 12: launch(std::integral_constant<int, 12>{}); break;
+          case 16: launch(std::integral_constant<int, 16>{}); break;
+          case 20: launch(std::integral_constant<int, 20>{}); break;
+          case 24: launch(std::integral_constant<int, 24>{}); break;
+          case 32: launch(std::integral_constant<int, 32>{}); break;
+          case 40: launch(std::integral_constant<int, 40>{}); break;
+          case 48: launch(std::integral_constant<int, 48>{}); break;
+          default: launch(std::integral_constant<int, 64>{}); break;
+        }
+        MM_KERNEL_CHECK();
+        at += run.second;
+      }
+      hl("K2 launches");
+      MM_HIP(hipStreamSynchronize(st));                          // RB.order is the source of the async upload
+      hl("K2 sync (kernels)");
+    }
+    std::vector<int64_t> cnt;                                     // longer lists (reads beyond ~73 kb): bitonic network, by power-of-two capacity
+    if (any_big) { cnt.assign((size_t)n, 0); for (int64_t r = 0; r < n; ++r) { const int64_t c = (int64_t)(hoff[(size_t)r + 1] - hoff[(size_t)r]); if (c > 16384) cnt[(size_t)r] = c; } }
     for (auto& cls : make_classes(cnt, 256)) {
       DBuf<int32_t> list(cls.reads.size());
-      if (cls.npow2 <= 16384) {                                  // radix sort in LDS: 4 ... 64 elements per thread
-        // the sort's cost follows the elements per thread, so the reads of a power-of-two class are split by the
-        // capacity they really need (a 10 kb read has ~2 200 minimizers: 10 per thread instead of 16)
-        static const int ipts[] = {4, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48, 64};
-        std::map<int, std::vector<int32_t>> by_ipt;
-        for (int32_t r : cls.reads) { int need = (int)((cnt[(size_t)r] + 255) / 256), ip = 64; for (int v : ipts) if (v >= need) { ip = v; break; } by_ipt[ip].push_back(r); }
-        std::vector<int32_t> ordered; std::vector<std::pair<int, size_t>> runs;   // (IPT, number of reads), lists back to back in `list`
-        for (auto& kv : by_ipt) { runs.emplace_back(kv.first, kv.second.size()); ordered.insert(ordered.end(), kv.second.begin(), kv.second.end()); }
-        list.upload(ordered.data(), ordered.size(), st);
-        size_t at = 0;
-        for (auto& run : runs) {
-          const unsigned nb = (unsigned)run.second;
-          const int32_t* lp = list.p + at;
-          auto launch = [&](auto ipt_tag) {
-            constexpr int IPT = decltype(ipt_tag)::value;
-            using SortT = rocprim::block_radix_sort<uint32_t, 256, IPT, uint16_t>;
-            using ScanT = rocprim::block_scan<int, 256>;
-            const size_t lds = std::max(sizeof(typename SortT::storage_type), sizeof(typename ScanT::storage_type)) + 16;
-            if (lds > 48 * 1024) MM_HIP(hipFuncSetAttribute((const void*)sketch_radix_kernel<IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            sketch_radix_kernel<IPT><<<dim3(nb), dim3(256), lds, st>>>(M->mz.rec.p, M->mz.off.p, lp, M->sk_hash.p, M->sk_strand.p, M->sk_n.p, M->amb.p);
-          };
-          switch (run.first) {
-            case 4: launch(std::integral_constant<int, 4>{}); break;
-            case 6: launch(std::integral_constant<int, 6>{}); break;
-            case 8: launch(std::integral_constant<int, 8>{}); break;
-            case 10: launch(std::integral_constant<int, 10>{}); break;
-            case 12: launch(std::integral_constant<int, 12>{}); break;
-            case 16: launch(std::integral_constant<int, 16>{}); break;
-            case 20: launch(std::integral_constant<int, 20>{}); break;
-            case 24: launch(std::integral_constant<int, 24>{}); break;
-            case 32: launch(std::integral_constant<int, 32>{}); break;
-            case 40: launch(std::integral_constant<int, 40>{}); break;
-            case 48: launch(std::integral_constant<int, 48>{}); break;
-            default: launch(std::integral_constant<int, 64>{}); break;
-          }
-          MM_KERNEL_CHECK();
-          at += run.second;
-        }
-        MM_HIP(hipStreamSynchronize(st));                        // `ordered` is the source of the async upload
-        continue;
-      }
       list.upload(cls.reads.data(), cls.reads.size(), st);
       if (cls.npow2 <= LDS_SORT_MAX) {
         size_t lds = (size_t)cls.npow2 * 8;
@@ -930,8 +1003,10 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     }
     T.end(t_sk);
   }
+  HostLap hl;
   M->h_sk_n = M->sk_n.to_host(st, (size_t)n);
   std::vector<uint8_t> h_amb = M->amb.to_host(st, (size_t)n);
+  hl("post-K2 downloads");
   {
     // Reads whose sketch has >= 32768 hashes (~145 kb at w = 8) are beyond the LDS-resident window state of the K5 classes:
     // their candidates go through l2_giant_kernel (state in global memory); counted for the caller's information only.
@@ -1013,7 +1088,9 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       MM_HIP(hipStreamSynchronize(st));                          // host vectors above are the H2D sources
     };
   };
+  hl("post-K2 amb lists");
   if (!eager_reads.empty()) amb_finish = start_tiebreak(eager_reads);
+  hl("post-K2 tiebreak start");
   // ---- K7 host thresholds per distinct sketch size
   {
     if (!ctx->lut_cache || ctx->lut_k != P.k || ctx->lut_pi != P.perc_identity) {
@@ -1041,6 +1118,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     M->accept_min.alloc((size_t)std::max<int64_t>(n, 1)); M->accept_min.upload(am.data(), (size_t)n, st);
     M->h_min_hits = mh;
     MM_HIP(hipStreamSynchronize(st));
+    hl("K7 thresholds + uploads");
   }
   M->d_read_len.alloc((size_t)std::max<int64_t>(n, 1));
   M->d_read_len.upload(reads->len.data(), (size_t)n, st);
@@ -1063,6 +1141,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     need_old.alloc((size_t)n); need_old.upload(h_need.data(), (size_t)n, st);
     MM_HIP(hipStreamSynchronize(st));                            // h_need is the source of the async upload
   }
+  hl("K3 prep (need_old etc.)");
   const size_t t_pg = T.begin(&M->stats.ms_probe_gather);
   M->read_hit_off.alloc((size_t)n + 1);
   uint64_t raw_hits = 0;
@@ -1078,6 +1157,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     stage_off.alloc((size_t)n + 1); stage_off.upload(h_stage_off.data(), h_stage_off.size(), st);
     stage.alloc((size_t)std::max<uint64_t>(h_stage_off[(size_t)n], 1));
     MM_HIP(hipStreamSynchronize(st));                            // h_stage_off is the source of the async upload
+    hl("K3 stage_off loop + upload");
     if (use_fused && n_fused > 0) {
       const size_t lds = sizeof(SeedFilterLds);
       MM_HIP(hipFuncSetAttribute((const void*)seed_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1114,7 +1194,9 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     read_hit_bounds_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(M->mz.off.p, hit_off.p, n, M->read_hit_off.p);
     MM_KERNEL_CHECK();
   }
+  hl("K3 launches");
   M->h_read_hit_off = M->read_hit_off.to_host(st);
+  hl("K3 wait + hit_off download");
   const int64_t total_hits = (int64_t)M->h_read_hit_off[(size_t)n];
   M->stats.sum_hits = (int64_t)raw_hits;
   M->stats.sum_hits_kept = total_hits;
@@ -1131,8 +1213,9 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   if (total_hits > 0) {
     const size_t t_sh = T.begin(&M->stats.ms_sort_hits);
     // ---- K4a
-    std::vector<int64_t> hc((size_t)n);
-    for (int64_t r = 0; r < n; ++r) hc[(size_t)r] = (int64_t)(M->h_read_hit_off[(size_t)r + 1] - M->h_read_hit_off[(size_t)r]);
+    hl("K4 hits alloc + emit launch");
+    std::vector<int64_t> hc;                                      // hit counts of the reads the LDS radix sort does not take
+    auto hits_of = [&](int64_t r) -> int64_t { return (int64_t)(M->h_read_hit_off[(size_t)r + 1] - M->h_read_hit_off[(size_t)r]); };
     // beyond 4096 hits the device's segmented radix sort is faster (50 kb reads: 7.9 -> 7.0 ms); below, the LDS network (10 kb: 2.2 vs 3.9 ms)
     const char* ss_env = getenv("MM_SEGSORT_FROM");
     const int segsort_from = std::min(ss_env ? atoi(ss_env) : 4096, LDS_SORT_MAX);
@@ -1141,21 +1224,26 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     // up to 4096 hits per read: LDS radix sort, the reads grouped by the elements per thread they need
     int key_bits = 32; while (key_bits < 64 && ((int64_t)1 << (key_bits - 32)) < I->n_contigs) ++key_bits;
     const bool use_radix = !getenv("MM_HITS_BITONIC");
+    bool any_left = !use_radix;
     if (use_radix) {
       static const int ipts[] = {1, 2, 3, 4, 6, 8, 12, 16};
-      std::map<int, std::vector<int32_t>> by_ipt;
-      for (int64_t r = 0; r < n; ++r) {
-        const int64_t c = hc[(size_t)r];
-        if (c <= 1 || c > 4096) continue;
-        const int need = (int)((c + 255) / 256); int ip = 16; for (int v : ipts) if (v >= need) { ip = v; break; }
-        by_ipt[ip].push_back((int32_t)r);
-      }
-      std::vector<int32_t> ordered; std::vector<std::pair<int, size_t>> runs;
-      for (auto& kv : by_ipt) { runs.emplace_back(kv.first, kv.second.size()); ordered.insert(ordered.end(), kv.second.begin(), kv.second.end()); }
-      DBuf<int32_t> list(std::max<size_t>(ordered.size(), 1));
-      list.upload(ordered.data(), ordered.size(), st);
+      uint8_t cls_of_need[18];                                    // elements per thread needed -> index into ipts; [17]: beyond 4096 hits
+      for (int need = 0, i = 0; need <= 16; ++need) { while (ipts[i] < need) ++i; cls_of_need[need] = (uint8_t)i; }
+      cls_of_need[17] = 8;
+      uint64_t left_seen = 0;
+      const ReadBins RB = bin_reads(n, 8, [&](int64_t r) -> int {
+        const uint64_t c = (uint64_t)hits_of(r);
+        left_seen |= (uint64_t)(c > 4096);
+        const unsigned k = cls_of_need[std::min<uint64_t>((c + 255) / 256, 17)];
+        return c <= 1 ? 8 : (int)k;                              // zero or one hit: nothing to sort
+      });
+      any_left = left_seen != 0;
+      hl("K4 bin");
+      DBuf<int32_t> list(std::max<size_t>(RB.order.size(), 1));
+      list.upload(RB.order.data(), RB.order.size(), st);
+      hl("K4 list upload");
       size_t at = 0;
-      for (auto& run : runs) {
+      for (auto& run : RB.runs) {
         const int32_t* lp = list.p + at;
         auto launch = [&](auto tag) {
           constexpr int IPT = decltype(tag)::value;
@@ -1164,7 +1252,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           if (lds > 48 * 1024) MM_HIP(hipFuncSetAttribute((const void*)sort_hits_radix_kernel<IPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           sort_hits_radix_kernel<IPT><<<dim3((unsigned)run.second), dim3(256), lds, st>>>(M->hits.p, M->read_hit_off.p, lp, key_bits, use_filter ? stage.p : nullptr, use_filter ? stage_off.p : nullptr);
         };
-        switch (run.first) {
+        switch (ipts[run.first]) {
           case 1: launch(std::integral_constant<int, 1>{}); break;
           case 2: launch(std::integral_constant<int, 2>{}); break;
           case 3: launch(std::integral_constant<int, 3>{}); break;
@@ -1177,8 +1265,11 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         MM_KERNEL_CHECK();
         at += run.second;
       }
-      MM_HIP(hipStreamSynchronize(st));                          // `ordered` is the source of the async upload
-      for (auto& c : hc) if (c <= 4096) c = 0;                   // done: the loops below only see the longer lists
+      MM_HIP(hipStreamSynchronize(st));                          // RB.order is the source of the async upload
+    }
+    if (any_left) {                                              // the loops below only see the longer lists
+      hc.assign((size_t)n, 0);
+      for (int64_t r = 0; r < n; ++r) { const int64_t c = hits_of(r); if (!use_radix || c > 4096) hc[(size_t)r] = c; }
     }
     for (auto& cls : make_classes(hc, 256)) {
       if (cls.npow2 > segsort_from && seg_ok) { seg_reads.insert(seg_reads.end(), cls.reads.begin(), cls.reads.end()); continue; }
@@ -1244,6 +1335,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     }
     T.end(t_sh);
   }
+  hl("K4 launches + sync");
   // ---- K4b
   const size_t t_l1 = T.begin(&M->stats.ms_l1_scan);
   const bool l1_serial = getenv("MM_L1_SERIAL") != nullptr;       // cross-check switch: the one-thread-per-read loop
@@ -1257,6 +1349,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   }
   exclusive_scan_u32_u64(cand_n.p, n, M->cand_off.p, scan_tmp, st);
   M->h_cand_off = M->cand_off.to_host(st, (size_t)n + 1);
+  hl("L1 count + cand_off download");
   const int64_t ncand = (int64_t)M->h_cand_off[(size_t)n];
   M->n_cand = ncand;
   M->stats.n_candidates = ncand;
@@ -1274,11 +1367,29 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     const int smax = M->smax;
     const char* full_env = getenv("MM_L2_FULL");                 // cross-check switch: evaluate every window
     const bool skip = !(full_env && full_env[0] == '1');
+    // sketches from this size on take the dense path (MM_L2_DENSE_FROM: experiments; MM_L2_NO_DENSE=1: the LDS classes / literal automaton)
+    const bool use_dense = !getenv("MM_L2_NO_DENSE");
+    // (from ~58 kb reads on the streamed range of a candidate outgrows the 32 768-entry masks of the LDS classes' exact skip-ahead, which
+    //  then evaluate every window with a rebuild per zone exit: 6 000 reads of 60-73 kb: 171 ms there, 83 ms here)
+    const int dense_from = getenv("MM_L2_DENSE_FROM") ? atoi(getenv("MM_L2_DENSE_FROM")) : 13000;
+    const bool no_small_groups = getenv("MM_L2_NO_SMALL_GROUPS") != nullptr;   // cross-check / timing switch
+    // the workgroups of the 10 kb class are put together on the device while the L1 kernel above still runs (l2_group_kernel);
+    // MM_L2_HOST_GROUPS=1: the host loop makes them as well (cross-check)
+    const bool dev_groups = skip && !getenv("MM_L2_HOST_GROUPS");
+    DBuf<int32_t> d_gA0, d_gAn, d_gS0, d_gSn;
+    DBuf<unsigned int> grp_ctr(4);
+    if (dev_groups) {
+      d_gA0.alloc((size_t)ncand); d_gAn.alloc((size_t)ncand); d_gS0.alloc((size_t)ncand); d_gSn.alloc((size_t)ncand);
+      grp_ctr.zero(st);
+      l2_group_kernel<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st>>>(M->cand_off.p, M->sk_n.p, M->d_read_len.p, n, P.w + P.k + 1, use_dense ? dense_from : INT_MAX,
+                                                                            no_small_groups ? 1 : 0, d_gA0.p, d_gAn.p, d_gS0.p, d_gSn.p, grp_ctr.p);
+      MM_KERNEL_CHECK();
+    }
     const size_t lds_wide = l2_lds_bytes<uint16_t>(smax, skip, 1, 8);
     // Sketches of >= 32768 hashes (L2_SKETCH_LIMIT): the rebuild's 1024-bucket histogram would be as coarse as the 64-rank pivot
     // zone, and the window state of the full slide no longer fits LDS either -> l2_giant_kernel, state in global memory.
     std::vector<int32_t> listG; int smG = 0;
-    for (int64_t r = 0; r < n; ++r) {
+    for (int64_t r = 0; r < n && M->stats.n_reads_giant > 0; ++r) {
       const int sr = M->h_sk_n[(size_t)r];
       if (sr < L2_SKETCH_LIMIT) continue;
       smG = std::max(smG, sr);
@@ -1329,11 +1440,6 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       MM_KERNEL_CHECK();
       MM_HIP(hipStreamSynchronize(st));                          // host vectors above are upload sources; the buffers die with this scope
     };
-    // sketches from this size on take the dense path (MM_L2_DENSE_FROM: experiments; MM_L2_NO_DENSE=1: the LDS classes / literal automaton)
-    const bool use_dense = !getenv("MM_L2_NO_DENSE");
-    // (from ~58 kb reads on the streamed range of a candidate outgrows the 32 768-entry masks of the LDS classes' exact skip-ahead, which
-    //  then evaluate every window with a rebuild per zone exit: 6 000 reads of 60-73 kb: 171 ms there, 83 ms here)
-    const int dense_from = getenv("MM_L2_DENSE_FROM") ? atoi(getenv("MM_L2_DENSE_FROM")) : 13000;
     DBuf<int32_t> d_listG(listG.size());
     DBuf<uint32_t> giant_scratch;
     if (!listG.empty() && use_dense) run_dense(listG, smG);
@@ -1373,14 +1479,18 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         if (getenv("MM_L2_NO_CODES")) return nullptr;              // cross-check switch
         return ctx->l2_codes_at_least(n_waves * (size_t)(64 * 64 * nwq) * (nwq == 2 ? sizeof(uint16_t) : sizeof(uint32_t)));
       };
-      const bool no_small_groups = getenv("MM_L2_NO_SMALL_GROUPS") != nullptr;   // cross-check / timing switch
       std::vector<int32_t> gA0, gAn, gB0, gBn, gD0, gDn, listC, gS0, gSn;   // gS: groups of one or two candidates of the 10 kb class (two-wave workgroups)
       int smA = 0, smB = 0, smC = 0, smD = 0;
       std::vector<int32_t> listL; int smL = 0;                    // long reads below the giant class that take the dense path
-      for (int64_t r = 0; r < n; ++r) {
+      hl("K5 prep before grouping");
+      std::vector<unsigned int> gctr(4, 0);
+      if (dev_groups) gctr = grp_ctr.to_host(st);                 // (waits for the L1 kernel and the grouping kernel)
+      smA = (int)gctr[3];
+      for (int64_t r = 0; r < n && (!dev_groups || gctr[2] > 0); ++r) {   // the host's classes: everything the device did not group
         const uint64_t c_lo = M->h_cand_off[(size_t)r], c_hi = M->h_cand_off[(size_t)r + 1];
         if (c_lo == c_hi) continue;
         const int sr = M->h_sk_n[(size_t)r];
+        if (dev_groups && sr <= 3072 && !(use_dense && sr >= dense_from && sr < L2_SKETCH_LIMIT && M->read_len[(size_t)r] >= P.w + P.k + 1)) continue;
         if (use_dense && sr >= dense_from && sr < L2_SKETCH_LIMIT && M->read_len[(size_t)r] >= P.w + P.k + 1) {
           smL = std::max(smL, sr);
           for (uint64_t c0 = c_lo; c0 < c_hi; ++c0) listL.push_back((int32_t)c0);
@@ -1404,23 +1514,27 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           for (uint64_t c0 = c_lo; c0 < c_hi; ++c0) listC.push_back((int32_t)c0);
         }                                                        // (larger: listG above)
       }
+      hl("K5 grouping");
       run_dense(listL, smL);
-      DBuf<int32_t> d_gA0(gA0.size()), d_gAn(gAn.size()), d_gB0(gB0.size()), d_gBn(gBn.size()), d_listC(listC.size());
-      if (!gA0.empty()) {
-        d_gA0.upload(gA0.data(), gA0.size(), st); d_gAn.upload(gAn.data(), gAn.size(), st);
+      DBuf<int32_t> d_gB0(gB0.size()), d_gBn(gBn.size()), d_listC(listC.size());
+      size_t nA = gctr[0], nS = gctr[1];
+      if (!dev_groups) {
+        nA = gA0.size(); nS = gS0.size();
+        d_gA0.alloc(std::max<size_t>(nA, 1)); d_gAn.alloc(std::max<size_t>(nA, 1)); d_gS0.alloc(std::max<size_t>(nS, 1)); d_gSn.alloc(std::max<size_t>(nS, 1));
+        d_gA0.upload(gA0.data(), nA, st); d_gAn.upload(gAn.data(), nA, st); d_gS0.upload(gS0.data(), nS, st); d_gSn.upload(gSn.data(), nS, st);
+      }
+      if (nA) {
         const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 4, 2);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 2>, lds);
-        l2_kernel<true, uint8_t, 4, 2><<<dim3((unsigned)gA0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gA0.size() * 4, 2), masks_for(gA0.size() * 4, 2));
+        l2_kernel<true, uint8_t, 4, 2><<<dim3((unsigned)nA), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(nA * 4, 2), masks_for(nA * 4, 2));
         MM_KERNEL_CHECK();
       }
-      DBuf<int32_t> d_gS0(gS0.size()), d_gSn(gSn.size());
-      if (!gS0.empty()) {
-        d_gS0.upload(gS0.data(), gS0.size(), st); d_gSn.upload(gSn.data(), gSn.size(), st);
+      if (nS) {
         const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 2, 2);
         set_lds((const void*)l2_kernel<true, uint8_t, 2, 2>, lds);
-        l2_kernel<true, uint8_t, 2, 2><<<dim3((unsigned)gS0.size()), dim3(128), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gS0.p, d_gSn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gS0.size() * 2, 2), masks_for(gS0.size() * 2, 2));
+        l2_kernel<true, uint8_t, 2, 2><<<dim3((unsigned)nS), dim3(128), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gS0.p, d_gSn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(nS * 2, 2), masks_for(nS * 2, 2));
         MM_KERNEL_CHECK();
       }
       if (!gB0.empty()) {
@@ -1448,6 +1562,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
             M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smC, M->l2.p, counters.p, nullptr, nullptr, d_listC.p, ovf.p, ovf_n.p, amb_used_p, nullptr, masks_for(listC.size()));
         MM_KERNEL_CHECK();
       }
+      hl("K5 uploads + launches");
       // candidates the skip kernels hand back (reads shorter than w+k): the literal full slide
       int64_t n_fallback = 0;
       auto run_fallback = [&](uint8_t* amb_ptr) {
@@ -1492,6 +1607,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     l2_stats_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(ncand, 256), 1024)), dim3(256), 0, st>>>(M->l2.p, ncand, counters.p);
     MM_KERNEL_CHECK();
     T.end(t_l2);
+    hl("K5 wait");
     auto hc = counters.to_host(st);
     M->stats.sum_l2_stream_entries = (int64_t)hc[0];
     M->stats.sum_l2_evals = (int64_t)hc[1];

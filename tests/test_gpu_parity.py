@@ -258,6 +258,35 @@ def test_l2_skip_ahead_equals_full_slide(ctx, monkeypatch):
     idx.close(); reads.close(); ref.close()
 
 
+def test_l2_device_made_workgroups_equal_host_made(ctx, monkeypatch):
+    """K5's workgroups of the 10 kb class are put together by l2_group_kernel; MM_L2_HOST_GROUPS=1 makes them in the host loop, and
+    MM_L2_NO_SMALL_GROUPS=1 sends remainders of one or two candidates to four-wave workgroups: identical records and work counters.
+    Mixed read lengths, so that the host's classes (longer sketches) and the device's lists are both in use in one batch."""
+    ref = ctx.synth_reference(seed=15, n_species=40, strains_per_species=5, genome_len=300_000, strain_divergence=0.02, genus_divergence=0.08)
+    idx = ctx.index(ref, 16, 8)
+    for read_len, len_min in ((7000, None), (30000, 800)):
+        kw = dict(seed=19, n_reads=2500, read_len=read_len, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=30)
+        if len_min: kw["read_len_min"] = len_min
+        reads, _ = ctx.synth_reads(ref, **kw)
+        res = {}
+        for mode in ("device", "host", "host_nosmall", "device_nosmall"):
+            if mode.startswith("host"): monkeypatch.setenv("MM_L2_HOST_GROUPS", "1")
+            if mode.endswith("nosmall"): monkeypatch.setenv("MM_L2_NO_SMALL_GROUPS", "1")
+            M = ctx.map_batch(idx, reads, 16, 8)
+            off, rec = M.fetch()
+            res[mode] = (off.copy(), rec.copy(), M.stats())
+            M.close()
+            monkeypatch.delenv("MM_L2_HOST_GROUPS", raising=False); monkeypatch.delenv("MM_L2_NO_SMALL_GROUPS", raising=False)
+        for mode in ("host", "host_nosmall", "device_nosmall"):
+            assert np.array_equal(res["device"][0], res[mode][0]), mode
+            assert np.array_equal(res["device"][1], res[mode][1]), mode
+            for key in ("n_candidates", "sum_l2_stream_entries", "sum_l2_evals", "n_l2_rebuilds"):
+                assert res["device"][2][key] == res[mode][2][key], (mode, key)
+        assert res["device"][2]["n_mappings"] > 2000
+        reads.close()
+    idx.close(); ref.close()
+
+
 def test_hit_prefilter_keeps_candidates_identical(ctx, monkeypatch):
     """K3c drops seed hits that cannot belong to a qualifying run; candidates and mappings must not change."""
     ref = ctx.synth_reference(seed=6, n_species=40, strains_per_species=4, genome_len=300_000, strain_divergence=0.02, genus_divergence=0.08)

@@ -58,6 +58,9 @@ def parse_args():
                     help="host threads / contexts per GPU that take the steps in turn: while one runs the EM iterations, result download and host "
                          "bookkeeping of its step, the next step's mapping kernels run (the mapping sections themselves are serialised, so that "
                          "kernel durations — the roofline — are those of kernels that own the GPU)")
+    ap.add_argument("--staged-map", action="store_true", help="two locks instead of one around the mapping section (K1 + K2 | K3 ... K6, swapped at mm_map_batch_phased's "
+                    "callback): the next step's minimizer stage runs under this step's seed stage; ~2 percent more throughput, but the seed filter's "
+                    "duration then includes the time it shares the CUs (K1 issues VALU instructions in 99 percent of its cycles: the two do not complement each other)")
     ap.add_argument("--free-overlap", action="store_true", help="do not serialise the mapping sections of the workers (higher throughput, kernel durations inflated)")
     ap.add_argument("--measure-free-overlap", action="store_true", help="after the timed region, six more steps with nothing serialised, reported in config.free_overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -147,19 +150,36 @@ def main():
         agg = {"ms_l2": 0.0, "ms_hf": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0, "stats": None, "em_iters": 0}
         rec_bufs = [np.empty(max(64 * args.reads, 1 << 16), dtype=capi.RECORD_DTYPE) for _ in ctxs]   # host result buffers reused by every step
         map_lock, agg_lock = threading.Lock(), threading.Lock()
+        front_lock, back_lock = threading.Lock(), threading.Lock()
         em_turn = {"next": 0, "cv": threading.Condition()}
 
         def step(wi, serialise=True, ticket=0):
+            """serialise: "staged" (default) — one lock for K1 + K2, one for K3 ... K6 + mapping qualities, swapped at mm_map_batch_phased's
+            callback: the next step's minimizer stage starts when this step's seed stage does and runs under it (K1: integer multiplier,
+            K3: memory requests), everything from K4 on owns the GPU; "serial" (True): one lock around the whole mapping section;
+            False: nothing serialised"""
             c = ctxs[wi]
             tt = [time.perf_counter()]
-            if serialise:
+            staged = serialise == "staged"
+            swapped = [False]
+            def swap():
+                back_lock.acquire(); front_lock.release(); swapped[0] = True
+            if staged:
+                front_lock.acquire()
+            elif serialise:
                 map_lock.acquire()
             try:
-                M = c.map_batch(idx, reads_w[wi], k, w, pi=80.0, min_read_len=1000)
+                try:
+                    M = c.map_batch(idx, reads_w[wi], k, w, pi=80.0, min_read_len=1000, at_seed_stage=swap if staged else None)
+                finally:
+                    if staged and not swapped[0]:
+                        swap()
                 tt.append(time.perf_counter())
                 M.add_qualities(k)
             finally:
-                if serialise:
+                if staged:
+                    back_lock.release()
+                elif serialise:
                     map_lock.release()
             off, rec = M.fetch(rec_bufs[wi])
             st = M.stats()
@@ -207,11 +227,12 @@ def main():
 
         for wi in range(1, W):                                    # setup: every further worker context runs once (its scratch buffers get allocated)
             step(wi, True, 0); em_turn["next"] = 0
-        run_steps(max(warmup, 0))
+        sched = False if args.free_overlap else ("staged" if (args.staged_map and W > 1) else True)
+        run_steps(max(warmup, 0), sched)
         agg.update({"ms_l2": 0.0, "ms_hf": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0})
         barrier()
         t0 = time.perf_counter()
-        run_steps(steps, not args.free_overlap)
+        run_steps(steps, sched)
         barrier()
         dt = time.perf_counter() - t0
         st = agg["stats"]
@@ -263,7 +284,8 @@ def main():
                 "index_entries": info["n_entries"], "index_unique_hashes": info["n_unique_hashes"], "index_hbm_bytes": info["hbm_bytes"],
                 "freq_threshold": R["freq_threshold"], "reference_synth_s": round(R["t_ref"], 3), "index_build_s": round(R["t_index"], 3),
                 "parallelism": f"reads sharded x{world}, index replicated, RCCL all-reduce of EM sums; {W} worker contexts per GPU take the steps in turn"
-                               + (" (mapping sections serialised)" if W > 1 and not args.free_overlap else ""),
+                               + ("" if W == 1 or args.free_overlap else (" (mapping sections serialised)" if not args.staged_map else
+                                  " (the minimizer + sketch stage of step i+1 runs under the seed stage of step i; everything from the hit sort on owns the GPU)")),
                 "workers_per_gpu": W, "free_overlap": R["free"],
                 "em_iterations": agg["em_iters"],
                 "per_step": {kk: st[kk] for kk in ("n_reads_long_enough", "n_reads_mapped", "n_mappings", "sum_sketch", "sum_hits",

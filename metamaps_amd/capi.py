@@ -25,6 +25,9 @@ class MMError(RuntimeError):
         self.status = status
 
 
+SEED_STAGE_CB = C.CFUNCTYPE(None, C.c_void_p)
+
+
 class MapParams(C.Structure):
     _fields_ = [("k", C.c_int32), ("w", C.c_int32), ("perc_identity", C.c_float), ("min_read_len", C.c_int32)]
 
@@ -127,6 +130,7 @@ def lib() -> C.CDLL:
             "mm_min_hits_relaxed": (C.c_int, [C.c_int, C.c_int, f32]),
             "mm_identity": (None, [C.c_int, C.c_int, C.c_int, P(f32), P(f32)]),
             "mm_map_batch": (C.c_int, [vp, vp, vp, P(MapParams), P(vp)]),
+            "mm_map_batch_phased": (C.c_int, [vp, vp, vp, P(MapParams), SEED_STAGE_CB, vp, P(vp)]),
             "mm_mapping_destroy": (None, [vp]),
             "mm_mapping_get_stats": (C.c_int, [vp, P(MapStats)]),
             "mm_mapping_release_intermediates": (C.c_int, [vp]),
@@ -258,10 +262,15 @@ class Context:
             idx.set_freq_threshold(thr)
         return idx
 
-    def map_batch(self, idx: "Index", reads: "SeqSet", k: int, w: int, pi: float = 80.0, min_read_len: int = 1000) -> "Mapping":
+    def map_batch(self, idx: "Index", reads: "SeqSet", k: int, w: int, pi: float = 80.0, min_read_len: int = 1000, at_seed_stage=None) -> "Mapping":
+        """at_seed_stage: callable run once between the sketch stage and the seed stage (mm_map_batch_phased)"""
         p = MapParams(k, w, pi, min_read_len)
         h = C.c_void_p()
-        self.check(lib().mm_map_batch(self.h, idx.h, reads.h, C.byref(p), C.byref(h)))
+        if at_seed_stage is None:
+            self.check(lib().mm_map_batch(self.h, idx.h, reads.h, C.byref(p), C.byref(h)))
+        else:
+            cb = SEED_STAGE_CB(lambda _user: at_seed_stage())
+            self.check(lib().mm_map_batch_phased(self.h, idx.h, reads.h, C.byref(p), cb, None, C.byref(h)))
         return Mapping(self, h, reads.count)
 
     def em(self, read_off, taxon, mapq, inv_nloc, n_taxa: int) -> "EM":

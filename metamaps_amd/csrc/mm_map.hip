@@ -1005,6 +1005,8 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   }
   HostLap hl;
   M->h_sk_n = M->sk_n.to_host(st, (size_t)n);
+  // mm_map_batch_phased: K1 + K2 are complete (the download above waited for them), nothing of the seed stage is enqueued yet
+  if (M->at_seed_stage) { auto cb = M->at_seed_stage; M->at_seed_stage = nullptr; cb(M->at_seed_stage_user); }
   std::vector<uint8_t> h_amb = M->amb.to_host(st, (size_t)n);
   hl("post-K2 downloads");
   {

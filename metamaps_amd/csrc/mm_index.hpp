@@ -46,6 +46,7 @@ struct mm_index {
 namespace mm {
 
 constexpr int HF_BIN_SHIFT = 13, HF_SLOTS = 8192;              // seed-hit filter: 8192-base position bins, counted modulo 8192 bins
+constexpr int HF_SLOT_BITS_NARROW = 13, HF_SLOT_BITS_WIDE = 15; // ... or, for long reads, modulo 32768 slots (mm_map.hip, hit_filter_kernel)
 
 struct IndexView {
   const Rec* pos;

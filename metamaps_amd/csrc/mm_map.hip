@@ -237,89 +237,116 @@ __global__ void __launch_bounds__(256) gather_hits_kernel(IndexView I, const uin
 // read a quarter of the list bytes, mostly one 64-byte sector per list, and only survivors touch occ[] itself.
 // ---------------------------------------------------------------------------------------------------
 // survivors are staged per read (8 B each, capacity 1024 + 2 x sketch size: stage_off); reads with more are re-filtered by the write kernel
-template <bool WRITE>
-__global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint64_t* __restrict__ off, const int32_t* __restrict__ sk_n,
+// Two slot tables: 8 192 slots counted from the 13-bit codes of occ16[] (reads up to ~32 kb), and 32 768 slots counted from the
+// entries of occ[] themselves (slot = position bin + a per-contig offset) for longer reads.  Chance hits grow with the read length and
+// so does the window, so with 8 192 slots a 100 kb read (3.8*10^5 seed hits against the bench reference) has 650 hits in every
+// window — above minimumHits everywhere, nothing is dropped, K4 sorts 1.5*10^9 hits per 4 000 reads; 32 768 slots keep the
+// background a factor of four lower, below the threshold.  Any slot function that keeps neighbouring bins of a contig neighbours is
+// a valid (superset) filter; pass 1 and the write pass of a read use the same table.  `cls[r]`: 0 fused kernel, 1 narrow, 2 wide.
+template <int SLOT_BITS> struct HitFilterCfg {
+  static constexpr int SLOTS = 1 << SLOT_BITS, THREADS = SLOTS / 32;
+  static constexpr int EPL = SLOT_BITS == HF_SLOT_BITS_NARROW ? 8 : 2;   // entries per 16-byte load of a lane
+  static constexpr int CLS = SLOT_BITS == HF_SLOT_BITS_NARROW ? 1 : 2;
+  static constexpr size_t LDS = (size_t)SLOTS * 4 + (size_t)THREADS * 8 + 16;
+};
+template <bool WRITE, int SLOT_BITS>
+__global__ void __launch_bounds__(HitFilterCfg<SLOT_BITS>::THREADS) hit_filter_kernel(IndexView I, const uint64_t* __restrict__ off, const int32_t* __restrict__ sk_n,
                                                          const uint32_t* __restrict__ probe_cnt, const uint64_t* __restrict__ probe_start,
                                                          const int32_t* __restrict__ read_len, const int32_t* __restrict__ min_hits,
                                                          uint32_t* __restrict__ surv_n, const uint64_t* __restrict__ read_hit_off,
                                                          uint64_t* __restrict__ hits, uint64_t* __restrict__ stage, const uint64_t* __restrict__ stage_off, int dbg,
-                                                         const uint8_t* __restrict__ only /* optional (WRITE = false): reads to do */,
+                                                         const uint8_t* __restrict__ cls /* per read: which kernel filters it */,
                                                          uint32_t* __restrict__ raw_hits /* optional (WRITE = false): seed hits of the read before filtering */) {
-  __shared__ uint32_t cnt[HF_SLOTS];
-  __shared__ uint32_t good[HF_SLOTS / 32], alive[HF_SLOTS / 32];
-  __shared__ uint32_t cursor;
+  using Cfg = HitFilterCfg<SLOT_BITS>;
+  constexpr int SLOTS = Cfg::SLOTS, THREADS = Cfg::THREADS, EPL = Cfg::EPL;
+  constexpr bool NARROW = SLOT_BITS == HF_SLOT_BITS_NARROW;
+  extern __shared__ __align__(16) uint32_t hf_lds[];
+  uint32_t* const cnt = hf_lds;                                   // [SLOTS]
+  uint32_t* const good = cnt + SLOTS;                             // [THREADS]
+  uint32_t* const alive = good + THREADS;                         // [THREADS]
+  uint32_t& cursor = alive[THREADS];
   const int r = blockIdx.x;
-  if (!WRITE && only && !only[r]) return;
+  const int my_cls = cls[r];
+  if (!WRITE && my_cls != Cfg::CLS) return;
+  if (WRITE && (my_cls == 2) != (Cfg::CLS == 2)) return;         // (reads of the fused kernel whose stage overflowed are re-filtered by the narrow kernel)
   if (WRITE) {                                                   // staged reads only need a copy
     const uint32_t n_s = surv_n[r];
     if (n_s <= (uint32_t)(stage_off[r + 1] - stage_off[r])) {
       if (dbg == 100 && n_s >= 2u && n_s <= 4096u) return;        // (dbg 100: the LDS radix sort takes these straight from the stage)
       const uint64_t wb = read_hit_off[r];
-      for (uint32_t i = threadIdx.x; i < n_s; i += 256) hits[wb + i] = stage[stage_off[r] + i];
+      for (uint32_t i = threadIdx.x; i < n_s; i += THREADS) hits[wb + i] = stage[stage_off[r] + i];
       return;
     }
   }
   const uint64_t o = off[r];
   const int s = sk_n[r];
   const uint32_t len = (uint32_t)max(read_len[r], 1);
-  const int nb = min((int)((len - 1) >> HF_BIN_SHIFT) + 2, HF_SLOTS);
+  const int nb = min((int)((len - 1) >> HF_BIN_SHIFT) + 2, SLOTS);
   int m = min_hits[r]; if (m < 1) m = 1;
-  for (int i = threadIdx.x; i < HF_SLOTS; i += 256) cnt[i] = 0;
+  for (int i = threadIdx.x; i < SLOTS; i += THREADS) cnt[i] = 0;
   if (threadIdx.x == 0) cursor = 0;
   __syncthreads();
-  // One occurrence list per group of 4 lanes, one 16-byte load (8 bin codes) per lane: a list of up to 32 entries is a
+  // One occurrence list per group of 4 lanes, one 16-byte load per lane (8 bin codes, or 2 entries): a list of up to 32 codes is a
   // single request of at most 64 bytes.  Random reads are bound by requests, not bytes (tools/ubench/randread), so the
-  // lists of a group are software-pipelined: count/start three lists ahead, codes two ahead.
+  // lists of a group are software-pipelined: count/start three lists ahead, data two ahead.
+  constexpr int GROUPS = THREADS / 4, PER_REQ = 4 * EPL;
   const int grp = threadIdx.x >> 2, sub = threadIdx.x & 3;
-  // fn(c, st0, j0, v): lane `sub` of the group holds the codes of entries j0 + 8*sub .. +7 of a list of c entries that starts
+  // fn(c, st0, j0, v): lane `sub` of the group holds entries j0 + EPL*sub .. +EPL-1 of a list of c entries that starts
   // at occ[st0]; called by all lanes of the wave together (c == 0: nothing), so that fn may use wave-wide operations
   auto for_each_chunk = [&](auto&& fn) {
     auto meta = [&](int i, uint32_t& c, uint64_t& st0) { c = 0; st0 = 0; if (i < s) { c = probe_cnt[o + i]; st0 = probe_start[o + i]; } };
     auto issue = [&](uint32_t c, uint64_t st0, uint32_t j0, ulonglong2& v) {   // (clamped into the padded list)
-      if (c) v = *reinterpret_cast<const ulonglong2*>(I.occ16 + st0 + min(j0 + 8u * sub, (c - 1) & ~7u));
+      if (c) {
+        const uint64_t e = st0 + min(j0 + (uint32_t)EPL * sub, (c - 1) & ~(uint32_t)(EPL - 1));
+        v = NARROW ? *reinterpret_cast<const ulonglong2*>(I.occ16 + e) : *reinterpret_cast<const ulonglong2*>(I.occ + e);
+      }
     };
     uint32_t c0, c1, c2, c3; uint64_t s0, s1, s2, s3;
     ulonglong2 v0 = make_ulonglong2(0, 0), v1 = v0, v2 = v0;
-    meta(grp, c0, s0); meta(grp + 64, c1, s1); meta(grp + 128, c2, s2);
+    meta(grp, c0, s0); meta(grp + GROUPS, c1, s1); meta(grp + 2 * GROUPS, c2, s2);
     issue(c0, s0, 0, v0); issue(c1, s1, 0, v1);
-    for (int ib = 0; ib < s; ib += 64) {                         // (wave-uniform trip count)
-      meta(ib + grp + 192, c3, s3);
+    for (int ib = 0; ib < s; ib += GROUPS) {                     // (wave-uniform trip count)
+      meta(ib + grp + 3 * GROUPS, c3, s3);
       issue(c2, s2, 0, v2);
       fn(c0, s0, 0u, v0);
-      for (uint32_t j0 = 32; __any(j0 < c0); j0 += 32) {         // long lists: the rest
+      for (uint32_t j0 = PER_REQ; __any(j0 < c0); j0 += PER_REQ) {   // long lists: the rest
         const uint32_t cl = j0 < c0 ? c0 : 0u;
         ulonglong2 v = make_ulonglong2(0, 0); issue(cl, s0, j0, v); fn(cl, s0, j0, v);
       }
       c0 = c1; s0 = s1; v0 = v1; c1 = c2; s1 = s2; v1 = v2; c2 = c3; s2 = s3;
     }
   };
-  auto code_of = [](const ulonglong2& v, int t) { return (uint32_t)((t < 4 ? v.x : v.y) >> (16 * (t & 3))) & (uint32_t)(HF_SLOTS - 1); };
+  auto code_of = [](const ulonglong2& v, int t) -> uint32_t {
+    if (NARROW) return (uint32_t)((t < 4 ? v.x : v.y) >> (16 * (t & 3))) & (uint32_t)(SLOTS - 1);
+    const uint64_t e = t ? v.y : v.x;                            // contig << 32 | wpos << 3 | flags
+    return (((uint32_t)e >> (3 + HF_BIN_SHIFT)) + (uint32_t)(e >> 32) * 40503u) & (uint32_t)(SLOTS - 1);
+  };
   if (dbg == 2) {
     uint32_t a = 0;
-    for_each_chunk([&](uint32_t c, uint64_t, uint32_t j0, const ulonglong2& v) { for (int t = 0; t < 8; ++t) if (j0 + 8u * sub + t < c) a += code_of(v, t); });
+    for_each_chunk([&](uint32_t c, uint64_t, uint32_t j0, const ulonglong2& v) { for (int t = 0; t < EPL; ++t) if (j0 + (uint32_t)EPL * sub + t < c) a += code_of(v, t); });
     if (a == 0x12345678u) cnt[0] = 1;
   } else for_each_chunk([&](uint32_t c, uint64_t, uint32_t j0, const ulonglong2& v) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) if (j0 + 8u * sub + t < c) atomicAdd(&cnt[code_of(v, t)], 1u);
+    for (int t = 0; t < EPL; ++t) if (j0 + (uint32_t)EPL * sub + t < c) atomicAdd(&cnt[code_of(v, t)], 1u);
   });
   __syncthreads();
   if (dbg == 1 || dbg == 2) { if (!WRITE && threadIdx.x == 0) surv_n[r] = 0; return; }   // timing aid (MM_HF_DBG): pass 1 only
   {
     // good[b]: the window of nb bins starting at b holds >= m hits (sliding sum over this thread's 32 window starts);
-    // alive[b]: some good window contains b, i.e. good dilated by nb positions (all modulo 8192 bins)
+    // alive[b]: some good window contains b, i.e. good dilated by nb positions (all modulo the slot count)
     const int b0 = threadIdx.x * 32;
     uint32_t sum = 0, bits = 0;
-    for (int i = 0; i < nb; ++i) sum += cnt[(b0 + i) & (HF_SLOTS - 1)];
+    for (int i = 0; i < nb; ++i) sum += cnt[(b0 + i) & (SLOTS - 1)];
     for (int t = 0; t < 32; ++t) {
       bits |= (sum >= (uint32_t)m ? 1u : 0u) << t;
-      sum += cnt[(b0 + t + nb) & (HF_SLOTS - 1)] - cnt[(b0 + t) & (HF_SLOTS - 1)];
+      sum += cnt[(b0 + t + nb) & (SLOTS - 1)] - cnt[(b0 + t) & (SLOTS - 1)];
     }
     good[threadIdx.x] = bits;
     __syncthreads();
     uint32_t al = 0;
     for (int j = 0; j < nb; ++j) {                               // bit b of alive = OR over j < nb of good bit (b - j)
       const int wsh = j >> 5, bsh = j & 31;
-      const uint32_t g0 = good[(threadIdx.x - wsh) & 255], g1 = good[(threadIdx.x - wsh - 1) & 255];
+      const uint32_t g0 = good[(threadIdx.x - wsh) & (THREADS - 1)], g1 = good[(threadIdx.x - wsh - 1) & (THREADS - 1)];
       al |= bsh ? (g0 << bsh) | (g1 >> (32 - bsh)) : g0;
     }
     alive[threadIdx.x] = al;
@@ -335,10 +362,10 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   // an atomic per surviving entry would serialise the wave on LDS round trips.
   const int lane = threadIdx.x & 63;
   for_each_chunk([&](uint32_t c, uint64_t st0, uint32_t j0, const ulonglong2& v) {
-    const uint32_t e0 = j0 + 8u * sub;
+    const uint32_t e0 = j0 + (uint32_t)EPL * sub;
     uint32_t mask = 0;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) { const uint32_t b = code_of(v, t); mask |= ((e0 + t < c) ? (alive[b >> 5] >> (b & 31)) & 1u : 0u) << t; }
+    for (int t = 0; t < EPL; ++t) { const uint32_t b = code_of(v, t); mask |= ((e0 + t < c) ? (alive[b >> 5] >> (b & 31)) & 1u : 0u) << t; }
     if (dbg == 4) { if (mask == 0xdeadu) cnt[1] = 1; return; }   // timing aid: reads and bit tests only
     const int mine = __popc(mask);
     const int incl = wave_incl_scan(mine);
@@ -357,12 +384,12 @@ __global__ void __launch_bounds__(256) hit_filter_kernel(IndexView I, const uint
   __syncthreads();
   const uint32_t n_s = min(cursor, dst_cap);
   if (dbg == 3 || dbg == 4) { if (!WRITE && threadIdx.x == 0) surv_n[r] = 0; return; }   // timing aid: without the fetch of the survivors
-  for (uint32_t j = threadIdx.x; j < n_s; j += 256) dst[j] = I.occ[dst[j]] & ~(uint64_t)(PW_DP | PW_DN);
+  for (uint32_t j = threadIdx.x; j < n_s; j += THREADS) dst[j] = I.occ[dst[j]] & ~(uint64_t)(PW_DP | PW_DN);
   if (!WRITE && threadIdx.x == 0) surv_n[r] = cursor;
   if (!WRITE && raw_hits) {                                      // (the bin counters still hold every hit of the read)
     __syncthreads();
     uint32_t acc = 0;
-    for (int i = threadIdx.x; i < HF_SLOTS; i += 256) acc += cnt[i];
+    for (int i = threadIdx.x; i < SLOTS; i += THREADS) acc += cnt[i];
     for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&raw_hits[r], acc);
   }
@@ -1134,12 +1161,22 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   // the fused probe + filter kernel takes the reads whose sketch fits its LDS layout (MM_NO_FUSED_FILTER=1: cross-check switch)
   const bool use_fused = use_filter && !getenv("MM_NO_FUSED_FILTER");
   DBuf<uint8_t> need_old; DBuf<uint32_t> raw_per_read;
-  int64_t n_fused = 0;
+  int64_t n_fused = 0, n_wide = 0;
   if (use_filter && n > 0) { raw_per_read.alloc((size_t)n); raw_per_read.zero(st); }
   else if (total_mz > 0) probe_cnt.zero(st);                     // (unfiltered path: the offsets come from a scan over every slot)
-  if (use_fused && n > 0) {
+  if (use_filter && n > 0) {
+    // which kernel filters a read: 0 the fused kernel, 1 the two-pass kernels with 8 192 slots, 2 with 32 768 slots (sketches beyond
+    // MM_HF_WIDE_FROM hashes, default 13000 = reads from ~58 kb on; 0 switches the wide table off).  Measured on the bench reference:
+    // 45-58 kb reads 88.8 ms narrow / 91.2 ms wide per batch of 8 000 (the wide kernel reads 8-byte entries, three requests per list
+    // instead of one, on one workgroup per CU), 60-73 kb reads 873 / 125 ms per batch of 6 000, 75-140 kb 1 388 / 376 ms per 4 000.
+    const int wide_env = getenv("MM_HF_WIDE_FROM") ? atoi(getenv("MM_HF_WIDE_FROM")) : 13000;
+    const int wide_from = wide_env > 0 ? wide_env : INT_MAX;
     std::vector<uint8_t> h_need((size_t)n, 0);
-    for (int64_t r = 0; r < n; ++r) { h_need[(size_t)r] = M->h_sk_n[(size_t)r] > SF_SMAX ? 1 : 0; n_fused += !h_need[(size_t)r]; }
+    for (int64_t r = 0; r < n; ++r) {
+      const int sr = M->h_sk_n[(size_t)r];
+      const uint8_t c = sr > wide_from ? 2 : ((use_fused && sr <= SF_SMAX) ? 0 : 1);
+      h_need[(size_t)r] = c; n_fused += c == 0; n_wide += c == 2;
+    }
     need_old.alloc((size_t)n); need_old.upload(h_need.data(), (size_t)n, st);
     MM_HIP(hipStreamSynchronize(st));                            // h_need is the source of the async upload
   }
@@ -1170,7 +1207,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       T.end(t_sf);
     }
   }
-  const uint8_t* const only = use_fused ? need_old.p : nullptr;
+  const uint8_t* const only = (use_filter && n > 0) ? need_old.p : nullptr;
   if (n > 0 && total_mz > 0) {                                     // (reads the fused kernel flagged are only known on the device: the two-pass kernels always run and skip the rest)
     probe_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, only);
     MM_KERNEL_CHECK();
@@ -1183,9 +1220,17 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   if (use_filter && n > 0) {
     const bool time_old = !(use_fused && n_fused > 0);            // ms_hit_filter: the kernel that handles the bulk of the reads
     const size_t t_hf = time_old ? T.begin(&M->stats.ms_hit_filter) : 0;
-    hit_filter_kernel<false><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
-                                                                   M->min_hits.p, surv.p, nullptr, nullptr, stage.p, stage_off.p, getenv("MM_HF_DBG") ? atoi(getenv("MM_HF_DBG")) : 0, only, raw_per_read.p);
+    using HfN = HitFilterCfg<HF_SLOT_BITS_NARROW>; using HfW = HitFilterCfg<HF_SLOT_BITS_WIDE>;
+    const int hf_dbg = getenv("MM_HF_DBG") ? atoi(getenv("MM_HF_DBG")) : 0;
+    hit_filter_kernel<false, HF_SLOT_BITS_NARROW><<<dim3((unsigned)n), dim3(HfN::THREADS), HfN::LDS, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
+                                                                   M->min_hits.p, surv.p, nullptr, nullptr, stage.p, stage_off.p, hf_dbg, only, raw_per_read.p);
     MM_KERNEL_CHECK();
+    if (n_wide > 0) {
+      MM_HIP(hipFuncSetAttribute((const void*)hit_filter_kernel<false, HF_SLOT_BITS_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HfW::LDS));
+      hit_filter_kernel<false, HF_SLOT_BITS_WIDE><<<dim3((unsigned)n), dim3(HfW::THREADS), HfW::LDS, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
+                                                                   M->min_hits.p, surv.p, nullptr, nullptr, stage.p, stage_off.p, hf_dbg, only, raw_per_read.p);
+      MM_KERNEL_CHECK();
+    }
     if (time_old) T.end(t_hf);
     raw_sum.zero(st);                                            // only the total of the raw seed hits is needed
     sum_u32_kernel<<<dim3(256), dim3(256), 0, st>>>(raw_per_read.p, n, raw_sum.p);
@@ -1204,10 +1249,18 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   M->stats.sum_hits_kept = total_hits;
   M->hits.alloc((size_t)std::max<int64_t>(total_hits, 1));
   if (total_hits > 0) {
-    if (use_filter)
-      hit_filter_kernel<true><<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
-                                                                    M->min_hits.p, surv.p, M->read_hit_off.p, M->hits.p, stage.p, stage_off.p, getenv("MM_HITS_BITONIC") ? 0 : 100, nullptr, nullptr);
-    else
+    if (use_filter) {
+      using HfN = HitFilterCfg<HF_SLOT_BITS_NARROW>; using HfW = HitFilterCfg<HF_SLOT_BITS_WIDE>;
+      const int wdbg = getenv("MM_HITS_BITONIC") ? 0 : 100;
+      hit_filter_kernel<true, HF_SLOT_BITS_NARROW><<<dim3((unsigned)n), dim3(HfN::THREADS), HfN::LDS, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
+                                                                    M->min_hits.p, surv.p, M->read_hit_off.p, M->hits.p, stage.p, stage_off.p, wdbg, only, nullptr);
+      if (n_wide > 0) {
+        MM_KERNEL_CHECK();
+        MM_HIP(hipFuncSetAttribute((const void*)hit_filter_kernel<true, HF_SLOT_BITS_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HfW::LDS));
+        hit_filter_kernel<true, HF_SLOT_BITS_WIDE><<<dim3((unsigned)n), dim3(HfW::THREADS), HfW::LDS, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, M->d_read_len.p,
+                                                                    M->min_hits.p, surv.p, M->read_hit_off.p, M->hits.p, stage.p, stage_off.p, wdbg, only, nullptr);
+      }
+    } else
       gather_hits_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>(IV, M->mz.off.p, M->sk_n.p, probe_cnt.p, probe_start.p, hit_off.p, M->hits.p);
     MM_KERNEL_CHECK();
   }

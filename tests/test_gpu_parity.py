@@ -302,6 +302,35 @@ def test_phased_map_batch_calls_back_once_and_changes_nothing(ctx):
     A.close(); B.close(); idx.close(); reads.close(); ref.close()
 
 
+def test_wide_slot_table_of_the_hit_filter_changes_no_result(ctx, monkeypatch):
+    """Reads beyond ~32 kb are filtered with 32 768 slots counted from occ[] instead of 8 192 slots from occ16[]: fewer chance hits
+    survive, candidates and records stay what they are with the narrow table (MM_HF_WIDE_FROM=0), with no filter at all, and with a
+    tiny stage (the write pass re-filters with the same table)."""
+    ref = ctx.synth_reference(seed=45, n_species=30, strains_per_species=4, genome_len=500_000, strain_divergence=0.02, genus_divergence=0.08)
+    idx = ctx.index(ref, 12, 8)                                   # k = 12: plenty of chance hits, so that the filter has work to do
+    reads, _ = ctx.synth_reads(ref, seed=49, n_reads=300, read_len=120_000, read_len_min=3_000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=20)
+    res = {}
+    for mode in ("wide", "narrow", "none", "wide_tiny_stage"):
+        if mode.startswith("wide"): monkeypatch.setenv("MM_HF_WIDE_FROM", "4000")   # (default: 13000 hashes, reads from ~58 kb on)
+        if mode == "narrow": monkeypatch.setenv("MM_HF_WIDE_FROM", "0")
+        if mode == "none": monkeypatch.setenv("MM_NO_HIT_FILTER", "1")
+        if mode == "wide_tiny_stage": monkeypatch.setenv("MM_HF_STAGE_CAP", "16")
+        M = ctx.map_batch(idx, reads, 12, 8)
+        cand_off, cand = M.debug_candidates()
+        off, rec = M.fetch()
+        res[mode] = (cand_off.copy(), cand.copy(), off.copy(), rec.copy(), M.stats())
+        M.close()
+        for v in ("MM_HF_WIDE_FROM", "MM_NO_HIT_FILTER", "MM_HF_STAGE_CAP"): monkeypatch.delenv(v, raising=False)
+    for mode in ("narrow", "none", "wide_tiny_stage"):
+        for a, b in zip(res["wide"][:4], res[mode][:4]):
+            assert np.array_equal(a, b), mode
+    kept = {m: res[m][4]["sum_hits_kept"] for m in res}
+    print("seed hits kept:", kept)
+    assert kept["wide"] < kept["narrow"] < kept["none"] and kept["wide"] == kept["wide_tiny_stage"]
+    assert res["wide"][4]["n_mappings"] > 300
+    idx.close(); reads.close(); ref.close()
+
+
 def test_hit_prefilter_keeps_candidates_identical(ctx, monkeypatch):
     """K3c drops seed hits that cannot belong to a qualifying run; candidates and mappings must not change."""
     ref = ctx.synth_reference(seed=6, n_species=40, strains_per_species=4, genome_len=300_000, strain_divergence=0.02, genus_divergence=0.08)

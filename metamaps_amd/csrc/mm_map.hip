@@ -149,6 +149,52 @@ __global__ void __launch_bounds__(256) sketch_radix_kernel(const Rec* __restrict
   if (t == 0) { sk_n[r] = total; amb[r] = (uint8_t)(s_amb ? 2 : 0); }   // 2: ambiguous entries are marked
 }
 
+// Sketches of more than 16 384 minimizers (reads beyond ~73 kb): (hash << 32 | winnowing index) keys of the listed reads back to back
+// in one buffer, one segmented device radix sort, then unique + strand per read from the sorted keys — what sketch_kernel does
+// with its bitonic network through global memory (48 ms per 4 000 reads of 75-140 kb).  Like that kernel it writes no per-entry
+// ambiguity marks: a read with a duplicated hash on both strands is flagged (amb = 1) and resolved on the host up front, because the
+// long-read K5 path has no "vote read an unresolved strand" feedback.
+__global__ void __launch_bounds__(256) sketch_keys_kernel(const Rec* __restrict__ rec, const uint64_t* __restrict__ off, const int32_t* __restrict__ read_list,
+                                                          const uint64_t* __restrict__ koff, uint64_t* __restrict__ keys) {
+  const int r = read_list[blockIdx.x];
+  const uint64_t o = off[r], k0 = koff[blockIdx.x];
+  const uint32_t n = (uint32_t)(off[r + 1] - o);
+  for (uint32_t i = threadIdx.x; i < n; i += 256) keys[k0 + i] = ((uint64_t)rec[o + i].hash << 32) | i;
+}
+__global__ void __launch_bounds__(256) sketch_finish_kernel(const Rec* __restrict__ rec, const uint64_t* __restrict__ off, const int32_t* __restrict__ read_list,
+                                                            const uint64_t* __restrict__ koff, const uint64_t* __restrict__ sorted,
+                                                            uint32_t* __restrict__ sk_hash, uint8_t* __restrict__ sk_strand, int32_t* __restrict__ sk_n, uint8_t* __restrict__ amb) {
+  const int r = read_list[blockIdx.x];
+  const uint64_t o = off[r];
+  const uint64_t* __restrict__ a = sorted + koff[blockIdx.x];
+  const int n = (int)(off[r + 1] - o);
+  __shared__ int s_amb;
+  if (threadIdx.x == 0) s_amb = 0;
+  __syncthreads();
+  uint64_t carry = 0;
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + threadIdx.x;
+    bool first = false; uint32_t h = 0, stv = 0;
+    if (i < n) {
+      const uint64_t key = a[i];
+      h = (uint32_t)(key >> 32);
+      stv = rec[o + (uint32_t)key].pw & PW_STRAND;
+      if (i == 0) first = true;
+      else {
+        const uint64_t pk = a[i - 1];
+        first = (uint32_t)(pk >> 32) != h;
+        if (!first && (rec[o + (uint32_t)pk].pw & PW_STRAND) != stv) s_amb = 1;   // same hash, different strands
+      }
+    }
+    uint64_t tot;
+    const uint64_t ex = block_excl_scan_u64(first ? 1 : 0, &tot);
+    if (first) { sk_hash[o + carry + ex] = h; sk_strand[o + carry + ex] = (uint8_t)stv; }
+    carry += tot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { sk_n[r] = (int32_t)carry; amb[r] = (uint8_t)s_amb; }
+}
+
 // compact copies for the host-side duplicate-hash tie-break (one workgroup per flagged read)
 __global__ void __launch_bounds__(256) gather_amb_kernel(const Rec* __restrict__ rec, const uint64_t* __restrict__ src_off,
                                                          const uint64_t* __restrict__ dst_off, Rec* __restrict__ out) {
@@ -1009,8 +1055,25 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       MM_HIP(hipStreamSynchronize(st));                          // RB.order is the source of the async upload
       hl("K2 sync (kernels)");
     }
-    std::vector<int64_t> cnt;                                     // longer lists (reads beyond ~73 kb): bitonic network, by power-of-two capacity
-    if (any_big) { cnt.assign((size_t)n, 0); for (int64_t r = 0; r < n; ++r) { const int64_t c = (int64_t)(hoff[(size_t)r + 1] - hoff[(size_t)r]); if (c > 16384) cnt[(size_t)r] = c; } }
+    std::vector<int64_t> cnt;                                     // longer lists (reads beyond ~73 kb)
+    if (any_big && !getenv("MM_SKETCH_BITONIC")) {                 // one segmented device sort (MM_SKETCH_BITONIC=1: the bitonic network below, cross-check)
+      std::vector<int32_t> big; std::vector<uint64_t> koff{0};
+      for (int64_t r = 0; r < n; ++r) { const uint64_t c = hoff[(size_t)r + 1] - hoff[(size_t)r]; if (c > 16384) { big.push_back((int32_t)r); koff.push_back(koff.back() + c); } }
+      const size_t nb = big.size(); const uint64_t nk = koff.back();
+      MM_REQUIRE(nk < ((uint64_t)1 << 32), MM_ERR_LIMIT, "more than 2^32 minimizers of reads beyond 16384 minimizers in one batch");
+      DBuf<int32_t> d_big(nb); d_big.upload(big.data(), nb, st);
+      DBuf<uint64_t> d_koff(nb + 1); d_koff.upload(koff.data(), nb + 1, st);
+      DBuf<uint64_t> keys((size_t)nk), sorted((size_t)nk);
+      sketch_keys_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(M->mz.rec.p, M->mz.off.p, d_big.p, d_koff.p, keys.p);
+      MM_KERNEL_CHECK();
+      size_t tmp_bytes = 0;
+      MM_HIP(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, keys.p, sorted.p, (unsigned int)nk, (unsigned int)nb, d_koff.p, d_koff.p + 1, 0, 64, st));
+      DBuf<uint8_t> tmp(std::max<size_t>(tmp_bytes, 16));
+      MM_HIP(rocprim::segmented_radix_sort_keys((void*)tmp.p, tmp_bytes, keys.p, sorted.p, (unsigned int)nk, (unsigned int)nb, d_koff.p, d_koff.p + 1, 0, 64, st));
+      sketch_finish_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(M->mz.rec.p, M->mz.off.p, d_big.p, d_koff.p, sorted.p, M->sk_hash.p, M->sk_strand.p, M->sk_n.p, M->amb.p);
+      MM_KERNEL_CHECK();
+      MM_HIP(hipStreamSynchronize(st));                          // big / koff are upload sources
+    } else if (any_big) { cnt.assign((size_t)n, 0); for (int64_t r = 0; r < n; ++r) { const int64_t c = (int64_t)(hoff[(size_t)r + 1] - hoff[(size_t)r]); if (c > 16384) cnt[(size_t)r] = c; } }
     for (auto& cls : make_classes(cnt, 256)) {
       DBuf<int32_t> list(cls.reads.size());
       list.upload(cls.reads.data(), cls.reads.size(), st);

@@ -331,6 +331,29 @@ def test_wide_slot_table_of_the_hit_filter_changes_no_result(ctx, monkeypatch):
     idx.close(); reads.close(); ref.close()
 
 
+def test_long_sketches_segmented_sort_equals_bitonic_network(ctx, monkeypatch):
+    """K2 for reads with more than 16 384 minimizers: segmented device radix sort + finish kernel against the bitonic network
+    (MM_SKETCH_BITONIC=1): identical sketches (hash, strand after the tie-break), sizes, ambiguity flags and records."""
+    ref = ctx.synth_reference(seed=55, n_species=8, strains_per_species=3, genome_len=600_000, strain_divergence=0.02, genus_divergence=0.08)
+    idx = ctx.index(ref, 16, 5)                                   # w = 5: a 60 kb read already has ~20 000 minimizers
+    reads, _ = ctx.synth_reads(ref, seed=59, n_reads=120, read_len=150_000, read_len_min=20_000, sub_rate=0.03, ins_rate=0.02, del_rate=0.03, frac_random=0.05, n_abundant=6)
+    monkeypatch.setenv("MM_EAGER_TIEBREAK", "1")                  # every duplicated-hash strand resolved, so that whole sketches compare
+    res = {}
+    for mode in ("segmented", "bitonic"):
+        if mode == "bitonic": monkeypatch.setenv("MM_SKETCH_BITONIC", "1")
+        M = ctx.map_batch(idx, reads, 16, 5)
+        sk_off, sk_h, sk_s = M.debug_sketch()
+        off, rec = M.fetch()
+        res[mode] = (sk_off.copy(), sk_h.copy(), sk_s.copy(), off.copy(), rec.copy(), M.stats())
+        M.close()
+        monkeypatch.delenv("MM_SKETCH_BITONIC", raising=False)
+    for a, b in zip(res["segmented"][:5], res["bitonic"][:5]):
+        assert np.array_equal(a, b)
+    assert np.diff(res["segmented"][0]).max() > 16384 and res["segmented"][5]["n_mappings"] > 100
+    assert res["segmented"][5]["n_ambiguous_sketch_reads"] == res["bitonic"][5]["n_ambiguous_sketch_reads"]
+    idx.close(); reads.close(); ref.close()
+
+
 def test_hit_prefilter_keeps_candidates_identical(ctx, monkeypatch):
     """K3c drops seed hits that cannot belong to a qualifying run; candidates and mappings must not change."""
     ref = ctx.synth_reference(seed=6, n_species=40, strains_per_species=4, genome_len=300_000, strain_divergence=0.02, genus_divergence=0.08)

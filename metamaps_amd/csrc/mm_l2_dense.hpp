@@ -95,7 +95,9 @@ __global__ void __launch_bounds__(64) l2_dense_kernel(IndexView I, const int32_t
                                                       const int32_t* __restrict__ accept_min, int k, int w, int smax, L2Result* __restrict__ out,
                                                       const int32_t* __restrict__ cand_list, int n_list, const L2Range* __restrict__ ranges,
                                                       const uint64_t* __restrict__ code_off, const uint32_t* __restrict__ codes,
-                                                      uint32_t* __restrict__ scratch, unsigned int* __restrict__ next_item) {
+                                                      uint32_t* __restrict__ scratch, unsigned int* __restrict__ next_item,
+                                                      uint8_t* __restrict__ amb_used /* optional: set per read when a vote needed an unresolved strand (bit 1 of the strand byte) */,
+                                                      int force_amb /* tests: flag every read whose vote saw such an entry */) {
   constexpr int INF = 0x7fffffff;
   __shared__ int tst[64];
   __shared__ uint8_t fdel[64], fadd[64];
@@ -340,24 +342,29 @@ __global__ void __launch_bounds__(64) l2_dense_kernel(IndexView I, const int32_t
     int strand = -1, accepted = 0;
     if (best >= amin) {
       accepted = 1;
-      int votes = 0;
+      int votes = 0, amb_votes = 0;                               // votes of resolved strands / number of votes whose query strand is unresolved (l2_kernel's scheme)
       for (int base = opt_b; base < opt_e; base += 64) {
         const int j = base + lane;
         const uint32_t wd = cw[min(j, cmax)];
         const int code = ld_code(wd);
         const bool cnt_it = j < opt_e && code >= 0 && code < bestR;
-        const int contrib = cnt_it ? ((sk_strand[qo + code] & 1) ? 1 : -1) * pw_strand(ld_flags(wd)) : 0;
+        const uint32_t sq = cnt_it ? (uint32_t)sk_strand[qo + code] : 0u;
+        const bool unres = (sq & 2) && amb_used != nullptr;       // (after the host resolved the read, amb_used is null and bit 1 is gone)
+        const int contrib = cnt_it ? ((sq & 1) ? 1 : -1) * pw_strand(ld_flags(wd)) : 0;
         const bool flagged = cnt_it && (ld_flags(wd) & PW_DN);   // a later occurrence exists in the contig: inside the window?
-        if (cnt_it && !flagged) votes += contrib;
+        if (cnt_it && !flagged) { if (unres) ++amb_votes; else votes += contrib; }
         uint64_t fm = __ballot(flagged);
         while (fm) {
           const int l = __ffsll((unsigned long long)fm) - 1;
           fm &= fm - 1;
           const bool later = wave_has_hash(pos, base + l + 1, opt_e, pos[base + l].hash, lane);
-          if (!later && lane == l) votes += contrib;
+          if (!later && lane == l) { if (unres) ++amb_votes; else votes += contrib; }
         }
       }
       votes = wave_sum(votes);
+      amb_votes = wave_sum(amb_votes);
+      // each unresolved vote is +1 or -1: the sign of the total is already decided unless the resolved votes are that close
+      if (amb_votes > 0 && ((votes - amb_votes <= 0 && votes + amb_votes > 0) || force_amb) && lane == 0) amb_used[cand_read[c]] = 1;
       strand = votes > 0 ? 1 : -1;
     }
     if (lane == 0) {

@@ -151,9 +151,9 @@ __global__ void __launch_bounds__(256) sketch_radix_kernel(const Rec* __restrict
 
 // Sketches of more than 16 384 minimizers (reads beyond ~73 kb): (hash << 32 | winnowing index) keys of the listed reads back to back
 // in one buffer, one segmented device radix sort, then unique + strand per read from the sorted keys — what sketch_kernel does
-// with its bitonic network through global memory (48 ms per 4 000 reads of 75-140 kb).  Like that kernel it writes no per-entry
-// ambiguity marks: a read with a duplicated hash on both strands is flagged (amb = 1) and resolved on the host up front, because the
-// long-read K5 path has no "vote read an unresolved strand" feedback.
+// with its bitonic network through global memory (48 ms per 4 000 reads of 75-140 kb) — plus sketch_radix_kernel's per-entry
+// ambiguity marks, so that these reads take the lazy strand tie-break too (the bitonic kernel flags the whole read and all its
+// minimizer records go to the host up front: a third of 4 000 such reads, 0.5 GB per batch).
 __global__ void __launch_bounds__(256) sketch_keys_kernel(const Rec* __restrict__ rec, const uint64_t* __restrict__ off, const int32_t* __restrict__ read_list,
                                                           const uint64_t* __restrict__ koff, uint64_t* __restrict__ keys) {
   const int r = read_list[blockIdx.x];
@@ -171,28 +171,37 @@ __global__ void __launch_bounds__(256) sketch_finish_kernel(const Rec* __restric
   __shared__ int s_amb;
   if (threadIdx.x == 0) s_amb = 0;
   __syncthreads();
-  uint64_t carry = 0;
-  for (int base = 0; base < n; base += 256) {
-    const int i = base + threadIdx.x;
-    bool first = false; uint32_t h = 0, stv = 0;
-    if (i < n) {
-      const uint64_t key = a[i];
-      h = (uint32_t)(key >> 32);
-      stv = rec[o + (uint32_t)key].pw & PW_STRAND;
-      if (i == 0) first = true;
-      else {
-        const uint64_t pk = a[i - 1];
-        first = (uint32_t)(pk >> 32) != h;
-        if (!first && (rec[o + (uint32_t)pk].pw & PW_STRAND) != stv) s_amb = 1;   // same hash, different strands
+  for (int pass = 0; pass < 2; ++pass) {                          // 0: survivors (first of every run of equal hashes); 1: marks on them
+    uint64_t carry = 0;
+    for (int base = 0; base < n; base += 256) {
+      const int i = base + threadIdx.x;
+      bool first = false, differs = false; uint32_t h = 0, stv = 0;
+      if (i < n) {
+        const uint64_t key = a[i];
+        h = (uint32_t)(key >> 32);
+        stv = rec[o + (uint32_t)key].pw & PW_STRAND;
+        if (i == 0) first = true;
+        else {
+          const uint64_t pk = a[i - 1];
+          first = (uint32_t)(pk >> 32) != h;
+          differs = !first && (rec[o + (uint32_t)pk].pw & PW_STRAND) != stv;   // same hash, different strands
+        }
       }
+      uint64_t tot;
+      const uint64_t ex = block_excl_scan_u64(first ? 1 : 0, &tot);
+      if (pass == 0) {
+        if (first) { sk_hash[o + carry + ex] = h; sk_strand[o + carry + ex] = (uint8_t)stv; }
+        if (differs) s_amb = 1;
+      } else if (differs) sk_strand[o + carry + ex - 1] |= 2;     // bit 1 on the run's survivor (the last first at or before i): strand unresolved
+      carry += tot;
     }
-    uint64_t tot;
-    const uint64_t ex = block_excl_scan_u64(first ? 1 : 0, &tot);
-    if (first) { sk_hash[o + carry + ex] = h; sk_strand[o + carry + ex] = (uint8_t)stv; }
-    carry += tot;
+    __threadfence_block();
+    __syncthreads();
+    if (pass == 0) {
+      if (threadIdx.x == 0) { sk_n[r] = (int32_t)carry; amb[r] = (uint8_t)(s_amb ? 2 : 0); }   // 2: ambiguous entries are marked (lazy tie-break)
+      if (!s_amb) break;
+    }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) { sk_n[r] = (int32_t)carry; amb[r] = (uint8_t)s_amb; }
 }
 
 // compact copies for the host-side duplicate-hash tie-break (one workgroup per flagged read)
@@ -1116,7 +1125,10 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   std::vector<int64_t> eager_reads, lazy_reads;
   {
     const bool all_eager = getenv("MM_EAGER_TIEBREAK") != nullptr;   // tests that compare every sketch strand with the oracle
-    for (int64_t r = 0; r < n; ++r) if (h_amb[(size_t)r]) ((h_amb[(size_t)r] == 2 && !all_eager) ? lazy_reads : eager_reads).push_back(r);
+    // (MM_L2_NO_DENSE=1 sends sketches of >= 32768 hashes to l2_giant_kernel, which has no "vote read an unresolved strand" feedback)
+    const bool giant_eager = getenv("MM_L2_NO_DENSE") != nullptr;
+    for (int64_t r = 0; r < n; ++r) if (h_amb[(size_t)r])
+      ((h_amb[(size_t)r] == 2 && !all_eager && !(giant_eager && M->h_sk_n[(size_t)r] >= L2_SKETCH_LIMIT)) ? lazy_reads : eager_reads).push_back(r);
     M->stats.n_ambiguous_sketch_reads = (int64_t)(eager_reads.size() + lazy_reads.size());
   }
   // The tie-break states live in this frame: whatever way map_batch is left (return, MM_REQUIRE, a failed allocation), their
@@ -1527,7 +1539,8 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     const size_t t_l2 = T.begin(&M->stats.ms_l2);
     // Long reads: the window state in global memory, one wave per candidate (mm_l2_dense.hpp).  `list`: candidates, those of a read
     // consecutive; smax_l: largest sketch among them.
-    auto run_dense = [&](const std::vector<int32_t>& list, int smax_l) {
+    const int force_amb = getenv("MM_FORCE_AMB_REDO") ? 1 : 0;
+    auto run_dense = [&](const std::vector<int32_t>& list, int smax_l, uint8_t* amb_ptr) {
       if (list.empty()) return;
       const size_t nl = list.size();
       DBuf<int32_t> d_list(nl); d_list.upload(list.data(), nl, st);
@@ -1554,13 +1567,13 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       DBuf<uint32_t> scratch((size_t)slots * l2_dense_slot_words(smax_l));
       DBuf<unsigned int> next(1); next.zero(st);
       l2_dense_kernel<<<dim3(slots), dim3(64), 0, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p,
-                                                      P.k, P.w, smax_l, M->l2.p, d_list.p, (int)nl, d_rng.p, d_coff.p, codes.p, scratch.p, next.p);
+                                                      P.k, P.w, smax_l, M->l2.p, d_list.p, (int)nl, d_rng.p, d_coff.p, codes.p, scratch.p, next.p, amb_ptr, force_amb);
       MM_KERNEL_CHECK();
       MM_HIP(hipStreamSynchronize(st));                          // host vectors above are upload sources; the buffers die with this scope
     };
     DBuf<int32_t> d_listG(listG.size());
     DBuf<uint32_t> giant_scratch;
-    if (!listG.empty() && use_dense) run_dense(listG, smG);
+    if (!listG.empty() && use_dense) run_dense(listG, smG, amb_used_p);
     else if (!listG.empty()) {
       d_listG.upload(listG.data(), listG.size(), st);
       const unsigned slots = (unsigned)std::min<size_t>(listG.size(), (size_t)ctx->cus * 8);
@@ -1633,7 +1646,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         }                                                        // (larger: listG above)
       }
       hl("K5 grouping");
-      run_dense(listL, smL);
+      run_dense(listL, smL, amb_used_p);
       DBuf<int32_t> d_gB0(gB0.size()), d_gBn(gBn.size()), d_listC(listC.size());
       size_t nA = gctr[0], nS = gctr[1];
       if (!dev_groups) {
@@ -1704,18 +1717,24 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         for (int64_t r : lazy_reads) if (used[(size_t)r]) fix.push_back(r);
         if (!fix.empty()) {
           start_tiebreak(fix)();
-          std::vector<int32_t> redo; int smR = 0;
+          std::vector<int32_t> redo, redoL; int smR = 0, smRL = 0;   // redoL: reads of the dense path (long sketches) go through it again
           for (int64_t r : fix) {
-            smR = std::max(smR, M->h_sk_n[(size_t)r]);
-            for (uint64_t c0 = M->h_cand_off[(size_t)r]; c0 < M->h_cand_off[(size_t)r + 1]; ++c0) redo.push_back((int32_t)c0);
+            const int sr = M->h_sk_n[(size_t)r];
+            const bool dense_r = use_dense && (sr >= L2_SKETCH_LIMIT || (sr >= dense_from && M->read_len[(size_t)r] >= P.w + P.k + 1));
+            (dense_r ? smRL : smR) = std::max(dense_r ? smRL : smR, sr);
+            for (uint64_t c0 = M->h_cand_off[(size_t)r]; c0 < M->h_cand_off[(size_t)r + 1]; ++c0) (dense_r ? redoL : redo).push_back((int32_t)c0);
           }
-          DBuf<int32_t> d_redo(redo.size()); d_redo.upload(redo.data(), redo.size(), st);
-          const size_t lds = l2_lds_bytes<uint16_t>(smR, true, 1, 8);
-          set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
-          l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)redo.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smR, M->l2.p, counters.p, nullptr, nullptr, d_redo.p, ovf.p, ovf_n.p, nullptr, nullptr, masks_for(redo.size()));
-          MM_KERNEL_CHECK();
-          run_fallback(nullptr);
+          run_dense(redoL, smRL, nullptr);
+          n_redo += (int64_t)redoL.size();
+          DBuf<int32_t> d_redo(std::max<size_t>(redo.size(), 1)); d_redo.upload(redo.data(), redo.size(), st);
+          if (!redo.empty()) {
+            const size_t lds = l2_lds_bytes<uint16_t>(smR, true, 1, 8);
+            set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
+            l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)redo.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+                M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smR, M->l2.p, counters.p, nullptr, nullptr, d_redo.p, ovf.p, ovf_n.p, nullptr, nullptr, masks_for(redo.size()));
+            MM_KERNEL_CHECK();
+            run_fallback(nullptr);
+          }
           MM_HIP(hipStreamSynchronize(st));
           n_redo += (int64_t)redo.size();
         }

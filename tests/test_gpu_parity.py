@@ -485,6 +485,29 @@ def test_tiebreak_modes_agree(ctx, monkeypatch):
     idx.close(); reads.close(); ref.close()
 
 
+def test_tiebreak_modes_agree_on_long_reads(ctx, monkeypatch):
+    """the same for reads of the long-sketch paths (segmented sketch sort with per-entry marks, dense K5 path with the
+    unresolved-strand feedback and its redo): default (lazy), everything up front, every touched read resolved and redone"""
+    ref = ctx.synth_reference(seed=65, n_species=10, strains_per_species=4, genome_len=500_000, strain_divergence=0.02, genus_divergence=0.08)
+    reads, _ = ctx.synth_reads(ref, seed=69, n_reads=160, read_len=130_000, read_len_min=50_000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=8)
+    idx = ctx.index(ref, 16, 8)
+    res = {}
+    for mode, env in (("default", None), ("eager", "MM_EAGER_TIEBREAK"), ("redo", "MM_FORCE_AMB_REDO")):
+        if env:
+            monkeypatch.setenv(env, "1")
+        M = ctx.map_batch(idx, reads, 16, 8)
+        off, rec = M.fetch()
+        res[mode] = (off.copy(), rec.copy(), M.stats())
+        M.close()
+        if env:
+            monkeypatch.delenv(env)
+    assert res["default"][2]["n_ambiguous_sketch_reads"] > 10 and res["default"][2]["n_mappings"] > 200
+    assert res["redo"][2]["n_l2_wide_redo"] > 0                  # the host-resolution path really ran
+    for mode in ("eager", "redo"):
+        assert np.array_equal(res["default"][0], res[mode][0]) and np.array_equal(res["default"][1], res[mode][1]), mode
+    idx.close(); reads.close(); ref.close()
+
+
 @pytest.mark.parametrize("read_len,n_reads", [(20_000, 300), (45_000, 150), (90_000, 60)])
 def test_l2_long_read_classes_equal_full_slide(ctx, monkeypatch, read_len, n_reads):
     """the sketch-size classes of K5 beyond the 10 kb case (masks for 32 768 streamed entries, blocks of several words,

@@ -110,3 +110,62 @@ def test_random_configurations_match_oracle(oracle_lib, tmp_path, seed):
     print(f"seed {seed}: k={k} w={w} pi={pi} min_len={min_len}: {n_mapped} reads mapped, {n_rec} records")
     assert n_mapped >= 10
     oi.close(); M.close(); idx.close(); R.close(); S.close(); ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MM_FUZZ_LONG_SEEDS", "6"))))
+def test_random_long_reads_match_oracle(oracle_lib, tmp_path, seed):
+    """the long-read paths against the oracle: sketches beyond 16 384 minimizers (segmented sketch sort), the wide slot table of
+    the pre-filter (sketches beyond 13 000 hashes), the dense K5 path with its lazy strand tie-break; reads of 30 ... 260 kb next to
+    short ones in one batch, small windows so that the sketches get long, references with duplications and related contigs"""
+    from metamaps_amd import capi
+    rng = np.random.default_rng(7000 + seed)
+    k = int(rng.integers(12, 21)); w = int(rng.integers(3, 12)); pi = float(rng.choice([75.0, 80.0, 88.0]))
+    contigs = []
+    root = rng.choice(ACGT, size=int(rng.integers(300_000, 500_000)))
+    contigs.append(root)
+    for div in (0.01, 0.06):
+        c = root.copy(); m = rng.random(len(c)) < div; c[m] = rng.choice(ACGT, size=int(m.sum())); contigs.append(c)
+    d = rng.choice(ACGT, size=int(rng.integers(150_000, 300_000)))
+    seg = d[10_000:40_000].copy()
+    at = int(rng.integers(60_000, len(d) - 40_000)); d[at:at + 30_000] = seg        # a 30 kb duplication inside one contig
+    d[5_000:5_000 + int(rng.integers(50, 2_000))] = ord("N")
+    contigs.append(d)
+    fa = str(tmp_path / "DB.fa")
+    with open(fa, "wb") as f:
+        for i, c in enumerate(contigs):
+            f.write(f">L{i}|kraken:taxid|{200 + i}|x\n".encode() + c.tobytes() + b"\n")
+    reads = []
+    for i in range(14):
+        c = contigs[int(rng.integers(len(contigs)))]
+        L = int(min(len(c), np.exp(rng.uniform(np.log(30_000), np.log(260_000))))) if i < 10 else int(rng.integers(500, 8_000))
+        p = int(rng.integers(0, len(c) - L + 1))
+        s = c[p:p + L].copy()
+        rate = float(rng.choice([0.0, 0.03, 0.1]))
+        m = rng.random(L) < rate; s[m] = rng.choice(ACGT, size=int(m.sum()))
+        if rate > 0:                                              # a few indels as well, in blocks
+            for _ in range(int(rng.integers(0, 6))):
+                q = int(rng.integers(0, len(s) - 50)); s = np.concatenate([s[:q], s[q + int(rng.integers(1, 40)):]])
+        if rng.random() < 0.5: s = COMP[s[::-1]]
+        reads.append(s.tobytes())
+    ctx = capi.Context(0)
+    S = ctx.seqset([c.tobytes() for c in contigs]); R = ctx.seqset(reads)
+    idx = ctx.index(S, k, w)
+    oi = oracle_lib.index(fa, k, w)
+    M = ctx.map_batch(idx, R, k, w, pi=pi, min_read_len=1000)
+    off, rec = M.fetch()
+    st = M.stats()
+    n_rec = 0
+    for r, q in enumerate(reads):
+        a, b = int(off[r]), int(off[r + 1])
+        if len(q) < max(1000, k, w):
+            assert a == b
+            continue
+        m = oi.map_read(q, pi)["map"]
+        rr = rec[a:b]
+        assert b - a == len(m), (seed, k, w, pi, r, len(q), b - a, len(m))
+        assert np.array_equal(rr["ref_contig"], m[:, 0]) and np.array_equal(rr["ref_start"], m[:, 1]), (seed, r)
+        assert np.array_equal(rr["shared"], m[:, 3]) and np.array_equal(rr["sketch"], m[:, 4]) and np.array_equal(rr["strand"], m[:, 5]), (seed, r)
+        n_rec += len(m)
+    print(f"seed {seed}: k={k} w={w} pi={pi}: {n_rec} records, largest sketch {max(int(x) for x in rec['sketch']) if len(rec) else 0}, kept/raw hits {st['sum_hits_kept']}/{st['sum_hits']}")
+    assert n_rec >= 8
+    oi.close(); M.close(); idx.close(); R.close(); S.close(); ctx.close()

@@ -296,6 +296,8 @@ def main():
             },
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, dom_name),
+                         "note": "l2_kernel uses 87 percent of its VALU issue slots (profiles/r02_sq_counters.txt): an integer-ALU-bound kernel, the HBM "
+                                 "fraction says how far it sits from a bound it does not touch; seed_filter_kernel 40 percent, minimizer_kernel 99 percent",
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms,
                          "other_kernels": {n: {"ms_per_launch": m, "algorithmic_bytes_per_launch": b, "achieved": (b / (m * 1e-3) / 1e9 if m > 0 else 0.0)}
                                            for n, b, m in cands if n != dom_name}},

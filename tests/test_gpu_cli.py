@@ -181,6 +181,22 @@ _RANDOM_CASES = [
 ]
 
 
+def _more_random_cases(n):
+    """seeded random cases behind the hand-picked ones (MM_CLI_FUZZ_CASES=60 for a longer hunt; 60 ran clean in round 2)"""
+    import random
+    rng = random.Random(20260928)
+    out = []
+    for _ in range(n):
+        k = rng.randint(8, 26); w = rng.choice([1, 2, 3, 5, 8, 11, 16, 24, 40])
+        m = rng.choice([200, 500, 1000, 2500])
+        out.append((k, w, rng.choice([70, 78, 80, 85, 92]), m, max(rng.choice([1200, 2500, 5000, 9000]), 2 * m),    # (no read long enough: classify of both CLIs refuses)
+                    rng.choice([0.0, 0.3, 0.7]), rng.choice([0.0, 0.02, 0.05]), rng.choice([0.0, 0.02, 0.04]), rng.choice([0.0, 0.02, 0.05]), rng.random() < 0.6))
+    return out
+
+
+_RANDOM_CASES = _RANDOM_CASES + _more_random_cases(int(os.environ.get("MM_CLI_FUZZ_CASES", "4")))
+
+
 @pytest.mark.parametrize("case", _RANDOM_CASES, ids=lambda c: f"k{c[0]}w{c[1]}pi{c[2]}m{c[3]}")
 def test_cli_parameter_sweep_matches_oracle(oracle_lib, tmp_path, case):
     """mapDirectly + classify with k / w / identity threshold / minimum read length / read length spread / error rates
@@ -204,7 +220,7 @@ def test_cli_parameter_sweep_matches_oracle(oracle_lib, tmp_path, case):
     _cmp_table(pa + ".EM.WIMP", pb + ".EM.WIMP", "\t", {4, 5})
     _cmp_table(pa + ".EM.contigCoverage", pb + ".EM.contigCoverage", "\t", {6})
     _cmp_unknown_species(pa, pb, expect_tests=False)
-    assert sum(1 for _ in open(pa)) > 30
+    assert sum(1 for _ in open(pa)) > (30 if case in _RANDOM_CASES[:6] else 0)
 
 
 @pytest.mark.parametrize("limit,range_bases,all_flag", [(1_000_000, 100_000, ["--all"]), (1_000_000, 30_000, []), (2_000_000, 10_000_000, ["--all"]), (4_000_000, 150_000, ["--all"])])

@@ -598,9 +598,9 @@ int map_mode(const Options& o, const std::string& mode) {
     }
   };
   if (place == Place::Replicated) {
-    // ---- workers: two contexts per device, so that packing, result download and text formatting of one batch overlap the
+    // ---- workers: three contexts per device (--workers-per-gpu), so that packing, result download and text formatting of one batch overlap the
     // kernels of the other; the device's chunk indexes are shared (read-only) by its contexts
-    const size_t WPD = o.v.count("workers-per-gpu") ? (size_t)std::max(1, std::stoi(o.v.at("workers-per-gpu"))) : 2;
+    const size_t WPD = o.v.count("workers-per-gpu") ? (size_t)std::max(1, std::stoi(o.v.at("workers-per-gpu"))) : 3;
     std::vector<std::thread> workers;
     for (size_t d = 0; d < G; ++d) for (size_t wi = 0; wi < WPD; ++wi) workers.emplace_back([&, d, wi]() {
       mm_ctx* ctx = devs[d].ctx;

@@ -25,3 +25,4 @@ wc -l /tmp/clit/out
 if [ -n "$SMALL_BATCH" ]; then
 MM_CLI_BATCH_READS=$SMALL_BATCH MM_CLI_TIMING=1 metamaps_amd/csrc/metamaps mapDirectly --all -r /tmp/clit/DB.fa -q /tmp/clit/reads.fq -o /tmp/clit/out2 2>&1 | grep -E "worker" | head -12
 fi
+if [ -n "$WPG" ]; then for w in $WPG; do echo "workers-per-gpu $w"; MM_CLI_TIMING=1 metamaps_amd/csrc/metamaps mapDirectly --all -r /tmp/clit/DB.fa -q /tmp/clit/reads.fq -o /tmp/clit/out3 --workers-per-gpu $w 2>&1 | grep -E "lap 3 index|lap 8" | tail -2; done; fi

@@ -175,12 +175,12 @@ def main():
                     if staged and not swapped[0]:
                         swap()
                 tt.append(time.perf_counter())
-                M.add_qualities(k)
             finally:
                 if staged:
                     back_lock.release()
                 elif serialise:
                     map_lock.release()
+            M.add_qualities(k)                                      # (one 60 us kernel on this worker's stream: under the next step's minimizer stage)
             off, rec = M.fetch(rec_bufs[wi])
             st = M.stats()
             tt.append(time.perf_counter())

@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--staged-map", action="store_true", help="two locks instead of one around the mapping section (K1 + K2 | K3 ... K6, swapped at mm_map_batch_phased's "
                     "callback): the next step's minimizer stage runs under this step's seed stage; ~2 percent more throughput, but the seed filter's "
                     "duration then includes the time it shares the CUs (K1 issues VALU instructions in 99 percent of its cycles: the two do not complement each other)")
+    ap.add_argument("--hold-lock-to-the-end", action="store_true", help="release the mapping lock when mm_map_batch returns instead of when its last big kernel is enqueued")
     ap.add_argument("--free-overlap", action="store_true", help="do not serialise the mapping sections of the workers (higher throughput, kernel durations inflated)")
     ap.add_argument("--measure-free-overlap", action="store_true", help="after the timed region, six more steps with nothing serialised, reported in config.free_overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -154,32 +155,35 @@ def main():
         em_turn = {"next": 0, "cv": threading.Condition()}
 
         def step(wi, serialise=True, ticket=0):
-            """serialise: "staged" (default) — one lock for K1 + K2, one for K3 ... K6 + mapping qualities, swapped at mm_map_batch_phased's
-            callback: the next step's minimizer stage starts when this step's seed stage does and runs under it (K1: integer multiplier,
-            K3: memory requests), everything from K4 on owns the GPU; "serial" (True): one lock around the whole mapping section;
-            False: nothing serialised"""
+            """serialise: True (default) — one lock around the mapping section of a step, released when its last big kernel (K5) is
+            enqueued (mm_map_batch_phased, stage 2), so that the next step's minimizer stage fills the CUs that kernel leaves as it drains;
+            "staged" (--staged-map) — one lock for K1 + K2, one for K3 ... K6, swapped at stage 1; False: nothing serialised"""
             c = ctxs[wi]
             tt = [time.perf_counter()]
             staged = serialise == "staged"
             swapped = [False]
+            released = [False]
             def swap():
                 back_lock.acquire(); front_lock.release(); swapped[0] = True
+            def release():                                          # the step's last big kernel is enqueued: the next step may start its minimizer stage,
+                if released[0]: return                              # which takes the CUs that kernel leaves as it drains
+                released[0] = True
+                if staged: back_lock.release()
+                elif serialise: map_lock.release()
             if staged:
                 front_lock.acquire()
             elif serialise:
                 map_lock.acquire()
             try:
                 try:
-                    M = c.map_batch(idx, reads_w[wi], k, w, pi=80.0, min_read_len=1000, at_seed_stage=swap if staged else None)
+                    M = c.map_batch(idx, reads_w[wi], k, w, pi=80.0, min_read_len=1000, at_seed_stage=swap if staged else None,
+                                    at_last_kernel=release if (serialise and not args.hold_lock_to_the_end) else None)
                 finally:
                     if staged and not swapped[0]:
                         swap()
                 tt.append(time.perf_counter())
             finally:
-                if staged:
-                    back_lock.release()
-                elif serialise:
-                    map_lock.release()
+                release()
             M.add_qualities(k)                                      # (one 60 us kernel on this worker's stream: under the next step's minimizer stage)
             off, rec = M.fetch(rec_bufs[wi])
             st = M.stats()
@@ -284,7 +288,8 @@ def main():
                 "index_entries": info["n_entries"], "index_unique_hashes": info["n_unique_hashes"], "index_hbm_bytes": info["hbm_bytes"],
                 "freq_threshold": R["freq_threshold"], "reference_synth_s": round(R["t_ref"], 3), "index_build_s": round(R["t_index"], 3),
                 "parallelism": f"reads sharded x{world}, index replicated, RCCL all-reduce of EM sums; {W} worker contexts per GPU take the steps in turn"
-                               + ("" if W == 1 or args.free_overlap else (" (mapping sections serialised)" if not args.staged_map else
+                               + ("" if W == 1 or args.free_overlap else ((" (mapping sections serialised" + ("" if args.hold_lock_to_the_end else "; the lock passes on when a step's last big kernel, K5, is enqueued: the next step's minimizer "
+                                   "kernel waits in its queue and takes the CUs K5 leaves as it drains — its stage time, ms_minimizer, then includes that wait") + ")") if not args.staged_map else
                                   " (the minimizer + sketch stage of step i+1 runs under the seed stage of step i; everything from the hit sort on owns the GPU)")),
                 "workers_per_gpu": W, "free_overlap": R["free"],
                 "em_iterations": agg["em_iters"],

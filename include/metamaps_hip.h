@@ -197,13 +197,15 @@ typedef struct {
 } mm_map_stats;
 
 int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, mm_mapping** out);
-/* mm_map_batch with a stage boundary handed to the caller: `at_seed_stage(user)` is called once, on the calling thread, when the
- * sketches of the batch are complete (K1 + K2 have run) and before anything of its seed stage (K3) is enqueued; not at all when the
- * batch fails before that point.  A caller that drives several contexts of one device and wants every kernel from K3 on to own the
- * GPU (bench.py: clean kernel durations for the roofline) takes one lock for K1 + K2 and another for K3 ... K6 and swaps them in the
- * callback: the next batch's minimizer and sketch stage then fill the host sections and kernel tails of this batch's seed stage.
- * The callback must not call into `ctx`; results are the same with or without it. */
-int mm_map_batch_phased(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, void (*at_seed_stage)(void* user), void* user,
+/* mm_map_batch with two stage boundaries handed to the caller: `at_stage(user, stage)` is called on the calling thread, at most once per
+ * stage and not at all when the batch fails or ends before that point:
+ *   stage 1  the sketches of the batch are complete (K1 + K2 have run), nothing of its seed stage (K3) is enqueued yet;
+ *   stage 2  the last big kernel of the batch (K5 / K6) is enqueued; what follows are small kernels and downloads.
+ * A caller that drives several contexts of one device decides with it which stages of two batches may share the GPU: bench.py lets
+ * the next batch start at stage 2 (its minimizer stage takes the CUs that this batch's last kernel leaves as it drains), or — with
+ * --staged-map — takes one lock for K1 + K2 and another for K3 ... K6 and swaps them at stage 1.  The callback must not call into
+ * `ctx`; results are the same with or without it. */
+int mm_map_batch_phased(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, void (*at_stage)(void* user, int stage), void* user,
                         mm_mapping** out);
 void mm_mapping_destroy(mm_mapping* m);
 int mm_mapping_get_stats(const mm_mapping* m, mm_map_stats* out);

@@ -25,7 +25,7 @@ class MMError(RuntimeError):
         self.status = status
 
 
-SEED_STAGE_CB = C.CFUNCTYPE(None, C.c_void_p)
+SEED_STAGE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
 
 
 class MapParams(C.Structure):
@@ -262,14 +262,18 @@ class Context:
             idx.set_freq_threshold(thr)
         return idx
 
-    def map_batch(self, idx: "Index", reads: "SeqSet", k: int, w: int, pi: float = 80.0, min_read_len: int = 1000, at_seed_stage=None) -> "Mapping":
-        """at_seed_stage: callable run once between the sketch stage and the seed stage (mm_map_batch_phased)"""
+    def map_batch(self, idx: "Index", reads: "SeqSet", k: int, w: int, pi: float = 80.0, min_read_len: int = 1000, at_seed_stage=None, at_last_kernel=None) -> "Mapping":
+        """at_seed_stage / at_last_kernel: callables run between the sketch stage and the seed stage / once K5 is enqueued (mm_map_batch_phased)"""
         p = MapParams(k, w, pi, min_read_len)
         h = C.c_void_p()
-        if at_seed_stage is None:
+        if at_seed_stage is None and at_last_kernel is None:
             self.check(lib().mm_map_batch(self.h, idx.h, reads.h, C.byref(p), C.byref(h)))
         else:
-            cb = SEED_STAGE_CB(lambda _user: at_seed_stage())
+            def _stage(_user, stage):
+                f = at_seed_stage if stage == 1 else at_last_kernel
+                if f is not None:
+                    f()
+            cb = SEED_STAGE_CB(_stage)
             self.check(lib().mm_map_batch_phased(self.h, idx.h, reads.h, C.byref(p), cb, None, C.byref(h)))
         return Mapping(self, h, reads.count)
 

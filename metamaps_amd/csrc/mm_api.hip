@@ -280,12 +280,12 @@ int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const
     *out = M;
   });
 }
-int mm_map_batch_phased(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, void (*at_seed_stage)(void*), void* user, mm_mapping** out) {
+int mm_map_batch_phased(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, void (*at_stage)(void*, int), void* user, mm_mapping** out) {
   if (!ctx || !idx || !reads || !p || !out) return MM_ERR_ARG;
   return guarded(ctx, [&] {
     MM_HIP(hipSetDevice(ctx->device));
     auto* M = new mm_mapping;
-    M->at_seed_stage = at_seed_stage; M->at_seed_stage_user = user;
+    M->at_stage = at_stage; M->at_stage_user = user;
     try { mm::map_batch(ctx, idx, reads, *p, M); } catch (...) { delete M; throw; }
     *out = M;
   });

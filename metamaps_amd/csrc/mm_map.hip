@@ -1104,8 +1104,8 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   }
   HostLap hl;
   M->h_sk_n = M->sk_n.to_host(st, (size_t)n);
-  // mm_map_batch_phased: K1 + K2 are complete (the download above waited for them), nothing of the seed stage is enqueued yet
-  if (M->at_seed_stage) { auto cb = M->at_seed_stage; M->at_seed_stage = nullptr; cb(M->at_seed_stage_user); }
+  // mm_map_batch_phased, stage 1: K1 + K2 are complete (the download above waited for them), nothing of the seed stage is enqueued yet
+  if (M->at_stage) M->at_stage(M->at_stage_user, 1);
   std::vector<uint8_t> h_amb = M->amb.to_host(st, (size_t)n);
   hl("post-K2 downloads");
   {
@@ -1694,6 +1694,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         MM_KERNEL_CHECK();
       }
       hl("K5 uploads + launches");
+      if (M->at_stage) M->at_stage(M->at_stage_user, 2);          // mm_map_batch_phased, stage 2: the last big kernel is enqueued
       // candidates the skip kernels hand back (reads shorter than w+k): the literal full slide
       int64_t n_fallback = 0;
       auto run_fallback = [&](uint8_t* amb_ptr) {

@@ -20,7 +20,7 @@ struct mm_mapping {
   mm_map_stats stats{};
   std::vector<int32_t> read_len;
   std::vector<uint8_t> active;
-  void (*at_seed_stage)(void*) = nullptr; void* at_seed_stage_user = nullptr;   // mm_map_batch_phased: called once between K2 and K3
+  void (*at_stage)(void*, int) = nullptr; void* at_stage_user = nullptr;   // mm_map_batch_phased: stage 1 between K2 and K3, stage 2 once K5 is enqueued
   // K1
   mm::MinimizerSet mz;
   // K2 (same per-read offsets as mz.off; only the first sk_n[r] slots of a read are used)

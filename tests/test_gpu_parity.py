@@ -288,15 +288,15 @@ def test_l2_device_made_workgroups_equal_host_made(ctx, monkeypatch):
 
 
 def test_phased_map_batch_calls_back_once_and_changes_nothing(ctx):
-    """mm_map_batch_phased: the callback between the sketch and the seed stage runs once, on the calling thread; same records"""
+    """mm_map_batch_phased: the callbacks (sketches complete / last big kernel enqueued) run once each, in order, on the calling thread; same records"""
     import threading
     ref = ctx.synth_reference(seed=25, n_species=12, strains_per_species=3, genome_len=200_000, strain_divergence=0.02, genus_divergence=0.08)
     reads, _ = ctx.synth_reads(ref, seed=29, n_reads=600, read_len=6000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=10)
     idx = ctx.index(ref, 16, 8)
     calls = []
     A = ctx.map_batch(idx, reads, 16, 8)
-    B = ctx.map_batch(idx, reads, 16, 8, at_seed_stage=lambda: calls.append(threading.get_ident()))
-    assert calls == [threading.get_ident()]
+    B = ctx.map_batch(idx, reads, 16, 8, at_seed_stage=lambda: calls.append((1, threading.get_ident())), at_last_kernel=lambda: calls.append((2, threading.get_ident())))
+    assert calls == [(1, threading.get_ident()), (2, threading.get_ident())]
     (oa, ra), (ob, rb) = A.fetch(), B.fetch()
     assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and len(ra) > 500
     A.close(); B.close(); idx.close(); reads.close(); ref.close()

@@ -152,6 +152,7 @@ def main():
         rec_bufs = [np.empty(max(64 * args.reads, 1 << 16), dtype=capi.RECORD_DTYPE) for _ in ctxs]   # host result buffers reused by every step
         map_lock, agg_lock = threading.Lock(), threading.Lock()
         front_lock, back_lock = threading.Lock(), threading.Lock()
+        hold_lock = [bool(args.hold_lock_to_the_end)]
         em_turn = {"next": 0, "cv": threading.Condition()}
 
         def step(wi, serialise=True, ticket=0):
@@ -177,7 +178,7 @@ def main():
             try:
                 try:
                     M = c.map_batch(idx, reads_w[wi], k, w, pi=80.0, min_read_len=1000, at_seed_stage=swap if staged else None,
-                                    at_last_kernel=release if (serialise and not args.hold_lock_to_the_end) else None)
+                                    at_last_kernel=release if (serialise and not hold_lock[0]) else None)
                 finally:
                     if staged and not swapped[0]:
                         swap()
@@ -240,6 +241,13 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         st = agg["stats"]
+        # stage times of a step whose kernels all own the GPU (the timed region lets the next step's K1 queue behind K5): two more steps, untimed
+        st_clean = st
+        if W > 1 and sched is True and not hold_lock[0]:
+            keep = dict(agg)
+            hold_lock[0] = True; run_steps(2, sched); hold_lock[0] = False
+            st_clean = agg["stats"]
+            agg.clear(); agg.update(keep)
         free = None
         if args.measure_free_overlap and W > 1 and not args.free_overlap and world == 1 and shape == args.shape:   # beside the headline: the same steps with nothing serialised
             keep = dict(agg)
@@ -257,7 +265,7 @@ def main():
         else:
             bases_all = float(st["bases_long_enough"])
         return dict(ref=ref, idx=idx, reads=reads, reads_w=reads_w, truth=truth, contig_taxon=contig_taxon, info=info, desc=desc, t_ref=t_ref, t_index=t_index, free=free,
-                    agg=agg, st=st, dt=dt, steps=steps, bases_all=bases_all, value=bases_all * steps / dt / 1e9, ms_step=dt / steps * 1e3,
+                    agg=agg, st=st, st_clean=st_clean, dt=dt, steps=steps, bases_all=bases_all, value=bases_all * steps / dt / 1e9, ms_step=dt / steps * 1e3,
                     freq_threshold=idx.freq_threshold, reference_bp=int(ref.total_bases))
 
     R = run_shape(args.shape, args.steps, args.warmup)
@@ -296,7 +304,10 @@ def main():
                 "per_step": {kk: st[kk] for kk in ("n_reads_long_enough", "n_reads_mapped", "n_mappings", "sum_sketch", "sum_hits",
                                                    "n_candidates", "sum_l2_stream_entries", "sum_l2_evals", "n_ambiguous_sketch_reads",
                                                    "sum_hits_kept", "n_l2_rebuilds", "n_l2_wide_redo")},
-                "stage_ms": {kk: round(st[kk], 3) for kk in st if kk.startswith("ms_")},
+                "stage_ms": {kk: round(R["st_clean"][kk], 3) for kk in st if kk.startswith("ms_")},
+                "stage_ms_note": "stage times of a step run after the timed region with the mapping lock held to the end of the step; in the timed region the next step's K1 "
+                                 "queues behind K5 (config.parallelism), which shows up in that step's ms_minimizer / ms_total: stage_ms_timed_region",
+                "stage_ms_timed_region": {kk: round(st[kk], 3) for kk in st if kk.startswith("ms_")},
                 "host_wall_ms": {kk: round(v, 3) for kk, v in agg.get("host_ms", {}).items()},
             },
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -323,7 +334,7 @@ def main():
             R2 = run_shape(other, max(3, min(args.steps, 5)), 1)
             out["config"]["other_shape"] = {"shape": R2["desc"], "value": R2["value"], "unit": "Gbp/s", "ms_per_step": R2["ms_step"], "steps": R2["steps"],
                                             "reference_bp": R2["reference_bp"], "freq_threshold": R2["freq_threshold"],
-                                            "stage_ms": {kk: round(R2["st"][kk], 3) for kk in R2["st"] if kk.startswith("ms_")},
+                                            "stage_ms": {kk: round(R2["st_clean"][kk], 3) for kk in R2["st"] if kk.startswith("ms_")},
                                             "per_step": {kk: R2["st"][kk] for kk in ("n_reads_mapped", "n_mappings", "sum_sketch", "sum_hits", "sum_hits_kept", "n_candidates", "sum_l2_stream_entries")}}
         except Exception as e:
             out["config"]["other_shape"] = {"failed": str(e)}

@@ -12,7 +12,7 @@ def short(name):
 f = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 with open(os.path.join(out, "kernel_stats.txt"), "w") as w:
-    w.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-other-shape   (setup kernels: index build, synthetic data; per-step kernels: 6 calls)\n")
+    w.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-other-shape   (setup kernels: index build, synthetic data; per-step kernels: 10 calls = 2 warm-up + 4 timed + 2 with the lock held to the end + one per further worker context)\n")
     w.write(f"{'calls':>7} {'total_ms':>12} {'avg_ms':>12} {'%':>7}  kernel\n")
     for r in rows:
         w.write(f"{int(r['Calls']):>7} {float(r['TotalDurationNs'])/1e6:>12.3f} {float(r['AverageNs'])/1e6:>12.3f} {float(r['Percentage']):>7.3f}  {short(r['Name'])}\n")

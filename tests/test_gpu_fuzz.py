@@ -79,7 +79,7 @@ def _reads(rng, contigs, n):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MM_FUZZ_SEEDS", "24"))))   # MM_FUZZ_SEEDS=500 for a longer hunt
 def test_random_configurations_match_oracle(oracle_lib, tmp_path, seed):
     from metamaps_amd import capi
-    rng = np.random.default_rng(9000 + seed)
+    rng = np.random.default_rng(9000 + int(os.environ.get("MM_FUZZ_SEED_BASE", "0")) + seed)
     k = int(rng.integers(8, 25)); w = int(rng.integers(2, 26))
     pi = float(rng.choice([70.0, 80.0, 85.0, 92.0])); min_len = int(rng.choice([100, 500, 1000, 3000]))
     contigs = _reference(rng)
@@ -119,7 +119,7 @@ def test_random_long_reads_match_oracle(oracle_lib, tmp_path, seed):
     the pre-filter (sketches beyond 13 000 hashes), the dense K5 path with its lazy strand tie-break; reads of 30 ... 260 kb next to
     short ones in one batch, small windows so that the sketches get long, references with duplications and related contigs"""
     from metamaps_amd import capi
-    rng = np.random.default_rng(7000 + seed)
+    rng = np.random.default_rng(7000 + int(os.environ.get("MM_FUZZ_SEED_BASE", "0")) + seed)
     k = int(rng.integers(12, 21)); w = int(rng.integers(3, 12)); pi = float(rng.choice([75.0, 80.0, 88.0]))
     contigs = []
     root = rng.choice(ACGT, size=int(rng.integers(300_000, 500_000)))

@@ -3,7 +3,8 @@ position directory): seeded random parameters (k, w, identity threshold, minimum
 cases (related contigs, duplications inside a contig, tandem repeats, homopolymers, N runs, lower case, contigs shorter than
 w + k), reads of 60 ... 40 000 bases (shorter than k, shorter than w + k, longer than the 10 kb class) with 0-15 % errors, either
 strand, some random, some with N — every mapping record must equal the oracle's (computeMap.hpp:90-538 restated in oracle/).
-Round 2: MM_FUZZ_SEEDS=2500 MM_FUZZ_LONG_SEEDS=300 ran clean on an MI355X (35 minutes); the suite keeps 24 + 6 seeds."""
+Round 2: MM_FUZZ_SEEDS=2500 MM_FUZZ_LONG_SEEDS=300 and, with MM_FUZZ_SEED_BASE=100000, 2000 + 250 more ran clean on an MI355X
+(66 minutes together); the suite keeps 24 + 6 seeds."""
 import os
 
 import numpy as np

@@ -97,7 +97,8 @@ __global__ void __launch_bounds__(64) l2_dense_kernel(IndexView I, const int32_t
                                                       const uint64_t* __restrict__ code_off, const uint32_t* __restrict__ codes,
                                                       uint32_t* __restrict__ scratch, unsigned int* __restrict__ next_item,
                                                       uint8_t* __restrict__ amb_used /* optional: set per read when a vote needed an unresolved strand (bit 1 of the strand byte) */,
-                                                      int force_amb /* tests: flag every read whose vote saw such an entry */) {
+                                                      int force_amb /* tests: flag every read whose vote saw such an entry */,
+                                                      int early_stop /* leave a candidate once no later window can reach its best so far (0: evaluate every window, cross-check) */) {
   constexpr int INF = 0x7fffffff;
   __shared__ int tst[64];
   __shared__ uint8_t fdel[64], fadd[64];
@@ -213,7 +214,24 @@ __global__ void __launch_bounds__(64) l2_dense_kernel(IndexView I, const int32_t
     // ---- the reference's loop (computeMap.hpp:496-533): evaluate [b,e), then MIIteratorL2::next — 64 windows per round
     int best = 0, bestR = 0, beg_pos = 0, last_pos = 0, opt_b = 0, opt_e = 0;
     unsigned long long evals = 0, shifts = 0;
+    // Early end: a window shares at most as many hashes as it holds entries that carry a sketch hash, and every later window lies in
+    // [b, last_end).  Once fewer such entries are left there than the best so far (or than the acceptance threshold while nothing has
+    // reached it), no later window can reach OR equal it — neither the maximum nor the last position equal to it can change — and the
+    // candidate is done.  On a true hit that is shortly after the optimum: the tail of the range, about half of it, is not slid over.
+    int rem = 0;                                                  // entries with a sketch hash in [b, last_end)
+    if (early_stop) {
+      int a = 0;
+      for (int base = 0; base < last_end; base += 256) {
+        uint32_t wq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wq[u] = cw[min(base + 64 * u + lane, cmax)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a += (base + 64 * u + lane < last_end && ld_code(wq[u]) >= 0) ? 1 : 0;
+      }
+      rem = wave_sum(a);
+    }
     while (e < last_end) {
+      if (early_stop && rem < max(best, amin)) break;
       const Rec xb = pos[min(b + lane, nmax)];
       const Rec xe = pos[min(e + lane, nmax)];
       const int w64 = pw_wpos(pos[min(b + 64, nmax)].pw);
@@ -321,6 +339,7 @@ __global__ void __launch_bounds__(64) l2_dense_kernel(IndexView I, const int32_t
       int dn, an;
       if (n_eval < 64) { dn = __builtin_amdgcn_readlane(dj, n_eval); an = __builtin_amdgcn_readlane(aj, n_eval); }
       else { dn = __builtin_amdgcn_readlane(dj, 63) + __builtin_amdgcn_readlane(hasDel, 63); an = __builtin_amdgcn_readlane(aj, 63) + __builtin_amdgcn_readlane(hasAdd, 63); }
+      if (early_stop) rem -= __popcll(__ballot(lane < dn && cB >= 0));   // entries b .. b+dn-1 leave [b, last_end)
       b += dn; e += an;
       {                                                          // scalars of the zone after the consumed steps
         const int fE = an > 0 ? __builtin_amdgcn_readlane(pE, an - 1) : 0, fB = dn > 0 ? __builtin_amdgcn_readlane(pB, dn - 1) : 0;

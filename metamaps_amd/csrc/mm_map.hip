@@ -1567,7 +1567,8 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       DBuf<uint32_t> scratch((size_t)slots * l2_dense_slot_words(smax_l));
       DBuf<unsigned int> next(1); next.zero(st);
       l2_dense_kernel<<<dim3(slots), dim3(64), 0, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p,
-                                                      P.k, P.w, smax_l, M->l2.p, d_list.p, (int)nl, d_rng.p, d_coff.p, codes.p, scratch.p, next.p, amb_ptr, force_amb);
+                                                      P.k, P.w, smax_l, M->l2.p, d_list.p, (int)nl, d_rng.p, d_coff.p, codes.p, scratch.p, next.p, amb_ptr, force_amb,
+                                                      getenv("MM_L2_DENSE_NO_STOP") ? 0 : 1);
       MM_KERNEL_CHECK();
       MM_HIP(hipStreamSynchronize(st));                          // host vectors above are upload sources; the buffers die with this scope
     };

@@ -527,8 +527,15 @@ def test_l2_long_read_classes_equal_full_slide(ctx, monkeypatch, read_len, n_rea
     assert res["0"][2]["n_mappings"] > n_reads
     if read_len < 58_000:                                         # the LDS classes skip most windows ...
         assert res["0"][2]["sum_l2_evals"] < res["1"][2]["sum_l2_evals"]
-    else:                                                         # ... the long-read path (state in global memory) evaluates every window, like the full slide
-        assert res["0"][2]["sum_l2_evals"] == res["1"][2]["sum_l2_evals"]
+    else:                                                         # ... the long-read path (state in global memory) slides over every window up to the point
+        assert res["0"][2]["sum_l2_evals"] <= res["1"][2]["sum_l2_evals"]   # where nothing later can reach the best so far
+        monkeypatch.setenv("MM_L2_DENSE_NO_STOP", "1")            # without that early end: every window, like the full slide
+        M = ctx.map_batch(idx, reads, 16, 8)
+        off, rec = M.fetch()
+        assert np.array_equal(res["0"][0], off) and np.array_equal(res["0"][1], rec)
+        assert M.stats()["sum_l2_evals"] == res["1"][2]["sum_l2_evals"] and res["0"][2]["sum_l2_evals"] < 0.9 * res["1"][2]["sum_l2_evals"]
+        M.close()
+        monkeypatch.delenv("MM_L2_DENSE_NO_STOP")
     idx.close(); reads.close(); ref.close()
 
 

@@ -220,7 +220,9 @@ int mm_mapping_add_qualities(mm_ctx* ctx, mm_mapping* m, const mm_seqset* reads,
 /* default (non --all) reporting: per read keep the records whose identity is >= best - 1.0
  * (reportReadMappings, computeMap.hpp:546-587).  Apply per index chunk, before mm_mapping_concat / add_qualities. */
 int mm_mapping_keep_best(mm_ctx* ctx, mm_mapping* m, int k);
-/* merge the records of several index chunks read-wise, chunk order preserved (unifyFiles, mapWrap.h:128-132) */
+/* merge the records of several index chunks read-wise, chunk order preserved (unifyFiles, mapWrap.h:128-132).  The result carries
+ * records only (as after mm_mapping_release_intermediates: the debug taps return MM_ERR_STATE); its statistics are the work
+ * counters and stage times summed over the parts. */
 int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* contig_base, int n_parts, mm_mapping** out);
 /* the same from host-side parts, i.e. what mm_mapping_fetch returned for index chunks that live on OTHER GPUs (SURVEY §8 E1:
  * "records gathered to the read's owner"; the reference gathers them through its PREFIX.N files, mapWrap.h:417-437):
@@ -264,6 +266,11 @@ int mm_em_iterate_allreduce(mm_em* em, const double* f, double* f_next, double* 
  * (optional, up to ll_cap <= 1024 values) = log-likelihood of every iteration, *n_iter = iterations done.  Every rank of the
  * communicator calls it together and gets the same result. */
 int mm_em_run(mm_em* em, const double* f0, int max_iter, double* f_out, double* ll_trace, int ll_cap, int* n_iter);
+/* Goes on where the previous mm_em_run / mm_em_continue on `em` ended (same f, iteration count, previous log-likelihood) for up to
+ * max_iter more iterations; ll_trace receives the log-likelihoods of THESE iterations, *n_iter their number, *stopped (optional)
+ * whether the stop rule has fired (then further calls do nothing).  A caller that wants every round's log-likelihood of a long
+ * run (the reference prints each, fEM.h:616-634) calls mm_em_run and then mm_em_continue in slices of <= 1024 iterations. */
+int mm_em_continue(mm_em* em, int max_iter, double* f_out, double* ll_trace, int ll_cap, int* n_iter, int* stopped);
 /* final posteriors p_i for the current f (fEM.h:684-707) and the index of the best mapping per read (fEM.h:217) */
 int mm_em_posteriors(mm_em* em, const double* f, double* post /* [n_entries] */, int64_t* best /* [n_reads] */);
 

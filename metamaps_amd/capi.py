@@ -154,6 +154,7 @@ def lib() -> C.CDLL:
             "mm_em_iterate_allreduce": (C.c_int, [vp, vp, vp, P(f64)]),
             "mm_em_posteriors": (C.c_int, [vp, vp, vp, vp]),
             "mm_em_run": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, P(C.c_int)]),
+            "mm_em_continue": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, P(C.c_int), P(C.c_int)]),
             "mm_comm_unique_id": (C.c_int, [C.c_char_p]),
             "mm_comm_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
             "mm_comm_allreduce_f64": (C.c_int, [vp, vp, i64]),
@@ -507,6 +508,14 @@ class EM:
         n = C.c_int()
         self.ctx.check(lib().mm_em_run(self.h, _ptr(f0), max_iter, _ptr(f), _ptr(ll), len(ll), C.byref(n)))
         return f, ll[:min(n.value, len(ll))]
+
+    def continue_run(self, max_iter: int = 1000):
+        """up to max_iter more iterations from where run() / continue_run() stopped: (f, their log-likelihoods, stop rule fired)"""
+        f = np.zeros(self.n_taxa, dtype=np.float64)
+        ll = np.zeros(1024, dtype=np.float64)
+        n, stopped = C.c_int(), C.c_int()
+        self.ctx.check(lib().mm_em_continue(self.h, max_iter, _ptr(f), _ptr(ll), len(ll), C.byref(n), C.byref(stopped)))
+        return f, ll[:min(n.value, len(ll))], bool(stopped.value)
 
     def taxon_counts(self) -> np.ndarray:
         c = np.zeros(self.n_taxa, dtype=np.int64)

@@ -83,7 +83,7 @@ std::vector<std::string> split(const std::string& in, const std::string& d) {   
   return out;
 }
 
-struct Options { std::map<std::string, std::string> v; bool all = false, stream = false, shard = false; };
+struct Options { std::map<std::string, std::string> v; bool all = false, stream = false, shard = false, em_host = false; };
 Options parse(int argc, char** argv) {
   static const std::map<std::string, std::string> alias{{"-r", "reference"}, {"-q", "query"}, {"-o", "output"}, {"-k", "kmer"}, {"-p", "pval"},
       {"-w", "window"}, {"-m", "minReadLen"}, {"-t", "threads"}, {"--mm", "maxmemory"}, {"--pi", "perc_identity"}, {"-i", "index"}};
@@ -93,6 +93,7 @@ Options parse(int argc, char** argv) {
     if (a == "--all") { o.all = true; continue; }
     if (a == "--stream-chunks") { o.stream = true; continue; }
     if (a == "--shard-index") { o.shard = true; continue; }
+    if (a == "--em-host-reduce") { o.em_host = true; continue; }
     if (a == "-h" || a == "--help") { std::cout << "see the header of metamaps_main.cpp / the reference's README\n"; exit(0); }
     std::string key = alias.count(a) ? alias.at(a) : (a.rfind("--", 0) == 0 ? a.substr(2) : "");
     if (key.empty() || i + 1 >= argc) die("Unknown or incomplete option " + a);
@@ -957,7 +958,100 @@ bool write_unknown_species(const std::string& fn, const std::string& db, const T
   return true;
 }
 
-int classify_one(const std::vector<Dev>& devs, bool use_comm, const std::string& mapped, const std::string& db, size_t minReadsU) {   // meta::doEM, fEM.h:466-803
+// ------------------------------------------------------------------------------------------------------
+// The EM loop of classify across devices (meta::doEM, fEM.h:501-661).  The reads are sharded contiguously — rank order = read
+// order, as the reference shards them over OpenMP threads (:1229) —, every rank computes the per-taxon posterior sums and the
+// log-likelihood of its reads, the sums of the ranks are added (the merge of the per-thread sums, :583-600), and every rank
+// normalises and evaluates the stop rule (:624-639) on identical values.
+//   Rccl  one ncclAllReduce(f64, T+1) per iteration inside the device-resident loop (mm_em_run / mm_em_continue): the production path
+//   Host  each rank's partial sums (mm_em_iterate) added on the host in rank order — what the all-reduce delivers —; several ranks
+//         may then share one device, which is how everything AROUND the collective is tested on a one-GPU box (--em-host-reduce)
+//   None  one rank, no communicator
+enum class EmReduce { None, Rccl, Host };
+struct EmShard { size_t lo = 0, hi = 0, e0 = 0; std::vector<int64_t> soff; };   // reads [lo, hi); e0: first mapping of the shard; soff: shard-local offsets
+EmShard em_shard(const std::vector<int64_t>& off, size_t G, size_t d) {
+  const size_t NR = off.size() - 1, base = NR / G, rem = NR % G;
+  EmShard s;
+  s.lo = d * base + std::min(d, rem); s.hi = s.lo + base + (d < rem ? 1 : 0);
+  s.e0 = (size_t)off[s.lo];
+  s.soff.resize(s.hi - s.lo + 1);
+  for (size_t i = 0; i <= s.hi - s.lo; ++i) s.soff[i] = off[s.lo + i] - off[s.lo];
+  return s;
+}
+struct ThreadBarrier {
+  std::mutex m; std::condition_variable cv; const size_t n; size_t waiting = 0, gen = 0;
+  explicit ThreadBarrier(size_t n_) : n(n_) {}
+  void wait() { std::unique_lock<std::mutex> lk(m); const size_t g = gen; if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); } else cv.wait(lk, [&] { return gen != g; }); }
+};
+void print_em_round(long long it, double ll, double ll_prev) {  // the per-round lines of the reference's log (fEM.h:503, :602-603, :631-632)
+  std::cout << "EM round " << it << std::endl << "\n\tLog likelihood: " << ll << std::endl;
+  if (it > 0) std::cout << "\tImprovement: " << ll - ll_prev << "\n\tRelative   : " << ll / ll_prev << std::endl;
+}
+// f: start frequencies in, final frequencies out; post[mapping], best[read] (index into the whole mapping list) out
+void run_em_sharded(const std::vector<Dev>& devs, EmReduce reduce, const std::vector<int64_t>& off, const std::vector<int32_t>& taxon,
+                    const std::vector<double>& mapq, const std::vector<double>& inv, size_t NT, std::vector<double>& f,
+                    std::vector<double>& post, std::vector<int64_t>& best) {
+  const size_t G = devs.size();
+  if (reduce == EmReduce::None && G != 1) die("internal error: several EM ranks without a reduction");
+  char comm_id[MM_COMM_ID_BYTES];
+  if (reduce == EmReduce::Rccl && mm_comm_unique_id(comm_id) != MM_OK) die("RCCL: cannot create a communicator id");
+  const std::vector<double> f0 = f;
+  std::vector<std::vector<double>> part(G, std::vector<double>(NT + 1, 0.0));   // Host: the ranks' partial sums of one iteration
+  std::vector<double> f_cur = f0; bool host_stop = false; double ll_prev = 0;
+  ThreadBarrier bar(G);
+  const long long MAX_ITER = getenv("MM_EM_MAX_ITER") ? atoll(getenv("MM_EM_MAX_ITER")) : LLONG_MAX;   // (test hook; the reference has no cap)
+  const int SLICE = getenv("MM_EM_SLICE") ? std::max(1, atoi(getenv("MM_EM_SLICE"))) : 1024;           // iterations per device-resident call (test hook)
+  on_each(G, [&](size_t d) {
+    mm_ctx* ctx = devs[d].ctx;
+    if (reduce == EmReduce::Rccl) ck(ctx, mm_comm_init(ctx, comm_id, (int)d, (int)G), "RCCL communicator");
+    const EmShard sh = em_shard(off, G, d);
+    const size_t n = sh.hi - sh.lo;
+    mm_em* em; ck(ctx, mm_em_create(ctx, (int64_t)n, sh.soff.data(), taxon.data() + sh.e0, mapq.data() + sh.e0, inv.data() + sh.e0, (int32_t)NT, &em), "em");
+    std::vector<double> fl(NT);
+    if (reduce != EmReduce::Host) {
+      // the loop itself runs on the device (E step, sums, all-reduce, normalisation and the stop rule per iteration, no host round
+      // trip), in slices of <= 1024 iterations so that every round's log-likelihood reaches the log as in the reference
+      std::vector<double> lls((size_t)std::min(SLICE, 1024));
+      long long done = 0; double prev = 0;
+      for (bool first = true;; first = false) {
+        int n_iter = 0, stopped = 0;
+        const int want = (int)std::min<long long>((long long)lls.size(), MAX_ITER - done);
+        if (want <= 0) break;
+        if (first) { ck(ctx, mm_em_run(em, f0.data(), want, fl.data(), lls.data(), (int)lls.size(), &n_iter), "em"); stopped = n_iter < want; }
+        else ck(ctx, mm_em_continue(em, want, fl.data(), lls.data(), (int)lls.size(), &n_iter, &stopped), "em");
+        if (d == 0) for (int it = 0; it < n_iter; ++it) { print_em_round(done + it, lls[(size_t)it], prev); prev = lls[(size_t)it]; }
+        done += n_iter;
+        if (stopped || n_iter == 0) break;
+      }
+    } else {
+      for (long long it = 0; it < MAX_ITER; ++it) {
+        ck(ctx, mm_em_iterate(em, f_cur.data(), part[d].data(), &part[d][NT]), "em");
+        bar.wait();
+        if (d == 0) {                                            // the sum over the ranks, in rank order; normalisation (fEM.h:606-615); stop rule (:624-639)
+          std::vector<double> tot(NT + 1, 0.0);
+          for (size_t g = 0; g < G; ++g) for (size_t t = 0; t <= NT; ++t) tot[t] += part[g][t];
+          double sum = 0; for (size_t t = 0; t < NT; ++t) sum += tot[t];
+          for (size_t t = 0; t < NT; ++t) f_cur[t] = tot[t] / sum;
+          const double ll = tot[NT];
+          print_em_round(it, ll, ll_prev);
+          if (it > 0 && (ll - ll_prev) <= 1 && (1 - ll / ll_prev) < 0.0001) host_stop = true;
+          ll_prev = ll;
+        }
+        bar.wait();
+        if (host_stop) break;
+      }
+      fl = f_cur;
+    }
+    std::vector<int64_t> bl(n);
+    ck(ctx, mm_em_posteriors(em, fl.data(), post.data() + sh.e0, bl.data()), "posteriors");
+    for (size_t i = 0; i < n; ++i) best[sh.lo + i] = bl[i] < 0 ? -1 : bl[i] + (int64_t)sh.e0;   // rank-local index -> index into the whole mapping list
+    mm_em_destroy(em);
+    bar.wait();                                                  // (every rank has read f_cur)
+    if (d == 0) f = fl;
+  });
+}
+
+int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::string& mapped, const std::string& db, size_t minReadsU) {   // meta::doEM, fEM.h:466-803
   PhaseClock pc;
   // The mappings file once through: every line is tokenised where it lies (the reference splits every line again in every EM round,
   // fEM.h:1171-1214, :234-373), lines of one read are consecutive (mapWrap.h:128-149), contig IDs are interned.
@@ -1050,39 +1144,11 @@ int classify_one(const std::vector<Dev>& devs, bool use_comm, const std::string&
     }
   }
   pc.lap("c3 per-mapping fields");
-  // The EM loop (fEM.h:501-661).  With several GPUs the reads are sharded contiguously (the reference shards them over OpenMP
-  // threads, :1229); every rank computes the per-taxon posterior sums and the log-likelihood of its reads, one RCCL all-reduce
-  // per iteration (mm_em_iterate_allreduce) replaces the merge of the per-thread sums (:583-600), and every rank normalises and
-  // evaluates the stop rule on identical values.
-  const size_t G = devs.size(), NT = taxa.size(), NR = NRD;
+  const size_t NT = taxa.size(), NR = NRD;
   std::vector<double> f(NT, 1 / (double)NT);
   std::vector<double> post(taxon.size()); std::vector<int64_t> best(NR);
-  char comm_id[MM_COMM_ID_BYTES];
-  if (use_comm && mm_comm_unique_id(comm_id) != MM_OK) die("RCCL: cannot create a communicator id");
   std::cout << "Starting EM..." << std::endl;
-  on_each(G, [&](size_t d) {
-    mm_ctx* ctx = devs[d].ctx;
-    if (use_comm) ck(ctx, mm_comm_init(ctx, comm_id, (int)d, (int)G), "RCCL communicator");
-    const size_t base = NR / G, rem = NR % G, lo = d * base + std::min(d, rem), hi = lo + base + (d < rem ? 1 : 0);   // contiguous shard, rank order = read order
-    std::vector<int64_t> soff(hi - lo + 1);
-    for (size_t i = 0; i <= hi - lo; ++i) soff[i] = off[lo + i] - off[lo];
-    const size_t e0 = (size_t)off[lo];
-    mm_em* em; ck(ctx, mm_em_create(ctx, (int64_t)(hi - lo), soff.data(), taxon.data() + e0, mapq.data() + e0, inv.data() + e0, (int32_t)NT, &em), "em");
-    // the loop itself runs on the device (mm_em_run: E step, sums, all-reduce, normalisation and the stop rule of fEM.h:624-639 per
-    // iteration, no host round trip); the per-round lines of the reference's log follow from the log-likelihood trace
-    std::vector<double> fl(NT), lls(1024);
-    int n_iter = 0;
-    ck(ctx, mm_em_run(em, f.data(), 100000, fl.data(), lls.data(), (int)lls.size(), &n_iter), "em");
-    if (d == 0) for (int it = 0; it < n_iter && it < (int)lls.size(); ++it) {
-      std::cout << "EM round " << it << std::endl << "\n\tLog likelihood: " << lls[(size_t)it] << std::endl;
-      if (it > 0) std::cout << "\tImprovement: " << lls[(size_t)it] - lls[(size_t)it - 1] << "\n\tRelative   : " << lls[(size_t)it] / lls[(size_t)it - 1] << std::endl;
-    }
-    std::vector<int64_t> bl(hi - lo);
-    ck(ctx, mm_em_posteriors(em, fl.data(), post.data() + e0, bl.data()), "posteriors");
-    for (size_t i = 0; i < hi - lo; ++i) best[lo + i] = bl[i] < 0 ? -1 : bl[i] + (int64_t)e0;
-    if (d == 0) f = fl;
-    mm_em_destroy(em);
-  });
+  run_em_sharded(devs, reduce, off, taxon, mapq, inv, NT, f, post, best);
   pc.lap("c4 EM");
   std::cout << "Outputting mappings with adjusted alignment qualities." << std::endl;
   std::ofstream emf(mapped + ".EM"), r2t(mapped + ".EM.reads2Taxon"), kr(mapped + ".EM.reads2Taxon.krona"), li(mapped + ".EM.lengthAndIdentitiesPerMappingUnit");
@@ -1157,10 +1223,11 @@ int main(int argc, char** argv) {
     for (int p : device_list(o)) { Dev d; d.phys = p; devs.push_back(d); }
     for (auto& d : devs) if (mm_ctx_create(d.phys, &d.ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
     since("contexts created");
-    const bool use_comm = devs.size() > 1 || o.v.count("gpus") || o.v.count("devices");   // an explicit --gpus 1 also goes through RCCL (one rank)
+    // an explicit --gpus 1 also goes through RCCL (one rank); --em-host-reduce: the ranks' sums are added on the host (test hook: ranks may share a device)
+    const EmReduce reduce = o.em_host ? EmReduce::Host : ((devs.size() > 1 || o.v.count("gpus") || o.v.count("devices")) ? EmReduce::Rccl : EmReduce::None);
     const size_t minReadsU = o.v.count("minreads") ? std::stoull(o.v.at("minreads")) : 10000;   // parseCmdArgs.hpp:462-471
     for (auto& m : split(o.v.at("mappings"), ",")) {
-      classify_one(devs, use_comm, m, o.v.at("DB"), minReadsU);
+      classify_one(devs, reduce, m, o.v.at("DB"), minReadsU);
       for (auto& d : devs) mm_comm_destroy(d.ctx);
       since("mappings file done");
     }

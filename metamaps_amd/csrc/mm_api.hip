@@ -275,6 +275,8 @@ int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const
   if (!ctx || !idx || !reads || !p || !out) return MM_ERR_ARG;
   return guarded(ctx, [&] {
     MM_HIP(hipSetDevice(ctx->device));
+    MM_REQUIRE(idx->ctx->device == ctx->device, MM_ERR_ARG, "mm_map_batch: the index lives on another device than the context");
+    MM_REQUIRE(reads->ctx->device == ctx->device, MM_ERR_ARG, "mm_map_batch: the reads live on another device than the context");
     auto* M = new mm_mapping;
     try { mm::map_batch(ctx, idx, reads, *p, M); } catch (...) { delete M; throw; }
     *out = M;
@@ -284,6 +286,8 @@ int mm_map_batch_phased(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads
   if (!ctx || !idx || !reads || !p || !out) return MM_ERR_ARG;
   return guarded(ctx, [&] {
     MM_HIP(hipSetDevice(ctx->device));
+    MM_REQUIRE(idx->ctx->device == ctx->device, MM_ERR_ARG, "mm_map_batch_phased: the index lives on another device than the context");
+    MM_REQUIRE(reads->ctx->device == ctx->device, MM_ERR_ARG, "mm_map_batch_phased: the reads live on another device than the context");
     auto* M = new mm_mapping;
     M->at_stage = at_stage; M->at_stage_user = user;
     try { mm::map_batch(ctx, idx, reads, *p, M); } catch (...) { delete M; throw; }
@@ -384,11 +388,17 @@ int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* cont
     MM_HIP(hipStreamSynchronize(ctx->stream));
     for (int p = 0; p < n_parts; ++p) { op.push_back(offs[(size_t)p].data()); rp.push_back(recs[(size_t)p].data()); }
     mm_mapping* M = merge_parts(ctx, n, parts[0]->read_len, parts[0]->params, n_parts, op.data(), rp.data(), contig_base);
-    for (int p = 0; p < n_parts; ++p) {
-      M->stats.sum_hits += parts[p]->stats.sum_hits; M->stats.n_candidates += parts[p]->stats.n_candidates;
-      M->stats.sum_l2_stream_entries += parts[p]->stats.sum_l2_stream_entries; M->stats.sum_l2_evals += parts[p]->stats.sum_l2_evals;
-      M->stats.sum_sketch = parts[p]->stats.sum_sketch;
+    for (int p = 0; p < n_parts; ++p) {                          // work counters and stage times: summed over the chunks; per-read facts: of chunk 0
+      const mm_map_stats& S = parts[p]->stats;
+      M->stats.sum_hits += S.sum_hits; M->stats.n_candidates += S.n_candidates; M->stats.sum_hits_kept += S.sum_hits_kept;
+      M->stats.sum_l2_stream_entries += S.sum_l2_stream_entries; M->stats.sum_l2_evals += S.sum_l2_evals;
+      M->stats.n_l2_rebuilds += S.n_l2_rebuilds; M->stats.n_l2_wide_redo += S.n_l2_wide_redo;
+      M->stats.ms_minimizer += S.ms_minimizer; M->stats.ms_sketch += S.ms_sketch; M->stats.ms_probe_gather += S.ms_probe_gather;
+      M->stats.ms_sort_hits += S.ms_sort_hits; M->stats.ms_l1_scan += S.ms_l1_scan; M->stats.ms_l2 += S.ms_l2; M->stats.ms_compact += S.ms_compact;
+      M->stats.ms_total += S.ms_total; M->stats.ms_hit_filter += S.ms_hit_filter;
     }
+    M->stats.sum_sketch = parts[0]->stats.sum_sketch; M->stats.n_ambiguous_sketch_reads = parts[0]->stats.n_ambiguous_sketch_reads;
+    M->stats.n_reads_giant = parts[0]->stats.n_reads_giant;
     *out = M;
   });
 }
@@ -544,7 +554,16 @@ int mm_em_iterate_allreduce(mm_em* em, const double* f, double* f_next, double* 
 }
 int mm_em_run(mm_em* em, const double* f0, int max_iter, double* f_out, double* ll_trace, int ll_cap, int* n_iter) {
   if (!em || !f0 || max_iter <= 0 || !n_iter) return MM_ERR_ARG;
-  return guarded(em->ctx, [&] { *n_iter = mm::em_run(em, f0, max_iter, f_out, ll_trace, ll_cap); });
+  return guarded(em->ctx, [&] { MM_HIP(hipSetDevice(em->ctx->device)); *n_iter = mm::em_run(em, f0, max_iter, f_out, ll_trace, ll_cap, nullptr); });
+}
+int mm_em_continue(mm_em* em, int max_iter, double* f_out, double* ll_trace, int ll_cap, int* n_iter, int* stopped) {
+  if (!em || max_iter <= 0 || !n_iter) return MM_ERR_ARG;
+  return guarded(em->ctx, [&] {
+    MM_HIP(hipSetDevice(em->ctx->device));
+    bool st = false;
+    *n_iter = mm::em_run(em, nullptr, max_iter, f_out, ll_trace, ll_cap, &st);
+    if (stopped) *stopped = st ? 1 : 0;
+  });
 }
 int mm_em_posteriors(mm_em* em, const double* f, double* post, int64_t* best) {
   if (!em || !f) return MM_ERR_ARG;

@@ -25,7 +25,7 @@ void em_create_from_mapping(mm_ctx* ctx, const ::mm_mapping* M, const int32_t* c
                             int32_t n_taxa, mm_em* E);
 void em_iterate(mm_em* E, const double* f, double* f_partial, double* ll_partial);
 void em_iterate_allreduce(mm_em* E, const double* f, double* f_next, double* ll);
-int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_trace, int ll_cap);
+int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_trace, int ll_cap, bool* stopped);
 void em_posteriors(mm_em* E, const double* f, double* post, int64_t* best);
 void comm_unique_id(char* id);
 void comm_init(mm_ctx* ctx, const char* id, int rank, int nranks);

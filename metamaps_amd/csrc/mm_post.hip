@@ -308,7 +308,8 @@ void em_iterate_allreduce(mm_em* E, const double* f, double* f_next, double* ll)
 // the RCCL all-reduce, normalisation and the stop rule — all stream ordered, no host round trip.  The host enqueues iterations in
 // groups and only looks at the control word afterwards; iterations enqueued past the stop are no-ops (every rank sees the same
 // all-reduced values, so every rank stops at the same iteration and the collectives stay matched).
-// ctrl[0] = iterations done, ctrl[1] = stopped, ctrl[2] = bits of the previous log-likelihood.
+// ctrl[0] = iterations done, ctrl[1] = stopped (1: the stop rule fired, 2: the caller's iteration limit), ctrl[2] = bits of the
+// previous log-likelihood, ctrl[3] = first iteration of the current log-likelihood trace.
 // ---------------------------------------------------------------------------------------------------
 __global__ void em_estep_loop_kernel(const int64_t* __restrict__ read_off, const int32_t* __restrict__ taxon, const double* __restrict__ mapq,
                                      const double* __restrict__ inv_nloc, const double* __restrict__ f, int64_t n_reads,
@@ -359,7 +360,7 @@ __global__ void __launch_bounds__(256) em_ll_final_kernel(const double* __restri
 }
 // normalise (fEM.h:606-615; fixed-shape sum over the taxa, the same on every rank), log-likelihood trace, stop rule (:624-639)
 __global__ void __launch_bounds__(256) em_finalize_kernel(const double* __restrict__ partial, int32_t n_taxa, double* __restrict__ f, long long* __restrict__ ctrl,
-                                                          double* __restrict__ ll_trace, int ll_cap) {
+                                                          double* __restrict__ ll_trace, int ll_cap, long long it_limit) {
   if (ctrl[1]) return;
   __shared__ double sh[256];
   double acc = 0;
@@ -372,18 +373,23 @@ __global__ void __launch_bounds__(256) em_finalize_kernel(const double* __restri
   if (threadIdx.x == 0) {
     const long long it = ctrl[0];
     const double ll = partial[n_taxa], ll_prev = __longlong_as_double(ctrl[2]);
-    if (it < ll_cap) ll_trace[it] = ll;
+    const long long ti = it - ctrl[3];                             // ctrl[3]: iteration the trace buffer starts at (mm_em_continue)
+    if (ti >= 0 && ti < ll_cap) ll_trace[ti] = ll;
     if (it > 0 && (ll - ll_prev) <= 1 && (1 - ll / ll_prev) < 0.0001) ctrl[1] = 1;
+    if (it + 1 >= it_limit) ctrl[1] = 2;                           // the caller's iteration limit: the rest of the enqueued group are no-ops (on every rank)
     ctrl[2] = __double_as_longlong(ll);
     ctrl[0] = it + 1;
   }
 }
 
-int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_trace, int ll_cap) {
+// f0 == nullptr continues the loop where the previous call on E left it (same f, iteration count and previous log-likelihood):
+// mm_em_continue.  Returns the iterations done by this call; *stopped = the stop rule has fired.
+int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_trace, int ll_cap, bool* stopped) {
   mm_ctx* ctx = E->ctx;
   hipStream_t st = ctx->stream;
   const int32_t T = E->n_taxa;
   if (E->n_present < 0) {                                        // taxa with mappings on this rank
+    MM_REQUIRE(f0 != nullptr, MM_ERR_STATE, "mm_em_continue before mm_em_run");
     std::vector<int64_t> ts = E->tstart.to_host(st, (size_t)T + 1);
     std::vector<int32_t> pr;
     for (int32_t t = 0; t < T; ++t) if (ts[(size_t)t + 1] > ts[(size_t)t]) pr.push_back(t);
@@ -395,14 +401,25 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
     MM_HIP(hipStreamSynchronize(st));
   }
   const int cap = 1024;
-  E->f.upload(f0, (size_t)T, st);
-  E->local_partial.zero(st);
-  E->ctrl.zero(st);
-  const int64_t nb = ceil_div(std::max<int64_t>(E->n_reads, 1), 256);
   long long h_ctrl[4] = {0, 0, 0, 0};
+  if (f0) {
+    E->f.upload(f0, (size_t)T, st);
+    E->local_partial.zero(st);
+    E->ctrl.zero(st);
+  } else {                                                       // go on: a limit stop is lifted, a rule stop stays; the trace starts here
+    MM_HIP(hipMemcpyAsync(h_ctrl, E->ctrl.p, sizeof h_ctrl, hipMemcpyDeviceToHost, st));
+    MM_HIP(hipStreamSynchronize(st));
+    if (h_ctrl[1] == 2) h_ctrl[1] = 0;
+    h_ctrl[3] = h_ctrl[0];
+    MM_HIP(hipMemcpyAsync(E->ctrl.p, h_ctrl, sizeof h_ctrl, hipMemcpyHostToDevice, st));
+    MM_HIP(hipStreamSynchronize(st));
+  }
+  const long long it0 = h_ctrl[0], it_limit = it0 + max_iter;
+  const int64_t nb = ceil_div(std::max<int64_t>(E->n_reads, 1), 256);
   const int GROUP = 8;
-  while (true) {
-    for (int g = 0; g < GROUP; ++g) {
+  while (!h_ctrl[1]) {
+    const int g_n = (int)std::min<long long>(GROUP, it_limit - h_ctrl[0]);   // (the same on every rank: h_ctrl holds all-reduced decisions)
+    for (int g = 0; g < g_n; ++g) {
       if (E->n_reads > 0) {
         em_estep_loop_kernel<<<dim3((unsigned)ceil_div(E->n_reads, 128)), dim3(128), 0, st>>>(E->read_off.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->f.p,
                                                                                          E->n_reads, E->post.p, E->ll_read.p, E->ctrl.p);
@@ -421,16 +438,17 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
         ncclResult_t rc = ncclAllReduce(E->local_partial.p, E->partial.p, (size_t)T + 1, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, st);
         MM_REQUIRE(rc == ncclSuccess, MM_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
       } else MM_HIP(hipMemcpyAsync(E->partial.p, E->local_partial.p, sizeof(double) * ((size_t)T + 1), hipMemcpyDeviceToDevice, st));
-      em_finalize_kernel<<<dim3(1), dim3(256), 0, st>>>(E->partial.p, T, E->f.p, E->ctrl.p, E->ll_trace.p, cap);
+      em_finalize_kernel<<<dim3(1), dim3(256), 0, st>>>(E->partial.p, T, E->f.p, E->ctrl.p, E->ll_trace.p, cap, it_limit);
       MM_KERNEL_CHECK();
     }
     MM_HIP(hipMemcpyAsync(h_ctrl, E->ctrl.p, sizeof h_ctrl, hipMemcpyDeviceToHost, st));
     MM_HIP(hipStreamSynchronize(st));
-    if (h_ctrl[1] || h_ctrl[0] >= max_iter) break;
+    if (g_n <= 0) break;
   }
-  const int n_iter = (int)h_ctrl[0];
+  const int n_iter = (int)(h_ctrl[0] - it0);
+  if (stopped) *stopped = h_ctrl[1] == 1;
   if (f_out) E->f.download(f_out, (size_t)T, st);
-  if (ll_trace && ll_cap > 0) E->ll_trace.download(ll_trace, (size_t)std::min(std::min(n_iter, ll_cap), cap), st);
+  if (ll_trace && ll_cap > 0 && n_iter > 0) E->ll_trace.download(ll_trace, (size_t)std::min(std::min(n_iter, ll_cap), cap), st);
   MM_HIP(hipStreamSynchronize(st));
   return n_iter;
 }

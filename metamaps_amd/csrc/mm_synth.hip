@@ -137,6 +137,7 @@ __global__ void synth_community_kernel(uint32_t* __restrict__ packed, int64_t n_
 }
 
 void synth_community(mm_ctx* ctx, const mm_synth_community_params& p, mm_seqset* S, int32_t* contig_genome) {
+  MM_REQUIRE(p.n_genomes <= 12 * (int64_t)p.n_species, MM_ERR_ARG, "synthetic community: at most 12 strains per species (n_genomes <= 12 * n_species)");
   MM_REQUIRE(p.n_genomes > 0 && p.n_species > 0 && p.n_species <= p.n_genomes && p.n_genera > 0 && p.n_genera <= p.n_species && p.min_len >= 64 &&
              p.max_len >= p.min_len && p.median_len > 0 && p.human_contigs >= 0 && (p.human_contigs == 0 || (p.human_bases >= 4096 * (int64_t)p.human_contigs && p.n_repeat_families > 0)),
              MM_ERR_ARG, "bad synthetic community parameters");
@@ -147,7 +148,7 @@ void synth_community(mm_ctx* ctx, const mm_synth_community_params& p, mm_seqset*
   // strains per species: 1..12, heavier towards few, summing to n_genomes
   const int SP = p.n_species, NG = p.n_genomes;
   std::vector<int> strains((size_t)SP, 1);
-  { int left = NG - SP; while (left > 0) { const int sp = (int)(gen() % (uint64_t)SP); if (strains[(size_t)sp] < 12) { ++strains[(size_t)sp]; --left; } else if (NG > 12 * SP) break; } }
+  { int left = NG - SP; while (left > 0) { const int sp = (int)(gen() % (uint64_t)SP); if (strains[(size_t)sp] < 12) { ++strains[(size_t)sp]; --left; } } }   // (terminates: NG <= 12 * SP)
   std::vector<double> sp_len((size_t)SP);
   for (int i = 0; i < SP; ++i) sp_len[(size_t)i] = std::min<double>(p.max_len, std::max<double>(p.min_len, p.median_len * std::exp(p.sigma_len * gauss())));
   std::vector<int64_t> hlen((size_t)p.human_contigs);

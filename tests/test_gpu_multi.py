@@ -175,3 +175,125 @@ def test_records_gathered_from_parts_equal_device_concat(oracle_lib):
     for fld in ("read", "ref_contig", "ref_start", "shared", "sketch", "strand", "mapq"):
         assert np.array_equal(ra[fld], rb[fld]), fld
     ctx.close(); ctx2.close()
+
+
+# ---- the multi-rank classify bookkeeping (shard ranges, shard-local offsets, best-mapping rebasing, final f), everything around the
+# collective: `--em-host-reduce` adds the ranks' partial sums on the host in rank order (what the all-reduce delivers), so several
+# ranks may share the one GPU of the test box (run_em_sharded, csrc/host/metamaps_main.cpp; fEM.h:583-600, :1229)
+def _classify(prefix, db, extra, env=None):
+    p = subprocess.run([CLI, "classify", "--DB", db, "--mappings", prefix, "--minreads", "3"] + extra, capture_output=True, timeout=900,
+                       env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return p.stdout.decode()
+
+
+def _em_log(out):
+    return [l for l in out.splitlines() if l.startswith("EM round") or "Log likelihood" in l or "Improvement" in l or "Relative" in l]
+
+
+def _copy_run(src, dst, n_reads=None):
+    """the mapping run `src` as prefix `dst`; n_reads: only the lines of the first n mapped reads (the .meta follows)"""
+    import shutil
+    lines = open(src).read().splitlines(keepends=True)
+    meta = dict(l.split() for l in open(src + ".meta"))
+    if n_reads is not None:
+        ids, keep = [], []
+        for l in lines:
+            rid = l.split(" ", 1)[0]
+            if not ids or ids[-1] != rid:
+                if len(ids) == n_reads:
+                    break
+                ids.append(rid)
+            keep.append(l)
+        dropped = int(meta["ReadsMapped"]) - len(ids)
+        meta["ReadsMapped"] = str(len(ids)); meta["TotalReads"] = str(int(meta["TotalReads"]) - dropped)
+        lines = keep
+    open(dst, "w").write("".join(lines))
+    open(dst + ".meta", "w").write("".join(f"{k} {v}\n" for k, v in meta.items()))
+    shutil.copy(src + ".meta.unmappedReadsLengths", dst + ".meta.unmappedReadsLengths")
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_classify_shards_with_host_reduce_equal_oracle(small_run, devices):
+    """G = 2, 3 EM ranks on one device: .EM, reads2Taxon, WIMP, coverage == one rank == oracle; the EM log has the same rounds"""
+    o1, _, _ = _gpu_map(small_run, "hr", [])
+    d = small_run["dir"]
+    one, many = str(d / "hr_one"), str(d / ("hr_" + devices.replace(",", "")))
+    _copy_run(o1, one); _copy_run(o1, many)
+    log_one = _em_log(_classify(one, small_run["db"].dir, []))
+    log_many = _em_log(_classify(many, small_run["db"].dir, ["--devices", devices, "--em-host-reduce"]))
+    assert len(log_one) == len(log_many) > 4 and [l for l in log_one if l.startswith("EM round")] == [l for l in log_many if l.startswith("EM round")]
+    _classify_files_equal(many, one)
+    _classify_files_equal(many, small_run["oracle"]["plain"][0])
+
+
+@pytest.mark.parametrize("n_reads", [1, 2, 3, 4, 7, 10])
+def test_classify_shard_boundaries(small_run, n_reads):
+    """few reads, so that shards are empty (NR < G) or one read long and every cut falls on another read boundary:
+    G = 2, 3 (host reduce) == one rank, reads2Taxon byte for byte, posteriors and frequencies 1e-5"""
+    o1, _, _ = _gpu_map(small_run, "hb", [])
+    d = small_run["dir"]
+    one = str(d / f"hb_{n_reads}_one")
+    _copy_run(o1, one, n_reads)
+    _classify(one, small_run["db"].dir, [])
+    assert sum(1 for _ in open(one + ".EM.reads2Taxon")) >= n_reads
+    for devices in ("0,0", "0,0,0"):
+        many = str(d / f"hb_{n_reads}_{devices.replace(',', '')}")
+        _copy_run(o1, many, n_reads)
+        _classify(many, small_run["db"].dir, ["--devices", devices, "--em-host-reduce"])
+        _classify_files_equal(many, one)
+
+
+def test_classify_em_log_in_slices(small_run):
+    """the device-resident loop run in slices of 3 iterations (mm_em_run + mm_em_continue) prints and computes what one call does;
+    an iteration cap that is no multiple of the enqueue group ends exactly there"""
+    o1, _, _ = _gpu_map(small_run, "sl", [])
+    d = small_run["dir"]
+    a, b, c = str(d / "sl_a"), str(d / "sl_b"), str(d / "sl_c")
+    for x in (a, b, c):
+        _copy_run(o1, x)
+    log_a = _em_log(_classify(a, small_run["db"].dir, ["--gpus", "1"]))
+    log_b = _em_log(_classify(b, small_run["db"].dir, ["--gpus", "1"], {"MM_EM_SLICE": "3"}))
+    assert log_a == log_b and len(log_a) > 4
+    for suf in (".EM", ".EM.WIMP", ".EM.reads2Taxon"):
+        assert open(a + suf).read() == open(b + suf).read(), suf
+    log_c = _em_log(_classify(c, small_run["db"].dir, ["--gpus", "1"], {"MM_EM_MAX_ITER": "3"}))
+    assert [l for l in log_c if l.startswith("EM round")] == ["EM round 0", "EM round 1", "EM round 2"]
+
+
+def test_em_run_stops_at_max_iter_and_continues():
+    """mm_em_run(max_iter = 5) does 5 iterations, not a whole enqueue group of 8 (round-2 advisor finding); mm_em_continue goes on
+    from there to what an uninterrupted run gives"""
+    from metamaps_amd import capi, emhost
+    rng = np.random.default_rng(5)
+    n_reads, n_taxa = 3000, 23
+    per = rng.integers(1, 7, size=n_reads)
+    off = np.concatenate([[0], np.cumsum(per)]).astype(np.int64)
+    ne = int(off[-1])
+    taxon = rng.integers(0, n_taxa, size=ne).astype(np.int32)
+    mapq = rng.random(ne)
+    inv = 1.0 / rng.integers(1000, 5_000_000, size=ne).astype(np.float64)
+    ctx = capi.Context(0)
+    e = ctx.em(off, taxon, mapq, inv, n_taxa)
+    f0 = np.full(n_taxa, 1.0 / n_taxa)
+    f_all, lls_all = e.run(f0)
+    assert len(lls_all) > 6
+    f_ref, lls_ref = emhost.run_em(lambda x: e.iterate_allreduce(x), n_taxa)
+    assert len(lls_ref) == len(lls_all)
+    for cap in (1, 5, 9):
+        if cap + 2 >= len(lls_all):
+            continue
+        f5, lls5 = e.run(f0, max_iter=cap)
+        assert len(lls5) == cap and np.array_equal(lls5, lls_all[:cap])
+        f_host = f0
+        for _ in range(cap):
+            f_host, _ll = e.iterate_allreduce(f_host)
+        assert np.allclose(f5, f_host, rtol=1e-12, atol=1e-300)
+        f_c, lls_c, stopped = e.continue_run(2)
+        assert np.array_equal(lls_c, lls_all[cap:cap + 2]) and not stopped
+        f_c, lls_c, stopped = e.continue_run(1000)
+        assert stopped and np.array_equal(np.concatenate([lls5, lls_all[cap:cap + 2], lls_c])[:len(lls_all)], lls_all)
+        assert np.array_equal(f_c, f_all)
+        f_c2, lls_c2, stopped = e.continue_run(10)               # a stopped run stays stopped
+        assert stopped and len(lls_c2) == 0 and np.array_equal(f_c2, f_all)
+    e.close(); ctx.close()

@@ -29,6 +29,7 @@
 
 #include "../../../include/metamaps_hip.h"
 #include "seq_reader.hpp"
+#include "host_util.hpp"
 #include <sys/mman.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -73,15 +74,6 @@ struct PhaseClock {
 
 [[noreturn]] void die(const std::string& m) { std::cerr << m << std::endl; exit(1); }
 void ck(mm_ctx* ctx, int st, const char* what) { if (st != MM_OK) die(std::string(what) + ": " + mm_last_error(ctx)); }
-
-std::vector<std::string> split(const std::string& in, const std::string& d) {   // meta/util.h:80
-  std::vector<std::string> out;
-  if (in.empty()) return out;
-  size_t s = 0, p;
-  while ((p = in.find(d, s)) != std::string::npos) { out.push_back(in.substr(s, p - s)); s = p + d.size(); }
-  out.push_back(in.substr(s));
-  return out;
-}
 
 struct Options { std::map<std::string, std::string> v; bool all = false, stream = false, shard = false, em_host = false; };
 Options parse(int argc, char** argv) {
@@ -791,16 +783,6 @@ void write_wimp(const std::string& fn, const Taxonomy& T, const std::map<std::st
   }
 }
 
-// overlap of two closed intervals as computed by meta/util.h:118-172
-size_t iv_overlap_big_small(size_t bigL, size_t bigR, size_t smL, size_t smR) {
-  if (bigL <= smL && bigR >= smR) return smR - smL + 1;
-  if (smL >= bigL && smL <= bigR) return bigR - smL + 1;
-  if (smR >= bigL && smR <= bigR) return smR - bigL + 1;
-  return 0;
-}
-size_t iv_overlap(size_t aL, size_t aR, size_t bL, size_t bR) {
-  return (aR - aL + 1 > bR - bL + 1) ? iv_overlap_big_small(aL, aR, bL, bR) : iv_overlap_big_small(bL, bR, aL, aR);
-}
 // .EM.contigCoverage: bases of best mappings per 1000-bp window of every contig that carries one (fEM.h:684, :730-776,
 // :805-845).  Kept as the reference computes it, including the length it assigns to the last window of a contig that is
 // not a multiple of the window size (:744 subtracts after incrementing the window count, so the unsigned value wraps).

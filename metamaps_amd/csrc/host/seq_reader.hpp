@@ -72,7 +72,7 @@ class SeqFile {
           const unsigned char* ql = pl + 1;
           unsigned char qb = 0;
           for (const unsigned char* q = ql; q < ql + L; ++q) qb |= (unsigned char)((unsigned char)(*q - 33) > 94);
-          if (!qb) { view = (const char*)p; view_len = L; beg_ = (size_t)(ql + L - base); pending_ = 0; return true; }
+          if (!qb) { view = (const char*)p; view_len = L; beg_ = (size_t)(ql + L - base) + (ql + L < fe ? 1 : 0); pending_ = 0; return true; }   // (+1: kseq.h:200, below)
         }
       }
     }
@@ -103,6 +103,7 @@ class SeqFile {
     pending_ = (c == '>' || c == '@') ? c : 0; pending_pos_ = beg_ - 1;
     if (c != '+') return true;
     while ((c = get()) != -1 && c != '\n') {}
+    if (c == -1) { pending_ = 0; return false; }                 // the '+' line runs into the end of the file: -2 in kseq (kseq.h:196), also for an empty sequence
     size_t got = 0;                                              // qualities: as many characters in [33,127] as there are bases
     while (got < seq.size()) {
       if (beg_ >= end_) { const int ch = get(); if (ch == -1) break; --beg_; }
@@ -120,7 +121,9 @@ class SeqFile {
       }
     }
     pending_ = 0;
-    return got == seq.size();                                    // truncated quality string: kseq returns -2 and the callers' loops end (kseq.h:204)
+    if (got != seq.size()) return false;                         // truncated quality string: kseq returns -2 and the callers' loops end (kseq.h:204)
+    (void)get();                                                 // kseq.h:200 reads a character before it tests the count: the one behind the last quality is consumed too
+    return true;                                                 // (normally the line's '\n'; a '@' that follows without a line break is lost, as in the reference)
   }
 };
 

@@ -116,4 +116,19 @@ int orc_classify(const char* mapped, const char* db, double* ll, int ll_cap) {
   } catch (std::exception& e) { std::cerr << "oracle: " << e.what() << "\n"; return -1; }
 }
 
+// every record SeqReader returns, as tests/test_ref_host.py prints them for the real kseq: "name len fnv1a(seq)" lines + "END code"
+long orc_read_dump(const char* path, char* out, long cap) {
+  SeqReader rd(path);
+  long used = 0, len;
+  auto fnv = [](const std::string& s) { uint64_t h = 1469598103934665603ull; for (unsigned char ch : s) { h ^= ch; h *= 1099511628211ull; } return h; };
+  while ((len = rd.next()) >= 0) {
+    const int n = snprintf(out + used, (size_t)(cap - used), "%s %ld %016llx\n", rd.name.c_str(), len, (unsigned long long)fnv(rd.seq));
+    if (n < 0 || used + n >= cap) return -2;
+    used += n;
+  }
+  const int n = snprintf(out + used, (size_t)(cap - used), "END %ld\n", len);
+  if (n < 0 || used + n >= cap) return -2;
+  return used + n;
+}
+
 }  // extern "C"

@@ -2,8 +2,9 @@
 // FASTA/FASTQ(.gz) record reader with the observable behaviour of kseq_read
 // (common/kseq.h:170-207): a record starts at the next '>' or '@'; the name is the header
 // up to the first whitespace; sequence = every isgraph() byte until a '>', '+' or '@'
-// (anywhere, not just at line start); after '+', the rest of that line is skipped and
-// exactly len(seq) quality bytes in [33,127] are consumed.
+// (anywhere, not just at line start); after '+', the rest of that line is skipped,
+// len(seq) quality bytes in [33,127] are consumed and one more byte behind them (kseq.h:200).
+// Not reproduced: kseq holds its buffer as (signed) char, so a 0xFF byte reads as end of input.
 #pragma once
 #include <zlib.h>
 #include <cctype>
@@ -57,7 +58,9 @@ class SeqReader {
     while ((c = getc_()) != -1 && c != '\n') {}
     if (c == -1) return -2;
     size_t got = 0;
-    while (got < seq.size() && (c = getc_()) != -1)
+    // kseq.h:200 reads the character BEFORE it tests the count: the character behind the last quality (normally the line's
+    // '\n'; a '@' that follows without a line break is lost) is consumed too — pinned against the real kseq.h, tests/test_ref_host.py
+    while ((c = getc_()) != -1 && got < seq.size())
       if (c >= 33 && c <= 127) ++got;
     pending_ = 0;
     if (got != seq.size()) return -2;

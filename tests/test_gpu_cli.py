@@ -417,3 +417,100 @@ def test_cli_parallel_block_parser_equals_sequential_reader(tmp_path, mode):
         outs[tag] = (open(pre).read(), open(pre + ".meta").read(), open(pre + ".meta.unmappedReadsLengths").read())
     assert outs["seq"] == outs["one"] == outs["blocks"]
     assert len(outs["seq"][0]) > 10_000
+
+
+def test_cli_config0_against_committed_golden(tmp_path):
+    """BASELINE configs[0] through the GPU CLI against tests/golden/core_golden.json (hashes of the oracle CLI's files, committed):
+    integer-only files byte for byte, mapping lines / WIMP with the float columns at 1e-5"""
+    import hashlib, json
+    from metamaps_amd import synth
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "core_golden.json")))["config0"]
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=10, genome_len=200_000, seed=7)
+    rd = synth.make_reads(db, str(tmp_path / "reads.fq"), n_reads=1000, read_len=5000, seed=1)
+    pre = str(tmp_path / "out")
+    subprocess.run([CLI, "mapDirectly", "--all", "-r", db.fasta, "-q", rd["path"], "-o", pre], check=True, capture_output=True, timeout=900)
+    p = subprocess.run([CLI, "classify", "--DB", db.dir, "--mappings", pre, "--minreads", "3"], check=True, capture_output=True, timeout=900)
+    sha = lambda suf: hashlib.sha256(open(pre + suf, "rb").read()).hexdigest()[:24]
+    for suf in (".meta", ".meta.unmappedReadsLengths", ".EM.reads2Taxon"):
+        assert sha(suf) == g["sha"][suf], suf
+    assert sum(1 for _ in open(pre)) == g["n_lines"]
+    for x, y in zip(open(pre).read().splitlines()[:12], g["first_lines"]):
+        fx, fy = x.split(" "), y.split(" ")
+        assert fx[:13] == fy[:13] and _close(fx[13], fy[13]), (x, y)
+    par = dict(l.split(" ", 1) for l in open(pre + ".parameters").read().splitlines())
+    for l in g["parameters"]:
+        k_, v_ = l.split(" ", 1)
+        assert par[k_] == v_, l
+    wa, wb = open(pre + ".EM.WIMP").read().splitlines(), g["wimp"].splitlines()
+    assert len(wa) == len(wb)
+    for x, y in zip(wa, wb):
+        fx, fy = x.split("\t"), y.split("\t")
+        assert fx[:4] == fy[:4] and all(_close(u, v) for u, v in zip(fx[4:], fy[4:])), (x, y)
+    import re
+    lls = [float(x) for x in re.findall(r"Log likelihood: (\S+)", p.stdout.decode())]
+    assert len(lls) == len(g["log_likelihood"]) and np.allclose(lls, g["log_likelihood"], rtol=1e-5)
+
+
+def _two_line_fastq(path, recs, gz=False):
+    import gzip
+    op = gzip.open if gz else open
+    with op(path, "wb") as f:
+        for name, s in recs:
+            f.write(b"@" + name.encode() + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
+
+
+def test_cli_gz_query_and_gz_reference(oracle_lib, tmp_path):
+    """.gz query and .gz reference through the GPU CLI (kseq over gzFile: winSketch.hpp:245-248, computeMap.hpp:121) == plain files == oracle;
+    referenceSize is the size of the compressed file (commonFunc.hpp:211-231), so -w is given to keep the runs comparable"""
+    import gzip, shutil
+    import orc
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=6, genome_len=50_000, seed=5)
+    rd = synth.make_reads(db, str(tmp_path / "reads.fq"), n_reads=150, read_len=3000, seed=9)
+    for src in (db.fasta, rd["path"]):
+        with open(src, "rb") as f, gzip.open(src + ".gz", "wb") as g:
+            shutil.copyfileobj(f, g)
+    runs = {}
+    for tag, exe, r, q in (("plain", CLI, db.fasta, rd["path"]), ("gzq", CLI, db.fasta, rd["path"] + ".gz"), ("gzrq", CLI, db.fasta + ".gz", rd["path"] + ".gz"),
+                           ("cpu", orc.CLI, db.fasta + ".gz", rd["path"] + ".gz")):
+        pre = str(tmp_path / tag)
+        subprocess.run([exe, "mapDirectly", "--all", "-r", r, "-q", q, "-o", pre, "-w", "10"], check=True, capture_output=True, timeout=900)
+        runs[tag] = pre
+    assert sum(1 for _ in open(runs["plain"])) > 100
+    for tag in ("gzq", "gzrq"):
+        assert open(runs[tag]).read() == open(runs["plain"]).read()
+        assert open(runs[tag] + ".meta").read() == open(runs["plain"] + ".meta").read()
+    _cmp_table(runs["gzrq"], runs["cpu"], " ", {13})
+    assert open(runs["gzrq"] + ".meta.unmappedReadsLengths").read() == open(runs["cpu"] + ".meta.unmappedReadsLengths").read()
+
+
+def test_cli_duplicate_read_ids(oracle_lib, tmp_path):
+    """mapWrap.h:71-75: a read ID seen before stops the run (exit 1) when the repeat carries mappings; a repeated ID on reads that
+    do not map (or are too short) goes through.  GPU CLI and oracle CLI behave alike in both cases"""
+    import orc
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=4, genome_len=40_000, seed=3)
+    rd = synth.make_reads(db, str(tmp_path / "reads.fq"), n_reads=30, read_len=2500, seed=2, frac_random=0.0, frac_short=0.0, with_oddities=False)
+    recs = []
+    with open(rd["path"], "rb") as f:
+        while True:
+            h = f.readline()
+            if not h:
+                break
+            recs.append((h[1:].split()[0].decode(), f.readline().strip())); f.readline(); f.readline()
+    rng = np.random.default_rng(1)
+    junk = lambda n: bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n))
+    # (a) unmapped and too-short reads share IDs: fine
+    ok = recs[:10] + [("dupU", junk(2000)), ("dupU", junk(2100)), ("dupS", junk(100)), ("dupS", junk(120))] + recs[10:20]
+    _two_line_fastq(str(tmp_path / "ok.fq"), ok)
+    # (b) a mapped read repeats the ID of an earlier mapped read: both programs stop with exit code 1
+    bad = recs[:10] + [(recs[3][0], recs[12][1])] + recs[13:20]
+    _two_line_fastq(str(tmp_path / "bad.fq"), bad)
+    for exe, tag in ((CLI, "gpu"), (orc.CLI, "cpu")):
+        p = subprocess.run([exe, "mapDirectly", "--all", "-r", db.fasta, "-q", str(tmp_path / "ok.fq"), "-o", str(tmp_path / (tag + "_ok")), "-w", "10"], capture_output=True, timeout=900)
+        assert p.returncode == 0, (tag, p.stderr.decode()[-500:])
+        p = subprocess.run([exe, "mapDirectly", "--all", "-r", db.fasta, "-q", str(tmp_path / "bad.fq"), "-o", str(tmp_path / (tag + "_bad")), "-w", "10"], capture_output=True, timeout=900)
+        assert p.returncode == 1 and b"has already been processed" in p.stderr + p.stdout, (tag, p.returncode, p.stderr.decode()[-500:])
+    _cmp_table(str(tmp_path / "gpu_ok"), str(tmp_path / "cpu_ok"), " ", {13})
+    for suf in (".meta", ".meta.unmappedReadsLengths"):
+        assert open(str(tmp_path / "gpu_ok") + suf).read() == open(str(tmp_path / "cpu_ok") + suf).read(), suf

@@ -708,3 +708,47 @@ def test_l2_dense_path_equals_lds_classes(ctx, monkeypatch):
     assert res["lds"][2]["n_mappings"] > 4000
     assert res["dense"][2]["sum_l2_evals"] > 3 * res["lds"][2]["sum_l2_evals"]      # every window against the skip-ahead's few
     idx.close(); reads.close(); ref.close()
+
+
+def test_adversarial_minimizers_match_committed_golden(ctx):
+    """K1 on the adversarial winnowing set against tests/golden/core_golden.json (oracle output pinned in the repository: N runs,
+    lower case, palindromes, tandem repeats, len == k, len == k + w - 1, w from 1 to 100, k from 5 to 32)"""
+    import json, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    from make_core_golden import a2_digest
+    from adversarial import adversarial_cases
+    g = json.load(open(os.path.join(here, "golden", "core_golden.json")))["a2"]
+    by_kw = {}
+    for name, seq, k, w in adversarial_cases():
+        by_kw.setdefault((k, w), []).append((name, seq))
+    n = 0
+    for (k, w), lst in sorted(by_kw.items()):
+        S = ctx.seqset([s for _, s in lst])
+        off, h, wp, st = ctx.minimizers(S, k, w)
+        for i, (name, _) in enumerate(lst):
+            a, b = int(off[i]), int(off[i + 1])
+            assert [b - a, a2_digest(h[a:b], wp[a:b], st[a:b])] == g[name], (name, k, w)
+            n += 1
+        S.close()
+    assert n == len(g)
+
+
+def test_host_statistics_match_committed_golden():
+    """mm_min_hits_relaxed and the accept threshold behind mm_identity (host side of the library) against the committed tables"""
+    import json
+    from metamaps_amd import capi
+    import ctypes as C
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = json.load(open(os.path.join(here, "golden", "core_golden.json")))
+    L = capi.lib()
+    steps = np.array(g["min_hits"]["steps_up_at"])
+    for s in list(range(1, 300)) + list(range(300, 12001, 211)) + [12000]:
+        assert L.mm_min_hits_relaxed(s, 16, 80.0) == int((steps <= s).sum()), s
+    a, b = C.c_float(), C.c_float()
+    for s, v in list(zip(g["accept_min"]["s"], g["accept_min"]["min_shared"]))[::5]:
+        L.mm_identity(v, s, 16, C.byref(a), C.byref(b))
+        assert b.value >= 80.0
+        if v > 0:
+            L.mm_identity(v - 1, s, 16, C.byref(a), C.byref(b))
+            assert b.value < 80.0, (s, v)

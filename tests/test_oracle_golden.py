@@ -191,3 +191,47 @@ def test_unknown_species_distribution_functions_vs_scipy(oracle_lib):
         n = int(rng.integers(1, 20000)); lam = float(10 ** rng.uniform(-4, 1.5)); p = math.exp(-lam)
         k = int(min(n, max(0, rng.normal(n * p, 3 * math.sqrt(n * p * (1 - p)) + 1))))
         assert oracle_lib.L.orc_binom_cdf_sum(n, p, k) == pytest.approx(stats.binom.cdf(k, n, p), rel=1e-9, abs=1e-14)
+
+
+# ---- regression pins of the oracle's integer core (tests/golden/core_golden.json, written by tests/golden/make_core_golden.py)
+def _core_golden():
+    return json.load(open(os.path.join(HERE, "golden", "core_golden.json")))
+
+
+def test_core_golden_adversarial_minimizers(oracle_lib):
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_core_golden import a2_digest
+    from adversarial import adversarial_cases
+    g = _core_golden()["a2"]
+    cases = adversarial_cases()
+    assert len(cases) == len(g) >= 290
+    n_nonempty = 0
+    for name, seq, k, w in cases:
+        h, wp, st = oracle_lib.minimizers(seq, k, w)
+        assert [int(len(h)), a2_digest(h, wp, st)] == g[name], name
+        n_nonempty += len(h) > 0
+    assert n_nonempty > 200
+
+
+def test_core_golden_min_hits_and_accept_tables(oracle_lib):
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_core_golden import accept_min
+    g = _core_golden()
+    steps = np.array(g["min_hits"]["steps_up_at"])
+    for s in list(range(1, 400)) + list(range(400, 12001, 97)) + [785, 1176, 2353, 12000]:
+        assert oracle_lib.L.orc_min_hits_relaxed(s, 16, 80.0) == int((steps <= s).sum()), s
+    for s, v in list(zip(g["accept_min"]["s"], g["accept_min"]["min_shared"]))[::3]:
+        assert accept_min(oracle_lib, s) == v, s
+
+
+def test_core_golden_config0_through_the_oracle_cli(oracle_lib, tmp_path):
+    """BASELINE configs[0] (1000 x 5 kb reads vs the 10-genome mini DB) through the oracle CLI reproduces the committed file hashes"""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_core_golden import config0
+    g = _core_golden()["config0"]
+    now = config0(str(tmp_path))
+    assert now["sha"] == g["sha"] and now["meta"] == g["meta"] and now["first_lines"] == g["first_lines"]
+    assert now["wimp"] == g["wimp"] and now["log_likelihood"] == g["log_likelihood"] and len(g["log_likelihood"]) >= 3

@@ -73,6 +73,12 @@ int mm_seqset_upload(mm_seqset* s);                                /* pack + cop
  * winSketch.hpp:73-83).  The device index is rebuilt from it in seconds (mm_index_build), nothing derived is stored. */
 int mm_seqset_save(mm_seqset* set, const char* path);
 int mm_seqset_load(mm_ctx* ctx, const char* path, mm_seqset** out);
+/* Sequences [first, first + count) of an uploaded set as a set of their own, and several uploaded sets of one device back to back
+ * as one — device-side copies of the packed stream, nothing is packed again.  The CLI uploads the reference in bounded groups as
+ * its parser delivers the contigs (the reference streams contig by contig, winSketch.hpp:242-252), concatenates them and cuts
+ * the index chunks of --maxmemory (winSketch.hpp:274-329) out of the resident whole. */
+int mm_seqset_slice(mm_ctx* ctx, const mm_seqset* set, int64_t first, int64_t count, mm_seqset** out);
+int mm_seqset_concat(mm_ctx* ctx, const mm_seqset* const* parts, int n_parts, mm_seqset** out);
 int64_t mm_seqset_count(const mm_seqset* s);
 int64_t mm_seqset_total_bases(const mm_seqset* s);
 int mm_seqset_lengths(const mm_seqset* s, int32_t* len_out /* [count] */);
@@ -121,6 +127,9 @@ typedef struct {
   int64_t total_bases_target;                  /* > 0: microbial lengths are scaled so that everything sums to this          */
 } mm_synth_community_params;
 int mm_synth_community(mm_ctx* ctx, const mm_synth_community_params* p, mm_seqset** out, int32_t* contig_genome);
+/* genome_species[n_genomes]: the species (0 .. n_species-1) of every microbial genome of the community the same parameters generate
+ * (host arithmetic only: the truth labels of bench.py's and the full-size tests' species-level checks) */
+int mm_synth_community_species(const mm_synth_community_params* p, int32_t* genome_species);
 /* truth_genome (optional, [n_reads]) receives the source contig index or -1.  Reads are drawn from `n_abundant` contigs among
  * those long enough for the longest read (exception runs — N — of the reference read as A). */
 int mm_synth_reads(mm_ctx* ctx, const mm_seqset* reference, const mm_synth_read_params* p, mm_seqset** out,

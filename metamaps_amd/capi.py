@@ -110,6 +110,8 @@ def lib() -> C.CDLL:
             "mm_seqset_save": (C.c_int, [vp, C.c_char_p]),
             "mm_seqset_load": (C.c_int, [vp, C.c_char_p, P(vp)]),
             "mm_seqset_upload": (C.c_int, [vp]),
+            "mm_seqset_slice": (C.c_int, [vp, vp, i64, i64, P(vp)]),
+            "mm_seqset_concat": (C.c_int, [vp, P(vp), C.c_int, P(vp)]),
             "mm_seqset_count": (i64, [vp]),
             "mm_seqset_total_bases": (i64, [vp]),
             "mm_seqset_lengths": (C.c_int, [vp, vp]),
@@ -117,6 +119,7 @@ def lib() -> C.CDLL:
             "mm_synth_reference": (C.c_int, [vp, P(SynthRefParams), P(vp)]),
             "mm_synth_reads": (C.c_int, [vp, vp, P(SynthReadParams), P(vp), vp]),
             "mm_synth_community": (C.c_int, [vp, P(SynthCommunityParams), P(vp), vp]),
+            "mm_synth_community_species": (C.c_int, [P(SynthCommunityParams), vp]),
             "mm_minimizers": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, i64]),
             "mm_index_build": (C.c_int, [vp, vp, C.c_int, C.c_int, P(vp)]),
             "mm_index_destroy": (None, [vp]),
@@ -235,6 +238,16 @@ class Context:
         self.check(lib().mm_synth_community(self.h, C.byref(p), C.byref(h), _ptr(genome)))
         return SeqSet(self, h), genome
 
+    @staticmethod
+    def synth_community_species(**kw) -> np.ndarray:
+        """genome -> species of the community synth_community(**kw) generates"""
+        p = SynthCommunityParams(**kw)
+        sp = np.zeros(p.n_genomes, dtype=np.int32)
+        st = lib().mm_synth_community_species(C.byref(p), _ptr(sp))
+        if st != 0:
+            raise MMError(st, "mm_synth_community_species: bad parameters")
+        return sp
+
     def synth_reads(self, ref: "SeqSet", **kw):
         p = SynthReadParams(**kw)
         h = C.c_void_p()
@@ -334,6 +347,19 @@ class SeqSet:
         a = np.zeros(self.count, dtype=np.int32)
         self.ctx.check(lib().mm_seqset_lengths(self.h, _ptr(a)))
         return a
+
+    def slice(self, first: int, count: int) -> "SeqSet":
+        """sequences [first, first + count) as a set of their own (device-side copy)"""
+        h = C.c_void_p()
+        self.ctx.check(lib().mm_seqset_slice(self.ctx.h, self.h, first, count, C.byref(h)))
+        return SeqSet(self.ctx, h)
+
+    @staticmethod
+    def concat(ctx: "Context", parts: list) -> "SeqSet":
+        arr = (C.c_void_p * len(parts))(*[p.h for p in parts])
+        h = C.c_void_p()
+        ctx.check(lib().mm_seqset_concat(ctx.h, arr, len(parts), C.byref(h)))
+        return SeqSet(ctx, h)
 
     def save(self, path: str):
         self.ctx.check(lib().mm_seqset_save(self.h, path.encode()))

@@ -12,6 +12,8 @@ void seqset_upload(mm_seqset* s);
 void seqset_save(mm_seqset* s, const char* path);
 void seqset_load(mm_seqset* s, const char* path);
 void seqset_fetch(mm_seqset* s, int64_t i, char* out, int64_t cap);
+void seqset_slice(const mm_seqset* s, int64_t first, int64_t count, mm_seqset* o);
+void seqset_concat(const mm_seqset* const* parts, int n_parts, mm_seqset* o);
 }
 
 namespace {
@@ -130,6 +132,25 @@ int mm_seqset_load(mm_ctx* ctx, const char* path, mm_seqset** out) {
     *out = S;
   });
 }
+int mm_seqset_slice(mm_ctx* ctx, const mm_seqset* set, int64_t first, int64_t count, mm_seqset** out) {
+  if (!ctx || !set || !out) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
+    MM_REQUIRE(set->ctx->device == ctx->device, MM_ERR_ARG, "mm_seqset_slice: the set lives on another device than the context");
+    auto* S = new mm_seqset; S->ctx = ctx;
+    try { mm::seqset_slice(set, first, count, S); } catch (...) { delete S; throw; }
+    *out = S;
+  });
+}
+int mm_seqset_concat(mm_ctx* ctx, const mm_seqset* const* parts, int n_parts, mm_seqset** out) {
+  if (!ctx || !parts || n_parts <= 0 || !out) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
+    auto* S = new mm_seqset; S->ctx = ctx;
+    try { mm::seqset_concat(parts, n_parts, S); } catch (...) { delete S; throw; }
+    *out = S;
+  });
+}
 int64_t mm_seqset_count(const mm_seqset* s) { return s ? (s->frozen ? s->count() : (int64_t)s->staged.size()) : 0; }
 int64_t mm_seqset_total_bases(const mm_seqset* s) { return s ? s->total_bases : 0; }
 int mm_seqset_lengths(const mm_seqset* s, int32_t* len_out) {
@@ -149,6 +170,10 @@ int mm_synth_reference(mm_ctx* ctx, const mm_synth_ref_params* p, mm_seqset** ou
 int mm_synth_community(mm_ctx* ctx, const mm_synth_community_params* p, mm_seqset** out, int32_t* contig_genome) {
   if (!ctx || !p || !out) return MM_ERR_ARG;
   return guarded(ctx, [&] { auto* s = new mm_seqset; s->ctx = ctx; try { mm::synth_community(ctx, *p, s, contig_genome); } catch (...) { delete s; throw; } *out = s; });
+}
+int mm_synth_community_species(const mm_synth_community_params* p, int32_t* genome_species) {
+  if (!p || !genome_species) return MM_ERR_ARG;
+  return guarded(nullptr, [&] { mm::synth_community_species(*p, genome_species); });
 }
 int mm_synth_reads(mm_ctx* ctx, const mm_seqset* reference, const mm_synth_read_params* p, mm_seqset** out, int32_t* truth_genome) {
   if (!ctx || !reference || !p || !out) return MM_ERR_ARG;

@@ -14,7 +14,7 @@ struct mm_em {
   mm::DBuf<double> post, ll_read, f, partial, block_sum;
   // device-resident loop (mm_em_run): taxa with mappings on this rank, their partial sums, loop control, log-likelihood trace
   mm::DBuf<int32_t> present; int32_t n_present = -1;
-  mm::DBuf<double> local_partial, ll_trace;
+  mm::DBuf<double> local_partial, ll_trace, f_run;   // f_run: the loop's own frequencies (mm_em_iterate / mm_em_posteriors in between do not disturb mm_em_continue)
   mm::DBuf<long long> ctrl;
 };
 

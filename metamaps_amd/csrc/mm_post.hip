@@ -397,13 +397,14 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
     E->present.alloc(std::max<size_t>(pr.size(), 1)); E->present.upload(pr.data(), pr.size(), st);
     E->local_partial.alloc((size_t)T + 1);
     E->ll_trace.alloc(1024);
+    E->f_run.alloc((size_t)T);
     E->ctrl.alloc(4);
     MM_HIP(hipStreamSynchronize(st));
   }
   const int cap = 1024;
   long long h_ctrl[4] = {0, 0, 0, 0};
   if (f0) {
-    E->f.upload(f0, (size_t)T, st);
+    E->f_run.upload(f0, (size_t)T, st);
     E->local_partial.zero(st);
     E->ctrl.zero(st);
   } else {                                                       // go on: a limit stop is lifted, a rule stop stays; the trace starts here
@@ -421,7 +422,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
     const int g_n = (int)std::min<long long>(GROUP, it_limit - h_ctrl[0]);   // (the same on every rank: h_ctrl holds all-reduced decisions)
     for (int g = 0; g < g_n; ++g) {
       if (E->n_reads > 0) {
-        em_estep_loop_kernel<<<dim3((unsigned)ceil_div(E->n_reads, 128)), dim3(128), 0, st>>>(E->read_off.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->f.p,
+        em_estep_loop_kernel<<<dim3((unsigned)ceil_div(E->n_reads, 128)), dim3(128), 0, st>>>(E->read_off.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->f_run.p,
                                                                                          E->n_reads, E->post.p, E->ll_read.p, E->ctrl.p);
         MM_KERNEL_CHECK();
       }
@@ -438,7 +439,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
         ncclResult_t rc = ncclAllReduce(E->local_partial.p, E->partial.p, (size_t)T + 1, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, st);
         MM_REQUIRE(rc == ncclSuccess, MM_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
       } else MM_HIP(hipMemcpyAsync(E->partial.p, E->local_partial.p, sizeof(double) * ((size_t)T + 1), hipMemcpyDeviceToDevice, st));
-      em_finalize_kernel<<<dim3(1), dim3(256), 0, st>>>(E->partial.p, T, E->f.p, E->ctrl.p, E->ll_trace.p, cap, it_limit);
+      em_finalize_kernel<<<dim3(1), dim3(256), 0, st>>>(E->partial.p, T, E->f_run.p, E->ctrl.p, E->ll_trace.p, cap, it_limit);
       MM_KERNEL_CHECK();
     }
     MM_HIP(hipMemcpyAsync(h_ctrl, E->ctrl.p, sizeof h_ctrl, hipMemcpyDeviceToHost, st));
@@ -447,7 +448,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
   }
   const int n_iter = (int)(h_ctrl[0] - it0);
   if (stopped) *stopped = h_ctrl[1] == 1;
-  if (f_out) E->f.download(f_out, (size_t)T, st);
+  if (f_out) E->f_run.download(f_out, (size_t)T, st);
   if (ll_trace && ll_cap > 0 && n_iter > 0) E->ll_trace.download(ll_trace, (size_t)std::min(std::min(n_iter, ll_cap), cap), st);
   MM_HIP(hipStreamSynchronize(st));
   return n_iter;

@@ -252,6 +252,79 @@ void seqset_load(mm_seqset* s, const char* path) {
   s->frozen = true;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Slices and concatenations of uploaded sets, on the device: every sequence starts on a word boundary of the packed stream, so a
+// run of sequences is a run of words and only the stream coordinates (sequence starts, exception runs) shift.  The CLI packs the
+// reference once, in bounded groups as the parser delivers the contigs (winSketch.hpp:242-252 streams contig by contig),
+// concatenates the groups and cuts the index chunks of --maxmemory out of the resident whole.
+// ---------------------------------------------------------------------------------------------------
+static void exc_to_host(const mm_seqset* s, std::vector<uint64_t>& es, std::vector<uint32_t>& el, std::vector<uint8_t>& eb) {
+  hipStream_t st = s->ctx->stream;
+  if (s->n_exc) { es = s->exc_start.to_host(st, (size_t)s->n_exc); el = s->exc_len.to_host(st, (size_t)s->n_exc); eb = s->exc_byte.to_host(st, (size_t)s->n_exc); }
+}
+static void finish_derived(mm_seqset* o, const std::vector<uint64_t>& es, const std::vector<uint32_t>& el, const std::vector<uint8_t>& eb) {
+  hipStream_t st = o->ctx->stream;
+  const size_t n = o->len.size();
+  o->d_base.alloc(n + 1); o->d_base.upload(o->base.data(), n + 1, st);
+  o->d_len.alloc(std::max<size_t>(n, 1)); o->d_len.upload(o->len.data(), n, st);
+  o->n_exc = (int64_t)es.size();
+  if (o->n_exc) {
+    o->exc_start.alloc(es.size()); o->exc_start.upload(es.data(), es.size(), st);
+    o->exc_len.alloc(el.size()); o->exc_len.upload(el.data(), el.size(), st);
+    o->exc_byte.alloc(eb.size()); o->exc_byte.upload(eb.data(), eb.size(), st);
+  }
+  MM_HIP(hipStreamSynchronize(st));
+  o->frozen = true;
+}
+void seqset_slice(const mm_seqset* s, int64_t first, int64_t count, mm_seqset* o) {
+  MM_REQUIRE(s->frozen, MM_ERR_STATE, "sequence set not uploaded");
+  MM_REQUIRE(first >= 0 && count >= 0 && first + count <= s->count(), MM_ERR_ARG, "slice out of range");
+  hipStream_t st = o->ctx->stream;
+  const uint64_t b0 = s->base[(size_t)first], b1 = s->base[(size_t)(first + count)];
+  o->len.assign(s->len.begin() + first, s->len.begin() + first + count);
+  o->base.resize((size_t)count + 1);
+  o->total_bases = 0;
+  for (int64_t i = 0; i <= count; ++i) o->base[(size_t)i] = s->base[(size_t)(first + i)] - b0;
+  for (int64_t i = 0; i < count; ++i) o->total_bases += o->len[(size_t)i];
+  const size_t nw = (size_t)((b1 - b0) >> 4);
+  o->packed.alloc(nw + 1);                                       // (+1: the pad word every set ends on)
+  if (nw) MM_HIP(hipMemcpyAsync(o->packed.p, s->packed.p + (b0 >> 4), nw * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  MM_HIP(hipMemsetAsync(o->packed.p + nw, 0, sizeof(uint32_t), st));
+  std::vector<uint64_t> es, oes; std::vector<uint32_t> el, oel; std::vector<uint8_t> eb, oeb;
+  exc_to_host(s, es, el, eb);
+  const size_t lo = (size_t)(std::lower_bound(es.begin(), es.end(), b0) - es.begin()), hi = (size_t)(std::lower_bound(es.begin(), es.end(), b1) - es.begin());
+  for (size_t r = lo; r < hi; ++r) { oes.push_back(es[r] - b0); oel.push_back(el[r]); oeb.push_back(eb[r]); }   // (a run never crosses a sequence border)
+  finish_derived(o, oes, oel, oeb);
+}
+void seqset_concat(const mm_seqset* const* parts, int n_parts, mm_seqset* o) {
+  hipStream_t st = o->ctx->stream;
+  uint64_t bases = 0; size_t nseq = 0;
+  for (int p = 0; p < n_parts; ++p) {
+    MM_REQUIRE(parts[p] && parts[p]->frozen, MM_ERR_STATE, "sequence set not uploaded");
+    MM_REQUIRE(parts[p]->ctx->device == o->ctx->device, MM_ERR_ARG, "mm_seqset_concat: the parts live on another device");
+    bases += parts[p]->base.back(); nseq += parts[p]->len.size();
+  }
+  o->len.clear(); o->len.reserve(nseq); o->base.clear(); o->base.reserve(nseq + 1);
+  o->total_bases = 0;
+  o->packed.alloc((size_t)(bases >> 4) + 1);
+  std::vector<uint64_t> oes; std::vector<uint32_t> oel; std::vector<uint8_t> oeb;
+  uint64_t b0 = 0;
+  for (int p = 0; p < n_parts; ++p) {
+    const mm_seqset* s = parts[p];
+    const size_t nw = (size_t)(s->base.back() >> 4);
+    if (nw) MM_HIP(hipMemcpyAsync(o->packed.p + (b0 >> 4), s->packed.p, nw * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    for (size_t i = 0; i < s->len.size(); ++i) { o->len.push_back(s->len[i]); o->base.push_back(b0 + s->base[i]); }
+    o->total_bases += s->total_bases;
+    std::vector<uint64_t> es; std::vector<uint32_t> el; std::vector<uint8_t> eb;
+    exc_to_host(s, es, el, eb);
+    for (size_t r = 0; r < es.size(); ++r) { oes.push_back(es[r] + b0); oel.push_back(el[r]); oeb.push_back(eb[r]); }
+    b0 += s->base.back();
+  }
+  o->base.push_back(b0);
+  MM_HIP(hipMemsetAsync(o->packed.p + (b0 >> 4), 0, sizeof(uint32_t), st));
+  finish_derived(o, oes, oel, oeb);
+}
+
 void seqset_fetch(mm_seqset* s, int64_t i, char* out, int64_t cap) {
   MM_REQUIRE(s->frozen, MM_ERR_STATE, "sequence set not uploaded");
   MM_REQUIRE(i >= 0 && i < s->count(), MM_ERR_ARG, "sequence index out of range");

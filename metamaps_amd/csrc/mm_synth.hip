@@ -136,6 +136,23 @@ __global__ void synth_community_kernel(uint32_t* __restrict__ packed, int64_t n_
   }
 }
 
+// strains per species: 1..12, heavier towards few, summing to n_genomes (the first draws of the generator's random stream)
+static std::vector<int> community_strains(const mm_synth_community_params& p, std::mt19937_64& gen) {
+  const int SP = p.n_species, NG = p.n_genomes;
+  std::vector<int> strains((size_t)SP, 1);
+  int left = NG - SP;
+  while (left > 0) { const int sp = (int)(gen() % (uint64_t)SP); if (strains[(size_t)sp] < 12) { ++strains[(size_t)sp]; --left; } }   // (terminates: NG <= 12 * SP)
+  return strains;
+}
+// genome (= strain, numbered species by species) -> species of the community mm_synth_community generates from the same parameters
+void synth_community_species(const mm_synth_community_params& p, int32_t* genome_species) {
+  MM_REQUIRE(p.n_genomes > 0 && p.n_species > 0 && p.n_species <= p.n_genomes && p.n_genomes <= 12 * (int64_t)p.n_species, MM_ERR_ARG, "bad synthetic community parameters");
+  std::mt19937_64 gen(p.seed ^ 0x5eedc0ffeeull);
+  const std::vector<int> strains = community_strains(p, gen);
+  int g = 0;
+  for (int sp = 0; sp < p.n_species; ++sp) for (int k = 0; k < strains[(size_t)sp]; ++k) genome_species[g++] = sp;
+}
+
 void synth_community(mm_ctx* ctx, const mm_synth_community_params& p, mm_seqset* S, int32_t* contig_genome) {
   MM_REQUIRE(p.n_genomes <= 12 * (int64_t)p.n_species, MM_ERR_ARG, "synthetic community: at most 12 strains per species (n_genomes <= 12 * n_species)");
   MM_REQUIRE(p.n_genomes > 0 && p.n_species > 0 && p.n_species <= p.n_genomes && p.n_genera > 0 && p.n_genera <= p.n_species && p.min_len >= 64 &&
@@ -145,10 +162,8 @@ void synth_community(mm_ctx* ctx, const mm_synth_community_params& p, mm_seqset*
   std::mt19937_64 gen(p.seed ^ 0x5eedc0ffeeull);
   auto uni = [&]() { return (double)(gen() >> 11) * (1.0 / 9007199254740992.0); };
   auto gauss = [&]() { const double u1 = ((gen() >> 11) + 1) * (1.0 / 9007199254740993.0), u2 = uni(); return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2); };
-  // strains per species: 1..12, heavier towards few, summing to n_genomes
   const int SP = p.n_species, NG = p.n_genomes;
-  std::vector<int> strains((size_t)SP, 1);
-  { int left = NG - SP; while (left > 0) { const int sp = (int)(gen() % (uint64_t)SP); if (strains[(size_t)sp] < 12) { ++strains[(size_t)sp]; --left; } } }   // (terminates: NG <= 12 * SP)
+  std::vector<int> strains = community_strains(p, gen);
   std::vector<double> sp_len((size_t)SP);
   for (int i = 0; i < SP; ++i) sp_len[(size_t)i] = std::min<double>(p.max_len, std::max<double>(p.min_len, p.median_len * std::exp(p.sigma_len * gauss())));
   std::vector<int64_t> hlen((size_t)p.human_contigs);

@@ -5,5 +5,6 @@
 namespace mm {
 void synth_reference(mm_ctx* ctx, const mm_synth_ref_params& p, mm_seqset* out);
 void synth_community(mm_ctx* ctx, const mm_synth_community_params& p, mm_seqset* out, int32_t* contig_genome);
+void synth_community_species(const mm_synth_community_params& p, int32_t* genome_species);
 void synth_reads(mm_ctx* ctx, const mm_seqset* ref, const mm_synth_read_params& p, mm_seqset* out, int32_t* truth_genome);
 }

@@ -23,9 +23,25 @@ struct Params {
 // ---------------------------------------------------------------------------------------
 // A3/A4  reference sketch — map/include/winSketch.hpp:68-556
 // ---------------------------------------------------------------------------------------
+// minimizerPosLookupIndex (winSketch.hpp:119-120): hash -> occurrences in position order.  One unordered_map as in the reference;
+// for the timed CPU baseline of bench.py (no --maxmemory, -t N) the same map is split by hash % parts so that N threads can fill
+// it — the reference's single-threaded build of a >= 1 Gbp slice would take minutes of untimed set-up.  Lookups see no difference.
+struct HashLookup {
+  typedef std::unordered_map<uint32_t, std::vector<Hit>> Map;
+  std::vector<Map> part = std::vector<Map>(1);
+  Map& of(uint32_t h) { return part[part.size() == 1 ? 0 : h % part.size()]; }
+  const Map& of(uint32_t h) const { return part[part.size() == 1 ? 0 : h % part.size()]; }
+  std::vector<Hit>& operator[](uint32_t h) { return of(h)[h]; }
+  const std::vector<Hit>* find(uint32_t h) const { const Map& m = of(h); auto f = m.find(h); return f == m.end() ? nullptr : &f->second; }
+  size_t count(uint32_t h) const { return of(h).count(h); }
+  size_t size() const { size_t n = 0; for (auto& m : part) n += m.size(); return n; }
+  bool empty() const { return size() == 0; }
+  void clear() { part.assign(1, Map()); }
+};
+
 struct RefSketch {
   std::vector<Contig> meta;                                      // :102
-  std::unordered_map<uint32_t, std::vector<Hit>> lookup;         // :119-120
+  HashLookup lookup;                                             // :119-120
   std::vector<Mz> byPos;                                         // :129 (seq,wpos) ordered
   std::map<int, int> freqHist;                                   // :133 — never cleared between chunks
   int freqThreshold = INT_MAX;                                   // :94
@@ -42,7 +58,7 @@ struct RefSketch {
   // winSketch.hpp:452-494
   void compute_freq_hist() {
     if (lookup.empty()) return;
-    for (auto& e : lookup) freqHist[(int)e.second.size()] += 1;
+    for (auto& m : lookup.part) for (auto& e : m) freqHist[(int)e.second.size()] += 1;
     int64_t uniq = (int64_t)lookup.size();
     float pct = 0.001f;                                          // :91
     int64_t ignore = uniq * pct / 100;                           // int64 * float -> float, / int, truncation
@@ -109,6 +125,28 @@ struct RefSketch {
         for (int t = 1; t < std::max(1, P.threads); ++t) pool.emplace_back(work);
         work();
         for (auto& th : pool) th.join();
+      }
+      // no --maxmemory: the chunk rule decides nothing, so the per-contig count of novel hashes (a lookup per distinct hash) is
+      // skipped and, with -t N, the map is filled by N threads, thread t owning the hashes with hash % N == t; every thread walks
+      // the contigs in order, so every occurrence list is in position order exactly as the serial loop leaves it
+      const bool bulk = P.maxMem == 0 && P.threads > 1 && lookup.empty() && byPos.empty();
+      if (bulk) {
+        for (auto& x : pre) {
+          if (x.len < P.w || x.len < P.k) { meta.push_back(Contig{x.name, (int32_t)x.len}); ++seen; continue; }
+          for (auto& e : x.mz) e.seq = (int)seen;
+          byPos.insert(byPos.end(), x.mz.begin(), x.mz.end());
+          meta.push_back(Contig{x.name, (int32_t)x.len});
+          ++seen;
+          std::vector<Mz>().swap(x.mz);
+        }
+        const size_t NP = (size_t)std::min(P.threads, 64);
+        lookup.part.assign(NP, HashLookup::Map());
+        auto fill = [&](size_t t) { auto& m = lookup.part[t]; m.reserve(byPos.size() / NP / 8 + 16); for (const Mz& e : byPos) if (e.hash % NP == t) m[e.hash].push_back(Hit{e.seq, e.wpos, e.strand}); };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < NP; ++t) pool.emplace_back(fill, t);
+        fill(0);
+        for (auto& th : pool) th.join();
+        continue;
       }
       for (auto& x : pre) {
         const long len = x.len;
@@ -192,10 +230,10 @@ static inline void do_l1(const RefSketch& R, const Params& P, Query& Q, std::vec
   if (Q.sketch == 0) return;                                     // :302
   std::vector<Hit> hits;
   for (auto it = Q.mins.begin(); it != ue; ++it) {               // :307-323
-    auto f = R.lookup.find(it->hash);
-    if (f == R.lookup.end()) continue;
-    if (f->second.size() < (size_t)R.freqThreshold)              // size_t < int → converted as in the reference
-      hits.insert(hits.end(), f->second.begin(), f->second.end());
+    const std::vector<Hit>* f = R.lookup.find(it->hash);
+    if (!f) continue;
+    if (f->size() < (size_t)R.freqThreshold)                     // size_t < int → converted as in the reference
+      hits.insert(hits.end(), f->begin(), f->end());
   }
   int minHits = estimate_min_hits_relaxed(Q.sketch, P.k, P.pi);  // :325
   l1_candidates(Q, hits, minHits, out);

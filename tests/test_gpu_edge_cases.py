@@ -167,3 +167,49 @@ def test_seqset_save_load_round_trip(tmp_path):
     with pytest.raises(Exception):
         ctx.load_seqset(path)
     S.close(); T.close(); ctx.close()
+
+
+def test_seqset_slice_and_concat(ctx):
+    """mm_seqset_slice / mm_seqset_concat (device-side, no repacking): the sequences, their exception runs (N, IUPAC, lower case
+    upper-cased) and the minimizers computed from them equal those of sets uploaded from the same strings"""
+    from metamaps_amd import capi
+    rng = np.random.default_rng(12)
+    seqs = []
+    for i in range(37):
+        n = int(rng.choice([0, 1, 15, 16, 17, 31, 32, 33, 100, 1000, 4097]))
+        s = bytearray(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).tobytes())
+        if n > 40 and i % 3 == 0:
+            a = int(rng.integers(0, n - 20)); s[a:a + 17] = b"N" * 17
+        if n > 40 and i % 4 == 1:
+            s[5:9] = b"RYnn"
+        if n > 16 and i % 5 == 2:
+            s[n - 1:n] = b"N"                                      # an exception on the last base of a sequence
+        seqs.append(bytes(s))
+    whole = ctx.seqset(seqs)
+    want = [s.upper() for s in seqs]
+    k, w = 16, 5
+    off_w, h_w, wp_w, st_w = ctx.minimizers(whole, k, w)
+    cuts = [(0, 37), (0, 0), (5, 1), (3, 20), (20, 17), (36, 1), (37, 0)]
+    for a, n in cuts:
+        sl = whole.slice(a, n)
+        assert sl.count == n and list(sl.lengths()) == [len(x) for x in want[a:a + n]]
+        for j in range(n):
+            assert sl.fetch(j, len(want[a + j])) == want[a + j], (a, n, j)
+        off, h, wp, st = ctx.minimizers(sl, k, w)
+        lo, hi = int(off_w[a]), int(off_w[a + n])
+        assert np.array_equal(np.diff(off), np.diff(off_w[a:a + n + 1]))
+        assert np.array_equal(h, h_w[lo:hi]) and np.array_equal(wp, wp_w[lo:hi]) and np.array_equal(st, st_w[lo:hi])
+        sl.close()
+    parts = [whole.slice(0, 7), whole.slice(7, 0), whole.slice(7, 13), ctx.seqset(seqs[20:30]), whole.slice(30, 7)]
+    cat = capi.SeqSet.concat(ctx, parts)
+    assert cat.count == 37 and cat.total_bases == whole.total_bases
+    for j in range(37):
+        assert cat.fetch(j, len(want[j])) == want[j], j
+    off, h, wp, st = ctx.minimizers(cat, k, w)
+    assert np.array_equal(off, off_w) and np.array_equal(h, h_w) and np.array_equal(wp, wp_w) and np.array_equal(st, st_w)
+    idx_a, idx_b = ctx.index(whole, k, w), ctx.index(cat, k, w)
+    ea, eb = idx_a.entries(), idx_b.entries()
+    assert all(np.array_equal(x, y) for x, y in zip(ea, eb)) and len(ea[0]) > 100
+    for x in parts + [cat, whole]:
+        x.close()
+    idx_a.close(); idx_b.close()

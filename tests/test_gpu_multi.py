@@ -267,12 +267,15 @@ def test_em_run_stops_at_max_iter_and_continues():
     from metamaps_amd import capi, emhost
     rng = np.random.default_rng(5)
     n_reads, n_taxa = 3000, 23
-    per = rng.integers(1, 7, size=n_reads)
-    off = np.concatenate([[0], np.cumsum(per)]).astype(np.int64)
-    ne = int(off[-1])
-    taxon = rng.integers(0, n_taxa, size=ne).astype(np.int32)
-    mapq = rng.random(ne)
-    inv = 1.0 / rng.integers(1000, 5_000_000, size=ne).astype(np.float64)
+    ab = rng.lognormal(0, 2.0, n_taxa); ab /= ab.sum()           # skewed abundances + ambiguous reads: a dozen EM rounds
+    true = rng.choice(n_taxa, size=n_reads, p=ab)
+    off, taxon, mapq = [0], [], []
+    for r in range(n_reads):
+        others = rng.choice(n_taxa, size=rng.integers(1, 6), replace=False)
+        ts = [int(true[r])] + [int(o) for o in others if o != true[r]]
+        taxon += ts; mapq += [0.5] + list(rng.uniform(0.35, 0.5, len(ts) - 1)); off.append(len(taxon))
+    off = np.array(off, dtype=np.int64); taxon = np.array(taxon, dtype=np.int32); mapq = np.array(mapq)
+    inv = np.full(len(taxon), 1e-6)
     ctx = capi.Context(0)
     e = ctx.em(off, taxon, mapq, inv, n_taxa)
     f0 = np.full(n_taxa, 1.0 / n_taxa)
@@ -280,6 +283,7 @@ def test_em_run_stops_at_max_iter_and_continues():
     assert len(lls_all) > 6
     f_ref, lls_ref = emhost.run_em(lambda x: e.iterate_allreduce(x), n_taxa)
     assert len(lls_ref) == len(lls_all)
+    assert len(lls_all) >= 11
     for cap in (1, 5, 9):
         if cap + 2 >= len(lls_all):
             continue

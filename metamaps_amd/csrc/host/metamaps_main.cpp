@@ -236,30 +236,69 @@ int map_mode(const Options& o, const std::string& mode) {
   std::vector<std::string> cname; std::vector<int> clen;
   struct Chunk { int first, count; std::string file; };
   std::vector<Chunk> chunks;
-  std::deque<std::string> cseq;                                  // contig sequences, kept while chunk indexes are still to be built from them
+  // The packed reference (2 bits per base + exception runs, a quarter of the FASTA's size) lives on every device that builds indexes
+  // from it; the host holds contig names and lengths only.  Index chunks are cut out of it on the device (mm_seqset_slice).
+  std::vector<mm_seqset*> refset(G, nullptr);
   uint64_t hbm_free = 0;
   { char nm[8]; int cus; uint64_t tot; mm_ctx_device_info(ctx0, nm, sizeof nm, &cus, &tot, &hbm_free); }
   const double INDEX_BYTES_PER_BASE = 5.5;                       // pos + padded occ + table at w = 8; denser for smaller w
   auto fits = [&](uint64_t bases, double share) { return (double)bases * INDEX_BYTES_PER_BASE * 1.2 * share <= 0.8 * (double)hbm_free; };
-  auto make_part = [&](mm_ctx* ctx, int a, int bnd) {
-    mm_seqset* part; ck(ctx, mm_seqset_create(ctx, &part), "seqset");
-    for (int i = a; i < bnd; ++i) ck(ctx, mm_seqset_add_view(part, cseq[(size_t)i].data(), (int64_t)cseq[(size_t)i].size()), "add contig");
-    ck(ctx, mm_seqset_upload(part), "upload reference chunk");
+  auto make_part = [&](size_t d, int a, int bnd) {               // contigs [a, bnd) of the reference as a set of their own, on device d
+    mm_seqset* part; ck(devs[d].ctx, mm_seqset_slice(devs[d].ctx, refset[d], a, bnd - a, &part), "reference chunk");
     return part;
   };
+  auto drop_refsets = [&]() { for (auto*& r : refset) if (r) { mm_seqset_destroy(r); r = nullptr; } };
   uint64_t ref_bases = 0;
   mm_index* whole = nullptr;                                     // index of the whole reference on device 0, when one was built for the chunk plan
   if (!from_index) {
     // ---- reference (winSketch.hpp:180-365)
-    SeqFile f(ref);
-    while (f.next()) { cname.push_back(f.name); clen.push_back((int)f.seq.size()); ref_bases += f.seq.size(); cseq.push_back(std::move(f.seq)); f.seq.clear(); }
-    pc.lap("1 reference parse");
+    // The reference streams contig by contig (winSketch.hpp:242-252): a parser thread fills groups of ~1 Gbase, the main thread packs
+    // and uploads each group to every device while the next one is parsed, and drops the text.  Host memory: two groups.
+    {
+      struct Group { std::deque<std::string> seq; uint64_t bases = 0; };
+      std::mutex gm; std::condition_variable gcv; std::deque<std::unique_ptr<Group>> ready; bool parsed = false;
+      const uint64_t GROUP_BASES = getenv("MM_CLI_REF_GROUP_BASES") ? std::stoull(getenv("MM_CLI_REF_GROUP_BASES")) : (uint64_t)1 << 30;   // (test hook: small groups)
+      std::thread parser([&]() {
+        SeqFile f(ref);
+        auto g = std::make_unique<Group>();
+        auto hand_over = [&]() { std::unique_lock<std::mutex> lk(gm); gcv.wait(lk, [&] { return ready.size() < 2; }); ready.push_back(std::move(g)); gcv.notify_all(); g = std::make_unique<Group>(); };
+        while (f.next()) {
+          cname.push_back(f.name); clen.push_back((int)f.seq.size()); ref_bases += f.seq.size();
+          g->bases += f.seq.size(); g->seq.push_back(std::move(f.seq)); f.seq.clear();
+          if (g->bases >= GROUP_BASES) hand_over();
+        }
+        if (!g->seq.empty()) hand_over();
+        std::lock_guard<std::mutex> lk(gm); parsed = true; gcv.notify_all();
+      });
+      std::vector<std::vector<mm_seqset*>> parts(only_index ? 1 : G);
+      double t_pack = 0;
+      for (;;) {
+        std::unique_ptr<Group> g;
+        { std::unique_lock<std::mutex> lk(gm); gcv.wait(lk, [&] { return !ready.empty() || parsed; }); if (ready.empty()) break; g = std::move(ready.front()); ready.pop_front(); gcv.notify_all(); }
+        const auto t0 = std::chrono::steady_clock::now();
+        on_each(parts.size(), [&](size_t d) {
+          mm_seqset* p; ck(devs[d].ctx, mm_seqset_create(devs[d].ctx, &p), "seqset");
+          for (auto& q : g->seq) ck(devs[d].ctx, mm_seqset_add_view(p, q.data(), (int64_t)q.size()), "add contig");
+          ck(devs[d].ctx, mm_seqset_upload(p), "upload reference");
+          parts[d].push_back(p);
+        });
+        t_pack += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      }
+      parser.join();
+      on_each(parts.size(), [&](size_t d) {
+        if (parts[d].size() == 1) { refset[d] = parts[d][0]; return; }
+        if (parts[d].empty()) { ck(devs[d].ctx, mm_seqset_create(devs[d].ctx, &refset[d]), "seqset"); ck(devs[d].ctx, mm_seqset_upload(refset[d]), "upload reference"); return; }
+        ck(devs[d].ctx, mm_seqset_concat(devs[d].ctx, parts[d].data(), (int)parts[d].size(), &refset[d]), "reference");
+        for (auto* p : parts[d]) mm_seqset_destroy(p);
+      });
+      pc.lap("1 reference parse + pack + upload");
+      pc.add("2 reference pack+upload (inside 1)", t_pack);
+    }
     std::vector<int32_t> first(1, 0);
     if (!maxMem || fits(ref_bases, 1.0)) {
       // the index of the whole reference: the only chunk, or what the chunk rule of --maxmemory is evaluated on
       if (!maxMem && o.stream) die("--stream-chunks needs --maxmemory (the chunk rule of the reference, winSketch.hpp:274-329)");
-      mm_seqset* contigs = make_part(ctx0, 0, (int)cname.size());
-      pc.lap("2 reference pack+upload");
+      mm_seqset* contigs = refset[0];
       ck(ctx0, mm_index_build(ctx0, contigs, k, w, &whole), "index");
       pc.lap("3 index build");
       if (maxMem) {
@@ -269,7 +308,6 @@ int map_mode(const Options& o, const std::string& mode) {
         ck(ctx0, mm_index_plan_chunks(ctx0, whole, maxMem, first.data(), n, &n), "chunk plan");
       }
       if (only_index && first.size() == 1) ck(ctx0, mm_seqset_save(contigs, (ipre + ".1.seqset").c_str()), "store index chunk");
-      mm_seqset_destroy(contigs);
     } else {
       // The chunk rule without an index of the whole reference: it decides to close a chunk from the chunk's own content
       // and the next contig only, so it can be evaluated on the index of a contig range that fits the device.  Every cut
@@ -281,7 +319,7 @@ int map_mode(const Options& o, const std::string& mode) {
       while (c0 < C) {
         int c1 = c0; uint64_t bases = 0;
         while (c1 < C && (bases < range_bases || c1 == c0)) bases += (uint64_t)clen[(size_t)c1++];
-        mm_seqset* part = make_part(ctx0, c0, c1);
+        mm_seqset* part = make_part(0, c0, c1);
         mm_index* ri; ck(ctx0, mm_index_build(ctx0, part, k, w, &ri), "index (chunk planning range)");
         mm_seqset_destroy(part);
         int32_t n = 0;
@@ -310,11 +348,12 @@ int map_mode(const Options& o, const std::string& mode) {
       for (size_t c = 0; c < chunks.size(); ++c) {
         chunk_files.push_back(ipre + "." + std::to_string(c + 1) + ".seqset");
         if (chunks.size() == 1 && whole) continue;                // stored above, from the set the index was built on
-        mm_seqset* part = make_part(ctx0, chunks[c].first, chunks[c].first + chunks[c].count);
+        mm_seqset* part = make_part(0, chunks[c].first, chunks[c].first + chunks[c].count);
         ck(ctx0, mm_seqset_save(part, chunk_files.back().c_str()), "store index chunk");
         mm_seqset_destroy(part);
       }
       if (whole) mm_index_destroy(whole);
+      drop_refsets();
       std::ofstream args(ipre + ".arguments");
       if (!args.is_open()) die("Cannot open file " + ipre + ".arguments for serialization.");
       args.precision(17);
@@ -372,9 +411,10 @@ int map_mode(const Options& o, const std::string& mode) {
     if (!ch.file.empty()) {
       ck(d.ctx, mm_seqset_load(d.ctx, ch.file.c_str(), &part), "load index chunk");
       if ((int64_t)ch.count != mm_seqset_count(part)) die("Index chunk " + ch.file + " does not match " + ipre + ".contigs");
-    } else part = make_part(d.ctx, ch.first, ch.first + ch.count);
+    } else if (NC == 1) part = refset[(size_t)(&d - &devs[0])];    // the whole reference is the chunk: no copy
+    else part = make_part((size_t)(&d - &devs[0]), ch.first, ch.first + ch.count);
     ck(d.ctx, mm_index_build(d.ctx, part, k, w, &d.idx[c]), "index chunk");
-    mm_seqset_destroy(part);
+    if (!(ch.file.empty() && NC == 1)) mm_seqset_destroy(part);
   };
   // freqThreshold of chunk c from the histogram accumulated over chunks 0..c: call once per chunk, in chunk order, after some
   // device has built it; the value is then set on every copy of that chunk
@@ -398,7 +438,7 @@ int map_mode(const Options& o, const std::string& mode) {
   if (place == Place::Replicated) {
     on_each(G, [&](size_t d) { for (size_t c = 0; c < NC; ++c) build_chunk(devs[d], c); });
     for (size_t c = 0; c < NC; ++c) settle_threshold(c);
-    cseq.clear();
+    drop_refsets();
     pc.lap("3 index build");
   }
   // ---- reads (computeMap.hpp:104-172 + unifyFiles mapWrap.h:34-213)
@@ -695,7 +735,7 @@ int map_mode(const Options& o, const std::string& mode) {
     });
   }
   pc.lap("8 write");
-  cseq.clear();
+  drop_refsets();
   for (auto& d : devs) { for (auto* ix : d.idx) if (ix) mm_index_destroy(ix); mm_ctx_destroy(d.ctx); }
   return 0;
 }

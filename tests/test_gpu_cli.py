@@ -514,3 +514,12 @@ def test_cli_duplicate_read_ids(oracle_lib, tmp_path):
     _cmp_table(str(tmp_path / "gpu_ok"), str(tmp_path / "cpu_ok"), " ", {13})
     for suf in (".meta", ".meta.unmappedReadsLengths"):
         assert open(str(tmp_path / "gpu_ok") + suf).read() == open(str(tmp_path / "cpu_ok") + suf).read(), suf
+
+
+@pytest.mark.parametrize("extra", [["--all"], ["--all", "--maxmemory-bytes", "1000000"], ["--all", "--maxmemory-bytes", "1000000", "--stream-chunks"]])
+def test_cli_reference_streamed_in_groups(oracle_lib, tmp_path, monkeypatch, extra):
+    """the reference reaches the device in groups of contigs (here ~100 kb each: a dozen groups, concatenated on the device), the index
+    chunks are slices of the resident packed reference: same files as the oracle"""
+    monkeypatch.setenv("MM_CLI_REF_GROUP_BASES", "100000")
+    pa, g, c = _run_pair(tmp_path, [x for x in extra if x != "--stream-chunks"], gpu_only=[x for x in extra if x == "--stream-chunks"])
+    assert g == c and (g >= 2 or len(extra) == 1)

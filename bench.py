@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 
 def parse_args():
@@ -64,11 +64,20 @@ def parse_args():
     ap.add_argument("--hold-lock-to-the-end", action="store_true", help="release the mapping lock when mm_map_batch returns instead of when its last big kernel is enqueued")
     ap.add_argument("--free-overlap", action="store_true", help="do not serialise the mapping sections of the workers (higher throughput, kernel durations inflated)")
     ap.add_argument("--measure-free-overlap", action="store_true", help="after the timed region, six more steps with nothing serialised, reported in config.free_overlap")
+    ap.add_argument("--config", type=int, choices=(1, 3, 4), default=1, help="BASELINE.json configs[N] as far as one GPU carries it: 1 (default, the configuration `value` is "
+                    "quoted on) 100k x 10 kb ONT reads vs the resident index; 3: mixed 1-50 kb PacBio reads vs the index split by the --maxmemory chunk rule into resident "
+                    "chunk indexes; 4: 10 kb reads vs chunk indexes that are built, mapped and dropped in turn (the multi-pass streaming of an index larger than HBM)")
+    ap.add_argument("--distinct-batches", type=int, default=24, help="read batches generated up front (seeds 1000 + rank + 97 i); step s maps batch s mod this")
+    ap.add_argument("--chunk-gib", type=float, default=0.0, help="--maxmemory of configs 3 / 4 in GiB (default 70 -> 4 chunks for config 3, 25 -> 11 chunks for config 4)")
+    ap.add_argument("--batches-per-pass", type=int, default=4, help="config 4: read batches mapped against every chunk index of a pass (the index builds of a pass are inside the timed region)")
+    ap.add_argument("--no-e2e-full", action="store_true", help="skip e2e_cli_full (the drop-in CLI on the whole 26.8 GB DB.fa written to local disk: ~2 minutes)")
+    ap.add_argument("--e2e-dir", default=os.environ.get("MM_BENCH_E2E_DIR", ""), help="directory for the files of e2e_cli_full (default: a temporary directory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-shape", action="store_true", help="skip the second reference shape (config.other_shape)")
     ap.add_argument("--cpu-sample-reads", type=int, default=20000)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads for cpu_baseline (0 = all host cores, at most 64)")
-    ap.add_argument("--cpu-sample-genomes", type=int, default=100)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads for cpu_baseline (0 = all host cores)")
+    ap.add_argument("--cpu-sample-genomes", type=int, default=100, help="at least this many contigs in the CPU sample reference ...")
+    ap.add_argument("--cpu-sample-bases", type=float, default=1.0e9, help="... and at least this many bases (filled up with further contigs of the bench reference)")
     return ap.parse_args()
 
 
@@ -140,15 +149,19 @@ def main():
         ctx.synchronize()
         t_index = time.time() - t0
         info = idx.info()
-        reads_w, truth = [], None
-        for c in ctxs:                                           # every worker context holds the batch (the same reads)
-            rd, truth = c.synth_reads(ref, seed=1000 + rank, n_reads=args.reads, read_len=args.read_len, read_len_min=args.read_len_min,
-                                      frac_random=0.05, n_abundant=100, **err)
-            reads_w.append(rd)
-        reads = reads_w[0]
+        # distinct read batches, generated up front (packed 2-bit, resident): step s maps batch s mod B, so that no step re-maps what the
+        # step before it left in the caches.  The worker contexts read them in turn (read-only; any context of the device may).
+        B = max(1, min(args.distinct_batches, steps + max(warmup, 0)))
+        batches, truth = [], None
+        for b in range(B):
+            rd, tr = ctx.synth_reads(ref, seed=1000 + rank + 97 * b, n_reads=args.reads, read_len=args.read_len, read_len_min=args.read_len_min,
+                                     frac_random=0.05, n_abundant=100, **err)
+            batches.append(rd)
+            truth = tr if b == 0 else truth
+        reads = batches[0]
         ctx.synchronize()
         contig_len = ref.lengths().astype(np.int32)
-        agg = {"ms_l2": 0.0, "ms_hf": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0, "stats": None, "em_iters": 0}
+        agg = {"ms_l2": 0.0, "ms_hf": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0, "stats": None, "em_iters": 0, "bases": 0, "done_t": []}
         rec_bufs = [np.empty(max(64 * args.reads, 1 << 16), dtype=capi.RECORD_DTYPE) for _ in ctxs]   # host result buffers reused by every step
         map_lock, agg_lock = threading.Lock(), threading.Lock()
         front_lock, back_lock = threading.Lock(), threading.Lock()
@@ -177,7 +190,7 @@ def main():
                 map_lock.acquire()
             try:
                 try:
-                    M = c.map_batch(idx, reads_w[wi], k, w, pi=80.0, min_read_len=1000, at_seed_stage=swap if staged else None,
+                    M = c.map_batch(idx, batches[ticket % B], k, w, pi=80.0, min_read_len=1000, at_seed_stage=swap if staged else None,
                                     at_last_kernel=release if (serialise and not hold_lock[0]) else None)
                 finally:
                     if staged and not swapped[0]:
@@ -214,15 +227,19 @@ def main():
                                   "posteriors": (tt[4] - tt[3]) * 1e3}
                 agg["ms_l2"] += st["ms_l2"]; agg["launches"] += 1; agg["l2_stream"] += st["sum_l2_stream_entries"]
                 agg["ms_hf"] += st["ms_hit_filter"]; agg["hf_units"] += st["sum_hits"] + st["sum_sketch"]
-                agg["stats"] = st; agg["em_iters"] = len(lls)
+                agg["stats"] = st; agg["em_iters"] = len(lls); agg["bases"] += st["bases_long_enough"]; agg["done_t"].append(tt[4])
             return st
+
+        step_base = [0]
 
         def run_steps(n, serialise=True):
             """n steps, taken in turn by the worker threads (every rank runs the same schedule, so the collectives of communicator i match)"""
-            em_turn["next"] = 0
+            em_turn["next"] = step_base[0]
+            base = step_base[0]
+            step_base[0] += n
             def work(wi):
                 for s_i in range(wi, n, W):
-                    step(wi, serialise, s_i)
+                    step(wi, serialise, base + s_i)
             th = [threading.Thread(target=work, args=(wi,)) for wi in range(1, W)]
             for t in th:
                 t.start()
@@ -231,42 +248,65 @@ def main():
                 t.join()
 
         for wi in range(1, W):                                    # setup: every further worker context runs once (its scratch buffers get allocated)
-            step(wi, True, 0); em_turn["next"] = 0
+            em_turn["next"] = 0; step(wi, True, 0)
         sched = False if args.free_overlap else ("staged" if (args.staged_map and W > 1) else True)
         run_steps(max(warmup, 0), sched)
-        agg.update({"ms_l2": 0.0, "ms_hf": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0})
+        agg.update({"ms_l2": 0.0, "ms_hf": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0, "bases": 0, "done_t": []})
         barrier()
         t0 = time.perf_counter()
         run_steps(steps, sched)
         barrier()
         dt = time.perf_counter() - t0
         st = agg["stats"]
+        bases_timed = float(agg["bases"])
+        # step times inside the timed region: a step's time = from the previous step's completion (or the start) to its own — with W worker
+        # contexts the steps overlap, so this is the steady-state distance between results, the quantity `value` averages
+        done = sorted(agg["done_t"])
+        gaps = np.diff(np.array([t0] + done)) * 1e3 if done else np.array([dt * 1e3])
+        step_ms = {"min": float(gaps.min()), "median": float(np.median(gaps)), "max": float(gaps.max()), "first": float(gaps[0])}
         # stage times of a step whose kernels all own the GPU (the timed region lets the next step's K1 queue behind K5): two more steps, untimed
         st_clean = st
         if W > 1 and sched is True and not hold_lock[0]:
-            keep = dict(agg)
+            keep = dict(agg); keep["done_t"] = list(agg["done_t"])
             hold_lock[0] = True; run_steps(2, sched); hold_lock[0] = False
             st_clean = agg["stats"]
             agg.clear(); agg.update(keep)
         free = None
         if args.measure_free_overlap and W > 1 and not args.free_overlap and world == 1 and shape == args.shape:   # beside the headline: the same steps with nothing serialised
-            keep = dict(agg)
+            keep = dict(agg); agg["bases"] = 0
             barrier(); t1 = time.perf_counter(); run_steps(6, False); barrier()
             d1 = time.perf_counter() - t1
-            free = {"ms_per_step": d1 / 6 * 1e3, "value": float(st["bases_long_enough"]) * 6 / d1 / 1e9, "steps": 6}
+            free = {"ms_per_step": d1 / 6 * 1e3, "value": float(agg["bases"]) / d1 / 1e9, "steps": 6}
             agg.clear(); agg.update(keep)
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-            bb = torch.tensor([float(st["bases_long_enough"])], dtype=torch.float64, device="cuda")
+            bb = torch.tensor([bases_timed], dtype=torch.float64, device="cuda")
             dist.all_reduce(bb, op=dist.ReduceOp.SUM)
             bases_all = float(bb.item())
         else:
-            bases_all = float(st["bases_long_enough"])
-        return dict(ref=ref, idx=idx, reads=reads, reads_w=reads_w, truth=truth, contig_taxon=contig_taxon, info=info, desc=desc, t_ref=t_ref, t_index=t_index, free=free,
-                    agg=agg, st=st, st_clean=st_clean, dt=dt, steps=steps, bases_all=bases_all, value=bases_all * steps / dt / 1e9, ms_step=dt / steps * 1e3,
-                    freq_threshold=idx.freq_threshold, reference_bp=int(ref.total_bases))
+            bases_all = bases_timed
+        return dict(ref=ref, idx=idx, reads=reads, reads_w=batches, truth=truth, contig_taxon=contig_taxon, info=info, desc=desc, t_ref=t_ref, t_index=t_index, free=free,
+                    agg=agg, st=st, st_clean=st_clean, dt=dt, steps=steps, bases_all=bases_all, value=bases_all / dt / 1e9, ms_step=dt / steps * 1e3, step_ms=step_ms,
+                    n_batches=B, freq_threshold=idx.freq_threshold, reference_bp=int(ref.total_bases))
+
+    if args.config in (3, 4):
+        def allreduce_max_sum(dt, bases):
+            if world == 1:
+                return dt, bases
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            bb = torch.tensor([bases], dtype=torch.float64, device="cuda"); dist.all_reduce(bb, op=dist.ReduceOp.SUM)
+            return float(tt.item()), float(bb.item())
+        out = run_chunked(args, ctx, k, w, rank, world, barrier, allreduce_max_sum)
+        for c in ctxs:
+            c.close()
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     R = run_shape(args.shape, args.steps, args.warmup)
 
@@ -288,10 +328,11 @@ def main():
         out = {
             "metric": "Gbp long reads mapped+classified per sec (whole node), miniSeq+H DB",
             "value": R["value"], "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": R["ms_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": R["ms_step"], "step_ms": {kk: round(v, 3) for kk, v in R["step_ms"].items()}, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {
                 "workload": out_workload,
+                "baseline_config": "configs[1]", "distinct_read_batches": R["n_batches"],
                 "reads_per_gpu": args.reads, "read_len": args.read_len, "reference_bp": R["reference_bp"], "reference_contigs": info["n_contigs"],
                 "index_entries": info["n_entries"], "index_unique_hashes": info["n_unique_hashes"], "index_hbm_bytes": info["hbm_bytes"],
                 "freq_threshold": R["freq_threshold"], "reference_synth_s": round(R["t_ref"], 3), "index_build_s": round(R["t_index"], 3),
@@ -336,15 +377,167 @@ def main():
                                             "reference_bp": R2["reference_bp"], "freq_threshold": R2["freq_threshold"],
                                             "stage_ms": {kk: round(R2["st_clean"][kk], 3) for kk in R2["st"] if kk.startswith("ms_")},
                                             "per_step": {kk: R2["st"][kk] for kk in ("n_reads_mapped", "n_mappings", "sum_sketch", "sum_hits", "sum_hits_kept", "n_candidates", "sum_l2_stream_entries")}}
+            for rd in R2["reads_w"]:
+                rd.close()
+            R2["idx"].close(); R2["ref"].close()
         except Exception as e:
             out["config"]["other_shape"] = {"failed": str(e)}
+    for rd in R.get("reads_w", []):                              # everything off the device before the contexts go (and the CLI of e2e_cli_full comes)
+        rd.close()
+    R["idx"].close(); R["ref"].close()
+    for c in ctxs:
+        c.close()
+    if rank == 0 and world == 1 and not args.no_e2e_full and (args.scale == 1.0 or os.environ.get("MM_BENCH_E2E_ANY_SCALE")) and args.shape == "community" and not args.read_len_min:
+        try:
+            out["e2e_cli_full"] = e2e_cli_full(args, k, w, 1000 + rank)
+        except Exception as e:  # a reported side number; never let it kill the bench line
+            out["e2e_cli_full"] = {"failed": str(e)[:600]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    for c in ctxs:
-        c.close()
+
+
+def run_chunked(args, ctx, k, w, rank, world, barrier, allreduce_max_sum):
+    """BASELINE configs[3] / configs[4] as far as one GPU carries them (the same JSON contract as the default mode):
+      3  mixed-length PacBio-error reads (1-50 kb, log-uniform) against the reference split by the --maxmemory chunk rule
+         (winSketch.hpp:274-329) into chunk indexes that all stay resident; a step maps one batch against every chunk, merges read-wise in
+         chunk order (unifyFiles, mapWrap.h:128-145), mapping qualities over the union, EM
+      4  the multi-pass streaming of an index that does not fit HBM: a step is one PASS — every chunk index is built, `--batches-per-pass`
+         resident read batches are mapped against it, the records go to the host, the index is dropped; then merge, mapping qualities, EM
+         per batch.  The index builds are inside the timed region (they recur with every pass; the reference rebuilds them with every run)."""
+    from metamaps_amd import capi
+    mode = args.config
+    if mode == 3 and args.read_len == 10_000 and not args.read_len_min:      # config 3's read shape unless the caller chose one
+        args.read_len, args.read_len_min, args.pacbio, args.reads = 50_000, 1_000, True, min(args.reads, 60_000)
+    err = dict(sub_rate=0.02, ins_rate=0.08, del_rate=0.02) if args.pacbio else dict(sub_rate=0.04, ins_rate=0.03, del_rate=0.05)
+    gib = args.chunk_gib or (70.0 if mode == 3 else 25.0)
+    t0 = time.time()
+    ref, contig_taxon, n_taxa, desc = build_reference(ctx, args, args.shape)
+    contig_len = ref.lengths().astype(np.int32)
+    whole = ctx.index(ref, k, w)
+    info = whole.info()
+    plan = whole.plan_chunks(int(gib * args.scale * (1 << 30)))
+    whole.close()
+    bounds = [(a, (plan[i + 1] if i + 1 < len(plan) else ref.count) - a) for i, a in enumerate(plan)]
+    base = [a for a, _ in bounds]
+    # per-chunk freqThreshold from the histogram accumulated over the chunks (never cleared, winSketch.hpp:452-494)
+    acc, thr, thrs, chunk_idx, t_build = {}, 2**31 - 1, [], [], []
+    for a, n in bounds:
+        tb = time.time()
+        sl = ref.slice(a, n); ix = ctx.index(sl, k, w, auto_threshold=False); sl.close()
+        ctx.synchronize(); t_build.append(time.time() - tb)
+        counts, nh = ix.freq_hist()
+        for c_, n_ in zip(counts.tolist(), nh.tolist()):
+            acc[c_] = acc.get(c_, 0) + n_
+        cc = np.array(sorted(acc), dtype=np.int64); hh = np.array([acc[c_] for c_ in cc.tolist()], dtype=np.int64)
+        thr = capi.lib().mm_freq_threshold_from_hist(cc.ctypes.data, hh.ctypes.data, len(cc), ix.info()["n_unique_hashes"], thr)
+        thrs.append(int(thr)); ix.set_freq_threshold(thr)
+        if mode == 3:
+            chunk_idx.append(ix)
+        else:
+            ix.close()
+    t_setup = time.time() - t0
+    n_batches = max(1, min(args.distinct_batches, (args.steps + max(args.warmup, 0)) * (args.batches_per_pass if mode == 4 else 1)))
+    batches = [ctx.synth_reads(ref, seed=1000 + rank + 97 * b, n_reads=args.reads, read_len=args.read_len, read_len_min=args.read_len_min, frac_random=0.05, n_abundant=100, **err)[0]
+               for b in range(n_batches)]
+    lens = [b.lengths() for b in batches]
+    agg = {"ms_l2": 0.0, "ms_hf": 0.0, "l2_stream": 0, "hf_units": 0, "bases": 0, "launch_sets": 0, "em_iters": 0, "ms_index": 0.0, "stage": {}, "st": None, "done_t": []}
+
+    def note(st):
+        agg["ms_l2"] += st["ms_l2"]; agg["ms_hf"] += st["ms_hit_filter"]; agg["l2_stream"] += st["sum_l2_stream_entries"]; agg["hf_units"] += st["sum_hits"] + st["sum_sketch"]
+        for kk in st:
+            if kk.startswith("ms_"):
+                agg["stage"][kk] = agg["stage"].get(kk, 0.0) + st[kk]
+
+    def classify(M):
+        em = ctx.em_from_mapping(M, contig_taxon, contig_len, n_taxa)
+        seen = (em.taxon_counts() > 0).astype(np.float64)
+        ctx.comm_allreduce(seen)
+        present = seen > 0
+        f, lls = em.run(np.where(present, 1.0 / max(int(present.sum()), 1), 0.0))
+        em.posteriors(f)
+        em.close()
+        agg["em_iters"] = len(lls)
+
+    def step(s_i):
+        if mode == 3:
+            rd = batches[s_i % n_batches]
+            parts = [ctx.map_batch(ix, rd, k, w, pi=80.0, min_read_len=1000) for ix in chunk_idx]
+            U = capi.Mapping.concat(ctx, parts, base)
+            for p_ in parts:
+                p_.close()
+            U.add_qualities(k); U.fetch()
+            st = U.stats(); note(st); agg["st"] = st; agg["bases"] += st["bases_long_enough"]; agg["launch_sets"] += 1
+            classify(U); U.close()
+        else:
+            bs = [(s_i * args.batches_per_pass + j) % n_batches for j in range(args.batches_per_pass)]
+            host = [[] for _ in bs]
+            for ci, (a, n) in enumerate(bounds):
+                tb = time.perf_counter()
+                sl = ref.slice(a, n); ix = ctx.index(sl, k, w, auto_threshold=False); sl.close(); ix.set_freq_threshold(thrs[ci])
+                ctx.synchronize(); agg["ms_index"] += (time.perf_counter() - tb) * 1e3
+                for j, b in enumerate(bs):
+                    M = ctx.map_batch(ix, batches[b], k, w, pi=80.0, min_read_len=1000)
+                    o, r = M.fetch(); host[j].append((o, r.copy()))
+                    st = M.stats(); note(st); agg["st"] = st
+                    M.close()
+                ix.close()
+            for j, b in enumerate(bs):
+                V = capi.Mapping.from_parts(ctx, lens[b], host[j], base, k, w)
+                V.add_qualities(k); V.fetch()
+                agg["bases"] += V.stats()["bases_long_enough"]; agg["launch_sets"] += 1
+                classify(V); V.close()
+        agg["done_t"].append(time.perf_counter())
+
+    for s_i in range(max(args.warmup, 0)):
+        step(s_i)
+    for kk in ("ms_l2", "ms_hf", "ms_index"):
+        agg[kk] = 0.0
+    agg.update({"l2_stream": 0, "hf_units": 0, "bases": 0, "launch_sets": 0, "stage": {}, "done_t": []})
+    barrier()
+    t0 = time.perf_counter()
+    for s_i in range(args.steps):
+        step(max(args.warmup, 0) + s_i)
+    barrier()
+    dt = time.perf_counter() - t0
+    dt, bases_all = allreduce_max_sum(dt, float(agg["bases"]))
+    gaps = np.diff(np.array([t0] + agg["done_t"])) * 1e3
+    cands = [("l2_kernel (all launches of the timed region)", 8.0 * agg["l2_stream"], agg["ms_l2"]), ("seed_filter_kernel / hit_filter_kernel (all launches of the timed region)", 8.0 * agg["hf_units"], agg["ms_hf"])]
+    dom_name, dom_bytes, dom_ms = max(cands, key=lambda c_: c_[2])
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    len_txt = f"{args.read_len}" if not args.read_len_min else f"{args.read_len_min}-{args.read_len}"
+    what = ("the index split by the --maxmemory chunk rule into resident chunk indexes, every batch mapped against each, merged in chunk order" if mode == 3 else
+            f"chunk indexes built, mapped ({args.batches_per_pass} resident read batches per pass) and dropped in turn: the index builds of every pass are inside the timed region")
+    out = {
+        "metric": "Gbp long reads mapped+classified per sec (whole node), miniSeq+H DB",
+        "value": bases_all / dt / 1e9, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "step_ms": {"min": round(float(gaps.min()), 3), "median": round(float(np.median(gaps)), 3), "max": round(float(gaps.max()), 3)},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[{mode}] on one GPU per rank: {args.reads} synthetic {len_txt} bp {'PacBio' if args.pacbio else 'ONT'}-error reads per batch vs synthetic miniSeq+H-shaped "
+                        f"index ({desc}; {ref.total_bases / 1e9:.2f} Gbp), k=16 w={w}, --all, --maxmemory {gib:g} GiB -> {len(bounds)} index chunks; {what}",
+            "baseline_config": f"configs[{mode}]", "reads_per_batch": args.reads, "read_len": args.read_len, "read_len_min": args.read_len_min,
+            "batches_per_step": args.batches_per_pass if mode == 4 else 1, "distinct_read_batches": n_batches,
+            "reference_bp": int(ref.total_bases), "reference_contigs": info["n_contigs"], "index_entries": info["n_entries"],
+            "chunks": len(bounds), "chunk_first_contig": base, "chunk_freq_thresholds": thrs, "chunk_index_build_s": [round(x, 3) for x in t_build],
+            "setup_s": round(t_setup, 2), "em_iterations": agg["em_iters"],
+            "per_timed_region": {"bases": int(agg["bases"]), "batches_classified": agg["launch_sets"], "sum_l2_stream_entries": int(agg["l2_stream"]), "probes_plus_hits": int(agg["hf_units"]),
+                                 "ms_index_builds": round(agg["ms_index"], 1), "stage_ms_sum": {kk: round(v, 2) for kk, v in agg["stage"].items()}},
+            "mapping_only_value": (bases_all / max(dt - agg["ms_index"] * 1e-3, 1e-9) / 1e9) if mode == 4 else None,
+            "parallelism": f"reads sharded x{world}, every rank holds / streams every chunk index, RCCL all-reduce of EM sums; one context per GPU, steps one after the other",
+        },
+        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes": dom_bytes, "ms": dom_ms,
+                     "other_kernels": {n_: {"ms": m_, "algorithmic_bytes": b_, "achieved": (b_ / (m_ * 1e-3) / 1e9 if m_ > 0 else 0.0)} for n_, b_, m_ in cands if n_ != dom_name}},
+    }
+    for b in batches:
+        b.close()
+    for ix in chunk_idx:
+        ix.close()
+    ref.close()
+    return out
 
 
 def measured_traffic(args, kernel: str):
@@ -362,12 +555,12 @@ def measured_traffic(args, kernel: str):
 
 
 def cpu_baseline_and_cli(args, R, k, w):
-    """The oracle (CPU restatement of the reference, `-t` = host cores) and the drop-in CLI (FASTQ in, files out) on the same
+    """The oracle (CPU restatement of the reference, `-t` = every host core) and the drop-in CLI (FASTQ in, files out) on the same
     bounded sample of the bench workload, written to disk: the contigs the first `cpu_sample_reads` bench reads come from (up to
-    `cpu_sample_genomes`, filled up with further contigs) as DB.fa + DBDIR, those reads as FASTQ.  The full 26.8 Gbp index is far
-    beyond a CPU budget of seconds (the reference indexes ~2 Mbp/s on one thread), so the sample reference is ~1/100 of it;
-    per-read CPU cost grows with the seed hits the reference draws, i.e. the CPU figure is an UPPER bound of what the full
-    reference would give."""
+    `cpu_sample_genomes`), filled up with further contigs of the bench reference to `cpu_sample_bases` (1 Gbp), as DB.fa + DBDIR;
+    those reads as FASTQ.  The full 26.8 Gbp index is beyond a CPU budget of seconds (the reference indexes ~2 Mbp/s on one thread;
+    the oracle fills its hash map with all threads when no --maxmemory is given), so the sample reference is ~1/27 of it; per-read
+    CPU cost grows with the seed hits the reference draws, i.e. the CPU figure is an UPPER bound of what the full reference would give."""
     from metamaps_amd import synth
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
     exe = os.path.join(ROOT, "oracle", "_build", "metamaps_oracle")
@@ -386,13 +579,13 @@ def cpu_baseline_and_cli(args, R, k, w):
         if len(pick_reads) >= args.cpu_sample_reads:
             break
     contigs = sorted(allowed)
-    c = 0
-    while len(contigs) < args.cpu_sample_genomes and c < len(cl):
-        if c not in contigs and cl[c] <= 20_000_000:
-            contigs.append(c)
+    have, bases_have, c = set(contigs), int(sum(int(cl[ci]) for ci in contigs)), 0
+    while (len(contigs) < args.cpu_sample_genomes or bases_have < args.cpu_sample_bases * min(args.scale, 1.0)) and c < len(cl):
+        if c not in have and cl[c] <= 20_000_000:
+            contigs.append(c); have.add(c); bases_have += int(cl[c])
         c += 1
     nproc = len(os.sched_getaffinity(0))
-    cores = args.cpu_threads or min(nproc, 64)
+    cores = args.cpu_threads or nproc                              # every hardware thread the box grants this process
     with tempfile.TemporaryDirectory() as d:
         t0 = time.time()
         db = synth.write_db_dir(os.path.join(d, "db"), [(int(contig_taxon[ci]), ref.fetch(ci, int(cl[ci]))) for ci in contigs])
@@ -462,6 +655,132 @@ def cpu_baseline_and_cli(args, R, k, w):
                "mapping_only_value": bases_all / max(t_map_all - t_setup, 1e-9) / 1e9,
                "map_phases_s": map_phases, "classify_phases_s": cls_phases, "on_the_cpu_sample": small_run, "reads2taxon_identical_to_oracle": same, "sample_files_written_s": round(t_files, 2)}
     return cpu, e2e
+
+
+def _run_cli_with_rss(cmd, env, timeout):
+    """run a child process; returns (CompletedProcess-like, wall seconds, peak resident set in bytes — VmHWM polled from /proc)"""
+    import threading
+    t0 = time.time()
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    peak = [0]
+
+    def poll():
+        while p.poll() is None:
+            try:
+                for ln in open(f"/proc/{p.pid}/status"):
+                    if ln.startswith("VmHWM:"):
+                        peak[0] = max(peak[0], int(ln.split()[1]) * 1024)
+            except OSError:
+                pass
+            time.sleep(0.25)
+    th = threading.Thread(target=poll, daemon=True); th.start()
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill(); out, err = p.communicate()
+        raise RuntimeError(f"{cmd[0]} {cmd[1]} timed out after {timeout} s")
+    th.join(timeout=1)
+    if p.returncode != 0:
+        raise RuntimeError(f"{cmd[0]} {cmd[1]} failed ({p.returncode}): {err.decode(errors='replace')[-600:]}")
+    return out.decode(errors="replace"), err.decode(errors="replace"), time.time() - t0, peak[0]
+
+
+def e2e_cli_full(args, k, w, rank_seed):
+    """The drop-in binary at configs[1] scale, once: the device generator's community reference written as a 26.8 GB DB.fa (+ taxonInfo,
+    taxonomy, contigNstats) to local disk, the bench's first read batch as FASTQ, then `metamaps mapDirectly --all -r DB.fa -q reads.fq
+    -o PREFIX` (no -w: the CLI derives it from the file size as the reference does, parseCmdArgs.hpp:363-374) and `metamaps classify`.
+    Everything the resident-data headline leaves out is inside: FASTA / FASTQ parsing, 2-bit packing, H2D, the index build, text
+    formatting and file output, two process starts.  Runs after the bench has released the device."""
+    from metamaps_amd import capi
+    cli = os.path.join(ROOT, "metamaps_amd", "csrc", "metamaps")
+    own_tmp = None
+    if args.e2e_dir:
+        d = args.e2e_dir; os.makedirs(d, exist_ok=True)
+    else:
+        own_tmp = tempfile.TemporaryDirectory(dir="/tmp"); d = own_tmp.name
+    try:
+        ctx = capi.Context(int(os.environ.get("LOCAL_RANK", 0)))
+        t0 = time.time()
+        ref, contig_taxon, n_taxa, desc = build_reference(ctx, args, "community")
+        cl = ref.lengths()
+        db = os.path.join(d, "db"); os.makedirs(os.path.join(db, "taxonomy"), exist_ok=True)
+        fasta = os.path.join(db, "DB.fa")
+        nodes = {"1": ("1", "no rank", "root"), "2": ("1", "superkingdom", "Bacteria"), "100": ("2", "phylum", "Synthphyla"), "200": ("100", "order", "Synthales"),
+                 "300": ("200", "family", "Synthaceae")}
+        per_taxon, cids = {}, []
+        with open(fasta, "wb", buffering=1 << 24) as f, open(os.path.join(db, "contigNstats_windowSize_1000.txt"), "w") as ns:
+            for ci in range(len(cl)):
+                g = int(contig_taxon[ci])
+                tid, sp, ge = str(1000000 + g), str(500000 + g // 4), str(100000 + g // 16)
+                nodes.setdefault(ge, ("300", "genus", f"Synthus{g // 16}")); nodes.setdefault(sp, (ge, "species", f"Synthus{g // 16} species{g // 4}"))
+                nodes.setdefault(tid, (sp, "no rank", f"Synthus{g // 16} species{g // 4} strain{g}"))
+                cid = f"C{ci}|kraken:taxid|{tid}|SYN{ci:05d}.1"
+                seq = ref.fetch(ci, int(cl[ci]))
+                f.write(b">" + cid.encode() + b"\n"); f.write(seq); f.write(b"\n")
+                per_taxon.setdefault(tid, []).append(f"{cid}={len(seq)}")
+                nwin = -(-len(seq) // 1000)
+                if b"N" in seq:                                   # (only the human-like contigs carry N runs)
+                    a = np.frombuffer(seq, dtype=np.uint8) == ord("N")
+                    counts = np.add.reduceat(a.astype(np.int32), np.arange(0, len(seq), 1000))[:nwin].tolist()
+                    ns.write(f"{tid}\t{cid}\t" + ";".join(map(str, counts)) + "\n")
+                else:
+                    ns.write(f"{tid}\t{cid}\t" + ";".join(["0"] * nwin) + "\n")
+                del seq
+        with open(os.path.join(db, "taxonInfo.txt"), "w") as f:
+            for tid, lst in per_taxon.items():
+                f.write(tid + " " + ";".join(lst) + "\n")
+        with open(os.path.join(db, "taxonomy", "nodes.dmp"), "w") as f:
+            for tid, (par, rank_, _) in nodes.items():
+                f.write(f"{tid}\t|\t{par}\t|\t{rank_}\t|\n")
+        with open(os.path.join(db, "taxonomy", "names.dmp"), "w") as f:
+            for tid, (_, _, name) in nodes.items():
+                f.write(f"{tid}\t|\t{name}\t|\t\t|\tscientific name\t|\n")
+        open(os.path.join(db, "taxonomy", "merged.dmp"), "w").close()
+        err = dict(sub_rate=0.02, ins_rate=0.08, del_rate=0.02) if args.pacbio else dict(sub_rate=0.04, ins_rate=0.03, del_rate=0.05)
+        reads, _truth = ctx.synth_reads(ref, seed=rank_seed, n_reads=args.reads, read_len=args.read_len, read_len_min=args.read_len_min, frac_random=0.05, n_abundant=100, **err)
+        rl = reads.lengths()
+        fq, bases = os.path.join(d, "reads.fq"), 0
+        with open(fq, "wb", buffering=1 << 24) as f:
+            for r in range(len(rl)):
+                sq = reads.fetch(r, int(rl[r]))
+                f.write(b"@r%d\n" % r); f.write(sq); f.write(b"\n+\n"); f.write(b"I" * len(sq)); f.write(b"\n")
+                bases += len(sq) if len(sq) >= 1000 else 0
+        t_files = time.time() - t0
+        fasta_bytes = os.path.getsize(fasta)
+        reads.close(); ref.close(); ctx.close()                   # the device is the CLI's from here on
+        env = dict(os.environ, MM_CLI_TIMING="1")
+        pre = os.path.join(d, "out")
+        out, errtxt, t_map, rss_map = _run_cli_with_rss([cli, "mapDirectly", "--all", "-r", fasta, "-q", fq, "-o", pre], env, 1500)
+        laps, phases = {}, {}
+        for ln in errtxt.splitlines():
+            if ln.startswith("INFO, lap "):
+                laps[ln.split(" at +")[0][len("INFO, lap "):]] = float(ln.split(" at +")[1].split()[0])
+            if ln.startswith("INFO, time "):
+                phases[" ".join(ln.split()[2:-2])] = float(ln.split()[-2])
+        t_setup = laps.get("3 index build", 0.0)                 # context + reference parse/pack/upload + index build
+        out2, err2, t_cls, rss_cls = _run_cli_with_rss([cli, "classify", "--DB", db, "--mappings", pre], env, 1500)
+        cls_phases = {ln.split()[2] + " " + " ".join(ln.split()[3:-2]): float(ln.split()[-2]) for ln in err2.splitlines() if ln.startswith("INFO, time c")}
+        cls_main = {ln.split(" at +")[0][12:]: float(ln.split(" at +")[1].split()[0]) for ln in err2.splitlines() if ln.startswith("INFO, main: ")}
+        par = dict(l.split(" ", 1) for l in open(pre + ".parameters").read().splitlines() if " " in l)
+        meta = dict(l.split() for l in open(pre + ".meta"))
+        t_ingest = max(t_map - t_setup, 1e-9)
+        t_cls_work = max(t_cls - cls_main.get("contexts created", 0.0), 1e-9)
+        return {"what": "metamaps mapDirectly --all (26.8 GB DB.fa + reads FASTQ -> PREFIX, .meta) + metamaps classify (-> .EM.*) on the bench reference and the bench's first read "
+                        "batch, all host work inside (FASTA / FASTQ parse, 2-bit packing, H2D, index build, text formatting, file output, two process starts)",
+                "reads": int(len(rl)), "bases": int(bases), "fasta_bytes": int(fasta_bytes), "window_derived_by_the_cli": int(par.get("windowSize", -1)),
+                "input_files_written_s": round(t_files, 2),
+                "mapDirectly_wall_s": round(t_map, 3), "of_which_reference_and_index_s": round(t_setup, 3), "classify_wall_s": round(t_cls, 3),
+                "value": bases / (t_map + t_cls) / 1e9, "unit": "Gbp/s",
+                "include_ingest": {"value": bases / (t_ingest + t_cls_work) / 1e9, "unit": "Gbp/s",
+                                   "what": "the same reads with the reference already indexed and HIP initialised: FASTQ parse + pack + H2D + map + mapQ + D2H + text + write "
+                                           f"({t_ingest:.3f} s) + classify without its context creation ({t_cls_work:.3f} s) — what the resident-data headline leaves out, in one number",
+                                   "mapping_only_value": bases / t_ingest / 1e9},
+                "map_laps_s": laps, "map_phases_s": phases, "classify_phases_s": cls_phases, "classify_main_s": cls_main,
+                "peak_host_rss_bytes": {"mapDirectly": int(rss_map), "classify": int(rss_cls)},
+                "meta": {kk: int(v) for kk, v in meta.items()}}
+    finally:
+        if own_tmp is not None:
+            own_tmp.cleanup()
 
 
 if __name__ == "__main__":

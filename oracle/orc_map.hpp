@@ -4,6 +4,8 @@
 #include "orc_core.hpp"
 #include "orc_io.hpp"
 #include <functional>
+#include <chrono>
+#include <cstdio>
 #include <atomic>
 #include <thread>
 #include <algorithm>
@@ -58,7 +60,14 @@ struct RefSketch {
   // winSketch.hpp:452-494
   void compute_freq_hist() {
     if (lookup.empty()) return;
-    for (auto& m : lookup.part) for (auto& e : m) freqHist[(int)e.second.size()] += 1;
+    if (lookup.part.size() == 1) { for (auto& e : lookup.part[0]) freqHist[(int)e.second.size()] += 1; }
+    else {                                                       // partitions counted side by side, then added (the histogram is a sum)
+      std::vector<std::map<int, int>> h(lookup.part.size());
+      std::vector<std::thread> pool;
+      for (size_t p = 0; p < h.size(); ++p) pool.emplace_back([&, p] { for (auto& e : lookup.part[p]) h[p][(int)e.second.size()] += 1; });
+      for (auto& th : pool) th.join();
+      for (auto& hp : h) for (auto& kv : hp) freqHist[kv.first] += kv.second;
+    }
     int64_t uniq = (int64_t)lookup.size();
     float pct = 0.001f;                                          // :91
     int64_t ignore = uniq * pct / 100;                           // int64 * float -> float, / int, truncation
@@ -106,6 +115,9 @@ struct RefSketch {
       // threads (seqId patched in when the contig is consumed); everything stateful below stays the reference's serial loop.
       struct Pre { std::string name, seq; long len = 0; std::vector<Mz> mz; };
       std::vector<Pre> pre;
+      const bool timing = getenv("ORC_TIMING") != nullptr;
+      const auto tb0 = std::chrono::steady_clock::now();
+      auto lap = [&](const char* what) { if (timing) fprintf(stderr, "ORC_TIMING %s at +%.2f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count()); };
       {
         SeqReader rd(fn);
         long len;
@@ -126,11 +138,13 @@ struct RefSketch {
         work();
         for (auto& th : pool) th.join();
       }
+      lap("contigs read and winnowed");
       // no --maxmemory: the chunk rule decides nothing, so the per-contig count of novel hashes (a lookup per distinct hash) is
       // skipped and, with -t N, the map is filled by N threads, thread t owning the hashes with hash % N == t; every thread walks
       // the contigs in order, so every occurrence list is in position order exactly as the serial loop leaves it
       const bool bulk = P.maxMem == 0 && P.threads > 1 && lookup.empty() && byPos.empty();
       if (bulk) {
+        { size_t tot = 0; for (auto& x : pre) tot += x.mz.size(); byPos.reserve(tot); }
         for (auto& x : pre) {
           if (x.len < P.w || x.len < P.k) { meta.push_back(Contig{x.name, (int32_t)x.len}); ++seen; continue; }
           for (auto& e : x.mz) e.seq = (int)seen;
@@ -139,13 +153,23 @@ struct RefSketch {
           ++seen;
           std::vector<Mz>().swap(x.mz);
         }
-        const size_t NP = (size_t)std::min(P.threads, 64);
+        // two passes over the entries: every thread buckets a contiguous range of byPos by partition (indices only), then thread p
+        // fills partition p from the buckets in range order — position order inside every occurrence list, as the serial loop leaves it
+        lap("byPos assembled");
+        const size_t NP = (size_t)std::min(P.threads, 64), NT = NP, N = byPos.size();
         lookup.part.assign(NP, HashLookup::Map());
-        auto fill = [&](size_t t) { auto& m = lookup.part[t]; m.reserve(byPos.size() / NP / 8 + 16); for (const Mz& e : byPos) if (e.hash % NP == t) m[e.hash].push_back(Hit{e.seq, e.wpos, e.strand}); };
-        std::vector<std::thread> pool;
-        for (size_t t = 1; t < NP; ++t) pool.emplace_back(fill, t);
-        fill(0);
-        for (auto& th : pool) th.join();
+        std::vector<std::vector<std::vector<uint32_t>>> bucket(NT, std::vector<std::vector<uint32_t>>(NP));
+        if (N >= ((size_t)1 << 32)) throw std::runtime_error("oracle: more than 2^32 index entries");
+        auto scatter = [&](size_t t) { const size_t a = N * t / NT, b = N * (t + 1) / NT; for (auto& v : bucket[t]) v.reserve((b - a) / NP + 64); for (size_t i = a; i < b; ++i) bucket[t][byPos[i].hash % NP].push_back((uint32_t)i); };
+        auto fill = [&](size_t p) { auto& m = lookup.part[p]; m.reserve(N / NP / 8 + 16);
+                                    for (size_t t = 0; t < NT; ++t) for (uint32_t i : bucket[t][p]) { const Mz& e = byPos[i]; m[e.hash].push_back(Hit{e.seq, e.wpos, e.strand}); } };
+        for (const std::function<void(size_t)>& phase : {std::function<void(size_t)>(scatter), std::function<void(size_t)>(fill)}) {
+          std::vector<std::thread> pool;
+          for (size_t t = 1; t < NP; ++t) pool.emplace_back([&phase, t] { phase(t); });
+          phase(0);
+          for (auto& th : pool) th.join();
+          lap("lookup phase");
+        }
         continue;
       }
       for (auto& x : pre) {

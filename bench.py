@@ -273,6 +273,20 @@ def main():
             hold_lock[0] = True; run_steps(2, sched); hold_lock[0] = False
             st_clean = agg["stats"]
             agg.clear(); agg.update(keep)
+        # beside the headline: the same number of steps ... six steps that map ONE batch again and again (what rounds 1 and 2 timed): the
+        # distance between the two is what the batch-to-batch variation of the workload costs (other genomes, other candidate counts)
+        same = None
+        if world == 1 and B > 1 and shape == args.shape:
+            keep = dict(agg); keep["done_t"] = list(agg["done_t"]); agg["bases"] = 0
+            saved = list(batches)
+            batches[:] = [saved[0]] * len(saved)
+            run_steps(2, sched)
+            agg["bases"] = 0
+            barrier(); t1 = time.perf_counter(); run_steps(6, sched); barrier()
+            d1 = time.perf_counter() - t1
+            same = {"ms_per_step": d1 / 6 * 1e3, "value": float(agg["bases"]) / d1 / 1e9, "steps": 6}
+            batches[:] = saved
+            agg.clear(); agg.update(keep)
         free = None
         if args.measure_free_overlap and W > 1 and not args.free_overlap and world == 1 and shape == args.shape:   # beside the headline: the same steps with nothing serialised
             keep = dict(agg); agg["bases"] = 0
@@ -290,7 +304,7 @@ def main():
         else:
             bases_all = bases_timed
         return dict(ref=ref, idx=idx, reads=reads, reads_w=batches, truth=truth, contig_taxon=contig_taxon, info=info, desc=desc, t_ref=t_ref, t_index=t_index, free=free,
-                    agg=agg, st=st, st_clean=st_clean, dt=dt, steps=steps, bases_all=bases_all, value=bases_all / dt / 1e9, ms_step=dt / steps * 1e3, step_ms=step_ms,
+                    agg=agg, st=st, st_clean=st_clean, same_batch=same, dt=dt, steps=steps, bases_all=bases_all, value=bases_all / dt / 1e9, ms_step=dt / steps * 1e3, step_ms=step_ms,
                     n_batches=B, freq_threshold=idx.freq_threshold, reference_bp=int(ref.total_bases))
 
     if args.config in (3, 4):
@@ -334,7 +348,7 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {
                 "workload": out_workload,
-                "baseline_config": "configs[1]", "distinct_read_batches": R["n_batches"],
+                "baseline_config": "configs[1]", "distinct_read_batches": R["n_batches"], "one_batch_repeated": R["same_batch"],
                 "reads_per_gpu": args.reads, "read_len": args.read_len, "reference_bp": R["reference_bp"], "reference_contigs": info["n_contigs"],
                 "index_entries": info["n_entries"], "index_unique_hashes": info["n_unique_hashes"], "index_hbm_bytes": info["hbm_bytes"],
                 "freq_threshold": R["freq_threshold"], "reference_synth_s": round(R["t_ref"], 3), "index_build_s": round(R["t_index"], 3),

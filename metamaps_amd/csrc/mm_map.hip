@@ -477,7 +477,7 @@ struct SeedFilterLds {
   uint16_t coff8[SF_SMAX + 8];                                  // first code chunk of every list (+ total)
   uint32_t extra[SF_EXTRA];                                     // 32-entry pieces beyond a list's first: list << 11 | piece
   uint32_t wsum[SF_THREADS / 64], wsum2[SF_THREADS / 64];
-  uint32_t cursor, fallback, total8, hraw, n_extra, pad_[3];
+  uint32_t cursor, fallback, total8, hraw, n_extra, tick[2], pad_[1];
   ulonglong2 codes[SF_CHUNKS];
 };
 __global__ void __launch_bounds__(SF_THREADS) seed_filter_kernel(IndexView I, const uint32_t* __restrict__ sk_hash, const uint64_t* __restrict__ off,
@@ -685,6 +685,308 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_kernel(IndexView I, co
   if (n_s > stage_cap) { if (tid == 0) { need_old[r] = 1; surv_n[r] = 0; raw_hits[r] = 0; } return; }   // stage too small: the two-pass kernels redo the read
   for (uint32_t j = tid; j < n_s; j += SF_THREADS) dst[j] = I.occ[dst[j]] & ~(uint64_t)(PW_DP | PW_DN);
   if (tid == 0) { surv_n[r] = n_s; raw_hits[r] = L.hraw; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same filter as a resident workgroup that streams through the reads (one workgroup per CU, reads handed out by a ticket
+// counter) and overlaps itself: the table look-ups of read r + 1 are in flight — their answers wait in registers, 11 x 16 bytes per
+// lane, so the LDS layout is unchanged — while read r tests its parked codes against the surviving bins, writes its survivor slots
+// and fetches its survivors.  seed_filter_kernel above does a read's phases one after the other on a CU that holds one workgroup
+// (152 KB of LDS): VALU 40 %, LDS 19 %, waiting on memory 26 % of the cycles (profiles/r02_sq_counters.txt).
+// What the form needs to work at all (each found in the ISA, tools/ notes in DESIGN.md):
+//   * the barriers of the loop are LDS-only (s_waitcnt lgkmcnt(0) + s_barrier): nothing may drain the vector memory counter
+//     between the issue of the look-ups and their use;
+//   * everything a read needs from global memory besides its lists comes through SCALAR loads (class byte, sketch size, offsets,
+//     stage bounds, read length, minimumHits): a vector load behind the look-ups waits for them (the counter is in-order);
+//   * values derived from the thread index are re-derived per iteration from a value the compiler cannot see through: hoisted out of
+//     the loop they are spilled, and a reload from scratch is a vector memory operation;
+//   * look-ups that need a second probe (a full home sector) are re-issued together, after all eleven answers have been looked at:
+//     one more round trip per read instead of one per list of a lane group (2.4 ms of 15.6 in the first version).
+// Results are those of seed_filter_kernel read for read (tests: MM_SF_ONESHOT=1 runs the one-read-per-workgroup form).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ void __launch_bounds__(SF_THREADS) seed_filter_stream_kernel(IndexView I, const uint32_t* __restrict__ sk_hash, const uint64_t* __restrict__ off,
+                                                                        const int32_t* __restrict__ sk_n, const int32_t* __restrict__ read_len,
+                                                                        const int32_t* __restrict__ min_hits, uint32_t* __restrict__ surv_n,
+                                                                        uint64_t* __restrict__ stage, const uint64_t* __restrict__ stage_off,
+                                                                        uint8_t* need_old, const uint32_t* __restrict__ cls_words /* = need_old, read-only view */,
+                                                                        uint32_t* __restrict__ raw_hits, int n_reads, uint32_t* __restrict__ ticket,
+                                                                        unsigned long long* __restrict__ prof /* optional (MM_SF_PROF): cycles per phase, summed over the workgroups */) {
+  extern __shared__ __align__(16) unsigned char sf_dyn[];
+  SeedFilterLds& L = *reinterpret_cast<SeedFilterLds*>(sf_dyn);
+  const ulonglong2* __restrict__ tab = reinterpret_cast<const ulonglong2*>(I.tab);
+  const uint64_t tmask = ((uint64_t)1 << I.tab_bits) - 1;
+  uint32_t hq[SF_LPG]; ulonglong2 vq[SF_LPG];                      // the look-ups in flight: hashes and home-sector slots of the NEXT read
+  int r_cur = 0, s_cur = 0; uint64_t o_cur = 0;
+  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = 0;
+  auto lapp = [&](int i) { if (prof) { const unsigned long long t = __builtin_readcyclecounter(); pt[i] += t - pt0; pt0 = t; } };
+  if (prof) pt0 = __builtin_readcyclecounter();
+  for (int it = -1; it < 0 || r_cur < n_reads; ++it) {           // it = -1: the prologue (first ticket, first look-ups)
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wid = tid >> 6;
+    const int grp = tid >> 2, sub = tid & 3, gshift = lane & ~3;
+    auto uni64 = [](uint64_t v) { return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32; };
+    // class, sketch size and offset of read r: three independent scalar loads (cls_words aliases need_old read-only: the class byte of
+    // read r is written by the host before the launch and by the workgroup that handles r; nobody else's view of it matters).
+    // A read this kernel does not take (another class, or no sketch) comes back with s = 0.
+    auto head = [&](int r, int& s, uint64_t& o) {
+      const int rr = min(r, n_reads - 1);
+      const uint32_t cw = cls_words[rr >> 2]; const int sn = sk_n[rr]; const uint64_t on = off[rr];
+      s = 0; o = 0;
+      if (r < n_reads && !((cw >> (8 * (rr & 3))) & 0xffu)) {
+        s = sn; o = on;
+        if (s <= 0) { s = 0; if (tid == 0) { surv_n[r] = 0; raw_hits[r] = 0; } }
+      }
+    };
+    // (unconditional loads off a scalar base with 32-bit lane offsets, the index clamped into the sketch: a load under its own branch,
+    // or one whose address registers are recycled, gets a vector-memory wait in front of it — eleven serial round trips; lanes beyond
+    // the sketch look a valid hash up again and ignore the answer)
+    auto load_hashes = [&](int s_, uint64_t o_) {
+      const int su = __builtin_amdgcn_readfirstlane(s_);
+      const char* __restrict__ hb = reinterpret_cast<const char*>(sk_hash + uni64(o_));
+      const uint32_t last = (uint32_t)max(su - 1, 0);
+      if (su > 0) {
+#pragma unroll
+        for (int u = 0; u < SF_LPG; ++u) hq[u] = *reinterpret_cast<const uint32_t*>(hb + (size_t)(min((uint32_t)(grp + SF_GROUPS * u), last) << 2));
+      } else {
+#pragma unroll
+        for (int u = 0; u < SF_LPG; ++u) hq[u] = 0u;
+      }
+    };
+    auto issue_lookups = [&]() {
+#pragma unroll
+      for (int u = 0; u < SF_LPG; ++u) asm volatile("" : "+v"(hq[u]));   // (the hashes are first used HERE: keeps the slot arithmetic, and the wait for the hash loads with it, from drifting up to the loads)
+      int sub_ = (int)threadIdx.x & 3;
+      asm volatile("" : "+v"(sub_));                               // (a value of its own: the lane's table address of the resolve step need not live — in scratch — until here)
+#pragma unroll
+      for (int u = 0; u < SF_LPG; ++u) vq[u] = tab[tab_slot(hq[u], I.tab_bits) + sub_];
+    };
+    if (it < 0) {
+      if (tid == 0) L.tick[0] = atomicAdd(ticket, 1u);
+      lds_barrier();
+      r_cur = __builtin_amdgcn_readfirstlane((int)L.tick[0]);
+      head(r_cur, s_cur, o_cur);
+      load_hashes(s_cur, o_cur);
+      issue_lookups();
+      continue;
+    }
+    if (tid == 0) L.tick[(it + 1) & 1] = atomicAdd(ticket, 1u);   // the read after this one (read by all after the next barrier)
+    int r_next = n_reads, s_next = 0; uint64_t o_next = 0;
+    bool next_issued = false, next_known = false;
+    if (s_cur > 0) {
+      const int r = __builtin_amdgcn_readfirstlane(r_cur), s = __builtin_amdgcn_readfirstlane(s_cur);
+      // what phase 2 needs of the read, fetched now (scalar loads)
+      const uint64_t stage_base = stage_off[r];
+      const uint32_t stage_cap = (uint32_t)(stage_off[r + 1] - stage_base);
+      const uint32_t len = (uint32_t)max(read_len[r], 1);
+      const int nb = min((int)((len - 1) >> HF_BIN_SHIFT) + 2, HF_SLOTS);
+      int m = min_hits[r]; if (m < 1) m = 1;
+      for (int i = tid; i < HF_SLOTS / 2; i += SF_THREADS) L.cnt16[i] = 0;
+      if (tid == 0) { L.cursor = 0; L.fallback = 0; }
+      lds_barrier();
+      lapp(0);
+      // the next read's ticket is visible: its class, sketch size and offset are on their way while this read's look-ups are resolved
+      r_next = __builtin_amdgcn_readfirstlane((int)L.tick[(it + 1) & 1]);
+      head(r_next, s_next, o_next);
+      next_known = true;
+      // ---- phase 0: resolve the look-ups issued during the previous read.  Round 0 looks at all eleven answers and re-issues, for the
+      // lane groups whose home sector was full without a match, the next sector; round 1 (rarely 2) looks at those.
+      {
+        uint32_t pmask = 0;
+#pragma unroll
+        for (int u = 0; u < SF_LPG; ++u) pmask |= (grp + SF_GROUPS * u < s ? 1u : 0u) << u;
+        for (uint32_t round = 0; __any(pmask != 0); ++round) {
+#pragma unroll
+          for (int u = 0; u < SF_LPG; ++u) {
+            const int i = grp + SF_GROUPS * u;
+            const uint32_t h = hq[u]; const ulonglong2 v = vq[u];
+            const bool pending = (pmask >> u) & 1u;
+            const bool match = pending && v.x != 0 && (uint32_t)v.x == h, empty = pending && v.x == 0;
+            const uint32_t gm = (uint32_t)(__ballot(match) >> gshift) & 0xfu, ge = (uint32_t)(__ballot(empty) >> gshift) & 0xfu;
+            if (pending && (gm | ge)) {
+              // slots are filled in probing order and never emptied: a match is the key's slot, an empty slot without one means absent
+              if (match) {
+                const uint32_t cnt = (uint32_t)(v.x >> 32);
+                const bool keep = (uint64_t)cnt < (uint64_t)(int64_t)I.freq_threshold;   // computeMap.hpp:317
+                if (keep && cnt > 0xffffu) L.fallback = 1;          // (a list this long overflows the code area anyway)
+                L.lcnt[i] = keep ? (uint16_t)cnt : (uint16_t)0; L.lstart[i] = keep ? v.y : 0ull;
+              } else if (!gm && sub == 0) { L.lcnt[i] = 0; L.lstart[i] = 0ull; }
+              pmask &= ~(1u << u);
+            } else if (pending) vq[u] = tab[((tab_slot(h, I.tab_bits) + 4ull * (round + 1)) & tmask) + sub];
+          }
+        }
+      }
+      lds_barrier();
+      lapp(1);
+      // ---- code chunk offsets (seed_filter_kernel)
+      {
+        uint32_t c8[3], hr = 0, mine = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const int i = tid * 3 + j; const uint32_t c = i < s ? L.lcnt[i] : 0u; c8[j] = (c + 7) >> 3; mine += c8[j]; hr += c; }
+        const uint32_t inc = (uint32_t)wave_incl_scan((int)mine), inc2 = (uint32_t)wave_incl_scan((int)hr);
+        if (lane == 63) { L.wsum[wid] = inc; L.wsum2[wid] = inc2; }
+        lds_barrier();
+        uint32_t basew = 0, tot = 0, tot2 = 0;
+#pragma unroll
+        for (int q = 0; q < SF_THREADS / 64; ++q) { const uint32_t x = L.wsum[q]; if (q < wid) basew += x; tot += x; tot2 += L.wsum2[q]; }
+        uint32_t ex = basew + inc - mine;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const int i = tid * 3 + j; if (i <= s) L.coff8[i] = (uint16_t)min(ex, 0xffffu); ex += c8[j]; }
+        if (tid == 0) { L.total8 = tot; L.hraw = tot2; L.n_extra = 0; if (tot > (uint32_t)SF_CHUNKS || tot2 > 65535u) L.fallback = 1; }
+      }
+      lds_barrier();
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int i = tid * 3 + j;
+        const uint32_t c = i < s ? (uint32_t)L.lcnt[i] : 0u;
+        if (c > 32) {
+          const uint32_t np = (c - 1) >> 5;
+          const uint32_t at = atomicAdd(&L.n_extra, np);
+          for (uint32_t p = 0; p < np; ++p) if (at + p < (uint32_t)SF_EXTRA) L.extra[at + p] = ((uint32_t)i << 11) | (p + 1);
+        }
+      }
+      lds_barrier();
+      if (L.n_extra > (uint32_t)SF_EXTRA) L.fallback = 1;         // (every thread writes the same value)
+      lds_barrier();
+      lapp(2);
+      if (L.fallback) { if (tid == 0) { need_old[r] = 1; surv_n[r] = 0; raw_hits[r] = 0; } }
+      else {
+        // ---- phase 1: every list once (seed_filter_kernel, phase 1)
+        {
+          auto code_of = [](const ulonglong2& v, int t) { return (uint32_t)((t < 4 ? v.x : v.y) >> (16 * (t & 3))) & 0xffffu; };
+          auto take = [&](uint32_t cc, uint32_t li, uint32_t chunk0, uint32_t j0, const ulonglong2& x) {
+            const uint32_t e0 = j0 + 8u * sub;
+            if (e0 >= cc) return;
+            const uint32_t nv = min(8u, cc - e0), meta = li | ((nv - 1u) << 12);
+            uint64_t w0 = 0, w1 = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              const uint32_t code = code_of(x, t) & (uint32_t)(HF_SLOTS - 1);
+              if ((uint32_t)t < nv) atomicAdd(&L.cnt16[code >> 1], 1u << (16 * (code & 1)));
+              const uint64_t slot = code | (((meta >> (3 * t)) & 7u) << 13);
+              if (t < 4) w0 |= slot << (16 * t); else w1 |= slot << (16 * (t - 4));
+            }
+            L.codes[chunk0 + (e0 >> 3)] = make_ulonglong2(w0, w1);
+          };
+          {
+            uint32_t c[SF_LPG]; ulonglong2 v[SF_LPG];
+#pragma unroll
+            for (int u = 0; u < SF_LPG; ++u) {
+              const int i = grp + SF_GROUPS * u;
+              c[u] = i < s ? (uint32_t)L.lcnt[i] : 0u;
+              v[u] = make_ulonglong2(0, 0);
+              if (c[u]) v[u] = *reinterpret_cast<const ulonglong2*>(I.occ16 + L.lstart[i] + min(8u * sub, (c[u] - 1) & ~7u));
+            }
+#pragma unroll
+            for (int u = 0; u < SF_LPG; ++u) { const int i = grp + SF_GROUPS * u; if (c[u]) take(c[u], (uint32_t)i, (uint32_t)L.coff8[i], 0u, v[u]); }
+          }
+          {
+            constexpr int EPG = SF_EXTRA / SF_GROUPS;
+            const uint32_t ne = L.n_extra;
+            uint32_t c[EPG], ch0[EPG], j0[EPG], li[EPG]; ulonglong2 v[EPG];
+#pragma unroll
+            for (int u = 0; u < EPG; ++u) {
+              const uint32_t k = (uint32_t)(grp + SF_GROUPS * u);
+              c[u] = 0; v[u] = make_ulonglong2(0, 0); ch0[u] = 0; j0[u] = 0; li[u] = 0;
+              if (k < ne) {
+                const uint32_t e = L.extra[k], i = e >> 11;
+                li[u] = i; c[u] = (uint32_t)L.lcnt[i]; ch0[u] = (uint32_t)L.coff8[i]; j0[u] = (e & 0x7ffu) << 5;
+                v[u] = *reinterpret_cast<const ulonglong2*>(I.occ16 + L.lstart[i] + min(j0[u] + 8u * sub, (c[u] - 1) & ~7u));
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < EPG; ++u) if (c[u]) take(c[u], li[u], ch0[u], j0[u], v[u]);
+          }
+        }
+        // the next read's hashes: requested here, behind the counting (held across phase 1 — eleven lists of a lane group in registers —
+        // they do not fit the 128 registers a 1024-thread workgroup leaves a lane); they arrive under the window sums
+        load_hashes(s_next, o_next);
+        lds_barrier();
+        lapp(3);
+        {
+          const uint16_t* cnt = reinterpret_cast<const uint16_t*>(L.cnt16);
+          const int b0 = tid * 8;
+          uint32_t sum = 0, bits = 0;
+          for (int i = 0; i < nb; ++i) sum += cnt[(b0 + i) & (HF_SLOTS - 1)];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            bits |= (sum >= (uint32_t)m ? 1u : 0u) << t;
+            sum += (uint32_t)cnt[(b0 + t + nb) & (HF_SLOTS - 1)] - (uint32_t)cnt[(b0 + t) & (HF_SLOTS - 1)];
+          }
+          reinterpret_cast<uint8_t*>(L.good)[tid] = (uint8_t)bits;
+        }
+        lds_barrier();
+        if (tid < HF_SLOTS / 32) {
+          uint32_t al = 0;
+          for (int j = 0; j < nb; ++j) {
+            const int wsh = j >> 5, bsh = j & 31;
+            const uint32_t g0 = L.good[(tid - wsh) & 255], g1 = L.good[(tid - wsh - 1) & 255];
+            al |= bsh ? (g0 << bsh) | (g1 >> (32 - bsh)) : g0;
+          }
+          L.alive[tid] = al;
+        }
+        // the next read's home sectors: in flight from here to the top of the next iteration
+        issue_lookups();
+        next_issued = true;
+        lds_barrier();
+        lapp(4);
+        // ---- phase 2: bit tests over the parked codes (seed_filter_kernel, phase 2)
+        uint64_t* const dst = stage + stage_base;
+        const uint32_t T8 = L.total8;
+        for (uint32_t q0 = 0; q0 < T8; q0 += SF_THREADS) {
+          const uint32_t q = q0 + tid;
+          uint32_t mask = 0, meta = 0;
+          if (q < T8) {
+            const ulonglong2 x = L.codes[q];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              const uint32_t slot = (uint32_t)((t < 4 ? x.x : x.y) >> (16 * (t & 3))) & 0xffffu, code = slot & (uint32_t)(HF_SLOTS - 1);
+              meta |= (slot >> 13) << (3 * t);
+              mask |= ((L.alive[code >> 5] >> (code & 31)) & 1u) << t;
+            }
+            mask &= (2u << (meta >> 12 & 7u)) - 1u;
+          }
+          const int mine = __popc(mask);
+          const int incl = wave_incl_scan(mine);
+          const int total = __builtin_amdgcn_readlane(incl, 63);
+          if (total == 0) continue;
+          uint32_t base = 0;
+          if (lane == 63) base = atomicAdd(&L.cursor, (uint32_t)total);
+          base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+          uint32_t pos = base + (uint32_t)(incl - mine);
+          if (mask) {
+            const uint32_t li = meta & 0xfffu;
+            const uint64_t first = L.lstart[li] + (uint64_t)(q - (uint32_t)L.coff8[li]) * 8u;
+            while (mask) {
+              const int t = __ffs(mask) - 1; mask &= mask - 1;
+              if (pos < stage_cap) dst[pos] = first + (uint32_t)t;
+              ++pos;
+            }
+          }
+        }
+        __syncthreads();                                           // (full barrier: the survivor slots written above are read back below)
+        lapp(5);
+        const uint32_t n_s = L.cursor;
+        if (n_s > stage_cap) { if (tid == 0) { need_old[r] = 1; surv_n[r] = 0; raw_hits[r] = 0; } }   // stage too small: the two-pass kernels redo the read
+        else {
+          for (uint32_t j = tid; j < n_s; j += SF_THREADS) dst[j] = I.occ[dst[j]] & ~(uint64_t)(PW_DP | PW_DN);
+          if (tid == 0) { surv_n[r] = n_s; raw_hits[r] = L.hraw; }
+        }
+      }
+    }
+    if (!next_issued) {                                          // a read that was skipped or fell back: nothing to hide the look-ups behind
+      lds_barrier();
+      if (!next_known) { r_next = __builtin_amdgcn_readfirstlane((int)L.tick[(it + 1) & 1]); head(r_next, s_next, o_next); }
+      load_hashes(s_next, o_next);
+      issue_lookups();
+    }
+    lds_barrier();                                               // the LDS areas are free for the next read
+    lapp(6);
+    r_cur = r_next; s_cur = s_next; o_cur = o_next;
+  }
+  if (prof && threadIdx.x == 0) for (int i = 0; i < 8; ++i) atomicAdd(&prof[i], pt[i]);
 }
 
 // range blockIdx.x of src, [sb, se), goes to dst starting at db
@@ -1252,7 +1554,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       const uint8_t c = sr > wide_from ? 2 : ((use_fused && sr <= SF_SMAX) ? 0 : 1);
       h_need[(size_t)r] = c; n_fused += c == 0; n_wide += c == 2;
     }
-    need_old.alloc((size_t)n); need_old.upload(h_need.data(), (size_t)n, st);
+    need_old.alloc((size_t)n + 4); need_old.upload(h_need.data(), (size_t)n, st);   // (+4: the streaming seed filter reads the class bytes as whole words)
     MM_HIP(hipStreamSynchronize(st));                            // h_need is the source of the async upload
   }
   hl("K3 prep (need_old etc.)");
@@ -1275,11 +1577,30 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     if (use_fused && n_fused > 0) {
       const size_t lds = sizeof(SeedFilterLds);
       MM_HIP(hipFuncSetAttribute((const void*)seed_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      MM_HIP(hipFuncSetAttribute((const void*)seed_filter_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      // default: the streaming form (one resident workgroup per CU, look-ups of the next read under the LDS phases of this one);
+      // MM_SF_ONESHOT=1 / MM_SF_DBG: one workgroup per read, the form the phase timings of DESIGN.md were taken on
+      const bool oneshot = getenv("MM_SF_ONESHOT") || getenv("MM_SF_DBG");
+      DBuf<uint32_t> sf_ticket(1);
+      if (!oneshot) sf_ticket.zero(st);
+      DBuf<unsigned long long> sf_prof;                            // MM_SF_PROF=1: cycles per phase of the streaming kernel, printed per batch
+      if (getenv("MM_SF_PROF")) { sf_prof.alloc(8); sf_prof.zero(st); }
+      const int sf_grid = (int)std::min<int64_t>(n, std::max(ctx->cus, 1));
       const size_t t_sf = T.begin(&M->stats.ms_hit_filter);
-      seed_filter_kernel<<<dim3((unsigned)n), dim3(SF_THREADS), lds, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->min_hits.p, surv.p,
-                                                                         stage.p, stage_off.p, need_old.p, raw_per_read.p, getenv("MM_SF_DBG") ? atoi(getenv("MM_SF_DBG")) : 0);
+      if (oneshot)
+        seed_filter_kernel<<<dim3((unsigned)n), dim3(SF_THREADS), lds, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->min_hits.p, surv.p,
+                                                                           stage.p, stage_off.p, need_old.p, raw_per_read.p, getenv("MM_SF_DBG") ? atoi(getenv("MM_SF_DBG")) : 0);
+      else
+        seed_filter_stream_kernel<<<dim3((unsigned)sf_grid), dim3(SF_THREADS), lds, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->min_hits.p, surv.p, stage.p, stage_off.p,
+                                                                           need_old.p, reinterpret_cast<const uint32_t*>(need_old.p), raw_per_read.p, (int)n, sf_ticket.p, sf_prof.p);
       MM_KERNEL_CHECK();
       T.end(t_sf);
+      if (sf_prof.p && !oneshot) {
+        auto h = sf_prof.to_host(st);
+        const double tot = (double)std::accumulate(h.begin(), h.end(), 0ull);
+        fprintf(stderr, "MM_SF_PROF share of cycles: zero+top %.3f | next head + resolve %.3f | scan+extras %.3f | lists+count %.3f | window sums+alive+issue %.3f | phase 2 %.3f | survivors+end %.3f | total %.3g cycles over %d workgroups\n",
+                h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot, tot, sf_grid);
+      }
     }
   }
   const uint8_t* const only = (use_filter && n > 0) ? need_old.p : nullptr;

@@ -706,6 +706,7 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_kernel(IndexView I, co
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+template <bool PROF>
 __global__ void __launch_bounds__(SF_THREADS) seed_filter_stream_kernel(IndexView I, const uint32_t* __restrict__ sk_hash, const uint64_t* __restrict__ off,
                                                                         const int32_t* __restrict__ sk_n, const int32_t* __restrict__ read_len,
                                                                         const int32_t* __restrict__ min_hits, uint32_t* __restrict__ surv_n,
@@ -720,8 +721,9 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_stream_kernel(IndexVie
   uint32_t hq[SF_LPG]; ulonglong2 vq[SF_LPG];                      // the look-ups in flight: hashes and home-sector slots of the NEXT read
   int r_cur = 0, s_cur = 0; uint64_t o_cur = 0;
   unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = 0;
-  auto lapp = [&](int i) { if (prof) { const unsigned long long t = __builtin_readcyclecounter(); pt[i] += t - pt0; pt0 = t; } };
-  if (prof) pt0 = __builtin_readcyclecounter();
+  auto lapp = [&](int i) { if (PROF) { const unsigned long long t = __builtin_readcyclecounter(); pt[i] += t - pt0; pt0 = t; } };
+  if (PROF) pt0 = __builtin_readcyclecounter();
+  
   for (int it = -1; it < 0 || r_cur < n_reads; ++it) {           // it = -1: the prologue (first ticket, first look-ups)
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -793,28 +795,38 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_stream_kernel(IndexVie
       next_known = true;
       // ---- phase 0: resolve the look-ups issued during the previous read.  Round 0 looks at all eleven answers and re-issues, for the
       // lane groups whose home sector was full without a match, the next sector; round 1 (rarely 2) looks at those.
-      {
-        uint32_t pmask = 0;
+      // pass 1: every answer looked at once; a lane group whose home sector is full without a match asks for the next sector — all such
+      // requests of the lane are in flight together; pass 2 takes them up (and probes on, one sector at a time, in the rare case)
+      auto settle = [&](int i, uint32_t h, const ulonglong2& v, bool pending) -> bool {   // true: the look-up of this lane group is done
+        const bool match = pending && v.x != 0 && (uint32_t)v.x == h, empty = pending && v.x == 0;
+        const uint32_t gm = (uint32_t)(__ballot(match) >> gshift) & 0xfu, ge = (uint32_t)(__ballot(empty) >> gshift) & 0xfu;
+        if (pending && (gm | ge)) {
+          // slots are filled in probing order and never emptied: a match is the key's slot, an empty slot without one means absent
+          if (match) {
+            const uint32_t cnt = (uint32_t)(v.x >> 32);
+            const bool keep = (uint64_t)cnt < (uint64_t)(int64_t)I.freq_threshold;   // computeMap.hpp:317
+            if (keep && cnt > 0xffffu) L.fallback = 1;            // (a list this long overflows the code area anyway)
+            L.lcnt[i] = keep ? (uint16_t)cnt : (uint16_t)0; L.lstart[i] = keep ? v.y : 0ull;
+          } else if (!gm && sub == 0) { L.lcnt[i] = 0; L.lstart[i] = 0ull; }
+          return true;
+        }
+        return !pending;
+      };
+      uint32_t pmask = 0;
 #pragma unroll
-        for (int u = 0; u < SF_LPG; ++u) pmask |= (grp + SF_GROUPS * u < s ? 1u : 0u) << u;
-        for (uint32_t round = 0; __any(pmask != 0); ++round) {
+      for (int u = 0; u < SF_LPG; ++u) {
+        const int i = grp + SF_GROUPS * u;
+        if (!settle(i, hq[u], vq[u], i < s)) { pmask |= 1u << u; vq[u] = tab[((tab_slot(hq[u], I.tab_bits) + 4ull) & tmask) + sub]; }
+      }
+      if (__any(pmask != 0)) {
 #pragma unroll
-          for (int u = 0; u < SF_LPG; ++u) {
-            const int i = grp + SF_GROUPS * u;
-            const uint32_t h = hq[u]; const ulonglong2 v = vq[u];
-            const bool pending = (pmask >> u) & 1u;
-            const bool match = pending && v.x != 0 && (uint32_t)v.x == h, empty = pending && v.x == 0;
-            const uint32_t gm = (uint32_t)(__ballot(match) >> gshift) & 0xfu, ge = (uint32_t)(__ballot(empty) >> gshift) & 0xfu;
-            if (pending && (gm | ge)) {
-              // slots are filled in probing order and never emptied: a match is the key's slot, an empty slot without one means absent
-              if (match) {
-                const uint32_t cnt = (uint32_t)(v.x >> 32);
-                const bool keep = (uint64_t)cnt < (uint64_t)(int64_t)I.freq_threshold;   // computeMap.hpp:317
-                if (keep && cnt > 0xffffu) L.fallback = 1;          // (a list this long overflows the code area anyway)
-                L.lcnt[i] = keep ? (uint16_t)cnt : (uint16_t)0; L.lstart[i] = keep ? v.y : 0ull;
-              } else if (!gm && sub == 0) { L.lcnt[i] = 0; L.lstart[i] = 0ull; }
-              pmask &= ~(1u << u);
-            } else if (pending) vq[u] = tab[((tab_slot(h, I.tab_bits) + 4ull * (round + 1)) & tmask) + sub];
+        for (int u = 0; u < SF_LPG; ++u) {
+          const int i = grp + SF_GROUPS * u;
+          const uint32_t h = hq[u]; uint64_t slot = (tab_slot(h, I.tab_bits) + 4ull) & tmask; ulonglong2 v = vq[u];
+          bool pending = (pmask >> u) & 1u;
+          while (__any(pending)) {
+            if (settle(i, h, v, pending)) pending = false;
+            if (pending) { slot = (slot + 4) & tmask; v = tab[slot + sub]; }
           }
         }
       }
@@ -986,7 +998,7 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_stream_kernel(IndexVie
     lapp(6);
     r_cur = r_next; s_cur = s_next; o_cur = o_next;
   }
-  if (prof && threadIdx.x == 0) for (int i = 0; i < 8; ++i) atomicAdd(&prof[i], pt[i]);
+  if (PROF && threadIdx.x == 0) for (int i = 0; i < 8; ++i) atomicAdd(&prof[i], pt[i]);
 }
 
 // range blockIdx.x of src, [sb, se), goes to dst starting at db
@@ -1577,7 +1589,8 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     if (use_fused && n_fused > 0) {
       const size_t lds = sizeof(SeedFilterLds);
       MM_HIP(hipFuncSetAttribute((const void*)seed_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      MM_HIP(hipFuncSetAttribute((const void*)seed_filter_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      MM_HIP(hipFuncSetAttribute((const void*)seed_filter_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      MM_HIP(hipFuncSetAttribute((const void*)seed_filter_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       // default: the streaming form (one resident workgroup per CU, look-ups of the next read under the LDS phases of this one);
       // MM_SF_ONESHOT=1 / MM_SF_DBG: one workgroup per read, the form the phase timings of DESIGN.md were taken on
       const bool oneshot = getenv("MM_SF_ONESHOT") || getenv("MM_SF_DBG");
@@ -1590,9 +1603,12 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       if (oneshot)
         seed_filter_kernel<<<dim3((unsigned)n), dim3(SF_THREADS), lds, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->min_hits.p, surv.p,
                                                                            stage.p, stage_off.p, need_old.p, raw_per_read.p, getenv("MM_SF_DBG") ? atoi(getenv("MM_SF_DBG")) : 0);
-      else
-        seed_filter_stream_kernel<<<dim3((unsigned)sf_grid), dim3(SF_THREADS), lds, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->min_hits.p, surv.p, stage.p, stage_off.p,
+      else if (sf_prof.p)
+        seed_filter_stream_kernel<true><<<dim3((unsigned)sf_grid), dim3(SF_THREADS), lds, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->min_hits.p, surv.p, stage.p, stage_off.p,
                                                                            need_old.p, reinterpret_cast<const uint32_t*>(need_old.p), raw_per_read.p, (int)n, sf_ticket.p, sf_prof.p);
+      else
+        seed_filter_stream_kernel<false><<<dim3((unsigned)sf_grid), dim3(SF_THREADS), lds, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->min_hits.p, surv.p, stage.p, stage_off.p,
+                                                                           need_old.p, reinterpret_cast<const uint32_t*>(need_old.p), raw_per_read.p, (int)n, sf_ticket.p, nullptr);
       MM_KERNEL_CHECK();
       T.end(t_sf);
       if (sf_prof.p && !oneshot) {

@@ -752,3 +752,47 @@ def test_host_statistics_match_committed_golden():
         if v > 0:
             L.mm_identity(v - 1, s, 16, C.byref(a), C.byref(b))
             assert b.value < 80.0, (s, v)
+
+
+def test_streaming_seed_filter_equals_one_read_per_workgroup(ctx, dense, monkeypatch):
+    """K3: the resident-workgroup form (default: reads handed out by a ticket, the next read's look-ups in flight under this read's
+    LDS phases) against the one-workgroup-per-read form (MM_SF_ONESHOT=1) and against the two-pass kernels (MM_NO_FUSED_FILTER=1), at
+    bench hit density: the filtered seed hits, hit for hit, the raw hit counts, candidates and records; with a batch smaller than
+    the grid, with reads of other classes in between (skipped by this kernel) and with a stage too small for some reads (fallback)"""
+    names, contigs = _read_fasta(dense["db"].fasta)
+    rnames, reads = _read_fastq(dense["reads"])
+    rng = np.random.default_rng(3)
+    long_read = contigs[0][:40_000]                               # beyond SF_SMAX: another class, the streaming kernel skips it
+    mixed = []
+    for i, q in enumerate(reads):
+        mixed.append(q)
+        if i % 37 == 5:
+            mixed.append(long_read)
+        if i % 53 == 7:
+            mixed.append(b"ACGT" * 10)                            # too short: no sketch
+    S = ctx.seqset(contigs)
+    idx = ctx.index(S, 10, 8)
+    for batch, cap in ((mixed, None), (reads[:7], None), (mixed, "40")):
+        R = ctx.seqset(batch)
+        got = {}
+        for mode, env in (("stream", {}), ("oneshot", {"MM_SF_ONESHOT": "1"}), ("twopass", {"MM_NO_FUSED_FILTER": "1"})):
+            for k_, v_ in env.items():
+                monkeypatch.setenv(k_, v_)
+            if cap:
+                monkeypatch.setenv("MM_HF_STAGE_CAP", cap)
+            M = ctx.map_batch(idx, R, 10, 8, pi=80.0, min_read_len=1000)
+            got[mode] = dict(st=M.stats(), hits=M.debug_hits(), cand=M.debug_candidates(), rec=M.fetch())
+            M.close()
+            for k_ in list(env) + ["MM_HF_STAGE_CAP"]:
+                monkeypatch.delenv(k_, raising=False)
+        a = got["stream"]
+        assert a["st"]["sum_hits"] > 100_000 and a["st"]["sum_hits_kept"] > 0
+        for other in ("oneshot", "twopass"):
+            b = got[other]
+            assert a["st"]["sum_hits"] == b["st"]["sum_hits"] and a["st"]["sum_hits_kept"] == b["st"]["sum_hits_kept"], other
+            for x, y in zip(a["hits"], b["hits"]):
+                assert np.array_equal(x, y), other
+            assert np.array_equal(a["cand"][0], b["cand"][0]) and np.array_equal(a["cand"][1], b["cand"][1]), other
+            assert np.array_equal(a["rec"][0], b["rec"][0]) and a["rec"][1].tobytes() == b["rec"][1].tobytes(), other
+        R.close()
+    idx.close(); S.close()

@@ -12,7 +12,7 @@ def short(name):
 f = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 with open(os.path.join(out, "kernel_stats.txt"), "w") as w:
-    w.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-other-shape   (setup kernels: index build, synthetic data; per-step kernels: 10 calls = 2 warm-up + 4 timed + 2 with the lock held to the end + one per further worker context)\n")
+    w.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-shape --no-e2e-full   (setup kernels: index build, synthetic data; per-step kernels: 22 calls = 2 warm-up + 6 timed (a different read batch each) + 2 with the lock held to the end + 2 + 6 on one batch repeated + one per further worker context + the 6 extra batches' generation does not launch them)\n")
     w.write(f"{'calls':>7} {'total_ms':>12} {'avg_ms':>12} {'%':>7}  kernel\n")
     for r in rows:
         w.write(f"{int(r['Calls']):>7} {float(r['TotalDurationNs'])/1e6:>12.3f} {float(r['AverageNs'])/1e6:>12.3f} {float(r['Percentage']):>7.3f}  {short(r['Name'])}\n")
@@ -27,10 +27,10 @@ def pmc(kind):
 fe, wr = pmc("fetch"), pmc("write")
 
 def fetch_corr(kernel):
-    return 1.0 if ("hit_filter_kernel" in kernel or "probe_kernel" in kernel or "seed_filter_kernel" in kernel) else 2.0
+    return 1.0 if ("hit_filter_kernel" in kernel or "probe_kernel" in kernel or "seed_filter" in kernel) else 2.0
 
 with open(os.path.join(out, "pmc_hbm_traffic.txt"), "w") as w:
-    w.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE   and   --pmc WRITE_SIZE   (separate passes), bench.py --steps 1 --warmup 0 --workers 1 --no-cpu-baseline --no-other-shape\n")
+    w.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE   and   --pmc WRITE_SIZE   (separate passes), bench.py --steps 1 --warmup 0 --workers 1 --distinct-batches 1 --no-cpu-baseline --no-other-shape --no-e2e-full\n")
     w.write("# counter unit: KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> x2;\n")
     w.write("# kernels whose reads are random pieces of <= 64 bytes (seed filter, hit filter, probe: 4 lanes x 16 B) are counted exactly -> x1\n")
     w.write("# (calibration on a known byte count in that access pattern: profiles/r01_fetch_size_calibration.txt).\n")
@@ -39,10 +39,10 @@ with open(os.path.join(out, "pmc_hbm_traffic.txt"), "w") as w:
         w.write(f"{k:<62} {fe[k][0]:>8} {fe[k][1]:>14.0f} {fetch_corr(k):>5.0f} {fe[k][1]*1024*fetch_corr(k)/1e9:>10.2f} {wr.get(k,[0,0])[1]:>14.0f} {wr.get(k,[0,0])[1]*1024/1e9:>9.2f}\n")
 traffic = {}
 for k in fe:
-    if "l2_kernel" in k or "hit_filter_kernel<false>" in k or "seed_filter_kernel" in k or "minimizer_kernel<2>" in k:
+    if "l2_kernel" in k or "hit_filter_kernel<false>" in k or "seed_filter" in k or "minimizer_kernel<2>" in k:
         traffic[k] = (fe[k][1] * 1024 * fetch_corr(k) + wr.get(k, [0, 0])[1] * 1024) / max(fe[k][0], 1)
 json.dump({"shape": "community", "reads": 100000, "read_len": 10000,
-           "source": "profiles/r02_pmc_hbm_traffic.txt (FETCH_SIZE*1024*corr + WRITE_SIZE*1024 per launch, separate rocprofv3 --pmc passes; corr = 1 for the kernels that read "
+           "source": "profiles/r03_pmc_hbm_traffic.txt (FETCH_SIZE*1024*corr + WRITE_SIZE*1024 per launch, separate rocprofv3 --pmc passes; corr = 1 for the kernels that read "
                      "random pieces of <= 64 bytes, 2 for streaming kernels: profiles/r01_fetch_size_calibration.txt; tools/collect_profiles.sh)",
            "by_kernel": traffic}, open(os.path.join(out, "traffic_by_kernel.json"), "w"), indent=1)
 print(open(os.path.join(out, "kernel_stats.txt")).read()[:3000])

@@ -480,7 +480,9 @@ def run_chunked(args, ctx, k, w, rank, world, barrier, allreduce_max_sum):
     def step(s_i):
         if mode == 3:
             rd = batches[s_i % n_batches]
-            parts = [ctx.map_batch(ix, rd, k, w, pi=80.0, min_read_len=1000) for ix in chunk_idx]
+            parts = []
+            for ix in chunk_idx:                                    # (minimizers and sketches once per batch: mm_map_batch_reusing, as the CLI does)
+                parts.append(ctx.map_batch(ix, rd, k, w, pi=80.0, min_read_len=1000, sketch_of=parts[0] if parts else None))
             U = capi.Mapping.concat(ctx, parts, base)
             for p_ in parts:
                 p_.close()

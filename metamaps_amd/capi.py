@@ -134,6 +134,7 @@ def lib() -> C.CDLL:
             "mm_identity": (None, [C.c_int, C.c_int, C.c_int, P(f32), P(f32)]),
             "mm_map_batch": (C.c_int, [vp, vp, vp, P(MapParams), P(vp)]),
             "mm_map_batch_phased": (C.c_int, [vp, vp, vp, P(MapParams), SEED_STAGE_CB, vp, P(vp)]),
+            "mm_map_batch_reusing": (C.c_int, [vp, vp, vp, P(MapParams), vp, P(vp)]),
             "mm_mapping_destroy": (None, [vp]),
             "mm_mapping_get_stats": (C.c_int, [vp, P(MapStats)]),
             "mm_mapping_release_intermediates": (C.c_int, [vp]),
@@ -276,10 +277,15 @@ class Context:
             idx.set_freq_threshold(thr)
         return idx
 
-    def map_batch(self, idx: "Index", reads: "SeqSet", k: int, w: int, pi: float = 80.0, min_read_len: int = 1000, at_seed_stage=None, at_last_kernel=None) -> "Mapping":
-        """at_seed_stage / at_last_kernel: callables run between the sketch stage and the seed stage / once K5 is enqueued (mm_map_batch_phased)"""
+    def map_batch(self, idx: "Index", reads: "SeqSet", k: int, w: int, pi: float = 80.0, min_read_len: int = 1000, at_seed_stage=None, at_last_kernel=None,
+                  sketch_of: "Mapping | None" = None) -> "Mapping":
+        """at_seed_stage / at_last_kernel: callables run between the sketch stage and the seed stage / once K5 is enqueued (mm_map_batch_phased);
+        sketch_of: a mapping of the same reads whose minimizers and sketches are copied instead of recomputed (mm_map_batch_reusing)"""
         p = MapParams(k, w, pi, min_read_len)
         h = C.c_void_p()
+        if sketch_of is not None:
+            self.check(lib().mm_map_batch_reusing(self.h, idx.h, reads.h, C.byref(p), sketch_of.h, C.byref(h)))
+            return Mapping(self, h, reads.count)
         if at_seed_stage is None and at_last_kernel is None:
             self.check(lib().mm_map_batch(self.h, idx.h, reads.h, C.byref(p), C.byref(h)))
         else:

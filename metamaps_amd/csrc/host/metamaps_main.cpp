@@ -580,8 +580,12 @@ int map_mode(const Options& o, const std::string& mode) {
     ck(ctx, mm_seqset_upload(reads), "upload reads");
     return reads;
   };
-  auto map_chunk = [&](mm_ctx* ctx, mm_index* idx, mm_seqset* reads) {   // one "PREFIX.N" per chunk in the reference (mapWrap.h:419-437)
-    mm_mapping* pm; ck(ctx, mm_map_batch(ctx, idx, reads, &mp, &pm), "map");
+  // one "PREFIX.N" per chunk in the reference (mapWrap.h:419-437); `sketch_of`: an earlier mapping of the same batch on this device,
+  // whose minimizers and sketches are reused (they do not depend on the index)
+  auto map_chunk = [&](mm_ctx* ctx, mm_index* idx, mm_seqset* reads, const mm_mapping* sketch_of = nullptr) {
+    mm_mapping* pm;
+    if (sketch_of) ck(ctx, mm_map_batch_reusing(ctx, idx, reads, &mp, sketch_of, &pm), "map");
+    else ck(ctx, mm_map_batch(ctx, idx, reads, &mp, &pm), "map");
     if (!o.all) ck(ctx, mm_mapping_keep_best(ctx, pm, k), "best mappings");
     return pm;
   };
@@ -650,7 +654,7 @@ int map_mode(const Options& o, const std::string& mode) {
         mm_seqset* reads = upload_batch(ctx, *bt);
         const auto t1 = std::chrono::steady_clock::now();
         std::vector<mm_mapping*> parts;
-        for (size_t c = 0; c < NC; ++c) parts.push_back(map_chunk(ctx, devs[d].idx[c], reads));
+        for (size_t c = 0; c < NC; ++c) parts.push_back(map_chunk(ctx, devs[d].idx[c], reads, c ? parts[0] : nullptr));
         mm_mapping* m = parts[0];
         if (parts.size() > 1) {                                   // unifyFiles: read-wise concatenation in chunk order
           ck(ctx, mm_mapping_concat(ctx, parts.data(), chunk_base.data(), (int)parts.size(), &m), "merge chunks");

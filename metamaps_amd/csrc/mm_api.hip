@@ -307,6 +307,22 @@ int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const
     *out = M;
   });
 }
+int mm_map_batch_reusing(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, const mm_mapping* sketch_of, mm_mapping** out) {
+  if (!ctx || !idx || !reads || !p || !sketch_of || !out) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
+    MM_REQUIRE(idx->ctx->device == ctx->device && reads->ctx->device == ctx->device && sketch_of->ctx->device == ctx->device, MM_ERR_ARG,
+               "mm_map_batch_reusing: index, reads and donor mapping must live on the context's device");
+    MM_REQUIRE(!sketch_of->released, MM_ERR_STATE, "mm_map_batch_reusing: the donor mapping has released its intermediates");
+    MM_REQUIRE(sketch_of->n_reads == reads->count() && sketch_of->read_len == reads->len && sketch_of->params.k == p->k && sketch_of->params.w == p->w &&
+               sketch_of->params.min_read_len == p->min_read_len, MM_ERR_ARG, "mm_map_batch_reusing: the donor mapping is of other reads or other parameters");
+    auto* M = new mm_mapping;
+    M->sketch_donor = sketch_of;
+    try { mm::map_batch(ctx, idx, reads, *p, M); } catch (...) { delete M; throw; }
+    M->sketch_donor = nullptr;
+    *out = M;
+  });
+}
 int mm_map_batch_phased(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, void (*at_stage)(void*, int), void* user, mm_mapping** out) {
   if (!ctx || !idx || !reads || !p || !out) return MM_ERR_ARG;
   return guarded(ctx, [&] {

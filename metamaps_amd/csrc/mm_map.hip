@@ -1314,16 +1314,30 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     if (ok) { M->stats.n_reads_long_enough++; M->stats.bases_long_enough += L; }
   }
   const size_t t_total = T.begin(&M->stats.ms_total);
+  // The minimizers and the sketch of a read do not depend on the index: when the same batch is mapped against one index chunk after
+  // the other (--maxmemory; the reference runs the whole of mapSingleQuerySeq per chunk, computeMap.hpp:277-298 included), the second
+  // and later mappings copy them from the first (mm_map_batch_reusing).  Strands the donor's tie-break has resolved meanwhile are the
+  // strands this mapping would resolve them to (the same library calls on the same records).
+  const mm_mapping* const donor = M->sketch_donor;
   // ---- K1
-  { size_t t = T.begin(&M->stats.ms_minimizer); run_minimizers(ctx, reads, P.k, P.w, M->active, false, M->mz); T.end(t); }
+  if (donor) {
+    const size_t t = T.begin(&M->stats.ms_minimizer);
+    auto dcopy = [&](auto& dst, const auto& src) { dst.alloc(src.n); if (src.n) MM_HIP(hipMemcpyAsync(dst.p, src.p, src.bytes(), hipMemcpyDeviceToDevice, st)); };
+    dcopy(M->mz.rec, donor->mz.rec); dcopy(M->mz.off, donor->mz.off);
+    M->mz.h_off = donor->mz.h_off; M->mz.total = donor->mz.total;
+    dcopy(M->sk_hash, donor->sk_hash); dcopy(M->sk_strand, donor->sk_strand); dcopy(M->sk_n, donor->sk_n); dcopy(M->amb, donor->amb);
+    T.end(t);
+  } else { size_t t = T.begin(&M->stats.ms_minimizer); run_minimizers(ctx, reads, P.k, P.w, M->active, false, M->mz); T.end(t); }
   const int64_t total_mz = M->mz.total;
   const std::vector<uint64_t>& hoff = M->mz.h_off;
-  M->sk_hash.alloc((size_t)std::max<int64_t>(total_mz, 1));
-  M->sk_strand.alloc((size_t)std::max<int64_t>(total_mz, 1));
-  M->sk_n.alloc((size_t)std::max<int64_t>(n, 1)); M->sk_n.zero(st);
-  M->amb.alloc((size_t)std::max<int64_t>(n, 1)); M->amb.zero(st);
+  if (!donor) {
+    M->sk_hash.alloc((size_t)std::max<int64_t>(total_mz, 1));
+    M->sk_strand.alloc((size_t)std::max<int64_t>(total_mz, 1));
+    M->sk_n.alloc((size_t)std::max<int64_t>(n, 1)); M->sk_n.zero(st);
+    M->amb.alloc((size_t)std::max<int64_t>(n, 1)); M->amb.zero(st);
+  }
   // ---- K2
-  {
+  if (!donor) {
     size_t t_sk = T.begin(&M->stats.ms_sketch);
     // up to 16384 minimizers: radix sort in LDS, 4 ... 64 elements per thread.  The sort's cost follows the elements per thread, so the
     // reads are grouped by the capacity they really need (a 10 kb read has ~2 200 minimizers: 10 per thread instead of 16).

@@ -273,9 +273,9 @@ def test_resident_chunks_equal_whole_index(world):
     world["thr3"] = thr
     assert thr == sorted(thr) and 100 < thr[0] and 1000 < thr[-1] < 3000, thr   # the histogram accumulates over the chunks: the cut rises towards the whole index's
     parts = []
-    for ix, t in zip(world["chunk_idx"], thr):
-        ix.set_freq_threshold(t)
-        parts.append(ctx.map_batch(ix, mixed, K, W))
+    for ix, t in zip(world["chunk_idx"], thr):                    # (chunks 2.. reuse the sketches of the first mapping, as the CLI does; the
+        ix.set_freq_threshold(t)                                  #  streamed run below computes them per chunk: the two must agree)
+        parts.append(ctx.map_batch(ix, mixed, K, W, sketch_of=parts[0] if parts else None))
     U = capi.Mapping.concat(ctx, parts, base); U.add_qualities(K)
     off, rec = U.fetch()
     world["res3_off"], world["res3_rec"] = off.copy(), rec.copy()

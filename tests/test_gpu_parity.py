@@ -796,3 +796,44 @@ def test_streaming_seed_filter_equals_one_read_per_workgroup(ctx, dense, monkeyp
             assert np.array_equal(a["rec"][0], b["rec"][0]) and a["rec"][1].tobytes() == b["rec"][1].tobytes(), other
         R.close()
     idx.close(); S.close()
+
+
+def test_map_batch_reusing_sketches_equals_map_batch(ctx, oracle_lib, mini, monkeypatch):
+    """mm_map_batch_reusing (minimizers + sketches copied from an earlier mapping of the same reads — the second and later index chunks
+    of --maxmemory) gives the records, candidates and sketches of mm_map_batch, in all three strand tie-break modes; a donor of other
+    reads or other parameters is refused"""
+    from metamaps_amd import capi
+    names, contigs = _read_fasta(mini["db"].fasta)
+    rnames, reads = _read_fastq(mini["reads"])
+    k, w = 16, 8
+    half = len(contigs) // 2
+    A, B = ctx.seqset(contigs[:half]), ctx.seqset(contigs[half:])
+    ia, ib = ctx.index(A, k, w), ctx.index(B, k, w)
+    R = ctx.seqset(reads)
+    for env in ({}, {"MM_EAGER_TIEBREAK": "1"}, {"MM_FORCE_AMB_REDO": "1"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        Ma = ctx.map_batch(ia, R, k, w)
+        Mb = ctx.map_batch(ib, R, k, w)
+        Mr = ctx.map_batch(ib, R, k, w, sketch_of=Ma)
+        (ob, rb), (orr, rr) = Mb.fetch(), Mr.fetch()
+        assert np.array_equal(ob, orr) and rb.tobytes() == rr.tobytes() and len(rb) > 100
+        for x, y in zip(Mb.debug_sketch(), Mr.debug_sketch()):
+            assert np.array_equal(x, y)
+        for x, y in zip(Mb.debug_candidates(), Mr.debug_candidates()):
+            assert np.array_equal(x, y)
+        assert Mr.stats()["ms_sketch"] == 0.0 and Mb.stats()["ms_sketch"] > 0.0
+        Mr2 = ctx.map_batch(ia, R, k, w, sketch_of=Mr)            # a mapping made from copied sketches is a donor like any other
+        assert Mr2.fetch()[1].tobytes() == Ma.fetch()[1].tobytes()
+        for m_ in (Mb, Mr, Mr2):
+            m_.close()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        R2 = ctx.seqset(reads[:-1])
+        with pytest.raises(capi.MMError):
+            ctx.map_batch(ib, R2, k, w, sketch_of=Ma)
+        with pytest.raises(capi.MMError):
+            ctx.map_batch(ib, R, k, w, min_read_len=500, sketch_of=Ma)
+        R2.close(); Ma.close()
+    for x in (ia, ib, A, B, R):
+        x.close()

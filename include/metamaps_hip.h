@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 2
+#define MM_ABI_VERSION 3   /* 3: mm_seqset_slice/concat, mm_map_batch_reusing, mm_em_continue, mm_synth_community_species */
 
 typedef enum {
   MM_OK = 0,

@@ -66,6 +66,7 @@ void mm_ctx_destroy(mm_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->alloc.trim();
+  mm::big_pool_trim(ctx->device);                                  // (recycled index-scale blocks go back to the driver with any context of the device)
   mm::comm_destroy(ctx);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->l2_codes) (void)hipFree(ctx->l2_codes);
@@ -207,6 +208,7 @@ int mm_index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index
     MM_HIP(hipSetDevice(ctx->device));
     auto* I = new mm_index;
     try { mm::index_build(ctx, contigs, k, w, I); } catch (...) { delete I; throw; }
+    ctx->alloc.trim_to((size_t)32 << 30);                        // the build's temporaries are cached for the next chunk's build, within bounds (DevAlloc::trim_to)
     *out = I;
   });
 }

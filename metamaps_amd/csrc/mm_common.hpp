@@ -12,6 +12,8 @@
 #include <memory>
 #include <chrono>
 #include <map>
+#include <iterator>
+#include <mutex>
 #include "../../include/metamaps_hip.h"
 
 namespace mm {
@@ -39,6 +41,7 @@ struct Error : std::runtime_error {
 // recycled by hand: a context owns ONE stream, every kernel and copy is issued on it, and a freed block
 // handed to a later allocation is therefore only touched by work that is stream-ordered after its previous
 // user.  Index-scale buffers (>= 8 GiB) bypass the cache.
+void big_pool_trim(int device);
 struct DevAlloc {
   hipStream_t stream = nullptr;
   std::multimap<size_t, void*> cache;        // size -> free block
@@ -55,10 +58,19 @@ struct DevAlloc {
     for (auto& kv : cache) (void)hipFree(kv.second);
     cache.clear(); cached_bytes = 0;
   }
+  // hands the largest cached blocks back to the driver until at most `keep` bytes stay cached (after an index build: its temporaries
+  // are worth keeping for the next chunk's build, not a hundred gigabytes of them beside the mapping buffers of other contexts)
+  void trim_to(size_t keep) {
+    if (cached_bytes <= keep) return;
+    (void)hipStreamSynchronize(stream);
+    while (cached_bytes > keep && !cache.empty()) { auto it = std::prev(cache.end()); (void)hipFree(it->second); cached_bytes -= it->first; cache.erase(it); }
+  }
   void* get(size_t bytes, size_t* got) {
     const size_t want = round_up(bytes);
     auto it = cache.lower_bound(want);
-    if (it != cache.end() && it->first <= want + want / 4) {
+    // (from 64 MiB on a cached block up to twice the size will do: what the driver hands out costs ~1 ms per 27 MB on this runtime —
+    // it clears the memory —, and an index build asks for dozens of temporaries whose sizes drift from chunk to chunk)
+    if (it != cache.end() && it->first <= want + (want >= ((size_t)64 << 20) ? want : want / 4)) {
       void* p = it->second; *got = it->first; cached_bytes -= it->first; cache.erase(it); return p;
     }
     void* p = nullptr;
@@ -66,7 +78,7 @@ struct DevAlloc {
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, want);
     if (trace) fprintf(stderr, "MM_ALLOC_TRACE hipMalloc %zu bytes %.3f ms\n", want, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); trim(); e = hipMalloc(&p, want); }
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); trim(); int dv = 0; (void)hipGetDevice(&dv); big_pool_trim(dv); e = hipMalloc(&p, want); }
     if (e != hipSuccess) { (void)hipGetLastError(); throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     *got = want;
     return p;
@@ -74,6 +86,27 @@ struct DevAlloc {
   void put(void* p, size_t bytes) { cache.emplace(bytes, p); cached_bytes += bytes; }
   ~DevAlloc() { trim(); }
 };
+// Index-scale blocks (>= 8 GiB) are recycled per device: on this runtime a freed block of that size is not free for long — one of the
+// next allocations stalls for ~6 s (constant, whatever its own size; MM_ALLOC_TRACE) — and an index build, let alone a pass over
+// the chunk indexes of a reference larger than HBM (built, mapped, dropped, chunk after chunk), frees and allocates tens of them.  A
+// released block waits here for a request it fits (at most half too large); everything is handed back to the driver when an
+// allocation fails for lack of memory or the last context of the process goes.
+struct BigPool {
+  std::mutex m;
+  std::multimap<size_t, void*> free_;
+  size_t bytes = 0;
+  void* take(size_t want, size_t* got) {
+    std::lock_guard<std::mutex> lk(m);
+    auto it = free_.lower_bound(want);
+    if (it == free_.end() || it->first > want + want / 2) return nullptr;
+    void* p = it->second; *got = it->first; bytes -= it->first; free_.erase(it);
+    return p;
+  }
+  void give(void* p, size_t sz) { std::lock_guard<std::mutex> lk(m); free_.emplace(sz, p); bytes += sz; }
+  void trim() { std::lock_guard<std::mutex> lk(m); for (auto& kv : free_) (void)hipFree(kv.second); free_.clear(); bytes = 0; }
+};
+inline BigPool& big_pool(int device) { static BigPool pools[64]; return pools[device < 0 || device >= 64 ? 0 : device]; }
+inline void big_pool_trim(int device) { big_pool(device).trim(); }
 inline DevAlloc*& current_alloc() { static thread_local DevAlloc* a = nullptr; return a; }
 inline hipStream_t& current_stream() { static thread_local hipStream_t s = nullptr; return s; }
 constexpr size_t DIRECT_ALLOC_BYTES = (size_t)8 << 30;
@@ -82,15 +115,16 @@ template <typename T>
 struct DBuf {
   T* p = nullptr;
   size_t n = 0;
-  size_t block = 0;            // bytes of the underlying block (0 = direct hipMalloc)
+  size_t block = 0;            // bytes of the underlying block (0 = index-scale block: big_bytes)
+  size_t big_bytes = 0; int big_dev = 0;
   DevAlloc* owner = nullptr;
   DBuf() = default;
   explicit DBuf(size_t count) { alloc(count); }
   DBuf(const DBuf&) = delete;
   DBuf& operator=(const DBuf&) = delete;
-  DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), block(o.block), owner(o.owner) { o.p = nullptr; o.n = 0; }
+  DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), block(o.block), big_bytes(o.big_bytes), big_dev(o.big_dev), owner(o.owner) { o.p = nullptr; o.n = 0; }
   DBuf& operator=(DBuf&& o) noexcept {
-    if (this != &o) { release(); p = o.p; n = o.n; block = o.block; owner = o.owner; o.p = nullptr; o.n = 0; }
+    if (this != &o) { release(); p = o.p; n = o.n; block = o.block; big_bytes = o.big_bytes; big_dev = o.big_dev; owner = o.owner; o.p = nullptr; o.n = 0; }
     return *this;
   }
   ~DBuf() { release(); }
@@ -101,15 +135,28 @@ struct DBuf {
     const size_t bytes = count * sizeof(T);
     owner = current_alloc();
     if (bytes >= DIRECT_ALLOC_BYTES || !owner) {
-      if (owner) owner->trim();
+      // (the cache is only given up when the device is out of memory: trimming it before every index-scale allocation sent every
+      // mid-size temporary of the next index build back to hipMalloc — 1 400 driver allocations per 25 builds, six of which stalled for
+      // 6.1 s each on this runtime: MM_ALLOC_TRACE, round 3)
       block = 0;
-      MM_HIP(hipMalloc((void**)&p, bytes));
+      static const bool trace = getenv("MM_ALLOC_TRACE") != nullptr;
+      const auto t0 = std::chrono::steady_clock::now();
+      (void)hipGetDevice(&big_dev);
+      BigPool& bp = big_pool(big_dev);
+      p = (T*)bp.take(bytes, &big_bytes);
+      if (!p) {
+        big_bytes = bytes;
+        hipError_t e = hipMalloc((void**)&p, bytes);
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); bp.trim(); if (owner) owner->trim(); e = hipMalloc((void**)&p, bytes); }
+        if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; n = 0; throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        if (trace) fprintf(stderr, "MM_ALLOC_TRACE direct hipMalloc %zu bytes %.3f ms\n", bytes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      } else if (trace) fprintf(stderr, "MM_ALLOC_TRACE big block of %zu bytes reused for %zu\n", big_bytes, bytes);
     } else p = (T*)owner->get(bytes, &block);
   }
   void release() {
     if (p) {
       if (block && owner) owner->put(p, block);
-      else { (void)hipDeviceSynchronize(); (void)hipFree(p); }
+      else { (void)hipDeviceSynchronize(); big_pool(big_dev).give(p, big_bytes); }   // (nothing on the device still uses it: any context may take it)
       p = nullptr;
     }
     n = 0; block = 0;
@@ -219,12 +266,17 @@ struct mm_ctx {
   std::shared_ptr<void> lut_cache;
   int lut_k = 0; float lut_pi = 0;
   // K5 scratch kept across batches: the per-entry code words of pass A (4 B per streamed entry slot, mm_l2.hpp)
+  void raw_alloc(void** p, size_t bytes) {                       // hipMalloc; out of memory: the caches of this context and the device's block pool go first
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); alloc.trim(); mm::big_pool_trim(device); e = hipMalloc(p, bytes); }
+    if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+  }
   void* l2_codes = nullptr; size_t l2_codes_bytes = 0;
   void* l2_codes_at_least(size_t bytes) {
     if (bytes > l2_codes_bytes) {
       if (l2_codes) { MM_HIP(hipStreamSynchronize(stream)); (void)hipFree(l2_codes); }
       l2_codes = nullptr; l2_codes_bytes = 0;
-      MM_HIP(hipMalloc(&l2_codes, bytes));
+      raw_alloc(&l2_codes, bytes);
       l2_codes_bytes = bytes;
     }
     return l2_codes;
@@ -234,7 +286,7 @@ struct mm_ctx {
     if (bytes > l2_masks_bytes) {
       if (l2_masks) { MM_HIP(hipStreamSynchronize(stream)); (void)hipFree(l2_masks); }
       l2_masks = nullptr; l2_masks_bytes = 0;
-      MM_HIP(hipMalloc(&l2_masks, bytes));
+      raw_alloc(&l2_masks, bytes);
       l2_masks_bytes = bytes;
     }
     return l2_masks;

@@ -186,7 +186,8 @@ static void build_directory(mm_index* I, hipStream_t st) {
 
 void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* I) {
   hipStream_t st = ctx->stream;
-  ctx->alloc.trim();                                            // hand cached blocks back before the big allocations
+  // (the cached blocks of earlier work stay: an allocation that fails for lack of memory trims the caches itself, mm_common.hpp — handing
+  // them back up front sent every temporary of every chunk index build of a --maxmemory run through the driver again)
   I->ctx = ctx; I->k = k; I->w = w;
   I->n_contigs = contigs->count();
   I->contig_len = contigs->len;

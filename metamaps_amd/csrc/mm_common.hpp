@@ -68,8 +68,7 @@ struct DevAlloc {
   void* get(size_t bytes, size_t* got) {
     const size_t want = round_up(bytes);
     auto it = cache.lower_bound(want);
-    // (from 64 MiB on a cached block up to twice the size will do: what the driver hands out costs ~1 ms per 27 MB on this runtime —
-    // it clears the memory —, and an index build asks for dozens of temporaries whose sizes drift from chunk to chunk)
+    // (from 64 MiB on a cached block up to twice the size will do: the temporaries of an index build drift in size from chunk to chunk)
     if (it != cache.end() && it->first <= want + (want >= ((size_t)64 << 20) ? want : want / 4)) {
       void* p = it->second; *got = it->first; cached_bytes -= it->first; cache.erase(it); return p;
     }

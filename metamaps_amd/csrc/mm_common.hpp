@@ -42,6 +42,10 @@ struct Error : std::runtime_error {
 // handed to a later allocation is therefore only touched by work that is stream-ordered after its previous
 // user.  Index-scale buffers (>= 8 GiB) bypass the cache.
 void big_pool_trim(int device);
+inline std::string oom_text(size_t want, hipError_t e) {         // what the device looks like when an allocation fails for good
+  size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot);
+  return std::string("hipMalloc of ") + std::to_string(want) + " bytes: " + hipGetErrorString(e) + " (device: " + std::to_string(fr >> 20) + " MiB free of " + std::to_string(tot >> 20) + ")";
+}
 struct DevAlloc {
   hipStream_t stream = nullptr;
   std::multimap<size_t, void*> cache;        // size -> free block
@@ -68,8 +72,10 @@ struct DevAlloc {
   void* get(size_t bytes, size_t* got) {
     const size_t want = round_up(bytes);
     auto it = cache.lower_bound(want);
-    // (from 64 MiB on a cached block up to twice the size will do: the temporaries of an index build drift in size from chunk to chunk)
-    if (it != cache.end() && it->first <= want + (want >= ((size_t)64 << 20) ? want : want / 4)) {
+    // (at most a quarter too large: with a looser fit the chunk index builds of a --maxmemory run find more of their drifting temporaries
+    // in the cache — 3.2 instead of 4.6 s per pass of 12 chunks — but four resident chunk indexes plus the buffers of 50 kb reads then no
+    // longer fit the device: bench.py --config 3 ran out of memory with a fit of up to twice the size)
+    if (it != cache.end() && it->first <= want + want / 4) {
       void* p = it->second; *got = it->first; cached_bytes -= it->first; cache.erase(it); return p;
     }
     void* p = nullptr;
@@ -78,7 +84,7 @@ struct DevAlloc {
     hipError_t e = hipMalloc(&p, want);
     if (trace) fprintf(stderr, "MM_ALLOC_TRACE hipMalloc %zu bytes %.3f ms\n", want, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); trim(); int dv = 0; (void)hipGetDevice(&dv); big_pool_trim(dv); e = hipMalloc(&p, want); }
-    if (e != hipSuccess) { (void)hipGetLastError(); throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipGetLastError(); throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, oom_text(want, e)); }
     *got = want;
     return p;
   }
@@ -88,7 +94,7 @@ struct DevAlloc {
 // Index-scale blocks (>= 8 GiB) are recycled per device: on this runtime a freed block of that size is not free for long — one of the
 // next allocations stalls for ~6 s (constant, whatever its own size; MM_ALLOC_TRACE) — and an index build, let alone a pass over
 // the chunk indexes of a reference larger than HBM (built, mapped, dropped, chunk after chunk), frees and allocates tens of them.  A
-// released block waits here for a request it fits (at most half too large); everything is handed back to the driver when an
+// released block waits here for a request it fits (at most an eighth too large: index-scale blocks are what fills the device); everything is handed back to the driver when an
 // allocation fails for lack of memory or the last context of the process goes.
 struct BigPool {
   std::mutex m;
@@ -97,7 +103,7 @@ struct BigPool {
   void* take(size_t want, size_t* got) {
     std::lock_guard<std::mutex> lk(m);
     auto it = free_.lower_bound(want);
-    if (it == free_.end() || it->first > want + want / 2) return nullptr;
+    if (it == free_.end() || it->first > want + want / 8) return nullptr;
     void* p = it->second; *got = it->first; bytes -= it->first; free_.erase(it);
     return p;
   }
@@ -147,7 +153,7 @@ struct DBuf {
         big_bytes = bytes;
         hipError_t e = hipMalloc((void**)&p, bytes);
         if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); bp.trim(); if (owner) owner->trim(); e = hipMalloc((void**)&p, bytes); }
-        if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; n = 0; throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; n = 0; throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, mm::oom_text(bytes, e)); }
         if (trace) fprintf(stderr, "MM_ALLOC_TRACE direct hipMalloc %zu bytes %.3f ms\n", bytes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       } else if (trace) fprintf(stderr, "MM_ALLOC_TRACE big block of %zu bytes reused for %zu\n", big_bytes, bytes);
     } else p = (T*)owner->get(bytes, &block);
@@ -268,7 +274,7 @@ struct mm_ctx {
   void raw_alloc(void** p, size_t bytes) {                       // hipMalloc; out of memory: the caches of this context and the device's block pool go first
     hipError_t e = hipMalloc(p, bytes);
     if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); alloc.trim(); mm::big_pool_trim(device); e = hipMalloc(p, bytes); }
-    if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, mm::oom_text(bytes, e)); }
   }
   void* l2_codes = nullptr; size_t l2_codes_bytes = 0;
   void* l2_codes_at_least(size_t bytes) {

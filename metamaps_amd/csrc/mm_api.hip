@@ -208,11 +208,6 @@ int mm_index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index
     MM_HIP(hipSetDevice(ctx->device));
     auto* I = new mm_index;
     try { mm::index_build(ctx, contigs, k, w, I); } catch (...) { delete I; throw; }
-    // The build's temporaries stay cached for the next chunk's build (a --maxmemory run builds index after index: 0.15 s per 13 GB chunk
-    // with them, 1-6 s through the driver) — unless the index just built takes a good part of the device: then whatever is cached beside
-    // it (up to 100 GB after a miniSeq+H-scale build) goes back, because with the device that full every later allocation of the
-    // mapping buffers takes the driver 30-450 ms instead of 0.2 (MM_ALLOC_TRACE, round 3).
-    { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)I->hbm_bytes() > tot / 4) { ctx->alloc.trim(); mm::big_pool_trim(ctx->device); } }
     *out = I;
   });
 }

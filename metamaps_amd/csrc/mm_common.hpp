@@ -48,6 +48,10 @@ inline std::string oom_text(size_t want, hipError_t e) {         // what the dev
 }
 struct DevAlloc {
   hipStream_t stream = nullptr;
+  // set for the duration of a device-filling index build (mm_index.hip): every index-scale allocation first hands the cached blocks back
+  // and index-scale blocks go straight to and from the driver, so that the build's memory is returned WHILE it runs.  Returned in one
+  // piece afterwards (~100 GB), it came back as a 1 s stall of a mapping step a few seconds later, twice in four bench runs (round 3).
+  bool eager = false;
   std::multimap<size_t, void*> cache;        // size -> free block
   size_t cached_bytes = 0;
   static size_t round_up(size_t b) {
@@ -72,20 +76,28 @@ struct DevAlloc {
   void* get(size_t bytes, size_t* got) {
     const size_t want = round_up(bytes);
     auto it = cache.lower_bound(want);
-    // (at most a quarter too large: with a looser fit the chunk index builds of a --maxmemory run find more of their drifting temporaries
-    // in the cache — 3.2 instead of 4.6 s per pass of 12 chunks — but four resident chunk indexes plus the buffers of 50 kb reads then no
-    // longer fit the device: bench.py --config 3 ran out of memory with a fit of up to twice the size)
-    if (it != cache.end() && it->first <= want + want / 4) {
+    // A cached block serves a request it is at most 60 % too large for, and what comes from the driver (from 64 MiB on) is asked for a
+    // quarter larger than needed: read batches differ (more or fewer seed hits, candidates, records), and on this runtime memory the
+    // driver has seen freed is cleared when it is handed out again — 1 ms per 27 MB, up to seconds when a large region is due
+    // (MM_ALLOC_TRACE, round 3: one 738 MB allocation of a bench step took 2.0 s).  With headroom the buffers of the first batches also
+    // serve the later ones, and a process in steady state does not go to the driver at all.
+    if (it != cache.end() && it->first <= want + want / 4 + (want >= ((size_t)64 << 20) ? want * 7 / 20 : 0)) {
       void* p = it->second; *got = it->first; cached_bytes -= it->first; cache.erase(it); return p;
+    }
+    size_t ask = want;
+    if (want >= ((size_t)64 << 20)) {                            // (headroom only while a fifth of the device is free: resident chunk indexes can leave less)
+      size_t fr = 0, tot = 0;
+      if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > tot / 5) ask = round_up(want + want / 4);
     }
     void* p = nullptr;
     static const bool trace = getenv("MM_ALLOC_TRACE") != nullptr;     // every block that comes from the driver, with its cost
     const auto t0 = std::chrono::steady_clock::now();
-    hipError_t e = hipMalloc(&p, want);
-    if (trace) fprintf(stderr, "MM_ALLOC_TRACE hipMalloc %zu bytes %.3f ms\n", want, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); trim(); int dv = 0; (void)hipGetDevice(&dv); big_pool_trim(dv); e = hipMalloc(&p, want); }
+    hipError_t e = hipMalloc(&p, ask);
+    size_t granted = ask;
+    if (trace) fprintf(stderr, "MM_ALLOC_TRACE hipMalloc %zu bytes %.3f ms\n", ask, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); trim(); int dv = 0; (void)hipGetDevice(&dv); big_pool_trim(dv); granted = want; e = hipMalloc(&p, want); }   // (no headroom when memory is short)
     if (e != hipSuccess) { (void)hipGetLastError(); throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, oom_text(want, e)); }
-    *got = want;
+    *got = granted;
     return p;
   }
   void put(void* p, size_t bytes) { cache.emplace(bytes, p); cached_bytes += bytes; }
@@ -148,7 +160,8 @@ struct DBuf {
       const auto t0 = std::chrono::steady_clock::now();
       (void)hipGetDevice(&big_dev);
       BigPool& bp = big_pool(big_dev);
-      p = (T*)bp.take(bytes, &big_bytes);
+      if (owner && owner->eager) { owner->trim(); p = nullptr; }
+      else p = (T*)bp.take(bytes, &big_bytes);
       if (!p) {
         big_bytes = bytes;
         hipError_t e = hipMalloc((void**)&p, bytes);
@@ -161,6 +174,7 @@ struct DBuf {
   void release() {
     if (p) {
       if (block && owner) owner->put(p, block);
+      else if (owner && owner->eager) { (void)hipDeviceSynchronize(); (void)hipFree(p); }
       else { (void)hipDeviceSynchronize(); big_pool(big_dev).give(p, big_bytes); }   // (nothing on the device still uses it: any context may take it)
       p = nullptr;
     }

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 3   /* 3: mm_seqset_slice/concat, mm_map_batch_reusing, mm_em_continue, mm_synth_community_species */
+#define MM_ABI_VERSION 4   /* 3: mm_seqset_slice/concat, mm_map_batch_reusing, mm_em_continue, mm_synth_community_species */
 
 typedef enum {
   MM_OK = 0,
@@ -163,6 +163,9 @@ int mm_freq_threshold_from_hist(const int64_t* counts, const int64_t* n_hashes, 
 int mm_index_set_freq_threshold(mm_index* idx, int threshold);
 /* debug tap: position-ordered entries (hash, contig, wpos, strand) */
 int mm_index_entries(mm_index* idx, uint32_t* hash, int32_t* contig, int32_t* wpos, int32_t* strand, int64_t cap);
+/* debug tap: per entry, the distance in entries to the previous / next entry of its contig with the same hash (0: there is none),
+ * saturated at 65535 — what K5 answers slidingMap.hpp:139-214's "is this hash already / still inside the window?" from */
+int mm_index_dup_neighbours(mm_index* idx, int32_t* prev_dist, int32_t* next_dist, int64_t cap);
 
 /* ---- host statistics (float math of map_stats.hpp; Boost.Math binomial restated) -------------- */
 int mm_recommended_window(double p_value, int k, float pi, int min_read_len, uint64_t reference_size);   /* map_stats.hpp:226 */

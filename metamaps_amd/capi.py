@@ -128,6 +128,7 @@ def lib() -> C.CDLL:
             "mm_freq_threshold_from_hist": (C.c_int, [vp, vp, i64, i64, C.c_int]),
             "mm_index_set_freq_threshold": (C.c_int, [vp, C.c_int]),
             "mm_index_entries": (C.c_int, [vp, vp, vp, vp, vp, i64]),
+            "mm_index_dup_neighbours": (C.c_int, [vp, vp, vp, i64]),
             "mm_recommended_window": (C.c_int, [f64, C.c_int, f32, C.c_int, u64]),
             "mm_estimate_pvalue": (f64, [C.c_int, C.c_int, f32, C.c_int, u64]),
             "mm_min_hits_relaxed": (C.c_int, [C.c_int, C.c_int, f32]),
@@ -419,6 +420,14 @@ class Index:
         st = np.zeros(n, dtype=np.int32)
         self.ctx.check(lib().mm_index_entries(self.h, _ptr(hsh), _ptr(ct), _ptr(wp), _ptr(st), n))
         return hsh, ct, wp, st
+
+    def dup_neighbours(self):
+        """per entry: distance to the previous / next entry of its contig with the same hash (0 = none), as K5 reads them"""
+        n = self.info()["n_entries"]
+        pd = np.zeros(n, dtype=np.int32)
+        nd = np.zeros(n, dtype=np.int32)
+        self.ctx.check(lib().mm_index_dup_neighbours(self.h, _ptr(pd), _ptr(nd), n))
+        return pd, nd
 
     def close(self):
         if self.h:

@@ -277,6 +277,29 @@ int mm_index_entries(mm_index* idx, uint32_t* hash, int32_t* contig, int32_t* wp
   });
 }
 
+int mm_index_dup_neighbours(mm_index* idx, int32_t* prev_dist, int32_t* next_dist, int64_t cap) {
+  if (!idx || !prev_dist || !next_dist) return MM_ERR_ARG;
+  return guarded(idx->ctx, [&] {
+    MM_REQUIRE(cap >= idx->N, MM_ERR_ARG, "output capacity too small");
+    if (idx->N == 0) return;
+    hipStream_t st = idx->ctx->stream;
+    auto h = idx->pos.to_host(st, (size_t)idx->N);
+    auto bits = idx->dup_bits.to_host(st), rank = idx->dup_rank.to_host(st);
+    auto dist = idx->dup_dist.to_host(st);
+    for (int64_t i = 0; i < idx->N; ++i) {
+      prev_dist[i] = 0; next_dist[i] = 0;
+      const uint32_t fl = h[(size_t)i].pw & (mm::PW_DP | mm::PW_DN);
+      const bool bit = (bits[(size_t)(i >> 6)] >> (i & 63)) & 1ull;
+      MM_REQUIRE(bit == (fl != 0), MM_ERR_DEVICE, "duplicate bitmap and entry flags disagree");
+      if (!fl) continue;
+      const uint64_t r = rank[(size_t)(i >> 6)] + (uint64_t)__builtin_popcountll(bits[(size_t)(i >> 6)] & ((1ull << (i & 63)) - 1ull));
+      MM_REQUIRE(r < dist.size(), MM_ERR_DEVICE, "duplicate rank out of range");
+      if (fl & mm::PW_DP) prev_dist[i] = (int32_t)(dist[(size_t)r] & 0xffffu);
+      if (fl & mm::PW_DN) next_dist[i] = (int32_t)(dist[(size_t)r] >> 16);
+    }
+  });
+}
+
 // ---- statistics ---------------------------------------------------------------------------------------
 int mm_recommended_window(double p_value, int k, float pi, int min_read_len, uint64_t reference_size) {
   return mm::stats::recommended_window(p_value, k, 4, pi, min_read_len, reference_size);

@@ -118,22 +118,50 @@ __global__ void table_insert_kernel(const uint32_t* __restrict__ uh, const uint6
 // Duplicate flags: two entries of one contig with the same hash.  The hash-sorted table is stable, so such
 // entries are adjacent there.  DN on the earlier, DP on the later (slidingMap.hpp:139-214 needs "is another
 // occurrence of this hash inside the window?", which only same-contig neighbours can answer yes to).
-__global__ void dup_flags_kernel(const uint32_t* __restrict__ key, const uint64_t* __restrict__ val, int64_t n,
-                                 const uint64_t* __restrict__ cstart, Rec* __restrict__ pos, unsigned long long* __restrict__ ndup) {
+// Entry number of (contig c, wpos p) in pos[]: one directory read bounds it to a bucket of ~128 entries.
+__device__ inline int64_t entry_ordinal(const Rec* __restrict__ pos, const uint64_t* __restrict__ cstart, const uint32_t* __restrict__ dir,
+                                        const uint64_t* __restrict__ dir_off, int dir_shift, int32_t c, int32_t p) {
+  const int64_t cbeg = (int64_t)cstart[c];
+  const uint64_t d0 = dir_off[c], nb = dir_off[c + 1] - d0 - 1;
+  const uint64_t bk = min((uint64_t)max(p, 0) >> dir_shift, nb - 1);
+  int64_t lo = cbeg + (int64_t)dir[d0 + bk], hi = cbeg + (int64_t)dir[d0 + bk + 1];
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (pw_wpos(pos[mid].pw) < p) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+// DIST=false: the flags.  DIST=true (second sweep, once the flags of all entries are known and ranked): the distance between the
+// two entries of every pair, into the slot of the later one as "previous" and of the earlier one as "next" (mm_index.hpp).
+template <bool DIST>
+__global__ void dup_pairs_kernel(const uint32_t* __restrict__ key, const uint64_t* __restrict__ val, int64_t n,
+                                 const uint64_t* __restrict__ cstart, const uint32_t* __restrict__ dir, const uint64_t* __restrict__ dir_off, int dir_shift,
+                                 Rec* __restrict__ pos, unsigned long long* __restrict__ ndup,
+                                 const uint64_t* __restrict__ dup_bits, const uint64_t* __restrict__ dup_rank, uint16_t* __restrict__ dist16, int sat) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n; i += (int64_t)gridDim.x * blockDim.x) {
     if (key[i] != key[i + 1]) continue;
-    uint64_t a = val[i], b = val[i + 1];
+    const uint64_t a = val[i], b = val[i + 1];
     if ((a >> 32) != (b >> 32)) continue;
-    int32_t c = (int32_t)(a >> 32);
-    auto ordinal = [&](uint32_t pw) {
-      int32_t p = pw_wpos(pw);
-      int64_t lo = (int64_t)cstart[c], hi = (int64_t)cstart[c + 1];
-      while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (pw_wpos(pos[mid].pw) < p) lo = mid + 1; else hi = mid; }
-      return lo;
-    };
-    atomicOr(&pos[ordinal((uint32_t)a)].pw, PW_DN);
-    atomicOr(&pos[ordinal((uint32_t)b)].pw, PW_DP);
-    atomicAdd(ndup, 1ull);
+    const int32_t c = (int32_t)(a >> 32);
+    const int64_t oa = entry_ordinal(pos, cstart, dir, dir_off, dir_shift, c, pw_wpos((uint32_t)a));
+    const int64_t ob = entry_ordinal(pos, cstart, dir, dir_off, dir_shift, c, pw_wpos((uint32_t)b));
+    if (!DIST) {
+      atomicOr(&pos[oa].pw, PW_DN);
+      atomicOr(&pos[ob].pw, PW_DP);
+      atomicAdd(ndup, 1ull);
+    } else {
+      const uint16_t d = (uint16_t)min<int64_t>(ob - oa, (int64_t)sat);
+      auto slot = [&](int64_t j) -> uint64_t { return dup_rank[j >> 6] + (uint64_t)__popcll(dup_bits[j >> 6] & ((1ull << (j & 63)) - 1ull)); };
+      dist16[2 * slot(oa) + 1] = d;                               // an entry has at most one pair on each side: no two threads write one half
+      dist16[2 * slot(ob)] = d;
+    }
+  }
+}
+// one wave per block of 64 entries: which of them are flagged
+__global__ void __launch_bounds__(256) dup_bits_kernel(const Rec* __restrict__ pos, int64_t N, uint64_t* __restrict__ bits, uint32_t* __restrict__ cnt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nblk = (N + 63) >> 6, stride = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t blk = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6; blk < nblk; blk += stride) {
+    const int64_t j = (blk << 6) + lane;
+    const uint64_t m = __ballot(j < N && (pos[j].pw & (PW_DP | PW_DN)) != 0u);
+    if (lane == 0) { bits[blk] = m; cnt[blk] = (uint32_t)__popcll(m); }
   }
 }
 
@@ -213,6 +241,8 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
     I->tab_bits = 8;
     I->tab.alloc((size_t)2 << I->tab_bits); I->tab.zero(st);
     I->occ.alloc(1); I->occ16.alloc(16);
+    I->dup_bits.alloc(1); I->dup_rank.alloc(2); I->dup_dist.alloc(1);
+    I->dup_bits.zero(st); I->dup_rank.zero(st); I->dup_dist.zero(st);
     MM_HIP(hipStreamSynchronize(st));
     return;
   }
@@ -296,8 +326,28 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   flag.release(); rank.release();
   // duplicate flags into pos[]
   DBuf<unsigned long long> ndup(1); ndup.zero(st);
-  dup_flags_kernel<<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, I->occ.p, N, I->cstart.p, I->pos.p, ndup.p);
+  dup_pairs_kernel<false><<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, I->occ.p, N, I->cstart.p, I->dir.p, I->dir_off.p, I->dir_shift, I->pos.p, ndup.p,
+                                                            nullptr, nullptr, nullptr, 0);
   MM_KERNEL_CHECK();
+  {                                                              // ... and how far the flagged entries' same-hash neighbours are (mm_index.hpp)
+    const int64_t nb64 = (N + 63) >> 6;
+    if (const char* e = getenv("MM_DUP_SAT")) I->dup_sat = std::min(std::max(atoi(e), 1), 65535);
+    I->dup_bits.alloc((size_t)nb64); I->dup_rank.alloc((size_t)nb64 + 1);
+    DBuf<uint32_t> bcnt((size_t)nb64);
+    DBuf<uint64_t> scan_tmp4;
+    dup_bits_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(nb64, 4), 1 << 20)), dim3(256), 0, st>>>(I->pos.p, N, I->dup_bits.p, bcnt.p);
+    MM_KERNEL_CHECK();
+    exclusive_scan_u32_u64(bcnt.p, nb64, I->dup_rank.p, scan_tmp4, st);
+    uint64_t nflag = 0;
+    MM_HIP(hipMemcpyAsync(&nflag, I->dup_rank.p + nb64, sizeof nflag, hipMemcpyDeviceToHost, st));
+    MM_HIP(hipStreamSynchronize(st));
+    I->dup_dist.alloc(std::max<size_t>((size_t)nflag, 1)); I->dup_dist.zero(st);
+    if (nflag) {
+      dup_pairs_kernel<true><<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, I->occ.p, N, I->cstart.p, I->dir.p, I->dir_off.p, I->dir_shift, I->pos.p, nullptr,
+                                                               I->dup_bits.p, I->dup_rank.p, (uint16_t*)I->dup_dist.p, I->dup_sat);
+      MM_KERNEL_CHECK();
+    }
+  }
   // occurrence histogram (winSketch.hpp:456-459)
   const int64_t big_cap = 1 << 20;
   DBuf<unsigned long long> bins(HIST_BINS), big((size_t)big_cap), nbig(1);

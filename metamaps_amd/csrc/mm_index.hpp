@@ -10,6 +10,11 @@
 //               ((first base of the contig in the concatenated reference + wpos) >> 13) & 8191
 //   tab[2*cap]  open-addressing table hash -> (count, first occ): slot = {count<<32 | hash, start}; one 64-byte
 //               line per lookup on average (uh[]/ustart[] CSR arrays only live during the build)
+//   dup_bits / dup_rank / dup_dist   same-hash neighbours of the entries whose hash occurs more than once in their contig
+//               (flags PW_DP / PW_DN in pos[].pw): bit j&63 of dup_bits[j>>6] marks a flagged entry, dup_rank[j>>6] counts the
+//               flagged entries before that block of 64, and dup_dist[rank] = distance in entries to the previous such entry
+//               (low half) and to the next one (high half), saturated at dup_sat = 65535.  K5's "is another occurrence of this hash inside
+//               the window?" (slidingMap.hpp:139-214) is then one comparison instead of a scan of the window.
 #pragma once
 #include "mm_common.hpp"
 #include <climits>
@@ -35,11 +40,15 @@ struct mm_index {
   mm::DBuf<uint32_t> dir;
   mm::DBuf<uint64_t> dir_off;
   int dir_shift = 9;
+  mm::DBuf<uint64_t> dup_bits, dup_rank;
+  mm::DBuf<uint32_t> dup_dist;
+  int dup_sat = 65535;                       // saturation value of the stored distances (MM_DUP_SAT lowers it: tests of the scan fall-back)
   std::vector<int32_t> contig_len;
   std::vector<uint64_t> h_cstart;
   std::map<int64_t, int64_t> hist;           // occurrence count -> number of hashes (this chunk)
   int64_t hbm_bytes() const {
-    return (int64_t)(pos.bytes() + cstart.bytes() + uh.bytes() + ustart.bytes() + occ.bytes() + occ16.bytes() + tab.bytes() + d_contig_len.bytes() + dir.bytes() + dir_off.bytes());
+    return (int64_t)(pos.bytes() + cstart.bytes() + uh.bytes() + ustart.bytes() + occ.bytes() + occ16.bytes() + tab.bytes() + d_contig_len.bytes() + dir.bytes() + dir_off.bytes() +
+                     dup_bits.bytes() + dup_rank.bytes() + dup_dist.bytes());
   }
 };
 
@@ -60,9 +69,14 @@ struct IndexView {
   const uint32_t* dir;
   const uint64_t* dir_off;
   int dir_shift;
+  const uint64_t* dup_bits;
+  const uint64_t* dup_rank;
+  const uint32_t* dup_dist;
+  int dup_sat;
 };
 inline IndexView make_view(const mm_index* I) {
-  return IndexView{I->pos.p, I->cstart.p, I->occ.p, I->occ16.p, I->tab.p, I->N, I->U, I->tab_bits, I->freq_threshold, I->dir.p, I->dir_off.p, I->dir_shift};
+  return IndexView{I->pos.p, I->cstart.p, I->occ.p, I->occ16.p, I->tab.p, I->N, I->U, I->tab_bits, I->freq_threshold, I->dir.p, I->dir_off.p, I->dir_shift,
+                   I->dup_bits.p, I->dup_rank.p, I->dup_dist.p, I->dup_sat};
 }
 
 // Home slot of a hash: the first slot of a 4-slot bucket (4 x 16 B = one 64-byte sector), linear probing from there.  A lookup

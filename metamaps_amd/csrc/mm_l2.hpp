@@ -64,6 +64,32 @@ __device__ inline bool wave_has_hash(const Rec* __restrict__ pos, int64_t lo, in
   }
   return false;
 }
+// The same question answered from the index's same-hash neighbour distances (mm_index.hpp: dup_bits / dup_rank / dup_dist) for an entry
+// that carries the flag: g = entry number in pos[], the window bounds relative to it.  1 yes, 0 no, -1 when the stored distance is
+// saturated (I.dup_sat = 65535; tests lower it) and the window reaches at least that far (the caller then scans).  Any lane may ask about its own entry.
+__device__ inline uint32_t dup_word(const IndexView& I, int64_t g) {
+  const uint64_t bits = I.dup_bits[g >> 6], r = I.dup_rank[g >> 6];
+  return I.dup_dist[r + (uint64_t)__popcll(bits & ((1ull << (g & 63)) - 1ull))];
+}
+__device__ inline int dup_before(const IndexView& I, int64_t g, int64_t back /* entries of the window before g */) {
+  const int64_t d = (int64_t)(dup_word(I, g) & 0xffffu);
+  if (d < I.dup_sat) return d <= back ? 1 : 0;
+  return back < I.dup_sat ? 0 : -1;
+}
+__device__ inline int dup_after(const IndexView& I, int64_t g, int64_t ahead /* entries of the window after g */) {
+  const int64_t d = (int64_t)(dup_word(I, g) >> 16);
+  if (d < I.dup_sat) return d <= ahead ? 1 : 0;
+  return ahead < I.dup_sat ? 0 : -1;
+}
+// wave-uniform forms for the serial automata (x, lo, hi uniform): does [lo, x) / (x, hi) of pos[] hold the hash of the flagged entry x?
+__device__ inline bool wave_dup_before(const IndexView& I, const Rec* __restrict__ pos, int64_t g0, int lo, int x, uint32_t h, int lane) {
+  const int r = dup_before(I, g0 + x, (int64_t)x - lo);
+  return r >= 0 ? r != 0 : wave_has_hash(pos, lo, x, h, lane);
+}
+__device__ inline bool wave_dup_after(const IndexView& I, const Rec* __restrict__ pos, int64_t g0, int x, int hi, uint32_t h, int lane) {
+  const int r = dup_after(I, g0 + x, (int64_t)hi - 1 - x);
+  return r >= 0 ? r != 0 : wave_has_hash(pos, x + 1, hi, h, lane);
+}
 // the results of the wave reductions are uniform; readfirstlane tells the compiler so (SGPRs, scalar branches)
 __device__ inline int wave_sum(int v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline int wave_min(int v) { for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64)); return __builtin_amdgcn_readfirstlane(v); }
@@ -346,7 +372,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     const uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)rE.pw, ln);
     const int code = __builtin_amdgcn_readlane(codeE, ln);
     if (code == -(s + 1)) return;                                // above every query hash: never counted
-    if ((pw & PW_DP) && wave_has_hash(pos, b, x, h, lane)) return;   // REV: hash already in the window
+    if ((pw & PW_DP) && wave_dup_before(I, pos, first0, b, x, h, lane)) return;   // REV: hash already in the window
     if (code >= 0) l2_add_matched(S, code); else l2_add_wonly(S, -code - 1);
   };
   auto del_entry = [&](int x, int wend) {                // slidingMap.hpp:170-214
@@ -355,7 +381,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     const uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)rb.pw, ln);
     const int code = __builtin_amdgcn_readlane(codeB, ln);
     if (code == -(s + 1)) return;
-    if ((pw & PW_DN) && wave_has_hash(pos, x + 1, wend, h, lane)) return;   // NOOP: a later occurrence stays
+    if ((pw & PW_DN) && wave_dup_after(I, pos, first0, x, wend, h, lane)) return;   // NOOP: a later occurrence stays
     if (code >= 0) l2_del_matched(S, code); else l2_del_wonly(S, -code - 1);
   };
 
@@ -411,8 +437,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         if (in && code >= 0) atomicOr(&mt[code >> 5], 1u << (code & 31));
         const bool wonly = in && code < 0 && g < s;
         const bool flagged = wonly && (fl[i] & PW_DP);            // an earlier occurrence exists in the contig: inside the window?
-        if (wonly && !flagged) d_inc(g);
-        uint64_t fm = __ballot(flagged);                         // rare: resolved one by one with a wave-wide scan
+        const int dres = flagged ? dup_before(I, first0 + j, (int64_t)j - nb) : 0;
+        if (wonly && dres == 0) d_inc(g);
+        uint64_t fm = __ballot(dres < 0);                        // (windows of 65535+ entries only: a wave-wide scan each)
         while (fm) {
           const int l = __ffsll((unsigned long long)fm) - 1;
           fm &= fm - 1;
@@ -530,8 +557,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         const int g = -cd[i] - 1;
         const bool wonly = j < ne && cd[i] < 0 && g < s;
         const bool flagged = wonly && (fl[i] & PW_DP);
-        bool count_it = wonly && !flagged;
-        uint64_t fm = __ballot(flagged);
+        const int dres = flagged ? dup_before(I, first0 + j, (int64_t)j - nb) : 0;
+        bool count_it = wonly && dres == 0;
+        uint64_t fm = __ballot(dres < 0);
         while (fm) {
           const int l = __builtin_ctzll(fm); fm &= fm - 1;
           const bool ok = first_in_window(base + l + 64 * i);
@@ -577,7 +605,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         const bool wonly = in && code < 0 && g < s;
         bool part_w = wonly && g >= zb && g < z0, zone_w = wonly && g >= z0 && g < z0 + 64;
         bool low_m = in && code >= 0 && code < z0, zone_m = in && code >= z0 && code < z0 + 64;
-        uint64_t fm = __ballot((part_w || zone_w || low_m) && (fl[i] & PW_DP));
+        const int dres = ((part_w || zone_w || low_m) && (fl[i] & PW_DP)) ? dup_before(I, first0 + j, (int64_t)j - nb) : 0;
+        if (dres > 0) { part_w = false; zone_w = false; low_m = false; }
+        uint64_t fm = __ballot(dres < 0);
         while (fm) {
           const int l = __builtin_ctzll(fm); fm &= fm - 1;
           const bool ok = first_in_window(base + l + 64 * i);
@@ -670,21 +700,32 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
       // events that count: not "above every query hash", and distinct inside their window (flagged entries are rare)
       bool vE = cE != -(s + 1) && kB < n_eval, vB = cB != -(s + 1) && kA < n_eval;
       {
-        uint64_t fm = __ballot(vE && (xe.pw & PW_DP));           // REV: the hash is already inside [b', x)
-        while (fm) {
-          const int l = __builtin_ctzll(fm); fm &= fm - 1;
-          const int kk = __builtin_amdgcn_readlane(kB, l);
-          const int hb = b + __builtin_amdgcn_readlane(dj, kk) + __builtin_amdgcn_readlane(hasDel, kk);
-          const bool dup = wave_has_hash(pos, hb, e + l, (uint32_t)__builtin_amdgcn_readlane((int)xe.hash, l), lane);
-          if (dup && lane == l) vE = false;
-        }
-        fm = __ballot(vB && (xb.pw & PW_DN));                    // NOOP: a later occurrence stays inside (x, e')
-        while (fm) {
-          const int l = __builtin_ctzll(fm); fm &= fm - 1;
-          const int kk = __builtin_amdgcn_readlane(kA, l);
-          const int we = e + __builtin_amdgcn_readlane(aj, kk);
-          const bool stays = wave_has_hash(pos, b + l + 1, we, (uint32_t)__builtin_amdgcn_readlane((int)xb.hash, l), lane);
-          if (stays && lane == l) vB = false;
+        const bool fE = vE && (xe.pw & PW_DP), fB = vB && (xb.pw & PW_DN);
+        if (__ballot(fE || fB) != 0ull) {                         // (flagged entries are rare outside repeats)
+          // REV: the hash of the entering entry e + lane is already inside [b', x), b' = window start at its step (after the step's deletion)
+          const int kEc = min(kB, 63), kBc = min(kA, 63);
+          const int hbL = b + __shfl(dj, kEc, 64) + __shfl(hasDel, kEc, 64), weL = e + __shfl(aj, kBc, 64);
+          const int rE = fE ? dup_before(I, first0 + e + lane, (int64_t)(e + lane) - hbL) : 0;
+          if (rE > 0) vE = false;
+          uint64_t fm = __ballot(rE < 0);                        // (windows of 65535+ entries only)
+          while (fm) {
+            const int l = __builtin_ctzll(fm); fm &= fm - 1;
+            const int kk = __builtin_amdgcn_readlane(kB, l);
+            const int hb = b + __builtin_amdgcn_readlane(dj, kk) + __builtin_amdgcn_readlane(hasDel, kk);
+            const bool dup = wave_has_hash(pos, hb, e + l, (uint32_t)__builtin_amdgcn_readlane((int)xe.hash, l), lane);
+            if (dup && lane == l) vE = false;
+          }
+          // NOOP: a later occurrence of the leaving entry b + lane stays inside (x, e'), e' = window end at its step (before the step's addition)
+          const int rB = fB ? dup_after(I, first0 + b + lane, (int64_t)weL - 1 - (b + lane)) : 0;
+          if (rB > 0) vB = false;
+          fm = __ballot(rB < 0);
+          while (fm) {
+            const int l = __builtin_ctzll(fm); fm &= fm - 1;
+            const int kk = __builtin_amdgcn_readlane(kA, l);
+            const int we = e + __builtin_amdgcn_readlane(aj, kk);
+            const bool stays = wave_has_hash(pos, b + l + 1, we, (uint32_t)__builtin_amdgcn_readlane((int)xb.hash, l), lane);
+            if (stays && lane == l) vB = false;
+          }
         }
       }
       // below-zone indicators, packed (window-only | matched << 16), inclusive prefix per side
@@ -1108,8 +1149,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         const bool unres = (sq & 2) && amb_used != nullptr;       // (after the host resolved the read, amb_used is null and bit 1 is gone)
         const int contrib = cnt_it ? ((sq & 1) ? 1 : -1) * pw_strand(fl[i]) : 0;
         const bool flagged = cnt_it && (fl[i] & PW_DN);           // a later occurrence exists in the contig: inside the window?
-        if (cnt_it && !flagged) { if (unres) ++amb_votes; else votes += contrib; }
-        uint64_t fm = __ballot(flagged);
+        const int dres = flagged ? dup_after(I, first0 + j, (int64_t)opt_e - 1 - j) : 0;
+        if (cnt_it && dres == 0) { if (unres) ++amb_votes; else votes += contrib; }
+        uint64_t fm = __ballot(dres < 0);
         while (fm) {
           const int l = __ffsll((unsigned long long)fm) - 1;
           fm &= fm - 1;
@@ -1197,7 +1239,7 @@ __global__ void __launch_bounds__(64) l2_giant_kernel(IndexView I, const int32_t
       const uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)rE.pw, ln);
       const int code = __builtin_amdgcn_readlane(codeE, ln);
       if (code == -(s + 1)) return;                              // above every query hash: never counted
-      if ((pw & PW_DP) && wave_has_hash(pos, b, x, h, lane)) return;   // REV: hash already in the window
+      if ((pw & PW_DP) && wave_dup_before(I, pos, first0, b, x, h, lane)) return;   // REV: hash already in the window
       if (code >= 0) l2_add_matched(S, code); else l2_add_wonly(S, -code - 1);
     };
     auto del_entry = [&](int x, int wend) {                      // slidingMap.hpp:170-214
@@ -1206,7 +1248,7 @@ __global__ void __launch_bounds__(64) l2_giant_kernel(IndexView I, const int32_t
       const uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)rb.pw, ln);
       const int code = __builtin_amdgcn_readlane(codeB, ln);
       if (code == -(s + 1)) return;
-      if ((pw & PW_DN) && wave_has_hash(pos, x + 1, wend, h, lane)) return;   // NOOP: a later occurrence stays
+      if ((pw & PW_DN) && wave_dup_after(I, pos, first0, x, wend, h, lane)) return;   // NOOP: a later occurrence stays
       if (code >= 0) l2_del_matched(S, code); else l2_del_wonly(S, -code - 1);
     };
     int best = 0, bestR = 0, beg_pos = 0, last_pos = 0, opt_b = 0, opt_e = 0;
@@ -1244,8 +1286,9 @@ __global__ void __launch_bounds__(64) l2_giant_kernel(IndexView I, const int32_t
         const bool cnt_it = j < opt_e && code >= 0 && code < bestR;
         const int contrib = cnt_it ? ((sk_strand[qo + code] & 1) ? 1 : -1) * pw_strand(x.pw) : 0;
         const bool flagged = cnt_it && (x.pw & PW_DN);           // a later occurrence exists in the contig: inside the window?
-        if (cnt_it && !flagged) votes += contrib;
-        uint64_t fm = __ballot(flagged);
+        const int dres = flagged ? dup_after(I, first0 + j, (int64_t)opt_e - 1 - j) : 0;
+        if (cnt_it && dres == 0) votes += contrib;
+        uint64_t fm = __ballot(dres < 0);
         while (fm) {
           const int l = __ffsll((unsigned long long)fm) - 1;
           fm &= fm - 1;

@@ -149,7 +149,10 @@ __global__ void __launch_bounds__(64) l2_dense_kernel(IndexView I, const int32_t
       const uint32_t wd = cw[min(j, cmax)];
       const int code = ld_code(wd);
       bool on = j < e && code != -(s + 1);
-      uint64_t fm = __ballot(on && (ld_flags(wd) & PW_DP));      // an earlier occurrence exists in the contig: inside the window?
+      // an earlier occurrence exists in the contig: inside the window?  (mm_index.hpp: neighbour distances; a scan only beyond their reach)
+      const int dres = (on && (ld_flags(wd) & PW_DP)) ? dup_before(I, RG.first + j, (int64_t)j) : 0;
+      if (dres > 0) on = false;
+      uint64_t fm = __ballot(dres < 0);
       while (fm) {
         const int l = __builtin_ctzll(fm); fm &= fm - 1;
         const bool dup = wave_has_hash(pos, 0, base + l, pos[base + l].hash, lane);
@@ -264,21 +267,32 @@ __global__ void __launch_bounds__(64) l2_dense_kernel(IndexView I, const int32_t
       int n_eval = (~cm == 0ull) ? 64 : __builtin_ctzll(~cm);    // windows 0 .. n_eval-1 are evaluated (n_eval >= 1)
       bool vE = cE != -(s + 1) && kB < n_eval, vB = cB != -(s + 1) && kA < n_eval;
       {
-        uint64_t fm = __ballot(vE && (xe.pw & PW_DP));           // REV: the hash is already inside [b', x)
-        while (fm) {
-          const int l = __builtin_ctzll(fm); fm &= fm - 1;
-          const int kk = __builtin_amdgcn_readlane(kB, l);
-          const int hb = b + __builtin_amdgcn_readlane(dj, kk) + __builtin_amdgcn_readlane(hasDel, kk);
-          const bool dup = wave_has_hash(pos, hb, e + l, (uint32_t)__builtin_amdgcn_readlane((int)xe.hash, l), lane);
-          if (dup && lane == l) vE = false;
-        }
-        fm = __ballot(vB && (xb.pw & PW_DN));                    // NOOP: a later occurrence stays inside (x, e')
-        while (fm) {
-          const int l = __builtin_ctzll(fm); fm &= fm - 1;
-          const int kk = __builtin_amdgcn_readlane(kA, l);
-          const int we = e + __builtin_amdgcn_readlane(aj, kk);
-          const bool stays = wave_has_hash(pos, b + l + 1, we, (uint32_t)__builtin_amdgcn_readlane((int)xb.hash, l), lane);
-          if (stays && lane == l) vB = false;
+        const bool fE = vE && (xe.pw & PW_DP), fB = vB && (xb.pw & PW_DN);
+        if (__ballot(fE || fB) != 0ull) {
+          // REV: the hash of the entering entry e + lane is already inside [b', x), b' = window start at its step (after the step's deletion)
+          const int kEc = min(kB, 63), kBc = min(kA, 63);
+          const int hbL = b + __shfl(dj, kEc, 64) + __shfl(hasDel, kEc, 64), weL = e + __shfl(aj, kBc, 64);
+          const int rE = fE ? dup_before(I, RG.first + e + lane, (int64_t)(e + lane) - hbL) : 0;
+          if (rE > 0) vE = false;
+          uint64_t fm = __ballot(rE < 0);                        // (windows of 65535+ entries only)
+          while (fm) {
+            const int l = __builtin_ctzll(fm); fm &= fm - 1;
+            const int kk = __builtin_amdgcn_readlane(kB, l);
+            const int hb = b + __builtin_amdgcn_readlane(dj, kk) + __builtin_amdgcn_readlane(hasDel, kk);
+            const bool dup = wave_has_hash(pos, hb, e + l, (uint32_t)__builtin_amdgcn_readlane((int)xe.hash, l), lane);
+            if (dup && lane == l) vE = false;
+          }
+          // NOOP: a later occurrence of the leaving entry b + lane stays inside (x, e'), e' = window end at its step (before the step's addition)
+          const int rB = fB ? dup_after(I, RG.first + b + lane, (int64_t)weL - 1 - (b + lane)) : 0;
+          if (rB > 0) vB = false;
+          fm = __ballot(rB < 0);
+          while (fm) {
+            const int l = __builtin_ctzll(fm); fm &= fm - 1;
+            const int kk = __builtin_amdgcn_readlane(kA, l);
+            const int we = e + __builtin_amdgcn_readlane(aj, kk);
+            const bool stays = wave_has_hash(pos, b + l + 1, we, (uint32_t)__builtin_amdgcn_readlane((int)xb.hash, l), lane);
+            if (stays && lane == l) vB = false;
+          }
         }
       }
       const int gE = -cE - 1, gB = -cB - 1;
@@ -371,8 +385,9 @@ __global__ void __launch_bounds__(64) l2_dense_kernel(IndexView I, const int32_t
         const bool unres = (sq & 2) && amb_used != nullptr;       // (after the host resolved the read, amb_used is null and bit 1 is gone)
         const int contrib = cnt_it ? ((sq & 1) ? 1 : -1) * pw_strand(ld_flags(wd)) : 0;
         const bool flagged = cnt_it && (ld_flags(wd) & PW_DN);   // a later occurrence exists in the contig: inside the window?
-        if (cnt_it && !flagged) { if (unres) ++amb_votes; else votes += contrib; }
-        uint64_t fm = __ballot(flagged);
+        const int dres = flagged ? dup_after(I, RG.first + j, (int64_t)opt_e - 1 - j) : 0;
+        if (cnt_it && dres == 0) { if (unres) ++amb_votes; else votes += contrib; }
+        uint64_t fm = __ballot(dres < 0);
         while (fm) {
           const int l = __ffsll((unsigned long long)fm) - 1;
           fm &= fm - 1;

@@ -837,3 +837,58 @@ def test_map_batch_reusing_sketches_equals_map_batch(ctx, oracle_lib, mini, monk
         R2.close(); Ma.close()
     for x in (ia, ib, A, B, R):
         x.close()
+
+
+def test_duplicate_neighbour_distances_and_scan_fallback(ctx, monkeypatch):
+    """"Is another occurrence of this hash inside the window?" (slidingMap.hpp:139-214) is answered from the index's same-hash neighbour
+    distances (mm_index.hpp: dup_bits / dup_rank / dup_dist) and by a scan of the window only where a stored distance is saturated and
+    the window reaches that far.  MM_DUP_SAT lowers the saturation value at index build, so that a repeat-rich reference (45 % library
+    repeats, tandem copies inside contigs) sends most questions through the saturated branches: 1 = every distance saturated (all scans,
+    the behaviour before the distances existed), 7 / 300 = a mix.  Every K5 form — LDS classes with skip-ahead, the literal full slide,
+    the long-read path — must give the records of the default index (which test_community_generator_and_parity_on_it pins to the oracle)."""
+    ref, genome = ctx.synth_community(seed=21, n_genomes=40, n_species=10, n_genera=4, median_len=250_000.0, sigma_len=0.5, min_len=20_000, max_len=700_000,
+                                      strain_div_min=0.001, strain_div_max=0.05, genus_div_min=0.15, genus_div_max=0.25, strain_indel_events=6,
+                                      human_contigs=3, human_bases=6_000_000, repeat_fraction=0.45, n_fraction=0.01, n_repeat_families=12, total_bases_target=0)
+    reads, truth = ctx.synth_reads(ref, seed=23, n_reads=1500, read_len=40_000, read_len_min=1_500, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.03, n_abundant=43)
+    res = {}
+    for sat in ("default", "1", "7", "300"):
+        if sat != "default": monkeypatch.setenv("MM_DUP_SAT", sat)
+        idx = ctx.index(ref, 16, 8)
+        monkeypatch.delenv("MM_DUP_SAT", raising=False)
+        if sat == "default": assert idx.info()["n_dup_flagged"] > 10_000   # pairs of same-hash entries inside one contig
+        for mode, env in (("lds", {}), ("full", {"MM_L2_FULL": "1"}), ("dense", {"MM_L2_DENSE_FROM": "1"})):
+            if sat in ("7", "300") and mode == "full": continue
+            for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
+            M = ctx.map_batch(idx, reads, 16, 8)
+            off, rec = M.fetch()
+            res[(sat, mode)] = (off.copy(), rec.copy(), M.stats()["n_mappings"])
+            M.close()
+            for k_ in env: monkeypatch.delenv(k_)
+        idx.close()
+    base = res[("default", "lds")]
+    assert base[2] > 1500
+    for key, got in res.items():
+        assert np.array_equal(base[0], got[0]) and np.array_equal(base[1], got[1]), key
+    reads.close(); ref.close()
+
+
+def test_duplicate_neighbour_distances_match_definition(ctx):
+    """the index's same-hash neighbour distances (mm_index.hpp) against their definition, entry by entry: within a contig, the
+    distance in entries to the nearest earlier / later entry with the same hash; flags PW_DP / PW_DN exactly where one exists"""
+    ref, genome = ctx.synth_community(seed=31, n_genomes=12, n_species=4, n_genera=2, median_len=120_000.0, sigma_len=0.5, min_len=20_000, max_len=300_000,
+                                      strain_div_min=0.001, strain_div_max=0.05, genus_div_min=0.15, genus_div_max=0.25, strain_indel_events=6,
+                                      human_contigs=2, human_bases=1_500_000, repeat_fraction=0.45, n_fraction=0.01, n_repeat_families=8, total_bases_target=0)
+    idx = ctx.index(ref, 16, 8)
+    hsh, ct, wp, st = idx.entries()
+    pd, nd = idx.dup_neighbours()
+    n = len(hsh)
+    order = np.lexsort((np.arange(n), hsh, ct))                   # by contig, hash, entry number
+    same = (ct[order][1:] == ct[order][:-1]) & (hsh[order][1:] == hsh[order][:-1])
+    exp_p = np.zeros(n, dtype=np.int64); exp_n = np.zeros(n, dtype=np.int64)
+    d = (order[1:] - order[:-1])[same]
+    exp_p[order[1:][same]] = d
+    exp_n[order[:-1][same]] = d
+    assert same.sum() == idx.info()["n_dup_flagged"] and same.sum() > 5_000
+    assert d.max() > 65535                                        # some neighbours lie beyond the stored range ...
+    assert np.array_equal(pd, np.minimum(exp_p, 65535)) and np.array_equal(nd, np.minimum(exp_n, 65535))   # ... and are stored saturated
+    idx.close(); ref.close()

@@ -314,7 +314,7 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             bb = torch.tensor([bases], dtype=torch.float64, device="cuda"); dist.all_reduce(bb, op=dist.ReduceOp.SUM)
             return float(tt.item()), float(bb.item())
-        out = run_chunked(args, ctx, k, w, rank, world, barrier, allreduce_max_sum)
+        out = run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum)
         for c in ctxs:
             c.close()
         if rank == 0:
@@ -418,7 +418,7 @@ def main():
         dist.destroy_process_group()
 
 
-def run_chunked(args, ctx, k, w, rank, world, barrier, allreduce_max_sum):
+def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
     """BASELINE configs[3] / configs[4] as far as one GPU carries them (the same JSON contract as the default mode):
       3  mixed-length PacBio-error reads (1-50 kb, log-uniform) against the reference split by the --maxmemory chunk rule
          (winSketch.hpp:274-329) into chunk indexes that all stay resident; a step maps one batch against every chunk, merges read-wise in
@@ -427,7 +427,10 @@ def run_chunked(args, ctx, k, w, rank, world, barrier, allreduce_max_sum):
          resident read batches are mapped against it, the records go to the host, the index is dropped; then merge, mapping qualities, EM
          per batch.  The index builds are inside the timed region (they recur with every pass; the reference rebuilds them with every run)."""
     from metamaps_amd import capi
+    import threading
     mode = args.config
+    ctx = ctxs[0]
+    W = len(ctxs) if mode == 3 else 1                               # config 3: the steps are taken in turn by the worker contexts, as in the default mode
     if mode == 3 and args.read_len == 10_000 and not args.read_len_min:      # config 3's read shape unless the caller chose one
         args.read_len, args.read_len_min, args.pacbio, args.reads = 50_000, 1_000, True, min(args.reads, 60_000)
     err = dict(sub_rate=0.02, ins_rate=0.08, del_rate=0.02) if args.pacbio else dict(sub_rate=0.04, ins_rate=0.03, del_rate=0.05)
@@ -464,67 +467,96 @@ def run_chunked(args, ctx, k, w, rank, world, barrier, allreduce_max_sum):
     lens = [b.lengths() for b in batches]
     agg = {"ms_l2": 0.0, "ms_hf": 0.0, "l2_stream": 0, "hf_units": 0, "bases": 0, "launch_sets": 0, "em_iters": 0, "ms_index": 0.0, "stage": {}, "st": None, "done_t": []}
 
+    agg_lock = threading.Lock()
+    em_turn = {"next": 0, "cv": threading.Condition()}
+
     def note(st):
         agg["ms_l2"] += st["ms_l2"]; agg["ms_hf"] += st["ms_hit_filter"]; agg["l2_stream"] += st["sum_l2_stream_entries"]; agg["hf_units"] += st["sum_hits"] + st["sum_sketch"]
         for kk in st:
             if kk.startswith("ms_"):
                 agg["stage"][kk] = agg["stage"].get(kk, 0.0) + st[kk]
 
-    def classify(M):
-        em = ctx.em_from_mapping(M, contig_taxon, contig_len, n_taxa)
-        seen = (em.taxon_counts() > 0).astype(np.float64)
-        ctx.comm_allreduce(seen)
-        present = seen > 0
-        f, lls = em.run(np.where(present, 1.0 / max(int(present.sum()), 1), 0.0))
+    def classify(c, M, ticket=None):
+        """ticket: the classify sections of overlapping steps run in step order (one communicator shared by the worker contexts: the same
+        sequence of collectives on every rank)"""
+        em = c.em_from_mapping(M, contig_taxon, contig_len, n_taxa)
+        if ticket is not None:
+            with em_turn["cv"]:
+                em_turn["cv"].wait_for(lambda: em_turn["next"] == ticket)
+        try:
+            seen = (em.taxon_counts() > 0).astype(np.float64)
+            c.comm_allreduce(seen)
+            present = seen > 0
+            f, lls = em.run(np.where(present, 1.0 / max(int(present.sum()), 1), 0.0))
+        finally:
+            if ticket is not None:
+                with em_turn["cv"]:
+                    em_turn["next"] = ticket + 1
+                    em_turn["cv"].notify_all()
         em.posteriors(f)
         em.close()
         agg["em_iters"] = len(lls)
 
-    def step(s_i):
+    def step(s_i, c):
         if mode == 3:
             rd = batches[s_i % n_batches]
             parts = []
             for ix in chunk_idx:                                    # (minimizers and sketches once per batch: mm_map_batch_reusing, as the CLI does)
-                parts.append(ctx.map_batch(ix, rd, k, w, pi=80.0, min_read_len=1000, sketch_of=parts[0] if parts else None))
-            U = capi.Mapping.concat(ctx, parts, base)
+                parts.append(c.map_batch(ix, rd, k, w, pi=80.0, min_read_len=1000, sketch_of=parts[0] if parts else None))
+            U = capi.Mapping.concat(c, parts, base)
             for p_ in parts:
                 p_.close()
             U.add_qualities(k); U.fetch()
-            st = U.stats(); note(st); agg["st"] = st; agg["bases"] += st["bases_long_enough"]; agg["launch_sets"] += 1
-            classify(U); U.close()
+            st = U.stats()
+            with agg_lock:
+                note(st); agg["st"] = st; agg["bases"] += st["bases_long_enough"]; agg["launch_sets"] += 1
+            classify(c, U, s_i); U.close()
         else:
             bs = [(s_i * args.batches_per_pass + j) % n_batches for j in range(args.batches_per_pass)]
             host = [[] for _ in bs]
             for ci, (a, n) in enumerate(bounds):
                 tb = time.perf_counter()
-                sl = ref.slice(a, n); ix = ctx.index(sl, k, w, auto_threshold=False); sl.close(); ix.set_freq_threshold(thrs[ci])
-                ctx.synchronize(); agg["ms_index"] += (time.perf_counter() - tb) * 1e3
+                sl = ref.slice(a, n); ix = c.index(sl, k, w, auto_threshold=False); sl.close(); ix.set_freq_threshold(thrs[ci])
+                c.synchronize(); agg["ms_index"] += (time.perf_counter() - tb) * 1e3
                 for j, b in enumerate(bs):
-                    M = ctx.map_batch(ix, batches[b], k, w, pi=80.0, min_read_len=1000)
+                    M = c.map_batch(ix, batches[b], k, w, pi=80.0, min_read_len=1000)
                     o, r = M.fetch(); host[j].append((o, r.copy()))
                     st = M.stats(); note(st); agg["st"] = st
                     M.close()
                 ix.close()
             for j, b in enumerate(bs):
-                V = capi.Mapping.from_parts(ctx, lens[b], host[j], base, k, w)
+                V = capi.Mapping.from_parts(c, lens[b], host[j], base, k, w)
                 V.add_qualities(k); V.fetch()
                 agg["bases"] += V.stats()["bases_long_enough"]; agg["launch_sets"] += 1
-                classify(V); V.close()
-        agg["done_t"].append(time.perf_counter())
+                classify(c, V); V.close()
+        with agg_lock:
+            agg["done_t"].append(time.perf_counter())
 
-    for s_i in range(max(args.warmup, 0)):
-        step(s_i)
+    def run_steps(first, n):
+        em_turn["next"] = first
+        def work(wi):
+            for s_i in range(wi, n, W):
+                step(first + s_i, ctxs[wi])
+        th = [threading.Thread(target=work, args=(wi,)) for wi in range(1, W)]
+        for t in th:
+            t.start()
+        work(0)
+        for t in th:
+            t.join()
+
+    for wi in range(1, W):                                          # setup: every further worker context runs once (its scratch buffers get allocated)
+        em_turn["next"] = 0; step(0, ctxs[wi])
+    run_steps(0, max(args.warmup, 0))
     for kk in ("ms_l2", "ms_hf", "ms_index"):
         agg[kk] = 0.0
     agg.update({"l2_stream": 0, "hf_units": 0, "bases": 0, "launch_sets": 0, "stage": {}, "done_t": []})
     barrier()
     t0 = time.perf_counter()
-    for s_i in range(args.steps):
-        step(max(args.warmup, 0) + s_i)
+    run_steps(max(args.warmup, 0), args.steps)
     barrier()
     dt = time.perf_counter() - t0
     dt, bases_all = allreduce_max_sum(dt, float(agg["bases"]))
-    gaps = np.diff(np.array([t0] + agg["done_t"])) * 1e3
+    gaps = np.diff(np.array([t0] + sorted(agg["done_t"]))) * 1e3
     cands = [("l2_kernel (all launches of the timed region)", 8.0 * agg["l2_stream"], agg["ms_l2"]), ("seed_filter_kernel / hit_filter_kernel (all launches of the timed region)", 8.0 * agg["hf_units"], agg["ms_hf"])]
     dom_name, dom_bytes, dom_ms = max(cands, key=lambda c_: c_[2])
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -547,7 +579,7 @@ def run_chunked(args, ctx, k, w, rank, world, barrier, allreduce_max_sum):
             "per_timed_region": {"bases": int(agg["bases"]), "batches_classified": agg["launch_sets"], "sum_l2_stream_entries": int(agg["l2_stream"]), "probes_plus_hits": int(agg["hf_units"]),
                                  "ms_index_builds": round(agg["ms_index"], 1), "stage_ms_sum": {kk: round(v, 2) for kk, v in agg["stage"].items()}},
             "mapping_only_value": (bases_all / max(dt - agg["ms_index"] * 1e-3, 1e-9) / 1e9) if mode == 4 else None,
-            "parallelism": f"reads sharded x{world}, every rank holds / streams every chunk index, RCCL all-reduce of EM sums; one context per GPU, steps one after the other",
+            "parallelism": f"reads sharded x{world}, every rank holds / streams every chunk index, RCCL all-reduce of EM sums; " + (f"{W} worker contexts per GPU take the steps in turn (mapping sections not serialised)" if W > 1 else "one context per GPU, steps one after the other"),
         },
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes": dom_bytes, "ms": dom_ms,

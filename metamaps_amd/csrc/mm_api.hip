@@ -56,6 +56,7 @@ int mm_ctx_create(int device_id, mm_ctx** out) {
     c->cus = p.multiProcessorCount;
     MM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->alloc.stream = c->stream;
+    mm::alloc_register(&c->alloc, c->device);
   });
   if (st != MM_OK) { delete c; return st; }
   *out = c;

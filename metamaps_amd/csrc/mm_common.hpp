@@ -46,8 +46,16 @@ inline std::string oom_text(size_t want, hipError_t e) {         // what the dev
   size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot);
   return std::string("hipMalloc of ") + std::to_string(want) + " bytes: " + hipGetErrorString(e) + " (device: " + std::to_string(fr >> 20) + " MiB free of " + std::to_string(tot >> 20) + ")";
 }
+struct DevAlloc;
+// Free blocks cached by one context are memory another context of the same device may need (worker contexts beside the one that built
+// the indexes): an allocation that fails for lack of memory asks every other context's cache to go back to the driver before it gives up.
+void alloc_register(DevAlloc* a, int device);
+void alloc_unregister(DevAlloc* a);
+void alloc_trim_others(DevAlloc* self, int device);
 struct DevAlloc {
   hipStream_t stream = nullptr;
+  int device = -1;                           // set by alloc_register
+  std::mutex m;                              // the cache: its own context's thread, and any thread that trims it when the device is full
   // set for the duration of a device-filling index build (mm_index.hip): every index-scale allocation first hands the cached blocks back
   // and index-scale blocks go straight to and from the driver, so that the build's memory is returned WHILE it runs.  Returned in one
   // piece afterwards (~100 GB), it came back as a 1 s stall of a mapping step a few seconds later, twice in four bench runs (round 3).
@@ -61,6 +69,7 @@ struct DevAlloc {
     return (b + gran - 1) / gran * gran;
   }
   void trim() {
+    std::lock_guard<std::mutex> lk(m);
     if (cache.empty()) return;
     (void)hipStreamSynchronize(stream);
     for (auto& kv : cache) (void)hipFree(kv.second);
@@ -69,12 +78,15 @@ struct DevAlloc {
   // hands the largest cached blocks back to the driver until at most `keep` bytes stay cached (after an index build: its temporaries
   // are worth keeping for the next chunk's build, not a hundred gigabytes of them beside the mapping buffers of other contexts)
   void trim_to(size_t keep) {
+    std::lock_guard<std::mutex> lk(m);
     if (cached_bytes <= keep) return;
     (void)hipStreamSynchronize(stream);
     while (cached_bytes > keep && !cache.empty()) { auto it = std::prev(cache.end()); (void)hipFree(it->second); cached_bytes -= it->first; cache.erase(it); }
   }
   void* get(size_t bytes, size_t* got) {
     const size_t want = round_up(bytes);
+    {
+    std::lock_guard<std::mutex> lk(m);
     auto it = cache.lower_bound(want);
     // A cached block serves a request it is at most 60 % too large for, and what comes from the driver (from 64 MiB on) is asked for a
     // quarter larger than needed: read batches differ (more or fewer seed hits, candidates, records), and on this runtime memory the
@@ -83,6 +95,7 @@ struct DevAlloc {
     // serve the later ones, and a process in steady state does not go to the driver at all.
     if (it != cache.end() && it->first <= want + want / 4 + (want >= ((size_t)64 << 20) ? want * 7 / 20 : 0)) {
       void* p = it->second; *got = it->first; cached_bytes -= it->first; cache.erase(it); return p;
+    }
     }
     size_t ask = want;
     if (want >= ((size_t)64 << 20)) {                            // (headroom only while a fifth of the device is free: resident chunk indexes can leave less)
@@ -95,14 +108,25 @@ struct DevAlloc {
     hipError_t e = hipMalloc(&p, ask);
     size_t granted = ask;
     if (trace) fprintf(stderr, "MM_ALLOC_TRACE hipMalloc %zu bytes %.3f ms\n", ask, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); trim(); int dv = 0; (void)hipGetDevice(&dv); big_pool_trim(dv); granted = want; e = hipMalloc(&p, want); }   // (no headroom when memory is short)
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); trim(); int dv = 0; (void)hipGetDevice(&dv); big_pool_trim(dv); alloc_trim_others(this, dv); granted = want; e = hipMalloc(&p, want); }   // (no headroom when memory is short)
     if (e != hipSuccess) { (void)hipGetLastError(); throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, oom_text(want, e)); }
     *got = granted;
     return p;
   }
-  void put(void* p, size_t bytes) { cache.emplace(bytes, p); cached_bytes += bytes; }
-  ~DevAlloc() { trim(); }
+  void put(void* p, size_t bytes) { std::lock_guard<std::mutex> lk(m); cache.emplace(bytes, p); cached_bytes += bytes; }
+  ~DevAlloc() { alloc_unregister(this); trim(); }
 };
+struct AllocRegistry { std::mutex m; std::vector<DevAlloc*> v; };
+inline AllocRegistry& alloc_registry() { static AllocRegistry r; return r; }
+inline void alloc_register(DevAlloc* a, int device) { AllocRegistry& r = alloc_registry(); std::lock_guard<std::mutex> lk(r.m); a->device = device; r.v.push_back(a); }
+inline void alloc_unregister(DevAlloc* a) {
+  AllocRegistry& r = alloc_registry(); std::lock_guard<std::mutex> lk(r.m);
+  for (size_t i = 0; i < r.v.size(); ++i) if (r.v[i] == a) { r.v.erase(r.v.begin() + (long)i); break; }
+}
+inline void alloc_trim_others(DevAlloc* self, int device) {      // (the caller holds no allocator lock)
+  AllocRegistry& r = alloc_registry(); std::lock_guard<std::mutex> lk(r.m);
+  for (DevAlloc* a : r.v) if (a != self && a->device == device) a->trim();
+}
 // Index-scale blocks (>= 8 GiB) are recycled per device: on this runtime a freed block of that size is not free for long — one of the
 // next allocations stalls for ~6 s (constant, whatever its own size; MM_ALLOC_TRACE) — and an index build, let alone a pass over
 // the chunk indexes of a reference larger than HBM (built, mapped, dropped, chunk after chunk), frees and allocates tens of them.  A
@@ -165,7 +189,7 @@ struct DBuf {
       if (!p) {
         big_bytes = bytes;
         hipError_t e = hipMalloc((void**)&p, bytes);
-        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); bp.trim(); if (owner) owner->trim(); e = hipMalloc((void**)&p, bytes); }
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); bp.trim(); if (owner) owner->trim(); alloc_trim_others(owner, big_dev); e = hipMalloc((void**)&p, bytes); }
         if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; n = 0; throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, mm::oom_text(bytes, e)); }
         if (trace) fprintf(stderr, "MM_ALLOC_TRACE direct hipMalloc %zu bytes %.3f ms\n", bytes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       } else if (trace) fprintf(stderr, "MM_ALLOC_TRACE big block of %zu bytes reused for %zu\n", big_bytes, bytes);
@@ -287,7 +311,7 @@ struct mm_ctx {
   // K5 scratch kept across batches: the per-entry code words of pass A (4 B per streamed entry slot, mm_l2.hpp)
   void raw_alloc(void** p, size_t bytes) {                       // hipMalloc; out of memory: the caches of this context and the device's block pool go first
     hipError_t e = hipMalloc(p, bytes);
-    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); alloc.trim(); mm::big_pool_trim(device); e = hipMalloc(p, bytes); }
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); alloc.trim(); mm::big_pool_trim(device); mm::alloc_trim_others(&alloc, device); e = hipMalloc(p, bytes); }
     if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, mm::oom_text(bytes, e)); }
   }
   void* l2_codes = nullptr; size_t l2_codes_bytes = 0;

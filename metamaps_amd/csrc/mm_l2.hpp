@@ -260,8 +260,10 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                                                 const int32_t* __restrict__ cand_list /* WAVES==1: optional indirection (fallback runs) */,
                                                 int32_t* __restrict__ ovf_list, unsigned int* __restrict__ ovf_n,
                                                 uint8_t* __restrict__ amb_used /* optional: set per read when a vote read an unresolved strand */,
-                                                void* __restrict__ code_buf /* optional: 64*64*NWQ code words per wave of the launch (2 bytes each for NWQ == 2, else 4) */,
-                                                uint8_t* __restrict__ mask_buf /* NWQ > 2: l2_skip_bytes(NWQ) per wave of the launch */) {
+                                                void* __restrict__ code_buf /* optional: 64*64*NWQ code words (2 bytes each for NWQ == 2, else 4) per scratch slot */,
+                                                uint8_t* __restrict__ mask_buf /* NWQ > 2: l2_skip_bytes(NWQ) per scratch slot */,
+                                                unsigned int* __restrict__ slot_flags /* n_slots (a multiple of 8) words, all 0 between launches: a wave takes a free slot of its XCD's share for its lifetime (null: slot = wave number in the launch) */,
+                                                int n_slots) {
   extern __shared__ __align__(16) uint32_t lds[];
   uint32_t* Q = lds;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -318,7 +320,37 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   // vote instead of searching the sketch again.
   // 10 kb class (NWQ == 2, sketch <= 3072): 13-bit code + 3 flag bits in 16 bits; other classes: 16-bit code + flags in 32 bits
   using CW = std::conditional_t<NWQ == 2, uint16_t, uint32_t>;
-  CW* const cw = code_buf ? (CW*)code_buf + (size_t)(WAVES > 1 ? blockIdx.x * WAVES + wave : blockIdx.x) * (size_t)(64 * 64 * NWQ) : nullptr;
+  // The code words and class masks of a candidate live in a scratch slot for as long as its wave does.  A launch has hundreds of
+  // thousands of waves and a few thousand of them are resident at a time: the slots are taken and given back (one flag word each),
+  // so the scratch of a launch is what its resident waves need — a few hundred MB that stay in the last-level cache between the pass
+  // that writes the words and the passes that read them — instead of 16-128 KB for every wave of the launch (7-20 GB per read batch).
+  // The L2s of the XCDs are not coherent with each other (a line one holder left dirty in its XCD's L2 could be written back over
+  // the next holder's data), so the slots are split by XCD — a wave takes one from the share of the XCD it runs on
+  // (HW_REG_XCC_ID) and all traffic of a slot goes through ONE L2 for the whole launch.  Within an XCD the hand-over needs: the
+  // holder's stores landed in L2 before the flag falls (s_waitcnt vmcnt(0): the L1 is write-through), and nothing from the new
+  // holder — it writes every word before it reads it, and a CU's L1 follows its own stores.
+  CW* cw = nullptr;
+  int slot = -1;
+  auto acquire_slot = [&]() {
+    unsigned int sidx = WAVES > 1 ? blockIdx.x * WAVES + wave : blockIdx.x;
+    if (slot_flags) {
+      const unsigned int per = (unsigned int)n_slots >> 3;        // slots of one XCD (n_slots is a multiple of 8)
+      const unsigned int lo = ((unsigned int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u) * per;   // hwreg(HW_REG_XCC_ID, 0, 4)
+      unsigned int t = (sidx * 2654435761u >> 7) % per;            // (scattered start: workgroup b runs on XCD b % 8, the plain remainder would use an eighth of the share's starts)
+      if (lane == 0) while (atomicCAS(&slot_flags[lo + t], 0u, 1u) != 0u) t = t + 1u == per ? 0u : t + 1u;
+      sidx = lo + (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+    }
+    slot = (int)sidx;
+    if (code_buf) cw = (CW*)code_buf + (size_t)sidx * (size_t)(64 * 64 * NWQ);
+  };
+  auto release_slot = [&]() {                                    // (every read of the slot has returned: the wave used the values)
+    if (slot_flags && slot >= 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) atomicExch(&slot_flags[slot], 0u);
+    }
+    slot = -1;
+  };
+
   bool have_codes = false;                                       // set once pass A has run
   auto cw_make = [](int code, uint32_t flags) -> CW {
     if constexpr (NWQ == 2) return (CW)(((uint32_t)code & 0x1fffu) | (flags << 13));
@@ -842,7 +874,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     bool finished = false;
     // class masks and their prefix counts: LDS for the 10 kb class; for the long-read classes (NWQ > 2) they are written once
     // and read a few times per block, so they live in global memory and the LDS they would take buys resident waves instead
-    uint64_t* mAll = (uint64_t*)(mask_buf + (size_t)(WAVES > 1 ? blockIdx.x * WAVES + wave : blockIdx.x) * l2_skip_bytes(NWQ));
+    acquire_slot();
+    uint64_t* mAll = (uint64_t*)(mask_buf + (size_t)slot * l2_skip_bytes(NWQ));
     uint64_t* mLo = mAll + (NWORDS_MAX + 1);
     uint64_t* mA = mLo + (NWORDS_MAX + 1);
     uint16_t* pAll = (uint16_t*)(mA + (NWORDS_MAX + 1));
@@ -1010,7 +1043,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
       pass_matched();
       have_codes = cw != nullptr;
       lap(1);
-      if (dbg_stop == 2) return;
+      if (dbg_stop == 2) { release_slot(); return; }
       // per block of `bspan` b's: largest window [bF, eHi), smallest window [bL, eLo)   (lane l owns blocks l and l+64)
       {
         const int up0 = __shfl_down(eLo[0], 1, 64), up1 = __shfl_down(eLo[1], 1, 64);   // e_min of the next block start
@@ -1044,7 +1077,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         const int r0 = min(s, (int)((float)s * pq) + max(8, (int)(2.5f * sigma) + 4));
         pass_low(r0);
         lap(5);
-        if (dbg_stop == 4) return;
+        if (dbg_stop == 4) { release_slot(); return; }
         for (int q = 0; q < 2; ++q) {
           const int bq = lane + 64 * q;
           int u = -1;
@@ -1092,7 +1125,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
       lap(2);
       block_slide(last_end);                                     // the only instance of the slide code
       lap(4);
-      if (dbg_stop == 8 || dbg_stop == 9) return;
+      if (dbg_stop == 8 || dbg_stop == 9) { release_slot(); return; }
       if (phase != 1) break;
       // the slide stopped inside block bk, whose bound failed (or at the right end of the candidate)
       live = false;
@@ -1118,7 +1151,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   // sum over query ranks below the pivot that are present in the window of strandQ * strandR, where
   // strandR comes from the LAST occurrence of the hash in the window (insert_ref overwrites, :155-156).
   lap(4);
-  if (dbg_stop == 5) return;
+  if (dbg_stop == 5) { release_slot(); return; }
   int strand = -1, accepted = 0;
   if (best >= amin) {
     accepted = 1;
@@ -1167,6 +1200,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     if (amb_votes > 0 && ((votes - amb_votes <= 0 && votes + amb_votes > 0) || (dbg_flags & 0x200)) && lane == 0) amb_used[r] = 1;   // (0x200: tests force the resolution path)
     strand = votes > 0 ? 1 : -1;
   }
+  release_slot();
   if (NWQ == 2 && __ballot(overflow) != 0ull) {                   // a packed 8-bit counter saturated: hand the candidate to the full slide
     if (lane == 0) ovf_list[atomicAdd(ovf_n, 1u)] = (int32_t)c;
     accepted = 0; best = 0;

@@ -1943,7 +1943,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         d_listF.upload(listF.data(), listF.size(), st);
         set_lds((const void*)l2_kernel<false, uint16_t, 1, 8>, lds_wide);
         l2_kernel<false, uint16_t, 1, 8><<<dim3((unsigned)listF.size()), dim3(64), lds_wide, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, d_listF.p, nullptr, nullptr, amb_used_p, nullptr, nullptr);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, d_listF.p, nullptr, nullptr, amb_used_p, nullptr, nullptr, nullptr, 0);
         MM_KERNEL_CHECK();
       }
       MM_HIP(hipStreamSynchronize(st));                          // listF is the source of the async upload
@@ -1957,10 +1957,21 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       // Reads shorter than w+k are handed back by these kernels and go through the literal full slide.
       // per-entry code words of pass A: one slot range per wave of a launch (the launches of a batch run one after the other
       // on the stream, so they share the buffer); classes whose ranks do not fit 16 bits (C) search the sketch instead
-      auto masks_for = [&](size_t n_waves, int nwq = 8) -> uint8_t* { return (uint8_t*)ctx->l2_masks_at_least(std::max<size_t>(n_waves, 1) * l2_skip_bytes(nwq)); };
+      // scratch slots of the skip kernels (mm_l2.hpp): a slot per RESIDENT wave (the hardware keeps at most 32 per CU), taken and given
+      // back by the waves through one flag word each; MM_L2_NO_SLOTS=1: one slot per wave of the launch, no flags (cross-check switch)
+      // (MM_L2_SLOTS=n: fewer slots than resident waves — they wait for each other's; tests of the hand-over)
+      // twice as many slots as waves can be resident (the 10 kb class keeps 24 per CU, the long-read classes 8-12): a wave finds a free one at
+      // its first or second try
+      const bool no_slots = getenv("MM_L2_NO_SLOTS") != nullptr;
+      const size_t env_slots = getenv("MM_L2_SLOTS") ? ((size_t)std::max(atoi(getenv("MM_L2_SLOTS")), 1) + 7) / 8 * 8 : 0;
+      auto max_slots = [&](int nwq) -> size_t { return no_slots ? (size_t)1 << 40 : env_slots ? env_slots : (size_t)ctx->cus * (nwq == 2 ? 64 : 32); };
+      DBuf<unsigned int> slot_flags((size_t)ctx->cus * 64); slot_flags.zero(st);
+      unsigned int* const slot_flags_p = no_slots ? nullptr : slot_flags.p;
+      auto slots_of = [&](size_t n_waves, int nwq = 8) -> size_t { return std::min((std::max<size_t>(n_waves, 1) + 7) / 8 * 8, max_slots(nwq)); };   // (a multiple of 8: one share per XCD)
+      auto masks_for = [&](size_t n_waves, int nwq = 8) -> uint8_t* { return (uint8_t*)ctx->l2_masks_at_least(slots_of(n_waves, nwq) * l2_skip_bytes(nwq)); };
       auto codes_for = [&](size_t n_waves, int nwq) -> void* {
         if (getenv("MM_L2_NO_CODES")) return nullptr;              // cross-check switch
-        return ctx->l2_codes_at_least(n_waves * (size_t)(64 * 64 * nwq) * (nwq == 2 ? sizeof(uint16_t) : sizeof(uint32_t)));
+        return ctx->l2_codes_at_least(slots_of(n_waves, nwq) * (size_t)(64 * 64 * nwq) * (nwq == 2 ? sizeof(uint16_t) : sizeof(uint32_t)));
       };
       std::vector<int32_t> gA0, gAn, gB0, gBn, gD0, gDn, listC, gS0, gSn;   // gS: groups of one or two candidates of the 10 kb class (two-wave workgroups)
       int smA = 0, smB = 0, smC = 0, smD = 0;
@@ -2010,14 +2021,14 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 4, 2);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 2>, lds);
         l2_kernel<true, uint8_t, 4, 2><<<dim3((unsigned)nA), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(nA * 4, 2), masks_for(nA * 4, 2));
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(nA * 4, 2), masks_for(nA * 4, 2), slot_flags_p, (int)slots_of(nA * 4, 2));
         MM_KERNEL_CHECK();
       }
       if (nS) {
         const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 2, 2);
         set_lds((const void*)l2_kernel<true, uint8_t, 2, 2>, lds);
         l2_kernel<true, uint8_t, 2, 2><<<dim3((unsigned)nS), dim3(128), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gS0.p, d_gSn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(nS * 2, 2), masks_for(nS * 2, 2));
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gS0.p, d_gSn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(nS * 2, 2), masks_for(nS * 2, 2), slot_flags_p, (int)slots_of(nS * 2, 2));
         MM_KERNEL_CHECK();
       }
       if (!gB0.empty()) {
@@ -2025,7 +2036,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smB, true, 4, 8);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
         l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gB0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smB, M->l2.p, counters.p, d_gB0.p, d_gBn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gB0.size() * 4, 8), masks_for(gB0.size() * 4));
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smB, M->l2.p, counters.p, d_gB0.p, d_gBn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gB0.size() * 4, 8), masks_for(gB0.size() * 4), slot_flags_p, (int)slots_of(gB0.size() * 4));
         MM_KERNEL_CHECK();
       }
       DBuf<int32_t> d_gD0(gD0.size()), d_gDn(gDn.size());
@@ -2034,7 +2045,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smD, true, 4, 8);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
         l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gD0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gD0.size() * 4, 8), masks_for(gD0.size() * 4));
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gD0.size() * 4, 8), masks_for(gD0.size() * 4), slot_flags_p, (int)slots_of(gD0.size() * 4));
         MM_KERNEL_CHECK();
       }
       if (!listC.empty()) {
@@ -2042,7 +2053,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint16_t>(smC, true, 1, 8);
         set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
         l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)listC.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smC, M->l2.p, counters.p, nullptr, nullptr, d_listC.p, ovf.p, ovf_n.p, amb_used_p, nullptr, masks_for(listC.size()));
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smC, M->l2.p, counters.p, nullptr, nullptr, d_listC.p, ovf.p, ovf_n.p, amb_used_p, nullptr, masks_for(listC.size()), slot_flags_p, (int)slots_of(listC.size()));
         MM_KERNEL_CHECK();
       }
       hl("K5 uploads + launches");
@@ -2057,7 +2068,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint16_t>(smax, false, 1, 8);
         set_lds((const void*)l2_kernel<false, uint16_t, 1, 8>, lds);
         l2_kernel<false, uint16_t, 1, 8><<<dim3(h_ovf), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr, amb_ptr, nullptr, nullptr);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr, amb_ptr, nullptr, nullptr, nullptr, 0);
         MM_KERNEL_CHECK();
         ovf_n.zero(st);
         n_fallback += h_ovf;
@@ -2084,7 +2095,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
             const size_t lds = l2_lds_bytes<uint16_t>(smR, true, 1, 8);
             set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
             l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)redo.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-                M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smR, M->l2.p, counters.p, nullptr, nullptr, d_redo.p, ovf.p, ovf_n.p, nullptr, nullptr, masks_for(redo.size()));
+                M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smR, M->l2.p, counters.p, nullptr, nullptr, d_redo.p, ovf.p, ovf_n.p, nullptr, nullptr, masks_for(redo.size()), slot_flags_p, (int)slots_of(redo.size()));
             MM_KERNEL_CHECK();
             run_fallback(nullptr);
           }

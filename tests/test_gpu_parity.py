@@ -892,3 +892,27 @@ def test_duplicate_neighbour_distances_match_definition(ctx):
     assert d.max() > 65535                                        # some neighbours lie beyond the stored range ...
     assert np.array_equal(pd, np.minimum(exp_p, 65535)) and np.array_equal(nd, np.minimum(exp_n, 65535))   # ... and are stored saturated
     idx.close(); ref.close()
+
+
+def test_l2_scratch_slots_hand_over(ctx, monkeypatch):
+    """K5's code words and class masks live in scratch slots that the waves of a launch take and give back (mm_l2.hpp: one slot per
+    resident wave instead of one per wave of the launch).  Reads of 1-60 kb (every class of the skip kernels in one batch, far more
+    waves than slots in the 10 kb class): the default, a pool of 48 slots that every launch's waves queue for (MM_L2_SLOTS), and one
+    slot per wave of the launch without any hand-over (MM_L2_NO_SLOTS, the layout before) must give identical records."""
+    ref = ctx.synth_reference(seed=35, n_species=12, strains_per_species=4, genome_len=600_000, strain_divergence=0.02, genus_divergence=0.08)
+    reads, _ = ctx.synth_reads(ref, seed=39, n_reads=6000, read_len=60_000, read_len_min=1_000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=10)
+    idx = ctx.index(ref, 16, 8)
+    res = {}
+    for mode, env in (("default", {}), ("few", {"MM_L2_SLOTS": "48"}), ("per_wave", {"MM_L2_NO_SLOTS": "1"})):
+        for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
+        for rep in range(2):                                      # twice: the flags of the first launch must all have come back
+            M = ctx.map_batch(idx, reads, 16, 8)
+            off, rec = M.fetch()
+            res[(mode, rep)] = (off.copy(), rec.copy(), M.stats())
+            M.close()
+        for k_ in env: monkeypatch.delenv(k_)
+    base = res[("default", 0)]
+    assert base[2]["n_candidates"] > 16_000 and base[2]["n_l2_rebuilds"] > 0
+    for key, got in res.items():
+        assert np.array_equal(base[0], got[0]) and np.array_equal(base[1], got[1]), key
+    idx.close(); reads.close(); ref.close()

@@ -544,6 +544,15 @@ def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
         for t in th:
             t.join()
 
+    # how many worker contexts the device has room for beside the resident chunk indexes (four of them take 238 of 288 GiB at full
+    # scale): the first context's step shows what one needs (hit lists, sort buffers, K5 scratch), every further one must fit 1.3 times over
+    if W > 1:
+        import torch
+        torch.cuda.synchronize(); f0 = torch.cuda.mem_get_info()[0]
+        em_turn["next"] = 0; step(0, ctxs[0])
+        torch.cuda.synchronize(); f1 = torch.cuda.mem_get_info()[0]
+        need = max(f0 - f1, 1 << 30)
+        W = max(1, min(W, 1 + int(f1 / (1.3 * need))))
     for wi in range(1, W):                                          # setup: every further worker context runs once (its scratch buffers get allocated)
         em_turn["next"] = 0; step(0, ctxs[wi])
     run_steps(0, max(args.warmup, 0))

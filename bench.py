@@ -546,8 +546,9 @@ def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
         for t in th:
             t.join()
 
-    # how many worker contexts the device has room for beside the resident chunk indexes (four of them take 238 of 288 GiB at full
-    # scale): the first context's step shows what one needs (hit lists, sort buffers, K5 scratch), every further one must fit 1.3 times over
+    # how many worker contexts the device has room for beside the resident chunk indexes (four of them take 227 of 288 GiB at full
+    # scale): the first context's step shows what one needs (hit lists, sort buffers: 16 GiB), every further one must fit 1.3 times over.
+    # At full scale: one (two were tried, MM_BENCH_C3_WORKERS=2: out of memory with every cache given back, tools/mem_config3.py)
     if W > 1:
         import torch
         torch.cuda.synchronize(); f0 = torch.cuda.mem_get_info()[0]
@@ -555,6 +556,8 @@ def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
         torch.cuda.synchronize(); f1 = torch.cuda.mem_get_info()[0]
         need = max(f0 - f1, 1 << 30)
         W = max(1, min(W, 1 + int(f1 / (1.3 * need))))
+        if os.environ.get("MM_BENCH_C3_WORKERS"): W = max(1, min(len(ctxs), int(os.environ["MM_BENCH_C3_WORKERS"])))   # (measurement aid)
+        print(f"config 3: {f0 / 2**30:.1f} GiB free beside the chunk indexes, {need / 2**30:.1f} GiB per worker context -> {W} worker context(s)", file=sys.stderr)
     for wi in range(1, W):                                          # setup: every further worker context runs once (its scratch buffers get allocated)
         em_turn["next"] = 0; step(0, ctxs[wi])
     run_steps(0, max(args.warmup, 0))

@@ -53,6 +53,11 @@ const char* mm_last_error(const mm_ctx* ctx);            /* valid until the next
 /* device name, CU count, total HBM bytes, free HBM bytes */
 int mm_ctx_device_info(mm_ctx* ctx, char* name, size_t name_cap, int* cus, uint64_t* hbm_total, uint64_t* hbm_free);
 int mm_ctx_synchronize(mm_ctx* ctx);
+/* Hands the context's cached free device blocks, and the device's recycled index-scale blocks, back to the driver.  The library caches
+ * what it frees (a context's own allocator; index-scale blocks per device) and gives it up by itself only when an allocation fails for
+ * lack of memory; a host that has finished a phase — e.g. all chunk indexes of a --maxmemory run built, worker contexts about to start
+ * beside them — calls this so that the memory is there without that detour. */
+int mm_ctx_release_cached(mm_ctx* ctx);
 /* raw hipStream_t the kernels are launched on (for event timing by the caller) */
 void* mm_ctx_stream(mm_ctx* ctx);
 

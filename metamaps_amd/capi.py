@@ -96,6 +96,7 @@ def lib() -> C.CDLL:
         P = C.POINTER
         sig = {
             "mm_abi_version": (C.c_int, []),
+            "mm_ctx_release_cached": (C.c_int, [vp]),
             "mm_device_count": (C.c_int, []),
             "mm_ctx_create": (C.c_int, [C.c_int, P(vp)]),
             "mm_ctx_destroy": (None, [vp]),
@@ -200,6 +201,10 @@ class Context:
         tot, free = C.c_uint64(), C.c_uint64()
         self.check(lib().mm_ctx_device_info(self.h, name, 256, C.byref(cus), C.byref(tot), C.byref(free)))
         return {"name": name.value.decode(), "cus": cus.value, "hbm_total": tot.value, "hbm_free": free.value}
+
+    def release_cached(self):
+        """cached free device blocks of this context (and the device's recycled index-scale blocks) back to the driver"""
+        self.check(lib().mm_ctx_release_cached(self.h))
 
     def synchronize(self):
         self.check(lib().mm_ctx_synchronize(self.h))

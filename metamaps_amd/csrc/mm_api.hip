@@ -94,6 +94,10 @@ int mm_ctx_synchronize(mm_ctx* ctx) {
   if (!ctx) return MM_ERR_ARG;
   return guarded(ctx, [&] { MM_HIP(hipStreamSynchronize(ctx->stream)); });
 }
+int mm_ctx_release_cached(mm_ctx* ctx) {
+  if (!ctx) return MM_ERR_ARG;
+  return guarded(ctx, [&] { MM_HIP(hipSetDevice(ctx->device)); ctx->alloc.trim(); mm::big_pool_trim(ctx->device); });
+}
 void* mm_ctx_stream(mm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 // ---- sequences ----------------------------------------------------------------------------------------

@@ -103,14 +103,14 @@ __global__ void __launch_bounds__(256) pad_lists_kernel(const uint64_t* __restri
 
 // open-addressing insert of every unique hash: slot word 0 = count<<32 | hash (non-zero: count >= 1), word 1 = start
 __global__ void table_insert_kernel(const uint32_t* __restrict__ uh, const uint64_t* __restrict__ ustart, const uint64_t* __restrict__ pstart,
-                                    int64_t U, int bits, unsigned long long* __restrict__ tab) {
-  const uint64_t mask = ((uint64_t)1 << bits) - 1;
+                                    int64_t U, uint32_t buckets, unsigned long long* __restrict__ tab) {
+  const uint64_t slots = (uint64_t)buckets << 2;
   for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t h = uh[u];
     const uint64_t st = pstart[u], cnt = ustart[u + 1] - ustart[u];
     const unsigned long long w0 = ((unsigned long long)(cnt > 0xFFFFFFFFull ? 0xFFFFFFFFull : cnt) << 32) | h;
-    uint64_t slot = tab_slot(h, bits);
-    while (atomicCAS(&tab[2 * slot], 0ull, w0) != 0ull) slot = (slot + 1) & mask;
+    uint64_t slot = tab_slot(h, buckets);
+    while (atomicCAS(&tab[2 * slot], 0ull, w0) != 0ull) slot = tab_next_slot(slot, slots);
     tab[2 * slot + 1] = st;
   }
 }
@@ -238,8 +238,8 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   I->U = 0; I->n_dup = 0; I->hist.clear();
   build_directory(I, st);
   if (N == 0) {
-    I->tab_bits = 8;
-    I->tab.alloc((size_t)2 << I->tab_bits); I->tab.zero(st);
+    I->tab_buckets = 64;
+    I->tab.alloc((size_t)I->tab_buckets * 8); I->tab.zero(st);
     I->occ.alloc(1); I->occ16.alloc(16);
     I->dup_bits.alloc(1); I->dup_rank.alloc(2); I->dup_dist.alloc(1);
     I->dup_bits.zero(st); I->dup_rank.zero(st); I->dup_dist.zero(st);
@@ -384,12 +384,11 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
     MM_HIP(hipStreamSynchronize(st));
     I->occ = std::move(padded);
   }
-  // lookup table (load factor <= 0.625), then the CSR arrays are no longer needed
-  int bits = 8; while (((int64_t)1 << bits) * 5 < (int64_t)U * 8) ++bits;
-  I->tab_bits = bits;
-  I->tab.alloc((size_t)2 << bits);
+  // lookup table (load factor <= 0.55, any number of 4-slot buckets), then the CSR arrays are no longer needed
+  I->tab_buckets = tab_buckets_for((int64_t)U);
+  I->tab.alloc((size_t)I->tab_buckets * 8);
   I->tab.zero(st);
-  table_insert_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div((int64_t)U, 256), 1 << 20)), dim3(256), 0, st>>>(I->uh.p, I->ustart.p, pstart.p, (int64_t)U, bits,
+  table_insert_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div((int64_t)U, 256), 1 << 20)), dim3(256), 0, st>>>(I->uh.p, I->ustart.p, pstart.p, (int64_t)U, I->tab_buckets,
                                                                                                               (unsigned long long*)I->tab.p);
   MM_KERNEL_CHECK();
   MM_HIP(hipStreamSynchronize(st));
@@ -431,7 +430,7 @@ void index_plan_chunks(mm_ctx* ctx, const mm_index* I, uint64_t max_memory, std:
   hipStream_t st = ctx->stream;
   first_contig.assign(1, 0);
   if (max_memory == 0 || I->n_contigs == 0) return;
-  const int64_t C = I->n_contigs, slots = (int64_t)1 << I->tab_bits;
+  const int64_t C = I->n_contigs, slots = (int64_t)I->tab_buckets * 4;
   DBuf<unsigned int> novel((size_t)C);
   std::vector<unsigned int> h((size_t)C);
   int64_t c0 = 0;

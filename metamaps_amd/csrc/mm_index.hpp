@@ -8,7 +8,7 @@
 //               occ entry = contig<<32 | pw  (8 bytes, directly usable as an L1 seed hit / sort key)
 //   occ16[P]    per occ entry (same index) the 13-bit position bin the seed-hit filter counts in:
 //               ((first base of the contig in the concatenated reference + wpos) >> 13) & 8191
-//   tab[2*cap]  open-addressing table hash -> (count, first occ): slot = {count<<32 | hash, start}; one 64-byte
+//   tab[2*cap]  open-addressing table hash -> (count, first occ), cap = 4 * tab_buckets: slot = {count<<32 | hash, start}; one 64-byte
 //               line per lookup on average (uh[]/ustart[] CSR arrays only live during the build)
 //   dup_bits / dup_rank / dup_dist   same-hash neighbours of the entries whose hash occurs more than once in their contig
 //               (flags PW_DP / PW_DN in pos[].pw): bit j&63 of dup_bits[j>>6] marks a flagged entry, dup_rank[j>>6] counts the
@@ -18,13 +18,14 @@
 #pragma once
 #include "mm_common.hpp"
 #include <climits>
+#include <algorithm>
 #include <map>
 
 struct mm_index {
   mm_ctx* ctx = nullptr;
   int k = 0, w = 0;
   int64_t n_contigs = 0, N = 0, U = 0, n_dup = 0;
-  int tab_bits = 0;
+  uint32_t tab_buckets = 0;                  // 4-slot buckets of tab[] (any number, not a power of two)
   int freq_threshold = INT_MAX;              // winSketch.hpp:94
   mm::DBuf<mm::Rec> pos;
   mm::DBuf<uint64_t> cstart;
@@ -64,7 +65,7 @@ struct IndexView {
   const uint16_t* occ16;
   const uint64_t* tab;
   int64_t N, U;
-  int tab_bits;
+  uint32_t tab_buckets;
   int freq_threshold;
   const uint32_t* dir;
   const uint64_t* dir_off;
@@ -75,25 +76,36 @@ struct IndexView {
   int dup_sat;
 };
 inline IndexView make_view(const mm_index* I) {
-  return IndexView{I->pos.p, I->cstart.p, I->occ.p, I->occ16.p, I->tab.p, I->N, I->U, I->tab_bits, I->freq_threshold, I->dir.p, I->dir_off.p, I->dir_shift,
+  return IndexView{I->pos.p, I->cstart.p, I->occ.p, I->occ16.p, I->tab.p, I->N, I->U, I->tab_buckets, I->freq_threshold, I->dir.p, I->dir_off.p, I->dir_shift,
                    I->dup_bits.p, I->dup_rank.p, I->dup_dist.p, I->dup_sat};
 }
 
 // Home slot of a hash: the first slot of a 4-slot bucket (4 x 16 B = one 64-byte sector), linear probing from there.  A lookup
-// reads whole sectors: at load factor <= 0.625 nearly every hash is resolved (found, or an empty slot seen) by its home sector,
+// reads whole sectors: at load factor <= 0.55 nearly every hash is resolved (found, or an empty slot seen) by its home sector,
 // i.e. by one memory request — random requests, not bytes, are what the probe stage pays for (tools/ubench/randread).
-__host__ __device__ inline uint64_t tab_slot(uint32_t h, int bits) { return (((uint64_t)h * 0x9E3779B97F4A7C15ULL) >> (64 - (bits - 2))) << 2; }
+// The table has ANY number of buckets (multiply-shift range reduction of the mixed hash: minimizer hashes are window minima, skewed
+// towards small values, so the hash is multiplied by an odd constant first): a power-of-two table is up to twice as large as its
+// load factor asks for — 17 GB instead of 10 for each of the chunk indexes of a --maxmemory run.
+__host__ __device__ inline uint64_t tab_slot(uint32_t h, uint32_t buckets) {
+  return (uint64_t)(uint32_t)(((uint64_t)(h * 0x9E3779B1u) * (uint64_t)buckets) >> 32) << 2;
+}
+__host__ __device__ inline uint64_t tab_next_sector(uint64_t slot, uint64_t slots) { slot += 4; return slot >= slots ? slot - slots : slot; }
+__host__ __device__ inline uint64_t tab_next_slot(uint64_t slot, uint64_t slots) { return slot + 1 == slots ? 0 : slot + 1; }
+__host__ inline uint32_t tab_buckets_for(int64_t unique_hashes) {   // load factor <= 0.55 (what the 2^30-slot table of the miniSeq+H index had)
+  const int64_t slots = (int64_t)((double)unique_hashes / 0.55) + 4;
+  return (uint32_t)std::max<int64_t>((slots + 3) / 4, 64);
+}
 
 // hash -> (occurrence count, first occurrence); false when the hash is not in the index
 // (minimizerPosLookupIndex.find, computeMap.hpp:310).  One lane per lookup; probe_kernel has the 4-lanes-per-sector form.
 __device__ inline bool index_find(const IndexView& I, uint32_t h, uint32_t* count, uint64_t* start) {
-  const uint64_t mask = ((uint64_t)1 << I.tab_bits) - 1;
-  uint64_t slot = tab_slot(h, I.tab_bits);
+  const uint64_t slots = (uint64_t)I.tab_buckets << 2;
+  uint64_t slot = tab_slot(h, I.tab_buckets);
   for (;;) {
     const uint64_t w0 = I.tab[2 * slot];
     if (w0 == 0) return false;
     if ((uint32_t)w0 == h) { *count = (uint32_t)(w0 >> 32); *start = I.tab[2 * slot + 1]; return true; }
-    slot = (slot + 1) & mask;
+    slot = tab_next_slot(slot, slots);
   }
 }
 

@@ -232,12 +232,12 @@ __global__ void __launch_bounds__(256) probe_kernel(IndexView I, const uint32_t*
   const int s = sk_n[r];
   const int grp = threadIdx.x >> 2, sub = threadIdx.x & 3, gshift = (threadIdx.x & 63) & ~3;
   const ulonglong2* __restrict__ tab = reinterpret_cast<const ulonglong2*>(I.tab);
-  const uint64_t mask = ((uint64_t)1 << I.tab_bits) - 1;
+  const uint64_t tslots = (uint64_t)I.tab_buckets << 2;
   constexpr int NP = 4;                                          // lookups in flight per group
   for (int i0 = grp; i0 < s; i0 += 64 * NP) {
     uint32_t hq[NP]; uint64_t sq[NP]; ulonglong2 vq[NP];
 #pragma unroll
-    for (int u = 0; u < NP; ++u) { hq[u] = i0 + 64 * u < s ? sk_hash[o + i0 + 64 * u] : 0u; sq[u] = tab_slot(hq[u], I.tab_bits); }
+    for (int u = 0; u < NP; ++u) { hq[u] = i0 + 64 * u < s ? sk_hash[o + i0 + 64 * u] : 0u; sq[u] = tab_slot(hq[u], I.tab_buckets); }
 #pragma unroll
     for (int u = 0; u < NP; ++u) vq[u] = tab[sq[u] + sub];
     auto resolve = [&](uint32_t h, uint64_t slot, ulonglong2 v, bool active, int i) {
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) probe_kernel(IndexView I, const uint32_t*
           } else if (!gm && sub == 0) { probe_cnt[o + i] = 0u; probe_start[o + i] = 0ull; }
           pending = false;
         }
-        if (pending) { slot = (slot + 4) & mask; v = tab[slot + sub]; }
+        if (pending) { slot = tab_next_sector(slot, tslots); v = tab[slot + sub]; }
       }
     };
 #pragma unroll
@@ -500,16 +500,16 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_kernel(IndexView I, co
   // of a lane group are loaded first, then all home sectors requested, then resolved: two memory latencies for the whole sketch.
   {
     const ulonglong2* __restrict__ tab = reinterpret_cast<const ulonglong2*>(I.tab);
-    const uint64_t mask = ((uint64_t)1 << I.tab_bits) - 1;
+    const uint64_t tslots = (uint64_t)I.tab_buckets << 2;
     uint32_t hq[SF_LPG]; ulonglong2 vq[SF_LPG];
 #pragma unroll
     for (int u = 0; u < SF_LPG; ++u) { const int i = grp + SF_GROUPS * u; hq[u] = i < s ? sk_hash[o + i] : 0u; }
 #pragma unroll
-    for (int u = 0; u < SF_LPG; ++u) vq[u] = tab[tab_slot(hq[u], I.tab_bits) + sub];
+    for (int u = 0; u < SF_LPG; ++u) vq[u] = tab[tab_slot(hq[u], I.tab_buckets) + sub];
 #pragma unroll
     for (int u = 0; u < SF_LPG; ++u) {
       const int i = grp + SF_GROUPS * u;
-      const uint32_t h = hq[u]; uint64_t slot = tab_slot(h, I.tab_bits); ulonglong2 v = vq[u];
+      const uint32_t h = hq[u]; uint64_t slot = tab_slot(h, I.tab_buckets); ulonglong2 v = vq[u];
       bool pending = i < s;
       while (__any(pending)) {
         const bool match = pending && v.x != 0 && (uint32_t)v.x == h, empty = pending && v.x == 0;
@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_kernel(IndexView I, co
           } else if (!gm && sub == 0) { L.lcnt[i] = 0; L.lstart[i] = 0ull; }
           pending = false;
         }
-        if (pending) { slot = (slot + 4) & mask; v = tab[slot + sub]; }
+        if (pending) { slot = tab_next_sector(slot, tslots); v = tab[slot + sub]; }
       }
     }
   }
@@ -717,7 +717,7 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_stream_kernel(IndexVie
   extern __shared__ __align__(16) unsigned char sf_dyn[];
   SeedFilterLds& L = *reinterpret_cast<SeedFilterLds*>(sf_dyn);
   const ulonglong2* __restrict__ tab = reinterpret_cast<const ulonglong2*>(I.tab);
-  const uint64_t tmask = ((uint64_t)1 << I.tab_bits) - 1;
+  const uint64_t tslots = (uint64_t)I.tab_buckets << 2;
   uint32_t hq[SF_LPG]; ulonglong2 vq[SF_LPG];                      // the look-ups in flight: hashes and home-sector slots of the NEXT read
   int r_cur = 0, s_cur = 0; uint64_t o_cur = 0;
   unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = 0;
@@ -763,7 +763,7 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_stream_kernel(IndexVie
       int sub_ = (int)threadIdx.x & 3;
       asm volatile("" : "+v"(sub_));                               // (a value of its own: the lane's table address of the resolve step need not live — in scratch — until here)
 #pragma unroll
-      for (int u = 0; u < SF_LPG; ++u) vq[u] = tab[tab_slot(hq[u], I.tab_bits) + sub_];
+      for (int u = 0; u < SF_LPG; ++u) vq[u] = tab[tab_slot(hq[u], I.tab_buckets) + sub_];
     };
     if (it < 0) {
       if (tid == 0) L.tick[0] = atomicAdd(ticket, 1u);
@@ -816,17 +816,17 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_stream_kernel(IndexVie
 #pragma unroll
       for (int u = 0; u < SF_LPG; ++u) {
         const int i = grp + SF_GROUPS * u;
-        if (!settle(i, hq[u], vq[u], i < s)) { pmask |= 1u << u; vq[u] = tab[((tab_slot(hq[u], I.tab_bits) + 4ull) & tmask) + sub]; }
+        if (!settle(i, hq[u], vq[u], i < s)) { pmask |= 1u << u; vq[u] = tab[tab_next_sector(tab_slot(hq[u], I.tab_buckets), tslots) + sub]; }
       }
       if (__any(pmask != 0)) {
 #pragma unroll
         for (int u = 0; u < SF_LPG; ++u) {
           const int i = grp + SF_GROUPS * u;
-          const uint32_t h = hq[u]; uint64_t slot = (tab_slot(h, I.tab_bits) + 4ull) & tmask; ulonglong2 v = vq[u];
+          const uint32_t h = hq[u]; uint64_t slot = tab_next_sector(tab_slot(h, I.tab_buckets), tslots); ulonglong2 v = vq[u];
           bool pending = (pmask >> u) & 1u;
           while (__any(pending)) {
             if (settle(i, h, v, pending)) pending = false;
-            if (pending) { slot = (slot + 4) & tmask; v = tab[slot + sub]; }
+            if (pending) { slot = tab_next_sector(slot, tslots); v = tab[slot + sub]; }
           }
         }
       }

@@ -213,3 +213,19 @@ def test_seqset_slice_and_concat(ctx):
     for x in parts + [cat, whole]:
         x.close()
     idx_a.close(); idx_b.close()
+
+
+def test_release_cached_returns_memory_to_the_driver(ctx):
+    """mm_ctx_release_cached: what an index build leaves in the context's cache (its temporaries) goes back to the driver on request —
+    a host does this before worker contexts start beside the resident indexes, instead of waiting for an allocation to fail"""
+    ref = ctx.synth_reference(seed=3, n_species=24, strains_per_species=4, genome_len=500_000, strain_divergence=0.02, genus_divergence=0.08)
+    idx = ctx.index(ref, 16, 8)
+    idx.close()
+    ctx.synchronize()
+    free_before = ctx.device_info()["hbm_free"]
+    ctx.release_cached()
+    free_after = ctx.device_info()["hbm_free"]
+    assert free_after > free_before + (64 << 20)                 # the sort buffers of a 48 Mbp index alone are > 100 MB
+    idx = ctx.index(ref, 16, 8)                                  # and the context works as before
+    assert idx.info()["n_entries"] > 1_000_000
+    idx.close(); ref.close()

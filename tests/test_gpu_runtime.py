@@ -40,3 +40,34 @@ def test_same_results_with_and_without_pytorch_runtime(tmp_path):
         res[mode] = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert res["plain"] == res["torch"]
     assert res["plain"][0] == res["plain"][1] and res["plain"][0][0] > 3000
+
+
+def test_cached_blocks_of_one_context_serve_another():
+    """A context keeps the device blocks it frees (its allocator's cache) and gives them up when one of ITS allocations fails for lack of
+    memory.  Worker contexts beside the context that built the indexes need that memory too: an allocation that fails now also trims the
+    caches of the other contexts of the device (mm_common.hpp: alloc_trim_others).  Context A fills three quarters of the free memory with
+    ~3 GiB sequence sets and closes them (all cached, nothing back at the driver); context B then allocates half of what was free."""
+    from metamaps_amd import capi
+    a, b = capi.Context(0), capi.Context(0)
+    free0 = a.device_info()["hbm_free"]
+    if free0 < (48 << 30):
+        pytest.skip("needs 48 GiB of free device memory")
+    shape = dict(n_species=60, strains_per_species=4, genome_len=50_000_000, strain_divergence=0.02, genus_divergence=0.2)   # 12 Gbases = 3 GiB packed
+    sets = []
+    while a.device_info()["hbm_free"] > free0 // 4:
+        sets.append(a.synth_reference(seed=len(sets) + 1, **shape))
+    n_a = len(sets)
+    for s_ in sets:
+        s_.close()
+    a.synchronize()
+    assert a.device_info()["hbm_free"] < free0 // 3              # closed, but cached by A
+    want = int(free0 // 2 // (3 << 30))
+    assert want > n_a // 4 + 1                                    # more than what is free without A's cache
+    sets = [b.synth_reference(seed=100 + i, **shape) for i in range(want)]   # (fails with MM_ERR_NOMEM without the cross-context trim)
+    assert all(s_.total_bases == 12_000_000_000 for s_ in sets)
+    for s_ in sets:
+        s_.close()
+    ref = a.synth_reference(seed=3, n_species=8, strains_per_species=2, genome_len=200_000, strain_divergence=0.02, genus_divergence=0.2)
+    idx = a.index(ref, 16, 8)                                     # A works as before
+    assert idx.info()["n_entries"] > 100_000
+    idx.close(); ref.close(); b.close(); a.close()

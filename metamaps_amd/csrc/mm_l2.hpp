@@ -46,9 +46,11 @@ namespace mm {
 // (2: up to 8 192 streamed entries, reads up to ~18 kb at w=8; 8: 32 768 entries).  Bounds are taken per block of BW words,
 // BW the smallest power of two with at most 128 blocks (two per lane).
 constexpr int L2_NBLK_MAX = 128;
-constexpr int L2_TBITS = 10;                     // bucket table over the top hash bits of the sketch
-constexpr int L2_TSHIFT = 32 - L2_TBITS;
-constexpr int L2_TSIZE = (1 << L2_TBITS) + 1;
+// bucket table over the top hash bits of the sketch: 1 024 buckets for the 10 kb class (sketches up to 3 072 hashes: at most four halving steps
+// inside a bucket; 2 048 buckets were measured in round 2 and cost in LDS what they saved), 4 096 for the long-read classes (sketches up to
+// 32 768: with 1 024 buckets their searches needed five steps and the generic loop, tools/l2_long_phases.py)
+__host__ __device__ constexpr int l2_tbits(int nwq) { return nwq == 2 ? 10 : 12; }
+__host__ __device__ constexpr int l2_tsize(int nwq) { return (1 << l2_tbits(nwq)) + 1; }
 
 // does [lo, hi) of pos[] hold hash h?  512 entries per step, the eight loads of a step in flight together: one load per step
 // made every duplicate-flagged entry of a 50 kb window cost ~200 dependent memory latencies (two thirds of the rebuild time).
@@ -138,14 +140,14 @@ __device__ inline int64_t contig_lower_bound_wpos(const IndexView& I, int contig
   return wave_lower_bound_wpos(I.pos, lo, hi, target, lane);
 }
 
-// Rank of a hash in the sorted sketch Q (lower bound).  T[b] = first rank whose hash >= b << L2_TSHIFT, so the answer lies
+// Rank of a hash in the sorted sketch Q (lower bound).  T[b] = first rank whose hash >= b << tshift, so the answer lies
 // in a run of fewer than 2^steps elements starting at T[b]; because all of Q is sorted, the branch-free doubling search
 // below needs no upper limit (elements behind the bucket are larger than h anyway; Q is padded with 16 x 0xffffffff).
 // Four independent searches are interleaved so that one step costs one LDS latency for four entries.
 constexpr int L2_QPAD = 16;
-__device__ inline void l2_classify4(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int steps, int s,
+__device__ inline void l2_classify4(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int tshift, int steps, int s,
                                     const uint32_t (&h)[4], int (&code)[4]) {
-  int lo0 = T[h[0] >> L2_TSHIFT], lo1 = T[h[1] >> L2_TSHIFT], lo2 = T[h[2] >> L2_TSHIFT], lo3 = T[h[3] >> L2_TSHIFT];
+  int lo0 = T[h[0] >> tshift], lo1 = T[h[1] >> tshift], lo2 = T[h[2] >> tshift], lo3 = T[h[3] >> tshift];
   if (steps <= 4) {
 #define MM_L2_STEP(ST)                                                                                              \
     { const uint32_t v0 = Q[lo0 + ST - 1], v1 = Q[lo1 + ST - 1], v2 = Q[lo2 + ST - 1], v3 = Q[lo3 + ST - 1];         \
@@ -156,7 +158,7 @@ __device__ inline void l2_classify4(const uint32_t* __restrict__ Q, const uint16
     if (steps > 0) MM_L2_STEP(1)
 #undef MM_L2_STEP
   } else {
-    int hi0 = T[(h[0] >> L2_TSHIFT) + 1], hi1 = T[(h[1] >> L2_TSHIFT) + 1], hi2 = T[(h[2] >> L2_TSHIFT) + 1], hi3 = T[(h[3] >> L2_TSHIFT) + 1];
+    int hi0 = T[(h[0] >> tshift) + 1], hi1 = T[(h[1] >> tshift) + 1], hi2 = T[(h[2] >> tshift) + 1], hi3 = T[(h[3] >> tshift) + 1];
     for (int it = 0; it < steps; ++it) {
       const int m0 = min((lo0 + hi0) >> 1, s - 1), m1 = min((lo1 + hi1) >> 1, s - 1), m2 = min((lo2 + hi2) >> 1, s - 1), m3 = min((lo3 + hi3) >> 1, s - 1);
       const uint32_t v0 = Q[m0], v1 = Q[m1], v2 = Q[m2], v3 = Q[m3];
@@ -173,18 +175,18 @@ __device__ inline void l2_classify4(const uint32_t* __restrict__ Q, const uint16
   code[3] = (lo3 < s && e3 == h[3]) ? lo3 : -(lo3 + 1);
 }
 // Eight at a time (the streaming passes hold eight chunks in registers): twice the LDS reads in flight per step.
-__device__ inline void l2_classify8(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int steps, int s,
+__device__ inline void l2_classify8(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int tshift, int steps, int s,
                                     const uint32_t (&h)[8], int (&code)[8]) {
   if (steps > 4) {
     uint32_t a[4], b[4]; int ca[4], cb[4];
     for (int i = 0; i < 4; ++i) { a[i] = h[i]; b[i] = h[4 + i]; }
-    l2_classify4(Q, T, steps, s, a, ca); l2_classify4(Q, T, steps, s, b, cb);
+    l2_classify4(Q, T, tshift, steps, s, a, ca); l2_classify4(Q, T, tshift, steps, s, b, cb);
     for (int i = 0; i < 4; ++i) { code[i] = ca[i]; code[4 + i] = cb[i]; }
     return;
   }
   int lo[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) lo[i] = T[h[i] >> L2_TSHIFT];
+  for (int i = 0; i < 8; ++i) lo[i] = T[h[i] >> tshift];
 #define MM_L2_STEP8(ST)                                                                   \
   { uint32_t v[8];                                                                        \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) v[i] = Q[lo[i] + ST - 1];               \
@@ -200,15 +202,15 @@ __device__ inline void l2_classify8(const uint32_t* __restrict__ Q, const uint16
 #pragma unroll
   for (int i = 0; i < 8; ++i) code[i] = (lo[i] < s && ev[i] == h[i]) ? lo[i] : -(lo[i] + 1);
 }
-__device__ inline int l2_classify1(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int steps, int s, uint32_t h) {
-  int lo = T[h >> L2_TSHIFT];
+__device__ inline int l2_classify1(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int tshift, int steps, int s, uint32_t h) {
+  int lo = T[h >> tshift];
   if (steps <= 4) {
     if (steps > 3) lo += Q[lo + 7] < h ? 8 : 0;
     if (steps > 2) lo += Q[lo + 3] < h ? 4 : 0;
     if (steps > 1) lo += Q[lo + 1] < h ? 2 : 0;
     if (steps > 0) lo += Q[lo] < h ? 1 : 0;
   } else {
-    int hi = T[(h >> L2_TSHIFT) + 1];
+    int hi = T[(h >> tshift) + 1];
     for (int it = 0; it < steps; ++it) {
       const int m = min((lo + hi) >> 1, s - 1);
       const uint32_t v = Q[m];
@@ -234,11 +236,11 @@ __host__ __device__ inline size_t l2_wave_bytes(int smax, bool skip, int nwq) {
   return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t l2_qpart_bytes(int smax) { return ((size_t)(smax + L2_QPAD) * 4 + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t l2_tpart_bytes() { return ((size_t)L2_TSIZE * 2 + 4 + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t l2_tpart_bytes(int nwq) { return ((size_t)l2_tsize(nwq) * 2 + 4 + 15) & ~(size_t)15; }
 // sketch | search table | strand bits of the sketch (two 64-bit words per 64 ranks: strand, unresolved duplicate)
-__host__ __device__ inline size_t l2_q_bytes(int smax) { return l2_qpart_bytes(smax) + l2_tpart_bytes() + (size_t)((smax + 63) / 64) * 16; }
+__host__ __device__ inline size_t l2_q_bytes(int smax, int nwq) { return l2_qpart_bytes(smax) + l2_tpart_bytes(nwq) + (size_t)((smax + 63) / 64) * 16; }
 template <typename DT>
-inline size_t l2_lds_bytes(int smax, bool skip, int waves, int nwq) { return l2_q_bytes(smax) + (size_t)waves * l2_wave_bytes<DT>(smax, skip, nwq); }
+inline size_t l2_lds_bytes(int smax, bool skip, int waves, int nwq) { return l2_q_bytes(smax, nwq) + (size_t)waves * l2_wave_bytes<DT>(smax, skip, nwq); }
 
 // visibility of a wave's own LDS writes to its other lanes (workgroups may hold several independent waves)
 __device__ inline void wave_sync() {
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   extern __shared__ __align__(16) uint32_t lds[];
   uint32_t* Q = lds;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint8_t* wbase = (uint8_t*)lds + l2_q_bytes(smax) + (size_t)wave * l2_wave_bytes<DT>(smax, SKIP, NWQ);
+  uint8_t* wbase = (uint8_t*)lds + l2_q_bytes(smax, NWQ) + (size_t)wave * l2_wave_bytes<DT>(smax, SKIP, NWQ);
   DT* D = (DT*)wbase;                                            // (full slide only; the skip kernels keep a histogram here)
   uint32_t* mt = (uint32_t*)(wbase + (((size_t)smax * sizeof(DT) + 3) & ~(size_t)3));
   const int64_t c0 = WAVES > 1 ? (int64_t)grp_cand0[blockIdx.x] : (cand_list ? (int64_t)cand_list[blockIdx.x] : (int64_t)blockIdx.x);
@@ -276,7 +278,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   const uint64_t qo = mz_off[r];
   const int len = read_len[r];
   uint16_t* T = (uint16_t*)((uint8_t*)lds + l2_qpart_bytes(smax));
-  int* tmaxp = (int*)(T + ((L2_TSIZE + 1) & ~1));
+  constexpr int TBITS = l2_tbits(NWQ), tshift = 32 - TBITS;
+  int* tmaxp = (int*)(T + ((l2_tsize(NWQ) + 1) & ~1));
   const int dbg_early = (int)counters[11] & 0xff;
   auto early_out = [&]() { if (!(WAVES > 1 && wave >= grp_n[blockIdx.x]) && lane == 0) { L2Result z{}; out[c0 + (WAVES > 1 ? wave : 0)] = z; } };
   if (dbg_early == 6) { early_out(); return; }
@@ -284,7 +287,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   if (dbg_early == 7) { __syncthreads(); early_out(); return; }
   // strand byte of every sketch entry (bit 0 strand, bit 1 unresolved duplicate: mm_map.hip, K2) as two bit sets: the vote
   // looks them up per matched entry, and a global load there is a second dependent memory latency in every step
-  uint64_t* const SB = (uint64_t*)((uint8_t*)lds + l2_qpart_bytes(smax) + l2_tpart_bytes());
+  uint64_t* const SB = (uint64_t*)((uint8_t*)lds + l2_qpart_bytes(smax) + l2_tpart_bytes(NWQ));
   for (int i0 = 64 * wave; i0 < s; i0 += 64 * WAVES) {
     const uint8_t sbyte = i0 + lane < s ? sk_strand[qo + i0 + lane] : (uint8_t)0;
     const uint64_t b0 = __ballot(sbyte & 1), b1 = __ballot(sbyte & 2);
@@ -293,17 +296,17 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   if (threadIdx.x < L2_QPAD) Q[s + threadIdx.x] = 0xffffffffu;
   if (threadIdx.x == 0) *tmaxp = 0;
   __syncthreads();
-  // T[b] = first rank whose hash >= b << L2_TSHIFT: element i is the answer for the buckets after Q[i-1]'s up to its own
+  // T[b] = first rank whose hash >= b << tshift: element i is the answer for the buckets after Q[i-1]'s up to its own
   // (i == s closes the table), so every T entry is written exactly once, without searching
   for (int i = threadIdx.x; i <= s; i += 64 * WAVES) {
-    const int lo = i ? (int)(Q[i - 1] >> L2_TSHIFT) + 1 : 0;
-    const int hi = i < s ? (int)(Q[i] >> L2_TSHIFT) : (1 << L2_TBITS);
+    const int lo = i ? (int)(Q[i - 1] >> tshift) + 1 : 0;
+    const int hi = i < s ? (int)(Q[i] >> tshift) : (1 << TBITS);
     for (int bb = lo; bb <= hi; ++bb) T[bb] = (uint16_t)i;
   }
   __syncthreads();
   {                                                              // longest bucket: wave maximum first, one LDS atomic per wave
     int tm = 0;
-    for (int bkt = threadIdx.x; bkt < (1 << L2_TBITS); bkt += 64 * WAVES) tm = max(tm, (int)T[bkt + 1] - (int)T[bkt]);
+    for (int bkt = threadIdx.x; bkt < (1 << TBITS); bkt += 64 * WAVES) tm = max(tm, (int)T[bkt + 1] - (int)T[bkt]);
     tm = wave_max(tm);
     if ((threadIdx.x & 63) == 0) atomicMax(tmaxp, tm);
   }
@@ -391,9 +394,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   // ---- register-resident chunks of 64 consecutive entries at both window ends -------------------------
   int baseB = first, baseE = first;
   Rec rb = pos[min(baseB + lane, nmax)], rE = rb;
-  int codeB = l2_classify1(Q, T, tsteps, s, rb.hash), codeE = codeB;
-  auto loadB = [&](int nb) { baseB = nb; rb = pos[min(nb + lane, nmax)]; codeB = l2_classify1(Q, T, tsteps, s, rb.hash); };
-  auto loadE = [&](int ne) { baseE = ne; rE = pos[min(ne + lane, nmax)]; codeE = l2_classify1(Q, T, tsteps, s, rE.hash); };
+  int codeB = l2_classify1(Q, T, tshift, tsteps, s, rb.hash), codeE = codeB;
+  auto loadB = [&](int nb) { baseB = nb; rb = pos[min(nb + lane, nmax)]; codeB = l2_classify1(Q, T, tshift, tsteps, s, rb.hash); };
+  auto loadE = [&](int ne) { baseE = ne; rE = pos[min(ne + lane, nmax)]; codeE = l2_classify1(Q, T, tshift, tsteps, s, rE.hash); };
 
   int b = first, e = first;
   int sw_pos = 0;
@@ -457,7 +460,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         uint32_t hh[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { hh[i] = x[i].hash; fl[i] = x[i].pw & 7u; }
-        l2_classify8(Q, T, tsteps, s, hh, cd);
+        l2_classify8(Q, T, tshift, tsteps, s, hh, cd);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -552,7 +555,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         uint32_t hh[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { hh[i] = x[i].hash; fl[i] = x[i].pw & 7u; }
-        l2_classify8(Q, T, tsteps, s, hh, cd);
+        l2_classify8(Q, T, tshift, tsteps, s, hh, cd);
       }
     };
     // an entry flagged DP counts only if no earlier occurrence of its hash lies inside the window
@@ -700,7 +703,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
       const int w64 = pw_wpos(pos[min(b + 64, nmax)].pw);
       int cB, cE;
       if (have_codes) { cB = cw_code(cw[min(b - first + lane, 64 * 64 * NWQ - 1)]); cE = cw_code(cw[min(e - first + lane, 64 * 64 * NWQ - 1)]); }
-      else { cB = l2_classify1(Q, T, tsteps, s, xb.hash); cE = l2_classify1(Q, T, tsteps, s, xe.hash); }
+      else { cB = l2_classify1(Q, T, tshift, tsteps, s, xb.hash); cE = l2_classify1(Q, T, tshift, tsteps, s, xe.hash); }
       const int wpb = pw_wpos(xb.pw);
       int nextw = __shfl_down(wpb, 1, 64);
       if (lane == 63) nextw = w64;
@@ -949,7 +952,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
           uint32_t hh[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) hh[i] = x[i].hash;
-          l2_classify8(Q, T, tsteps, s, hh, cd);
+          l2_classify8(Q, T, tshift, tsteps, s, hh, cd);
         }
         if (cw) {
           CW* __restrict__ pc = cw + (base - first) + lane;
@@ -1169,7 +1172,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         uint32_t hh[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { hh[i] = x[i].hash; fl[i] = x[i].pw & 7u; }
-        l2_classify8(Q, T, tsteps, s, hh, cd);
+        l2_classify8(Q, T, tshift, tsteps, s, hh, cd);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {

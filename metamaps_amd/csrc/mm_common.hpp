@@ -159,16 +159,30 @@ struct DBuf {
   size_t block = 0;            // bytes of the underlying block (0 = index-scale block: big_bytes)
   size_t big_bytes = 0; int big_dev = 0;
   DevAlloc* owner = nullptr;
+  // A block held jointly by several DBufs (share_from: the read-only minimizers and sketch hashes of a read batch, mapped against one
+  // chunk index after the other): the block lives in `shared`, p / n alias it, the last holder's release frees it.
+  std::shared_ptr<DBuf<T>> shared;
   DBuf() = default;
   explicit DBuf(size_t count) { alloc(count); }
   DBuf(const DBuf&) = delete;
   DBuf& operator=(const DBuf&) = delete;
-  DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), block(o.block), big_bytes(o.big_bytes), big_dev(o.big_dev), owner(o.owner) { o.p = nullptr; o.n = 0; }
+  DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), block(o.block), big_bytes(o.big_bytes), big_dev(o.big_dev), owner(o.owner), shared(std::move(o.shared)) { o.p = nullptr; o.n = 0; }
   DBuf& operator=(DBuf&& o) noexcept {
-    if (this != &o) { release(); p = o.p; n = o.n; block = o.block; big_bytes = o.big_bytes; big_dev = o.big_dev; owner = o.owner; o.p = nullptr; o.n = 0; }
+    if (this != &o) { release(); p = o.p; n = o.n; block = o.block; big_bytes = o.big_bytes; big_dev = o.big_dev; owner = o.owner; shared = std::move(o.shared); o.p = nullptr; o.n = 0; }
     return *this;
   }
   ~DBuf() { release(); }
+  void share_from(DBuf& src) {                                   // afterwards both hold the block; neither may write to it
+    if (this == &src) return;
+    release();
+    if (!src.p) return;
+    if (!src.shared) {
+      auto sp = std::make_shared<DBuf<T>>();
+      sp->p = src.p; sp->n = src.n; sp->block = src.block; sp->big_bytes = src.big_bytes; sp->big_dev = src.big_dev; sp->owner = src.owner;
+      src.shared = std::move(sp);
+    }
+    shared = src.shared; p = shared->p; n = shared->n; block = 0; owner = nullptr;
+  }
   void alloc(size_t count) {
     release();
     n = count;
@@ -196,6 +210,7 @@ struct DBuf {
     } else p = (T*)owner->get(bytes, &block);
   }
   void release() {
+    if (shared) { shared.reset(); p = nullptr; n = 0; block = 0; return; }
     if (p) {
       if (block && owner) owner->put(p, block);
       else if (owner && owner->eager) { (void)hipDeviceSynchronize(); (void)hipFree(p); }

@@ -57,23 +57,47 @@ __global__ void __launch_bounds__(256) select_range_kernel(const Rec* __restrict
     if (mask & (1u << i)) { Rec r = rec[base + i]; key[o] = r.hash; val[o] = ((uint64_t)rec_seq[base + i] << 32) | r.pw; ++o; }
 }
 
-__global__ void head_flags_kernel(const uint32_t* __restrict__ key, int64_t n, uint32_t* __restrict__ flag) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
+// CSR over the unique hashes of the hash-sorted keys without per-entry arrays: a "head" is an entry whose key differs from its predecessor's.
+// Heads are counted per tile of SCAN_TILE entries, the tile counts are scanned (mm_scan.hpp, a few MB), and the fill pass finds the heads of
+// its tile again and ranks them with a block scan.  (Rounds 1-2 wrote a flag word and a 64-bit rank per entry — 71 GB for the miniSeq+H
+// index, allocated in the middle of the build: the driver clears recycled memory when it hands it out, and those two allocations alone
+// cost 2-3 s of the build's 9, MM_ALLOC_TRACE.)  Thread t of a tile owns SCAN_ITEMS consecutive entries, so ranks follow the entry order.
+__global__ void __launch_bounds__(SCAN_THREADS) head_count_kernel(const uint32_t* __restrict__ key, int64_t n, uint32_t* __restrict__ tile_cnt) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t c = 0;
+  uint32_t prev = base > 0 && base <= n ? key[base - 1] : 0u;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    const int64_t j = base + i;
+    if (j < n) { const uint32_t kj = key[j]; c += (j == 0 || kj != prev) ? 1u : 0u; prev = kj; }
+  }
+  uint64_t tot;
+  block_excl_scan_u64(c, &tot);
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = (uint32_t)tot;
+}
+__global__ void __launch_bounds__(SCAN_THREADS) csr_fill_tiles_kernel(const uint32_t* __restrict__ key, int64_t n, const uint64_t* __restrict__ tile_off, int64_t ntiles,
+                                                                      uint32_t* __restrict__ uh, uint64_t* __restrict__ ustart) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t kk[SCAN_ITEMS]; bool head[SCAN_ITEMS];
+  uint32_t c = 0;
+  uint32_t prev = base > 0 && base <= n ? key[base - 1] : 0u;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    const int64_t j = base + i;
+    kk[i] = j < n ? key[j] : 0u;
+    head[i] = j < n && (j == 0 || kk[i] != prev);
+    c += head[i] ? 1u : 0u; prev = kk[i];
+  }
+  uint64_t u = block_excl_scan_u64(c, nullptr) + tile_off[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) if (head[i]) { uh[u] = kk[i]; ustart[u] = (uint64_t)(base + i); ++u; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) ustart[tile_off[ntiles]] = (uint64_t)n;   // tile_off[ntiles] = U (scan total)
 }
 
 // paranoia for > 2^32-element library sorts: number of adjacent inversions must be zero
 __global__ void count_inversions_kernel(const uint32_t* __restrict__ key, int64_t n, unsigned long long* __restrict__ bad) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n; i += (int64_t)gridDim.x * blockDim.x)
     if (key[i] > key[i + 1]) atomicAdd(bad, 1ull);
-}
-
-__global__ void csr_fill_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ rank,
-                                int64_t n, uint32_t* __restrict__ uh, uint64_t* __restrict__ ustart) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) {
-    if (i < n && flag[i]) { uint64_t u = rank[i]; uh[u] = key[i]; ustart[u] = (uint64_t)i; }
-    if (i == n) ustart[rank[n]] = (uint64_t)n;      // rank[n] = U (scan total)
-  }
 }
 
 // Occurrence lists are laid out on 64-byte sector boundaries: the seed-hit filter reads every list of every read twice and
@@ -220,7 +244,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   // proceeds (DevAlloc::eager), nothing is left cached beside it.
   struct EagerGuard { DevAlloc& a; bool was; ~EagerGuard() { a.eager = was; } } eager_guard{ctx->alloc, ctx->alloc.eager};
   { size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess && (double)contigs->total_bases * 5.5 > (double)tot / 4) { ctx->alloc.eager = true; ctx->alloc.trim(); big_pool_trim(ctx->device); } }
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && (double)contigs->total_bases * 5.5 > (double)tot / 4) { ctx->alloc.eager = true; if (!getenv("MM_INDEX_NO_PRETRIM")) { ctx->alloc.trim(); big_pool_trim(ctx->device); } } }
   I->ctx = ctx; I->k = k; I->w = w;
   I->n_contigs = contigs->count();
   I->contig_len = contigs->len;
@@ -252,11 +276,12 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   DBuf<uint32_t> key_in, key_out((size_t)N);
   DBuf<uint64_t> val_in;
   I->occ.alloc((size_t)N + 2);                                  // +2: the seed-hit filter reads lists in aligned 16-byte pieces
-  auto library_sort = [&](uint32_t* kin, uint64_t* vin, uint32_t* kout, uint64_t* vout, size_t cnt) {
+  DBuf<uint8_t> sort_tmp;                                        // the library's double buffers (12 B per element), kept across the partitions: every
+  auto library_sort = [&](uint32_t* kin, uint64_t* vin, uint32_t* kout, uint64_t* vout, size_t cnt) {   // fresh 18 GB block is recycled memory the driver clears first
     size_t tmp_bytes = 0;
     MM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, cnt, 0, 32, st));
-    DBuf<uint8_t> tmp(tmp_bytes);
-    MM_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kin, kout, vin, vout, cnt, 0, 32, st));
+    if (sort_tmp.bytes() < tmp_bytes) sort_tmp.alloc(tmp_bytes);
+    MM_HIP(rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, kin, kout, vin, vout, cnt, 0, 32, st));
     MM_HIP(hipStreamSynchronize(st));
   };
   const char* pm_env = getenv("MM_INDEX_PART_MAX");              // tests force the partitioned path on small inputs
@@ -288,6 +313,9 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
     DBuf<uint64_t> toff((size_t)ntile + 1), scan_tmp2;
     int64_t maxp = 0; for (auto c : part_cnt) maxp = std::max(maxp, c);
     key_in.alloc((size_t)maxp); val_in.alloc((size_t)maxp);
+    { size_t tb = 0;                                             // (sized for the largest partition once)
+      MM_HIP(rocprim::radix_sort_pairs(nullptr, tb, key_in.p, key_out.p, val_in.p, I->occ.p, (size_t)maxp, 0, 32, st));
+      sort_tmp.alloc(tb + (tb >> 6)); }
     int64_t done = 0;
     for (size_t p = 0; p < parts.size(); ++p) {
       if (part_cnt[p] == 0) continue;
@@ -309,21 +337,22 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
     auto hb = bad.to_host(st);
     MM_REQUIRE(hb[0] == 0, MM_ERR_DEVICE, "radix sort of the index left the hash keys unsorted");
   }
-  key_in.release(); val_in.release();
+  key_in.release(); val_in.release(); sort_tmp.release();
   // CSR over unique hashes
-  DBuf<uint32_t> flag((size_t)N);
-  DBuf<uint64_t> rank((size_t)N + 1), scan_tmp;
-  head_flags_kernel<<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, N, flag.p);
+  const int64_t ntiles_csr = ceil_div(N, SCAN_TILE);
+  DBuf<uint32_t> tile_heads((size_t)ntiles_csr);
+  DBuf<uint64_t> tile_rank((size_t)ntiles_csr + 1), scan_tmp;
+  head_count_kernel<<<dim3((unsigned)ntiles_csr), dim3(SCAN_THREADS), 0, st>>>(key_out.p, N, tile_heads.p);
   MM_KERNEL_CHECK();
-  exclusive_scan_u32_u64(flag.p, N, rank.p, scan_tmp, st);
+  exclusive_scan_u32_u64(tile_heads.p, ntiles_csr, tile_rank.p, scan_tmp, st);
   uint64_t U = 0;
-  MM_HIP(hipMemcpyAsync(&U, rank.p + N, sizeof U, hipMemcpyDeviceToHost, st));
+  MM_HIP(hipMemcpyAsync(&U, tile_rank.p + ntiles_csr, sizeof U, hipMemcpyDeviceToHost, st));
   MM_HIP(hipStreamSynchronize(st));
   I->U = (int64_t)U;
   I->uh.alloc((size_t)U); I->ustart.alloc((size_t)U + 1);
-  csr_fill_kernel<<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, flag.p, rank.p, N, I->uh.p, I->ustart.p);
+  csr_fill_tiles_kernel<<<dim3((unsigned)ntiles_csr), dim3(SCAN_THREADS), 0, st>>>(key_out.p, N, tile_rank.p, ntiles_csr, I->uh.p, I->ustart.p);
   MM_KERNEL_CHECK();
-  flag.release(); rank.release();
+  tile_heads.release(); tile_rank.release();
   // duplicate flags into pos[]
   DBuf<unsigned long long> ndup(1); ndup.zero(st);
   dup_pairs_kernel<false><<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, I->occ.p, N, I->cstart.p, I->dir.p, I->dir_off.p, I->dir_shift, I->pos.p, ndup.p,

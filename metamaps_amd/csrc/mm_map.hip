@@ -1316,7 +1316,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   const size_t t_total = T.begin(&M->stats.ms_total);
   // The minimizers and the sketch of a read do not depend on the index: when the same batch is mapped against one index chunk after
   // the other (--maxmemory; the reference runs the whole of mapSingleQuerySeq per chunk, computeMap.hpp:277-298 included), the second
-  // and later mappings copy them from the first (mm_map_batch_reusing).  Strands the donor's tie-break has resolved meanwhile are the
+  // and later mappings take them from the first (mm_map_batch_reusing: the two large arrays held jointly, the rest copied).  Strands the donor's tie-break has resolved meanwhile are the
   // strands this mapping would resolve them to (the same library calls on the same records).
   const mm_mapping* const donor = M->sketch_donor;
   // ---- K1

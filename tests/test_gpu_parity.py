@@ -799,7 +799,7 @@ def test_streaming_seed_filter_equals_one_read_per_workgroup(ctx, dense, monkeyp
 
 
 def test_map_batch_reusing_sketches_equals_map_batch(ctx, oracle_lib, mini, monkeypatch):
-    """mm_map_batch_reusing (minimizers + sketches copied from an earlier mapping of the same reads — the second and later index chunks
+    """mm_map_batch_reusing (minimizers + sketches taken from an earlier mapping of the same reads — the second and later index chunks
     of --maxmemory) gives the records, candidates and sketches of mm_map_batch, in all three strand tie-break modes; a donor of other
     reads or other parameters is refused"""
     from metamaps_amd import capi

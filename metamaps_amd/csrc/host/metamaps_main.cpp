@@ -262,36 +262,112 @@ int map_mode(const Options& o, const std::string& mode) {
     // The reference streams contig by contig (winSketch.hpp:242-252): a parser thread fills groups of ~1 Gbase, the main thread packs
     // and uploads each group to every device while the next one is parsed, and drops the text.  Host memory: two groups.
     {
-      struct Group { std::deque<std::string> seq; uint64_t bases = 0; };
-      std::mutex gm; std::condition_variable gcv; std::deque<std::unique_ptr<Group>> ready; bool parsed = false;
+      struct Group { std::deque<std::string> seq; std::vector<std::string> names; uint64_t bases = 0; };
       const uint64_t GROUP_BASES = getenv("MM_CLI_REF_GROUP_BASES") ? std::stoull(getenv("MM_CLI_REF_GROUP_BASES")) : (uint64_t)1 << 30;   // (test hook: small groups)
-      std::thread parser([&]() {
-        SeqFile f(ref);
-        auto g = std::make_unique<Group>();
-        auto hand_over = [&]() { std::unique_lock<std::mutex> lk(gm); gcv.wait(lk, [&] { return ready.size() < 2; }); ready.push_back(std::move(g)); gcv.notify_all(); g = std::make_unique<Group>(); };
-        while (f.next()) {
-          cname.push_back(f.name); clen.push_back((int)f.seq.size()); ref_bases += f.seq.size();
-          g->bases += f.seq.size(); g->seq.push_back(std::move(f.seq)); f.seq.clear();
-          if (g->bases >= GROUP_BASES) hand_over();
-        }
-        if (!g->seq.empty()) hand_over();
-        std::lock_guard<std::mutex> lk(gm); parsed = true; gcv.notify_all();
-      });
       std::vector<std::vector<mm_seqset*>> parts(only_index ? 1 : G);
       double t_pack = 0;
-      for (;;) {
-        std::unique_ptr<Group> g;
-        { std::unique_lock<std::mutex> lk(gm); gcv.wait(lk, [&] { return !ready.empty() || parsed; }); if (ready.empty()) break; g = std::move(ready.front()); ready.pop_front(); gcv.notify_all(); }
+      auto consume = [&](Group& g) {                               // names and lengths in file order, then pack + upload to every device
+        for (size_t i = 0; i < g.seq.size(); ++i) { cname.push_back(std::move(g.names[i])); clen.push_back((int)g.seq[i].size()); ref_bases += g.seq[i].size(); }
         const auto t0 = std::chrono::steady_clock::now();
         on_each(parts.size(), [&](size_t d) {
           mm_seqset* p; ck(devs[d].ctx, mm_seqset_create(devs[d].ctx, &p), "seqset");
-          for (auto& q : g->seq) ck(devs[d].ctx, mm_seqset_add_view(p, q.data(), (int64_t)q.size()), "add contig");
+          for (auto& q : g.seq) ck(devs[d].ctx, mm_seqset_add_view(p, q.data(), (int64_t)q.size()), "add contig");
           ck(devs[d].ctx, mm_seqset_upload(p), "upload reference");
           parts[d].push_back(p);
         });
         t_pack += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      };
+      // records of `f` (all, or those that start before `stop` in memory mode) in groups of GROUP_BASES handed to `emit`; false when the
+      // reader gave up before `stop` (a truncated quality string ends the file for kseq, kseq.h:204)
+      auto parse_groups = [&](SeqFile& f, size_t stop, const std::function<void(std::unique_ptr<Group>)>& emit) -> bool {
+        auto g = std::make_unique<Group>();
+        bool ok = true;
+        for (;;) {
+          if (stop != (size_t)-1) { const size_t ps = f.peek_start(); if (ps == (size_t)-1 || ps >= stop) break; }
+          if (!f.next()) { ok = stop == (size_t)-1; break; }
+          g->names.push_back(f.name);
+          if (f.view) g->seq.emplace_back(f.view, f.view_len); else { g->seq.push_back(std::move(f.seq)); f.seq.clear(); }
+          g->bases += g->seq.back().size();
+          if (g->bases >= GROUP_BASES) { emit(std::move(g)); g = std::make_unique<Group>(); }
+        }
+        if (!g->seq.empty()) emit(std::move(g));
+        return ok;
+      };
+      MappedFile rmf;
+      if (!getenv("MM_CLI_NO_MMAP") && !getenv("MM_CLI_REF_SEQUENTIAL") && rmf.open(ref)) {
+        // A plain file: blocks of the mapping parsed by several threads (the block parser of the query files below: a block's records
+        // count only once the block before it has been seen to end exactly where this one starts), consumed — packed, uploaded — in file
+        // order.  The winSketch.hpp:242-252 loop reads contig by contig; here the text of at most P + 2 blocks of 256 MB is resident, and the
+        // mapped pages of a block are given back once it is consumed (they would count as resident until the end otherwise: 27 GB).
+        const size_t blk = getenv("MM_CLI_REF_BLOCK_BYTES") ? (size_t)std::max(1, atoi(getenv("MM_CLI_REF_BLOCK_BYTES"))) : (size_t)std::min<uint64_t>(GROUP_BASES, (uint64_t)256 << 20);
+        const size_t nb = std::max<size_t>(1, (rmf.size + blk - 1) / blk);
+        std::vector<size_t> start(nb + 1, rmf.size);
+        start[0] = 0;
+        struct Block { std::vector<std::unique_ptr<Group>> out; size_t next = 0; bool done = false, empty = false, over = false; };
+        std::vector<Block> blocks(nb);
+        std::mutex bm; std::condition_variable bcv; size_t next_block = 0, consumed = 0; bool abandon = false;
+        const unsigned P = (unsigned)std::max<size_t>(1, std::min<size_t>({nb, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4)}));
+        auto worker = [&]() {
+          for (;;) {
+            size_t j;
+            {
+              std::unique_lock<std::mutex> lk(bm);
+              bcv.wait(lk, [&] { return abandon || next_block >= nb || next_block < consumed + P + 1; });   // not too far ahead of the consumer
+              if (abandon || next_block >= nb) return;
+              j = next_block++;
+            }
+            if (j > 0) start[j] = rmf.sync(j * blk, std::min(rmf.size, (j + 1) * blk));
+            Block& B = blocks[j];
+            const size_t lim = std::min(rmf.size, (j + 1) * blk);
+            if (j == 0 || start[j] < lim) {
+              SeqFile f(rmf.data, j == 0 ? 0 : start[j], rmf.size);
+              B.over = !parse_groups(f, lim, [&](std::unique_ptr<Group> g) { B.out.push_back(std::move(g)); });
+              B.next = f.peek_start();
+            } else B.empty = true;
+            { std::lock_guard<std::mutex> lk(bm); B.done = true; }
+            bcv.notify_all();
+          }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < P; ++t) pool.emplace_back(worker);
+        size_t expect = 0; bool chain_ok = true, file_over = false;
+        for (size_t j = 0; j < nb && chain_ok && !file_over; ++j) {
+          { std::unique_lock<std::mutex> lk(bm); bcv.wait(lk, [&] { return blocks[j].done; }); }
+          Block& B = blocks[j];
+          if (!B.empty) {
+            if (j > 0 && start[j] != expect) { chain_ok = false; break; }
+            for (auto& g : B.out) consume(*g);
+            B.out.clear();
+            if (B.over || B.next == (size_t)-1) { file_over = true; break; }
+            expect = B.next;
+          } else if (expect < std::min(rmf.size, (j + 1) * blk)) { chain_ok = false; break; }
+          { std::lock_guard<std::mutex> lk(bm); consumed = j + 1; } bcv.notify_all();
+          if (j > 0) rmf.drop(((j - 1) * blk) & ~(size_t)4095, (j * blk) & ~(size_t)4095);   // (block j - 1: its last record may end inside block j, parsed by now)
+        }
+        { std::lock_guard<std::mutex> lk(bm); abandon = true; } bcv.notify_all();
+        for (auto& t : pool) t.join();
+        if (!chain_ok) {                                           // a block did not start where the parse stood: the rest sequentially, from there
+          for (auto& B : blocks) B.out.clear();
+          SeqFile f(rmf.data, expect, rmf.size);
+          parse_groups(f, (size_t)-1, [&](std::unique_ptr<Group> g) { consume(*g); });
+        }
+      } else {
+        // gzip, pipes: a parser thread fills groups, the main thread packs and uploads each while the next one is parsed.  Host memory: two groups.
+        std::mutex gm; std::condition_variable gcv; std::deque<std::unique_ptr<Group>> ready; bool parsed = false;
+        std::thread parser([&]() {
+          SeqFile f(ref);
+          parse_groups(f, (size_t)-1, [&](std::unique_ptr<Group> g) {
+            std::unique_lock<std::mutex> lk(gm); gcv.wait(lk, [&] { return ready.size() < 2; }); ready.push_back(std::move(g)); gcv.notify_all();
+          });
+          std::lock_guard<std::mutex> lk(gm); parsed = true; gcv.notify_all();
+        });
+        for (;;) {
+          std::unique_ptr<Group> g;
+          { std::unique_lock<std::mutex> lk(gm); gcv.wait(lk, [&] { return !ready.empty() || parsed; }); if (ready.empty()) break; g = std::move(ready.front()); ready.pop_front(); gcv.notify_all(); }
+          consume(*g);
+        }
+        parser.join();
       }
-      parser.join();
       on_each(parts.size(), [&](size_t d) {
         if (parts[d].size() == 1) { refset[d] = parts[d][0]; return; }
         if (parts[d].empty()) { ck(devs[d].ctx, mm_seqset_create(devs[d].ctx, &refset[d]), "seqset"); ck(devs[d].ctx, mm_seqset_upload(refset[d]), "upload reference"); return; }

@@ -147,6 +147,8 @@ struct MappedFile {
     return true;
   }
   ~MappedFile() { if (data) munmap((void*)data, size); }
+  // the pages of [a, b) (page aligned) are not needed again: they stop counting as resident
+  void drop(size_t a, size_t b) const { if (data && b > a && b <= size) madvise((void*)(data + a), b - a, MADV_DONTNEED); }
   // first offset >= x that is certainly a record start, or `limit` if none is found before it: a FASTA header ('>' at the start of
   // a line; any '>' ends a sequence for kseq), or a FASTQ record whose four lines and whose successor's first line check out
   size_t sync(size_t x, size_t limit) const {

@@ -70,6 +70,7 @@ void mm_ctx_destroy(mm_ctx* ctx) {
   mm::big_pool_trim(ctx->device);                                  // (recycled index-scale blocks go back to the driver with any context of the device)
   mm::comm_destroy(ctx);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->pinned_up) (void)hipHostFree(ctx->pinned_up);
   if (ctx->l2_codes) (void)hipFree(ctx->l2_codes);
   if (ctx->l2_masks) (void)hipFree(ctx->l2_masks);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -351,6 +351,18 @@ struct mm_ctx {
   }
   // pinned bounce buffer for result downloads into caller-owned (pageable) memory
   void* pinned = nullptr; size_t pinned_bytes = 0;
+  // pinned staging buffer of sequence uploads (mm_seq.hip: the 2-bit words are packed straight into it)
+  void* pinned_up = nullptr; size_t pinned_up_bytes = 0;
+  void* pinned_up_at_least(size_t bytes) {
+    if (bytes > pinned_up_bytes) {
+      if (pinned_up) { MM_HIP(hipStreamSynchronize(stream)); (void)hipHostFree(pinned_up); }
+      pinned_up = nullptr; pinned_up_bytes = 0;
+      const size_t want = bytes + bytes / 8;
+      MM_HIP(hipHostMalloc(&pinned_up, want, hipHostMallocDefault));
+      pinned_up_bytes = want;
+    }
+    return pinned_up;
+  }
   void* pinned_at_least(size_t bytes) {
     if (bytes > pinned_bytes) {
       if (pinned) (void)hipHostFree(pinned);

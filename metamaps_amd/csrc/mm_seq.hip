@@ -2,6 +2,7 @@
 #include "mm_minimizer.hpp"
 #include <algorithm>
 #include <thread>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 
@@ -111,30 +112,38 @@ void seqset_upload(mm_seqset* s) {
     s->total_bases += s->len[i];
   }
   const size_t nwords = (size_t)(s->base[n] >> 4);
-  std::vector<uint32_t> words(nwords + 1, 0);
+  // the packed words are written straight into the context's pinned upload buffer (kept across calls: a fresh 256 MB vector per Gbase group
+  // cost more in page faults and zero-filling than the packing itself, and pageable memory uploads at a fraction of the pinned rate)
+  uint32_t* const words = (uint32_t*)s->ctx->pinned_up_at_least((nwords + 1) * sizeof(uint32_t));
+  words[nwords] = 0;
   std::vector<uint64_t> es; std::vector<uint32_t> el; std::vector<uint8_t> eb;
   {
     // 16 bases per step through a byte table (code, or 0x80 for anything but ACGT after upper-casing, commonFunc.hpp:57-66);
-    // only words with such a base take the per-base path.  Sequences start on word boundaries, so threads own disjoint
-    // word ranges; their exception runs are concatenated in sequence order afterwards.
+    // only words with such a base take the per-base path.  Work items are pieces of at most 4 Mbases of one sequence (sequences start on
+    // word boundaries and pieces on multiples of 16 bases, so items own disjoint words); the exception runs of the items are concatenated in
+    // order, a run that crosses a piece boundary inside a sequence is joined again.
     static const struct Lut { uint8_t t[256]; Lut() { for (int c = 0; c < 256; ++c) { int u = (c > 96 && c < 123) ? c - 32 : c; int k = code_of((uint8_t)u); t[c] = k >= 0 ? (uint8_t)k : 0x80; } } } lut;
+    struct Item { size_t seq; size_t j0, j1; };
     struct Runs { std::vector<uint64_t> es; std::vector<uint32_t> el; std::vector<uint8_t> eb; };
+    constexpr size_t PIECE = (size_t)4 << 20;
+    std::vector<Item> items;
+    for (size_t i = 0; i < n; ++i) { const size_t L = s->staged[i].second; for (size_t j0 = 0; j0 < L; j0 += PIECE) items.push_back(Item{i, j0, std::min(L, j0 + PIECE)}); }
+    std::vector<Runs> runs(items.size());
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t nthr = (size_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)hw, 16, (uint64_t)(s->total_bases >> 22) + 1, (uint64_t)std::max<size_t>(n, 1)}));
-    std::vector<Runs> runs(nthr);
-    std::vector<size_t> cut(nthr + 1, n);                         // sequence ranges of about equal bases
-    cut[0] = 0;
-    { size_t t = 1; for (size_t i = 0; i < n && t < nthr; ++i) if (s->base[i] >= s->base[n] / nthr * t) cut[t++] = i; }
-    auto work = [&](size_t t) {
-      Runs& R = runs[t];
-      for (size_t i = cut[t]; i < cut[t + 1]; ++i) {
-        const uint8_t* p = (const uint8_t*)s->staged[i].first;
-        const size_t L = s->staged[i].second;
-        uint32_t* wp = words.data() + (s->base[i] >> 4);
-        const uint64_t b0 = s->base[i];
+    const size_t nthr = (size_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)std::max(1u, hw / 2), 32, (uint64_t)(s->total_bases >> 22) + 1, (uint64_t)std::max<size_t>(items.size(), 1)}));
+    std::atomic<size_t> next_item{0};
+    auto work = [&]() {
+      for (;;) {
+        const size_t it = next_item.fetch_add(1);
+        if (it >= items.size()) return;
+        const Item I = items[it];
+        Runs& R = runs[it];
+        const uint8_t* p = (const uint8_t*)s->staged[I.seq].first;
+        uint32_t* wp = words + (s->base[I.seq] >> 4);
+        const uint64_t b0 = s->base[I.seq];
         bool open = false;
-        for (size_t j0 = 0; j0 < L; j0 += 16) {
-          const size_t m = std::min<size_t>(16, L - j0);
+        for (size_t j0 = I.j0; j0 < I.j1; j0 += 16) {
+          const size_t m = std::min<size_t>(16, I.j1 - j0);
           uint32_t wv = 0; uint8_t bad = 0;
           for (size_t j = 0; j < m; ++j) { const uint8_t k = lut.t[p[j0 + j]]; bad |= k; wv |= (uint32_t)(k & 3) << (2 * j); }
           if (!(bad & 0x80)) { wp[j0 >> 4] = wv; open = false; continue; }
@@ -152,13 +161,20 @@ void seqset_upload(mm_seqset* s) {
       }
     };
     std::vector<std::thread> pool;
-    for (size_t t = 1; t < nthr; ++t) pool.emplace_back(work, t);
-    work(0);
+    for (size_t t = 1; t < nthr; ++t) pool.emplace_back(work);
+    work();
     for (auto& th : pool) th.join();
-    for (auto& R : runs) { es.insert(es.end(), R.es.begin(), R.es.end()); el.insert(el.end(), R.el.begin(), R.el.end()); eb.insert(eb.end(), R.eb.begin(), R.eb.end()); }
+    for (size_t it = 0; it < items.size(); ++it) {
+      Runs& R = runs[it];
+      size_t from = 0;
+      // (the sequential loop continues a run across what is a piece boundary here: same sequence, next base, same byte)
+      if (it > 0 && items[it].seq == items[it - 1].seq && !R.es.empty() && !es.empty() && es.back() + el.back() == R.es[0] && eb.back() == R.eb[0] &&
+          R.es[0] == s->base[items[it].seq] + items[it].j0 && (uint64_t)el.back() + R.el[0] <= 0xFFFFFFFFull) { el.back() += R.el[0]; from = 1; }
+      es.insert(es.end(), R.es.begin() + (long)from, R.es.end()); el.insert(el.end(), R.el.begin() + (long)from, R.el.end()); eb.insert(eb.end(), R.eb.begin() + (long)from, R.eb.end());
+    }
   }
-  s->packed.alloc(words.size());
-  s->packed.upload(words.data(), words.size(), st);
+  s->packed.alloc(nwords + 1);
+  s->packed.upload(words, nwords + 1, st);
   s->d_base.alloc(n + 1); s->d_base.upload(s->base.data(), n + 1, st);
   s->d_len.alloc(std::max<size_t>(n, 1)); s->d_len.upload(s->len.data(), n, st);
   s->n_exc = (int64_t)es.size();

@@ -523,3 +523,57 @@ def test_cli_reference_streamed_in_groups(oracle_lib, tmp_path, monkeypatch, ext
     monkeypatch.setenv("MM_CLI_REF_GROUP_BASES", "100000")
     pa, g, c = _run_pair(tmp_path, [x for x in extra if x != "--stream-chunks"], gpu_only=[x for x in extra if x == "--stream-chunks"])
     assert g == c and (g >= 2 or len(extra) == 1)
+
+
+@pytest.mark.parametrize("layout", ["wrapped", "hostile"])
+def test_cli_reference_parsed_in_parallel_blocks(oracle_lib, tmp_path, monkeypatch, layout):
+    """The reference FASTA is memory mapped and parsed in blocks by several threads (the chain-checked block parser of the query files:
+    a block's records count once the block before it is seen to end exactly where this one starts), consumed in file order.  Same files as
+    the sequential reader (MM_CLI_REF_SEQUENTIAL=1) and as the oracle (whose reader follows kseq.h character by character), for blocks of
+    61 bytes, 5 kB and the default, on a reference rewritten with line widths from 1 to unwrapped, CRLF, blank lines, lower case,
+    header comments that contain '>', '+' and '@'; "hostile": no line break at the end of the file."""
+    import orc
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=8, genome_len=50_000, seed=11)
+    rd = synth.make_reads(db, str(tmp_path / "reads.fq"), n_reads=150, read_len=3000, seed=5)
+    recs, name, seq = [], None, []
+    for line in open(db.fasta, "rb"):
+        if line.startswith(b">"):
+            if name is not None: recs.append((name, b"".join(seq)))
+            name, seq = line[1:].split()[0], []
+        else:
+            seq.append(line.strip())
+    recs.append((name, b"".join(seq)))
+    rng = np.random.default_rng(17)
+    out = bytearray(b"\n\n")                                    # kseq skips everything before the first header character
+    for i, (nm, sq) in enumerate(recs):
+        width = [1, 7, 60, 61, 80, 1000, len(sq) + 1][i % 7]
+        eol = b"\r\n" if i % 3 == 1 else b"\n"
+        comment = [b"", b" plain comment", b" odd >comment +with @signs", b"\tTAB > + @"][i % 4]
+        body = sq.lower() if i % 5 == 2 else sq
+        out += b">" + nm + comment + eol
+        for o in range(0, len(body), width):
+            out += body[o:o + width] + eol
+            if i % 4 == 3 and o == 0: out += eol                 # a blank line inside a record
+    ref_path = str(tmp_path / "DB_rewritten.fa")
+    if layout == "hostile":
+        out = out.rstrip(b"\r\n")                                # no newline at the end of the file
+    open(ref_path, "wb").write(bytes(out))
+    import shutil
+    for fn in os.listdir(os.path.dirname(db.fasta)):             # taxonomy files next to the reference
+        if fn != os.path.basename(db.fasta) and os.path.isfile(os.path.join(os.path.dirname(db.fasta), fn)):
+            shutil.copy(os.path.join(os.path.dirname(db.fasta), fn), str(tmp_path / fn))
+    runs = {}
+    for tag, env in (("seq", {"MM_CLI_REF_SEQUENTIAL": "1"}), ("b61", {"MM_CLI_REF_BLOCK_BYTES": "61"}), ("b5k", {"MM_CLI_REF_BLOCK_BYTES": "5000"}), ("default", {})):
+        e = dict(os.environ); e.update(env)
+        pre = str(tmp_path / ("gpu_" + tag))
+        p = subprocess.run([CLI, "mapDirectly", "--all", "-r", ref_path, "-q", rd["path"], "-o", pre], capture_output=True, timeout=900, env=e)
+        assert p.returncode == 0, (tag, p.stderr.decode()[-800:])
+        runs[tag] = {suf: open(pre + suf, "rb").read() for suf in ("", ".meta", ".meta.unmappedReadsLengths")}
+    for tag in ("b61", "b5k", "default"):
+        assert runs[tag] == runs["seq"], tag
+    assert len(runs["seq"][""]) > 10_000
+    pb = str(tmp_path / "cpu")
+    subprocess.run([orc.CLI, "mapDirectly", "--all", "-r", ref_path, "-q", rd["path"], "-o", pb], check=True, capture_output=True, timeout=900)
+    _cmp_table(str(tmp_path / "gpu_default"), pb, " ", {13})
+    assert open(str(tmp_path / "gpu_default") + ".meta").read() == open(pb + ".meta").read()

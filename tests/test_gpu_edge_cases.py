@@ -229,3 +229,29 @@ def test_release_cached_returns_memory_to_the_driver(ctx):
     idx = ctx.index(ref, 16, 8)                                  # and the context works as before
     assert idx.info()["n_entries"] > 1_000_000
     idx.close(); ref.close()
+
+
+def test_long_sequences_are_packed_in_pieces(ctx, tmp_path):
+    """mm_seqset_upload packs a sequence in pieces of 4 Mbases on several threads; a run of non-ACGT characters that crosses a piece boundary
+    is one exception run again (counted in the persistent form of the set, mm_seqset_save), and the sequence comes back as it went in"""
+    from metamaps_amd import capi
+    rng = np.random.default_rng(5)
+    P = 4 << 20
+    n = 2 * P + 12345
+    s = bytearray(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).tobytes())
+    s[P - 7:P + 9] = b"N" * 16                                   # across the first boundary
+    s[2 * P - 1:2 * P] = b"R"                                    # the last base of a piece ...
+    s[2 * P:2 * P + 1] = b"R"                                    # ... and the first of the next: one run of two
+    s[2 * P + 1:2 * P + 2] = b"Y"                                # another byte right behind: its own run
+    s[100:103] = b"nnn"
+    short = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 1000).tobytes())
+    S = ctx.seqset([short, bytes(s), short])
+    assert S.fetch(1, n) == bytes(s).upper() and S.fetch(0, 1000) == short and S.fetch(2, 1000) == short
+    S.save(str(tmp_path / "a.seqset"))
+    L = ctx.load_seqset(str(tmp_path / "a.seqset"))
+    assert L.fetch(1, n) == bytes(s).upper() and L.total_bases == S.total_bases
+    import struct
+    raw = open(str(tmp_path / "a.seqset"), "rb").read()
+    n_seq, total, n_words, n_exc = struct.unpack_from("<4q", raw, 16)
+    assert n_seq == 3 and n_exc == 4                             # nnn | 16 N | RR | Y — not 5 (a run split at the boundary) or 6
+    S.close(); L.close()

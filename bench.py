@@ -516,16 +516,19 @@ def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
         else:
             bs = [(s_i * args.batches_per_pass + j) % n_batches for j in range(args.batches_per_pass)]
             host = [[] for _ in bs]
+            sk = [c.sketch_batch(batches[b], k, w, pi=80.0, min_read_len=1000) for b in bs]   # K1 + K2 once per batch and pass, not once per chunk
             for ci, (a, n) in enumerate(bounds):
                 tb = time.perf_counter()
                 sl = ref.slice(a, n); ix = c.index(sl, k, w, auto_threshold=False); sl.close(); ix.set_freq_threshold(thrs[ci])
                 c.synchronize(); agg["ms_index"] += (time.perf_counter() - tb) * 1e3
                 for j, b in enumerate(bs):
-                    M = c.map_batch(ix, batches[b], k, w, pi=80.0, min_read_len=1000)
+                    M = c.map_batch(ix, batches[b], k, w, pi=80.0, min_read_len=1000, sketch_of=sk[j])
                     o, r = M.fetch(); host[j].append((o, r.copy()))
                     st = M.stats(); note(st); agg["st"] = st
                     M.close()
                 ix.close()
+            for m_ in sk:
+                m_.close()
             for j, b in enumerate(bs):
                 V = capi.Mapping.from_parts(c, lens[b], host[j], base, k, w)
                 V.add_qualities(k); V.fetch()

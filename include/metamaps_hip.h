@@ -229,6 +229,11 @@ int mm_map_batch_phased(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads
  * have not been released, instead of being computed again (the reference recomputes them per chunk, computeMap.hpp:277-298).
  * Results are those of mm_map_batch. */
 int mm_map_batch_reusing(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, const mm_mapping* sketch_of, mm_mapping** out);
+/* Minimizers and sketches of a read batch alone (K1 + K2, computeMap.hpp:277-298) — a `sketch_of` for mm_map_batch_reusing that is tied to
+ * no index: a run that maps one batch against many chunk indexes one after the other, each built and dropped in turn, computes them once
+ * and keeps nothing else of a chunk's mapping.  The object holds no records (the other mm_mapping_* calls see an empty mapping);
+ * mm_mapping_destroy frees it. */
+int mm_sketch_batch(mm_ctx* ctx, const mm_seqset* reads, const mm_map_params* p, mm_mapping** out);
 void mm_mapping_destroy(mm_mapping* m);
 int mm_mapping_get_stats(const mm_mapping* m, mm_map_stats* out);
 /* frees everything of a batch result but its records, offsets and read lengths (what fetch, keep_best, concat, add_qualities and

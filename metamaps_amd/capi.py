@@ -137,6 +137,7 @@ def lib() -> C.CDLL:
             "mm_map_batch": (C.c_int, [vp, vp, vp, P(MapParams), P(vp)]),
             "mm_map_batch_phased": (C.c_int, [vp, vp, vp, P(MapParams), SEED_STAGE_CB, vp, P(vp)]),
             "mm_map_batch_reusing": (C.c_int, [vp, vp, vp, P(MapParams), vp, P(vp)]),
+            "mm_sketch_batch": (C.c_int, [vp, vp, P(MapParams), P(vp)]),
             "mm_mapping_destroy": (None, [vp]),
             "mm_mapping_get_stats": (C.c_int, [vp, P(MapStats)]),
             "mm_mapping_release_intermediates": (C.c_int, [vp]),
@@ -286,7 +287,7 @@ class Context:
     def map_batch(self, idx: "Index", reads: "SeqSet", k: int, w: int, pi: float = 80.0, min_read_len: int = 1000, at_seed_stage=None, at_last_kernel=None,
                   sketch_of: "Mapping | None" = None) -> "Mapping":
         """at_seed_stage / at_last_kernel: callables run between the sketch stage and the seed stage / once K5 is enqueued (mm_map_batch_phased);
-        sketch_of: a mapping of the same reads whose minimizers and sketches are copied instead of recomputed (mm_map_batch_reusing)"""
+        sketch_of: a mapping of the same reads (or their sketch_batch) whose minimizers and sketches are taken instead of recomputed (mm_map_batch_reusing)"""
         p = MapParams(k, w, pi, min_read_len)
         h = C.c_void_p()
         if sketch_of is not None:
@@ -301,6 +302,13 @@ class Context:
                     f()
             cb = SEED_STAGE_CB(_stage)
             self.check(lib().mm_map_batch_phased(self.h, idx.h, reads.h, C.byref(p), cb, None, C.byref(h)))
+        return Mapping(self, h, reads.count)
+
+    def sketch_batch(self, reads: "SeqSet", k: int, w: int, pi: float = 80.0, min_read_len: int = 1000) -> "Mapping":
+        """minimizers and sketches of the reads alone (mm_sketch_batch): a `sketch_of` for map_batch against any index"""
+        p = MapParams(k, w, pi, min_read_len)
+        h = C.c_void_p()
+        self.check(lib().mm_sketch_batch(self.h, reads.h, C.byref(p), C.byref(h)))
         return Mapping(self, h, reads.count)
 
     def em(self, read_off, taxon, mapq, inv_nloc, n_taxa: int) -> "EM":

@@ -353,6 +353,17 @@ int mm_map_batch_reusing(mm_ctx* ctx, const mm_index* idx, const mm_seqset* read
     *out = M;
   });
 }
+int mm_sketch_batch(mm_ctx* ctx, const mm_seqset* reads, const mm_map_params* p, mm_mapping** out) {
+  if (!ctx || !reads || !p || !out) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
+    MM_REQUIRE(reads->ctx->device == ctx->device, MM_ERR_ARG, "mm_sketch_batch: the reads live on another device than the context");
+    auto* M = new mm_mapping;
+    M->sketch_only = true;
+    try { mm::map_batch(ctx, nullptr, reads, *p, M); } catch (...) { delete M; throw; }
+    *out = M;
+  });
+}
 int mm_map_batch_phased(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, void (*at_stage)(void*, int), void* user, mm_mapping** out) {
   if (!ctx || !idx || !reads || !p || !out) return MM_ERR_ARG;
   return guarded(ctx, [&] {

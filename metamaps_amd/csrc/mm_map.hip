@@ -1300,7 +1300,7 @@ struct AmbState {
 void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_map_params& P, mm_mapping* M) {
   hipStream_t st = ctx->stream;
   StageTimer T(st);
-  MM_REQUIRE(I->k == P.k && I->w == P.w, MM_ERR_ARG, "index was built with different k / window size");
+  MM_REQUIRE(M->sketch_only || (I && I->k == P.k && I->w == P.w), MM_ERR_ARG, "index was built with different k / window size");   // (mm_sketch_batch: no index)
   const int64_t n = reads->count();
   MM_REQUIRE(n < (1LL << 31), MM_ERR_LIMIT, "more than 2^31 reads in one batch");
   M->ctx = ctx; M->n_reads = n; M->params = P; M->stats = mm_map_stats{};
@@ -1436,6 +1436,13 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   }
   HostLap hl;
   M->h_sk_n = M->sk_n.to_host(st, (size_t)n);
+  if (M->sketch_only) {                                           // mm_sketch_batch: K1 + K2 alone, the donor of mm_map_batch_reusing
+    for (int64_t r = 0; r < n; ++r) M->stats.sum_sketch += M->h_sk_n[(size_t)r];
+    M->h_rec_off.assign((size_t)n + 1, 0); M->n_rec = 0;          // an empty mapping for every call that reads records
+    T.end(t_total);
+    T.collect();
+    return;
+  }
   // mm_map_batch_phased, stage 1: K1 + K2 are complete (the download above waited for them), nothing of the seed stage is enqueued yet
   if (M->at_stage) M->at_stage(M->at_stage_user, 1);
   std::vector<uint8_t> h_amb = M->amb.to_host(st, (size_t)n);

@@ -21,7 +21,8 @@ struct mm_mapping {
   std::vector<int32_t> read_len;
   std::vector<uint8_t> active;
   void (*at_stage)(void*, int) = nullptr; void* at_stage_user = nullptr;   // mm_map_batch_phased: stage 1 between K2 and K3, stage 2 once K5 is enqueued
-  const mm_mapping* sketch_donor = nullptr;  // mm_map_batch_reusing: minimizers and sketches are copied from this mapping of the same reads
+  const mm_mapping* sketch_donor = nullptr;  // mm_map_batch_reusing: minimizers and sketches are taken from this mapping of the same reads
+  bool sketch_only = false;                  // mm_sketch_batch: K1 + K2 alone, no index, no records
   // K1
   mm::MinimizerSet mz;
   // K2 (same per-read offsets as mz.off; only the first sk_n[r] slots of a read are used)

@@ -825,6 +825,15 @@ def test_map_batch_reusing_sketches_equals_map_batch(ctx, oracle_lib, mini, monk
         assert Mr.stats()["ms_sketch"] == 0.0 and Mb.stats()["ms_sketch"] > 0.0
         Mr2 = ctx.map_batch(ia, R, k, w, sketch_of=Mr)            # a mapping made from copied sketches is a donor like any other
         assert Mr2.fetch()[1].tobytes() == Ma.fetch()[1].tobytes()
+        Sk = ctx.sketch_batch(R, k, w)                            # mm_sketch_batch: K1 + K2 alone, tied to no index; holds no records
+        assert len(Sk.fetch()[1]) == 0 and Sk.stats()["sum_sketch"] == Ma.stats()["sum_sketch"] and Sk.stats()["n_candidates"] == 0
+        for ix, Mfull in ((ia, Ma), (ib, Mb)):
+            Ms = ctx.map_batch(ix, R, k, w, sketch_of=Sk)
+            assert Ms.fetch()[1].tobytes() == Mfull.fetch()[1].tobytes() and Ms.stats()["ms_sketch"] == 0.0
+            for x, y in zip(Mfull.debug_sketch(), Ms.debug_sketch()):
+                assert np.array_equal(x, y)
+            Ms.close()
+        Sk.close()
         for m_ in (Mb, Mr, Mr2):
             m_.close()
         for k_ in env:

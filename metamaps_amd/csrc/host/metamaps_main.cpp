@@ -764,12 +764,13 @@ int map_mode(const Options& o, const std::string& mode) {
   } else {
     // ---- sharded / streamed: every read batch is packed onto every device and stays there (2 bits per base) ...
     struct Held { size_t file = 0; std::vector<std::string> names; std::vector<int> lens; std::vector<mm_seqset*> reads;
+                  std::vector<mm_mapping*> sk;                 // per device: the batch's minimizers + sketches (mm_sketch_batch), computed once for all chunks
                   std::vector<std::vector<int64_t>> poff; std::vector<std::vector<mm_map_record>> prec; };
     std::vector<Held> held;
     while (std::unique_ptr<Batch> bt = reader.take()) {
       held.emplace_back();
       Held& h = held.back();
-      h.file = bt->file; h.reads.assign(G, nullptr); h.poff.resize(NC); h.prec.resize(NC);
+      h.file = bt->file; h.reads.assign(G, nullptr); h.sk.assign(G, nullptr); h.poff.resize(NC); h.prec.resize(NC);
       on_each(G, [&](size_t d) { h.reads[d] = upload_batch(devs[d].ctx, *bt); });
       h.names = std::move(bt->names); h.lens = std::move(bt->lens);
       reader.recycle(std::move(bt));
@@ -780,6 +781,14 @@ int map_mode(const Options& o, const std::string& mode) {
     // order from the accumulated histogram, then every device maps every batch against its chunks; the records of a pass go to the
     // host, where the reference keeps its PREFIX.N files (mapWrap.h:417-437).
     const size_t per_round = place == Place::Streamed ? G : NC;
+    // Minimizers and sketches do not depend on the chunk: a batch keeps them on its device from its first chunk on (about 3 bytes per read
+    // base, twelve times the packed reads), as long as all of them stay within an eighth of the device's memory; batches beyond that
+    // recompute them per chunk (MM_CLI_NO_SKETCH_REUSE=1: all of them, the cross-check).
+    std::vector<uint64_t> sk_used(G, 0), sk_budget(G, 0);
+    for (size_t d = 0; d < G; ++d) {
+      uint64_t tot = 0, fr = 0; char nm[8]; int cus = 0;
+      if (mm_ctx_device_info(devs[d].ctx, nm, sizeof nm, &cus, &tot, &fr) == MM_OK && !getenv("MM_CLI_NO_SKETCH_REUSE")) sk_budget[d] = tot / 8;
+    }
     for (size_t c0 = 0; c0 < NC; c0 += per_round) {
       const size_t c1 = std::min(NC, c0 + per_round);
       on_each(G, [&](size_t d) { for (size_t c = c0; c < c1; ++c) if (c % G == d) build_chunk(devs[d], c); });
@@ -789,7 +798,11 @@ int map_mode(const Options& o, const std::string& mode) {
         for (size_t c = c0; c < c1; ++c) {
           if (c % G != d) continue;
           for (auto& h : held) {
-            mm_mapping* pm = map_chunk(devs[d].ctx, devs[d].idx[c], h.reads[d]);
+            if (!h.sk[d] && sk_budget[d]) {
+              uint64_t bases = 0; for (int L : h.lens) bases += (uint64_t)L;
+              if (sk_used[d] + 3 * bases <= sk_budget[d]) { ck(devs[d].ctx, mm_sketch_batch(devs[d].ctx, h.reads[d], &mp, &h.sk[d]), "sketch"); sk_used[d] += 3 * bases; }
+            }
+            mm_mapping* pm = map_chunk(devs[d].ctx, devs[d].idx[c], h.reads[d], h.sk[d]);
             h.poff[c].resize(h.names.size() + 1);
             ck(devs[d].ctx, mm_mapping_fetch(pm, h.poff[c].data(), nullptr, 0), "fetch");
             h.prec[c].resize((size_t)h.poff[c].back());
@@ -804,7 +817,7 @@ int map_mode(const Options& o, const std::string& mode) {
     // merge in chunk order (unifyFiles), mapping qualities over the union and text: batch b on device b mod N
     std::vector<std::unique_ptr<Done>> results(held.size());
     on_each(G, [&](size_t d) {
-      for (auto& h : held) mm_seqset_destroy(h.reads[d]);
+      for (auto& h : held) { if (h.sk[d]) mm_mapping_destroy(h.sk[d]); mm_seqset_destroy(h.reads[d]); }
       for (size_t b = d; b < held.size(); b += G) {
         Held& h = held[b];
         std::vector<const int64_t*> op; std::vector<const mm_map_record*> rp;

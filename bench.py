@@ -371,8 +371,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, dom_name),
                          "note": "achieved = algorithmic bytes / hipEvent time, both averaged over the distinct read batches of the timed region; traffic = "
                                  "FETCH_SIZE x 2 + WRITE_SIZE of one launch pair on batch 0 (profiles/r03_pmc_hbm_traffic.txt): 3.5 x the algorithmic bytes, 4.5 TB/s "
-                                 "of fetch while the kernel runs, 21 percent of its L2 requests hit (profiles/r03_l2_cache.txt); VALU in 86 percent of the issue "
-                                 "slots (profiles/r03_sq_counters.txt).  seed_filter_stream_kernel: 42 percent VALU, bound by random requests per CU (DESIGN.md 4); "
+                                 "of fetch while the kernel runs, 21 percent of its L2 requests hit (profiles/r03_l2_cache.txt); VALU in 88 percent of the issue "
+                                 "slots (profiles/r03_sq_counters.txt).  seed_filter_stream_kernel: 45 percent VALU, bound by random requests per CU (DESIGN.md 4); "
                                  "minimizer_kernel 99 percent VALU",
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms,
                          "other_kernels": {n: {"ms_per_launch": m, "algorithmic_bytes_per_launch": b, "achieved": (b / (m * 1e-3) / 1e9 if m > 0 else 0.0)}

@@ -225,7 +225,7 @@ int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const
 int mm_map_batch_phased(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, void (*at_stage)(void* user, int stage), void* user,
                         mm_mapping** out);
 /* The same batch against another index (the next chunk of --maxmemory): minimizers and sketches of the reads — which do not depend on
- * the index — are taken from `sketch_of` (the two large read-only arrays held jointly, the rest copied), a mapping of THESE reads with the same k, w and minimum read length whose intermediates
+ * the index — are taken from `sketch_of` (the two large read-only arrays held jointly when it belongs to `ctx`, everything copied otherwise), a mapping of THESE reads with the same k, w and minimum read length whose intermediates
  * have not been released, instead of being computed again (the reference recomputes them per chunk, computeMap.hpp:277-298).
  * Results are those of mm_map_batch. */
 int mm_map_batch_reusing(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, const mm_mapping* sketch_of, mm_mapping** out);

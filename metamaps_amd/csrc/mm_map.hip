@@ -1327,9 +1327,12 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     // copied (2.2 GB per chunk mapping of a 0.8 Gbp batch); the strand bytes and the per-read arrays are this mapping's own (its tie-break
     // writes to them)
     mm_mapping* const dn = const_cast<mm_mapping*>(donor);       // (only the ownership record of the two blocks changes)
-    M->mz.rec.share_from(dn->mz.rec); dcopy(M->mz.off, donor->mz.off);
+    const bool same_ctx = donor->ctx == ctx;                     // (a block shared across contexts could go back to one context's cache while the other's stream still reads it)
+    if (same_ctx) M->mz.rec.share_from(dn->mz.rec); else dcopy(M->mz.rec, donor->mz.rec);
+    dcopy(M->mz.off, donor->mz.off);
     M->mz.h_off = donor->mz.h_off; M->mz.total = donor->mz.total;
-    M->sk_hash.share_from(dn->sk_hash); dcopy(M->sk_strand, donor->sk_strand); dcopy(M->sk_n, donor->sk_n); dcopy(M->amb, donor->amb);
+    if (same_ctx) M->sk_hash.share_from(dn->sk_hash); else dcopy(M->sk_hash, donor->sk_hash);
+    dcopy(M->sk_strand, donor->sk_strand); dcopy(M->sk_n, donor->sk_n); dcopy(M->amb, donor->amb);
     T.end(t);
   } else { size_t t = T.begin(&M->stats.ms_minimizer); run_minimizers(ctx, reads, P.k, P.w, M->active, false, M->mz); T.end(t); }
   const int64_t total_mz = M->mz.total;

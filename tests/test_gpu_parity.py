@@ -834,6 +834,10 @@ def test_map_batch_reusing_sketches_equals_map_batch(ctx, oracle_lib, mini, monk
                 assert np.array_equal(x, y)
             Ms.close()
         Sk.close()
+        other = capi.Context(0)                                   # a donor of another context of the device: everything is copied, nothing held jointly
+        Mo = other.map_batch(ib, R, k, w, sketch_of=Ma)
+        assert Mo.fetch()[1].tobytes() == rb.tobytes()
+        Mo.close(); other.close()
         for m_ in (Mb, Mr, Mr2):
             m_.close()
         for k_ in env:

@@ -375,6 +375,13 @@ def main():
                                  "slots (profiles/r03_sq_counters.txt).  seed_filter_stream_kernel: 45 percent VALU, bound by random requests per CU (DESIGN.md 4); "
                                  "minimizer_kernel 99 percent VALU",
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms,
+                         # the same kernel pair with the GPU to itself (two untimed steps whose mapping sections hold the lock to their end: the
+                         # hipEvents of the timed region also count the time a launch waits behind another worker's kernels, rocprofv3's
+                         # durations — profiles/r03_kernel_stats.txt — do not): what the kernel does, beside what the pipeline makes of it
+                         "alone": ({"ms_per_launch": R["st_clean"]["ms_l2"], "algorithmic_bytes_per_launch": 8.0 * R["st_clean"]["sum_l2_stream_entries"],
+                                    "achieved": 8.0 * R["st_clean"]["sum_l2_stream_entries"] / (R["st_clean"]["ms_l2"] * 1e-3) / 1e9,
+                                    "frac": 8.0 * R["st_clean"]["sum_l2_stream_entries"] / (R["st_clean"]["ms_l2"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                   if dom_name.startswith("l2_kernel") and R["st_clean"].get("ms_l2", 0) > 0 else None),
                          "other_kernels": {n: {"ms_per_launch": m, "algorithmic_bytes_per_launch": b, "achieved": (b / (m * 1e-3) / 1e9 if m > 0 else 0.0)}
                                            for n, b, m in cands if n != dom_name}},
         }

@@ -54,15 +54,18 @@ def parse_args():
     ap.add_argument("--pacbio", action="store_true", help="PacBio-like errors (2/8/2 percent del/ins/sub) instead of ONT-like (5/3/4)")
     ap.add_argument("--scale", type=float, default=float(os.environ.get("MM_BENCH_SCALE", 1.0)), help="scales the number of genomes of the reference (quick checks)")
     ap.add_argument("--window", type=int, default=8, help="w the CLI derives for a 26.76 GB DB.fa at default flags")
-    ap.add_argument("--workers", type=int, default=int(os.environ.get("MM_BENCH_WORKERS", 3)),
-                    help="host threads / contexts per GPU that take the steps in turn: while one runs the EM iterations, result download and host "
-                         "bookkeeping of its step, the next step's mapping kernels run (the mapping sections themselves are serialised, so that "
-                         "kernel durations — the roofline — are those of kernels that own the GPU)")
+    ap.add_argument("--workers", type=int, default=int(os.environ.get("MM_BENCH_WORKERS", 2)),
+                    help="host threads / contexts per GPU that take the steps in turn, each on its own stream: the kernels of two steps share the GPU "
+                         "(what one leaves idle — launch gaps, draining kernels, host sections — the other fills).  Measured on the distinct-batch "
+                         "workload (round 3): 2 workers 47.3 ms per step, 3 workers 47.6, 3 workers with the mapping sections serialised "
+                         "(--serialise-map, the default of rounds 2-3) 50.6")
+    ap.add_argument("--serialise-map", action="store_true", help="one lock around the mapping section of a step, passed on when its last big kernel (K5) is enqueued: "
+                    "kernel durations are then those of kernels that (nearly) own the GPU; 7 percent less throughput on distinct batches")
     ap.add_argument("--staged-map", action="store_true", help="two locks instead of one around the mapping section (K1 + K2 | K3 ... K6, swapped at mm_map_batch_phased's "
                     "callback): the next step's minimizer stage runs under this step's seed stage; ~2 percent more throughput, but the seed filter's "
                     "duration then includes the time it shares the CUs (K1 issues VALU instructions in 99 percent of its cycles: the two do not complement each other)")
     ap.add_argument("--hold-lock-to-the-end", action="store_true", help="release the mapping lock when mm_map_batch returns instead of when its last big kernel is enqueued")
-    ap.add_argument("--free-overlap", action="store_true", help="do not serialise the mapping sections of the workers (higher throughput, kernel durations inflated)")
+    ap.add_argument("--free-overlap", action="store_true", help="(the default since round 3; kept for old command lines) do not serialise the mapping sections of the workers")
     ap.add_argument("--measure-free-overlap", action="store_true", help="after the timed region, six more steps with nothing serialised, reported in config.free_overlap")
     ap.add_argument("--config", type=int, choices=(1, 3, 4), default=1, help="BASELINE.json configs[N] as far as one GPU carries it: 1 (default, the configuration `value` is "
                     "quoted on) 100k x 10 kb ONT reads vs the resident index; 3: mixed 1-50 kb PacBio reads vs the index split by the --maxmemory chunk rule into resident "
@@ -97,6 +100,10 @@ def build_reference(ctx, args, shape):
     desc = (f"community (SURVEY D1): {ng} microbial genomes in {sp} species / {ge} genera, lognormal lengths, 0.1-5 % strain divergence + block indels, "
             f"{human} human-like contigs ({int(3.1e9 * min(args.scale, 1.0))} bp, 45 % library repeats, 1 % N), contigs shuffled")
     return ref, genome.astype(np.int32), ng + 1, desc
+
+
+def sched_free(args):
+    return not ((args.serialise_map or args.staged_map) and not args.free_overlap)
 
 
 def main():
@@ -249,7 +256,7 @@ def main():
 
         for wi in range(1, W):                                    # setup: every further worker context runs once (its scratch buffers get allocated)
             em_turn["next"] = 0; step(wi, True, 0)
-        sched = False if args.free_overlap else ("staged" if (args.staged_map and W > 1) else True)
+        sched = ("staged" if (args.staged_map and W > 1) else True) if (args.serialise_map or args.staged_map) and not args.free_overlap else False
         run_steps(max(warmup, 0), sched)
         agg.update({"ms_l2": 0.0, "ms_hf": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0, "bases": 0, "done_t": []})
         barrier()
@@ -268,9 +275,9 @@ def main():
             step_ms["all"] = [round(float(g), 1) for g in gaps]
         # stage times of a step whose kernels all own the GPU (the timed region lets the next step's K1 queue behind K5): two more steps, untimed
         st_clean = st
-        if W > 1 and sched is True and not hold_lock[0]:
+        if W > 1 and not hold_lock[0]:                               # (one lock, held to the end of the mapping section)
             keep = dict(agg); keep["done_t"] = list(agg["done_t"])
-            hold_lock[0] = True; run_steps(2, sched); hold_lock[0] = False
+            hold_lock[0] = True; run_steps(2, True); hold_lock[0] = False
             st_clean = agg["stats"]
             agg.clear(); agg.update(keep)
         # beside the headline: the same number of steps ... six steps that map ONE batch again and again (what rounds 1 and 2 timed): the
@@ -288,7 +295,7 @@ def main():
             batches[:] = saved
             agg.clear(); agg.update(keep)
         free = None
-        if args.measure_free_overlap and W > 1 and not args.free_overlap and world == 1 and shape == args.shape:   # beside the headline: the same steps with nothing serialised
+        if args.measure_free_overlap and W > 1 and sched is not False and world == 1 and shape == args.shape:   # beside the headline: the same steps with nothing serialised
             keep = dict(agg); agg["bases"] = 0
             barrier(); t1 = time.perf_counter(); run_steps(6, False); barrier()
             d1 = time.perf_counter() - t1
@@ -353,7 +360,7 @@ def main():
                 "index_entries": info["n_entries"], "index_unique_hashes": info["n_unique_hashes"], "index_hbm_bytes": info["hbm_bytes"],
                 "freq_threshold": R["freq_threshold"], "reference_synth_s": round(R["t_ref"], 3), "index_build_s": round(R["t_index"], 3),
                 "parallelism": f"reads sharded x{world}, index replicated, RCCL all-reduce of EM sums; {W} worker contexts per GPU take the steps in turn"
-                               + ("" if W == 1 or args.free_overlap else ((" (mapping sections serialised" + ("" if args.hold_lock_to_the_end else "; the lock passes on when a step's last big kernel, K5, is enqueued: the next step's minimizer "
+                               + ("" if W == 1 else " (nothing serialised: the kernels of the steps in flight share the GPU)" if sched_free(args) else ((" (mapping sections serialised" + ("" if args.hold_lock_to_the_end else "; the lock passes on when a step's last big kernel, K5, is enqueued: the next step's minimizer "
                                    "kernel waits in its queue and takes the CUs K5 leaves as it drains — its stage time, ms_minimizer, then includes that wait") + ")") if not args.staged_map else
                                   " (the minimizer + sketch stage of step i+1 runs under the seed stage of step i; everything from the hit sort on owns the GPU)")),
                 "workers_per_gpu": W, "free_overlap": R["free"],
@@ -369,7 +376,7 @@ def main():
             },
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, dom_name),
-                         "note": "achieved = algorithmic bytes / hipEvent time, both averaged over the distinct read batches of the timed region; traffic = "
+                         "note": "achieved = algorithmic bytes / hipEvent time, both averaged over the distinct read batches of the timed region — where the kernels of two steps share the GPU, so a launch also waits for and runs beside the other step's kernels (roofline.alone: the same launches with the GPU to themselves — the durations of profiles/r03_kernel_stats_serialised.txt, rocprofv3 of this bench with --serialise-map --workers 3; profiles/r03_kernel_stats.txt is the default command); traffic = "
                                  "FETCH_SIZE x 2 + WRITE_SIZE of one launch pair on batch 0 (profiles/r03_pmc_hbm_traffic.txt): 3.5 x the algorithmic bytes, 4.5 TB/s "
                                  "of fetch while the kernel runs, 21 percent of its L2 requests hit (profiles/r03_l2_cache.txt); VALU in 88 percent of the issue "
                                  "slots (profiles/r03_sq_counters.txt).  seed_filter_stream_kernel: 45 percent VALU, bound by random requests per CU (DESIGN.md 4); "

@@ -1,11 +1,13 @@
 #!/bin/bash
 # Regenerates the measurement artefacts committed under profiles/ (run on the GPU box through gpurun):
-#   kernel-trace statistics of the default bench command (without its CPU / CLI legs), and HBM traffic per kernel from two separate PMC passes.
+#   kernel-trace statistics of the default bench command (without its CPU / CLI legs) and of the same with the mapping sections serialised
+#   (kernels that own the GPU), and HBM traffic per kernel from two separate PMC passes.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/profiles; rm -rf $out; mkdir -p $out
 FLAGS="--no-cpu-baseline --no-other-shape --no-e2e-full"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 6 --warmup 2 $FLAGS > $out/bench_stats_run.json 2> $out/stats.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_serialised -- python bench.py --steps 6 --warmup 2 --serialise-map --workers 3 $FLAGS > /dev/null 2> $out/stats_serialised.err
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python bench.py --steps 1 --warmup 0 --workers 1 --distinct-batches 1 $FLAGS > /dev/null 2> $out/fetch.err
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python bench.py --steps 1 --warmup 0 --workers 1 --distinct-batches 1 $FLAGS > /dev/null 2> $out/write.err
 python tools/summarize_profiles.py $out

@@ -9,13 +9,16 @@ def short(name):
         n = "rocprim::" + ("radix_sort_onesweep" if "onesweep" in name else "radix_sort_histogram" if "histogram" in name else "other")
     return n[:60]
 
-f = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
-rows = list(csv.DictReader(open(f)))
-with open(os.path.join(out, "kernel_stats.txt"), "w") as w:
-    w.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-shape --no-e2e-full   (setup kernels: index build, synthetic data; per-step kernels: 22 calls = 2 warm-up + 6 timed (a different read batch each) + 2 with the lock held to the end + 2 + 6 on one batch repeated + one per further worker context + the 6 extra batches' generation does not launch them)\n")
-    w.write(f"{'calls':>7} {'total_ms':>12} {'avg_ms':>12} {'%':>7}  kernel\n")
-    for r in rows:
-        w.write(f"{int(r['Calls']):>7} {float(r['TotalDurationNs'])/1e6:>12.3f} {float(r['AverageNs'])/1e6:>12.3f} {float(r['Percentage']):>7.3f}  {short(r['Name'])}\n")
+for sub, name, what in (("stats", "kernel_stats.txt", "python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-shape --no-e2e-full   (the default scheduling: two worker contexts, the kernels of two steps share the GPU, so a kernel's duration includes what it waits for and runs beside"),
+                        ("stats_serialised", "kernel_stats_serialised.txt", "python bench.py --steps 6 --warmup 2 --serialise-map --workers 3 --no-cpu-baseline --no-other-shape --no-e2e-full   (mapping sections serialised: the durations of kernels that own the GPU")):
+    fs = glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if not fs: continue
+    rows = list(csv.DictReader(open(fs[0])))
+    with open(os.path.join(out, name), "w") as w:
+        w.write(f"# rocprofv3 --kernel-trace --stats -- {what}; setup kernels: index build, synthetic data; per-step kernels: 2 warm-up + 6 timed steps (a different read batch each) + 2 with the lock held to the end + 2 + 6 on one batch repeated + one per further worker context)\n")
+        w.write(f"{'calls':>7} {'total_ms':>12} {'avg_ms':>12} {'%':>7}  kernel\n")
+        for r in rows:
+            w.write(f"{int(r['Calls']):>7} {float(r['TotalDurationNs'])/1e6:>12.3f} {float(r['AverageNs'])/1e6:>12.3f} {float(r['Percentage']):>7.3f}  {short(r['Name'])}\n")
 
 def pmc(kind):
     f = glob.glob(os.path.join(out, kind, "**", "*counter_collection.csv"), recursive=True)[0]

@@ -65,8 +65,9 @@ __device__ inline uint64_t ascii8_of_codes(uint32_t x, bool comp) {
   const uint32_t sa = ((a | (a << 6) | (a << 12) | (a << 18)) & 0x03030303u) ^ flip, sb = ((b | (b << 6) | (b << 12) | (b << 18)) & 0x03030303u) ^ flip;
   return (uint64_t)__builtin_amdgcn_perm(0u, 0x54474341u, sa) | ((uint64_t)__builtin_amdgcn_perm(0u, 0x54474341u, sb) << 32);
 }
-__device__ inline KmerInfo kmer_info_serial(const SeqView& S, uint64_t gbase, int p, int k) {
-  if (k == 16 && S.n_exc == 0) {                                // sixteen codes straddle at most two packed words
+// clean_pos: positions below it have no exception run (non-ACGT bytes) among their k bases — the packed words are then the sequence
+__device__ inline KmerInfo kmer_info_serial(const SeqView& S, uint64_t gbase, int p, int k, int clean_pos) {
+  if (k == 16 && (S.n_exc == 0 || p < clean_pos)) {             // sixteen codes straddle at most two packed words
     const uint64_t g = gbase + (uint64_t)p;
     const uint32_t off = (uint32_t)(g & 15), w0 = S.packed[g >> 4], w1 = off ? S.packed[(g >> 4) + 1] : 0u;
     const uint32_t codes = off ? (w0 >> (2 * off)) | (w1 << (32 - 2 * off)) : w0;
@@ -90,18 +91,26 @@ static __global__ void jstar_kernel(SeqView S, const uint8_t* __restrict__ activ
   int npos = S.len[s] - k + 1;
   if ((active == nullptr || active[s]) && npos >= w) {
     uint64_t gb = S.base[s];
-    KmerInfo e = kmer_info_serial(S, gb, w - 1, k);
+    // the walk looks at the first few dozen positions: when the sequence's first exception run starts behind them (a reference contig with N runs
+    // somewhere inside), they take the packed-word path instead of sixteen binary searches over the exception table per position
+    int clean_pos = 0;
+    if (S.n_exc) {
+      const int64_t r = exc_lower(S, gb);
+      const uint64_t first_exc = r < S.n_exc ? S.exc_start[r] : ~0ull;
+      clean_pos = first_exc <= gb ? 0 : (int)min<uint64_t>(first_exc - gb, (uint64_t)0x7fffffff) - (k - 1);
+    }
+    KmerInfo e = kmer_info_serial(S, gb, w - 1, k, clean_pos);
     if (e.ns) {
       // c(w-1): argmin over NS positions 0..w-1, ties -> rightmost
       int cpos = w - 1; uint32_t ch = e.hash; bool cf = e.fwd;
       for (int q = w - 2; q >= 0; --q) {
-        KmerInfo t = kmer_info_serial(S, gb, q, k);
+        KmerInfo t = kmer_info_serial(S, gb, q, k, clean_pos);
         if (t.ns && t.hash < ch) { ch = t.hash; cpos = q; cf = t.fwd; }
       }
       const uint32_t h0 = ch; const bool f0 = cf;
       res = npos;                                  // swallowed to the end unless a differing change point shows up
       for (int p = w; p < npos; ++p) {
-        KmerInfo t = kmer_info_serial(S, gb, p, k);
+        KmerInfo t = kmer_info_serial(S, gb, p, k, clean_pos);
         if (!t.ns) continue;
         int ncpos; uint32_t nch; bool ncf;
         if (t.hash <= ch || cpos <= p - w) {
@@ -109,7 +118,7 @@ static __global__ void jstar_kernel(SeqView S, const uint8_t* __restrict__ activ
           else {                                   // previous minimum left the window: rescan
             ncpos = p; nch = t.hash; ncf = t.fwd;
             for (int q = p - 1; q > p - w; --q) {
-              KmerInfo u = kmer_info_serial(S, gb, q, k);
+              KmerInfo u = kmer_info_serial(S, gb, q, k, clean_pos);
               if (u.ns && u.hash < nch) { nch = u.hash; ncpos = q; ncf = u.fwd; }
             }
           }

@@ -98,17 +98,30 @@ struct DevAlloc {
     }
     }
     size_t ask = want;
+    // The last GiB of the device stays with the runtime: a device filled to the brim by hipMalloc lets a later kernel launch fail inside the
+    // runtime (its own allocations: HSA_STATUS_ERROR_OUT_OF_RESOURCES, the queue is aborted and the process with it — seen with three worker
+    // contexts beside four resident chunk indexes); a request that would take it is treated as one that failed for lack of memory.
+    constexpr size_t RUNTIME_RESERVE = (size_t)1 << 30;
+    bool refuse = false;
     if (want >= ((size_t)64 << 20)) {                            // (headroom only while a fifth of the device is free: resident chunk indexes can leave less)
       size_t fr = 0, tot = 0;
-      if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > tot / 5) ask = round_up(want + want / 4);
+      if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+        if (fr > tot / 5) ask = round_up(want + want / 4);
+        refuse = fr < want + RUNTIME_RESERVE;
+      }
     }
     void* p = nullptr;
     static const bool trace = getenv("MM_ALLOC_TRACE") != nullptr;     // every block that comes from the driver, with its cost
     const auto t0 = std::chrono::steady_clock::now();
-    hipError_t e = hipMalloc(&p, ask);
+    hipError_t e = refuse ? hipErrorOutOfMemory : hipMalloc(&p, ask);
     size_t granted = ask;
     if (trace) fprintf(stderr, "MM_ALLOC_TRACE hipMalloc %zu bytes %.3f ms\n", ask, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); trim(); int dv = 0; (void)hipGetDevice(&dv); big_pool_trim(dv); alloc_trim_others(this, dv); granted = want; e = hipMalloc(&p, want); }   // (no headroom when memory is short)
+    if (e == hipErrorOutOfMemory) {
+      (void)hipGetLastError(); trim(); int dv = 0; (void)hipGetDevice(&dv); big_pool_trim(dv); alloc_trim_others(this, dv); granted = want;
+      size_t fr = 0, tot = 0;
+      if (refuse && hipMemGetInfo(&fr, &tot) == hipSuccess && fr < want + RUNTIME_RESERVE) e = hipErrorOutOfMemory;   // still not there with every cache given back
+      else e = hipMalloc(&p, want);
+    }   // (no headroom when memory is short)
     if (e != hipSuccess) { (void)hipGetLastError(); throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, oom_text(want, e)); }
     *got = granted;
     return p;

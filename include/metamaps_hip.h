@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 4   /* 3: mm_seqset_slice/concat, mm_map_batch_reusing, mm_em_continue, mm_synth_community_species */
+#define MM_ABI_VERSION 4   /* 3: mm_seqset_slice/concat, mm_map_batch_reusing, mm_em_continue, mm_synth_community_species;
+                            * 4: mm_sketch_batch, mm_ctx_release_cached, mm_index_dup_neighbours */
 
 typedef enum {
   MM_OK = 0,

@@ -172,12 +172,12 @@ std::vector<int> device_list(const Options& o) {                 // --gpus N: de
 }
 
 // records of one batch -> the text of PREFIX (computeMap.hpp:565-581 + the two fields of mapWrap.h:311-320), reads in order
-void format_records(const std::vector<std::string>& names, const std::vector<int>& lens, const std::vector<int64_t>& off,
-                    const std::vector<mm_map_record>& rec, const std::vector<std::string>& cname, const std::vector<int>& clen, int k, std::string& out) {
+static void format_range(const std::vector<std::string>& names, const std::vector<int>& lens, const std::vector<int64_t>& off,
+                         const std::vector<mm_map_record>& rec, const std::vector<std::string>& cname, const std::vector<int>& clen, int k, size_t r0, size_t r1, std::string& out) {
   out.clear();
-  out.reserve(rec.size() * 160);
+  out.reserve((size_t)(off[r1] - off[r0]) * 160);
   char num[256];
-  for (size_t r = 0; r < names.size(); ++r) {
+  for (size_t r = r0; r < r1; ++r) {
     const int len = lens[r];
     for (int64_t i = off[r]; i < off[r + 1]; ++i) {
       const mm_map_record& x = rec[(size_t)i];
@@ -194,6 +194,24 @@ void format_records(const std::vector<std::string>& names, const std::vector<int
       out.append(num, (size_t)n);
     }
   }
+}
+// the mapping lines of a batch (mapWrap.h:300-323): ranges of reads formatted by a few threads, joined in read order
+void format_records(const std::vector<std::string>& names, const std::vector<int>& lens, const std::vector<int64_t>& off,
+                    const std::vector<mm_map_record>& rec, const std::vector<std::string>& cname, const std::vector<int>& clen, int k, std::string& out) {
+  const size_t n = names.size();
+  const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 8), rec.size() / 20000 + 1}));
+  if (T == 1) { format_range(names, lens, off, rec, cname, clen, k, 0, n, out); return; }
+  std::vector<size_t> cut(T + 1, n);
+  cut[0] = 0;
+  { size_t t = 1; for (size_t r = 0; r < n && t < T; ++r) if ((uint64_t)off[r] >= (uint64_t)rec.size() * t / T) cut[t++] = r; }
+  std::vector<std::string> part(T);
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < T; ++t) pool.emplace_back([&, t] { format_range(names, lens, off, rec, cname, clen, k, cut[t], cut[t + 1], part[t]); });
+  format_range(names, lens, off, rec, cname, clen, k, cut[0], cut[1], part[0]);
+  for (auto& th : pool) th.join();
+  size_t total = 0; for (auto& p_ : part) total += p_.size();
+  out.clear(); out.reserve(total);
+  for (auto& p_ : part) out += p_;
 }
 
 int map_mode(const Options& o, const std::string& mode) {

@@ -322,12 +322,14 @@ def test_streamed_chunks_equal_resident_chunks(world):
     assert len(bounds) >= 8
     sub = _subset(ctx, mixed, world["sub_which"])
     host = []
+    sk = ctx.sketch_batch(sub, K, W)                              # minimizers + sketches once for all chunks (mm_sketch_batch), as the chunk-major runs do
     for a, n in bounds:
         sl = ref.slice(a, n); ix = ctx.index(sl, K, W, auto_threshold=False); sl.close()
         ix.set_freq_threshold(INT_MAX)
-        M = ctx.map_batch(ix, sub, K, W)
+        M = ctx.map_batch(ix, sub, K, W, sketch_of=sk)
         o, r = M.fetch(); host.append((o.copy(), r.copy()))
         M.close(); ix.close()
+    sk.close()
     V = capi.Mapping.from_parts(ctx, sub.lengths(), host, [a for a, _ in bounds], K, W); V.add_qualities(K)
     off, rec = V.fetch()
     assert np.array_equal(off, world["sub_off"])

@@ -159,6 +159,7 @@ __global__ void dup_pairs_kernel(const uint32_t* __restrict__ key, const uint64_
                                  const uint64_t* __restrict__ cstart, const uint32_t* __restrict__ dir, const uint64_t* __restrict__ dir_off, int dir_shift,
                                  Rec* __restrict__ pos, unsigned long long* __restrict__ ndup,
                                  const uint64_t* __restrict__ dup_bits, const uint64_t* __restrict__ dup_rank, uint16_t* __restrict__ dist16, int sat) {
+  unsigned long long mine = 0;                                   // pairs this thread found (one add per wave at the end: 3*10^8 adds to one word serialise)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n; i += (int64_t)gridDim.x * blockDim.x) {
     if (key[i] != key[i + 1]) continue;
     const uint64_t a = val[i], b = val[i + 1];
@@ -169,13 +170,17 @@ __global__ void dup_pairs_kernel(const uint32_t* __restrict__ key, const uint64_
     if (!DIST) {
       atomicOr(&pos[oa].pw, PW_DN);
       atomicOr(&pos[ob].pw, PW_DP);
-      atomicAdd(ndup, 1ull);
+      ++mine;
     } else {
       const uint16_t d = (uint16_t)min<int64_t>(ob - oa, (int64_t)sat);
       auto slot = [&](int64_t j) -> uint64_t { return dup_rank[j >> 6] + (uint64_t)__popcll(dup_bits[j >> 6] & ((1ull << (j & 63)) - 1ull)); };
       dist16[2 * slot(oa) + 1] = d;                               // an entry has at most one pair on each side: no two threads write one half
       dist16[2 * slot(ob)] = d;
     }
+  }
+  if (!DIST) {
+    for (int dlt = 32; dlt > 0; dlt >>= 1) mine += __shfl_xor(mine, dlt, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(ndup, mine);
   }
 }
 // one wave per block of 64 entries: which of them are flagged

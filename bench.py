@@ -392,6 +392,8 @@ def main():
                          "other_kernels": {n: {"ms_per_launch": m, "algorithmic_bytes_per_launch": b, "achieved": (b / (m * 1e-3) / 1e9 if m > 0 else 0.0)}
                                            for n, b, m in cands if n != dom_name}},
         }
+        if out["roofline"].get("alone"):                             # (beside `frac`, for the reader of the one line)
+            out["roofline"]["frac_alone"] = out["roofline"]["alone"]["frac"]; out["roofline"]["achieved_alone"] = out["roofline"]["alone"]["achieved"]
         if not args.no_cpu_baseline and world == 1:              # (the contract asks for it at N=1 only)
             try:
                 out["cpu_baseline"], out["e2e_cli"] = cpu_baseline_and_cli(args, R, k, w)

@@ -19,7 +19,8 @@ reference are generated on the device (csrc/mm_synth.hip):
   uniform    round 1's shape: 3 000 species × 4 strains × 2.2 Mbp, substitutions only (reported beside it in config.other_shape)
 
 Multi-GPU: one process per GPU (torch.distributed launch), index replicated, every rank maps its own
-`--reads` reads (weak scaling: per-GPU work fixed), EM sufficient statistics all-reduced over RCCL (also at N = 1: the same
+`--reads` reads (weak scaling: per-GPU work fixed; the default) or — `--scaling strong`, BASELINE configs[2] — its contiguous shard of
+ONE batch of `--reads` reads that every rank generates; EM sufficient statistics all-reduced over RCCL (also at N = 1: the same
 code path at every N).  Timing: barrier + synchronize on both sides of exactly K steps, MAX over ranks; rank 0 prints one JSON line.
 """
 from __future__ import annotations
@@ -49,6 +50,10 @@ def parse_args():
     # workload: BASELINE configs[1] shape; scale knobs exist so that smaller boxes / quick checks can run
     ap.add_argument("--shape", choices=("community", "uniform"), default=os.environ.get("MM_BENCH_SHAPE", "community"))
     ap.add_argument("--reads", type=int, default=int(os.environ.get("MM_BENCH_READS", 100_000)), help="reads per GPU")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("MM_BENCH_SCALING", "weak"),
+                    help="weak (default): every rank maps its own --reads reads per step.  strong: --reads is the TOTAL per step (BASELINE configs[2]: the 100k x 10 kb "
+                         "batch of configs[1] sharded 8x); every rank generates the same batches (seed independent of the rank) and maps "
+                         "shard_range(total, rank, world) of each (metamaps_amd/dist.py), the EM sums are all-reduced as at every N")
     ap.add_argument("--read-len", type=int, default=10_000)
     ap.add_argument("--read-len-min", type=int, default=0, help="mixed lengths, log-uniform in [read-len-min, read-len] (BASELINE config 3 shape); 0 = fixed")
     ap.add_argument("--pacbio", action="store_true", help="PacBio-like errors (2/8/2 percent del/ins/sub) instead of ONT-like (5/3/4)")
@@ -160,16 +165,23 @@ def main():
         # step before it left in the caches.  The worker contexts read them in turn (read-only; any context of the device may).
         B = max(1, min(args.distinct_batches, steps + max(warmup, 0)))
         batches, truth = [], None
+        strong = args.scaling == "strong"
+        from metamaps_amd.dist import shard_range
+        lo, hi = shard_range(args.reads, rank, world) if strong else (0, args.reads)
         for b in range(B):
-            rd, tr = ctx.synth_reads(ref, seed=1000 + rank + 97 * b, n_reads=args.reads, read_len=args.read_len, read_len_min=args.read_len_min,
+            rd, tr = ctx.synth_reads(ref, seed=1000 + (0 if strong else rank) + 97 * b, n_reads=args.reads, read_len=args.read_len, read_len_min=args.read_len_min,
                                      frac_random=0.05, n_abundant=100, **err)
+            if strong and world > 1:                                # this rank's contiguous shard of the batch every rank generated
+                whole = rd
+                rd = whole.slice(lo, hi - lo); whole.close()
+                tr = tr[lo:hi]
             batches.append(rd)
             truth = tr if b == 0 else truth
         reads = batches[0]
         ctx.synchronize()
         contig_len = ref.lengths().astype(np.int32)
         agg = {"ms_l2": 0.0, "ms_hf": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0, "stats": None, "em_iters": 0, "bases": 0, "done_t": []}
-        rec_bufs = [np.empty(max(64 * args.reads, 1 << 16), dtype=capi.RECORD_DTYPE) for _ in ctxs]   # host result buffers reused by every step
+        rec_bufs = [np.empty(max(64 * (hi - lo), 1 << 16), dtype=capi.RECORD_DTYPE) for _ in ctxs]   # host result buffers reused by every step
         map_lock, agg_lock = threading.Lock(), threading.Lock()
         front_lock, back_lock = threading.Lock(), threading.Lock()
         hold_lock = [bool(args.hold_lock_to_the_end)]
@@ -205,7 +217,7 @@ def main():
                 tt.append(time.perf_counter())
             finally:
                 release()
-            M.add_qualities(k)                                      # (one 60 us kernel on this worker's stream: under the next step's minimizer stage)
+            M.add_qualities(k)                                      # K8: three small launches, thread per mapping (round 3: one thread per read, 3.2 ms)
             off, rec = M.fetch(rec_bufs[wi])
             st = M.stats()
             tt.append(time.perf_counter())
@@ -346,20 +358,21 @@ def main():
         dom_name, dom_bytes, dom_ms = max(cands, key=lambda c: c[2])
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         len_txt = f"{args.read_len}" if not args.read_len_min else f"{args.read_len_min}-{args.read_len}"
-        out_workload = (f"{args.reads} synthetic {len_txt} bp {'PacBio' if args.pacbio else 'ONT'}-error reads per GPU vs synthetic miniSeq+H-shaped index "
+        out_workload = (f"{args.reads} synthetic {len_txt} bp {'PacBio' if args.pacbio else 'ONT'}-error reads {'per GPU' if args.scaling == 'weak' else f'in all, sharded over {world} GPU(s)'} vs synthetic miniSeq+H-shaped index "
                         f"({R['desc']}; {R['reference_bp'] / 1e9:.2f} Gbp), k=16 w={w}, --all")
         out = {
             "metric": "Gbp long reads mapped+classified per sec (whole node), miniSeq+H DB",
             "value": R["value"], "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": R["ms_step"], "step_ms": {kk: (round(v, 3) if not isinstance(v, list) else v) for kk, v in R["step_ms"].items()}, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": R["ms_step"], "step_ms": {kk: (round(v, 3) if not isinstance(v, list) else v) for kk, v in R["step_ms"].items()}, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {
                 "workload": out_workload,
-                "baseline_config": "configs[1]", "distinct_read_batches": R["n_batches"], "one_batch_repeated": R["same_batch"],
-                "reads_per_gpu": args.reads, "read_len": args.read_len, "reference_bp": R["reference_bp"], "reference_contigs": info["n_contigs"],
+                "baseline_config": "configs[1]" if args.scaling == "weak" else f"configs[2] (the configs[1] batch of {args.reads} reads sharded x{world}: strong scaling)",
+                "distinct_read_batches": R["n_batches"], "one_batch_repeated": R["same_batch"],
+                "reads_per_gpu": args.reads if args.scaling == "weak" else [list(__import__("metamaps_amd.dist", fromlist=["shard_range"]).shard_range(args.reads, r, world)) for r in range(world)], "read_len": args.read_len, "reference_bp": R["reference_bp"], "reference_contigs": info["n_contigs"],
                 "index_entries": info["n_entries"], "index_unique_hashes": info["n_unique_hashes"], "index_hbm_bytes": info["hbm_bytes"],
                 "freq_threshold": R["freq_threshold"], "reference_synth_s": round(R["t_ref"], 3), "index_build_s": round(R["t_index"], 3),
-                "parallelism": f"reads sharded x{world}, index replicated, RCCL all-reduce of EM sums; {W} worker contexts per GPU take the steps in turn"
+                "parallelism": f"reads sharded x{world} ({args.scaling} scaling), index replicated, RCCL all-reduce of EM sums; {W} worker contexts per GPU take the steps in turn"
                                + ("" if W == 1 else " (nothing serialised: the kernels of the steps in flight share the GPU)" if sched_free(args) else ((" (mapping sections serialised" + ("" if args.hold_lock_to_the_end else "; the lock passes on when a step's last big kernel, K5, is enqueued: the next step's minimizer "
                                    "kernel waits in its queue and takes the CUs K5 leaves as it drains — its stage time, ms_minimizer, then includes that wait") + ")") if not args.staged_map else
                                   " (the minimizer + sketch stage of step i+1 runs under the seed stage of step i; everything from the hit sort on owns the GPU)")),

@@ -73,7 +73,9 @@ int mm_seqset_add(mm_seqset* s, const char* ascii, int64_t len);   /* host stagi
 /* same, without the copy: the caller keeps `ascii` valid and unchanged until mm_seqset_upload has returned (a parser that
  * fills one arena per batch hands its records over this way) */
 int mm_seqset_add_view(mm_seqset* s, const char* ascii, int64_t len);
-int mm_seqset_upload(mm_seqset* s);                                /* pack + copy to HBM; set is then frozen */
+int mm_seqset_upload(mm_seqset* s);                                /* pack + copy to HBM; set is then frozen.  Packs into the CONTEXT's pinned
+                                                                    * staging buffer: two uploads of sets of one context must not overlap (the one-thread-
+                                                                    * per-context rule above applies to this entry point too) */
 /* Persistent packed form of an uploaded sequence set (2-bit bases, exception runs, lengths): what `metamaps index` stores
  * per index chunk in place of the reference's Boost archive of the sketch (createIndex, mapWrap.h:358-405;
  * winSketch.hpp:73-83).  The device index is rebuilt from it in seconds (mm_index_build), nothing derived is stored. */

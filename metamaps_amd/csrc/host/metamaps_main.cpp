@@ -265,7 +265,8 @@ int map_mode(const Options& o, const std::string& mode) {
   // from it; the host holds contig names and lengths only.  Index chunks are cut out of it on the device (mm_seqset_slice).
   std::vector<mm_seqset*> refset(G, nullptr);
   uint64_t hbm_free = 0;
-  { char nm[8]; int cus; uint64_t tot; mm_ctx_device_info(ctx0, nm, sizeof nm, &cus, &tot, &hbm_free); }
+  auto query_free = [&] { char nm[8]; int cus; uint64_t tot; mm_ctx_device_info(ctx0, nm, sizeof nm, &cus, &tot, &hbm_free); };
+  query_free();
   const double INDEX_BYTES_PER_BASE = 5.5;                       // pos + padded occ + table at w = 8; denser for smaller w
   auto fits = [&](uint64_t bases, double share) { return (double)bases * INDEX_BYTES_PER_BASE * 1.2 * share <= 0.8 * (double)hbm_free; };
   auto make_part = [&](size_t d, int a, int bnd) {               // contigs [a, bnd) of the reference as a set of their own, on device d
@@ -395,6 +396,7 @@ int map_mode(const Options& o, const std::string& mode) {
       pc.lap("1 reference parse + pack + upload");
       pc.add("2 reference pack+upload (inside 1)", t_pack);
     }
+    query_free();                                                // the packed reference now lives on the device (0.25 B per base, for as long as chunks are cut out of it): what is left is what the indexes get
     std::vector<int32_t> first(1, 0);
     if (!maxMem || fits(ref_bases, 1.0)) {
       // the index of the whole reference: the only chunk, or what the chunk rule of --maxmemory is evaluated on

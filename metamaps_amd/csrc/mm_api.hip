@@ -71,8 +71,8 @@ void mm_ctx_destroy(mm_ctx* ctx) {
   mm::comm_destroy(ctx);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->pinned_up) (void)hipHostFree(ctx->pinned_up);
-  if (ctx->l2_codes) (void)hipFree(ctx->l2_codes);
-  if (ctx->l2_masks) (void)hipFree(ctx->l2_masks);
+  if (ctx->l2_codes) mm::dev_free(ctx->l2_codes, ctx->l2_codes_bytes);
+  if (ctx->l2_masks) mm::dev_free(ctx->l2_masks, ctx->l2_masks_bytes);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -86,7 +86,7 @@ int mm_ctx_device_info(mm_ctx* ctx, char* name, size_t name_cap, int* cus, uint6
     if (name && name_cap) { snprintf(name, name_cap, "%s (%s)", p.name, p.gcnArchName); }
     if (cus) *cus = p.multiProcessorCount;
     size_t f = 0, t = 0;
-    MM_HIP(hipMemGetInfo(&f, &t));
+    MM_HIP(mm::dev_mem_info(&f, &t));                             // (capped by the test hook MM_DEVICE_BYTES_CAP, mm_common.hpp)
     if (hbm_total) *hbm_total = t;
     if (hbm_free) *hbm_free = f;
   });

@@ -14,6 +14,8 @@
 #include <map>
 #include <iterator>
 #include <mutex>
+#include <atomic>
+#include <algorithm>
 #include "../../include/metamaps_hip.h"
 
 namespace mm {
@@ -42,8 +44,37 @@ struct Error : std::runtime_error {
 // handed to a later allocation is therefore only touched by work that is stream-ordered after its previous
 // user.  Index-scale buffers (>= 8 GiB) bypass the cache.
 void big_pool_trim(int device);
+// Every device block of the library comes from dev_malloc and goes back through dev_free, so that the bytes it holds per device are known.
+// MM_DEVICE_BYTES_CAP=<bytes> (a TEST HOOK) makes the library behave as if every device had only that much memory: dev_malloc fails with
+// hipErrorOutOfMemory beyond it and dev_mem_info reports it — the CLI's resident / sharded / streamed decision and the allocator's
+// out-of-memory paths are then exercised on a small input (tests/test_gpu_cli.py) instead of on a reference larger than 288 GB.
+struct DevMeter {
+  std::atomic<long long> used[64];
+  long long cap;
+  DevMeter() { for (auto& u : used) u = 0; const char* e = getenv("MM_DEVICE_BYTES_CAP"); cap = e ? atoll(e) : 0; }
+};
+inline DevMeter& dev_meter() { static DevMeter m; return m; }
+inline int dev_current() { int d = 0; (void)hipGetDevice(&d); return d < 0 || d >= 64 ? 0 : d; }
+inline hipError_t dev_malloc(void** p, size_t bytes) {
+  DevMeter& m = dev_meter();
+  const int d = dev_current();
+  if (m.cap > 0 && m.used[d].load() + (long long)bytes > m.cap) { *p = nullptr; return hipErrorOutOfMemory; }
+  const hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) m.used[d] += (long long)bytes;
+  return e;
+}
+inline void dev_free(void* p, size_t bytes) { if (!p) return; dev_meter().used[dev_current()] -= (long long)bytes; (void)hipFree(p); }
+inline hipError_t dev_mem_info(size_t* fr, size_t* tot) {
+  const hipError_t e = hipMemGetInfo(fr, tot);
+  DevMeter& m = dev_meter();
+  if (e == hipSuccess && m.cap > 0) {
+    const long long left = std::max(0LL, m.cap - m.used[dev_current()].load());
+    *tot = std::min<size_t>(*tot, (size_t)m.cap); *fr = std::min<size_t>(*fr, (size_t)left);
+  }
+  return e;
+}
 inline std::string oom_text(size_t want, hipError_t e) {         // what the device looks like when an allocation fails for good
-  size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot);
+  size_t fr = 0, tot = 0; (void)dev_mem_info(&fr, &tot);
   return std::string("hipMalloc of ") + std::to_string(want) + " bytes: " + hipGetErrorString(e) + " (device: " + std::to_string(fr >> 20) + " MiB free of " + std::to_string(tot >> 20) + ")";
 }
 struct DevAlloc;
@@ -72,7 +103,7 @@ struct DevAlloc {
     std::lock_guard<std::mutex> lk(m);
     if (cache.empty()) return;
     (void)hipStreamSynchronize(stream);
-    for (auto& kv : cache) (void)hipFree(kv.second);
+    for (auto& kv : cache) dev_free(kv.second, kv.first);
     cache.clear(); cached_bytes = 0;
   }
   // hands the largest cached blocks back to the driver until at most `keep` bytes stay cached (after an index build: its temporaries
@@ -81,7 +112,7 @@ struct DevAlloc {
     std::lock_guard<std::mutex> lk(m);
     if (cached_bytes <= keep) return;
     (void)hipStreamSynchronize(stream);
-    while (cached_bytes > keep && !cache.empty()) { auto it = std::prev(cache.end()); (void)hipFree(it->second); cached_bytes -= it->first; cache.erase(it); }
+    while (cached_bytes > keep && !cache.empty()) { auto it = std::prev(cache.end()); dev_free(it->second, it->first); cached_bytes -= it->first; cache.erase(it); }
   }
   void* get(size_t bytes, size_t* got) {
     const size_t want = round_up(bytes);
@@ -105,7 +136,7 @@ struct DevAlloc {
     bool refuse = false;
     if (want >= ((size_t)64 << 20)) {                            // (headroom only while a fifth of the device is free: resident chunk indexes can leave less)
       size_t fr = 0, tot = 0;
-      if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+      if (dev_mem_info(&fr, &tot) == hipSuccess) {
         if (fr > tot / 5) ask = round_up(want + want / 4);
         refuse = fr < want + RUNTIME_RESERVE;
       }
@@ -113,14 +144,14 @@ struct DevAlloc {
     void* p = nullptr;
     static const bool trace = getenv("MM_ALLOC_TRACE") != nullptr;     // every block that comes from the driver, with its cost
     const auto t0 = std::chrono::steady_clock::now();
-    hipError_t e = refuse ? hipErrorOutOfMemory : hipMalloc(&p, ask);
+    hipError_t e = refuse ? hipErrorOutOfMemory : dev_malloc(&p, ask);
     size_t granted = ask;
     if (trace) fprintf(stderr, "MM_ALLOC_TRACE hipMalloc %zu bytes %.3f ms\n", ask, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (e == hipErrorOutOfMemory) {
       (void)hipGetLastError(); trim(); int dv = 0; (void)hipGetDevice(&dv); big_pool_trim(dv); alloc_trim_others(this, dv); granted = want;
       size_t fr = 0, tot = 0;
-      if (refuse && hipMemGetInfo(&fr, &tot) == hipSuccess && fr < want + RUNTIME_RESERVE) e = hipErrorOutOfMemory;   // still not there with every cache given back
-      else e = hipMalloc(&p, want);
+      if (refuse && dev_mem_info(&fr, &tot) == hipSuccess && fr < want + RUNTIME_RESERVE) e = hipErrorOutOfMemory;   // still not there with every cache given back
+      else e = dev_malloc(&p, want);
     }   // (no headroom when memory is short)
     if (e != hipSuccess) { (void)hipGetLastError(); throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, oom_text(want, e)); }
     *got = granted;
@@ -157,7 +188,7 @@ struct BigPool {
     return p;
   }
   void give(void* p, size_t sz) { std::lock_guard<std::mutex> lk(m); free_.emplace(sz, p); bytes += sz; }
-  void trim() { std::lock_guard<std::mutex> lk(m); for (auto& kv : free_) (void)hipFree(kv.second); free_.clear(); bytes = 0; }
+  void trim() { std::lock_guard<std::mutex> lk(m); for (auto& kv : free_) dev_free(kv.second, kv.first); free_.clear(); bytes = 0; }
 };
 inline BigPool& big_pool(int device) { static BigPool pools[64]; return pools[device < 0 || device >= 64 ? 0 : device]; }
 inline void big_pool_trim(int device) { big_pool(device).trim(); }
@@ -202,6 +233,14 @@ struct DBuf {
     if (!count) return;
     const size_t bytes = count * sizeof(T);
     owner = current_alloc();
+    if (bytes < DIRECT_ALLOC_BYTES && !owner) {                  // no context bound to this thread: a plain driver block (not the index-scale pool, whose
+      block = 0; big_bytes = 0;                                  // take() only matches requests within an eighth of a block's size: small blocks would pile up there)
+      (void)hipGetDevice(&big_dev);
+      hipError_t e = dev_malloc((void**)&p, bytes);
+      if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); big_pool(big_dev).trim(); alloc_trim_others(nullptr, big_dev); e = dev_malloc((void**)&p, bytes); }
+      if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; n = 0; throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, mm::oom_text(bytes, e)); }
+      return;
+    }
     if (bytes >= DIRECT_ALLOC_BYTES || !owner) {
       // (the cache is only given up when the device is out of memory: trimming it before every index-scale allocation sent every
       // mid-size temporary of the next index build back to hipMalloc — 1 400 driver allocations per 25 builds, six of which stalled for
@@ -215,8 +254,8 @@ struct DBuf {
       else p = (T*)bp.take(bytes, &big_bytes);
       if (!p) {
         big_bytes = bytes;
-        hipError_t e = hipMalloc((void**)&p, bytes);
-        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); bp.trim(); if (owner) owner->trim(); alloc_trim_others(owner, big_dev); e = hipMalloc((void**)&p, bytes); }
+        hipError_t e = dev_malloc((void**)&p, bytes);
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); bp.trim(); if (owner) owner->trim(); alloc_trim_others(owner, big_dev); e = dev_malloc((void**)&p, bytes); }
         if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; n = 0; throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, mm::oom_text(bytes, e)); }
         if (trace) fprintf(stderr, "MM_ALLOC_TRACE direct hipMalloc %zu bytes %.3f ms\n", bytes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       } else if (trace) fprintf(stderr, "MM_ALLOC_TRACE big block of %zu bytes reused for %zu\n", big_bytes, bytes);
@@ -226,8 +265,14 @@ struct DBuf {
     if (shared) { shared.reset(); p = nullptr; n = 0; block = 0; return; }
     if (p) {
       if (block && owner) owner->put(p, block);
-      else if (owner && owner->eager) { (void)hipDeviceSynchronize(); (void)hipFree(p); }
-      else { (void)hipDeviceSynchronize(); big_pool(big_dev).give(p, big_bytes); }   // (nothing on the device still uses it: any context may take it)
+      else {
+        int cur = 0; (void)hipGetDevice(&cur);
+        if (cur != big_dev) (void)hipSetDevice(big_dev);         // the synchronisation below is for the block's device, whichever the calling thread is on
+        (void)hipDeviceSynchronize();
+        if ((owner && owner->eager) || !big_bytes) dev_free(p, big_bytes ? big_bytes : n * sizeof(T));
+        else big_pool(big_dev).give(p, big_bytes);                // (nothing on the device still uses it: any context may take it)
+        if (cur != big_dev) (void)hipSetDevice(cur);
+      }
       p = nullptr;
     }
     n = 0; block = 0;
@@ -333,19 +378,20 @@ struct mm_ctx {
   void* comm = nullptr;          // ncclComm_t
   bool comm_shared = false;      // the communicator belongs to another context of this device (mm_comm_share)
   int comm_rank = 0, comm_size = 1;
+  bool em_split = false;         // the resident EM kernel once failed to get its grid onto the device: one launch per phase from then on (mm_post.hip)
   // per-(k, pi) cache of the host statistics thresholds (pure functions of the sketch size), mm_stats.hpp
   std::shared_ptr<void> lut_cache;
   int lut_k = 0; float lut_pi = 0;
   // K5 scratch kept across batches: the per-entry code words of pass A (4 B per streamed entry slot, mm_l2.hpp)
   void raw_alloc(void** p, size_t bytes) {                       // hipMalloc; out of memory: the caches of this context and the device's block pool go first
-    hipError_t e = hipMalloc(p, bytes);
-    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); alloc.trim(); mm::big_pool_trim(device); mm::alloc_trim_others(&alloc, device); e = hipMalloc(p, bytes); }
+    hipError_t e = mm::dev_malloc(p, bytes);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); alloc.trim(); mm::big_pool_trim(device); mm::alloc_trim_others(&alloc, device); e = mm::dev_malloc(p, bytes); }
     if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, mm::oom_text(bytes, e)); }
   }
   void* l2_codes = nullptr; size_t l2_codes_bytes = 0;
   void* l2_codes_at_least(size_t bytes) {
     if (bytes > l2_codes_bytes) {
-      if (l2_codes) { MM_HIP(hipStreamSynchronize(stream)); (void)hipFree(l2_codes); }
+      if (l2_codes) { MM_HIP(hipStreamSynchronize(stream)); mm::dev_free(l2_codes, l2_codes_bytes); }
       l2_codes = nullptr; l2_codes_bytes = 0;
       raw_alloc(&l2_codes, bytes);
       l2_codes_bytes = bytes;
@@ -355,7 +401,7 @@ struct mm_ctx {
   void* l2_masks = nullptr; size_t l2_masks_bytes = 0;           // class masks of the long-read K5 classes
   void* l2_masks_at_least(size_t bytes) {
     if (bytes > l2_masks_bytes) {
-      if (l2_masks) { MM_HIP(hipStreamSynchronize(stream)); (void)hipFree(l2_masks); }
+      if (l2_masks) { MM_HIP(hipStreamSynchronize(stream)); mm::dev_free(l2_masks, l2_masks_bytes); }
       l2_masks = nullptr; l2_masks_bytes = 0;
       raw_alloc(&l2_masks, bytes);
       l2_masks_bytes = bytes;

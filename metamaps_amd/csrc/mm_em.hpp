@@ -14,6 +14,10 @@ struct mm_em {
   mm::DBuf<double> post, ll_read, f, partial, block_sum;
   // device-resident loop (mm_em_run): taxa with mappings on this rank, their partial sums, loop control, log-likelihood trace
   mm::DBuf<int32_t> present; int32_t n_present = -1;
+  // the per-taxon sums in fixed shape: items of <= 512 consecutive entries of one taxon (one wavefront each), the items of present taxon p
+  // are [pt_item[p], pt_item[p + 1]); the resident kernel's grid, its per-workgroup log-likelihood partials and its barrier words
+  mm::DBuf<int32_t> pt_item; mm::DBuf<int64_t> item_lo, item_hi; int32_t n_items = 0, n_wg = 0;
+  mm::DBuf<double> item_sum, wg_ll; mm::DBuf<unsigned> bar;
   mm::DBuf<double> local_partial, ll_trace, f_run;   // f_run: the loop's own frequencies (mm_em_iterate / mm_em_posteriors in between do not disturb mm_em_continue)
   mm::DBuf<long long> ctrl;
 };

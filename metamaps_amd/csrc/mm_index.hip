@@ -249,7 +249,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   // proceeds (DevAlloc::eager), nothing is left cached beside it.
   struct EagerGuard { DevAlloc& a; bool was; ~EagerGuard() { a.eager = was; } } eager_guard{ctx->alloc, ctx->alloc.eager};
   { size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess && (double)contigs->total_bases * 5.5 > (double)tot / 4) { ctx->alloc.eager = true; if (!getenv("MM_INDEX_NO_PRETRIM")) { ctx->alloc.trim(); big_pool_trim(ctx->device); } } }
+    if (dev_mem_info(&fr, &tot) == hipSuccess && (double)contigs->total_bases * 5.5 > (double)tot / 4) { ctx->alloc.eager = true; if (!getenv("MM_INDEX_NO_PRETRIM")) { ctx->alloc.trim(); big_pool_trim(ctx->device); } } }
   I->ctx = ctx; I->k = k; I->w = w;
   I->n_contigs = contigs->count();
   I->contig_len = contigs->len;

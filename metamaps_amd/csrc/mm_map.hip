@@ -1979,7 +1979,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       const bool no_slots = getenv("MM_L2_NO_SLOTS") != nullptr;
       const size_t env_slots = getenv("MM_L2_SLOTS") ? ((size_t)std::max(atoi(getenv("MM_L2_SLOTS")), 1) + 7) / 8 * 8 : 0;
       auto max_slots = [&](int nwq) -> size_t { return no_slots ? (size_t)1 << 40 : env_slots ? env_slots : (size_t)ctx->cus * (nwq == 2 ? 64 : 32); };
-      DBuf<unsigned int> slot_flags((size_t)ctx->cus * 64); slot_flags.zero(st);
+      DBuf<unsigned int> slot_flags(std::max((size_t)ctx->cus * 64, env_slots)); slot_flags.zero(st);   // (MM_L2_SLOTS may ask for more slots than cus * 64)
       unsigned int* const slot_flags_p = no_slots ? nullptr : slot_flags.p;
       auto slots_of = [&](size_t n_waves, int nwq = 8) -> size_t { return std::min((std::max<size_t>(n_waves, 1) + 7) / 8 * 8, max_slots(nwq)); };   // (a multiple of 8: one share per XCD)
       auto masks_for = [&](size_t n_waves, int nwq = 8) -> uint8_t* { return (uint8_t*)ctx->l2_masks_at_least(slots_of(n_waves, nwq) * l2_skip_bytes(nwq)); };

@@ -59,25 +59,39 @@ __device__ inline double dev_binom_pmf(int n, double p, int k) {  // boost pdf(b
   return exp(lgamma((double)n + 1) - lgamma((double)k + 1) - lgamma((double)(n - k) + 1) + k * log(p) + (n - k) * log1p(-p));
 }
 
-__global__ void mapq_kernel(mm_map_record* __restrict__ rec, const uint64_t* __restrict__ rec_off, const int32_t* __restrict__ read_len,
-                            int64_t n_reads, int k, int* __restrict__ err) {
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_reads) return;
+// K8 in three launches, one thread per MAPPING where the arithmetic is (round 3 ran one thread per READ through three serial loops
+// of f64 lgamma / pow: 3.2 ms per 10^5-read batch, 423 k records).
+//   mapq_identity_kernel   per record: the identity the mappings file would carry (6 significant digits, mapWrap.h:237)
+//   mapq_likelihood_kernel per record: the read's best identity -> p (mapWrap.h:261-266, :335-338), the record's binomial mass (:340)
+//   mapq_normalise_kernel  per read:   sum of the masses IN RECORD ORDER (the reference's loop, :279-296) and the division (:301)
+__global__ void __launch_bounds__(256) mapq_identity_kernel(const mm_map_record* __restrict__ rec, int64_t n_rec, int k, double* __restrict__ ident) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rec) return;
+  ident[i] = parse6((double)dev_identity(rec[i].shared, rec[i].sketch, k)) / 100.0;
+}
+__global__ void __launch_bounds__(256) mapq_likelihood_kernel(mm_map_record* __restrict__ rec, const uint64_t* __restrict__ rec_off, const int32_t* __restrict__ read_len,
+                                                              const double* __restrict__ ident, int64_t n_rec, int k) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rec) return;
+  const int64_t r = rec[i].read;
   const uint64_t lo = rec_off[r], hi = rec_off[r + 1];
-  if (lo == hi) return;
   double maxid = -1;
-  for (uint64_t i = lo; i < hi; ++i) {
-    double id = parse6((double)dev_identity(rec[i].shared, rec[i].sketch, k)) / 100.0;   // mapWrap.h:237
-    if (id > maxid) maxid = id;
-  }
+  for (uint64_t j = lo; j < hi; ++j) { const double id = ident[j]; if (id > maxid) maxid = id; }
   maxid = exp(-(1 - maxid));                                      // :261
   const int nk = read_len[r] - k + 1;                             // :266
   const double surv = pow(maxid, (double)k);                      // :335
   const double es = round(surv * nk);
   const double eu = nk + (nk - es);
   const double p = es / eu;
+  rec[i].mapq = dev_binom_pmf(rec[i].sketch, p, rec[i].shared);
+}
+__global__ void __launch_bounds__(256) mapq_normalise_kernel(mm_map_record* __restrict__ rec, const uint64_t* __restrict__ rec_off, int64_t n_reads, int* __restrict__ err) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_reads) return;
+  const uint64_t lo = rec_off[r], hi = rec_off[r + 1];
+  if (lo == hi) return;
   double sum = 0;
-  for (uint64_t i = lo; i < hi; ++i) { double l = dev_binom_pmf(rec[i].sketch, p, rec[i].shared); rec[i].mapq = l; sum += l; }
+  for (uint64_t i = lo; i < hi; ++i) sum += rec[i].mapq;
   if (!(sum > 0)) { atomicExch(err, 1); return; }                 // reference asserts here, :298
   for (uint64_t i = lo; i < hi; ++i) rec[i].mapq = rec[i].mapq / sum;
 }
@@ -86,7 +100,13 @@ void mapping_add_qualities(mm_ctx* ctx, mm_mapping* M, int k) {
   hipStream_t st = ctx->stream;
   if (M->n_reads == 0 || M->n_rec == 0) { M->has_mapq = true; return; }
   DBuf<int> err(1); err.zero(st);
-  mapq_kernel<<<dim3((unsigned)ceil_div(M->n_reads, 128)), dim3(128), 0, st>>>(M->rec.p, M->rec_off.p, M->d_read_len.p, M->n_reads, k, err.p);
+  DBuf<double> ident((size_t)M->n_rec);
+  const unsigned gb = (unsigned)ceil_div(M->n_rec, 256);
+  mapq_identity_kernel<<<dim3(gb), dim3(256), 0, st>>>(M->rec.p, M->n_rec, k, ident.p);
+  MM_KERNEL_CHECK();
+  mapq_likelihood_kernel<<<dim3(gb), dim3(256), 0, st>>>(M->rec.p, M->rec_off.p, M->d_read_len.p, ident.p, M->n_rec, k);
+  MM_KERNEL_CHECK();
+  mapq_normalise_kernel<<<dim3((unsigned)ceil_div(M->n_reads, 256)), dim3(256), 0, st>>>(M->rec.p, M->rec_off.p, M->n_reads, err.p);
   MM_KERNEL_CHECK();
   auto he = err.to_host(st);
   MM_REQUIRE(he[0] == 0, MM_ERR_NUMERIC, "likelihood sum of a read is 0 (the reference aborts here, mapWrap.h:298)");
@@ -165,7 +185,7 @@ void em_create(mm_ctx* ctx, int64_t n_reads, const int64_t* read_off, const int3
   E->post.alloc((size_t)std::max<int64_t>(ne, 1));
   E->ll_read.alloc((size_t)std::max<int64_t>(n_reads, 1));
   E->f.alloc((size_t)n_taxa);
-  E->partial.alloc((size_t)n_taxa + 1);
+  E->partial.alloc((size_t)n_taxa + 2);
   E->block_sum.alloc((size_t)ceil_div(std::max<int64_t>(n_reads, 1), 256));
   MM_HIP(hipStreamSynchronize(st));
 }
@@ -259,7 +279,7 @@ void em_create_from_mapping(mm_ctx* ctx, const mm_mapping* M, const int32_t* con
   MM_KERNEL_CHECK();
   E->ll_read.alloc((size_t)std::max<int64_t>(n_reads, 1));
   E->f.alloc((size_t)n_taxa);
-  E->partial.alloc((size_t)n_taxa + 1);
+  E->partial.alloc((size_t)n_taxa + 2);
   E->block_sum.alloc((size_t)ceil_div(std::max<int64_t>(n_reads, 1), 256));
   MM_HIP(hipStreamSynchronize(st));
 }
@@ -304,82 +324,203 @@ void em_iterate_allreduce(mm_em* E, const double* f, double* f_next, double* ll)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The whole EM loop on the device (meta::doEM's while loop, fEM.h:501-661): an iteration is E step, per-taxon sums, log-likelihood,
-// the RCCL all-reduce, normalisation and the stop rule — all stream ordered, no host round trip.  The host enqueues iterations in
-// groups and only looks at the control word afterwards; iterations enqueued past the stop are no-ops (every rank sees the same
-// all-reduced values, so every rank stops at the same iteration and the collectives stay matched).
+// The whole EM loop on the device (meta::doEM's while loop, fEM.h:501-661), round 4: ONE resident kernel per run.
+//
+// An iteration has three phases with a dependency between each:
+//   P1  E step, thread per read (fEM.h:350-361, :578): post[i] = l_i / sum l, log-likelihood partial per workgroup
+//   P2  per-taxon sums of the posteriors in a FIXED SHAPE: the entries of a taxon (read order, `perm`) are cut into items of <= 512,
+//       an item is summed by one wavefront (lane l takes l, l + 64, ...; butterfly), the items of a taxon are added in order.  The
+//       shape depends on the number of entries only, so exactly tied taxa stay exactly tied (getBestMapping's first-maximum rule,
+//       fEM.h:217-232, sees the same ties as the reference's sequential sums)
+//   P3  one workgroup: item sums -> per-taxon sums, their total, f = sum / total (fEM.h:606-615), log-likelihood, stop rule (:624-639)
+// Round 3 ran them as five launches + a copy per iteration (136 us per iteration, 4.3 ms of a 48 ms bench step for a 5 MB problem).
+// Now the grid (<= 128 workgroups, all resident) loops over the iterations itself; the phases are separated by grid barriers (agent-scope
+// release / acquire around one atomic counter; the workgroup that arrives last at the second barrier runs P3 before it releases the
+// others).  With several ranks an iteration is kernel A = P1 | barrier | P2 | last arriver: P3' (local sums), the ncclAllReduce, and
+// kernel B = normalise + stop rule on the all-reduced sums (every rank decides on identical values, so the collectives stay matched).
+// A barrier that is not released within 2 s (a grid that cannot become resident: many contexts of one device inside their EM loops at
+// once) raises the abort flag; the host then finishes the run with the same phases as separate launches (MM_EM_SPLIT=1 forces that
+// path: bit-identical results, same shapes).
 // ctrl[0] = iterations done, ctrl[1] = stopped (1: the stop rule fired, 2: the caller's iteration limit), ctrl[2] = bits of the
-// previous log-likelihood, ctrl[3] = first iteration of the current log-likelihood trace.
+// previous log-likelihood, ctrl[3] = first iteration of the current log-likelihood trace, ctrl[4] = a barrier timed out.
 // ---------------------------------------------------------------------------------------------------
-__global__ void em_estep_loop_kernel(const int64_t* __restrict__ read_off, const int32_t* __restrict__ taxon, const double* __restrict__ mapq,
-                                     const double* __restrict__ inv_nloc, const double* __restrict__ f, int64_t n_reads,
-                                     double* __restrict__ post, double* __restrict__ ll_read, const long long* __restrict__ ctrl) {
-  if (ctrl[1]) return;
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_reads) return;
-  const int64_t lo = read_off[r], hi = read_off[r + 1];
-  double sum = 0;
-  for (int64_t i = lo; i < hi; ++i) { double l = f[taxon[i]] * inv_nloc[i] * mapq[i]; post[i] = l; sum += l; }   // fEM.h:353
-  for (int64_t i = lo; i < hi; ++i) post[i] = post[i] / sum;                                                      // :361
-  ll_read[r] = hi > lo ? log(sum) : 0.0;                                                                          // fEM.h:578
+struct EmLoop {
+  const int64_t* read_off; const int32_t* taxon; const double* mapq; const double* inv_nloc;
+  int64_t n_reads;
+  double* post;
+  const int64_t* perm; const int64_t* item_lo; const int64_t* item_hi; int n_items;
+  const int32_t* present; const int32_t* pt_item; int n_present;   // items of present taxon p: [pt_item[p], pt_item[p + 1])
+  double* item_sum; double* wg_ll;
+  double* f; double* local_partial; int32_t n_taxa;
+  long long* ctrl; double* ll_trace; int ll_cap; long long it_limit;
+  unsigned* bar;                                                  // [0] arrivals, [1] released generation
+  long long barrier_ticks;                                        // a barrier not released within this many ticks of the 100 MHz wall clock gives up (ctrl[4])
+};
+constexpr int EM_ITEM = 512;
+constexpr long long EM_BARRIER_TICKS = 200000000LL;               // 2 s of the 100 MHz wall clock (MM_EM_BARRIER_TICKS: test hook)
+
+__device__ inline void em_p1(const EmLoop& a, int wg, int n_wg, double* sh) {
+  const int tid = threadIdx.x;
+  const int64_t stride = (int64_t)n_wg * 256;
+  double ll = 0;
+  for (int64_t r = (int64_t)wg * 256 + tid; r < a.n_reads; r += stride) {
+    const int64_t lo = a.read_off[r], hi = a.read_off[r + 1];
+    double sum = 0;
+    for (int64_t i = lo; i < hi; ++i) { const double l = a.f[a.taxon[i]] * a.inv_nloc[i] * a.mapq[i]; a.post[i] = l; sum += l; }   // fEM.h:353
+    for (int64_t i = lo; i < hi; ++i) a.post[i] = a.post[i] / sum;                                                                    // :361
+    if (hi > lo) ll += log(sum);                                                                                                      // :578
+  }
+  sh[tid] = ll;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if (tid < d) sh[tid] += sh[tid + d]; __syncthreads(); }
+  if (tid == 0) a.wg_ll[wg] = sh[0];
 }
-// per-taxon sums for the taxa that have mappings on this rank: one workgroup per taxon (an abundant genome owns tens of thousands of
-// entries; one wavefront walking them is what an iteration then waits for).  Fixed shape: 256 strided partial sums, butterfly per
-// wavefront, the four wavefront sums added in order — it depends on the segment length only, so exactly tied taxa stay tied.
-__global__ void __launch_bounds__(256) em_taxon_sum_present_kernel(const double* __restrict__ post, const int64_t* __restrict__ tstart, const int64_t* __restrict__ perm,
-                                                                   const int32_t* __restrict__ present, int n_present, double* __restrict__ local_partial,
-                                                                   const long long* __restrict__ ctrl) {
-  if (ctrl[1]) return;
-  __shared__ double ws[4];
-  const int t = present[blockIdx.x];
+__device__ inline void em_p2(const EmLoop& a, int wg, int n_wg) {
+  const int lane = threadIdx.x & 63;
+  const int n_waves = n_wg * 4;
+  for (int it = wg * 4 + (threadIdx.x >> 6); it < a.n_items; it += n_waves) {
+    const int64_t hi = a.item_hi[it];
+    double acc = 0;
+    for (int64_t j = a.item_lo[it] + lane; j < hi; j += 64) acc += a.post[a.perm[j]];
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane == 0) a.item_sum[it] = acc;
+  }
+}
+// fixed-shape sum of v(0..n) by one workgroup of 256: thread t adds t, t + 256, ... in order, then a tree
+template <typename F>
+__device__ inline double wg_sum256(int n, double* sh, F v) {
+  const int tid = threadIdx.x;
   double acc = 0;
-  for (int64_t j = tstart[t] + threadIdx.x; j < tstart[t + 1]; j += 256) acc += post[perm[j]];
-  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  for (int i = tid; i < n; i += 256) acc += v(i);
   __syncthreads();
-  if (threadIdx.x == 0) local_partial[t] = ((ws[0] + ws[1]) + ws[2]) + ws[3];
+  sh[tid] = acc;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if (tid < d) sh[tid] += sh[tid + d]; __syncthreads(); }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
 }
-__global__ void __launch_bounds__(256) em_ll_sum_kernel(const double* __restrict__ ll_read, int64_t n, double* __restrict__ block_sum, const long long* __restrict__ ctrl) {
-  if (ctrl[1]) return;
+__device__ inline void em_stop_rule(long long* ctrl, double ll, double* ll_trace, int ll_cap, long long it_limit) {   // one thread
+  const long long it = ctrl[0];
+  const double ll_prev = __longlong_as_double(ctrl[2]);
+  const long long ti = it - ctrl[3];                               // ctrl[3]: iteration the trace buffer starts at (mm_em_continue)
+  if (ti >= 0 && ti < ll_cap) ll_trace[ti] = ll;
+  if (it > 0 && (ll - ll_prev) <= 1 && (1 - ll / ll_prev) < 0.0001) ctrl[1] = 1;   // fEM.h:624-639
+  if (!ctrl[1] && it + 1 >= it_limit) ctrl[1] = 2;                 // the caller's limit, unless the rule has just fired (a rule stop is final, a limit stop is lifted by mm_em_continue)
+  ctrl[2] = __double_as_longlong(ll);
+  ctrl[0] = it + 1;
+}
+// P3 (one workgroup).  LOCAL: the per-taxon sums and the log-likelihood of this rank go to local_partial[0..T] (all-reduced next);
+// otherwise: normalise over the present taxa, write f, evaluate the stop rule.
+template <bool LOCAL>
+__device__ inline void em_p3(const EmLoop& a, int n_wg, double* sh) {
+  const int tid = threadIdx.x;
+  for (int p = tid; p < a.n_present; p += 256) {
+    double s = 0;
+    for (int it = a.pt_item[p]; it < a.pt_item[p + 1]; ++it) s += a.item_sum[it];
+    a.local_partial[a.present[p]] = s;
+  }
+  __syncthreads();
+  const double ll = wg_sum256(n_wg, sh, [&](int g) { return a.wg_ll[g]; });
+  if (LOCAL) { if (tid == 0) a.local_partial[a.n_taxa] = ll; return; }
+  const double total = wg_sum256(a.n_present, sh, [&](int p) { return a.local_partial[a.present[p]]; });
+  if (a.ctrl[0] == 0) {                                            // taxa without a mapping: 0 / total from the first iteration on (fEM.h:606-615)
+    for (int t = tid; t < a.n_taxa; t += 256) a.f[t] = 0.0;
+    __syncthreads();
+  }
+  for (int p = tid; p < a.n_present; p += 256) { const int t = a.present[p]; a.f[t] = a.local_partial[t] / total; }
+  __syncthreads();
+  if (tid == 0) em_stop_rule(a.ctrl, ll, a.ll_trace, a.ll_cap, a.it_limit);
+}
+
+// grid barrier pieces (thread 0 of every workgroup talks; agent-scope fences publish / fetch the other workgroups' plain stores: the
+// XCDs' L2s are not coherent with each other, DESIGN.md K5 scratch slots)
+__device__ inline bool grid_arrive_is_last(unsigned* bar, unsigned epoch, unsigned n_wg, int* s_flag) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned old = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old + 1 == epoch * n_wg;
+    if (last) __threadfence();
+    *s_flag = last;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+__device__ inline void grid_release(unsigned* bar, unsigned epoch) {
+  __syncthreads();
+  if (threadIdx.x == 0) { __threadfence(); __hip_atomic_store(&bar[1], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
+__device__ inline bool grid_wait(unsigned* bar, unsigned epoch, long long* ctrl, int* s_flag, long long ticks) {   // false: timed out / aborted
+  if (threadIdx.x == 0) {
+    const long long t0 = (long long)wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((long long)wall_clock64() - t0 > ticks || __hip_atomic_load(&ctrl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(&ctrl[4], 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break;
+      }
+    }
+    __threadfence();
+    *s_flag = ok;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+// ONE_ITERATION = false: the whole run of one rank.  true: kernel A of a multi-rank iteration (P1 | P2 | local sums), leaves after it.
+template <bool ONE_ITERATION>
+__global__ void __launch_bounds__(256) em_loop_kernel(EmLoop a) {
   __shared__ double sh[256];
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  sh[threadIdx.x] = i < n ? ll_read[i] : 0.0;
-  __syncthreads();
-  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
-  if (threadIdx.x == 0) block_sum[blockIdx.x] = sh[0];
+  __shared__ int s_flag;
+  const int wg = blockIdx.x, n_wg = gridDim.x;
+  if (__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // (iterations enqueued past the stop are no-ops)
+  unsigned epoch = 0;
+  for (;;) {
+    em_p1(a, wg, n_wg, sh);
+    ++epoch;
+    if (grid_arrive_is_last(a.bar, epoch, n_wg, &s_flag)) grid_release(a.bar, epoch);
+    else if (!grid_wait(a.bar, epoch, a.ctrl, &s_flag, a.barrier_ticks)) {
+      if (ONE_ITERATION && threadIdx.x == 0) a.local_partial[a.n_taxa + 1] = 1.0;   // all-reduced: every rank learns that this iteration did not happen
+      return;
+    }
+    em_p2(a, wg, n_wg);
+    ++epoch;
+    if (grid_arrive_is_last(a.bar, epoch, n_wg, &s_flag)) {
+      em_p3<ONE_ITERATION>(a, n_wg, sh);
+      if (ONE_ITERATION) return;
+      grid_release(a.bar, epoch);
+    } else {
+      if (ONE_ITERATION) return;
+      if (!grid_wait(a.bar, epoch, a.ctrl, &s_flag, a.barrier_ticks)) return;
+    }
+    if (__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  }
 }
-__global__ void __launch_bounds__(256) em_ll_final_kernel(const double* __restrict__ block_sum, int64_t nb, double* __restrict__ out, const long long* __restrict__ ctrl) {
-  if (ctrl[1]) return;
-  __shared__ double sh[256];
-  double acc = 0;
-  for (int64_t i = threadIdx.x; i < nb; i += 256) acc += block_sum[i];
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
-  if (threadIdx.x == 0) *out = sh[0];
-}
-// normalise (fEM.h:606-615; fixed-shape sum over the taxa, the same on every rank), log-likelihood trace, stop rule (:624-639)
+// the same phases as separate launches (no barrier inside): the path after a barrier time-out, and MM_EM_SPLIT=1
+__global__ void __launch_bounds__(256) em_p1_kernel(EmLoop a) { __shared__ double sh[256]; if (a.ctrl[1]) return; em_p1(a, blockIdx.x, gridDim.x, sh); }
+__global__ void __launch_bounds__(256) em_p2_kernel(EmLoop a) { if (a.ctrl[1]) return; em_p2(a, blockIdx.x, gridDim.x); }
+template <bool LOCAL>
+__global__ void __launch_bounds__(256) em_p3_kernel(EmLoop a, int n_wg) { __shared__ double sh[256]; if (a.ctrl[1]) return; em_p3<LOCAL>(a, n_wg, sh); }
+// kernel B of a multi-rank iteration: normalise the all-reduced sums (fEM.h:606-615; fixed-shape sum over the taxa, the same on every
+// rank), log-likelihood trace, stop rule (:624-639)
 __global__ void __launch_bounds__(256) em_finalize_kernel(const double* __restrict__ partial, int32_t n_taxa, double* __restrict__ f, long long* __restrict__ ctrl,
                                                           double* __restrict__ ll_trace, int ll_cap, long long it_limit) {
   if (ctrl[1]) return;
   __shared__ double sh[256];
-  double acc = 0;
-  for (int t = threadIdx.x; t < n_taxa; t += 256) acc += partial[t];
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
-  const double sum = sh[0];
-  for (int t = threadIdx.x; t < n_taxa; t += 256) f[t] = partial[t] / sum;
-  if (threadIdx.x == 0) {
-    const long long it = ctrl[0];
-    const double ll = partial[n_taxa], ll_prev = __longlong_as_double(ctrl[2]);
-    const long long ti = it - ctrl[3];                             // ctrl[3]: iteration the trace buffer starts at (mm_em_continue)
-    if (ti >= 0 && ti < ll_cap) ll_trace[ti] = ll;
-    if (it > 0 && (ll - ll_prev) <= 1 && (1 - ll / ll_prev) < 0.0001) ctrl[1] = 1;
-    if (it + 1 >= it_limit) ctrl[1] = 2;                           // the caller's iteration limit: the rest of the enqueued group are no-ops (on every rank)
-    ctrl[2] = __double_as_longlong(ll);
-    ctrl[0] = it + 1;
+  if (partial[n_taxa + 1] > 0) {                                   // some rank's kernel A gave up at its barrier: nothing is applied, every rank repeats the iteration phase by phase
+    if (threadIdx.x == 0) { ctrl[4] = 1; ctrl[1] = 3; }
+    return;
   }
+  const double sum = wg_sum256(n_taxa, sh, [&](int t) { return partial[t]; });
+  for (int t = threadIdx.x; t < n_taxa; t += 256) f[t] = partial[t] / sum;
+  if (threadIdx.x == 0) em_stop_rule(ctrl, partial[n_taxa], ll_trace, ll_cap, it_limit);
+}
+
+static int em_grid(int64_t n_reads) {                            // (fixed per problem: the log-likelihood partials are summed in the grid's shape)
+  const char* e = getenv("MM_EM_GRID");
+  const int cap = std::min(std::max(e ? atoi(e) : 128, 1), 1024);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(cap, ceil_div(std::max<int64_t>(n_reads, 1), 256)));
 }
 
 // f0 == nullptr continues the loop where the previous call on E left it (same f, iteration count and previous log-likelihood):
@@ -388,21 +529,35 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
   mm_ctx* ctx = E->ctx;
   hipStream_t st = ctx->stream;
   const int32_t T = E->n_taxa;
-  if (E->n_present < 0) {                                        // taxa with mappings on this rank
+  const int cap = 1024;
+  if (E->n_present < 0) {                                        // first run: taxa with mappings on this rank, the items of the per-taxon sums
     MM_REQUIRE(f0 != nullptr, MM_ERR_STATE, "mm_em_continue before mm_em_run");
     std::vector<int64_t> ts = E->tstart.to_host(st, (size_t)T + 1);
-    std::vector<int32_t> pr;
-    for (int32_t t = 0; t < T; ++t) if (ts[(size_t)t + 1] > ts[(size_t)t]) pr.push_back(t);
-    E->n_present = (int32_t)pr.size();
+    std::vector<int32_t> pr, pti(1, 0);
+    std::vector<int64_t> ilo, ihi;
+    for (int32_t t = 0; t < T; ++t) {
+      if (ts[(size_t)t + 1] == ts[(size_t)t]) continue;
+      pr.push_back(t);
+      for (int64_t j = ts[(size_t)t]; j < ts[(size_t)t + 1]; j += EM_ITEM) { ilo.push_back(j); ihi.push_back(std::min(j + EM_ITEM, ts[(size_t)t + 1])); }
+      MM_REQUIRE(ilo.size() < (size_t)INT32_MAX, MM_ERR_LIMIT, "EM problem beyond 2^31 sum items");
+      pti.push_back((int32_t)ilo.size());
+    }
+    E->n_present = (int32_t)pr.size(); E->n_items = (int32_t)ilo.size();
+    E->n_wg = em_grid(E->n_reads);
     E->present.alloc(std::max<size_t>(pr.size(), 1)); E->present.upload(pr.data(), pr.size(), st);
-    E->local_partial.alloc((size_t)T + 1);
-    E->ll_trace.alloc(1024);
+    E->pt_item.alloc(pti.size()); E->pt_item.upload(pti.data(), pti.size(), st);
+    E->item_lo.alloc(std::max<size_t>(ilo.size(), 1)); E->item_lo.upload(ilo.data(), ilo.size(), st);
+    E->item_hi.alloc(std::max<size_t>(ihi.size(), 1)); E->item_hi.upload(ihi.data(), ihi.size(), st);
+    E->item_sum.alloc(std::max<size_t>(ilo.size(), 1));
+    E->wg_ll.alloc((size_t)E->n_wg);
+    E->local_partial.alloc((size_t)T + 2);
+    E->ll_trace.alloc((size_t)cap);
     E->f_run.alloc((size_t)T);
-    E->ctrl.alloc(4);
+    E->ctrl.alloc(8);
+    E->bar.alloc(2);
     MM_HIP(hipStreamSynchronize(st));
   }
-  const int cap = 1024;
-  long long h_ctrl[4] = {0, 0, 0, 0};
+  long long h_ctrl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (f0) {
     E->f_run.upload(f0, (size_t)T, st);
     E->local_partial.zero(st);
@@ -411,40 +566,59 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
     MM_HIP(hipMemcpyAsync(h_ctrl, E->ctrl.p, sizeof h_ctrl, hipMemcpyDeviceToHost, st));
     MM_HIP(hipStreamSynchronize(st));
     if (h_ctrl[1] == 2) h_ctrl[1] = 0;
-    h_ctrl[3] = h_ctrl[0];
+    h_ctrl[3] = h_ctrl[0]; h_ctrl[4] = 0;
     MM_HIP(hipMemcpyAsync(E->ctrl.p, h_ctrl, sizeof h_ctrl, hipMemcpyHostToDevice, st));
     MM_HIP(hipStreamSynchronize(st));
   }
   const long long it0 = h_ctrl[0], it_limit = it0 + max_iter;
-  const int64_t nb = ceil_div(std::max<int64_t>(E->n_reads, 1), 256);
-  const int GROUP = 8;
-  while (!h_ctrl[1]) {
-    const int g_n = (int)std::min<long long>(GROUP, it_limit - h_ctrl[0]);   // (the same on every rank: h_ctrl holds all-reduced decisions)
-    for (int g = 0; g < g_n; ++g) {
-      if (E->n_reads > 0) {
-        em_estep_loop_kernel<<<dim3((unsigned)ceil_div(E->n_reads, 128)), dim3(128), 0, st>>>(E->read_off.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->f_run.p,
-                                                                                         E->n_reads, E->post.p, E->ll_read.p, E->ctrl.p);
-        MM_KERNEL_CHECK();
-      }
-      if (E->n_present > 0) {
-        em_taxon_sum_present_kernel<<<dim3((unsigned)E->n_present), dim3(256), 0, st>>>(E->post.p, E->tstart.p, E->perm.p, E->present.p, E->n_present,
-                                                                                               E->local_partial.p, E->ctrl.p);
-        MM_KERNEL_CHECK();
-      }
-      em_ll_sum_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(E->ll_read.p, E->n_reads, E->block_sum.p, E->ctrl.p);
-      MM_KERNEL_CHECK();
-      em_ll_final_kernel<<<dim3(1), dim3(256), 0, st>>>(E->block_sum.p, nb, E->local_partial.p + T, E->ctrl.p);
-      MM_KERNEL_CHECK();
-      if (ctx->comm) {                                           // fEM.h:583-600, across GPUs instead of OpenMP threads
-        ncclResult_t rc = ncclAllReduce(E->local_partial.p, E->partial.p, (size_t)T + 1, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, st);
-        MM_REQUIRE(rc == ncclSuccess, MM_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
-      } else MM_HIP(hipMemcpyAsync(E->partial.p, E->local_partial.p, sizeof(double) * ((size_t)T + 1), hipMemcpyDeviceToDevice, st));
-      em_finalize_kernel<<<dim3(1), dim3(256), 0, st>>>(E->partial.p, T, E->f_run.p, E->ctrl.p, E->ll_trace.p, cap, it_limit);
-      MM_KERNEL_CHECK();
-    }
+  EmLoop a{E->read_off.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->n_reads, E->post.p, E->perm.p, E->item_lo.p, E->item_hi.p, E->n_items,
+           E->present.p, E->pt_item.p, E->n_present, E->item_sum.p, E->wg_ll.p, E->f_run.p, E->local_partial.p, T, E->ctrl.p, E->ll_trace.p, cap, it_limit, E->bar.p,
+           getenv("MM_EM_BARRIER_TICKS") ? atoll(getenv("MM_EM_BARRIER_TICKS")) : EM_BARRIER_TICKS};
+  const dim3 grid((unsigned)E->n_wg), blk(256);
+  const bool force_split = getenv("MM_EM_SPLIT") != nullptr;
+  bool split = force_split || ctx->em_split;
+  auto fetch_ctrl = [&] {
     MM_HIP(hipMemcpyAsync(h_ctrl, E->ctrl.p, sizeof h_ctrl, hipMemcpyDeviceToHost, st));
     MM_HIP(hipStreamSynchronize(st));
-    if (g_n <= 0) break;
+    if (h_ctrl[4]) {                                             // a grid barrier timed out: the state is that of the last completed iteration (P1 / P2 only write scratch)
+      if (!ctx->em_split) fprintf(stderr, "libmetamaps_hip: the resident EM kernel could not get its %d workgroups onto device %d together; "
+                                          "this context goes on with one launch per phase\n", E->n_wg, ctx->device);
+      ctx->em_split = split = true;
+      h_ctrl[4] = 0;
+      if (h_ctrl[1] == 3) h_ctrl[1] = 0;                         // (several ranks: the all-reduced abort mark stopped the rest of the enqueued group on every rank)
+      MM_HIP(hipMemcpyAsync(E->ctrl.p, h_ctrl, sizeof h_ctrl, hipMemcpyHostToDevice, st));
+      MM_HIP(hipMemsetAsync(E->local_partial.p + T + 1, 0, sizeof(double), st));
+      MM_HIP(hipStreamSynchronize(st));
+    }
+  };
+  const int GROUP = 8;
+  while (!h_ctrl[1] && h_ctrl[0] < it_limit) {
+    if (!ctx->comm && !split) {                                  // one rank: the whole run is one launch
+      E->bar.zero(st);
+      em_loop_kernel<false><<<grid, blk, 0, st>>>(a);
+      MM_KERNEL_CHECK();
+    } else {
+      const int g_n = (int)std::min<long long>(GROUP, it_limit - h_ctrl[0]);   // (the same on every rank: h_ctrl holds all-reduced decisions)
+      for (int g = 0; g < g_n; ++g) {
+        if (!split) {
+          E->bar.zero(st);
+          em_loop_kernel<true><<<grid, blk, 0, st>>>(a);
+          MM_KERNEL_CHECK();
+        } else {
+          em_p1_kernel<<<grid, blk, 0, st>>>(a); MM_KERNEL_CHECK();
+          em_p2_kernel<<<grid, blk, 0, st>>>(a); MM_KERNEL_CHECK();
+          if (ctx->comm) em_p3_kernel<true><<<dim3(1), blk, 0, st>>>(a, E->n_wg); else em_p3_kernel<false><<<dim3(1), blk, 0, st>>>(a, E->n_wg);
+          MM_KERNEL_CHECK();
+        }
+        if (ctx->comm) {                                         // fEM.h:583-600, across GPUs instead of OpenMP threads
+          ncclResult_t rc = ncclAllReduce(E->local_partial.p, E->partial.p, (size_t)T + 2, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, st);
+          MM_REQUIRE(rc == ncclSuccess, MM_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
+          em_finalize_kernel<<<dim3(1), blk, 0, st>>>(E->partial.p, T, E->f_run.p, E->ctrl.p, E->ll_trace.p, cap, it_limit);
+          MM_KERNEL_CHECK();
+        }
+      }
+    }
+    fetch_ctrl();
   }
   const int n_iter = (int)(h_ctrl[0] - it0);
   if (stopped) *stopped = h_ctrl[1] == 1;

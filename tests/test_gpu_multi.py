@@ -149,6 +149,94 @@ def test_allreduce_iteration_equals_local_iteration():
     ea.close(); eb.close(); ctx_a.close(); ctx_b.close()
 
 
+
+def _em_problem(seed, n_reads, n_taxa, sigma=2.0, tied=True):
+    """skewed abundances, ambiguous reads, a pair of exactly tied taxa (identical mapping lists), one very abundant taxon (many sum items)"""
+    rng = np.random.default_rng(seed)
+    ab = rng.lognormal(0, sigma, n_taxa); ab /= ab.sum()
+    true = rng.choice(n_taxa, size=n_reads, p=ab)
+    n_extra = rng.integers(0, 6, size=n_reads)
+    off = np.concatenate([[0], np.cumsum(1 + n_extra)]).astype(np.int64)
+    taxon = np.empty(int(off[-1]), dtype=np.int32)
+    taxon[off[:-1]] = true
+    for r in np.nonzero(n_extra)[0]:
+        taxon[off[r] + 1:off[r + 1]] = rng.integers(0, n_taxa, size=n_extra[r])
+    if tied and n_taxa > 4:                                       # every mapping on taxon 1 also goes, identically, to taxon 2: exactly tied sums
+        taxon[taxon == 2] = 3
+        t1 = taxon == 1
+        idx = np.nonzero(t1)[0]
+        taxon2 = taxon.copy()
+        # rebuild with a twin entry behind every taxon-1 entry
+        rd = np.searchsorted(off, idx, side="right") - 1
+        add = np.bincount(rd, minlength=n_reads)
+        noff = np.concatenate([[0], np.cumsum(np.diff(off) + add)]).astype(np.int64)
+        nt = np.empty(int(noff[-1]), dtype=np.int32)
+        src = np.repeat(np.arange(len(taxon)), 1 + t1.astype(np.int64))
+        nt[:] = taxon2[src]
+        twin = np.concatenate([[False], src[1:] == src[:-1]])
+        nt[twin] = 2
+        taxon, off = nt, noff
+        mapq_src = rng.uniform(0.05, 1.0, len(taxon2))[src]
+    else:
+        mapq_src = rng.uniform(0.05, 1.0, len(taxon))
+    inv = 1.0 / rng.integers(1000, 5_000_000, size=n_taxa).astype(np.float64)
+    inv[2] = inv[1]
+    return off, taxon, mapq_src, inv[taxon], n_taxa
+
+
+@pytest.mark.parametrize("n_reads,n_taxa", [(60_000, 700), (900, 40), (3, 5)])
+def test_em_resident_kernel_equals_its_phases_as_launches(n_reads, n_taxa, monkeypatch):
+    """the whole EM run as ONE resident kernel (grid barriers between E step, per-taxon sums and normalisation + stop rule) gives, bit for bit,
+    what the same phases give as separate launches (MM_EM_SPLIT), also when a barrier gives up mid-run (MM_EM_BARRIER_TICKS=1: the run goes on
+    phase by phase from the last completed iteration); other grid sizes (another summation shape of the log-likelihood) agree to 1e-12; with a
+    one-rank communicator (kernel A | ncclAllReduce | kernel B per iteration) as well; exactly tied taxa stay exactly tied in every form"""
+    from metamaps_amd import capi, emhost
+    off, taxon, mapq, inv, T = _em_problem(7 + n_reads, n_reads, n_taxa)
+    f0 = np.full(T, 1.0 / T)
+
+    def run(env, comm=False):
+        for kk in ("MM_EM_SPLIT", "MM_EM_GRID", "MM_EM_BARRIER_TICKS"):
+            monkeypatch.delenv(kk, raising=False)
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        ctx = capi.Context(0)
+        if comm:
+            ctx.comm_init(capi.Context.comm_unique_id(), 0, 1)
+        e = ctx.em(off, taxon, mapq, inv, T)
+        f, lls = e.run(f0)
+        f5, lls5 = e.run(f0, max_iter=2)
+        fc, llsc, stopped = e.continue_run(1000)
+        post, best = e.posteriors(f)
+        e.close(); ctx.close()
+        assert stopped and np.array_equal(np.concatenate([lls5, llsc]), lls) and np.array_equal(fc, f)
+        return f, lls, best
+
+    f_a, ll_a, best_a = run({})
+    assert len(ll_a) >= 3 and abs(f_a.sum() - 1) < 1e-12
+    if T > 4:
+        assert f_a[1] == f_a[2] and f_a[1] > 0                    # the twins
+    f_b, ll_b, best_b = run({"MM_EM_SPLIT": "1"})
+    assert np.array_equal(f_a, f_b) and np.array_equal(ll_a, ll_b) and np.array_equal(best_a, best_b)
+    f_c, ll_c, best_c = run({"MM_EM_BARRIER_TICKS": "1"})
+    assert np.array_equal(f_a, f_c) and np.array_equal(ll_a, ll_c)
+    for grid in ("1", "7", "256"):
+        f_g, ll_g, _ = run({"MM_EM_GRID": grid})
+        assert len(ll_g) == len(ll_a) and np.allclose(ll_g, ll_a, rtol=1e-12, atol=0) and np.allclose(f_g, f_a, rtol=1e-10, atol=1e-300)
+        if T > 4:
+            assert f_g[1] == f_g[2]
+    for env in ({}, {"MM_EM_SPLIT": "1"}, {"MM_EM_BARRIER_TICKS": "1"}):
+        f_m, ll_m, _ = run(env, comm=True)
+        assert len(ll_m) == len(ll_a) and np.allclose(ll_m, ll_a, rtol=1e-12, atol=0) and np.allclose(f_m, f_a, rtol=1e-10, atol=1e-300)
+        if T > 4:
+            assert f_m[1] == f_m[2]
+    # against the host-driven loop (mm_em_iterate per iteration, numpy normalisation and stop rule)
+    ctx = capi.Context(0)
+    e = ctx.em(off, taxon, mapq, inv, T)
+    f_ref, lls_ref = emhost.run_em(lambda x: e.iterate_allreduce(x), T)
+    e.close(); ctx.close()
+    assert len(lls_ref) == len(ll_a) and np.allclose(lls_ref, ll_a, rtol=1e-12, atol=0) and np.allclose(f_ref, f_a, rtol=1e-10, atol=1e-300)
+
+
 def test_records_gathered_from_parts_equal_device_concat(oracle_lib):
     """mm_mapping_from_parts (host-side parts of chunks mapped elsewhere) == mm_mapping_concat, incl. mapping qualities"""
     from metamaps_amd import capi, synth
@@ -253,10 +341,11 @@ def test_classify_em_log_in_slices(small_run):
     for x in (a, b, c):
         _copy_run(o1, x)
     log_a = _em_log(_classify(a, small_run["db"].dir, ["--gpus", "1"]))
-    log_b = _em_log(_classify(b, small_run["db"].dir, ["--gpus", "1"], {"MM_EM_SLICE": "3"}))
-    assert log_a == log_b and len(log_a) > 4
-    for suf in (".EM", ".EM.WIMP", ".EM.reads2Taxon"):
-        assert open(a + suf).read() == open(b + suf).read(), suf
+    for sl in ("1", "2", "3", "4"):                               # (round-3 advisor: a slice whose last iteration is the converging one must not run on)
+        log_b = _em_log(_classify(b, small_run["db"].dir, ["--gpus", "1"], {"MM_EM_SLICE": sl}))
+        assert log_a == log_b and len(log_a) > 4, sl
+        for suf in (".EM", ".EM.WIMP", ".EM.reads2Taxon"):
+            assert open(a + suf).read() == open(b + suf).read(), (suf, sl)
     log_c = _em_log(_classify(c, small_run["db"].dir, ["--gpus", "1"], {"MM_EM_MAX_ITER": "3"}))
     assert [l for l in log_c if l.startswith("EM round")] == ["EM round 0", "EM round 1", "EM round 2"]
 

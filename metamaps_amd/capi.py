@@ -460,6 +460,10 @@ class Mapping:
     def add_qualities(self, k: int):
         self.ctx.check(lib().mm_mapping_add_qualities(self.ctx.h, self.h, None, k))
 
+    def release_intermediates(self):
+        """frees everything but the records (minimizers, sketches, hits, candidates): what a chunk mapping keeps while the other chunks are mapped"""
+        self.ctx.check(lib().mm_mapping_release_intermediates(self.h))
+
     def keep_best(self, k: int):
         """default (non --all) reporting: per read keep identity >= best - 1.0"""
         self.ctx.check(lib().mm_mapping_keep_best(self.ctx.h, self.h, k))

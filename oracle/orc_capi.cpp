@@ -116,6 +116,22 @@ int orc_classify(const char* mapped, const char* db, double* ll, int ll_cap) {
   } catch (std::exception& e) { std::cerr << "oracle: " << e.what() << "\n"; return -1; }
 }
 
+// classify with given start frequencies (file of "taxon value" lines) instead of uniform ones
+int orc_classify_from(const char* mapped, const char* db, const char* f0File, double* ll, int ll_cap) {
+  try {
+    std::map<std::string, double> f0;
+    { std::ifstream s(f0File); std::string t; double v; while (s >> t >> v) f0[t] = v; }
+    EMTrace tr = do_em(mapped, db, true, 10000, &f0);
+    for (int i = 0; i < (int)tr.ll.size() && i < ll_cap; ++i) ll[i] = tr.ll[i];
+    return (int)tr.ll.size();
+  } catch (std::exception& e) { std::cerr << "oracle: " << e.what() << "\n"; return -1; }
+}
+// the reference's example run pushed through the output writer: see finish_from_posteriors (orc_post.hpp)
+int orc_finish_from_posteriors(const char* emFile, const char* metaPrefix, const char* db, const char* outPrefix) {
+  try { finish_from_posteriors(emFile, metaPrefix, db, outPrefix); return 0; }
+  catch (std::exception& e) { std::cerr << "oracle: " << e.what() << "\n"; return -1; }
+}
+
 // every record SeqReader returns, as tests/test_ref_host.py prints them for the real kseq: "name len fnv1a(seq)" lines + "END code"
 long orc_read_dump(const char* path, char* out, long cap) {
   SeqReader rd(path);

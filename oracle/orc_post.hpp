@@ -524,54 +524,12 @@ static inline void write_wimp(const std::string& fn, const Taxonomy& T, std::map
   }
 }
 
-// meta/fEM.h:466-803 (EM loop + .EM / .EM.reads2Taxon / .krona / .EM.WIMP).  Single summation order
-// (the reference sums per OpenMP thread chunk, then across threads; with -t 1 it is exactly this order).
-static inline EMTrace do_em(const std::string& mapped, const std::string& dbDir, bool writeFiles = true, size_t minReadsU = 10000) {
-  EMTrace tr;
-  std::set<std::string> taxa;                                    // :1366-1394
-  {
-    std::ifstream s(mapped); std::string ln;
-    while (std::getline(s, ln)) if (!ln.empty()) taxa.insert(extract_taxon(split(ln, " ").at(5)));
-  }
-  if (taxa.empty()) throw std::runtime_error("No relevant taxon IDs found in your mappings file");
-  std::map<std::string, size_t> st;                              // :398-421
-  { std::ifstream s(mapped + ".meta"); std::string a; size_t b; while (s >> a >> b) st[a] = b; }
-  size_t nUnmapped = st.at("ReadsNotMapped"), nTooShort = st.at("ReadsTooShort"), nTotal = st.at("TotalReads");
-  TaxonInfo TI;                                                  // :1320-1364
-  {
-    std::ifstream s(dbDir + "/taxonInfo.txt"); std::string ln;
-    if (!s.is_open()) { std::cerr << "Could not open file " << dbDir << "/taxonInfo.txt\n"; exit(1); }
-    while (std::getline(s, ln)) {
-      if (ln.empty()) continue;
-      auto f = split(ln, " ");
-      for (auto& c : split(f.at(1), ";")) { auto kv = split(c, "="); TI[f.at(0)][kv.at(0)] = std::stoull(kv.at(1)); }
-    }
-  }
-  Taxonomy T(dbDir + "/taxonomy");
-  std::map<std::string, double> f;
-  for (auto& t : taxa) f[t] = 1 / (double)taxa.size();           // :491-495
-  auto groups = group_reads(mapped);
-  double llPrev = 0; size_t iter = 0; bool go = true;
-  while (go) {                                                   // :501-661
-    std::map<std::string, double> fn = f; for (auto& e : fn) e.second = 0;
-    double ll = 0;
-    for (auto& g : groups) {
-      auto locs = mapping_locations(TI, f, g);
-      double lr = 0;
-      for (auto& l : locs) { lr += l.l; fn.at(l.taxon) += l.p; }
-      ll += std::log(lr);
-    }
-    double sum = 0; for (auto& e : fn) sum += e.second;
-    for (auto& e : fn) e.second /= sum;
-    tr.ll.push_back(ll);
-    if (iter > 0) {
-      double diff = ll - llPrev, rel = 1 - ll / llPrev;
-      if (diff <= 1 && rel < 0.0001) go = false;                 // :636
-    }
-    f = fn; ++iter; llPrev = ll;
-  }
-  tr.f = f;
-  if (!writeFiles) return tr;
+// everything doEM writes behind its loop (fEM.h:663-803): .EM, .EM.reads2Taxon, .krona, .EM.lengthAndIdentitiesPerMappingUnit, cleanF (:1135-1163),
+// .EM.WIMP, .EM.contigCoverage, .EM.evidenceUnknownSpecies.  `locs_of(group)` = the read's mapping locations with their final posteriors.
+template <typename LocsOf>
+static inline void write_classify_outputs(const std::string& mapped, const std::string& dbDir, const Taxonomy& T, const TaxonInfo& TI, std::map<std::string, double> f,
+                                          const std::map<std::string, size_t>& st, const std::vector<std::vector<std::string>>& groups, LocsOf locs_of, size_t minReadsU) {
+  const size_t nUnmapped = st.at("ReadsNotMapped"), nTooShort = st.at("ReadsTooShort"), nTotal = st.at("TotalReads");
   std::ofstream em(mapped + ".EM"), r2t(mapped + ".EM.reads2Taxon"), kr(mapped + ".EM.reads2Taxon.krona"), li(mapped + ".EM.lengthAndIdentitiesPerMappingUnit");
   li << "AnalysisLevel\tID\treadI\tIdentity\tLength\n";     // :686
   std::map<std::string, size_t> readsPer;
@@ -580,7 +538,7 @@ static inline EMTrace do_em(const std::string& mapped, const std::string& dbDir,
   long long maxReadLen = -1;                                     // :692
   size_t readI = 0;
   for (auto& g : groups) {                                       // :684-779
-    auto locs = mapping_locations(TI, f, g);
+    auto locs = locs_of(g);
     std::string rid;
     for (size_t i = 0; i < g.size(); ++i) {
       auto fld = split(g[i], " "); rid = fld.at(0);
@@ -617,7 +575,101 @@ static inline EMTrace do_em(const std::string& mapped, const std::string& dbDir,
   coverage.write(mapped + ".EM.contigCoverage", T);
   if (!write_unknown_species(mapped + ".EM.evidenceUnknownSpecies", dbDir, T, coverage, identPerTaxon, maxReadLen, minReadsU))
     std::cerr << "no contigNstats_windowSize_1000.txt in " << dbDir << ": .EM.evidenceUnknownSpecies not written\n";
+}
+
+// meta/fEM.h:466-803 (EM loop + .EM / .EM.reads2Taxon / .krona / .EM.WIMP).  Single summation order
+// (the reference sums per OpenMP thread chunk, then across threads; with -t 1 it is exactly this order).
+// f0: start frequencies instead of the uniform ones of :491-495 (tests/test_example_pins.py starts the loop AT a fixed point to see it hold it)
+static inline EMTrace do_em(const std::string& mapped, const std::string& dbDir, bool writeFiles = true, size_t minReadsU = 10000,
+                            const std::map<std::string, double>* f0 = nullptr) {
+  EMTrace tr;
+  std::set<std::string> taxa;                                    // :1366-1394
+  {
+    std::ifstream s(mapped); std::string ln;
+    while (std::getline(s, ln)) if (!ln.empty()) taxa.insert(extract_taxon(split(ln, " ").at(5)));
+  }
+  if (taxa.empty()) throw std::runtime_error("No relevant taxon IDs found in your mappings file");
+  std::map<std::string, size_t> st;                              // :398-421
+  { std::ifstream s(mapped + ".meta"); std::string a; size_t b; while (s >> a >> b) st[a] = b; }
+  (void)st.at("ReadsNotMapped"); (void)st.at("ReadsTooShort"); (void)st.at("TotalReads");
+  TaxonInfo TI;                                                  // :1320-1364
+  {
+    std::ifstream s(dbDir + "/taxonInfo.txt"); std::string ln;
+    if (!s.is_open()) { std::cerr << "Could not open file " << dbDir << "/taxonInfo.txt\n"; exit(1); }
+    while (std::getline(s, ln)) {
+      if (ln.empty()) continue;
+      auto f = split(ln, " ");
+      for (auto& c : split(f.at(1), ";")) { auto kv = split(c, "="); TI[f.at(0)][kv.at(0)] = std::stoull(kv.at(1)); }
+    }
+  }
+  Taxonomy T(dbDir + "/taxonomy");
+  std::map<std::string, double> f;
+  for (auto& t : taxa) f[t] = f0 ? (f0->count(t) ? f0->at(t) : 0.0) : 1 / (double)taxa.size();   // :491-495
+  auto groups = group_reads(mapped);
+  double llPrev = 0; size_t iter = 0; bool go = true;
+  while (go) {                                                   // :501-661
+    std::map<std::string, double> fn = f; for (auto& e : fn) e.second = 0;
+    double ll = 0;
+    for (auto& g : groups) {
+      auto locs = mapping_locations(TI, f, g);
+      double lr = 0;
+      for (auto& l : locs) { lr += l.l; fn.at(l.taxon) += l.p; }
+      ll += std::log(lr);
+    }
+    double sum = 0; for (auto& e : fn) sum += e.second;
+    for (auto& e : fn) e.second /= sum;
+    tr.ll.push_back(ll);
+    if (iter > 0) {
+      double diff = ll - llPrev, rel = 1 - ll / llPrev;
+      if (diff <= 1 && rel < 0.0001) go = false;                 // :636
+    }
+    f = fn; ++iter; llPrev = ll;
+  }
+  tr.f = f;
+  if (!writeFiles) return tr;
+  write_classify_outputs(mapped, dbDir, T, TI, f, st, groups, [&](const std::vector<std::string>& g) { return mapping_locations(TI, f, g); }, minReadsU);
   return tr;
+}
+
+// The part of doEM behind the loop (fEM.h:663-803) on its own, fed with mappings that ALREADY carry final posteriors in field 14 (the
+// format of PREFIX.EM): f is one M step from them (fEM.h:575, :606-615), everything else as in do_em.  Exists so that the reference's
+// own example run (tests/golden/example/example.EM, whose field 14 the reference computed) can be pushed through this writer and held
+// against the reference's example.EM.WIMP / .reads2Taxon / .krona / .lengthAndIdentitiesPerMappingUnit (tests/test_example_pins.py).
+static inline void finish_from_posteriors(const std::string& emFile, const std::string& metaPrefix, const std::string& dbDir, const std::string& outPrefix) {
+  std::map<std::string, size_t> st;
+  { std::ifstream s(metaPrefix + ".meta"); std::string a; size_t b; while (s >> a >> b) st[a] = b; }
+  TaxonInfo TI;
+  {
+    std::ifstream s(dbDir + "/taxonInfo.txt"); std::string ln;
+    while (std::getline(s, ln)) {
+      if (ln.empty()) continue;
+      auto f = split(ln, " ");
+      for (auto& c : split(f.at(1), ";")) { auto kv = split(c, "="); TI[f.at(0)][kv.at(0)] = std::stoull(kv.at(1)); }
+    }
+  }
+  Taxonomy T(dbDir + "/taxonomy");
+  auto groups = group_reads(emFile);
+  auto locs_of = [&](const std::vector<std::string>& g) {
+    std::vector<Loc> locs;
+    for (auto& ln : g) {
+      auto fld = split(ln, " ");
+      Loc l; l.contig = fld.at(5); l.taxon = extract_taxon(l.contig);
+      l.start = std::stoull(fld.at(7)); l.stop = std::stoull(fld.at(8));
+      l.identity = std::stod(fld.at(9)) / 100.0; l.readLen = (size_t)std::stoi(fld.at(1));
+      l.p = std::stod(fld.at(13)); l.l = 0;
+      locs.push_back(l);
+    }
+    return locs;
+  };
+  std::map<std::string, double> f;
+  for (auto& g : groups) for (auto& l : locs_of(g)) f[l.taxon] += l.p;
+  double sum = 0; for (auto& e : f) sum += e.second;
+  for (auto& e : f) e.second /= sum;
+  // outputs next to outPrefix; the unmapped read list is taken from metaPrefix
+  {
+    std::ifstream src(metaPrefix + ".meta.unmappedReadsLengths"); std::ofstream dst(outPrefix + ".meta.unmappedReadsLengths"); dst << src.rdbuf();
+  }
+  write_classify_outputs(outPrefix, dbDir, T, TI, f, st, groups, locs_of, 10000);
 }
 
 }  // namespace orc

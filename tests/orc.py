@@ -48,6 +48,8 @@ class Oracle:
                                    C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long]
         L.orc_map_directly.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_void_p]
         L.orc_classify.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int]
+        L.orc_finish_from_posteriors.argtypes = [C.c_char_p] * 4
+        L.orc_classify_from.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int]
         self.L = L
 
     def kmer_hash(self, s: bytes, k: int) -> int:

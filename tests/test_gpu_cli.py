@@ -577,3 +577,30 @@ def test_cli_reference_parsed_in_parallel_blocks(oracle_lib, tmp_path, monkeypat
     subprocess.run([orc.CLI, "mapDirectly", "--all", "-r", ref_path, "-q", rd["path"], "-o", pb], check=True, capture_output=True, timeout=900)
     _cmp_table(str(tmp_path / "gpu_default"), pb, " ", {13})
     assert open(str(tmp_path / "gpu_default") + ".meta").read() == open(pb + ".meta").read()
+
+
+def test_cli_device_cap_decides_placement(tmp_path):
+    """BASELINE config 5's decision — resident / spread over the devices / streamed — taken BY THE CLI, not by a flag: MM_DEVICE_BYTES_CAP (a test
+    hook of the library's allocator: allocations beyond it fail, mm_ctx_device_info reports it) makes a 100 Mbp reference "larger than
+    the device", so that `mapDirectly --maxmemory-bytes ...` must go to chunk streaming on one device and to sharding on three logical
+    devices by itself, with the allocator enforcing the cap while it does.  Same files as the uncapped resident run."""
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=50, genome_len=2_000_000, seed=5)
+    rd = synth.make_reads(db, str(tmp_path / "r.fq"), n_reads=1500, read_len=6000, seed=3)
+    base = ["mapDirectly", "--all", "-r", db.fasta, "-q", rd["path"], "--maxmemory-bytes", "300000000", "--workers-per-gpu", "1"]
+    cap = int(os.environ.get("MM_TEST_DEVICE_CAP", 800 << 20))   # 100 Mbp x 5.5 B x 1.2 = 660 MB > 0.8 x 800 MB; three devices: 660 x 1.3 / 3 = 286 MB fits
+    env = dict(os.environ, MM_DEVICE_BYTES_CAP=str(cap))
+    runs = {}
+    for tag, extra, e in (("resident", [], os.environ), ("auto_stream", [], env), ("auto_shard", ["--devices", "0,0,0"], env)):
+        o = str(tmp_path / tag)
+        p = subprocess.run([CLI] + base + ["-o", o] + extra, capture_output=True, timeout=900, env=dict(e))
+        assert p.returncode == 0, (tag, p.stderr.decode()[-1500:], p.stdout.decode()[-1500:])
+        runs[tag] = (open(o).read(), open(o + ".meta").read(), p.stdout.decode())
+    assert "does not fit one device" not in runs["resident"][2]
+    assert "chunk indexes are built and mapped one after the other" in runs["auto_stream"][2], runs["auto_stream"][2][-1500:]
+    assert "the chunk indexes are spread over the devices" in runs["auto_shard"][2], runs["auto_shard"][2][-1500:]
+    n_chunks = runs["resident"][2].count("INFO, index chunk ")
+    assert n_chunks >= 4, runs["resident"][2][-1500:]
+    assert len(runs["resident"][0]) > 100_000
+    for tag in ("auto_stream", "auto_shard"):
+        assert runs[tag][0] == runs["resident"][0] and runs[tag][1] == runs["resident"][1], tag

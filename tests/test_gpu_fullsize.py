@@ -31,8 +31,8 @@ COMM = dict(seed=20260928, n_genomes=12000, n_species=3000, n_genera=600, median
             strain_div_min=0.001, strain_div_max=0.05, genus_div_min=0.15, genus_div_max=0.25, strain_indel_events=8,
             human_contigs=24, human_bases=int(3.1e9), repeat_fraction=0.45, n_fraction=0.01, n_repeat_families=1000,
             total_bases_target=26_762_276_280)
-N_READS, RLEN = 20_000, 10_000
-N_MIXED, MIXED_MIN, MIXED_MAX = 4_000, 1_000, 50_000
+N_READS, RLEN = 100_000, 10_000                               # configs[1]: the bench batch at its size
+N_MIXED, MIXED_MIN, MIXED_MAX = 32_000, 1_000, 50_000         # configs[3]: a quarter of the per-GPU share of 125 000 (0.4 Gbp in ONE call; the CLI maps such reads in batches of <= 0.256 Gbp)
 INT_MAX = 2**31 - 1
 GIB = 1 << 30
 
@@ -276,6 +276,8 @@ def test_resident_chunks_equal_whole_index(world):
     for ix, t in zip(world["chunk_idx"], thr):                    # (chunks 2.. reuse the sketches of the first mapping, as the CLI does; the
         ix.set_freq_threshold(t)                                  #  streamed run below computes them per chunk: the two must agree)
         parts.append(ctx.map_batch(ix, mixed, K, W, sketch_of=parts[0] if parts else None))
+        if len(parts) > 1:
+            parts[-1].release_intermediates()                     # (the first part keeps the sketches the others borrow)
     U = capi.Mapping.concat(ctx, parts, base); U.add_qualities(K)
     off, rec = U.fetch()
     world["res3_off"], world["res3_rec"] = off.copy(), rec.copy()

@@ -577,6 +577,9 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
   const dim3 grid((unsigned)E->n_wg), blk(256);
   const bool force_split = getenv("MM_EM_SPLIT") != nullptr;
   bool split = force_split || ctx->em_split;
+  // a communicator of ONE rank has nothing to exchange: the run is the resident kernel, as without a communicator (MM_EM_FORCE_COLLECTIVE=1
+  // keeps kernel A | ncclAllReduce | kernel B also then: how the tests drive the collective path on a one-GPU box)
+  const bool collective = ctx->comm && (ctx->comm_size > 1 || getenv("MM_EM_FORCE_COLLECTIVE") != nullptr);
   auto fetch_ctrl = [&] {
     MM_HIP(hipMemcpyAsync(h_ctrl, E->ctrl.p, sizeof h_ctrl, hipMemcpyDeviceToHost, st));
     MM_HIP(hipStreamSynchronize(st));
@@ -593,7 +596,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
   };
   const int GROUP = 8;
   while (!h_ctrl[1] && h_ctrl[0] < it_limit) {
-    if (!ctx->comm && !split) {                                  // one rank: the whole run is one launch
+    if (!collective && !split) {                                 // one rank: the whole run is one launch
       E->bar.zero(st);
       em_loop_kernel<false><<<grid, blk, 0, st>>>(a);
       MM_KERNEL_CHECK();
@@ -607,10 +610,10 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
         } else {
           em_p1_kernel<<<grid, blk, 0, st>>>(a); MM_KERNEL_CHECK();
           em_p2_kernel<<<grid, blk, 0, st>>>(a); MM_KERNEL_CHECK();
-          if (ctx->comm) em_p3_kernel<true><<<dim3(1), blk, 0, st>>>(a, E->n_wg); else em_p3_kernel<false><<<dim3(1), blk, 0, st>>>(a, E->n_wg);
+          if (collective) em_p3_kernel<true><<<dim3(1), blk, 0, st>>>(a, E->n_wg); else em_p3_kernel<false><<<dim3(1), blk, 0, st>>>(a, E->n_wg);
           MM_KERNEL_CHECK();
         }
-        if (ctx->comm) {                                         // fEM.h:583-600, across GPUs instead of OpenMP threads
+        if (collective) {                                        // fEM.h:583-600, across GPUs instead of OpenMP threads
           ncclResult_t rc = ncclAllReduce(E->local_partial.p, E->partial.p, (size_t)T + 2, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, st);
           MM_REQUIRE(rc == ncclSuccess, MM_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
           em_finalize_kernel<<<dim3(1), blk, 0, st>>>(E->partial.p, T, E->f_run.p, E->ctrl.p, E->ll_trace.p, cap, it_limit);
@@ -630,7 +633,12 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
 
 void em_posteriors(mm_em* E, const double* f, double* post, int64_t* best) {
   hipStream_t st = E->ctx->stream;
-  em_step_device(E, f);
+  E->f.upload(f, (size_t)E->n_taxa, st);                         // the E step alone (fEM.h:696-716): no sums
+  if (E->n_reads > 0) {
+    em_estep_kernel<<<dim3((unsigned)ceil_div(E->n_reads, 128)), dim3(128), 0, st>>>(E->read_off.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->f.p,
+                                                                                 E->n_reads, E->post.p, E->ll_read.p);
+    MM_KERNEL_CHECK();
+  }
   if (post) E->post.download(post, (size_t)E->n_entries, st);
   if (best && E->n_reads > 0) {
     DBuf<int64_t> b((size_t)E->n_reads);

@@ -89,11 +89,13 @@ def test_replicated_chunks_over_devices(small_run):
 
 
 def test_classify_through_rccl_one_rank(small_run):
-    """`classify --gpus 1`: the EM loop goes through ncclCommInitRank / ncclAllReduce (one rank) and writes the oracle's files"""
+    """`classify --gpus 1` with MM_EM_FORCE_COLLECTIVE=1: the EM loop goes through ncclCommInitRank / kernel A | ncclAllReduce | kernel B (one rank)
+    and writes the oracle's files; without the switch the one-rank communicator takes the resident kernel: the same files"""
     o1, _, _ = _gpu_map(small_run, "cls", [])
-    p = subprocess.run([CLI, "classify", "--DB", small_run["db"].dir, "--mappings", o1, "--minreads", "3", "--gpus", "1"], capture_output=True, timeout=900)
-    assert p.returncode == 0, p.stderr.decode()[-2000:]
-    _classify_files_equal(o1, small_run["oracle"]["plain"][0])
+    for env in (dict(os.environ, MM_EM_FORCE_COLLECTIVE="1"), dict(os.environ)):
+        p = subprocess.run([CLI, "classify", "--DB", small_run["db"].dir, "--mappings", o1, "--minreads", "3", "--gpus", "1"], capture_output=True, timeout=900, env=env)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        _classify_files_equal(o1, small_run["oracle"]["plain"][0])
 
 
 def test_two_physical_gpus(small_run):
@@ -111,7 +113,7 @@ def test_two_physical_gpus(small_run):
     _classify_files_equal(o1, small_run["oracle"]["plain"][0])
 
 
-def test_allreduce_iteration_equals_local_iteration():
+def test_allreduce_iteration_equals_local_iteration(monkeypatch):
     """mm_comm_init(nranks = 1), then mm_em_iterate_allreduce (device partial sums -> ncclAllReduce -> normalise) must equal
     mm_em_iterate + the same normalisation on the host, bit for bit; mm_comm_allreduce_f64 is the identity"""
     from metamaps_amd import capi
@@ -141,6 +143,7 @@ def test_allreduce_iteration_equals_local_iteration():
         f = f_b
     # the device-resident loop (mm_em_run), with and without the communicator, against the host-driven loop above
     from metamaps_amd import emhost
+    monkeypatch.setenv("MM_EM_FORCE_COLLECTIVE", "1")             # the loop with the ncclAllReduce inside, also on this one rank
     f_ref, lls_ref = emhost.run_em(lambda x: ea.iterate_allreduce(x), n_taxa)
     for e in (ea, eb):
         f_run, lls_run = e.run(np.full(n_taxa, 1.0 / n_taxa))
@@ -195,10 +198,12 @@ def test_em_resident_kernel_equals_its_phases_as_launches(n_reads, n_taxa, monke
     f0 = np.full(T, 1.0 / T)
 
     def run(env, comm=False):
-        for kk in ("MM_EM_SPLIT", "MM_EM_GRID", "MM_EM_BARRIER_TICKS"):
+        for kk in ("MM_EM_SPLIT", "MM_EM_GRID", "MM_EM_BARRIER_TICKS", "MM_EM_FORCE_COLLECTIVE"):
             monkeypatch.delenv(kk, raising=False)
         for kk, v in env.items():
             monkeypatch.setenv(kk, v)
+        if comm:
+            monkeypatch.setenv("MM_EM_FORCE_COLLECTIVE", "1")     # (a one-rank communicator alone takes the resident kernel: nothing to exchange)
         ctx = capi.Context(0)
         if comm:
             ctx.comm_init(capi.Context.comm_unique_id(), 0, 1)
@@ -229,6 +234,13 @@ def test_em_resident_kernel_equals_its_phases_as_launches(n_reads, n_taxa, monke
         assert len(ll_m) == len(ll_a) and np.allclose(ll_m, ll_a, rtol=1e-12, atol=0) and np.allclose(f_m, f_a, rtol=1e-10, atol=1e-300)
         if T > 4:
             assert f_m[1] == f_m[2]
+    monkeypatch.delenv("MM_EM_FORCE_COLLECTIVE", raising=False)
+    ctx = capi.Context(0)                                         # a one-rank communicator without the switch: the resident kernel, bit for bit
+    ctx.comm_init(capi.Context.comm_unique_id(), 0, 1)
+    e = ctx.em(off, taxon, mapq, inv, T)
+    f_1, ll_1 = e.run(f0)
+    e.close(); ctx.close()
+    assert np.array_equal(f_1, f_a) and np.array_equal(ll_1, ll_a)
     # against the host-driven loop (mm_em_iterate per iteration, numpy normalisation and stop rule)
     ctx = capi.Context(0)
     e = ctx.em(off, taxon, mapq, inv, T)
@@ -342,7 +354,7 @@ def test_classify_em_log_in_slices(small_run):
         _copy_run(o1, x)
     log_a = _em_log(_classify(a, small_run["db"].dir, ["--gpus", "1"]))
     for sl in ("1", "2", "3", "4"):                               # (round-3 advisor: a slice whose last iteration is the converging one must not run on)
-        log_b = _em_log(_classify(b, small_run["db"].dir, ["--gpus", "1"], {"MM_EM_SLICE": sl}))
+        log_b = _em_log(_classify(b, small_run["db"].dir, ["--gpus", "1"], {"MM_EM_SLICE": sl, "MM_EM_FORCE_COLLECTIVE": "1"} if sl == "3" else {"MM_EM_SLICE": sl}))
         assert log_a == log_b and len(log_a) > 4, sl
         for suf in (".EM", ".EM.WIMP", ".EM.reads2Taxon"):
             assert open(a + suf).read() == open(b + suf).read(), (suf, sl)

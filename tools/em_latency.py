@@ -1,0 +1,61 @@
+"""Latency of one EM iteration (K9) on an idle GPU, on a problem of the bench's shape (10^5 reads, ~4 mappings per read, 12 001 taxa of
+which a few hundred have mappings, lognormal abundances): the resident kernel at several grid sizes, the same phases as separate launches
+(MM_EM_SPLIT), and the collective form (kernel A | ncclAllReduce | kernel B) on a one-rank communicator.  Prints one line per variant.
+Usage: python tools/em_latency.py [n_reads]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from metamaps_amd import capi
+
+
+def problem(n_reads, n_taxa=12001, n_present=300, seed=1):
+    rng = np.random.default_rng(seed)
+    present = rng.choice(n_taxa, size=n_present, replace=False)
+    ab = rng.lognormal(0, 1.5, n_present); ab /= ab.sum()
+    true = rng.choice(n_present, size=n_reads, p=ab)
+    extra = rng.poisson(3.2, size=n_reads)
+    off = np.concatenate([[0], np.cumsum(1 + extra)]).astype(np.int64)
+    taxon = present[rng.integers(0, n_present, size=int(off[-1]))].astype(np.int32)
+    taxon[off[:-1]] = present[true]
+    mapq = rng.uniform(0.01, 1.0, len(taxon))
+    inv = 1.0 / rng.integers(1_000_000, 8_000_000, size=len(taxon)).astype(np.float64)
+    return off, taxon, mapq, inv, n_taxa
+
+
+def main():
+    n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+    off, taxon, mapq, inv, T = problem(n_reads)
+    print(f"{n_reads} reads, {len(taxon)} mappings, {T} taxa, largest taxon {np.bincount(taxon).max()} mappings")
+    f0 = np.full(T, 1.0 / T)
+    variants = [("resident grid 128", {}), ("resident grid 64", {"MM_EM_GRID": "64"}), ("resident grid 256", {"MM_EM_GRID": "256"}), ("resident grid 32", {"MM_EM_GRID": "32"}),
+                ("phases as launches", {"MM_EM_SPLIT": "1"}), ("collective, one rank", {"MM_EM_FORCE_COLLECTIVE": "1", "_comm": "1"}),
+                ("collective + split", {"MM_EM_FORCE_COLLECTIVE": "1", "MM_EM_SPLIT": "1", "_comm": "1"})]
+    for name, env in variants:
+        for k in ("MM_EM_GRID", "MM_EM_SPLIT", "MM_EM_FORCE_COLLECTIVE"):
+            os.environ.pop(k, None)
+        for k, v in env.items():
+            if not k.startswith("_"):
+                os.environ[k] = v
+        ctx = capi.Context(0)
+        if env.get("_comm"):
+            ctx.comm_init(capi.Context.comm_unique_id(), 0, 1)
+        e = ctx.em(off, taxon, mapq, inv, T)
+        e.run(f0, max_iter=3)                                     # first launch, allocation of the loop's buffers
+        best = None
+        for n_it in (40, 40, 200):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            f, lls = e.run(f0, max_iter=n_it)
+            dt = time.perf_counter() - t0
+            per = dt / max(len(lls), 1) * 1e6
+            best = per if best is None else min(best, per)
+        print(f"{name:<24} {best:8.1f} us per iteration ({len(lls)} iterations in the last run, ll {lls[-1]:.6f})")
+        e.close(); ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,7 +132,7 @@ struct DevAlloc {
     // The last GiB of the device stays with the runtime: a device filled to the brim by hipMalloc lets a later kernel launch fail inside the
     // runtime (its own allocations: HSA_STATUS_ERROR_OUT_OF_RESOURCES, the queue is aborted and the process with it — seen with three worker
     // contexts beside four resident chunk indexes); a request that would take it is treated as one that failed for lack of memory.
-    constexpr size_t RUNTIME_RESERVE = (size_t)1 << 30;
+    const size_t RUNTIME_RESERVE = dev_meter().cap > 0 ? 0 : (size_t)1 << 30;   // (under the test hook MM_DEVICE_BYTES_CAP the "device" ends at the cap, far below the real one)
     bool refuse = false;
     if (want >= ((size_t)64 << 20)) {                            // (headroom only while a fifth of the device is free: resident chunk indexes can leave less)
       size_t fr = 0, tot = 0;

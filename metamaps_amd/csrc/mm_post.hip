@@ -347,8 +347,8 @@ void em_iterate_allreduce(mm_em* E, const double* f, double* f_next, double* ll)
 struct EmLoop {
   const int64_t* read_off; const int32_t* taxon; const double* mapq; const double* inv_nloc;
   int64_t n_reads;
-  double* post;
-  const int64_t* perm; const int64_t* item_lo; const int64_t* item_hi; int n_items;
+  double* post_sorted; const int64_t* pos;                        // posteriors in taxon-sorted order (P1 writes entry i to pos[i], the inverse of perm[])
+  const int64_t* item_lo; const int64_t* item_hi; int n_items;
   const int32_t* present; const int32_t* pt_item; int n_present;   // items of present taxon p: [pt_item[p], pt_item[p + 1])
   double* item_sum; double* wg_ll;
   double* f; double* local_partial; int32_t n_taxa;
@@ -357,31 +357,64 @@ struct EmLoop {
   long long barrier_ticks;                                        // a barrier not released within this many ticks of the 100 MHz wall clock gives up (ctrl[4])
 };
 constexpr int EM_ITEM = 512;
+constexpr int EM_P3_LDS_ITEMS = 4096;
 constexpr long long EM_BARRIER_TICKS = 200000000LL;               // 2 s of the 100 MHz wall clock (MM_EM_BARRIER_TICKS: test hook)
 
+// P1.  A thread walks its reads; the mappings of a read are taken four at a time with every load of the four issued before the first is
+// used (clamped indices instead of branches: a loop with one dependent load chain per mapping cost ~1 us of latency per mapping, 30 us
+// per iteration).  The likelihoods are added in mapping order, as the reference adds them (fEM.h:353-358).  The posterior goes straight
+// to its place in the taxon-sorted array P2 reads (pos[i]): P2 then streams instead of gathering through perm[].
 __device__ inline void em_p1(const EmLoop& a, int wg, int n_wg, double* sh) {
   const int tid = threadIdx.x;
   const int64_t stride = (int64_t)n_wg * 256;
   double ll = 0;
   for (int64_t r = (int64_t)wg * 256 + tid; r < a.n_reads; r += stride) {
     const int64_t lo = a.read_off[r], hi = a.read_off[r + 1];
-    double sum = 0;
-    for (int64_t i = lo; i < hi; ++i) { const double l = a.f[a.taxon[i]] * a.inv_nloc[i] * a.mapq[i]; a.post[i] = l; sum += l; }   // fEM.h:353
-    for (int64_t i = lo; i < hi; ++i) a.post[i] = a.post[i] / sum;                                                                    // :361
-    if (hi > lo) ll += log(sum);                                                                                                      // :578
+    if (hi <= lo) continue;
+    const int64_t last = hi - 1;
+    double sum = 0, l4[4]; int64_t p4[4];
+    for (int64_t c = lo; c < hi; c += 4) {
+      int t4[4]; double w4[4], q4[4], f4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int64_t i = c + u < last ? c + u : last; t4[u] = a.taxon[i]; w4[u] = a.inv_nloc[i]; q4[u] = a.mapq[i]; p4[u] = a.pos[i]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) f4[u] = a.f[t4[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { l4[u] = f4[u] * w4[u] * q4[u]; if (c + u < hi) sum += l4[u]; }   // fEM.h:353
+    }
+    if (hi - lo <= 4) {                                            // the usual read: everything is still in registers
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (lo + u < hi) a.post_sorted[p4[u]] = l4[u] / sum;              // :361
+    } else {
+      for (int64_t c = lo; c < hi; c += 4) {
+        int t4[4]; double w4[4], q4[4], f4[4]; int64_t q_pos[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int64_t i = c + u < last ? c + u : last; t4[u] = a.taxon[i]; w4[u] = a.inv_nloc[i]; q4[u] = a.mapq[i]; q_pos[u] = a.pos[i]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f4[u] = a.f[t4[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (c + u < hi) a.post_sorted[q_pos[u]] = (f4[u] * w4[u] * q4[u]) / sum;
+      }
+    }
+    ll += log(sum);                                                // :578
   }
   sh[tid] = ll;
   __syncthreads();
   for (int d = 128; d > 0; d >>= 1) { if (tid < d) sh[tid] += sh[tid + d]; __syncthreads(); }
   if (tid == 0) a.wg_ll[wg] = sh[0];
 }
+// P2.  An item = up to 512 consecutive posteriors of one taxon (read order): lane l adds l, l + 64, ... in order, then a butterfly.
 __device__ inline void em_p2(const EmLoop& a, int wg, int n_wg) {
   const int lane = threadIdx.x & 63;
   const int n_waves = n_wg * 4;
   for (int it = wg * 4 + (threadIdx.x >> 6); it < a.n_items; it += n_waves) {
-    const int64_t hi = a.item_hi[it];
+    const int64_t lo = a.item_lo[it], hi = a.item_hi[it], last = hi - 1;
+    double v[EM_ITEM / 64];
+#pragma unroll
+    for (int u = 0; u < EM_ITEM / 64; ++u) { const int64_t j = lo + lane + 64 * u; v[u] = a.post_sorted[j < last ? j : last]; }
     double acc = 0;
-    for (int64_t j = a.item_lo[it] + lane; j < hi; j += 64) acc += a.post[a.perm[j]];
+#pragma unroll
+    for (int u = 0; u < EM_ITEM / 64; ++u) if (lo + lane + 64 * u < hi) acc += v[u];
     for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
     if (lane == 0) a.item_sum[it] = acc;
   }
@@ -415,9 +448,14 @@ __device__ inline void em_stop_rule(long long* ctrl, double ll, double* ll_trace
 template <bool LOCAL>
 __device__ inline void em_p3(const EmLoop& a, int n_wg, double* sh) {
   const int tid = threadIdx.x;
+  __shared__ double s_item[EM_P3_LDS_ITEMS];                       // the item sums of a taxon are added in order by one thread: from LDS, not one global round trip each
+  const bool staged = a.n_items <= EM_P3_LDS_ITEMS;
+  if (staged) { for (int it = tid; it < a.n_items; it += 256) s_item[it] = a.item_sum[it]; __syncthreads(); }
   for (int p = tid; p < a.n_present; p += 256) {
     double s = 0;
-    for (int it = a.pt_item[p]; it < a.pt_item[p + 1]; ++it) s += a.item_sum[it];
+    const int i0 = a.pt_item[p], i1 = a.pt_item[p + 1];
+    if (staged) for (int it = i0; it < i1; ++it) s += s_item[it];
+    else for (int it = i0; it < i1; ++it) s += a.item_sum[it];
     a.local_partial[a.present[p]] = s;
   }
   __syncthreads();
@@ -517,6 +555,10 @@ __global__ void __launch_bounds__(256) em_finalize_kernel(const double* __restri
   if (threadIdx.x == 0) em_stop_rule(ctrl, partial[n_taxa], ll_trace, ll_cap, it_limit);
 }
 
+__global__ void em_pos_kernel(const int64_t* __restrict__ perm, int64_t ne, int64_t* __restrict__ pos) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < ne) pos[perm[j]] = j;
+}
 static int em_grid(int64_t n_reads) {                            // (fixed per problem: the log-likelihood partials are summed in the grid's shape)
   const char* e = getenv("MM_EM_GRID");
   const int cap = std::min(std::max(e ? atoi(e) : 128, 1), 1024);
@@ -549,6 +591,8 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
     E->item_lo.alloc(std::max<size_t>(ilo.size(), 1)); E->item_lo.upload(ilo.data(), ilo.size(), st);
     E->item_hi.alloc(std::max<size_t>(ihi.size(), 1)); E->item_hi.upload(ihi.data(), ihi.size(), st);
     E->item_sum.alloc(std::max<size_t>(ilo.size(), 1));
+    E->pos.alloc((size_t)std::max<int64_t>(E->n_entries, 1)); E->post_sorted.alloc((size_t)std::max<int64_t>(E->n_entries, 1));
+    if (E->n_entries > 0) { em_pos_kernel<<<dim3((unsigned)ceil_div(E->n_entries, 256)), dim3(256), 0, st>>>(E->perm.p, E->n_entries, E->pos.p); MM_KERNEL_CHECK(); }
     E->wg_ll.alloc((size_t)E->n_wg);
     E->local_partial.alloc((size_t)T + 2);
     E->ll_trace.alloc((size_t)cap);
@@ -571,7 +615,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
     MM_HIP(hipStreamSynchronize(st));
   }
   const long long it0 = h_ctrl[0], it_limit = it0 + max_iter;
-  EmLoop a{E->read_off.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->n_reads, E->post.p, E->perm.p, E->item_lo.p, E->item_hi.p, E->n_items,
+  EmLoop a{E->read_off.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->n_reads, E->post_sorted.p, E->pos.p, E->item_lo.p, E->item_hi.p, E->n_items,
            E->present.p, E->pt_item.p, E->n_present, E->item_sum.p, E->wg_ll.p, E->f_run.p, E->local_partial.p, T, E->ctrl.p, E->ll_trace.p, cap, it_limit, E->bar.p,
            getenv("MM_EM_BARRIER_TICKS") ? atoll(getenv("MM_EM_BARRIER_TICKS")) : EM_BARRIER_TICKS};
   const dim3 grid((unsigned)E->n_wg), blk(256);

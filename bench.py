@@ -79,6 +79,8 @@ def parse_args():
     ap.add_argument("--chunk-gib", type=float, default=0.0, help="--maxmemory of configs 3 / 4 in GiB (default 70 -> 4 chunks for config 3, 25 -> 11 chunks for config 4)")
     ap.add_argument("--batches-per-pass", type=int, default=4, help="config 4: read batches mapped against every chunk index of a pass (the index builds of a pass are inside the timed region)")
     ap.add_argument("--no-e2e-full", action="store_true", help="skip e2e_cli_full (the drop-in CLI on the whole 26.8 GB DB.fa written to local disk: ~2 minutes)")
+    ap.add_argument("--no-e2e-stream", action="store_true", help="skip e2e_cli_stream (the CLI on --e2e-stream-batches batches in one FASTQ; inside e2e_cli_full)")
+    ap.add_argument("--e2e-stream-batches", type=int, default=10)
     ap.add_argument("--e2e-dir", default=os.environ.get("MM_BENCH_E2E_DIR", ""), help="directory for the files of e2e_cli_full (default: a temporary directory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-shape", action="store_true", help="skip the second reference shape (config.other_shape)")
@@ -449,6 +451,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_e2e_full and (args.scale == 1.0 or os.environ.get("MM_BENCH_E2E_ANY_SCALE")) and args.shape == "community" and not args.read_len_min:
         try:
             out["e2e_cli_full"] = e2e_cli_full(args, k, w, 1000 + rank)
+            out["e2e_cli_stream"] = out["e2e_cli_full"].pop("e2e_cli_stream", None)
         except Exception as e:  # a reported side number; never let it kill the bench line
             out["e2e_cli_full"] = {"failed": str(e)[:600]}
     if rank == 0:
@@ -855,6 +858,24 @@ def e2e_cli_full(args, k, w, rank_seed):
                 bases += len(sq) if len(sq) >= 1000 else 0
         t_files = time.time() - t0
         fasta_bytes = os.path.getsize(fasta)
+        # e2e_cli_stream: N_STREAM distinct batches (the seeds of the bench's own batches) in ONE FASTQ — the CLI in steady state
+        n_stream = 0 if args.no_e2e_stream else max(1, args.e2e_stream_batches)
+        fq_s, bases_s, reads_s = os.path.join(d, "reads_stream.fq"), 0, 0
+        t1 = time.time()
+        if n_stream:
+            with open(fq_s, "wb", buffering=1 << 24) as f:
+                for b in range(n_stream):
+                    rb, _t = ctx.synth_reads(ref, seed=1000 + 97 * b, n_reads=args.reads, read_len=args.read_len, read_len_min=args.read_len_min, frac_random=0.05, n_abundant=100, **err)
+                    buf, ln = rb.fetch_range(0, rb.count)
+                    mv, at = memoryview(buf), 0
+                    qual = b"I" * int(ln.max())
+                    for r, L in enumerate(ln.tolist()):
+                        f.write(b"@b%dr%d\n" % (b, r)); f.write(mv[at:at + L]); f.write(b"\n+\n"); f.write(qual[:L]); f.write(b"\n")
+                        at += L
+                        bases_s += L if L >= 1000 else 0
+                    reads_s += len(ln)
+                    rb.close(); del buf, mv
+        t_files_stream = time.time() - t1
         reads.close(); ref.close(); ctx.close()                   # the device is the CLI's from here on
         env = dict(os.environ, MM_CLI_TIMING="1")
         pre = os.path.join(d, "out")
@@ -871,6 +892,27 @@ def e2e_cli_full(args, k, w, rank_seed):
         cls_main = {ln.split(" at +")[0][12:]: float(ln.split(" at +")[1].split()[0]) for ln in err2.splitlines() if ln.startswith("INFO, main: ")}
         par = dict(l.split(" ", 1) for l in open(pre + ".parameters").read().splitlines() if " " in l)
         meta = dict(l.split() for l in open(pre + ".meta"))
+        stream = None
+        if n_stream:
+            pre_s = os.path.join(d, "out_stream")
+            _o, e_s, t_map_s, rss_s = _run_cli_with_rss([cli, "mapDirectly", "--all", "-r", fasta, "-q", fq_s, "-o", pre_s], env, 1500)
+            laps_s = {ln.split(" at +")[0][len("INFO, lap "):]: float(ln.split(" at +")[1].split()[0]) for ln in e_s.splitlines() if ln.startswith("INFO, lap ")}
+            ph_s = {" ".join(ln.split()[2:-2]): float(ln.split()[-2]) for ln in e_s.splitlines() if ln.startswith("INFO, time ")}
+            _o2, e_c, t_cls_s, rss_cs = _run_cli_with_rss([cli, "classify", "--DB", db, "--mappings", pre_s], env, 1500)
+            cph = {ln.split()[2] + " " + " ".join(ln.split()[3:-2]): float(ln.split()[-2]) for ln in e_c.splitlines() if ln.startswith("INFO, time c")}
+            cmain = {ln.split(" at +")[0][12:]: float(ln.split(" at +")[1].split()[0]) for ln in e_c.splitlines() if ln.startswith("INFO, main: ")}
+            t_phase_s = max(laps_s.get("8 write", t_map_s) - laps_s.get("3 index build", 0.0), 1e-9)
+            t_cls_work_s = max(t_cls_s - cmain.get("contexts created", 0.0), 1e-9)
+            meta_s = dict(l.split() for l in open(pre_s + ".meta"))
+            stream = {"what": f"the drop-in CLI in steady state: {n_stream} distinct batches ({reads_s} reads, one {os.path.getsize(fq_s) / 1e9:.1f} GB FASTQ) through `metamaps mapDirectly --all` + "
+                              "`metamaps classify`; value = read bases / (mapping phase by the CLI's own laps: index built -> last output file written, + classify without its context "
+                              "creation) — SURVEY D1's metric at the boundary users see, index build reported apart",
+                      "batches": n_stream, "reads": int(reads_s), "bases": int(bases_s), "fastq_written_s": round(t_files_stream, 2),
+                      "mapping_phase_s": round(t_phase_s, 3), "classify_work_s": round(t_cls_work_s, 3), "classify_wall_s": round(t_cls_s, 3), "mapDirectly_wall_s": round(t_map_s, 3),
+                      "value": bases_s / (t_phase_s + t_cls_work_s) / 1e9, "unit": "Gbp/s", "mapping_phase_value": bases_s / t_phase_s / 1e9,
+                      "map_laps_s": laps_s, "map_phases_s": ph_s, "classify_phases_s": cph, "classify_main_s": cmain,
+                      "mappings_file_bytes": os.path.getsize(pre_s), "peak_host_rss_bytes": {"mapDirectly": int(rss_s), "classify": int(rss_cs)},
+                      "meta": {kk: int(v) for kk, v in meta_s.items()}}
         t_ingest = max(t_map - t_setup, 1e-9)                    # (process wall behind the index build: includes the driver's teardown of 150 GB at exit, ~0.5 s)
         t_phase = max(laps.get("8 write", t_map) - t_setup, 1e-9)  # the mapping phase by the CLI's own clock: index built -> last output file written
         t_cls_work = max(t_cls - cls_main.get("contexts created", 0.0), 1e-9)
@@ -888,7 +930,7 @@ def e2e_cli_full(args, k, w, rank_seed):
                                    "mapping_phase_what": "index built -> last output file written, by the CLI's own laps (without the process exit)"},
                 "map_laps_s": laps, "map_phases_s": phases, "classify_phases_s": cls_phases, "classify_main_s": cls_main,
                 "peak_host_rss_bytes": {"mapDirectly": int(rss_map), "classify": int(rss_cls)},
-                "meta": {kk: int(v) for kk, v in meta.items()}}
+                "meta": {kk: int(v) for kk, v in meta.items()}, "e2e_cli_stream": stream}
     finally:
         if own_tmp is not None:
             own_tmp.cleanup()

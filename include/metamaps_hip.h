@@ -92,6 +92,8 @@ int64_t mm_seqset_total_bases(const mm_seqset* s);
 int mm_seqset_lengths(const mm_seqset* s, int32_t* len_out /* [count] */);
 /* read back sequence i as (upper-cased) ASCII — round-trip check for tests */
 int mm_seqset_fetch(mm_seqset* s, int64_t i, char* ascii_out, int64_t cap);
+/* sequences [first, first + count) one behind the other, no separators (lengths: mm_seqset_lengths); cap >= their total length */
+int mm_seqset_fetch_range(mm_seqset* s, int64_t first, int64_t count, char* ascii_out, int64_t cap);
 
 /* Device-side synthetic inputs (bench.py; DESIGN.md "Synthetic workload").  The reference is a set of
  * genomes grouped in species (strains = substituted copies of a species root), generated straight into

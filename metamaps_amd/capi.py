@@ -117,6 +117,7 @@ def lib() -> C.CDLL:
             "mm_seqset_total_bases": (i64, [vp]),
             "mm_seqset_lengths": (C.c_int, [vp, vp]),
             "mm_seqset_fetch": (C.c_int, [vp, i64, C.c_char_p, i64]),
+            "mm_seqset_fetch_range": (C.c_int, [vp, i64, i64, C.c_void_p, i64]),
             "mm_synth_reference": (C.c_int, [vp, P(SynthRefParams), P(vp)]),
             "mm_synth_reads": (C.c_int, [vp, vp, P(SynthReadParams), P(vp), vp]),
             "mm_synth_community": (C.c_int, [vp, P(SynthCommunityParams), P(vp), vp]),
@@ -388,6 +389,13 @@ class SeqSet:
         buf = C.create_string_buffer(length + 1)
         self.ctx.check(lib().mm_seqset_fetch(self.h, i, buf, length))
         return buf.raw[:length]
+
+    def fetch_range(self, first: int, count: int):
+        """(ASCII of sequences [first, first + count) back to back as a uint8 array, their lengths)"""
+        ln = self.lengths()[first:first + count]
+        buf = np.empty(int(ln.sum()), dtype=np.uint8)
+        self.ctx.check(lib().mm_seqset_fetch_range(self.h, first, count, buf.ctypes.data, len(buf)))
+        return buf, ln
 
     def close(self):
         if self.h:

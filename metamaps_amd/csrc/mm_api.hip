@@ -12,6 +12,7 @@ void seqset_upload(mm_seqset* s);
 void seqset_save(mm_seqset* s, const char* path);
 void seqset_load(mm_seqset* s, const char* path);
 void seqset_fetch(mm_seqset* s, int64_t i, char* out, int64_t cap);
+void seqset_fetch_range(mm_seqset* s, int64_t first, int64_t count, char* out, int64_t cap);
 void seqset_slice(const mm_seqset* s, int64_t first, int64_t count, mm_seqset* o);
 void seqset_concat(const mm_seqset* const* parts, int n_parts, mm_seqset* o);
 }
@@ -168,6 +169,11 @@ int mm_seqset_lengths(const mm_seqset* s, int32_t* len_out) {
 int mm_seqset_fetch(mm_seqset* s, int64_t i, char* ascii_out, int64_t cap) {
   if (!s || !ascii_out) return MM_ERR_ARG;
   return guarded(s->ctx, [&] { mm::seqset_fetch(s, i, ascii_out, cap); });
+}
+
+int mm_seqset_fetch_range(mm_seqset* s, int64_t first, int64_t count, char* ascii_out, int64_t cap) {
+  if (!s || (!ascii_out && cap > 0)) return MM_ERR_ARG;
+  return guarded(s->ctx, [&] { mm::seqset_fetch_range(s, first, count, ascii_out, cap); });
 }
 
 int mm_synth_reference(mm_ctx* ctx, const mm_synth_ref_params* p, mm_seqset** out) {

@@ -357,7 +357,8 @@ struct EmLoop {
   long long barrier_ticks;                                        // a barrier not released within this many ticks of the 100 MHz wall clock gives up (ctrl[4])
 };
 constexpr int EM_ITEM = 512;
-constexpr int EM_P3_LDS_ITEMS = 4096;
+constexpr int EM_P3_LDS_ITEMS = 4096;                              // item sums staged in (dynamic) LDS by P3 up to this many, read from global memory beyond
+constexpr int EM_BAR_GROUP = 16;                                  // workgroups per first-level barrier counter
 constexpr long long EM_BARRIER_TICKS = 200000000LL;               // 2 s of the 100 MHz wall clock (MM_EM_BARRIER_TICKS: test hook)
 
 // P1.  A thread walks its reads; the mappings of a read are taken four at a time with every load of the four issued before the first is
@@ -448,7 +449,7 @@ __device__ inline void em_stop_rule(long long* ctrl, double ll, double* ll_trace
 template <bool LOCAL>
 __device__ inline void em_p3(const EmLoop& a, int n_wg, double* sh) {
   const int tid = threadIdx.x;
-  __shared__ double s_item[EM_P3_LDS_ITEMS];                       // the item sums of a taxon are added in order by one thread: from LDS, not one global round trip each
+  extern __shared__ double s_item[];                               // the item sums of a taxon are added in order by one thread: from LDS, not one global round trip each
   const bool staged = a.n_items <= EM_P3_LDS_ITEMS;
   if (staged) { for (int it = tid; it < a.n_items; it += 256) s_item[it] = a.item_sum[it]; __syncthreads(); }
   for (int p = tid; p < a.n_present; p += 256) {
@@ -473,12 +474,20 @@ __device__ inline void em_p3(const EmLoop& a, int n_wg, double* sh) {
 
 // grid barrier pieces (thread 0 of every workgroup talks; agent-scope fences publish / fetch the other workgroups' plain stores: the
 // XCDs' L2s are not coherent with each other, DESIGN.md K5 scratch slots)
+// bar[0]: groups that have arrived, bar[1]: released generation, bar[16 * (1 + g)]: arrivals of group g (EM_BAR_GROUP workgroups, a
+// 64-byte line each).  Two levels because 128 agent-scope atomics on ONE word are served one after the other: ~13 us per barrier,
+// more than the phases between them.
 __device__ inline bool grid_arrive_is_last(unsigned* bar, unsigned epoch, unsigned n_wg, int* s_flag) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
-    const unsigned old = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = old + 1 == epoch * n_wg;
+    const unsigned g = blockIdx.x / EM_BAR_GROUP, n_groups = (n_wg + EM_BAR_GROUP - 1) / EM_BAR_GROUP;
+    const unsigned g_size = min((unsigned)EM_BAR_GROUP, n_wg - g * EM_BAR_GROUP);
+    int last = 0;
+    if (__hip_atomic_fetch_add(&bar[16 * (1 + g)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == epoch * g_size) {
+      __threadfence();
+      last = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == epoch * n_groups;
+    }
     if (last) __threadfence();
     *s_flag = last;
   }
@@ -598,7 +607,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
     E->ll_trace.alloc((size_t)cap);
     E->f_run.alloc((size_t)T);
     E->ctrl.alloc(8);
-    E->bar.alloc(2);
+    E->bar.alloc(16 * (size_t)(1 + ceil_div(E->n_wg, EM_BAR_GROUP)));
     MM_HIP(hipStreamSynchronize(st));
   }
   long long h_ctrl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -619,6 +628,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
            E->present.p, E->pt_item.p, E->n_present, E->item_sum.p, E->wg_ll.p, E->f_run.p, E->local_partial.p, T, E->ctrl.p, E->ll_trace.p, cap, it_limit, E->bar.p,
            getenv("MM_EM_BARRIER_TICKS") ? atoll(getenv("MM_EM_BARRIER_TICKS")) : EM_BARRIER_TICKS};
   const dim3 grid((unsigned)E->n_wg), blk(256);
+  const size_t p3_lds = E->n_items <= EM_P3_LDS_ITEMS ? sizeof(double) * (size_t)std::max(E->n_items, 1) : 0;
   const bool force_split = getenv("MM_EM_SPLIT") != nullptr;
   bool split = force_split || ctx->em_split;
   // a communicator of ONE rank has nothing to exchange: the run is the resident kernel, as without a communicator (MM_EM_FORCE_COLLECTIVE=1
@@ -642,19 +652,19 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
   while (!h_ctrl[1] && h_ctrl[0] < it_limit) {
     if (!collective && !split) {                                 // one rank: the whole run is one launch
       E->bar.zero(st);
-      em_loop_kernel<false><<<grid, blk, 0, st>>>(a);
+      em_loop_kernel<false><<<grid, blk, p3_lds, st>>>(a);
       MM_KERNEL_CHECK();
     } else {
       const int g_n = (int)std::min<long long>(GROUP, it_limit - h_ctrl[0]);   // (the same on every rank: h_ctrl holds all-reduced decisions)
       for (int g = 0; g < g_n; ++g) {
         if (!split) {
           E->bar.zero(st);
-          em_loop_kernel<true><<<grid, blk, 0, st>>>(a);
+          em_loop_kernel<true><<<grid, blk, p3_lds, st>>>(a);
           MM_KERNEL_CHECK();
         } else {
           em_p1_kernel<<<grid, blk, 0, st>>>(a); MM_KERNEL_CHECK();
           em_p2_kernel<<<grid, blk, 0, st>>>(a); MM_KERNEL_CHECK();
-          if (collective) em_p3_kernel<true><<<dim3(1), blk, 0, st>>>(a, E->n_wg); else em_p3_kernel<false><<<dim3(1), blk, 0, st>>>(a, E->n_wg);
+          if (collective) em_p3_kernel<true><<<dim3(1), blk, p3_lds, st>>>(a, E->n_wg); else em_p3_kernel<false><<<dim3(1), blk, p3_lds, st>>>(a, E->n_wg);
           MM_KERNEL_CHECK();
         }
         if (collective) {                                        // fEM.h:583-600, across GPUs instead of OpenMP threads

@@ -581,14 +581,19 @@ def test_cli_reference_parsed_in_parallel_blocks(oracle_lib, tmp_path, monkeypat
 
 def test_cli_device_cap_decides_placement(tmp_path):
     """BASELINE config 5's decision — resident / spread over the devices / streamed — taken BY THE CLI, not by a flag: MM_DEVICE_BYTES_CAP (a test
-    hook of the library's allocator: allocations beyond it fail, mm_ctx_device_info reports it) makes a 100 Mbp reference "larger than
-    the device", so that `mapDirectly --maxmemory-bytes ...` must go to chunk streaming on one device and to sharding on three logical
-    devices by itself, with the allocator enforcing the cap while it does.  Same files as the uncapped resident run."""
+    hook of the library's allocator: allocations beyond it fail, mm_ctx_device_info reports it) makes a 1 Gbp reference "larger than the
+    device", so that `mapDirectly --maxmemory-bytes ...` must go to chunk streaming on one device and to sharding on three logical devices by
+    itself — chunk rule on contig ranges, per-chunk thresholds from the accumulated histogram — with the allocator ENFORCING the cap while it
+    does (a plan whose index builds or mapping buffers do not fit ends in MM_ERR_NOMEM).  Same files as the uncapped resident run.
+    (1 Gbp and 8 GiB rather than something smaller: below that the fixed-size buffers of a context — K5 scratch slots, minimum table sizes —
+    weigh more than the index, and the test would measure those.)"""
     from metamaps_amd import synth
-    db = synth.make_db(str(tmp_path / "db"), n_genomes=50, genome_len=2_000_000, seed=5)
-    rd = synth.make_reads(db, str(tmp_path / "r.fq"), n_reads=1500, read_len=6000, seed=3)
-    base = ["mapDirectly", "--all", "-r", db.fasta, "-q", rd["path"], "--maxmemory-bytes", "300000000", "--workers-per-gpu", "1"]
-    cap = int(os.environ.get("MM_TEST_DEVICE_CAP", 800 << 20))   # 100 Mbp x 5.5 B x 1.2 = 660 MB > 0.8 x 800 MB; three devices: 660 x 1.3 / 3 = 286 MB fits
+    n_genomes = int(os.environ.get("MM_TEST_CAP_GENOMES", 100))
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=n_genomes, genome_len=10_000_000, seed=5)
+    rd = synth.make_reads(db, str(tmp_path / "r.fq"), n_reads=3000, read_len=6000, seed=3)
+    ref_bases = n_genomes * 10_000_000
+    base = ["mapDirectly", "--all", "-r", db.fasta, "-q", rd["path"], "--maxmemory-bytes", str(int(ref_bases * 3)), "--workers-per-gpu", "1"]
+    cap = int(os.environ.get("MM_TEST_DEVICE_CAP", int(ref_bases * 8.0)))   # index estimate 5.5 B x 1.2 per base = 6.6 GB > 0.8 x 8 GB; three devices: 6.6 x 1.3 / 3 = 2.9 GB fits
     env = dict(os.environ, MM_DEVICE_BYTES_CAP=str(cap))
     runs = {}
     for tag, extra, e in (("resident", [], os.environ), ("auto_stream", [], env), ("auto_shard", ["--devices", "0,0,0"], env)):

@@ -252,7 +252,8 @@ int mm_mapping_add_qualities(mm_ctx* ctx, mm_mapping* m, const mm_seqset* reads,
 /* default (non --all) reporting: per read keep the records whose identity is >= best - 1.0
  * (reportReadMappings, computeMap.hpp:546-587).  Apply per index chunk, before mm_mapping_concat / add_qualities. */
 int mm_mapping_keep_best(mm_ctx* ctx, mm_mapping* m, int k);
-/* merge the records of several index chunks read-wise, chunk order preserved (unifyFiles, mapWrap.h:128-132).  The result carries
+/* merge the records of several index chunks read-wise, chunk order preserved (unifyFiles, mapWrap.h:128-132), on the device.  The parts may
+ * belong to any context of this process: records of a part on another device are fetched with a peer copy.  The result carries
  * records only (as after mm_mapping_release_intermediates: the debug taps return MM_ERR_STATE); its statistics are the work
  * counters and stage times summed over the parts. */
 int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* contig_base, int n_parts, mm_mapping** out);
@@ -263,6 +264,15 @@ int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* cont
  * mm_mapping_fetch and mm_em_create_from_mapping. */
 int mm_mapping_from_parts(mm_ctx* ctx, int64_t n_reads, const int32_t* read_len, const mm_map_params* p, int n_parts,
                           const int64_t* const* offsets, const mm_map_record* const* records, const int32_t* contig_base, mm_mapping** out);
+
+/* the same exchange between the RANKS of ctx's communicator (mm_comm_init; one process per GPU, or one host thread per GPU of one process), device
+ * to device over RCCL (ncclSend / ncclRecv over xGMI) — nothing is staged in host memory.  Collective: every rank calls it for the
+ * same read batch, batches in the same order on every rank.  parts[i] = this rank's mapping of the batch against chunk chunk_id[i] (it must hold
+ * every chunk c with chunk_rank[c] == its rank); n_chunks / chunk_rank[c] / contig_base[c] describe all chunks of the reference and are the same
+ * on every rank.  On rank `owner`, *out receives the merged mapping (records only, chunk order; takes mm_mapping_add_qualities ...); on the other
+ * ranks *out = NULL.  A one-rank communicator (or none) merges locally. */
+int mm_mapping_gather(mm_ctx* ctx, int owner, int64_t n_reads, const int32_t* read_len, const mm_map_params* p, mm_mapping* const* parts, const int32_t* chunk_id,
+                      int n_parts, int n_chunks, const int32_t* chunk_rank, const int32_t* contig_base, mm_mapping** out);
 
 /* debug taps for one batch (parity tests).  Any output pointer may be NULL. */
 int mm_debug_sketch(mm_mapping* m, int64_t* offsets, uint32_t* hash, int32_t* strand, int64_t cap);          /* computeMap.hpp:292-298 */

@@ -141,6 +141,7 @@ def lib() -> C.CDLL:
             "mm_sketch_batch": (C.c_int, [vp, vp, P(MapParams), P(vp)]),
             "mm_mapping_destroy": (None, [vp]),
             "mm_mapping_get_stats": (C.c_int, [vp, P(MapStats)]),
+            "mm_mapping_gather": (C.c_int, [vp, C.c_int, i64, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
             "mm_mapping_release_intermediates": (C.c_int, [vp]),
             "mm_mapping_fetch": (C.c_int, [vp, vp, vp, i64]),
             "mm_mapping_add_qualities": (C.c_int, [vp, vp, vp, C.c_int]),
@@ -497,6 +498,18 @@ class Mapping:
         out = C.c_void_p()
         ctx.check(lib().mm_mapping_from_parts(ctx.h, len(rl), _ptr(rl), C.byref(mp), len(parts), oarr, rarr, _ptr(base), C.byref(out)))
         return Mapping(ctx, out, len(rl))
+
+    @staticmethod
+    def gather(ctx: "Context", owner: int, read_len, parts: list["Mapping"], chunk_id: list[int], chunk_rank: list[int], contig_base: list[int],
+               k: int, w: int, pi: float = 80.0, min_read_len: int = 1000):
+        """mm_mapping_gather: this rank's chunk mappings of one batch -> the merged mapping on `owner` (None on the other ranks); collective"""
+        rl = np.ascontiguousarray(read_len, dtype=np.int32)
+        arr = (C.c_void_p * max(len(parts), 1))(*[p.h for p in parts])
+        cid = np.asarray(chunk_id, dtype=np.int32); crk = np.asarray(chunk_rank, dtype=np.int32); base = np.asarray(contig_base, dtype=np.int32)
+        mp = MapParams(k, w, pi, min_read_len)
+        out = C.c_void_p()
+        ctx.check(lib().mm_mapping_gather(ctx.h, owner, len(rl), _ptr(rl), C.byref(mp), arr, _ptr(cid), len(parts), len(crk), _ptr(crk), _ptr(base), C.byref(out)))
+        return Mapping(ctx, out, len(rl)) if out.value else None
 
     def fetch(self, rec_buf: np.ndarray | None = None):
         """offsets [n_reads+1] and the mm_map_record array.  `rec_buf` (RECORD_DTYPE, any capacity) lets a caller

@@ -6,6 +6,8 @@
 #include "mm_stats.hpp"
 #include "mm_synth.hpp"
 #include <new>
+#include <rccl/rccl.h>
+#include <rocprim/rocprim.hpp>
 
 namespace mm {
 void seqset_upload(mm_seqset* s);
@@ -423,8 +425,28 @@ int mm_mapping_add_qualities(mm_ctx* ctx, mm_mapping* m, const mm_seqset* reads,
   return guarded(ctx, [&] { MM_HIP(hipSetDevice(ctx->device)); mm::mapping_add_qualities(ctx, m, k); });
 }
 // read-wise concatenation of per-chunk record lists in chunk order (unifyFiles, mapWrap.h:128-132); small, done on the host
-static mm_mapping* merge_parts(mm_ctx* ctx, int64_t n, const std::vector<int32_t>& read_len, const mm_map_params& params, int n_parts,
-                               const int64_t* const* offsets, const mm_map_record* const* records, const int32_t* contig_base) {
+// ---- read-wise merge of the records of several index chunks, chunk order preserved (unifyFiles, mapWrap.h:128-132) — on the device.
+// Rounds 1-3 merged on the host (download, a serial loop, upload), also for chunk indexes resident on ONE device.
+struct PartDev { const uint64_t* off; const mm_map_record* rec; int32_t base; int32_t pad; };
+__global__ void __launch_bounds__(256) merge_count_kernel(const PartDev* __restrict__ parts, int n_parts, int64_t n, uint64_t* __restrict__ cnt) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r > n) return;
+  uint64_t c = 0;
+  if (r < n) for (int p = 0; p < n_parts; ++p) c += parts[p].off[r + 1] - parts[p].off[r];
+  cnt[r] = c;
+}
+__global__ void __launch_bounds__(256) merge_copy_kernel(const PartDev* __restrict__ parts, int n_parts, int64_t n, const uint64_t* __restrict__ off,
+                                                         mm_map_record* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  uint64_t o = off[r];
+  for (int p = 0; p < n_parts; ++p) {
+    const PartDev P = parts[p];
+    for (uint64_t i = P.off[r]; i < P.off[r + 1]; ++i) { mm_map_record x = P.rec[i]; x.ref_contig += P.base; out[o++] = x; }
+  }
+}
+static mm_mapping* merge_parts_device(mm_ctx* ctx, int64_t n, const std::vector<int32_t>& read_len, const mm_map_params& params, const std::vector<PartDev>& parts) {
+  hipStream_t st = ctx->stream;
   auto* M = new mm_mapping;
   try {
     M->ctx = ctx; M->n_reads = n; M->params = params; M->read_len = read_len;
@@ -437,56 +459,67 @@ static mm_mapping* merge_parts(mm_ctx* ctx, int64_t n, const std::vector<int32_t
       M->active[(size_t)r] = ok;
       if (ok) { M->stats.n_reads_long_enough++; M->stats.bases_long_enough += L; }
     }
-    std::vector<mm_map_record> all; std::vector<uint64_t> off((size_t)n + 1, 0);
-    for (int64_t r = 0; r < n; ++r) {
-      for (int p = 0; p < n_parts; ++p)
-        for (int64_t i = offsets[p][r]; i < offsets[p][r + 1]; ++i) {
-          mm_map_record x = records[p][i];
-          x.ref_contig += contig_base ? contig_base[p] : 0;
-          all.push_back(x);
-        }
-      off[(size_t)r + 1] = all.size();
+    mm::DBuf<PartDev> d_parts(parts.size()); d_parts.upload(parts.data(), parts.size(), st);
+    mm::DBuf<uint64_t> cnt((size_t)n + 1);
+    M->rec_off.alloc((size_t)n + 1);
+    const unsigned gb = (unsigned)mm::ceil_div(n + 1, 256);
+    merge_count_kernel<<<dim3(gb), dim3(256), 0, st>>>(d_parts.p, (int)parts.size(), n, cnt.p);
+    MM_KERNEL_CHECK();
+    size_t tmp_bytes = 0;
+    MM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt.p, M->rec_off.p, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), st));
+    mm::DBuf<uint8_t> tmp(std::max<size_t>(tmp_bytes, 1));
+    MM_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, cnt.p, M->rec_off.p, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), st));
+    M->h_rec_off = M->rec_off.to_host(st);
+    M->n_rec = (int64_t)M->h_rec_off[(size_t)n];
+    M->rec.alloc(std::max<size_t>((size_t)M->n_rec, 1));
+    if (n > 0 && M->n_rec > 0) {
+      merge_copy_kernel<<<dim3((unsigned)mm::ceil_div(n, 256)), dim3(256), 0, st>>>(d_parts.p, (int)parts.size(), n, M->rec_off.p, M->rec.p);
+      MM_KERNEL_CHECK();
     }
-    M->n_rec = (int64_t)all.size();
-    M->rec.alloc(std::max<size_t>(all.size(), 1)); M->rec.upload(all.data(), all.size(), ctx->stream);
-    M->rec_off.alloc((size_t)n + 1); M->rec_off.upload(off.data(), off.size(), ctx->stream);
-    M->d_read_len.alloc((size_t)std::max<int64_t>(n, 1)); M->d_read_len.upload(M->read_len.data(), (size_t)n, ctx->stream);
-    M->h_rec_off = off;
+    M->d_read_len.alloc((size_t)std::max<int64_t>(n, 1)); M->d_read_len.upload(M->read_len.data(), (size_t)n, st);
     M->stats.n_mappings = M->n_rec;
-    for (int64_t r = 0; r < n; ++r) if (off[(size_t)r + 1] > off[(size_t)r]) M->stats.n_reads_mapped++;
+    for (int64_t r = 0; r < n; ++r) if (M->h_rec_off[(size_t)r + 1] > M->h_rec_off[(size_t)r]) M->stats.n_reads_mapped++;
     M->released = true;                                          // records only: the debug taps have nothing to show
-    MM_HIP(hipStreamSynchronize(ctx->stream));
+    MM_HIP(hipStreamSynchronize(st));
   } catch (...) { delete M; throw; }
   return M;
 }
+static void add_part_stats(mm_mapping* M, mm_mapping* const* parts, int n_parts) {   // work counters and stage times: summed over the chunks; per-read facts: of chunk 0
+  for (int p = 0; p < n_parts; ++p) {
+    const mm_map_stats& S = parts[p]->stats;
+    M->stats.sum_hits += S.sum_hits; M->stats.n_candidates += S.n_candidates; M->stats.sum_hits_kept += S.sum_hits_kept;
+    M->stats.sum_l2_stream_entries += S.sum_l2_stream_entries; M->stats.sum_l2_evals += S.sum_l2_evals;
+    M->stats.n_l2_rebuilds += S.n_l2_rebuilds; M->stats.n_l2_wide_redo += S.n_l2_wide_redo;
+    M->stats.ms_minimizer += S.ms_minimizer; M->stats.ms_sketch += S.ms_sketch; M->stats.ms_probe_gather += S.ms_probe_gather;
+    M->stats.ms_sort_hits += S.ms_sort_hits; M->stats.ms_l1_scan += S.ms_l1_scan; M->stats.ms_l2 += S.ms_l2; M->stats.ms_compact += S.ms_compact;
+    M->stats.ms_total += S.ms_total; M->stats.ms_hit_filter += S.ms_hit_filter;
+  }
+  if (n_parts > 0) {
+    M->stats.sum_sketch = parts[0]->stats.sum_sketch; M->stats.n_ambiguous_sketch_reads = parts[0]->stats.n_ambiguous_sketch_reads;
+    M->stats.n_reads_giant = parts[0]->stats.n_reads_giant;
+  }
+}
+// Parts may live in any context of this process: those of another DEVICE come over with a peer copy (xGMI), nothing is staged on the host.
 int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* contig_base, int n_parts, mm_mapping** out) {
   if (!ctx || !parts || n_parts <= 0 || !out) return MM_ERR_ARG;
   return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
     const int64_t n = parts[0]->n_reads;
-    std::vector<std::vector<mm_map_record>> recs((size_t)n_parts);
-    std::vector<std::vector<int64_t>> offs((size_t)n_parts);
-    std::vector<const int64_t*> op; std::vector<const mm_map_record*> rp;
+    std::vector<PartDev> pv((size_t)n_parts);
+    std::vector<mm::DBuf<uint64_t>> t_off((size_t)n_parts); std::vector<mm::DBuf<mm_map_record>> t_rec((size_t)n_parts);
     for (int p = 0; p < n_parts; ++p) {
-      MM_REQUIRE(parts[p]->n_reads == n, MM_ERR_ARG, "chunk results cover different read sets");
-      MM_REQUIRE(parts[p]->ctx->device == ctx->device, MM_ERR_ARG, "mm_mapping_concat: parts of another device go through mm_mapping_fetch + mm_mapping_from_parts");
-      recs[(size_t)p].resize((size_t)parts[p]->n_rec);
-      parts[p]->rec.download(recs[(size_t)p].data(), (size_t)parts[p]->n_rec, ctx->stream);
-      offs[(size_t)p].assign(parts[p]->h_rec_off.begin(), parts[p]->h_rec_off.end());
+      mm_mapping* P = parts[p];
+      MM_REQUIRE(P->n_reads == n, MM_ERR_ARG, "chunk results cover different read sets");
+      pv[(size_t)p] = PartDev{P->rec_off.p, P->rec.p, contig_base ? contig_base[p] : 0, 0};
+      if (P->ctx->device != ctx->device) {                       // (the part's own stream has been waited for by the call that made it)
+        t_off[(size_t)p].alloc((size_t)n + 1); t_rec[(size_t)p].alloc(std::max<size_t>((size_t)P->n_rec, 1));
+        MM_HIP(hipMemcpyPeerAsync(t_off[(size_t)p].p, ctx->device, P->rec_off.p, P->ctx->device, sizeof(uint64_t) * ((size_t)n + 1), ctx->stream));
+        if (P->n_rec > 0) MM_HIP(hipMemcpyPeerAsync(t_rec[(size_t)p].p, ctx->device, P->rec.p, P->ctx->device, sizeof(mm_map_record) * (size_t)P->n_rec, ctx->stream));
+        pv[(size_t)p].off = t_off[(size_t)p].p; pv[(size_t)p].rec = t_rec[(size_t)p].p;
+      }
     }
-    MM_HIP(hipStreamSynchronize(ctx->stream));
-    for (int p = 0; p < n_parts; ++p) { op.push_back(offs[(size_t)p].data()); rp.push_back(recs[(size_t)p].data()); }
-    mm_mapping* M = merge_parts(ctx, n, parts[0]->read_len, parts[0]->params, n_parts, op.data(), rp.data(), contig_base);
-    for (int p = 0; p < n_parts; ++p) {                          // work counters and stage times: summed over the chunks; per-read facts: of chunk 0
-      const mm_map_stats& S = parts[p]->stats;
-      M->stats.sum_hits += S.sum_hits; M->stats.n_candidates += S.n_candidates; M->stats.sum_hits_kept += S.sum_hits_kept;
-      M->stats.sum_l2_stream_entries += S.sum_l2_stream_entries; M->stats.sum_l2_evals += S.sum_l2_evals;
-      M->stats.n_l2_rebuilds += S.n_l2_rebuilds; M->stats.n_l2_wide_redo += S.n_l2_wide_redo;
-      M->stats.ms_minimizer += S.ms_minimizer; M->stats.ms_sketch += S.ms_sketch; M->stats.ms_probe_gather += S.ms_probe_gather;
-      M->stats.ms_sort_hits += S.ms_sort_hits; M->stats.ms_l1_scan += S.ms_l1_scan; M->stats.ms_l2 += S.ms_l2; M->stats.ms_compact += S.ms_compact;
-      M->stats.ms_total += S.ms_total; M->stats.ms_hit_filter += S.ms_hit_filter;
-    }
-    M->stats.sum_sketch = parts[0]->stats.sum_sketch; M->stats.n_ambiguous_sketch_reads = parts[0]->stats.n_ambiguous_sketch_reads;
-    M->stats.n_reads_giant = parts[0]->stats.n_reads_giant;
+    mm_mapping* M = merge_parts_device(ctx, n, parts[0]->read_len, parts[0]->params, pv);
+    add_part_stats(M, parts, n_parts);
     *out = M;
   });
 }
@@ -496,7 +529,88 @@ int mm_mapping_from_parts(mm_ctx* ctx, int64_t n_reads, const int32_t* read_len,
   for (int i = 0; i < n_parts; ++i) if (!offsets[i] || (!records[i] && offsets[i][n_reads] > 0)) return MM_ERR_ARG;
   return guarded(ctx, [&] {
     std::vector<int32_t> len(read_len, read_len + n_reads);
-    *out = merge_parts(ctx, n_reads, len, *p, n_parts, offsets, records, contig_base);
+    std::vector<PartDev> pv((size_t)n_parts);
+    std::vector<mm::DBuf<uint64_t>> t_off((size_t)n_parts); std::vector<mm::DBuf<mm_map_record>> t_rec((size_t)n_parts);
+    for (int i = 0; i < n_parts; ++i) {
+      const size_t nr = (size_t)offsets[i][n_reads];
+      t_off[(size_t)i].alloc((size_t)n_reads + 1); t_off[(size_t)i].upload((const uint64_t*)offsets[i], (size_t)n_reads + 1, ctx->stream);
+      t_rec[(size_t)i].alloc(std::max<size_t>(nr, 1)); t_rec[(size_t)i].upload(records[i], nr, ctx->stream);
+      pv[(size_t)i] = PartDev{t_off[(size_t)i].p, t_rec[(size_t)i].p, contig_base ? contig_base[i] : 0, 0};
+    }
+    *out = merge_parts_device(ctx, n_reads, len, *p, pv);
+  });
+}
+// The same exchange between the ranks of a communicator (one process per GPU, or one thread per GPU of one process): ncclSend / ncclRecv of the
+// offsets, then of the records, straight between the devices.  Collective: every rank calls it for the same batch.
+int mm_mapping_gather(mm_ctx* ctx, int owner, int64_t n_reads, const int32_t* read_len, const mm_map_params* p, mm_mapping* const* parts, const int32_t* chunk_id,
+                      int n_parts, int n_chunks, const int32_t* chunk_rank, const int32_t* contig_base, mm_mapping** out) {
+  if (!ctx || !p || n_reads < 0 || (!read_len && n_reads > 0) || n_parts < 0 || (n_parts > 0 && (!parts || !chunk_id)) || n_chunks <= 0 || !chunk_rank || !out) return MM_ERR_ARG;
+  *out = nullptr;
+  return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int rank = ctx->comm ? ctx->comm_rank : 0, nranks = ctx->comm ? ctx->comm_size : 1;
+    MM_REQUIRE(owner >= 0 && owner < nranks, MM_ERR_ARG, "mm_mapping_gather: owner is no rank of the communicator");
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    const bool self_send = getenv("MM_GATHER_SELF_SEND") != nullptr && comm;   // test hook: the owner's own parts go through ncclSend / ncclRecv too
+    auto nccl_ok = [&](ncclResult_t rc, const char* what) { MM_REQUIRE(rc == ncclSuccess, MM_ERR_COMM, std::string(what) + ": " + ncclGetErrorString(rc)); };
+    std::vector<int> part_of((size_t)n_chunks, -1);              // chunk -> index into parts[] (this rank's chunks)
+    for (int i = 0; i < n_parts; ++i) {
+      MM_REQUIRE(chunk_id[i] >= 0 && chunk_id[i] < n_chunks && chunk_rank[chunk_id[i]] == rank && parts[i] && parts[i]->n_reads == n_reads, MM_ERR_ARG, "mm_mapping_gather: a part is not a chunk of this rank");
+      MM_REQUIRE(parts[i]->ctx->device == ctx->device, MM_ERR_ARG, "mm_mapping_gather: parts live on the rank's own device");
+      part_of[(size_t)chunk_id[i]] = i;
+    }
+    for (int c = 0; c < n_chunks; ++c) MM_REQUIRE(chunk_rank[c] != rank || part_of[(size_t)c] >= 0, MM_ERR_ARG, "mm_mapping_gather: a chunk of this rank has no part");
+    const size_t n1 = (size_t)n_reads + 1;
+    if (rank != owner) {                                         // my chunks, ascending: all offset arrays, then all record arrays
+      MM_REQUIRE(comm, MM_ERR_STATE, "mm_mapping_gather needs a communicator (mm_comm_init)");
+      nccl_ok(ncclGroupStart(), "ncclGroupStart");
+      for (int c = 0; c < n_chunks; ++c) if (chunk_rank[c] == rank) nccl_ok(ncclSend(parts[part_of[(size_t)c]]->rec_off.p, n1, ncclUint64, owner, comm, st), "ncclSend");
+      nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+      nccl_ok(ncclGroupStart(), "ncclGroupStart");
+      for (int c = 0; c < n_chunks; ++c) if (chunk_rank[c] == rank) { mm_mapping* P = parts[part_of[(size_t)c]]; if (P->n_rec > 0) nccl_ok(ncclSend(P->rec.p, sizeof(mm_map_record) * (size_t)P->n_rec, ncclInt8, owner, comm, st), "ncclSend"); }
+      nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+      MM_HIP(hipStreamSynchronize(st));
+      return;
+    }
+    std::vector<mm::DBuf<uint64_t>> t_off((size_t)n_chunks); std::vector<mm::DBuf<mm_map_record>> t_rec((size_t)n_chunks);
+    auto remote = [&](int c) { return chunk_rank[c] != rank || self_send; };
+    bool any_remote = false;
+    for (int c = 0; c < n_chunks; ++c) any_remote = any_remote || remote(c);
+    std::vector<uint64_t> n_rec_of((size_t)n_chunks, 0);
+    if (any_remote) {
+      MM_REQUIRE(comm, MM_ERR_STATE, "mm_mapping_gather needs a communicator (mm_comm_init)");
+      nccl_ok(ncclGroupStart(), "ncclGroupStart");
+      for (int c = 0; c < n_chunks; ++c) {
+        if (!remote(c)) continue;
+        t_off[(size_t)c].alloc(n1);
+        if (chunk_rank[c] == rank) nccl_ok(ncclSend(parts[part_of[(size_t)c]]->rec_off.p, n1, ncclUint64, rank, comm, st), "ncclSend");
+        nccl_ok(ncclRecv(t_off[(size_t)c].p, n1, ncclUint64, chunk_rank[c], comm, st), "ncclRecv");
+      }
+      nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+      for (int c = 0; c < n_chunks; ++c) if (remote(c)) t_off[(size_t)c].download(&n_rec_of[(size_t)c], 1, st, (size_t)n_reads);
+      MM_HIP(hipStreamSynchronize(st));
+      nccl_ok(ncclGroupStart(), "ncclGroupStart");
+      for (int c = 0; c < n_chunks; ++c) {
+        if (!remote(c) || n_rec_of[(size_t)c] == 0) continue;
+        t_rec[(size_t)c].alloc((size_t)n_rec_of[(size_t)c]);
+        if (chunk_rank[c] == rank) nccl_ok(ncclSend(parts[part_of[(size_t)c]]->rec.p, sizeof(mm_map_record) * (size_t)n_rec_of[(size_t)c], ncclInt8, rank, comm, st), "ncclSend");
+        nccl_ok(ncclRecv(t_rec[(size_t)c].p, sizeof(mm_map_record) * (size_t)n_rec_of[(size_t)c], ncclInt8, chunk_rank[c], comm, st), "ncclRecv");
+      }
+      nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+    }
+    std::vector<PartDev> pv((size_t)n_chunks);
+    for (int c = 0; c < n_chunks; ++c) {
+      const int32_t base = contig_base ? contig_base[c] : 0;
+      if (remote(c)) pv[(size_t)c] = PartDev{t_off[(size_t)c].p, t_rec[(size_t)c].p, base, 0};
+      else { mm_mapping* P = parts[part_of[(size_t)c]]; pv[(size_t)c] = PartDev{P->rec_off.p, P->rec.p, base, 0}; }
+    }
+    std::vector<int32_t> len(read_len, read_len + n_reads);
+    *out = merge_parts_device(ctx, n_reads, len, *p, pv);
+    if (*out) {
+      std::vector<mm_mapping*> mine(parts, parts + n_parts);
+      add_part_stats(*out, mine.data(), n_parts);                // (of the owner's own chunks: the counters of the other ranks stay with them)
+    }
   });
 }
 

@@ -249,7 +249,7 @@ def test_em_resident_kernel_equals_its_phases_as_launches(n_reads, n_taxa, monke
     assert len(lls_ref) == len(ll_a) and np.allclose(lls_ref, ll_a, rtol=1e-12, atol=0) and np.allclose(f_ref, f_a, rtol=1e-10, atol=1e-300)
 
 
-def test_records_gathered_from_parts_equal_device_concat(oracle_lib):
+def test_records_gathered_from_parts_equal_device_concat(oracle_lib, monkeypatch):
     """mm_mapping_from_parts (host-side parts of chunks mapped elsewhere) == mm_mapping_concat, incl. mapping qualities"""
     from metamaps_amd import capi, synth
     import tempfile
@@ -274,7 +274,28 @@ def test_records_gathered_from_parts_equal_device_concat(oracle_lib):
     assert np.array_equal(oa, ob) and len(ra) > 100
     for fld in ("read", "ref_contig", "ref_start", "shared", "sketch", "strand", "mapq"):
         assert np.array_equal(ra[fld], rb[fld]), fld
-    ctx.close(); ctx2.close()
+    # mm_mapping_gather: no communicator (local merge), a one-rank communicator, and — MM_GATHER_SELF_SEND=1 — the owner's own parts through
+    # ncclSend / ncclRecv (offsets, then records): the RCCL exchange of the sharded-index mode, as far as one GPU can run it
+    ctx3 = capi.Context(0)
+    ctx3.comm_init(capi.Context.comm_unique_id(), 0, 1)
+    parts3 = []
+    for a, b in ((0, half), (half, len(contigs))):
+        S = ctx3.seqset(contigs[a:b]); idx3 = ctx3.index(S, k, w)
+        R3 = ctx3.seqset(reads)
+        parts3.append(ctx3.map_batch(idx3, R3, k, w))
+    for c, pp, env in ((ctx, parts, None), (ctx3, parts3, None), (ctx3, parts3, "1")):
+        if env:
+            monkeypatch.setenv("MM_GATHER_SELF_SEND", env)
+        G = capi.Mapping.gather(c, 0, lens, pp, [0, 1], [0, 0], [0, half], k, w); G.add_qualities(k)
+        monkeypatch.delenv("MM_GATHER_SELF_SEND", raising=False)
+        og, rg = G.fetch()
+        assert np.array_equal(oa, og) and ra.tobytes() == rg.tobytes()
+        assert G.stats()["sum_hits"] == U.stats()["sum_hits"]
+        G.close()
+    Y = capi.Mapping.concat(ctx2, parts, [0, half]); Y.add_qualities(k)      # parts of another context of the device
+    oy, ry = Y.fetch()
+    assert np.array_equal(oa, oy) and ra.tobytes() == ry.tobytes()
+    ctx.close(); ctx2.close(); ctx3.close()
 
 
 # ---- the multi-rank classify bookkeeping (shard ranges, shard-local offsets, best-mapping rebasing, final f), everything around the

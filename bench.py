@@ -896,9 +896,21 @@ def e2e_cli_full(args, k, w, rank_seed):
         if n_stream:
             pre_s = os.path.join(d, "out_stream")
             _o, e_s, t_map_s, rss_s = _run_cli_with_rss([cli, "mapDirectly", "--all", "-r", fasta, "-q", fq_s, "-o", pre_s], env, 1500)
+            if os.environ.get("MM_BENCH_E2E_LOG"):
+                open(os.path.join(os.environ["MM_BENCH_E2E_LOG"], "cli_stream_map.err"), "w").write(e_s)
             laps_s = {ln.split(" at +")[0][len("INFO, lap "):]: float(ln.split(" at +")[1].split()[0]) for ln in e_s.splitlines() if ln.startswith("INFO, lap ")}
             ph_s = {" ".join(ln.split()[2:-2]): float(ln.split()[-2]) for ln in e_s.splitlines() if ln.startswith("INFO, time ")}
             _o2, e_c, t_cls_s, rss_cs = _run_cli_with_rss([cli, "classify", "--DB", db, "--mappings", pre_s], env, 1500)
+            if os.environ.get("MM_BENCH_E2E_LOG"):
+                open(os.path.join(os.environ["MM_BENCH_E2E_LOG"], "cli_stream_classify.err"), "w").write(e_c)
+            variants = {}
+            for wv in [x for x in os.environ.get("MM_BENCH_E2E_WORKER_SWEEP", "").split(",") if x]:   # the mapping phase again with other numbers of worker contexts per device
+                _o3, e_v, t_v, _r = _run_cli_with_rss([cli, "mapDirectly", "--all", "-r", fasta, "-q", fq_s, "-o", pre_s + "_w" + wv, "--workers-per-gpu", wv], env, 1500)
+                lv = {ln.split(" at +")[0][len("INFO, lap "):]: float(ln.split(" at +")[1].split()[0]) for ln in e_v.splitlines() if ln.startswith("INFO, lap ")}
+                pv = {" ".join(ln.split()[2:-2]): float(ln.split()[-2]) for ln in e_v.splitlines() if ln.startswith("INFO, time ")}
+                variants[wv] = {"mapping_phase_s": round(lv.get("8 write", t_v) - lv.get("3 index build", 0.0), 3), "phases": pv,
+                                "same_file": open(pre_s).read() == open(pre_s + "_w" + wv).read()}
+                os.remove(pre_s + "_w" + wv)
             cph = {ln.split()[2] + " " + " ".join(ln.split()[3:-2]): float(ln.split()[-2]) for ln in e_c.splitlines() if ln.startswith("INFO, time c")}
             cmain = {ln.split(" at +")[0][12:]: float(ln.split(" at +")[1].split()[0]) for ln in e_c.splitlines() if ln.startswith("INFO, main: ")}
             t_phase_s = max(laps_s.get("8 write", t_map_s) - laps_s.get("3 index build", 0.0), 1e-9)
@@ -911,7 +923,7 @@ def e2e_cli_full(args, k, w, rank_seed):
                       "mapping_phase_s": round(t_phase_s, 3), "classify_work_s": round(t_cls_work_s, 3), "classify_wall_s": round(t_cls_s, 3), "mapDirectly_wall_s": round(t_map_s, 3),
                       "value": bases_s / (t_phase_s + t_cls_work_s) / 1e9, "unit": "Gbp/s", "mapping_phase_value": bases_s / t_phase_s / 1e9,
                       "map_laps_s": laps_s, "map_phases_s": ph_s, "classify_phases_s": cph, "classify_main_s": cmain,
-                      "mappings_file_bytes": os.path.getsize(pre_s), "peak_host_rss_bytes": {"mapDirectly": int(rss_s), "classify": int(rss_cs)},
+                      "mappings_file_bytes": os.path.getsize(pre_s), "worker_sweep": variants, "peak_host_rss_bytes": {"mapDirectly": int(rss_s), "classify": int(rss_cs)},
                       "meta": {kk: int(v) for kk, v in meta_s.items()}}
         t_ingest = max(t_map - t_setup, 1e-9)                    # (process wall behind the index build: includes the driver's teardown of 150 GB at exit, ~0.5 s)
         t_phase = max(laps.get("8 write", t_map) - t_setup, 1e-9)  # the mapping phase by the CLI's own clock: index built -> last output file written

@@ -417,7 +417,7 @@ int map_mode(const Options& o, const std::string& mode) {
       // inside the range is final; the range's last chunk is not (it may go on), so the next range starts there.
       std::cout << "INFO, the index of " << ref_bases << " reference bases does not fit one device's " << (hbm_free >> 30) << " GiB: the chunk rule is evaluated on contig ranges\n";
       const int C = (int)cname.size();
-      uint64_t range_bases = o.v.count("stream-range-bases") ? std::stoull(o.v.at("stream-range-bases")) : (uint64_t)(0.5 * (double)hbm_free / INDEX_BYTES_PER_BASE);
+      uint64_t range_bases = o.v.count("stream-range-bases") ? std::stoull(o.v.at("stream-range-bases")) : (uint64_t)(0.4 * (double)hbm_free / INDEX_BYTES_PER_BASE)   /* (the build of a range index peaks at about twice its resident size) */;
       int c0 = 0;
       while (c0 < C) {
         int c1 = c0; uint64_t bases = 0;
@@ -740,7 +740,8 @@ int map_mode(const Options& o, const std::string& mode) {
   if (place == Place::Replicated) {
     // ---- workers: three contexts per device (--workers-per-gpu), so that packing, result download and text formatting of one batch overlap the
     // kernels of the other; the device's chunk indexes are shared (read-only) by its contexts
-    const size_t WPD = o.v.count("workers-per-gpu") ? (size_t)std::max(1, std::stoi(o.v.at("workers-per-gpu"))) : 3;
+    const size_t WPD = o.v.count("workers-per-gpu") ? (size_t)std::max(1, std::stoi(o.v.at("workers-per-gpu")))
+                     : getenv("MM_CLI_WORKERS") ? (size_t)std::max(1, atoi(getenv("MM_CLI_WORKERS"))) : 3;
     std::vector<std::thread> workers;
     for (size_t d = 0; d < G; ++d) for (size_t wi = 0; wi < WPD; ++wi) workers.emplace_back([&, d, wi]() {
       mm_ctx* ctx = devs[d].ctx;
@@ -951,7 +952,8 @@ struct ContigCoverage {
   const size_t W = 1000;
   std::map<std::string, std::map<std::string, std::vector<size_t>>> cov, reads;   // bases / best mappings per window
   std::map<std::string, std::map<std::string, size_t>> last;
-  void add(const std::string& tx, const std::string& cg, size_t L, size_t start, size_t stop_in) {
+  struct Slot { std::vector<size_t>* v = nullptr; std::vector<size_t>* nr = nullptr; };   // the two window vectors of a contig (map nodes do not move)
+  Slot slot(const std::string& tx, const std::string& cg, size_t L) {
     auto& per = cov[tx];
     if (!per.count(cg)) {
       size_t n = L / W;
@@ -961,9 +963,13 @@ struct ContigCoverage {
       per[cg].assign(n, 0);
       reads[tx][cg].assign(n, 0);
     }
+    return Slot{&per[cg], &reads[tx][cg]};
+  }
+  void add(const std::string& tx, const std::string& cg, size_t L, size_t start, size_t stop_in) { add(slot(tx, cg, L), L, start, stop_in); }
+  void add(const Slot& sl, size_t L, size_t start, size_t stop_in) {
     const size_t stop = stop_in >= L ? L - 1 : stop_in;
-    std::vector<size_t>& v = per[cg];
-    std::vector<size_t>& nr = reads[tx][cg];
+    std::vector<size_t>& v = *sl.v;
+    std::vector<size_t>& nr = *sl.nr;
     for (size_t p = start; p <= stop; p += W) {
       const size_t wi = p / W, ws = wi * W;
       size_t we = (wi + 1) * W - 1;
@@ -1194,43 +1200,122 @@ void run_em_sharded(const std::vector<Dev>& devs, EmReduce reduce, const std::ve
   });
 }
 
+// std::to_string(double) = "%f" for a posterior in [0, 1] (fEM.h:705), without printf: the six decimals are the product with 10^6 rounded
+// half-to-even on the EXACT value, as glibc rounds; the product is only trusted when it is clear of a tie by far more than its own
+// rounding error (2^-33 at this magnitude), anything else — and anything outside [0, 1] — goes through snprintf.
+inline void append_f6(std::string& out, double x) {
+  if (x >= 0 && x <= 1) {
+    const double v = x * 1e6, fl = std::floor(v), fr = v - fl;
+    if (std::fabs(fr - 0.5) > 1e-6) {
+      unsigned long long q = (unsigned long long)fl + (fr > 0.5 ? 1 : 0);   // 0 .. 1000000
+      char b[8]; b[0] = (char)('0' + q / 1000000); q %= 1000000; b[1] = '.';
+      for (int i = 7; i >= 2; --i) { b[i] = (char)('0' + q % 10); q /= 10; }
+      out.append(b, 8);
+      return;
+    }
+  }
+  char num[400]; snprintf(num, sizeof num, "%f", x); out += num;
+}
+
 int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::string& mapped, const std::string& db, size_t minReadsU) {   // meta::doEM, fEM.h:466-803
   PhaseClock pc;
   // The mappings file once through: every line is tokenised where it lies (the reference splits every line again in every EM round,
   // fEM.h:1171-1214, :234-373), lines of one read are consecutive (mapWrap.h:128-149), contig IDs are interned.
+  // Round 4: read and tokenised by several threads — pieces of the file that begin on a read boundary are parsed on their own and joined in
+  // file order (read offsets shifted, contig IDs interned in the order a single pass would meet them): 4.2 M lines took 1.3 s on one thread.
   std::string text;
-  { std::ifstream s(mapped, std::ios::binary); if (!s.is_open()) die("Cannot open mappings file " + mapped);
-    s.seekg(0, std::ios::end); const std::streamoff n = s.tellg(); s.seekg(0); text.resize((size_t)std::max<std::streamoff>(n, 0)); if (n > 0) s.read(&text[0], n); }
+  const unsigned HW = std::max(1u, std::thread::hardware_concurrency());
+  {
+    const int fd = ::open(mapped.c_str(), O_RDONLY);
+    if (fd < 0) die("Cannot open mappings file " + mapped);
+    struct stat stt; if (fstat(fd, &stt) != 0) die("Cannot open mappings file " + mapped);
+    text.resize((size_t)stt.st_size);
+    const size_t PIECE = (size_t)32 << 20, np = (text.size() + PIECE - 1) / PIECE;
+    std::atomic<size_t> nx{0}; std::atomic<bool> bad{false};
+    auto rd = [&] { for (;;) { const size_t i = nx.fetch_add(1); if (i >= np) return; size_t a0 = i * PIECE; const size_t e0 = std::min(text.size(), a0 + PIECE);
+                      while (a0 < e0) { const ssize_t g = pread(fd, &text[a0], e0 - a0, (off_t)a0); if (g <= 0) { bad = true; return; } a0 += (size_t)g; } } };
+    std::vector<std::thread> pool; for (unsigned t = 1; t < std::min<unsigned>({8u, HW, (unsigned)std::max<size_t>(np, 1)}); ++t) pool.emplace_back(rd);
+    rd(); for (auto& t : pool) t.join();
+    ::close(fd);
+    if (bad) die("Cannot read mappings file " + mapped);
+  }
   struct MapLine { size_t beg, last_space, end; int contig; long long len; size_t start, stop; double ident, mapq; };   // [beg, end): the line; last_space: the blank before field 14
   std::vector<MapLine> lines; std::vector<int64_t> off{0};       // read r owns lines [off[r], off[r+1])
   std::vector<std::string> contig_id; std::unordered_map<std::string, int> contig_index;
   {
     const char* const T0 = text.c_str();
-    size_t cur_beg = 0, cur_len = (size_t)-1;                    // the current read's ID, as a span of `text`
-    for (size_t p = 0; p < text.size();) {
-      const char* nl = (const char*)memchr(T0 + p, '\n', text.size() - p);
-      const size_t e = nl ? (size_t)(nl - T0) : text.size();
-      if (e == p) { p = e + 1; continue; }                       // empty line
-      size_t fb[16], fe[16]; int nf = 0;                         // fields (single blanks, util.h:80)
-      for (size_t q = p; nf < 16;) { const char* sp = (const char*)memchr(T0 + q, ' ', e - q); fb[nf] = q; fe[nf] = sp ? (size_t)(sp - T0) : e; ++nf; if (!sp) break; q = fe[nf - 1] + 1; }
-      if (nf < 6) die("File " + mapped + " has weird format - is this a mappings file generated by MetaMap?");
-      if (nf < 14) die("File " + mapped + " has lines with fewer than 14 fields - is this a mappings file generated by MetaMap?");
-      if (fe[0] - fb[0] != cur_len || memcmp(T0 + fb[0], T0 + cur_beg, cur_len) != 0) { if (!lines.empty()) off.push_back((int64_t)lines.size()); cur_beg = fb[0]; cur_len = fe[0] - fb[0]; }
-      MapLine L{};
-      L.beg = p; L.end = e; L.last_space = fb[13] - 1;
-      std::string cid(T0 + fb[5], fe[5] - fb[5]);
-      auto it = contig_index.find(cid);
-      if (it == contig_index.end()) { it = contig_index.emplace(cid, (int)contig_id.size()).first; contig_id.push_back(cid); }
-      L.contig = it->second;
-      L.len = std::stoi(std::string(T0 + fb[1], fe[1] - fb[1]));
-      L.start = std::stoull(std::string(T0 + fb[7], fe[7] - fb[7])); L.stop = std::stoull(std::string(T0 + fb[8], fe[8] - fb[8]));
-      L.ident = strtod(T0 + fb[9], nullptr) / 100.0;
-      { errno = 0; char* endp = nullptr; L.mapq = strtod(T0 + fb[13], &endp);   // std::stod: out of range (also a denormal) throws; the reference then takes 0 for "…e-…" (fEM.h:269-275)
-        if (errno == ERANGE) { if (std::string(T0 + fb[13], fe[13] - fb[13]).find("e-") != std::string::npos) L.mapq = 0; else die("mapping quality out of range in " + mapped); }
-        if (endp == T0 + fb[13]) die("File " + mapped + " has a mapping quality that is not a number"); }
-      lines.push_back(L);
-      p = e + 1;
+    const size_t TS = text.size();
+    // the read ID of the line that starts at p (text up to the first blank or the line's end)
+    auto id_of = [&](size_t p, size_t& len) { const char* nl = (const char*)memchr(T0 + p, '\n', TS - p); const size_t e = nl ? (size_t)(nl - T0) : TS;
+                                              const char* sp = (const char*)memchr(T0 + p, ' ', e - p); len = (sp ? (size_t)(sp - T0) : e) - p; };
+    auto next_line = [&](size_t p) { const char* nl = (const char*)memchr(T0 + p, '\n', TS - p); return nl ? (size_t)(nl - T0) + 1 : TS; };
+    // first read boundary at or after x: a line start whose ID differs from the ID of the last non-empty line before it
+    auto read_boundary = [&](size_t x) {
+      if (x == 0) return (size_t)0;
+      size_t p = next_line(x - 1);                                // start of the first line that begins at or after x
+      while (p < TS) {
+        if (T0[p] == '\n') { ++p; continue; }                     // empty line
+        size_t q = p;                                            // start of the previous non-empty line
+        for (;;) { if (q == 0) return p; size_t e = q - 1; size_t b0 = e; while (b0 > 0 && T0[b0 - 1] != '\n') --b0; if (e > b0) { q = b0; break; } q = b0; }
+        size_t la, lb; id_of(p, la); id_of(q, lb);
+        if (la != lb || memcmp(T0 + p, T0 + q, la) != 0) return p;
+        p = next_line(p);
+      }
+      return TS;
+    };
+    const size_t NTH = std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::max(1u, HW / 4), TS / ((size_t)4 << 20) + 1, (size_t)(getenv("MM_CLASSIFY_THREADS") ? std::max(1, atoi(getenv("MM_CLASSIFY_THREADS"))) : 1 << 20)}));
+    std::vector<size_t> cut(NTH + 1, TS);
+    cut[0] = 0;
+    for (size_t t = 1; t < NTH; ++t) cut[t] = std::max(cut[t - 1], read_boundary(TS / NTH * t));
+    struct Piece { std::vector<MapLine> lines; std::vector<int64_t> starts; std::vector<std::string> cid; std::unordered_map<std::string, int> cix; };
+    std::vector<Piece> pieces(NTH);
+    auto parse_piece = [&](size_t t) {
+      Piece& P = pieces[t];
+      size_t cur_beg = 0, cur_len = (size_t)-1;                  // the current read's ID, as a span of `text`
+      for (size_t p = cut[t]; p < cut[t + 1];) {
+        const char* nl = (const char*)memchr(T0 + p, '\n', cut[t + 1] - p);
+        const size_t e = nl ? (size_t)(nl - T0) : cut[t + 1];
+        if (e == p) { p = e + 1; continue; }                     // empty line
+        size_t fb[16], fe[16]; int nf = 0;                       // fields (single blanks, util.h:80)
+        for (size_t q = p; nf < 16;) { const char* sp = (const char*)memchr(T0 + q, ' ', e - q); fb[nf] = q; fe[nf] = sp ? (size_t)(sp - T0) : e; ++nf; if (!sp) break; q = fe[nf - 1] + 1; }
+        if (nf < 6) die("File " + mapped + " has weird format - is this a mappings file generated by MetaMap?");
+        if (nf < 14) die("File " + mapped + " has lines with fewer than 14 fields - is this a mappings file generated by MetaMap?");
+        if (fe[0] - fb[0] != cur_len || memcmp(T0 + fb[0], T0 + cur_beg, cur_len) != 0) { P.starts.push_back((int64_t)P.lines.size()); cur_beg = fb[0]; cur_len = fe[0] - fb[0]; }
+        MapLine L{};
+        L.beg = p; L.end = e; L.last_space = fb[13] - 1;
+        std::string cid(T0 + fb[5], fe[5] - fb[5]);
+        auto it = P.cix.find(cid);
+        if (it == P.cix.end()) { it = P.cix.emplace(cid, (int)P.cid.size()).first; P.cid.push_back(cid); }
+        L.contig = it->second;
+        L.len = strtoll(T0 + fb[1], nullptr, 10);
+        L.start = strtoull(T0 + fb[7], nullptr, 10); L.stop = strtoull(T0 + fb[8], nullptr, 10);
+        L.ident = strtod(T0 + fb[9], nullptr) / 100.0;
+        { errno = 0; char* endp = nullptr; L.mapq = strtod(T0 + fb[13], &endp);   // std::stod: out of range (also a denormal) throws; the reference then takes 0 for "…e-…" (fEM.h:269-275)
+          if (errno == ERANGE) { if (std::string(T0 + fb[13], fe[13] - fb[13]).find("e-") != std::string::npos) L.mapq = 0; else die("mapping quality out of range in " + mapped); }
+          if (endp == T0 + fb[13]) die("File " + mapped + " has a mapping quality that is not a number"); }
+        P.lines.push_back(L);
+        p = e + 1;
+      }
+    };
+    { std::vector<std::thread> pool; for (size_t t = 1; t < NTH; ++t) pool.emplace_back(parse_piece, t); parse_piece(0); for (auto& th : pool) th.join(); }
+    // join: contig IDs in the order of their first line, read offsets shifted by the lines before the piece
+    std::vector<std::vector<int>> remap(NTH);
+    std::vector<size_t> line0(NTH + 1, 0);
+    for (size_t t = 0; t < NTH; ++t) {
+      line0[t + 1] = line0[t] + pieces[t].lines.size();
+      remap[t].resize(pieces[t].cid.size());
+      for (size_t c = 0; c < pieces[t].cid.size(); ++c) {
+        auto it = contig_index.find(pieces[t].cid[c]);
+        if (it == contig_index.end()) { it = contig_index.emplace(pieces[t].cid[c], (int)contig_id.size()).first; contig_id.push_back(pieces[t].cid[c]); }
+        remap[t][c] = it->second;
+      }
     }
+    lines.resize(line0[NTH]);
+    off.clear();
+    for (size_t t = 0; t < NTH; ++t) for (int64_t st0 : pieces[t].starts) off.push_back(st0 + (int64_t)line0[t]);
+    if (off.empty()) off.push_back(0);
+    auto place = [&](size_t t) { MapLine* o = lines.data() + line0[t]; const auto& src = pieces[t].lines; for (size_t i = 0; i < src.size(); ++i) { o[i] = src[i]; o[i].contig = remap[t][(size_t)src[i].contig]; } };
+    { std::vector<std::thread> pool; for (size_t t = 1; t < NTH; ++t) pool.emplace_back(place, t); place(0); for (auto& th : pool) th.join(); }
     if (!lines.empty()) off.push_back((int64_t)lines.size());
   }
   const size_t NRD = off.size() - 1;
@@ -1301,34 +1386,65 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
   std::map<std::string, std::vector<double>> identsPerTaxon;     // :691, :718
   long long maxReadLen = -1;                                     // :692, :719-722
   {
-    std::string emtxt; emtxt.reserve(text.size() + lines.size() * 8);
-    std::string r2txt, krtxt, litxt;
-    char num[64];
+    // the four per-read / per-line files: ranges of reads formatted by several threads into their own buffers, written in read order
+    // (4.2 M lines through std::to_string on one thread took 1.2 s); the per-taxon tallies and the coverage windows follow in read order
     std::vector<std::string> tax_nonx(taxa.size());              // getFirstNonXNode per taxon (taxonomy.h:51-74), once
     for (size_t t = 0; t < taxa.size(); ++t) tax_nonx[t] = T.first_non_x(taxa[t]);
-    for (size_t r = 0; r < NRD; ++r) {                           // fEM.h:684-779
-      for (size_t i = (size_t)off[r]; i < (size_t)off[r + 1]; ++i) {   // the line with field 14 replaced by std::to_string(posterior) (:705)
-        emtxt.append(text, lines[i].beg, lines[i].last_space + 1 - lines[i].beg);
-        emtxt += std::to_string(post[i]);
-        emtxt += '\n';
+    const size_t NTH = std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::max(1u, HW / 4), lines.size() / 50000 + 1, (size_t)(getenv("MM_CLASSIFY_THREADS") ? std::max(1, atoi(getenv("MM_CLASSIFY_THREADS"))) : 1 << 20)}));
+    std::vector<size_t> rcut(NTH + 1, NRD);
+    rcut[0] = 0;
+    { size_t t = 1; for (size_t r = 0; r < NRD && t < NTH; ++r) if ((uint64_t)off[r] >= (uint64_t)lines.size() * t / NTH) rcut[t++] = r; }
+    struct Out { std::string em, r2, kr, li; };
+    std::vector<Out> outs(NTH);
+    auto fmt = [&](size_t t) {
+      Out& O = outs[t];
+      const size_t r0 = rcut[t], r1 = rcut[t + 1];
+      if (r1 <= r0) return;
+      O.em.reserve((lines[(size_t)off[r1] - 1].end - lines[(size_t)off[r0]].beg) + ((size_t)off[r1] - (size_t)off[r0]) * 4 + 64);
+      char num[64];
+      for (size_t r = r0; r < r1; ++r) {                         // fEM.h:684-779
+        for (size_t i = (size_t)off[r]; i < (size_t)off[r + 1]; ++i) {   // the line with field 14 replaced by std::to_string(posterior) (:705)
+          O.em.append(text, lines[i].beg, lines[i].last_space + 1 - lines[i].beg);
+          append_f6(O.em, post[i]);
+          O.em += '\n';
+        }
+        const size_t b = (size_t)best[r];
+        const MapLine& B = lines[b];
+        const std::string& cg = contig_id[(size_t)B.contig];
+        const size_t rid_end = (size_t)((const char*)memchr(text.c_str() + B.beg, ' ', B.end - B.beg) - text.c_str());
+        O.li += "EqualCoverageUnit\t"; O.li += cg; O.li += '\t';
+        snprintf(num, sizeof num, "%zu\t%g\t%lld\n", r, B.ident, B.len); O.li += num;                  // :711
+        O.r2.append(text, B.beg, rid_end - B.beg); O.r2 += '\t'; O.r2 += taxa[(size_t)taxon[b]]; O.r2 += '\n';
+        O.kr.append(text, B.beg, rid_end - B.beg); O.kr += '\t'; O.kr += tax_nonx[(size_t)taxon[b]];
+        snprintf(num, sizeof num, "\t%g\n", post[b]); O.kr += num;
       }
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < NTH; ++t) pool.emplace_back(fmt, t);
+    // meanwhile, on this thread: tallies per taxon and coverage windows, in read order (taxon and contig by index, strings only at the end)
+    std::vector<size_t> readsPerIdx(taxa.size(), 0);
+    std::vector<std::vector<double>> identsIdx(taxa.size());
+    std::vector<ContigCoverage::Slot> cslot(contig_id.size());
+    fmt(0);
+    for (size_t r = 0; r < NRD; ++r) {
       const size_t b = (size_t)best[r];
       const MapLine& B = lines[b];
-      const std::string& tx = taxa[(size_t)taxon[b]];
-      const std::string& cg = contig_id[(size_t)B.contig];
-      const size_t rid_end = (size_t)((const char*)memchr(text.c_str() + B.beg, ' ', B.end - B.beg) - text.c_str());
-      litxt += "EqualCoverageUnit\t"; litxt += cg; litxt += '\t';
-      snprintf(num, sizeof num, "%zu\t%g\t%lld\n", r, B.ident, B.len); litxt += num;                   // :711
-      r2txt.append(text, B.beg, rid_end - B.beg); r2txt += '\t'; r2txt += tx; r2txt += '\n';
-      krtxt.append(text, B.beg, rid_end - B.beg); krtxt += '\t'; krtxt += tax_nonx[(size_t)taxon[b]];
-      snprintf(num, sizeof num, "\t%g\n", post[b]); krtxt += num;
-      readsPer[tx]++;
-      identsPerTaxon[tx].push_back(B.ident);
+      const size_t tx = (size_t)taxon[b];
+      readsPerIdx[tx]++;
+      identsIdx[tx].push_back(B.ident);
       maxReadLen = std::max(maxReadLen, B.len);
-      if (contig_len_ti[(size_t)B.contig] < 0) die("contig " + cg + " is not listed for taxon " + tx + " in " + db + "/taxonInfo.txt");
-      coverage.add(tx, cg, (size_t)contig_len_ti[(size_t)B.contig], B.start, B.stop);
+      if (contig_len_ti[(size_t)B.contig] < 0) die("contig " + contig_id[(size_t)B.contig] + " is not listed for taxon " + taxa[tx] + " in " + db + "/taxonInfo.txt");
+      ContigCoverage::Slot& sl = cslot[(size_t)B.contig];
+      if (!sl.v) sl = coverage.slot(taxa[tx], contig_id[(size_t)B.contig], (size_t)contig_len_ti[(size_t)B.contig]);
+      coverage.add(sl, (size_t)contig_len_ti[(size_t)B.contig], B.start, B.stop);
     }
-    emf << emtxt; r2t << r2txt; kr << krtxt; li << litxt;
+    for (size_t t = 0; t < taxa.size(); ++t) if (readsPerIdx[t]) { readsPer[taxa[t]] = readsPerIdx[t]; identsPerTaxon[taxa[t]] = std::move(identsIdx[t]); }
+    for (auto& th : pool) th.join();
+    pc.lap("c5a format");
+    auto put = [&](std::ofstream& f, std::string Out::*m) { for (auto& O : outs) f.write((O.*m).data(), (std::streamsize)(O.*m).size()); };
+    std::thread w1([&] { put(r2t, &Out::r2); put(kr, &Out::kr); put(li, &Out::li); });
+    put(emf, &Out::em);
+    w1.join();
   }
   { std::ifstream s(mapped + ".meta.unmappedReadsLengths"); std::string ln;
     while (std::getline(s, ln)) { if (ln.empty()) continue; auto fl = split(ln, "\t"); r2t << fl.at(1) << "\t" << 0 << "\n"; kr << fl.at(1) << "\t" << 0 << "\t" << 0 << "\n"; } }
@@ -1340,9 +1456,12 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
     double s = 0; for (auto& e : fmap) s += e.second; for (auto& e : fmap) e.second /= s; }
   pc.lap("c5 output files");
   write_wimp(mapped + ".EM.WIMP", T, fmap, readsPer, nTotal, nUnmapped, nTooShort);
+  pc.lap("c6 WIMP");
   coverage.write(mapped + ".EM.contigCoverage", T);
+  pc.lap("c7 contig coverage");
   if (!write_unknown_species(mapped + ".EM.evidenceUnknownSpecies", db, T, coverage, identsPerTaxon, maxReadLen, minReadsU))
     std::cerr << "Warning: " << db << "/contigNstats_windowSize_1000.txt not found - " << mapped << ".EM.evidenceUnknownSpecies is not written." << std::endl;
+  pc.lap("c8 evidence of unknown species");
   return 0;
 }
 

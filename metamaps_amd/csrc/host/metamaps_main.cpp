@@ -30,6 +30,7 @@
 #include "../../../include/metamaps_hip.h"
 #include "seq_reader.hpp"
 #include "host_util.hpp"
+#include "fast_format.hpp"
 #include <sys/mman.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -148,6 +149,12 @@ struct Batch {
     if (f.view) put_view(f.view); else put(f.seq);
   }
   void reset() { names.clear(); lens.clear(); off.clear(); view.clear(); used = 0; }
+  int64_t bases() const { int64_t b = 0; for (int L : lens) b += L; return b; }
+  void absorb(Batch& o) {                                        // o's reads behind this batch's (the block parser's small batches joined up to the batch limits)
+    const size_t base = used;
+    if (o.used) { reserve(used + o.used); memcpy(arena + used, o.arena, o.used); used += o.used; }
+    for (size_t i = 0; i < o.names.size(); ++i) { names.push_back(std::move(o.names[i])); lens.push_back(o.lens[i]); view.push_back(o.view[i]); off.push_back(o.view[i] ? 0 : base + o.off[i]); }
+  }
 };
 
 // one logical GPU: a context (stream + allocator) on a physical device, and the chunk indexes that live there
@@ -176,22 +183,39 @@ static void format_range(const std::vector<std::string>& names, const std::vecto
                          const std::vector<mm_map_record>& rec, const std::vector<std::string>& cname, const std::vector<int>& clen, int k, size_t r0, size_t r1, std::string& out) {
   out.clear();
   out.reserve((size_t)(off[r1] - off[r0]) * 160);
-  char num[256];
+  // fields 10 and 13 are functions of (conserved sketches, sketch size) alone: formatted once per pair and thread (a few thousand pairs cover a
+  // batch); no printf anywhere on the line (fast_format.hpp) — 4.2 M lines took 2 s of the mapping phase of a million reads
+  struct Pair { uint64_t key; char ids[16], corr[16]; uint8_t n_ids, n_corr; };
+  static thread_local std::vector<Pair> cache; static thread_local int cache_k = -1;
+  constexpr size_t CB = 1 << 14;
+  if (cache.size() != CB || cache_k != k) { cache.assign(CB, Pair{~0ull, {0}, {0}, 0, 0}); cache_k = k; }
+  std::string tmp;
   for (size_t r = r0; r < r1; ++r) {
     const int len = lens[r];
     for (int64_t i = off[r]; i < off[r + 1]; ++i) {
       const mm_map_record& x = rec[(size_t)i];
-      float id; mm_identity(x.shared, x.sketch, k, &id, nullptr);
-      char ids[48]; snprintf(ids, sizeof ids, "%g", (double)id);   // operator<<(float): %g with 6 significant digits; printed, then re-parsed (mapWrap.h:237)
-      const double reported = strtod(ids, nullptr) / 100.0;
-      const float corrected = std::exp(-(1 - reported));          // mapWrap.h:311
+      const uint64_t key = (uint64_t)(uint32_t)x.sketch << 32 | (uint32_t)x.shared;
+      Pair& P = cache[(size_t)((key * 0x9E3779B97F4A7C15ull) >> 50)];
+      if (P.key != key) {
+        float id; mm_identity(x.shared, x.sketch, k, &id, nullptr);
+        tmp.clear(); append_g6(tmp, (double)id);                   // operator<<(float): %g with 6 significant digits; printed, then re-parsed (mapWrap.h:237)
+        P.n_ids = (uint8_t)tmp.size(); memcpy(P.ids, tmp.data(), tmp.size());
+        const double reported = strtod(tmp.c_str(), nullptr) / 100.0;
+        const float corrected = std::exp(-(1 - reported));        // mapWrap.h:311
+        tmp.clear(); append_g6(tmp, (double)(corrected * 100));
+        P.n_corr = (uint8_t)tmp.size(); memcpy(P.corr, tmp.data(), tmp.size());
+        P.key = key;
+      }
       out += names[r];
-      int n = snprintf(num, sizeof num, " %d 0 %d %c ", len, len - 1, x.strand == 1 ? '+' : '-');
-      out.append(num, (size_t)n);
+      out += ' '; append_int(out, len); out += " 0 "; append_int(out, len - 1); out += ' '; out += x.strand == 1 ? '+' : '-'; out += ' ';
       out += cname[(size_t)x.ref_contig];
-      n = snprintf(num, sizeof num, " %d %d %d %s %d %d %g %g\n", clen[(size_t)x.ref_contig], x.ref_start, x.ref_start + len - 1, ids, x.shared, x.sketch,
-                   (double)(corrected * 100), x.mapq);              // :318-320
-      out.append(num, (size_t)n);
+      out += ' '; append_int(out, clen[(size_t)x.ref_contig]);
+      out += ' '; append_int(out, x.ref_start); out += ' '; append_int(out, (long long)x.ref_start + len - 1);
+      out += ' '; out.append(P.ids, P.n_ids);
+      out += ' '; append_int(out, x.shared); out += ' '; append_int(out, x.sketch);
+      out += ' '; out.append(P.corr, P.n_corr);
+      out += ' '; append_g6(out, x.mapq);                          // :318-320
+      out += '\n';
     }
   }
 }
@@ -199,7 +223,7 @@ static void format_range(const std::vector<std::string>& names, const std::vecto
 void format_records(const std::vector<std::string>& names, const std::vector<int>& lens, const std::vector<int64_t>& off,
                     const std::vector<mm_map_record>& rec, const std::vector<std::string>& cname, const std::vector<int>& clen, int k, std::string& out) {
   const size_t n = names.size();
-  const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 8), rec.size() / 20000 + 1}));
+  const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 8), rec.size() / 30000 + 1}));
   if (T == 1) { format_range(names, lens, off, rec, cname, clen, k, 0, n, out); return; }
   std::vector<size_t> cut(T + 1, n);
   cut[0] = 0;
@@ -267,8 +291,19 @@ int map_mode(const Options& o, const std::string& mode) {
   uint64_t hbm_free = 0;
   auto query_free = [&] { char nm[8]; int cus; uint64_t tot; mm_ctx_device_info(ctx0, nm, sizeof nm, &cus, &tot, &hbm_free); };
   query_free();
-  const double INDEX_BYTES_PER_BASE = 5.5;                       // pos + padded occ + table at w = 8; denser for smaller w
-  auto fits = [&](uint64_t bases, double share) { return (double)bases * INDEX_BYTES_PER_BASE * 1.2 * share <= 0.8 * (double)hbm_free; };
+  // Resident bytes of the index of `bases` reference bases: N = 2 bases / (w + 1) entries; U distinct hashes — minimizer
+  // hashes are window minima, so they crowd into the low end of the 32-bit space: measured 5.92e8 distinct among 5.94e9 entries at w = 8,
+  // i.e. an effective space of H = 1.3 * 2^32 / (w + 1) values that fills as U = H (1 - exp(-N / H)); pos 8 N + occurrence lists padded to
+  // 64-byte sectors 8 (N + 7 U) at most + a quarter of that in bin codes + 29 U of table.  Per base this FALLS with the size of the
+  // reference: 6 bytes at 26.8 Gbp, 22 at 1 Gbp, where nearly every hash is a list of one padded to eight (a flat 5.5 bytes per base,
+  // rounds 1-3, let a 0.5 Gbp planning range ask for 5.5 GiB on a device with 2 GiB left — found with MM_DEVICE_BYTES_CAP).  The build
+  // holds another 12 N of sort buffers at its peak.
+  auto index_bytes = [&](uint64_t bases, bool peak) {
+    const double N = 2.0 * (double)bases / (double)(w + 1), H = 1.3 * 4294967296.0 / (double)(w + 1), U = H * (1 - std::exp(-N / H));
+    return 18.0 * N + 99.0 * U + (peak ? 12.0 * N : 0.0);
+  };
+  // `share` of the index of `bases` bases fits beside what the device already holds (the estimate errs on the large side by ~10 %)
+  auto fits = [&](uint64_t bases, double share) { return index_bytes(bases, share >= 1.0) * share <= 0.8 * (double)hbm_free; };
   auto make_part = [&](size_t d, int a, int bnd) {               // contigs [a, bnd) of the reference as a set of their own, on device d
     mm_seqset* part; ck(devs[d].ctx, mm_seqset_slice(devs[d].ctx, refset[d], a, bnd - a, &part), "reference chunk");
     return part;
@@ -417,7 +452,13 @@ int map_mode(const Options& o, const std::string& mode) {
       // inside the range is final; the range's last chunk is not (it may go on), so the next range starts there.
       std::cout << "INFO, the index of " << ref_bases << " reference bases does not fit one device's " << (hbm_free >> 30) << " GiB: the chunk rule is evaluated on contig ranges\n";
       const int C = (int)cname.size();
-      uint64_t range_bases = o.v.count("stream-range-bases") ? std::stoull(o.v.at("stream-range-bases")) : (uint64_t)(0.4 * (double)hbm_free / INDEX_BYTES_PER_BASE)   /* (the build of a range index peaks at about twice its resident size) */;
+      uint64_t range_bases = 0;
+      if (o.v.count("stream-range-bases")) range_bases = std::stoull(o.v.at("stream-range-bases"));
+      else {                                                     // the largest range whose index BUILD stays within 70 % of what is free
+        uint64_t lo = 1, hi = ref_bases;
+        while (lo < hi) { const uint64_t mid = lo + (hi - lo + 1) / 2; if (index_bytes(mid, true) <= 0.7 * (double)hbm_free) lo = mid; else hi = mid - 1; }
+        range_bases = lo;
+      }
       int c0 = 0;
       while (c0 < C) {
         int c1 = c0; uint64_t bases = 0;
@@ -431,7 +472,7 @@ int map_mode(const Options& o, const std::string& mode) {
         ck(ctx0, mm_index_plan_chunks(ctx0, ri, maxMem, loc.data(), n, &n), "chunk plan");
         mm_index_destroy(ri);
         if (n == 1 && c1 < C) {                                   // the chunk that starts at c0 is longer than the range
-          if ((double)bases * 2 * INDEX_BYTES_PER_BASE > 0.8 * (double)hbm_free && !o.v.count("stream-range-bases"))
+          if (index_bytes(bases * 2, true) > 0.9 * (double)hbm_free && !o.v.count("stream-range-bases"))
             die("--maxmemory describes index chunks larger than this device can hold one at a time");
           range_bases = bases * 2; continue;
         }
@@ -497,8 +538,20 @@ int map_mode(const Options& o, const std::string& mode) {
   enum class Place { Replicated, Sharded, Streamed } place = Place::Replicated;
   if (o.stream) place = Place::Streamed;
   else if (o.shard) place = Place::Sharded;
-  else if (!fits(ref_bases, 1.0) && NC > 1) {
-    place = (G > 1 && fits(ref_bases, 1.3 / (double)G)) ? Place::Sharded : Place::Streamed;
+  else if (NC > 1) {
+    // every chunk index resident on every device / chunk c on device c mod G / one round of G chunks at a time: the first that fits
+    // (a chunk index costs more per base than the whole reference's: fewer occurrences per hash, the same padding per list)
+    std::vector<double> per_dev(G, 0.0); double all = 0, build_extra = 0;
+    for (size_t c = 0; c < NC; ++c) {
+      uint64_t cb = 0; for (int i = chunks[c].first; i < chunks[c].first + chunks[c].count; ++i) cb += (uint64_t)clen[(size_t)i];
+      const double b = index_bytes(cb, false);
+      all += b; per_dev[c % G] += b; build_extra = std::max(build_extra, index_bytes(cb, true) - b);
+    }
+    const double room = 0.8 * (double)hbm_free;
+    if (all + build_extra <= room) place = Place::Replicated;
+    else place = (G > 1 && *std::max_element(per_dev.begin(), per_dev.end()) + build_extra <= room) ? Place::Sharded : Place::Streamed;
+  }
+  if (place != Place::Replicated && !o.stream && !o.shard) {
     std::cout << "INFO, the index of " << ref_bases << " reference bases does not fit one device's " << (hbm_free >> 30) << " GiB: "
               << (place == Place::Sharded ? "the chunk indexes are spread over the devices" : "chunk indexes are built and mapped one after the other") << "\n";
   }
@@ -646,12 +699,17 @@ int map_mode(const Options& o, const std::string& mode) {
         // `expect`: where the parse stands = the start of the first record not handed on yet.  A block continues the parse iff it
         // starts exactly there (block 0 starts at the file's first record by construction).
         size_t expect = 0; bool chain_ok = true, file_over = false;
+        std::unique_ptr<Batch> pend; int64_t pend_bases = 0;
         for (size_t j = 0; j < nb && chain_ok && !file_over; ++j) {
           { std::unique_lock<std::mutex> lk(bm); bcv.wait(lk, [&] { return blocks[j].done; }); }
           Block& B = blocks[j];
           if (!B.empty) {
             if (j > 0 && start[j] != expect) { chain_ok = false; break; }
-            for (auto& b : B.out) enqueue(std::move(b), fi);
+            for (auto& b : B.out) {                                 // a block ends where its 128 MB end, not where a batch is full: its last batch goes on in the next block
+              if (pend && ((int64_t)(pend->names.size() + b->names.size()) > BATCH_READS || pend_bases + b->bases() > BATCH_BASES)) { enqueue(std::move(pend), fi); pend_bases = 0; }
+              if (!pend) { pend_bases = b->bases(); pend = std::move(b); }
+              else { pend_bases += b->bases(); pend->absorb(*b); reader.recycle(std::move(b)); }
+            }
             B.out.clear();
             if (B.over || B.next == (size_t)-1) { file_over = true; break; }
             expect = B.next;
@@ -660,6 +718,7 @@ int map_mode(const Options& o, const std::string& mode) {
         }
         { std::lock_guard<std::mutex> lk(bm); abandon = true; } bcv.notify_all();
         for (auto& t : pool) t.join();
+        if (pend) enqueue(std::move(pend), fi);
         if (!chain_ok) {                                           // a block did not start where the parse stood: the rest sequentially, from there
           for (auto& B : blocks) for (auto& b : B.out) reader.recycle(std::move(b));
           SeqFile f(mf.data, expect, mf.size);
@@ -738,10 +797,10 @@ int map_mode(const Options& o, const std::string& mode) {
     }
   };
   if (place == Place::Replicated) {
-    // ---- workers: three contexts per device (--workers-per-gpu), so that packing, result download and text formatting of one batch overlap the
+    // ---- workers: four contexts per device (--workers-per-gpu; three until round 4: with ten batches of 10^5 reads in one file the GPU idled 60 % of the mapping phase), so that packing, result download and text formatting of one batch overlap the
     // kernels of the other; the device's chunk indexes are shared (read-only) by its contexts
     const size_t WPD = o.v.count("workers-per-gpu") ? (size_t)std::max(1, std::stoi(o.v.at("workers-per-gpu")))
-                     : getenv("MM_CLI_WORKERS") ? (size_t)std::max(1, atoi(getenv("MM_CLI_WORKERS"))) : 3;
+                     : getenv("MM_CLI_WORKERS") ? (size_t)std::max(1, atoi(getenv("MM_CLI_WORKERS"))) : 4;
     std::vector<std::thread> workers;
     for (size_t d = 0; d < G; ++d) for (size_t wi = 0; wi < WPD; ++wi) workers.emplace_back([&, d, wi]() {
       mm_ctx* ctx = devs[d].ctx;
@@ -978,14 +1037,33 @@ struct ContigCoverage {
       nr.at(wi)++;
     }
   }
-  void write(const std::string& fn, const Taxonomy& T) const {
+  void write(const std::string& fn, const Taxonomy& T) const {   // fEM.h:805-832; one line per 1000-base window of every contig with a best mapping: contigs formatted by several threads
     std::ofstream o(fn);
     o << "taxonID\tequalCoverageUnitLabel\tcontigID\tstart\tstop\tnBases\treadCoverage\n";
-    for (auto& t : cov) for (auto& c : t.second) for (size_t wi = 0; wi < c.second.size(); ++wi) {
-      const size_t wl = wi + 1 == c.second.size() ? last.at(t.first).at(c.first) : W;
-      o << t.first << "\t" << T.T.at(t.first).sci << "\t" << c.first << "\t" << wi * W << "\t" << (wi + 1) * W - 1 << "\t" << c.second[wi] << "\t"
-        << (double)c.second[wi] / (double)wl << "\n";
-    }
+    struct Item { const std::string* tx; const std::string* sci; const std::string* cg; const std::vector<size_t>* v; size_t last; };
+    std::vector<Item> items;
+    for (auto& t : cov) for (auto& c : t.second) items.push_back(Item{&t.first, &T.T.at(t.first).sci, &c.first, &c.second, last.at(t.first).at(c.first)});
+    std::vector<std::string> txt(items.size());
+    std::atomic<size_t> nx{0};
+    auto work = [&] {
+      for (;;) {
+        const size_t i = nx.fetch_add(1);
+        if (i >= items.size()) return;
+        const Item& it = items[i]; std::string& s = txt[i];
+        s.reserve(it.v->size() * (it.tx->size() + it.sci->size() + it.cg->size() + 40));
+        for (size_t wi = 0; wi < it.v->size(); ++wi) {
+          const size_t wl = wi + 1 == it.v->size() ? it.last : W;
+          s += *it.tx; s += '\t'; s += *it.sci; s += '\t'; s += *it.cg; s += '\t'; append_uint(s, wi * W); s += '\t'; append_uint(s, (wi + 1) * W - 1); s += '\t';
+          append_uint(s, (*it.v)[wi]); s += '\t'; append_g6(s, (double)(*it.v)[wi] / (double)wl); s += '\n';
+        }
+      }
+    };
+    std::vector<std::thread> pool;
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4), items.size()}));
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    for (auto& s : txt) o.write(s.data(), (std::streamsize)s.size());
   }
 };
 
@@ -1198,23 +1276,6 @@ void run_em_sharded(const std::vector<Dev>& devs, EmReduce reduce, const std::ve
     bar.wait();                                                  // (every rank has read f_cur)
     if (d == 0) f = fl;
   });
-}
-
-// std::to_string(double) = "%f" for a posterior in [0, 1] (fEM.h:705), without printf: the six decimals are the product with 10^6 rounded
-// half-to-even on the EXACT value, as glibc rounds; the product is only trusted when it is clear of a tie by far more than its own
-// rounding error (2^-33 at this magnitude), anything else — and anything outside [0, 1] — goes through snprintf.
-inline void append_f6(std::string& out, double x) {
-  if (x >= 0 && x <= 1) {
-    const double v = x * 1e6, fl = std::floor(v), fr = v - fl;
-    if (std::fabs(fr - 0.5) > 1e-6) {
-      unsigned long long q = (unsigned long long)fl + (fr > 0.5 ? 1 : 0);   // 0 .. 1000000
-      char b[8]; b[0] = (char)('0' + q / 1000000); q %= 1000000; b[1] = '.';
-      for (int i = 7; i >= 2; --i) { b[i] = (char)('0' + q % 10); q /= 10; }
-      out.append(b, 8);
-      return;
-    }
-  }
-  char num[400]; snprintf(num, sizeof num, "%f", x); out += num;
 }
 
 int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::string& mapped, const std::string& db, size_t minReadsU) {   // meta::doEM, fEM.h:466-803

@@ -593,7 +593,9 @@ def test_cli_device_cap_decides_placement(tmp_path):
     rd = synth.make_reads(db, str(tmp_path / "r.fq"), n_reads=3000, read_len=6000, seed=3)
     ref_bases = n_genomes * 10_000_000
     base = ["mapDirectly", "--all", "-r", db.fasta, "-q", rd["path"], "--maxmemory-bytes", str(int(ref_bases * 3)), "--workers-per-gpu", "1"]
-    cap = int(os.environ.get("MM_TEST_DEVICE_CAP", int(ref_bases * 8.0)))   # index estimate 5.5 B x 1.2 per base = 6.6 GB > 0.8 x 8 GB; three devices: 6.6 x 1.3 / 3 = 2.9 GB fits
+    # the CLI's size model (index_bytes, metamaps_main.cpp): 22 GB for the whole 1 Gbp reference (at this size nearly every hash is a list of one,
+    # padded to a 64-byte sector), ~4 GB for each of the ~6 chunks of --maxmemory: 25 GB together do not fit 0.8 x 20 GiB, two per device do
+    cap = int(os.environ.get("MM_TEST_DEVICE_CAP", 20 << 30))
     env = dict(os.environ, MM_DEVICE_BYTES_CAP=str(cap))
     runs = {}
     for tag, extra, e in (("resident", [], os.environ), ("auto_stream", [], env), ("auto_shard", ["--devices", "0,0,0"], env)):

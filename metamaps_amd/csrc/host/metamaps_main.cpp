@@ -289,7 +289,11 @@ int map_mode(const Options& o, const std::string& mode) {
   // from it; the host holds contig names and lengths only.  Index chunks are cut out of it on the device (mm_seqset_slice).
   std::vector<mm_seqset*> refset(G, nullptr);
   uint64_t hbm_free = 0;
-  auto query_free = [&] { char nm[8]; int cus; uint64_t tot; mm_ctx_device_info(ctx0, nm, sizeof nm, &cus, &tot, &hbm_free); };
+  auto query_free = [&] {
+    char nm[8]; int cus; uint64_t tot; mm_ctx_device_info(ctx0, nm, sizeof nm, &cus, &tot, &hbm_free);
+    size_t share = 0; for (auto& d : devs) share += d.phys == devs[0].phys;   // logical devices of one physical device (--devices 0,0,..) share its memory
+    hbm_free /= std::max<size_t>(share, 1);
+  };
   query_free();
   // Resident bytes of the index of `bases` reference bases: N = 2 bases / (w + 1) entries; U distinct hashes — minimizer
   // hashes are window minima, so they crowd into the low end of the 32-bit space: measured 5.92e8 distinct among 5.94e9 entries at w = 8,
@@ -1278,7 +1282,8 @@ void run_em_sharded(const std::vector<Dev>& devs, EmReduce reduce, const std::ve
   });
 }
 
-int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::string& mapped, const std::string& db, size_t minReadsU) {   // meta::doEM, fEM.h:466-803
+int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::string& mapped, const std::string& db, size_t minReadsU,
+                 const std::function<void()>& leave_now = nullptr /* the last file: called once everything is written; the process ends there */) {   // meta::doEM, fEM.h:466-803
   PhaseClock pc;
   // The mappings file once through: every line is tokenised where it lies (the reference splits every line again in every EM round,
   // fEM.h:1171-1214, :234-373), lines of one read are consecutive (mapWrap.h:128-149), contig IDs are interned.
@@ -1523,6 +1528,7 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
   if (!write_unknown_species(mapped + ".EM.evidenceUnknownSpecies", db, T, coverage, identsPerTaxon, maxReadLen, minReadsU))
     std::cerr << "Warning: " << db << "/contigNstats_windowSize_1000.txt not found - " << mapped << ".EM.evidenceUnknownSpecies is not written." << std::endl;
   pc.lap("c8 evidence of unknown species");
+  if (leave_now && !getenv("MM_CLI_FULL_TEARDOWN")) { emf.close(); r2t.close(); kr.close(); li.close(); pc.report(); leave_now(); finish_fast(); }   // (a GB of vectors and strings: nothing left to do with them)
   return 0;
 }
 
@@ -1549,8 +1555,10 @@ int main(int argc, char** argv) {
     // an explicit --gpus 1 also goes through RCCL (one rank); --em-host-reduce: the ranks' sums are added on the host (test hook: ranks may share a device)
     const EmReduce reduce = o.em_host ? EmReduce::Host : ((devs.size() > 1 || o.v.count("gpus") || o.v.count("devices")) ? EmReduce::Rccl : EmReduce::None);
     const size_t minReadsU = o.v.count("minreads") ? std::stoull(o.v.at("minreads")) : 10000;   // parseCmdArgs.hpp:462-471
-    for (auto& m : split(o.v.at("mappings"), ",")) {
-      classify_one(devs, reduce, m, o.v.at("DB"), minReadsU);
+    const std::vector<std::string> files = split(o.v.at("mappings"), ",");
+    for (size_t fi = 0; fi < files.size(); ++fi) {
+      if (fi + 1 == files.size()) classify_one(devs, reduce, files[fi], o.v.at("DB"), minReadsU, [&] { since("mappings file done"); });
+      else classify_one(devs, reduce, files[fi], o.v.at("DB"), minReadsU);
       for (auto& d : devs) mm_comm_destroy(d.ctx);
       since("mappings file done");
     }

@@ -597,8 +597,9 @@ def test_cli_device_cap_decides_placement(tmp_path):
     # padded to a 64-byte sector), ~4 GB for each of the ~6 chunks of --maxmemory: 25 GB together do not fit 0.8 x 20 GiB, two per device do
     cap = int(os.environ.get("MM_TEST_DEVICE_CAP", 20 << 30))
     env = dict(os.environ, MM_DEVICE_BYTES_CAP=str(cap))
+    env3 = dict(os.environ, MM_DEVICE_BYTES_CAP=str(3 * cap))     # three logical devices on the one physical device share its memory: the CLI gives each a third
     runs = {}
-    for tag, extra, e in (("resident", [], os.environ), ("auto_stream", [], env), ("auto_shard", ["--devices", "0,0,0"], env)):
+    for tag, extra, e in (("resident", [], os.environ), ("auto_stream", [], env), ("auto_shard", ["--devices", "0,0,0"], env3)):
         o = str(tmp_path / tag)
         p = subprocess.run([CLI] + base + ["-o", o] + extra, capture_output=True, timeout=900, env=dict(e))
         assert p.returncode == 0, (tag, p.stderr.decode()[-1500:], p.stdout.decode()[-1500:])

@@ -72,7 +72,7 @@ def parse_args():
     ap.add_argument("--hold-lock-to-the-end", action="store_true", help="release the mapping lock when mm_map_batch returns instead of when its last big kernel is enqueued")
     ap.add_argument("--free-overlap", action="store_true", help="(the default since round 3; kept for old command lines) do not serialise the mapping sections of the workers")
     ap.add_argument("--measure-free-overlap", action="store_true", help="after the timed region, six more steps with nothing serialised, reported in config.free_overlap")
-    ap.add_argument("--config", type=int, choices=(1, 3, 4), default=1, help="BASELINE.json configs[N] as far as one GPU carries it: 1 (default, the configuration `value` is "
+    ap.add_argument("--config", type=int, choices=(1, 3, 4, 5), default=1, help="BASELINE.json configs[N] as far as one GPU carries it: 1 (default, the configuration `value` is "
                     "quoted on) 100k x 10 kb ONT reads vs the resident index; 3: mixed 1-50 kb PacBio reads vs the index split by the --maxmemory chunk rule into resident "
                     "chunk indexes; 4: 10 kb reads vs chunk indexes that are built, mapped and dropped in turn (the multi-pass streaming of an index larger than HBM)")
     ap.add_argument("--distinct-batches", type=int, default=24, help="read batches generated up front (seeds 1000 + rank + 97 i); step s maps batch s mod this")
@@ -328,7 +328,11 @@ def main():
                     agg=agg, st=st, st_clean=st_clean, same_batch=same, dt=dt, steps=steps, bases_all=bases_all, value=bases_all / dt / 1e9, ms_step=dt / steps * 1e3, step_ms=step_ms,
                     n_batches=B, freq_threshold=idx.freq_threshold, reference_bp=int(ref.total_bases))
 
-    if args.config in (3, 4):
+    if args.config == 5 and args.scale == 1.0:
+        args.scale = 11.2                                          # SURVEY D1, DB-refseq-scale: 140 000 genomes, ~300 Gbp
+    if args.config == 5 and args.window == 8:
+        args.window = w = 6                                        # what the CLI derives for a ~300 GB DB.fa
+    if args.config in (3, 4, 5):
         def allreduce_max_sum(dt, bases):
             if world == 1:
                 return dt, bases
@@ -477,14 +481,35 @@ def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
     if mode == 3 and args.read_len == 10_000 and not args.read_len_min:      # config 3's read shape unless the caller chose one
         args.read_len, args.read_len_min, args.pacbio, args.reads = 50_000, 1_000, True, min(args.reads, 60_000)
     err = dict(sub_rate=0.02, ins_rate=0.08, del_rate=0.02) if args.pacbio else dict(sub_rate=0.04, ins_rate=0.03, del_rate=0.05)
-    gib = args.chunk_gib or (70.0 if mode == 3 else 25.0)
+    gib = args.chunk_gib or (70.0 if mode == 3 else 25.0 if mode == 4 else 260.0)
     t0 = time.time()
     ref, contig_taxon, n_taxa, desc = build_reference(ctx, args, args.shape)
     contig_len = ref.lengths().astype(np.int32)
-    whole = ctx.index(ref, k, w)
-    info = whole.info()
-    plan = whole.plan_chunks(int(gib * args.scale * (1 << 30)))
-    whole.close()
+    if mode == 5:
+        # configs[4] at its size: the index of the whole reference does not fit the device, so the chunk rule is evaluated on the indexes of contig
+        # ranges, as the CLI does (metamaps_main.cpp: every cut inside a range is final, the range's last, open chunk starts the next range)
+        maxmem, C = int(gib * (1 << 30)), ref.count
+        range_bases = int(float(os.environ.get("MM_BENCH_RANGE_GBP", 14)) * 1e9)
+        plan, c0, info = [0], 0, {"n_contigs": C, "n_entries": 0, "n_unique_hashes": 0, "hbm_bytes": 0}
+        while c0 < C:
+            c1, bases = c0, 0
+            while c1 < C and (bases < range_bases or c1 == c0):
+                bases += int(contig_len[c1]); c1 += 1
+            sl = ref.slice(c0, c1 - c0); ri = ctx.index(sl, k, w, auto_threshold=False); sl.close()
+            loc = ri.plan_chunks(maxmem)
+            ii = ri.info(); info["n_entries"] += ii["n_entries"] if c0 == 0 or len(loc) > 1 else 0; info["hbm_bytes"] = max(info["hbm_bytes"], ii["hbm_bytes"])
+            ri.close()
+            if len(loc) == 1 and c1 < C:
+                range_bases = bases * 2; continue
+            plan += [c0 + x for x in loc[1:]]
+            if c1 == C:
+                break
+            c0 += loc[-1]
+    else:
+        whole = ctx.index(ref, k, w)
+        info = whole.info()
+        plan = whole.plan_chunks(int(gib * args.scale * (1 << 30)))
+        whole.close()
     bounds = [(a, (plan[i + 1] if i + 1 < len(plan) else ref.count) - a) for i, a in enumerate(plan)]
     base = [a for a, _ in bounds]
     # per-chunk freqThreshold from the histogram accumulated over the chunks (never cleared, winSketch.hpp:452-494)
@@ -504,7 +529,7 @@ def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
         else:
             ix.close()
     t_setup = time.time() - t0
-    n_batches = max(1, min(args.distinct_batches, (args.steps + max(args.warmup, 0)) * (args.batches_per_pass if mode == 4 else 1)))
+    n_batches = max(1, min(args.distinct_batches, (args.steps + max(args.warmup, 0)) * (args.batches_per_pass if mode in (4, 5) else 1)))
     batches = [ctx.synth_reads(ref, seed=1000 + rank + 97 * b, n_reads=args.reads, read_len=args.read_len, read_len_min=args.read_len_min, frac_random=0.05, n_abundant=100, **err)[0]
                for b in range(n_batches)]
     lens = [b.lengths() for b in batches]
@@ -564,14 +589,15 @@ def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
                 c.synchronize(); agg["ms_index"] += (time.perf_counter() - tb) * 1e3
                 for j, b in enumerate(bs):
                     M = c.map_batch(ix, batches[b], k, w, pi=80.0, min_read_len=1000, sketch_of=sk[j])
-                    o, r = M.fetch(); host[j].append((o, r.copy()))
+                    M.release_intermediates(); host[j].append(M)    # the records stay on the device (rounds 1-3: to the host and back, mm_mapping_from_parts)
                     st = M.stats(); note(st); agg["st"] = st
-                    M.close()
                 ix.close()
             for m_ in sk:
                 m_.close()
             for j, b in enumerate(bs):
-                V = capi.Mapping.from_parts(c, lens[b], host[j], base, k, w)
+                V = capi.Mapping.concat(c, host[j], base)
+                for p_ in host[j]:
+                    p_.close()
                 V.add_qualities(k); V.fetch()
                 agg["bases"] += V.stats()["bases_long_enough"]; agg["launch_sets"] += 1
                 classify(c, V); V.close()
@@ -627,16 +653,16 @@ def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
         "step_ms": {"min": round(float(gaps.min()), 3), "median": round(float(np.median(gaps)), 3), "max": round(float(gaps.max()), 3)},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[{mode}] on one GPU per rank: {args.reads} synthetic {len_txt} bp {'PacBio' if args.pacbio else 'ONT'}-error reads per batch vs synthetic miniSeq+H-shaped "
+            "workload": f"BASELINE configs[{min(mode, 4)}] on one GPU per rank: {args.reads} synthetic {len_txt} bp {'PacBio' if args.pacbio else 'ONT'}-error reads per batch vs synthetic miniSeq+H-shaped "
                         f"index ({desc}; {ref.total_bases / 1e9:.2f} Gbp), k=16 w={w}, --all, --maxmemory {gib:g} GiB -> {len(bounds)} index chunks; {what}",
-            "baseline_config": f"configs[{mode}]", "reads_per_batch": args.reads, "read_len": args.read_len, "read_len_min": args.read_len_min,
-            "batches_per_step": args.batches_per_pass if mode == 4 else 1, "distinct_read_batches": n_batches,
+            "baseline_config": f"configs[{min(mode, 4)}]" + (" at its size: the whole reference's index does not fit the device" if mode == 5 else ""), "reads_per_batch": args.reads, "read_len": args.read_len, "read_len_min": args.read_len_min,
+            "batches_per_step": args.batches_per_pass if mode in (4, 5) else 1, "distinct_read_batches": n_batches,
             "reference_bp": int(ref.total_bases), "reference_contigs": info["n_contigs"], "index_entries": info["n_entries"],
             "chunks": len(bounds), "chunk_first_contig": base, "chunk_freq_thresholds": thrs, "chunk_index_build_s": [round(x, 3) for x in t_build],
             "setup_s": round(t_setup, 2), "em_iterations": agg["em_iters"],
             "per_timed_region": {"bases": int(agg["bases"]), "batches_classified": agg["launch_sets"], "sum_l2_stream_entries": int(agg["l2_stream"]), "probes_plus_hits": int(agg["hf_units"]),
                                  "ms_index_builds": round(agg["ms_index"], 1), "stage_ms_sum": {kk: round(v, 2) for kk, v in agg["stage"].items()}},
-            "mapping_only_value": (bases_all / max(dt - agg["ms_index"] * 1e-3, 1e-9) / 1e9) if mode == 4 else None,
+            "mapping_only_value": (bases_all / max(dt - agg["ms_index"] * 1e-3, 1e-9) / 1e9) if mode in (4, 5) else None,
             "parallelism": f"reads sharded x{world}, every rank holds / streams every chunk index, RCCL all-reduce of EM sums; " + (f"{W} worker contexts per GPU take the steps in turn (mapping sections not serialised)" if W > 1 else "one context per GPU, steps one after the other"),
         },
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

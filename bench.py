@@ -188,6 +188,7 @@ def main():
         front_lock, back_lock = threading.Lock(), threading.Lock()
         hold_lock = [bool(args.hold_lock_to_the_end)]
         em_turn = {"next": 0, "cv": threading.Condition()}
+        em_wall = [0.0, 0]                                            # seconds inside em.run, iterations
 
         def step(wi, serialise=True, ticket=0):
             """serialise: True (default) — one lock around the mapping section of a step, released when its last big kernel (K5) is
@@ -234,7 +235,9 @@ def main():
                 c.comm_allreduce(seen)
                 present = seen > 0
                 f = np.where(present, 1.0 / max(int(present.sum()), 1), 0.0)
+                t_em = time.perf_counter()
                 f, lls = em.run(f)                                  # the EM loop, device resident (fEM.h:501-661)
+                em_wall[0] += time.perf_counter() - t_em; em_wall[1] += len(lls)
             finally:
                 with em_turn["cv"]:
                     em_turn["next"] = ticket + 1
@@ -278,6 +281,10 @@ def main():
         run_steps(steps, sched)
         barrier()
         dt = time.perf_counter() - t0
+        if os.environ.get("MM_BENCH_RANK_LOG"):                       # tools/scale_check.sh: what every rank saw
+            nr, rk = ctx.comm_info()
+            print(f"RANKLOG rank {rank}/{world}: RCCL communicator of {nr} ranks (this one {rk}), {steps} steps in {dt * 1e3:.1f} ms, "
+                  f"{em_wall[1]} EM iterations at {em_wall[0] / max(em_wall[1], 1) * 1e6:.1f} us each (warm-up included)", file=sys.stderr, flush=True)
         st = agg["stats"]
         bases_timed = float(agg["bases"])
         # step times inside the timed region: a step's time = from the previous step's completion (or the start) to its own — with W worker
@@ -481,7 +488,7 @@ def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
     if mode == 3 and args.read_len == 10_000 and not args.read_len_min:      # config 3's read shape unless the caller chose one
         args.read_len, args.read_len_min, args.pacbio, args.reads = 50_000, 1_000, True, min(args.reads, 60_000)
     err = dict(sub_rate=0.02, ins_rate=0.08, del_rate=0.02) if args.pacbio else dict(sub_rate=0.04, ins_rate=0.03, del_rate=0.05)
-    gib = args.chunk_gib or (70.0 if mode == 3 else 25.0 if mode == 4 else 260.0)
+    gib = args.chunk_gib or (70.0 if mode == 3 else 25.0 if mode == 4 else 150.0)
     t0 = time.time()
     ref, contig_taxon, n_taxa, desc = build_reference(ctx, args, args.shape)
     contig_len = ref.lengths().astype(np.int32)
@@ -489,7 +496,7 @@ def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
         # configs[4] at its size: the index of the whole reference does not fit the device, so the chunk rule is evaluated on the indexes of contig
         # ranges, as the CLI does (metamaps_main.cpp: every cut inside a range is final, the range's last, open chunk starts the next range)
         maxmem, C = int(gib * (1 << 30)), ref.count
-        range_bases = int(float(os.environ.get("MM_BENCH_RANGE_GBP", 14)) * 1e9)
+        range_bases = int(float(os.environ.get("MM_BENCH_RANGE_GBP", 8)) * 1e9)
         plan, c0, info = [0], 0, {"n_contigs": C, "n_entries": 0, "n_unique_hashes": 0, "hbm_bytes": 0}
         while c0 < C:
             c1, bases = c0, 0
@@ -816,10 +823,11 @@ def _run_cli_with_rss(cmd, env, timeout):
     except subprocess.TimeoutExpired:
         p.kill(); out, err = p.communicate()
         raise RuntimeError(f"{cmd[0]} {cmd[1]} timed out after {timeout} s")
+    wall = time.time() - t0                                        # (before the poller is joined: its 0.25 s nap is not the child's time — rounds 2-3 charged it)
     th.join(timeout=1)
     if p.returncode != 0:
         raise RuntimeError(f"{cmd[0]} {cmd[1]} failed ({p.returncode}): {err.decode(errors='replace')[-600:]}")
-    return out.decode(errors="replace"), err.decode(errors="replace"), time.time() - t0, peak[0]
+    return out.decode(errors="replace"), err.decode(errors="replace"), wall, peak[0]
 
 
 def e2e_cli_full(args, k, w, rank_seed):

@@ -320,6 +320,8 @@ int mm_em_posteriors(mm_em* em, const double* f, double* post /* [n_entries] */,
 #define MM_COMM_ID_BYTES 128
 int mm_comm_unique_id(char id[MM_COMM_ID_BYTES]);                     /* rank 0 creates, caller broadcasts */
 int mm_comm_init(mm_ctx* ctx, const char id[MM_COMM_ID_BYTES], int rank, int nranks);
+/* what RCCL itself says about ctx's communicator (ncclCommCount / ncclCommUserRank); 1 / 0 without one */
+int mm_comm_info(mm_ctx* ctx, int* n_ranks, int* rank);
 /* Several contexts of one device (e.g. two host threads that take read batches in turn) use ONE communicator: `ctx` borrows the
  * communicator of `owner` (same device; the owner outlives it).  The caller issues the collectives of the sharing contexts in
  * the same order on every rank. */

@@ -141,6 +141,7 @@ def lib() -> C.CDLL:
             "mm_sketch_batch": (C.c_int, [vp, vp, P(MapParams), P(vp)]),
             "mm_mapping_destroy": (None, [vp]),
             "mm_mapping_get_stats": (C.c_int, [vp, P(MapStats)]),
+            "mm_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "mm_mapping_gather": (C.c_int, [vp, C.c_int, i64, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
             "mm_mapping_release_intermediates": (C.c_int, [vp]),
             "mm_mapping_fetch": (C.c_int, [vp, vp, vp, i64]),
@@ -347,6 +348,12 @@ class Context:
     def comm_share(self, owner: "Context"):
         """use the communicator of another context of the same device (collectives then go out in the caller's order)"""
         self.check(lib().mm_comm_share(self.h, owner.h))
+
+    def comm_info(self):
+        """(ranks, this rank) as RCCL reports them for the context's communicator"""
+        n, r = C.c_int(), C.c_int()
+        self.check(lib().mm_comm_info(self.h, C.byref(n), C.byref(r)))
+        return n.value, r.value
 
     def comm_allreduce(self, arr: np.ndarray):
         assert arr.dtype == np.float64 and arr.flags.c_contiguous

@@ -94,6 +94,7 @@ Options parse(int argc, char** argv) {
     if (a == "--stream-chunks") { o.stream = true; continue; }
     if (a == "--shard-index") { o.shard = true; continue; }
     if (a == "--em-host-reduce") { o.em_host = true; continue; }
+    if (a == "--host-gather" || a == "--peer-gather") { o.v[a.substr(2)] = "1"; continue; }
     if (a == "-h" || a == "--help") { std::cout << "see the header of metamaps_main.cpp / the reference's README\n"; exit(0); }
     std::string key = alias.count(a) ? alias.at(a) : (a.rfind("--", 0) == 0 ? a.substr(2) : "");
     if (key.empty() || i + 1 >= argc) die("Unknown or incomplete option " + a);
@@ -119,9 +120,11 @@ uint64_t file_size(const std::string& f) {                       // commonFunc.h
 //   replicated   every device holds every chunk index; read batches go to whichever worker is free and the output is written
 //                in batch order (= input order, all ThreadPool.hpp:13-17 guarantees).  No exchange between devices.
 //   sharded      (--shard-index, or automatic when the chunk indexes fit the devices together but not one of them) chunk c
-//                lives on device c mod N, every read batch visits every device, the records go to the batch's owner device
-//                through the host (mm_mapping_fetch -> mm_mapping_from_parts) for the merge in chunk order and the mapping
-//                qualities — what the reference does with its PREFIX.N files (mapWrap.h:417-437, :128-145).
+//                lives on device c mod N, every read batch visits every device, the records stay on the device that made them
+//                and go to the batch's owner device — RCCL send / receive between physical devices (mm_mapping_gather), device-to-
+//                device copies between logical devices of one GPU (mm_mapping_concat), through the host only with --host-gather —
+//                for the merge in chunk order and the mapping qualities: what the reference does with its PREFIX.N files
+//                (mapWrap.h:417-437, :128-145).
 //   streamed     (--stream-chunks, or automatic when not even that fits) rounds of N chunks, one per device, built, mapped
 //                against every (device-resident) read batch and dropped.
 // A batch's sequences live back to back in one arena (huge pages when the system grants them) that is handed to the library by
@@ -849,12 +852,20 @@ int map_mode(const Options& o, const std::string& mode) {
     // ---- sharded / streamed: every read batch is packed onto every device and stays there (2 bits per base) ...
     struct Held { size_t file = 0; std::vector<std::string> names; std::vector<int> lens; std::vector<mm_seqset*> reads;
                   std::vector<mm_mapping*> sk;                 // per device: the batch's minimizers + sketches (mm_sketch_batch), computed once for all chunks
-                  std::vector<std::vector<int64_t>> poff; std::vector<std::vector<mm_map_record>> prec; };
+                  std::vector<mm_mapping*> part;               // per chunk: the batch's records against that chunk, on the device that holds the chunk (c mod G)
+                  std::vector<std::vector<int64_t>> poff; std::vector<std::vector<mm_map_record>> prec; };   // --host-gather: the same in host memory (rounds 1-3)
+    // How the records of a batch reach the device that merges them (unifyFiles, mapWrap.h:128-145, in place of the PREFIX.N files):
+    //   rccl  (several physical devices) mm_mapping_gather: ncclSend / ncclRecv over xGMI, one collective per batch
+    //   peer  (logical devices of one GPU, or --peer-gather) mm_mapping_concat pulls the parts of other contexts with device-to-device copies
+    //   host  (--host-gather) mm_mapping_fetch + mm_mapping_from_parts: through host memory, the path of rounds 1-3, kept as the cross-check
+    bool distinct = true; for (size_t a = 0; a < G; ++a) for (size_t b2 = a + 1; b2 < G; ++b2) distinct = distinct && devs[a].phys != devs[b2].phys;
+    enum class Gather { Rccl, Peer, Host } gather = o.v.count("host-gather") ? Gather::Host : (G > 1 && distinct && !o.v.count("peer-gather")) ? Gather::Rccl : Gather::Peer;
+    if (getenv("MM_CLI_TIMING")) std::cerr << "INFO, records of the chunks are gathered by " << (gather == Gather::Rccl ? "RCCL send / receive" : gather == Gather::Peer ? "device-to-device copies" : "the host") << "\n";
     std::vector<Held> held;
     while (std::unique_ptr<Batch> bt = reader.take()) {
       held.emplace_back();
       Held& h = held.back();
-      h.file = bt->file; h.reads.assign(G, nullptr); h.sk.assign(G, nullptr); h.poff.resize(NC); h.prec.resize(NC);
+      h.file = bt->file; h.reads.assign(G, nullptr); h.sk.assign(G, nullptr); h.part.assign(NC, nullptr); h.poff.resize(NC); h.prec.resize(NC);
       on_each(G, [&](size_t d) { h.reads[d] = upload_batch(devs[d].ctx, *bt); });
       h.names = std::move(bt->names); h.lens = std::move(bt->lens);
       reader.recycle(std::move(bt));
@@ -887,11 +898,13 @@ int map_mode(const Options& o, const std::string& mode) {
               if (sk_used[d] + 3 * bases <= sk_budget[d]) { ck(devs[d].ctx, mm_sketch_batch(devs[d].ctx, h.reads[d], &mp, &h.sk[d]), "sketch"); sk_used[d] += 3 * bases; }
             }
             mm_mapping* pm = map_chunk(devs[d].ctx, devs[d].idx[c], h.reads[d], h.sk[d]);
-            h.poff[c].resize(h.names.size() + 1);
-            ck(devs[d].ctx, mm_mapping_fetch(pm, h.poff[c].data(), nullptr, 0), "fetch");
-            h.prec[c].resize((size_t)h.poff[c].back());
-            ck(devs[d].ctx, mm_mapping_fetch(pm, h.poff[c].data(), h.prec[c].data(), (int64_t)h.prec[c].size()), "fetch");
-            mm_mapping_destroy(pm);
+            if (gather == Gather::Host) {
+              h.poff[c].resize(h.names.size() + 1);
+              ck(devs[d].ctx, mm_mapping_fetch(pm, h.poff[c].data(), nullptr, 0), "fetch");
+              h.prec[c].resize((size_t)h.poff[c].back());
+              ck(devs[d].ctx, mm_mapping_fetch(pm, h.poff[c].data(), h.prec[c].data(), (int64_t)h.prec[c].size()), "fetch");
+              mm_mapping_destroy(pm);
+            } else { ck(devs[d].ctx, mm_mapping_release_intermediates(pm), "release"); h.part[c] = pm; }   // the records stay where they were made
           }
           if (place == Place::Streamed) { mm_index_destroy(devs[d].idx[c]); devs[d].idx[c] = nullptr; }
         }
@@ -900,18 +913,44 @@ int map_mode(const Options& o, const std::string& mode) {
     }
     // merge in chunk order (unifyFiles), mapping qualities over the union and text: batch b on device b mod N
     std::vector<std::unique_ptr<Done>> results(held.size());
+    std::vector<int32_t> chunk_rank(NC); for (size_t c = 0; c < NC; ++c) chunk_rank[c] = (int32_t)(c % G);
+    char comm_id[MM_COMM_ID_BYTES];
+    if (gather == Gather::Rccl && mm_comm_unique_id(comm_id) != MM_OK) die("RCCL: cannot create a communicator id");
+    std::vector<mm_mapping*> merged(held.size(), nullptr);
     on_each(G, [&](size_t d) {
+      mm_ctx* ctx = devs[d].ctx;
       for (auto& h : held) { if (h.sk[d]) mm_mapping_destroy(h.sk[d]); mm_seqset_destroy(h.reads[d]); }
+      if (gather == Gather::Rccl) {                                // every rank takes part in the gather of every batch, batch b ends on rank b mod G
+        ck(ctx, mm_comm_init(ctx, comm_id, (int)d, (int)G), "RCCL communicator");
+        for (size_t b = 0; b < held.size(); ++b) {
+          Held& h = held[b];
+          std::vector<mm_mapping*> mine; std::vector<int32_t> ids;
+          for (size_t c = d; c < NC; c += G) { mine.push_back(h.part[c]); ids.push_back((int32_t)c); }
+          mm_mapping* m = nullptr;
+          ck(ctx, mm_mapping_gather(ctx, (int)(b % G), (int64_t)h.names.size(), h.lens.data(), &mp, mine.data(), ids.data(), (int)mine.size(), (int)NC, chunk_rank.data(), chunk_base.data(), &m), "gather chunks");
+          if (b % G == d) merged[b] = m;
+          for (auto* pm : mine) mm_mapping_destroy(pm);
+        }
+        mm_comm_destroy(ctx);
+      }
+    });
+    on_each(G, [&](size_t d) {
       for (size_t b = d; b < held.size(); b += G) {
         Held& h = held[b];
-        std::vector<const int64_t*> op; std::vector<const mm_map_record*> rp;
-        for (size_t c = 0; c < NC; ++c) { op.push_back(h.poff[c].data()); rp.push_back(h.prec[c].data()); }
-        mm_mapping* m;
-        ck(devs[d].ctx, mm_mapping_from_parts(devs[d].ctx, (int64_t)h.names.size(), h.lens.data(), &mp, (int)NC, op.data(), rp.data(), chunk_base.data(), &m), "merge chunks");
+        mm_mapping* m = merged[b];
+        if (gather == Gather::Peer) {
+          ck(devs[d].ctx, mm_mapping_concat(devs[d].ctx, h.part.data(), chunk_base.data(), (int)NC, &m), "merge chunks");
+        } else if (gather == Gather::Host) {
+          std::vector<const int64_t*> op; std::vector<const mm_map_record*> rp;
+          for (size_t c = 0; c < NC; ++c) { op.push_back(h.poff[c].data()); rp.push_back(h.prec[c].data()); }
+          ck(devs[d].ctx, mm_mapping_from_parts(devs[d].ctx, (int64_t)h.names.size(), h.lens.data(), &mp, (int)NC, op.data(), rp.data(), chunk_base.data(), &m), "merge chunks");
+        }
         results[b] = finish_mapping(devs[d].ctx, m, std::move(h.names), std::move(h.lens), h.file);
         std::vector<std::vector<int64_t>>().swap(h.poff); std::vector<std::vector<mm_map_record>>().swap(h.prec);
       }
     });
+    if (gather == Gather::Peer) for (auto& h : held) for (size_t c = 0; c < NC; ++c) if (h.part[c]) {   // (after every owner has pulled what it needed; destroyed through its own context)
+      mm_mapping_destroy(h.part[c]); h.part[c] = nullptr; }
     pc.lap("7 mapq+fetch+format");
     write_all([&](size_t fi, size_t seq) -> std::unique_ptr<Done> {
       if (seq >= results.size() || results[seq]->file != fi) return nullptr;

@@ -781,6 +781,17 @@ int mm_comm_init(mm_ctx* ctx, const char id[MM_COMM_ID_BYTES], int rank, int nra
   if (!ctx || !id || rank < 0 || rank >= nranks) return MM_ERR_ARG;
   return guarded(ctx, [&] { mm::comm_init(ctx, id, rank, nranks); });
 }
+int mm_comm_info(mm_ctx* ctx, int* n_ranks, int* rank) {
+  if (!ctx) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    int n = 1, r = 0;
+    if (ctx->comm) {
+      MM_REQUIRE(ncclCommCount((ncclComm_t)ctx->comm, &n) == ncclSuccess && ncclCommUserRank((ncclComm_t)ctx->comm, &r) == ncclSuccess, MM_ERR_COMM, "ncclCommCount / ncclCommUserRank failed");
+    }
+    if (n_ranks) *n_ranks = n;
+    if (rank) *rank = r;
+  });
+}
 int mm_comm_share(mm_ctx* ctx, mm_ctx* owner) {
   if (!ctx || !owner || ctx == owner) return MM_ERR_ARG;
   return guarded(ctx, [&] {

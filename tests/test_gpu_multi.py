@@ -71,11 +71,15 @@ def test_replicated_index_batches_over_devices(small_run, devices):
     _map_files_equal(o2, small_run["oracle"]["plain"][1])
 
 
-@pytest.mark.parametrize("devices,mode", [("0,0", "--shard-index"), ("0,0,0", "--shard-index"), ("0,0", "--stream-chunks"), ("0,0,0", "--stream-chunks"), ("0", "--shard-index")])
-def test_chunk_indexes_spread_over_devices(small_run, devices, mode):
+@pytest.mark.parametrize("devices,mode,gather", [("0,0", "--shard-index", None), ("0,0,0", "--shard-index", None), ("0,0", "--stream-chunks", None), ("0,0,0", "--stream-chunks", None),
+                                                 ("0", "--shard-index", None), ("0,0,0", "--shard-index", "--host-gather"), ("0,0", "--stream-chunks", "--host-gather")])
+def test_chunk_indexes_spread_over_devices(small_run, devices, mode, gather):
     """--maxmemory chunks, chunk c on device c mod N (all resident, or N at a time), every batch visits every device, records
-    gathered on the batch's owner: same files as the oracle under the same --maxmemory"""
-    o1, o2, out = _gpu_map(small_run, mode.strip("-")[:5] + devices.replace(",", ""), ["--devices", devices, mode, "--maxmemory-bytes", "1000000"])
+    gathered on the batch's owner — device to device (the parts stay on the device that mapped them; logical devices of one GPU: copies
+    inside mm_mapping_concat; physical devices: RCCL, tools/scale_check.sh) or, --host-gather, through host memory as in rounds 1-3:
+    same files as the oracle under the same --maxmemory"""
+    o1, o2, out = _gpu_map(small_run, mode.strip("-")[:5] + devices.replace(",", "") + (gather or "").strip("-")[:4],
+                           ["--devices", devices, mode, "--maxmemory-bytes", "1000000"] + ([gather] if gather else []))
     assert sum(1 for l in out.splitlines() if l.startswith("INFO, index chunk")) >= 3
     _map_files_equal(o1, small_run["oracle"]["chunks"][0])
     _map_files_equal(o2, small_run["oracle"]["chunks"][1])

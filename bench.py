@@ -443,7 +443,7 @@ def main():
         other = "uniform" if args.shape == "community" else "community"
         try:
             R2 = run_shape(other, max(3, min(args.steps, 8)), max(1, args.warmup))   # (the headline's warm-up: the steps right after an index build can meet
-            # the runtime's clean-up of the memory the previous index gave back — a 1-2 s stall of one step)
+            # the runtime's clean-up of the memory the previous index gave back — a 1-2 s stall of one step, docs/history.md section 6)
             out["config"]["other_shape"] = {"shape": R2["desc"], "value": R2["value"], "unit": "Gbp/s", "ms_per_step": R2["ms_step"], "steps": R2["steps"], "warmup": max(1, args.warmup),
                                             "step_ms": {kk: (round(v, 3) if not isinstance(v, list) else v) for kk, v in R2["step_ms"].items()},
                                             "reference_bp": R2["reference_bp"], "freq_threshold": R2["freq_threshold"],

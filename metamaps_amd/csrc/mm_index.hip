@@ -101,7 +101,7 @@ __global__ void count_inversions_kernel(const uint32_t* __restrict__ key, int64_
 }
 
 // Occurrence lists are laid out on 64-byte sector boundaries: the seed-hit filter reads every list of every read twice and
-// pays per 64-byte sector touched; a list that starts mid-sector touches one sector more than it needs.
+// pays per 64-byte sector touched (docs/history.md K3c); a list that starts mid-sector touches one sector more than it needs.
 // Cost: each list is padded to a multiple of 8 entries (~3.5 entries per unique hash).
 __global__ void padded_counts_kernel(const uint64_t* __restrict__ ustart, int64_t U, uint32_t* __restrict__ pc) {
   for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (int64_t)gridDim.x * blockDim.x) {

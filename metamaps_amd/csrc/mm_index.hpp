@@ -85,7 +85,7 @@ inline IndexView make_view(const mm_index* I) {
 // i.e. by one memory request — random requests, not bytes, are what the probe stage pays for (tools/ubench/randread).
 // The table has ANY number of buckets (multiply-shift range reduction of the mixed hash: minimizer hashes are window minima, skewed
 // towards small values, so the hash is multiplied by an odd constant first): a power-of-two table is up to twice as large as its
-// load factor asks for — 17 GB instead of 10 for each of the chunk indexes of a --maxmemory run.
+// load factor asks for — 17 GB instead of 10 for each of the chunk indexes of a --maxmemory run (docs/history.md section 7).
 __host__ __device__ inline uint64_t tab_slot(uint32_t h, uint32_t buckets) {
   return (uint64_t)(uint32_t)(((uint64_t)(h * 0x9E3779B1u) * (uint64_t)buckets) >> 32) << 2;
 }

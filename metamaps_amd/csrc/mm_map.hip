@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_kernel(IndexView I, co
 // lane, so the LDS layout is unchanged — while read r tests its parked codes against the surviving bins, writes its survivor slots
 // and fetches its survivors.  seed_filter_kernel above does a read's phases one after the other on a CU that holds one workgroup
 // (152 KB of LDS): VALU 40 %, LDS 19 %, waiting on memory 26 % of the cycles (profiles/r02_sq_counters.txt).
-// What the form needs to work at all (each found in the ISA, tools/ notes in DESIGN.md):
+// What the form needs to work at all (each found in the ISA, docs/history.md section 4):
 //   * the barriers of the loop are LDS-only (s_waitcnt lgkmcnt(0) + s_barrier): nothing may drain the vector memory counter
 //     between the issue of the look-ups and their use;
 //   * everything a read needs from global memory besides its lists comes through SCALAR loads (class byte, sketch size, offsets,
@@ -1620,7 +1620,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       MM_HIP(hipFuncSetAttribute((const void*)seed_filter_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       MM_HIP(hipFuncSetAttribute((const void*)seed_filter_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       // default: the streaming form (one resident workgroup per CU, look-ups of the next read under the LDS phases of this one);
-      // MM_SF_ONESHOT=1 / MM_SF_DBG: one workgroup per read, the form the phase timings of DESIGN.md were taken on
+      // MM_SF_ONESHOT=1 / MM_SF_DBG: one workgroup per read, the form the phase timings of docs/history.md were taken on
       const bool oneshot = getenv("MM_SF_ONESHOT") || getenv("MM_SF_DBG");
       DBuf<uint32_t> sf_ticket(1);
       if (!oneshot) sf_ticket.zero(st);

@@ -473,7 +473,7 @@ __device__ inline void em_p3(const EmLoop& a, int n_wg, double* sh) {
 }
 
 // grid barrier pieces (thread 0 of every workgroup talks; agent-scope fences publish / fetch the other workgroups' plain stores: the
-// XCDs' L2s are not coherent with each other, DESIGN.md K5 scratch slots)
+// XCDs' L2s are not coherent with each other, docs/history.md K5 scratch slots)
 // bar[0]: groups that have arrived, bar[1]: released generation, bar[16 * (1 + g)]: arrivals of group g (EM_BAR_GROUP workgroups, a
 // 64-byte line each).  Two levels because 128 agent-scope atomics on ONE word are served one after the other: ~13 us per barrier,
 // more than the phases between them.

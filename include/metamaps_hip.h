@@ -25,9 +25,8 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 5   /* 3: mm_seqset_slice/concat, mm_map_batch_reusing, mm_em_continue, mm_synth_community_species;
-                            * 4: mm_sketch_batch, mm_ctx_release_cached, mm_index_dup_neighbours;
-                            * 5: mm_mapping_gather, mm_comm_info, mm_seqset_fetch_range, mm_map_stats.n_l2_fused */
+#define MM_ABI_VERSION 4   /* 3: mm_seqset_slice/concat, mm_map_batch_reusing, mm_em_continue, mm_synth_community_species;
+                            * 4: mm_sketch_batch, mm_ctx_release_cached, mm_index_dup_neighbours */
 
 typedef enum {
   MM_OK = 0,
@@ -217,7 +216,6 @@ typedef struct {
   /* reads whose sketch has >= 32768 hashes (longer than ~145 kb at w = 8): mapped like every other read, but by the slow
    * K5 class that keeps its window state in global memory (informational) */
   int64_t n_reads_giant;
-  int64_t n_l2_fused;                 /* K5 candidates whose pivot bound was predicted from L1's seed-hit count, so that pass B's masks came out of pass A */
 } mm_map_stats;
 
 int mm_map_batch(mm_ctx* ctx, const mm_index* idx, const mm_seqset* reads, const mm_map_params* p, mm_mapping** out);

@@ -48,7 +48,7 @@ class MapStats(C.Structure):
                                            "sum_l2_stream_entries", "sum_l2_evals", "n_ambiguous_sketch_reads", "sum_hits_kept", "n_l2_rebuilds", "n_l2_wide_redo")] + \
                [(n, C.c_double) for n in ("ms_minimizer", "ms_sketch", "ms_probe_gather", "ms_sort_hits", "ms_l1_scan",
                                           "ms_l2", "ms_compact", "ms_total", "ms_hit_filter")] + \
-               [("n_reads_giant", C.c_int64), ("n_l2_fused", C.c_int64)]
+               [("n_reads_giant", C.c_int64)]
 
     def as_dict(self):
         return {n: (int(getattr(self, n)) if t is C.c_int64 else float(getattr(self, n))) for n, t in self._fields_}

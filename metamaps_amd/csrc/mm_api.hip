@@ -392,7 +392,7 @@ int mm_mapping_release_intermediates(mm_mapping* m) {
     m->mz = mm::MinimizerSet{};
     m->sk_hash.release(); m->sk_strand.release(); m->sk_n.release(); m->amb.release();
     m->min_hits.release(); m->accept_min.release();
-    m->read_hit_off.release(); m->hits.release(); m->cand_off.release(); m->cand.release(); m->cand_read.release(); m->cand_hint.release(); m->l2.release();
+    m->read_hit_off.release(); m->hits.release(); m->cand_off.release(); m->cand.release(); m->cand_read.release(); m->l2.release();
     std::vector<int32_t>().swap(m->h_sk_n); std::vector<int32_t>().swap(m->h_min_hits);
     std::vector<uint64_t>().swap(m->h_read_hit_off); std::vector<uint64_t>().swap(m->h_cand_off);
     m->n_cand = 0; m->released = true;

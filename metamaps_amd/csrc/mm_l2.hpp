@@ -265,8 +265,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                                                 void* __restrict__ code_buf /* optional: 64*64*NWQ code words (2 bytes each for NWQ == 2, else 4) per scratch slot */,
                                                 uint8_t* __restrict__ mask_buf /* NWQ > 2: l2_skip_bytes(NWQ) per scratch slot */,
                                                 unsigned int* __restrict__ slot_flags /* n_slots (a multiple of 8) words, all 0 between launches: a wave takes a free slot of its XCD's share for its lifetime (null: slot = wave number in the launch) */,
-                                                int n_slots,
-                                                const int32_t* __restrict__ cand_hint /* optional (SKIP): seed hits inside each candidate, l1_wave_kernel: the matched count pass A may expect */) {
+                                                int n_slots) {
   extern __shared__ __align__(16) uint32_t lds[];
   uint32_t* Q = lds;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -423,7 +422,6 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 
   // ---- state of window [nb,ne) from scratch, all lanes (the arrays are order independent) ---------------
   unsigned long long rebuilds = 0, rounds = 0;
-  int fused = 0;                                                 // pass B was not needed: its masks came out of pass A (predicted pivot bound)
   // Pivot zone (SKIP path).  The serial slide keeps no LDS state at all: lane l owns rank r = z0 + l and holds
   //   fz = r + D[z0] + ... + D[r]                  (VGPR; huge for r >= s so that lane r == s acts as the "R = s" sentinel)
   // next to the wave-uniform scalars cbase = D[0] + ... + D[z0-1], sb = matched ranks below z0 present in the window and
@@ -941,12 +939,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     uint64_t rAll[NWQ];
 #pragma unroll
     for (int q = 0; q < NWQ; ++q) { w0r[q] = 0x7fffffff; rAll[q] = 0; }
-    // r0p >= 0: the pivot bound is predicted (below) — the two masks pass B would make for it (matched entries below Q[r0p]; window-only
-    // first occurrences below it) come out of this pass, from the entries it holds anyway
-    auto pass_matched = [&](int r0p) {
-      const bool fuse = r0p >= 0;
-      const bool every_p = r0p >= s;
-      const uint32_t qr0p = !fuse || every_p ? 0xffffffffu : Q[r0p];
+    auto pass_matched = [&]() {
       Rec nx[8];
       load8(nx, first);
       for (int base = first; base < last_end; base += 512) {
@@ -980,23 +973,10 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
             rAll[QH] = mine ? m : rAll[QH];
             const int wfirst = pw_wpos((uint32_t)__builtin_amdgcn_readfirstlane((int)x[i].pw));
             w0r[QH] = mine ? wfirst : w0r[QH];
-            if (fuse) {
-              uint64_t below = __ballot(every_p || x[i].hash < qr0p);
-              if (!FULL) below &= valid_mask(base + 64 * i);
-              const uint64_t first_occ = __ballot(!(x[i].pw & PW_DP));
-              if (lane == 0) { mLo[wd] = below & m; mA[wd] = below & ~m & first_occ; }   // (wave-uniform words straight to the mask arrays: no registers held across the loop)
-            }
           }
         });
       }
       store_masks(mAll, pAll, rAll);
-      if (fuse) {                                                 // word prefixes of the two masks (and zeros behind the last word)
-        wave_sync();
-        uint64_t t0[NWQ], t1[NWQ];
-#pragma unroll
-        for (int q = 0; q < NWQ; ++q) { const bool in = lane + 64 * q < nwords; t0[q] = in ? mLo[lane + 64 * q] : 0ull; t1[q] = in ? mA[lane + 64 * q] : 0ull; }
-        store_masks(mLo, pLo, t0); store_masks(mA, pA, t1);
-      }
       {
         // lane l owns blocks l and l+64; their first words are (l << bwl) and ((l + 64) << bwl)
         int tg[2], lo[2], hi[2];
@@ -1063,26 +1043,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     nblk_s = nblk;
     if (phase == 0) {
       lap(0);
-      // Predicted pivot bound.  The pivot rank of a window is the number of query hashes among the s smallest of query + window-only hashes:
-      // hypergeometric, mean s s / (s + wo) with wo = window entries - matched entries.  The window's entries follow from the streamed range
-      // (entries per base x cnt), the matched count of the BEST window is what L1 counted as the candidate's seed hits (cand_hint).  A bound
-      // that turns out too low for a block only loses tightness there (validity is checked per block), so the prediction is used when it lies
-      // within [-fuse_lo, +fuse_hi] ranks of what the matched counts ask for afterwards; otherwise pass B runs as before.
-      int r0p = -1;
-      const int fuse_cfg = (int)(counters[11] >> 32);             // MM_L2_FUSE: lo | hi << 8 | extra slack << 16 (0: defaults)
-      if (cand_hint != nullptr) {
-        const int hc = cand_hint[c];
-        const int span = max(pw_wpos(pos[last_end - 1].pw) - pw_wpos(pos[first].pw), 1);
-        if (hc > 0 && last_end - first >= 2) {
-          const float we = (float)(last_end - first) * (float)cnt / (float)span;
-          const float wo_p = fmaxf(we - (float)hc, 0.0f);
-          const float pq = (float)s / ((float)s + wo_p);
-          const float sigma = sqrtf((float)s * pq * (1.0f - pq) * (1.0f - pq));
-          const int extra = fuse_cfg ? ((fuse_cfg >> 16) & 0xff) : 12;
-          r0p = min(s, (int)((float)s * pq) + max(8, (int)(2.5f * sigma) + 4) + extra);
-        }
-      }
-      pass_matched(r0p);
+      pass_matched();
       have_codes = cw != nullptr;
       lap(1);
       if (dbg_stop == 2) { release_slot(); return; }
@@ -1116,10 +1077,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         const int wo = max(lane2(eLo, bkb) - bLb - ubmax, 0);
         const float pq = (float)s / (float)(s + wo);
         const float sigma = sqrtf((float)s * pq * (1.0f - pq) * (1.0f - pq));
-        int r0 = min(s, (int)((float)s * pq) + max(8, (int)(2.5f * sigma) + 4));
-        const int fuse_lo = fuse_cfg ? (fuse_cfg & 0xff) : 10, fuse_hi = fuse_cfg ? ((fuse_cfg >> 8) & 0xff) : 60;
-        if (r0p >= 0 && r0p >= r0 - fuse_lo && r0p <= r0 + fuse_hi) { r0 = r0p; ++fused; }   // the masks of pass A stand
-        else pass_low(r0);
+        const int r0 = min(s, (int)((float)s * pq) + max(8, (int)(2.5f * sigma) + 4));
+        pass_low(r0);
         lap(5);
         if (dbg_stop == 4) { release_slot(); return; }
         for (int q = 0; q < 2; ++q) {
@@ -1252,7 +1211,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   if (lane == 0) {
     L2Result o;
     o.contig = contig; o.mean_pos = (beg_pos + last_pos) / 2;    // :537
-    o.shared = best; o.strand = strand; o.accepted = accepted; o.pad = fused;
+    o.shared = best; o.strand = strand; o.accepted = accepted; o.pad = 0;
     o.opt_beg = first0 + opt_b; o.opt_end = first0 + opt_e;
     // work counters travel with the result: hundreds of thousands of waves adding to the same few words would
     // serialise in one L2 channel (measured: half of the kernel's time)

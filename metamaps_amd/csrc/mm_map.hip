@@ -1104,7 +1104,7 @@ template <bool WRITE>
 __global__ void __launch_bounds__(256) l1_wave_kernel(const uint64_t* __restrict__ hits, const uint64_t* __restrict__ read_hit_off,
                                                       const int32_t* __restrict__ read_len, const int32_t* __restrict__ min_hits, int64_t n_reads,
                                                       uint32_t* __restrict__ cand_n, const uint64_t* __restrict__ cand_off, int32_t* __restrict__ cand,
-                                                      int32_t* __restrict__ cand_read, int32_t* __restrict__ cand_hint /* optional: seed hits inside the candidate */) {
+                                                      int32_t* __restrict__ cand_read) {
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (r >= n_reads) return;
@@ -1114,7 +1114,6 @@ __global__ void __launch_bounds__(256) l1_wave_kernel(const uint64_t* __restrict
   int m = min_hits[r]; if (m < 1) m = 1;                         // :349
   const uint64_t wbase = WRITE ? cand_off[r] : 0;
   int count = 0, prev_seq = -1, prev_wa = 0;
-  int64_t open_i = 0;                                            // the hit that opened the candidate the previous chunk ended in
   for (int64_t base = 0; base + m <= H; base += 64) {
     const int64_t i = base + lane;
     const bool valid = i + m <= H;
@@ -1137,15 +1136,7 @@ __global__ void __launch_bounds__(256) l1_wave_kernel(const uint64_t* __restrict
       int32_t* c = cand + 3 * (wbase + (uint64_t)k);
       if (brk) { c[0] = sa; c[1] = cs; cand_read[wbase + (uint64_t)k] = (int32_t)r; }
       if (last) c[2] = wa;
-      if (last && cand_hint) {
-        // the seed hits of the candidate: from the hit that opened it to the last hit of the last qualifying run — with --all nearly all of them
-        // lie inside ONE read-length window, so this is what K5 will find as the matched count of its best window (its r0, mm_l2.hpp)
-        const uint64_t opened = bm & ((2ull << lane) - 1ull);
-        const int64_t oi = opened ? base + (63 - __builtin_clzll(opened)) : open_i;
-        cand_hint[wbase + (uint64_t)k] = (int32_t)min((int64_t)0x7fffffff, i + m - oi);
-      }
     }
-    if (bm) open_i = base + (63 - __builtin_clzll(bm));
     count += __popcll(bm);
     if (qm) { const int ll = 63 - __builtin_clzll(qm); prev_seq = __shfl(sa, ll, 64); prev_wa = __shfl(wa, ll, 64); }
   }
@@ -1195,16 +1186,15 @@ __global__ void __launch_bounds__(256) l2_group_kernel(const uint64_t* __restric
 }
 
 __global__ void __launch_bounds__(256) l2_stats_kernel(const L2Result* __restrict__ l2, int64_t n, unsigned long long* __restrict__ counters) {
-  __shared__ unsigned long long acc[5];
-  if (threadIdx.x < 5) acc[threadIdx.x] = 0;
+  __shared__ unsigned long long acc[4];
+  if (threadIdx.x < 4) acc[threadIdx.x] = 0;
   __syncthreads();
-  unsigned long long a = 0, b = 0, c = 0, d = 0, e = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { a += l2[i].n_stream; b += l2[i].n_evals; c += l2[i].n_rebuilds; d += l2[i].pad2; e += (unsigned)l2[i].pad; }
-  atomicAdd(&acc[0], a); atomicAdd(&acc[1], b); atomicAdd(&acc[2], c); atomicAdd(&acc[3], d); atomicAdd(&acc[4], e);
+  unsigned long long a = 0, b = 0, c = 0, d = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { a += l2[i].n_stream; b += l2[i].n_evals; c += l2[i].n_rebuilds; d += l2[i].pad2; }
+  atomicAdd(&acc[0], a); atomicAdd(&acc[1], b); atomicAdd(&acc[2], c); atomicAdd(&acc[3], d);
   __syncthreads();
   if (threadIdx.x < 3) atomicAdd(&counters[threadIdx.x], acc[threadIdx.x]);
   if (threadIdx.x == 3) atomicAdd(&counters[15], acc[3]);   // slide rounds (diagnostic)
-  if (threadIdx.x == 4) atomicAdd(&counters[14], acc[4]);   // candidates whose pass B was fused into pass A
 }
 
 __global__ void accept_flags_kernel(const L2Result* __restrict__ l2, int64_t n, uint32_t* __restrict__ flag) {
@@ -1849,7 +1839,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   const unsigned rblk = (unsigned)ceil_div(std::max<int64_t>(n, 1), 128);
   if (n > 0) {
     if (l1_serial) l1_scan_kernel<false><<<dim3(rblk), dim3(128), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, cand_n.p, nullptr, nullptr, nullptr);
-    else l1_wave_kernel<false><<<dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, cand_n.p, nullptr, nullptr, nullptr, nullptr);
+    else l1_wave_kernel<false><<<dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, cand_n.p, nullptr, nullptr, nullptr);
     MM_KERNEL_CHECK();
   }
   exclusive_scan_u32_u64(cand_n.p, n, M->cand_off.p, scan_tmp, st);
@@ -1860,16 +1850,11 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   M->stats.n_candidates = ncand;
   M->cand.alloc((size_t)std::max<int64_t>(3 * ncand, 1));
   M->cand_read.alloc((size_t)std::max<int64_t>(ncand, 1));
-  M->cand_hint.alloc((size_t)std::max<int64_t>(ncand, 1));
-  if (l1_serial) M->cand_hint.zero(st);                          // (the serial cross-check loop does not count: 0 = no hint)
-  // K5 takes the candidate's seed-hit count as the matched count of its best window: the pivot bound r0 is then known BEFORE the candidate is
-  // streamed and the masks of pass B come out of pass A (mm_l2.hpp).  MM_L2_NO_FUSE=1: two passes for every candidate, as in rounds 1-3
-  const int32_t* const hint_p = getenv("MM_L2_NO_FUSE") ? nullptr : M->cand_hint.p;
   M->l2.alloc((size_t)std::max<int64_t>(ncand, 1));
   M->rec_off.alloc((size_t)n + 1);
   if (ncand > 0) {
     if (l1_serial) l1_scan_kernel<true><<<dim3(rblk), dim3(128), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, nullptr, M->cand_off.p, M->cand.p, M->cand_read.p);
-    else l1_wave_kernel<true><<<dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, nullptr, M->cand_off.p, M->cand.p, M->cand_read.p, M->cand_hint.p);
+    else l1_wave_kernel<true><<<dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, nullptr, M->cand_off.p, M->cand.p, M->cand_read.p);
     MM_KERNEL_CHECK();
     T.end(t_l1);
     // ---- K5/K6
@@ -1908,11 +1893,8 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     MM_REQUIRE(lds_wide <= 160 * 1024, MM_ERR_LIMIT, "L2 window state does not fit LDS");
     auto set_lds = [&](const void* fn, size_t bytes) { if (bytes > 64 * 1024) MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); };
     DBuf<unsigned long long> counters(16); counters.zero(st);
-    if (getenv("MM_L2_STOP") || getenv("MM_L2_PHASES") || getenv("MM_FORCE_AMB_REDO") || getenv("MM_L2_FUSE")) {   // timing aid: leave the kernel after phase n (results are then meaningless); MM_L2_FUSE=lo,hi,extra: tuning of the fused pass (mm_l2.hpp)
-      const char* ds = getenv("MM_L2_STOP"); unsigned long long v = (unsigned long long)((ds ? atoi(ds) & 0xff : 0) | (getenv("MM_L2_PHASES") ? 0x100 : 0) | (getenv("MM_FORCE_AMB_REDO") ? 0x200 : 0));
-      if (const char* fz = getenv("MM_L2_FUSE")) { int lo = 10, hi = 60, ex = 12; sscanf(fz, "%d,%d,%d", &lo, &hi, &ex); v |= (unsigned long long)((lo & 0xff) | (hi & 0xff) << 8 | (ex & 0xff) << 16 | 1 << 24) << 32; }
-      MM_HIP(hipMemcpyAsync(counters.p + 11, &v, sizeof v, hipMemcpyHostToDevice, st)); MM_HIP(hipStreamSynchronize(st));
-    }
+    if (getenv("MM_L2_STOP") || getenv("MM_L2_PHASES") || getenv("MM_FORCE_AMB_REDO")) {
+      const char* ds = getenv("MM_L2_STOP"); unsigned long long v = (unsigned long long)((ds ? atoi(ds) & 0xff : 0) | (getenv("MM_L2_PHASES") ? 0x100 : 0) | (getenv("MM_FORCE_AMB_REDO") ? 0x200 : 0)); MM_HIP(hipMemcpyAsync(counters.p + 11, &v, sizeof v, hipMemcpyHostToDevice, st)); MM_HIP(hipStreamSynchronize(st)); }   // timing aid: leave the kernel after phase n (results are then meaningless)
     DBuf<int32_t> ovf((size_t)ncand);
     DBuf<unsigned int> ovf_n(1); ovf_n.zero(st);
     DBuf<uint8_t> amb_used;
@@ -1975,7 +1957,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         d_listF.upload(listF.data(), listF.size(), st);
         set_lds((const void*)l2_kernel<false, uint16_t, 1, 8>, lds_wide);
         l2_kernel<false, uint16_t, 1, 8><<<dim3((unsigned)listF.size()), dim3(64), lds_wide, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, d_listF.p, nullptr, nullptr, amb_used_p, nullptr, nullptr, nullptr, 0, nullptr);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, d_listF.p, nullptr, nullptr, amb_used_p, nullptr, nullptr, nullptr, 0);
         MM_KERNEL_CHECK();
       }
       MM_HIP(hipStreamSynchronize(st));                          // listF is the source of the async upload
@@ -2053,14 +2035,14 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 4, 2);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 2>, lds);
         l2_kernel<true, uint8_t, 4, 2><<<dim3((unsigned)nA), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(nA * 4, 2), masks_for(nA * 4, 2), slot_flags_p, (int)slots_of(nA * 4, 2), hint_p);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(nA * 4, 2), masks_for(nA * 4, 2), slot_flags_p, (int)slots_of(nA * 4, 2));
         MM_KERNEL_CHECK();
       }
       if (nS) {
         const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 2, 2);
         set_lds((const void*)l2_kernel<true, uint8_t, 2, 2>, lds);
         l2_kernel<true, uint8_t, 2, 2><<<dim3((unsigned)nS), dim3(128), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gS0.p, d_gSn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(nS * 2, 2), masks_for(nS * 2, 2), slot_flags_p, (int)slots_of(nS * 2, 2), hint_p);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gS0.p, d_gSn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(nS * 2, 2), masks_for(nS * 2, 2), slot_flags_p, (int)slots_of(nS * 2, 2));
         MM_KERNEL_CHECK();
       }
       if (!gB0.empty()) {
@@ -2068,7 +2050,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smB, true, 4, 8);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
         l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gB0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smB, M->l2.p, counters.p, d_gB0.p, d_gBn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gB0.size() * 4, 8), masks_for(gB0.size() * 4), slot_flags_p, (int)slots_of(gB0.size() * 4), hint_p);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smB, M->l2.p, counters.p, d_gB0.p, d_gBn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gB0.size() * 4, 8), masks_for(gB0.size() * 4), slot_flags_p, (int)slots_of(gB0.size() * 4));
         MM_KERNEL_CHECK();
       }
       DBuf<int32_t> d_gD0(gD0.size()), d_gDn(gDn.size());
@@ -2077,7 +2059,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint8_t>(smD, true, 4, 8);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
         l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gD0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gD0.size() * 4, 8), masks_for(gD0.size() * 4), slot_flags_p, (int)slots_of(gD0.size() * 4), hint_p);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gD0.size() * 4, 8), masks_for(gD0.size() * 4), slot_flags_p, (int)slots_of(gD0.size() * 4));
         MM_KERNEL_CHECK();
       }
       if (!listC.empty()) {
@@ -2085,7 +2067,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint16_t>(smC, true, 1, 8);
         set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
         l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)listC.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smC, M->l2.p, counters.p, nullptr, nullptr, d_listC.p, ovf.p, ovf_n.p, amb_used_p, nullptr, masks_for(listC.size()), slot_flags_p, (int)slots_of(listC.size()), hint_p);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smC, M->l2.p, counters.p, nullptr, nullptr, d_listC.p, ovf.p, ovf_n.p, amb_used_p, nullptr, masks_for(listC.size()), slot_flags_p, (int)slots_of(listC.size()));
         MM_KERNEL_CHECK();
       }
       hl("K5 uploads + launches");
@@ -2100,7 +2082,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         const size_t lds = l2_lds_bytes<uint16_t>(smax, false, 1, 8);
         set_lds((const void*)l2_kernel<false, uint16_t, 1, 8>, lds);
         l2_kernel<false, uint16_t, 1, 8><<<dim3(h_ovf), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr, amb_ptr, nullptr, nullptr, nullptr, 0, nullptr);
+            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, ovf.p, nullptr, nullptr, amb_ptr, nullptr, nullptr, nullptr, 0);
         MM_KERNEL_CHECK();
         ovf_n.zero(st);
         n_fallback += h_ovf;
@@ -2127,7 +2109,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
             const size_t lds = l2_lds_bytes<uint16_t>(smR, true, 1, 8);
             set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
             l2_kernel<true, uint16_t, 1, 8><<<dim3((unsigned)redo.size()), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-                M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smR, M->l2.p, counters.p, nullptr, nullptr, d_redo.p, ovf.p, ovf_n.p, nullptr, nullptr, masks_for(redo.size()), slot_flags_p, (int)slots_of(redo.size()), nullptr);
+                M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smR, M->l2.p, counters.p, nullptr, nullptr, d_redo.p, ovf.p, ovf_n.p, nullptr, nullptr, masks_for(redo.size()), slot_flags_p, (int)slots_of(redo.size()));
             MM_KERNEL_CHECK();
             run_fallback(nullptr);
           }
@@ -2145,7 +2127,6 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     M->stats.sum_l2_stream_entries = (int64_t)hc[0];
     M->stats.sum_l2_evals = (int64_t)hc[1];
     M->stats.n_l2_rebuilds = (int64_t)hc[2];
-    M->stats.n_l2_fused = (int64_t)hc[14];
     if (getenv("MM_L2_PHASES")) { fprintf(stderr, "l2 rounds %llu; ", hc[15]); fprintf(stderr, "l2 phase clocks [setup passA bounds rebuild slide passB vote]:"); for (int i = 0; i < 7; ++i) fprintf(stderr, " %.3g", (double)hc[3 + i]); fprintf(stderr, "\n"); }
     // ---- compaction
     if (amb_finish) { amb_finish(); amb_finish = nullptr; }

@@ -40,7 +40,6 @@ struct mm_mapping {
   std::vector<uint64_t> h_cand_off;
   mm::DBuf<int32_t> cand;                    // triples contig,start,end
   mm::DBuf<int32_t> cand_read;
-  mm::DBuf<int32_t> cand_hint;               // seed hits inside each candidate (l1_wave_kernel): K5's estimate of the matched count of the best window
   // K5
   mm::DBuf<mm::L2Result> l2;
   // final

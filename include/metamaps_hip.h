@@ -25,8 +25,9 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 4   /* 3: mm_seqset_slice/concat, mm_map_batch_reusing, mm_em_continue, mm_synth_community_species;
-                            * 4: mm_sketch_batch, mm_ctx_release_cached, mm_index_dup_neighbours */
+#define MM_ABI_VERSION 5   /* 3: mm_seqset_slice/concat, mm_map_batch_reusing, mm_em_continue, mm_synth_community_species;
+                            * 4: mm_sketch_batch, mm_ctx_release_cached, mm_index_dup_neighbours;
+                            * 5: mm_mapping_gather, mm_comm_info, mm_seqset_fetch_range */
 
 typedef enum {
   MM_OK = 0,

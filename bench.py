@@ -928,6 +928,23 @@ def e2e_cli_full(args, k, w, rank_seed):
         cls_main = {ln.split(" at +")[0][12:]: float(ln.split(" at +")[1].split()[0]) for ln in err2.splitlines() if ln.startswith("INFO, main: ")}
         par = dict(l.split(" ", 1) for l in open(pre + ".parameters").read().splitlines() if " " in l)
         meta = dict(l.split() for l in open(pre + ".meta"))
+        # measurement aid: the single-batch mapDirectly again under other environments / flags ("name:KEY=VAL KEY2=VAL2 --flag value;name2:...")
+        variants_1 = {}
+        for spec in [x for x in os.environ.get("MM_BENCH_E2E_VARIANTS", "").split(";") if x]:
+            vname, _, rest = spec.partition(":")
+            venv, vflags = dict(env), []
+            for tok in rest.split():
+                if "=" in tok and not tok.startswith("-"):
+                    kk, _, vv = tok.partition("="); venv[kk] = vv
+                else:
+                    vflags.append(tok)
+            for rep in range(int(os.environ.get("MM_BENCH_E2E_VARIANT_REPS", 2))):
+                _ov, ev, tv, _rv = _run_cli_with_rss([cli, "mapDirectly", "--all", "-r", fasta, "-q", fq, "-o", pre + "_v"] + vflags, venv, 1500)
+                lv = {ln.split(" at +")[0][len("INFO, lap "):]: float(ln.split(" at +")[1].split()[0]) for ln in ev.splitlines() if ln.startswith("INFO, lap ")}
+                pv = {" ".join(ln.split()[2:-2]): float(ln.split()[-2]) for ln in ev.splitlines() if ln.startswith("INFO, time ")}
+                variants_1.setdefault(vname, []).append({"wall_s": round(tv, 3), "index_build_lap_s": round(lv.get("3 index build", 0) - lv.get("1 reference parse + pack + upload", 0), 3),
+                                                         "mapping_phase_s": round(lv.get("8 write", tv) - lv.get("3 index build", 0.0), 3), "map_sum_s": round(pv.get("6 map", 0), 3),
+                                                         "same_file": open(pre).read() == open(pre + "_v").read()})
         stream = None
         if n_stream:
             pre_s = os.path.join(d, "out_stream")
@@ -978,7 +995,7 @@ def e2e_cli_full(args, k, w, rank_seed):
                                    "mapping_phase_what": "index built -> last output file written, by the CLI's own laps (without the process exit)"},
                 "map_laps_s": laps, "map_phases_s": phases, "classify_phases_s": cls_phases, "classify_main_s": cls_main,
                 "peak_host_rss_bytes": {"mapDirectly": int(rss_map), "classify": int(rss_cls)},
-                "meta": {kk: int(v) for kk, v in meta.items()}, "e2e_cli_stream": stream}
+                "meta": {kk: int(v) for kk, v in meta.items()}, "variants": variants_1, "e2e_cli_stream": stream}
     finally:
         if own_tmp is not None:
             own_tmp.cleanup()

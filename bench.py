@@ -115,8 +115,6 @@ def sched_free(args):
 
 def main():
     args = parse_args()
-    if args.config in (4, 5):
-        os.environ.setdefault("MM_KEEP_INDEX_BLOCKS", "1")          # passes of index builds of one size: their blocks go round through the device pool, not through the driver
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))

@@ -270,7 +270,11 @@ struct DBuf {
         int cur = 0; (void)hipGetDevice(&cur);
         if (cur != big_dev) (void)hipSetDevice(big_dev);         // the synchronisation below is for the block's device, whichever the calling thread is on
         (void)hipDeviceSynchronize();
-        static const bool keep = getenv("MM_KEEP_INDEX_BLOCKS") != nullptr;   // a series of builds of one size (passes over chunk indexes): the build's temporaries stay pooled too
+        // Index-scale blocks a build lets go of stay in the device's pool (since round 4; MM_RETURN_INDEX_BLOCKS=1: back to the driver as in round 3).
+        // Handing the sort buffers of a 26.8 Gbp build (~70 GB) back with hipFree made the FIRST allocations of the other contexts of the device wait
+        // 3.2 s in two runs of three (the worker contexts of `mapDirectly`: mapping phase 3.2 s instead of 0.23 s); pooled, 0 of 6.  What the pool holds
+        // is given up when an allocation fails for lack of memory (every allocation path trims it and tries again).
+        static const bool keep = getenv("MM_RETURN_INDEX_BLOCKS") == nullptr;
         if ((owner && owner->eager && !keep) || !big_bytes) dev_free(p, big_bytes ? big_bytes : n * sizeof(T));
         else big_pool(big_dev).give(p, big_bytes);                // (nothing on the device still uses it: any context may take it)
         if (cur != big_dev) (void)hipSetDevice(cur);

@@ -1368,7 +1368,9 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
       }
       return TS;
     };
-    const size_t NTH = std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::max(1u, HW / 4), TS / ((size_t)4 << 20) + 1, (size_t)(getenv("MM_CLASSIFY_THREADS") ? std::max(1, atoi(getenv("MM_CLASSIFY_THREADS"))) : 1 << 20)}));
+    // (MM_CLASSIFY_THREADS=n: exactly n pieces, whatever the size of the file — the tests cut small files into many)
+    const size_t NTH = getenv("MM_CLASSIFY_THREADS") ? (size_t)std::min(256, std::max(1, atoi(getenv("MM_CLASSIFY_THREADS"))))
+                                                     : std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::max(1u, HW / 4), TS / ((size_t)4 << 20) + 1}));
     std::vector<size_t> cut(NTH + 1, TS);
     cut[0] = 0;
     for (size_t t = 1; t < NTH; ++t) cut[t] = std::max(cut[t - 1], read_boundary(TS / NTH * t));
@@ -1495,7 +1497,8 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
     // (4.2 M lines through std::to_string on one thread took 1.2 s); the per-taxon tallies and the coverage windows follow in read order
     std::vector<std::string> tax_nonx(taxa.size());              // getFirstNonXNode per taxon (taxonomy.h:51-74), once
     for (size_t t = 0; t < taxa.size(); ++t) tax_nonx[t] = T.first_non_x(taxa[t]);
-    const size_t NTH = std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::max(1u, HW / 4), lines.size() / 50000 + 1, (size_t)(getenv("MM_CLASSIFY_THREADS") ? std::max(1, atoi(getenv("MM_CLASSIFY_THREADS"))) : 1 << 20)}));
+    const size_t NTH = getenv("MM_CLASSIFY_THREADS") ? (size_t)std::min(256, std::max(1, atoi(getenv("MM_CLASSIFY_THREADS"))))
+                                                     : std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::max(1u, HW / 4), lines.size() / 50000 + 1}));
     std::vector<size_t> rcut(NTH + 1, NRD);
     rcut[0] = 0;
     { size_t t = 1; for (size_t r = 0; r < NRD && t < NTH; ++r) if ((uint64_t)off[r] >= (uint64_t)lines.size() * t / NTH) rcut[t++] = r; }

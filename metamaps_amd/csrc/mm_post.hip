@@ -504,7 +504,7 @@ __device__ inline bool grid_wait(unsigned* bar, unsigned epoch, long long* ctrl,
     int ok = 1;
     while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
       __builtin_amdgcn_s_sleep(1);
-      if ((long long)wall_clock64() - t0 > ticks || __hip_atomic_load(&ctrl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      if ((long long)wall_clock64() - t0 > (ticks < 0 ? -ticks : ticks) || __hip_atomic_load(&ctrl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         __hip_atomic_store(&ctrl[4], 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break;
       }
     }
@@ -523,15 +523,21 @@ __global__ void __launch_bounds__(256) em_loop_kernel(EmLoop a) {
   const int wg = blockIdx.x, n_wg = gridDim.x;
   if (__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // (iterations enqueued past the stop are no-ops)
   unsigned epoch = 0;
+  const bool prof = a.barrier_ticks < 0 && wg == 0 && threadIdx.x == 0;   // MM_EM_PROF: workgroup 0's wall-clock ticks per phase into ctrl[5..7]
+  long long t_prev = prof ? (long long)wall_clock64() : 0;
+  auto tick = [&](int slot) { if (prof) { const long long t = (long long)wall_clock64(); a.ctrl[slot] += t - t_prev; t_prev = t; } };
   for (;;) {
     em_p1(a, wg, n_wg, sh);
+    tick(5);
     ++epoch;
     if (grid_arrive_is_last(a.bar, epoch, n_wg, &s_flag)) grid_release(a.bar, epoch);
     else if (!grid_wait(a.bar, epoch, a.ctrl, &s_flag, a.barrier_ticks)) {
       if (ONE_ITERATION && threadIdx.x == 0) a.local_partial[a.n_taxa + 1] = 1.0;   // all-reduced: every rank learns that this iteration did not happen
       return;
     }
+    tick(6);                                                       // (barrier 1)
     em_p2(a, wg, n_wg);
+    tick(7);
     ++epoch;
     if (grid_arrive_is_last(a.bar, epoch, n_wg, &s_flag)) {
       em_p3<ONE_ITERATION>(a, n_wg, sh);
@@ -626,7 +632,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
   const long long it0 = h_ctrl[0], it_limit = it0 + max_iter;
   EmLoop a{E->read_off.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->n_reads, E->post_sorted.p, E->pos.p, E->item_lo.p, E->item_hi.p, E->n_items,
            E->present.p, E->pt_item.p, E->n_present, E->item_sum.p, E->wg_ll.p, E->f_run.p, E->local_partial.p, T, E->ctrl.p, E->ll_trace.p, cap, it_limit, E->bar.p,
-           getenv("MM_EM_BARRIER_TICKS") ? atoll(getenv("MM_EM_BARRIER_TICKS")) : EM_BARRIER_TICKS};
+           (getenv("MM_EM_PROF") ? -1 : 1) * (getenv("MM_EM_BARRIER_TICKS") ? atoll(getenv("MM_EM_BARRIER_TICKS")) : EM_BARRIER_TICKS)};
   const dim3 grid((unsigned)E->n_wg), blk(256);
   const size_t p3_lds = E->n_items <= EM_P3_LDS_ITEMS ? sizeof(double) * (size_t)std::max(E->n_items, 1) : 0;
   const bool force_split = getenv("MM_EM_SPLIT") != nullptr;
@@ -678,6 +684,8 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
     fetch_ctrl();
   }
   const int n_iter = (int)(h_ctrl[0] - it0);
+  if (getenv("MM_EM_PROF") && n_iter > 0)                        // ticks of the 100 MHz clock, workgroup 0: P1 | barrier 1 | P2 — the rest of an iteration is barrier 2 + P3
+    fprintf(stderr, "MM_EM_PROF %d iterations: P1 %.1f us, barrier 1 %.1f us, P2 %.1f us per iteration\n", n_iter, h_ctrl[5] / 100.0 / n_iter, h_ctrl[6] / 100.0 / n_iter, h_ctrl[7] / 100.0 / n_iter);
   if (stopped) *stopped = h_ctrl[1] == 1;
   if (f_out) E->f_run.download(f_out, (size_t)T, st);
   if (ll_trace && ll_cap > 0 && n_iter > 0) E->ll_trace.download(ll_trace, (size_t)std::min(std::min(n_iter, ll_cap), cap), st);

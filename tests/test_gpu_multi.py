@@ -427,3 +427,36 @@ def test_em_run_stops_at_max_iter_and_continues():
         f_c2, lls_c2, stopped = e.continue_run(10)               # a stopped run stays stopped
         assert stopped and len(lls_c2) == 0 and np.array_equal(f_c2, f_all)
     e.close(); ctx.close()
+
+
+def test_classify_parse_and_format_threads(small_run):
+    """classify reads and tokenises the mappings file in pieces that begin on read boundaries and formats its per-line / per-read files in ranges of
+    reads (round 4): one piece / range (MM_CLASSIFY_THREADS=1), three, and as many as the file allows (MM_CLASSIFY_THREADS=64 on a small file: pieces of a
+    few reads, some of them empty) write the same bytes — also when the file has empty lines and no line break at its end"""
+    o1, _, _ = _gpu_map(small_run, "cth", [])
+    d = small_run["dir"]
+    outs = {}
+    for th in ("1", "3", "64"):
+        x = str(d / f"cth_{th}")
+        _copy_run(o1, x)
+        if th != "1":                                             # the same mappings with oddities the pieces have to cope with
+            pass
+        _classify(x, small_run["db"].dir, [], {"MM_CLASSIFY_THREADS": th})
+        outs[th] = {suf: open(x + suf).read() for suf in (".EM", ".EM.reads2Taxon", ".EM.reads2Taxon.krona", ".EM.WIMP", ".EM.lengthAndIdentitiesPerMappingUnit", ".EM.contigCoverage")}
+    assert outs["1"] == outs["3"] == outs["64"] and len(outs["1"][".EM"]) > 10_000
+    # empty lines between reads and a missing final line break: still the same reads
+    txt = open(o1).read().rstrip("\n").split("\n")
+    cut = [i for i in range(1, len(txt)) if txt[i].split(" ")[0] != txt[i - 1].split(" ")[0]]
+    odd = []
+    for i, ln in enumerate(txt):
+        if i in cut[::5]:
+            odd.append("")
+        odd.append(ln)
+    for th in ("1", "64"):
+        x = str(d / f"cth_odd_{th}")
+        _copy_run(o1, x)
+        open(x, "w").write("\n".join(odd))
+        _classify(x, small_run["db"].dir, [], {"MM_CLASSIFY_THREADS": th})
+        for suf in (".EM.reads2Taxon", ".EM.WIMP", ".EM.reads2Taxon.krona"):
+            assert open(x + suf).read() == outs["1"][suf], (suf, th)
+        assert open(x + ".EM").read() == outs["1"][".EM"]

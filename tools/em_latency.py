@@ -57,5 +57,23 @@ def main():
         e.close(); ctx.close()
 
 
+def phases():
+    """MM_EM_PROF=1: the library prints workgroup 0's time per phase of the resident kernel"""
+    n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+    off, taxon, mapq, inv, T = problem(n_reads)
+    for k in ("MM_EM_GRID", "MM_EM_SPLIT", "MM_EM_FORCE_COLLECTIVE"):
+        os.environ.pop(k, None)
+    os.environ["MM_EM_PROF"] = "1"
+    ctx = capi.Context(0)
+    e = ctx.em(off, taxon, mapq, inv, T)
+    e.run(np.full(T, 1.0 / T), max_iter=3)
+    sys.stderr.flush()
+    t0 = time.perf_counter(); f, lls = e.run(np.full(T, 1.0 / T), max_iter=200); dt = time.perf_counter() - t0
+    print(f"with MM_EM_PROF: {dt / len(lls) * 1e6:.1f} us per iteration over {len(lls)} iterations (phase split on stderr)")
+    e.close(); ctx.close()
+    os.environ.pop("MM_EM_PROF", None)
+
+
 if __name__ == "__main__":
     main()
+    phases()

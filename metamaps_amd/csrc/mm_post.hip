@@ -345,7 +345,8 @@ void em_iterate_allreduce(mm_em* E, const double* f, double* f_next, double* ll)
 // previous log-likelihood, ctrl[3] = first iteration of the current log-likelihood trace, ctrl[4] = a barrier timed out.
 // ---------------------------------------------------------------------------------------------------
 struct EmLoop {
-  const int64_t* read_off; const int32_t* taxon; const double* mapq; const double* inv_nloc;
+  const longlong2* span;                                          // per read, in the order of the mapping counts (longest first): [first, behind-last) mapping
+  const int32_t* taxon; const double* mapq; const double* inv_nloc;
   int64_t n_reads;
   double* post_sorted; const int64_t* pos;                        // posteriors in taxon-sorted order (P1 writes entry i to pos[i], the inverse of perm[])
   const int64_t* item_lo; const int64_t* item_hi; int n_items;
@@ -361,40 +362,45 @@ constexpr int EM_P3_LDS_ITEMS = 4096;                              // item sums 
 constexpr int EM_BAR_GROUP = 16;                                  // workgroups per first-level barrier counter
 constexpr long long EM_BARRIER_TICKS = 200000000LL;               // 2 s of the 100 MHz wall clock (MM_EM_BARRIER_TICKS: test hook)
 
-// P1.  A thread walks its reads; the mappings of a read are taken four at a time with every load of the four issued before the first is
-// used (clamped indices instead of branches: a loop with one dependent load chain per mapping cost ~1 us of latency per mapping, 30 us
-// per iteration).  The likelihoods are added in mapping order, as the reference adds them (fEM.h:353-358).  The posterior goes straight
-// to its place in the taxon-sorted array P2 reads (pos[i]): P2 then streams instead of gathering through perm[].
+// P1.  A thread walks its reads; the mappings of a read are taken EIGHT at a time with every load of the eight issued before the first is used
+// (clamped indices instead of branches), so a read of up to eight mappings — 98 % of them at ~4 per read — costs two dependent memory round
+// trips; longer reads loop over such chunks twice (sum, then posteriors).  A wave takes as many rounds as its LONGEST read, so the reads
+// are visited in the order of their mapping counts (`span`: the reads' [first, behind-last) mapping pairs sorted by count, longest first,
+// made once per problem): lanes of a wave then hold reads of equal length.  (Round 4 measured the first form of this phase — four at a time,
+// file order, two passes from five mappings on — at 38 of an iteration's 53 us: per wave the maximum over 64 lanes of ~6 rounds of two dependent
+// loads.)  The likelihoods are added in mapping order, as the reference adds them (fEM.h:353-358).  The posterior goes straight to its place
+// in the taxon-sorted array P2 reads (pos[i]): P2 then streams instead of gathering through perm[].
 __device__ inline void em_p1(const EmLoop& a, int wg, int n_wg, double* sh) {
   const int tid = threadIdx.x;
   const int64_t stride = (int64_t)n_wg * 256;
   double ll = 0;
-  for (int64_t r = (int64_t)wg * 256 + tid; r < a.n_reads; r += stride) {
-    const int64_t lo = a.read_off[r], hi = a.read_off[r + 1];
+  for (int64_t q = (int64_t)wg * 256 + tid; q < a.n_reads; q += stride) {
+    const longlong2 sp = a.span[q];
+    const int64_t lo = sp.x, hi = sp.y;
     if (hi <= lo) continue;
     const int64_t last = hi - 1;
-    double sum = 0, l4[4]; int64_t p4[4];
-    for (int64_t c = lo; c < hi; c += 4) {
-      int t4[4]; double w4[4], q4[4], f4[4];
+    double sum = 0, l8[8]; int64_t p8[8];
+    for (int64_t c = lo; c < hi; c += 8) {
+      int t8[8]; double w8[8], q8[8], f8[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int64_t i = c + u < last ? c + u : last; t4[u] = a.taxon[i]; w4[u] = a.inv_nloc[i]; q4[u] = a.mapq[i]; p4[u] = a.pos[i]; }
+      for (int u = 0; u < 8; ++u) { const int64_t i = c + u < last ? c + u : last; t8[u] = a.taxon[i]; w8[u] = a.inv_nloc[i]; q8[u] = a.mapq[i]; p8[u] = a.pos[i]; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) f4[u] = a.f[t4[u]];
+      for (int u = 0; u < 8; ++u) f8[u] = a.f[t8[u]];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { l4[u] = f4[u] * w4[u] * q4[u]; if (c + u < hi) sum += l4[u]; }   // fEM.h:353
+      for (int u = 0; u < 8; ++u) { l8[u] = f8[u] * w8[u] * q8[u]; if (c + u < hi) sum += l8[u]; }   // fEM.h:353
     }
-    if (hi - lo <= 4) {                                            // the usual read: everything is still in registers
+    if (hi - lo <= 8) {                                            // the usual read: everything is still in registers
 #pragma unroll
-      for (int u = 0; u < 4; ++u) if (lo + u < hi) a.post_sorted[p4[u]] = l4[u] / sum;              // :361
+      for (int u = 0; u < 8; ++u) if (lo + u < hi) a.post_sorted[p8[u]] = l8[u] / sum;              // :361
     } else {
-      for (int64_t c = lo; c < hi; c += 4) {
-        int t4[4]; double w4[4], q4[4], f4[4]; int64_t q_pos[4];
+      for (int64_t c = lo; c < hi; c += 8) {
+        int t8[8]; double w8[8], q8[8], f8[8]; int64_t q_pos[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int64_t i = c + u < last ? c + u : last; t4[u] = a.taxon[i]; w4[u] = a.inv_nloc[i]; q4[u] = a.mapq[i]; q_pos[u] = a.pos[i]; }
+        for (int u = 0; u < 8; ++u) { const int64_t i = c + u < last ? c + u : last; t8[u] = a.taxon[i]; w8[u] = a.inv_nloc[i]; q8[u] = a.mapq[i]; q_pos[u] = a.pos[i]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) f4[u] = a.f[t4[u]];
+        for (int u = 0; u < 8; ++u) f8[u] = a.f[t8[u]];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (c + u < hi) a.post_sorted[q_pos[u]] = (f4[u] * w4[u] * q4[u]) / sum;
+        for (int u = 0; u < 8; ++u) if (c + u < hi) a.post_sorted[q_pos[u]] = (f8[u] * w8[u] * q8[u]) / sum;
       }
     }
     ll += log(sum);                                                // :578
@@ -606,6 +612,19 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
     E->item_lo.alloc(std::max<size_t>(ilo.size(), 1)); E->item_lo.upload(ilo.data(), ilo.size(), st);
     E->item_hi.alloc(std::max<size_t>(ihi.size(), 1)); E->item_hi.upload(ihi.data(), ihi.size(), st);
     E->item_sum.alloc(std::max<size_t>(ilo.size(), 1));
+    {                                                              // the reads by mapping count, longest first (stable: file order among equals)
+      std::vector<int64_t> ro = E->read_off.to_host(st, (size_t)E->n_reads + 1);
+      std::vector<int64_t> sp(2 * (size_t)std::max<int64_t>(E->n_reads, 1), 0);
+      int64_t cmax = 0; for (int64_t r = 0; r < E->n_reads; ++r) cmax = std::max(cmax, ro[(size_t)r + 1] - ro[(size_t)r]);
+      const int64_t NB = std::min<int64_t>(cmax, 255) + 1;       // (counts beyond 255 share the first bucket: order among them does not matter for what this is for)
+      std::vector<int64_t> start((size_t)NB + 1, 0);
+      auto bucket = [&](int64_t c) { return NB - 1 - std::min<int64_t>(c, NB - 1); };
+      for (int64_t r = 0; r < E->n_reads; ++r) start[(size_t)bucket(ro[(size_t)r + 1] - ro[(size_t)r]) + 1]++;
+      for (int64_t b2 = 0; b2 < NB; ++b2) start[(size_t)b2 + 1] += start[(size_t)b2];
+      for (int64_t r = 0; r < E->n_reads; ++r) { const int64_t k2 = start[(size_t)bucket(ro[(size_t)r + 1] - ro[(size_t)r])]++; sp[2 * (size_t)k2] = ro[(size_t)r]; sp[2 * (size_t)k2 + 1] = ro[(size_t)r + 1]; }
+      E->span.alloc(sp.size()); E->span.upload(sp.data(), sp.size(), st);
+      MM_HIP(hipStreamSynchronize(st));                          // (sp is the upload's source)
+    }
     E->pos.alloc((size_t)std::max<int64_t>(E->n_entries, 1)); E->post_sorted.alloc((size_t)std::max<int64_t>(E->n_entries, 1));
     if (E->n_entries > 0) { em_pos_kernel<<<dim3((unsigned)ceil_div(E->n_entries, 256)), dim3(256), 0, st>>>(E->perm.p, E->n_entries, E->pos.p); MM_KERNEL_CHECK(); }
     E->wg_ll.alloc((size_t)E->n_wg);
@@ -630,7 +649,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
     MM_HIP(hipStreamSynchronize(st));
   }
   const long long it0 = h_ctrl[0], it_limit = it0 + max_iter;
-  EmLoop a{E->read_off.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->n_reads, E->post_sorted.p, E->pos.p, E->item_lo.p, E->item_hi.p, E->n_items,
+  EmLoop a{(const longlong2*)E->span.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->n_reads, E->post_sorted.p, E->pos.p, E->item_lo.p, E->item_hi.p, E->n_items,
            E->present.p, E->pt_item.p, E->n_present, E->item_sum.p, E->wg_ll.p, E->f_run.p, E->local_partial.p, T, E->ctrl.p, E->ll_trace.p, cap, it_limit, E->bar.p,
            (getenv("MM_EM_PROF") ? -1 : 1) * (getenv("MM_EM_BARRIER_TICKS") ? atoll(getenv("MM_EM_BARRIER_TICKS")) : EM_BARRIER_TICKS)};
   const dim3 grid((unsigned)E->n_wg), blk(256);

@@ -618,7 +618,8 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
       int64_t cmax = 0; for (int64_t r = 0; r < E->n_reads; ++r) cmax = std::max(cmax, ro[(size_t)r + 1] - ro[(size_t)r]);
       const int64_t NB = std::min<int64_t>(cmax, 255) + 1;       // (counts beyond 255 share the first bucket: order among them does not matter for what this is for)
       std::vector<int64_t> start((size_t)NB + 1, 0);
-      auto bucket = [&](int64_t c) { return NB - 1 - std::min<int64_t>(c, NB - 1); };
+      const bool by_count = getenv("MM_EM_ORDER") && !strcmp(getenv("MM_EM_ORDER"), "count");   // default: file order (one bucket)
+      auto bucket = [&](int64_t c) { return by_count ? NB - 1 - std::min<int64_t>(c, NB - 1) : (int64_t)0; };
       for (int64_t r = 0; r < E->n_reads; ++r) start[(size_t)bucket(ro[(size_t)r + 1] - ro[(size_t)r]) + 1]++;
       for (int64_t b2 = 0; b2 < NB; ++b2) start[(size_t)b2 + 1] += start[(size_t)b2];
       for (int64_t r = 0; r < E->n_reads; ++r) { const int64_t k2 = start[(size_t)bucket(ro[(size_t)r + 1] - ro[(size_t)r])]++; sp[2 * (size_t)k2] = ro[(size_t)r]; sp[2 * (size_t)k2 + 1] = ro[(size_t)r + 1]; }

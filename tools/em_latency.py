@@ -31,11 +31,11 @@ def main():
     off, taxon, mapq, inv, T = problem(n_reads)
     print(f"{n_reads} reads, {len(taxon)} mappings, {T} taxa, largest taxon {np.bincount(taxon).max()} mappings")
     f0 = np.full(T, 1.0 / T)
-    variants = [("resident grid 128", {}), ("resident grid 64", {"MM_EM_GRID": "64"}), ("resident grid 256", {"MM_EM_GRID": "256"}), ("resident grid 32", {"MM_EM_GRID": "32"}),
+    variants = [("resident grid 128", {}), ("resident, reads by count", {"MM_EM_ORDER": "count"}), ("resident grid 64", {"MM_EM_GRID": "64"}), ("resident grid 256", {"MM_EM_GRID": "256"}), ("resident grid 32", {"MM_EM_GRID": "32"}),
                 ("phases as launches", {"MM_EM_SPLIT": "1"}), ("collective, one rank", {"MM_EM_FORCE_COLLECTIVE": "1", "_comm": "1"}),
                 ("collective + split", {"MM_EM_FORCE_COLLECTIVE": "1", "MM_EM_SPLIT": "1", "_comm": "1"})]
     for name, env in variants:
-        for k in ("MM_EM_GRID", "MM_EM_SPLIT", "MM_EM_FORCE_COLLECTIVE"):
+        for k in ("MM_EM_GRID", "MM_EM_SPLIT", "MM_EM_FORCE_COLLECTIVE", "MM_EM_ORDER"):
             os.environ.pop(k, None)
         for k, v in env.items():
             if not k.startswith("_"):

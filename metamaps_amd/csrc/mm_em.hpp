@@ -18,6 +18,7 @@ struct mm_em {
   // are [pt_item[p], pt_item[p + 1]); the resident kernel's grid, its per-workgroup log-likelihood partials and its barrier words
   mm::DBuf<int32_t> pt_item; mm::DBuf<int64_t> item_lo, item_hi; int32_t n_items = 0, n_wg = 0;
   mm::DBuf<double> item_sum, wg_ll; mm::DBuf<unsigned> bar;
+  mm::DBuf<int32_t> eread;                                // read of every mapping
   mm::DBuf<int64_t> span;                                 // per read (sorted by mapping count, longest first): first and behind-last mapping
   mm::DBuf<int64_t> pos; mm::DBuf<double> post_sorted;   // pos[i]: place of entry i in taxon-sorted order (inverse of perm); the loop keeps its posteriors there
   mm::DBuf<double> local_partial, ll_trace, f_run;   // f_run: the loop's own frequencies (mm_em_iterate / mm_em_posteriors in between do not disturb mm_em_continue)

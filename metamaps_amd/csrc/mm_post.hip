@@ -345,7 +345,8 @@ void em_iterate_allreduce(mm_em* E, const double* f, double* f_next, double* ll)
 // previous log-likelihood, ctrl[3] = first iteration of the current log-likelihood trace, ctrl[4] = a barrier timed out.
 // ---------------------------------------------------------------------------------------------------
 struct EmLoop {
-  const longlong2* span;                                          // per read, in the order of the mapping counts (longest first): [first, behind-last) mapping
+  const longlong2* span;                                          // per read (file order; MM_EM_ORDER=count: by mapping count): [first, behind-last) mapping
+  const int64_t* read_off; const int32_t* eread;                  // [n_reads + 1]; read of every mapping
   const int32_t* taxon; const double* mapq; const double* inv_nloc;
   int64_t n_reads;
   double* post_sorted; const int64_t* pos;                        // posteriors in taxon-sorted order (P1 writes entry i to pos[i], the inverse of perm[])
@@ -356,9 +357,9 @@ struct EmLoop {
   long long* ctrl; double* ll_trace; int ll_cap; long long it_limit;
   unsigned* bar;                                                  // [0] arrivals, [1] released generation
   long long barrier_ticks;                                        // a barrier not released within this many ticks of the 100 MHz wall clock gives up (ctrl[4])
+  int dbg;                                                        // MM_EM_DBG (timing aid, results then meaningless): 1 = P1 without its scattered stores, 2 = without the f gather
 };
 constexpr int EM_ITEM = 512;
-constexpr int EM_P3_LDS_ITEMS = 4096;                              // item sums staged in (dynamic) LDS by P3 up to this many, read from global memory beyond
 constexpr int EM_BAR_GROUP = 16;                                  // workgroups per first-level barrier counter
 constexpr long long EM_BARRIER_TICKS = 200000000LL;               // 2 s of the 100 MHz wall clock (MM_EM_BARRIER_TICKS: test hook)
 
@@ -370,11 +371,10 @@ constexpr long long EM_BARRIER_TICKS = 200000000LL;               // 2 s of the 
 // file order, two passes from five mappings on — at 38 of an iteration's 53 us: per wave the maximum over 64 lanes of ~6 rounds of two dependent
 // loads.)  The likelihoods are added in mapping order, as the reference adds them (fEM.h:353-358).  The posterior goes straight to its place
 // in the taxon-sorted array P2 reads (pos[i]): P2 then streams instead of gathering through perm[].
-__device__ inline void em_p1(const EmLoop& a, int wg, int n_wg, double* sh) {
+__device__ inline double em_p1_reads(const EmLoop& a, int64_t q0, int64_t q1) {   // thread-per-read form over reads [q0, q1) of `span`; returns the thread's log-likelihood share
   const int tid = threadIdx.x;
-  const int64_t stride = (int64_t)n_wg * 256;
   double ll = 0;
-  for (int64_t q = (int64_t)wg * 256 + tid; q < a.n_reads; q += stride) {
+  for (int64_t q = q0 + tid; q < q1; q += 256) {
     const longlong2 sp = a.span[q];
     const int64_t lo = sp.x, hi = sp.y;
     if (hi <= lo) continue;
@@ -385,13 +385,13 @@ __device__ inline void em_p1(const EmLoop& a, int wg, int n_wg, double* sh) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) { const int64_t i = c + u < last ? c + u : last; t8[u] = a.taxon[i]; w8[u] = a.inv_nloc[i]; q8[u] = a.mapq[i]; p8[u] = a.pos[i]; }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) f8[u] = a.f[t8[u]];
+      for (int u = 0; u < 8; ++u) f8[u] = a.dbg == 2 ? 1e-4 : a.f[t8[u]];
 #pragma unroll
       for (int u = 0; u < 8; ++u) { l8[u] = f8[u] * w8[u] * q8[u]; if (c + u < hi) sum += l8[u]; }   // fEM.h:353
     }
     if (hi - lo <= 8) {                                            // the usual read: everything is still in registers
 #pragma unroll
-      for (int u = 0; u < 8; ++u) if (lo + u < hi) a.post_sorted[p8[u]] = l8[u] / sum;              // :361
+      for (int u = 0; u < 8; ++u) if (lo + u < hi && a.dbg != 1) a.post_sorted[p8[u]] = l8[u] / sum;              // :361
     } else {
       for (int64_t c = lo; c < hi; c += 8) {
         int t8[8]; double w8[8], q8[8], f8[8]; int64_t q_pos[8];
@@ -400,11 +400,55 @@ __device__ inline void em_p1(const EmLoop& a, int wg, int n_wg, double* sh) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) f8[u] = a.f[t8[u]];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (c + u < hi) a.post_sorted[q_pos[u]] = (f8[u] * w8[u] * q8[u]) / sum;
+        for (int u = 0; u < 8; ++u) if (c + u < hi && a.dbg != 1) a.post_sorted[q_pos[u]] = (f8[u] * w8[u] * q8[u]) / sum;
       }
     }
     ll += log(sum);                                                // :578
   }
+  return ll;
+}
+// P1 of a workgroup = a contiguous block of reads, hence a contiguous block of mappings.  Round 4's phase clocks put the thread-per-read form at
+// 40 of an iteration's 53 us whatever its chunk width, grid or read order: it is bound by the ~0.9 M sector requests its strided accesses make
+// (four arrays, a lane's mappings 34 bytes from its neighbour's; without the scattered posterior stores -12 us, without the f gather -7 us).
+// Here the mappings are walked thread-per-MAPPING (coalesced), the likelihoods parked in LDS, the reads' sums taken from LDS in mapping order (the
+// reference's order, fEM.h:353-358), and the posteriors written in a second coalesced walk.  A block with more mappings or reads than the LDS
+// arrays hold takes the thread-per-read form.
+constexpr int EM_LBUF = 5120, EM_RBUF = 1536;                     // mappings / reads of a block that fit the LDS arrays
+__device__ inline void em_p1(const EmLoop& a, int wg, int n_wg, double* sh, double* lbuf, double* rsum) {
+  const int tid = threadIdx.x;
+  const int64_t rb = (a.n_reads + n_wg - 1) / n_wg, R0 = min((int64_t)wg * rb, a.n_reads), R1 = min(R0 + rb, a.n_reads);
+  double ll = 0;
+  const int64_t E0 = R1 > R0 ? a.read_off[R0] : 0, E1 = R1 > R0 ? a.read_off[R1] : 0;
+  const int nE = (int)min(E1 - E0, (int64_t)EM_LBUF + 1), nR = (int)(R1 - R0);
+  if (a.span != nullptr && (a.dbg == 3 || E1 - E0 > EM_LBUF || nR > EM_RBUF)) ll = em_p1_reads(a, R0, R1);
+  else if (nR > 0) {
+    for (int e0 = 0; e0 < nE; e0 += 4 * 256) {                   // four coalesced mappings per thread in flight
+      int t4[4]; double w4[4], q4[4], f4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int64_t i = E0 + min(e0 + u * 256 + tid, nE - 1); t4[u] = a.taxon[i]; w4[u] = a.inv_nloc[i]; q4[u] = a.mapq[i]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) f4[u] = a.f[t4[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int e = e0 + u * 256 + tid; if (e < nE) lbuf[e] = f4[u] * w4[u] * q4[u]; }   // fEM.h:353
+    }
+    __syncthreads();
+    for (int r = tid; r < nR; r += 256) {
+      const int lo = (int)(a.read_off[R0 + r] - E0), hi = (int)(a.read_off[R0 + r + 1] - E0);
+      double sum = 0;
+      for (int e = lo; e < hi; ++e) sum += lbuf[e];
+      rsum[r] = sum;
+      if (hi > lo) ll += log(sum);                                 // :578
+    }
+    __syncthreads();
+    for (int e0 = 0; e0 < nE; e0 += 4 * 256) {
+      int64_t p4[4]; int r4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int64_t i = E0 + min(e0 + u * 256 + tid, nE - 1); p4[u] = a.pos[i]; r4[u] = a.eread[i]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int e = e0 + u * 256 + tid; if (e < nE) a.post_sorted[p4[u]] = lbuf[e] / rsum[r4[u] - (int)R0]; }   // :361
+    }
+  }
+  __syncthreads();
   sh[tid] = ll;
   __syncthreads();
   for (int d = 128; d > 0; d >>= 1) { if (tid < d) sh[tid] += sh[tid + d]; __syncthreads(); }
@@ -453,10 +497,10 @@ __device__ inline void em_stop_rule(long long* ctrl, double ll, double* ll_trace
 // P3 (one workgroup).  LOCAL: the per-taxon sums and the log-likelihood of this rank go to local_partial[0..T] (all-reduced next);
 // otherwise: normalise over the present taxa, write f, evaluate the stop rule.
 template <bool LOCAL>
-__device__ inline void em_p3(const EmLoop& a, int n_wg, double* sh) {
+__device__ inline void em_p3(const EmLoop& a, int n_wg, double* sh, double* s_item) {
   const int tid = threadIdx.x;
-  extern __shared__ double s_item[];                               // the item sums of a taxon are added in order by one thread: from LDS, not one global round trip each
-  const bool staged = a.n_items <= EM_P3_LDS_ITEMS;
+  // the item sums of a taxon are added in order by one thread: from LDS (P1's likelihood buffer, free by now), not one global round trip each
+  const bool staged = a.n_items <= EM_LBUF;
   if (staged) { for (int it = tid; it < a.n_items; it += 256) s_item[it] = a.item_sum[it]; __syncthreads(); }
   for (int p = tid; p < a.n_present; p += 256) {
     double s = 0;
@@ -524,7 +568,7 @@ __device__ inline bool grid_wait(unsigned* bar, unsigned epoch, long long* ctrl,
 // ONE_ITERATION = false: the whole run of one rank.  true: kernel A of a multi-rank iteration (P1 | P2 | local sums), leaves after it.
 template <bool ONE_ITERATION>
 __global__ void __launch_bounds__(256) em_loop_kernel(EmLoop a) {
-  __shared__ double sh[256];
+  __shared__ double sh[256], lbuf[EM_LBUF], rsum[EM_RBUF];
   __shared__ int s_flag;
   const int wg = blockIdx.x, n_wg = gridDim.x;
   if (__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // (iterations enqueued past the stop are no-ops)
@@ -533,7 +577,7 @@ __global__ void __launch_bounds__(256) em_loop_kernel(EmLoop a) {
   long long t_prev = prof ? (long long)wall_clock64() : 0;
   auto tick = [&](int slot) { if (prof) { const long long t = (long long)wall_clock64(); a.ctrl[slot] += t - t_prev; t_prev = t; } };
   for (;;) {
-    em_p1(a, wg, n_wg, sh);
+    em_p1(a, wg, n_wg, sh, lbuf, rsum);
     tick(5);
     ++epoch;
     if (grid_arrive_is_last(a.bar, epoch, n_wg, &s_flag)) grid_release(a.bar, epoch);
@@ -546,7 +590,7 @@ __global__ void __launch_bounds__(256) em_loop_kernel(EmLoop a) {
     tick(7);
     ++epoch;
     if (grid_arrive_is_last(a.bar, epoch, n_wg, &s_flag)) {
-      em_p3<ONE_ITERATION>(a, n_wg, sh);
+      em_p3<ONE_ITERATION>(a, n_wg, sh, lbuf);
       if (ONE_ITERATION) return;
       grid_release(a.bar, epoch);
     } else {
@@ -557,10 +601,10 @@ __global__ void __launch_bounds__(256) em_loop_kernel(EmLoop a) {
   }
 }
 // the same phases as separate launches (no barrier inside): the path after a barrier time-out, and MM_EM_SPLIT=1
-__global__ void __launch_bounds__(256) em_p1_kernel(EmLoop a) { __shared__ double sh[256]; if (a.ctrl[1]) return; em_p1(a, blockIdx.x, gridDim.x, sh); }
+__global__ void __launch_bounds__(256) em_p1_kernel(EmLoop a) { __shared__ double sh[256], lbuf[EM_LBUF], rsum[EM_RBUF]; if (a.ctrl[1]) return; em_p1(a, blockIdx.x, gridDim.x, sh, lbuf, rsum); }
 __global__ void __launch_bounds__(256) em_p2_kernel(EmLoop a) { if (a.ctrl[1]) return; em_p2(a, blockIdx.x, gridDim.x); }
 template <bool LOCAL>
-__global__ void __launch_bounds__(256) em_p3_kernel(EmLoop a, int n_wg) { __shared__ double sh[256]; if (a.ctrl[1]) return; em_p3<LOCAL>(a, n_wg, sh); }
+__global__ void __launch_bounds__(256) em_p3_kernel(EmLoop a, int n_wg) { __shared__ double sh[256], s_item[EM_LBUF]; if (a.ctrl[1]) return; em_p3<LOCAL>(a, n_wg, sh, s_item); }
 // kernel B of a multi-rank iteration: normalise the all-reduced sums (fEM.h:606-615; fixed-shape sum over the taxa, the same on every
 // rank), log-likelihood trace, stop rule (:624-639)
 __global__ void __launch_bounds__(256) em_finalize_kernel(const double* __restrict__ partial, int32_t n_taxa, double* __restrict__ f, long long* __restrict__ ctrl,
@@ -576,6 +620,10 @@ __global__ void __launch_bounds__(256) em_finalize_kernel(const double* __restri
   if (threadIdx.x == 0) em_stop_rule(ctrl, partial[n_taxa], ll_trace, ll_cap, it_limit);
 }
 
+__global__ void em_eread_kernel(const int64_t* __restrict__ read_off, int64_t n_reads, int32_t* __restrict__ eread) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_reads) for (int64_t i = read_off[r]; i < read_off[r + 1]; ++i) eread[i] = (int32_t)r;
+}
 __global__ void em_pos_kernel(const int64_t* __restrict__ perm, int64_t ne, int64_t* __restrict__ pos) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j < ne) pos[perm[j]] = j;
@@ -627,6 +675,9 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
       MM_HIP(hipStreamSynchronize(st));                          // (sp is the upload's source)
     }
     E->pos.alloc((size_t)std::max<int64_t>(E->n_entries, 1)); E->post_sorted.alloc((size_t)std::max<int64_t>(E->n_entries, 1));
+    MM_REQUIRE(E->n_reads < (1LL << 31), MM_ERR_LIMIT, "EM problem beyond 2^31 reads");
+    E->eread.alloc((size_t)std::max<int64_t>(E->n_entries, 1));
+    if (E->n_reads > 0) { em_eread_kernel<<<dim3((unsigned)ceil_div(E->n_reads, 256)), dim3(256), 0, st>>>(E->read_off.p, E->n_reads, E->eread.p); MM_KERNEL_CHECK(); }
     if (E->n_entries > 0) { em_pos_kernel<<<dim3((unsigned)ceil_div(E->n_entries, 256)), dim3(256), 0, st>>>(E->perm.p, E->n_entries, E->pos.p); MM_KERNEL_CHECK(); }
     E->wg_ll.alloc((size_t)E->n_wg);
     E->local_partial.alloc((size_t)T + 2);
@@ -650,11 +701,11 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
     MM_HIP(hipStreamSynchronize(st));
   }
   const long long it0 = h_ctrl[0], it_limit = it0 + max_iter;
-  EmLoop a{(const longlong2*)E->span.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->n_reads, E->post_sorted.p, E->pos.p, E->item_lo.p, E->item_hi.p, E->n_items,
+  EmLoop a{(const longlong2*)E->span.p, E->read_off.p, E->eread.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->n_reads, E->post_sorted.p, E->pos.p, E->item_lo.p, E->item_hi.p, E->n_items,
            E->present.p, E->pt_item.p, E->n_present, E->item_sum.p, E->wg_ll.p, E->f_run.p, E->local_partial.p, T, E->ctrl.p, E->ll_trace.p, cap, it_limit, E->bar.p,
-           (getenv("MM_EM_PROF") ? -1 : 1) * (getenv("MM_EM_BARRIER_TICKS") ? atoll(getenv("MM_EM_BARRIER_TICKS")) : EM_BARRIER_TICKS)};
+           (getenv("MM_EM_PROF") ? -1 : 1) * (getenv("MM_EM_BARRIER_TICKS") ? atoll(getenv("MM_EM_BARRIER_TICKS")) : EM_BARRIER_TICKS),
+           getenv("MM_EM_DBG") ? atoi(getenv("MM_EM_DBG")) : 0};
   const dim3 grid((unsigned)E->n_wg), blk(256);
-  const size_t p3_lds = E->n_items <= EM_P3_LDS_ITEMS ? sizeof(double) * (size_t)std::max(E->n_items, 1) : 0;
   const bool force_split = getenv("MM_EM_SPLIT") != nullptr;
   bool split = force_split || ctx->em_split;
   // a communicator of ONE rank has nothing to exchange: the run is the resident kernel, as without a communicator (MM_EM_FORCE_COLLECTIVE=1
@@ -678,19 +729,19 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
   while (!h_ctrl[1] && h_ctrl[0] < it_limit) {
     if (!collective && !split) {                                 // one rank: the whole run is one launch
       E->bar.zero(st);
-      em_loop_kernel<false><<<grid, blk, p3_lds, st>>>(a);
+      em_loop_kernel<false><<<grid, blk, 0, st>>>(a);
       MM_KERNEL_CHECK();
     } else {
       const int g_n = (int)std::min<long long>(GROUP, it_limit - h_ctrl[0]);   // (the same on every rank: h_ctrl holds all-reduced decisions)
       for (int g = 0; g < g_n; ++g) {
         if (!split) {
           E->bar.zero(st);
-          em_loop_kernel<true><<<grid, blk, p3_lds, st>>>(a);
+          em_loop_kernel<true><<<grid, blk, 0, st>>>(a);
           MM_KERNEL_CHECK();
         } else {
           em_p1_kernel<<<grid, blk, 0, st>>>(a); MM_KERNEL_CHECK();
           em_p2_kernel<<<grid, blk, 0, st>>>(a); MM_KERNEL_CHECK();
-          if (collective) em_p3_kernel<true><<<dim3(1), blk, p3_lds, st>>>(a, E->n_wg); else em_p3_kernel<false><<<dim3(1), blk, p3_lds, st>>>(a, E->n_wg);
+          if (collective) em_p3_kernel<true><<<dim3(1), blk, 0, st>>>(a, E->n_wg); else em_p3_kernel<false><<<dim3(1), blk, 0, st>>>(a, E->n_wg);
           MM_KERNEL_CHECK();
         }
         if (collective) {                                        // fEM.h:583-600, across GPUs instead of OpenMP threads

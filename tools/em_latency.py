@@ -31,11 +31,11 @@ def main():
     off, taxon, mapq, inv, T = problem(n_reads)
     print(f"{n_reads} reads, {len(taxon)} mappings, {T} taxa, largest taxon {np.bincount(taxon).max()} mappings")
     f0 = np.full(T, 1.0 / T)
-    variants = [("resident grid 128", {}), ("resident, reads by count", {"MM_EM_ORDER": "count"}), ("resident grid 64", {"MM_EM_GRID": "64"}), ("resident grid 256", {"MM_EM_GRID": "256"}), ("resident grid 32", {"MM_EM_GRID": "32"}),
+    variants = [("resident grid 128", {}), ("thread-per-read P1", {"MM_EM_DBG": "3"}), ("resident grid 64", {"MM_EM_GRID": "64"}), ("resident grid 256", {"MM_EM_GRID": "256"}), ("resident grid 32", {"MM_EM_GRID": "32"}),
                 ("phases as launches", {"MM_EM_SPLIT": "1"}), ("collective, one rank", {"MM_EM_FORCE_COLLECTIVE": "1", "_comm": "1"}),
                 ("collective + split", {"MM_EM_FORCE_COLLECTIVE": "1", "MM_EM_SPLIT": "1", "_comm": "1"})]
     for name, env in variants:
-        for k in ("MM_EM_GRID", "MM_EM_SPLIT", "MM_EM_FORCE_COLLECTIVE", "MM_EM_ORDER"):
+        for k in ("MM_EM_GRID", "MM_EM_SPLIT", "MM_EM_FORCE_COLLECTIVE", "MM_EM_ORDER", "MM_EM_DBG"):
             os.environ.pop(k, None)
         for k, v in env.items():
             if not k.startswith("_"):
@@ -57,18 +57,21 @@ def main():
         e.close(); ctx.close()
 
 
-def phases():
-    """MM_EM_PROF=1: the library prints workgroup 0's time per phase of the resident kernel"""
+def phases(dbg=None):
+    """MM_EM_PROF=1: the library prints workgroup 0's time per phase of the resident kernel (dbg: MM_EM_DBG, parts of P1 left out)"""
     n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
     off, taxon, mapq, inv, T = problem(n_reads)
-    for k in ("MM_EM_GRID", "MM_EM_SPLIT", "MM_EM_FORCE_COLLECTIVE"):
+    for k in ("MM_EM_GRID", "MM_EM_SPLIT", "MM_EM_FORCE_COLLECTIVE", "MM_EM_DBG"):
         os.environ.pop(k, None)
     os.environ["MM_EM_PROF"] = "1"
+    if dbg:
+        os.environ["MM_EM_DBG"] = dbg
+        print(f"MM_EM_DBG={dbg}:", file=sys.stderr, flush=True)
     ctx = capi.Context(0)
     e = ctx.em(off, taxon, mapq, inv, T)
     e.run(np.full(T, 1.0 / T), max_iter=3)
     sys.stderr.flush()
-    t0 = time.perf_counter(); f, lls = e.run(np.full(T, 1.0 / T), max_iter=200); dt = time.perf_counter() - t0
+    t0 = time.perf_counter(); f, lls = e.run(np.full(T, 1.0 / T), max_iter=12); dt = time.perf_counter() - t0
     print(f"with MM_EM_PROF: {dt / len(lls) * 1e6:.1f} us per iteration over {len(lls)} iterations (phase split on stderr)")
     e.close(); ctx.close()
     os.environ.pop("MM_EM_PROF", None)
@@ -77,3 +80,4 @@ def phases():
 if __name__ == "__main__":
     main()
     phases()
+    phases("3")                                                   # the thread-per-read form of P1

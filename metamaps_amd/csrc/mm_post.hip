@@ -706,7 +706,11 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
            (getenv("MM_EM_PROF") ? -1 : 1) * (getenv("MM_EM_BARRIER_TICKS") ? atoll(getenv("MM_EM_BARRIER_TICKS")) : EM_BARRIER_TICKS),
            getenv("MM_EM_DBG") ? atoi(getenv("MM_EM_DBG")) : 0};
   const dim3 grid((unsigned)E->n_wg), blk(256);
-  const bool force_split = getenv("MM_EM_SPLIT") != nullptr;
+  // One launch per phase is the default: measured against the resident kernel (MM_EM_RESIDENT=1, same phases behind grid barriers, bit-identical)
+  // it is the faster form on an idle GPU (35 against 44 us per iteration, tools/em_latency.py) and no slower beside another context's kernels
+  // (bench: 1.9 against 2.2 ms of EM per step) — the barriers' L2 write-back / invalidate and the wait for the slowest workgroup cost more
+  // than three launches on one stream do.
+  const bool force_split = getenv("MM_EM_RESIDENT") == nullptr || getenv("MM_EM_SPLIT") != nullptr;
   bool split = force_split || ctx->em_split;
   // a communicator of ONE rank has nothing to exchange: the run is the resident kernel, as without a communicator (MM_EM_FORCE_COLLECTIVE=1
   // keeps kernel A | ncclAllReduce | kernel B also then: how the tests drive the collective path on a one-GPU box)

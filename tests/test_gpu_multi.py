@@ -193,8 +193,8 @@ def _em_problem(seed, n_reads, n_taxa, sigma=2.0, tied=True):
 
 @pytest.mark.parametrize("n_reads,n_taxa", [(60_000, 700), (900, 40), (3, 5)])
 def test_em_resident_kernel_equals_its_phases_as_launches(n_reads, n_taxa, monkeypatch):
-    """the whole EM run as ONE resident kernel (grid barriers between E step, per-taxon sums and normalisation + stop rule) gives, bit for bit,
-    what the same phases give as separate launches (MM_EM_SPLIT), also when a barrier gives up mid-run (MM_EM_BARRIER_TICKS=1: the run goes on
+    """the whole EM run as ONE resident kernel (MM_EM_RESIDENT=1: grid barriers between E step, per-taxon sums and normalisation + stop rule) gives, bit for bit,
+    what the same phases give as separate launches (the default since the two were measured against each other), also when a barrier gives up mid-run (MM_EM_BARRIER_TICKS=1: the run goes on
     phase by phase from the last completed iteration); other grid sizes (another summation shape of the log-likelihood) agree to 1e-12; with a
     one-rank communicator (kernel A | ncclAllReduce | kernel B per iteration) as well; exactly tied taxa stay exactly tied in every form"""
     from metamaps_amd import capi, emhost
@@ -202,7 +202,7 @@ def test_em_resident_kernel_equals_its_phases_as_launches(n_reads, n_taxa, monke
     f0 = np.full(T, 1.0 / T)
 
     def run(env, comm=False):
-        for kk in ("MM_EM_SPLIT", "MM_EM_GRID", "MM_EM_BARRIER_TICKS", "MM_EM_FORCE_COLLECTIVE"):
+        for kk in ("MM_EM_SPLIT", "MM_EM_RESIDENT", "MM_EM_GRID", "MM_EM_BARRIER_TICKS", "MM_EM_FORCE_COLLECTIVE"):
             monkeypatch.delenv(kk, raising=False)
         for kk, v in env.items():
             monkeypatch.setenv(kk, v)
@@ -220,26 +220,29 @@ def test_em_resident_kernel_equals_its_phases_as_launches(n_reads, n_taxa, monke
         assert stopped and np.array_equal(np.concatenate([lls5, llsc]), lls) and np.array_equal(fc, f)
         return f, lls, best
 
-    f_a, ll_a, best_a = run({})
+    f_a, ll_a, best_a = run({"MM_EM_RESIDENT": "1"})
     assert len(ll_a) >= 3 and abs(f_a.sum() - 1) < 1e-12
     if T > 4:
         assert f_a[1] == f_a[2] and f_a[1] > 0                    # the twins
-    f_b, ll_b, best_b = run({"MM_EM_SPLIT": "1"})
+    f_b, ll_b, best_b = run({})                                   # the default: one launch per phase
     assert np.array_equal(f_a, f_b) and np.array_equal(ll_a, ll_b) and np.array_equal(best_a, best_b)
-    f_c, ll_c, best_c = run({"MM_EM_BARRIER_TICKS": "1"})
+    f_c, ll_c, best_c = run({"MM_EM_RESIDENT": "1", "MM_EM_BARRIER_TICKS": "1"})
     assert np.array_equal(f_a, f_c) and np.array_equal(ll_a, ll_c)
+    f_d, ll_d, _ = run({"MM_EM_DBG": "3"})                        # P1 thread-per-read (the form blocks too large for the LDS buffers take): another summation order of ll only
+    monkeypatch.delenv("MM_EM_DBG", raising=False)
+    assert len(ll_d) == len(ll_a) and np.allclose(ll_d, ll_a, rtol=1e-12, atol=0) and np.allclose(f_d, f_a, rtol=1e-10, atol=1e-300)
     for grid in ("1", "7", "256"):
-        f_g, ll_g, _ = run({"MM_EM_GRID": grid})
+        f_g, ll_g, _ = run({"MM_EM_GRID": grid} if grid == "7" else {"MM_EM_GRID": grid, "MM_EM_RESIDENT": "1"})
         assert len(ll_g) == len(ll_a) and np.allclose(ll_g, ll_a, rtol=1e-12, atol=0) and np.allclose(f_g, f_a, rtol=1e-10, atol=1e-300)
         if T > 4:
             assert f_g[1] == f_g[2]
-    for env in ({}, {"MM_EM_SPLIT": "1"}, {"MM_EM_BARRIER_TICKS": "1"}):
+    for env in ({}, {"MM_EM_RESIDENT": "1"}, {"MM_EM_RESIDENT": "1", "MM_EM_BARRIER_TICKS": "1"}):
         f_m, ll_m, _ = run(env, comm=True)
         assert len(ll_m) == len(ll_a) and np.allclose(ll_m, ll_a, rtol=1e-12, atol=0) and np.allclose(f_m, f_a, rtol=1e-10, atol=1e-300)
         if T > 4:
             assert f_m[1] == f_m[2]
-    monkeypatch.delenv("MM_EM_FORCE_COLLECTIVE", raising=False)
-    ctx = capi.Context(0)                                         # a one-rank communicator without the switch: the resident kernel, bit for bit
+    monkeypatch.delenv("MM_EM_FORCE_COLLECTIVE", raising=False); monkeypatch.delenv("MM_EM_RESIDENT", raising=False); monkeypatch.delenv("MM_EM_BARRIER_TICKS", raising=False)
+    ctx = capi.Context(0)                                         # a one-rank communicator without the switch: no collective, bit for bit the plain run
     ctx.comm_init(capi.Context.comm_unique_id(), 0, 1)
     e = ctx.em(off, taxon, mapq, inv, T)
     f_1, ll_1 = e.run(f0)

@@ -629,8 +629,8 @@ __global__ void em_pos_kernel(const int64_t* __restrict__ perm, int64_t ne, int6
   if (j < ne) pos[perm[j]] = j;
 }
 static int em_grid(int64_t n_reads) {                            // (fixed per problem: the log-likelihood partials are summed in the grid's shape)
-  const char* e = getenv("MM_EM_GRID");
-  const int cap = std::min(std::max(e ? atoi(e) : 128, 1), 1024);
+  const char* e = getenv("MM_EM_GRID");                           // default: 256 workgroups as launches (33 us per iteration against 38 at 128), 128 for the resident kernel (all must be resident together)
+  const int cap = std::min(std::max(e ? atoi(e) : (getenv("MM_EM_RESIDENT") ? 128 : 256), 1), 1024);
   return (int)std::max<int64_t>(1, std::min<int64_t>(cap, ceil_div(std::max<int64_t>(n_reads, 1), 256)));
 }
 

@@ -628,6 +628,7 @@ def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
     # At full scale: one (two were tried, MM_BENCH_C3_WORKERS=2: out of memory with every cache given back, tools/mem_config3.py)
     if W > 1:
         import torch
+        ctx.release_cached()                                       # (the index builds' pooled temporaries: room for a second worker context)
         torch.cuda.synchronize(); f0 = torch.cuda.mem_get_info()[0]
         em_turn["next"] = 0; step(0, ctxs[0])
         torch.cuda.synchronize(); f1 = torch.cuda.mem_get_info()[0]

@@ -17,8 +17,9 @@ With those,
      closer: measured 1.33e-3); the 31 of 943 taxa that survive cleanF (fEM.h:1135-1163) exactly;
   2. the oracle's WHOLE classify (EM loop included) is run on mappings whose field 14 is w_i = p*_i / f^[t_i] * nLoc_i, f^ = M(p*): the
      E step only sees f[t] w_i / nLoc_i up to a per-read factor, so f^ is an exact fixed point of this problem with posteriors p*; the
-     oracle's loop, started from uniform frequencies like the reference's, has to arrive there (stop rule included) and write the same
-     files again.
+     oracle's loop, STARTED AT f^, has to hold it — two iterations, unchanged log-likelihood, stop rule fires — and write the same
+     files again.  (Started from uniform frequencies the problem does not retrace the reference's run: the zip lacks the frequencies of
+     the 912 taxa cleanF removed, and w_i needs them to a relative precision one M step cannot give.)
 Not pinned by any of this: nLoc itself (the zip has no contig without a mapping) and the mapping qualities that entered the EM."""
 import collections
 import os

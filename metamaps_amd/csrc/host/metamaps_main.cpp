@@ -1322,7 +1322,8 @@ void run_em_sharded(const std::vector<Dev>& devs, EmReduce reduce, const std::ve
 }
 
 int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::string& mapped, const std::string& db, size_t minReadsU,
-                 const std::function<void()>& leave_now = nullptr /* the last file: called once everything is written; the process ends there */) {   // meta::doEM, fEM.h:466-803
+                 const std::function<void()>& leave_now = nullptr /* the last file: called once everything is written; the process ends there */,
+                 const std::function<void()>& need_devices = nullptr /* called before the first device call: the contexts are created beside the parsing of the file */) {   // meta::doEM, fEM.h:466-803
   PhaseClock pc;
   // The mappings file once through: every line is tokenised where it lies (the reference splits every line again in every EM round,
   // fEM.h:1171-1214, :234-373), lines of one read are consecutive (mapWrap.h:128-149), contig IDs are interned.
@@ -1483,6 +1484,7 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
   std::vector<double> f(NT, 1 / (double)NT);
   std::vector<double> post(taxon.size()); std::vector<int64_t> best(NR);
   std::cout << "Starting EM..." << std::endl;
+  if (need_devices) need_devices();
   run_em_sharded(devs, reduce, off, taxon, mapq, inv, NT, f, post, best);
   pc.lap("c4 EM");
   std::cout << "Outputting mappings with adjusted alignment qualities." << std::endl;
@@ -1534,17 +1536,29 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
     std::vector<std::vector<double>> identsIdx(taxa.size());
     std::vector<ContigCoverage::Slot> cslot(contig_id.size());
     fmt(0);
-    for (size_t r = 0; r < NRD; ++r) {
-      const size_t b = (size_t)best[r];
-      const MapLine& B = lines[b];
-      const size_t tx = (size_t)taxon[b];
-      readsPerIdx[tx]++;
-      identsIdx[tx].push_back(B.ident);
+    for (size_t r = 0; r < NRD; ++r) {                           // the window vectors of every contig with a best mapping (map insertions: one thread)
+      const MapLine& B = lines[(size_t)best[r]];
+      const size_t tx = (size_t)taxon[(size_t)best[r]];
       maxReadLen = std::max(maxReadLen, B.len);
       if (contig_len_ti[(size_t)B.contig] < 0) die("contig " + contig_id[(size_t)B.contig] + " is not listed for taxon " + taxa[tx] + " in " + db + "/taxonInfo.txt");
       ContigCoverage::Slot& sl = cslot[(size_t)B.contig];
       if (!sl.v) sl = coverage.slot(taxa[tx], contig_id[(size_t)B.contig], (size_t)contig_len_ti[(size_t)B.contig]);
-      coverage.add(sl, (size_t)contig_len_ti[(size_t)B.contig], B.start, B.stop);
+    }
+    {                                                            // tallies: thread k owns the taxa and the contigs with index % NT2 == k and walks the reads in order
+      const size_t NT2 = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, HW / 8), NRD / 20000 + 1}));
+      auto tally = [&](size_t k) {
+        for (size_t r = 0; r < NRD; ++r) {
+          const size_t b = (size_t)best[r];
+          const MapLine& B = lines[b];
+          const size_t tx = (size_t)taxon[b];
+          if (tx % NT2 == k) { readsPerIdx[tx]++; identsIdx[tx].push_back(B.ident); }
+          if ((size_t)B.contig % NT2 == k) coverage.add(cslot[(size_t)B.contig], (size_t)contig_len_ti[(size_t)B.contig], B.start, B.stop);
+        }
+      };
+      std::vector<std::thread> tp;
+      for (size_t k = 1; k < NT2; ++k) tp.emplace_back(tally, k);
+      tally(0);
+      for (auto& th : tp) th.join();
     }
     for (size_t t = 0; t < taxa.size(); ++t) if (readsPerIdx[t]) { readsPer[taxa[t]] = readsPerIdx[t]; identsPerTaxon[taxa[t]] = std::move(identsIdx[t]); }
     for (auto& th : pool) th.join();
@@ -1592,15 +1606,20 @@ int main(int argc, char** argv) {
     auto since = [&](const char* what) { if (getenv("MM_CLI_TIMING")) std::cerr << "INFO, main: " << what << " at +" << std::chrono::duration<double>(std::chrono::steady_clock::now() - m0).count() << " s\n"; };
     std::vector<Dev> devs;
     for (int p : device_list(o)) { Dev d; d.phys = p; devs.push_back(d); }
-    for (auto& d : devs) if (mm_ctx_create(d.phys, &d.ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
-    since("contexts created");
+    // the contexts (HIP initialisation: ~0.1 s) come up on a thread of their own while the mappings file is read and tokenised
+    std::thread ctx_thread([&] {
+      for (auto& d : devs) if (mm_ctx_create(d.phys, &d.ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
+      since("contexts created");
+    });
+    const std::function<void()> need_devices = [&] { if (ctx_thread.joinable()) ctx_thread.join(); };
     // an explicit --gpus 1 also goes through RCCL (one rank); --em-host-reduce: the ranks' sums are added on the host (test hook: ranks may share a device)
     const EmReduce reduce = o.em_host ? EmReduce::Host : ((devs.size() > 1 || o.v.count("gpus") || o.v.count("devices")) ? EmReduce::Rccl : EmReduce::None);
     const size_t minReadsU = o.v.count("minreads") ? std::stoull(o.v.at("minreads")) : 10000;   // parseCmdArgs.hpp:462-471
     const std::vector<std::string> files = split(o.v.at("mappings"), ",");
     for (size_t fi = 0; fi < files.size(); ++fi) {
-      if (fi + 1 == files.size()) classify_one(devs, reduce, files[fi], o.v.at("DB"), minReadsU, [&] { since("mappings file done"); });
-      else classify_one(devs, reduce, files[fi], o.v.at("DB"), minReadsU);
+      if (fi + 1 == files.size()) classify_one(devs, reduce, files[fi], o.v.at("DB"), minReadsU, [&] { since("mappings file done"); }, need_devices);
+      else classify_one(devs, reduce, files[fi], o.v.at("DB"), minReadsU, nullptr, need_devices);
+      need_devices();
       for (auto& d : devs) mm_comm_destroy(d.ctx);
       since("mappings file done");
     }

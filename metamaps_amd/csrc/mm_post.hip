@@ -375,8 +375,8 @@ __device__ inline double em_p1_reads(const EmLoop& a, int64_t q0, int64_t q1) { 
   const int tid = threadIdx.x;
   double ll = 0;
   for (int64_t q = q0 + tid; q < q1; q += 256) {
-    const longlong2 sp = a.span[q];
-    const int64_t lo = sp.x, hi = sp.y;
+    int64_t lo, hi;
+    if (a.span) { const longlong2 sp = a.span[q]; lo = sp.x; hi = sp.y; } else { lo = a.read_off[q]; hi = a.read_off[q + 1]; }
     if (hi <= lo) continue;
     const int64_t last = hi - 1;
     double sum = 0, l8[8]; int64_t p8[8];
@@ -420,7 +420,7 @@ __device__ inline void em_p1(const EmLoop& a, int wg, int n_wg, double* sh, doub
   double ll = 0;
   const int64_t E0 = R1 > R0 ? a.read_off[R0] : 0, E1 = R1 > R0 ? a.read_off[R1] : 0;
   const int nE = (int)min(E1 - E0, (int64_t)EM_LBUF + 1), nR = (int)(R1 - R0);
-  if (a.span != nullptr && (a.dbg == 3 || E1 - E0 > EM_LBUF || nR > EM_RBUF)) ll = em_p1_reads(a, R0, R1);
+  if (a.dbg == 3 || E1 - E0 > EM_LBUF || nR > EM_RBUF) ll = em_p1_reads(a, R0, R1);
   else if (nR > 0) {
     for (int e0 = 0; e0 < nE; e0 += 4 * 256) {                   // four coalesced mappings per thread in flight
       int t4[4]; double w4[4], q4[4], f4[4];
@@ -628,7 +628,11 @@ __global__ void em_pos_kernel(const int64_t* __restrict__ perm, int64_t ne, int6
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j < ne) pos[perm[j]] = j;
 }
-static int em_grid(int64_t n_reads) {                            // (fixed per problem: the log-likelihood partials are summed in the grid's shape)
+static int em_grid(int64_t n_reads, int64_t n_entries) {         // (fixed per problem: the log-likelihood partials are summed in the grid's shape)
+  if (!getenv("MM_EM_GRID") && !getenv("MM_EM_RESIDENT")) {        // launches: as many blocks as keep a block within P1's LDS buffers (1 024 reads, 4 096 mappings), 256 at least
+    const int64_t want = std::max<int64_t>({(int64_t)256, ceil_div(std::max<int64_t>(n_reads, 1), 1024), ceil_div(std::max<int64_t>(n_entries, 1), 4096)});
+    return (int)std::max<int64_t>(1, std::min<int64_t>({want, (int64_t)8192, ceil_div(std::max<int64_t>(n_reads, 1), 256)}));
+  }
   const char* e = getenv("MM_EM_GRID");                           // default: 256 workgroups as launches (33 us per iteration against 38 at 128), 128 for the resident kernel (all must be resident together)
   const int cap = std::min(std::max(e ? atoi(e) : (getenv("MM_EM_RESIDENT") ? 128 : 256), 1), 1024);
   return (int)std::max<int64_t>(1, std::min<int64_t>(cap, ceil_div(std::max<int64_t>(n_reads, 1), 256)));
@@ -654,13 +658,13 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
       pti.push_back((int32_t)ilo.size());
     }
     E->n_present = (int32_t)pr.size(); E->n_items = (int32_t)ilo.size();
-    E->n_wg = em_grid(E->n_reads);
+    E->n_wg = em_grid(E->n_reads, E->n_entries);
     E->present.alloc(std::max<size_t>(pr.size(), 1)); E->present.upload(pr.data(), pr.size(), st);
     E->pt_item.alloc(pti.size()); E->pt_item.upload(pti.data(), pti.size(), st);
     E->item_lo.alloc(std::max<size_t>(ilo.size(), 1)); E->item_lo.upload(ilo.data(), ilo.size(), st);
     E->item_hi.alloc(std::max<size_t>(ihi.size(), 1)); E->item_hi.upload(ihi.data(), ihi.size(), st);
     E->item_sum.alloc(std::max<size_t>(ilo.size(), 1));
-    {                                                              // the reads by mapping count, longest first (stable: file order among equals)
+    if (getenv("MM_EM_ORDER") && !strcmp(getenv("MM_EM_ORDER"), "count")) {   // measurement aid: the thread-per-read form (MM_EM_DBG=3) with the reads by mapping count, longest first
       std::vector<int64_t> ro = E->read_off.to_host(st, (size_t)E->n_reads + 1);
       std::vector<int64_t> sp(2 * (size_t)std::max<int64_t>(E->n_reads, 1), 0);
       int64_t cmax = 0; for (int64_t r = 0; r < E->n_reads; ++r) cmax = std::max(cmax, ro[(size_t)r + 1] - ro[(size_t)r]);
@@ -701,7 +705,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
     MM_HIP(hipStreamSynchronize(st));
   }
   const long long it0 = h_ctrl[0], it_limit = it0 + max_iter;
-  EmLoop a{(const longlong2*)E->span.p, E->read_off.p, E->eread.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->n_reads, E->post_sorted.p, E->pos.p, E->item_lo.p, E->item_hi.p, E->n_items,
+  EmLoop a{(const longlong2*)(E->span.n ? E->span.p : nullptr), E->read_off.p, E->eread.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->n_reads, E->post_sorted.p, E->pos.p, E->item_lo.p, E->item_hi.p, E->n_items,
            E->present.p, E->pt_item.p, E->n_present, E->item_sum.p, E->wg_ll.p, E->f_run.p, E->local_partial.p, T, E->ctrl.p, E->ll_trace.p, cap, it_limit, E->bar.p,
            (getenv("MM_EM_PROF") ? -1 : 1) * (getenv("MM_EM_BARRIER_TICKS") ? atoll(getenv("MM_EM_BARRIER_TICKS")) : EM_BARRIER_TICKS),
            getenv("MM_EM_DBG") ? atoi(getenv("MM_EM_DBG")) : 0};

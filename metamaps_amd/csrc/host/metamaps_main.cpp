@@ -1579,11 +1579,12 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
   pc.lap("c5 output files");
   write_wimp(mapped + ".EM.WIMP", T, fmap, readsPer, nTotal, nUnmapped, nTooShort);
   pc.lap("c6 WIMP");
-  coverage.write(mapped + ".EM.contigCoverage", T);
-  pc.lap("c7 contig coverage");
+  std::thread cov_thread([&] { coverage.write(mapped + ".EM.contigCoverage", T); });   // (the two side files only read what is there)
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } cov_join{cov_thread};
   if (!write_unknown_species(mapped + ".EM.evidenceUnknownSpecies", db, T, coverage, identsPerTaxon, maxReadLen, minReadsU))
     std::cerr << "Warning: " << db << "/contigNstats_windowSize_1000.txt not found - " << mapped << ".EM.evidenceUnknownSpecies is not written." << std::endl;
-  pc.lap("c8 evidence of unknown species");
+  cov_thread.join();
+  pc.lap("c8 evidence of unknown species + contig coverage");
   if (leave_now && !getenv("MM_CLI_FULL_TEARDOWN")) { emf.close(); r2t.close(); kr.close(); li.close(); pc.report(); leave_now(); finish_fast(); }   // (a GB of vectors and strings: nothing left to do with them)
   return 0;
 }

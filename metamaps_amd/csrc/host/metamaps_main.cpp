@@ -1612,7 +1612,12 @@ int main(int argc, char** argv) {
       for (auto& d : devs) if (mm_ctx_create(d.phys, &d.ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
       since("contexts created");
     });
-    const std::function<void()> need_devices = [&] { if (ctx_thread.joinable()) ctx_thread.join(); };
+    const std::function<void()> need_devices = [&] {
+      if (!ctx_thread.joinable()) return;
+      const auto w0 = std::chrono::steady_clock::now();
+      ctx_thread.join();
+      if (getenv("MM_CLI_TIMING")) std::cerr << "INFO, main: waited for the contexts " << std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() << " s\n";
+    };
     // an explicit --gpus 1 also goes through RCCL (one rank); --em-host-reduce: the ranks' sums are added on the host (test hook: ranks may share a device)
     const EmReduce reduce = o.em_host ? EmReduce::Host : ((devs.size() > 1 || o.v.count("gpus") || o.v.count("devices")) ? EmReduce::Rccl : EmReduce::None);
     const size_t minReadsU = o.v.count("minreads") ? std::stoull(o.v.at("minreads")) : 10000;   // parseCmdArgs.hpp:462-471

@@ -220,14 +220,17 @@ def test_em_resident_kernel_equals_its_phases_as_launches(n_reads, n_taxa, monke
         assert stopped and np.array_equal(np.concatenate([lls5, llsc]), lls) and np.array_equal(fc, f)
         return f, lls, best
 
-    f_a, ll_a, best_a = run({"MM_EM_RESIDENT": "1"})
+    G = {"MM_EM_GRID": "96"}                                      # (the two forms default to different grids; the log-likelihood is summed in the grid's shape)
+    f_a, ll_a, best_a = run({"MM_EM_RESIDENT": "1", **G})
     assert len(ll_a) >= 3 and abs(f_a.sum() - 1) < 1e-12
     if T > 4:
         assert f_a[1] == f_a[2] and f_a[1] > 0                    # the twins
-    f_b, ll_b, best_b = run({})                                   # the default: one launch per phase
+    f_b, ll_b, best_b = run(G)                                    # the default form: one launch per phase
     assert np.array_equal(f_a, f_b) and np.array_equal(ll_a, ll_b) and np.array_equal(best_a, best_b)
-    f_c, ll_c, best_c = run({"MM_EM_RESIDENT": "1", "MM_EM_BARRIER_TICKS": "1"})
+    f_c, ll_c, best_c = run({"MM_EM_RESIDENT": "1", "MM_EM_BARRIER_TICKS": "1", **G})
     assert np.array_equal(f_a, f_c) and np.array_equal(ll_a, ll_c)
+    f_0, ll_0, _ = run({})                                        # the default grid
+    assert len(ll_0) == len(ll_a) and np.allclose(ll_0, ll_a, rtol=1e-12, atol=0) and np.allclose(f_0, f_a, rtol=1e-10, atol=1e-300)
     f_d, ll_d, _ = run({"MM_EM_DBG": "3"})                        # P1 thread-per-read (the form blocks too large for the LDS buffers take): another summation order of ll only
     monkeypatch.delenv("MM_EM_DBG", raising=False)
     assert len(ll_d) == len(ll_a) and np.allclose(ll_d, ll_a, rtol=1e-12, atol=0) and np.allclose(f_d, f_a, rtol=1e-10, atol=1e-300)
@@ -247,7 +250,7 @@ def test_em_resident_kernel_equals_its_phases_as_launches(n_reads, n_taxa, monke
     e = ctx.em(off, taxon, mapq, inv, T)
     f_1, ll_1 = e.run(f0)
     e.close(); ctx.close()
-    assert np.array_equal(f_1, f_a) and np.array_equal(ll_1, ll_a)
+    assert np.array_equal(f_1, f_0) and np.array_equal(ll_1, ll_0)
     # against the host-driven loop (mm_em_iterate per iteration, numpy normalisation and stop rule)
     ctx = capi.Context(0)
     e = ctx.em(off, taxon, mapq, inv, T)

@@ -413,7 +413,9 @@ __device__ inline double em_p1_reads(const EmLoop& a, int64_t q0, int64_t q1) { 
 // Here the mappings are walked thread-per-MAPPING (coalesced), the likelihoods parked in LDS, the reads' sums taken from LDS in mapping order (the
 // reference's order, fEM.h:353-358), and the posteriors written in a second coalesced walk.  A block with more mappings or reads than the LDS
 // arrays hold takes the thread-per-read form.
-constexpr int EM_LBUF = 5120, EM_RBUF = 1536;                     // mappings / reads of a block that fit the LDS arrays
+// 5.5 KB of LDS + 2 KB for the reduction: a P1 workgroup fits beside the seed filter's resident workgroups (152 of a CU's 160 KB), so that the
+// EM of one worker context does not wait for the other context's K3 to leave the CUs (with 54 KB it did: 240-320 us per iteration in the bench)
+constexpr int EM_LBUF = 512, EM_RBUF = 192;                       // mappings / reads of a block that fit the LDS arrays
 __device__ inline void em_p1(const EmLoop& a, int wg, int n_wg, double* sh, double* lbuf, double* rsum) {
   const int tid = threadIdx.x;
   const int64_t rb = (a.n_reads + n_wg - 1) / n_wg, R0 = min((int64_t)wg * rb, a.n_reads), R1 = min(R0 + rb, a.n_reads);
@@ -497,16 +499,19 @@ __device__ inline void em_stop_rule(long long* ctrl, double ll, double* ll_trace
 // P3 (one workgroup).  LOCAL: the per-taxon sums and the log-likelihood of this rank go to local_partial[0..T] (all-reduced next);
 // otherwise: normalise over the present taxa, write f, evaluate the stop rule.
 template <bool LOCAL>
-__device__ inline void em_p3(const EmLoop& a, int n_wg, double* sh, double* s_item) {
+__device__ inline void em_p3(const EmLoop& a, int n_wg, double* sh) {
   const int tid = threadIdx.x;
-  // the item sums of a taxon are added in order by one thread: from LDS (P1's likelihood buffer, free by now), not one global round trip each
-  const bool staged = a.n_items <= EM_LBUF;
-  if (staged) { for (int it = tid; it < a.n_items; it += 256) s_item[it] = a.item_sum[it]; __syncthreads(); }
+  // the item sums of a taxon are added in order by one thread; their loads are independent: eight in flight per round trip
   for (int p = tid; p < a.n_present; p += 256) {
     double s = 0;
     const int i0 = a.pt_item[p], i1 = a.pt_item[p + 1];
-    if (staged) for (int it = i0; it < i1; ++it) s += s_item[it];
-    else for (int it = i0; it < i1; ++it) s += a.item_sum[it];
+    for (int it = i0; it < i1; it += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = a.item_sum[min(it + u, i1 - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (it + u < i1) s += v[u];
+    }
     a.local_partial[a.present[p]] = s;
   }
   __syncthreads();
@@ -590,7 +595,7 @@ __global__ void __launch_bounds__(256) em_loop_kernel(EmLoop a) {
     tick(7);
     ++epoch;
     if (grid_arrive_is_last(a.bar, epoch, n_wg, &s_flag)) {
-      em_p3<ONE_ITERATION>(a, n_wg, sh, lbuf);
+      em_p3<ONE_ITERATION>(a, n_wg, sh);
       if (ONE_ITERATION) return;
       grid_release(a.bar, epoch);
     } else {
@@ -604,7 +609,7 @@ __global__ void __launch_bounds__(256) em_loop_kernel(EmLoop a) {
 __global__ void __launch_bounds__(256) em_p1_kernel(EmLoop a) { __shared__ double sh[256], lbuf[EM_LBUF], rsum[EM_RBUF]; if (a.ctrl[1]) return; em_p1(a, blockIdx.x, gridDim.x, sh, lbuf, rsum); }
 __global__ void __launch_bounds__(256) em_p2_kernel(EmLoop a) { if (a.ctrl[1]) return; em_p2(a, blockIdx.x, gridDim.x); }
 template <bool LOCAL>
-__global__ void __launch_bounds__(256) em_p3_kernel(EmLoop a, int n_wg) { __shared__ double sh[256], s_item[EM_LBUF]; if (a.ctrl[1]) return; em_p3<LOCAL>(a, n_wg, sh, s_item); }
+__global__ void __launch_bounds__(256) em_p3_kernel(EmLoop a, int n_wg) { __shared__ double sh[256]; if (a.ctrl[1]) return; em_p3<LOCAL>(a, n_wg, sh); }
 // kernel B of a multi-rank iteration: normalise the all-reduced sums (fEM.h:606-615; fixed-shape sum over the taxa, the same on every
 // rank), log-likelihood trace, stop rule (:624-639)
 __global__ void __launch_bounds__(256) em_finalize_kernel(const double* __restrict__ partial, int32_t n_taxa, double* __restrict__ f, long long* __restrict__ ctrl,
@@ -629,9 +634,9 @@ __global__ void em_pos_kernel(const int64_t* __restrict__ perm, int64_t ne, int6
   if (j < ne) pos[perm[j]] = j;
 }
 static int em_grid(int64_t n_reads, int64_t n_entries) {         // (fixed per problem: the log-likelihood partials are summed in the grid's shape)
-  if (!getenv("MM_EM_GRID") && !getenv("MM_EM_RESIDENT")) {        // launches: as many blocks as keep a block within P1's LDS buffers (1 024 reads, 4 096 mappings), 256 at least
-    const int64_t want = std::max<int64_t>({(int64_t)256, ceil_div(std::max<int64_t>(n_reads, 1), 1024), ceil_div(std::max<int64_t>(n_entries, 1), 4096)});
-    return (int)std::max<int64_t>(1, std::min<int64_t>({want, (int64_t)8192, ceil_div(std::max<int64_t>(n_reads, 1), 256)}));
+  if (!getenv("MM_EM_GRID") && !getenv("MM_EM_RESIDENT")) {        // launches: as many blocks as keep a block within P1's LDS buffers (a little under EM_RBUF reads and EM_LBUF mappings on average), 256 at least
+    const int64_t want = std::max<int64_t>({(int64_t)256, ceil_div(std::max<int64_t>(n_reads, 1), EM_RBUF * 5 / 6), ceil_div(std::max<int64_t>(n_entries, 1), EM_LBUF * 7 / 8)});
+    return (int)std::max<int64_t>(1, std::min<int64_t>({want, (int64_t)1 << 20, std::max<int64_t>(n_reads, 1)}));
   }
   const char* e = getenv("MM_EM_GRID");                           // default: 256 workgroups as launches (33 us per iteration against 38 at 128), 128 for the resident kernel (all must be resident together)
   const int cap = std::min(std::max(e ? atoi(e) : (getenv("MM_EM_RESIDENT") ? 128 : 256), 1), 1024);

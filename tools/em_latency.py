@@ -31,7 +31,7 @@ def main():
     off, taxon, mapq, inv, T = problem(n_reads)
     print(f"{n_reads} reads, {len(taxon)} mappings, {T} taxa, largest taxon {np.bincount(taxon).max()} mappings")
     f0 = np.full(T, 1.0 / T)
-    variants = [("launch per phase (default)", {}), ("thread-per-read P1", {"MM_EM_DBG": "3"}), ("resident grid 128", {"MM_EM_RESIDENT": "1"}), ("resident grid 64", {"MM_EM_GRID": "64", "MM_EM_RESIDENT": "1"}), ("resident grid 256", {"MM_EM_GRID": "256", "MM_EM_RESIDENT": "1"}), ("launches, grid 256", {"MM_EM_GRID": "256"}), ("launches, grid 512", {"MM_EM_GRID": "512"}),
+    variants = [("launch per phase (default)", {}), ("thread-per-read P1", {"MM_EM_DBG": "3"}), ("resident grid 128", {"MM_EM_RESIDENT": "1"}), ("resident grid 64", {"MM_EM_GRID": "64", "MM_EM_RESIDENT": "1"}), ("resident grid 256", {"MM_EM_GRID": "256", "MM_EM_RESIDENT": "1"}), ("launches, grid 256", {"MM_EM_GRID": "256"}), ("launches, grid 1024", {"MM_EM_GRID": "1024"}),
                 ("collective, one rank", {"MM_EM_FORCE_COLLECTIVE": "1", "_comm": "1"}),
                 ("collective, kernel A resident", {"MM_EM_FORCE_COLLECTIVE": "1", "MM_EM_RESIDENT": "1", "_comm": "1"})]
     for name, env in variants:

@@ -1329,7 +1329,12 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
   // fEM.h:1171-1214, :234-373), lines of one read are consecutive (mapWrap.h:128-149), contig IDs are interned.
   // Round 4: read and tokenised by several threads — pieces of the file that begin on a read boundary are parsed on their own and joined in
   // file order (read offsets shifted, contig IDs interned in the order a single pass would meet them): 4.2 M lines took 1.3 s on one thread.
-  std::string text;
+  struct TextBuf {                                               // the file's bytes + a terminating 0, not zero-filled first (std::string::resize spent 0.1 s on that per 0.5 GB)
+    char* p = nullptr; size_t n = 0;
+    void resize(size_t k) { p = (char*)malloc(k + 1); if (!p) die("out of host memory for the mappings file"); n = k; p[k] = 0; }
+    size_t size() const { return n; } const char* c_str() const { return p; } char& operator[](size_t i) { return p[i]; }
+    ~TextBuf() { free(p); }
+  } text;
   const unsigned HW = std::max(1u, std::thread::hardware_concurrency());
   {
     const int fd = ::open(mapped.c_str(), O_RDONLY);
@@ -1514,7 +1519,7 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
       char num[64];
       for (size_t r = r0; r < r1; ++r) {                         // fEM.h:684-779
         for (size_t i = (size_t)off[r]; i < (size_t)off[r + 1]; ++i) {   // the line with field 14 replaced by std::to_string(posterior) (:705)
-          O.em.append(text, lines[i].beg, lines[i].last_space + 1 - lines[i].beg);
+          O.em.append(text.c_str() + lines[i].beg, lines[i].last_space + 1 - lines[i].beg);
           append_f6(O.em, post[i]);
           O.em += '\n';
         }
@@ -1524,8 +1529,8 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
         const size_t rid_end = (size_t)((const char*)memchr(text.c_str() + B.beg, ' ', B.end - B.beg) - text.c_str());
         O.li += "EqualCoverageUnit\t"; O.li += cg; O.li += '\t';
         snprintf(num, sizeof num, "%zu\t%g\t%lld\n", r, B.ident, B.len); O.li += num;                  // :711
-        O.r2.append(text, B.beg, rid_end - B.beg); O.r2 += '\t'; O.r2 += taxa[(size_t)taxon[b]]; O.r2 += '\n';
-        O.kr.append(text, B.beg, rid_end - B.beg); O.kr += '\t'; O.kr += tax_nonx[(size_t)taxon[b]];
+        O.r2.append(text.c_str() + B.beg, rid_end - B.beg); O.r2 += '\t'; O.r2 += taxa[(size_t)taxon[b]]; O.r2 += '\n';
+        O.kr.append(text.c_str() + B.beg, rid_end - B.beg); O.kr += '\t'; O.kr += tax_nonx[(size_t)taxon[b]];
         snprintf(num, sizeof num, "\t%g\n", post[b]); O.kr += num;
       }
     };

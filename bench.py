@@ -402,15 +402,15 @@ def main():
             },
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, dom_name),
-                         "note": "achieved = algorithmic bytes / hipEvent time of the launch pair with the GPU to itself (two steps right behind the timed region, mapping sections serialised; rocprofv3 of this bench with --serialise-map --workers 3 shows the same durations: profiles/r03_kernel_stats.txt).  In the timed region the kernels of two steps share the GPU, a launch waits for and runs beside the other step's kernels: *_timed_region, averaged over the distinct read batches (rocprofv3 of the default command: profiles/r03_kernel_stats_default_cmd.txt); traffic = "
-                                 "FETCH_SIZE x 2 + WRITE_SIZE of one launch pair on batch 0 (profiles/r03_pmc_hbm_traffic.txt): 3.5 x the algorithmic bytes, 4.5 TB/s "
+                         "note": "achieved = algorithmic bytes / hipEvent time of the launch pair with the GPU to itself (two steps right behind the timed region, mapping sections serialised; rocprofv3 of this bench with --serialise-map --workers 3 shows the same durations: profiles/r04_kernel_stats.txt).  In the timed region the kernels of two steps share the GPU, a launch waits for and runs beside the other step's kernels: *_timed_region, averaged over the distinct read batches (rocprofv3 of the default command: profiles/r04_kernel_stats_default_cmd.txt); traffic = "
+                                 "FETCH_SIZE x 2 + WRITE_SIZE of one launch pair on batch 0 (profiles/r04_pmc_hbm_traffic.txt): 3.5 x the algorithmic bytes, 4.5 TB/s "
                                  "of fetch while the kernel runs, 21 percent of its L2 requests hit (profiles/r03_l2_cache.txt); VALU in 88 percent of the issue "
                                  "slots (profiles/r03_sq_counters.txt).  seed_filter_stream_kernel: 45 percent VALU, bound by random requests per CU (DESIGN.md 4); "
                                  "minimizer_kernel 99 percent VALU",
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms,
                          # the same kernel pair with the GPU to itself (two untimed steps whose mapping sections hold the lock to their end: the
                          # hipEvents of the timed region also count the time a launch waits behind another worker's kernels, rocprofv3's
-                         # durations — profiles/r03_kernel_stats.txt — do not): what the kernel does, beside what the pipeline makes of it
+                         # durations — profiles/r04_kernel_stats.txt — do not): what the kernel does, beside what the pipeline makes of it
                          "alone": ({"ms_per_launch": R["st_clean"]["ms_l2"], "algorithmic_bytes_per_launch": 8.0 * R["st_clean"]["sum_l2_stream_entries"],
                                     "achieved": 8.0 * R["st_clean"]["sum_l2_stream_entries"] / (R["st_clean"]["ms_l2"] * 1e-3) / 1e9,
                                     "frac": 8.0 * R["st_clean"]["sum_l2_stream_entries"] / (R["st_clean"]["ms_l2"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -420,7 +420,7 @@ def main():
         }
         # A roofline figure is a statement about a kernel: achieved / frac / ms_per_launch are those of the launches that had the GPU to
         # themselves (HIP events on the worker's stream, two steps right behind the timed region with the mapping sections serialised: the
-        # durations profiles/r03_kernel_stats.txt shows).  What the same launches take while they share the GPU with the other worker's
+        # durations profiles/r04_kernel_stats.txt shows).  What the same launches take while they share the GPU with the other worker's
         # step — inside the timed region, the default scheduling — stays beside it as *_timed_region.
         rl = out["roofline"]
         if rl.get("alone"):
@@ -792,7 +792,7 @@ def cpu_baseline_and_cli(args, R, k, w):
         pc = subprocess.run([cli, "classify", "--DB", db["dir"], "--mappings", os.path.join(d, "gpuall")], capture_output=True, check=True, timeout=900, env=env)
         t_cli_cls = time.time() - t0
         cls_phases = {ln.split()[2] + " " + " ".join(ln.split()[3:-2]): float(ln.split()[-2]) for ln in pc.stderr.decode().splitlines() if ln.startswith("INFO, time c")}
-        cls_phases.update({"main: " + ln.split(" at +")[0][12:]: float(ln.split(" at +")[1].split()[0]) for ln in pc.stderr.decode().splitlines() if ln.startswith("INFO, main: ")})
+        cls_phases.update({"main: " + ln.split(" at +")[0][12:]: float(ln.split(" at +")[1].split()[0]) for ln in pc.stderr.decode().splitlines() if ln.startswith("INFO, main: ") and " at +" in ln})
         e2e = {"value": bases_all / max(t_map_all - t_setup + t_cli_cls, 1e-9) / 1e9, "unit": "Gbp/s",
                "what": "metamaps mapDirectly (reads FASTQ -> PREFIX, .meta) + metamaps classify (-> .EM.*), wall clock of the two processes minus "
                        "context + reference parse + index build, on every bench read that stems from the cpu_baseline's reference slice",
@@ -924,7 +924,7 @@ def e2e_cli_full(args, k, w, rank_seed):
         t_setup = laps.get("3 index build", 0.0)                 # context + reference parse/pack/upload + index build
         out2, err2, t_cls, rss_cls = _run_cli_with_rss([cli, "classify", "--DB", db, "--mappings", pre], env, 1500)
         cls_phases = {ln.split()[2] + " " + " ".join(ln.split()[3:-2]): float(ln.split()[-2]) for ln in err2.splitlines() if ln.startswith("INFO, time c")}
-        cls_main = {ln.split(" at +")[0][12:]: float(ln.split(" at +")[1].split()[0]) for ln in err2.splitlines() if ln.startswith("INFO, main: ")}
+        cls_main = {ln.split(" at +")[0][12:]: float(ln.split(" at +")[1].split()[0]) for ln in err2.splitlines() if ln.startswith("INFO, main: ") and " at +" in ln}
         par = dict(l.split(" ", 1) for l in open(pre + ".parameters").read().splitlines() if " " in l)
         meta = dict(l.split() for l in open(pre + ".meta"))
         # measurement aid: the single-batch mapDirectly again under other environments / flags ("name:KEY=VAL KEY2=VAL2 --flag value;name2:...")
@@ -964,7 +964,7 @@ def e2e_cli_full(args, k, w, rank_seed):
                                 "same_file": open(pre_s).read() == open(pre_s + "_w" + wv).read()}
                 os.remove(pre_s + "_w" + wv)
             cph = {ln.split()[2] + " " + " ".join(ln.split()[3:-2]): float(ln.split()[-2]) for ln in e_c.splitlines() if ln.startswith("INFO, time c")}
-            cmain = {ln.split(" at +")[0][12:]: float(ln.split(" at +")[1].split()[0]) for ln in e_c.splitlines() if ln.startswith("INFO, main: ")}
+            cmain = {ln.split(" at +")[0][12:]: float(ln.split(" at +")[1].split()[0]) for ln in e_c.splitlines() if ln.startswith("INFO, main: ") and " at +" in ln}
             t_phase_s = max(laps_s.get("8 write", t_map_s) - laps_s.get("3 index build", 0.0), 1e-9)
             # the process without what it WAITED for its contexts (they come up beside the parsing of the mappings file; right behind a mapDirectly
             # that has just given 150 GB back, the driver lets the next process' HIP initialisation wait up to 2 s: not classify's work)

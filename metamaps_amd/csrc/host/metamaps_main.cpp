@@ -170,14 +170,18 @@ template <typename F> void on_each(size_t n, F&& fn) {           // fn(i) for i 
   for (auto& t : th) t.join();
 }
 
-std::vector<int> device_list(const Options& o) {                 // --gpus N: devices 0..N-1; --devices a,b,..: explicit (a device may repeat: test hook)
+void check_devices(const std::vector<int>& phys) {                // (the first HIP call of the process: the runtime comes up here)
+  const int n = mm_device_count();
+  if (n <= 0) die("No MI355X (gfx950) device available — this build has no CPU path");
+  for (int p : phys) if (p < 0 || p >= n) die("device " + std::to_string(p) + " requested but only " + std::to_string(n) + " visible");
+}
+
+std::vector<int> device_list(const Options& o, bool check = true) {   // --gpus N: devices 0..N-1; --devices a,b,..: explicit (a device may repeat: test hook)
   std::vector<int> phys;
   if (o.v.count("devices")) for (auto& s : split(o.v.at("devices"), ",")) phys.push_back(std::stoi(s));
   else { const int g = o.v.count("gpus") ? std::stoi(o.v.at("gpus")) : 1; for (int i = 0; i < g; ++i) phys.push_back(i); }
   if (phys.empty()) die("--gpus must be at least 1");
-  const int n = mm_device_count();
-  if (n <= 0) die("No MI355X (gfx950) device available — this build has no CPU path");
-  for (int p : phys) if (p < 0 || p >= n) die("device " + std::to_string(p) + " requested but only " + std::to_string(n) + " visible");
+  if (check) check_devices(phys);
   return phys;
 }
 
@@ -1611,9 +1615,12 @@ int main(int argc, char** argv) {
     const auto m0 = std::chrono::steady_clock::now();
     auto since = [&](const char* what) { if (getenv("MM_CLI_TIMING")) std::cerr << "INFO, main: " << what << " at +" << std::chrono::duration<double>(std::chrono::steady_clock::now() - m0).count() << " s\n"; };
     std::vector<Dev> devs;
-    for (int p : device_list(o)) { Dev d; d.phys = p; devs.push_back(d); }
-    // the contexts (HIP initialisation: ~0.1 s) come up on a thread of their own while the mappings file is read and tokenised
+    for (int p : device_list(o, false)) { Dev d; d.phys = p; devs.push_back(d); }
+    // the HIP runtime and the contexts (0.1 s; up to 2 s right behind a process that gave 150 GB back) come up on a thread of their own while the
+    // mappings file is read and tokenised
     std::thread ctx_thread([&] {
+      std::vector<int> phys; for (auto& d : devs) phys.push_back(d.phys);
+      check_devices(phys);
       for (auto& d : devs) if (mm_ctx_create(d.phys, &d.ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
       since("contexts created");
     });

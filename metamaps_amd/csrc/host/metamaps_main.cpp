@@ -30,6 +30,7 @@
 #include "../../../include/metamaps_hip.h"
 #include "seq_reader.hpp"
 #include "host_util.hpp"
+#include "id_set.hpp"
 #include "fast_format.hpp"
 #include <sys/mman.h>
 #include <fcntl.h>
@@ -780,7 +781,7 @@ int map_mode(const Options& o, const std::string& mode) {
       const std::string& prefix = prefixes[fi];
       std::ofstream out(prefix), unm(prefix + ".meta.unmappedReadsLengths");
       if (!out.is_open()) die("Cannot open output file " + prefix);
-      size_t total = 0, tooShort = 0, mapped = 0, notMapped = 0; std::set<std::string> seen;
+      size_t total = 0, tooShort = 0, mapped = 0, notMapped = 0; IdSet seen;   // (id_set.hpp: a std::set of 10^6 IDs bounded the mapping phase)
       for (;;) {
         std::unique_ptr<Done> d = next(fi, seq);
         if (!d) break;
@@ -793,7 +794,7 @@ int map_mode(const Options& o, const std::string& mode) {
           // mapWrap.h:71-75 checks the IDs of mapping LINES against the reads already handled: a repeated ID only stops the run
           // when the repeat carries mappings; every handled read's ID is remembered (:154-157)
           if (d->off[r] == d->off[r + 1]) { ++notMapped; unm << len << "\t" << d->names[r] << "\n"; seen.insert(d->names[r]); continue; }
-          if (!seen.insert(d->names[r]).second) die("Seems that read ID " + d->names[r] + " has already been processed");
+          if (!seen.insert(d->names[r])) die("Seems that read ID " + d->names[r] + " has already been processed");
           ++mapped;
         }
         out << d->text;

@@ -957,7 +957,12 @@ def e2e_cli_full(args, k, w, rank_seed):
                 open(os.path.join(os.environ["MM_BENCH_E2E_LOG"], "cli_stream_classify.err"), "w").write(e_c)
             variants = {}
             for wv in [x for x in os.environ.get("MM_BENCH_E2E_WORKER_SWEEP", "").split(",") if x]:   # the mapping phase again with other numbers of worker contexts per device
-                _o3, e_v, t_v, _r = _run_cli_with_rss([cli, "mapDirectly", "--all", "-r", fasta, "-q", fq_s, "-o", pre_s + "_w" + wv, "--workers-per-gpu", wv], env, 1500)
+                env_v = dict(env)                                  # "W" or "W@S": W worker contexts per device, S of them inside their mapping section at a time
+                if "@" in wv:
+                    env_v["MM_CLI_MAP_SLOTS"] = wv.split("@")[1]
+                if wv.count("@") > 1:                              # "W@S@B": batches of up to B Mbases
+                    env_v["MM_CLI_BATCH_MBASES"] = wv.split("@")[2]
+                _o3, e_v, t_v, _r = _run_cli_with_rss([cli, "mapDirectly", "--all", "-r", fasta, "-q", fq_s, "-o", pre_s + "_w" + wv, "--workers-per-gpu", wv.split("@")[0]], env_v, 1500)
                 lv = {ln.split(" at +")[0][len("INFO, lap "):]: float(ln.split(" at +")[1].split()[0]) for ln in e_v.splitlines() if ln.startswith("INFO, lap ")}
                 pv = {" ".join(ln.split()[2:-2]): float(ln.split()[-2]) for ln in e_v.splitlines() if ln.startswith("INFO, time ")}
                 variants[wv] = {"mapping_phase_s": round(lv.get("8 write", t_v) - lv.get("3 index build", 0.0), 3), "phases": pv,

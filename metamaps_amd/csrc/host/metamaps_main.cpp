@@ -611,7 +611,8 @@ int map_mode(const Options& o, const std::string& mode) {
   }
   // ---- reads (computeMap.hpp:104-172 + unifyFiles mapWrap.h:34-213)
   // ~0.25 Gbp per device batch (16 ms of mapping); the next ones are parsed meanwhile.  (MM_CLI_BATCH_READS: test hook, small batches)
-  const int64_t BATCH_READS = getenv("MM_CLI_BATCH_READS") ? std::max(1, atoi(getenv("MM_CLI_BATCH_READS"))) : 100000, BATCH_BASES = 256000000LL;
+  const int64_t BATCH_READS = getenv("MM_CLI_BATCH_READS") ? std::max(1, atoi(getenv("MM_CLI_BATCH_READS"))) : 100000,
+                BATCH_BASES = getenv("MM_CLI_BATCH_MBASES") ? (int64_t)std::max(1, atoi(getenv("MM_CLI_BATCH_MBASES"))) * 1000000LL : 256000000LL;
   const mm_map_params mp{k, w, pi, minLen};
   std::vector<int32_t> chunk_base; for (auto& ch : chunks) chunk_base.push_back(ch.first);
   // a reader thread parses the query files into batches (bounded queue); `take` hands them out in order, nullptr at the end
@@ -813,6 +814,16 @@ int map_mode(const Options& o, const std::string& mode) {
     // kernels of the other; the device's chunk indexes are shared (read-only) by its contexts
     const size_t WPD = o.v.count("workers-per-gpu") ? (size_t)std::max(1, std::stoi(o.v.at("workers-per-gpu")))
                      : getenv("MM_CLI_WORKERS") ? (size_t)std::max(1, atoi(getenv("MM_CLI_WORKERS"))) : 4;
+    // The kernels of a batch fill the device; batches mapped side by side only take turns on it, and four workers that start together
+    // then also finish together: they packed, fetched and formatted at the same time with the device idle, and mapped at the same time
+    // in each other's way (the done-times of the workers came in groups of four, 60 ms apart).  So at most MAP_SLOTS batches per device are
+    // inside their mapping section at a time (two: one fills the host-side gaps of the other), which staggers the workers.
+    const size_t MAP_SLOTS = getenv("MM_CLI_MAP_SLOTS") ? (size_t)std::max(1, atoi(getenv("MM_CLI_MAP_SLOTS"))) : 2;
+    struct Slots { std::mutex m; std::condition_variable cv; size_t free_ = 0;
+                   void acquire() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return free_ > 0; }); --free_; }
+                   void release() { { std::lock_guard<std::mutex> lk(m); ++free_; } cv.notify_one(); } };
+    std::vector<Slots> map_slots(G);
+    for (auto& sl : map_slots) sl.free_ = MAP_SLOTS;
     std::vector<std::thread> workers;
     for (size_t d = 0; d < G; ++d) for (size_t wi = 0; wi < WPD; ++wi) workers.emplace_back([&, d, wi]() {
       mm_ctx* ctx = devs[d].ctx;
@@ -822,7 +833,10 @@ int map_mode(const Options& o, const std::string& mode) {
         mm_seqset* reads = upload_batch(ctx, *bt);
         const auto t1 = std::chrono::steady_clock::now();
         std::vector<mm_mapping*> parts;
+        map_slots[d].acquire();
+        const auto t1a = std::chrono::steady_clock::now();
         for (size_t c = 0; c < NC; ++c) parts.push_back(map_chunk(ctx, devs[d].idx[c], reads, c ? parts[0] : nullptr));
+        map_slots[d].release();
         mm_mapping* m = parts[0];
         if (parts.size() > 1) {                                   // unifyFiles: read-wise concatenation in chunk order
           ck(ctx, mm_mapping_concat(ctx, parts.data(), chunk_base.data(), (int)parts.size(), &m), "merge chunks");
@@ -834,10 +848,11 @@ int map_mode(const Options& o, const std::string& mode) {
         auto dn = finish_mapping(ctx, m, std::move(bt->names), std::move(bt->lens), bt->file);
         const auto t3 = std::chrono::steady_clock::now();
         pc.add("5 reads pack+upload", std::chrono::duration<double>(t1 - t0).count());
-        pc.add("6 map", std::chrono::duration<double>(t2 - t1).count());
+        pc.add("6 map", std::chrono::duration<double>(t2 - t1a).count());
+        pc.add("6a waited for the device", std::chrono::duration<double>(t1a - t1).count());
         pc.add("7 mapq+fetch+format", std::chrono::duration<double>(t3 - t2).count());
         if (getenv("MM_CLI_TIMING")) { std::ostringstream os; os << "INFO, worker " << d << "." << wi << " batch " << seq << ": upload " << std::chrono::duration<double>(t1 - t0).count() << " map "
-          << std::chrono::duration<double>(t2 - t1).count() << " finish " << std::chrono::duration<double>(t3 - t2).count() << " done at +" << std::chrono::duration<double>(t3 - pc.t0).count() << " s\n"; std::cerr << os.str(); }
+          << std::chrono::duration<double>(t2 - t1a).count() << " (waited " << std::chrono::duration<double>(t1a - t1).count() << ") finish " << std::chrono::duration<double>(t3 - t2).count() << " done at +" << std::chrono::duration<double>(t3 - pc.t0).count() << " s\n"; std::cerr << os.str(); }
         reader.recycle(std::move(bt));
         writer.put(seq, std::move(dn));
       }

@@ -5,6 +5,7 @@
 #include "mm_em.hpp"
 #include "mm_stats.hpp"
 #include "mm_synth.hpp"
+#include <chrono>
 #include <new>
 #include <rccl/rccl.h>
 #include <rocprim/rocprim.hpp>
@@ -36,9 +37,25 @@ extern "C" {
 
 int mm_abi_version(void) { return MM_ABI_VERSION; }
 
+namespace {
+// MM_CTX_TRACE=1: what the process' first HIP calls cost (right behind a process that gave back a device-filling index they wait for the driver)
+struct CtxTrace {
+  const bool on = getenv("MM_CTX_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char* what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "MM_CTX_TRACE %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+}  // namespace
+
 int mm_device_count(void) {
   int n = 0;
+  CtxTrace tr;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  tr.lap("hipGetDeviceCount");
   return n;
 }
 int mm_ctx_create(int device_id, mm_ctx** out) {
@@ -51,13 +68,18 @@ int mm_ctx_create(int device_id, mm_ctx** out) {
   if (!c) return MM_ERR_NOMEM;
   c->device = device_id;
   int st = guarded(c, [&] {
+    CtxTrace tr;
     MM_HIP(hipSetDevice(device_id));
+    tr.lap("hipSetDevice");
     hipDeviceProp_t p;
     MM_HIP(hipGetDeviceProperties(&p, device_id));
+    tr.lap("hipGetDeviceProperties");
     MM_REQUIRE(std::string(p.gcnArchName).rfind("gfx950", 0) == 0, MM_ERR_DEVICE,
                std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
     c->cus = p.multiProcessorCount;
     MM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    tr.lap("hipStreamCreateWithFlags");
+    if (tr.on) { void* q = nullptr; if (hipMalloc(&q, 1 << 20) == hipSuccess) { tr.lap("first hipMalloc (1 MiB)"); (void)hipFree(q); } }
     c->alloc.stream = c->stream;
     mm::alloc_register(&c->alloc, c->device);
   });

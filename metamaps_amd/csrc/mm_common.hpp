@@ -17,6 +17,7 @@
 #include <atomic>
 #include <algorithm>
 #include "../../include/metamaps_hip.h"
+#include "mm_slab.hpp"
 
 namespace mm {
 
@@ -63,7 +64,13 @@ inline hipError_t dev_malloc(void** p, size_t bytes) {
   if (e == hipSuccess) m.used[d] += (long long)bytes;
   return e;
 }
-inline void dev_free(void* p, size_t bytes) { if (!p) return; dev_meter().used[dev_current()] -= (long long)bytes; (void)hipFree(p); }
+// (SlabSet: mm_slab.hpp)
+inline SlabSet& slab_set() { static SlabSet s; return s; }
+inline void dev_free(void* p, size_t bytes) {
+  if (!p) return;
+  if (slab_set().give_back(p, bytes)) return;                    // (a piece of a pooled block: the block stays the device's)
+  dev_meter().used[dev_current()] -= (long long)bytes; (void)hipFree(p);
+}
 inline hipError_t dev_mem_info(size_t* fr, size_t* tot) {
   const hipError_t e = hipMemGetInfo(fr, tot);
   DevMeter& m = dev_meter();
@@ -83,6 +90,8 @@ struct DevAlloc;
 void alloc_register(DevAlloc* a, int device);
 void alloc_unregister(DevAlloc* a);
 void alloc_trim_others(DevAlloc* self, int device);
+constexpr size_t SLAB_FROM_BYTES = (size_t)1 << 20;             // smaller requests stay with the driver (they come from its own small pools, quickly)
+void* slab_piece(int device, size_t bytes);                      // a piece of a pooled index-scale block of the device, or nullptr (defined behind BigPool)
 struct DevAlloc {
   hipStream_t stream = nullptr;
   int device = -1;                           // set by alloc_register
@@ -91,6 +100,7 @@ struct DevAlloc {
   // and index-scale blocks go straight to and from the driver, so that the build's memory is returned WHILE it runs.  Returned in one
   // piece afterwards (~100 GB), it came back as a 1 s stall of a mapping step a few seconds later, twice in four bench runs (round 3).
   bool eager = false;
+  bool in_build = false;                     // an index build runs on this context: its temporaries do not cut into pooled blocks the build itself is about to ask for
   std::multimap<size_t, void*> cache;        // size -> free block
   size_t cached_bytes = 0;
   static size_t round_up(size_t b) {
@@ -143,12 +153,16 @@ struct DevAlloc {
     }
     void* p = nullptr;
     static const bool trace = getenv("MM_ALLOC_TRACE") != nullptr;     // every block that comes from the driver, with its cost
+    static const bool use_slabs = getenv("MM_NO_SLABS") == nullptr;
+    if (use_slabs && !eager && !in_build && want >= SLAB_FROM_BYTES) {
+      if (void* q = slab_piece(device, ask)) { *got = SlabSet::granules(ask); if (trace) fprintf(stderr, "MM_ALLOC_TRACE slab piece %zu bytes\n", *got); return q; }
+    }
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = refuse ? hipErrorOutOfMemory : dev_malloc(&p, ask);
     size_t granted = ask;
     if (trace) fprintf(stderr, "MM_ALLOC_TRACE hipMalloc %zu bytes %.3f ms\n", ask, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (e == hipErrorOutOfMemory) {
-      (void)hipGetLastError(); trim(); int dv = 0; (void)hipGetDevice(&dv); big_pool_trim(dv); alloc_trim_others(this, dv); granted = want;
+      (void)hipGetLastError(); trim(); int dv = 0; (void)hipGetDevice(&dv); alloc_trim_others(this, dv); big_pool_trim(dv); granted = want;   // (the caches first: their pieces of pooled blocks go back to the blocks)
       size_t fr = 0, tot = 0;
       if (refuse && dev_mem_info(&fr, &tot) == hipSuccess && fr < want + RUNTIME_RESERVE) e = hipErrorOutOfMemory;   // still not there with every cache given back
       else e = dev_malloc(&p, want);
@@ -187,11 +201,29 @@ struct BigPool {
     void* p = it->second; *got = it->first; bytes -= it->first; free_.erase(it);
     return p;
   }
+  void* take_at_least(size_t want, size_t* got) {               // the smallest pooled block that holds `want` (for a slab)
+    std::lock_guard<std::mutex> lk(m);
+    auto it = free_.lower_bound(want);
+    if (it == free_.end()) return nullptr;
+    void* p = it->second; *got = it->first; bytes -= it->first; free_.erase(it);
+    return p;
+  }
   void give(void* p, size_t sz) { std::lock_guard<std::mutex> lk(m); free_.emplace(sz, p); bytes += sz; }
   void trim() { std::lock_guard<std::mutex> lk(m); for (auto& kv : free_) dev_free(kv.second, kv.first); free_.clear(); bytes = 0; }
 };
 inline BigPool& big_pool(int device) { static BigPool pools[64]; return pools[device < 0 || device >= 64 ? 0 : device]; }
-inline void big_pool_trim(int device) { big_pool(device).trim(); }
+inline void big_pool_trim(int device) {                          // (slabs nothing is cut from any more are pooled blocks again, and go with the rest)
+  for (auto& sl : slab_set().take_idle(device)) big_pool(device).give(sl.first, sl.second);
+  big_pool(device).trim();
+}
+inline void* slab_piece(int device, size_t bytes) {
+  if (void* p = slab_set().alloc(device, bytes)) return p;
+  size_t got = 0;
+  void* blk = big_pool(device).take_at_least(SlabSet::granules(bytes), &got);
+  if (!blk) return nullptr;
+  slab_set().adopt(device, blk, got);
+  return slab_set().alloc(device, bytes);
+}
 inline DevAlloc*& current_alloc() { static thread_local DevAlloc* a = nullptr; return a; }
 inline hipStream_t& current_stream() { static thread_local hipStream_t s = nullptr; return s; }
 constexpr size_t DIRECT_ALLOC_BYTES = (size_t)8 << 30;
@@ -237,7 +269,7 @@ struct DBuf {
       block = 0; big_bytes = 0;                                  // take() only matches requests within an eighth of a block's size: small blocks would pile up there)
       (void)hipGetDevice(&big_dev);
       hipError_t e = dev_malloc((void**)&p, bytes);
-      if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); big_pool(big_dev).trim(); alloc_trim_others(nullptr, big_dev); e = dev_malloc((void**)&p, bytes); }
+      if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); alloc_trim_others(nullptr, big_dev); big_pool_trim(big_dev); e = dev_malloc((void**)&p, bytes); }
       if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; n = 0; throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, mm::oom_text(bytes, e)); }
       return;
     }
@@ -256,7 +288,7 @@ struct DBuf {
       if (!p) {
         big_bytes = bytes;
         hipError_t e = dev_malloc((void**)&p, bytes);
-        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); bp.trim(); if (owner) owner->trim(); alloc_trim_others(owner, big_dev); e = dev_malloc((void**)&p, bytes); }
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); if (owner) owner->trim(); alloc_trim_others(owner, big_dev); big_pool_trim(big_dev); e = dev_malloc((void**)&p, bytes); }
         if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; n = 0; throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, mm::oom_text(bytes, e)); }
         if (trace) fprintf(stderr, "MM_ALLOC_TRACE direct hipMalloc %zu bytes %.3f ms\n", bytes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       } else if (trace) fprintf(stderr, "MM_ALLOC_TRACE big block of %zu bytes reused for %zu\n", big_bytes, bytes);

@@ -247,7 +247,8 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   // earlier work stay and serve this build (0.15 s per 13 GB chunk instead of 1-6 s through the driver), an allocation that fails for
   // lack of memory trims the caches itself.  An index that takes a good part of the device: memory goes back to the driver as the build
   // proceeds (DevAlloc::eager), nothing is left cached beside it.
-  struct EagerGuard { DevAlloc& a; bool was; ~EagerGuard() { a.eager = was; } } eager_guard{ctx->alloc, ctx->alloc.eager};
+  struct EagerGuard { DevAlloc& a; bool was, was_build; ~EagerGuard() { a.eager = was; a.in_build = was_build; } } eager_guard{ctx->alloc, ctx->alloc.eager, ctx->alloc.in_build};
+  ctx->alloc.in_build = true;
   { size_t fr = 0, tot = 0;
     if (dev_mem_info(&fr, &tot) == hipSuccess && (double)contigs->total_bases * 5.5 > (double)tot / 4) { ctx->alloc.eager = true; if (!getenv("MM_INDEX_NO_PRETRIM")) { ctx->alloc.trim(); big_pool_trim(ctx->device); } } }
   I->ctx = ctx; I->k = k; I->w = w;

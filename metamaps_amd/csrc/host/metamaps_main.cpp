@@ -32,6 +32,7 @@
 #include "host_util.hpp"
 #include "id_set.hpp"
 #include "fast_format.hpp"
+#include "huge_new.hpp"
 #include <sys/mman.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -187,16 +188,25 @@ std::vector<int> device_list(const Options& o, bool check = true) {   // --gpus 
 }
 
 // records of one batch -> the text of PREFIX (computeMap.hpp:565-581 + the two fields of mapWrap.h:311-320), reads in order
+// fields 10 and 13 of a mapping line are functions of (conserved sketches, sketch size) alone: formatted once per pair and kept.  The table belongs
+// to the CALLER (one per formatting slot of a worker thread) and lives as long as that thread: the pool threads of format_records are new with every
+// batch, and a table that was theirs (thread_local) was rebuilt — 0.8 MB cleared, every pair formatted again — by every one of them for every batch:
+// 19 ms per batch of 85 000 lines, the whole of a worker's "finish" time.
+struct FormatCache {
+  struct Pair { uint64_t key; char ids[16], corr[16]; uint8_t n_ids, n_corr; };
+  static constexpr size_t CB = 1 << 14;
+  std::vector<Pair> slots; int k = -1;
+  void prepare(int k_now) { if (slots.size() != CB || k != k_now) { slots.assign(CB, Pair{~0ull, {0}, {0}, 0, 0}); k = k_now; } }
+};
 static void format_range(const std::vector<std::string>& names, const std::vector<int>& lens, const std::vector<int64_t>& off,
-                         const std::vector<mm_map_record>& rec, const std::vector<std::string>& cname, const std::vector<int>& clen, int k, size_t r0, size_t r1, std::string& out) {
+                         const std::vector<mm_map_record>& rec, const std::vector<std::string>& cname, const std::vector<int>& clen, int k, size_t r0, size_t r1, std::string& out,
+                         FormatCache& fc) {
   out.clear();
   out.reserve((size_t)(off[r1] - off[r0]) * 160);
-  // fields 10 and 13 are functions of (conserved sketches, sketch size) alone: formatted once per pair and thread (a few thousand pairs cover a
-  // batch); no printf anywhere on the line (fast_format.hpp) — 4.2 M lines took 2 s of the mapping phase of a million reads
-  struct Pair { uint64_t key; char ids[16], corr[16]; uint8_t n_ids, n_corr; };
-  static thread_local std::vector<Pair> cache; static thread_local int cache_k = -1;
-  constexpr size_t CB = 1 << 14;
-  if (cache.size() != CB || cache_k != k) { cache.assign(CB, Pair{~0ull, {0}, {0}, 0, 0}); cache_k = k; }
+  // no printf anywhere on the line (fast_format.hpp) — 4.2 M lines took 2 s of the mapping phase of a million reads
+  using Pair = FormatCache::Pair;
+  fc.prepare(k);
+  std::vector<Pair>& cache = fc.slots;
   std::string tmp;
   for (size_t r = r0; r < r1; ++r) {
     const int len = lens[r];
@@ -231,19 +241,22 @@ static void format_range(const std::vector<std::string>& names, const std::vecto
 void format_records(const std::vector<std::string>& names, const std::vector<int>& lens, const std::vector<int64_t>& off,
                     const std::vector<mm_map_record>& rec, const std::vector<std::string>& cname, const std::vector<int>& clen, int k, std::string& out) {
   const size_t n = names.size();
-  const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 8), rec.size() / 30000 + 1}));
-  if (T == 1) { format_range(names, lens, off, rec, cname, clen, k, 0, n, out); return; }
+  const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 8), rec.size() / 10000 + 1}));
+  static thread_local std::vector<FormatCache> caches(8);          // (the calling thread's: a worker of mapDirectly formats batch after batch)
+  if (T == 1) { format_range(names, lens, off, rec, cname, clen, k, 0, n, out, caches[0]); return; }
   std::vector<size_t> cut(T + 1, n);
   cut[0] = 0;
   { size_t t = 1; for (size_t r = 0; r < n && t < T; ++r) if ((uint64_t)off[r] >= (uint64_t)rec.size() * t / T) cut[t++] = r; }
-  std::vector<std::string> part(T);
+  static thread_local std::vector<std::string> part_store(8);      // (kept with their capacity: fresh text buffers are page faults, batch after batch)
+  std::vector<std::string>& part = part_store;
   std::vector<std::thread> pool;
-  for (size_t t = 1; t < T; ++t) pool.emplace_back([&, t] { format_range(names, lens, off, rec, cname, clen, k, cut[t], cut[t + 1], part[t]); });
-  format_range(names, lens, off, rec, cname, clen, k, cut[0], cut[1], part[0]);
+  FormatCache* const fcs = caches.data();
+  for (size_t t = 1; t < T; ++t) pool.emplace_back([&, t] { format_range(names, lens, off, rec, cname, clen, k, cut[t], cut[t + 1], part[t], fcs[t]); });
+  format_range(names, lens, off, rec, cname, clen, k, cut[0], cut[1], part[0], fcs[0]);
   for (auto& th : pool) th.join();
-  size_t total = 0; for (auto& p_ : part) total += p_.size();
+  size_t total = 0; for (size_t t = 0; t < T; ++t) total += part[t].size();
   out.clear(); out.reserve(total);
-  for (auto& p_ : part) out += p_;
+  for (size_t t = 0; t < T; ++t) out += part[t];
 }
 
 int map_mode(const Options& o, const std::string& mode) {
@@ -762,13 +775,20 @@ int map_mode(const Options& o, const std::string& mode) {
   auto finish_mapping = [&](mm_ctx* ctx, mm_mapping* m, std::vector<std::string>&& names, std::vector<int>&& lens, size_t file) {   // mapping qualities + text; consumes m
     auto dn = std::make_unique<Done>();
     dn->file = file; dn->names = std::move(names); dn->lens = std::move(lens);
+    const auto f0 = std::chrono::steady_clock::now();
     ck(ctx, mm_mapping_add_qualities(ctx, m, nullptr, k), "mapping qualities");
     dn->off.resize(dn->names.size() + 1);
     ck(ctx, mm_mapping_fetch(m, dn->off.data(), nullptr, 0), "fetch");
+    const auto f1 = std::chrono::steady_clock::now();
     std::vector<mm_map_record> rec((size_t)dn->off.back());
     ck(ctx, mm_mapping_fetch(m, dn->off.data(), rec.data(), (int64_t)rec.size()), "fetch");
     mm_mapping_destroy(m);
+    const auto f2 = std::chrono::steady_clock::now();
     format_records(dn->names, dn->lens, dn->off, rec, cname, clen, k, dn->text);
+    const auto f3 = std::chrono::steady_clock::now();
+    pc.add("7a mapping qualities + offsets", std::chrono::duration<double>(f1 - f0).count());
+    pc.add("7b fetch records", std::chrono::duration<double>(f2 - f1).count());
+    pc.add("7c format", std::chrono::duration<double>(f3 - f2).count());
     return dn;
   };
   // the writer: batches in input order -> PREFIX, .meta.unmappedReadsLengths, .meta, .parameters of every query file (mapWrap.h:34-213)
@@ -1351,9 +1371,9 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
   // file order (read offsets shifted, contig IDs interned in the order a single pass would meet them): 4.2 M lines took 1.3 s on one thread.
   struct TextBuf {                                               // the file's bytes + a terminating 0, not zero-filled first (std::string::resize spent 0.1 s on that per 0.5 GB)
     char* p = nullptr; size_t n = 0;
-    void resize(size_t k) { p = (char*)malloc(k + 1); if (!p) die("out of host memory for the mappings file"); n = k; p[k] = 0; }
+    void resize(size_t k) { p = new (std::nothrow) char[k + 1]; if (!p) die("out of host memory for the mappings file"); n = k; p[k] = 0; }   // (huge_new.hpp: on huge pages)
     size_t size() const { return n; } const char* c_str() const { return p; } char& operator[](size_t i) { return p[i]; }
-    ~TextBuf() { free(p); }
+    ~TextBuf() { delete[] p; }
   } text;
   const unsigned HW = std::max(1u, std::thread::hardware_concurrency());
   {

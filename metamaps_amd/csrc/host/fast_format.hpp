@@ -4,6 +4,7 @@
 // that rounding is only trusted when the product is further from a tie than any such error could reach; everything else (ties, huge or tiny
 // magnitudes, non-finite values) goes through snprintf.  tests/test_fast_format.cpp holds both against snprintf on 10^7 values.
 #pragma once
+#include <cstdint>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -76,10 +77,19 @@ inline void append_f6(std::string& out, double x) {
 }
 
 // appends a non-negative integer in decimal
-inline void append_uint(std::string& out, unsigned long long v) {
-  char b[24]; int n = 0;
-  do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-  for (int i = n - 1; i >= 0; --i) out += b[i];
+inline void append_uint(std::string& out, unsigned long long v) {   // two digits per division, one append
+  static const char pairs[] = "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+                              "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+  char b[24]; char* e = b + sizeof b; char* p = e;
+  if (v <= 0xffffffffull) {                                       // (32-bit divisions: lengths, positions, counts)
+    uint32_t u = (uint32_t)v;
+    while (u >= 100) { const uint32_t q = u / 100, r = u - q * 100; u = q; p -= 2; p[0] = pairs[2 * r]; p[1] = pairs[2 * r + 1]; }
+    if (u >= 10) { p -= 2; p[0] = pairs[2 * u]; p[1] = pairs[2 * u + 1]; } else *--p = (char)('0' + u);
+  } else {
+    while (v >= 100) { const unsigned long long q = v / 100; const unsigned r = (unsigned)(v - q * 100); v = q; p -= 2; p[0] = pairs[2 * r]; p[1] = pairs[2 * r + 1]; }
+    if (v >= 10) { p -= 2; p[0] = pairs[2 * v]; p[1] = pairs[2 * v + 1]; } else *--p = (char)('0' + v);
+  }
+  out.append(p, (size_t)(e - p));
 }
 
 inline void append_int(std::string& out, long long v) { if (v < 0) { out += '-'; append_uint(out, 0ull - (unsigned long long)v); } else append_uint(out, (unsigned long long)v); }

@@ -334,6 +334,138 @@ int map_mode(const Options& o, const std::string& mode) {
     return part;
   };
   auto drop_refsets = [&]() { for (auto*& r : refset) if (r) { mm_seqset_destroy(r); r = nullptr; } };
+  // ---- reads (computeMap.hpp:104-172 + unifyFiles mapWrap.h:34-213)
+  // ~0.25 Gbp per device batch (16 ms of mapping); the next ones are parsed meanwhile.  (MM_CLI_BATCH_READS: test hook, small batches)
+  const int64_t BATCH_READS = getenv("MM_CLI_BATCH_READS") ? std::max(1, atoi(getenv("MM_CLI_BATCH_READS"))) : 100000,
+                BATCH_BASES = getenv("MM_CLI_BATCH_MBASES") ? (int64_t)std::max(1, atoi(getenv("MM_CLI_BATCH_MBASES"))) * 1000000LL : 256000000LL;
+  // a reader thread parses the query files into batches (bounded queue); `take` hands them out in order, nullptr at the end
+  struct Reader {
+    std::mutex m; std::condition_variable cv; std::deque<std::unique_ptr<Batch>> queue, spare; bool done = false, started = false; size_t max_queued = 2;
+    std::vector<size_t> file_end;                                // file_end[f] = number of batches of files 0..f (set when file f has been read to its end)
+    std::thread th;
+    std::unique_ptr<Batch> take() {
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return !queue.empty() || done; });
+      if (queue.empty()) return nullptr;
+      auto b = std::move(queue.front()); queue.pop_front();
+      cv.notify_all();
+      return b;
+    }
+    void recycle(std::unique_ptr<Batch> b) { b->reset(); std::lock_guard<std::mutex> lk(m); spare.push_back(std::move(b)); }
+    ~Reader() { if (th.joinable()) th.join(); }
+  } reader;
+  reader.max_queued = std::max<size_t>(2, 2 * G);
+  std::deque<MappedFile> mapped;                                 // query files whose sequences the batches point into: alive until the end
+  // (started as soon as the reference has been parsed: the first batches are ready when the index is)
+  auto start_reader = [&]() { if (reader.th.joinable() || reader.started) return; reader.started = true; reader.th = std::thread([&]() {
+    size_t seq = 0;
+    auto fresh = [&]() {
+      std::unique_ptr<Batch> b;
+      { std::lock_guard<std::mutex> lk(reader.m); if (!reader.spare.empty()) { b = std::move(reader.spare.back()); reader.spare.pop_back(); } }
+      if (!b) b = std::make_unique<Batch>();
+      return b;
+    };
+    auto enqueue = [&](std::unique_ptr<Batch> b, size_t fi) {
+      b->seq = seq++; b->file = fi;
+      if (getenv("MM_CLI_TIMING")) std::cerr << "INFO, reader: batch of " << b->names.size() << " reads parsed at +" << std::chrono::duration<double>(std::chrono::steady_clock::now() - pc.t0).count() << " s\n";
+      std::unique_lock<std::mutex> lk(reader.m);
+      reader.cv.wait(lk, [&] { return reader.queue.size() < reader.max_queued; });
+      reader.queue.push_back(std::move(b));
+      reader.cv.notify_all();
+    };
+    // records of `f` while they start before `stop` (memory mode; (size_t)-1: all) -> batches handed to `emit`; false if the reader
+    // gave up on the file (a truncated quality string ends the file for kseq, kseq.h:204)
+    auto parse_into = [&](SeqFile& f, size_t stop, const std::function<void(std::unique_ptr<Batch>)>& emit) -> bool {
+      bool more = true, gave_up = false;
+      while (more) {
+        std::unique_ptr<Batch> b = fresh();
+        int64_t bases = 0;
+        while ((int64_t)b->names.size() < BATCH_READS && bases < BATCH_BASES) {
+          if (stop != (size_t)-1) { const size_t ps = f.peek_start(); if (ps == (size_t)-1 || ps >= stop) { more = false; break; } }
+          if (!(more = f.next())) { gave_up = stop != (size_t)-1; break; }
+          if (b->names.empty() && !f.view) b->reserve((size_t)std::min<int64_t>(BATCH_BASES, (int64_t)f.length() * BATCH_READS) + ((size_t)64 << 20));
+          bases += (int64_t)f.length();
+          b->add(f);
+        }
+        if (b->names.empty()) { std::lock_guard<std::mutex> lk(reader.m); reader.spare.push_back(std::move(b)); break; }
+        emit(std::move(b));
+      }
+      return !gave_up;
+    };
+    for (size_t fi = 0; fi < queries.size(); ++fi) {
+      mapped.emplace_back();
+      MappedFile& mf = mapped.back();
+      if (getenv("MM_CLI_NO_MMAP") || !mf.open(queries[fi])) {   // gzip, pipes, ...: the sequential reader
+        mapped.pop_back();
+        SeqFile f(queries[fi]);
+        parse_into(f, (size_t)-1, [&](std::unique_ptr<Batch> b) { enqueue(std::move(b), fi); });
+      } else {
+        // blocks of the mapped file, parsed by several threads, handed on in file order; a block's batches only go out once the
+        // block before it has been seen to end exactly where this one starts
+        const size_t blk = getenv("MM_CLI_BLOCK_BYTES") ? (size_t)std::max(1, atoi(getenv("MM_CLI_BLOCK_BYTES"))) : (size_t)128 << 20;
+        const size_t nb = std::max<size_t>(1, (mf.size + blk - 1) / blk);
+        std::vector<size_t> start(nb + 1, mf.size);
+        start[0] = 0;
+        struct Block { std::vector<std::unique_ptr<Batch>> out; size_t next = 0; bool done = false, empty = false, over = false; };   // next: first record start behind the block's records
+        std::vector<Block> blocks(nb);
+        std::mutex bm; std::condition_variable bcv; size_t next_block = 0, consumed = 0; bool abandon = false;
+        const unsigned P = (unsigned)std::max<size_t>(1, std::min<size_t>({nb, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4)}));
+        auto worker = [&]() {
+          for (;;) {
+            size_t j;
+            {
+              std::unique_lock<std::mutex> lk(bm);
+              bcv.wait(lk, [&] { return abandon || next_block >= nb || next_block < consumed + P + 2; });   // not too far ahead of the consumer
+              if (abandon || next_block >= nb) return;
+              j = next_block++;
+            }
+            if (j > 0) start[j] = mf.sync(j * blk, std::min(mf.size, (j + 1) * blk));   // (only this thread writes start[j]; read after `done`)
+            Block& B = blocks[j];
+            const size_t lim = std::min(mf.size, (j + 1) * blk);
+            if (j == 0 || start[j] < lim) {                        // records that start in [start[j], lim)
+              SeqFile f(mf.data, j == 0 ? 0 : start[j], mf.size);
+              B.over = !parse_into(f, lim, [&](std::unique_ptr<Batch> b) { B.out.push_back(std::move(b)); });
+              B.next = f.peek_start();
+            } else B.empty = true;                                 // no record start was recognised in this block
+            { std::lock_guard<std::mutex> lk(bm); B.done = true; }
+            bcv.notify_all();
+          }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < P; ++t) pool.emplace_back(worker);
+        // `expect`: where the parse stands = the start of the first record not handed on yet.  A block continues the parse iff it
+        // starts exactly there (block 0 starts at the file's first record by construction).
+        size_t expect = 0; bool chain_ok = true, file_over = false;
+        std::unique_ptr<Batch> pend; int64_t pend_bases = 0;
+        for (size_t j = 0; j < nb && chain_ok && !file_over; ++j) {
+          { std::unique_lock<std::mutex> lk(bm); bcv.wait(lk, [&] { return blocks[j].done; }); }
+          Block& B = blocks[j];
+          if (!B.empty) {
+            if (j > 0 && start[j] != expect) { chain_ok = false; break; }
+            for (auto& b : B.out) {                                 // a block ends where its 128 MB end, not where a batch is full: its last batch goes on in the next block
+              if (pend && ((int64_t)(pend->names.size() + b->names.size()) > BATCH_READS || pend_bases + b->bases() > BATCH_BASES)) { enqueue(std::move(pend), fi); pend_bases = 0; }
+              if (!pend) { pend_bases = b->bases(); pend = std::move(b); }
+              else { pend_bases += b->bases(); pend->absorb(*b); reader.recycle(std::move(b)); }
+            }
+            B.out.clear();
+            if (B.over || B.next == (size_t)-1) { file_over = true; break; }
+            expect = B.next;
+          } else if (expect < std::min(mf.size, (j + 1) * blk)) { chain_ok = false; break; }   // a record starts in this block, but none was recognised
+          { std::lock_guard<std::mutex> lk(bm); consumed = j + 1; } bcv.notify_all();
+        }
+        { std::lock_guard<std::mutex> lk(bm); abandon = true; } bcv.notify_all();
+        for (auto& t : pool) t.join();
+        if (pend) enqueue(std::move(pend), fi);
+        if (!chain_ok) {                                           // a block did not start where the parse stood: the rest sequentially, from there
+          for (auto& B : blocks) for (auto& b : B.out) reader.recycle(std::move(b));
+          SeqFile f(mf.data, expect, mf.size);
+          parse_into(f, (size_t)-1, [&](std::unique_ptr<Batch> b) { enqueue(std::move(b), fi); });
+        }
+      }
+      std::lock_guard<std::mutex> lk(reader.m); reader.file_end.push_back(seq); reader.cv.notify_all();
+    }
+    std::lock_guard<std::mutex> lk(reader.m); reader.done = true; reader.cv.notify_all();
+  }); };
   uint64_t ref_bases = 0;
   mm_index* whole = nullptr;                                     // index of the whole reference on device 0, when one was built for the chunk plan
   if (!from_index) {
@@ -455,6 +587,7 @@ int map_mode(const Options& o, const std::string& mode) {
       });
       pc.lap("1 reference parse + pack + upload");
       pc.add("2 reference pack+upload (inside 1)", t_pack);
+      if (!only_index) start_reader();
     }
     query_free();                                                // the packed reference now lives on the device (0.25 B per base, for as long as chunks are cut out of it): what is left is what the indexes get
     std::vector<int32_t> first(1, 0);
@@ -622,139 +755,9 @@ int map_mode(const Options& o, const std::string& mode) {
     drop_refsets();
     pc.lap("3 index build");
   }
-  // ---- reads (computeMap.hpp:104-172 + unifyFiles mapWrap.h:34-213)
-  // ~0.25 Gbp per device batch (16 ms of mapping); the next ones are parsed meanwhile.  (MM_CLI_BATCH_READS: test hook, small batches)
-  const int64_t BATCH_READS = getenv("MM_CLI_BATCH_READS") ? std::max(1, atoi(getenv("MM_CLI_BATCH_READS"))) : 100000,
-                BATCH_BASES = getenv("MM_CLI_BATCH_MBASES") ? (int64_t)std::max(1, atoi(getenv("MM_CLI_BATCH_MBASES"))) * 1000000LL : 256000000LL;
   const mm_map_params mp{k, w, pi, minLen};
   std::vector<int32_t> chunk_base; for (auto& ch : chunks) chunk_base.push_back(ch.first);
-  // a reader thread parses the query files into batches (bounded queue); `take` hands them out in order, nullptr at the end
-  struct Reader {
-    std::mutex m; std::condition_variable cv; std::deque<std::unique_ptr<Batch>> queue, spare; bool done = false; size_t max_queued = 2;
-    std::vector<size_t> file_end;                                // file_end[f] = number of batches of files 0..f (set when file f has been read to its end)
-    std::thread th;
-    std::unique_ptr<Batch> take() {
-      std::unique_lock<std::mutex> lk(m);
-      cv.wait(lk, [&] { return !queue.empty() || done; });
-      if (queue.empty()) return nullptr;
-      auto b = std::move(queue.front()); queue.pop_front();
-      cv.notify_all();
-      return b;
-    }
-    void recycle(std::unique_ptr<Batch> b) { b->reset(); std::lock_guard<std::mutex> lk(m); spare.push_back(std::move(b)); }
-    ~Reader() { if (th.joinable()) th.join(); }
-  } reader;
-  reader.max_queued = std::max<size_t>(2, 2 * G);
-  std::deque<MappedFile> mapped;                                 // query files whose sequences the batches point into: alive until the end
-  reader.th = std::thread([&]() {
-    size_t seq = 0;
-    auto fresh = [&]() {
-      std::unique_ptr<Batch> b;
-      { std::lock_guard<std::mutex> lk(reader.m); if (!reader.spare.empty()) { b = std::move(reader.spare.back()); reader.spare.pop_back(); } }
-      if (!b) b = std::make_unique<Batch>();
-      return b;
-    };
-    auto enqueue = [&](std::unique_ptr<Batch> b, size_t fi) {
-      b->seq = seq++; b->file = fi;
-      if (getenv("MM_CLI_TIMING")) std::cerr << "INFO, reader: batch of " << b->names.size() << " reads parsed at +" << std::chrono::duration<double>(std::chrono::steady_clock::now() - pc.t0).count() << " s\n";
-      std::unique_lock<std::mutex> lk(reader.m);
-      reader.cv.wait(lk, [&] { return reader.queue.size() < reader.max_queued; });
-      reader.queue.push_back(std::move(b));
-      reader.cv.notify_all();
-    };
-    // records of `f` while they start before `stop` (memory mode; (size_t)-1: all) -> batches handed to `emit`; false if the reader
-    // gave up on the file (a truncated quality string ends the file for kseq, kseq.h:204)
-    auto parse_into = [&](SeqFile& f, size_t stop, const std::function<void(std::unique_ptr<Batch>)>& emit) -> bool {
-      bool more = true, gave_up = false;
-      while (more) {
-        std::unique_ptr<Batch> b = fresh();
-        int64_t bases = 0;
-        while ((int64_t)b->names.size() < BATCH_READS && bases < BATCH_BASES) {
-          if (stop != (size_t)-1) { const size_t ps = f.peek_start(); if (ps == (size_t)-1 || ps >= stop) { more = false; break; } }
-          if (!(more = f.next())) { gave_up = stop != (size_t)-1; break; }
-          if (b->names.empty() && !f.view) b->reserve((size_t)std::min<int64_t>(BATCH_BASES, (int64_t)f.length() * BATCH_READS) + ((size_t)64 << 20));
-          bases += (int64_t)f.length();
-          b->add(f);
-        }
-        if (b->names.empty()) { std::lock_guard<std::mutex> lk(reader.m); reader.spare.push_back(std::move(b)); break; }
-        emit(std::move(b));
-      }
-      return !gave_up;
-    };
-    for (size_t fi = 0; fi < queries.size(); ++fi) {
-      mapped.emplace_back();
-      MappedFile& mf = mapped.back();
-      if (getenv("MM_CLI_NO_MMAP") || !mf.open(queries[fi])) {   // gzip, pipes, ...: the sequential reader
-        mapped.pop_back();
-        SeqFile f(queries[fi]);
-        parse_into(f, (size_t)-1, [&](std::unique_ptr<Batch> b) { enqueue(std::move(b), fi); });
-      } else {
-        // blocks of the mapped file, parsed by several threads, handed on in file order; a block's batches only go out once the
-        // block before it has been seen to end exactly where this one starts
-        const size_t blk = getenv("MM_CLI_BLOCK_BYTES") ? (size_t)std::max(1, atoi(getenv("MM_CLI_BLOCK_BYTES"))) : (size_t)128 << 20;
-        const size_t nb = std::max<size_t>(1, (mf.size + blk - 1) / blk);
-        std::vector<size_t> start(nb + 1, mf.size);
-        start[0] = 0;
-        struct Block { std::vector<std::unique_ptr<Batch>> out; size_t next = 0; bool done = false, empty = false, over = false; };   // next: first record start behind the block's records
-        std::vector<Block> blocks(nb);
-        std::mutex bm; std::condition_variable bcv; size_t next_block = 0, consumed = 0; bool abandon = false;
-        const unsigned P = (unsigned)std::max<size_t>(1, std::min<size_t>({nb, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4)}));
-        auto worker = [&]() {
-          for (;;) {
-            size_t j;
-            {
-              std::unique_lock<std::mutex> lk(bm);
-              bcv.wait(lk, [&] { return abandon || next_block >= nb || next_block < consumed + P + 2; });   // not too far ahead of the consumer
-              if (abandon || next_block >= nb) return;
-              j = next_block++;
-            }
-            if (j > 0) start[j] = mf.sync(j * blk, std::min(mf.size, (j + 1) * blk));   // (only this thread writes start[j]; read after `done`)
-            Block& B = blocks[j];
-            const size_t lim = std::min(mf.size, (j + 1) * blk);
-            if (j == 0 || start[j] < lim) {                        // records that start in [start[j], lim)
-              SeqFile f(mf.data, j == 0 ? 0 : start[j], mf.size);
-              B.over = !parse_into(f, lim, [&](std::unique_ptr<Batch> b) { B.out.push_back(std::move(b)); });
-              B.next = f.peek_start();
-            } else B.empty = true;                                 // no record start was recognised in this block
-            { std::lock_guard<std::mutex> lk(bm); B.done = true; }
-            bcv.notify_all();
-          }
-        };
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < P; ++t) pool.emplace_back(worker);
-        // `expect`: where the parse stands = the start of the first record not handed on yet.  A block continues the parse iff it
-        // starts exactly there (block 0 starts at the file's first record by construction).
-        size_t expect = 0; bool chain_ok = true, file_over = false;
-        std::unique_ptr<Batch> pend; int64_t pend_bases = 0;
-        for (size_t j = 0; j < nb && chain_ok && !file_over; ++j) {
-          { std::unique_lock<std::mutex> lk(bm); bcv.wait(lk, [&] { return blocks[j].done; }); }
-          Block& B = blocks[j];
-          if (!B.empty) {
-            if (j > 0 && start[j] != expect) { chain_ok = false; break; }
-            for (auto& b : B.out) {                                 // a block ends where its 128 MB end, not where a batch is full: its last batch goes on in the next block
-              if (pend && ((int64_t)(pend->names.size() + b->names.size()) > BATCH_READS || pend_bases + b->bases() > BATCH_BASES)) { enqueue(std::move(pend), fi); pend_bases = 0; }
-              if (!pend) { pend_bases = b->bases(); pend = std::move(b); }
-              else { pend_bases += b->bases(); pend->absorb(*b); reader.recycle(std::move(b)); }
-            }
-            B.out.clear();
-            if (B.over || B.next == (size_t)-1) { file_over = true; break; }
-            expect = B.next;
-          } else if (expect < std::min(mf.size, (j + 1) * blk)) { chain_ok = false; break; }   // a record starts in this block, but none was recognised
-          { std::lock_guard<std::mutex> lk(bm); consumed = j + 1; } bcv.notify_all();
-        }
-        { std::lock_guard<std::mutex> lk(bm); abandon = true; } bcv.notify_all();
-        for (auto& t : pool) t.join();
-        if (pend) enqueue(std::move(pend), fi);
-        if (!chain_ok) {                                           // a block did not start where the parse stood: the rest sequentially, from there
-          for (auto& B : blocks) for (auto& b : B.out) reader.recycle(std::move(b));
-          SeqFile f(mf.data, expect, mf.size);
-          parse_into(f, (size_t)-1, [&](std::unique_ptr<Batch> b) { enqueue(std::move(b), fi); });
-        }
-      }
-      std::lock_guard<std::mutex> lk(reader.m); reader.file_end.push_back(seq); reader.cv.notify_all();
-    }
-    std::lock_guard<std::mutex> lk(reader.m); reader.done = true; reader.cv.notify_all();
-  });
+  start_reader();
   auto upload_batch = [&](mm_ctx* ctx, const Batch& bt) {
     mm_seqset* reads; ck(ctx, mm_seqset_create(ctx, &reads), "seqset");
     for (size_t r = 0; r < bt.names.size(); ++r) ck(ctx, mm_seqset_add_view(reads, bt.seq_of(r), (int64_t)bt.lens[r]), "add read");

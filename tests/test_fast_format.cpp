@@ -35,6 +35,15 @@ int main(int argc, char** argv) {
     if (check_g(a) || check_f(a) || check_g(b) || check_g(c) || check_g(d) || check_f(t6) || check_g(t6) || check_g(g6)) return 1;
     cnt += 8;
   }
+  // integers (append_int / append_uint against %lld / %llu): every digit count, the powers of ten and their neighbours, the extremes
+  {
+    auto check_i = [](long long v) { char ref[32]; snprintf(ref, sizeof ref, "%lld", v); std::string s = "x"; append_int(s, v); if (s != std::string("x") + ref) { printf("MISMATCH int %lld: '%s'\n", v, s.c_str()); return 1; } return 0; };
+    auto check_u = [](unsigned long long v) { char ref[32]; snprintf(ref, sizeof ref, "%llu", v); std::string s; append_uint(s, v); if (s != ref) { printf("MISMATCH uint %llu: '%s'\n", v, s.c_str()); return 1; } return 0; };
+    unsigned long long p10 = 1;
+    for (int d = 0; d < 20; ++d) { for (long long dl = -2; dl <= 2; ++dl) { const unsigned long long v = p10 + (unsigned long long)dl; if (check_u(v) || (v <= 0x7fffffffffffffffull && (check_i((long long)v) || check_i(-(long long)v)))) return 1; cnt += 3; } if (d < 19) p10 *= 10; }
+    if (check_u(0) || check_u(~0ull) || check_u(0xffffffffull) || check_u(0x100000000ull) || check_i(0) || check_i(-1) || check_i(-0x7fffffffffffffffLL - 1) || check_i(0x7fffffffffffffffLL)) return 1;
+    for (long i = 0; i < n; ++i) { const int bits = 1 + (int)(rng() % 64); const unsigned long long v = rng() >> (64 - bits); if (check_u(v) || check_i((long long)v)) return 1; cnt += 2; }
+  }
   printf("ok %ld\n", cnt);
   return 0;
 }

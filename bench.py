@@ -163,6 +163,9 @@ def main():
         ctx.synchronize()
         t_index = time.time() - t0
         info = idx.info()
+        # the build's sort buffers (~100 GB, kept pooled by the library for the next build or for the contexts' own buffers) go back to the
+        # driver here: this process builds one index per shape, and the CLI legs further down are other processes on the same device
+        ctx.release_cached()
         # distinct read batches, generated up front (packed 2-bit, resident): step s maps batch s mod B, so that no step re-maps what the
         # step before it left in the caches.  The worker contexts read them in turn (read-only; any context of the device may).
         B = max(1, min(args.distinct_batches, steps + max(warmup, 0)))
@@ -430,10 +433,17 @@ def main():
             rl["algorithmic_bytes_per_launch"] = rl["alone"]["algorithmic_bytes_per_launch"]
             del rl["alone"]
         if not args.no_cpu_baseline and world == 1:              # (the contract asks for it at N=1 only)
+            # the CLI of the e2e_cli leg is another process on this device: what this one holds in reserve goes back first (the contexts'
+            # cached blocks, which since round 4 are pieces of the ~100 GB of pooled index-build buffers: with those kept the device had
+            # 0.6 GiB left and the CLI's index build failed for lack of memory)
+            for c in ctxs:
+                c.release_cached()
             try:
                 out["cpu_baseline"], out["e2e_cli"] = cpu_baseline_and_cli(args, R, k, w)
             except Exception as e:  # the baseline is a reported side number; never let it kill the bench line
-                out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+                tail = getattr(e, "stderr", None)
+                tail = (" | stderr: " + tail.decode(errors="replace")[-400:]) if isinstance(tail, (bytes, bytearray)) and tail else ""
+                out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": 1, "kind": "port", "sample": f"failed: {e}{tail}"}
     # the other reference shape, beside the headline (one GPU only: it costs a second index build)
     if world == 1 and not args.no_other_shape:
         for rd in R["reads_w"]:

@@ -466,6 +466,35 @@ int map_mode(const Options& o, const std::string& mode) {
     }
     std::lock_guard<std::mutex> lk(reader.m); reader.done = true; reader.cv.notify_all();
   }); };
+  // worker contexts of the replicated mode (WPD per device, --workers-per-gpu).  The ones beside the device's first context come up while the
+  // index is built, each with its upload staging in place (a batch-sized dummy goes through mm_seqset_upload once: pinned buffer, device
+  // block): the first batch of a worker used to spend 40-60 ms there, and 38 ms creating its stream, with the device idle.
+  const size_t WPD = o.v.count("workers-per-gpu") ? (size_t)std::max(1, std::stoi(o.v.at("workers-per-gpu")))
+                   : getenv("MM_CLI_WORKERS") ? (size_t)std::max(1, atoi(getenv("MM_CLI_WORKERS"))) : 4;
+  std::vector<mm_ctx*> wctx(G * WPD, nullptr);
+  std::thread prewarm;
+  auto start_prewarm = [&]() {
+    if (prewarm.joinable() || getenv("MM_CLI_NO_PREWARM")) return;
+    int64_t query_bytes = 0; for (auto& q : queries) query_bytes += (int64_t)file_size(q);
+    const int64_t warm_bases = std::min<int64_t>(BATCH_BASES, query_bytes / 2);   // (a FASTQ is two bytes per base; small inputs get small staging)
+    prewarm = std::thread([&, warm_bases]() {
+      static const std::string dummy((size_t)1 << 20, 'A');
+      std::vector<std::thread> th;
+      for (size_t d = 0; d < G; ++d) for (size_t wi = 1; wi < WPD; ++wi) th.emplace_back([&, d, wi]() {
+        mm_ctx* c = nullptr;
+        if (mm_ctx_create(devs[d].phys, &c) != MM_OK) die("cannot create a worker context");
+        mm_seqset* sq = nullptr;
+        if (mm_seqset_create(c, &sq) == MM_OK) {                  // (a failure here only means the first batch pays for its staging itself)
+          bool ok = true;
+          for (int64_t b = 0; ok && b < warm_bases; b += (int64_t)dummy.size()) ok = mm_seqset_add_view(sq, dummy.data(), (int64_t)dummy.size()) == MM_OK;
+          if (ok) (void)mm_seqset_upload(sq);
+          mm_seqset_destroy(sq);
+        }
+        wctx[d * WPD + wi] = c;
+      });
+      for (auto& t : th) t.join();
+    });
+  };
   uint64_t ref_bases = 0;
   mm_index* whole = nullptr;                                     // index of the whole reference on device 0, when one was built for the chunk plan
   if (!from_index) {
@@ -587,7 +616,7 @@ int map_mode(const Options& o, const std::string& mode) {
       });
       pc.lap("1 reference parse + pack + upload");
       pc.add("2 reference pack+upload (inside 1)", t_pack);
-      if (!only_index) start_reader();
+      if (!only_index) { start_reader(); start_prewarm(); }
     }
     query_free();                                                // the packed reference now lives on the device (0.25 B per base, for as long as chunks are cut out of it): what is left is what the indexes get
     std::vector<int32_t> first(1, 0);
@@ -758,6 +787,8 @@ int map_mode(const Options& o, const std::string& mode) {
   const mm_map_params mp{k, w, pi, minLen};
   std::vector<int32_t> chunk_base; for (auto& ch : chunks) chunk_base.push_back(ch.first);
   start_reader();
+  if (prewarm.joinable()) prewarm.join();
+  if (place != Place::Replicated) for (auto*& c : wctx) if (c) { mm_ctx_destroy(c); c = nullptr; }   // (the other modes drive one context per device)
   auto upload_batch = [&](mm_ctx* ctx, const Batch& bt) {
     mm_seqset* reads; ck(ctx, mm_seqset_create(ctx, &reads), "seqset");
     for (size_t r = 0; r < bt.names.size(); ++r) ck(ctx, mm_seqset_add_view(reads, bt.seq_of(r), (int64_t)bt.lens[r]), "add read");
@@ -835,8 +866,6 @@ int map_mode(const Options& o, const std::string& mode) {
   if (place == Place::Replicated) {
     // ---- workers: four contexts per device (--workers-per-gpu; three until round 4: with ten batches of 10^5 reads in one file the GPU idled 60 % of the mapping phase), so that packing, result download and text formatting of one batch overlap the
     // kernels of the other; the device's chunk indexes are shared (read-only) by its contexts
-    const size_t WPD = o.v.count("workers-per-gpu") ? (size_t)std::max(1, std::stoi(o.v.at("workers-per-gpu")))
-                     : getenv("MM_CLI_WORKERS") ? (size_t)std::max(1, atoi(getenv("MM_CLI_WORKERS"))) : 4;
     // The kernels of a batch fill the device; batches mapped side by side only take turns on it, and four workers that start together
     // then also finish together: they packed, fetched and formatted at the same time with the device idle, and mapped at the same time
     // in each other's way (the done-times of the workers came in groups of four, 60 ms apart).  So at most MAP_SLOTS batches per device are
@@ -849,8 +878,8 @@ int map_mode(const Options& o, const std::string& mode) {
     for (auto& sl : map_slots) sl.free_ = MAP_SLOTS;
     std::vector<std::thread> workers;
     for (size_t d = 0; d < G; ++d) for (size_t wi = 0; wi < WPD; ++wi) workers.emplace_back([&, d, wi]() {
-      mm_ctx* ctx = devs[d].ctx;
-      if (wi > 0 && mm_ctx_create(devs[d].phys, &ctx) != MM_OK) die("cannot create a worker context");
+      mm_ctx* ctx = wi == 0 ? devs[d].ctx : wctx[d * WPD + wi];
+      if (!ctx && mm_ctx_create(devs[d].phys, &ctx) != MM_OK) die("cannot create a worker context");
       while (std::unique_ptr<Batch> bt = reader.take()) {
         const auto t0 = std::chrono::steady_clock::now();
         mm_seqset* reads = upload_batch(ctx, *bt);

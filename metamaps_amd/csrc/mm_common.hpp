@@ -226,7 +226,13 @@ inline void* slab_piece(int device, size_t bytes) {
 }
 inline DevAlloc*& current_alloc() { static thread_local DevAlloc* a = nullptr; return a; }
 inline hipStream_t& current_stream() { static thread_local hipStream_t s = nullptr; return s; }
-constexpr size_t DIRECT_ALLOC_BYTES = (size_t)8 << 30;
+// blocks from this size on are "index-scale": pooled per device, not cached per context (MM_INDEX_SCALE_MB: test hook — with a few MB the pool,
+// and the slabs cut from it, come into play on a reference of a few Mbp)
+inline size_t direct_alloc_bytes() {
+  static const size_t v = [] { const char* e = getenv("MM_INDEX_SCALE_MB"); return e && atoll(e) > 0 ? (size_t)atoll(e) << 20 : (size_t)8 << 30; }();
+  return v;
+}
+#define DIRECT_ALLOC_BYTES (mm::direct_alloc_bytes())
 
 template <typename T>
 struct DBuf {

@@ -59,6 +59,30 @@ def test_cli_outputs_match_oracle(oracle_lib, tmp_path, w_flag):
     _cmp_unknown_species(pa, pb)
 
 
+def test_cli_pooled_blocks_serve_the_workers(tmp_path):
+    """mm_slab.hpp on the device: with the index-scale threshold lowered to 2 MiB (MM_INDEX_SCALE_MB) the buffers a 10 Mbp index build lets go
+    of are pooled, and the worker contexts' allocations are cut out of them (MM_ALLOC_TRACE shows the pieces).  Files equal those of a run
+    without slabs, byte for byte; several batches per worker, so pieces go back to their slabs and out again."""
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=20, genome_len=500_000, seed=11)
+    rd = synth.make_reads(db, str(tmp_path / "reads.fq"), n_reads=600, read_len=5000, seed=5)
+    outs = {}
+    for name, extra in (("slabs", {}), ("plain", {"MM_NO_SLABS": "1"})):
+        pre = str(tmp_path / name)
+        env = dict(os.environ, MM_INDEX_SCALE_MB="2", MM_ALLOC_TRACE="1", MM_CLI_BATCH_READS="60", **extra)
+        p = subprocess.run([CLI, "mapDirectly", "--all", "-r", db.fasta, "-q", rd["path"], "-o", pre, "--workers-per-gpu", "3"], capture_output=True, timeout=900, env=env)
+        assert p.returncode == 0, p.stderr.decode()[-600:]
+        err = p.stderr.decode()
+        n_pieces = err.count("MM_ALLOC_TRACE slab piece")
+        assert (n_pieces > 0) == (name == "slabs"), (name, n_pieces)
+        if name == "slabs":
+            assert "big block of" in err or "direct hipMalloc" in err     # the build did go through the index-scale path
+        subprocess.run([CLI, "classify", "--DB", db.dir, "--mappings", pre, "--minreads", "3"], check=True, capture_output=True, timeout=900, env=env)
+        outs[name] = {suf: open(pre + suf, "rb").read() for suf in ("", ".meta", ".EM", ".EM.WIMP", ".EM.reads2Taxon")}
+    assert outs["slabs"] == outs["plain"]
+    assert outs["slabs"][""].count(b"\n") > 400
+
+
 def _cmp_unknown_species(pa, pb, expect_tests=True):
     # NA and integer columns as text, the six std::to_string doubles numerically
     suf = ".EM.evidenceUnknownSpecies"

@@ -33,6 +33,7 @@
 #include "id_set.hpp"
 #include "fast_format.hpp"
 #include "huge_new.hpp"
+#include "task_pool.hpp"
 #include <sys/mman.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -249,14 +250,24 @@ void format_records(const std::vector<std::string>& names, const std::vector<int
   { size_t t = 1; for (size_t r = 0; r < n && t < T; ++r) if ((uint64_t)off[r] >= (uint64_t)rec.size() * t / T) cut[t++] = r; }
   static thread_local std::vector<std::string> part_store(8);      // (kept with their capacity: fresh text buffers are page faults, batch after batch)
   std::vector<std::string>& part = part_store;
-  std::vector<std::thread> pool;
   FormatCache* const fcs = caches.data();
-  for (size_t t = 1; t < T; ++t) pool.emplace_back([&, t] { format_range(names, lens, off, rec, cname, clen, k, cut[t], cut[t + 1], part[t], fcs[t]); });
-  format_range(names, lens, off, rec, cname, clen, k, cut[0], cut[1], part[0], fcs[0]);
-  for (auto& th : pool) th.join();
+  const auto q0 = std::chrono::steady_clock::now();
+  std::vector<double> took(T, 0.0);
+  auto timed = [&](size_t t) { const auto a = std::chrono::steady_clock::now(); format_range(names, lens, off, rec, cname, clen, k, cut[t], cut[t + 1], part[t], fcs[t]);
+                               took[t] = std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
+  static thread_local TaskPool helpers(7);                         // (task_pool.hpp: the calling worker's own helpers, there from batch to batch)
+  const auto q1 = q0;
+  helpers.run(T, timed);
+  const auto q2 = std::chrono::steady_clock::now();
   size_t total = 0; for (size_t t = 0; t < T; ++t) total += part[t].size();
   out.clear(); out.reserve(total);
   for (size_t t = 0; t < T; ++t) out += part[t];
+  if (getenv("MM_CLI_FORMAT_TRACE")) {
+    const auto q3 = std::chrono::steady_clock::now();
+    double mx = 0; for (double x : took) mx = std::max(mx, x);
+    fprintf(stderr, "FORMAT_TRACE %zu records, %zu threads: all parts %.2f ms (own part %.2f ms, slowest part %.2f ms), join text %.2f ms\n", rec.size(), T,
+            std::chrono::duration<double, std::milli>(q2 - q1).count(), took[0] * 1e3, mx * 1e3, std::chrono::duration<double, std::milli>(q3 - q2).count());
+  }
 }
 
 int map_mode(const Options& o, const std::string& mode) {

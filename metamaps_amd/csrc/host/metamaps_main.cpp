@@ -33,7 +33,7 @@
 #include "id_set.hpp"
 #include "fast_format.hpp"
 #include "huge_new.hpp"
-#include "task_pool.hpp"
+#include "../task_pool.hpp"
 #include <sys/mman.h>
 #include <fcntl.h>
 #include <unistd.h>

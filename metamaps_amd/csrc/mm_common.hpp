@@ -18,6 +18,7 @@
 #include <algorithm>
 #include "../../include/metamaps_hip.h"
 #include "mm_slab.hpp"
+#include "task_pool.hpp"
 
 namespace mm {
 
@@ -454,8 +455,9 @@ struct mm_ctx {
   }
   // pinned bounce buffer for result downloads into caller-owned (pageable) memory
   void* pinned = nullptr; size_t pinned_bytes = 0;
-  // pinned staging buffer of sequence uploads (mm_seq.hip: the 2-bit words are packed straight into it)
+  // pinned staging buffer of sequence uploads (mm_seq.hip: the 2-bit words are packed straight into it), and the threads that pack
   void* pinned_up = nullptr; size_t pinned_up_bytes = 0;
+  std::unique_ptr<TaskPool> pack_pool;
   void* pinned_up_at_least(size_t bytes) {
     if (bytes > pinned_up_bytes) {
       if (pinned_up) { MM_HIP(hipStreamSynchronize(stream)); (void)hipHostFree(pinned_up); }

@@ -160,10 +160,9 @@ void seqset_upload(mm_seqset* s) {
         }
       }
     };
-    std::vector<std::thread> pool;
-    for (size_t t = 1; t < nthr; ++t) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
+    // (the context's own helpers, there from upload to upload: a context uploads one set at a time)
+    if (nthr > 1) { if (!s->ctx->pack_pool) s->ctx->pack_pool = std::make_unique<TaskPool>(31); s->ctx->pack_pool->run(nthr, [&](size_t) { work(); }); }
+    else work();
     for (size_t it = 0; it < items.size(); ++it) {
       Runs& R = runs[it];
       size_t from = 0;

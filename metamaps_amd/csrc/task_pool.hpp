@@ -1,6 +1,7 @@
 // A handful of helper threads that stay: run(n, fn) calls fn(0) ... fn(n-1), fn(0) on the calling thread, the others on helpers that wait for
-// work between calls.  `mapDirectly` formats the text of every batch with eight threads; started anew per batch (std::thread), the slowest of
-// them came in 2-3 times behind the caller's own part — stacks mapped, caches cold, now and then 30-50 ms before one got going at all.
+// work between calls.  `mapDirectly` formats the text of every batch with eight threads, and every sequence upload packs its bases with up to
+// thirty-two; started anew per call (std::thread), the slowest of them came in 2-3 times behind the caller's own part — stacks mapped, caches
+// cold, now and then 30-50 ms before one got going at all.  No HIP in here (tests/test_task_pool.cpp drives it on the CPU).
 #pragma once
 #include <condition_variable>
 #include <functional>

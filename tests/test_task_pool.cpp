@@ -1,5 +1,5 @@
 // CPU harness: metamaps_amd/csrc/host/task_pool.hpp — every task of every round runs exactly once, rounds of any width, pools of several owners side by side.
-#include "../metamaps_amd/csrc/host/task_pool.hpp"
+#include "../metamaps_amd/csrc/task_pool.hpp"
 #include <atomic>
 #include <cstdio>
 

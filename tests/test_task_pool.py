@@ -1,4 +1,4 @@
-"""metamaps_amd/csrc/host/task_pool.hpp (the helper threads that format a batch's text): tests/test_task_pool.cpp.  CPU."""
+"""metamaps_amd/csrc/task_pool.hpp (the helper threads that format a batch's text): tests/test_task_pool.cpp.  CPU."""
 import os
 import subprocess
 

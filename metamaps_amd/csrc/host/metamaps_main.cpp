@@ -1582,6 +1582,8 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
   ContigCoverage coverage;
   std::map<std::string, std::vector<double>> identsPerTaxon;     // :691, :718
   long long maxReadLen = -1;                                     // :692, :719-722
+  std::thread side_files; bool unknown_written = true;
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } side_join{side_files};
   {
     // the four per-read / per-line files: ranges of reads formatted by several threads into their own buffers, written in read order
     // (4.2 M lines through std::to_string on one thread took 1.2 s); the per-taxon tallies and the coverage windows follow in read order
@@ -1651,6 +1653,12 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
     for (size_t t = 0; t < taxa.size(); ++t) if (readsPerIdx[t]) { readsPer[taxa[t]] = readsPerIdx[t]; identsPerTaxon[taxa[t]] = std::move(identsIdx[t]); }
     for (auto& th : pool) th.join();
     pc.lap("c5a format");
+    // the two side files only read the tallies, which are complete here: they are written beside the per-read files and the WIMP (0.1 s of their own)
+    side_files = std::thread([&] {
+      std::thread cov_thread([&] { coverage.write(mapped + ".EM.contigCoverage", T); });
+      unknown_written = write_unknown_species(mapped + ".EM.evidenceUnknownSpecies", db, T, coverage, identsPerTaxon, maxReadLen, minReadsU);
+      cov_thread.join();
+    });
     auto put = [&](std::ofstream& f, std::string Out::*m) { for (auto& O : outs) f.write((O.*m).data(), (std::streamsize)(O.*m).size()); };
     std::thread w1([&] { put(r2t, &Out::r2); put(kr, &Out::kr); put(li, &Out::li); });
     put(emf, &Out::em);
@@ -1667,11 +1675,9 @@ int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::strin
   pc.lap("c5 output files");
   write_wimp(mapped + ".EM.WIMP", T, fmap, readsPer, nTotal, nUnmapped, nTooShort);
   pc.lap("c6 WIMP");
-  std::thread cov_thread([&] { coverage.write(mapped + ".EM.contigCoverage", T); });   // (the two side files only read what is there)
-  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } cov_join{cov_thread};
-  if (!write_unknown_species(mapped + ".EM.evidenceUnknownSpecies", db, T, coverage, identsPerTaxon, maxReadLen, minReadsU))
+  side_files.join();
+  if (!unknown_written)
     std::cerr << "Warning: " << db << "/contigNstats_windowSize_1000.txt not found - " << mapped << ".EM.evidenceUnknownSpecies is not written." << std::endl;
-  cov_thread.join();
   pc.lap("c8 evidence of unknown species + contig coverage");
   if (leave_now && !getenv("MM_CLI_FULL_TEARDOWN")) { emf.close(); r2t.close(); kr.close(); li.close(); pc.report(); leave_now(); finish_fast(); }   // (a GB of vectors and strings: nothing left to do with them)
   return 0;

@@ -25,9 +25,10 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 5   /* 3: mm_seqset_slice/concat, mm_map_batch_reusing, mm_em_continue, mm_synth_community_species;
+#define MM_ABI_VERSION 6   /* 3: mm_seqset_slice/concat, mm_map_batch_reusing, mm_em_continue, mm_synth_community_species;
                             * 4: mm_sketch_batch, mm_ctx_release_cached, mm_index_dup_neighbours;
-                            * 5: mm_mapping_gather, mm_comm_info, mm_seqset_fetch_range */
+                            * 5: mm_mapping_gather, mm_comm_info, mm_seqset_fetch_range;
+                            * 6: mm_index_save, mm_index_load */
 
 typedef enum {
   MM_OK = 0,
@@ -158,6 +159,14 @@ typedef struct {
 } mm_index_info;
 int mm_index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index** out);
 void mm_index_destroy(mm_index* idx);
+/* Persistent device index: what createIndex stores and mapAgainstIndex loads per index chunk (mapWrap.h:358-405, :443-554;
+ * the Boost archives of winSketch.hpp:73-83), in an own versioned binary format — the index arrays as they lie in HBM (entries, occurrence
+ * lists + bins, hash table, position directory, duplicate distances), the contig lengths, the occurrence histogram of the chunk (so that
+ * the accumulated freqThreshold of winSketch.hpp:452-494 comes out as after a build) and the threshold that was set when it was stored.
+ * A load is file -> pinned staging -> device, no kernel runs; the loaded index behaves as the built one in every entry point.
+ * MM_ERR_ARG with a message for an unreadable, foreign, truncated or inconsistent file. */
+int mm_index_save(mm_index* idx, const char* path);
+int mm_index_load(mm_ctx* ctx, const char* path, mm_index** out);
 /* --maxmemory chunk rule (Sketch::build flush test winSketch.hpp:274-329, memory model :165-178), evaluated on the
  * index of the WHOLE reference: returns the first contig of every chunk the reference would create under the
  * given limit (n_chunks == 1, first_contig[0] == 0 when everything fits or max_memory_bytes == 0).  The caller then

@@ -124,6 +124,8 @@ def lib() -> C.CDLL:
             "mm_synth_community_species": (C.c_int, [P(SynthCommunityParams), vp]),
             "mm_minimizers": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, i64]),
             "mm_index_build": (C.c_int, [vp, vp, C.c_int, C.c_int, P(vp)]),
+            "mm_index_save": (C.c_int, [vp, C.c_char_p]),
+            "mm_index_load": (C.c_int, [vp, C.c_char_p, P(vp)]),
             "mm_index_destroy": (None, [vp]),
             "mm_index_get_info": (C.c_int, [vp, P(IndexInfo)]),
             "mm_index_freq_hist": (C.c_int, [vp, vp, vp, i64, P(i64)]),
@@ -287,6 +289,12 @@ class Context:
             idx.set_freq_threshold(thr)
         return idx
 
+    def load_index(self, path: str) -> "Index":
+        """the persistent device index Index.save wrote (mm_index_load): no kernel runs, the stored freqThreshold is in force"""
+        h = C.c_void_p()
+        self.check(lib().mm_index_load(self.h, path.encode(), C.byref(h)))
+        return Index(self, h)
+
     def map_batch(self, idx: "Index", reads: "SeqSet", k: int, w: int, pi: float = 80.0, min_read_len: int = 1000, at_seed_stage=None, at_last_kernel=None,
                   sketch_of: "Mapping | None" = None) -> "Mapping":
         """at_seed_stage / at_last_kernel: callables run between the sketch stage and the seed stage / once K5 is enqueued (mm_map_batch_phased);
@@ -420,6 +428,9 @@ class Index:
         i = IndexInfo()
         self.ctx.check(lib().mm_index_get_info(self.h, C.byref(i)))
         return {n: int(getattr(i, n)) for n, _ in i._fields_}
+
+    def save(self, path: str):
+        self.ctx.check(lib().mm_index_save(self.h, path.encode()))
 
     def freq_hist(self):
         n = C.c_int64()

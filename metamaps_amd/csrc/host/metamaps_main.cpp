@@ -23,7 +23,9 @@
 // place of the PREFIX.N files.  (--stream-range-bases N: test hook, size of the contig ranges the chunk rule is evaluated on.)
 //
 // `index` stores the packed reference per chunk (own versioned format, include/metamaps_hip.h: mm_seqset_save) instead of
-// the reference's Boost archives of the sketch; the device index is rebuilt from it in seconds.
+// the reference's Boost archives of the sketch; the device index is rebuilt from it in seconds.  `index --full-index` stores the
+// device index itself (IDX.N.mmidx, mm_index_save: the arrays as they lie in HBM) and mapAgainstIndex loads it without running a
+// kernel — the persistent index of SURVEY N2; which of the two is faster is a question of file bandwidth against build time.
 //
 // Not provided: classifyU (disabled upstream).
 
@@ -97,7 +99,7 @@ Options parse(int argc, char** argv) {
     if (a == "--stream-chunks") { o.stream = true; continue; }
     if (a == "--shard-index") { o.shard = true; continue; }
     if (a == "--em-host-reduce") { o.em_host = true; continue; }
-    if (a == "--host-gather" || a == "--peer-gather") { o.v[a.substr(2)] = "1"; continue; }
+    if (a == "--host-gather" || a == "--peer-gather" || a == "--full-index") { o.v[a.substr(2)] = "1"; continue; }
     if (a == "-h" || a == "--help") { std::cout << "see the header of metamaps_main.cpp / the reference's README\n"; exit(0); }
     std::string key = alias.count(a) ? alias.at(a) : (a.rfind("--", 0) == 0 ? a.substr(2) : "");
     if (key.empty() || i + 1 >= argc) die("Unknown or incomplete option " + a);
@@ -643,7 +645,7 @@ int map_mode(const Options& o, const std::string& mode) {
         first.resize((size_t)n);
         ck(ctx0, mm_index_plan_chunks(ctx0, whole, maxMem, first.data(), n, &n), "chunk plan");
       }
-      if (only_index && first.size() == 1) ck(ctx0, mm_seqset_save(contigs, (ipre + ".1.seqset").c_str()), "store index chunk");
+      if (only_index && first.size() == 1 && !o.v.count("full-index")) ck(ctx0, mm_seqset_save(contigs, (ipre + ".1.seqset").c_str()), "store index chunk");
     } else {
       // The chunk rule without an index of the whole reference: it decides to close a chunk from the chunk's own content
       // and the next contig only, so it can be evaluated on the index of a contig range that fits the device.  Every cut
@@ -687,8 +689,21 @@ int map_mode(const Options& o, const std::string& mode) {
     if (only_index) {
       { std::ofstream flag(ipre + ".index"); if (!flag.is_open()) die("Cannot open " + ipre + ".index"); flag << 0 << "\n"; }   // mapWrap.h:363-366
       std::vector<std::string> chunk_files;
+      const bool full = o.v.count("full-index") != 0;            // the device index itself (mm_index_save) instead of the packed reference it is rebuilt from
       for (size_t c = 0; c < chunks.size(); ++c) {
-        chunk_files.push_back(ipre + "." + std::to_string(c + 1) + ".seqset");
+        chunk_files.push_back(ipre + "." + std::to_string(c + 1) + (full ? ".mmidx" : ".seqset"));
+        if (full) {
+          mm_index* ix = whole;
+          if (!(chunks.size() == 1 && whole)) {
+            if (whole) { mm_index_destroy(whole); whole = nullptr; }   // (the chunk rule is done with it)
+            mm_seqset* part = make_part(0, chunks[c].first, chunks[c].first + chunks[c].count);
+            ck(ctx0, mm_index_build(ctx0, part, k, w, &ix), "index chunk");
+            mm_seqset_destroy(part);
+          }
+          ck(ctx0, mm_index_save(ix, chunk_files.back().c_str()), "store index chunk");
+          if (ix != whole) mm_index_destroy(ix);
+          continue;
+        }
         if (chunks.size() == 1 && whole) continue;                // stored above, from the set the index was built on
         mm_seqset* part = make_part(0, chunks[c].first, chunks[c].first + chunks[c].count);
         ck(ctx0, mm_seqset_save(part, chunk_files.back().c_str()), "store index chunk");
@@ -762,6 +777,12 @@ int map_mode(const Options& o, const std::string& mode) {
     if (d.idx[c]) return;
     if (whole && NC == 1 && &d == &devs[0]) { d.idx[c] = whole; whole = nullptr; return; }
     mm_seqset* part;
+    if (ch.file.size() > 6 && ch.file.compare(ch.file.size() - 6, 6, ".mmidx") == 0) {   // `index --full-index`: the stored device index, nothing to build
+      ck(d.ctx, mm_index_load(d.ctx, ch.file.c_str(), &d.idx[c]), "load index chunk");
+      mm_index_info info; mm_index_get_info(d.idx[c], &info);
+      if ((int64_t)ch.count != info.n_contigs) die("Index chunk " + ch.file + " does not match " + ipre + ".contigs");
+      return;
+    }
     if (!ch.file.empty()) {
       ck(d.ctx, mm_seqset_load(d.ctx, ch.file.c_str(), &part), "load index chunk");
       if ((int64_t)ch.count != mm_seqset_count(part)) die("Index chunk " + ch.file + " does not match " + ipre + ".contigs");

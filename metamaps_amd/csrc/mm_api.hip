@@ -260,6 +260,23 @@ int mm_index_plan_chunks(mm_ctx* ctx, const mm_index* whole, uint64_t max_memory
     }
   });
 }
+int mm_index_save(mm_index* idx, const char* path) {
+  if (!idx || !path) return MM_ERR_ARG;
+  return guarded(idx->ctx, [&] {
+    MM_HIP(hipSetDevice(idx->ctx->device));
+    mm::index_save(idx, path);
+  });
+}
+int mm_index_load(mm_ctx* ctx, const char* path, mm_index** out) {
+  if (!ctx || !path || !out) return MM_ERR_ARG;
+  return guarded(ctx, [&] {
+    MM_HIP(hipSetDevice(ctx->device));
+    auto* I = new mm_index;
+    I->ctx = ctx;
+    try { mm::index_load(ctx, path, I); } catch (...) { delete I; throw; }
+    *out = I;
+  });
+}
 void mm_index_destroy(mm_index* idx) { if (idx) { (void)hipSetDevice(idx->ctx->device); mm::current_stream() = idx->ctx->stream; mm::current_alloc() = &idx->ctx->alloc; delete idx; } }
 int mm_index_get_info(const mm_index* idx, mm_index_info* out) {
   if (!idx || !out) return MM_ERR_ARG;

@@ -496,3 +496,135 @@ void index_plan_chunks(mm_ctx* ctx, const mm_index* I, uint64_t max_memory, std:
 }
 
 }  // namespace mm
+
+// ---------------------------------------------------------------------------------------------------
+// Persistent device index (what createIndex / the archive loads of mapAgainstIndex are to the reference,
+// mapWrap.h:358-405, :443-554, winSketch.hpp:73-83): the arrays of mm_index as they lie in HBM, so that a load is file -> pinned
+// staging -> device with no kernel at all.  Little endian, versioned; every array is preceded by its element count and the file ends
+// with a closing word (a truncated file is refused).
+//   "MMINDEX1"  u32 version=1  i32 k  i32 w  i32 dir_shift  i32 dup_sat  i32 freq_threshold  u32 tab_buckets  u32 0
+//   i64 n_contigs  i64 N  i64 U  i64 n_dup  i64 n_hist
+//   i64 hist[n_hist][2]  i32 contig_len[n_contigs]  u64 h_cstart[n_contigs + 1]
+//   { u64 count, bytes }  for pos, cstart, occ, occ16, tab, dir, dir_off, dup_bits, dup_rank, dup_dist
+//   u64 0x58444e4958444e49
+// ---------------------------------------------------------------------------------------------------
+namespace {
+constexpr uint64_t IDX_TAIL = 0x58444e4958444e49ull;
+constexpr size_t IDX_STAGE = (size_t)64 << 20;
+struct IdxFile { FILE* f = nullptr; ~IdxFile() { if (f) fclose(f); } };
+struct Pinned2 {                                                   // two staging buffers: the device copies into / out of one while the file has the other
+  char* b[2] = {nullptr, nullptr};
+  Pinned2() { for (auto& p : b) MM_HIP(hipHostMalloc((void**)&p, IDX_STAGE, hipHostMallocDefault)); }
+  ~Pinned2() { for (auto p : b) if (p) (void)hipHostFree(p); }
+};
+void put(FILE* f, const void* p, size_t bytes, const char* what) {
+  MM_REQUIRE(bytes == 0 || fwrite(p, 1, bytes, f) == bytes, MM_ERR_ARG, std::string("short write (") + what + ")");
+}
+void get(FILE* f, void* p, size_t bytes, const char* what) {
+  MM_REQUIRE(bytes == 0 || fread(p, 1, bytes, f) == bytes, MM_ERR_ARG, std::string("truncated index file (") + what + ")");
+}
+template <typename T> void put_array(FILE* f, const mm::DBuf<T>& a, size_t count, Pinned2& pin, hipStream_t st, const char* what) {
+  const uint64_t c64 = count; put(f, &c64, 8, what);
+  const size_t bytes = count * sizeof(T);
+  const char* src = (const char*)a.p;
+  size_t off = 0; int cur = 0;
+  if (bytes) MM_HIP(hipMemcpyAsync(pin.b[0], src, std::min(bytes, IDX_STAGE), hipMemcpyDeviceToHost, st));
+  while (off < bytes) {
+    const size_t n = std::min(bytes - off, IDX_STAGE);
+    MM_HIP(hipStreamSynchronize(st));
+    if (off + n < bytes) MM_HIP(hipMemcpyAsync(pin.b[cur ^ 1], src + off + n, std::min(bytes - off - n, IDX_STAGE), hipMemcpyDeviceToHost, st));
+    put(f, pin.b[cur], n, what);
+    off += n; cur ^= 1;
+  }
+}
+template <typename T> void get_array(FILE* f, mm::DBuf<T>& a, size_t min_alloc, Pinned2& pin, hipStream_t st, uint64_t expect, const char* what) {
+  uint64_t c64 = 0; get(f, &c64, 8, what);
+  MM_REQUIRE(expect == (uint64_t)-1 || c64 == expect, MM_ERR_ARG, std::string("index file is inconsistent (") + what + ")");
+  MM_REQUIRE(c64 < ((uint64_t)1 << 40), MM_ERR_ARG, std::string("corrupt index file (") + what + ")");
+  a.alloc(std::max<size_t>((size_t)c64, min_alloc));
+  const size_t bytes = (size_t)c64 * sizeof(T);
+  char* dst = (char*)a.p;
+  size_t off = 0; int cur = 0;
+  while (off < bytes) {                                            // the read of block i+1 runs beside the copy of block i
+    const size_t n = std::min(bytes - off, IDX_STAGE);
+    get(f, pin.b[cur], n, what);
+    MM_HIP(hipStreamSynchronize(st));                              // (the other buffer's copy: done before that buffer is read into again)
+    MM_HIP(hipMemcpyAsync(dst + off, pin.b[cur], n, hipMemcpyHostToDevice, st));
+    off += n; cur ^= 1;
+  }
+  MM_HIP(hipStreamSynchronize(st));
+}
+}  // namespace
+
+namespace mm {
+
+void index_save(const mm_index* I, const char* path) {
+  hipStream_t st = I->ctx->stream;
+  IdxFile fc; fc.f = fopen(path, "wb");
+  MM_REQUIRE(fc.f != nullptr, MM_ERR_ARG, std::string("cannot open ") + path + " for writing");
+  setvbuf(fc.f, nullptr, _IONBF, 0);
+  Pinned2 pin;
+  const uint32_t head[8] = {1u, (uint32_t)I->k, (uint32_t)I->w, (uint32_t)I->dir_shift, (uint32_t)I->dup_sat, (uint32_t)I->freq_threshold, I->tab_buckets, 0u};
+  const int64_t dims[5] = {I->n_contigs, I->N, I->U, I->n_dup, (int64_t)I->hist.size()};
+  put(fc.f, "MMINDEX1", 8, "magic"); put(fc.f, head, sizeof head, "header"); put(fc.f, dims, sizeof dims, "header");
+  std::vector<int64_t> hh; for (auto& kv : I->hist) { hh.push_back(kv.first); hh.push_back(kv.second); }
+  put(fc.f, hh.data(), hh.size() * 8, "histogram");
+  MM_REQUIRE((int64_t)I->contig_len.size() == I->n_contigs && (int64_t)I->h_cstart.size() == I->n_contigs + 1, MM_ERR_STATE, "index without its contig table");
+  put(fc.f, I->contig_len.data(), I->contig_len.size() * 4, "contig lengths");
+  put(fc.f, I->h_cstart.data(), I->h_cstart.size() * 8, "contig entry ranges");
+  put_array(fc.f, I->pos, I->pos.n, pin, st, "entries");
+  put_array(fc.f, I->cstart, I->cstart.n, pin, st, "contig starts");
+  put_array(fc.f, I->occ, I->occ.n, pin, st, "occurrences");
+  put_array(fc.f, I->occ16, I->occ16.n, pin, st, "occurrence bins");
+  put_array(fc.f, I->tab, I->tab.n, pin, st, "hash table");
+  put_array(fc.f, I->dir, I->dir.n, pin, st, "position directory");
+  put_array(fc.f, I->dir_off, I->dir_off.n, pin, st, "directory offsets");
+  put_array(fc.f, I->dup_bits, I->dup_bits.n, pin, st, "duplicate bits");
+  put_array(fc.f, I->dup_rank, I->dup_rank.n, pin, st, "duplicate ranks");
+  put_array(fc.f, I->dup_dist, I->dup_dist.n, pin, st, "duplicate distances");
+  put(fc.f, &IDX_TAIL, 8, "closing word");
+  MM_REQUIRE(fflush(fc.f) == 0, MM_ERR_ARG, std::string("write to ") + path + " failed");
+}
+
+void index_load(mm_ctx* ctx, const char* path, mm_index* I) {
+  hipStream_t st = ctx->stream;
+  IdxFile fc; fc.f = fopen(path, "rb");
+  MM_REQUIRE(fc.f != nullptr, MM_ERR_ARG, std::string("cannot open ") + path);
+  setvbuf(fc.f, nullptr, _IONBF, 0);
+  char magic[8]; uint32_t head[8]; int64_t dims[5];
+  get(fc.f, magic, 8, "magic"); get(fc.f, head, sizeof head, "header"); get(fc.f, dims, sizeof dims, "header");
+  MM_REQUIRE(memcmp(magic, "MMINDEX1", 8) == 0 && head[0] == 1u, MM_ERR_ARG, std::string(path) + " is not an index file of this version");
+  I->ctx = ctx;
+  I->k = (int)head[1]; I->w = (int)head[2]; I->dir_shift = (int)head[3]; I->dup_sat = (int)head[4]; I->freq_threshold = (int)head[5]; I->tab_buckets = head[6];
+  I->n_contigs = dims[0]; I->N = dims[1]; I->U = dims[2]; I->n_dup = dims[3];
+  MM_REQUIRE(I->k >= 1 && I->k <= 64 && I->w >= 1 && I->n_contigs >= 0 && I->n_contigs < (1LL << 31) && I->N >= 0 && I->U >= 0 && I->U <= I->N && dims[4] >= 0 &&
+             dims[4] <= I->N + 1 && I->dir_shift >= 1 && I->dir_shift < 30, MM_ERR_ARG, "corrupt index header");
+  std::vector<int64_t> hh((size_t)dims[4] * 2);
+  get(fc.f, hh.data(), hh.size() * 8, "histogram");
+  I->hist.clear(); for (size_t i = 0; i + 1 < hh.size(); i += 2) I->hist[hh[i]] = hh[i + 1];
+  I->contig_len.resize((size_t)I->n_contigs); I->h_cstart.resize((size_t)I->n_contigs + 1);
+  get(fc.f, I->contig_len.data(), I->contig_len.size() * 4, "contig lengths");
+  get(fc.f, I->h_cstart.data(), I->h_cstart.size() * 8, "contig entry ranges");
+  MM_REQUIRE(I->h_cstart.front() == 0 && (int64_t)I->h_cstart.back() == I->N, MM_ERR_ARG, "index file is inconsistent (contig entry ranges)");
+  Pinned2 pin;
+  const uint64_t ANY = (uint64_t)-1;
+  get_array(fc.f, I->pos, 1, pin, st, ANY, "entries");
+  get_array(fc.f, I->cstart, 1, pin, st, ANY, "contig starts");
+  get_array(fc.f, I->occ, 1, pin, st, ANY, "occurrences");
+  get_array(fc.f, I->occ16, 1, pin, st, ANY, "occurrence bins");
+  get_array(fc.f, I->tab, 1, pin, st, (uint64_t)I->tab_buckets * 8, "hash table");
+  get_array(fc.f, I->dir, 1, pin, st, ANY, "position directory");
+  get_array(fc.f, I->dir_off, 1, pin, st, ANY, "directory offsets");
+  get_array(fc.f, I->dup_bits, 1, pin, st, ANY, "duplicate bits");
+  get_array(fc.f, I->dup_rank, 1, pin, st, ANY, "duplicate ranks");
+  get_array(fc.f, I->dup_dist, 1, pin, st, ANY, "duplicate distances");
+  MM_REQUIRE((int64_t)I->pos.n >= I->N && (int64_t)I->cstart.n >= I->n_contigs + 1 && (int64_t)I->dir_off.n >= I->n_contigs + 1 && I->occ16.n >= I->occ.n &&
+             I->dup_rank.n >= I->dup_bits.n, MM_ERR_ARG, "index file is inconsistent (array sizes)");
+  uint64_t tail = 0; get(fc.f, &tail, 8, "closing word");
+  MM_REQUIRE(tail == IDX_TAIL, MM_ERR_ARG, "index file is inconsistent (closing word)");
+  I->d_contig_len.alloc(std::max<size_t>(I->contig_len.size(), 1));
+  I->d_contig_len.upload(I->contig_len.data(), I->contig_len.size(), st);
+  MM_HIP(hipStreamSynchronize(st));
+}
+
+}  // namespace mm

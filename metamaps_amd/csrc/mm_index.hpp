@@ -121,5 +121,7 @@ __device__ inline int64_t index_search(const IndexView& I, int32_t c, int32_t p)
 
 void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* out);
 void index_plan_chunks(mm_ctx* ctx, const mm_index* whole, uint64_t max_memory, std::vector<int32_t>& first_contig);
+void index_save(const mm_index* idx, const char* path);
+void index_load(mm_ctx* ctx, const char* path, mm_index* out);
 
 }  // namespace mm

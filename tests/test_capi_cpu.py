@@ -16,7 +16,7 @@ def test_exports_every_declared_symbol():
     assert len(names) >= 45
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.mm_abi_version() == 5
+    assert L.mm_abi_version() == 6
 
 
 def test_no_cpu_fallback():

@@ -149,25 +149,35 @@ def test_cli_maxmemory_contig_too_large(tmp_path):
     assert p.returncode != 0 and b"too large" in p.stderr
 
 
+@pytest.mark.parametrize("full", [[], ["--full-index"]])
 @pytest.mark.parametrize("extra", [[], ["--maxmemory-bytes", "1000000"]])
-def test_cli_index_then_map_against_index(tmp_path, extra):
-    """`index` + `mapAgainstIndex` (own packed index files) give byte-identical output to `mapDirectly`"""
+def test_cli_index_then_map_against_index(tmp_path, extra, full):
+    """`index` + `mapAgainstIndex` give byte-identical output to `mapDirectly`, from the packed reference (index rebuilt) and from the
+    persistent device index of `index --full-index` (IDX.N.mmidx, nothing rebuilt: SURVEY N2, mapWrap.h:358-405, :443-554), also with the
+    chunk indexes of a --maxmemory run loaded one at a time (--stream-chunks)"""
     from metamaps_amd import synth
     db = synth.make_db(str(tmp_path / "db"), n_genomes=10, genome_len=60_000, seed=7)
     rd = synth.make_reads(db, str(tmp_path / "reads.fq"), n_reads=200, read_len=3000, seed=3)
     direct, via = str(tmp_path / "direct"), str(tmp_path / "via")
     subprocess.run([CLI, "mapDirectly", "--all", "-r", db.fasta, "-q", rd["path"], "-o", direct] + extra, check=True, capture_output=True, timeout=900)
-    p = subprocess.run([CLI, "index", "-r", db.fasta, "-i", str(tmp_path / "idx")] + extra, check=True, capture_output=True, timeout=900)
-    n_files = sum(1 for l in p.stdout.decode().splitlines() if l.startswith("Stored state in file"))
-    assert n_files == (8 if extra else 1)
+    p = subprocess.run([CLI, "index", "-r", db.fasta, "-i", str(tmp_path / "idx")] + extra + full, check=True, capture_output=True, timeout=900)
+    stored = [l.split()[-1] for l in p.stdout.decode().splitlines() if l.startswith("Stored state in file")]
+    assert len(stored) == (8 if extra else 1)
+    assert all(f.endswith(".mmidx" if full else ".seqset") and os.path.getsize(f) > 0 for f in stored)
     assert open(str(tmp_path / "idx.index")).read().split()[0] == "1"
-    subprocess.run([CLI, "mapAgainstIndex", "--all", "-i", str(tmp_path / "idx"), "-q", rd["path"], "-o", via], check=True, capture_output=True, timeout=900)
-    assert open(direct).read() == open(via).read()
-    for suf in (".meta", ".meta.unmappedReadsLengths"):
-        assert open(direct + suf).read() == open(via + suf).read(), suf
-    a = [l for l in open(direct + ".parameters") if not l.startswith("outFileName")]
-    b = [l for l in open(via + ".parameters") if not l.startswith("outFileName")]
-    assert a == b
+    for mode in ([], ["--stream-chunks"]) if extra else ([],):
+        subprocess.run([CLI, "mapAgainstIndex", "--all", "-i", str(tmp_path / "idx"), "-q", rd["path"], "-o", via] + mode, check=True, capture_output=True, timeout=900)
+        assert open(direct).read() == open(via).read()
+        for suf in (".meta", ".meta.unmappedReadsLengths"):
+            assert open(direct + suf).read() == open(via + suf).read(), suf
+        a = [l for l in open(direct + ".parameters") if not l.startswith("outFileName")]
+        b = [l for l in open(via + ".parameters") if not l.startswith("outFileName")]
+        assert a == b
+    if full:                                                       # a truncated index file is refused with a message, not mapped against
+        data = open(stored[-1], "rb").read()
+        open(stored[-1], "wb").write(data[: len(data) // 2])
+        q = subprocess.run([CLI, "mapAgainstIndex", "--all", "-i", str(tmp_path / "idx"), "-q", rd["path"], "-o", via], capture_output=True, timeout=900)
+        assert q.returncode != 0 and b"index file" in q.stderr
     # an incomplete index is refused (mapWrap.h:466-470)
     open(str(tmp_path / "idx.index"), "w").write("0\n")
     q = subprocess.run([CLI, "mapAgainstIndex", "--all", "-i", str(tmp_path / "idx"), "-q", rd["path"], "-o", via], capture_output=True, timeout=900)

@@ -135,6 +135,45 @@ def test_index_matches_oracle(ctx, oracle_lib, mini, k, w, part_max, monkeypatch
     oi.close(); idx.close(); S.close()
 
 
+@pytest.mark.parametrize("k,w,thr", [(16, 8, None), (16, 13, 3)])
+def test_index_stored_and_loaded_equals_built(ctx, mini, tmp_path, k, w, thr):
+    """persistent device index (mm_index_save / mm_index_load; mapWrap.h:358-405, :443-554): the loaded index has the
+    built one's entries, duplicate distances, histogram and threshold, plans the same chunks and maps to the same records;
+    foreign and truncated files are refused"""
+    from metamaps_amd import capi
+    names, contigs = _read_fasta(mini["db"].fasta)
+    rnames, reads = _read_fastq(mini["reads"])
+    S = ctx.seqset(contigs)
+    built = ctx.index(S, k, w)
+    if thr:
+        built.set_freq_threshold(thr)
+    path = str(tmp_path / "chunk.mmidx")
+    built.save(path)
+    assert os.path.getsize(path) > built.info()["n_entries"] * 8
+    loaded = ctx.load_index(path)
+    assert loaded.info() == built.info()
+    for a, b in zip(built.entries(), loaded.entries()):
+        assert np.array_equal(a, b)
+    for a, b in zip(built.dup_neighbours(), loaded.dup_neighbours()):
+        assert np.array_equal(a, b)
+    for a, b in zip(built.freq_hist(), loaded.freq_hist()):
+        assert np.array_equal(a, b)
+    assert built.plan_chunks(1_000_000) == loaded.plan_chunks(1_000_000) and len(built.plan_chunks(1_000_000)) > 1
+    R = ctx.seqset(reads)
+    Mb, Ml = ctx.map_batch(built, R, k, w), ctx.map_batch(loaded, R, k, w)
+    (ob, rb), (ol, rl) = Mb.fetch(), Ml.fetch()
+    assert np.array_equal(ob, ol) and rb.tobytes() == rl.tobytes() and len(rb) > 100
+    Mb.close(); Ml.close(); R.close(); loaded.close()
+    data = open(path, "rb").read()
+    for bad in (data[: len(data) - 5], data[: len(data) // 3], b"MMSEQSET" + data[8:], data[:8] + b"\x09" + data[9:]):
+        open(path, "wb").write(bad)
+        with pytest.raises(capi.MMError):
+            ctx.load_index(path)
+    with pytest.raises(capi.MMError):
+        ctx.load_index(str(tmp_path / "absent.mmidx"))
+    built.close(); S.close()
+
+
 @pytest.mark.parametrize("k,w,force_thr,eager", [(16, 13, None, True), (16, 8, None, True), (16, 8, 3, True), (16, 8, None, False), (16, 8, None, "redo")])
 def test_mapping_stages_match_oracle(ctx, oracle_lib, mini, k, w, force_thr, eager, monkeypatch):
     from metamaps_amd import capi

@@ -159,7 +159,7 @@ typedef struct {
 } mm_index_info;
 int mm_index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index** out);
 void mm_index_destroy(mm_index* idx);
-/* Persistent device index: what createIndex stores and mapAgainstIndex loads per index chunk (mapWrap.h:358-405, :443-554;
+/* Persistent device index: what createIndex stores and mapAgainstIndex loads per index chunk (written mapWrap.h:388-391, read :525-529;
  * the Boost archives of winSketch.hpp:73-83), in an own versioned binary format — the index arrays as they lie in HBM (entries, occurrence
  * lists + bins, hash table, position directory, duplicate distances), the contig lengths, the occurrence histogram of the chunk (so that
  * the accumulated freqThreshold of winSketch.hpp:452-494 comes out as after a build) and the threshold that was set when it was stored.

@@ -93,6 +93,9 @@ void alloc_unregister(DevAlloc* a);
 void alloc_trim_others(DevAlloc* self, int device);
 constexpr size_t SLAB_FROM_BYTES = (size_t)1 << 20;             // smaller requests stay with the driver (they come from its own small pools, quickly)
 void* slab_piece(int device, size_t bytes);                      // a piece of a pooled index-scale block of the device, or nullptr (defined behind BigPool)
+size_t big_pool_bytes(int device);
+void* big_pool_rescue(DevAlloc* self, int device, size_t bytes, size_t* got);
+bool big_pool_trim_until(int device, size_t need);
 struct DevAlloc {
   hipStream_t stream = nullptr;
   int device = -1;                           // set by alloc_register
@@ -163,10 +166,17 @@ struct DevAlloc {
     size_t granted = ask;
     if (trace) fprintf(stderr, "MM_ALLOC_TRACE hipMalloc %zu bytes %.3f ms\n", ask, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (e == hipErrorOutOfMemory) {
-      (void)hipGetLastError(); trim(); int dv = 0; (void)hipGetDevice(&dv); alloc_trim_others(this, dv); big_pool_trim(dv); granted = want;   // (the caches first: their pieces of pooled blocks go back to the blocks)
+      if (trace) { int dv0 = 0; (void)hipGetDevice(&dv0); fprintf(stderr, "MM_ALLOC_TRACE out of memory at a request of %zu bytes: caches and %zu pooled bytes go back to the driver\n", want, big_pool_bytes(dv0)); }
+      (void)hipGetLastError(); int dv = 0; (void)hipGetDevice(&dv);
+      static const bool rescue = getenv("MM_NO_POOL_RESCUE") == nullptr;
+      if (rescue && use_slabs) { size_t g = 0; if (void* q = big_pool_rescue(this, dv, want, &g)) { *got = g; if (trace) fprintf(stderr, "MM_ALLOC_TRACE ... served from the pool (%zu bytes)\n", g); return q; } }
+      else { trim(); alloc_trim_others(this, dv); }               // (the caches first: their pieces of pooled blocks go back to the blocks)
+      if (!(rescue && big_pool_trim_until(dv, want + RUNTIME_RESERVE))) big_pool_trim(dv);
+      granted = want;
       size_t fr = 0, tot = 0;
       if (refuse && dev_mem_info(&fr, &tot) == hipSuccess && fr < want + RUNTIME_RESERVE) e = hipErrorOutOfMemory;   // still not there with every cache given back
       else e = dev_malloc(&p, want);
+      if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); big_pool_trim(dv); e = dev_malloc(&p, want); }
     }   // (no headroom when memory is short)
     if (e != hipSuccess) { (void)hipGetLastError(); throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, oom_text(want, e)); }
     *got = granted;
@@ -211,8 +221,25 @@ struct BigPool {
   }
   void give(void* p, size_t sz) { std::lock_guard<std::mutex> lk(m); free_.emplace(sz, p); bytes += sz; }
   void trim() { std::lock_guard<std::mutex> lk(m); for (auto& kv : free_) dev_free(kv.second, kv.first); free_.clear(); bytes = 0; }
+  // pooled blocks back to the driver, largest first, only until it can serve `need` bytes (what stays pooled is what the next chunk build takes
+  // without a driver call; true: the driver now has the room)
+  bool trim_until(size_t need) {
+    std::lock_guard<std::mutex> lk(m);
+    for (;;) {
+      size_t fr = 0, tot = 0;
+      if (dev_mem_info(&fr, &tot) == hipSuccess && fr >= need) return true;
+      if (free_.empty()) return false;
+      auto it = std::prev(free_.end());
+      dev_free(it->second, it->first); bytes -= it->first; free_.erase(it);
+    }
+  }
 };
 inline BigPool& big_pool(int device) { static BigPool pools[64]; return pools[device < 0 || device >= 64 ? 0 : device]; }
+inline size_t big_pool_bytes(int device) { return big_pool(device).bytes; }
+inline void big_pool_adopt_idle(int device) {                    // slabs nothing is cut from any more are pooled blocks again
+  for (auto& sl : slab_set().take_idle(device)) big_pool(device).give(sl.first, sl.second);
+}
+inline bool big_pool_trim_until(int device, size_t need) { return big_pool(device).trim_until(need); }
 inline void big_pool_trim(int device) {                          // (slabs nothing is cut from any more are pooled blocks again, and go with the rest)
   for (auto& sl : slab_set().take_idle(device)) big_pool(device).give(sl.first, sl.second);
   big_pool(device).trim();
@@ -233,8 +260,27 @@ inline size_t direct_alloc_bytes() {
   static const size_t v = [] { const char* e = getenv("MM_INDEX_SCALE_MB"); return e && atoll(e) > 0 ? (size_t)atoll(e) << 20 : (size_t)8 << 30; }();
   return v;
 }
+// A request the driver has refused for lack of memory, served from what the device's pool holds WITHOUT handing the pool back to the driver:
+// the caches go back first (their pieces of pooled blocks return to the blocks), blocks nothing is cut from any more are pooled blocks again, and
+// then a pooled block of the right size or a piece of a larger one (a slab) is taken; nullptr when the pool has nothing that large.  Until
+// round 4's last session every such miss gave the WHOLE pool back (hipFree) and the following allocations came fresh from the driver, which
+// clears what it hands out at ~25 GB/s: with the chunk indexes of a reference larger than the device built, mapped and dropped in turn
+// (bench.py --config 5, 15 Gbp chunks) that happened once or twice per chunk — 5.6 s of a 7.0 s chunk build (MM_ALLOC_TRACE, tools/alloc_config5_small.sh).
+inline void* big_pool_rescue(DevAlloc* self, int device, size_t bytes, size_t* got) {
+  if (self) self->trim();
+  alloc_trim_others(self, device);
+  big_pool_adopt_idle(device);
+  if (bytes >= direct_alloc_bytes()) if (void* p = big_pool(device).take(bytes, got)) return p;
+  if (bytes >= SLAB_FROM_BYTES) if (void* p = slab_piece(device, bytes)) { *got = SlabSet::granules(bytes); return p; }
+  return nullptr;
+}
 #define DIRECT_ALLOC_BYTES (mm::direct_alloc_bytes())
 
+inline size_t index_scale_class(size_t b) {
+  int lg = 63 - __builtin_clzll((unsigned long long)std::max<size_t>(b, 1));
+  const size_t gran = std::max<size_t>((size_t)1 << (lg > 6 ? lg - 6 : 0), (size_t)16 << 20);
+  return (b + gran - 1) / gran * gran;
+}
 template <typename T>
 struct DBuf {
   T* p = nullptr;
@@ -286,18 +332,45 @@ struct DBuf {
       // 6.1 s each on this runtime: MM_ALLOC_TRACE, round 3)
       block = 0;
       static const bool trace = getenv("MM_ALLOC_TRACE") != nullptr;
+      static const bool rescue = getenv("MM_NO_POOL_RESCUE") == nullptr;
       const auto t0 = std::chrono::steady_clock::now();
       (void)hipGetDevice(&big_dev);
       BigPool& bp = big_pool(big_dev);
+      // Index-scale blocks come in size classes (a 64th of the size's power of two, at least 16 MiB: <= 1.6 % slack): the chunk indexes of a
+      // pass differ by a fraction of a percent, and a pooled block a few KB too small for the next chunk's array is a miss
+      const size_t count_bytes = bytes;
+      const size_t bytes = rescue ? index_scale_class(count_bytes) : count_bytes;
       if (owner && owner->eager) owner->trim();                  // (a device-filling build: nothing stays cached beside it ...)
+      big_pool_adopt_idle(big_dev);                              // (blocks the mapping phase had cut its buffers from and has given back)
       p = (T*)bp.take(bytes, &big_bytes);                        // ... but a pooled block of the right size — the previous chunk index of a streaming pass — is taken:
                                                                  // a fresh block from the driver is cleared as it is handed out, 6 s of a 7 s build of a 15 Gbp chunk (round 4)
+      if (!p && rescue && owner && owner->in_build) {
+        // the mapping phase between two chunk builds cuts its buffers out of pooled blocks (slabs) and keeps them cached: with the caches given
+        // back those blocks are whole again — the arrays of the previous chunk's index, which this build is about to ask for
+        owner->trim(); alloc_trim_others(owner, big_dev); big_pool_adopt_idle(big_dev);
+        p = (T*)bp.take(bytes, &big_bytes);
+        // (a piece of a LARGER pooled block before the driver is asked was tried too: the long-lived arrays then sit inside the blocks the next
+        // arrays need whole, and the 62 GB occurrence array of a 15 Gbp chunk found neither a block nor room — out of memory with 33 GB free)
+        if (p && trace) fprintf(stderr, "MM_ALLOC_TRACE big block of %zu bytes for %zu after the caches went back\n", big_bytes, bytes);
+      }
       if (!p) {
         big_bytes = bytes;
         hipError_t e = dev_malloc((void**)&p, bytes);
-        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); if (owner) owner->trim(); alloc_trim_others(owner, big_dev); big_pool_trim(big_dev); e = dev_malloc((void**)&p, bytes); }
+        if (e == hipErrorOutOfMemory) {
+          if (trace) fprintf(stderr, "MM_ALLOC_TRACE out of memory at an index-scale request of %zu bytes (%zu bytes pooled)\n", bytes, bp.bytes);
+          (void)hipGetLastError();
+          void* q = rescue ? big_pool_rescue(owner, big_dev, bytes, &big_bytes) : nullptr;
+          if (q) { p = (T*)q; e = hipSuccess; if (trace) fprintf(stderr, "MM_ALLOC_TRACE ... served from the pool (%zu bytes)\n", big_bytes); }
+          else {
+            big_bytes = bytes;
+            if (!rescue) { if (owner) owner->trim(); alloc_trim_others(owner, big_dev); }
+            if (!(rescue && bp.trim_until(bytes))) big_pool_trim(big_dev);
+            e = dev_malloc((void**)&p, bytes);
+            if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); big_pool_trim(big_dev); e = dev_malloc((void**)&p, bytes); }
+          }
+        }
         if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; n = 0; throw mm::Error(e == hipErrorOutOfMemory ? MM_ERR_NOMEM : MM_ERR_DEVICE, mm::oom_text(bytes, e)); }
-        if (trace) fprintf(stderr, "MM_ALLOC_TRACE direct hipMalloc %zu bytes %.3f ms\n", bytes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        if (trace && big_bytes == bytes && !slab_set().owns(p)) fprintf(stderr, "MM_ALLOC_TRACE direct hipMalloc %zu bytes %.3f ms\n", bytes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       } else if (trace) fprintf(stderr, "MM_ALLOC_TRACE big block of %zu bytes reused for %zu\n", big_bytes, bytes);
     } else p = (T*)owner->get(bytes, &block);
   }
@@ -315,7 +388,7 @@ struct DBuf {
         // is given up when an allocation fails for lack of memory (every allocation path trims it and tries again).
         static const bool keep = getenv("MM_RETURN_INDEX_BLOCKS") == nullptr;
         if ((owner && owner->eager && !keep) || !big_bytes) dev_free(p, big_bytes ? big_bytes : n * sizeof(T));
-        else big_pool(big_dev).give(p, big_bytes);                // (nothing on the device still uses it: any context may take it)
+        else if (!slab_set().give_back(p, big_bytes)) big_pool(big_dev).give(p, big_bytes);   // (nothing on the device still uses it: any context may take it; a piece of a larger pooled block returns to that block)
         if (cur != big_dev) (void)hipSetDevice(cur);
       }
       p = nullptr;

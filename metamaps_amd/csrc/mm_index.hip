@@ -250,7 +250,13 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   struct EagerGuard { DevAlloc& a; bool was, was_build; ~EagerGuard() { a.eager = was; a.in_build = was_build; } } eager_guard{ctx->alloc, ctx->alloc.eager, ctx->alloc.in_build};
   ctx->alloc.in_build = true;
   { size_t fr = 0, tot = 0;
-    if (dev_mem_info(&fr, &tot) == hipSuccess && (double)contigs->total_bases * 5.5 > (double)tot / 4) { ctx->alloc.eager = true; if (!getenv("MM_INDEX_NO_PRETRIM")) { ctx->alloc.trim(); big_pool_trim(ctx->device); } } }
+    if (dev_mem_info(&fr, &tot) == hipSuccess && (double)contigs->total_bases * 5.5 > (double)tot / 4) {
+      // (until round 4's last session the device's pool went back to the driver here, before every device-filling build: with the chunk indexes of a
+      // reference larger than the device built in turn that meant ~150 GB fresh from the driver per 15 Gbp chunk, cleared as it is handed out — 5.6 s of a
+      // 7.0 s build.  Now the pool stays: what the build asks for and the pool has is taken, what the driver cannot give is freed block by block.  MM_INDEX_PRETRIM=1: as before)
+      ctx->alloc.eager = true;
+      if (!getenv("MM_INDEX_NO_PRETRIM")) { ctx->alloc.trim(); if (getenv("MM_INDEX_PRETRIM") || getenv("MM_NO_POOL_RESCUE")) big_pool_trim(ctx->device); else big_pool_adopt_idle(ctx->device); }
+    } }
   I->ctx = ctx; I->k = k; I->w = w;
   I->n_contigs = contigs->count();
   I->contig_len = contigs->len;

@@ -58,6 +58,11 @@ struct SlabSet {
     }
     return false;
   }
+  bool owns(const void* p) {                                     // p lies inside a slab (trace output only)
+    std::lock_guard<std::mutex> lk(m);
+    for (const Slab& sl : slabs) if ((const char*)p >= sl.base && (const char*)p < sl.base + sl.size) return true;
+    return false;
+  }
   // slabs of `device` no piece of which is out: taken off the list, for the caller to hand on (base, size)
   std::vector<std::pair<void*, size_t>> take_idle(int device) {
     std::vector<std::pair<void*, size_t>> out;

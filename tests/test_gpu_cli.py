@@ -633,7 +633,11 @@ def test_cli_device_cap_decides_placement(tmp_path):
     env = dict(os.environ, MM_DEVICE_BYTES_CAP=str(cap))
     env3 = dict(os.environ, MM_DEVICE_BYTES_CAP=str(3 * cap))     # three logical devices on the one physical device share its memory: the CLI gives each a third
     runs = {}
-    for tag, extra, e in (("resident", [], os.environ), ("auto_stream", [], env), ("auto_shard", ["--devices", "0,0,0"], env3)):
+    # (the streamed runs with the index-scale threshold at 256 MiB, so that the chunk indexes' arrays and sort buffers go through the device's block
+    # pool; once with the pool rescue — a refused request is served from pooled blocks — and once with the earlier give-everything-back path)
+    env_s = dict(env, MM_INDEX_SCALE_MB="256", MM_ALLOC_TRACE="1")
+    for tag, extra, e in (("resident", [], os.environ), ("auto_stream", [], env_s), ("auto_stream_no_rescue", [], dict(env_s, MM_NO_POOL_RESCUE="1")),
+                          ("auto_shard", ["--devices", "0,0,0"], env3)):
         o = str(tmp_path / tag)
         p = subprocess.run([CLI] + base + ["-o", o] + extra, capture_output=True, timeout=900, env=dict(e))
         assert p.returncode == 0, (tag, p.stderr.decode()[-1500:], p.stdout.decode()[-1500:])
@@ -644,5 +648,5 @@ def test_cli_device_cap_decides_placement(tmp_path):
     n_chunks = runs["resident"][2].count("INFO, index chunk ")
     assert n_chunks >= 4, runs["resident"][2][-1500:]
     assert len(runs["resident"][0]) > 100_000
-    for tag in ("auto_stream", "auto_shard"):
+    for tag in ("auto_stream", "auto_stream_no_rescue", "auto_shard"):
         assert runs[tag][0] == runs["resident"][0] and runs[tag][1] == runs["resident"][1], tag

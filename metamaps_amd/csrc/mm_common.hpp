@@ -94,7 +94,7 @@ void alloc_trim_others(DevAlloc* self, int device);
 constexpr size_t SLAB_FROM_BYTES = (size_t)1 << 20;             // smaller requests stay with the driver (they come from its own small pools, quickly)
 void* slab_piece(int device, size_t bytes);                      // a piece of a pooled index-scale block of the device, or nullptr (defined behind BigPool)
 size_t big_pool_bytes(int device);
-void* big_pool_rescue(DevAlloc* self, int device, size_t bytes, size_t* got);
+void* big_pool_rescue(DevAlloc* self, int device, size_t bytes, size_t* got, bool caches_first);
 bool big_pool_trim_until(int device, size_t need);
 struct DevAlloc {
   hipStream_t stream = nullptr;
@@ -169,8 +169,8 @@ struct DevAlloc {
       if (trace) { int dv0 = 0; (void)hipGetDevice(&dv0); fprintf(stderr, "MM_ALLOC_TRACE out of memory at a request of %zu bytes: caches and %zu pooled bytes go back to the driver\n", want, big_pool_bytes(dv0)); }
       (void)hipGetLastError(); int dv = 0; (void)hipGetDevice(&dv);
       static const bool rescue = getenv("MM_NO_POOL_RESCUE") == nullptr;
-      if (rescue && use_slabs) { size_t g = 0; if (void* q = big_pool_rescue(this, dv, want, &g)) { *got = g; if (trace) fprintf(stderr, "MM_ALLOC_TRACE ... served from the pool (%zu bytes)\n", g); return q; } }
-      else { trim(); alloc_trim_others(this, dv); }               // (the caches first: their pieces of pooled blocks go back to the blocks)
+      if (rescue && use_slabs) { size_t g = 0; if (void* q = big_pool_rescue(this, dv, want, &g, false)) { *got = g; if (trace) fprintf(stderr, "MM_ALLOC_TRACE ... served from the pool (%zu bytes)\n", g); return q; } }
+      trim(); alloc_trim_others(this, dv);                        // (the caches first: their pieces of pooled blocks go back to the blocks)
       if (!(rescue && big_pool_trim_until(dv, want + RUNTIME_RESERVE))) big_pool_trim(dv);
       granted = want;
       size_t fr = 0, tot = 0;
@@ -266,9 +266,10 @@ inline size_t direct_alloc_bytes() {
 // round 4's last session every such miss gave the WHOLE pool back (hipFree) and the following allocations came fresh from the driver, which
 // clears what it hands out at ~25 GB/s: with the chunk indexes of a reference larger than the device built, mapped and dropped in turn
 // (bench.py --config 5, 15 Gbp chunks) that happened once or twice per chunk — 5.6 s of a 7.0 s chunk build (MM_ALLOC_TRACE, tools/alloc_config5_small.sh).
-inline void* big_pool_rescue(DevAlloc* self, int device, size_t bytes, size_t* got) {
-  if (self) self->trim();
-  alloc_trim_others(self, device);
+inline void* big_pool_rescue(DevAlloc* self, int device, size_t bytes, size_t* got, bool caches_first) {
+  // (the caches only for a device-filling build, which is after the whole blocks the mapping phase has cut its buffers from; given back at every refused
+  // mid-size request they come straight back from the driver: config 4's 2.2 Gbp chunk builds beside 250 GB of pooled blocks went from 0.16 to 0.23 s)
+  if (caches_first) { if (self) self->trim(); alloc_trim_others(self, device); }
   big_pool_adopt_idle(device);
   if (bytes >= direct_alloc_bytes()) if (void* p = big_pool(device).take(bytes, got)) return p;
   if (bytes >= SLAB_FROM_BYTES) if (void* p = slab_piece(device, bytes)) { *got = SlabSet::granules(bytes); return p; }
@@ -344,7 +345,7 @@ struct DBuf {
       big_pool_adopt_idle(big_dev);                              // (blocks the mapping phase had cut its buffers from and has given back)
       p = (T*)bp.take(bytes, &big_bytes);                        // ... but a pooled block of the right size — the previous chunk index of a streaming pass — is taken:
                                                                  // a fresh block from the driver is cleared as it is handed out, 6 s of a 7 s build of a 15 Gbp chunk (round 4)
-      if (!p && rescue && owner && owner->in_build) {
+      if (!p && rescue && owner && owner->eager) {               // (device-filling builds only: the chunk builds of a --maxmemory run live on their context's cached blocks)
         // the mapping phase between two chunk builds cuts its buffers out of pooled blocks (slabs) and keeps them cached: with the caches given
         // back those blocks are whole again — the arrays of the previous chunk's index, which this build is about to ask for
         owner->trim(); alloc_trim_others(owner, big_dev); big_pool_adopt_idle(big_dev);
@@ -359,7 +360,8 @@ struct DBuf {
         if (e == hipErrorOutOfMemory) {
           if (trace) fprintf(stderr, "MM_ALLOC_TRACE out of memory at an index-scale request of %zu bytes (%zu bytes pooled)\n", bytes, bp.bytes);
           (void)hipGetLastError();
-          void* q = rescue ? big_pool_rescue(owner, big_dev, bytes, &big_bytes) : nullptr;
+          void* q = rescue ? big_pool_rescue(owner, big_dev, bytes, &big_bytes, owner && owner->eager) : nullptr;
+          if (!q && rescue && !(owner && owner->eager)) { if (owner) owner->trim(); alloc_trim_others(owner, big_dev); q = big_pool_rescue(owner, big_dev, bytes, &big_bytes, false); }
           if (q) { p = (T*)q; e = hipSuccess; if (trace) fprintf(stderr, "MM_ALLOC_TRACE ... served from the pool (%zu bytes)\n", big_bytes); }
           else {
             big_bytes = bytes;

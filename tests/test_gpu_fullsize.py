@@ -32,7 +32,7 @@ COMM = dict(seed=20260928, n_genomes=12000, n_species=3000, n_genera=600, median
             human_contigs=24, human_bases=int(3.1e9), repeat_fraction=0.45, n_fraction=0.01, n_repeat_families=1000,
             total_bases_target=26_762_276_280)
 N_READS, RLEN = 100_000, 10_000                               # configs[1]: the bench batch at its size
-N_MIXED, MIXED_MIN, MIXED_MAX = 32_000, 1_000, 50_000         # configs[3]: a quarter of the per-GPU share of 125 000 (0.4 Gbp in ONE call; the CLI maps such reads in batches of <= 0.256 Gbp)
+N_MIXED, MIXED_MIN, MIXED_MAX = 64_000, 1_000, 50_000         # configs[3]: half of the per-GPU share of 125 000 in ONE call (0.8 Gbp, what bench.py --config 3 maps per step beside the four resident chunk indexes: 227 of 288 GiB; the CLI maps such reads in batches of <= 0.256 Gbp)
 INT_MAX = 2**31 - 1
 GIB = 1 << 30
 

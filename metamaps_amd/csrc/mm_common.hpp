@@ -166,7 +166,7 @@ struct DevAlloc {
     size_t granted = ask;
     if (trace) fprintf(stderr, "MM_ALLOC_TRACE hipMalloc %zu bytes %.3f ms\n", ask, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (e == hipErrorOutOfMemory) {
-      if (trace) { int dv0 = 0; (void)hipGetDevice(&dv0); fprintf(stderr, "MM_ALLOC_TRACE out of memory at a request of %zu bytes: caches and %zu pooled bytes go back to the driver\n", want, big_pool_bytes(dv0)); }
+      if (trace) { int dv0 = 0; (void)hipGetDevice(&dv0); fprintf(stderr, "MM_ALLOC_TRACE out of memory at a request of %zu bytes (%zu bytes pooled)\n", want, big_pool_bytes(dv0)); }
       (void)hipGetLastError(); int dv = 0; (void)hipGetDevice(&dv);
       static const bool rescue = getenv("MM_NO_POOL_RESCUE") == nullptr;
       if (rescue && use_slabs) { size_t g = 0; if (void* q = big_pool_rescue(this, dv, want, &g, false)) { *got = g; if (trace) fprintf(stderr, "MM_ALLOC_TRACE ... served from the pool (%zu bytes)\n", g); return q; } }
@@ -239,7 +239,7 @@ inline size_t big_pool_bytes(int device) { return big_pool(device).bytes; }
 inline void big_pool_adopt_idle(int device) {                    // slabs nothing is cut from any more are pooled blocks again
   for (auto& sl : slab_set().take_idle(device)) big_pool(device).give(sl.first, sl.second);
 }
-inline bool big_pool_trim_until(int device, size_t need) { return big_pool(device).trim_until(need); }
+inline bool big_pool_trim_until(int device, size_t need) { big_pool_adopt_idle(device); return big_pool(device).trim_until(need); }
 inline void big_pool_trim(int device) {                          // (slabs nothing is cut from any more are pooled blocks again, and go with the rest)
   for (auto& sl : slab_set().take_idle(device)) big_pool(device).give(sl.first, sl.second);
   big_pool(device).trim();
@@ -366,7 +366,7 @@ struct DBuf {
           else {
             big_bytes = bytes;
             if (!rescue) { if (owner) owner->trim(); alloc_trim_others(owner, big_dev); }
-            if (!(rescue && bp.trim_until(bytes))) big_pool_trim(big_dev);
+            if (!(rescue && big_pool_trim_until(big_dev, bytes))) big_pool_trim(big_dev);
             e = dev_malloc((void**)&p, bytes);
             if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); big_pool_trim(big_dev); e = dev_malloc((void**)&p, bytes); }
           }

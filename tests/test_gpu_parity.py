@@ -135,6 +135,27 @@ def test_index_matches_oracle(ctx, oracle_lib, mini, k, w, part_max, monkeypatch
     oi.close(); idx.close(); S.close()
 
 
+def test_l2_workgroups_in_position_order_give_the_same_records(ctx, mini, monkeypatch):
+    """K5's workgroups are launched in the order of their first candidate's position (l2_group_keys_kernel + radix sort; from 8 192 workgroups
+    on, MM_L2_GROUP_SORT_MIN lowers that): results are indexed by candidate, so the records are those of the unsorted launch, byte for byte"""
+    names, contigs = _read_fasta(mini["db"].fasta)
+    rnames, reads = _read_fastq(mini["reads"])
+    S, R = ctx.seqset(contigs), ctx.seqset(reads)
+    idx = ctx.index(S, 16, 8)
+    out = {}
+    for tag, env in (("sorted", {"MM_L2_GROUP_SORT_MIN": "1"}), ("plain", {"MM_L2_NO_GROUP_SORT": "1"})):
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        M = ctx.map_batch(idx, R, 16, 8); M.add_qualities(16)
+        off, rec = M.fetch()
+        out[tag] = (off.copy(), rec.tobytes(), len(rec))
+        M.close()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    assert np.array_equal(out["sorted"][0], out["plain"][0]) and out["sorted"][1] == out["plain"][1] and out["plain"][2] > 100
+    idx.close(); R.close(); S.close()
+
+
 @pytest.mark.parametrize("k,w,thr", [(16, 8, None), (16, 13, 3)])
 def test_index_stored_and_loaded_equals_built(ctx, mini, tmp_path, k, w, thr):
     """persistent device index (mm_index_save / mm_index_load; mapWrap.h:358-405, :443-554): the loaded index has the

@@ -2055,7 +2055,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         d_gA0.upload(gA0.data(), nA, st); d_gAn.upload(gAn.data(), nA, st); d_gS0.upload(gS0.data(), nS, st); d_gSn.upload(gSn.data(), nS, st);
       }
       const bool sort_groups = getenv("MM_L2_NO_GROUP_SORT") == nullptr;
-      const size_t sort_from = getenv("MM_L2_GROUP_SORT_MIN") ? (size_t)std::max(atoi(getenv("MM_L2_GROUP_SORT_MIN")), 1) : 8192;   // (test hook: small batches take the sort too)
+      const size_t sort_from = getenv("MM_L2_GROUP_SORT_MIN") ? (size_t)std::max(atoi(getenv("MM_L2_GROUP_SORT_MIN")), 1) : 2048;   // (test hook: small batches take the sort too)
       auto sort_by_position = [&](DBuf<int32_t>& g0, DBuf<int32_t>& gn, size_t ng) {
         if (!sort_groups || ng < sort_from || I->n_contigs <= 0) return;                // (small batches: three launches and a sort cost more than the order gives)
         DBuf<uint64_t> key(ng), val(ng), key2(ng), val2(ng);
@@ -2086,6 +2086,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       }
       if (!gB0.empty()) {
         d_gB0.upload(gB0.data(), gB0.size(), st); d_gBn.upload(gBn.data(), gBn.size(), st);
+        sort_by_position(d_gB0, d_gBn, gB0.size());
         const size_t lds = l2_lds_bytes<uint8_t>(smB, true, 4, 8);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
         l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gB0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
@@ -2095,6 +2096,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       DBuf<int32_t> d_gD0(gD0.size()), d_gDn(gDn.size());
       if (!gD0.empty()) {
         d_gD0.upload(gD0.data(), gD0.size(), st); d_gDn.upload(gDn.data(), gDn.size(), st);
+        sort_by_position(d_gD0, d_gDn, gD0.size());
         const size_t lds = l2_lds_bytes<uint8_t>(smD, true, 4, 8);
         set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
         l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gD0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,

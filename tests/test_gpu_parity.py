@@ -136,7 +136,7 @@ def test_index_matches_oracle(ctx, oracle_lib, mini, k, w, part_max, monkeypatch
 
 
 def test_l2_workgroups_in_position_order_give_the_same_records(ctx, mini, monkeypatch):
-    """K5's workgroups are launched in the order of their first candidate's position (l2_group_keys_kernel + radix sort; from 8 192 workgroups
+    """K5's workgroups are launched in the order of their first candidate's position (l2_group_keys_kernel + radix sort; from 2 048 workgroups
     on, MM_L2_GROUP_SORT_MIN lowers that): results are indexed by candidate, so the records are those of the unsorted launch, byte for byte"""
     names, contigs = _read_fasta(mini["db"].fasta)
     rnames, reads = _read_fastq(mini["reads"])

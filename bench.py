@@ -406,9 +406,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, dom_name),
                          "note": "achieved = algorithmic bytes / hipEvent time of the launch pair with the GPU to itself (two steps right behind the timed region, mapping sections serialised; rocprofv3 of this bench with --serialise-map --workers 3 shows the same durations: profiles/r04_kernel_stats.txt).  In the timed region the kernels of two steps share the GPU, a launch waits for and runs beside the other step's kernels: *_timed_region, averaged over the distinct read batches (rocprofv3 of the default command: profiles/r04_kernel_stats_default_cmd.txt); traffic = "
-                                 "FETCH_SIZE x 2 + WRITE_SIZE of one launch pair on batch 0 (profiles/r04_pmc_hbm_traffic.txt): 3.5 x the algorithmic bytes, 4.5 TB/s "
-                                 "of fetch while the kernel runs, 21 percent of its L2 requests hit (profiles/r03_l2_cache.txt); VALU in 88 percent of the issue "
-                                 "slots (profiles/r03_sq_counters.txt).  seed_filter_stream_kernel: 45 percent VALU, bound by random requests per CU (DESIGN.md 4); "
+                                 "FETCH_SIZE x 2 + WRITE_SIZE of one launch pair on batch 0 (profiles/r04_pmc_hbm_traffic.txt): 1.9 x the algorithmic bytes since the workgroups are "
+                                 "launched in the order of their candidates' positions (3.5 x before, 21 percent of its L2 requests hitting: profiles/r03_l2_cache.txt); VALU in 88 percent of the issue "
+                                 "slots (profiles/r03_sq_counters.txt, measured before that change).  seed_filter_stream_kernel: 45 percent VALU, bound by random requests per CU (DESIGN.md 4); "
                                  "minimizer_kernel 99 percent VALU",
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms,
                          # the same kernel pair with the GPU to itself (two untimed steps whose mapping sections hold the lock to their end: the

@@ -140,6 +140,21 @@ __device__ inline int64_t contig_lower_bound_wpos(const IndexView& I, int contig
   return wave_lower_bound_wpos(I.pos, lo, hi, target, lane);
 }
 
+// Bucket of a hash in the rank table T.  Sketch hashes are window minima of minima (two strands, w windows): half of a read's
+// sketch lies below 2^28, four fifths below 2^29, 97 % below 2^30 (w = 8), so buckets of equal width (h >> tshift) put 25-35
+// hashes of a 10 kb read into the lowest ones and every search below ran 5-6 steps on the generic path.  Four pieces of
+// falling resolution follow the distribution — [0, 2^28): half of the buckets, [2^28, 2^29): a quarter, [2^29, 2^30): an eighth,
+// the rest 3/32 — monotone (every piece saturates where the next begins), so T's meaning "first rank whose bucket >= b"
+// and the searches are unchanged; the longest bucket of such a read drops below 16: four doubling steps (the `steps <= 4` path).
+__device__ __forceinline__ int l2_bucket(uint32_t h, int tshift) {
+  const uint32_t half = 1u << (31 - tshift);
+  const uint32_t b0 = min(h >> (tshift - 3), half);
+  const uint32_t b1 = min((max(h, 1u << 28) - (1u << 28)) >> (tshift - 2), half >> 1);
+  const uint32_t b2 = min((max(h, 1u << 29) - (1u << 29)) >> tshift, half >> 2);
+  const uint32_t b3 = (max(h, 1u << 30) - (1u << 30)) >> (tshift + 3);
+  return (int)(b0 + b1 + b2 + b3);
+}
+
 // Rank of a hash in the sorted sketch Q (lower bound).  T[b] = first rank whose hash >= b << tshift, so the answer lies
 // in a run of fewer than 2^steps elements starting at T[b]; because all of Q is sorted, the branch-free doubling search
 // below needs no upper limit (elements behind the bucket are larger than h anyway; Q is padded with 16 x 0xffffffff).
@@ -147,7 +162,7 @@ __device__ inline int64_t contig_lower_bound_wpos(const IndexView& I, int contig
 constexpr int L2_QPAD = 16;
 __device__ inline void l2_classify4(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int tshift, int steps, int s,
                                     const uint32_t (&h)[4], int (&code)[4]) {
-  int lo0 = T[h[0] >> tshift], lo1 = T[h[1] >> tshift], lo2 = T[h[2] >> tshift], lo3 = T[h[3] >> tshift];
+  int lo0 = T[l2_bucket(h[0], tshift)], lo1 = T[l2_bucket(h[1], tshift)], lo2 = T[l2_bucket(h[2], tshift)], lo3 = T[l2_bucket(h[3], tshift)];
   if (steps <= 4) {
 #define MM_L2_STEP(ST)                                                                                              \
     { const uint32_t v0 = Q[lo0 + ST - 1], v1 = Q[lo1 + ST - 1], v2 = Q[lo2 + ST - 1], v3 = Q[lo3 + ST - 1];         \
@@ -158,7 +173,7 @@ __device__ inline void l2_classify4(const uint32_t* __restrict__ Q, const uint16
     if (steps > 0) MM_L2_STEP(1)
 #undef MM_L2_STEP
   } else {
-    int hi0 = T[(h[0] >> tshift) + 1], hi1 = T[(h[1] >> tshift) + 1], hi2 = T[(h[2] >> tshift) + 1], hi3 = T[(h[3] >> tshift) + 1];
+    int hi0 = T[l2_bucket(h[0], tshift) + 1], hi1 = T[l2_bucket(h[1], tshift) + 1], hi2 = T[l2_bucket(h[2], tshift) + 1], hi3 = T[l2_bucket(h[3], tshift) + 1];
     for (int it = 0; it < steps; ++it) {
       const int m0 = min((lo0 + hi0) >> 1, s - 1), m1 = min((lo1 + hi1) >> 1, s - 1), m2 = min((lo2 + hi2) >> 1, s - 1), m3 = min((lo3 + hi3) >> 1, s - 1);
       const uint32_t v0 = Q[m0], v1 = Q[m1], v2 = Q[m2], v3 = Q[m3];
@@ -186,7 +201,7 @@ __device__ inline void l2_classify8(const uint32_t* __restrict__ Q, const uint16
   }
   int lo[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) lo[i] = T[h[i] >> tshift];
+  for (int i = 0; i < 8; ++i) lo[i] = T[l2_bucket(h[i], tshift)];
 #define MM_L2_STEP8(ST)                                                                   \
   { uint32_t v[8];                                                                        \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) v[i] = Q[lo[i] + ST - 1];               \
@@ -203,14 +218,14 @@ __device__ inline void l2_classify8(const uint32_t* __restrict__ Q, const uint16
   for (int i = 0; i < 8; ++i) code[i] = (lo[i] < s && ev[i] == h[i]) ? lo[i] : -(lo[i] + 1);
 }
 __device__ inline int l2_classify1(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int tshift, int steps, int s, uint32_t h) {
-  int lo = T[h >> tshift];
+  int lo = T[l2_bucket(h, tshift)];
   if (steps <= 4) {
     if (steps > 3) lo += Q[lo + 7] < h ? 8 : 0;
     if (steps > 2) lo += Q[lo + 3] < h ? 4 : 0;
     if (steps > 1) lo += Q[lo + 1] < h ? 2 : 0;
     if (steps > 0) lo += Q[lo] < h ? 1 : 0;
   } else {
-    int hi = T[(h >> tshift) + 1];
+    int hi = T[l2_bucket(h, tshift) + 1];
     for (int it = 0; it < steps; ++it) {
       const int m = min((lo + hi) >> 1, s - 1);
       const uint32_t v = Q[m];
@@ -296,11 +311,11 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   if (threadIdx.x < L2_QPAD) Q[s + threadIdx.x] = 0xffffffffu;
   if (threadIdx.x == 0) *tmaxp = 0;
   __syncthreads();
-  // T[b] = first rank whose hash >= b << tshift: element i is the answer for the buckets after Q[i-1]'s up to its own
+  // T[b] = first rank whose bucket (l2_bucket) is >= b: element i is the answer for the buckets after Q[i-1]'s up to its own
   // (i == s closes the table), so every T entry is written exactly once, without searching
   for (int i = threadIdx.x; i <= s; i += 64 * WAVES) {
-    const int lo = i ? (int)(Q[i - 1] >> tshift) + 1 : 0;
-    const int hi = i < s ? (int)(Q[i] >> tshift) : (1 << TBITS);
+    const int lo = i ? l2_bucket(Q[i - 1], tshift) + 1 : 0;
+    const int hi = i < s ? l2_bucket(Q[i], tshift) : (1 << TBITS);
     for (int bb = lo; bb <= hi; ++bb) T[bb] = (uint16_t)i;
   }
   __syncthreads();

@@ -142,17 +142,18 @@ __device__ inline int64_t contig_lower_bound_wpos(const IndexView& I, int contig
 
 // Bucket of a hash in the rank table T.  Sketch hashes are window minima of minima (two strands, w windows): half of a read's
 // sketch lies below 2^28, four fifths below 2^29, 97 % below 2^30 (w = 8), so buckets of equal width (h >> tshift) put 25-35
-// hashes of a 10 kb read into the lowest ones and every search below ran 5-6 steps on the generic path.  Four pieces of
-// falling resolution follow the distribution — [0, 2^28): half of the buckets, [2^28, 2^29): a quarter, [2^29, 2^30): an eighth,
-// the rest 3/32 — monotone (every piece saturates where the next begins), so T's meaning "first rank whose bucket >= b"
-// and the searches are unchanged; the longest bucket of such a read drops below 16: four doubling steps (the `steps <= 4` path).
+// hashes of a 10 kb read (40-55 of a 50 kb read) into the lowest ones and every search below ran 5-7 steps on the generic path.
+// The buckets follow the distribution instead: b = nb * (1 - (1 - h / 2^32)^10) — the tenth power sits between the shapes of
+// w = 6 and w = 16 — which leaves the longest bucket of a read at 8-15 entries in every class: four doubling steps.  Every
+// operation below is correctly rounded and monotone (no contraction possible: products feed products, the two fused
+// operations are written as such), so the bucket never falls as the hash rises — all that T ("first rank whose bucket
+// is >= b") and the searches need — and the table's builder and its readers evaluate the same instructions.
 __device__ __forceinline__ int l2_bucket(uint32_t h, int tshift) {
-  const uint32_t half = 1u << (31 - tshift);
-  const uint32_t b0 = min(h >> (tshift - 3), half);
-  const uint32_t b1 = min((max(h, 1u << 28) - (1u << 28)) >> (tshift - 2), half >> 1);
-  const uint32_t b2 = min((max(h, 1u << 29) - (1u << 29)) >> tshift, half >> 2);
-  const uint32_t b3 = (max(h, 1u << 30) - (1u << 30)) >> (tshift + 3);
-  return (int)(b0 + b1 + b2 + b3);
+#pragma clang fp contract(off)
+  const float nb = (float)(1u << (32 - tshift));
+  const float y = __builtin_fmaf(__uint2float_rz(h), -0x1p-32f, 1.0f);        // 1 - h / 2^32, in [0, 1]
+  const float y2 = y * y, y4 = y2 * y2, y8 = y4 * y4, y10 = y8 * y2;
+  return min((int)__builtin_fmaf(-y10, nb, nb), (1 << (32 - tshift)) - 1);
 }
 
 // Rank of a hash in the sorted sketch Q (lower bound).  T[b] = first rank whose hash >= b << tshift, so the answer lies
@@ -163,10 +164,11 @@ constexpr int L2_QPAD = 16;
 __device__ inline void l2_classify4(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int tshift, int steps, int s,
                                     const uint32_t (&h)[4], int (&code)[4]) {
   int lo0 = T[l2_bucket(h[0], tshift)], lo1 = T[l2_bucket(h[1], tshift)], lo2 = T[l2_bucket(h[2], tshift)], lo3 = T[l2_bucket(h[3], tshift)];
-  if (steps <= 4) {
+  if (steps <= 5) {
 #define MM_L2_STEP(ST)                                                                                              \
     { const uint32_t v0 = Q[lo0 + ST - 1], v1 = Q[lo1 + ST - 1], v2 = Q[lo2 + ST - 1], v3 = Q[lo3 + ST - 1];         \
       lo0 += v0 < h[0] ? ST : 0; lo1 += v1 < h[1] ? ST : 0; lo2 += v2 < h[2] ? ST : 0; lo3 += v3 < h[3] ? ST : 0; }
+    if (steps > 4) MM_L2_STEP(16)
     if (steps > 3) MM_L2_STEP(8)
     if (steps > 2) MM_L2_STEP(4)
     if (steps > 1) MM_L2_STEP(2)
@@ -192,7 +194,7 @@ __device__ inline void l2_classify4(const uint32_t* __restrict__ Q, const uint16
 // Eight at a time (the streaming passes hold eight chunks in registers): twice the LDS reads in flight per step.
 __device__ inline void l2_classify8(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int tshift, int steps, int s,
                                     const uint32_t (&h)[8], int (&code)[8]) {
-  if (steps > 4) {
+  if (steps > 5) {
     uint32_t a[4], b[4]; int ca[4], cb[4];
     for (int i = 0; i < 4; ++i) { a[i] = h[i]; b[i] = h[4 + i]; }
     l2_classify4(Q, T, tshift, steps, s, a, ca); l2_classify4(Q, T, tshift, steps, s, b, cb);
@@ -206,6 +208,7 @@ __device__ inline void l2_classify8(const uint32_t* __restrict__ Q, const uint16
   { uint32_t v[8];                                                                        \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) v[i] = Q[lo[i] + ST - 1];               \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) lo[i] += v[i] < h[i] ? ST : 0; }
+  if (steps > 4) MM_L2_STEP8(16)
   if (steps > 3) MM_L2_STEP8(8)
   if (steps > 2) MM_L2_STEP8(4)
   if (steps > 1) MM_L2_STEP8(2)
@@ -219,7 +222,8 @@ __device__ inline void l2_classify8(const uint32_t* __restrict__ Q, const uint16
 }
 __device__ inline int l2_classify1(const uint32_t* __restrict__ Q, const uint16_t* __restrict__ T, int tshift, int steps, int s, uint32_t h) {
   int lo = T[l2_bucket(h, tshift)];
-  if (steps <= 4) {
+  if (steps <= 5) {
+    if (steps > 4) lo += Q[lo + 15] < h ? 16 : 0;
     if (steps > 3) lo += Q[lo + 7] < h ? 8 : 0;
     if (steps > 2) lo += Q[lo + 3] < h ? 4 : 0;
     if (steps > 1) lo += Q[lo + 1] < h ? 2 : 0;

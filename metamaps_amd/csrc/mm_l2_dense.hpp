@@ -21,7 +21,7 @@
 
 namespace mm {
 
-constexpr int LD_TBITS = 12;                                    // bucket table over the top hash bits of the sketch
+constexpr int LD_TBITS = 12;                                    // bucket table over the sketch (l2_bucket)
 constexpr int LD_TSIZE = (1 << LD_TBITS) + 1;
 constexpr int LD_Q_LDS_MAX = 32768;                             // sketches up to this size are searched in LDS
 
@@ -45,7 +45,8 @@ __global__ void __launch_bounds__(256) l2_range_kernel(IndexView I, const int32_
 
 // rank / gap code of hash h: >= 0 matched rank, < 0 window only in gap -code-1 (gap s: above every query hash)
 __device__ inline int ld_classify(const uint32_t* __restrict__ Q, const uint32_t* __restrict__ T, int s, uint32_t h) {
-  int lo = (int)T[h >> (32 - LD_TBITS)], hi = (int)T[(h >> (32 - LD_TBITS)) + 1];
+  const int bkt = l2_bucket(h, 32 - LD_TBITS);                 // (buckets follow the distribution of sketch hashes: mm_l2.hpp)
+  int lo = (int)T[bkt], hi = (int)T[bkt + 1];
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (Q[mid] < h) lo = mid + 1; else hi = mid; }
   return (lo < s && Q[lo] == h) ? lo : -(lo + 1);
 }
@@ -64,10 +65,10 @@ __global__ void __launch_bounds__(256) l2_codes_kernel(IndexView I, const int32_
   const int s = sk_n[r];
   const uint32_t* __restrict__ Qg = sk_hash + mz_off[r];
   if (q_in_lds) for (int i = threadIdx.x; i < s; i += 256) Ql[i] = Qg[i];
-  // T[b] = first rank whose hash >= b << (32 - LD_TBITS): element i closes the buckets after Q[i-1]'s up to its own
+  // T[b] = first rank whose bucket (l2_bucket) is >= b: element i closes the buckets after Q[i-1]'s up to its own
   for (int i = threadIdx.x; i <= s; i += 256) {
-    const int lo = i ? (int)(Qg[i - 1] >> (32 - LD_TBITS)) + 1 : 0;
-    const int hi = i < s ? (int)(Qg[i] >> (32 - LD_TBITS)) : (1 << LD_TBITS);
+    const int lo = i ? l2_bucket(Qg[i - 1], 32 - LD_TBITS) + 1 : 0;
+    const int hi = i < s ? l2_bucket(Qg[i], 32 - LD_TBITS) : (1 << LD_TBITS);
     for (int bb = lo; bb <= hi; ++bb) T[bb] = (uint32_t)i;
   }
   __syncthreads();

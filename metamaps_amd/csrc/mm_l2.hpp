@@ -150,10 +150,11 @@ __device__ inline int64_t contig_lower_bound_wpos(const IndexView& I, int contig
 // is >= b") and the searches need — and the table's builder and its readers evaluate the same instructions.
 __device__ __forceinline__ int l2_bucket(uint32_t h, int tshift) {
 #pragma clang fp contract(off)
-  const float nb = (float)(1u << (32 - tshift));
-  const float y = __builtin_fmaf(__uint2float_rz(h), -0x1p-32f, 1.0f);        // 1 - h / 2^32, in [0, 1]
+  const float c = (float)(1u << (32 - tshift)) - 0.0625f;       // (just below nb: the product truncates to nb - 1 at most, no clamp)
+  const float y = __builtin_fmaf((float)h, -0x1p-32f, 1.0f);    // 1 - h / 2^32, in [0, 1] (v_cvt_f32_u32: to nearest, monotone; the
+                                                                 //  round-towards-zero conversion is ten instructions of software here)
   const float y2 = y * y, y4 = y2 * y2, y8 = y4 * y4, y10 = y8 * y2;
-  return min((int)__builtin_fmaf(-y10, nb, nb), (1 << (32 - tshift)) - 1);
+  return (int)__builtin_fmaf(-y10, c, c);
 }
 
 // Rank of a hash in the sorted sketch Q (lower bound).  T[b] = first rank whose hash >= b << tshift, so the answer lies

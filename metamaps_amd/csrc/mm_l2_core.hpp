@@ -106,4 +106,23 @@ template <typename DT> MM_HD void l2_wonly_event(L2StateT<DT>& S, int g, int sig
 template <typename DT> MM_HD void l2_add_wonly(L2StateT<DT>& S, int g) { l2_wonly_event(S, g, +1); }
 template <typename DT> MM_HD void l2_del_wonly(L2StateT<DT>& S, int g) { l2_wonly_event(S, g, -1); }
 
+// Bucket of a hash in the rank table T.  Sketch hashes are window minima of minima (two strands, w windows): half of a read's
+// sketch lies below 2^28, four fifths below 2^29, 97 % below 2^30 (w = 8), so buckets of equal width (h >> tshift) put 25-35
+// hashes of a 10 kb read (40-55 of a 50 kb read) into the lowest ones and every search below ran 5-7 steps on the generic path.
+// The buckets follow the distribution instead: b = nb * (1 - (1 - h / 2^32)^10) — the tenth power sits between the shapes of
+// w = 6 and w = 16 — which leaves the longest bucket of a read at 8-15 entries in every class: four doubling steps.  Every
+// operation below is correctly rounded and monotone (no contraction possible: products feed products, the two fused
+// operations are written as such), so the bucket never falls as the hash rises — all that T ("first rank whose bucket
+// is >= b") and the searches need — and the table's builder and its readers evaluate the same instructions.
+MM_HD int l2_bucket(uint32_t h, int tshift) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  const float c = (float)(1u << (32 - tshift)) - 0.0625f;       // (just below nb: the product truncates to nb - 1 at most, no clamp)
+  const float y = __builtin_fmaf((float)h, -0x1p-32f, 1.0f);    // 1 - h / 2^32, in [0, 1] (v_cvt_f32_u32: to nearest, monotone; the
+                                                                 //  round-towards-zero conversion is ten instructions of software here)
+  const float y2 = y * y, y4 = y2 * y2, y8 = y4 * y4, y10 = y8 * y2;
+  return (int)__builtin_fmaf(-y10, c, c);
+}
+
 }  // namespace mm

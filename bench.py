@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r05_traffic.json", "r04_traffic.json")]   # the newest committed PMC summary that exists
 
 
 def parse_args():
@@ -185,7 +185,7 @@ def main():
         reads = batches[0]
         ctx.synchronize()
         contig_len = ref.lengths().astype(np.int32)
-        agg = {"ms_l2": 0.0, "ms_hf": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0, "stats": None, "em_iters": 0, "bases": 0, "done_t": []}
+        agg = {"ms_l2": 0.0, "ms_hf": 0.0, "ms_mz": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0, "stats": None, "em_iters": 0, "bases": 0, "done_t": []}
         rec_bufs = [np.empty(max(64 * (hi - lo), 1 << 16), dtype=capi.RECORD_DTYPE) for _ in ctxs]   # host result buffers reused by every step
         map_lock, agg_lock = threading.Lock(), threading.Lock()
         front_lock, back_lock = threading.Lock(), threading.Lock()
@@ -253,7 +253,7 @@ def main():
                 agg["host_ms"] = {"map_batch": (tt[1] - tt[0]) * 1e3, "mapq_fetch": (tt[2] - tt[1]) * 1e3, "em_prepare_iterate": (tt[3] - tt[2]) * 1e3,
                                   "posteriors": (tt[4] - tt[3]) * 1e3}
                 agg["ms_l2"] += st["ms_l2"]; agg["launches"] += 1; agg["l2_stream"] += st["sum_l2_stream_entries"]
-                agg["ms_hf"] += st["ms_hit_filter"]; agg["hf_units"] += st["sum_hits"] + st["sum_sketch"]
+                agg["ms_hf"] += st["ms_hit_filter"]; agg["hf_units"] += st["sum_hits"] + st["sum_sketch"]; agg["ms_mz"] += st["ms_minimizer"]
                 agg["stats"] = st; agg["em_iters"] = len(lls); agg["bases"] += st["bases_long_enough"]; agg["done_t"].append(tt[4])
             return st
 
@@ -278,7 +278,7 @@ def main():
             em_turn["next"] = 0; step(wi, True, 0)
         sched = ("staged" if (args.staged_map and W > 1) else True) if (args.serialise_map or args.staged_map) and not args.free_overlap else False
         run_steps(max(warmup, 0), sched)
-        agg.update({"ms_l2": 0.0, "ms_hf": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0, "bases": 0, "done_t": []})
+        agg.update({"ms_l2": 0.0, "ms_hf": 0.0, "ms_mz": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0, "bases": 0, "done_t": []})
         barrier()
         t0 = time.perf_counter()
         run_steps(steps, sched)
@@ -364,15 +364,7 @@ def main():
     out = None
     if rank == 0:
         agg, st, info = R["agg"], R["st"], R["info"]
-        # roofline of the dominant kernel — whichever of the two big kernels took longer per launch (hipEvents on the ctx
-        # stream around each).  Algorithmic bytes per launch, SURVEY.md §8 D3:
-        #   K5/K6  l2_kernel            8 B per streamed index entry                          (8·Σ_c M_{r,c})
-        #   K3     seed_filter_kernel   8 B per sketch hash probed + 8 B per seed hit         (8·s_r + 8·H_r)
-        nl = max(agg["launches"], 1)
-        cands = [("l2_kernel (launches of one step: <true,u8,4,2> + <true,u8,2,2>)", 8.0 * agg["l2_stream"] / nl, agg["ms_l2"] / nl),
-                 ("seed_filter_stream_kernel", 8.0 * agg["hf_units"] / nl, agg["ms_hf"] / nl)]
-        dom_name, dom_bytes, dom_ms = max(cands, key=lambda c: c[2])
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        roof = roofline_block(args, R)
         len_txt = f"{args.read_len}" if not args.read_len_min else f"{args.read_len_min}-{args.read_len}"
         out_workload = (f"{args.reads} synthetic {len_txt} bp {'PacBio' if args.pacbio else 'ONT'}-error reads {'per GPU' if args.scaling == 'weak' else f'in all, sharded over {world} GPU(s)'} vs synthetic miniSeq+H-shaped index "
                         f"({R['desc']}; {R['reference_bp'] / 1e9:.2f} Gbp), k=16 w={w}, --all")
@@ -403,35 +395,8 @@ def main():
                 "stage_ms_timed_region": {kk: round(st[kk], 3) for kk in st if kk.startswith("ms_")},
                 "host_wall_ms": {kk: round(v, 3) for kk, v in agg.get("host_ms", {}).items()},
             },
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, dom_name),
-                         "note": "achieved = algorithmic bytes / hipEvent time of the launch pair with the GPU to itself (two steps right behind the timed region, mapping sections serialised; rocprofv3 of this bench with --serialise-map --workers 3 shows the same durations: profiles/r04_kernel_stats.txt).  In the timed region the kernels of two steps share the GPU, a launch waits for and runs beside the other step's kernels: *_timed_region, averaged over the distinct read batches (rocprofv3 of the default command: profiles/r04_kernel_stats_default_cmd.txt); traffic = "
-                                 "FETCH_SIZE x 2 + WRITE_SIZE of one launch pair on batch 0 (profiles/r04_pmc_hbm_traffic.txt): 1.9 x the algorithmic bytes since the workgroups are "
-                                 "launched in the order of their candidates' positions (3.5 x before, 21 percent of its L2 requests hitting: profiles/r03_l2_cache.txt); VALU in 88 percent of the issue "
-                                 "slots (profiles/r03_sq_counters.txt, measured before that change).  seed_filter_stream_kernel: 45 percent VALU, bound by random requests per CU (DESIGN.md 4); "
-                                 "minimizer_kernel 99 percent VALU",
-                         "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms,
-                         # the same kernel pair with the GPU to itself (two untimed steps whose mapping sections hold the lock to their end: the
-                         # hipEvents of the timed region also count the time a launch waits behind another worker's kernels, rocprofv3's
-                         # durations — profiles/r04_kernel_stats.txt — do not): what the kernel does, beside what the pipeline makes of it
-                         "alone": ({"ms_per_launch": R["st_clean"]["ms_l2"], "algorithmic_bytes_per_launch": 8.0 * R["st_clean"]["sum_l2_stream_entries"],
-                                    "achieved": 8.0 * R["st_clean"]["sum_l2_stream_entries"] / (R["st_clean"]["ms_l2"] * 1e-3) / 1e9,
-                                    "frac": 8.0 * R["st_clean"]["sum_l2_stream_entries"] / (R["st_clean"]["ms_l2"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                                   if dom_name.startswith("l2_kernel") and R["st_clean"].get("ms_l2", 0) > 0 else None),
-                         "other_kernels": {n: {"ms_per_launch": m, "algorithmic_bytes_per_launch": b, "achieved": (b / (m * 1e-3) / 1e9 if m > 0 else 0.0)}
-                                           for n, b, m in cands if n != dom_name}},
+            "roofline": roof,
         }
-        # A roofline figure is a statement about a kernel: achieved / frac / ms_per_launch are those of the launches that had the GPU to
-        # themselves (HIP events on the worker's stream, two steps right behind the timed region with the mapping sections serialised: the
-        # durations profiles/r04_kernel_stats.txt shows).  What the same launches take while they share the GPU with the other worker's
-        # step — inside the timed region, the default scheduling — stays beside it as *_timed_region.
-        rl = out["roofline"]
-        if rl.get("alone"):
-            rl["achieved_timed_region"], rl["frac_timed_region"], rl["ms_per_launch_timed_region"] = rl["achieved"], rl["frac"], rl["ms_per_launch"]
-            rl["algorithmic_bytes_per_launch_timed_region"] = rl["algorithmic_bytes_per_launch"]
-            rl["achieved"], rl["frac"], rl["ms_per_launch"] = rl["alone"]["achieved"], rl["alone"]["frac"], rl["alone"]["ms_per_launch"]
-            rl["algorithmic_bytes_per_launch"] = rl["alone"]["algorithmic_bytes_per_launch"]
-            del rl["alone"]
         if not args.no_cpu_baseline and world == 1:              # (the contract asks for it at N=1 only)
             # the CLI of the e2e_cli leg is another process on this device: what this one holds in reserve goes back first (the contexts'
             # cached blocks, which since round 4 are pieces of the ~100 GB of pooled index-build buffers: with those kept the device had
@@ -505,23 +470,8 @@ def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
     if mode == 5:
         # configs[4] at its size: the index of the whole reference does not fit the device, so the chunk rule is evaluated on the indexes of contig
         # ranges, as the CLI does (metamaps_main.cpp: every cut inside a range is final, the range's last, open chunk starts the next range)
-        maxmem, C = int(gib * (1 << 30)), ref.count
-        range_bases = int(float(os.environ.get("MM_BENCH_RANGE_GBP", 8)) * 1e9)
-        plan, c0, info = [0], 0, {"n_contigs": C, "n_entries": 0, "n_unique_hashes": 0, "hbm_bytes": 0}
-        while c0 < C:
-            c1, bases = c0, 0
-            while c1 < C and (bases < range_bases or c1 == c0):
-                bases += int(contig_len[c1]); c1 += 1
-            sl = ref.slice(c0, c1 - c0); ri = ctx.index(sl, k, w, auto_threshold=False); sl.close()
-            loc = ri.plan_chunks(maxmem)
-            ii = ri.info(); info["n_entries"] += ii["n_entries"] if c0 == 0 or len(loc) > 1 else 0; info["hbm_bytes"] = max(info["hbm_bytes"], ii["hbm_bytes"])
-            ri.close()
-            if len(loc) == 1 and c1 < C:
-                range_bases = bases * 2; continue
-            plan += [c0 + x for x in loc[1:]]
-            if c1 == C:
-                break
-            c0 += loc[-1]
+        from metamaps_amd.chunkplan import plan_chunks_by_ranges
+        plan, info = plan_chunks_by_ranges(ctx, ref, contig_len, k, w, int(gib * (1 << 30)), int(float(os.environ.get("MM_BENCH_RANGE_GBP", 8)) * 1e9))
     else:
         whole = ctx.index(ref, k, w)
         info = whole.info()
@@ -530,17 +480,13 @@ def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
     bounds = [(a, (plan[i + 1] if i + 1 < len(plan) else ref.count) - a) for i, a in enumerate(plan)]
     base = [a for a, _ in bounds]
     # per-chunk freqThreshold from the histogram accumulated over the chunks (never cleared, winSketch.hpp:452-494)
-    acc, thr, thrs, chunk_idx, t_build = {}, 2**31 - 1, [], [], []
+    from metamaps_amd.chunkplan import AccumulatedThreshold
+    acc_thr, thrs, chunk_idx, t_build = AccumulatedThreshold(), [], [], []
     for a, n in bounds:
         tb = time.time()
         sl = ref.slice(a, n); ix = ctx.index(sl, k, w, auto_threshold=False); sl.close()
         ctx.synchronize(); t_build.append(time.time() - tb)
-        counts, nh = ix.freq_hist()
-        for c_, n_ in zip(counts.tolist(), nh.tolist()):
-            acc[c_] = acc.get(c_, 0) + n_
-        cc = np.array(sorted(acc), dtype=np.int64); hh = np.array([acc[c_] for c_ in cc.tolist()], dtype=np.int64)
-        thr = capi.lib().mm_freq_threshold_from_hist(cc.ctypes.data, hh.ctypes.data, len(cc), ix.info()["n_unique_hashes"], thr)
-        thrs.append(int(thr)); ix.set_freq_threshold(thr)
+        thrs.append(acc_thr.next(ix))
         if mode == 3:
             chunk_idx.append(ix)
         else:
@@ -695,18 +641,73 @@ def run_chunked(args, ctxs, k, w, rank, world, barrier, allreduce_max_sum):
     return out
 
 
-def measured_traffic(args, kernel: str):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-    collected and corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes; profiles/r02_pmc_hbm_traffic.txt).
-    bench.py cannot run the profiler itself, so the number is reported only for the workload it was measured on."""
-    try:
-        t = json.load(open(TRAFFIC_FILE))
+def roofline_block(args, R):
+    """The `roofline` object of the bench line.  One regime per field:
+      *_alone         the kernel's launches of ONE step with the GPU to itself — HIP events on the worker's stream around the launches, in the two steps
+                      right behind the timed region whose mapping sections hold the lock to their end (the durations `rocprofv3 --kernel-trace --stats`
+                      shows for this command with --serialise-map: profiles/r05_kernel_stats.txt); algorithmic bytes from THAT step's counters
+      *_timed_region  the same events inside the timed region, averaged over its steps: two worker contexts share the GPU there, so a launch also
+                      waits for and runs beside the other step's kernels (profiles/r05_kernel_stats_default_cmd.txt); bytes averaged over the same steps
+    Algorithmic bytes per launch follow SURVEY.md section 8 D3 (B_map = ceil(L/4) + 8 s + 8 H + 8 sum M + 32 O per read):
+      K1 minimizer stage   ceil(L/4)            the packed bases it reads (what it writes, 8 B per minimizer, is not part of D3; VALU-bound)
+      K3 seed filter       8 (s + H)            one probe per sketch hash + every seed hit of the kept lists
+      K5 L2 kernel pair    8 sum M              every streamed index entry
+    frac = bytes / ms_alone / 8 TB/s.  The dominant kernel — `kernel`, `achieved`, `frac`, `ms_per_launch` at the top level — is the one with the largest
+    ms_alone.  traffic = HBM bytes per launch from the committed PMC passes (a file constant, not measured by this run): traffic_source."""
+    agg, st_t, st_a = R["agg"], R["st"], R["st_clean"]
+    nl = max(agg["launches"], 1)
+    def entry(kernels, ms_a, b_a, ms_t, b_t, prof_names, bound_note):
+        tr, src = measured_traffic(args, prof_names)
+        e = {"kernels": kernels, "ms_alone": ms_a, "algorithmic_bytes": b_a, "achieved": (b_a / (ms_a * 1e-3) / 1e9 if ms_a > 0 else 0.0),
+             "ms_timed_region": ms_t, "algorithmic_bytes_timed_region": b_t, "achieved_timed_region": (b_t / (ms_t * 1e-3) / 1e9 if ms_t > 0 else 0.0),
+             "traffic": tr, "traffic_source": src, "bound": bound_note}
+        e["frac"] = e["achieved"] / HBM_PEAK_GBS; e["frac_timed_region"] = e["achieved_timed_region"] / HBM_PEAK_GBS
+        e["traffic_over_algorithmic"] = (tr / b_a) if tr and b_a else None
+        return e
+    kern = {
+        "K1": entry("minimizer_kernel<2> + jstar_kernel + compact_tiles_kernel (the stage: mm_map_stats.ms_minimizer)", st_a["ms_minimizer"], st_a["bases_long_enough"] / 4.0,
+                    agg["ms_mz"] / nl, agg["bases"] / 4.0 / nl, ["mm::minimizer_kernel<2>"],
+                    "VALU: two MurmurHash3 x64-128 per position = sixteen 64-bit multiplies (profiles/r04_sq_counters.txt: 97 percent of the issue slots); the HBM fraction is not its limit"),
+        "K3": entry("seed_filter_stream_kernel<false> (mm_map_stats.ms_hit_filter)", st_a["ms_hit_filter"], 8.0 * (st_a["sum_hits"] + st_a["sum_sketch"]),
+                    agg["ms_hf"] / nl, 8.0 * agg["hf_units"] / nl, ["mm::seed_filter_stream_kernel<false>"],
+                    "random 64-byte requests: table sector, occurrence list, survivors (tools/ubench/randread: 49e9 requests/s from HBM, 81e9/s from L2; profiles/r05_randread.txt); VALU 44 percent"),
+        "K5": entry("l2_kernel<true,u8,4,2> + l2_kernel<true,u8,2,2> (the launch pair of a step: mm_map_stats.ms_l2)", st_a["ms_l2"], 8.0 * st_a["sum_l2_stream_entries"],
+                    agg["ms_l2"] / nl, 8.0 * agg["l2_stream"] / nl, ["mm::l2_kernel<true, unsigned char, 4, 2>", "mm::l2_kernel<true, unsigned char, 2, 2>"],
+                    "VALU: 2.8 wave-instructions per streamed entry, 88 percent of the issue slots (profiles/r04_sq_counters.txt)"),
+    }
+    dom = max(kern, key=lambda kk: kern[kk]["ms_alone"])
+    d = kern[dom]
+    d3 = {"reads_2bit": st_a["bases_long_enough"] / 4.0, "probes_8s": 8.0 * st_a["sum_sketch"], "seed_hits_8H": 8.0 * st_a["sum_hits"],
+          "l2_stream_8M": 8.0 * st_a["sum_l2_stream_entries"], "records_32O": 32.0 * st_a["n_mappings"]}
+    d3_sum = sum(d3.values())
+    return {"bound": "hbm", "kernel": f"{dom}: {d['kernels']}", "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"], "traffic": d["traffic"],
+            "ms_per_launch": d["ms_alone"], "algorithmic_bytes_per_launch": d["algorithmic_bytes"], "regime": "alone (see kernels.*.ms_alone); the same kernel inside the timed region: kernels." + dom + ".*_timed_region",
+            "kernels": kern,
+            "whole_step": {"d3_bytes": d3, "algorithmic_bytes": d3_sum, "ms_per_step": R["ms_step"], "achieved": d3_sum / (R["ms_step"] * 1e-3) / 1e9,
+                           "frac": d3_sum / (R["ms_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "note": "all D3 bytes of one step (counters of the step measured alone) over the timed region's ms_per_step: what the pipeline as a whole moves per second"},
+            "how_to_recompute": "frac = kernels.K.algorithmic_bytes / (kernels.K.ms_alone * 1e-3) / 1e9 / peak; ms_alone agrees with the avg_ms column of profiles/r05_kernel_stats.txt "
+                                "(K5: the sum of its two launches; K1: minimizer_kernel<2> + compact_tiles_kernel + jstar_kernel), ms_timed_region with profiles/r05_kernel_stats_default_cmd.txt; "
+                                "the bytes follow from config.per_step (counters of the last timed step; the step measured alone maps another batch: kernels.K.algorithmic_bytes is its own)"}
+
+
+def measured_traffic(args, prof_names):
+    """(HBM bytes per launch, where they come from) for the kernels named as the rocprofv3 summaries name them, from the newest committed PMC summary
+    (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, collected and corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes:
+    tools/collect_profiles.sh -> profiles/rNN_pmc_hbm_traffic.txt -> rNN_traffic.json).  bench.py cannot run the profiler itself: the number is a FILE
+    CONSTANT, reported only for the workload it was measured on, and the source string says so."""
+    for path in TRAFFIC_FILES:
+        try:
+            t = json.load(open(path))
+        except Exception:
+            continue
         if t.get("shape") != args.shape or t.get("reads") != args.reads or t.get("read_len") != args.read_len or args.read_len_min or args.scale != 1.0:
-            return None
-        hits = [v for name, v in t.get("by_kernel", {}).items() if kernel.split(" ")[0] in name]   # (K5 runs as two launches per step: the
-        return sum(hits) if hits else None                                                          #  4-wave and the 2-wave workgroup shape)
-    except Exception:
-        return None
+            return None, "no PMC pass for this workload"
+        vals = [t.get("by_kernel", {}).get(n) for n in prof_names]
+        if any(v is None for v in vals):
+            continue
+        return float(sum(vals)), f"file constant: {os.path.relpath(path, ROOT)} ({' + '.join(prof_names)}; FETCH_SIZE x corr + WRITE_SIZE of one launch on batch 0, not measured by this run)"
+    return None, "no committed PMC summary names this kernel"
 
 
 def cpu_baseline_and_cli(args, R, k, w):

@@ -290,6 +290,10 @@ int mm_debug_hits(mm_mapping* m, int64_t* offsets, int32_t* contig, int32_t* wpo
 int mm_debug_candidates(mm_mapping* m, int64_t* offsets, int32_t* triples /* contig,start,end */, int64_t cap);   /* :346-386 */
 int mm_debug_l2(mm_mapping* m, int64_t* per_cand /* contig, meanPos, shared, optBeg, optEnd, accepted */, int64_t cap);      /* :460-538 */
 int mm_debug_min_hits(mm_mapping* m, int32_t* min_hits /* [n_reads] */);
+/* measurement tap: lengths of the occurrence lists the batch's sketch hashes ask `idx` for (minimizerPosLookupIndex.find, computeMap.hpp:310):
+ * hist[0] = hashes not in the index, hist[c] = lists of c entries (c < n_bins - 2), hist[n_bins - 2] = longer lists that are kept,
+ * hist[n_bins - 1] = lists cut by freqThreshold (:317) */
+int mm_debug_probed_lists(mm_mapping* m, const mm_index* idx, int64_t* hist, int32_t n_bins);
 
 /* ---- EM (replaces meta::doEM's iteration, fEM.h:501-661, and the per-read likelihood fEM.h:234-373) */
 /* Mappings are given read-wise: read r owns entries [read_off[r], read_off[r+1]).  For entry i:

@@ -157,6 +157,7 @@ def lib() -> C.CDLL:
             "mm_debug_candidates": (C.c_int, [vp, vp, vp, i64]),
             "mm_debug_l2": (C.c_int, [vp, vp, i64]),
             "mm_debug_min_hits": (C.c_int, [vp, vp]),
+            "mm_debug_probed_lists": (C.c_int, [vp, vp, vp, i32]),
             "mm_em_create": (C.c_int, [vp, i64, vp, vp, vp, vp, i32, P(vp)]),
             "mm_em_create_from_mapping": (C.c_int, [vp, vp, vp, vp, i32, i32, P(vp)]),
             "mm_em_taxon_counts": (C.c_int, [vp, vp]),
@@ -571,6 +572,11 @@ class Mapping:
     def debug_min_hits(self):
         a = np.zeros(self.n_reads, dtype=np.int32)
         self.ctx.check(lib().mm_debug_min_hits(self.h, _ptr(a)))
+        return a
+
+    def debug_probed_lists(self, idx: "Index", n_bins: int = 66) -> np.ndarray:
+        a = np.zeros(n_bins, dtype=np.int64)
+        self.ctx.check(lib().mm_debug_probed_lists(self.h, idx.h, _ptr(a), n_bins))
         return a
 
     def close(self):

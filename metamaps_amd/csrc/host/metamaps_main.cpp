@@ -85,7 +85,11 @@ struct PhaseClock {
 // whole.  (MM_CLI_FULL_TEARDOWN=1 keeps the orderly path: the tests of handle lifetimes under a leak checker use it.)
 [[noreturn]] void finish_fast() { std::cout.flush(); std::cerr.flush(); fflush(nullptr); _exit(0); }
 
-[[noreturn]] void die(const std::string& m) { std::cerr << m << std::endl; exit(1); }
+// An error exit leaves through _exit: helper threads (the HIP runtime coming up beside the parse of `classify`, the worker contexts' prewarm, the
+// readers) may be inside the driver at this moment, and exit() would run static destructors and the runtime's atexit handlers under them.
+[[noreturn]] void die(const std::string& m) { std::cerr << m << std::endl; std::cout.flush(); fflush(nullptr); _exit(1); }
+// a helper thread that is joined on every way out of its scope (an exception that passes a joinable std::thread ends in std::terminate)
+struct JoinOnExit { std::thread& t; ~JoinOnExit() { if (t.joinable()) t.join(); } };
 void ck(mm_ctx* ctx, int st, const char* what) { if (st != MM_OK) die(std::string(what) + ": " + mm_last_error(ctx)); }
 
 struct Options { std::map<std::string, std::string> v; bool all = false, stream = false, shard = false, em_host = false; };
@@ -486,6 +490,7 @@ int map_mode(const Options& o, const std::string& mode) {
                    : getenv("MM_CLI_WORKERS") ? (size_t)std::max(1, atoi(getenv("MM_CLI_WORKERS"))) : 4;
   std::vector<mm_ctx*> wctx(G * WPD, nullptr);
   std::thread prewarm;
+  JoinOnExit prewarm_guard{prewarm};
   auto start_prewarm = [&]() {
     if (prewarm.joinable() || getenv("MM_CLI_NO_PREWARM")) return;
     int64_t query_bytes = 0; for (auto& q : queries) query_bytes += (int64_t)file_size(q);
@@ -1730,6 +1735,7 @@ int main(int argc, char** argv) {
       for (auto& d : devs) if (mm_ctx_create(d.phys, &d.ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
       since("contexts created");
     });
+    JoinOnExit ctx_thread_guard{ctx_thread};
     const std::function<void()> need_devices = [&] {
       if (!ctx_thread.joinable()) return;
       const auto w0 = std::chrono::steady_clock::now();

@@ -18,7 +18,7 @@
 #include <vector>
 
 namespace {
-[[noreturn]] inline void seq_reader_die(const std::string& m) { std::cerr << m << std::endl; exit(1); }
+[[noreturn]] inline void seq_reader_die(const std::string& m) { std::cerr << m << std::endl; std::cout.flush(); fflush(nullptr); _exit(1); }   // (_exit: other threads may be inside the HIP runtime, metamaps_main.cpp die())
 
 // FASTA/FASTQ(.gz) records with kseq's observable behaviour (common/kseq.h:170-207)
 // Two sources: a (gz) file read through zlib in 1 MiB pieces, or a byte range of a memory-mapped plain file (MemView: the parallel

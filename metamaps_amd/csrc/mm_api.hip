@@ -549,6 +549,7 @@ int mm_mapping_concat(mm_ctx* ctx, mm_mapping* const* parts, const int32_t* cont
     for (int p = 0; p < n_parts; ++p) {
       mm_mapping* P = parts[p];
       MM_REQUIRE(P->n_reads == n, MM_ERR_ARG, "chunk results cover different read sets");
+      MM_REQUIRE(!P->sketch_only && P->rec_off.p && (P->n_rec == 0 || P->rec.p), MM_ERR_STATE, "mm_mapping_concat: a part holds no records (a mm_sketch_batch result is no chunk mapping)");
       pv[(size_t)p] = PartDev{P->rec_off.p, P->rec.p, contig_base ? contig_base[p] : 0, 0};
       if (P->ctx->device != ctx->device) {                       // (the part's own stream has been waited for by the call that made it)
         t_off[(size_t)p].alloc((size_t)n + 1); t_rec[(size_t)p].alloc(std::max<size_t>((size_t)P->n_rec, 1));
@@ -597,6 +598,7 @@ int mm_mapping_gather(mm_ctx* ctx, int owner, int64_t n_reads, const int32_t* re
     for (int i = 0; i < n_parts; ++i) {
       MM_REQUIRE(chunk_id[i] >= 0 && chunk_id[i] < n_chunks && chunk_rank[chunk_id[i]] == rank && parts[i] && parts[i]->n_reads == n_reads, MM_ERR_ARG, "mm_mapping_gather: a part is not a chunk of this rank");
       MM_REQUIRE(parts[i]->ctx->device == ctx->device, MM_ERR_ARG, "mm_mapping_gather: parts live on the rank's own device");
+      MM_REQUIRE(!parts[i]->sketch_only && parts[i]->rec_off.p && (parts[i]->n_rec == 0 || parts[i]->rec.p), MM_ERR_STATE, "mm_mapping_gather: a part holds no records (a mm_sketch_batch result is no chunk mapping)");
       part_of[(size_t)chunk_id[i]] = i;
     }
     for (int c = 0; c < n_chunks; ++c) MM_REQUIRE(chunk_rank[c] != rank || part_of[(size_t)c] >= 0, MM_ERR_ARG, "mm_mapping_gather: a chunk of this rank has no part");
@@ -747,6 +749,15 @@ int mm_debug_min_hits(mm_mapping* m, int32_t* min_hits) {
   if (!m || !min_hits) return MM_ERR_ARG;
   memcpy(min_hits, m->h_min_hits.data(), m->h_min_hits.size() * sizeof(int32_t));
   return MM_OK;
+}
+
+int mm_debug_probed_lists(mm_mapping* m, const mm_index* idx, int64_t* hist, int32_t n_bins) {
+  if (m && m->released) return MM_ERR_STATE;
+  if (!m || !idx || !hist || n_bins < 3) return MM_ERR_ARG;
+  return guarded(m->ctx, [&] {
+    MM_HIP(hipSetDevice(m->ctx->device));
+    mm::probed_list_hist(m->ctx, idx, m, n_bins, hist);
+  });
 }
 
 // ---- EM -----------------------------------------------------------------------------------------------

@@ -70,7 +70,12 @@ inline SlabSet& slab_set() { static SlabSet s; return s; }
 inline void dev_free(void* p, size_t bytes) {
   if (!p) return;
   if (slab_set().give_back(p, bytes)) return;                    // (a piece of a pooled block: the block stays the device's)
-  dev_meter().used[dev_current()] -= (long long)bytes; (void)hipFree(p);
+  // the bytes go off the account of the device the block LIVES on (hipMalloc charged the device current at that time): the thread that frees —
+  // a context's destructor on the CLI's main thread, another context trimming this one's cache — may have any device current
+  int d = dev_current();
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, p) == hipSuccess && at.device >= 0 && at.device < 64) d = at.device; else (void)hipGetLastError();
+  dev_meter().used[d] -= (long long)bytes; (void)hipFree(p);
 }
 inline hipError_t dev_mem_info(size_t* fr, size_t* tot) {
   const hipError_t e = hipMemGetInfo(fr, tot);

@@ -506,18 +506,45 @@ void index_plan_chunks(mm_ctx* ctx, const mm_index* I, uint64_t max_memory, std:
 // ---------------------------------------------------------------------------------------------------
 // Persistent device index (what createIndex / the archive loads of mapAgainstIndex are to the reference,
 // mapWrap.h:358-405, :443-554, winSketch.hpp:73-83): the arrays of mm_index as they lie in HBM, so that a load is file -> pinned
-// staging -> device with no kernel at all.  Little endian, versioned; every array is preceded by its element count and the file ends
-// with a closing word (a truncated file is refused).
-//   "MMINDEX1"  u32 version=1  i32 k  i32 w  i32 dir_shift  i32 dup_sat  i32 freq_threshold  u32 tab_buckets  u32 0
+// staging -> device, and the only kernel is the one that sums every array up again.  Little endian, versioned; every array is preceded by
+// its element count and a checksum of its bytes as they lay in HBM (array_sum_kernel: a position-dependent 64-bit sum, taken on the
+// device on both sides, so a load also vouches for its own copies), and the file ends with a closing word (a truncated file is
+// refused).  Counts are held against the header (N entries, U hashes, the contig table) before anything is allocated.
+//   "MMINDEX1"  u32 version=2  i32 k  i32 w  i32 dir_shift  i32 dup_sat  i32 freq_threshold  u32 tab_buckets  u32 0
 //   i64 n_contigs  i64 N  i64 U  i64 n_dup  i64 n_hist
 //   i64 hist[n_hist][2]  i32 contig_len[n_contigs]  u64 h_cstart[n_contigs + 1]
-//   { u64 count, bytes }  for pos, cstart, occ, occ16, tab, dir, dir_off, dup_bits, dup_rank, dup_dist
+//   { u64 count, u64 checksum, bytes }  for pos, cstart, occ, occ16, tab, dir, dir_off, dup_bits, dup_rank, dup_dist
 //   u64 0x58444e4958444e49
 // ---------------------------------------------------------------------------------------------------
 namespace {
+constexpr uint32_t IDX_VERSION = 2;
+// checksum of an array as it lies in HBM: sum over its 8-byte words of mix(word + C * index) (+ the same over the bytes of a last partial
+// word); a sum, so the order of the threads does not matter
+__device__ __forceinline__ uint64_t sum_mix(uint64_t x) { x ^= x >> 31; x *= 0x9E3779B97F4A7C15ull; x ^= x >> 29; return x; }
+__global__ void __launch_bounds__(256) array_sum_kernel(const uint64_t* __restrict__ w, uint64_t n_words, const uint8_t* __restrict__ tail, int n_tail,
+                                                        unsigned long long* __restrict__ out) {
+  uint64_t acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * 256) acc += sum_mix(w[i] + 0xD6E8FEB86659FD93ull * (i + 1));
+  if (blockIdx.x == 0 && threadIdx.x == 0) for (int t = 0; t < n_tail; ++t) acc += sum_mix((uint64_t)tail[t] + 0xD6E8FEB86659FD93ull * (n_words + 1 + (uint64_t)t));
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, (unsigned long long)acc);
+}
+template <typename T> uint64_t array_sum(const mm::DBuf<T>& a, size_t count, hipStream_t st) {
+  const size_t bytes = count * sizeof(T);
+  if (!bytes) return 0;
+  mm::DBuf<unsigned long long> d(1); d.zero(st);
+  const uint64_t nw = bytes >> 3;
+  array_sum_kernel<<<dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>((nw + 255) / 256, 1), 4096)), dim3(256), 0, st>>>((const uint64_t*)a.p, nw, (const uint8_t*)a.p + (nw << 3), (int)(bytes & 7), d.p);
+  MM_KERNEL_CHECK();
+  return (uint64_t)d.to_host(st)[0];
+}
 constexpr uint64_t IDX_TAIL = 0x58444e4958444e49ull;
 constexpr size_t IDX_STAGE = (size_t)64 << 20;
-struct IdxFile { FILE* f = nullptr; ~IdxFile() { if (f) fclose(f); } };
+struct IdxFile {
+  FILE* f = nullptr;
+  ~IdxFile() { if (f) fclose(f); }
+  int close() { const int rc = f ? fclose(f) : 0; f = nullptr; return rc; }   // (a deferred write error — quota, a network file system — shows up here)
+};
 struct Pinned2 {                                                   // two staging buffers: the device copies into / out of one while the file has the other
   char* b[2] = {nullptr, nullptr};
   Pinned2() { for (auto& p : b) MM_HIP(hipHostMalloc((void**)&p, IDX_STAGE, hipHostMallocDefault)); }
@@ -530,7 +557,7 @@ void get(FILE* f, void* p, size_t bytes, const char* what) {
   MM_REQUIRE(bytes == 0 || fread(p, 1, bytes, f) == bytes, MM_ERR_ARG, std::string("truncated index file (") + what + ")");
 }
 template <typename T> void put_array(FILE* f, const mm::DBuf<T>& a, size_t count, Pinned2& pin, hipStream_t st, const char* what) {
-  const uint64_t c64 = count; put(f, &c64, 8, what);
+  const uint64_t c64 = count, sum = array_sum(a, count, st); put(f, &c64, 8, what); put(f, &sum, 8, what);
   const size_t bytes = count * sizeof(T);
   const char* src = (const char*)a.p;
   size_t off = 0; int cur = 0;
@@ -543,9 +570,10 @@ template <typename T> void put_array(FILE* f, const mm::DBuf<T>& a, size_t count
     off += n; cur ^= 1;
   }
 }
-template <typename T> void get_array(FILE* f, mm::DBuf<T>& a, size_t min_alloc, Pinned2& pin, hipStream_t st, uint64_t expect, const char* what) {
-  uint64_t c64 = 0; get(f, &c64, 8, what);
-  MM_REQUIRE(expect == (uint64_t)-1 || c64 == expect, MM_ERR_ARG, std::string("index file is inconsistent (") + what + ")");
+// the element count must lie in [lo, hi] (what the header's N, U and contig table allow for this array) before anything is allocated
+template <typename T> void get_array(FILE* f, mm::DBuf<T>& a, size_t min_alloc, Pinned2& pin, hipStream_t st, uint64_t lo, uint64_t hi, const char* what) {
+  uint64_t c64 = 0, sum = 0; get(f, &c64, 8, what); get(f, &sum, 8, what);
+  MM_REQUIRE(c64 >= lo && c64 <= hi, MM_ERR_ARG, std::string("index file is inconsistent (") + what + ")");
   MM_REQUIRE(c64 < ((uint64_t)1 << 40), MM_ERR_ARG, std::string("corrupt index file (") + what + ")");
   a.alloc(std::max<size_t>((size_t)c64, min_alloc));
   const size_t bytes = (size_t)c64 * sizeof(T);
@@ -559,6 +587,7 @@ template <typename T> void get_array(FILE* f, mm::DBuf<T>& a, size_t min_alloc, 
     off += n; cur ^= 1;
   }
   MM_HIP(hipStreamSynchronize(st));
+  MM_REQUIRE(array_sum(a, (size_t)c64, st) == sum, MM_ERR_ARG, std::string("index file is damaged: checksum of the ") + what + " differs");
 }
 }  // namespace
 
@@ -570,7 +599,7 @@ void index_save(const mm_index* I, const char* path) {
   MM_REQUIRE(fc.f != nullptr, MM_ERR_ARG, std::string("cannot open ") + path + " for writing");
   setvbuf(fc.f, nullptr, _IONBF, 0);
   Pinned2 pin;
-  const uint32_t head[8] = {1u, (uint32_t)I->k, (uint32_t)I->w, (uint32_t)I->dir_shift, (uint32_t)I->dup_sat, (uint32_t)I->freq_threshold, I->tab_buckets, 0u};
+  const uint32_t head[8] = {IDX_VERSION, (uint32_t)I->k, (uint32_t)I->w, (uint32_t)I->dir_shift, (uint32_t)I->dup_sat, (uint32_t)I->freq_threshold, I->tab_buckets, 0u};
   const int64_t dims[5] = {I->n_contigs, I->N, I->U, I->n_dup, (int64_t)I->hist.size()};
   put(fc.f, "MMINDEX1", 8, "magic"); put(fc.f, head, sizeof head, "header"); put(fc.f, dims, sizeof dims, "header");
   std::vector<int64_t> hh; for (auto& kv : I->hist) { hh.push_back(kv.first); hh.push_back(kv.second); }
@@ -590,6 +619,7 @@ void index_save(const mm_index* I, const char* path) {
   put_array(fc.f, I->dup_dist, I->dup_dist.n, pin, st, "duplicate distances");
   put(fc.f, &IDX_TAIL, 8, "closing word");
   MM_REQUIRE(fflush(fc.f) == 0, MM_ERR_ARG, std::string("write to ") + path + " failed");
+  MM_REQUIRE(fc.close() == 0, MM_ERR_ARG, std::string("closing ") + path + " failed: the index file is incomplete");
 }
 
 void index_load(mm_ctx* ctx, const char* path, mm_index* I) {
@@ -599,33 +629,36 @@ void index_load(mm_ctx* ctx, const char* path, mm_index* I) {
   setvbuf(fc.f, nullptr, _IONBF, 0);
   char magic[8]; uint32_t head[8]; int64_t dims[5];
   get(fc.f, magic, 8, "magic"); get(fc.f, head, sizeof head, "header"); get(fc.f, dims, sizeof dims, "header");
-  MM_REQUIRE(memcmp(magic, "MMINDEX1", 8) == 0 && head[0] == 1u, MM_ERR_ARG, std::string(path) + " is not an index file of this version");
+  MM_REQUIRE(memcmp(magic, "MMINDEX1", 8) == 0 && head[0] == IDX_VERSION, MM_ERR_ARG, std::string(path) + " is not an index file of this version");
   I->ctx = ctx;
   I->k = (int)head[1]; I->w = (int)head[2]; I->dir_shift = (int)head[3]; I->dup_sat = (int)head[4]; I->freq_threshold = (int)head[5]; I->tab_buckets = head[6];
   I->n_contigs = dims[0]; I->N = dims[1]; I->U = dims[2]; I->n_dup = dims[3];
-  MM_REQUIRE(I->k >= 1 && I->k <= 64 && I->w >= 1 && I->n_contigs >= 0 && I->n_contigs < (1LL << 31) && I->N >= 0 && I->U >= 0 && I->U <= I->N && dims[4] >= 0 &&
-             dims[4] <= I->N + 1 && I->dir_shift >= 1 && I->dir_shift < 30, MM_ERR_ARG, "corrupt index header");
+  MM_REQUIRE(I->k >= 1 && I->k <= 64 && I->w >= 1 && I->w <= 4096 && I->n_contigs >= 0 && I->n_contigs < (1LL << 31) && I->N >= 0 && I->N < (1LL << 38) && I->U >= 0 && I->U <= I->N &&
+             I->n_dup >= 0 && I->n_dup <= I->N && dims[4] >= 0 && dims[4] <= std::min<int64_t>(I->N + 1, 1 << 21) && I->dir_shift >= 1 && I->dir_shift < 30 &&
+             I->dup_sat >= 1 && I->dup_sat <= 65535 && I->tab_buckets >= 1 && (I->N == 0 || I->tab_buckets == mm::tab_buckets_for(I->U)), MM_ERR_ARG, "corrupt index header");
   std::vector<int64_t> hh((size_t)dims[4] * 2);
   get(fc.f, hh.data(), hh.size() * 8, "histogram");
   I->hist.clear(); for (size_t i = 0; i + 1 < hh.size(); i += 2) I->hist[hh[i]] = hh[i + 1];
   I->contig_len.resize((size_t)I->n_contigs); I->h_cstart.resize((size_t)I->n_contigs + 1);
   get(fc.f, I->contig_len.data(), I->contig_len.size() * 4, "contig lengths");
   get(fc.f, I->h_cstart.data(), I->h_cstart.size() * 8, "contig entry ranges");
-  MM_REQUIRE(I->h_cstart.front() == 0 && (int64_t)I->h_cstart.back() == I->N, MM_ERR_ARG, "index file is inconsistent (contig entry ranges)");
+  MM_REQUIRE(I->h_cstart.front() == 0 && (int64_t)I->h_cstart.back() == I->N && std::is_sorted(I->h_cstart.begin(), I->h_cstart.end()), MM_ERR_ARG,
+             "index file is inconsistent (contig entry ranges)");
+  uint64_t dir_total = 0;                                          // what build_directory lays out for these contigs
+  for (int32_t len : I->contig_len) { MM_REQUIRE(len >= 0, MM_ERR_ARG, "index file is inconsistent (contig lengths)"); dir_total += ((uint64_t)len >> I->dir_shift) + 2; }
   Pinned2 pin;
-  const uint64_t ANY = (uint64_t)-1;
-  get_array(fc.f, I->pos, 1, pin, st, ANY, "entries");
-  get_array(fc.f, I->cstart, 1, pin, st, ANY, "contig starts");
-  get_array(fc.f, I->occ, 1, pin, st, ANY, "occurrences");
-  get_array(fc.f, I->occ16, 1, pin, st, ANY, "occurrence bins");
-  get_array(fc.f, I->tab, 1, pin, st, (uint64_t)I->tab_buckets * 8, "hash table");
-  get_array(fc.f, I->dir, 1, pin, st, ANY, "position directory");
-  get_array(fc.f, I->dir_off, 1, pin, st, ANY, "directory offsets");
-  get_array(fc.f, I->dup_bits, 1, pin, st, ANY, "duplicate bits");
-  get_array(fc.f, I->dup_rank, 1, pin, st, ANY, "duplicate ranks");
-  get_array(fc.f, I->dup_dist, 1, pin, st, ANY, "duplicate distances");
-  MM_REQUIRE((int64_t)I->pos.n >= I->N && (int64_t)I->cstart.n >= I->n_contigs + 1 && (int64_t)I->dir_off.n >= I->n_contigs + 1 && I->occ16.n >= I->occ.n &&
-             I->dup_rank.n >= I->dup_bits.n, MM_ERR_ARG, "index file is inconsistent (array sizes)");
+  // element counts as index_build leaves them: a few spare elements behind N entries / P <= N + 7 U padded occurrences, never fewer than the kernels read
+  const uint64_t N = (uint64_t)I->N, U = (uint64_t)I->U, C = (uint64_t)I->n_contigs, nb64 = (N + 63) >> 6, SP = 64;
+  get_array(fc.f, I->pos, 1, pin, st, N, N + SP, "entries");
+  get_array(fc.f, I->cstart, 1, pin, st, C + 1, C + 1 + SP, "contig starts");
+  get_array(fc.f, I->occ, 1, pin, st, N ? N : 1, N + 7 * U + SP, "occurrences");
+  get_array(fc.f, I->occ16, 1, pin, st, I->occ.n, (uint64_t)I->occ.n + SP, "occurrence bins");
+  get_array(fc.f, I->tab, 1, pin, st, (uint64_t)I->tab_buckets * 8, (uint64_t)I->tab_buckets * 8, "hash table");
+  get_array(fc.f, I->dir, 1, pin, st, std::max<uint64_t>(dir_total, 1), std::max<uint64_t>(dir_total, 1), "position directory");
+  get_array(fc.f, I->dir_off, 1, pin, st, C + 1, C + 1, "directory offsets");
+  get_array(fc.f, I->dup_bits, 1, pin, st, std::max<uint64_t>(nb64, 1), nb64 + SP, "duplicate bits");
+  get_array(fc.f, I->dup_rank, 1, pin, st, (uint64_t)I->dup_bits.n + (N ? 1 : 0), (uint64_t)I->dup_bits.n + SP, "duplicate ranks");
+  get_array(fc.f, I->dup_dist, 1, pin, st, 1, N + SP, "duplicate distances");
   uint64_t tail = 0; get(fc.f, &tail, 8, "closing word");
   MM_REQUIRE(tail == IDX_TAIL, MM_ERR_ARG, "index file is inconsistent (closing word)");
   I->d_contig_len.alloc(std::max<size_t>(I->contig_len.size(), 1));

@@ -1015,6 +1015,21 @@ __global__ void __launch_bounds__(256) sum_u32_kernel(const uint32_t* __restrict
   if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
 
+// debug tap (mm_debug_probed_lists): how long are the occurrence lists the sketches of a batch ask for?  One thread per sketch hash;
+// hist[0] = hash not in the index, hist[c] = lists of c entries (c < nb - 2), hist[nb - 2] = longer lists that are kept,
+// hist[nb - 1] = lists cut by freqThreshold (computeMap.hpp:317)
+__global__ void __launch_bounds__(256) probed_list_hist_kernel(IndexView I, const uint32_t* __restrict__ sk_hash, const uint64_t* __restrict__ off,
+                                                               const int32_t* __restrict__ sk_n, int nb, unsigned long long* __restrict__ hist) {
+  const int r = blockIdx.x, s = sk_n[r];
+  const uint64_t o = off[r];
+  for (int i = threadIdx.x; i < s; i += 256) {
+    uint32_t cnt = 0; uint64_t start = 0;
+    int b = 0;
+    if (index_find(I, sk_hash[o + i], &cnt, &start)) b = (uint64_t)cnt < (uint64_t)(int64_t)I.freq_threshold ? (int)min(cnt, (uint32_t)(nb - 2)) : nb - 1;
+    atomicAdd(&hist[b], 1ull);
+  }
+}
+
 __global__ void read_hit_bounds_kernel(const uint64_t* __restrict__ off, const uint64_t* __restrict__ hit_off, int64_t n,
                                        uint64_t* __restrict__ read_hit_off) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2201,6 +2216,17 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   T.collect();
   M->stats.n_mappings = M->n_rec;
   for (int64_t r = 0; r < n; ++r) if (M->h_rec_off[(size_t)r + 1] > M->h_rec_off[(size_t)r]) M->stats.n_reads_mapped++;
+}
+
+void probed_list_hist(mm_ctx* ctx, const mm_index* I, const mm_mapping* M, int nb, int64_t* hist) {
+  hipStream_t st = ctx->stream;
+  DBuf<unsigned long long> d((size_t)nb);
+  d.zero(st);
+  if (M->n_reads > 0)
+    probed_list_hist_kernel<<<dim3((unsigned)M->n_reads), dim3(256), 0, st>>>(make_view(I), M->sk_hash.p, M->mz.off.p, M->sk_n.p, nb, d.p);
+  MM_KERNEL_CHECK();
+  auto h = d.to_host(st);
+  for (int i = 0; i < nb; ++i) hist[i] = (int64_t)h[(size_t)i];
 }
 
 }  // namespace mm

@@ -53,4 +53,5 @@ struct mm_mapping {
 namespace mm {
 void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_map_params& P, mm_mapping* M);
 void mapping_add_qualities(mm_ctx* ctx, mm_mapping* M, int k);
+void probed_list_hist(mm_ctx* ctx, const mm_index* I, const mm_mapping* M, int nb, int64_t* hist);
 }

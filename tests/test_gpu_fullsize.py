@@ -1,14 +1,20 @@
 """Parity at BASELINE.json's full single-GPU size, on the workload `value` is quoted on: the SURVEY D1 community reference
 (12 000 microbial genomes in 3 000 species of 1-12 strains + 24 human-like contigs with 45 % library repeats and N runs,
-26.76 Gbp, k = 16, w = 8; bench.py builds the same one) — configs[1] — and on the shapes of configs[3] and configs[4] as far as
-one GPU carries them: mixed 1-50 kb PacBio-error reads against the same reference split by the --maxmemory chunk rule into
-resident chunk indexes (config 3) and into more chunks that are built, mapped and dropped in turn (config 4's multi-pass
-streaming).  No oracle run is feasible at 26.76 Gbp, so what is checked is what must hold at any size:
+26.76 Gbp, k = 16, w = 8; bench.py builds the same one) — configs[1] —, on configs[2] as one GPU can stand in for eight (the batch as
+eight read shards mapped in turn, the EM's per-rank partial sums added on the host), and on configs[3] at the size of its per-GPU
+share: 125 000 mixed 1-50 kb PacBio-error reads (10^6 / 8 GPUs) against the same reference split by the --maxmemory chunk rule into
+resident chunk indexes, and into more chunks that are built, mapped and dropped in turn (multi-pass streaming; configs[4] at ITS size,
+the 300 Gbp reference, is tests/test_gpu_refseq_scale.py).  No oracle run is feasible at 26.76 Gbp, so what is checked is what must hold at any size:
 
   configs[1]  truth recovery at species level; determinism; shard invariance (the multi-GPU partition of the reads);
               the seed-hit pre-filter is exact (MM_NO_HIT_FILTER=1), the K5 sweep equals the full slide (MM_L2_FULL=1), eager = lazy
               strand tie-break; record invariants; EM: frequencies sum to 1, log-likelihood never decreases, posteriors sum to 1,
               abundant genomes come out on top
+  configs[2]  the 100 000 reads as eight contiguous shards (dist.shard_range): records of the shards one behind the other ==
+              records of the whole batch, byte for byte; the EM run as eight ranks would run it — every shard its own EM problem, one E+M
+              step each per iteration, the eight partial (T + 1)-vectors added on the host (what ncclAllReduce does between physical
+              GPUs, fEM.h:583-600) — follows the single-rank trajectory to 1e-12 and ends at the same frequencies; a shard's one-rank
+              RCCL iteration (MM_EM_FORCE_COLLECTIVE=1: P1-P3' | ncclAllReduce | finalize) == its plain partial sums, normalised
   configs[3]  the chunk rule on the whole index gives >= 3 chunks; mapping against the chunk indexes and merging read-wise in chunk
               order (unifyFiles, mapWrap.h:128-145) == mapping against the whole index when no hash is cut by freqThreshold (a hash
               spread over several chunks meets a different count in each, so only then is equality exact); with the reference's
@@ -32,7 +38,8 @@ COMM = dict(seed=20260928, n_genomes=12000, n_species=3000, n_genera=600, median
             human_contigs=24, human_bases=int(3.1e9), repeat_fraction=0.45, n_fraction=0.01, n_repeat_families=1000,
             total_bases_target=26_762_276_280)
 N_READS, RLEN = 100_000, 10_000                               # configs[1]: the bench batch at its size
-N_MIXED, MIXED_MIN, MIXED_MAX = 64_000, 1_000, 50_000         # configs[3]: half of the per-GPU share of 125 000 in ONE call (0.8 Gbp, what bench.py --config 3 maps per step beside the four resident chunk indexes: 227 of 288 GiB; the CLI maps such reads in batches of <= 0.256 Gbp)
+N_MIXED, MIXED_MIN, MIXED_MAX = 125_000, 1_000, 50_000        # configs[3]: the per-GPU share of 10^6 reads over 8 GPUs, mapped as TWO calls of 62 500 reads (0.8 Gbp each, what bench.py --config 3 maps per step beside the four resident chunk indexes: 227 of 288 GiB; the CLI maps such reads in batches of <= 0.256 Gbp)
+N_HALVES = 2
 INT_MAX = 2**31 - 1
 GIB = 1 << 30
 
@@ -57,6 +64,20 @@ def _map(ctx, idx, reads, env=None, qualities=True):
     return off, rec, st
 
 
+def _halves(world):
+    """the mixed batch as N_HALVES device-side slices: [(first read, SeqSet)]"""
+    return world["mixed_halves"]
+
+
+def _join(parts):
+    """[(first read, off, rec)] of consecutive read ranges -> (off, rec) of the whole batch"""
+    offs, recs, base = [np.zeros(1, dtype=parts[0][1].dtype)], [], 0
+    for first, off, rec in parts:
+        rec = rec.copy(); rec["read"] += first
+        offs.append(off[1:] + base); recs.append(rec); base += len(rec)
+    return np.concatenate(offs), np.concatenate(recs)
+
+
 def _subset(ctx, reads, which):
     rl = reads.lengths()
     return ctx.seqset([reads.fetch(int(i), int(rl[i])) for i in which])
@@ -75,9 +96,13 @@ def world():
     off, rec, stats = _map(ctx, idx, reads)
     mixed, mtruth = ctx.synth_reads(ref, seed=777, n_reads=N_MIXED, read_len=MIXED_MAX, read_len_min=MIXED_MIN, sub_rate=0.02, ins_rate=0.08, del_rate=0.02,
                                     frac_random=0.05, n_abundant=100)
+    bounds = [N_MIXED * i // N_HALVES for i in range(N_HALVES + 1)]
+    halves = [(a, mixed.slice(a, b - a)) for a, b in zip(bounds, bounds[1:])]
     w = dict(ctx=ctx, ref=ref, genome=genome, species=species, contig_species=contig_species, idx=idx, reads=reads, truth=truth, off=off, rec=rec, stats=stats,
-             mixed=mixed, mtruth=mtruth, stage=1, chunk_idx=[])
+             mixed=mixed, mixed_halves=halves, mtruth=mtruth, stage=1, chunk_idx=[])
     yield w
+    for _a, h in halves:
+        h.close()
     for ix in w["chunk_idx"]:
         ix.close()
     if w["idx"] is not None:
@@ -185,6 +210,68 @@ def test_em_properties(world):
     em.close(); M.close()
 
 
+# ---------------------------------------------------------------------------------------------- configs[2] on one GPU
+def test_eight_read_shards_equal_the_whole_batch(world, monkeypatch):
+    """configs[2] (100k x 10 kb reads sharded over 8 GPUs, EM sufficient statistics all-reduced per iteration) as far as one GPU can carry it"""
+    from metamaps_amd import capi
+    from metamaps_amd.dist import shard_range, em_distributed
+    ctx, idx, reads = world["ctx"], world["idx"], world["reads"]
+    n_taxa = COMM["n_genomes"] + 1
+    contig_len = world["ref"].lengths().astype(np.int64)
+    shards, ems, recs, offs = [], [], [], []
+    for rk in range(8):
+        lo, hi = shard_range(N_READS, rk, 8)
+        sl = reads.slice(lo, hi - lo)
+        M = ctx.map_batch(idx, sl, K, W); M.add_qualities(K)
+        off, rec = M.fetch()
+        offs.append((lo, off.copy(), rec.copy()))
+        ems.append(ctx.em_from_mapping(M, world["genome"], contig_len, n_taxa))
+        M.release_intermediates()
+        shards.append((sl, M))
+    off, rec = _join(offs)
+    assert np.array_equal(off, world["off"]) and rec.tobytes() == world["rec"].tobytes()
+    # single rank: the whole batch
+    M = ctx.map_batch(idx, reads, K, W); M.add_qualities(K)
+    em = ctx.em_from_mapping(M, world["genome"], contig_len, n_taxa)
+    counts = em.taxon_counts()
+    assert np.array_equal(counts, sum(e.taxon_counts() for e in ems))
+    seen = (counts > 0).astype(np.float64)
+    f_one, lls_one = em.run(seen / seen.sum())
+    # eight ranks: every rank its E+M step on its own reads, the partial sums added (here: on the host), normalisation and stop rule as fEM.h:606-639
+    def step(f):
+        tot, ll = np.zeros(n_taxa), 0.0
+        for e in ems:
+            part, l = e.iterate(f)
+            tot += part; ll += l
+        return tot, ll
+    f_eight, lls_eight = em_distributed(step, lambda v: v, seen)
+    assert len(lls_eight) == len(lls_one) >= 2
+    assert np.allclose(lls_eight, lls_one, rtol=1e-12, atol=0), (lls_eight, lls_one)
+    assert np.allclose(f_eight, f_one, rtol=1e-9, atol=1e-15)
+    post1, best1 = em.posteriors(f_one)
+    best8, base = [], 0
+    for e, (_lo, _o, r_) in zip(ems, offs):                       # best mapping per read: an entry index of the shard's own EM problem
+        b = e.posteriors(f_eight)[1]
+        best8.append(np.where(b >= 0, b + base, -1)); base += len(r_)
+    best8 = np.concatenate(best8)
+    differ = np.nonzero(best8 != best1)[0]                        # reads2Taxon: the same best mapping for every read (two mappings whose posteriors agree to 1e-9 may swap)
+    assert len(differ) <= 5 and all(abs(post1[best8[r]] - post1[best1[r]]) < 1e-9 for r in differ), differ[:10]
+    # the RCCL form of one rank's iteration (one-rank communicator, the collective kept): == its plain partial sums, normalised
+    monkeypatch.setenv("MM_EM_FORCE_COLLECTIVE", "1")
+    ctx.comm_init(capi.Context.comm_unique_id(), 0, 1)
+    f0 = seen / seen.sum()
+    for e in ems[:2]:
+        part, ll = e.iterate(f0)
+        fn, lla = e.iterate_allreduce(f0)
+        assert np.allclose(fn, part / part.sum(), rtol=1e-12, atol=0) and abs(lla - ll) <= 1e-12 * abs(ll)
+    monkeypatch.delenv("MM_EM_FORCE_COLLECTIVE")
+    for e in ems:
+        e.close()
+    for sl, Ms in shards:
+        Ms.close(); sl.close()
+    em.close(); M.close()
+
+
 # ---------------------------------------------------------------------------------------------- configs[3] / [4] shapes
 def _microbial_subset(world, n):
     """reads of the mixed batch that stem from microbial genomes or from nowhere (a read from a human-like contig draws 1e7+ seed
@@ -200,7 +287,8 @@ def test_mixed_lengths_unchunked(world):
     ctx, idx, mixed = world["ctx"], world["idx"], world["mixed"]
     rl = mixed.lengths()
     assert rl.min() >= MIXED_MIN * 0.8 and rl.max() > 40_000 and np.median(rl) < 12_000      # log-uniform: half the reads below ~7 kb
-    off, rec, st = _map(ctx, idx, mixed)
+    off, rec = _join([(a,) + _map(ctx, idx, h)[:2] for a, h in _halves(world)])   # two calls of 62 500 reads
+    assert len(off) == N_MIXED + 1
     world["mixed_off"], world["mixed_rec"] = off, rec
     frac_mapped, frac_right = _species_recovery(world, off, rec, world["mtruth"], random_may_map=0.05)
     assert frac_mapped > 0.97 and frac_right > 0.98, (frac_mapped, frac_right)
@@ -272,15 +360,23 @@ def test_resident_chunks_equal_whole_index(world):
     thr = _accumulated_thresholds(hists, uniq)
     world["thr3"] = thr
     assert thr == sorted(thr) and 100 < thr[0] and 1000 < thr[-1] < 3000, thr   # the histogram accumulates over the chunks: the cut rises towards the whole index's
-    parts = []
-    for ix, t in zip(world["chunk_idx"], thr):                    # (chunks 2.. reuse the sketches of the first mapping, as the CLI does; the
-        ix.set_freq_threshold(t)                                  #  streamed run below computes them per chunk: the two must agree)
-        parts.append(ctx.map_batch(ix, mixed, K, W, sketch_of=parts[0] if parts else None))
-        if len(parts) > 1:
-            parts[-1].release_intermediates()                     # (the first part keeps the sketches the others borrow)
-    U = capi.Mapping.concat(ctx, parts, base); U.add_qualities(K)
-    off, rec = U.fetch()
-    world["res3_off"], world["res3_rec"] = off.copy(), rec.copy()
+    for ix, t in zip(world["chunk_idx"], thr):
+        ix.set_freq_threshold(t)
+    joined = []
+    for a, half in _halves(world):
+        parts = []
+        for ix in world["chunk_idx"]:                             # (chunks 2.. reuse the sketches of the first mapping, as the CLI does; the
+            parts.append(ctx.map_batch(ix, half, K, W, sketch_of=parts[0] if parts else None))   #  streamed run below computes them per chunk: the two must agree)
+            if len(parts) > 1:
+                parts[-1].release_intermediates()                 # (the first part keeps the sketches the others borrow)
+        U = capi.Mapping.concat(ctx, parts, base); U.add_qualities(K)
+        o_, r_ = U.fetch()
+        joined.append((a, o_.copy(), r_.copy()))
+        for p in parts:
+            p.close()
+        U.close()
+    off, rec = _join(joined)
+    world["res3_off"], world["res3_rec"] = off, rec
     key = rec["read"].astype(np.int64) << 44 | rec["ref_contig"].astype(np.int64) << 30 | rec["ref_start"].astype(np.int64)
     assert (np.diff(key) > 0).all()                               # within a read: chunk order = contig order, positions ascending
     sums = np.add.reduceat(rec["mapq"], off[:-1][np.diff(off) > 0])
@@ -292,9 +388,6 @@ def test_resident_chunks_equal_whole_index(world):
         return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in ("ref_contig", "ref_start", "shared"))
     same = sum(_same(r) for r in range(0, N_MIXED, 7))
     assert same > 0.9 * len(range(0, N_MIXED, 7))                 # (thresholds differ per chunk, so a few reads may differ from the unchunked run)
-    for p in parts:
-        p.close()
-    U.close()
 
 
 def test_streamed_chunks_equal_resident_chunks(world):
@@ -307,19 +400,24 @@ def test_streamed_chunks_equal_resident_chunks(world):
     for ix in world["chunk_idx"]:
         ix.close()
     world["chunk_idx"] = []
-    lens = mixed.lengths()
     bounds = _chunk_bounds(world["plan3"], ref.count)
-    host = []
+    host = [[] for _ in _halves(world)]
     for (a, n), t in zip(bounds, world["thr3"]):
         sl = ref.slice(a, n); ix = ctx.index(sl, K, W, auto_threshold=False); sl.close()
         ix.set_freq_threshold(t)
-        M = ctx.map_batch(ix, mixed, K, W)
-        o, r = M.fetch(); host.append((o.copy(), r.copy()))
-        M.close(); ix.close()
-    V = capi.Mapping.from_parts(ctx, lens, host, [a for a, _ in bounds], K, W); V.add_qualities(K)
-    off, rec = V.fetch()
+        for hi_, (_first, half) in enumerate(_halves(world)):     # every read batch against the chunk that is on the device
+            M = ctx.map_batch(ix, half, K, W)
+            o, r = M.fetch(); host[hi_].append((o.copy(), r.copy()))
+            M.close()
+        ix.close()
+    joined = []
+    for (first, half), parts_h in zip(_halves(world), host):
+        V = capi.Mapping.from_parts(ctx, half.lengths(), parts_h, [a for a, _ in bounds], K, W); V.add_qualities(K)
+        o_, r_ = V.fetch()
+        joined.append((first, o_.copy(), r_.copy()))
+        V.close()
+    off, rec = _join(joined)
     assert np.array_equal(off, world["res3_off"]) and rec.tobytes() == world["res3_rec"].tobytes()
-    V.close()
     bounds = _chunk_bounds(world["plan8"], ref.count)
     assert len(bounds) >= 8
     sub = _subset(ctx, mixed, world["sub_which"])

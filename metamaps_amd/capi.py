@@ -89,9 +89,10 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise FileNotFoundError(f"{LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'`")
-        L = C.CDLL(LIB_PATH)
+        path = os.environ.get("MM_LIB_PATH") or LIB_PATH            # (MM_LIB_PATH: an alternative build of the library, tools/ab.sh — A/B runs of two kernel variants on one box)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is missing — run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(path)
         vp, i32, i64, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
         P = C.POINTER
         sig = {

@@ -29,6 +29,7 @@
 //
 // Not provided: classifyU (disabled upstream).
 
+#include "../mm_env.hpp"
 #include "../../../include/metamaps_hip.h"
 #include "seq_reader.hpp"
 #include "host_util.hpp"
@@ -276,85 +277,48 @@ void format_records(const std::vector<std::string>& names, const std::vector<int
   }
 }
 
-int map_mode(const Options& o, const std::string& mode) {
-  const bool from_index = mode == "mapAgainstIndex", only_index = mode == "index";
-  if (!from_index && !o.v.count("reference")) die("Provide reference file (s)");
-  if ((from_index || only_index) && !o.v.count("index")) die("Please provide index");
-  if (!only_index && !o.v.count("query")) die("Provide query file (s)");
-  if (!only_index && !o.v.count("output")) die("Provide output file");
+// (defined behind map_mode; `mapDirectly --then-classify DBDIR` runs it in-process on the files it has just written)
+enum class EmReduce { None, Rccl, Host };
+int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::string& mapped, const std::string& db, size_t minReadsU,
+                 const std::function<void()>& leave_now, const std::function<void()>& need_devices);
+
+// One run of mapDirectly / index / mapAgainstIndex.  The state every stage shares lives in the object; the stages are its methods, in the order run()
+// calls them: parameters -> devices -> reference (parsed, packed, uploaded) or stored index -> chunk plan -> placement of the chunk indexes
+// (replicated / sharded / streamed) -> read batches through the worker pipeline (replicated) or chunk-major rounds with the exchange of the
+// records (sharded / streamed) -> writers -> optionally classify in-process.  (Until round 5 this was one 800-line function.)
+struct MapRun {
+  const Options& o; const std::string mode;
+  const bool from_index, only_index;
   std::string ref; uint64_t refSize = 0, maxMem = 0; int k = 16, w = 0, minLen = 1000; double pval = 1e-3; float pi = 80;
-  const std::string ipre = o.v.count("index") ? o.v.at("index") : "";
-  if (!from_index) {
-    ref = o.v.at("reference");
-    refSize = file_size(ref);
-    maxMem = o.v.count("maxmemory") ? (uint64_t)(std::pow(1024, 3) * std::stoull(o.v.at("maxmemory"))) : 0;
-    if (o.v.count("maxmemory-bytes")) maxMem = std::stoull(o.v.at("maxmemory-bytes"));
-    k = o.v.count("kmer") ? std::stoi(o.v.at("kmer")) : 16;
-    pval = o.v.count("pval") ? std::stod(o.v.at("pval")) : 1e-3;
-    minLen = o.v.count("minReadLen") ? std::stoi(o.v.at("minReadLen")) : 1000;
-    pi = o.v.count("perc_identity") ? std::stof(o.v.at("perc_identity")) : 80;
-    if (o.v.count("window")) {                                   // parseCmdArgs.hpp:363-374
-      w = std::stoi(o.v.at("window"));
-      pval = mm_estimate_pvalue(minLen * 2 / w, k, pi, minLen, refSize);
-    } else w = mm_recommended_window(pval, k, pi, minLen, refSize);
-  } else {                                                       // the parameters travel with the index (mapWrap.h:447-461)
-    std::ifstream a(ipre + ".arguments");
-    if (!a.is_open()) die("Cannot open file " + ipre + ".arguments for deserialization.");
-    std::string key, val; std::map<std::string, std::string> kv;
-    while (a >> key && std::getline(a, val)) { while (!val.empty() && val[0] == ' ') val.erase(0, 1); kv[key] = val; }
-    for (const char* need : {"kmerSize", "windowSize", "minReadLength", "percentageIdentity", "p_value", "referenceSize", "maximumMemory", "reference"})
-      if (!kv.count(need)) die("Index " + ipre + " is incomplete (" + need + " missing in .arguments)");
-    k = std::stoi(kv["kmerSize"]); w = std::stoi(kv["windowSize"]); minLen = std::stoi(kv["minReadLength"]); pi = std::stof(kv["percentageIdentity"]);
-    pval = std::stod(kv["p_value"]); refSize = std::stoull(kv["referenceSize"]); maxMem = std::stoull(kv["maximumMemory"]); ref = kv["reference"];
-  }
+  std::string ipre;
   std::vector<std::string> queries, prefixes;
-  if (!only_index) {
-    queries = split(o.v.at("query"), ","); prefixes = split(o.v.at("output"), ",");
-    if (queries.size() != prefixes.size()) die("Please specify an equal number of input and output files (as comma-separated lists)");
-  }
   PhaseClock pc;
-  std::vector<Dev> devs;
-  for (int p : device_list(o)) { Dev d; d.phys = p; devs.push_back(d); }
-  if (only_index) devs.resize(1);
-  const size_t G = devs.size();
-  for (auto& d : devs) if (mm_ctx_create(d.phys, &d.ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
-  mm_ctx* const ctx0 = devs[0].ctx;
-  pc.lap("0 context");
+  std::vector<Dev> devs; size_t G = 0; mm_ctx* ctx0 = nullptr;
   std::vector<std::string> cname; std::vector<int> clen;
   struct Chunk { int first, count; std::string file; };
   std::vector<Chunk> chunks;
   // The packed reference (2 bits per base + exception runs, a quarter of the FASTA's size) lives on every device that builds indexes
   // from it; the host holds contig names and lengths only.  Index chunks are cut out of it on the device (mm_seqset_slice).
-  std::vector<mm_seqset*> refset(G, nullptr);
+  std::vector<mm_seqset*> refset;
   uint64_t hbm_free = 0;
-  auto query_free = [&] {
-    char nm[8]; int cus; uint64_t tot; mm_ctx_device_info(ctx0, nm, sizeof nm, &cus, &tot, &hbm_free);
-    size_t share = 0; for (auto& d : devs) share += d.phys == devs[0].phys;   // logical devices of one physical device (--devices 0,0,..) share its memory
-    hbm_free /= std::max<size_t>(share, 1);
-  };
-  query_free();
-  // Resident bytes of the index of `bases` reference bases (DESIGN.md section 3): N = 2 bases / (w + 1) entries; U distinct hashes — minimizer
-  // hashes are window minima, so they crowd into the low end of the 32-bit space: measured 5.92e8 distinct among 5.94e9 entries at w = 8,
-  // i.e. an effective space of H = 1.3 * 2^32 / (w + 1) values that fills as U = H (1 - exp(-N / H)); pos 8 N + occurrence lists padded to
-  // 64-byte sectors 8 (N + 7 U) at most + a quarter of that in bin codes + 29 U of table.  Per base this FALLS with the size of the
-  // reference: 6 bytes at 26.8 Gbp, 22 at 1 Gbp, where nearly every hash is a list of one padded to eight (a flat 5.5 bytes per base,
-  // rounds 1-3, let a 0.5 Gbp planning range ask for 5.5 GiB on a device with 2 GiB left — found with MM_DEVICE_BYTES_CAP).  The build
-  // holds another 12 N of sort buffers at its peak.
-  auto index_bytes = [&](uint64_t bases, bool peak) {
-    const double N = 2.0 * (double)bases / (double)(w + 1), H = 1.3 * 4294967296.0 / (double)(w + 1), U = H * (1 - std::exp(-N / H));
-    return 18.0 * N + 99.0 * U + (peak ? 12.0 * N : 0.0);
-  };
-  // `share` of the index of `bases` bases fits beside what the device already holds (the estimate errs on the large side by ~10 %)
-  auto fits = [&](uint64_t bases, double share) { return index_bytes(bases, share >= 1.0) * share <= 0.8 * (double)hbm_free; };
-  auto make_part = [&](size_t d, int a, int bnd) {               // contigs [a, bnd) of the reference as a set of their own, on device d
-    mm_seqset* part; ck(devs[d].ctx, mm_seqset_slice(devs[d].ctx, refset[d], a, bnd - a, &part), "reference chunk");
-    return part;
-  };
-  auto drop_refsets = [&]() { for (auto*& r : refset) if (r) { mm_seqset_destroy(r); r = nullptr; } };
-  // ---- reads (computeMap.hpp:104-172 + unifyFiles mapWrap.h:34-213)
-  // ~0.25 Gbp per device batch (16 ms of mapping); the next ones are parsed meanwhile.  (MM_CLI_BATCH_READS: test hook, small batches)
-  const int64_t BATCH_READS = getenv("MM_CLI_BATCH_READS") ? std::max(1, atoi(getenv("MM_CLI_BATCH_READS"))) : 100000,
-                BATCH_BASES = getenv("MM_CLI_BATCH_MBASES") ? (int64_t)std::max(1, atoi(getenv("MM_CLI_BATCH_MBASES"))) * 1000000LL : 256000000LL;
+  int64_t BATCH_READS = 100000, BATCH_BASES = 256000000LL;
+  size_t WPD = 4;                                               // worker contexts per device (replicated mode)
+  std::vector<mm_ctx*> wctx;
+  uint64_t ref_bases = 0;
+  mm_index* whole = nullptr;                                     // index of the whole reference on device 0, when one was built for the chunk plan
+  size_t NC = 0;
+  enum class Place { Replicated, Sharded, Streamed } place = Place::Replicated;
+  std::vector<int> thr_of;
+  std::map<int64_t, int64_t> thr_acc; int thr = INT_MAX;          // occurrence histogram accumulated over the chunks, never cleared (winSketch.hpp:452-494)
+  mm_map_params mp{};
+  std::vector<int32_t> chunk_base;
+  // what a worker hands to the writer: the finished text of one batch
+  struct Done { size_t file = 0; std::vector<std::string> names; std::vector<int> lens; std::vector<int64_t> off; std::string text; };
+  // the writer: batches in input order -> PREFIX, .meta.unmappedReadsLengths, .meta, .parameters of every query file (mapWrap.h:34-213)
+  struct Writer {
+    std::mutex m; std::condition_variable cv; std::map<size_t, std::unique_ptr<Done>> ready;
+    void put(size_t seq, std::unique_ptr<Done> d) { std::lock_guard<std::mutex> lk(m); ready[seq] = std::move(d); cv.notify_all(); }
+  } writer;
   // a reader thread parses the query files into batches (bounded queue); `take` hands them out in order, nullptr at the end
   struct Reader {
     std::mutex m; std::condition_variable cv; std::deque<std::unique_ptr<Batch>> queue, spare; bool done = false, started = false; size_t max_queued = 2;
@@ -371,11 +335,101 @@ int map_mode(const Options& o, const std::string& mode) {
     void recycle(std::unique_ptr<Batch> b) { b->reset(); std::lock_guard<std::mutex> lk(m); spare.push_back(std::move(b)); }
     ~Reader() { if (th.joinable()) th.join(); }
   } reader;
-  reader.max_queued = std::max<size_t>(2, 2 * G);
   std::deque<MappedFile> mapped;                                 // query files whose sequences the batches point into: alive until the end
+  std::thread prewarm;                                           // (declared last: joined first)
+
+  MapRun(const Options& o_, const std::string& mode_) : o(o_), mode(mode_), from_index(mode_ == "mapAgainstIndex"), only_index(mode_ == "index") {}
+  ~MapRun() { if (prewarm.joinable()) prewarm.join(); }
+
+  void read_parameters() {
+    if (!from_index && !o.v.count("reference")) die("Provide reference file (s)");
+    if ((from_index || only_index) && !o.v.count("index")) die("Please provide index");
+    if (!only_index && !o.v.count("query")) die("Provide query file (s)");
+    if (!only_index && !o.v.count("output")) die("Provide output file");
+    ipre = o.v.count("index") ? o.v.at("index") : "";
+    if (!from_index) {
+      ref = o.v.at("reference");
+      refSize = file_size(ref);
+      maxMem = o.v.count("maxmemory") ? (uint64_t)(std::pow(1024, 3) * std::stoull(o.v.at("maxmemory"))) : 0;
+      if (o.v.count("maxmemory-bytes")) maxMem = std::stoull(o.v.at("maxmemory-bytes"));
+      k = o.v.count("kmer") ? std::stoi(o.v.at("kmer")) : 16;
+      pval = o.v.count("pval") ? std::stod(o.v.at("pval")) : 1e-3;
+      minLen = o.v.count("minReadLen") ? std::stoi(o.v.at("minReadLen")) : 1000;
+      pi = o.v.count("perc_identity") ? std::stof(o.v.at("perc_identity")) : 80;
+      if (o.v.count("window")) {                                   // parseCmdArgs.hpp:363-374
+        w = std::stoi(o.v.at("window"));
+        pval = mm_estimate_pvalue(minLen * 2 / w, k, pi, minLen, refSize);
+      } else w = mm_recommended_window(pval, k, pi, minLen, refSize);
+    } else {                                                       // the parameters travel with the index (mapWrap.h:447-461)
+      std::ifstream a(ipre + ".arguments");
+      if (!a.is_open()) die("Cannot open file " + ipre + ".arguments for deserialization.");
+      std::string key, val; std::map<std::string, std::string> kv;
+      while (a >> key && std::getline(a, val)) { while (!val.empty() && val[0] == ' ') val.erase(0, 1); kv[key] = val; }
+      for (const char* need : {"kmerSize", "windowSize", "minReadLength", "percentageIdentity", "p_value", "referenceSize", "maximumMemory", "reference"})
+        if (!kv.count(need)) die("Index " + ipre + " is incomplete (" + need + " missing in .arguments)");
+      k = std::stoi(kv["kmerSize"]); w = std::stoi(kv["windowSize"]); minLen = std::stoi(kv["minReadLength"]); pi = std::stof(kv["percentageIdentity"]);
+      pval = std::stod(kv["p_value"]); refSize = std::stoull(kv["referenceSize"]); maxMem = std::stoull(kv["maximumMemory"]); ref = kv["reference"];
+    }
+    if (!only_index) {
+      queries = split(o.v.at("query"), ","); prefixes = split(o.v.at("output"), ",");
+      if (queries.size() != prefixes.size()) die("Please specify an equal number of input and output files (as comma-separated lists)");
+    }
+  }
+
+  void open_devices() {
+    for (int p : device_list(o)) { Dev d; d.phys = p; devs.push_back(d); }
+    if (only_index) devs.resize(1);
+    G = devs.size();
+    for (auto& d : devs) if (mm_ctx_create(d.phys, &d.ctx) != MM_OK) die("No MI355X (gfx950) device available — this build has no CPU path");
+    ctx0 = devs[0].ctx;
+    pc.lap("0 context");
+    refset.assign(G, nullptr);
+    query_free();
+    // ---- reads (computeMap.hpp:104-172 + unifyFiles mapWrap.h:34-213)
+    // ~0.25 Gbp per device batch (16 ms of mapping); the next ones are parsed meanwhile.  (MM_CLI_BATCH_READS: test hook, small batches)
+    if (getenv("MM_CLI_BATCH_READS")) BATCH_READS = std::max(1, atoi(getenv("MM_CLI_BATCH_READS")));
+    if (getenv("MM_CLI_BATCH_MBASES")) BATCH_BASES = (int64_t)std::max(1, atoi(getenv("MM_CLI_BATCH_MBASES"))) * 1000000LL;
+    reader.max_queued = std::max<size_t>(2, 2 * G);
+    // worker contexts of the replicated mode (WPD per device, --workers-per-gpu).  The ones beside the device's first context come up while the
+    // index is built, each with its upload staging in place (a batch-sized dummy goes through mm_seqset_upload once: pinned buffer, device
+    // block): the first batch of a worker used to spend 40-60 ms there, and 38 ms creating its stream, with the device idle.
+    WPD = o.v.count("workers-per-gpu") ? (size_t)std::max(1, std::stoi(o.v.at("workers-per-gpu")))
+        : getenv("MM_CLI_WORKERS") ? (size_t)std::max(1, atoi(getenv("MM_CLI_WORKERS"))) : 4;
+    wctx.assign(G * WPD, nullptr);
+  }
+
+  void query_free() {
+    char nm[8]; int cus; uint64_t tot; mm_ctx_device_info(ctx0, nm, sizeof nm, &cus, &tot, &hbm_free);
+    size_t share = 0; for (auto& d : devs) share += d.phys == devs[0].phys;   // logical devices of one physical device (--devices 0,0,..) share its memory
+    hbm_free /= std::max<size_t>(share, 1);
+  }
+
+  // Resident bytes of the index of `bases` reference bases (DESIGN.md section 3): N = 2 bases / (w + 1) entries; U distinct hashes — minimizer
+  // hashes are window minima, so they crowd into the low end of the 32-bit space: measured 5.92e8 distinct among 5.94e9 entries at w = 8,
+  // i.e. an effective space of H = 1.3 * 2^32 / (w + 1) values that fills as U = H (1 - exp(-N / H)); pos 8 N + occurrence lists padded to
+  // 64-byte sectors 8 (N + 7 U) at most + a quarter of that in bin codes + 29 U of table.  Per base this FALLS with the size of the
+  // reference: 6 bytes at 26.8 Gbp, 22 at 1 Gbp, where nearly every hash is a list of one padded to eight (a flat 5.5 bytes per base,
+  // rounds 1-3, let a 0.5 Gbp planning range ask for 5.5 GiB on a device with 2 GiB left — found with MM_DEVICE_BYTES_CAP).  The build
+  // holds another 12 N of sort buffers at its peak.
+  double index_bytes(uint64_t bases, bool peak) const {
+    const double N = 2.0 * (double)bases / (double)(w + 1), H = 1.3 * 4294967296.0 / (double)(w + 1), U = H * (1 - std::exp(-N / H));
+    return 18.0 * N + 99.0 * U + (peak ? 12.0 * N : 0.0);
+  }
+  // `share` of the index of `bases` bases fits beside what the device already holds (the estimate errs on the large side by ~10 %)
+  bool fits(uint64_t bases, double share) const { return index_bytes(bases, share >= 1.0) * share <= 0.8 * (double)hbm_free; }
+  mm_seqset* make_part(size_t d, int a, int bnd) {               // contigs [a, bnd) of the reference as a set of their own, on device d
+    mm_seqset* part; ck(devs[d].ctx, mm_seqset_slice(devs[d].ctx, refset[d], a, bnd - a, &part), "reference chunk");
+    return part;
+  }
+  void drop_refsets() { for (auto*& r : refset) if (r) { mm_seqset_destroy(r); r = nullptr; } }
+
   // (started as soon as the reference has been parsed: the first batches are ready when the index is)
-  auto start_reader = [&]() { if (reader.th.joinable() || reader.started) return; reader.started = true; reader.th = std::thread([&]() {
+  void start_reader() { if (reader.th.joinable() || reader.started) return; reader.started = true; reader.th = std::thread([this]() { reader_main(); }); }
+  // the reader thread: every query file in turn -> batches in the bounded queue
+  void reader_main() {
     size_t seq = 0;
+    const auto r_t0 = std::chrono::steady_clock::now();           // the reader's own rate (MM_CLI_TIMING): its wall time without what it waited for a free queue slot
+    double r_waited = 0;
     auto fresh = [&]() {
       std::unique_ptr<Batch> b;
       { std::lock_guard<std::mutex> lk(reader.m); if (!reader.spare.empty()) { b = std::move(reader.spare.back()); reader.spare.pop_back(); } }
@@ -386,7 +440,9 @@ int map_mode(const Options& o, const std::string& mode) {
       b->seq = seq++; b->file = fi;
       if (getenv("MM_CLI_TIMING")) std::cerr << "INFO, reader: batch of " << b->names.size() << " reads parsed at +" << std::chrono::duration<double>(std::chrono::steady_clock::now() - pc.t0).count() << " s\n";
       std::unique_lock<std::mutex> lk(reader.m);
+      const auto w0 = std::chrono::steady_clock::now();
       reader.cv.wait(lk, [&] { return reader.queue.size() < reader.max_queued; });
+      r_waited += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
       reader.queue.push_back(std::move(b));
       reader.cv.notify_all();
     };
@@ -436,6 +492,7 @@ int map_mode(const Options& o, const std::string& mode) {
               if (abandon || next_block >= nb) return;
               j = next_block++;
             }
+            const auto b_t0 = std::chrono::steady_clock::now();
             if (j > 0) start[j] = mf.sync(j * blk, std::min(mf.size, (j + 1) * blk));   // (only this thread writes start[j]; read after `done`)
             Block& B = blocks[j];
             const size_t lim = std::min(mf.size, (j + 1) * blk);
@@ -444,10 +501,12 @@ int map_mode(const Options& o, const std::string& mode) {
               B.over = !parse_into(f, lim, [&](std::unique_ptr<Batch> b) { B.out.push_back(std::move(b)); });
               B.next = f.peek_start();
             } else B.empty = true;                                 // no record start was recognised in this block
+            pc.add("R parse threads busy (summed over the block parser's threads)", std::chrono::duration<double>(std::chrono::steady_clock::now() - b_t0).count());
             { std::lock_guard<std::mutex> lk(bm); B.done = true; }
             bcv.notify_all();
           }
         };
+        pc.add("R parse threads", (double)P);
         std::vector<std::thread> pool;
         for (unsigned t = 0; t < P; ++t) pool.emplace_back(worker);
         // `expect`: where the parse stands = the start of the first record not handed on yet.  A block continues the parse iff it
@@ -481,17 +540,12 @@ int map_mode(const Options& o, const std::string& mode) {
       }
       std::lock_guard<std::mutex> lk(reader.m); reader.file_end.push_back(seq); reader.cv.notify_all();
     }
+    { const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - r_t0).count();
+      pc.add("R reader thread wall time without waiting for a queue slot", wall - r_waited); pc.add("R reader waited for a queue slot", r_waited); }
     std::lock_guard<std::mutex> lk(reader.m); reader.done = true; reader.cv.notify_all();
-  }); };
-  // worker contexts of the replicated mode (WPD per device, --workers-per-gpu).  The ones beside the device's first context come up while the
-  // index is built, each with its upload staging in place (a batch-sized dummy goes through mm_seqset_upload once: pinned buffer, device
-  // block): the first batch of a worker used to spend 40-60 ms there, and 38 ms creating its stream, with the device idle.
-  const size_t WPD = o.v.count("workers-per-gpu") ? (size_t)std::max(1, std::stoi(o.v.at("workers-per-gpu")))
-                   : getenv("MM_CLI_WORKERS") ? (size_t)std::max(1, atoi(getenv("MM_CLI_WORKERS"))) : 4;
-  std::vector<mm_ctx*> wctx(G * WPD, nullptr);
-  std::thread prewarm;
-  JoinOnExit prewarm_guard{prewarm};
-  auto start_prewarm = [&]() {
+  }
+
+  void start_prewarm() {
     if (prewarm.joinable() || getenv("MM_CLI_NO_PREWARM")) return;
     int64_t query_bytes = 0; for (auto& q : queries) query_bytes += (int64_t)file_size(q);
     const int64_t warm_bases = std::min<int64_t>(BATCH_BASES, query_bytes / 2);   // (a FASTQ is two bytes per base; small inputs get small staging)
@@ -512,225 +566,229 @@ int map_mode(const Options& o, const std::string& mode) {
       });
       for (auto& t : th) t.join();
     });
-  };
-  uint64_t ref_bases = 0;
-  mm_index* whole = nullptr;                                     // index of the whole reference on device 0, when one was built for the chunk plan
-  if (!from_index) {
-    // ---- reference (winSketch.hpp:180-365)
-    // The reference streams contig by contig (winSketch.hpp:242-252): a parser thread fills groups of ~1 Gbase, the main thread packs
-    // and uploads each group to every device while the next one is parsed, and drops the text.  Host memory: two groups.
-    {
-      struct Group { std::deque<std::string> seq; std::vector<std::string> names; uint64_t bases = 0; };
-      const uint64_t GROUP_BASES = getenv("MM_CLI_REF_GROUP_BASES") ? std::stoull(getenv("MM_CLI_REF_GROUP_BASES")) : (uint64_t)1 << 30;   // (test hook: small groups)
-      std::vector<std::vector<mm_seqset*>> parts(only_index ? 1 : G);
-      double t_pack = 0;
-      auto consume = [&](Group& g) {                               // names and lengths in file order, then pack + upload to every device
-        for (size_t i = 0; i < g.seq.size(); ++i) { cname.push_back(std::move(g.names[i])); clen.push_back((int)g.seq[i].size()); ref_bases += g.seq[i].size(); }
-        const auto t0 = std::chrono::steady_clock::now();
-        on_each(parts.size(), [&](size_t d) {
-          mm_seqset* p; ck(devs[d].ctx, mm_seqset_create(devs[d].ctx, &p), "seqset");
-          for (auto& q : g.seq) ck(devs[d].ctx, mm_seqset_add_view(p, q.data(), (int64_t)q.size()), "add contig");
-          ck(devs[d].ctx, mm_seqset_upload(p), "upload reference");
-          parts[d].push_back(p);
-        });
-        t_pack += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      };
-      // records of `f` (all, or those that start before `stop` in memory mode) in groups of GROUP_BASES handed to `emit`; false when the
-      // reader gave up before `stop` (a truncated quality string ends the file for kseq, kseq.h:204)
-      auto parse_groups = [&](SeqFile& f, size_t stop, const std::function<void(std::unique_ptr<Group>)>& emit) -> bool {
-        auto g = std::make_unique<Group>();
-        bool ok = true;
-        for (;;) {
-          if (stop != (size_t)-1) { const size_t ps = f.peek_start(); if (ps == (size_t)-1 || ps >= stop) break; }
-          if (!f.next()) { ok = stop == (size_t)-1; break; }
-          g->names.push_back(f.name);
-          if (f.view) g->seq.emplace_back(f.view, f.view_len); else { g->seq.push_back(std::move(f.seq)); f.seq.clear(); }
-          g->bases += g->seq.back().size();
-          if (g->bases >= GROUP_BASES) { emit(std::move(g)); g = std::make_unique<Group>(); }
-        }
-        if (!g->seq.empty()) emit(std::move(g));
-        return ok;
-      };
-      MappedFile rmf;
-      if (!getenv("MM_CLI_NO_MMAP") && !getenv("MM_CLI_REF_SEQUENTIAL") && rmf.open(ref)) {
-        // A plain file: blocks of the mapping parsed by several threads (the block parser of the query files below: a block's records
-        // count only once the block before it has been seen to end exactly where this one starts), consumed — packed, uploaded — in file
-        // order.  The winSketch.hpp:242-252 loop reads contig by contig; here the text of at most P + 2 blocks of 256 MB is resident, and the
-        // mapped pages of a block are given back once it is consumed (they would count as resident until the end otherwise: 27 GB).
-        const size_t blk = getenv("MM_CLI_REF_BLOCK_BYTES") ? (size_t)std::max(1, atoi(getenv("MM_CLI_REF_BLOCK_BYTES"))) : (size_t)std::min<uint64_t>(GROUP_BASES, (uint64_t)256 << 20);
-        const size_t nb = std::max<size_t>(1, (rmf.size + blk - 1) / blk);
-        std::vector<size_t> start(nb + 1, rmf.size);
-        start[0] = 0;
-        struct Block { std::vector<std::unique_ptr<Group>> out; size_t next = 0; bool done = false, empty = false, over = false; };
-        std::vector<Block> blocks(nb);
-        std::mutex bm; std::condition_variable bcv; size_t next_block = 0, consumed = 0; bool abandon = false;
-        const unsigned P = (unsigned)std::max<size_t>(1, std::min<size_t>({nb, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4)}));
-        auto worker = [&]() {
-          for (;;) {
-            size_t j;
-            {
-              std::unique_lock<std::mutex> lk(bm);
-              bcv.wait(lk, [&] { return abandon || next_block >= nb || next_block < consumed + P + 1; });   // not too far ahead of the consumer
-              if (abandon || next_block >= nb) return;
-              j = next_block++;
-            }
-            if (j > 0) start[j] = rmf.sync(j * blk, std::min(rmf.size, (j + 1) * blk));
-            Block& B = blocks[j];
-            const size_t lim = std::min(rmf.size, (j + 1) * blk);
-            if (j == 0 || start[j] < lim) {
-              SeqFile f(rmf.data, j == 0 ? 0 : start[j], rmf.size);
-              B.over = !parse_groups(f, lim, [&](std::unique_ptr<Group> g) { B.out.push_back(std::move(g)); });
-              B.next = f.peek_start();
-            } else B.empty = true;
-            { std::lock_guard<std::mutex> lk(bm); B.done = true; }
-            bcv.notify_all();
-          }
-        };
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < P; ++t) pool.emplace_back(worker);
-        size_t expect = 0; bool chain_ok = true, file_over = false;
-        for (size_t j = 0; j < nb && chain_ok && !file_over; ++j) {
-          { std::unique_lock<std::mutex> lk(bm); bcv.wait(lk, [&] { return blocks[j].done; }); }
-          Block& B = blocks[j];
-          if (!B.empty) {
-            if (j > 0 && start[j] != expect) { chain_ok = false; break; }
-            for (auto& g : B.out) consume(*g);
-            B.out.clear();
-            if (B.over || B.next == (size_t)-1) { file_over = true; break; }
-            expect = B.next;
-          } else if (expect < std::min(rmf.size, (j + 1) * blk)) { chain_ok = false; break; }
-          { std::lock_guard<std::mutex> lk(bm); consumed = j + 1; } bcv.notify_all();
-          if (j > 0) rmf.drop(((j - 1) * blk) & ~(size_t)4095, (j * blk) & ~(size_t)4095);   // (block j - 1: its last record may end inside block j, parsed by now)
-        }
-        { std::lock_guard<std::mutex> lk(bm); abandon = true; } bcv.notify_all();
-        for (auto& t : pool) t.join();
-        if (!chain_ok) {                                           // a block did not start where the parse stood: the rest sequentially, from there
-          for (auto& B : blocks) B.out.clear();
-          SeqFile f(rmf.data, expect, rmf.size);
-          parse_groups(f, (size_t)-1, [&](std::unique_ptr<Group> g) { consume(*g); });
-        }
-      } else {
-        // gzip, pipes: a parser thread fills groups, the main thread packs and uploads each while the next one is parsed.  Host memory: two groups.
-        std::mutex gm; std::condition_variable gcv; std::deque<std::unique_ptr<Group>> ready; bool parsed = false;
-        std::thread parser([&]() {
-          SeqFile f(ref);
-          parse_groups(f, (size_t)-1, [&](std::unique_ptr<Group> g) {
-            std::unique_lock<std::mutex> lk(gm); gcv.wait(lk, [&] { return ready.size() < 2; }); ready.push_back(std::move(g)); gcv.notify_all();
-          });
-          std::lock_guard<std::mutex> lk(gm); parsed = true; gcv.notify_all();
-        });
-        for (;;) {
-          std::unique_ptr<Group> g;
-          { std::unique_lock<std::mutex> lk(gm); gcv.wait(lk, [&] { return !ready.empty() || parsed; }); if (ready.empty()) break; g = std::move(ready.front()); ready.pop_front(); gcv.notify_all(); }
-          consume(*g);
-        }
-        parser.join();
-      }
+  }
+
+  // ---- reference (winSketch.hpp:180-365): parsed, packed and uploaded to every device that builds indexes from it
+  void load_reference() {
+    struct Group { std::deque<std::string> seq; std::vector<std::string> names; uint64_t bases = 0; };
+    const uint64_t GROUP_BASES = getenv("MM_CLI_REF_GROUP_BASES") ? std::stoull(getenv("MM_CLI_REF_GROUP_BASES")) : (uint64_t)1 << 30;   // (test hook: small groups)
+    std::vector<std::vector<mm_seqset*>> parts(only_index ? 1 : G);
+    double t_pack = 0;
+    auto consume = [&](Group& g) {                               // names and lengths in file order, then pack + upload to every device
+      for (size_t i = 0; i < g.seq.size(); ++i) { cname.push_back(std::move(g.names[i])); clen.push_back((int)g.seq[i].size()); ref_bases += g.seq[i].size(); }
+      const auto t0 = std::chrono::steady_clock::now();
       on_each(parts.size(), [&](size_t d) {
-        if (parts[d].size() == 1) { refset[d] = parts[d][0]; return; }
-        if (parts[d].empty()) { ck(devs[d].ctx, mm_seqset_create(devs[d].ctx, &refset[d]), "seqset"); ck(devs[d].ctx, mm_seqset_upload(refset[d]), "upload reference"); return; }
-        ck(devs[d].ctx, mm_seqset_concat(devs[d].ctx, parts[d].data(), (int)parts[d].size(), &refset[d]), "reference");
-        for (auto* p : parts[d]) mm_seqset_destroy(p);
+        mm_seqset* p; ck(devs[d].ctx, mm_seqset_create(devs[d].ctx, &p), "seqset");
+        for (auto& q : g.seq) ck(devs[d].ctx, mm_seqset_add_view(p, q.data(), (int64_t)q.size()), "add contig");
+        ck(devs[d].ctx, mm_seqset_upload(p), "upload reference");
+        parts[d].push_back(p);
       });
-      pc.lap("1 reference parse + pack + upload");
-      pc.add("2 reference pack+upload (inside 1)", t_pack);
-      if (!only_index) { start_reader(); start_prewarm(); }
-    }
-    query_free();                                                // the packed reference now lives on the device (0.25 B per base, for as long as chunks are cut out of it): what is left is what the indexes get
-    std::vector<int32_t> first(1, 0);
-    if (!maxMem || fits(ref_bases, 1.0)) {
-      // the index of the whole reference: the only chunk, or what the chunk rule of --maxmemory is evaluated on
-      if (!maxMem && o.stream) die("--stream-chunks needs --maxmemory (the chunk rule of the reference, winSketch.hpp:274-329)");
-      mm_seqset* contigs = refset[0];
-      ck(ctx0, mm_index_build(ctx0, contigs, k, w, &whole), "index");
-      pc.lap("3 index build");
-      if (maxMem) {
-        int32_t n = 0;
-        ck(ctx0, mm_index_plan_chunks(ctx0, whole, maxMem, nullptr, 0, &n), "chunk plan");
-        first.resize((size_t)n);
-        ck(ctx0, mm_index_plan_chunks(ctx0, whole, maxMem, first.data(), n, &n), "chunk plan");
+      t_pack += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
+    // records of `f` (all, or those that start before `stop` in memory mode) in groups of GROUP_BASES handed to `emit`; false when the
+    // reader gave up before `stop` (a truncated quality string ends the file for kseq, kseq.h:204)
+    auto parse_groups = [&](SeqFile& f, size_t stop, const std::function<void(std::unique_ptr<Group>)>& emit) -> bool {
+      auto g = std::make_unique<Group>();
+      bool ok = true;
+      for (;;) {
+        if (stop != (size_t)-1) { const size_t ps = f.peek_start(); if (ps == (size_t)-1 || ps >= stop) break; }
+        if (!f.next()) { ok = stop == (size_t)-1; break; }
+        g->names.push_back(f.name);
+        if (f.view) g->seq.emplace_back(f.view, f.view_len); else { g->seq.push_back(std::move(f.seq)); f.seq.clear(); }
+        g->bases += g->seq.back().size();
+        if (g->bases >= GROUP_BASES) { emit(std::move(g)); g = std::make_unique<Group>(); }
       }
-      if (only_index && first.size() == 1 && !o.v.count("full-index")) ck(ctx0, mm_seqset_save(contigs, (ipre + ".1.seqset").c_str()), "store index chunk");
-    } else {
-      // The chunk rule without an index of the whole reference: it decides to close a chunk from the chunk's own content
-      // and the next contig only, so it can be evaluated on the index of a contig range that fits the device.  Every cut
-      // inside the range is final; the range's last chunk is not (it may go on), so the next range starts there.
-      std::cout << "INFO, the index of " << ref_bases << " reference bases does not fit one device's " << (hbm_free >> 30) << " GiB: the chunk rule is evaluated on contig ranges\n";
-      const int C = (int)cname.size();
-      uint64_t range_bases = 0;
-      if (o.v.count("stream-range-bases")) range_bases = std::stoull(o.v.at("stream-range-bases"));
-      else {                                                     // the largest range whose index BUILD stays within 70 % of what is free
-        uint64_t lo = 1, hi = ref_bases;
-        while (lo < hi) { const uint64_t mid = lo + (hi - lo + 1) / 2; if (index_bytes(mid, true) <= 0.7 * (double)hbm_free) lo = mid; else hi = mid - 1; }
-        range_bases = lo;
-      }
-      int c0 = 0;
-      while (c0 < C) {
-        int c1 = c0; uint64_t bases = 0;
-        while (c1 < C && (bases < range_bases || c1 == c0)) bases += (uint64_t)clen[(size_t)c1++];
-        mm_seqset* part = make_part(0, c0, c1);
-        mm_index* ri; ck(ctx0, mm_index_build(ctx0, part, k, w, &ri), "index (chunk planning range)");
-        mm_seqset_destroy(part);
-        int32_t n = 0;
-        ck(ctx0, mm_index_plan_chunks(ctx0, ri, maxMem, nullptr, 0, &n), "chunk plan");
-        std::vector<int32_t> loc((size_t)n);
-        ck(ctx0, mm_index_plan_chunks(ctx0, ri, maxMem, loc.data(), n, &n), "chunk plan");
-        mm_index_destroy(ri);
-        if (n == 1 && c1 < C) {                                   // the chunk that starts at c0 is longer than the range
-          if (index_bytes(bases * 2, true) > 0.9 * (double)hbm_free && !o.v.count("stream-range-bases"))
-            die("--maxmemory describes index chunks larger than this device can hold one at a time");
-          range_bases = bases * 2; continue;
-        }
-        for (int32_t j = 1; j < n; ++j) first.push_back(c0 + loc[(size_t)j]);
-        if (c1 == C) break;
-        c0 += loc[(size_t)n - 1];
-      }
-      pc.lap("3 index build");
-    }
-    for (size_t c = 0; c < first.size(); ++c) {
-      const int a = first[c], b = c + 1 < first.size() ? first[c + 1] : (int)cname.size();
-      chunks.push_back(Chunk{a, b - a, ""});
-    }
-    if (only_index) {
-      { std::ofstream flag(ipre + ".index"); if (!flag.is_open()) die("Cannot open " + ipre + ".index"); flag << 0 << "\n"; }   // mapWrap.h:363-366
-      std::vector<std::string> chunk_files;
-      const bool full = o.v.count("full-index") != 0;            // the device index itself (mm_index_save) instead of the packed reference it is rebuilt from
-      for (size_t c = 0; c < chunks.size(); ++c) {
-        chunk_files.push_back(ipre + "." + std::to_string(c + 1) + (full ? ".mmidx" : ".seqset"));
-        if (full) {
-          mm_index* ix = whole;
-          if (!(chunks.size() == 1 && whole)) {
-            if (whole) { mm_index_destroy(whole); whole = nullptr; }   // (the chunk rule is done with it)
-            mm_seqset* part = make_part(0, chunks[c].first, chunks[c].first + chunks[c].count);
-            ck(ctx0, mm_index_build(ctx0, part, k, w, &ix), "index chunk");
-            mm_seqset_destroy(part);
+      if (!g->seq.empty()) emit(std::move(g));
+      return ok;
+    };
+    MappedFile rmf;
+    if (!getenv("MM_CLI_NO_MMAP") && !getenv("MM_CLI_REF_SEQUENTIAL") && rmf.open(ref)) {
+      // A plain file: blocks of the mapping parsed by several threads (the block parser of the query files below: a block's records
+      // count only once the block before it has been seen to end exactly where this one starts), consumed — packed, uploaded — in file
+      // order.  The winSketch.hpp:242-252 loop reads contig by contig; here the text of at most P + 2 blocks of 256 MB is resident, and the
+      // mapped pages of a block are given back once it is consumed (they would count as resident until the end otherwise: 27 GB).
+      const size_t blk = getenv("MM_CLI_REF_BLOCK_BYTES") ? (size_t)std::max(1, atoi(getenv("MM_CLI_REF_BLOCK_BYTES"))) : (size_t)std::min<uint64_t>(GROUP_BASES, (uint64_t)256 << 20);
+      const size_t nb = std::max<size_t>(1, (rmf.size + blk - 1) / blk);
+      std::vector<size_t> start(nb + 1, rmf.size);
+      start[0] = 0;
+      struct Block { std::vector<std::unique_ptr<Group>> out; size_t next = 0; bool done = false, empty = false, over = false; };
+      std::vector<Block> blocks(nb);
+      std::mutex bm; std::condition_variable bcv; size_t next_block = 0, consumed = 0; bool abandon = false;
+      const unsigned P = (unsigned)std::max<size_t>(1, std::min<size_t>({nb, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4)}));
+      auto worker = [&]() {
+        for (;;) {
+          size_t j;
+          {
+            std::unique_lock<std::mutex> lk(bm);
+            bcv.wait(lk, [&] { return abandon || next_block >= nb || next_block < consumed + P + 1; });   // not too far ahead of the consumer
+            if (abandon || next_block >= nb) return;
+            j = next_block++;
           }
-          ck(ctx0, mm_index_save(ix, chunk_files.back().c_str()), "store index chunk");
-          if (ix != whole) mm_index_destroy(ix);
-          continue;
+          if (j > 0) start[j] = rmf.sync(j * blk, std::min(rmf.size, (j + 1) * blk));
+          Block& B = blocks[j];
+          const size_t lim = std::min(rmf.size, (j + 1) * blk);
+          if (j == 0 || start[j] < lim) {
+            SeqFile f(rmf.data, j == 0 ? 0 : start[j], rmf.size);
+            B.over = !parse_groups(f, lim, [&](std::unique_ptr<Group> g) { B.out.push_back(std::move(g)); });
+            B.next = f.peek_start();
+          } else B.empty = true;
+          { std::lock_guard<std::mutex> lk(bm); B.done = true; }
+          bcv.notify_all();
         }
-        if (chunks.size() == 1 && whole) continue;                // stored above, from the set the index was built on
-        mm_seqset* part = make_part(0, chunks[c].first, chunks[c].first + chunks[c].count);
-        ck(ctx0, mm_seqset_save(part, chunk_files.back().c_str()), "store index chunk");
-        mm_seqset_destroy(part);
+      };
+      std::vector<std::thread> pool;
+      for (unsigned t = 0; t < P; ++t) pool.emplace_back(worker);
+      size_t expect = 0; bool chain_ok = true, file_over = false;
+      for (size_t j = 0; j < nb && chain_ok && !file_over; ++j) {
+        { std::unique_lock<std::mutex> lk(bm); bcv.wait(lk, [&] { return blocks[j].done; }); }
+        Block& B = blocks[j];
+        if (!B.empty) {
+          if (j > 0 && start[j] != expect) { chain_ok = false; break; }
+          for (auto& g : B.out) consume(*g);
+          B.out.clear();
+          if (B.over || B.next == (size_t)-1) { file_over = true; break; }
+          expect = B.next;
+        } else if (expect < std::min(rmf.size, (j + 1) * blk)) { chain_ok = false; break; }
+        { std::lock_guard<std::mutex> lk(bm); consumed = j + 1; } bcv.notify_all();
+        if (j > 0) rmf.drop(((j - 1) * blk) & ~(size_t)4095, (j * blk) & ~(size_t)4095);   // (block j - 1: its last record may end inside block j, parsed by now)
       }
-      if (whole) mm_index_destroy(whole);
-      drop_refsets();
-      std::ofstream args(ipre + ".arguments");
-      if (!args.is_open()) die("Cannot open file " + ipre + ".arguments for serialization.");
-      args.precision(17);
-      args << "kmerSize " << k << "\nwindowSize " << w << "\nminReadLength " << minLen << "\npercentageIdentity " << pi << "\np_value " << pval
-           << "\nreferenceSize " << refSize << "\nmaximumMemory " << maxMem << "\nreference " << ref << "\n";
-      std::ofstream cf(ipre + ".contigs");
-      for (size_t c = 0; c < chunks.size(); ++c)
-        for (int i = chunks[c].first; i < chunks[c].first + chunks[c].count; ++i) cf << cname[(size_t)i] << "\t" << clen[(size_t)i] << "\t" << c + 1 << "\n";
-      std::ofstream flag(ipre + ".index");                       // mapWrap.h:395-402
-      flag << 1 << "\n";
-      for (auto& fn : chunk_files) { flag << fn << "\n"; std::cout << "Stored state in file " << fn << "\n"; }
-      mm_ctx_destroy(ctx0);
-      return 0;
+      { std::lock_guard<std::mutex> lk(bm); abandon = true; } bcv.notify_all();
+      for (auto& t : pool) t.join();
+      if (!chain_ok) {                                           // a block did not start where the parse stood: the rest sequentially, from there
+        for (auto& B : blocks) B.out.clear();
+        SeqFile f(rmf.data, expect, rmf.size);
+        parse_groups(f, (size_t)-1, [&](std::unique_ptr<Group> g) { consume(*g); });
+      }
+    } else {
+      // gzip, pipes: a parser thread fills groups, the main thread packs and uploads each while the next one is parsed.  Host memory: two groups.
+      std::mutex gm; std::condition_variable gcv; std::deque<std::unique_ptr<Group>> ready; bool parsed = false;
+      std::thread parser([&]() {
+        SeqFile f(ref);
+        parse_groups(f, (size_t)-1, [&](std::unique_ptr<Group> g) {
+          std::unique_lock<std::mutex> lk(gm); gcv.wait(lk, [&] { return ready.size() < 2; }); ready.push_back(std::move(g)); gcv.notify_all();
+        });
+        std::lock_guard<std::mutex> lk(gm); parsed = true; gcv.notify_all();
+      });
+      for (;;) {
+        std::unique_ptr<Group> g;
+        { std::unique_lock<std::mutex> lk(gm); gcv.wait(lk, [&] { return !ready.empty() || parsed; }); if (ready.empty()) break; g = std::move(ready.front()); ready.pop_front(); gcv.notify_all(); }
+        consume(*g);
+      }
+      parser.join();
     }
+    on_each(parts.size(), [&](size_t d) {
+      if (parts[d].size() == 1) { refset[d] = parts[d][0]; return; }
+      if (parts[d].empty()) { ck(devs[d].ctx, mm_seqset_create(devs[d].ctx, &refset[d]), "seqset"); ck(devs[d].ctx, mm_seqset_upload(refset[d]), "upload reference"); return; }
+      ck(devs[d].ctx, mm_seqset_concat(devs[d].ctx, parts[d].data(), (int)parts[d].size(), &refset[d]), "reference");
+      for (auto* p : parts[d]) mm_seqset_destroy(p);
+    });
+    pc.lap("1 reference parse + pack + upload");
+    pc.add("2 reference pack+upload (inside 1)", t_pack);
+    if (!only_index) { start_reader(); start_prewarm(); }
+    query_free();                                                // the packed reference now lives on the device (0.25 B per base, for as long as chunks are cut out of it): what is left is what the indexes get
+  }
+
+  // ---- the chunk plan of --maxmemory (winSketch.hpp:274-329): on the index of the whole reference when that fits, on contig ranges otherwise
+  void plan_chunks() {
+  std::vector<int32_t> first(1, 0);
+  if (!maxMem || fits(ref_bases, 1.0)) {
+    // the index of the whole reference: the only chunk, or what the chunk rule of --maxmemory is evaluated on
+    if (!maxMem && o.stream) die("--stream-chunks needs --maxmemory (the chunk rule of the reference, winSketch.hpp:274-329)");
+    mm_seqset* contigs = refset[0];
+    ck(ctx0, mm_index_build(ctx0, contigs, k, w, &whole), "index");
+    pc.lap("3 index build");
+    if (maxMem) {
+      int32_t n = 0;
+      ck(ctx0, mm_index_plan_chunks(ctx0, whole, maxMem, nullptr, 0, &n), "chunk plan");
+      first.resize((size_t)n);
+      ck(ctx0, mm_index_plan_chunks(ctx0, whole, maxMem, first.data(), n, &n), "chunk plan");
+    }
+    if (only_index && first.size() == 1 && !o.v.count("full-index")) ck(ctx0, mm_seqset_save(contigs, (ipre + ".1.seqset").c_str()), "store index chunk");
   } else {
+    // The chunk rule without an index of the whole reference: it decides to close a chunk from the chunk's own content
+    // and the next contig only, so it can be evaluated on the index of a contig range that fits the device.  Every cut
+    // inside the range is final; the range's last chunk is not (it may go on), so the next range starts there.
+    std::cout << "INFO, the index of " << ref_bases << " reference bases does not fit one device's " << (hbm_free >> 30) << " GiB: the chunk rule is evaluated on contig ranges\n";
+    const int C = (int)cname.size();
+    uint64_t range_bases = 0;
+    if (o.v.count("stream-range-bases")) range_bases = std::stoull(o.v.at("stream-range-bases"));
+    else {                                                     // the largest range whose index BUILD stays within 70 % of what is free
+      uint64_t lo = 1, hi = ref_bases;
+      while (lo < hi) { const uint64_t mid = lo + (hi - lo + 1) / 2; if (index_bytes(mid, true) <= 0.7 * (double)hbm_free) lo = mid; else hi = mid - 1; }
+      range_bases = lo;
+    }
+    int c0 = 0;
+    while (c0 < C) {
+      int c1 = c0; uint64_t bases = 0;
+      while (c1 < C && (bases < range_bases || c1 == c0)) bases += (uint64_t)clen[(size_t)c1++];
+      mm_seqset* part = make_part(0, c0, c1);
+      mm_index* ri; ck(ctx0, mm_index_build(ctx0, part, k, w, &ri), "index (chunk planning range)");
+      mm_seqset_destroy(part);
+      int32_t n = 0;
+      ck(ctx0, mm_index_plan_chunks(ctx0, ri, maxMem, nullptr, 0, &n), "chunk plan");
+      std::vector<int32_t> loc((size_t)n);
+      ck(ctx0, mm_index_plan_chunks(ctx0, ri, maxMem, loc.data(), n, &n), "chunk plan");
+      mm_index_destroy(ri);
+      if (n == 1 && c1 < C) {                                   // the chunk that starts at c0 is longer than the range
+        if (index_bytes(bases * 2, true) > 0.9 * (double)hbm_free && !o.v.count("stream-range-bases"))
+          die("--maxmemory describes index chunks larger than this device can hold one at a time");
+        range_bases = bases * 2; continue;
+      }
+      for (int32_t j = 1; j < n; ++j) first.push_back(c0 + loc[(size_t)j]);
+      if (c1 == C) break;
+      c0 += loc[(size_t)n - 1];
+    }
+    pc.lap("3 index build");
+  }
+  for (size_t c = 0; c < first.size(); ++c) {
+    const int a = first[c], b = c + 1 < first.size() ? first[c + 1] : (int)cname.size();
+    chunks.push_back(Chunk{a, b - a, ""});
+  }
+  }
+
+  // `metamaps index`: PREFIX.N.seqset (or .mmidx with --full-index) per chunk + PREFIX.index / .arguments / .contigs (mapWrap.h:358-405)
+  int write_index_files() {
+    { std::ofstream flag(ipre + ".index"); if (!flag.is_open()) die("Cannot open " + ipre + ".index"); flag << 0 << "\n"; }   // mapWrap.h:363-366
+    std::vector<std::string> chunk_files;
+    const bool full = o.v.count("full-index") != 0;            // the device index itself (mm_index_save) instead of the packed reference it is rebuilt from
+    for (size_t c = 0; c < chunks.size(); ++c) {
+      chunk_files.push_back(ipre + "." + std::to_string(c + 1) + (full ? ".mmidx" : ".seqset"));
+      if (full) {
+        mm_index* ix = whole;
+        if (!(chunks.size() == 1 && whole)) {
+          if (whole) { mm_index_destroy(whole); whole = nullptr; }   // (the chunk rule is done with it)
+          mm_seqset* part = make_part(0, chunks[c].first, chunks[c].first + chunks[c].count);
+          ck(ctx0, mm_index_build(ctx0, part, k, w, &ix), "index chunk");
+          mm_seqset_destroy(part);
+        }
+        ck(ctx0, mm_index_save(ix, chunk_files.back().c_str()), "store index chunk");
+        if (ix != whole) mm_index_destroy(ix);
+        continue;
+      }
+      if (chunks.size() == 1 && whole) continue;                // stored above, from the set the index was built on
+      mm_seqset* part = make_part(0, chunks[c].first, chunks[c].first + chunks[c].count);
+      ck(ctx0, mm_seqset_save(part, chunk_files.back().c_str()), "store index chunk");
+      mm_seqset_destroy(part);
+    }
+    if (whole) mm_index_destroy(whole);
+    drop_refsets();
+    std::ofstream args(ipre + ".arguments");
+    if (!args.is_open()) die("Cannot open file " + ipre + ".arguments for serialization.");
+    args.precision(17);
+    args << "kmerSize " << k << "\nwindowSize " << w << "\nminReadLength " << minLen << "\npercentageIdentity " << pi << "\np_value " << pval
+         << "\nreferenceSize " << refSize << "\nmaximumMemory " << maxMem << "\nreference " << ref << "\n";
+    std::ofstream cf(ipre + ".contigs");
+    for (size_t c = 0; c < chunks.size(); ++c)
+      for (int i = chunks[c].first; i < chunks[c].first + chunks[c].count; ++i) cf << cname[(size_t)i] << "\t" << clen[(size_t)i] << "\t" << c + 1 << "\n";
+    std::ofstream flag(ipre + ".index");                       // mapWrap.h:395-402
+    flag << 1 << "\n";
+    for (auto& fn : chunk_files) { flag << fn << "\n"; std::cout << "Stored state in file " << fn << "\n"; }
+    mm_ctx_destroy(ctx0);
+    return 0;
+  }
+
+  // `metamaps mapAgainstIndex`: the chunk list and the contig table of a stored index (mapWrap.h:443-554)
+  void read_index_files() {
     std::ifstream flag(ipre + ".index");
     if (!flag.is_open()) die("Index " + ipre + " not found (" + ipre + ".index)");
     int done = 0; flag >> done;
@@ -751,33 +809,35 @@ int map_mode(const Options& o, const std::string& mode) {
       chunks.push_back(Chunk{first < 0 ? 0 : first, count, chunk_files[c]});
     }
   }
-  const size_t NC = chunks.size();
+
   // ---- where the chunk indexes live
-  enum class Place { Replicated, Sharded, Streamed } place = Place::Replicated;
-  if (o.stream) place = Place::Streamed;
-  else if (o.shard) place = Place::Sharded;
-  else if (NC > 1) {
-    // every chunk index resident on every device / chunk c on device c mod G / one round of G chunks at a time: the first that fits
-    // (a chunk index costs more per base than the whole reference's: fewer occurrences per hash, the same padding per list)
-    std::vector<double> per_dev(G, 0.0); double all = 0, build_extra = 0;
-    for (size_t c = 0; c < NC; ++c) {
-      uint64_t cb = 0; for (int i = chunks[c].first; i < chunks[c].first + chunks[c].count; ++i) cb += (uint64_t)clen[(size_t)i];
-      const double b = index_bytes(cb, false);
-      all += b; per_dev[c % G] += b; build_extra = std::max(build_extra, index_bytes(cb, true) - b);
+  void decide_placement() {
+    NC = chunks.size();
+    if (o.stream) place = Place::Streamed;
+    else if (o.shard) place = Place::Sharded;
+    else if (NC > 1) {
+      // every chunk index resident on every device / chunk c on device c mod G / one round of G chunks at a time: the first that fits
+      // (a chunk index costs more per base than the whole reference's: fewer occurrences per hash, the same padding per list)
+      std::vector<double> per_dev(G, 0.0); double all = 0, build_extra = 0;
+      for (size_t c = 0; c < NC; ++c) {
+        uint64_t cb = 0; for (int i = chunks[c].first; i < chunks[c].first + chunks[c].count; ++i) cb += (uint64_t)clen[(size_t)i];
+        const double b = index_bytes(cb, false);
+        all += b; per_dev[c % G] += b; build_extra = std::max(build_extra, index_bytes(cb, true) - b);
+      }
+      const double room = 0.8 * (double)hbm_free;
+      if (all + build_extra <= room) place = Place::Replicated;
+      else place = (G > 1 && *std::max_element(per_dev.begin(), per_dev.end()) + build_extra <= room) ? Place::Sharded : Place::Streamed;
     }
-    const double room = 0.8 * (double)hbm_free;
-    if (all + build_extra <= room) place = Place::Replicated;
-    else place = (G > 1 && *std::max_element(per_dev.begin(), per_dev.end()) + build_extra <= room) ? Place::Sharded : Place::Streamed;
+    if (place != Place::Replicated && !o.stream && !o.shard) {
+      std::cout << "INFO, the index of " << ref_bases << " reference bases does not fit one device's " << (hbm_free >> 30) << " GiB: "
+                << (place == Place::Sharded ? "the chunk indexes are spread over the devices" : "chunk indexes are built and mapped one after the other") << "\n";
+    }
+    if (place != Place::Replicated && NC == 1 && !from_index && !maxMem) die("--stream-chunks / --shard-index need --maxmemory (the chunk rule of the reference, winSketch.hpp:274-329)");
+    for (auto& d : devs) d.idx.assign(NC, nullptr);
+    thr_of.assign(NC, INT_MAX);
   }
-  if (place != Place::Replicated && !o.stream && !o.shard) {
-    std::cout << "INFO, the index of " << ref_bases << " reference bases does not fit one device's " << (hbm_free >> 30) << " GiB: "
-              << (place == Place::Sharded ? "the chunk indexes are spread over the devices" : "chunk indexes are built and mapped one after the other") << "\n";
-  }
-  if (place != Place::Replicated && NC == 1 && !from_index && !maxMem) die("--stream-chunks / --shard-index need --maxmemory (the chunk rule of the reference, winSketch.hpp:274-329)");
-  for (auto& d : devs) d.idx.assign(NC, nullptr);
-  std::vector<int> thr_of(NC, INT_MAX);
-  std::map<int64_t, int64_t> thr_acc; int thr = INT_MAX;          // occurrence histogram accumulated over the chunks, never cleared (winSketch.hpp:452-494)
-  auto build_chunk = [&](Dev& d, size_t c) {                     // the index of chunk c on device d
+
+  void build_chunk(Dev& d, size_t c) {                            // the index of chunk c on device d
     const Chunk& ch = chunks[c];
     if (d.idx[c]) return;
     if (whole && NC == 1 && &d == &devs[0]) { d.idx[c] = whole; whole = nullptr; return; }
@@ -795,10 +855,10 @@ int map_mode(const Options& o, const std::string& mode) {
     else part = make_part((size_t)(&d - &devs[0]), ch.first, ch.first + ch.count);
     ck(d.ctx, mm_index_build(d.ctx, part, k, w, &d.idx[c]), "index chunk");
     if (!(ch.file.empty() && NC == 1)) mm_seqset_destroy(part);
-  };
+  }
   // freqThreshold of chunk c from the histogram accumulated over chunks 0..c: call once per chunk, in chunk order, after some
   // device has built it; the value is then set on every copy of that chunk
-  auto settle_threshold = [&](size_t c) {
+  void settle_threshold(size_t c) {
     mm_index* any = nullptr;
     for (auto& d : devs) if (d.idx[c]) { any = d.idx[c]; break; }
     int64_t n = 0; mm_index_freq_hist(any, nullptr, nullptr, 0, &n);
@@ -813,37 +873,35 @@ int map_mode(const Options& o, const std::string& mode) {
     for (auto& d : devs) if (d.idx[c]) mm_index_set_freq_threshold(d.idx[c], thr);
     std::cout << "INFO, index chunk " << c + 1 << "/" << NC << ": contigs " << chunks[c].first << ".." << chunks[c].first + chunks[c].count - 1
               << ", " << info.n_entries << " minimizers, " << info.n_unique_hashes << " unique hashes\n";
-  };
-  if (whole && !(NC == 1 && place == Place::Replicated)) { mm_index_destroy(whole); whole = nullptr; }
-  if (place == Place::Replicated) {
-    on_each(G, [&](size_t d) { for (size_t c = 0; c < NC; ++c) build_chunk(devs[d], c); });
-    for (size_t c = 0; c < NC; ++c) settle_threshold(c);
-    drop_refsets();
-    pc.lap("3 index build");
   }
-  const mm_map_params mp{k, w, pi, minLen};
-  std::vector<int32_t> chunk_base; for (auto& ch : chunks) chunk_base.push_back(ch.first);
-  start_reader();
-  if (prewarm.joinable()) prewarm.join();
-  if (place != Place::Replicated) for (auto*& c : wctx) if (c) { mm_ctx_destroy(c); c = nullptr; }   // (the other modes drive one context per device)
-  auto upload_batch = [&](mm_ctx* ctx, const Batch& bt) {
+
+  // replicated: every chunk index on every device before the first batch; the packed reference goes
+  void build_resident_indexes() {
+    if (whole && !(NC == 1 && place == Place::Replicated)) { mm_index_destroy(whole); whole = nullptr; }
+    if (place == Place::Replicated) {
+      on_each(G, [&](size_t d) { for (size_t c = 0; c < NC; ++c) build_chunk(devs[d], c); });
+      for (size_t c = 0; c < NC; ++c) settle_threshold(c);
+      drop_refsets();
+      pc.lap("3 index build");
+    }
+  }
+
+  mm_seqset* upload_batch(mm_ctx* ctx, const Batch& bt) {
     mm_seqset* reads; ck(ctx, mm_seqset_create(ctx, &reads), "seqset");
     for (size_t r = 0; r < bt.names.size(); ++r) ck(ctx, mm_seqset_add_view(reads, bt.seq_of(r), (int64_t)bt.lens[r]), "add read");
     ck(ctx, mm_seqset_upload(reads), "upload reads");
     return reads;
-  };
+  }
   // one "PREFIX.N" per chunk in the reference (mapWrap.h:419-437); `sketch_of`: an earlier mapping of the same batch on this device,
   // whose minimizers and sketches are reused (they do not depend on the index)
-  auto map_chunk = [&](mm_ctx* ctx, mm_index* idx, mm_seqset* reads, const mm_mapping* sketch_of = nullptr) {
+  mm_mapping* map_chunk(mm_ctx* ctx, mm_index* idx, mm_seqset* reads, const mm_mapping* sketch_of = nullptr) {
     mm_mapping* pm;
     if (sketch_of) ck(ctx, mm_map_batch_reusing(ctx, idx, reads, &mp, sketch_of, &pm), "map");
     else ck(ctx, mm_map_batch(ctx, idx, reads, &mp, &pm), "map");
     if (!o.all) ck(ctx, mm_mapping_keep_best(ctx, pm, k), "best mappings");
     return pm;
-  };
-  // what a worker hands to the writer: the finished text of one batch
-  struct Done { size_t file = 0; std::vector<std::string> names; std::vector<int> lens; std::vector<int64_t> off; std::string text; };
-  auto finish_mapping = [&](mm_ctx* ctx, mm_mapping* m, std::vector<std::string>&& names, std::vector<int>&& lens, size_t file) {   // mapping qualities + text; consumes m
+  }
+  std::unique_ptr<Done> finish_mapping(mm_ctx* ctx, mm_mapping* m, std::vector<std::string>&& names, std::vector<int>&& lens, size_t file) {   // mapping qualities + text; consumes m
     auto dn = std::make_unique<Done>();
     dn->file = file; dn->names = std::move(names); dn->lens = std::move(lens);
     const auto f0 = std::chrono::steady_clock::now();
@@ -861,13 +919,8 @@ int map_mode(const Options& o, const std::string& mode) {
     pc.add("7b fetch records", std::chrono::duration<double>(f2 - f1).count());
     pc.add("7c format", std::chrono::duration<double>(f3 - f2).count());
     return dn;
-  };
-  // the writer: batches in input order -> PREFIX, .meta.unmappedReadsLengths, .meta, .parameters of every query file (mapWrap.h:34-213)
-  struct Writer {
-    std::mutex m; std::condition_variable cv; std::map<size_t, std::unique_ptr<Done>> ready;
-    void put(size_t seq, std::unique_ptr<Done> d) { std::lock_guard<std::mutex> lk(m); ready[seq] = std::move(d); cv.notify_all(); }
-  } writer;
-  auto write_all = [&](const std::function<std::unique_ptr<Done>(size_t, size_t)>& next /* (file, seq): batch `seq` if it belongs to that file, nullptr once the file has ended */) {
+  }
+  void write_all(const std::function<std::unique_ptr<Done>(size_t, size_t)>& next /* (file, seq): batch `seq` if it belongs to that file, nullptr once the file has ended */) {
     size_t seq = 0;
     for (size_t fi = 0; fi < queries.size(); ++fi) {
       const std::string& prefix = prefixes[fi];
@@ -899,8 +952,9 @@ int map_mode(const Options& o, const std::string& mode) {
          << "]\noutFileName " << prefix << "\nreportAll " << o.all << "\nindex " << "" << "\nmaximumMemory " << maxMem << "\n";
       std::cout << "INFO, [count of mapped reads, reads qualified for mapping, total input reads] = [" << mapped << ", " << total - tooShort << ", " << total << "]\n";
     }
-  };
-  if (place == Place::Replicated) {
+  }
+
+  void run_replicated() {
     // ---- workers: four contexts per device (--workers-per-gpu; three until round 4: with ten batches of 10^5 reads in one file the GPU idled 60 % of the mapping phase), so that packing, result download and text formatting of one batch overlap the
     // kernels of the other; the device's chunk indexes are shared (read-only) by its contexts
     // The kernels of a batch fill the device; batches mapped side by side only take turns on it, and four workers that start together
@@ -957,7 +1011,9 @@ int map_mode(const Options& o, const std::string& mode) {
       }
     });
     for (auto& t : workers) t.join();
-  } else {
+  }
+
+  void run_chunk_major() {
     // ---- sharded / streamed: every read batch is packed onto every device and stays there (2 bits per base) ...
     struct Held { size_t file = 0; std::vector<std::string> names; std::vector<int> lens; std::vector<mm_seqset*> reads;
                   std::vector<mm_mapping*> sk;                 // per device: the batch's minimizers + sketches (mm_sketch_batch), computed once for all chunks
@@ -1066,12 +1122,49 @@ int map_mode(const Options& o, const std::string& mode) {
       return std::move(results[seq]);
     });
   }
-  pc.lap("8 write");
-  if (!getenv("MM_CLI_FULL_TEARDOWN")) { if (reader.th.joinable()) reader.th.join(); pc.report(); finish_fast(); }
-  drop_refsets();
-  for (auto& d : devs) { for (auto* ix : d.idx) if (ix) mm_index_destroy(ix); mm_ctx_destroy(d.ctx); }
-  return 0;
-}
+
+  // --then-classify DBDIR (not in the reference): `metamaps classify --DB DBDIR --mappings PREFIX` for every output prefix, in THIS process, on the
+  // files just written — the same code (classify_one) on the same bytes, so the same .EM* files as the two-process form, which stays the tested
+  // default.  What it saves is what lies between the two processes: this one's exit (150 GB of index handed back), the next one's HIP
+  // initialisation behind it (1.3-1.9 s waiting for the driver) and its contexts: the live contexts are used.
+  void then_classify() {
+    if (!o.v.count("then-classify") || only_index) return;
+    if (reader.th.joinable()) reader.th.join();
+    const EmReduce reduce = o.em_host ? EmReduce::Host : ((devs.size() > 1 || o.v.count("gpus") || o.v.count("devices")) ? EmReduce::Rccl : EmReduce::None);
+    const size_t minReadsU = o.v.count("minreads") ? std::stoull(o.v.at("minreads")) : 10000;   // parseCmdArgs.hpp:462-471
+    for (size_t fi = 0; fi < prefixes.size(); ++fi) {
+      classify_one(devs, reduce, prefixes[fi], o.v.at("then-classify"), minReadsU, nullptr, nullptr);
+      for (auto& d : devs) mm_comm_destroy(d.ctx);
+      pc.lap("9 classify");
+    }
+  }
+
+  int run() {
+    read_parameters();
+    open_devices();
+    if (!from_index) {
+      load_reference();
+      plan_chunks();
+      if (only_index) return write_index_files();
+    } else read_index_files();
+    decide_placement();
+    build_resident_indexes();
+    mp = mm_map_params{k, w, pi, minLen};
+    for (auto& ch : chunks) chunk_base.push_back(ch.first);
+    start_reader();
+    if (prewarm.joinable()) prewarm.join();
+    if (place != Place::Replicated) for (auto*& c : wctx) if (c) { mm_ctx_destroy(c); c = nullptr; }   // (the other modes drive one context per device)
+    if (place == Place::Replicated) run_replicated(); else run_chunk_major();
+    pc.lap("8 write");
+    then_classify();
+    if (!getenv("MM_CLI_FULL_TEARDOWN")) { if (reader.th.joinable()) reader.th.join(); pc.report(); finish_fast(); }
+    drop_refsets();
+    for (auto& d : devs) { for (auto* ix : d.idx) if (ix) mm_index_destroy(ix); mm_ctx_destroy(d.ctx); }
+    return 0;
+  }
+};
+
+int map_mode(const Options& o, const std::string& mode) { MapRun run(o, mode); return run.run(); }
 
 // ------------------------------------------------------------------------------------------------------
 struct TaxNode { std::string parent, rank, sci; };
@@ -1346,7 +1439,6 @@ bool write_unknown_species(const std::string& fn, const std::string& db, const T
 //   Host  each rank's partial sums (mm_em_iterate) added on the host in rank order — what the all-reduce delivers —; several ranks
 //         may then share one device, which is how everything AROUND the collective is tested on a one-GPU box (--em-host-reduce)
 //   None  one rank, no communicator
-enum class EmReduce { None, Rccl, Host };
 struct EmShard { size_t lo = 0, hi = 0, e0 = 0; std::vector<int64_t> soff; };   // reads [lo, hi); e0: first mapping of the shard; soff: shard-local offsets
 EmShard em_shard(const std::vector<int64_t>& off, size_t G, size_t d) {
   const size_t NR = off.size() - 1, base = NR / G, rem = NR % G;
@@ -1430,283 +1522,325 @@ void run_em_sharded(const std::vector<Dev>& devs, EmReduce reduce, const std::ve
   });
 }
 
-int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::string& mapped, const std::string& db, size_t minReadsU,
-                 const std::function<void()>& leave_now = nullptr /* the last file: called once everything is written; the process ends there */,
-                 const std::function<void()>& need_devices = nullptr /* called before the first device call: the contexts are created beside the parsing of the file */) {   // meta::doEM, fEM.h:466-803
+// One `classify` of one mappings file (meta::doEM, fEM.h:466-803): the file read and tokenised, the database's tables, the EM on the devices, every output
+// file.  The stages are the methods, in the order run() calls them.  (Until round 5 one 280-line function.)
+struct ClassifyRun {
+  const std::vector<Dev>& devs; const EmReduce reduce; const std::string& mapped; const std::string& db; const size_t minReadsU;
+  const std::function<void()>& leave_now;      // the last file: called once everything is written; the process ends there (may be empty)
+  const std::function<void()>& need_devices;   // called before the first device call: the contexts are created beside the parsing of the file (may be empty)
   PhaseClock pc;
-  // The mappings file once through: every line is tokenised where it lies (the reference splits every line again in every EM round,
-  // fEM.h:1171-1214, :234-373), lines of one read are consecutive (mapWrap.h:128-149), contig IDs are interned.
-  // Round 4: read and tokenised by several threads — pieces of the file that begin on a read boundary are parsed on their own and joined in
-  // file order (read offsets shifted, contig IDs interned in the order a single pass would meet them): 4.2 M lines took 1.3 s on one thread.
+  const unsigned HW = std::max(1u, std::thread::hardware_concurrency());
   struct TextBuf {                                               // the file's bytes + a terminating 0, not zero-filled first (std::string::resize spent 0.1 s on that per 0.5 GB)
     char* p = nullptr; size_t n = 0;
     void resize(size_t k) { p = new (std::nothrow) char[k + 1]; if (!p) die("out of host memory for the mappings file"); n = k; p[k] = 0; }   // (huge_new.hpp: on huge pages)
     size_t size() const { return n; } const char* c_str() const { return p; } char& operator[](size_t i) { return p[i]; }
     ~TextBuf() { delete[] p; }
-  } text;
-  const unsigned HW = std::max(1u, std::thread::hardware_concurrency());
-  {
-    const int fd = ::open(mapped.c_str(), O_RDONLY);
-    if (fd < 0) die("Cannot open mappings file " + mapped);
-    struct stat stt; if (fstat(fd, &stt) != 0) die("Cannot open mappings file " + mapped);
-    text.resize((size_t)stt.st_size);
-    const size_t PIECE = (size_t)32 << 20, np = (text.size() + PIECE - 1) / PIECE;
-    std::atomic<size_t> nx{0}; std::atomic<bool> bad{false};
-    auto rd = [&] { for (;;) { const size_t i = nx.fetch_add(1); if (i >= np) return; size_t a0 = i * PIECE; const size_t e0 = std::min(text.size(), a0 + PIECE);
-                      while (a0 < e0) { const ssize_t g = pread(fd, &text[a0], e0 - a0, (off_t)a0); if (g <= 0) { bad = true; return; } a0 += (size_t)g; } } };
-    std::vector<std::thread> pool; for (unsigned t = 1; t < std::min<unsigned>({8u, HW, (unsigned)std::max<size_t>(np, 1)}); ++t) pool.emplace_back(rd);
-    rd(); for (auto& t : pool) t.join();
-    ::close(fd);
-    if (bad) die("Cannot read mappings file " + mapped);
-  }
+  };
+  TextBuf text;
   struct MapLine { size_t beg, last_space, end; int contig; long long len; size_t start, stop; double ident, mapq; };   // [beg, end): the line; last_space: the blank before field 14
   std::vector<MapLine> lines; std::vector<int64_t> off{0};       // read r owns lines [off[r], off[r+1])
   std::vector<std::string> contig_id; std::unordered_map<std::string, int> contig_index;
-  {
-    const char* const T0 = text.c_str();
-    const size_t TS = text.size();
-    // the read ID of the line that starts at p (text up to the first blank or the line's end)
-    auto id_of = [&](size_t p, size_t& len) { const char* nl = (const char*)memchr(T0 + p, '\n', TS - p); const size_t e = nl ? (size_t)(nl - T0) : TS;
-                                              const char* sp = (const char*)memchr(T0 + p, ' ', e - p); len = (sp ? (size_t)(sp - T0) : e) - p; };
-    auto next_line = [&](size_t p) { const char* nl = (const char*)memchr(T0 + p, '\n', TS - p); return nl ? (size_t)(nl - T0) + 1 : TS; };
-    // first read boundary at or after x: a line start whose ID differs from the ID of the last non-empty line before it
-    auto read_boundary = [&](size_t x) {
-      if (x == 0) return (size_t)0;
-      size_t p = next_line(x - 1);                                // start of the first line that begins at or after x
-      while (p < TS) {
-        if (T0[p] == '\n') { ++p; continue; }                     // empty line
-        size_t q = p;                                            // start of the previous non-empty line
-        for (;;) { if (q == 0) return p; size_t e = q - 1; size_t b0 = e; while (b0 > 0 && T0[b0 - 1] != '\n') --b0; if (e > b0) { q = b0; break; } q = b0; }
-        size_t la, lb; id_of(p, la); id_of(q, lb);
-        if (la != lb || memcmp(T0 + p, T0 + q, la) != 0) return p;
-        p = next_line(p);
-      }
-      return TS;
-    };
-    // (MM_CLASSIFY_THREADS=n: exactly n pieces, whatever the size of the file — the tests cut small files into many)
-    const size_t NTH = getenv("MM_CLASSIFY_THREADS") ? (size_t)std::min(256, std::max(1, atoi(getenv("MM_CLASSIFY_THREADS"))))
-                                                     : std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::max(1u, HW / 4), TS / ((size_t)4 << 20) + 1}));
-    std::vector<size_t> cut(NTH + 1, TS);
-    cut[0] = 0;
-    for (size_t t = 1; t < NTH; ++t) cut[t] = std::max(cut[t - 1], read_boundary(TS / NTH * t));
-    struct Piece { std::vector<MapLine> lines; std::vector<int64_t> starts; std::vector<std::string> cid; std::unordered_map<std::string, int> cix; };
-    std::vector<Piece> pieces(NTH);
-    auto parse_piece = [&](size_t t) {
-      Piece& P = pieces[t];
-      size_t cur_beg = 0, cur_len = (size_t)-1;                  // the current read's ID, as a span of `text`
-      for (size_t p = cut[t]; p < cut[t + 1];) {
-        const char* nl = (const char*)memchr(T0 + p, '\n', cut[t + 1] - p);
-        const size_t e = nl ? (size_t)(nl - T0) : cut[t + 1];
-        if (e == p) { p = e + 1; continue; }                     // empty line
-        size_t fb[16], fe[16]; int nf = 0;                       // fields (single blanks, util.h:80)
-        for (size_t q = p; nf < 16;) { const char* sp = (const char*)memchr(T0 + q, ' ', e - q); fb[nf] = q; fe[nf] = sp ? (size_t)(sp - T0) : e; ++nf; if (!sp) break; q = fe[nf - 1] + 1; }
-        if (nf < 6) die("File " + mapped + " has weird format - is this a mappings file generated by MetaMap?");
-        if (nf < 14) die("File " + mapped + " has lines with fewer than 14 fields - is this a mappings file generated by MetaMap?");
-        if (fe[0] - fb[0] != cur_len || memcmp(T0 + fb[0], T0 + cur_beg, cur_len) != 0) { P.starts.push_back((int64_t)P.lines.size()); cur_beg = fb[0]; cur_len = fe[0] - fb[0]; }
-        MapLine L{};
-        L.beg = p; L.end = e; L.last_space = fb[13] - 1;
-        std::string cid(T0 + fb[5], fe[5] - fb[5]);
-        auto it = P.cix.find(cid);
-        if (it == P.cix.end()) { it = P.cix.emplace(cid, (int)P.cid.size()).first; P.cid.push_back(cid); }
-        L.contig = it->second;
-        L.len = strtoll(T0 + fb[1], nullptr, 10);
-        L.start = strtoull(T0 + fb[7], nullptr, 10); L.stop = strtoull(T0 + fb[8], nullptr, 10);
-        L.ident = strtod(T0 + fb[9], nullptr) / 100.0;
-        { errno = 0; char* endp = nullptr; L.mapq = strtod(T0 + fb[13], &endp);   // std::stod: out of range (also a denormal) throws; the reference then takes 0 for "…e-…" (fEM.h:269-275)
-          if (errno == ERANGE) { if (std::string(T0 + fb[13], fe[13] - fb[13]).find("e-") != std::string::npos) L.mapq = 0; else die("mapping quality out of range in " + mapped); }
-          if (endp == T0 + fb[13]) die("File " + mapped + " has a mapping quality that is not a number"); }
-        P.lines.push_back(L);
-        p = e + 1;
-      }
-    };
-    { std::vector<std::thread> pool; for (size_t t = 1; t < NTH; ++t) pool.emplace_back(parse_piece, t); parse_piece(0); for (auto& th : pool) th.join(); }
-    // join: contig IDs in the order of their first line, read offsets shifted by the lines before the piece
-    std::vector<std::vector<int>> remap(NTH);
-    std::vector<size_t> line0(NTH + 1, 0);
-    for (size_t t = 0; t < NTH; ++t) {
-      line0[t + 1] = line0[t] + pieces[t].lines.size();
-      remap[t].resize(pieces[t].cid.size());
-      for (size_t c = 0; c < pieces[t].cid.size(); ++c) {
-        auto it = contig_index.find(pieces[t].cid[c]);
-        if (it == contig_index.end()) { it = contig_index.emplace(pieces[t].cid[c], (int)contig_id.size()).first; contig_id.push_back(pieces[t].cid[c]); }
-        remap[t][c] = it->second;
-      }
-    }
-    lines.resize(line0[NTH]);
-    off.clear();
-    for (size_t t = 0; t < NTH; ++t) for (int64_t st0 : pieces[t].starts) off.push_back(st0 + (int64_t)line0[t]);
-    if (off.empty()) off.push_back(0);
-    auto place = [&](size_t t) { MapLine* o = lines.data() + line0[t]; const auto& src = pieces[t].lines; for (size_t i = 0; i < src.size(); ++i) { o[i] = src[i]; o[i].contig = remap[t][(size_t)src[i].contig]; } };
-    { std::vector<std::thread> pool; for (size_t t = 1; t < NTH; ++t) pool.emplace_back(place, t); place(0); for (auto& th : pool) th.join(); }
-    if (!lines.empty()) off.push_back((int64_t)lines.size());
-  }
-  const size_t NRD = off.size() - 1;
-  std::vector<std::string> contig_taxon_id(contig_id.size());
-  std::set<std::string> taxaSet;
-  for (size_t c = 0; c < contig_id.size(); ++c) { contig_taxon_id[c] = extract_taxon(contig_id[c]); taxaSet.insert(contig_taxon_id[c]); }
-  if (taxaSet.empty()) die("No relevant taxon IDs found in your mappings file - is it possible that none of your reads are mapped?");
-  std::map<std::string, size_t> st;
-  { std::ifstream s(mapped + ".meta"); if (!s.is_open()) die("The file " + mapped + ".meta is not present or could not be opened - this file is generated automatically as part of the mapping process, so please check whether the mapping process finished successfully.");
-    std::string a; size_t b; while (s >> a >> b) st[a] = b; }
-  const size_t nUnmapped = st.at("ReadsNotMapped"), nTooShort = st.at("ReadsTooShort"), nTotal = st.at("TotalReads");
+  size_t NRD = 0;
+  std::vector<std::string> contig_taxon_id; std::set<std::string> taxaSet;
+  std::map<std::string, size_t> st; size_t nUnmapped = 0, nTooShort = 0, nTotal = 0;
   std::map<std::string, std::map<std::string, size_t>> TI;       // fEM.h:1320-1364
-  { std::ifstream s(db + "/taxonInfo.txt"); if (!s.is_open()) die("Could not open file " + db + "/taxonInfo.txt -- perhaps you have specified an incomplete DB?");
-    std::string ln; while (std::getline(s, ln)) { if (ln.empty()) continue; auto f = split(ln, " "); for (auto& c : split(f.at(1), ";")) { auto kv = split(c, "="); TI[f.at(0)][kv.at(0)] = std::stoull(kv.at(1)); } } }
-  pc.lap("c1 read mappings + taxonInfo");
-  Taxonomy T(db + "/taxonomy");
-  pc.lap("c2 taxonomy");
-  std::vector<std::string> taxa(taxaSet.begin(), taxaSet.end());
-  std::map<std::string, int> tindex; for (size_t i = 0; i < taxa.size(); ++i) tindex[taxa[i]] = (int)i;
-  // per mapping: taxon, quality, 1/nLoc (getMappingLocations, fEM.h:234-353).  nLoc(read, taxon) = sum over the taxon's contigs of
-  // (len - L + 1) if len >= L, else 1 if the read has a mapping on that contig (:325-348): sorted lengths + suffix sums per taxon
-  std::vector<int> contig_tx(contig_id.size()); std::vector<long long> contig_len_ti(contig_id.size(), -1);   // taxon index; length per taxonInfo (-1: not listed)
-  struct TaxLens { std::vector<long long> len, suffix; };
-  std::vector<TaxLens> tl(taxa.size());
-  for (size_t t = 0; t < taxa.size(); ++t) {
-    auto it = TI.find(taxa[t]);
-    if (it == TI.end()) die("Unknown taxonID '" + taxa[t] + "'; please check that your mappings file was mapped against the database now specified.");
-    for (auto& c : it->second) tl[t].len.push_back((long long)c.second);
-    std::sort(tl[t].len.begin(), tl[t].len.end());
-    tl[t].suffix.assign(tl[t].len.size() + 1, 0);
-    for (size_t i = tl[t].len.size(); i-- > 0;) tl[t].suffix[i] = tl[t].suffix[i + 1] + tl[t].len[i];
-  }
-  for (size_t c = 0; c < contig_id.size(); ++c) {
-    contig_tx[c] = tindex.at(contig_taxon_id[c]);
-    auto& m = TI.at(contig_taxon_id[c]); auto it = m.find(contig_id[c]);
-    if (it != m.end()) contig_len_ti[c] = (long long)it->second;
-  }
-  std::vector<int32_t> taxon(lines.size()); std::vector<double> mapq(lines.size()), inv(lines.size());
-  {
-    std::vector<int> seen_c;                                     // distinct contigs of the current read
-    for (size_t r = 0; r < NRD; ++r) {
-      const size_t a0 = (size_t)off[r], b0 = (size_t)off[r + 1];
-      const long long L = lines[a0].len;
-      seen_c.clear();
-      for (size_t i = a0; i < b0; ++i) if (std::find(seen_c.begin(), seen_c.end(), lines[i].contig) == seen_c.end()) seen_c.push_back(lines[i].contig);
-      for (size_t i = a0; i < b0; ++i) {
-        const int t = contig_tx[(size_t)lines[i].contig];
-        const TaxLens& X = tl[(size_t)t];
-        const size_t k0 = (size_t)(std::lower_bound(X.len.begin(), X.len.end(), L) - X.len.begin());
-        long long n = X.suffix[k0] - (long long)(X.len.size() - k0) * (L - 1);
-        for (int c : seen_c) if (contig_tx[(size_t)c] == t && contig_len_ti[(size_t)c] >= 0 && contig_len_ti[(size_t)c] < L) ++n;
-        taxon[i] = t; mapq[i] = lines[i].mapq; inv[i] = 1 / (double)(size_t)n;
-      }
+  std::unique_ptr<Taxonomy> tax;
+  std::vector<std::string> taxa;
+  std::vector<int> contig_tx; std::vector<long long> contig_len_ti;   // per contig: taxon index; length per taxonInfo (-1: not listed)
+  std::vector<int32_t> taxon; std::vector<double> mapq, inv;          // per mapping
+  std::vector<double> f, post; std::vector<int64_t> best;
+
+  ClassifyRun(const std::vector<Dev>& devs_, EmReduce reduce_, const std::string& mapped_, const std::string& db_, size_t minReadsU_, const std::function<void()>& leave_now_,
+              const std::function<void()>& need_devices_) : devs(devs_), reduce(reduce_), mapped(mapped_), db(db_), minReadsU(minReadsU_), leave_now(leave_now_), need_devices(need_devices_) {}
+
+  // The mappings file once through: every line is tokenised where it lies (the reference splits every line again in every EM round,
+  // fEM.h:1171-1214, :234-373), lines of one read are consecutive (mapWrap.h:128-149), contig IDs are interned.
+  // Round 4: read and tokenised by several threads — pieces of the file that begin on a read boundary are parsed on their own and joined in
+  // file order (read offsets shifted, contig IDs interned in the order a single pass would meet them): 4.2 M lines took 1.3 s on one thread.
+  void read_file() {
+    {
+      const int fd = ::open(mapped.c_str(), O_RDONLY);
+      if (fd < 0) die("Cannot open mappings file " + mapped);
+      struct stat stt; if (fstat(fd, &stt) != 0) die("Cannot open mappings file " + mapped);
+      text.resize((size_t)stt.st_size);
+      const size_t PIECE = (size_t)32 << 20, np = (text.size() + PIECE - 1) / PIECE;
+      std::atomic<size_t> nx{0}; std::atomic<bool> bad{false};
+      auto rd = [&] { for (;;) { const size_t i = nx.fetch_add(1); if (i >= np) return; size_t a0 = i * PIECE; const size_t e0 = std::min(text.size(), a0 + PIECE);
+                        while (a0 < e0) { const ssize_t g = pread(fd, &text[a0], e0 - a0, (off_t)a0); if (g <= 0) { bad = true; return; } a0 += (size_t)g; } } };
+      std::vector<std::thread> pool; for (unsigned t = 1; t < std::min<unsigned>({8u, HW, (unsigned)std::max<size_t>(np, 1)}); ++t) pool.emplace_back(rd);
+      rd(); for (auto& t : pool) t.join();
+      ::close(fd);
+      if (bad) die("Cannot read mappings file " + mapped);
     }
   }
-  pc.lap("c3 per-mapping fields");
-  const size_t NT = taxa.size(), NR = NRD;
-  std::vector<double> f(NT, 1 / (double)NT);
-  std::vector<double> post(taxon.size()); std::vector<int64_t> best(NR);
-  std::cout << "Starting EM..." << std::endl;
-  if (need_devices) need_devices();
-  run_em_sharded(devs, reduce, off, taxon, mapq, inv, NT, f, post, best);
-  pc.lap("c4 EM");
-  std::cout << "Outputting mappings with adjusted alignment qualities." << std::endl;
-  std::ofstream emf(mapped + ".EM"), r2t(mapped + ".EM.reads2Taxon"), kr(mapped + ".EM.reads2Taxon.krona"), li(mapped + ".EM.lengthAndIdentitiesPerMappingUnit");
-  li << "AnalysisLevel\tID\treadI\tIdentity\tLength\n";
-  std::map<std::string, size_t> readsPer;
-  ContigCoverage coverage;
-  std::map<std::string, std::vector<double>> identsPerTaxon;     // :691, :718
-  long long maxReadLen = -1;                                     // :692, :719-722
-  std::thread side_files; bool unknown_written = true;
-  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } side_join{side_files};
-  {
-    // the four per-read / per-line files: ranges of reads formatted by several threads into their own buffers, written in read order
-    // (4.2 M lines through std::to_string on one thread took 1.2 s); the per-taxon tallies and the coverage windows follow in read order
-    std::vector<std::string> tax_nonx(taxa.size());              // getFirstNonXNode per taxon (taxonomy.h:51-74), once
-    for (size_t t = 0; t < taxa.size(); ++t) tax_nonx[t] = T.first_non_x(taxa[t]);
-    const size_t NTH = getenv("MM_CLASSIFY_THREADS") ? (size_t)std::min(256, std::max(1, atoi(getenv("MM_CLASSIFY_THREADS"))))
-                                                     : std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::max(1u, HW / 4), lines.size() / 50000 + 1}));
-    std::vector<size_t> rcut(NTH + 1, NRD);
-    rcut[0] = 0;
-    { size_t t = 1; for (size_t r = 0; r < NRD && t < NTH; ++r) if ((uint64_t)off[r] >= (uint64_t)lines.size() * t / NTH) rcut[t++] = r; }
-    struct Out { std::string em, r2, kr, li; };
-    std::vector<Out> outs(NTH);
-    auto fmt = [&](size_t t) {
-      Out& O = outs[t];
-      const size_t r0 = rcut[t], r1 = rcut[t + 1];
-      if (r1 <= r0) return;
-      O.em.reserve((lines[(size_t)off[r1] - 1].end - lines[(size_t)off[r0]].beg) + ((size_t)off[r1] - (size_t)off[r0]) * 4 + 64);
-      char num[64];
-      for (size_t r = r0; r < r1; ++r) {                         // fEM.h:684-779
-        for (size_t i = (size_t)off[r]; i < (size_t)off[r + 1]; ++i) {   // the line with field 14 replaced by std::to_string(posterior) (:705)
-          O.em.append(text.c_str() + lines[i].beg, lines[i].last_space + 1 - lines[i].beg);
-          append_f6(O.em, post[i]);
-          O.em += '\n';
+  void tokenise() {
+    {
+      const char* const T0 = text.c_str();
+      const size_t TS = text.size();
+      // the read ID of the line that starts at p (text up to the first blank or the line's end)
+      auto id_of = [&](size_t p, size_t& len) { const char* nl = (const char*)memchr(T0 + p, '\n', TS - p); const size_t e = nl ? (size_t)(nl - T0) : TS;
+                                                const char* sp = (const char*)memchr(T0 + p, ' ', e - p); len = (sp ? (size_t)(sp - T0) : e) - p; };
+      auto next_line = [&](size_t p) { const char* nl = (const char*)memchr(T0 + p, '\n', TS - p); return nl ? (size_t)(nl - T0) + 1 : TS; };
+      // first read boundary at or after x: a line start whose ID differs from the ID of the last non-empty line before it
+      auto read_boundary = [&](size_t x) {
+        if (x == 0) return (size_t)0;
+        size_t p = next_line(x - 1);                                // start of the first line that begins at or after x
+        while (p < TS) {
+          if (T0[p] == '\n') { ++p; continue; }                     // empty line
+          size_t q = p;                                            // start of the previous non-empty line
+          for (;;) { if (q == 0) return p; size_t e = q - 1; size_t b0 = e; while (b0 > 0 && T0[b0 - 1] != '\n') --b0; if (e > b0) { q = b0; break; } q = b0; }
+          size_t la, lb; id_of(p, la); id_of(q, lb);
+          if (la != lb || memcmp(T0 + p, T0 + q, la) != 0) return p;
+          p = next_line(p);
         }
-        const size_t b = (size_t)best[r];
-        const MapLine& B = lines[b];
-        const std::string& cg = contig_id[(size_t)B.contig];
-        const size_t rid_end = (size_t)((const char*)memchr(text.c_str() + B.beg, ' ', B.end - B.beg) - text.c_str());
-        O.li += "EqualCoverageUnit\t"; O.li += cg; O.li += '\t';
-        snprintf(num, sizeof num, "%zu\t%g\t%lld\n", r, B.ident, B.len); O.li += num;                  // :711
-        O.r2.append(text.c_str() + B.beg, rid_end - B.beg); O.r2 += '\t'; O.r2 += taxa[(size_t)taxon[b]]; O.r2 += '\n';
-        O.kr.append(text.c_str() + B.beg, rid_end - B.beg); O.kr += '\t'; O.kr += tax_nonx[(size_t)taxon[b]];
-        snprintf(num, sizeof num, "\t%g\n", post[b]); O.kr += num;
-      }
-    };
-    std::vector<std::thread> pool;
-    for (size_t t = 1; t < NTH; ++t) pool.emplace_back(fmt, t);
-    // meanwhile, on this thread: tallies per taxon and coverage windows, in read order (taxon and contig by index, strings only at the end)
-    std::vector<size_t> readsPerIdx(taxa.size(), 0);
-    std::vector<std::vector<double>> identsIdx(taxa.size());
-    std::vector<ContigCoverage::Slot> cslot(contig_id.size());
-    fmt(0);
-    for (size_t r = 0; r < NRD; ++r) {                           // the window vectors of every contig with a best mapping (map insertions: one thread)
-      const MapLine& B = lines[(size_t)best[r]];
-      const size_t tx = (size_t)taxon[(size_t)best[r]];
-      maxReadLen = std::max(maxReadLen, B.len);
-      if (contig_len_ti[(size_t)B.contig] < 0) die("contig " + contig_id[(size_t)B.contig] + " is not listed for taxon " + taxa[tx] + " in " + db + "/taxonInfo.txt");
-      ContigCoverage::Slot& sl = cslot[(size_t)B.contig];
-      if (!sl.v) sl = coverage.slot(taxa[tx], contig_id[(size_t)B.contig], (size_t)contig_len_ti[(size_t)B.contig]);
-    }
-    {                                                            // tallies: thread k owns the taxa and the contigs with index % NT2 == k and walks the reads in order
-      const size_t NT2 = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, HW / 8), NRD / 20000 + 1}));
-      auto tally = [&](size_t k) {
-        for (size_t r = 0; r < NRD; ++r) {
-          const size_t b = (size_t)best[r];
-          const MapLine& B = lines[b];
-          const size_t tx = (size_t)taxon[b];
-          if (tx % NT2 == k) { readsPerIdx[tx]++; identsIdx[tx].push_back(B.ident); }
-          if ((size_t)B.contig % NT2 == k) coverage.add(cslot[(size_t)B.contig], (size_t)contig_len_ti[(size_t)B.contig], B.start, B.stop);
+        return TS;
+      };
+      // (MM_CLASSIFY_THREADS=n: exactly n pieces, whatever the size of the file — the tests cut small files into many)
+      const size_t NTH = getenv("MM_CLASSIFY_THREADS") ? (size_t)std::min(256, std::max(1, atoi(getenv("MM_CLASSIFY_THREADS"))))
+                                                       : std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::max(1u, HW / 4), TS / ((size_t)4 << 20) + 1}));
+      std::vector<size_t> cut(NTH + 1, TS);
+      cut[0] = 0;
+      for (size_t t = 1; t < NTH; ++t) cut[t] = std::max(cut[t - 1], read_boundary(TS / NTH * t));
+      struct Piece { std::vector<MapLine> lines; std::vector<int64_t> starts; std::vector<std::string> cid; std::unordered_map<std::string, int> cix; };
+      std::vector<Piece> pieces(NTH);
+      auto parse_piece = [&](size_t t) {
+        Piece& P = pieces[t];
+        size_t cur_beg = 0, cur_len = (size_t)-1;                  // the current read's ID, as a span of `text`
+        for (size_t p = cut[t]; p < cut[t + 1];) {
+          const char* nl = (const char*)memchr(T0 + p, '\n', cut[t + 1] - p);
+          const size_t e = nl ? (size_t)(nl - T0) : cut[t + 1];
+          if (e == p) { p = e + 1; continue; }                     // empty line
+          size_t fb[16], fe[16]; int nf = 0;                       // fields (single blanks, util.h:80)
+          for (size_t q = p; nf < 16;) { const char* sp = (const char*)memchr(T0 + q, ' ', e - q); fb[nf] = q; fe[nf] = sp ? (size_t)(sp - T0) : e; ++nf; if (!sp) break; q = fe[nf - 1] + 1; }
+          if (nf < 6) die("File " + mapped + " has weird format - is this a mappings file generated by MetaMap?");
+          if (nf < 14) die("File " + mapped + " has lines with fewer than 14 fields - is this a mappings file generated by MetaMap?");
+          if (fe[0] - fb[0] != cur_len || memcmp(T0 + fb[0], T0 + cur_beg, cur_len) != 0) { P.starts.push_back((int64_t)P.lines.size()); cur_beg = fb[0]; cur_len = fe[0] - fb[0]; }
+          MapLine L{};
+          L.beg = p; L.end = e; L.last_space = fb[13] - 1;
+          std::string cid(T0 + fb[5], fe[5] - fb[5]);
+          auto it = P.cix.find(cid);
+          if (it == P.cix.end()) { it = P.cix.emplace(cid, (int)P.cid.size()).first; P.cid.push_back(cid); }
+          L.contig = it->second;
+          L.len = strtoll(T0 + fb[1], nullptr, 10);
+          L.start = strtoull(T0 + fb[7], nullptr, 10); L.stop = strtoull(T0 + fb[8], nullptr, 10);
+          L.ident = strtod(T0 + fb[9], nullptr) / 100.0;
+          { errno = 0; char* endp = nullptr; L.mapq = strtod(T0 + fb[13], &endp);   // std::stod: out of range (also a denormal) throws; the reference then takes 0 for "…e-…" (fEM.h:269-275)
+            if (errno == ERANGE) { if (std::string(T0 + fb[13], fe[13] - fb[13]).find("e-") != std::string::npos) L.mapq = 0; else die("mapping quality out of range in " + mapped); }
+            if (endp == T0 + fb[13]) die("File " + mapped + " has a mapping quality that is not a number"); }
+          P.lines.push_back(L);
+          p = e + 1;
         }
       };
-      std::vector<std::thread> tp;
-      for (size_t k = 1; k < NT2; ++k) tp.emplace_back(tally, k);
-      tally(0);
-      for (auto& th : tp) th.join();
+      { std::vector<std::thread> pool; for (size_t t = 1; t < NTH; ++t) pool.emplace_back(parse_piece, t); parse_piece(0); for (auto& th : pool) th.join(); }
+      // join: contig IDs in the order of their first line, read offsets shifted by the lines before the piece
+      std::vector<std::vector<int>> remap(NTH);
+      std::vector<size_t> line0(NTH + 1, 0);
+      for (size_t t = 0; t < NTH; ++t) {
+        line0[t + 1] = line0[t] + pieces[t].lines.size();
+        remap[t].resize(pieces[t].cid.size());
+        for (size_t c = 0; c < pieces[t].cid.size(); ++c) {
+          auto it = contig_index.find(pieces[t].cid[c]);
+          if (it == contig_index.end()) { it = contig_index.emplace(pieces[t].cid[c], (int)contig_id.size()).first; contig_id.push_back(pieces[t].cid[c]); }
+          remap[t][c] = it->second;
+        }
+      }
+      lines.resize(line0[NTH]);
+      off.clear();
+      for (size_t t = 0; t < NTH; ++t) for (int64_t st0 : pieces[t].starts) off.push_back(st0 + (int64_t)line0[t]);
+      if (off.empty()) off.push_back(0);
+      auto place = [&](size_t t) { MapLine* o = lines.data() + line0[t]; const auto& src = pieces[t].lines; for (size_t i = 0; i < src.size(); ++i) { o[i] = src[i]; o[i].contig = remap[t][(size_t)src[i].contig]; } };
+      { std::vector<std::thread> pool; for (size_t t = 1; t < NTH; ++t) pool.emplace_back(place, t); place(0); for (auto& th : pool) th.join(); }
+      if (!lines.empty()) off.push_back((int64_t)lines.size());
     }
-    for (size_t t = 0; t < taxa.size(); ++t) if (readsPerIdx[t]) { readsPer[taxa[t]] = readsPerIdx[t]; identsPerTaxon[taxa[t]] = std::move(identsIdx[t]); }
-    for (auto& th : pool) th.join();
-    pc.lap("c5a format");
-    // the two side files only read the tallies, which are complete here: they are written beside the per-read files and the WIMP (0.1 s of their own)
-    side_files = std::thread([&] {
-      std::thread cov_thread([&] { coverage.write(mapped + ".EM.contigCoverage", T); });
-      unknown_written = write_unknown_species(mapped + ".EM.evidenceUnknownSpecies", db, T, coverage, identsPerTaxon, maxReadLen, minReadsU);
-      cov_thread.join();
-    });
-    auto put = [&](std::ofstream& f, std::string Out::*m) { for (auto& O : outs) f.write((O.*m).data(), (std::streamsize)(O.*m).size()); };
-    std::thread w1([&] { put(r2t, &Out::r2); put(kr, &Out::kr); put(li, &Out::li); });
-    put(emf, &Out::em);
-    w1.join();
+    NRD = off.size() - 1;
   }
-  { std::ifstream s(mapped + ".meta.unmappedReadsLengths"); std::string ln;
-    while (std::getline(s, ln)) { if (ln.empty()) continue; auto fl = split(ln, "\t"); r2t << fl.at(1) << "\t" << 0 << "\n"; kr << fl.at(1) << "\t" << 0 << "\t" << 0 << "\n"; } }
-  std::map<std::string, double> fmap;
-  for (size_t i = 0; i < taxa.size(); ++i) fmap[taxa[i]] = f[i];
-  { const double minF = 0.9 * (1.0 / (double)st.at("ReadsMapped")); std::set<std::string> drop;   // cleanF, fEM.h:1135-1163
-    for (auto& e : fmap) if (e.second < minF && !readsPer.count(e.first)) drop.insert(e.first);
-    for (auto& d : drop) fmap.erase(d);
-    double s = 0; for (auto& e : fmap) s += e.second; for (auto& e : fmap) e.second /= s; }
-  pc.lap("c5 output files");
-  write_wimp(mapped + ".EM.WIMP", T, fmap, readsPer, nTotal, nUnmapped, nTooShort);
-  pc.lap("c6 WIMP");
-  side_files.join();
-  if (!unknown_written)
-    std::cerr << "Warning: " << db << "/contigNstats_windowSize_1000.txt not found - " << mapped << ".EM.evidenceUnknownSpecies is not written." << std::endl;
-  pc.lap("c8 evidence of unknown species + contig coverage");
-  if (leave_now && !getenv("MM_CLI_FULL_TEARDOWN")) { emf.close(); r2t.close(); kr.close(); li.close(); pc.report(); leave_now(); finish_fast(); }   // (a GB of vectors and strings: nothing left to do with them)
-  return 0;
+  // the taxa of the mapped contigs, PREFIX.meta, DB/taxonInfo.txt
+  void read_tables() {
+    contig_taxon_id.assign(contig_id.size(), std::string());
+    for (size_t c = 0; c < contig_id.size(); ++c) { contig_taxon_id[c] = extract_taxon(contig_id[c]); taxaSet.insert(contig_taxon_id[c]); }
+    if (taxaSet.empty()) die("No relevant taxon IDs found in your mappings file - is it possible that none of your reads are mapped?");
+    { std::ifstream s(mapped + ".meta"); if (!s.is_open()) die("The file " + mapped + ".meta is not present or could not be opened - this file is generated automatically as part of the mapping process, so please check whether the mapping process finished successfully.");
+      std::string a; size_t b; while (s >> a >> b) st[a] = b; }
+    nUnmapped = st.at("ReadsNotMapped"); nTooShort = st.at("ReadsTooShort"); nTotal = st.at("TotalReads");
+    { std::ifstream s(db + "/taxonInfo.txt"); if (!s.is_open()) die("Could not open file " + db + "/taxonInfo.txt -- perhaps you have specified an incomplete DB?");
+      std::string ln; while (std::getline(s, ln)) { if (ln.empty()) continue; auto f = split(ln, " "); for (auto& c : split(f.at(1), ";")) { auto kv = split(c, "="); TI[f.at(0)][kv.at(0)] = std::stoull(kv.at(1)); } } }
+  }
+  void per_mapping_fields() {
+    taxa.assign(taxaSet.begin(), taxaSet.end());
+    std::map<std::string, int> tindex; for (size_t i = 0; i < taxa.size(); ++i) tindex[taxa[i]] = (int)i;
+    // per mapping: taxon, quality, 1/nLoc (getMappingLocations, fEM.h:234-353).  nLoc(read, taxon) = sum over the taxon's contigs of
+    // (len - L + 1) if len >= L, else 1 if the read has a mapping on that contig (:325-348): sorted lengths + suffix sums per taxon
+    contig_tx.assign(contig_id.size(), 0); contig_len_ti.assign(contig_id.size(), -1);
+    struct TaxLens { std::vector<long long> len, suffix; };
+    std::vector<TaxLens> tl(taxa.size());
+    for (size_t t = 0; t < taxa.size(); ++t) {
+      auto it = TI.find(taxa[t]);
+      if (it == TI.end()) die("Unknown taxonID '" + taxa[t] + "'; please check that your mappings file was mapped against the database now specified.");
+      for (auto& c : it->second) tl[t].len.push_back((long long)c.second);
+      std::sort(tl[t].len.begin(), tl[t].len.end());
+      tl[t].suffix.assign(tl[t].len.size() + 1, 0);
+      for (size_t i = tl[t].len.size(); i-- > 0;) tl[t].suffix[i] = tl[t].suffix[i + 1] + tl[t].len[i];
+    }
+    for (size_t c = 0; c < contig_id.size(); ++c) {
+      contig_tx[c] = tindex.at(contig_taxon_id[c]);
+      auto& m = TI.at(contig_taxon_id[c]); auto it = m.find(contig_id[c]);
+      if (it != m.end()) contig_len_ti[c] = (long long)it->second;
+    }
+    taxon.assign(lines.size(), 0); mapq.assign(lines.size(), 0.0); inv.assign(lines.size(), 0.0);
+    {
+      std::vector<int> seen_c;                                     // distinct contigs of the current read
+      for (size_t r = 0; r < NRD; ++r) {
+        const size_t a0 = (size_t)off[r], b0 = (size_t)off[r + 1];
+        const long long L = lines[a0].len;
+        seen_c.clear();
+        for (size_t i = a0; i < b0; ++i) if (std::find(seen_c.begin(), seen_c.end(), lines[i].contig) == seen_c.end()) seen_c.push_back(lines[i].contig);
+        for (size_t i = a0; i < b0; ++i) {
+          const int t = contig_tx[(size_t)lines[i].contig];
+          const TaxLens& X = tl[(size_t)t];
+          const size_t k0 = (size_t)(std::lower_bound(X.len.begin(), X.len.end(), L) - X.len.begin());
+          long long n = X.suffix[k0] - (long long)(X.len.size() - k0) * (L - 1);
+          for (int c : seen_c) if (contig_tx[(size_t)c] == t && contig_len_ti[(size_t)c] >= 0 && contig_len_ti[(size_t)c] < L) ++n;
+          taxon[i] = t; mapq[i] = lines[i].mapq; inv[i] = 1 / (double)(size_t)n;
+        }
+      }
+    }
+  }
+  void em() {
+    const size_t NT = taxa.size(), NR = NRD;
+    f.assign(NT, 1 / (double)NT);
+    post.assign(taxon.size(), 0.0); best.assign(NR, 0);
+    std::cout << "Starting EM..." << std::endl;
+    if (need_devices) need_devices();
+    run_em_sharded(devs, reduce, off, taxon, mapq, inv, NT, f, post, best);
+  }
+  void write_outputs() {
+    Taxonomy& T = *tax;
+    std::cout << "Outputting mappings with adjusted alignment qualities." << std::endl;
+    std::ofstream emf(mapped + ".EM"), r2t(mapped + ".EM.reads2Taxon"), kr(mapped + ".EM.reads2Taxon.krona"), li(mapped + ".EM.lengthAndIdentitiesPerMappingUnit");
+    li << "AnalysisLevel\tID\treadI\tIdentity\tLength\n";
+    std::map<std::string, size_t> readsPer;
+    ContigCoverage coverage;
+    std::map<std::string, std::vector<double>> identsPerTaxon;     // :691, :718
+    long long maxReadLen = -1;                                     // :692, :719-722
+    std::thread side_files; bool unknown_written = true;
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } side_join{side_files};
+    {
+      // the four per-read / per-line files: ranges of reads formatted by several threads into their own buffers, written in read order
+      // (4.2 M lines through std::to_string on one thread took 1.2 s); the per-taxon tallies and the coverage windows follow in read order
+      std::vector<std::string> tax_nonx(taxa.size());              // getFirstNonXNode per taxon (taxonomy.h:51-74), once
+      for (size_t t = 0; t < taxa.size(); ++t) tax_nonx[t] = T.first_non_x(taxa[t]);
+      const size_t NTH = getenv("MM_CLASSIFY_THREADS") ? (size_t)std::min(256, std::max(1, atoi(getenv("MM_CLASSIFY_THREADS"))))
+                                                       : std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::max(1u, HW / 4), lines.size() / 50000 + 1}));
+      std::vector<size_t> rcut(NTH + 1, NRD);
+      rcut[0] = 0;
+      { size_t t = 1; for (size_t r = 0; r < NRD && t < NTH; ++r) if ((uint64_t)off[r] >= (uint64_t)lines.size() * t / NTH) rcut[t++] = r; }
+      struct Out { std::string em, r2, kr, li; };
+      std::vector<Out> outs(NTH);
+      auto fmt = [&](size_t t) {
+        Out& O = outs[t];
+        const size_t r0 = rcut[t], r1 = rcut[t + 1];
+        if (r1 <= r0) return;
+        O.em.reserve((lines[(size_t)off[r1] - 1].end - lines[(size_t)off[r0]].beg) + ((size_t)off[r1] - (size_t)off[r0]) * 4 + 64);
+        char num[64];
+        for (size_t r = r0; r < r1; ++r) {                         // fEM.h:684-779
+          for (size_t i = (size_t)off[r]; i < (size_t)off[r + 1]; ++i) {   // the line with field 14 replaced by std::to_string(posterior) (:705)
+            O.em.append(text.c_str() + lines[i].beg, lines[i].last_space + 1 - lines[i].beg);
+            append_f6(O.em, post[i]);
+            O.em += '\n';
+          }
+          const size_t b = (size_t)best[r];
+          const MapLine& B = lines[b];
+          const std::string& cg = contig_id[(size_t)B.contig];
+          const size_t rid_end = (size_t)((const char*)memchr(text.c_str() + B.beg, ' ', B.end - B.beg) - text.c_str());
+          O.li += "EqualCoverageUnit\t"; O.li += cg; O.li += '\t';
+          snprintf(num, sizeof num, "%zu\t%g\t%lld\n", r, B.ident, B.len); O.li += num;                  // :711
+          O.r2.append(text.c_str() + B.beg, rid_end - B.beg); O.r2 += '\t'; O.r2 += taxa[(size_t)taxon[b]]; O.r2 += '\n';
+          O.kr.append(text.c_str() + B.beg, rid_end - B.beg); O.kr += '\t'; O.kr += tax_nonx[(size_t)taxon[b]];
+          snprintf(num, sizeof num, "\t%g\n", post[b]); O.kr += num;
+        }
+      };
+      std::vector<std::thread> pool;
+      for (size_t t = 1; t < NTH; ++t) pool.emplace_back(fmt, t);
+      // meanwhile, on this thread: tallies per taxon and coverage windows, in read order (taxon and contig by index, strings only at the end)
+      std::vector<size_t> readsPerIdx(taxa.size(), 0);
+      std::vector<std::vector<double>> identsIdx(taxa.size());
+      std::vector<ContigCoverage::Slot> cslot(contig_id.size());
+      fmt(0);
+      for (size_t r = 0; r < NRD; ++r) {                           // the window vectors of every contig with a best mapping (map insertions: one thread)
+        const MapLine& B = lines[(size_t)best[r]];
+        const size_t tx = (size_t)taxon[(size_t)best[r]];
+        maxReadLen = std::max(maxReadLen, B.len);
+        if (contig_len_ti[(size_t)B.contig] < 0) die("contig " + contig_id[(size_t)B.contig] + " is not listed for taxon " + taxa[tx] + " in " + db + "/taxonInfo.txt");
+        ContigCoverage::Slot& sl = cslot[(size_t)B.contig];
+        if (!sl.v) sl = coverage.slot(taxa[tx], contig_id[(size_t)B.contig], (size_t)contig_len_ti[(size_t)B.contig]);
+      }
+      {                                                            // tallies: thread k owns the taxa and the contigs with index % NT2 == k and walks the reads in order
+        const size_t NT2 = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, HW / 8), NRD / 20000 + 1}));
+        auto tally = [&](size_t k) {
+          for (size_t r = 0; r < NRD; ++r) {
+            const size_t b = (size_t)best[r];
+            const MapLine& B = lines[b];
+            const size_t tx = (size_t)taxon[b];
+            if (tx % NT2 == k) { readsPerIdx[tx]++; identsIdx[tx].push_back(B.ident); }
+            if ((size_t)B.contig % NT2 == k) coverage.add(cslot[(size_t)B.contig], (size_t)contig_len_ti[(size_t)B.contig], B.start, B.stop);
+          }
+        };
+        std::vector<std::thread> tp;
+        for (size_t k = 1; k < NT2; ++k) tp.emplace_back(tally, k);
+        tally(0);
+        for (auto& th : tp) th.join();
+      }
+      for (size_t t = 0; t < taxa.size(); ++t) if (readsPerIdx[t]) { readsPer[taxa[t]] = readsPerIdx[t]; identsPerTaxon[taxa[t]] = std::move(identsIdx[t]); }
+      for (auto& th : pool) th.join();
+      pc.lap("c5a format");
+      // the two side files only read the tallies, which are complete here: they are written beside the per-read files and the WIMP (0.1 s of their own)
+      side_files = std::thread([&] {
+        std::thread cov_thread([&] { coverage.write(mapped + ".EM.contigCoverage", T); });
+        unknown_written = write_unknown_species(mapped + ".EM.evidenceUnknownSpecies", db, T, coverage, identsPerTaxon, maxReadLen, minReadsU);
+        cov_thread.join();
+      });
+      auto put = [&](std::ofstream& f, std::string Out::*m) { for (auto& O : outs) f.write((O.*m).data(), (std::streamsize)(O.*m).size()); };
+      std::thread w1([&] { put(r2t, &Out::r2); put(kr, &Out::kr); put(li, &Out::li); });
+      put(emf, &Out::em);
+      w1.join();
+    }
+    { std::ifstream s(mapped + ".meta.unmappedReadsLengths"); std::string ln;
+      while (std::getline(s, ln)) { if (ln.empty()) continue; auto fl = split(ln, "\t"); r2t << fl.at(1) << "\t" << 0 << "\n"; kr << fl.at(1) << "\t" << 0 << "\t" << 0 << "\n"; } }
+    std::map<std::string, double> fmap;
+    for (size_t i = 0; i < taxa.size(); ++i) fmap[taxa[i]] = f[i];
+    { const double minF = 0.9 * (1.0 / (double)st.at("ReadsMapped")); std::set<std::string> drop;   // cleanF, fEM.h:1135-1163
+      for (auto& e : fmap) if (e.second < minF && !readsPer.count(e.first)) drop.insert(e.first);
+      for (auto& d : drop) fmap.erase(d);
+      double s = 0; for (auto& e : fmap) s += e.second; for (auto& e : fmap) e.second /= s; }
+    pc.lap("c5 output files");
+    write_wimp(mapped + ".EM.WIMP", T, fmap, readsPer, nTotal, nUnmapped, nTooShort);
+    pc.lap("c6 WIMP");
+    side_files.join();
+    if (!unknown_written)
+      std::cerr << "Warning: " << db << "/contigNstats_windowSize_1000.txt not found - " << mapped << ".EM.evidenceUnknownSpecies is not written." << std::endl;
+    pc.lap("c8 evidence of unknown species + contig coverage");
+    if (leave_now && !getenv("MM_CLI_FULL_TEARDOWN")) { emf.close(); r2t.close(); kr.close(); li.close(); pc.report(); leave_now(); finish_fast(); }   // (a GB of vectors and strings: nothing left to do with them)
+  }
+  int run() {
+    read_file();
+    tokenise();
+    read_tables();
+    pc.lap("c1 read mappings + taxonInfo");
+    tax = std::make_unique<Taxonomy>(db + "/taxonomy");
+    pc.lap("c2 taxonomy");
+    per_mapping_fields();
+    pc.lap("c3 per-mapping fields");
+    em();
+    pc.lap("c4 EM");
+    write_outputs();
+    return 0;
+  }
+};
+
+int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::string& mapped, const std::string& db, size_t minReadsU,
+                 const std::function<void()>& leave_now, const std::function<void()>& need_devices) {
+  ClassifyRun run(devs, reduce, mapped, db, minReadsU, leave_now, need_devices);
+  return run.run();
 }
 
 }  // namespace
@@ -1718,6 +1852,7 @@ int main(int argc, char** argv) {
     return 1;
   }
   const std::string mode = argv[1];
+  if (mm::env_strict()) { const std::string bad = mm::env_unknown(); if (!bad.empty()) die("unknown MM_* environment switch(es): " + bad + " (MM_STRICT_ENV is set; see INTEGRATION.md)"); }
   Options o = parse(argc, argv);
   if (mode == "mapDirectly" || mode == "index" || mode == "mapAgainstIndex") return map_mode(o, mode);
   if (mode == "classify") {

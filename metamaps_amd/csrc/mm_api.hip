@@ -1,6 +1,7 @@
 // extern "C" surface of libmetamaps_hip.so (include/metamaps_hip.h).  Converts internal exceptions into
 // status codes + mm_last_error(); owns handle lifetimes.  No CPU fallback anywhere: without a gfx950
 // device mm_ctx_create fails and nothing else can be called.
+#include "mm_env.hpp"
 #include "mm_map.hpp"
 #include "mm_em.hpp"
 #include "mm_stats.hpp"
@@ -61,6 +62,10 @@ int mm_device_count(void) {
 int mm_ctx_create(int device_id, mm_ctx** out) {
   if (!out) return MM_ERR_ARG;
   *out = nullptr;
+  if (mm::env_strict()) {                                          // MM_STRICT_ENV=1: a MM_* variable the table (mm_env.hpp) does not know is an error, not a silent default
+    const std::string bad = mm::env_unknown();
+    if (!bad.empty()) { fprintf(stderr, "mm_ctx_create: unknown MM_* environment switch(es): %s (MM_STRICT_ENV is set; the table is metamaps_amd/csrc/mm_env.hpp / INTEGRATION.md)\n", bad.c_str()); return MM_ERR_ARG; }
+  }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MM_ERR_DEVICE;   // no GPU: fail loudly, never fall back
   if (device_id < 0 || device_id >= n) return MM_ERR_ARG;

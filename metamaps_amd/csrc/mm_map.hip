@@ -472,7 +472,8 @@ constexpr int SF_EXTRA = 1024;                                  // pieces of 32 
 struct SeedFilterLds {
   uint32_t cnt16[HF_SLOTS / 2];                                 // two 16-bit bin counters per word
   uint32_t good[HF_SLOTS / 32], alive[HF_SLOTS / 32];
-  uint64_t lstart[SF_SMAX];
+  uint32_t lstart8[SF_SMAX];                                   // first occurrence of every list / 8: lists start on 64-byte sectors = multiples of 8 entries (padded_counts_kernel), and an index of
+                                                                // more than 2^35 padded occurrences (275 GB of occ[] alone) does not fit a device — 11 KB of LDS that a minimizer workgroup of ANOTHER batch fits into beside this kernel
   uint16_t lcnt[SF_SMAX];
   uint16_t coff8[SF_SMAX + 8];                                  // first code chunk of every list (+ total)
   uint32_t extra[SF_EXTRA];                                     // 32-entry pieces beyond a list's first: list << 11 | piece
@@ -519,8 +520,8 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_kernel(IndexView I, co
             const uint32_t cnt = (uint32_t)(v.x >> 32);
             const bool keep = (uint64_t)cnt < (uint64_t)(int64_t)I.freq_threshold;   // computeMap.hpp:317
             if (keep && cnt > 0xffffu) L.fallback = 1;              // (a list this long overflows the code area anyway)
-            L.lcnt[i] = keep ? (uint16_t)cnt : (uint16_t)0; L.lstart[i] = keep ? v.y : 0ull;
-          } else if (!gm && sub == 0) { L.lcnt[i] = 0; L.lstart[i] = 0ull; }
+            L.lcnt[i] = keep ? (uint16_t)cnt : (uint16_t)0; L.lstart8[i] = keep ? (uint32_t)(v.y >> 3) : 0u;
+          } else if (!gm && sub == 0) { L.lcnt[i] = 0; L.lstart8[i] = 0u; }
           pending = false;
         }
         if (pending) { slot = tab_next_sector(slot, tslots); v = tab[slot + sub]; }
@@ -592,7 +593,7 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_kernel(IndexView I, co
         const int i = grp + SF_GROUPS * u;
         c[u] = i < s ? (uint32_t)L.lcnt[i] : 0u;
         v[u] = make_ulonglong2(0, 0);
-        if (c[u]) v[u] = *reinterpret_cast<const ulonglong2*>(I.occ16 + L.lstart[i] + min(8u * sub, (c[u] - 1) & ~7u));
+        if (c[u]) v[u] = *reinterpret_cast<const ulonglong2*>(I.occ16 + ((uint64_t)L.lstart8[i] << 3) + min(8u * sub, (c[u] - 1) & ~7u));
       }
 #pragma unroll
       for (int u = 0; u < SF_LPG; ++u) { const int i = grp + SF_GROUPS * u; if (c[u]) take(c[u], (uint32_t)i, (uint32_t)L.coff8[i], 0u, v[u]); }
@@ -608,7 +609,7 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_kernel(IndexView I, co
         if (k < ne) {
           const uint32_t e = L.extra[k], i = e >> 11;
           li[u] = i; c[u] = (uint32_t)L.lcnt[i]; ch0[u] = (uint32_t)L.coff8[i]; j0[u] = (e & 0x7ffu) << 5;
-          v[u] = *reinterpret_cast<const ulonglong2*>(I.occ16 + L.lstart[i] + min(j0[u] + 8u * sub, (c[u] - 1) & ~7u));
+          v[u] = *reinterpret_cast<const ulonglong2*>(I.occ16 + ((uint64_t)L.lstart8[i] << 3) + min(j0[u] + 8u * sub, (c[u] - 1) & ~7u));
         }
       }
 #pragma unroll
@@ -671,7 +672,7 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_kernel(IndexView I, co
     uint32_t pos = base + (uint32_t)(incl - mine);
     if (mask) {
       const uint32_t li = meta & 0xfffu;
-      const uint64_t first = L.lstart[li] + (uint64_t)(q - (uint32_t)L.coff8[li]) * 8u;
+      const uint64_t first = ((uint64_t)L.lstart8[li] << 3) + (uint64_t)(q - (uint32_t)L.coff8[li]) * 8u;
       while (mask) {
         const int t = __ffs(mask) - 1; mask &= mask - 1;
         if (pos < stage_cap) dst[pos] = first + (uint32_t)t;
@@ -706,8 +707,17 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_kernel(IndexView I, co
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// SF_STREAM_WAVES_PER_EU: the register budget of the streaming kernel.  4 (default) = all 512 registers of a SIMD's lane slot go to its four waves, 128
+// each.  5 = 96 each, which leaves 128 per SIMD — one wave of another kernel — free beside the resident workgroup; together with the 11 KB of LDS
+// that lstart8 freed (20 KB left: a minimizer workgroup of the OTHER worker's batch fits) VALU-bound work could run under this kernel's memory
+// waits.  Measured in round 5 (tools/ab.sh, one box, in turns): at 96 registers 43 are spilled, and a reload from scratch waits behind the look-ups in
+// flight: this kernel 14.9 -> 16.9 ms alone; the other worker's K1 does get in (its time inside the timed region 17 -> 13 ms), the step does not
+// gain: 45.4 / 47.4 ms against 44.5 / 46.9.  Not adopted; the switch stays for the record (tools/ab_build.sh w5 "-DSF_STREAM_WAVES_PER_EU=5").
+#ifndef SF_STREAM_WAVES_PER_EU
+#define SF_STREAM_WAVES_PER_EU 4
+#endif
 template <bool PROF>
-__global__ void __launch_bounds__(SF_THREADS) seed_filter_stream_kernel(IndexView I, const uint32_t* __restrict__ sk_hash, const uint64_t* __restrict__ off,
+__global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu(SF_STREAM_WAVES_PER_EU, SF_STREAM_WAVES_PER_EU))) seed_filter_stream_kernel(IndexView I, const uint32_t* __restrict__ sk_hash, const uint64_t* __restrict__ off,
                                                                         const int32_t* __restrict__ sk_n, const int32_t* __restrict__ read_len,
                                                                         const int32_t* __restrict__ min_hits, uint32_t* __restrict__ surv_n,
                                                                         uint64_t* __restrict__ stage, const uint64_t* __restrict__ stage_off,
@@ -806,8 +816,8 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_stream_kernel(IndexVie
             const uint32_t cnt = (uint32_t)(v.x >> 32);
             const bool keep = (uint64_t)cnt < (uint64_t)(int64_t)I.freq_threshold;   // computeMap.hpp:317
             if (keep && cnt > 0xffffu) L.fallback = 1;            // (a list this long overflows the code area anyway)
-            L.lcnt[i] = keep ? (uint16_t)cnt : (uint16_t)0; L.lstart[i] = keep ? v.y : 0ull;
-          } else if (!gm && sub == 0) { L.lcnt[i] = 0; L.lstart[i] = 0ull; }
+            L.lcnt[i] = keep ? (uint16_t)cnt : (uint16_t)0; L.lstart8[i] = keep ? (uint32_t)(v.y >> 3) : 0u;
+          } else if (!gm && sub == 0) { L.lcnt[i] = 0; L.lstart8[i] = 0u; }
           return true;
         }
         return !pending;
@@ -889,7 +899,7 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_stream_kernel(IndexVie
               const int i = grp + SF_GROUPS * u;
               c[u] = i < s ? (uint32_t)L.lcnt[i] : 0u;
               v[u] = make_ulonglong2(0, 0);
-              if (c[u]) v[u] = *reinterpret_cast<const ulonglong2*>(I.occ16 + L.lstart[i] + min(8u * sub, (c[u] - 1) & ~7u));
+              if (c[u]) v[u] = *reinterpret_cast<const ulonglong2*>(I.occ16 + ((uint64_t)L.lstart8[i] << 3) + min(8u * sub, (c[u] - 1) & ~7u));
             }
 #pragma unroll
             for (int u = 0; u < SF_LPG; ++u) { const int i = grp + SF_GROUPS * u; if (c[u]) take(c[u], (uint32_t)i, (uint32_t)L.coff8[i], 0u, v[u]); }
@@ -905,7 +915,7 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_stream_kernel(IndexVie
               if (k < ne) {
                 const uint32_t e = L.extra[k], i = e >> 11;
                 li[u] = i; c[u] = (uint32_t)L.lcnt[i]; ch0[u] = (uint32_t)L.coff8[i]; j0[u] = (e & 0x7ffu) << 5;
-                v[u] = *reinterpret_cast<const ulonglong2*>(I.occ16 + L.lstart[i] + min(j0[u] + 8u * sub, (c[u] - 1) & ~7u));
+                v[u] = *reinterpret_cast<const ulonglong2*>(I.occ16 + ((uint64_t)L.lstart8[i] << 3) + min(j0[u] + 8u * sub, (c[u] - 1) & ~7u));
               }
             }
 #pragma unroll
@@ -970,7 +980,7 @@ __global__ void __launch_bounds__(SF_THREADS) seed_filter_stream_kernel(IndexVie
           uint32_t pos = base + (uint32_t)(incl - mine);
           if (mask) {
             const uint32_t li = meta & 0xfffu;
-            const uint64_t first = L.lstart[li] + (uint64_t)(q - (uint32_t)L.coff8[li]) * 8u;
+            const uint64_t first = ((uint64_t)L.lstart8[li] << 3) + (uint64_t)(q - (uint32_t)L.coff8[li]) * 8u;
             while (mask) {
               const int t = __ffs(mask) - 1; mask &= mask - 1;
               if (pos < stage_cap) dst[pos] = first + (uint32_t)t;

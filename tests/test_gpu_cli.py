@@ -59,6 +59,34 @@ def test_cli_outputs_match_oracle(oracle_lib, tmp_path, w_flag):
     _cmp_unknown_species(pa, pb)
 
 
+CLASSIFY_SUFFIXES = (".EM", ".EM.reads2Taxon", ".EM.reads2Taxon.krona", ".EM.WIMP", ".EM.lengthAndIdentitiesPerMappingUnit", ".EM.contigCoverage", ".EM.evidenceUnknownSpecies")
+
+
+@pytest.mark.parametrize("devices", [None, "0,0"])
+def test_cli_then_classify_in_one_process_writes_the_same_files(tmp_path, devices):
+    """`mapDirectly ... --then-classify DBDIR` (classify in the mapping process, on the files it has just written, with the live contexts) == `mapDirectly`
+    followed by `classify` as two processes — every file byte for byte; two query files -> two prefixes, both classified; with two logical devices
+    the reads are sharded over them and the shards' sums added on the host (--em-host-reduce: RCCL refuses two ranks on one physical device), as `classify --devices 0,0` does"""
+    from metamaps_amd import synth
+    db = synth.make_db(str(tmp_path / "db"), n_genomes=10, genome_len=60_000, seed=7)
+    r1 = synth.make_reads(db, str(tmp_path / "r1.fq"), n_reads=220, read_len=3000, seed=3)
+    r2 = synth.make_reads(db, str(tmp_path / "r2.fq"), n_reads=90, read_len=2500, seed=4)
+    q = r1["path"] + "," + r2["path"]
+    dev = ["--devices", devices, "--em-host-reduce"] if devices else []
+    two = [str(tmp_path / "two_a"), str(tmp_path / "two_b")]
+    one = [str(tmp_path / "one_a"), str(tmp_path / "one_b")]
+    subprocess.run([CLI, "mapDirectly", "--all", "-r", db.fasta, "-q", q, "-o", ",".join(two)] + dev, check=True, capture_output=True, timeout=900)
+    subprocess.run([CLI, "classify", "--DB", db.dir, "--mappings", ",".join(two), "--minreads", "3"] + dev, check=True, capture_output=True, timeout=900)
+    p = subprocess.run([CLI, "mapDirectly", "--all", "-r", db.fasta, "-q", q, "-o", ",".join(one), "--then-classify", db.dir, "--minreads", "3"] + dev,
+                       capture_output=True, timeout=900, env=dict(os.environ, MM_CLI_TIMING="1"))
+    assert p.returncode == 0, p.stderr.decode()[-1500:]
+    assert "INFO, lap 9 classify" in p.stderr.decode()
+    for a, b in zip(one, two):
+        for suf in ("", ".meta", ".meta.unmappedReadsLengths") + CLASSIFY_SUFFIXES:
+            assert open(a + suf, "rb").read() == open(b + suf, "rb").read(), suf
+        assert os.path.getsize(a + ".EM.WIMP") > 200
+
+
 def test_cli_pooled_blocks_serve_the_workers(tmp_path):
     """mm_slab.hpp on the device: with the index-scale threshold lowered to 2 MiB (MM_INDEX_SCALE_MB) the buffers a 10 Mbp index build lets go
     of are pooled, and the worker contexts' allocations are cut out of them (MM_ALLOC_TRACE shows the pieces).  Files equal those of a run

@@ -71,3 +71,17 @@ def test_cached_blocks_of_one_context_serve_another():
     idx = a.index(ref, 16, 8)                                     # A works as before
     assert idx.info()["n_entries"] > 100_000
     idx.close(); ref.close(); b.close(); a.close()
+
+
+def test_strict_env_refuses_unknown_switches():
+    """MM_STRICT_ENV=1: a MM_* variable that metamaps_amd/csrc/mm_env.hpp does not list (a misspelt switch) fails mm_ctx_create and the CLI instead of being ignored"""
+    code = "import sys; sys.path.insert(0, sys.argv[1])\nfrom metamaps_amd import capi\ntry:\n    capi.Context(0); print('created')\nexcept capi.MMError as e:\n    print('refused', e.status)\n"
+    cli = os.path.join(ROOT, "metamaps_amd", "csrc", "metamaps")
+    for extra, expect in (({}, "created"), ({"MM_L2_FUL": "1"}, "refused -1"), ({"MM_L2_FULL": "1", "MM_BENCH_READS": "7"}, "created")):
+        env = dict(os.environ, MM_STRICT_ENV="1", **extra)
+        r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, timeout=600, env=env)
+        assert r.stdout.decode().strip().splitlines()[-1] == expect, (extra, r.stdout.decode(), r.stderr.decode()[-500:])
+        if "MM_L2_FUL" in extra:
+            assert "MM_L2_FUL" in r.stderr.decode()
+            c = subprocess.run([cli, "classify", "--DB", "/nonexistent", "--mappings", "/nonexistent"], capture_output=True, timeout=600, env=env)
+            assert c.returncode == 1 and "MM_L2_FUL" in c.stderr.decode()

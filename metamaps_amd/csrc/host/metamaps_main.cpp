@@ -1132,8 +1132,12 @@ struct MapRun {
     if (reader.th.joinable()) reader.th.join();
     const EmReduce reduce = o.em_host ? EmReduce::Host : ((devs.size() > 1 || o.v.count("gpus") || o.v.count("devices")) ? EmReduce::Rccl : EmReduce::None);
     const size_t minReadsU = o.v.count("minreads") ? std::stoull(o.v.at("minreads")) : 10000;   // parseCmdArgs.hpp:462-471
+    // the last prefix ends the process from inside classify_one, as the last file of `classify` does: everything is written and closed, the
+    // gigabyte of line tables and text is not taken apart first (MM_CLI_FULL_TEARDOWN=1: the orderly way)
+    const std::function<void()> leave = [&] { pc.lap("9 classify"); pc.report(); };
     for (size_t fi = 0; fi < prefixes.size(); ++fi) {
-      classify_one(devs, reduce, prefixes[fi], o.v.at("then-classify"), minReadsU, nullptr, nullptr);
+      const bool last = fi + 1 == prefixes.size();
+      classify_one(devs, reduce, prefixes[fi], o.v.at("then-classify"), minReadsU, last ? leave : std::function<void()>(), nullptr);
       for (auto& d : devs) mm_comm_destroy(d.ctx);
       pc.lap("9 classify");
     }

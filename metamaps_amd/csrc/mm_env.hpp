@@ -56,8 +56,6 @@ inline const EnvSwitch* env_table(size_t* n) {
     {"MM_INDEX_PART_MAX", "2^31 - 2^24 entries", "test", "entries per partition of the hash sort (small values: the partitioned sort + merge on small inputs)"},
     {"MM_DUP_SAT", "65535", "test", "saturation value of the stored same-hash neighbour distances (small values: K5's scan fall-back)"},
     // ---- library: mapping (mm_map.hip, mm_seq.hip)
-    {"MM_MZ_TWO_PASS", "unset", "test", "K1 for read batches as count pass + scan + write pass (what index builds use) instead of one launch with a chained scan inside"},
-    {"MM_MZ_CAP", "3 / (w + 1) records per position", "test", "capacity of the record array of K1's single pass (tiny values: the overflow fall-back to two passes)"},
     {"MM_SKETCH_BITONIC", "unset", "test", "K2 for sketches beyond the LDS radix sort: bitonic network instead of one segmented device sort"},
     {"MM_EAGER_TIEBREAK", "unset", "test", "resolve every duplicate-hash strand by the reference's std::sort order up front instead of only where a strand vote reads one"},
     {"MM_FORCE_AMB_REDO", "unset", "test", "every read with an unresolved strand goes through the redo path"},

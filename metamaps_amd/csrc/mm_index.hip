@@ -608,7 +608,7 @@ void index_save(const mm_index* I, const char* path) {
   MM_REQUIRE((int64_t)I->contig_len.size() == I->n_contigs && (int64_t)I->h_cstart.size() == I->n_contigs + 1, MM_ERR_STATE, "index without its contig table");
   put(fc.f, I->contig_len.data(), I->contig_len.size() * 4, "contig lengths");
   put(fc.f, I->h_cstart.data(), I->h_cstart.size() * 8, "contig entry ranges");
-  put_array(fc.f, I->pos, (size_t)I->N, pin, st, "entries");   // (the array may be a few per cent longer than N: the single-pass minimizer sweep sizes it from the expected density)
+  put_array(fc.f, I->pos, I->pos.n, pin, st, "entries");
   put_array(fc.f, I->cstart, I->cstart.n, pin, st, "contig starts");
   put_array(fc.f, I->occ, I->occ.n, pin, st, "occurrences");
   put_array(fc.f, I->occ16, I->occ16.n, pin, st, "occurrence bins");

@@ -23,6 +23,7 @@ namespace mm {
 constexpr int MZ_THREADS = 256;
 constexpr int MZ_TILE = 2048;          // positions per workgroup
 constexpr int MZ_MAX_W = 4096;
+constexpr int MZ_STAGE = 1024;         // staged records per tile in the single-pass scheme
 constexpr int MZ_MAX_K = 64;
 
 struct SeqView {                       // device view of an mm_seqset
@@ -145,24 +146,20 @@ __device__ inline int64_t seq_of_tile(const uint64_t* __restrict__ tile_first, i
 static __device__ int mz_dbg_stop = 0;   // timing aid (MM_MZ_DBG=n: the read kernel leaves after step n and reports no minimizers; tools/stage_ms.py)
 // MODE 0: tile_count[tile] = number of emitted minimizers (count pass of the two-pass scheme, index scale).
 // MODE 1: records written at tile_out[tile]... (write pass).
-// (MODE 2, rounds 1-4: single pass into a per-tile staging area of 1 024 records + a compaction kernel; replaced by MODE 3)
-// MODE 3: single pass, records written straight to their final place (round 5).  The place of a tile's records is the number of records of all
-//         tiles before it — a prefix over the launch, taken INSIDE the launch by a chained scan with decoupled look-back (Merrill & Garland):
-//         a tile takes its number from a ticket counter (tiles are numbered in the order they start, so every tile with a smaller number is
-//         running or done: waiting for them cannot deadlock), publishes its own count (LB_AGG | count) as soon as it has it, then one wavefront
-//         looks back over up to 64 predecessors at a time — a descriptor with LB_PREFIX ends the walk, LB_AGG values are summed on the way —
-//         and publishes LB_PREFIX | (prefix + count).  Descriptors are single 64-bit words read and written with relaxed agent-scope atomics
-//         (flag and value travel together; the XCDs' L2s are not coherent, agent scope goes to the memory side).  No staging area (4 GB per
-//         Gbp batch), no second kernel, no scan kernels between the two.  tile_out_w[tile] receives the tile's prefix (tile_out_w[n_tiles] the
-//         total); records beyond out_cap are not written and the overflow flag is raised (the caller's two-pass fall-back).
-constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_VALUE = (1ull << 62) - 1ull;
+// MODE 2: single pass — records staged at tile*MZ_STAGE and counted; compact_tiles_kernel then packs them.  A tile
+//         normally emits ~2/(w+1) of its 2048 positions; if one exceeds MZ_STAGE (low-complexity sequence) the
+//         overflow flag is raised and the caller falls back to the two-pass scheme.  Used for read batches.
+// (Round 5 measured the alternative to MODE 2 + compact_tiles_kernel: ONE launch whose tiles take the place of their records from a chained scan
+//  with decoupled look-back inside the launch — ticketed tile numbers, 64-bit {flag, value} descriptors, agent-scope atomics, one wavefront walking
+//  back 64 or 256 predecessors per step.  Bit-identical, and slower: the stage 9.7 -> 9.9 ms (64 per step) / 11.4 ms (256), index builds no faster
+//  although they hash once instead of twice.  The ~1 800 resident tiles finish as a generation, the nearest known prefix is then hundreds of tiles
+//  back and every step of the walk is a round trip to the memory side (the XCDs' L2s are not coherent) with the tile's other three wavefronts
+//  parked at the barrier.  Commit b69326c keeps the code.)
 template <int MODE>
 __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const uint64_t* __restrict__ tile_first, int k, int w,
                                                                const int32_t* __restrict__ jstar, uint32_t* __restrict__ tile_count,
                                                                const uint64_t* __restrict__ tile_out, Rec* __restrict__ out,
-                                                               uint32_t* __restrict__ out_seq, int* __restrict__ stage_overflow,
-                                                               unsigned long long* __restrict__ lb_desc /* MODE 3: [n_tiles], zeroed */, unsigned int* __restrict__ lb_ticket /* zeroed */,
-                                                               uint64_t* __restrict__ tile_out_w /* MODE 3: [n_tiles + 1] */, uint64_t out_cap, uint64_t n_tiles) {
+                                                               uint32_t* __restrict__ out_seq, int* __restrict__ stage_overflow) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int halo = (2 * (w - 1) + 7) & ~7;         // rounded so that the tile's first byte is 8-byte aligned in LDS
   const int NP = MZ_TILE + halo;                   // positions held
@@ -173,13 +170,7 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
   uint16_t* cps = (uint16_t*)(hsh + NP);
   uint8_t* flg = (uint8_t*)(cps + NP);
 
-  uint64_t tile = blockIdx.x;
-  if (MODE == 3) {
-    __shared__ unsigned int s_ticket;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(lb_ticket, 1u);
-    __syncthreads();
-    tile = s_ticket;
-  }
+  const uint64_t tile = blockIdx.x;
   const int64_t s = seq_of_tile(tile_first, S.n, tile);
   const int len = S.len[s];
   const int npos = len - k + 1;
@@ -230,12 +221,7 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
     }
   }
   const int dbgs = mz_dbg_stop;
-  auto dbg_leave = [&]() {                                       // timing aid: the tile reports no minimizers (MODE 3: as an empty link of the chain)
-    if (tid != 0) return;
-    if (MODE == 3) { __hip_atomic_store(&lb_desc[tile], LB_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tile_out_w[tile] = 0; if (tile + 1 == n_tiles) tile_out_w[n_tiles] = 0; }
-    else if (MODE != 1) tile_count[tile] = 0;
-  };
-  if (dbgs == 1) { dbg_leave(); return; }
+  if (dbgs == 1) { if (MODE != 1 && tid == 0) tile_count[tile] = 0; return; }
   // 2. canonical hash / strand / non-symmetric flag per position
   const int np = Pend - H0;
   if (k == 16) {
@@ -272,7 +258,7 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
     }
   }
   __syncthreads();
-  if (dbgs == 2) { dbg_leave(); return; }
+  if (dbgs == 2) { if (MODE != 1 && tid == 0) tile_count[tile] = 0; return; }
   // 3. window argmin c(p) for every evaluated position from P0-(w-1) on
   const int jeval0 = max(max(P0 - (w - 1), w - 1), H0) - H0;
   if (w <= 9) {
@@ -349,7 +335,7 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
     cps[j] = c;
   }
   __syncthreads();
-  if (dbgs == 3) { dbg_leave(); return; }
+  if (dbgs == 3) { if (MODE != 1 && tid == 0) tile_count[tile] = 0; return; }
   // 4. emission flags for the tile's own positions, 8 consecutive positions per thread
   const int js = jstar[s];
   const int j0 = (P0 - H0) + tid * (MZ_TILE / MZ_THREADS);
@@ -369,56 +355,11 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
   const uint32_t cnt = __popc(mask);
   uint64_t tot;
   uint64_t ex = block_excl_scan_u64(cnt, &tot);
-  if (dbgs == 4) { dbg_leave(); return; }
-  if (MODE != 1 && MODE != 3 && tid == 0) tile_count[tile] = (uint32_t)tot;
-  uint64_t lb_base = 0;
-  if (MODE == 3) {
-    __shared__ uint64_t s_base;
-    if (tid < 64) {                                                // the first wavefront walks the chain
-      const int lane = tid;
-      uint64_t excl = 0;
-      if (tile > 0) {
-        if (lane == 0) __hip_atomic_store(&lb_desc[tile], LB_AGG | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // LB_U descriptors per lane and step: the tiles of a launch finish in generations of ~1 800 (as many as are resident), so the nearest known
-        // prefix is often a thousand tiles back and every step of the walk is a round trip to the memory side: 64 per step took longer than the
-        // compaction kernel it replaces, 256 per step is 7 round trips per generation
-        constexpr int LB_U = 4;
-        for (int64_t look = (int64_t)tile - 1;; look -= 64 * LB_U) {
-          unsigned long long d[LB_U];
-#pragma unroll
-          for (int u = 0; u < LB_U; ++u) {                         // position lane * LB_U + u of the step, nearest predecessor first
-            const int64_t idx = look - (int64_t)(lane * LB_U + u);
-            d[u] = idx >= 0 ? __hip_atomic_load(&lb_desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_PREFIX;   // (before tile 0: a prefix of nothing)
-          }
-          int up = LB_U;                                           // this lane's first position that knows its prefix
-          uint64_t mine = 0;
-#pragma unroll
-          for (int u = 0; u < LB_U; ++u) {
-            const int64_t idx = look - (int64_t)(lane * LB_U + u);
-            while ((d[u] >> 62) == 0ull) { __builtin_amdgcn_s_sleep(1); d[u] = __hip_atomic_load(&lb_desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            if (up == LB_U) { mine += (uint64_t)(d[u] & LB_VALUE); if ((d[u] >> 62) == 2ull) up = u; }
-          }
-          const uint64_t pm = __ballot(up < LB_U);
-          const int first_l = pm ? __ffsll((unsigned long long)pm) - 1 : 64;   // the lane that holds the nearest known prefix
-          uint64_t v = lane <= first_l ? mine : 0ull;
-          for (int dd = 32; dd > 0; dd >>= 1) v += __shfl_xor(v, dd, 64);
-          excl += v;
-          if (pm) break;
-        }
-      }
-      if (lane == 0) {
-        __hip_atomic_store(&lb_desc[tile], LB_PREFIX | (unsigned long long)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_base = excl; tile_out_w[tile] = excl;
-        if (tile + 1 == n_tiles) tile_out_w[n_tiles] = excl + tot;
-        if (excl + tot > out_cap) atomicExch(stage_overflow, 1);
-      }
-    }
-    __syncthreads();
-    lb_base = s_base;
-    if (lb_base + tot > out_cap) return;                           // (the caller redoes the batch with the two-pass scheme)
-  }
+  if (dbgs == 4) { if (MODE != 1 && tid == 0) tile_count[tile] = 0; return; }
+  if (MODE != 1 && tid == 0) tile_count[tile] = (uint32_t)tot;
+  if (MODE == 2 && tot > MZ_STAGE) { if (tid == 0) atomicExch(stage_overflow, 1); return; }
   if (MODE != 0) {
-    uint64_t o = (MODE == 1 ? tile_out[tile] : lb_base) + ex;
+    uint64_t o = (MODE == 1 ? tile_out[tile] : tile * (uint64_t)MZ_STAGE) + ex;
 #pragma unroll
     for (int i = 0; i < MZ_TILE / MZ_THREADS; ++i) {
       if (mask & (1u << i)) {
@@ -430,6 +371,15 @@ __global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const 
       }
     }
   }
+}
+
+// packs the staged tiles of the single-pass scheme
+static __global__ void __launch_bounds__(256) compact_tiles_kernel(const Rec* __restrict__ stage, const uint32_t* __restrict__ tile_count,
+                                                                   const uint64_t* __restrict__ tile_out, Rec* __restrict__ out) {
+  const uint64_t tile = blockIdx.x;
+  const uint32_t n = tile_count[tile];
+  const uint64_t o = tile_out[tile];
+  for (uint32_t i = threadIdx.x; i < n; i += 256) out[o + i] = stage[tile * (uint64_t)MZ_STAGE + i];
 }
 
 inline size_t minimizer_lds_bytes(int k, int w) {

@@ -52,55 +52,39 @@ void run_minimizers(mm_ctx* ctx, const mm_seqset* S, int k, int w, const std::ve
   if (lds > 64 * 1024) {
     MM_HIP(hipFuncSetAttribute((const void*)minimizer_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MM_HIP(hipFuncSetAttribute((const void*)minimizer_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MM_HIP(hipFuncSetAttribute((const void*)minimizer_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MM_HIP(hipFuncSetAttribute((const void*)minimizer_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  DBuf<uint32_t> tcount;
+  DBuf<uint32_t> tcount((size_t)ntiles);
   DBuf<uint64_t> tout((size_t)ntiles + 1), tmp;
+  // hashing is the expensive part: do it once when a per-tile staging area (16 KiB per tile) is affordable
+  bool single_pass = !want_rec_seq && (size_t)ntiles * MZ_STAGE * sizeof(Rec) <= ((size_t)6 << 30);
+  DBuf<Rec> stage;
   DBuf<int> d_ovf(1); d_ovf.zero(st);
-  { const char* e = getenv("MM_MZ_DBG"); int v = e ? atoi(e) : 0; MM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(mz_dbg_stop), &v, sizeof v, 0, hipMemcpyHostToDevice, st)); }   // timing aid, see mm_minimizer.hpp
-  // Hashing is the expensive part: it is done once.  ONE launch writes the records to their final place, the tiles' prefix taken inside it by a
-  // chained scan (minimizer_kernel<3>).  The record array is sized from the density 2 / (w + 1) of winnowing: half as much again for read batches
-  // (their arrays are small and recycled), 8 % more for index builds (the array stays: pos[] of the index; 5.94e9 entries for 26.76e9 bases at
-  // w = 8 is the density to four digits) — and a set that emits more (homopolymer runs emit one per position) raises the overflow flag and takes
-  // the two-pass scheme (count, scan, write into arrays sized exactly: rounds 1-4's path for index builds, which hashed everything twice).
-  uint64_t total = 0;
-  bool done = false;
-  if (!getenv("MM_MZ_TWO_PASS")) {
-    uint64_t npos_all = 0;
-    for (int64_t i = 0; i < n; ++i) if (tf[(size_t)i + 1] > tf[(size_t)i]) npos_all += (uint64_t)((int64_t)S->len[(size_t)i] - k + 1);
-    const char* cap_env = getenv("MM_MZ_CAP");                    // test hook: a tiny capacity forces the fall-back
-    const uint64_t cap = cap_env ? (uint64_t)std::max<long long>(atoll(cap_env), 1) :
-                         std::min<uint64_t>(npos_all, (uint64_t)((double)npos_all * std::min(1.0, (want_rec_seq ? 2.16 : 3.0) / (double)(w + 1))) + (uint64_t)ntiles * 16 + 1024);
-    DBuf<unsigned long long> desc((size_t)ntiles); desc.zero(st);
-    DBuf<unsigned int> ticket(1); ticket.zero(st);
-    out.rec.alloc((size_t)cap);
-    if (want_rec_seq) out.rec_seq.alloc((size_t)cap);
-    minimizer_kernel<3><<<dim3((unsigned)ntiles), dim3(MZ_THREADS), lds, st>>>(V, d_tf.p, k, w, d_js.p, nullptr, nullptr, out.rec.p, want_rec_seq ? out.rec_seq.p : nullptr, d_ovf.p, desc.p, ticket.p, tout.p, cap,
-                                                                             (uint64_t)ntiles);
-    MM_KERNEL_CHECK();
-    int h_ovf = 0;
-    MM_HIP(hipMemcpyAsync(&total, tout.p + ntiles, sizeof total, hipMemcpyDeviceToHost, st));
-    MM_HIP(hipMemcpyAsync(&h_ovf, d_ovf.p, sizeof h_ovf, hipMemcpyDeviceToHost, st));
-    MM_HIP(hipStreamSynchronize(st));
-    done = !h_ovf;
-    if (done) out.total = (int64_t)total;
-    else { out.rec.release(); out.rec_seq.release(); }
+  if (single_pass) {
+    stage.alloc((size_t)ntiles * MZ_STAGE);
+    { const char* e = getenv("MM_MZ_DBG"); int v = e ? atoi(e) : 0; MM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(mz_dbg_stop), &v, sizeof v, 0, hipMemcpyHostToDevice, st)); }   // timing aid, see mm_minimizer.hpp
+    minimizer_kernel<2><<<dim3((unsigned)ntiles), dim3(MZ_THREADS), lds, st>>>(V, d_tf.p, k, w, d_js.p, tcount.p, nullptr, stage.p, nullptr, d_ovf.p);
+  } else {
+    minimizer_kernel<0><<<dim3((unsigned)ntiles), dim3(MZ_THREADS), lds, st>>>(V, d_tf.p, k, w, d_js.p, tcount.p, nullptr, nullptr, nullptr, nullptr);
   }
-  if (!done) {
-    tcount.alloc((size_t)ntiles);
-    minimizer_kernel<0><<<dim3((unsigned)ntiles), dim3(MZ_THREADS), lds, st>>>(V, d_tf.p, k, w, d_js.p, tcount.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0);
-    MM_KERNEL_CHECK();
-    exclusive_scan_u32_u64(tcount.p, ntiles, tout.p, tmp, st);
-    MM_HIP(hipMemcpyAsync(&total, tout.p + ntiles, sizeof total, hipMemcpyDeviceToHost, st));
-    MM_HIP(hipStreamSynchronize(st));
-    out.total = (int64_t)total;
-    out.rec.alloc((size_t)total);
-    if (want_rec_seq) out.rec_seq.alloc((size_t)total);
-    if (total) {
+  MM_KERNEL_CHECK();
+  exclusive_scan_u32_u64(tcount.p, ntiles, tout.p, tmp, st);
+  uint64_t total = 0;
+  int h_ovf = 0;
+  MM_HIP(hipMemcpyAsync(&total, tout.p + ntiles, sizeof total, hipMemcpyDeviceToHost, st));
+  MM_HIP(hipMemcpyAsync(&h_ovf, d_ovf.p, sizeof h_ovf, hipMemcpyDeviceToHost, st));
+  MM_HIP(hipStreamSynchronize(st));
+  if (h_ovf) single_pass = false;                                // some tile emitted more than MZ_STAGE records: counts are right, redo the write
+  out.total = (int64_t)total;
+  out.rec.alloc((size_t)total);
+  if (want_rec_seq) out.rec_seq.alloc((size_t)total);
+  if (total) {
+    if (single_pass)
+      compact_tiles_kernel<<<dim3((unsigned)ntiles), dim3(256), 0, st>>>(stage.p, tcount.p, tout.p, out.rec.p);
+    else
       minimizer_kernel<1><<<dim3((unsigned)ntiles), dim3(MZ_THREADS), lds, st>>>(V, d_tf.p, k, w, d_js.p, nullptr, tout.p, out.rec.p,
-                                                                               want_rec_seq ? out.rec_seq.p : nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0);
-      MM_KERNEL_CHECK();
-    }
+                                                                               want_rec_seq ? out.rec_seq.p : nullptr, nullptr);
+    MM_KERNEL_CHECK();
   }
   gather_offsets_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(d_tf.p, tout.p, n, out.off.p);
   MM_KERNEL_CHECK();

@@ -71,24 +71,6 @@ def test_minimizers_match_oracle(ctx, oracle_lib, k, w):
     s.close()
 
 
-@pytest.mark.parametrize("env", [{"MM_MZ_TWO_PASS": "1"}, {"MM_MZ_CAP": "5000"}], ids=lambda e: next(iter(e)))
-def test_minimizer_single_pass_equals_two_pass(ctx, monkeypatch, env):
-    """K1 for read batches is ONE launch whose tiles find the place of their records by a chained scan with look-back inside the launch
-    (minimizer_kernel<3>); the two-pass scheme (count, scan, write: what index builds use) and the fall-back a too small record array raises
-    (MM_MZ_CAP) give the same records"""
-    rnd = random.Random(9)
-    seqs = adversarial_sequences(4242, 300) + [bytes(rnd.choice(b"ACGT") for _ in range(700_000))]      # 342 tiles: the look-back walks more than one step
-    s = ctx.seqset(seqs)
-    ref = ctx.minimizers(s, 16, 8)
-    assert len(ref[1]) > 60_000
-    for kk, v in env.items():
-        monkeypatch.setenv(kk, v)
-    got = ctx.minimizers(s, 16, 8)
-    for a, b in zip(ref, got):
-        assert np.array_equal(a, b)
-    s.close()
-
-
 def _read_fasta(path):
     names, seqs, cur = [], [], []
     for ln in open(path, "rb"):

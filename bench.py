@@ -667,13 +667,14 @@ def roofline_block(args, R):
     kern = {
         "K1": entry("minimizer_kernel<2> + jstar_kernel + compact_tiles_kernel (the stage: mm_map_stats.ms_minimizer)", st_a["ms_minimizer"], st_a["bases_long_enough"] / 4.0,
                     agg["ms_mz"] / nl, agg["bases"] / 4.0 / nl, ["mm::minimizer_kernel<2>"],
-                    "VALU: two MurmurHash3 x64-128 per position = sixteen 64-bit multiplies (profiles/r04_sq_counters.txt: 97 percent of the issue slots); the HBM fraction is not its limit"),
+                    "VALU: two MurmurHash3 x64-128 per position = sixteen 64-bit multiplies (profiles/r05_sq_counters.txt: 97 percent of the issue slots); the HBM fraction is not its limit.  "
+                    "D3 counts only the packed bases it reads: the 8-byte records it writes (2.1 GB per step, twice: staged, then compacted) are what traffic_over_algorithmic shows"),
         "K3": entry("seed_filter_stream_kernel<false> (mm_map_stats.ms_hit_filter)", st_a["ms_hit_filter"], 8.0 * (st_a["sum_hits"] + st_a["sum_sketch"]),
                     agg["ms_hf"] / nl, 8.0 * agg["hf_units"] / nl, ["mm::seed_filter_stream_kernel<false>"],
                     "random 64-byte requests: table sector, occurrence list, survivors (tools/ubench/randread: 49e9 requests/s from HBM, 81e9/s from L2; profiles/r05_randread.txt); VALU 44 percent"),
         "K5": entry("l2_kernel<true,u8,4,2> + l2_kernel<true,u8,2,2> (the launch pair of a step: mm_map_stats.ms_l2)", st_a["ms_l2"], 8.0 * st_a["sum_l2_stream_entries"],
                     agg["ms_l2"] / nl, 8.0 * agg["l2_stream"] / nl, ["mm::l2_kernel<true, unsigned char, 4, 2>", "mm::l2_kernel<true, unsigned char, 2, 2>"],
-                    "VALU: 2.8 wave-instructions per streamed entry, 88 percent of the issue slots (profiles/r04_sq_counters.txt)"),
+                    "VALU: 2.8 wave-instructions per streamed entry, 87 percent of the issue slots (profiles/r05_sq_counters.txt); phase shares: profiles/r05_l2_phases.txt"),
     }
     dom = max(kern, key=lambda kk: kern[kk]["ms_alone"])
     d = kern[dom]

@@ -49,7 +49,10 @@ constexpr int L2_NBLK_MAX = 128;
 // bucket table over the top hash bits of the sketch: 1 024 buckets for the 10 kb class (sketches up to 3 072 hashes: at most four halving steps
 // inside a bucket; 2 048 buckets were measured in round 2 and cost in LDS what they saved), 4 096 for the long-read classes (sketches up to
 // 32 768: with 1 024 buckets their searches needed five steps and the generic loop, tools/l2_long_phases.py)
-__host__ __device__ constexpr int l2_tbits(int nwq) { return nwq == 2 ? 10 : 12; }
+#ifndef L2_TBITS_10K
+#define L2_TBITS_10K 10
+#endif
+__host__ __device__ constexpr int l2_tbits(int nwq) { return nwq == 2 ? L2_TBITS_10K : 12; }
 __host__ __device__ constexpr int l2_tsize(int nwq) { return (1 << l2_tbits(nwq)) + 1; }
 
 // does [lo, hi) of pos[] hold hash h?  512 entries per step, the eight loads of a step in flight together: one load per step

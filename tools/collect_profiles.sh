@@ -11,3 +11,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python bench.py --steps 1 --warmup 0 --workers 1 --distinct-batches 1 $FLAGS > /dev/null 2> $out/fetch.err
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python bench.py --steps 1 --warmup 0 --workers 1 --distinct-batches 1 $FLAGS > /dev/null 2> $out/write.err
 python tools/summarize_profiles.py $out
+# K5 phase clocks on the bench batch (10^5 x 10 kb), the probed-list distribution and the random-request ceiling (round 5)
+timeout 600 python tools/l2_long_phases.py 10000 10000 100000 > $out/l2_phases.txt 2>&1
+timeout 600 python tools/probed_lists.py > $out/probed_lists.json 2> /dev/null
+(for s in 2m 16m 128m 40; do ./tools/ubench/randread $s; done) > $out/randread.txt 2>&1

@@ -15,7 +15,7 @@ from metamaps_amd import capi  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=float, default=0.1, help="fraction of the bench's community reference (1.0 = 26.8 Gbp, 149 GB index)")
-    ap.add_argument("--dir", default="/tmp")
+    ap.add_argument("--dir", default="/tmp", help="where the file goes (/dev/shm: memory-backed, what a 149 GB index needs on a box with a small disk)")
     ap.add_argument("--reads", type=int, default=20000)
     a = ap.parse_args()
     s = a.scale
@@ -26,7 +26,7 @@ def main():
                                  strain_div_min=0.001, strain_div_max=0.05, genus_div_min=0.15, genus_div_max=0.25, strain_indel_events=8,
                                  human_contigs=human, human_bases=int(3.1e9 * min(s, 1.0)), repeat_fraction=0.45, n_fraction=0.01, n_repeat_families=1000,
                                  total_bases_target=int(26_762_276_280 * s))
-    out = {"reference_bases": ref.total_bases}
+    out = {"reference_bases": ref.total_bases, "dir": a.dir}
     builds = []
     for _ in range(2):                                             # (the first build also pays the device's first big allocations)
         t = time.time(); idx = ctx.index(ref, 16, 8); builds.append(round(time.time() - t, 3))
@@ -36,7 +36,12 @@ def main():
     info = idx.info()
     out.update(entries=info["n_entries"], unique_hashes=info["n_unique_hashes"], hbm_bytes=info["hbm_bytes"])
     path = os.path.join(a.dir, "persist_test.mmidx")
-    t = time.time(); idx.save(path); out["save_s"] = round(time.time() - t, 3)
+    try:
+        t = time.time(); idx.save(path); out["save_s"] = round(time.time() - t, 3)
+    except Exception:
+        if os.path.exists(path):
+            os.remove(path)                                        # (a partial file of 100+ GB fills the disk for everything that follows)
+        raise
     out["file_bytes"] = os.path.getsize(path)
     reads = ctx.synth_reads(ref, seed=5, n_reads=a.reads, read_len=10000, sub_rate=0.03, ins_rate=0.03, del_rate=0.03, frac_random=0.02, n_abundant=200, read_len_min=0)[0]
     Mb = ctx.map_batch(idx, reads, 16, 8)

@@ -59,11 +59,13 @@ def parse_args():
     ap.add_argument("--pacbio", action="store_true", help="PacBio-like errors (2/8/2 percent del/ins/sub) instead of ONT-like (5/3/4)")
     ap.add_argument("--scale", type=float, default=float(os.environ.get("MM_BENCH_SCALE", 1.0)), help="scales the number of genomes of the reference (quick checks)")
     ap.add_argument("--window", type=int, default=8, help="w the CLI derives for a 26.76 GB DB.fa at default flags")
-    ap.add_argument("--workers", type=int, default=int(os.environ.get("MM_BENCH_WORKERS", 2)),
+    ap.add_argument("--workers", type=int, default=int(os.environ.get("MM_BENCH_WORKERS", 3)),
                     help="host threads / contexts per GPU that take the steps in turn, each on its own stream: the kernels of two steps share the GPU "
                          "(what one leaves idle — launch gaps, draining kernels, host sections — the other fills).  Measured on the distinct-batch "
                          "workload (round 3): 2 workers 47.3 ms per step, 3 workers 47.6, 3 workers with the mapping sections serialised "
-                         "(--serialise-map, the default of rounds 2-3) 50.6")
+                         "(--serialise-map, the default of rounds 2-3) 50.6.  Round 5 (tools: in turns on one box): at 10^5 reads per step 2, 3 and 4 workers are "
+                         "the same within the noise (45.1-46.2 ms); at configs[2]'s per-GPU share of 12 500 reads a step is a third launch gaps and host sections, "
+                         "and a third worker fills them: 6.86 -> 6.29 ms per step (median 7.0 -> 5.8): the default is 3")
     ap.add_argument("--serialise-map", action="store_true", help="one lock around the mapping section of a step, passed on when its last big kernel (K5) is enqueued: "
                     "kernel durations are then those of kernels that (nearly) own the GPU; 7 percent less throughput on distinct batches")
     ap.add_argument("--staged-map", action="store_true", help="two locks instead of one around the mapping section (K1 + K2 | K3 ... K6, swapped at mm_map_batch_phased's "
@@ -711,6 +713,20 @@ def measured_traffic(args, prof_names):
     return None, "no committed PMC summary names this kernel"
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max or v1 cfs quota / period), None when unlimited or unknown"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, int(round(float(q) / float(per))))
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, int(round(q / per)))
+    except Exception:
+        return None
+
+
 def cpu_baseline_and_cli(args, R, k, w):
     """The oracle (CPU restatement of the reference, `-t` = every host core) and the drop-in CLI (FASTQ in, files out) on the same
     bounded sample of the bench workload, written to disk: the contigs the first `cpu_sample_reads` bench reads come from (up to
@@ -742,7 +758,8 @@ def cpu_baseline_and_cli(args, R, k, w):
             contigs.append(c); have.add(c); bases_have += int(cl[c])
         c += 1
     nproc = len(os.sched_getaffinity(0))
-    cores = args.cpu_threads or nproc                              # every hardware thread the box grants this process
+    quota = cpu_quota()
+    cores = args.cpu_threads or (min(nproc, quota) if quota else nproc)   # every CPU the box grants this process: the affinity mask AND the container's CPU quota
     with tempfile.TemporaryDirectory() as d:
         t0 = time.time()
         db = synth.write_db_dir(os.path.join(d, "db"), [(int(contig_taxon[ci]), ref.fetch(ci, int(cl[ci]))) for ci in contigs])
@@ -769,7 +786,9 @@ def cpu_baseline_and_cli(args, R, k, w):
         subprocess.run([exe, "classify", "--DB", db["dir"], "--mappings", os.path.join(d, "cpu"), "-t", str(cores)], capture_output=True, check=True, timeout=1500)
         t_cls = time.time() - t0
         bases = js["bases"]
-        cpu = {"value": bases / (js["map_seconds"] + t_cls) / 1e9, "unit": "Gbp/s", "cores": cores, "nproc": nproc, "kind": "port",
+        cpu = {"value": bases / (js["map_seconds"] + t_cls) / 1e9, "unit": "Gbp/s", "cores": cores, "nproc": nproc, "cgroup_cpu_quota": quota, "kind": "port",
+               "cores_note": "cores = the threads the oracle ran with = min(hardware threads in the affinity mask, the container's CPU quota: cgroup cpu.max).  Rounds 1-4 ran it with one thread per "
+                             "hardware thread (256) on a box whose container is allowed 16 CPUs' worth of time per 100 ms and reported cores = 256: the throughput was that of ~16 CPUs then too",
                "sample": f"{len(pick_reads)} of the bench reads ({bases} bp long enough) vs a {len(contigs)}-contig slice of the bench reference ({ref_bp / 1e6:.1f} Mbp, "
                          f"{100.0 * ref_bp / R['reference_bp']:.2f} % of it), oracle -t {cores}: mapping {js['map_seconds']:.2f} s + classify {t_cls:.2f} s "
                          f"(index build {js['seconds'] - js['map_seconds']:.2f} s excluded, as for the GPU)",
@@ -814,9 +833,25 @@ def cpu_baseline_and_cli(args, R, k, w):
     return cpu, e2e
 
 
+def _throttled_s():
+    """seconds this container's processes have been stopped for having used up their CPU quota (cgroup v2 cpu.stat), None if unknown"""
+    try:
+        for ln in open("/sys/fs/cgroup/cpu.stat"):
+            if ln.startswith("throttled_usec"):
+                return int(ln.split()[1]) / 1e6
+    except Exception:
+        pass
+    return None
+
+
+LAST_CLI_THROTTLED_S = [None]
+
+
 def _run_cli_with_rss(cmd, env, timeout):
-    """run a child process; returns (CompletedProcess-like, wall seconds, peak resident set in bytes — VmHWM polled from /proc)"""
+    """run a child process; returns (CompletedProcess-like, wall seconds, peak resident set in bytes — VmHWM polled from /proc); LAST_CLI_THROTTLED_S[0] = seconds the
+    container was throttled for CPU quota meanwhile"""
     import threading
+    thr0 = _throttled_s()
     t0 = time.time()
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     peak = [0]
@@ -837,6 +872,8 @@ def _run_cli_with_rss(cmd, env, timeout):
         p.kill(); out, err = p.communicate()
         raise RuntimeError(f"{cmd[0]} {cmd[1]} timed out after {timeout} s")
     wall = time.time() - t0                                        # (before the poller is joined: its 0.25 s nap is not the child's time — rounds 2-3 charged it)
+    thr1 = _throttled_s()
+    LAST_CLI_THROTTLED_S[0] = round(thr1 - thr0, 3) if thr0 is not None and thr1 is not None else None
     th.join(timeout=1)
     if p.returncode != 0:
         raise RuntimeError(f"{cmd[0]} {cmd[1]} failed ({p.returncode}): {err.decode(errors='replace')[-600:]}")
@@ -971,6 +1008,7 @@ def e2e_cli_full(args, k, w, rank_seed):
             # the two sub-commands — no exit with 150 GB to hand back, no second HIP initialisation waiting behind it — and nothing excluded from the clock
             pre_t = os.path.join(d, "out_stream_tc")
             _o4, e_t, t_tc, rss_t = _run_cli_with_rss([cli, "mapDirectly", "--all", "-r", fasta, "-q", fq_s, "-o", pre_t, "--then-classify", db], env, 1500)
+            thr_tc = LAST_CLI_THROTTLED_S[0]
             laps_t = {ln.split(" at +")[0][len("INFO, lap "):]: float(ln.split(" at +")[1].split()[0]) for ln in e_t.splitlines() if ln.startswith("INFO, lap ")}
             ph_t = {" ".join(ln.split()[2:-2]): float(ln.split()[-2]) for ln in e_t.splitlines() if ln.startswith("INFO, time ")}
             t_tc_phase = max(laps_t.get("9 classify", t_tc) - laps_t.get("3 index build", 0.0), 1e-9)
@@ -989,6 +1027,25 @@ def e2e_cli_full(args, k, w, rank_seed):
                 variants[wv] = {"mapping_phase_s": round(lv.get("8 write", t_v) - lv.get("3 index build", 0.0), 3), "phases": pv,
                                 "same_file": open(pre_s).read() == open(pre_s + "_w" + wv).read()}
                 os.remove(pre_s + "_w" + wv)
+            # measurement aid: the stream's mapDirectly again under other environments / flags ("name:KEY=VAL KEY2=VAL2 --flag value;name2:...")
+            for spec in [x for x in os.environ.get("MM_BENCH_E2E_STREAM_VARIANTS", "").split(";") if x]:
+                vname, _, rest = spec.partition(":")
+                venv, vflags = dict(env), []
+                for tok in rest.split():
+                    if "=" in tok and not tok.startswith("-"):
+                        kk, _, vv = tok.partition("="); venv[kk] = vv
+                    else:
+                        vflags.append(tok)
+                for rep in range(int(os.environ.get("MM_BENCH_E2E_VARIANT_REPS", 2))):
+                    _o5, e_v, t_v, _r = _run_cli_with_rss([cli, "mapDirectly", "--all", "-r", fasta, "-q", fq_s, "-o", pre_s + "_v"] + vflags, venv, 1500)
+                    lv = {ln.split(" at +")[0][len("INFO, lap "):]: float(ln.split(" at +")[1].split()[0]) for ln in e_v.splitlines() if ln.startswith("INFO, lap ")}
+                    maps = sorted(float(ln.split(" map ")[1].split()[0]) for ln in e_v.splitlines() if ln.startswith("INFO, worker") and " map " in ln)
+                    variants.setdefault("env " + vname, []).append({"mapping_phase_s": round(lv.get("8 write", t_v) - lv.get("3 index build", 0.0), 3),
+                                                                    "map_section_s": {"median": maps[len(maps) // 2] if maps else None, "max": maps[-1] if maps else None, "above_40ms": sum(1 for m_ in maps if m_ > 0.04)},
+                                                                    "same_file": open(pre_s).read() == open(pre_s + "_v").read()})
+                    if os.environ.get("MM_BENCH_E2E_LOG"):
+                        open(os.path.join(os.environ["MM_BENCH_E2E_LOG"], f"cli_stream_map_{vname}_{rep}.err"), "w").write(e_v)
+                    os.remove(pre_s + "_v")
             cph = {ln.split()[2] + " " + " ".join(ln.split()[3:-2]): float(ln.split()[-2]) for ln in e_c.splitlines() if ln.startswith("INFO, time c")}
             cmain = {ln.split(" at +")[0][12:]: float(ln.split(" at +")[1].split()[0]) for ln in e_c.splitlines() if ln.startswith("INFO, main: ") and " at +" in ln}
             t_phase_s = max(laps_s.get("8 write", t_map_s) - laps_s.get("3 index build", 0.0), 1e-9)
@@ -1006,7 +1063,7 @@ def e2e_cli_full(args, k, w, rank_seed):
                       "value": bases_s / t_tc_phase / 1e9,
                       "then_classify": {"index_built_to_last_file_s": round(t_tc_phase, 3), "mapping_phase_s": round(laps_t.get("8 write", 0.0) - laps_t.get("3 index build", 0.0), 3),
                                         "classify_s": round(laps_t.get("9 classify", 0.0) - laps_t.get("8 write", 0.0), 3), "process_wall_s": round(t_tc, 3),
-                                        "same_files_as_two_processes": bool(tc_same), "laps_s": laps_t, "phases_s": ph_t, "peak_host_rss_bytes": int(rss_t)},
+                                        "same_files_as_two_processes": bool(tc_same), "cpu_quota_throttled_s": thr_tc, "laps_s": laps_t, "phases_s": ph_t, "peak_host_rss_bytes": int(rss_t)},
                       "two_processes": {"value_all_in": bases_s / (t_phase_s + t_cls_s) / 1e9, "value_without_the_wait": bases_s / (t_phase_s + t_cls_work_s) / 1e9},
                       "fastq_reader": {"bytes": os.path.getsize(fq_s), "parse_s": reader_parse_s, "GB_per_s": (os.path.getsize(fq_s) / reader_parse_s / 1e9) if reader_parse_s else None,
                                        "threads": r_thr,

@@ -30,6 +30,7 @@
 // Not provided: classifyU (disabled upstream).
 
 #include "../mm_env.hpp"
+#include "../cpu_budget.hpp"
 #include "../../../include/metamaps_hip.h"
 #include "seq_reader.hpp"
 #include "host_util.hpp"
@@ -249,7 +250,7 @@ static void format_range(const std::vector<std::string>& names, const std::vecto
 void format_records(const std::vector<std::string>& names, const std::vector<int>& lens, const std::vector<int64_t>& off,
                     const std::vector<mm_map_record>& rec, const std::vector<std::string>& cname, const std::vector<int>& clen, int k, std::string& out) {
   const size_t n = names.size();
-  const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 8), rec.size() / 10000 + 1}));
+  const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, mm::cpu_budget() / 4), rec.size() / 10000 + 1}));   // (a quarter of the CPU budget per worker: four workers rarely format at the same moment)
   static thread_local std::vector<FormatCache> caches(8);          // (the calling thread's: a worker of mapDirectly formats batch after batch)
   if (T == 1) { format_range(names, lens, off, rec, cname, clen, k, 0, n, out, caches[0]); return; }
   std::vector<size_t> cut(T + 1, n);
@@ -313,7 +314,7 @@ struct MapRun {
   mm_map_params mp{};
   std::vector<int32_t> chunk_base;
   // what a worker hands to the writer: the finished text of one batch
-  struct Done { size_t file = 0; std::vector<std::string> names; std::vector<int> lens; std::vector<int64_t> off; std::string text; };
+  struct Done { size_t file = 0; std::vector<std::string> names; std::vector<int> lens; std::vector<int64_t> off; std::string text; double t_mapq = 0, t_fetch = 0, t_format = 0; };
   // the writer: batches in input order -> PREFIX, .meta.unmappedReadsLengths, .meta, .parameters of every query file (mapWrap.h:34-213)
   struct Writer {
     std::mutex m; std::condition_variable cv; std::map<size_t, std::unique_ptr<Done>> ready;
@@ -482,7 +483,7 @@ struct MapRun {
         struct Block { std::vector<std::unique_ptr<Batch>> out; size_t next = 0; bool done = false, empty = false, over = false; };   // next: first record start behind the block's records
         std::vector<Block> blocks(nb);
         std::mutex bm; std::condition_variable bcv; size_t next_block = 0, consumed = 0; bool abandon = false;
-        const unsigned P = (unsigned)std::max<size_t>(1, std::min<size_t>({nb, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4)}));
+        const unsigned P = (unsigned)std::max<size_t>(1, std::min<size_t>({nb, (size_t)8, (size_t)std::max(1u, mm::cpu_budget() / 4)}));
         auto worker = [&]() {
           for (;;) {
             size_t j;
@@ -614,7 +615,7 @@ struct MapRun {
       struct Block { std::vector<std::unique_ptr<Group>> out; size_t next = 0; bool done = false, empty = false, over = false; };
       std::vector<Block> blocks(nb);
       std::mutex bm; std::condition_variable bcv; size_t next_block = 0, consumed = 0; bool abandon = false;
-      const unsigned P = (unsigned)std::max<size_t>(1, std::min<size_t>({nb, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4)}));
+      const unsigned P = (unsigned)std::max<size_t>(1, std::min<size_t>({nb, (size_t)8, (size_t)std::max(1u, mm::cpu_budget() / 4)}));
       auto worker = [&]() {
         for (;;) {
           size_t j;
@@ -918,6 +919,7 @@ struct MapRun {
     pc.add("7a mapping qualities + offsets", std::chrono::duration<double>(f1 - f0).count());
     pc.add("7b fetch records", std::chrono::duration<double>(f2 - f1).count());
     pc.add("7c format", std::chrono::duration<double>(f3 - f2).count());
+    dn->t_mapq = std::chrono::duration<double>(f1 - f0).count(); dn->t_fetch = std::chrono::duration<double>(f2 - f1).count(); dn->t_format = std::chrono::duration<double>(f3 - f2).count();
     return dn;
   }
   void write_all(const std::function<std::unique_ptr<Done>(size_t, size_t)>& next /* (file, seq): batch `seq` if it belongs to that file, nullptr once the file has ended */) {
@@ -980,6 +982,7 @@ struct MapRun {
         const auto t1a = std::chrono::steady_clock::now();
         for (size_t c = 0; c < NC; ++c) parts.push_back(map_chunk(ctx, devs[d].idx[c], reads, c ? parts[0] : nullptr));
         map_slots[d].release();
+        mm_map_stats gst{}; if (getenv("MM_CLI_TIMING")) mm_mapping_get_stats(parts[0], &gst);   // (device time of the batch's stages by the library's own events)
         mm_mapping* m = parts[0];
         if (parts.size() > 1) {                                   // unifyFiles: read-wise concatenation in chunk order
           ck(ctx, mm_mapping_concat(ctx, parts.data(), chunk_base.data(), (int)parts.size(), &m), "merge chunks");
@@ -995,7 +998,7 @@ struct MapRun {
         pc.add("6a waited for the device", std::chrono::duration<double>(t1a - t1).count());
         pc.add("7 mapq+fetch+format", std::chrono::duration<double>(t3 - t2).count());
         if (getenv("MM_CLI_TIMING")) { std::ostringstream os; os << "INFO, worker " << d << "." << wi << " batch " << seq << ": upload " << std::chrono::duration<double>(t1 - t0).count() << " map "
-          << std::chrono::duration<double>(t2 - t1a).count() << " (waited " << std::chrono::duration<double>(t1a - t1).count() << ") finish " << std::chrono::duration<double>(t3 - t2).count() << " done at +" << std::chrono::duration<double>(t3 - pc.t0).count() << " s\n"; std::cerr << os.str(); }
+          << std::chrono::duration<double>(t2 - t1a).count() << " (waited " << std::chrono::duration<double>(t1a - t1).count() << "; device ms: K1 " << gst.ms_minimizer << " K2 " << gst.ms_sketch << " K3 " << gst.ms_probe_gather << " K4 " << gst.ms_sort_hits + gst.ms_l1_scan << " K5 " << gst.ms_l2 << " all " << gst.ms_total << ") finish " << std::chrono::duration<double>(t3 - t2).count() << " (mapq " << dn->t_mapq << " fetch " << dn->t_fetch << " format " << dn->t_format << ") done at +" << std::chrono::duration<double>(t3 - pc.t0).count() << " s\n"; std::cerr << os.str(); }
         reader.recycle(std::move(bt));
         writer.put(seq, std::move(dn));
       }
@@ -1308,7 +1311,7 @@ struct ContigCoverage {
       }
     };
     std::vector<std::thread> pool;
-    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency() / 4), items.size()}));
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::max(1u, mm::cpu_budget() / 4), items.size()}));
     for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
     work();
     for (auto& th : pool) th.join();
@@ -1533,7 +1536,7 @@ struct ClassifyRun {
   const std::function<void()>& leave_now;      // the last file: called once everything is written; the process ends there (may be empty)
   const std::function<void()>& need_devices;   // called before the first device call: the contexts are created beside the parsing of the file (may be empty)
   PhaseClock pc;
-  const unsigned HW = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned HW = mm::cpu_budget();                        // CPUs this process may keep busy (cpu_budget.hpp: a container's quota counts, not the 256 the machine shows)
   struct TextBuf {                                               // the file's bytes + a terminating 0, not zero-filled first (std::string::resize spent 0.1 s on that per 0.5 GB)
     char* p = nullptr; size_t n = 0;
     void resize(size_t k) { p = new (std::nothrow) char[k + 1]; if (!p) die("out of host memory for the mappings file"); n = k; p[k] = 0; }   // (huge_new.hpp: on huge pages)
@@ -1601,7 +1604,7 @@ struct ClassifyRun {
       };
       // (MM_CLASSIFY_THREADS=n: exactly n pieces, whatever the size of the file — the tests cut small files into many)
       const size_t NTH = getenv("MM_CLASSIFY_THREADS") ? (size_t)std::min(256, std::max(1, atoi(getenv("MM_CLASSIFY_THREADS"))))
-                                                       : std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::max(1u, HW / 4), TS / ((size_t)4 << 20) + 1}));
+                                                       : std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)HW, TS / ((size_t)4 << 20) + 1}));
       std::vector<size_t> cut(NTH + 1, TS);
       cut[0] = 0;
       for (size_t t = 1; t < NTH; ++t) cut[t] = std::max(cut[t - 1], read_boundary(TS / NTH * t));
@@ -1734,7 +1737,7 @@ struct ClassifyRun {
       std::vector<std::string> tax_nonx(taxa.size());              // getFirstNonXNode per taxon (taxonomy.h:51-74), once
       for (size_t t = 0; t < taxa.size(); ++t) tax_nonx[t] = T.first_non_x(taxa[t]);
       const size_t NTH = getenv("MM_CLASSIFY_THREADS") ? (size_t)std::min(256, std::max(1, atoi(getenv("MM_CLASSIFY_THREADS"))))
-                                                       : std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::max(1u, HW / 4), lines.size() / 50000 + 1}));
+                                                       : std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)HW, lines.size() / 50000 + 1}));
       std::vector<size_t> rcut(NTH + 1, NRD);
       rcut[0] = 0;
       { size_t t = 1; for (size_t r = 0; r < NRD && t < NTH; ++r) if ((uint64_t)off[r] >= (uint64_t)lines.size() * t / NTH) rcut[t++] = r; }
@@ -1779,7 +1782,7 @@ struct ClassifyRun {
         if (!sl.v) sl = coverage.slot(taxa[tx], contig_id[(size_t)B.contig], (size_t)contig_len_ti[(size_t)B.contig]);
       }
       {                                                            // tallies: thread k owns the taxa and the contigs with index % NT2 == k and walks the reads in order
-        const size_t NT2 = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, HW / 8), NRD / 20000 + 1}));
+        const size_t NT2 = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, HW / 2), NRD / 20000 + 1}));
         auto tally = [&](size_t k) {
           for (size_t r = 0; r < NRD; ++r) {
             const size_t b = (size_t)best[r];

@@ -95,7 +95,7 @@ int mm_ctx_create(int device_id, mm_ctx** out) {
 void mm_ctx_destroy(mm_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)mm::stream_sync(ctx->stream);
   ctx->alloc.trim();
   mm::big_pool_trim(ctx->device);                                  // (recycled index-scale blocks go back to the driver with any context of the device)
   mm::comm_destroy(ctx);
@@ -103,6 +103,9 @@ void mm_ctx_destroy(mm_ctx* ctx) {
   if (ctx->pinned_up) (void)hipHostFree(ctx->pinned_up);
   if (ctx->l2_codes) mm::dev_free(ctx->l2_codes, ctx->l2_codes_bytes);
   if (ctx->l2_masks) mm::dev_free(ctx->l2_masks, ctx->l2_masks_bytes);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -123,7 +126,7 @@ int mm_ctx_device_info(mm_ctx* ctx, char* name, size_t name_cap, int* cus, uint6
 }
 int mm_ctx_synchronize(mm_ctx* ctx) {
   if (!ctx) return MM_ERR_ARG;
-  return guarded(ctx, [&] { MM_HIP(hipStreamSynchronize(ctx->stream)); });
+  return guarded(ctx, [&] { MM_HIP(mm::stream_sync(ctx->stream)); });
 }
 int mm_ctx_release_cached(mm_ctx* ctx) {
   if (!ctx) return MM_ERR_ARG;
@@ -457,7 +460,7 @@ int mm_mapping_fetch(mm_mapping* m, int64_t* offsets, mm_map_record* records, in
       if (bytes) {                                               // device -> pinned bounce buffer -> caller memory
         void* pin = m->ctx->pinned_at_least(bytes);
         MM_HIP(hipMemcpyAsync(pin, m->rec.p, bytes, hipMemcpyDeviceToHost, m->ctx->stream));
-        MM_HIP(hipStreamSynchronize(m->ctx->stream));
+        MM_HIP(mm::stream_sync(m->ctx->stream));
         memcpy(records, pin, bytes);
       }
     }
@@ -524,7 +527,7 @@ static mm_mapping* merge_parts_device(mm_ctx* ctx, int64_t n, const std::vector<
     M->stats.n_mappings = M->n_rec;
     for (int64_t r = 0; r < n; ++r) if (M->h_rec_off[(size_t)r + 1] > M->h_rec_off[(size_t)r]) M->stats.n_reads_mapped++;
     M->released = true;                                          // records only: the debug taps have nothing to show
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
   } catch (...) { delete M; throw; }
   return M;
 }
@@ -616,7 +619,7 @@ int mm_mapping_gather(mm_ctx* ctx, int owner, int64_t n_reads, const int32_t* re
       nccl_ok(ncclGroupStart(), "ncclGroupStart");
       for (int c = 0; c < n_chunks; ++c) if (chunk_rank[c] == rank) { mm_mapping* P = parts[part_of[(size_t)c]]; if (P->n_rec > 0) nccl_ok(ncclSend(P->rec.p, sizeof(mm_map_record) * (size_t)P->n_rec, ncclInt8, owner, comm, st), "ncclSend"); }
       nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
-      MM_HIP(hipStreamSynchronize(st));
+      MM_HIP(mm::stream_sync(st));
       return;
     }
     std::vector<mm::DBuf<uint64_t>> t_off((size_t)n_chunks); std::vector<mm::DBuf<mm_map_record>> t_rec((size_t)n_chunks);
@@ -635,7 +638,7 @@ int mm_mapping_gather(mm_ctx* ctx, int owner, int64_t n_reads, const int32_t* re
       }
       nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
       for (int c = 0; c < n_chunks; ++c) if (remote(c)) t_off[(size_t)c].download(&n_rec_of[(size_t)c], 1, st, (size_t)n_reads);
-      MM_HIP(hipStreamSynchronize(st));
+      MM_HIP(mm::stream_sync(st));
       nccl_ok(ncclGroupStart(), "ncclGroupStart");
       for (int c = 0; c < n_chunks; ++c) {
         if (!remote(c) || n_rec_of[(size_t)c] == 0) continue;
@@ -667,7 +670,7 @@ int mm_mapping_keep_best(mm_ctx* ctx, mm_mapping* m, int k) {
     // >= best - 1.0; the comparison happens in double exactly as there.  Record lists are small: host side.
     std::vector<mm_map_record> recs((size_t)m->n_rec), kept;
     m->rec.download(recs.data(), recs.size(), ctx->stream);
-    MM_HIP(hipStreamSynchronize(ctx->stream));
+    MM_HIP(mm::stream_sync(ctx->stream));
     std::vector<uint64_t> off((size_t)m->n_reads + 1, 0);
     int64_t mapped = 0;
     for (int64_t r = 0; r < m->n_reads; ++r) {
@@ -687,7 +690,7 @@ int mm_mapping_keep_best(mm_ctx* ctx, mm_mapping* m, int k) {
     m->rec_off.upload(off.data(), off.size(), ctx->stream);
     m->h_rec_off = off;
     m->stats.n_mappings = m->n_rec; m->stats.n_reads_mapped = mapped;
-    MM_HIP(hipStreamSynchronize(ctx->stream));
+    MM_HIP(mm::stream_sync(ctx->stream));
   });
 }
 
@@ -734,7 +737,7 @@ int mm_debug_candidates(mm_mapping* m, int64_t* offsets, int32_t* triples, int64
     if (!triples) return;
     MM_REQUIRE(cap >= m->n_cand, MM_ERR_ARG, "output capacity too small");
     m->cand.download(triples, (size_t)(3 * m->n_cand), m->ctx->stream);
-    MM_HIP(hipStreamSynchronize(m->ctx->stream));
+    MM_HIP(mm::stream_sync(m->ctx->stream));
   });
 }
 int mm_debug_l2(mm_mapping* m, int64_t* per_cand, int64_t cap) {

@@ -19,6 +19,7 @@
 #include "../../include/metamaps_hip.h"
 #include "mm_slab.hpp"
 #include "task_pool.hpp"
+#include "cpu_budget.hpp"
 
 namespace mm {
 
@@ -37,6 +38,32 @@ struct Error : std::runtime_error {
 #define MM_REQUIRE(cond, st, msg) \
   do { if (!(cond)) throw mm::Error((st), (msg)); } while (0)
 #define MM_KERNEL_CHECK() MM_HIP(hipGetLastError())
+
+// ---- waiting for a stream ------------------------------------------------------------------------------
+// hipStreamSynchronize spins: a host thread per context burns a CPU while its kernels run.  On a host with CPUs to spare that is the lowest
+// latency; in a container with a small CPU quota (cpu_budget.hpp) four spinning workers are a quarter of the quota gone, and once the quota of
+// a 100 ms period is used up the kernel stops every thread of the process.  So when the budget is small (<= 32 CPUs) a wait records an event
+// created with hipEventBlockingSync and sleeps on it instead (an interrupt wakes the thread; 10-30 us later than a spin would have noticed).
+// MM_SYNC=spin|block overrides.  Every wait of the library goes through here.
+inline bool sync_blocking() {
+  static const bool b = [] { const char* e = getenv("MM_SYNC"); if (e && *e) return strcmp(e, "block") == 0; return cpu_budget() <= 32; }();
+  return b;
+}
+inline hipError_t stream_sync(hipStream_t st) {
+  if (!sync_blocking()) return hipStreamSynchronize(st);
+  static thread_local hipEvent_t ev = nullptr; static thread_local int ev_dev = -1;
+  int dev = 0; (void)hipGetDevice(&dev);
+  if (!ev || ev_dev != dev) {
+    if (ev) (void)hipEventDestroy(ev);
+    ev = nullptr;
+    const hipError_t c = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
+    if (c != hipSuccess) { ev = nullptr; (void)hipGetLastError(); return hipStreamSynchronize(st); }
+    ev_dev = dev;
+  }
+  const hipError_t r = hipEventRecord(ev, st);
+  if (r != hipSuccess) return r;
+  return hipEventSynchronize(ev);
+}
 
 // ---- device memory -----------------------------------------------------------------------------------
 // Per-context caching allocator.  A batch needs dozens of temporaries; hipMalloc/hipFree synchronise the
@@ -121,7 +148,7 @@ struct DevAlloc {
   void trim() {
     std::lock_guard<std::mutex> lk(m);
     if (cache.empty()) return;
-    (void)hipStreamSynchronize(stream);
+    (void)mm::stream_sync(stream);
     for (auto& kv : cache) dev_free(kv.second, kv.first);
     cache.clear(); cached_bytes = 0;
   }
@@ -130,7 +157,7 @@ struct DevAlloc {
   void trim_to(size_t keep) {
     std::lock_guard<std::mutex> lk(m);
     if (cached_bytes <= keep) return;
-    (void)hipStreamSynchronize(stream);
+    (void)mm::stream_sync(stream);
     while (cached_bytes > keep && !cache.empty()) { auto it = std::prev(cache.end()); dev_free(it->second, it->first); cached_bytes -= it->first; cache.erase(it); }
   }
   void* get(size_t bytes, size_t* got) {
@@ -412,7 +439,7 @@ struct DBuf {
     if (count == (size_t)-1) count = n;
     std::vector<T> v(count);
     download(v.data(), count, st);
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
     return v;
   }
 };
@@ -497,6 +524,17 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 struct mm_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
+  // A second stream for ONE purpose: the two launches of K5's 10 kb class (four-wave and two-wave workgroups, independent candidates) run side by side,
+  // forked from and joined back into `stream` by events — everything else of a context stays on its one stream (the caching allocator relies on that;
+  // the buffers the two launches touch are allocated before the fork and live past the join).  Created at first use.
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  void aux_ready() {
+    if (aux_stream) return;
+    MM_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+    MM_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    MM_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
   mm::DevAlloc alloc;
   std::string err;
   int cus = 0;
@@ -516,7 +554,7 @@ struct mm_ctx {
   void* l2_codes = nullptr; size_t l2_codes_bytes = 0;
   void* l2_codes_at_least(size_t bytes) {
     if (bytes > l2_codes_bytes) {
-      if (l2_codes) { MM_HIP(hipStreamSynchronize(stream)); mm::dev_free(l2_codes, l2_codes_bytes); }
+      if (l2_codes) { MM_HIP(mm::stream_sync(stream)); mm::dev_free(l2_codes, l2_codes_bytes); }
       l2_codes = nullptr; l2_codes_bytes = 0;
       raw_alloc(&l2_codes, bytes);
       l2_codes_bytes = bytes;
@@ -526,7 +564,7 @@ struct mm_ctx {
   void* l2_masks = nullptr; size_t l2_masks_bytes = 0;           // class masks of the long-read K5 classes
   void* l2_masks_at_least(size_t bytes) {
     if (bytes > l2_masks_bytes) {
-      if (l2_masks) { MM_HIP(hipStreamSynchronize(stream)); mm::dev_free(l2_masks, l2_masks_bytes); }
+      if (l2_masks) { MM_HIP(mm::stream_sync(stream)); mm::dev_free(l2_masks, l2_masks_bytes); }
       l2_masks = nullptr; l2_masks_bytes = 0;
       raw_alloc(&l2_masks, bytes);
       l2_masks_bytes = bytes;
@@ -540,7 +578,7 @@ struct mm_ctx {
   std::unique_ptr<TaskPool> pack_pool;
   void* pinned_up_at_least(size_t bytes) {
     if (bytes > pinned_up_bytes) {
-      if (pinned_up) { MM_HIP(hipStreamSynchronize(stream)); (void)hipHostFree(pinned_up); }
+      if (pinned_up) { MM_HIP(mm::stream_sync(stream)); (void)hipHostFree(pinned_up); }
       pinned_up = nullptr; pinned_up_bytes = 0;
       const size_t want = bytes + bytes / 8;
       MM_HIP(hipHostMalloc(&pinned_up, want, hipHostMallocDefault));

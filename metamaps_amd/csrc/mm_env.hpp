@@ -22,6 +22,8 @@ struct EnvSwitch { const char* name; const char* dflt; const char* kind; const c
 inline const EnvSwitch* env_table(size_t* n) {
   static const EnvSwitch T[] = {
     {"MM_STRICT_ENV", "unset", "user", "refuse MM_* variables that are not in this table (mm_ctx_create returns MM_ERR_ARG, the CLI exits 1)"},
+    {"MM_CPU_BUDGET", "min(hardware threads, affinity mask, cgroup CPU quota)", "user", "CPUs the process may keep busy: what every thread pool of the library and the CLI is sized from (cpu_budget.hpp)"},
+    {"MM_SYNC", "block when the CPU budget is <= 32, else spin", "user", "how a host thread waits for its stream: \"spin\" (hipStreamSynchronize) or \"block\" (sleep on an event created with hipEventBlockingSync)"},
     // ---- CLI (host/metamaps_main.cpp, host/*.hpp)
     {"MM_CLI_WORKERS", "4", "user", "worker contexts per GPU that take read batches in turn (= --workers-per-gpu)"},
     {"MM_CLI_BATCH_READS", "100000", "user", "reads per batch handed to a worker"},
@@ -52,6 +54,7 @@ inline const EnvSwitch* env_table(size_t* n) {
     {"MM_ALLOC_TRACE", "unset", "debug", "every block that comes from the driver, with its cost, on stderr"},
     {"MM_CTX_TRACE", "unset", "debug", "phases of mm_ctx_create (HIP initialisation, stream, allocator) on stderr"},
     {"MM_HOST_TIMING", "unset", "debug", "host-side sections of mm_map_batch on stderr"},
+    {"MM_PACK_SCALAR", "unset", "test", "mm_seqset_upload packs bases with the byte-table loop only (cross-check of the AVX2 path, host_pack.cpp)"},
     // ---- library: index build (mm_index.hip)
     {"MM_INDEX_PART_MAX", "2^31 - 2^24 entries", "test", "entries per partition of the hash sort (small values: the partitioned sort + merge on small inputs)"},
     {"MM_DUP_SAT", "65535", "test", "saturation value of the stored same-hash neighbour distances (small values: K5's scan fall-back)"},
@@ -77,6 +80,7 @@ inline const EnvSwitch* env_table(size_t* n) {
     {"MM_L2_NO_GROUP_SORT", "unset", "test", "K5 workgroups in read order instead of the order of their candidates' positions"},
     {"MM_L2_GROUP_SORT_MIN", "2048", "tuning", "groups from which the launch order is sorted"},
     {"MM_L2_XCD_ORDER", "unset", "tuning", "deal the position-sorted workgroup list out per XCD (measured: slower, DESIGN.md section 7)"},
+    {"MM_L2_ONE_STREAM", "unset", "test", "the two launches of K5's 10 kb class one behind the other on the context's stream instead of side by side (auxiliary stream)"},
     {"MM_L2_NO_SLOTS", "unset", "test", "K5 scratch indexed by wave number of the launch instead of per-XCD slots taken and given back"},
     {"MM_L2_SLOTS", "auto (resident waves)", "tuning", "number of K5 scratch slots"},
     {"MM_L2_STOP", "0", "debug", "K5 leaves after phase n WITHOUT RESULTS (tools/l2_stop.py)"},

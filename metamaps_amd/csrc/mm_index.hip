@@ -238,7 +238,7 @@ static void build_directory(mm_index* I, hipStream_t st) {
     dir_build_kernel<<<dim3((unsigned)ceil_div((int64_t)total, 256)), dim3(256), 0, st>>>(I->pos.p, I->cstart.p, I->dir_off.p, I->n_contigs, shift, total, I->dir.p);
     MM_KERNEL_CHECK();
   }
-  MM_HIP(hipStreamSynchronize(st));                              // `off` is the upload source
+  MM_HIP(mm::stream_sync(st));                              // `off` is the upload source
 }
 
 void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* I) {
@@ -279,7 +279,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
     I->occ.alloc(1); I->occ16.alloc(16);
     I->dup_bits.alloc(1); I->dup_rank.alloc(2); I->dup_dist.alloc(1);
     I->dup_bits.zero(st); I->dup_rank.zero(st); I->dup_dist.zero(st);
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
     return;
   }
   // HIP caps gridDim.x*blockDim.x below 2^32 threads: per-element kernels are grid-stride loops on a capped grid
@@ -294,7 +294,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
     MM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, cnt, 0, 32, st));
     if (sort_tmp.bytes() < tmp_bytes) sort_tmp.alloc(tmp_bytes);
     MM_HIP(rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, kin, kout, vin, vout, cnt, 0, 32, st));
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
   };
   const char* pm_env = getenv("MM_INDEX_PART_MAX");              // tests force the partitioned path on small inputs
   const int64_t PART_MAX = pm_env ? std::max<int64_t>(atoll(pm_env), 1) : PART_MAX_DEFAULT;
@@ -359,7 +359,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   exclusive_scan_u32_u64(tile_heads.p, ntiles_csr, tile_rank.p, scan_tmp, st);
   uint64_t U = 0;
   MM_HIP(hipMemcpyAsync(&U, tile_rank.p + ntiles_csr, sizeof U, hipMemcpyDeviceToHost, st));
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
   I->U = (int64_t)U;
   I->uh.alloc((size_t)U); I->ustart.alloc((size_t)U + 1);
   csr_fill_tiles_kernel<<<dim3((unsigned)ntiles_csr), dim3(SCAN_THREADS), 0, st>>>(key_out.p, N, tile_rank.p, ntiles_csr, I->uh.p, I->ustart.p);
@@ -381,7 +381,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
     exclusive_scan_u32_u64(bcnt.p, nb64, I->dup_rank.p, scan_tmp4, st);
     uint64_t nflag = 0;
     MM_HIP(hipMemcpyAsync(&nflag, I->dup_rank.p + nb64, sizeof nflag, hipMemcpyDeviceToHost, st));
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
     I->dup_dist.alloc(std::max<size_t>((size_t)nflag, 1)); I->dup_dist.zero(st);
     if (nflag) {
       dup_pairs_kernel<true><<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, I->occ.p, N, I->cstart.p, I->dir.p, I->dir_off.p, I->dir_shift, I->pos.p, nullptr,
@@ -413,7 +413,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
     exclusive_scan_u32_u64(pc.p, (int64_t)U, pstart.p, scan_tmp3, st);
     uint64_t P = 0;
     MM_HIP(hipMemcpyAsync(&P, pstart.p + U, sizeof P, hipMemcpyDeviceToHost, st));
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
     MM_REQUIRE(P < ((uint64_t)1 << 35), MM_ERR_LIMIT, "more than 2^35 padded occurrences in one index chunk (the seed filter keeps list starts / 8 in 32 bits)");
     DBuf<uint64_t> padded((size_t)P + 2);
     I->occ16.alloc((size_t)P + 16);
@@ -423,7 +423,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
     pad_lists_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div((int64_t)U * 8, 256), 1 << 20)), dim3(256), 0, st>>>(I->occ.p, I->ustart.p, pstart.p, (int64_t)U, d_cbase.p,
                                                                                                                padded.p, I->occ16.p);
     MM_KERNEL_CHECK();
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
     I->occ = std::move(padded);
   }
   // lookup table (load factor <= 0.55, any number of 4-slot buckets), then the CSR arrays are no longer needed
@@ -433,7 +433,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   table_insert_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div((int64_t)U, 256), 1 << 20)), dim3(256), 0, st>>>(I->uh.p, I->ustart.p, pstart.p, (int64_t)U, I->tab_buckets,
                                                                                                               (unsigned long long*)I->tab.p);
   MM_KERNEL_CHECK();
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
   I->uh.release(); I->ustart.release();
 }
 
@@ -481,7 +481,7 @@ void index_plan_chunks(mm_ctx* ctx, const mm_index* I, uint64_t max_memory, std:
     novel_hashes_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(slots, 256), 1 << 20)), dim3(256), 0, st>>>(I->tab.p, slots, I->occ.p, (uint32_t)c0, novel.p);
     MM_KERNEL_CHECK();
     novel.download(h.data(), (size_t)C, st);
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
     size_t runH = 0, runM = 0;
     int64_t c = c0;
     for (; c < C; ++c) {
@@ -565,7 +565,7 @@ template <typename T> void put_array(FILE* f, const mm::DBuf<T>& a, size_t count
   if (bytes) MM_HIP(hipMemcpyAsync(pin.b[0], src, std::min(bytes, IDX_STAGE), hipMemcpyDeviceToHost, st));
   while (off < bytes) {
     const size_t n = std::min(bytes - off, IDX_STAGE);
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
     if (off + n < bytes) MM_HIP(hipMemcpyAsync(pin.b[cur ^ 1], src + off + n, std::min(bytes - off - n, IDX_STAGE), hipMemcpyDeviceToHost, st));
     put(f, pin.b[cur], n, what);
     off += n; cur ^= 1;
@@ -583,11 +583,11 @@ template <typename T> void get_array(FILE* f, mm::DBuf<T>& a, size_t min_alloc, 
   while (off < bytes) {                                            // the read of block i+1 runs beside the copy of block i
     const size_t n = std::min(bytes - off, IDX_STAGE);
     get(f, pin.b[cur], n, what);
-    MM_HIP(hipStreamSynchronize(st));                              // (the other buffer's copy: done before that buffer is read into again)
+    MM_HIP(mm::stream_sync(st));                              // (the other buffer's copy: done before that buffer is read into again)
     MM_HIP(hipMemcpyAsync(dst + off, pin.b[cur], n, hipMemcpyHostToDevice, st));
     off += n; cur ^= 1;
   }
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
   MM_REQUIRE(array_sum(a, (size_t)c64, st) == sum, MM_ERR_ARG, std::string("index file is damaged: checksum of the ") + what + " differs");
 }
 }  // namespace
@@ -664,7 +664,7 @@ void index_load(mm_ctx* ctx, const char* path, mm_index* I) {
   MM_REQUIRE(tail == IDX_TAIL, MM_ERR_ARG, "index file is inconsistent (closing word)");
   I->d_contig_len.alloc(std::max<size_t>(I->contig_len.size(), 1));
   I->d_contig_len.upload(I->contig_len.data(), I->contig_len.size(), st);
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
 }
 
 }  // namespace mm

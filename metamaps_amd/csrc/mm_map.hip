@@ -1331,7 +1331,7 @@ struct StageTimer {
   }
   void end(size_t i) { MM_HIP(hipEventRecord(ev[i].second, st)); }
   void collect() {
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
     for (size_t i = 0; i < ev.size(); ++i) { float ms = 0; MM_HIP(hipEventElapsedTime(&ms, ev[i].first, ev[i].second)); *dst[i] += ms; }
   }
 };
@@ -1444,7 +1444,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         at += run.second;
       }
       hl("K2 launches");
-      MM_HIP(hipStreamSynchronize(st));                          // RB.order is the source of the async upload
+      MM_HIP(mm::stream_sync(st));                          // RB.order is the source of the async upload
       hl("K2 sync (kernels)");
     }
     std::vector<int64_t> cnt;                                     // longer lists (reads beyond ~73 kb)
@@ -1464,7 +1464,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       MM_HIP(rocprim::segmented_radix_sort_keys((void*)tmp.p, tmp_bytes, keys.p, sorted.p, (unsigned int)nk, (unsigned int)nb, d_koff.p, d_koff.p + 1, 0, 64, st));
       sketch_finish_kernel<<<dim3((unsigned)nb), dim3(256), 0, st>>>(M->mz.rec.p, M->mz.off.p, d_big.p, d_koff.p, sorted.p, M->sk_hash.p, M->sk_strand.p, M->sk_n.p, M->amb.p);
       MM_KERNEL_CHECK();
-      MM_HIP(hipStreamSynchronize(st));                          // big / koff are upload sources
+      MM_HIP(mm::stream_sync(st));                          // big / koff are upload sources
     } else if (any_big) { cnt.assign((size_t)n, 0); for (int64_t r = 0; r < n; ++r) { const int64_t c = (int64_t)(hoff[(size_t)r + 1] - hoff[(size_t)r]); if (c > 16384) cnt[(size_t)r] = c; } }
     for (auto& cls : make_classes(cnt, 256)) {
       DBuf<int32_t> list(cls.reads.size());
@@ -1481,7 +1481,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
                                                                                     M->sk_hash.p, M->sk_strand.p, M->sk_n.p, M->amb.p);
         MM_KERNEL_CHECK();
       }
-      MM_HIP(hipStreamSynchronize(st));                          // cls.reads is the source of the async upload
+      MM_HIP(mm::stream_sync(st));                          // cls.reads is the source of the async upload
     }
     T.end(t_sk);
   }
@@ -1566,7 +1566,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           A->scnt[i] = (int32_t)sN;
         }
       };
-      const unsigned nthr = std::max(1u, std::min(32u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)((na + 15) / 16))));
+      const unsigned nthr = std::max(1u, std::min(32u, std::min<unsigned>(mm::cpu_budget(), (unsigned)((na + 15) / 16))));
       std::vector<std::thread> pool;
       for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
       worker();
@@ -1579,7 +1579,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       DBuf<int32_t> d_cnt(na); d_cnt.upload(A->scnt.data(), na, st);
       scatter_strand_kernel<<<dim3((unsigned)na), dim3(256), 0, st>>>(d_sv.p, A->d_so.p, A->d_do.p, d_cnt.p, M->sk_strand.p);
       MM_KERNEL_CHECK();
-      MM_HIP(hipStreamSynchronize(st));                          // host vectors above are the H2D sources
+      MM_HIP(mm::stream_sync(st));                          // host vectors above are the H2D sources
     };
   };
   hl("post-K2 amb lists");
@@ -1611,7 +1611,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     M->min_hits.alloc((size_t)std::max<int64_t>(n, 1)); M->min_hits.upload(mh.data(), (size_t)n, st);
     M->accept_min.alloc((size_t)std::max<int64_t>(n, 1)); M->accept_min.upload(am.data(), (size_t)n, st);
     M->h_min_hits = mh;
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
     hl("K7 thresholds + uploads");
   }
   M->d_read_len.alloc((size_t)std::max<int64_t>(n, 1));
@@ -1643,7 +1643,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       h_need[(size_t)r] = c; n_fused += c == 0; n_wide += c == 2;
     }
     need_old.alloc((size_t)n + 4); need_old.upload(h_need.data(), (size_t)n, st);   // (+4: the streaming seed filter reads the class bytes as whole words)
-    MM_HIP(hipStreamSynchronize(st));                            // h_need is the source of the async upload
+    MM_HIP(mm::stream_sync(st));                            // h_need is the source of the async upload
   }
   hl("K3 prep (need_old etc.)");
   const size_t t_pg = T.begin(&M->stats.ms_probe_gather);
@@ -1660,7 +1660,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       h_stage_off[(size_t)r + 1] = h_stage_off[(size_t)r] + (M->h_sk_n[(size_t)r] > 0 ? (cap_env ? (uint64_t)atoi(cap_env) : 1024 + 2 * (uint64_t)M->h_sk_n[(size_t)r]) : 0);
     stage_off.alloc((size_t)n + 1); stage_off.upload(h_stage_off.data(), h_stage_off.size(), st);
     stage.alloc((size_t)std::max<uint64_t>(h_stage_off[(size_t)n], 1));
-    MM_HIP(hipStreamSynchronize(st));                            // h_stage_off is the source of the async upload
+    MM_HIP(mm::stream_sync(st));                            // h_stage_off is the source of the async upload
     hl("K3 stage_off loop + upload");
     if (use_fused && n_fused > 0) {
       const size_t lds = sizeof(SeedFilterLds);
@@ -1808,7 +1808,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         MM_KERNEL_CHECK();
         at += run.second;
       }
-      MM_HIP(hipStreamSynchronize(st));                          // RB.order is the source of the async upload
+      MM_HIP(mm::stream_sync(st));                          // RB.order is the source of the async upload
     }
     if (any_left) {                                              // the loops below only see the longer lists
       hc.assign((size_t)n, 0);
@@ -1823,7 +1823,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)sort_hits_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         sort_hits_kernel<true><<<dim3((unsigned)cls.reads.size()), dim3(256), lds, st>>>(M->hits.p, M->read_hit_off.p, list.p, cls.npow2, nullptr);
         MM_KERNEL_CHECK();
-        MM_HIP(hipStreamSynchronize(st));
+        MM_HIP(mm::stream_sync(st));
       } else {
         // (fallback) a few reads at a time through a global scratch buffer
         const size_t per = (size_t)cls.npow2;
@@ -1834,7 +1834,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           sort_hits_kernel<false><<<dim3((unsigned)g), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, list.p + g0, cls.npow2, scratch.p);
           MM_KERNEL_CHECK();
         }
-        MM_HIP(hipStreamSynchronize(st));
+        MM_HIP(mm::stream_sync(st));
       }
     }
     if (!seg_reads.empty()) {
@@ -1867,13 +1867,13 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         seg_sort(packed.p, sorted.p, run, d_cb.p, d_ce.p);
         move_ranges_kernel<<<dim3((unsigned)ns), dim3(256), 0, st>>>(sorted.p, d_cb.p, d_ce.p, M->hits.p, d_hb.p);
         MM_KERNEL_CHECK();
-        MM_HIP(hipStreamSynchronize(st));
+        MM_HIP(mm::stream_sync(st));
       } else {
         DBuf<uint64_t> sorted((size_t)total_hits);
         seg_sort(M->hits.p, sorted.p, (uint64_t)total_hits, d_hb.p, d_he.p);
         move_ranges_kernel<<<dim3((unsigned)ns), dim3(256), 0, st>>>(sorted.p, d_hb.p, d_he.p, M->hits.p, d_hb.p);
         MM_KERNEL_CHECK();
-        MM_HIP(hipStreamSynchronize(st));
+        MM_HIP(mm::stream_sync(st));
       }
     }
     T.end(t_sh);
@@ -1942,7 +1942,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     auto set_lds = [&](const void* fn, size_t bytes) { if (bytes > 64 * 1024) MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); };
     DBuf<unsigned long long> counters(16); counters.zero(st);
     if (getenv("MM_L2_STOP") || getenv("MM_L2_PHASES") || getenv("MM_FORCE_AMB_REDO")) {
-      const char* ds = getenv("MM_L2_STOP"); unsigned long long v = (unsigned long long)((ds ? atoi(ds) & 0xff : 0) | (getenv("MM_L2_PHASES") ? 0x100 : 0) | (getenv("MM_FORCE_AMB_REDO") ? 0x200 : 0)); MM_HIP(hipMemcpyAsync(counters.p + 11, &v, sizeof v, hipMemcpyHostToDevice, st)); MM_HIP(hipStreamSynchronize(st)); }   // timing aid: leave the kernel after phase n (results are then meaningless)
+      const char* ds = getenv("MM_L2_STOP"); unsigned long long v = (unsigned long long)((ds ? atoi(ds) & 0xff : 0) | (getenv("MM_L2_PHASES") ? 0x100 : 0) | (getenv("MM_FORCE_AMB_REDO") ? 0x200 : 0)); MM_HIP(hipMemcpyAsync(counters.p + 11, &v, sizeof v, hipMemcpyHostToDevice, st)); MM_HIP(mm::stream_sync(st)); }   // timing aid: leave the kernel after phase n (results are then meaningless)
     DBuf<int32_t> ovf((size_t)ncand);
     DBuf<unsigned int> ovf_n(1); ovf_n.zero(st);
     DBuf<uint8_t> amb_used;
@@ -1983,7 +1983,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
                                                       P.k, P.w, smax_l, M->l2.p, d_list.p, (int)nl, d_rng.p, d_coff.p, codes.p, scratch.p, next.p, amb_ptr, force_amb,
                                                       getenv("MM_L2_DENSE_NO_STOP") ? 0 : 1);
       MM_KERNEL_CHECK();
-      MM_HIP(hipStreamSynchronize(st));                          // host vectors above are upload sources; the buffers die with this scope
+      MM_HIP(mm::stream_sync(st));                          // host vectors above are upload sources; the buffers die with this scope
     };
     DBuf<int32_t> d_listG(listG.size());
     DBuf<uint32_t> giant_scratch;
@@ -2008,7 +2008,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
             M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smax, M->l2.p, counters.p, nullptr, nullptr, d_listF.p, nullptr, nullptr, amb_used_p, nullptr, nullptr, nullptr, 0);
         MM_KERNEL_CHECK();
       }
-      MM_HIP(hipStreamSynchronize(st));                          // listF is the source of the async upload
+      MM_HIP(mm::stream_sync(st));                          // listF is the source of the async upload
     } else {
       // Reads are grouped by sketch size so that one long read does not size the LDS state (and the occupancy) of all:
       //   A  s <= 3072   (reads up to ~14 kb at w=8)  compact: 4 candidates of a read per workgroup share the sketch,
@@ -2095,19 +2095,43 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       };
       sort_by_position(d_gA0, d_gAn, nA);
       sort_by_position(d_gS0, d_gSn, nS);
-      if (nA) {
-        const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 4, 2);
-        set_lds((const void*)l2_kernel<true, uint8_t, 4, 2>, lds);
-        l2_kernel<true, uint8_t, 4, 2><<<dim3((unsigned)nA), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(nA * 4, 2), masks_for(nA * 4, 2), slot_flags_p, (int)slots_of(nA * 4, 2));
-        MM_KERNEL_CHECK();
-      }
-      if (nS) {
-        const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 2, 2);
-        set_lds((const void*)l2_kernel<true, uint8_t, 2, 2>, lds);
-        l2_kernel<true, uint8_t, 2, 2><<<dim3((unsigned)nS), dim3(128), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gS0.p, d_gSn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(nS * 2, 2), masks_for(nS * 2, 2), slot_flags_p, (int)slots_of(nS * 2, 2));
-        MM_KERNEL_CHECK();
+      // The 10 kb class runs as two launches — groups of three or four candidates of a read in four-wave workgroups, groups of one or two in two-wave
+      // workgroups — over disjoint candidates.  One behind the other on one stream each of them ends with a tail of a few long candidates on an otherwise
+      // idle device (the two-wave launch keeps the VALU 55 % busy against 87 %; at an eighth of the batch the tails are a third of K5's time).  Side by
+      // side — the second launch on the context's auxiliary stream, forked from and joined into the main one by events — each covers the other's tail.
+      // Both take their scratch slots from ONE pool with ONE split by XCD (a slot's traffic stays in one L2, mm_l2.hpp), sized for the larger launch.
+      // MM_L2_ONE_STREAM=1: one behind the other as until round 5 (cross-check and A/B).
+      {
+        const size_t n_waves = std::max(nA * 4, nS * 2);
+        void* const codes = (nA || nS) ? codes_for(n_waves, 2) : nullptr;
+        uint8_t* const masks = (nA || nS) ? masks_for(n_waves, 2) : nullptr;
+        const int n_slots = (int)slots_of(n_waves, 2);
+        const bool side_by_side = nA && nS && !no_slots && !getenv("MM_L2_ONE_STREAM");   // (without slots the scratch is indexed by wave number of the launch: one launch at a time)
+        hipStream_t st_small = st;
+        if (side_by_side) {
+          ctx->aux_ready();
+          st_small = ctx->aux_stream;
+          MM_HIP(hipEventRecord(ctx->ev_fork, st));
+          MM_HIP(hipStreamWaitEvent(st_small, ctx->ev_fork, 0));
+        }
+        if (nA) {
+          const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 4, 2);
+          set_lds((const void*)l2_kernel<true, uint8_t, 4, 2>, lds);
+          l2_kernel<true, uint8_t, 4, 2><<<dim3((unsigned)nA), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes, masks, slot_flags_p, n_slots);
+          MM_KERNEL_CHECK();
+        }
+        if (nS) {
+          const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 2, 2);
+          set_lds((const void*)l2_kernel<true, uint8_t, 2, 2>, lds);
+          l2_kernel<true, uint8_t, 2, 2><<<dim3((unsigned)nS), dim3(128), lds, st_small>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gS0.p, d_gSn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes, masks, slot_flags_p, n_slots);
+          MM_KERNEL_CHECK();
+        }
+        if (side_by_side) {
+          MM_HIP(hipEventRecord(ctx->ev_join, st_small));
+          MM_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        }
       }
       if (!gB0.empty()) {
         d_gB0.upload(gB0.data(), gB0.size(), st); d_gBn.upload(gBn.data(), gBn.size(), st);
@@ -2143,7 +2167,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       auto run_fallback = [&](uint8_t* amb_ptr) {
         unsigned int h_ovf = 0;
         MM_HIP(hipMemcpyAsync(&h_ovf, ovf_n.p, sizeof h_ovf, hipMemcpyDeviceToHost, st));
-        MM_HIP(hipStreamSynchronize(st));                        // also keeps the host lists alive until the uploads are done
+        MM_HIP(mm::stream_sync(st));                        // also keeps the host lists alive until the uploads are done
         if (!h_ovf) return;
         const size_t lds = l2_lds_bytes<uint16_t>(smax, false, 1, 8);
         set_lds((const void*)l2_kernel<false, uint16_t, 1, 8>, lds);
@@ -2179,7 +2203,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
             MM_KERNEL_CHECK();
             run_fallback(nullptr);
           }
-          MM_HIP(hipStreamSynchronize(st));
+          MM_HIP(mm::stream_sync(st));
           n_redo += (int64_t)redo.size();
         }
       }
@@ -2204,7 +2228,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     exclusive_scan_u32_u64(flag.p, ncand, rank.p, scan_tmp, st);
     uint64_t nrec = 0;
     MM_HIP(hipMemcpyAsync(&nrec, rank.p + ncand, sizeof nrec, hipMemcpyDeviceToHost, st));
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
     M->n_rec = (int64_t)nrec;
     M->rec.alloc((size_t)std::max<uint64_t>(nrec, 1));
     write_records_kernel<<<dim3((unsigned)ceil_div(ncand, 256)), dim3(256), 0, st>>>(M->l2.p, M->cand_read.p, M->sk_n.p, flag.p, rank.p, ncand, M->rec.p);
@@ -2212,14 +2236,14 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     read_rec_bounds_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(M->cand_off.p, rank.p, n, M->rec_off.p);
     MM_KERNEL_CHECK();
     T.end(t_cp);
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
   } else {
     T.end(t_l1);
     if (amb_finish) { amb_finish(); amb_finish = nullptr; }
     M->n_rec = 0;
     M->rec.alloc(1);
     M->rec_off.zero(st);
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
   }
   M->h_rec_off = M->rec_off.to_host(st, (size_t)n + 1);
   T.end(t_total);

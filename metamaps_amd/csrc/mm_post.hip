@@ -187,7 +187,7 @@ void em_create(mm_ctx* ctx, int64_t n_reads, const int64_t* read_off, const int3
   E->f.alloc((size_t)n_taxa);
   E->partial.alloc((size_t)n_taxa + 2);
   E->block_sum.alloc((size_t)ceil_div(std::max<int64_t>(n_reads, 1), 256));
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -281,7 +281,7 @@ void em_create_from_mapping(mm_ctx* ctx, const mm_mapping* M, const int32_t* con
   E->f.alloc((size_t)n_taxa);
   E->partial.alloc((size_t)n_taxa + 2);
   E->block_sum.alloc((size_t)ceil_div(std::max<int64_t>(n_reads, 1), 256));
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
 }
 
 // device part of one iteration: partial[0..T) = sum of posteriors per taxon, partial[T] = sum of log-likelihoods
@@ -681,7 +681,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
       for (int64_t b2 = 0; b2 < NB; ++b2) start[(size_t)b2 + 1] += start[(size_t)b2];
       for (int64_t r = 0; r < E->n_reads; ++r) { const int64_t k2 = start[(size_t)bucket(ro[(size_t)r + 1] - ro[(size_t)r])]++; sp[2 * (size_t)k2] = ro[(size_t)r]; sp[2 * (size_t)k2 + 1] = ro[(size_t)r + 1]; }
       E->span.alloc(sp.size()); E->span.upload(sp.data(), sp.size(), st);
-      MM_HIP(hipStreamSynchronize(st));                          // (sp is the upload's source)
+      MM_HIP(mm::stream_sync(st));                          // (sp is the upload's source)
     }
     E->pos.alloc((size_t)std::max<int64_t>(E->n_entries, 1)); E->post_sorted.alloc((size_t)std::max<int64_t>(E->n_entries, 1));
     MM_REQUIRE(E->n_reads < (1LL << 31), MM_ERR_LIMIT, "EM problem beyond 2^31 reads");
@@ -694,7 +694,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
     E->f_run.alloc((size_t)T);
     E->ctrl.alloc(8);
     E->bar.alloc(16 * (size_t)(1 + ceil_div(E->n_wg, EM_BAR_GROUP)));
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
   }
   long long h_ctrl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (f0) {
@@ -703,11 +703,11 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
     E->ctrl.zero(st);
   } else {                                                       // go on: a limit stop is lifted, a rule stop stays; the trace starts here
     MM_HIP(hipMemcpyAsync(h_ctrl, E->ctrl.p, sizeof h_ctrl, hipMemcpyDeviceToHost, st));
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
     if (h_ctrl[1] == 2) h_ctrl[1] = 0;
     h_ctrl[3] = h_ctrl[0]; h_ctrl[4] = 0;
     MM_HIP(hipMemcpyAsync(E->ctrl.p, h_ctrl, sizeof h_ctrl, hipMemcpyHostToDevice, st));
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
   }
   const long long it0 = h_ctrl[0], it_limit = it0 + max_iter;
   EmLoop a{(const longlong2*)(E->span.n ? E->span.p : nullptr), E->read_off.p, E->eread.p, E->taxon.p, E->mapq.p, E->inv_nloc.p, E->n_reads, E->post_sorted.p, E->pos.p, E->item_lo.p, E->item_hi.p, E->n_items,
@@ -726,7 +726,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
   const bool collective = ctx->comm && (ctx->comm_size > 1 || getenv("MM_EM_FORCE_COLLECTIVE") != nullptr);
   auto fetch_ctrl = [&] {
     MM_HIP(hipMemcpyAsync(h_ctrl, E->ctrl.p, sizeof h_ctrl, hipMemcpyDeviceToHost, st));
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
     if (h_ctrl[4]) {                                             // a grid barrier timed out: the state is that of the last completed iteration (P1 / P2 only write scratch)
       if (!ctx->em_split) fprintf(stderr, "libmetamaps_hip: the resident EM kernel could not get its %d workgroups onto device %d together; "
                                           "this context goes on with one launch per phase\n", E->n_wg, ctx->device);
@@ -735,7 +735,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
       if (h_ctrl[1] == 3) h_ctrl[1] = 0;                         // (several ranks: the all-reduced abort mark stopped the rest of the enqueued group on every rank)
       MM_HIP(hipMemcpyAsync(E->ctrl.p, h_ctrl, sizeof h_ctrl, hipMemcpyHostToDevice, st));
       MM_HIP(hipMemsetAsync(E->local_partial.p + T + 1, 0, sizeof(double), st));
-      MM_HIP(hipStreamSynchronize(st));
+      MM_HIP(mm::stream_sync(st));
     }
   };
   const int GROUP = 8;
@@ -773,7 +773,7 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
   if (stopped) *stopped = h_ctrl[1] == 1;
   if (f_out) E->f_run.download(f_out, (size_t)T, st);
   if (ll_trace && ll_cap > 0 && n_iter > 0) E->ll_trace.download(ll_trace, (size_t)std::min(std::min(n_iter, ll_cap), cap), st);
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
   return n_iter;
 }
 
@@ -791,9 +791,9 @@ void em_posteriors(mm_em* E, const double* f, double* post, int64_t* best) {
     em_best_kernel<<<dim3((unsigned)ceil_div(E->n_reads, 128)), dim3(128), 0, st>>>(E->read_off.p, E->post.p, E->n_reads, b.p);
     MM_KERNEL_CHECK();
     b.download(best, (size_t)E->n_reads, st);
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
   }
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -824,7 +824,7 @@ void comm_allreduce_f64(mm_ctx* ctx, double* host, int64_t n) {
   ncclResult_t rc = ncclAllReduce(d.p, d.p, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
   MM_REQUIRE(rc == ncclSuccess, MM_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(rc));
   d.download(host, (size_t)n, ctx->stream);
-  MM_HIP(hipStreamSynchronize(ctx->stream));
+  MM_HIP(mm::stream_sync(ctx->stream));
 }
 void comm_destroy(mm_ctx* ctx) {
   if (ctx->comm) { if (!ctx->comm_shared) ncclCommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; ctx->comm_shared = false; ctx->comm_size = 1; ctx->comm_rank = 0; }

@@ -6,6 +6,9 @@
 #include <cstdio>
 #include <cstring>
 
+extern "C" int mm_host_has_avx2();
+extern "C" size_t mm_pack_acgt_blocks(const uint8_t* p, size_t n_bases, uint32_t* out);   // host_pack.cpp
+
 namespace mm {
 
 SeqView make_view(const mm_seqset* S) {
@@ -36,7 +39,7 @@ void run_minimizers(mm_ctx* ctx, const mm_seqset* S, int k, int w, const std::ve
   out.off.alloc((size_t)n + 1);
   out.h_off.assign((size_t)n + 1, 0);
   out.total = 0;
-  if (ntiles == 0) { out.off.zero(st); out.rec.alloc(0); MM_HIP(hipStreamSynchronize(st)); return; }
+  if (ntiles == 0) { out.off.zero(st); out.rec.alloc(0); MM_HIP(mm::stream_sync(st)); return; }
   MM_REQUIRE(ntiles < (1LL << 31), MM_ERR_LIMIT, "too many tiles for one launch");
 
   DBuf<uint64_t> d_tf((size_t)n + 1);
@@ -73,7 +76,7 @@ void run_minimizers(mm_ctx* ctx, const mm_seqset* S, int k, int w, const std::ve
   int h_ovf = 0;
   MM_HIP(hipMemcpyAsync(&total, tout.p + ntiles, sizeof total, hipMemcpyDeviceToHost, st));
   MM_HIP(hipMemcpyAsync(&h_ovf, d_ovf.p, sizeof h_ovf, hipMemcpyDeviceToHost, st));
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
   if (h_ovf) single_pass = false;                                // some tile emitted more than MZ_STAGE records: counts are right, redo the write
   out.total = (int64_t)total;
   out.rec.alloc((size_t)total);
@@ -89,7 +92,7 @@ void run_minimizers(mm_ctx* ctx, const mm_seqset* S, int k, int w, const std::ve
   gather_offsets_kernel<<<dim3((unsigned)ceil_div(n + 1, 256)), dim3(256), 0, st>>>(d_tf.p, tout.p, n, out.off.p);
   MM_KERNEL_CHECK();
   out.off.download(out.h_off.data(), (size_t)n + 1, st);
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
 }
 
 // ---- host packing -----------------------------------------------------------------------------------
@@ -129,9 +132,10 @@ void seqset_upload(mm_seqset* s) {
     std::vector<Item> items;
     for (size_t i = 0; i < n; ++i) { const size_t L = s->staged[i].second; for (size_t j0 = 0; j0 < L; j0 += PIECE) items.push_back(Item{i, j0, std::min(L, j0 + PIECE)}); }
     std::vector<Runs> runs(items.size());
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned hw = mm::cpu_budget();                          // (not hardware_concurrency: cpu_budget.hpp)
     const size_t nthr = (size_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)std::max(1u, hw / 2), 32, (uint64_t)(s->total_bases >> 22) + 1, (uint64_t)std::max<size_t>(items.size(), 1)}));
     std::atomic<size_t> next_item{0};
+    const bool simd = mm_host_has_avx2() != 0 && !getenv("MM_PACK_SCALAR");
     auto work = [&]() {
       for (;;) {
         const size_t it = next_item.fetch_add(1);
@@ -143,6 +147,10 @@ void seqset_upload(mm_seqset* s) {
         const uint64_t b0 = s->base[I.seq];
         bool open = false;
         for (size_t j0 = I.j0; j0 < I.j1; j0 += 16) {
+          if (simd && j0 + 32 <= I.j1) {                             // runs of plain ACGT, 32 bases per step (host_pack.cpp); a block with any other byte falls through
+            const size_t done = mm_pack_acgt_blocks(p + j0, (I.j1 - j0) & ~(size_t)31, wp + (j0 >> 4));
+            if (done) { open = false; j0 += done; if (j0 >= I.j1) break; }
+          }
           const size_t m = std::min<size_t>(16, I.j1 - j0);
           uint32_t wv = 0; uint8_t bad = 0;
           for (size_t j = 0; j < m; ++j) { const uint8_t k = lut.t[p[j0 + j]]; bad |= k; wv |= (uint32_t)(k & 3) << (2 * j); }
@@ -182,7 +190,7 @@ void seqset_upload(mm_seqset* s) {
     s->exc_len.alloc(el.size()); s->exc_len.upload(el.data(), el.size(), st);
     s->exc_byte.alloc(eb.size()); s->exc_byte.upload(eb.data(), eb.size(), st);
   }
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
   s->staged.clear(); s->staged.shrink_to_fit(); s->owned.clear(); s->owned.shrink_to_fit();
   s->frozen = true;
 }
@@ -249,7 +257,7 @@ void seqset_load(mm_seqset* s, const char* path) {
     std::vector<uint32_t> w((size_t)nwords);
     read_all(fc.f, w.data(), (size_t)nwords, "bases");
     s->packed.alloc((size_t)nwords); s->packed.upload(w.data(), (size_t)nwords, st);
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
   }
   s->d_base.alloc((size_t)n + 1); s->d_base.upload(s->base.data(), (size_t)n + 1, st);
   s->d_len.alloc(std::max<size_t>((size_t)n, 1)); s->d_len.upload(s->len.data(), (size_t)n, st);
@@ -261,9 +269,9 @@ void seqset_load(mm_seqset* s, const char* path) {
     s->exc_start.alloc(es.size()); s->exc_start.upload(es.data(), es.size(), st);
     s->exc_len.alloc(el.size()); s->exc_len.upload(el.data(), el.size(), st);
     s->exc_byte.alloc(eb.size()); s->exc_byte.upload(eb.data(), eb.size(), st);
-    MM_HIP(hipStreamSynchronize(st));
+    MM_HIP(mm::stream_sync(st));
   }
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
   s->frozen = true;
 }
 
@@ -288,7 +296,7 @@ static void finish_derived(mm_seqset* o, const std::vector<uint64_t>& es, const 
     o->exc_len.alloc(el.size()); o->exc_len.upload(el.data(), el.size(), st);
     o->exc_byte.alloc(eb.size()); o->exc_byte.upload(eb.data(), eb.size(), st);
   }
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
   o->frozen = true;
 }
 void seqset_slice(const mm_seqset* s, int64_t first, int64_t count, mm_seqset* o) {
@@ -352,7 +360,7 @@ void seqset_fetch(mm_seqset* s, int64_t i, char* out, int64_t cap) {
   if (nw) MM_HIP(hipMemcpyAsync(w.data(), s->packed.p + (b0 >> 4), nw * 4, hipMemcpyDeviceToHost, st));
   std::vector<uint64_t> es; std::vector<uint32_t> el; std::vector<uint8_t> eb;
   if (s->n_exc) { es = s->exc_start.to_host(st); el = s->exc_len.to_host(st); eb = s->exc_byte.to_host(st); }
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
   {                                                              // four bases per table look-up (bench.py writes 26.8 Gbases of FASTA through this)
     static const struct Lut { uint32_t t[256]; Lut() { for (int b = 0; b < 256; ++b) { uint32_t v = 0; for (int j = 0; j < 4; ++j) v |= (uint32_t)ascii_of_code((uint32_t)(b >> (2 * j)) & 3u) << (8 * j); t[b] = v; } } } lut;
     const int64_t full = L >> 4;
@@ -384,9 +392,9 @@ void seqset_fetch_range(mm_seqset* s, int64_t first, int64_t count, char* out, i
   if (b1 > b0) MM_HIP(hipMemcpyAsync(w.data(), s->packed.p + (b0 >> 4), (size_t)((b1 - b0) >> 4) * 4, hipMemcpyDeviceToHost, st));
   std::vector<uint64_t> es; std::vector<uint32_t> el; std::vector<uint8_t> eb;
   if (s->n_exc) { es = s->exc_start.to_host(st); el = s->exc_len.to_host(st); eb = s->exc_byte.to_host(st); }
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
   static const struct Lut { uint32_t t[256]; Lut() { for (int b = 0; b < 256; ++b) { uint32_t v = 0; for (int j = 0; j < 4; ++j) v |= (uint32_t)ascii_of_code((uint32_t)(b >> (2 * j)) & 3u) << (8 * j); t[b] = v; } } } lut;
-  const unsigned nthr = (unsigned)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::max(1u, std::thread::hardware_concurrency() / 2), 16, count}));
+  const unsigned nthr = (unsigned)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::max(1u, mm::cpu_budget() / 2), 16, count}));
   std::atomic<int64_t> next{0};
   auto work = [&]() {
     for (;;) {

@@ -5,6 +5,7 @@
 // Float/double mix mirrors the reference expression by expression, because the results are compared
 // against thresholds (identity >= --pi) and printed with 6 significant digits.
 #pragma once
+#include "cpu_budget.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -159,7 +160,7 @@ class LutCache {
     for (int s : sizes) if (!memo_.count(s)) missing.push_back(s);
     if (!missing.empty()) {
       std::vector<SketchLut> out(missing.size());
-      const size_t nt = std::min<size_t>({missing.size() / 8 + 1, 16, std::max(1u, std::thread::hardware_concurrency())});
+      const size_t nt = std::min<size_t>({missing.size() / 8 + 1, 16, std::max(1u, mm::cpu_budget())});
       std::vector<std::thread> th;
       for (size_t t = 1; t < nt; ++t) th.emplace_back([&, t]() { for (size_t i = t; i < missing.size(); i += nt) out[i] = compute(missing[i]); });
       for (size_t i = 0; i < missing.size(); i += nt) out[i] = compute(missing[i]);

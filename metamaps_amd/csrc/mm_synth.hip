@@ -68,7 +68,7 @@ void synth_reference(mm_ctx* ctx, const mm_synth_ref_params& p, mm_seqset* S) {
   synth_ref_kernel<<<dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, st>>>(S->packed.p, wpg, G, p.genome_len, p.strains_per_species, p.seed,
                                                                             p.genus_divergence, p.strain_divergence);
   MM_KERNEL_CHECK();
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
   S->frozen = true;
 }
 
@@ -265,7 +265,7 @@ void synth_community(mm_ctx* ctx, const mm_synth_community_params& p, mm_seqset*
   DBuf<int32_t> d_fg((size_t)NF); d_fg.upload(fam_gran.data(), (size_t)NF, st);
   synth_community_kernel<<<dim3(ctx->cus * 64), dim3(256), 0, st>>>(S->packed.p, nw, d_c.p, (int)C, d_s.p, d_fc.p, d_fg.p, NF, p.repeat_fraction, p.seed);
   MM_KERNEL_CHECK();
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
   S->frozen = true;
 }
 
@@ -367,7 +367,7 @@ void synth_reads(mm_ctx* ctx, const mm_seqset* ref, const mm_synth_read_params& 
   for (auto L : S->len) S->total_bases += L;
   S->d_base.alloc((size_t)p.n_reads + 1); S->d_base.upload(S->base.data(), (size_t)p.n_reads + 1, st);
   S->n_exc = 0;
-  MM_HIP(hipStreamSynchronize(st));
+  MM_HIP(mm::stream_sync(st));
   S->frozen = true;
 }
 

@@ -156,6 +156,31 @@ def test_l2_workgroups_in_position_order_give_the_same_records(ctx, mini, monkey
     idx.close(); R.close(); S.close()
 
 
+def test_l2_launches_side_by_side_give_the_same_records(ctx, mini, monkeypatch):
+    """the two launches of K5's 10 kb class (four-wave and two-wave workgroups) run side by side, the second on the context's auxiliary stream, taking their
+    scratch slots from one pool: the records are those of the launches one behind the other (MM_L2_ONE_STREAM=1), byte for byte, also over repeated batches"""
+    names, contigs = _read_fasta(mini["db"].fasta)
+    rnames, reads = _read_fastq(mini["reads"])
+    S, R = ctx.seqset(contigs), ctx.seqset(reads)
+    idx = ctx.index(S, 16, 8)
+    out = {}
+    for tag, env in (("side_by_side", {}), ("one_stream", {"MM_L2_ONE_STREAM": "1"})):
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        for rep in range(3):
+            M = ctx.map_batch(idx, R, 16, 8); M.add_qualities(16)
+            off, rec = M.fetch()
+            st = M.stats()
+            cur = (off.copy(), rec.tobytes(), len(rec))
+            assert tag not in out or (np.array_equal(out[tag][0], cur[0]) and out[tag][1] == cur[1])
+            out[tag] = cur
+            M.close()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    assert np.array_equal(out["side_by_side"][0], out["one_stream"][0]) and out["side_by_side"][1] == out["one_stream"][1] and out["one_stream"][2] > 100
+    idx.close(); R.close(); S.close()
+
+
 @pytest.mark.parametrize("k,w,thr", [(16, 8, None), (16, 13, 3)])
 def test_index_stored_and_loaded_equals_built(ctx, mini, tmp_path, k, w, thr):
     """persistent device index (mm_index_save / mm_index_load; mapWrap.h:358-405, :443-554): the loaded index has the

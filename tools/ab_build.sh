@@ -9,5 +9,6 @@ for f in mm_seq mm_index mm_map mm_post mm_synth mm_api; do
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-result $flags -c $f.hip -o $out/_build/$f.o ) &
 done
 wait
+g++ -O3 -std=c++17 -fPIC -c host_pack.cpp -o $out/_build/host_pack.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libmetamaps_hip.so $out/_build/*.o -L/opt/rocm/lib -lrccl -lpthread -Wl,-rpath,/opt/rocm/lib
 ls -la $out/libmetamaps_hip.so

@@ -45,8 +45,8 @@ TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r05_traffic.json",
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)                  # (three worker contexts take the steps in turn: a timed region of three steps would be one round of them, no steady state)
+    ap.add_argument("--warmup", type=int, default=3)
     # workload: BASELINE configs[1] shape; scale knobs exist so that smaller boxes / quick checks can run
     ap.add_argument("--shape", choices=("community", "uniform"), default=os.environ.get("MM_BENCH_SHAPE", "community"))
     ap.add_argument("--reads", type=int, default=int(os.environ.get("MM_BENCH_READS", 100_000)), help="reads per GPU")

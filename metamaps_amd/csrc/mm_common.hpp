@@ -60,9 +60,12 @@ inline hipError_t stream_sync(hipStream_t st) {
     if (c != hipSuccess) { ev = nullptr; (void)hipGetLastError(); return hipStreamSynchronize(st); }
     ev_dev = dev;
   }
-  const hipError_t r = hipEventRecord(ev, st);
-  if (r != hipSuccess) return r;
-  return hipEventSynchronize(ev);
+  // (an event belongs to the device that was current when it was made: a thread that trims the cache of a context on ANOTHER device — the allocator's
+  //  out-of-memory path — records into a foreign stream; that, like any other failure here, falls back to the plain wait)
+  if (hipEventRecord(ev, st) != hipSuccess) { (void)hipGetLastError(); return hipStreamSynchronize(st); }
+  const hipError_t w = hipEventSynchronize(ev);
+  if (w != hipSuccess) { (void)hipGetLastError(); return hipStreamSynchronize(st); }
+  return hipSuccess;
 }
 
 // ---- device memory -----------------------------------------------------------------------------------

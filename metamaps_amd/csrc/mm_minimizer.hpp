@@ -155,8 +155,12 @@ static __device__ int mz_dbg_stop = 0;   // timing aid (MM_MZ_DBG=n: the read ke
 //  although they hash once instead of twice.  The ~1 800 resident tiles finish as a generation, the nearest known prefix is then hundreds of tiles
 //  back and every step of the walk is a round trip to the memory side (the XCDs' L2s are not coherent) with the tile's other three wavefronts
 //  parked at the barrier.  Commit b69326c keeps the code.)
+// (amdgpu_waves_per_eu(7): the kernel needs 68-70 registers; left to itself the compiler took 107 after an unrelated edit — one more kernel argument, round 5 — and ran
+//  four waves per SIMD instead of seven: the stage 9.6 -> 10.6 ms.  Pinned.  The same round measured index builds hashing ONCE — MODE 2 in groups of 2^19 tiles through a
+//  4 GB staging area, every group packed behind the previous one into a buffer sized from the winnowing density, the records then moved into an array of their exact size —
+//  against the count + write passes below: 1.355 against 1.366 s for the 26.8 Gbp build; the second hashing pass costs what staging, packing and moving 47 GB cost.  Not kept.)
 template <int MODE>
-__global__ void __launch_bounds__(MZ_THREADS) minimizer_kernel(SeqView S, const uint64_t* __restrict__ tile_first, int k, int w,
+__global__ void __launch_bounds__(MZ_THREADS) __attribute__((amdgpu_waves_per_eu(7))) minimizer_kernel(SeqView S, const uint64_t* __restrict__ tile_first, int k, int w,
                                                                const int32_t* __restrict__ jstar, uint32_t* __restrict__ tile_count,
                                                                const uint64_t* __restrict__ tile_out, Rec* __restrict__ out,
                                                                uint32_t* __restrict__ out_seq, int* __restrict__ stage_overflow) {

@@ -45,8 +45,8 @@ TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r05_traffic.json",
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)                  # (three worker contexts take the steps in turn: a timed region of three steps would be one round of them, no steady state)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 12; --config 4: 4 passes, --config 5: 2 passes of ~20 s)")   # (three worker contexts take the steps in turn: a timed region of three steps would be one round of them, no steady state)
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 3; --config 4: 1, --config 5: 0)")
     # workload: BASELINE configs[1] shape; scale knobs exist so that smaller boxes / quick checks can run
     ap.add_argument("--shape", choices=("community", "uniform"), default=os.environ.get("MM_BENCH_SHAPE", "community"))
     ap.add_argument("--reads", type=int, default=int(os.environ.get("MM_BENCH_READS", 100_000)), help="reads per GPU")
@@ -111,12 +111,21 @@ def build_reference(ctx, args, shape):
     return ref, genome.astype(np.int32), ng + 1, desc
 
 
+def default_steps(args):
+    """K / W when the caller names none: enough steps for a steady state of three workers, few passes where a pass is seconds"""
+    if args.steps is None:
+        args.steps = {4: 4, 5: 2}.get(args.config, 12)
+    if args.warmup is None:
+        args.warmup = {4: 1, 5: 0}.get(args.config, 3)
+
+
 def sched_free(args):
     return not ((args.serialise_map or args.staged_map) and not args.free_overlap)
 
 
 def main():
     args = parse_args()
+    default_steps(args)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))

@@ -49,6 +49,9 @@ constexpr int L2_NBLK_MAX = 128;
 // bucket table over the top hash bits of the sketch: 1 024 buckets for the 10 kb class (sketches up to 3 072 hashes: at most four halving steps
 // inside a bucket; 2 048 buckets were measured in round 2 and cost in LDS what they saved), 4 096 for the long-read classes (sketches up to
 // 32 768: with 1 024 buckets their searches needed five steps and the generic loop, tools/l2_long_phases.py)
+#ifndef L2_WAVES_10K
+#define L2_WAVES_10K 6          // waves per SIMD the 10 kb class is compiled for: 6 = 80 registers, 15 of them spilled (round 5 measured 5 = 96 registers: tools/ab_build.sh)
+#endif
 #ifndef L2_TBITS_10K
 #define L2_TBITS_10K 10
 #endif
@@ -258,7 +261,7 @@ __device__ inline void wave_sync() {
 // SKIP: exact skip-ahead on/off.  DT: counter width of D (uint8_t compact / uint16_t wide).  WAVES: candidates per
 // workgroup; with WAVES > 1 the waves of a workgroup map candidates of ONE read and share its sketch Q in LDS.
 template <bool SKIP, typename DT, int WAVES, int NWQ>
-__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(NWQ == 2 ? 6 : 2))) l2_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restrict__ cand_read,
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(NWQ == 2 ? L2_WAVES_10K : 2))) l2_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restrict__ cand_read,
                                                 const uint32_t* __restrict__ sk_hash, const uint8_t* __restrict__ sk_strand,
                                                 const uint64_t* __restrict__ mz_off, const int32_t* __restrict__ sk_n,
                                                 const int32_t* __restrict__ read_len, const int32_t* __restrict__ accept_min,

@@ -738,8 +738,12 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
       MM_HIP(mm::stream_sync(st));
     }
   };
-  const int GROUP = 8;
+  // iterations are enqueued in groups with one read of the control word behind each; iterations behind the stop are no-ops (every kernel leaves at once, the
+  // collective still runs: the ranks' sequences must match).  The reference's runs take 20-40 iterations: a first group of 24, then eights — two host round
+  // trips for a run of 29 instead of four (round 5; each is a copy, a wait and, under a small CPU budget, a sleep: mm::stream_sync).
+  int group_no = 0;
   while (!h_ctrl[1] && h_ctrl[0] < it_limit) {
+    const int GROUP = group_no++ == 0 ? 24 : 8;
     if (!collective && !split) {                                 // one rank: the whole run is one launch
       E->bar.zero(st);
       em_loop_kernel<false><<<grid, blk, 0, st>>>(a);

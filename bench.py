@@ -699,7 +699,8 @@ def roofline_block(args, R):
                            "frac": d3_sum / (R["ms_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "note": "all D3 bytes of one step (counters of the step measured alone) over the timed region's ms_per_step: what the pipeline as a whole moves per second"},
             "how_to_recompute": "frac = kernels.K.algorithmic_bytes / (kernels.K.ms_alone * 1e-3) / 1e9 / peak; ms_alone agrees with the avg_ms column of profiles/r05_kernel_stats.txt "
-                                "(K5: the sum of its two launches; K1: minimizer_kernel<2> + compact_tiles_kernel + jstar_kernel), ms_timed_region with profiles/r05_kernel_stats_default_cmd.txt; "
+                                "(K5: the sum of its two launches — that profile runs them one behind the other, MM_L2_ONE_STREAM=1; by default they run side by side on two streams and ms_alone is the time of the pair, "
+                                "within 0.1 ms of the sum at this batch size; K1: minimizer_kernel<2> + compact_tiles_kernel + jstar_kernel), ms_timed_region with profiles/r05_kernel_stats_default_cmd.txt; "
                                 "the bytes follow from config.per_step (counters of the last timed step; the step measured alone maps another batch: kernels.K.algorithmic_bytes is its own)"}
 
 

@@ -1,6 +1,10 @@
 """One-process-per-GPU orchestration helpers (mapping shards by read; EM exchanges one small vector per
 iteration).  Backend-agnostic so that the logic is testable with gloo on CPUs: the compute callbacks are
-injected (libmetamaps_hip on a GPU box; the tests inject the oracle)."""
+injected (libmetamaps_hip on a GPU box; the tests inject the oracle).
+
+TEST-SIDE code: the product (libmetamaps_hip.so, the `metamaps` CLI) never imports this module.  bench.py uses `shard_range` to cut its strong-scaling
+batch; `em_distributed` is the loop the world-size-2 gloo test (tests/test_em_host_and_dist.py) and the eight-shard test on one GPU
+(tests/test_gpu_fullsize.py) hold the per-rank partial sums against — the product's own exchange is C++ (mm_post.hip: P1-P3' | ncclAllReduce | finalize)."""
 from __future__ import annotations
 
 import numpy as np

@@ -5,6 +5,8 @@ csrc/host has the same logic).  Mirrors meta::doEM's data preparation and loop c
   loadRelevantTaxonInfo         fEM.h:1320   taxon -> {contig -> length}
   getMappingLocations           fEM.h:234    per (read, taxon): number of possible mapping locations
   doEM loop                     fEM.h:501    f <- normalised sums; stop when ll gain <= 1 and relative < 1e-4
+
+TEST-SIDE code: the product (libmetamaps_hip.so, the `metamaps` CLI) never imports this module; its `classify` is C++ (csrc/host/metamaps_main.cpp, ClassifyRun).
 """
 from __future__ import annotations
 

@@ -6,8 +6,9 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/profiles; rm -rf $out; mkdir -p $out
 FLAGS="--no-cpu-baseline --no-other-shape --no-e2e-full"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 6 --warmup 2 $FLAGS > $out/bench_stats_run.json 2> $out/stats.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_serialised -- python bench.py --steps 6 --warmup 2 --serialise-map --workers 3 $FLAGS > /dev/null 2> $out/stats_serialised.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 6 --warmup 3 $FLAGS > $out/bench_stats_run.json 2> $out/stats.err
+# (MM_L2_ONE_STREAM=1: K5's two launches one behind the other, so that each duration is that of a kernel that owns the GPU and the pair is their sum; by default they run side by side)
+MM_L2_ONE_STREAM=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_serialised -- python bench.py --steps 6 --warmup 2 --serialise-map --workers 3 $FLAGS > /dev/null 2> $out/stats_serialised.err
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python bench.py --steps 1 --warmup 0 --workers 1 --distinct-batches 1 $FLAGS > /dev/null 2> $out/fetch.err
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python bench.py --steps 1 --warmup 0 --workers 1 --distinct-batches 1 $FLAGS > /dev/null 2> $out/write.err
 python tools/summarize_profiles.py $out

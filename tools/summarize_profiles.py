@@ -9,8 +9,8 @@ def short(name):
         n = "rocprim::" + ("radix_sort_onesweep" if "onesweep" in name else "radix_sort_histogram" if "histogram" in name else "other")
     return n[:60]
 
-for sub, name, what in (("stats", "kernel_stats_default_cmd.txt", "python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-shape --no-e2e-full   (the default scheduling: two worker contexts, the kernels of two steps share the GPU, so a kernel's duration includes what it waits for and runs beside"),
-                        ("stats_serialised", "kernel_stats.txt", "python bench.py --steps 6 --warmup 2 --serialise-map --workers 3 --no-cpu-baseline --no-other-shape --no-e2e-full   (mapping sections serialised: the durations of kernels that own the GPU")):
+for sub, name, what in (("stats", "kernel_stats_default_cmd.txt", "python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-other-shape --no-e2e-full   (the default scheduling: three worker contexts, the kernels of their steps share the GPU, so a kernel's duration includes what it waits for and runs beside"),
+                        ("stats_serialised", "kernel_stats.txt", "MM_L2_ONE_STREAM=1 python bench.py --steps 6 --warmup 2 --serialise-map --workers 3 --no-cpu-baseline --no-other-shape --no-e2e-full   (mapping sections serialised and K5's two launches one behind the other: the durations of kernels that own the GPU")):
     fs = glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True)
     if not fs: continue
     rows = list(csv.DictReader(open(fs[0])))

@@ -211,10 +211,20 @@ def test_index_stored_and_loaded_equals_built(ctx, mini, tmp_path, k, w, thr):
     assert np.array_equal(ob, ol) and rb.tobytes() == rl.tobytes() and len(rb) > 100
     Mb.close(); Ml.close(); R.close(); loaded.close()
     data = open(path, "rb").read()
-    for bad in (data[: len(data) - 5], data[: len(data) // 3], b"MMSEQSET" + data[8:], data[:8] + b"\x09" + data[9:]):
+    # truncated, foreign magic, foreign version — and damage INSIDE intact framing (format version 2: every array carries a checksum taken on the device, and the
+    # element counts are held against the header before anything is allocated): one flipped bit in the middle of the entries, in the hash table and in the last
+    # array; an entry count in the header that no longer matches the arrays
+    def flipped(at):
+        b = bytearray(data); b[at] ^= 0x10; return bytes(b)
+    n_entries_at = 8 + 32 + 8                                        # dims[1] = N behind the magic and the eight header words
+    bad_n = data[:n_entries_at] + (int.from_bytes(data[n_entries_at:n_entries_at + 8], "little") + 3).to_bytes(8, "little") + data[n_entries_at + 8:]
+    for bad in (data[: len(data) - 5], data[: len(data) // 3], b"MMSEQSET" + data[8:], data[:8] + b"\x09" + data[9:],
+                flipped(len(data) // 5), flipped(len(data) // 2), flipped(len(data) - 40), bad_n):
         open(path, "wb").write(bad)
         with pytest.raises(capi.MMError):
             ctx.load_index(path)
+    open(path, "wb").write(data)
+    again = ctx.load_index(path); assert again.info() == built.info(); again.close()      # (the undamaged bytes still load)
     with pytest.raises(capi.MMError):
         ctx.load_index(str(tmp_path / "absent.mmidx"))
     built.close(); S.close()

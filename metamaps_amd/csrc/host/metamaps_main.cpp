@@ -483,7 +483,7 @@ struct MapRun {
         struct Block { std::vector<std::unique_ptr<Batch>> out; size_t next = 0; bool done = false, empty = false, over = false; };   // next: first record start behind the block's records
         std::vector<Block> blocks(nb);
         std::mutex bm; std::condition_variable bcv; size_t next_block = 0, consumed = 0; bool abandon = false;
-        const unsigned P = (unsigned)std::max<size_t>(1, std::min<size_t>({nb, (size_t)8, (size_t)std::max(1u, mm::cpu_budget() / 4)}));
+        const unsigned P = (unsigned)std::max<size_t>(1, std::min<size_t>({nb, (size_t)8, (size_t)std::max(1u, mm::cpu_budget() / 2)}));
         auto worker = [&]() {
           for (;;) {
             size_t j;
@@ -615,7 +615,7 @@ struct MapRun {
       struct Block { std::vector<std::unique_ptr<Group>> out; size_t next = 0; bool done = false, empty = false, over = false; };
       std::vector<Block> blocks(nb);
       std::mutex bm; std::condition_variable bcv; size_t next_block = 0, consumed = 0; bool abandon = false;
-      const unsigned P = (unsigned)std::max<size_t>(1, std::min<size_t>({nb, (size_t)8, (size_t)std::max(1u, mm::cpu_budget() / 4)}));
+      const unsigned P = (unsigned)std::max<size_t>(1, std::min<size_t>({nb, (size_t)8, (size_t)std::max(1u, mm::cpu_budget() / 2)}));
       auto worker = [&]() {
         for (;;) {
           size_t j;

@@ -1078,6 +1078,10 @@ def e2e_cli_full(args, k, w, rank_seed):
                       "fastq_reader": {"bytes": os.path.getsize(fq_s), "parse_s": reader_parse_s, "GB_per_s": (os.path.getsize(fq_s) / reader_parse_s / 1e9) if reader_parse_s else None,
                                        "threads": r_thr,
                                        "what": "block-parallel parse of the mmap-ed FASTQ into batches: busy time summed over the parser's threads / their number = the seconds the file takes the reader when nothing holds it up (it starts when the reference is parsed, i.e. runs beside the index build, and waits for queue slots most of the time): bounds what the mapping phase could take from the reader"},
+                      "index_build_note": "these runs follow one another within a second or two, each behind a process that held ~240 GB of the device: their index builds (laps '3 index build' - "
+                                          "'1 reference parse + pack + upload', 5-6 s) wait inside hipMalloc for the driver to wipe what the process before released (~27 GB/s); the same build is 1.4-1.8 s "
+                                          "with 15 s between the processes or as the second build of a process (profiles/r05_index_build_processes.txt, tools/index_build_repeat.py) - e2e_cli_full's "
+                                          "mapDirectly, which starts 17 s after the bench freed its index, shows that case",
                       "batches": n_stream, "reads": int(reads_s), "bases": int(bases_s), "fastq_written_s": round(t_files_stream, 2),
                       "mapping_phase_s": round(t_phase_s, 3), "classify_work_s": round(t_cls_work_s, 3), "classify_waited_for_contexts_s": round(ctx_wait_s, 3), "classify_wall_s": round(t_cls_s, 3), "mapDirectly_wall_s": round(t_map_s, 3),
                       "unit": "Gbp/s", "mapping_phase_value": bases_s / t_phase_s / 1e9,

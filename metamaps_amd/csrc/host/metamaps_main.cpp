@@ -685,7 +685,7 @@ struct MapRun {
     });
     pc.lap("1 reference parse + pack + upload");
     pc.add("2 reference pack+upload (inside 1)", t_pack);
-    if (!only_index) { start_reader(); start_prewarm(); }
+    if (!only_index) { if (!getenv("MM_CLI_LATE_READER")) start_reader(); start_prewarm(); }   // (MM_CLI_LATE_READER: measurement aid — the reader starts when the index is built)
     query_free();                                                // the packed reference now lives on the device (0.25 B per base, for as long as chunks are cut out of it): what is left is what the indexes get
   }
 

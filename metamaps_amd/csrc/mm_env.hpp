@@ -35,6 +35,7 @@ inline const EnvSwitch* env_table(size_t* n) {
     {"MM_CLI_REF_SEQUENTIAL", "unset", "test", "reference through the sequential kseq-style reader instead of the block parser"},
     {"MM_CLI_NO_MMAP", "unset", "test", "query and reference files through the sequential reader (what .gz and pipes always take)"},
     {"MM_CLI_NO_PREWARM", "unset", "test", "worker contexts come up with their first batch instead of beside the index build"},
+    {"MM_CLI_LATE_READER", "unset", "debug", "the query reader starts when the index is built instead of beside the build (measurement aid)"},
     {"MM_CLI_NO_SKETCH_REUSE", "unset", "test", "chunk-major runs recompute minimizers and sketches per chunk (mm_map_batch instead of mm_map_batch_reusing)"},
     {"MM_CLI_NO_HUGE", "unset", "test", "no transparent-huge-page arena for host blocks >= 4 MiB (huge_new.hpp)"},
     {"MM_CLI_FULL_TEARDOWN", "unset", "test", "destroy every object and run static destructors at exit instead of _exit after the last file is closed"},
@@ -53,7 +54,7 @@ inline const EnvSwitch* env_table(size_t* n) {
     {"MM_INDEX_NO_PRETRIM", "unset", "test", "... and does not even trim the context's own cache"},
     {"MM_ALLOC_TRACE", "unset", "debug", "every block that comes from the driver, with its cost, on stderr"},
     {"MM_CTX_TRACE", "unset", "debug", "phases of mm_ctx_create (HIP initialisation, stream, allocator) on stderr"},
-    {"MM_HOST_TIMING", "unset", "debug", "host-side sections of mm_map_batch on stderr"},
+    {"MM_HOST_TIMING", "unset", "debug", "host-side sections of mm_map_batch and of the index build on stderr"},
     {"MM_PACK_SCALAR", "unset", "test", "mm_seqset_upload packs bases with the byte-table loop only (cross-check of the AVX2 path, host_pack.cpp)"},
     // ---- library: index build (mm_index.hip)
     {"MM_INDEX_PART_MAX", "2^31 - 2^24 entries", "test", "entries per partition of the hash sort (small values: the partitioned sort + merge on small inputs)"},

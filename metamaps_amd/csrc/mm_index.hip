@@ -243,6 +243,15 @@ static void build_directory(mm_index* I, hipStream_t st) {
 
 void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* I) {
   hipStream_t st = ctx->stream;
+  struct BuildClock {                                            // MM_HOST_TIMING=1: wall time of the build's sections (stderr; each lap drains the stream)
+    hipStream_t st; bool on = getenv("MM_HOST_TIMING") != nullptr; std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+      if (!on) return;
+      (void)mm::stream_sync(st);
+      const auto n = std::chrono::steady_clock::now();
+      fprintf(stderr, "INFO, index build: %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count()); t = n;
+    }
+  } clk{st};
   // Two allocation regimes (mm_common.hpp).  The index of a chunk of a --maxmemory run, one of many of its size: the cached blocks of
   // earlier work stay and serve this build (0.15 s per 13 GB chunk instead of 1-6 s through the driver), an allocation that fails for
   // lack of memory trims the caches itself.  An index that takes a good part of the device: memory goes back to the driver as the build
@@ -257,6 +266,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
       ctx->alloc.eager = true;
       if (!getenv("MM_INDEX_NO_PRETRIM")) { ctx->alloc.trim(); if (getenv("MM_INDEX_PRETRIM") || getenv("MM_NO_POOL_RESCUE")) big_pool_trim(ctx->device); else big_pool_adopt_idle(ctx->device); }
     } }
+  clk.lap("pool handling");
   I->ctx = ctx; I->k = k; I->w = w;
   I->n_contigs = contigs->count();
   I->contig_len = contigs->len;
@@ -266,6 +276,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   // K1 over every contig; contigs shorter than w or k contribute metadata only (winSketch.hpp:258-264)
   MinimizerSet ms;
   run_minimizers(ctx, contigs, k, w, {}, /*want_rec_seq=*/true, ms);
+  clk.lap("minimizers");
   const int64_t N = ms.total;
   I->N = N;
   I->pos = std::move(ms.rec);
@@ -273,6 +284,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   I->h_cstart = ms.h_off;
   I->U = 0; I->n_dup = 0; I->hist.clear();
   build_directory(I, st);
+  clk.lap("position directory");
   if (N == 0) {
     I->tab_buckets = 64;
     I->tab.alloc((size_t)I->tab_buckets * 8); I->tab.zero(st);
@@ -349,6 +361,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
     auto hb = bad.to_host(st);
     MM_REQUIRE(hb[0] == 0, MM_ERR_DEVICE, "radix sort of the index left the hash keys unsorted");
   }
+  clk.lap("sort by hash");
   key_in.release(); val_in.release(); sort_tmp.release();
   // CSR over unique hashes
   const int64_t ntiles_csr = ceil_div(N, SCAN_TILE);
@@ -365,6 +378,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   csr_fill_tiles_kernel<<<dim3((unsigned)ntiles_csr), dim3(SCAN_THREADS), 0, st>>>(key_out.p, N, tile_rank.p, ntiles_csr, I->uh.p, I->ustart.p);
   MM_KERNEL_CHECK();
   tile_heads.release(); tile_rank.release();
+  clk.lap("distinct hashes");
   // duplicate flags into pos[]
   DBuf<unsigned long long> ndup(1); ndup.zero(st);
   dup_pairs_kernel<false><<<dim3(nblk), dim3(256), 0, st>>>(key_out.p, I->occ.p, N, I->cstart.p, I->dir.p, I->dir_off.p, I->dir_shift, I->pos.p, ndup.p,
@@ -389,6 +403,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
       MM_KERNEL_CHECK();
     }
   }
+  clk.lap("duplicate flags");
   // occurrence histogram (winSketch.hpp:456-459)
   const int64_t big_cap = 1 << 20;
   DBuf<unsigned long long> bins(HIST_BINS), big((size_t)big_cap), nbig(1);
@@ -404,6 +419,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   if (hn[0]) { auto hbig = big.to_host(st, (size_t)hn[0]); for (auto c : hbig) I->hist[(int64_t)c] += 1; }
   key_out.release();
   // sector-aligned occurrence lists (see padded_counts_kernel)
+  clk.lap("occurrence histogram");
   DBuf<uint64_t> pstart((size_t)U + 1);
   {
     DBuf<uint32_t> pc((size_t)U + 1); pc.zero(st);
@@ -426,6 +442,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
     MM_HIP(mm::stream_sync(st));
     I->occ = std::move(padded);
   }
+  clk.lap("padded lists + bin codes");
   // lookup table (load factor <= 0.55, any number of 4-slot buckets), then the CSR arrays are no longer needed
   I->tab_buckets = tab_buckets_for((int64_t)U);
   I->tab.alloc((size_t)I->tab_buckets * 8);
@@ -435,6 +452,7 @@ void index_build(mm_ctx* ctx, const mm_seqset* contigs, int k, int w, mm_index* 
   MM_KERNEL_CHECK();
   MM_HIP(mm::stream_sync(st));
   I->uh.release(); I->ustart.release();
+  clk.lap("lookup table");
 }
 
 

@@ -35,6 +35,7 @@ inline const EnvSwitch* env_table(size_t* n) {
     {"MM_CLI_REF_SEQUENTIAL", "unset", "test", "reference through the sequential kseq-style reader instead of the block parser"},
     {"MM_CLI_NO_MMAP", "unset", "test", "query and reference files through the sequential reader (what .gz and pipes always take)"},
     {"MM_CLI_NO_PREWARM", "unset", "test", "worker contexts come up with their first batch instead of beside the index build"},
+    {"MM_SF_GRID", "the device's CU count", "debug", "resident workgroups of the streaming seed filter (measurement aid: how K3 scales with the CUs at work)"},
     {"MM_CLI_LATE_READER", "unset", "debug", "the query reader starts when the index is built instead of beside the build (measurement aid)"},
     {"MM_CLI_NO_SKETCH_REUSE", "unset", "test", "chunk-major runs recompute minimizers and sketches per chunk (mm_map_batch instead of mm_map_batch_reusing)"},
     {"MM_CLI_NO_HUGE", "unset", "test", "no transparent-huge-page arena for host blocks >= 4 MiB (huge_new.hpp)"},

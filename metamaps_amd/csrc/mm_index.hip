@@ -116,11 +116,13 @@ __global__ void __launch_bounds__(256) pad_lists_kernel(const uint64_t* __restri
                                                         uint64_t* __restrict__ out, uint16_t* __restrict__ out16) {
   const int sub = threadIdx.x & 7;
   for (int64_t u = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; u < U; u += ((int64_t)gridDim.x * blockDim.x) >> 3) {
-    const uint64_t a = ustart[u], c = ustart[u + 1] - a, b = pstart[u];
-    for (uint64_t j = sub; j < c; j += 8) {
-      const uint64_t e = occ[a + j];
-      out[b + j] = e;
-      out16[b + j] = (uint16_t)(((cbase[e >> 32] + (uint64_t)pw_wpos((uint32_t)e)) >> HF_BIN_SHIFT) & (HF_SLOTS - 1));
+    const uint64_t a = ustart[u], c = ustart[u + 1] - a, b = pstart[u], cpad = (c + 7) & ~7ull;
+    for (uint64_t j = sub; j < cpad; j += 8) {
+      if (j < c) {
+        const uint64_t e = occ[a + j];
+        out[b + j] = e;
+        out16[b + j] = (uint16_t)(((cbase[e >> 32] + (uint64_t)pw_wpos((uint32_t)e)) >> HF_BIN_SHIFT) & (HF_SLOTS - 1));
+      } else { out[b + j] = 0; out16[b + j] = hf_pad_code(b, j); }   // padding: no occurrence, a bin of its own (mm_index.hpp)
     }
   }
 }
@@ -529,14 +531,14 @@ void index_plan_chunks(mm_ctx* ctx, const mm_index* I, uint64_t max_memory, std:
 // its element count and a checksum of its bytes as they lay in HBM (array_sum_kernel: a position-dependent 64-bit sum, taken on the
 // device on both sides, so a load also vouches for its own copies), and the file ends with a closing word (a truncated file is
 // refused).  Counts are held against the header (N entries, U hashes, the contig table) before anything is allocated.
-//   "MMINDEX1"  u32 version=2  i32 k  i32 w  i32 dir_shift  i32 dup_sat  i32 freq_threshold  u32 tab_buckets  u32 0
+//   "MMINDEX1"  u32 version=3  i32 k  i32 w  i32 dir_shift  i32 dup_sat  i32 freq_threshold  u32 tab_buckets  u32 0
 //   i64 n_contigs  i64 N  i64 U  i64 n_dup  i64 n_hist
 //   i64 hist[n_hist][2]  i32 contig_len[n_contigs]  u64 h_cstart[n_contigs + 1]
 //   { u64 count, u64 checksum, bytes }  for pos, cstart, occ, occ16, tab, dir, dir_off, dup_bits, dup_rank, dup_dist
 //   u64 0x58444e4958444e49
 // ---------------------------------------------------------------------------------------------------
 namespace {
-constexpr uint32_t IDX_VERSION = 2;
+constexpr uint32_t IDX_VERSION = 3;                             // (3: the padding entries of occ16[] carry codes of their own, hf_pad_code)
 // checksum of an array as it lies in HBM: sum over its 8-byte words of mix(word + C * index) (+ the same over the bytes of a last partial
 // word); a sum, so the order of the threads does not matter
 __device__ __forceinline__ uint64_t sum_mix(uint64_t x) { x ^= x >> 31; x *= 0x9E3779B97F4A7C15ull; x ^= x >> 29; return x; }

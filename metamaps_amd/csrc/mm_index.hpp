@@ -7,7 +7,11 @@
 //                                                                 == minimizerPosLookupIndex      (:119)
 //               occ entry = contig<<32 | pw  (8 bytes, directly usable as an L1 seed hit / sort key)
 //   occ16[P]    per occ entry (same index) the 13-bit position bin the seed-hit filter counts in:
-//               ((first base of the contig in the concatenated reference + wpos) >> 13) & 8191
+//               ((first base of the contig in the concatenated reference + wpos) >> 13) & 8191;
+//               the padding entries behind a list carry 8192 + (a number below 64): a bin no read position falls into, so a kernel that
+//               counts and tests a whole 16-byte piece (the streaming seed filter) needs neither the list's length nor a mask per entry —
+//               the pads land in 64 dummy counters (spread, so that they do not queue up on one LDS address) and are never "alive".
+//               Kernels that mask the code to 13 bits and go by the list's count ignore them as before.
 //   tab[2*cap]  open-addressing table hash -> (count, first occ), cap = 4 * tab_buckets: slot = {count<<32 | hash, start}; one 64-byte
 //               line per lookup on average (uh[]/ustart[] CSR arrays only live during the build)
 //   dup_bits / dup_rank / dup_dist   same-hash neighbours of the entries whose hash occurs more than once in their contig
@@ -56,6 +60,8 @@ struct mm_index {
 namespace mm {
 
 constexpr int HF_BIN_SHIFT = 13, HF_SLOTS = 8192;              // seed-hit filter: 8192-base position bins, counted modulo 8192 bins
+constexpr int HF_PAD_SLOTS = 64;                                // codes HF_SLOTS .. HF_SLOTS + 63: the padding entries of occ16[] (above)
+__host__ __device__ inline uint16_t hf_pad_code(uint64_t list_start, uint64_t j) { return (uint16_t)(HF_SLOTS + (((list_start >> 3) * 5 + j) & (uint64_t)(HF_PAD_SLOTS - 1))); }
 constexpr int HF_SLOT_BITS_NARROW = 13, HF_SLOT_BITS_WIDE = 15; // ... or, for long reads, modulo 32768 slots (mm_map.hip, hit_filter_kernel)
 
 struct IndexView {

@@ -716,6 +716,33 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #ifndef SF_STREAM_WAVES_PER_EU
 #define SF_STREAM_WAVES_PER_EU 4
 #endif
+// The streaming kernel's LDS.  Round 5 (tools/sf_grid_sweep.py): this kernel's time follows the number of CUs at work (64 resident workgroups:
+// 55.6 ms, 256: 15.2 ms — 13.9 ms x 4), i.e. it is bound by what a CU executes per read — 2 580 VALU instructions per wave and read, most of them
+// in phase 1's count-and-park of the codes (per code: extract, validity test under its own branch, counter address and increment of a packed 16-bit
+// pair; per piece: 28 instructions that spread the list number and the valid count over the spare bits) and their undoing in phase 2 — not by
+// the memory side, which it loads to 80 % of its random-request ceiling.  So:
+//   * the padding entries of occ16[] carry codes of their own (hf_pad_code, mm_index.hpp: 8192 + a number below 64), which land in 64 dummy
+//     counters and are never alive: no valid count, no mask, no branch per code;
+//   * counters are 32-bit words (address = code * 4, increment 1);
+//   * a 16-byte piece is parked as it was loaded; the list a piece belongs to is found from anchor[] (the list of every fourth piece) and a
+//     short walk over coff8[];
+//   * phase 1 hands the PIECES out to the lanes (piece q to lane q mod 1024), not the lists to groups of four lanes with a second round for what
+//     lies beyond a list's first 32 entries: the average list has 17 entries, so a third of the lanes had a piece to count, and an LDS atomic costs
+//     what it costs per wave-instruction (6.0 cycles with every third lane active, 7.5 with all: tools/ubench/lds_rates) — 48 of them per wave and
+//     read instead of 120, six loads per lane instead of fifteen, one round trip instead of two, and no table of further pieces to build.
+struct SeedFilterStreamLds {
+  uint32_t cnt[HF_SLOTS + HF_PAD_SLOTS];                        // hits per bin; the last 64: the padding entries' dummies
+  uint32_t good[HF_SLOTS / 32], alive[HF_SLOTS / 32 + 4];       // alive[256 ..]: the pad codes' words, zero for the life of the workgroup
+  uint32_t lstart8[SF_SMAX];                                    // first occurrence of every list / 8 (lists start on 64-byte sectors = multiples of 8 entries, padded_counts_kernel;
+                                                                // an index of more than 2^35 padded occurrences — 275 GB of occ[] alone — does not fit a device)
+  uint16_t lcnt[SF_SMAX];
+  uint16_t coff8[SF_SMAX + 8];                                  // first code piece of every list (+ total)
+  uint16_t anchor[SF_CHUNKS / 4];                               // the list piece 4 a belongs to
+  uint32_t wsum[SF_THREADS / 64], wsum2[SF_THREADS / 64];
+  uint32_t cursor, fallback, total8, hraw, tick[2], pad_[2];
+  ulonglong2 codes[SF_CHUNKS];                                  // 8 codes per piece, as loaded
+};
+static_assert(sizeof(SeedFilterStreamLds) <= 160 * 1024, "the streaming seed filter's LDS must fit one CU");
 template <bool PROF>
 __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu(SF_STREAM_WAVES_PER_EU, SF_STREAM_WAVES_PER_EU))) seed_filter_stream_kernel(IndexView I, const uint32_t* __restrict__ sk_hash, const uint64_t* __restrict__ off,
                                                                         const int32_t* __restrict__ sk_n, const int32_t* __restrict__ read_len,
@@ -725,12 +752,12 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
                                                                         uint32_t* __restrict__ raw_hits, int n_reads, uint32_t* __restrict__ ticket,
                                                                         unsigned long long* __restrict__ prof /* optional (MM_SF_PROF): cycles per phase, summed over the workgroups */) {
   extern __shared__ __align__(16) unsigned char sf_dyn[];
-  SeedFilterLds& L = *reinterpret_cast<SeedFilterLds*>(sf_dyn);
+  SeedFilterStreamLds& L = *reinterpret_cast<SeedFilterStreamLds*>(sf_dyn);
   const ulonglong2* __restrict__ tab = reinterpret_cast<const ulonglong2*>(I.tab);
   const uint64_t tslots = (uint64_t)I.tab_buckets << 2;
   uint32_t hq[SF_LPG]; ulonglong2 vq[SF_LPG];                      // the look-ups in flight: hashes and home-sector slots of the NEXT read
   int r_cur = 0, s_cur = 0; uint64_t o_cur = 0;
-  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = 0;
+  unsigned long long pt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = 0;
   auto lapp = [&](int i) { if (PROF) { const unsigned long long t = __builtin_readcyclecounter(); pt[i] += t - pt0; pt0 = t; } };
   if (PROF) pt0 = __builtin_readcyclecounter();
   
@@ -777,6 +804,7 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
     };
     if (it < 0) {
       if (tid == 0) L.tick[0] = atomicAdd(ticket, 1u);
+      if (tid < 4) L.alive[HF_SLOTS / 32 + tid] = 0;              // (the pad codes' bins: never alive)
       lds_barrier();
       r_cur = __builtin_amdgcn_readfirstlane((int)L.tick[0]);
       head(r_cur, s_cur, o_cur);
@@ -795,8 +823,12 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
       const uint32_t len = (uint32_t)max(read_len[r], 1);
       const int nb = min((int)((len - 1) >> HF_BIN_SHIFT) + 2, HF_SLOTS);
       int m = min_hits[r]; if (m < 1) m = 1;
-      for (int i = tid; i < HF_SLOTS / 2; i += SF_THREADS) L.cnt16[i] = 0;
-      if (tid == 0) { L.cursor = 0; L.fallback = 0; }
+      {
+        uint32_t z = 0;
+        asm volatile("" : "+v"(z));                                // (a zero made here: hoisted out of the loop, a register pair of zeros is kept in scratch, and its reload waits for the look-ups)
+        for (int i = tid; i < (HF_SLOTS + HF_PAD_SLOTS) / 4; i += SF_THREADS) reinterpret_cast<uint4*>(L.cnt)[i] = make_uint4(z, z, z, z);
+        if (tid == 0) { L.cursor = z; L.fallback = z; }
+      }
       lds_barrier();
       lapp(0);
       // the next read's ticket is visible: its class, sketch size and offset are on their way while this read's look-ups are resolved
@@ -828,6 +860,7 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
         const int i = grp + SF_GROUPS * u;
         if (!settle(i, hq[u], vq[u], i < s)) { pmask |= 1u << u; vq[u] = tab[tab_next_sector(tab_slot(hq[u], I.tab_buckets), tslots) + sub]; }
       }
+      lapp(7);                                                    // (first answers looked at, second probes issued)
       if (__any(pmask != 0)) {
 #pragma unroll
         for (int u = 0; u < SF_LPG; ++u) {
@@ -855,91 +888,66 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
         for (int q = 0; q < SF_THREADS / 64; ++q) { const uint32_t x = L.wsum[q]; if (q < wid) basew += x; tot += x; tot2 += L.wsum2[q]; }
         uint32_t ex = basew + inc - mine;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { const int i = tid * 3 + j; if (i <= s) L.coff8[i] = (uint16_t)min(ex, 0xffffu); ex += c8[j]; }
-        if (tid == 0) { L.total8 = tot; L.hraw = tot2; L.n_extra = 0; if (tot > (uint32_t)SF_CHUNKS || tot2 > 65535u) L.fallback = 1; }
-      }
-      lds_barrier();
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int i = tid * 3 + j;
-        const uint32_t c = i < s ? (uint32_t)L.lcnt[i] : 0u;
-        if (c > 32) {
-          const uint32_t np = (c - 1) >> 5;
-          const uint32_t at = atomicAdd(&L.n_extra, np);
-          for (uint32_t p = 0; p < np; ++p) if (at + p < (uint32_t)SF_EXTRA) L.extra[at + p] = ((uint32_t)i << 11) | (p + 1);
+        for (int j = 0; j < 3; ++j) {
+          const int i = tid * 3 + j;
+          if (i <= s) L.coff8[i] = (uint16_t)min(ex, 0xffffu);
+          for (uint32_t a = (ex + 3) >> 2, a1 = min((ex + c8[j] + 3) >> 2, (uint32_t)(SF_CHUNKS / 4)); a < a1; ++a) L.anchor[a] = (uint16_t)i;   // pieces 4 a of this list
+          ex += c8[j];
         }
+        if (tid == 0) { L.total8 = tot; L.hraw = tot2; if (tot > (uint32_t)SF_CHUNKS || tot2 > 65535u) L.fallback = 1; }
       }
-      lds_barrier();
-      if (L.n_extra > (uint32_t)SF_EXTRA) L.fallback = 1;         // (every thread writes the same value)
       lds_barrier();
       lapp(2);
       if (L.fallback) { if (tid == 0) { need_old[r] = 1; surv_n[r] = 0; raw_hits[r] = 0; } }
       else {
-        // ---- phase 1: every list once (seed_filter_kernel, phase 1)
-        {
-          auto code_of = [](const ulonglong2& v, int t) { return (uint32_t)((t < 4 ? v.x : v.y) >> (16 * (t & 3))) & 0xffffu; };
-          auto take = [&](uint32_t cc, uint32_t li, uint32_t chunk0, uint32_t j0, const ulonglong2& x) {
-            const uint32_t e0 = j0 + 8u * sub;
-            if (e0 >= cc) return;
-            const uint32_t nv = min(8u, cc - e0), meta = li | ((nv - 1u) << 12);
-            uint64_t w0 = 0, w1 = 0;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-              const uint32_t code = code_of(x, t) & (uint32_t)(HF_SLOTS - 1);
-              if ((uint32_t)t < nv) atomicAdd(&L.cnt16[code >> 1], 1u << (16 * (code & 1)));
-              const uint64_t slot = code | (((meta >> (3 * t)) & 7u) << 13);
-              if (t < 4) w0 |= slot << (16 * t); else w1 |= slot << (16 * (t - 4));
-            }
-            L.codes[chunk0 + (e0 >> 3)] = make_ulonglong2(w0, w1);
-          };
-          {
-            uint32_t c[SF_LPG]; ulonglong2 v[SF_LPG];
-#pragma unroll
-            for (int u = 0; u < SF_LPG; ++u) {
-              const int i = grp + SF_GROUPS * u;
-              c[u] = i < s ? (uint32_t)L.lcnt[i] : 0u;
-              v[u] = make_ulonglong2(0, 0);
-              if (c[u]) v[u] = *reinterpret_cast<const ulonglong2*>(I.occ16 + ((uint64_t)L.lstart8[i] << 3) + min(8u * sub, (c[u] - 1) & ~7u));
-            }
-#pragma unroll
-            for (int u = 0; u < SF_LPG; ++u) { const int i = grp + SF_GROUPS * u; if (c[u]) take(c[u], (uint32_t)i, (uint32_t)L.coff8[i], 0u, v[u]); }
-          }
-          {
-            constexpr int EPG = SF_EXTRA / SF_GROUPS;
-            const uint32_t ne = L.n_extra;
-            uint32_t c[EPG], ch0[EPG], j0[EPG], li[EPG]; ulonglong2 v[EPG];
-#pragma unroll
-            for (int u = 0; u < EPG; ++u) {
-              const uint32_t k = (uint32_t)(grp + SF_GROUPS * u);
-              c[u] = 0; v[u] = make_ulonglong2(0, 0); ch0[u] = 0; j0[u] = 0; li[u] = 0;
-              if (k < ne) {
-                const uint32_t e = L.extra[k], i = e >> 11;
-                li[u] = i; c[u] = (uint32_t)L.lcnt[i]; ch0[u] = (uint32_t)L.coff8[i]; j0[u] = (e & 0x7ffu) << 5;
-                v[u] = *reinterpret_cast<const ulonglong2*>(I.occ16 + ((uint64_t)L.lstart8[i] << 3) + min(j0[u] + 8u * sub, (c[u] - 1) & ~7u));
-              }
-            }
-#pragma unroll
-            for (int u = 0; u < EPG; ++u) if (c[u]) take(c[u], li[u], ch0[u], j0[u], v[u]);
-          }
-        }
-        // the next read's hashes: requested here, behind the counting (held across phase 1 — eleven lists of a lane group in registers —
-        // they do not fit the 128 registers a 1024-thread workgroup leaves a lane); they arrive under the window sums
+        // the next read's hashes: requested here, in front of the pieces (six pieces in flight leave the registers for them): they are there
+        // long before the look-ups are issued behind the window sums
         load_hashes(s_next, o_next);
+        // ---- phase 1: every 16-byte piece of every list once: piece q to lane q mod 1024, all loads of a lane in flight together, then all
+        // eight codes of a piece counted (the pads behind a list's last entry in their dummies) and the piece parked as it is
+        {
+          constexpr int NP = SF_CHUNKS / SF_THREADS;
+          const uint32_t T8u = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.total8);
+          ulonglong2 v[NP];
+#pragma unroll
+          for (int j = 0; j < NP; ++j) {
+            v[j] = make_ulonglong2(0, 0);
+            if ((uint32_t)(j * SF_THREADS) < T8u) {                // (wave-uniform; lanes beyond the last piece ask for it again and drop the answer)
+              const uint32_t q = min((uint32_t)(tid + j * SF_THREADS), T8u - 1);
+              uint32_t li = L.anchor[q >> 2];
+              while ((uint32_t)L.coff8[li + 1] <= q) ++li;
+              v[j] = *reinterpret_cast<const ulonglong2*>(I.occ16 + ((uint64_t)L.lstart8[li] << 3) + (uint64_t)(q - (uint32_t)L.coff8[li]) * 8u);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < NP; ++j) {
+            const uint32_t q = (uint32_t)(tid + j * SF_THREADS);
+            if (q < T8u) {
+              const ulonglong2 x = v[j];
+#pragma unroll
+              for (int t = 0; t < 8; ++t) atomicAdd(&L.cnt[(uint32_t)((t < 4 ? x.x : x.y) >> (16 * (t & 3))) & 0xffffu], 1u);
+              L.codes[q] = x;
+            }
+          }
+          lapp(8);                                                 // (all pieces loaded, counted and parked)
+        }
         lds_barrier();
         lapp(3);
         {
-          const uint16_t* cnt = reinterpret_cast<const uint16_t*>(L.cnt16);
-          const int b0 = tid * 8;
-          uint32_t sum = 0, bits = 0;
-          for (int i = 0; i < nb; ++i) sum += cnt[(b0 + i) & (HF_SLOTS - 1)];
+          // good[b] = the nb bins from b on hold minimumHits hits.  A lane takes the bins tid, tid + 1024, ...: neighbouring lanes read neighbouring
+          // counters (eight consecutive bins per lane — the sliding form — put the 64 lanes of a read on four LDS banks), and a wave's 64 answers are one ballot
+          const uint32_t* cnt = L.cnt;
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            bits |= (sum >= (uint32_t)m ? 1u : 0u) << t;
-            sum += (uint32_t)cnt[(b0 + t + nb) & (HF_SLOTS - 1)] - (uint32_t)cnt[(b0 + t) & (HF_SLOTS - 1)];
+          for (int kk = 0; kk < HF_SLOTS / SF_THREADS; ++kk) {
+            const int b = tid + kk * SF_THREADS;
+            uint32_t sum = 0;
+            for (int i = 0; i < nb; ++i) sum += cnt[(b + i) & (HF_SLOTS - 1)];
+            const uint64_t gb = __ballot(sum >= (uint32_t)m);
+            if (lane == 0) { L.good[(b >> 5)] = (uint32_t)gb; L.good[(b >> 5) + 1] = (uint32_t)(gb >> 32); }
           }
-          reinterpret_cast<uint8_t*>(L.good)[tid] = (uint8_t)bits;
         }
         lds_barrier();
+        lapp(9);                                                   // (window sums)
         if (tid < HF_SLOTS / 32) {
           uint32_t al = 0;
           for (int j = 0; j < nb; ++j) {
@@ -949,8 +957,10 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
           }
           L.alive[tid] = al;
         }
+        lapp(10);                                                  // (alive)
         // the next read's home sectors: in flight from here to the top of the next iteration
         issue_lookups();
+        lapp(11);                                                  // (hashes arrived, look-ups issued)
         next_issued = true;
         lds_barrier();
         lapp(4);
@@ -959,16 +969,14 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
         const uint32_t T8 = L.total8;
         for (uint32_t q0 = 0; q0 < T8; q0 += SF_THREADS) {
           const uint32_t q = q0 + tid;
-          uint32_t mask = 0, meta = 0;
+          uint32_t mask = 0;
           if (q < T8) {
             const ulonglong2 x = L.codes[q];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-              const uint32_t slot = (uint32_t)((t < 4 ? x.x : x.y) >> (16 * (t & 3))) & 0xffffu, code = slot & (uint32_t)(HF_SLOTS - 1);
-              meta |= (slot >> 13) << (3 * t);
+              const uint32_t code = (uint32_t)((t < 4 ? x.x : x.y) >> (16 * (t & 3))) & 0xffffu;   // (a pad: one of the bins nothing is alive in)
               mask |= ((L.alive[code >> 5] >> (code & 31)) & 1u) << t;
             }
-            mask &= (2u << (meta >> 12 & 7u)) - 1u;
           }
           const int mine = __popc(mask);
           const int incl = wave_incl_scan(mine);
@@ -979,7 +987,8 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
           base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
           uint32_t pos = base + (uint32_t)(incl - mine);
           if (mask) {
-            const uint32_t li = meta & 0xfffu;
+            uint32_t li = L.anchor[q >> 2];                        // the list of piece q: from the anchor of its group of four, past the lists that end at or before q
+            while ((uint32_t)L.coff8[li + 1] <= q) ++li;
             const uint64_t first = ((uint64_t)L.lstart8[li] << 3) + (uint64_t)(q - (uint32_t)L.coff8[li]) * 8u;
             while (mask) {
               const int t = __ffs(mask) - 1; mask &= mask - 1;
@@ -988,6 +997,7 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
             }
           }
         }
+        lapp(12);                                                  // (bit tests, survivor slots written)
         __syncthreads();                                           // (full barrier: the survivor slots written above are read back below)
         lapp(5);
         const uint32_t n_s = L.cursor;
@@ -1008,7 +1018,7 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
     lapp(6);
     r_cur = r_next; s_cur = s_next; o_cur = o_next;
   }
-  if (PROF && threadIdx.x == 0) for (int i = 0; i < 8; ++i) atomicAdd(&prof[i], pt[i]);
+  if (PROF && threadIdx.x == 0) for (int i = 0; i < 16; ++i) atomicAdd(&prof[i], pt[i]);
 }
 
 // range blockIdx.x of src, [sb, se), goes to dst starting at db
@@ -1663,8 +1673,8 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     MM_HIP(mm::stream_sync(st));                            // h_stage_off is the source of the async upload
     hl("K3 stage_off loop + upload");
     if (use_fused && n_fused > 0) {
-      const size_t lds = sizeof(SeedFilterLds);
-      MM_HIP(hipFuncSetAttribute((const void*)seed_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const size_t lds1 = sizeof(SeedFilterLds), lds = sizeof(SeedFilterStreamLds);
+      MM_HIP(hipFuncSetAttribute((const void*)seed_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
       MM_HIP(hipFuncSetAttribute((const void*)seed_filter_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       MM_HIP(hipFuncSetAttribute((const void*)seed_filter_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       // default: the streaming form (one resident workgroup per CU, look-ups of the next read under the LDS phases of this one);
@@ -1673,11 +1683,12 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       DBuf<uint32_t> sf_ticket(1);
       if (!oneshot) sf_ticket.zero(st);
       DBuf<unsigned long long> sf_prof;                            // MM_SF_PROF=1: cycles per phase of the streaming kernel, printed per batch
-      if (getenv("MM_SF_PROF")) { sf_prof.alloc(8); sf_prof.zero(st); }
-      const int sf_grid = (int)std::min<int64_t>(n, std::max(ctx->cus, 1));
+      if (getenv("MM_SF_PROF")) { sf_prof.alloc(16); sf_prof.zero(st); }
+      int sf_grid = (int)std::min<int64_t>(n, std::max(ctx->cus, 1));
+      if (const char* e = getenv("MM_SF_GRID")) sf_grid = std::max(1, std::min(sf_grid, atoi(e)));   // (measurement aid: fewer resident workgroups = fewer CUs at work)
       const size_t t_sf = T.begin(&M->stats.ms_hit_filter);
       if (oneshot)
-        seed_filter_kernel<<<dim3((unsigned)n), dim3(SF_THREADS), lds, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->min_hits.p, surv.p,
+        seed_filter_kernel<<<dim3((unsigned)n), dim3(SF_THREADS), lds1, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->min_hits.p, surv.p,
                                                                            stage.p, stage_off.p, need_old.p, raw_per_read.p, getenv("MM_SF_DBG") ? atoi(getenv("MM_SF_DBG")) : 0);
       else if (sf_prof.p)
         seed_filter_stream_kernel<true><<<dim3((unsigned)sf_grid), dim3(SF_THREADS), lds, st>>>(IV, M->sk_hash.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->min_hits.p, surv.p, stage.p, stage_off.p,
@@ -1691,7 +1702,10 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         auto h = sf_prof.to_host(st);
         const double tot = (double)std::accumulate(h.begin(), h.end(), 0ull);
         fprintf(stderr, "MM_SF_PROF share of cycles: zero+top %.3f | next head + resolve %.3f | scan+extras %.3f | lists+count %.3f | window sums+alive+issue %.3f | phase 2 %.3f | survivors+end %.3f | total %.3g cycles over %d workgroups\n",
-                h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot, tot, sf_grid);
+                h[0] / tot, (h[1] + h[7]) / tot, h[2] / tot, (h[3] + h[8]) / tot, (h[4] + h[9] + h[10] + h[11]) / tot, (h[5] + h[12]) / tot, h[6] / tot, tot, sf_grid);
+        fprintf(stderr, "MM_SF_PROF in detail: top %.3f | first answers + second probes issued %.3f, their answers %.3f | scan+extras %.3f | pieces loaded, counted, parked %.3f, next hashes asked for + barrier %.3f | "
+                        "window sums %.3f, alive %.3f, hashes there + look-ups issued %.3f, barrier %.3f | bit tests + slots %.3f, barrier %.3f | survivors+end %.3f\n",
+                h[0] / tot, h[7] / tot, h[1] / tot, h[2] / tot, h[8] / tot, h[3] / tot, h[9] / tot, h[10] / tot, h[11] / tot, h[4] / tot, h[12] / tot, h[5] / tot, h[6] / tot);
       }
     }
   }

@@ -966,6 +966,8 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
         lapp(4);
         // ---- phase 2: bit tests over the parked codes (seed_filter_kernel, phase 2)
         uint64_t* const dst = stage + stage_base;
+        uint16_t* const sv = reinterpret_cast<uint16_t*>(L.cnt);   // (2 x 8 256 slots: stage_cap = 1024 + 2 x sketch size <= 6 656, unless the test hook MM_HF_STAGE_CAP says otherwise)
+        const uint32_t sv_cap = min(stage_cap, (uint32_t)(2 * (HF_SLOTS + HF_PAD_SLOTS)));
         const uint32_t T8 = L.total8;
         for (uint32_t q0 = 0; q0 < T8; q0 += SF_THREADS) {
           const uint32_t q = q0 + tid;
@@ -986,24 +988,27 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
           if (lane == 63) base = atomicAdd(&L.cursor, (uint32_t)total);
           base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
           uint32_t pos = base + (uint32_t)(incl - mine);
-          if (mask) {
-            uint32_t li = L.anchor[q >> 2];                        // the list of piece q: from the anchor of its group of four, past the lists that end at or before q
-            while ((uint32_t)L.coff8[li + 1] <= q) ++li;
-            const uint64_t first = ((uint64_t)L.lstart8[li] << 3) + (uint64_t)(q - (uint32_t)L.coff8[li]) * 8u;
-            while (mask) {
-              const int t = __ffs(mask) - 1; mask &= mask - 1;
-              if (pos < stage_cap) dst[pos] = first + (uint32_t)t;
-              ++pos;
-            }
+          while (mask) {                                           // a survivor is noted as piece << 3 | entry, 16 bits, where the counters were (they are done with)
+            const int t = __ffs(mask) - 1; mask &= mask - 1;
+            if (pos < sv_cap) sv[pos] = (uint16_t)(q << 3 | (uint32_t)t);
+            ++pos;
           }
         }
-        lapp(12);                                                  // (bit tests, survivor slots written)
-        __syncthreads();                                           // (full barrier: the survivor slots written above are read back below)
+        lapp(12);                                                  // (bit tests, survivors noted)
+        lds_barrier();
         lapp(5);
         const uint32_t n_s = L.cursor;
-        if (n_s > stage_cap) { if (tid == 0) { need_old[r] = 1; surv_n[r] = 0; raw_hits[r] = 0; } }   // stage too small: the two-pass kernels redo the read
+        if (n_s > sv_cap) { if (tid == 0) { need_old[r] = 1; surv_n[r] = 0; raw_hits[r] = 0; } }   // stage too small: the two-pass kernels redo the read
         else {
-          for (uint32_t j = tid; j < n_s; j += SF_THREADS) dst[j] = I.occ[dst[j]] & ~(uint64_t)(PW_DP | PW_DN);
+          // the occurrence of every survivor: list start + position in the list (the list of a piece: from the anchor of its group of four,
+          // past the lists that end at or before it).  Noted in global memory and read back behind a full barrier, as until round 5, this
+          // cost a store, a round trip and a wait for the look-ups in flight before the occurrences could even be asked for.
+          for (uint32_t j = tid; j < n_s; j += SF_THREADS) {
+            const uint32_t e = sv[j], q = e >> 3;
+            uint32_t li = L.anchor[q >> 2];
+            while ((uint32_t)L.coff8[li + 1] <= q) ++li;
+            dst[j] = I.occ[((uint64_t)L.lstart8[li] << 3) + (uint64_t)(q - (uint32_t)L.coff8[li]) * 8u + (e & 7u)] & ~(uint64_t)(PW_DP | PW_DN);
+          }
           if (tid == 0) { surv_n[r] = n_s; raw_hits[r] = L.hraw; }
         }
       }

@@ -1537,6 +1537,8 @@ struct ClassifyRun {
   const std::function<void()>& need_devices;   // called before the first device call: the contexts are created beside the parsing of the file (may be empty)
   PhaseClock pc;
   const unsigned HW = mm::cpu_budget();                        // CPUs this process may keep busy (cpu_budget.hpp: a container's quota counts, not the 256 the machine shows)
+  const unsigned WIDE = std::max(1u, HW - std::max(1u, HW / 8));   // width of the pools that compute flat out: under a CPU quota (16 CPUs' worth of time per 100 ms) sixteen such threads plus
+                                                               // whatever else runs use the period up, and every thread of the process is stopped for the rest of it (bench: c1 0.11 -> 0.21 s)
   struct TextBuf {                                               // the file's bytes + a terminating 0, not zero-filled first (std::string::resize spent 0.1 s on that per 0.5 GB)
     char* p = nullptr; size_t n = 0;
     void resize(size_t k) { p = new (std::nothrow) char[k + 1]; if (!p) die("out of host memory for the mappings file"); n = k; p[k] = 0; }   // (huge_new.hpp: on huge pages)
@@ -1604,7 +1606,7 @@ struct ClassifyRun {
       };
       // (MM_CLASSIFY_THREADS=n: exactly n pieces, whatever the size of the file — the tests cut small files into many)
       const size_t NTH = getenv("MM_CLASSIFY_THREADS") ? (size_t)std::min(256, std::max(1, atoi(getenv("MM_CLASSIFY_THREADS"))))
-                                                       : std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)HW, TS / ((size_t)4 << 20) + 1}));
+                                                       : std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)WIDE, TS / ((size_t)4 << 20) + 1}));
       std::vector<size_t> cut(NTH + 1, TS);
       cut[0] = 0;
       for (size_t t = 1; t < NTH; ++t) cut[t] = std::max(cut[t - 1], read_boundary(TS / NTH * t));
@@ -1737,7 +1739,7 @@ struct ClassifyRun {
       std::vector<std::string> tax_nonx(taxa.size());              // getFirstNonXNode per taxon (taxonomy.h:51-74), once
       for (size_t t = 0; t < taxa.size(); ++t) tax_nonx[t] = T.first_non_x(taxa[t]);
       const size_t NTH = getenv("MM_CLASSIFY_THREADS") ? (size_t)std::min(256, std::max(1, atoi(getenv("MM_CLASSIFY_THREADS"))))
-                                                       : std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)HW, lines.size() / 50000 + 1}));
+                                                       : std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)WIDE, lines.size() / 50000 + 1}));
       std::vector<size_t> rcut(NTH + 1, NRD);
       rcut[0] = 0;
       { size_t t = 1; for (size_t r = 0; r < NRD && t < NTH; ++r) if ((uint64_t)off[r] >= (uint64_t)lines.size() * t / NTH) rcut[t++] = r; }

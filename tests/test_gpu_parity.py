@@ -211,7 +211,7 @@ def test_index_stored_and_loaded_equals_built(ctx, mini, tmp_path, k, w, thr):
     assert np.array_equal(ob, ol) and rb.tobytes() == rl.tobytes() and len(rb) > 100
     Mb.close(); Ml.close(); R.close(); loaded.close()
     data = open(path, "rb").read()
-    # truncated, foreign magic, foreign version — and damage INSIDE intact framing (format version 2: every array carries a checksum taken on the device, and the
+    # truncated, foreign magic, foreign version — and damage INSIDE intact framing (since format version 2 every array carries a checksum taken on the device, and the
     # element counts are held against the header before anything is allocated): one flipped bit in the middle of the entries, in the hash table and in the last
     # array; an entry count in the header that no longer matches the arrays
     def flipped(at):

@@ -682,7 +682,8 @@ def roofline_block(args, R):
                     "D3 counts only the packed bases it reads: the 8-byte records it writes (2.1 GB per step, twice: staged, then compacted) are what traffic_over_algorithmic shows"),
         "K3": entry("seed_filter_stream_kernel<false> (mm_map_stats.ms_hit_filter)", st_a["ms_hit_filter"], 8.0 * (st_a["sum_hits"] + st_a["sum_sketch"]),
                     agg["ms_hf"] / nl, 8.0 * agg["hf_units"] / nl, ["mm::seed_filter_stream_kernel<false>"],
-                    "random 64-byte requests: table sector, occurrence list, survivors (tools/ubench/randread: 49e9 requests/s from HBM, 81e9/s from L2; profiles/r05_randread.txt); VALU 44 percent"),
+                    "two things (DESIGN.md section 7): what a CU executes per read (the time follows the CUs at work: profiles/r05_sf_grid_sweep.txt; VALU 37 percent, LDS atomics, 13 barriers) and the memory side's rate "
+                    "of random 64-byte requests - table sector, list pieces, survivors: 5.3e8 per launch (FETCH_SIZE) against 47e9 requests/s over a 90 GB footprint, which 64 CUs reach alone (profiles/r05_randread_cus.txt)"),
         "K5": entry("l2_kernel<true,u8,4,2> + l2_kernel<true,u8,2,2> (the launch pair of a step: mm_map_stats.ms_l2)", st_a["ms_l2"], 8.0 * st_a["sum_l2_stream_entries"],
                     agg["ms_l2"] / nl, 8.0 * agg["l2_stream"] / nl, ["mm::l2_kernel<true, unsigned char, 4, 2>", "mm::l2_kernel<true, unsigned char, 2, 2>"],
                     "VALU: 2.8 wave-instructions per streamed entry, 87 percent of the issue slots (profiles/r05_sq_counters.txt); phase shares: profiles/r05_l2_phases.txt"),

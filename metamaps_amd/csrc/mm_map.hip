@@ -827,6 +827,7 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
         uint32_t z = 0;
         asm volatile("" : "+v"(z));                                // (a zero made here: hoisted out of the loop, a register pair of zeros is kept in scratch, and its reload waits for the look-ups)
         for (int i = tid; i < (HF_SLOTS + HF_PAD_SLOTS) / 4; i += SF_THREADS) reinterpret_cast<uint4*>(L.cnt)[i] = make_uint4(z, z, z, z);
+        if (tid < (int)(sizeof L.lcnt / 16)) reinterpret_cast<uint4*>(L.lcnt)[tid] = make_uint4(z, z, z, z);
         if (tid == 0) { L.cursor = z; L.fallback = z; }
       }
       lds_barrier();
@@ -839,20 +840,19 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
       // lane groups whose home sector was full without a match, the next sector; round 1 (rarely 2) looks at those.
       // pass 1: every answer looked at once; a lane group whose home sector is full without a match asks for the next sector — all such
       // requests of the lane are in flight together; pass 2 takes them up (and probes on, one sector at a time, in the rare case)
+      // (lcnt[] is zero from the top of the iteration: only a hash that is found and kept writes its list; absent or cut by freqThreshold = no list)
       auto settle = [&](int i, uint32_t h, const ulonglong2& v, bool pending) -> bool {   // true: the look-up of this lane group is done
+        // slots are filled in probing order and never emptied: a match is the key's slot, an empty slot without one means absent
         const bool match = pending && v.x != 0 && (uint32_t)v.x == h, empty = pending && v.x == 0;
-        const uint32_t gm = (uint32_t)(__ballot(match) >> gshift) & 0xfu, ge = (uint32_t)(__ballot(empty) >> gshift) & 0xfu;
-        if (pending && (gm | ge)) {
-          // slots are filled in probing order and never emptied: a match is the key's slot, an empty slot without one means absent
-          if (match) {
-            const uint32_t cnt = (uint32_t)(v.x >> 32);
-            const bool keep = (uint64_t)cnt < (uint64_t)(int64_t)I.freq_threshold;   // computeMap.hpp:317
-            if (keep && cnt > 0xffffu) L.fallback = 1;            // (a list this long overflows the code area anyway)
-            L.lcnt[i] = keep ? (uint16_t)cnt : (uint16_t)0; L.lstart8[i] = keep ? (uint32_t)(v.y >> 3) : 0u;
-          } else if (!gm && sub == 0) { L.lcnt[i] = 0; L.lstart8[i] = 0u; }
-          return true;
+        const uint32_t done = (uint32_t)(__ballot(match || empty) >> gshift) & 0xfu;
+        if (match) {
+          const uint32_t cnt = (uint32_t)(v.x >> 32);
+          if ((uint64_t)cnt < (uint64_t)(int64_t)I.freq_threshold) {   // computeMap.hpp:317
+            if (cnt > 0xffffu) L.fallback = 1;                    // (a list this long overflows the code area anyway)
+            L.lcnt[i] = (uint16_t)cnt; L.lstart8[i] = (uint32_t)(v.y >> 3);
+          }
         }
-        return !pending;
+        return !pending || done != 0;
       };
       uint32_t pmask = 0;
 #pragma unroll

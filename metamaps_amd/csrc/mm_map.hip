@@ -713,6 +713,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // waits.  Measured in round 5 (tools/ab.sh, one box, in turns): at 96 registers 43 are spilled, and a reload from scratch waits behind the look-ups in
 // flight: this kernel 14.9 -> 16.9 ms alone; the other worker's K1 does get in (its time inside the timed region 17 -> 13 ms), the step does not
 // gain: 45.4 / 47.4 ms against 44.5 / 46.9.  Not adopted; the switch stays for the record (tools/ab_build.sh w5 "-DSF_STREAM_WAVES_PER_EU=5").
+// (That was the 141 KB layout.  Since the round's last session the kernel keeps 32-bit counters and an anchor table: 158 KB of LDS, nothing fits beside it.)
 #ifndef SF_STREAM_WAVES_PER_EU
 #define SF_STREAM_WAVES_PER_EU 4
 #endif
@@ -1706,9 +1707,9 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       if (sf_prof.p && !oneshot) {
         auto h = sf_prof.to_host(st);
         const double tot = (double)std::accumulate(h.begin(), h.end(), 0ull);
-        fprintf(stderr, "MM_SF_PROF share of cycles: zero+top %.3f | next head + resolve %.3f | scan+extras %.3f | lists+count %.3f | window sums+alive+issue %.3f | phase 2 %.3f | survivors+end %.3f | total %.3g cycles over %d workgroups\n",
+        fprintf(stderr, "MM_SF_PROF share of cycles: zero+top %.3f | next head + resolve %.3f | scan %.3f | lists+count %.3f | window sums+alive+issue %.3f | phase 2 %.3f | survivors+end %.3f | total %.3g cycles over %d workgroups\n",
                 h[0] / tot, (h[1] + h[7]) / tot, h[2] / tot, (h[3] + h[8]) / tot, (h[4] + h[9] + h[10] + h[11]) / tot, (h[5] + h[12]) / tot, h[6] / tot, tot, sf_grid);
-        fprintf(stderr, "MM_SF_PROF in detail: top %.3f | first answers + second probes issued %.3f, their answers %.3f | scan+extras %.3f | pieces loaded, counted, parked %.3f, next hashes asked for + barrier %.3f | "
+        fprintf(stderr, "MM_SF_PROF in detail: top %.3f | first answers + second probes issued %.3f, their answers %.3f | scan %.3f | pieces loaded, counted, parked %.3f, next hashes asked for + barrier %.3f | "
                         "window sums %.3f, alive %.3f, hashes there + look-ups issued %.3f, barrier %.3f | bit tests + slots %.3f, barrier %.3f | survivors+end %.3f\n",
                 h[0] / tot, h[7] / tot, h[1] / tot, h[2] / tot, h[8] / tot, h[3] / tot, h[9] / tot, h[10] / tot, h[11] / tot, h[4] / tot, h[12] / tot, h[5] / tot, h[6] / tot);
       }

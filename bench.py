@@ -129,6 +129,10 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1 and "MM_CPU_BUDGET" not in os.environ:
+        # one process per GPU: every rank would size its pools (and choose between spinning and sleeping on its streams) from the whole
+        # container's CPU quota; a rank gets its share (read by the library at its first call, cpu_budget.hpp)
+        os.environ["MM_CPU_BUDGET"] = str(max(2, min(os.cpu_count() or 1, cpu_quota() or (os.cpu_count() or 1)) // world))
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local)

@@ -82,6 +82,10 @@ inline const EnvSwitch* env_table(size_t* n) {
     {"MM_L2_NO_GROUP_SORT", "unset", "test", "K5 workgroups in read order instead of the order of their candidates' positions"},
     {"MM_L2_GROUP_SORT_MIN", "2048", "tuning", "groups from which the launch order is sorted"},
     {"MM_L2_XCD_ORDER", "unset", "tuning", "deal the position-sorted workgroup list out per XCD (measured: slower, DESIGN.md section 7)"},
+    {"MM_L2_V1", "unset", "test", "K5's 10 kb class through l2_kernel (rank codes per entry) instead of the zone kernel l2z_kernel (mm_l2z.hpp): the cross-check and the A/B"},
+    {"MM_L2_V2_LONG", "unset", "tuning", "the long-read classes (sketches of 3 073 .. 13 000 hashes) through the zone kernel too"},
+    {"MM_L2_NO_FUSE", "unset", "test", "zone kernel without the band predicted from L1's seed-hit count: its masks always come from a second pass over the stream"},
+    {"MM_L2Z_DBG", "unset", "debug", "zone kernel writes pivot-minus-estimate and its pass count INSTEAD OF RESULTS (tools/l2z_pivot_hist.py; 2: against the predicted estimate)"},
     {"MM_L2_ONE_STREAM", "unset", "test", "the two launches of K5's 10 kb class one behind the other on the context's stream instead of side by side (auxiliary stream)"},
     {"MM_L2_NO_SLOTS", "unset", "test", "K5 scratch indexed by wave number of the launch instead of per-XCD slots taken and given back"},
     {"MM_L2_SLOTS", "auto (resident waves)", "tuning", "number of K5 scratch slots"},
@@ -114,7 +118,12 @@ inline std::string env_unknown() {
     if (strncmp(*e, "MM_", 3) != 0) continue;
     const char* eq = strchr(*e, '=');
     const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
-    if (name.rfind("MM_BENCH_", 0) == 0) continue;                 // (bench.py's own switches: read by Python, not by the product)
+    // switches of the repository's own Python / shell side (bench.py, tests/, tools/): read there, not by the product — a fuzz campaign or an
+    // A/B run (MM_LIB_PATH) must be combinable with strict mode.  tests/test_env_table.py holds this list against *.py and *.sh.
+    static const char* const outside[] = {"MM_BENCH_", "MM_FUZZ_", "MM_TEST_", "MM_CLI_FUZZ_CASES", "MM_LIB_PATH"};
+    bool ours = false;
+    for (const char* pfx : outside) ours = ours || name.rfind(pfx, 0) == 0;
+    if (ours) continue;
     bool known = false;
     for (size_t i = 0; i < n && !known; ++i) known = name == T[i].name;
     if (!known) bad += (bad.empty() ? "" : ", ") + name;

@@ -14,6 +14,7 @@
 #include <rocprim/rocprim.hpp>
 #include "mm_l2_core.hpp"
 #include "mm_l2.hpp"
+#include "mm_l2z.hpp"
 #include "mm_l2_dense.hpp"
 #include <cstdlib>
 #include <atomic>
@@ -1145,7 +1146,7 @@ template <bool WRITE>
 __global__ void __launch_bounds__(256) l1_wave_kernel(const uint64_t* __restrict__ hits, const uint64_t* __restrict__ read_hit_off,
                                                       const int32_t* __restrict__ read_len, const int32_t* __restrict__ min_hits, int64_t n_reads,
                                                       uint32_t* __restrict__ cand_n, const uint64_t* __restrict__ cand_off, int32_t* __restrict__ cand,
-                                                      int32_t* __restrict__ cand_read) {
+                                                      int32_t* __restrict__ cand_read, int32_t* __restrict__ cand_hint /* optional: seed hits inside the candidate */) {
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (r >= n_reads) return;
@@ -1155,6 +1156,7 @@ __global__ void __launch_bounds__(256) l1_wave_kernel(const uint64_t* __restrict
   int m = min_hits[r]; if (m < 1) m = 1;                         // :349
   const uint64_t wbase = WRITE ? cand_off[r] : 0;
   int count = 0, prev_seq = -1, prev_wa = 0;
+  int64_t open_i = 0;                                            // the hit that opened the candidate the previous chunk ended in
   for (int64_t base = 0; base + m <= H; base += 64) {
     const int64_t i = base + lane;
     const bool valid = i + m <= H;
@@ -1177,7 +1179,15 @@ __global__ void __launch_bounds__(256) l1_wave_kernel(const uint64_t* __restrict
       int32_t* c = cand + 3 * (wbase + (uint64_t)k);
       if (brk) { c[0] = sa; c[1] = cs; cand_read[wbase + (uint64_t)k] = (int32_t)r; }
       if (last) c[2] = wa;
+      if (last && cand_hint) {
+        // the seed hits of the candidate: from the hit that opened it to the last hit of the last qualifying run — with --all nearly all of them
+        // lie inside ONE read-length window, so this is about what K5 will find as the matched count of its best window (mm_l2z.hpp: the band it predicts)
+        const uint64_t opened = bm & ((2ull << lane) - 1ull);
+        const int64_t oi = opened ? base + (63 - __builtin_clzll(opened)) : open_i;
+        cand_hint[wbase + (uint64_t)k] = (int32_t)min((int64_t)0x7fffffff, i + m - oi);
+      }
     }
+    if (bm) open_i = base + (63 - __builtin_clzll(bm));
     count += __popcll(bm);
     if (qm) { const int ll = 63 - __builtin_clzll(qm); prev_seq = __shfl(sa, ll, 64); prev_wa = __shfl(wa, ll, 64); }
   }
@@ -1250,15 +1260,16 @@ __global__ void __launch_bounds__(256) l2_group_unpack_kernel(const uint64_t* __
 }
 
 __global__ void __launch_bounds__(256) l2_stats_kernel(const L2Result* __restrict__ l2, int64_t n, unsigned long long* __restrict__ counters) {
-  __shared__ unsigned long long acc[4];
-  if (threadIdx.x < 4) acc[threadIdx.x] = 0;
+  __shared__ unsigned long long acc[5];
+  if (threadIdx.x < 5) acc[threadIdx.x] = 0;
   __syncthreads();
-  unsigned long long a = 0, b = 0, c = 0, d = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { a += l2[i].n_stream; b += l2[i].n_evals; c += l2[i].n_rebuilds; d += l2[i].pad2; }
-  atomicAdd(&acc[0], a); atomicAdd(&acc[1], b); atomicAdd(&acc[2], c); atomicAdd(&acc[3], d);
+  unsigned long long a = 0, b = 0, c = 0, d = 0, e = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { a += l2[i].n_stream; b += l2[i].n_evals; c += l2[i].n_rebuilds; d += l2[i].pad2; e += (unsigned long long)l2[i].pad; }
+  atomicAdd(&acc[0], a); atomicAdd(&acc[1], b); atomicAdd(&acc[2], c); atomicAdd(&acc[3], d); atomicAdd(&acc[4], e);
   __syncthreads();
   if (threadIdx.x < 3) atomicAdd(&counters[threadIdx.x], acc[threadIdx.x]);
   if (threadIdx.x == 3) atomicAdd(&counters[15], acc[3]);   // slide rounds (diagnostic)
+  if (threadIdx.x == 4) atomicAdd(&counters[12], acc[4]);   // zone passes of the zone kernels (diagnostic)
 }
 
 __global__ void accept_flags_kernel(const L2Result* __restrict__ l2, int64_t n, uint32_t* __restrict__ flag) {
@@ -1907,7 +1918,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   const unsigned rblk = (unsigned)ceil_div(std::max<int64_t>(n, 1), 128);
   if (n > 0) {
     if (l1_serial) l1_scan_kernel<false><<<dim3(rblk), dim3(128), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, cand_n.p, nullptr, nullptr, nullptr);
-    else l1_wave_kernel<false><<<dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, cand_n.p, nullptr, nullptr, nullptr);
+    else l1_wave_kernel<false><<<dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, cand_n.p, nullptr, nullptr, nullptr, nullptr);
     MM_KERNEL_CHECK();
   }
   exclusive_scan_u32_u64(cand_n.p, n, M->cand_off.p, scan_tmp, st);
@@ -1919,10 +1930,12 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   M->cand.alloc((size_t)std::max<int64_t>(3 * ncand, 1));
   M->cand_read.alloc((size_t)std::max<int64_t>(ncand, 1));
   M->l2.alloc((size_t)std::max<int64_t>(ncand, 1));
+  DBuf<int32_t> cand_hint((size_t)std::max<int64_t>(ncand, 1));   // seed hits inside each candidate (l1_wave_kernel): the zone kernel's prediction of its band
+  if (l1_serial || getenv("MM_L2_NO_FUSE")) cand_hint.zero(st);    // (0: no prediction, the masks of the band come from a second pass over the stream)
   M->rec_off.alloc((size_t)n + 1);
   if (ncand > 0) {
     if (l1_serial) l1_scan_kernel<true><<<dim3(rblk), dim3(128), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, nullptr, M->cand_off.p, M->cand.p, M->cand_read.p);
-    else l1_wave_kernel<true><<<dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, nullptr, M->cand_off.p, M->cand.p, M->cand_read.p);
+    else l1_wave_kernel<true><<<dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, nullptr, M->cand_off.p, M->cand.p, M->cand_read.p, cand_hint.p);
     MM_KERNEL_CHECK();
     T.end(t_l1);
     // ---- K5/K6
@@ -1961,8 +1974,8 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     MM_REQUIRE(lds_wide <= 160 * 1024, MM_ERR_LIMIT, "L2 window state does not fit LDS");
     auto set_lds = [&](const void* fn, size_t bytes) { if (bytes > 64 * 1024) MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); };
     DBuf<unsigned long long> counters(16); counters.zero(st);
-    if (getenv("MM_L2_STOP") || getenv("MM_L2_PHASES") || getenv("MM_FORCE_AMB_REDO")) {
-      const char* ds = getenv("MM_L2_STOP"); unsigned long long v = (unsigned long long)((ds ? atoi(ds) & 0xff : 0) | (getenv("MM_L2_PHASES") ? 0x100 : 0) | (getenv("MM_FORCE_AMB_REDO") ? 0x200 : 0)); MM_HIP(hipMemcpyAsync(counters.p + 11, &v, sizeof v, hipMemcpyHostToDevice, st)); MM_HIP(mm::stream_sync(st)); }   // timing aid: leave the kernel after phase n (results are then meaningless)
+    if (getenv("MM_L2_STOP") || getenv("MM_L2_PHASES") || getenv("MM_FORCE_AMB_REDO") || getenv("MM_L2Z_DBG")) {
+      const char* ds = getenv("MM_L2_STOP"); unsigned long long v = (unsigned long long)((ds ? atoi(ds) & 0xff : 0) | (getenv("MM_L2_PHASES") ? 0x100 : 0) | (getenv("MM_FORCE_AMB_REDO") ? 0x200 : 0) | (getenv("MM_L2Z_DBG") ? (atoi(getenv("MM_L2Z_DBG")) == 2 ? 0xc00 : 0x400) : 0)); MM_HIP(hipMemcpyAsync(counters.p + 11, &v, sizeof v, hipMemcpyHostToDevice, st)); MM_HIP(mm::stream_sync(st)); }   // timing aid: leave the kernel after phase n (results are then meaningless)
     DBuf<int32_t> ovf((size_t)ncand);
     DBuf<unsigned int> ovf_n(1); ovf_n.zero(st);
     DBuf<uint8_t> amb_used;
@@ -2055,6 +2068,14 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         if (getenv("MM_L2_NO_CODES")) return nullptr;              // cross-check switch
         return ctx->l2_codes_at_least(slots_of(n_waves, nwq) * (size_t)(64 * 64 * nwq) * (nwq == 2 ? sizeof(uint16_t) : sizeof(uint32_t)));
       };
+      // the zone kernels (mm_l2z.hpp, the default; MM_L2_V1=1: l2_kernel for every class): matched list + masks per slot
+      const bool v2 = !getenv("MM_L2_V1");
+      const bool v2_long = v2 && getenv("MM_L2_V2_LONG");            // the long-read classes (sketches of 3 073 .. 13 000 hashes) through the zone kernel as well: measured slower on configs[3] so far
+      const int32_t* const cand_hint_p = cand_hint.p;
+      auto lists_for = [&](size_t n_waves, int nwq) -> void* { return ctx->l2_codes_at_least(slots_of(n_waves, nwq) * l2z_list_bytes(nwq)); };
+      auto zmasks_for = [&](size_t n_waves, int nwq) -> uint8_t* { return (uint8_t*)ctx->l2_masks_at_least(slots_of(n_waves, nwq) * l2z_mask_bytes(nwq)); };
+      DBuf<int32_t> big((size_t)(v2 ? ncand : 1));                // candidates with more streamed entries than the zone kernel's masks hold: l2_kernel's widest class
+      DBuf<unsigned int> big_n(1); big_n.zero(st);
       std::vector<int32_t> gA0, gAn, gB0, gBn, gD0, gDn, listC, gS0, gSn;   // gS: groups of one or two candidates of the 10 kb class (two-wave workgroups)
       int smA = 0, smB = 0, smC = 0, smD = 0;
       std::vector<int32_t> listL; int smL = 0;                    // long reads below the giant class that take the dense path
@@ -2123,8 +2144,8 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       // MM_L2_ONE_STREAM=1: one behind the other as until round 5 (cross-check and A/B).
       {
         const size_t n_waves = std::max(nA * 4, nS * 2);
-        void* const codes = (nA || nS) ? codes_for(n_waves, 2) : nullptr;
-        uint8_t* const masks = (nA || nS) ? masks_for(n_waves, 2) : nullptr;
+        void* const codes = !(nA || nS) ? nullptr : v2 ? lists_for(n_waves, 2) : codes_for(n_waves, 2);
+        uint8_t* const masks = !(nA || nS) ? nullptr : v2 ? zmasks_for(n_waves, 2) : masks_for(n_waves, 2);
         const int n_slots = (int)slots_of(n_waves, 2);
         const bool side_by_side = nA && nS && !no_slots && !getenv("MM_L2_ONE_STREAM");   // (without slots the scratch is indexed by wave number of the launch: one launch at a time)
         hipStream_t st_small = st;
@@ -2134,19 +2155,37 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           MM_HIP(hipEventRecord(ctx->ev_fork, st));
           MM_HIP(hipStreamWaitEvent(st_small, ctx->ev_fork, 0));
         }
+        if (v2) {
+          const int bbl = l2z_bloom_log2(smA);
+          if (nA) {
+            const size_t lds = l2z_lds_bytes(smA, 2, true, bbl, 4);
+            set_lds((const void*)l2z_kernel<4, 2, true>, lds);
+            l2z_kernel<4, 2, true><<<dim3((unsigned)nA), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p,
+                M->accept_min.p, P.k, P.w, smA, bbl, M->l2.p, counters.p, d_gA0.p, d_gAn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)codes, masks, slot_flags_p, n_slots, cand_hint_p);
+            MM_KERNEL_CHECK();
+          }
+          if (nS) {
+            const size_t lds = l2z_lds_bytes(smA, 2, true, bbl, 2);
+            set_lds((const void*)l2z_kernel<2, 2, true>, lds);
+            l2z_kernel<2, 2, true><<<dim3((unsigned)nS), dim3(128), lds, st_small>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p,
+                M->accept_min.p, P.k, P.w, smA, bbl, M->l2.p, counters.p, d_gS0.p, d_gSn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)codes, masks, slot_flags_p, n_slots, cand_hint_p);
+            MM_KERNEL_CHECK();
+          }
+        } else {
         if (nA) {
-          const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 4, 2);
-          set_lds((const void*)l2_kernel<true, uint8_t, 4, 2>, lds);
-          l2_kernel<true, uint8_t, 4, 2><<<dim3((unsigned)nA), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes, masks, slot_flags_p, n_slots);
-          MM_KERNEL_CHECK();
-        }
-        if (nS) {
-          const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 2, 2);
-          set_lds((const void*)l2_kernel<true, uint8_t, 2, 2>, lds);
-          l2_kernel<true, uint8_t, 2, 2><<<dim3((unsigned)nS), dim3(128), lds, st_small>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gS0.p, d_gSn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes, masks, slot_flags_p, n_slots);
-          MM_KERNEL_CHECK();
+            const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 4, 2);
+            set_lds((const void*)l2_kernel<true, uint8_t, 4, 2>, lds);
+            l2_kernel<true, uint8_t, 4, 2><<<dim3((unsigned)nA), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+                M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gA0.p, d_gAn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes, masks, slot_flags_p, n_slots);
+            MM_KERNEL_CHECK();
+          }
+          if (nS) {
+            const size_t lds = l2_lds_bytes<uint8_t>(smA, true, 2, 2);
+            set_lds((const void*)l2_kernel<true, uint8_t, 2, 2>, lds);
+            l2_kernel<true, uint8_t, 2, 2><<<dim3((unsigned)nS), dim3(128), lds, st_small>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+                M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smA, M->l2.p, counters.p, d_gS0.p, d_gSn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes, masks, slot_flags_p, n_slots);
+            MM_KERNEL_CHECK();
+          }
         }
         if (side_by_side) {
           MM_HIP(hipEventRecord(ctx->ev_join, st_small));
@@ -2156,21 +2195,39 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       if (!gB0.empty()) {
         d_gB0.upload(gB0.data(), gB0.size(), st); d_gBn.upload(gBn.data(), gBn.size(), st);
         sort_by_position(d_gB0, d_gBn, gB0.size());
-        const size_t lds = l2_lds_bytes<uint8_t>(smB, true, 4, 8);
-        set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
-        l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gB0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smB, M->l2.p, counters.p, d_gB0.p, d_gBn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gB0.size() * 4, 8), masks_for(gB0.size() * 4), slot_flags_p, (int)slots_of(gB0.size() * 4));
-        MM_KERNEL_CHECK();
+        if (v2_long) {
+          const int bbl = l2z_bloom_log2(smB);
+          const size_t lds = l2z_lds_bytes(smB, 8, false, bbl, 4);
+          set_lds((const void*)l2z_kernel<4, 8, false>, lds);
+          l2z_kernel<4, 8, false><<<dim3((unsigned)gB0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p,
+              M->accept_min.p, P.k, P.w, smB, bbl, M->l2.p, counters.p, d_gB0.p, d_gBn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)lists_for(gB0.size() * 4, 8), zmasks_for(gB0.size() * 4, 8), slot_flags_p, (int)slots_of(gB0.size() * 4), cand_hint_p);
+          MM_KERNEL_CHECK();
+        } else {
+          const size_t lds = l2_lds_bytes<uint8_t>(smB, true, 4, 8);
+          set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
+          l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gB0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smB, M->l2.p, counters.p, d_gB0.p, d_gBn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gB0.size() * 4, 8), masks_for(gB0.size() * 4), slot_flags_p, (int)slots_of(gB0.size() * 4));
+          MM_KERNEL_CHECK();
+        }
       }
       DBuf<int32_t> d_gD0(gD0.size()), d_gDn(gDn.size());
       if (!gD0.empty()) {
         d_gD0.upload(gD0.data(), gD0.size(), st); d_gDn.upload(gDn.data(), gDn.size(), st);
         sort_by_position(d_gD0, d_gDn, gD0.size());
-        const size_t lds = l2_lds_bytes<uint8_t>(smD, true, 4, 8);
-        set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
-        l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gD0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
-            M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gD0.size() * 4, 8), masks_for(gD0.size() * 4), slot_flags_p, (int)slots_of(gD0.size() * 4));
-        MM_KERNEL_CHECK();
+        if (v2_long) {
+          const int bbl = l2z_bloom_log2(smD);
+          const size_t lds = l2z_lds_bytes(smD, 8, false, bbl, 4);
+          set_lds((const void*)l2z_kernel<4, 8, false>, lds);
+          l2z_kernel<4, 8, false><<<dim3((unsigned)gD0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p,
+              M->accept_min.p, P.k, P.w, smD, bbl, M->l2.p, counters.p, d_gD0.p, d_gDn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)lists_for(gD0.size() * 4, 8), zmasks_for(gD0.size() * 4, 8), slot_flags_p, (int)slots_of(gD0.size() * 4), cand_hint_p);
+          MM_KERNEL_CHECK();
+        } else {
+          const size_t lds = l2_lds_bytes<uint8_t>(smD, true, 4, 8);
+          set_lds((const void*)l2_kernel<true, uint8_t, 4, 8>, lds);
+          l2_kernel<true, uint8_t, 4, 8><<<dim3((unsigned)gD0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smD, M->l2.p, counters.p, d_gD0.p, d_gDn.p, nullptr, ovf.p, ovf_n.p, amb_used_p, codes_for(gD0.size() * 4, 8), masks_for(gD0.size() * 4), slot_flags_p, (int)slots_of(gD0.size() * 4));
+          MM_KERNEL_CHECK();
+        }
       }
       if (!listC.empty()) {
         d_listC.upload(listC.data(), listC.size(), st);
@@ -2197,6 +2254,21 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         ovf_n.zero(st);
         n_fallback += h_ovf;
       };
+      int64_t n_big = 0;
+      if (v2) {                                                    // what the zone kernels handed back for its size: one wave per candidate, masks for 32 768 entries (beyond: every window)
+        unsigned int h_big = 0;
+        MM_HIP(hipMemcpyAsync(&h_big, big_n.p, sizeof h_big, hipMemcpyDeviceToHost, st));
+        MM_HIP(mm::stream_sync(st));
+        if (h_big) {
+          const int smW = std::max(std::max(smA, smB), smD);
+          const size_t lds = l2_lds_bytes<uint16_t>(smW, true, 1, 8);
+          set_lds((const void*)l2_kernel<true, uint16_t, 1, 8>, lds);
+          l2_kernel<true, uint16_t, 1, 8><<<dim3(h_big), dim3(64), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p,
+              M->mz.off.p, M->sk_n.p, M->d_read_len.p, M->accept_min.p, P.k, P.w, smW, M->l2.p, counters.p, nullptr, nullptr, big.p, ovf.p, ovf_n.p, amb_used_p, nullptr, masks_for(h_big), slot_flags_p, (int)slots_of(h_big));
+          MM_KERNEL_CHECK();
+          n_big = h_big;
+        }
+      }
       run_fallback(amb_used_p);
       int64_t n_redo = 0;
       if (!lazy_reads.empty()) {                                 // votes that read an unresolved strand: resolve those reads, redo their candidates
@@ -2227,7 +2299,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           n_redo += (int64_t)redo.size();
         }
       }
-      M->stats.n_l2_wide_redo = n_redo + n_fallback;
+      M->stats.n_l2_wide_redo = n_redo + n_fallback + n_big;
     }
     l2_stats_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(ncand, 256), 1024)), dim3(256), 0, st>>>(M->l2.p, ncand, counters.p);
     MM_KERNEL_CHECK();
@@ -2237,7 +2309,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     M->stats.sum_l2_stream_entries = (int64_t)hc[0];
     M->stats.sum_l2_evals = (int64_t)hc[1];
     M->stats.n_l2_rebuilds = (int64_t)hc[2];
-    if (getenv("MM_L2_PHASES")) { fprintf(stderr, "l2 rounds %llu; ", hc[15]); fprintf(stderr, "l2 phase clocks [setup passA bounds rebuild slide passB vote]:"); for (int i = 0; i < 7; ++i) fprintf(stderr, " %.3g", (double)hc[3 + i]); fprintf(stderr, "\n"); }
+    if (getenv("MM_L2_PHASES")) { fprintf(stderr, "l2 rounds %llu zone passes %llu; ", hc[15], hc[12]); fprintf(stderr, "l2 phase clocks [setup passA bounds rebuild slide passB vote]:"); for (int i = 0; i < 7; ++i) fprintf(stderr, " %.3g", (double)hc[3 + i]); fprintf(stderr, "\n"); }
     // ---- compaction
     if (amb_finish) { amb_finish(); amb_finish = nullptr; }
     const size_t t_cp = T.begin(&M->stats.ms_compact);

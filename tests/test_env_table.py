@@ -32,3 +32,21 @@ def test_integration_md_carries_the_table():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for line in env_table.markdown().splitlines():
         assert line in doc, line
+
+
+def test_switches_of_the_python_and_shell_side_are_known_or_exempt():
+    """Everything bench.py, the tests and tools/ set or read (os.environ / getenv / VAR=... on a command line) is either in the table or
+    carries one of the prefixes env_unknown() exempts — so MM_STRICT_ENV=1 can be combined with a fuzz campaign or an A/B run."""
+    src = open(os.path.join(ROOT, "metamaps_amd", "csrc", "mm_env.hpp")).read()
+    exempt = re.findall(r'"(MM_[A-Z_]+)"', src[src.index("static const char* const outside[]"):src.index("bool ours = false;")])
+    assert "MM_LIB_PATH" in exempt and "MM_FUZZ_" in exempt
+    table = {r[0] for r in env_table.rows()}
+    seen = set()
+    for pat in ("*.py", "tests/*.py", "tools/*.py", "tools/*.sh", "metamaps_amd/*.py"):
+        for f in glob.glob(os.path.join(ROOT, pat)):
+            seen |= set(re.findall(r'\b(MM_[A-Z][A-Z0-9_]+)\b', open(f).read()))
+    seen = {n for n in seen if not n.startswith(("MM_ERR_", "MM_OK", "MM_HIP", "MM_REQUIRE", "MM_KERNEL", "MM_HD"))}   # constants of the C ABI quoted in Python, macros
+    unknown = {n for n in seen if n not in table and not any(n.startswith(e) for e in exempt)}
+    # names that only occur as deliberately misspelt / historical examples in tests and docs
+    unknown -= {"MM_L2_FUL", "MM_L2_FUSE"}
+    assert unknown == set(), sorted(unknown)

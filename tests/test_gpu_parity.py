@@ -1024,3 +1024,38 @@ def test_l2_scratch_slots_hand_over(ctx, monkeypatch):
     for key, got in res.items():
         assert np.array_equal(base[0], got[0]) and np.array_equal(base[1], got[1]), key
     idx.close(); reads.close(); ref.close()
+
+
+def test_zone_kernel_equals_rank_code_kernel(ctx, monkeypatch):
+    """K5 runs as the zone kernel (mm_l2z.hpp: membership through a bit table + compaction, window states from threshold masks of a band of
+    128 ranks, the band predicted from L1's seed-hit count) by default; l2_kernel (a rank code per streamed entry, MM_L2_V1=1) is the same
+    algorithm in its first form.  Reads of 1-60 kb on a repeat-rich reference (duplicate hashes inside windows, DP/DN flags): the default, the zone
+    kernel without the predicted band (MM_L2_NO_FUSE: the band's masks from a second pass), the zone kernel for the long-read classes too
+    (MM_L2_V2_LONG), both with a lowered saturation of the duplicate distances (MM_DUP_SAT: the scan fall-back), and l2_kernel must give
+    identical records; the L2 tuples of every candidate are compared as well."""
+    res = {}
+    for sat in ("default", "40"):
+        if sat != "default": monkeypatch.setenv("MM_DUP_SAT", sat)
+        ref, _genome = ctx.synth_community(seed=23, n_genomes=40, n_species=10, n_genera=4, median_len=250_000.0, sigma_len=0.5, min_len=20_000, max_len=700_000,
+                                           strain_div_min=0.001, strain_div_max=0.05, genus_div_min=0.15, genus_div_max=0.25, strain_indel_events=6,
+                                           human_contigs=3, human_bases=6_000_000, repeat_fraction=0.45, n_fraction=0.01, n_repeat_families=12, total_bases_target=0)
+        reads, _ = ctx.synth_reads(ref, seed=41, n_reads=4000, read_len=60_000, read_len_min=1_000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=43)
+        idx = ctx.index(ref, 16, 8)
+        monkeypatch.delenv("MM_DUP_SAT", raising=False)
+        for mode, env in (("zone", {}), ("zone_two_pass", {"MM_L2_NO_FUSE": "1"}), ("zone_long", {"MM_L2_V2_LONG": "1"}), ("zone_long_two_pass", {"MM_L2_V2_LONG": "1", "MM_L2_NO_FUSE": "1"}),
+                          ("rank_codes", {"MM_L2_V1": "1"})):
+            for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
+            M = ctx.map_batch(idx, reads, 16, 8)
+            off, rec = M.fetch()
+            st = M.stats()
+            res[(sat, mode)] = (off.copy(), rec.copy(), M.debug_l2(st["n_candidates"]), st)
+            M.close()
+            for k_ in env: monkeypatch.delenv(k_)
+        base = res[(sat, "rank_codes")]
+        assert base[3]["n_candidates"] > 10_000 and base[3]["n_mappings"] > 5_000
+        for mode in ("zone", "zone_two_pass", "zone_long", "zone_long_two_pass"):
+            got = res[(sat, mode)]
+            assert np.array_equal(base[0], got[0]) and np.array_equal(base[1], got[1]), (sat, mode)
+            acc = base[2][:, 5] == 1
+            assert np.array_equal(base[2][acc], got[2][acc]), (sat, mode)
+        idx.close(); reads.close(); ref.close()

@@ -45,7 +45,10 @@
 
 namespace mm {
 
-constexpr int L2Z_QCAP = 128;                                   // ring of compacted (hash, entry) pairs waiting for the search; a word adds at most 64, 64 are taken at a time
+#ifndef L2Z_RING
+#define L2Z_RING 128
+#endif
+constexpr int L2Z_QCAP = L2Z_RING;                                   // ring of compacted (hash, entry) pairs waiting for the search (4 + 2 bytes each): eight words are added at a time, 64 taken
 #ifndef L2Z_WAVES_10K
 #define L2Z_WAVES_10K 6                                         // waves per SIMD the 10 kb class is compiled for
 #endif
@@ -75,8 +78,8 @@ constexpr int L2Z_BAND = 128;                                  // ranks of a ban
 // per-wave LDS: the first entry's position of every word (pass A writes, the e_min searches read) | a region used by pass A as
 // {ring of (hash, entry) pairs, matched bits of the current group of 64 words} and afterwards as {band gap counters / prefixes, the band's
 // hashes, band presence bits, slide scratch}
-constexpr int L2Z_X_BYTES = 1536 + 64;                            // (+ eight phase clocks at its end)
-static_assert(L2Z_QCAP * 8 + 64 * 8 + 64 <= L2Z_X_BYTES && L2Z_BAND * 4 * 2 + 16 + L2_SCRATCH_BYTES + 64 <= L2Z_X_BYTES, "per-wave LDS region");
+constexpr int L2Z_XA_BYTES = L2Z_QCAP * 6 + 64 * 8, L2Z_XB_BYTES = L2Z_BAND * 4 * 2 + 16 + L2_SCRATCH_BYTES;
+constexpr int L2Z_X_BYTES = (L2Z_XA_BYTES > L2Z_XB_BYTES ? L2Z_XA_BYTES : L2Z_XB_BYTES) + 64;   // (+ eight phase clocks at its end)
 __host__ __device__ inline size_t l2z_wave_bytes(int nwq) { return ((((size_t)(64 * nwq + 1) * 4) + 15) & ~(size_t)15) + L2Z_X_BYTES; }
 __host__ __device__ inline size_t l2z_shared_bytes(int smax, int nwq, bool qlds, int bbl) {
   return ((size_t)1 << (bbl - 3)) + l2_tpart_bytes(nwq) + (qlds ? l2_qpart_bytes(smax) : 0);
@@ -92,6 +95,19 @@ __device__ inline int rank_search_u(uint32_t arr, uint32_t v) {
 }
 __device__ inline uint64_t readlane_u64(uint64_t v, int l) {
   return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+}
+// lane l of three register pairs := three wave-uniform 64-bit values, M0 set up once
+__device__ inline void park64x3(uint64_t& r0, uint64_t v0, uint64_t& r1, uint64_t v1, uint64_t& r2, uint64_t v2, int l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t a0 = (uint32_t)r0, a1 = (uint32_t)(r0 >> 32), b0 = (uint32_t)r1, b1 = (uint32_t)(r1 >> 32), c0 = (uint32_t)r2, c1 = (uint32_t)(r2 >> 32);
+  const int ls = __builtin_amdgcn_readfirstlane(l);
+  uint32_t keep;
+  asm("s_mov_b32 %6, m0\n\ts_mov_b32 m0, %13\n\tv_writelane_b32 %0, %7, m0\n\tv_writelane_b32 %1, %8, m0\n\tv_writelane_b32 %2, %9, m0\n\tv_writelane_b32 %3, %10, m0\n\t"
+      "v_writelane_b32 %4, %11, m0\n\tv_writelane_b32 %5, %12, m0\n\ts_mov_b32 m0, %6"
+      : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "=&s"(keep)
+      : "s"((uint32_t)v0), "s"((uint32_t)(v0 >> 32)), "s"((uint32_t)v1), "s"((uint32_t)(v1 >> 32)), "s"((uint32_t)v2), "s"((uint32_t)(v2 >> 32)), "s"(ls));
+  r0 = (uint64_t)a0 | ((uint64_t)a1 << 32); r1 = (uint64_t)b0 | ((uint64_t)b1 << 32); r2 = (uint64_t)c0 | ((uint64_t)c1 << 32);
+#endif
 }
 // lane l of the register pair `reg` := val (a wave-uniform 64-bit value): two v_writelane, no compare, no select
 __device__ inline uint64_t park64(uint64_t reg, uint64_t val, int l) {
@@ -144,21 +160,29 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
   auto qat = [&](int i) -> uint32_t { if constexpr (QLDS) return QL[i]; else return Qg[i]; };
 
   // ---- per workgroup: bit table, bucket table (l2_bucket, mm_l2_core.hpp), the sketch itself (QLDS) -------------------------------
+  if (((int)counters[11] & 0xff) == 10) { if (threadIdx.x < 64 * WAVES && (int)(threadIdx.x >> 6) < grp_n[blockIdx.x] && lane == 0) { L2Result z{}; out[c0 + (threadIdx.x >> 6)] = z; } return; }   // MM_L2_STOP=10: nothing at all (what the launches and the grouping cost)
   for (int i = threadIdx.x; i <= (int)bm; i += 64 * WAVES) BL[i] = 0;
   if (threadIdx.x == 0) *tmaxp = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < s; i += 64 * WAVES) {
-    const uint32_t h = Qg[i];
-    if constexpr (QLDS) QL[i] = h;
-    atomicOr(&BL[(h >> 5) & bm], (1u << (h & 31)) | (1u << ((h >> 20) & 31)));   // two bits of one word: one LDS read per test, ~2 % false positives at 15 bits per hash
+  // T[b] = first rank whose bucket is >= b (every entry written exactly once, as in l2_kernel).  A thread takes a run of consecutive ranks, so that
+  // the bucket of a hash is computed once (the float arithmetic of l2_bucket is most of this set-up) and its predecessor's is at hand.
+  {
+    const int per = (s + 64 * WAVES) / (64 * WAVES);             // ranks 0 .. s: s + 1 table steps
+    const int i0 = (int)threadIdx.x * per, i1 = min(i0 + per, s + 1);
+    int bprev = (i0 > 0 && i0 <= s) ? l2_bucket(Qg[i0 - 1], tshift) : -1;
+    for (int i = i0; i < i1; ++i) {
+      int hi = 1 << TBITS;
+      if (i < s) {
+        const uint32_t h = Qg[i];
+        if constexpr (QLDS) QL[i] = h;
+        atomicOr(&BL[(h >> 5) & bm], (1u << (h & 31)) | (1u << ((h >> 20) & 31)));   // two bits of one word: one LDS read per test, ~2 % false positives at 15 bits per hash
+        hi = l2_bucket(h, tshift);
+      }
+      for (int bb = bprev + 1; bb <= hi; ++bb) T[bb] = (uint16_t)i;
+      bprev = hi;
+    }
   }
   if constexpr (QLDS) { if (threadIdx.x < L2_QPAD) QL[s + threadIdx.x] = 0xffffffffu; }
-  // T[b] = first rank whose bucket is >= b (every entry written exactly once, as in l2_kernel)
-  for (int i = threadIdx.x; i <= s; i += 64 * WAVES) {
-    const int lo = i ? l2_bucket(Qg[i - 1], tshift) + 1 : 0;
-    const int hi = i < s ? l2_bucket(Qg[i], tshift) : (1 << TBITS);
-    for (int bb = lo; bb <= hi; ++bb) T[bb] = (uint16_t)i;
-  }
   __syncthreads();
   {
     int tm = 0;
@@ -254,8 +278,9 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
   uint16_t* const pA = pLo + NW1;
   int* const W0 = (int*)wbase;                                   // wpos of the first entry of every word
   uint8_t* const xb_ = wbase + (l2z_wave_bytes(NWQ) - L2Z_X_BYTES);
-  uint2* const RQ = (uint2*)xb_;                                 // pass A
-  uint64_t* const mL = (uint64_t*)(xb_ + L2Z_QCAP * 8);          // pass A: matched bits of the current group of 64 words
+  uint32_t* const RQh = (uint32_t*)xb_;                          // pass A: the ring's hashes ...
+  uint16_t* const RQj = (uint16_t*)(xb_ + L2Z_QCAP * 4);         // ... and entry numbers
+  uint64_t* const mL = (uint64_t*)(xb_ + L2Z_QCAP * 6);          // pass A: matched bits of the current group of 64 words
   uint32_t* const zc = (uint32_t*)xb_;                           // afterwards: gap counters of the band, then their inclusive prefixes
   uint32_t* const BQ = zc + L2Z_BAND;                            // Q[zb .. zb + 128), 0xffffffff from rank s on
   uint32_t* const pmw = BQ + L2Z_BAND;                           // matched ranks of the band present in the window (128 bits)
@@ -298,10 +323,10 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     r_ref = max(zb, min(centre + L2Z_REF_ABOVE, min(zb + L2Z_BAND, s) - 1));
   };
   auto band_thresholds = [&]() {
-    tau_bh = qat(min(zb + L2Z_BAND, s) - 1);
+    tau_bh = (uint32_t)__builtin_amdgcn_readfirstlane((int)qat(min(zb + L2Z_BAND, s) - 1));   // (wave-uniform: compared from scalar registers)
     has_bl = zb > 0;
-    tau_bl = has_bl ? qat(zb - 1) : 0u;
-    tau_ref = qat(r_ref);
+    tau_bl = has_bl ? (uint32_t)__builtin_amdgcn_readfirstlane((int)qat(zb - 1)) : 0u;
+    tau_ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)qat(r_ref));
   };
   bool fused = false;
   int r_pred = 0;
@@ -327,17 +352,58 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     wave_sync();
     auto dense = [&](int n) {
       wave_sync();
-      const uint2 e = RQ[(head + lane) & (L2Z_QCAP - 1)];
-      const int code = classify(e.x);
+      const int slot_ = (head + lane) & (L2Z_QCAP - 1);
+      const uint32_t eh = RQh[slot_];
+      const uint32_t ej = RQj[slot_];
+      const int code = classify(eh);
       const bool hit = lane < n && code >= 0;
       const uint64_t hm = __ballot(hit);
       if (hit) {
-        ML[mbcnt64(hm, n_ml)] = e.y | ((uint32_t)code << 15);
-        const uint32_t jg = e.y & 4095u;
+        ML[mbcnt64(hm, n_ml)] = ej | ((uint32_t)code << 15);
+        const uint32_t jg = ej & 4095u;
         atomicOr(&((uint32_t*)mL)[jg >> 5], 1u << (jg & 31));
       }
       n_ml += __popcll(hm);
       head += n;
+    };
+    // The eight words of a step without control flow between them: eight table reads in flight, eight ballots, the parks of the fused masks; the ring
+    // takes what passed afterwards.  LAST: the step that holds the end of the stream (entries behind it are masked out there and nowhere else).
+    auto step = [&](const Rec (&x)[8], int wd0, auto last_tag) __attribute__((always_inline)) {
+      constexpr bool LAST = decltype(last_tag)::value;
+      uint32_t bw[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bw[i] = BL[(x[i].hash >> 5) & bm];
+      bool ps[8]; uint64_t pmk[8];
+      int total = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t h = x[i].hash;
+        ps[i] = ((bw[i] >> (h & 31)) & (bw[i] >> ((h >> 20) & 31)) & 1u) != 0u;
+        if (LAST) ps[i] = ps[i] && (wd0 + i) * 64 + lane < M;
+        pmk[i] = __ballot(ps[i]);
+        total += __popcll(pmk[i]);
+      }
+      if (fused) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int wd = wd0 + i;
+          if (LAST && wd >= nwords) continue;                    // (wave-uniform)
+          const uint32_t h = x[i].hash;
+          uint64_t le_bh = __ballot(h <= tau_bh);
+          if (LAST) le_bh &= valid_mask(wd * 64);
+          park64x3(rBH, le_bh, rRef, __ballot(h <= tau_ref), rBL, has_bl ? __ballot(h <= tau_bl) : 0ull, wd & 63);
+          const uint64_t nf = __ballot((x[i].pw & PW_DP) != 0u);
+          if (nf) rNF = park64(rNF, nf, wd & 63);
+        }
+      }
+      const bool room = tail - head + total <= L2Z_QCAP;         // (otherwise — more than a third of the entries passed the table — the ring is emptied after every word)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (ps[i]) { const int sl = (mbcnt64(pmk[i]) + tail) & (L2Z_QCAP - 1); RQh[sl] = x[i].hash; RQj[sl] = (uint16_t)((wd0 + i) * 64 + lane); }
+        tail += __popcll(pmk[i]);
+        if (!room) while (tail - head >= 64) dense(64);
+      }
+      while (tail - head >= 64) dense(64);
     };
     Rec nx[8];
     load8(nx, 0);
@@ -345,30 +411,8 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
       Rec x[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) x[i] = nx[i];
-      if (wd0 + 8 < nwords) load8(nx, (wd0 + 8) * 64);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int wd = wd0 + i;
-        if (wd >= nwords) continue;                              // (wave-uniform)
-        const uint32_t h = x[i].hash;
-        const uint32_t bw = BL[(h >> 5) & bm];
-        uint64_t pm_ = __ballot(((bw >> (h & 31)) & (bw >> ((h >> 20) & 31)) & 1u) != 0u);
-        if (wd0 + 8 >= nwords) pm_ &= valid_mask(wd * 64);
-        if (pm_) {
-          if ((pm_ >> lane) & 1ull) RQ[mbcnt64(pm_, tail) & (L2Z_QCAP - 1)] = make_uint2(h, (uint32_t)(wd * 64 + lane));
-          tail += __popcll(pm_);
-          if (tail - head >= 64) dense(64);
-        }
-        if (fused) {
-          uint64_t le_bh = __ballot(h <= tau_bh);
-          if (wd0 + 8 >= nwords) le_bh &= valid_mask(wd * 64);
-          rBH = park64(rBH, le_bh, wd & 63);
-          rRef = park64(rRef, __ballot(h <= tau_ref), wd & 63);
-          if (has_bl) rBL = park64(rBL, __ballot(h <= tau_bl), wd & 63);
-          const uint64_t nf = __ballot((x[i].pw & PW_DP) != 0u);
-          if (nf) rNF = park64(rNF, nf, wd & 63);
-        }
-      }
+      if (wd0 + 8 < nwords) { load8(nx, (wd0 + 8) * 64); step(x, wd0, std::false_type{}); }
+      else step(x, wd0, std::true_type{});
       if (((wd0 + 8) & 63) == 0 || wd0 + 8 >= nwords) {          // end of a group of 64 words: its matched bits are complete once the ring is empty
         while (tail > head) dense(min(64, tail - head));
         wave_sync();
@@ -427,11 +471,22 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     }
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) { lo[qq] = 64 * max(lo[qq] - 1, 0); hi[qq] = min(lo[qq] + 64, last_end); }
-    for (int it = 0; it < 7; ++it) {                             // the entry inside that word
-      const int m0 = min((lo[0] + hi[0]) >> 1, nmax), m1 = min((lo[1] + hi[1]) >> 1, nmax);
-      const int p0 = pw_wpos(pos[m0].pw), p1 = pw_wpos(pos[m1].pw);
-      if (lo[0] < hi[0]) { if (p0 < tg[0]) lo[0] = m0 + 1; else hi[0] = m0; }
-      if (lo[1] < hi[1]) { if (p1 < tg[1]) lo[1] = m1 + 1; else hi[1] = m1; }
+    // the entry inside that word (64 entries): two rounds of eight probes each, all sixteen loads of a round in flight, instead of seven dependent ones
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+      const int step = rnd == 0 ? 8 : 1;
+      int pv[2][8];
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) pv[qq][t] = pw_wpos(pos[min(lo[qq] + (t + 1) * step - 1, nmax)].pw);
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        int adv = 0;                                             // probes t with a position below the target (they come first: positions ascend)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) adv += (lo[qq] + (t + 1) * step - 1 < hi[qq] && pv[qq][t] < tg[qq]) ? 1 : 0;
+        lo[qq] = min(lo[qq] + adv * step, hi[qq]);
+      }
     }
     eLo[0] = lane < nblk ? lo[0] : last_end;
     eLo[1] = lane + 64 < nblk ? lo[1] : last_end;
@@ -494,9 +549,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
         if (wd0 + 8 >= nwords) le_bh &= valid_mask(wd * 64);
         const uint64_t le_ref = __ballot(x[i].hash <= tau_ref);
         const uint64_t nf = __ballot((x[i].pw & PW_DP) != 0u);
-        rBH = park64(rBH, le_bh, wd & 63);
-        rRef = park64(rRef, le_ref, wd & 63);
-        if (has_bl) rBL = park64(rBL, __ballot(x[i].hash <= tau_bl), wd & 63);
+        park64x3(rBH, le_bh, rRef, le_ref, rBL, has_bl ? __ballot(x[i].hash <= tau_bl) : 0ull, wd & 63);
         if (nf) rNF = park64(rNF, nf, wd & 63);
       }
       if (((wd0 + 8) & 63) == 0 || wd0 + 8 >= nwords) {
@@ -808,6 +861,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
 
   // ---- bands: the first one around the expected pivot of the most promising block, then those above and below it that windows asked for ----
   int zb_first = 0, r_est = 0;
+  if (dbg_stop == 9) { release_slot(); return; }
   bool any_pass = ubmax >= amin;                                 // otherwise no window can reach the acceptance threshold
   bool masks_ready = false;                                      // the band's masks came out of pass A
   int elig[2] = {1, 1};
@@ -833,8 +887,10 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     if (++n_pass > (s >> 6) + 4) break;                            // (cannot happen: every pass moves the band by 128 ranks in one direction)
     if (!masks_ready) { pass_low(); ++n_low; }
     masks_ready = false;
+    if (dbg_stop == 6) { release_slot(); return; }
     fill_band_hashes();
     lap(5);
+    if (dbg_stop == 7) { release_slot(); return; }
     for (int q = 0; q < 2; ++q) {
       const int bq = lane + 64 * q;
       int u = -1;
@@ -909,26 +965,35 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     accepted = 1;
     int votes = 0, amb_votes = 0;
     const int i0 = pfx(mAll, pAll, opt_b), i1 = pfx(mAll, pAll, opt_e);
-    for (int ib = i0; ib < i1; ib += 64) {
-      const int i = ib + lane;
-      const bool a = i < i1;
-      const uint32_t ew = a ? ML[i] : 0u;
-      const int j = (int)(ew & 0x7fffu), rk = (int)((ew >> 15) & 0x7fffu);
-      const bool cnt_it = a && rk < bestR;
-      const uint32_t sq = cnt_it ? (uint32_t)sk_strand[qo + rk] : 0u;   // bit 0 strand, bit 1 unresolved duplicate (mm_map.hip, K2)
-      const uint32_t pwj = cnt_it ? pos[j].pw : 0u;
-      const bool unres = (sq & 2u) && amb_used != nullptr;
-      const int contrib = cnt_it ? (((sq & 1u) ? 1 : -1) * pw_strand(pwj)) : 0;
-      const bool flagged = cnt_it && (pwj & PW_DN);                 // a later occurrence exists in the contig: inside the window?  (strandR is the LAST occurrence's, :155-156)
-      const int dres = flagged ? dup_after(I, first0 + j, (int64_t)opt_e - 1 - j) : 0;
-      if (cnt_it && dres == 0) { if (unres) ++amb_votes; else votes += contrib; }
-      uint64_t fm = __ballot(dres < 0);
-      while (fm) {
-        const int l = __builtin_ctzll(fm); fm &= fm - 1;
-        const int jj = __builtin_amdgcn_readlane(j, l);
-        const uint32_t hj = pos[jj].hash;
-        const bool later = wave_has_hash(pos, jj + 1, opt_e, hj, lane);
-        if (!later && lane == l) { if (unres) ++amb_votes; else votes += contrib; }
+    for (int ib = i0; ib < i1; ib += 256) {                      // four batches of 64 matched entries per step: their three dependent loads each in flight together
+      uint32_t ew[4], sq[4], pwj[4]; bool cnt_it[4]; int jv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = ib + 64 * u + lane; ew[u] = i < i1 ? ML[i] : 0xffffffffu; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rk = (int)((ew[u] >> 15) & 0x7fffu);
+        jv[u] = (int)(ew[u] & 0x7fffu);
+        cnt_it[u] = ew[u] != 0xffffffffu && rk < bestR;
+        sq[u] = cnt_it[u] ? (uint32_t)sk_strand[qo + rk] : 0u;   // bit 0 strand, bit 1 unresolved duplicate (mm_map.hip, K2)
+        pwj[u] = cnt_it[u] ? pos[jv[u]].pw : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (ib + 64 * u >= i1) continue;                         // (wave-uniform)
+        const bool unres = (sq[u] & 2u) && amb_used != nullptr;
+        const int contrib = cnt_it[u] ? (((sq[u] & 1u) ? 1 : -1) * pw_strand(pwj[u])) : 0;
+        const bool flagged = cnt_it[u] && (pwj[u] & PW_DN);      // a later occurrence exists in the contig: inside the window?  (strandR is the LAST occurrence's, :155-156)
+        int dres = 0;
+        if (__ballot(flagged) != 0ull) dres = flagged ? dup_after(I, first0 + jv[u], (int64_t)opt_e - 1 - jv[u]) : 0;
+        if (cnt_it[u] && dres == 0) { if (unres) ++amb_votes; else votes += contrib; }
+        uint64_t fm = __ballot(dres < 0);
+        while (fm) {
+          const int l = __builtin_ctzll(fm); fm &= fm - 1;
+          const int jj = __builtin_amdgcn_readlane(jv[u], l);
+          const uint32_t hj = pos[jj].hash;
+          const bool later = wave_has_hash(pos, jj + 1, opt_e, hj, lane);
+          if (!later && lane == l) { if (unres) ++amb_votes; else votes += contrib; }
+        }
       }
     }
     votes = wave_sum(votes);

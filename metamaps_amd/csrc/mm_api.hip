@@ -83,6 +83,7 @@ int mm_ctx_create(int device_id, mm_ctx** out) {
                std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
     c->cus = p.multiProcessorCount;
     MM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    mm::stream_event_register(c->stream);
     tr.lap("hipStreamCreateWithFlags");
     if (tr.on) { void* q = nullptr; if (hipMalloc(&q, 1 << 20) == hipSuccess) { tr.lap("first hipMalloc (1 MiB)"); (void)hipFree(q); } }
     c->alloc.stream = c->stream;
@@ -105,8 +106,8 @@ void mm_ctx_destroy(mm_ctx* ctx) {
   if (ctx->l2_masks) mm::dev_free(ctx->l2_masks, ctx->l2_masks_bytes);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-  if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->aux_stream) { mm::stream_event_unregister(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
+  if (ctx->stream) { mm::stream_event_unregister(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
   delete ctx;
 }
 const char* mm_last_error(const mm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }

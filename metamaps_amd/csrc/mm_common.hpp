@@ -49,19 +49,46 @@ inline bool sync_blocking() {
   static const bool b = [] { const char* e = getenv("MM_SYNC"); if (e && *e) return strcmp(e, "block") == 0; return cpu_budget() <= 32; }();
   return b;
 }
+// The event a wait sleeps on belongs to the stream: a context registers one with its stream when it is created (mm_ctx_create, aux_ready) and takes
+// it back when it goes (mm_ctx_destroy) — no event per host thread (the CLI's worker, pool and on_each threads are created per run and never destroyed
+// theirs), no hipGetDevice per wait, and a thread whose current device is another one (the allocator trimming a foreign context's cache) sleeps too
+// instead of falling back to the spin.  Streams nobody registered (none in the product) keep the thread-local event.
+struct StreamEvents {
+  std::mutex mu;
+  std::map<hipStream_t, hipEvent_t> ev;
+  static StreamEvents& get() { static StreamEvents* s = new StreamEvents; return *s; }   // (never destroyed: contexts may outlive static destruction)
+};
+inline void stream_event_register(hipStream_t st) {                // (the stream's device is current)
+  if (!sync_blocking()) return;
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+  StreamEvents& S = StreamEvents::get();
+  std::lock_guard<std::mutex> g(S.mu);
+  S.ev[st] = e;
+}
+inline void stream_event_unregister(hipStream_t st) {
+  StreamEvents& S = StreamEvents::get();
+  hipEvent_t e = nullptr;
+  { std::lock_guard<std::mutex> g(S.mu); auto it = S.ev.find(st); if (it != S.ev.end()) { e = it->second; S.ev.erase(it); } }
+  if (e) (void)hipEventDestroy(e);
+}
 inline hipError_t stream_sync(hipStream_t st) {
   if (!sync_blocking()) return hipStreamSynchronize(st);
-  static thread_local hipEvent_t ev = nullptr; static thread_local int ev_dev = -1;
-  int dev = 0; (void)hipGetDevice(&dev);
-  if (!ev || ev_dev != dev) {
-    if (ev) (void)hipEventDestroy(ev);
-    ev = nullptr;
-    const hipError_t c = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
-    if (c != hipSuccess) { ev = nullptr; (void)hipGetLastError(); return hipStreamSynchronize(st); }
-    ev_dev = dev;
+  hipEvent_t ev = nullptr;
+  { StreamEvents& S = StreamEvents::get(); std::lock_guard<std::mutex> g(S.mu); auto it = S.ev.find(st); if (it != S.ev.end()) ev = it->second; }
+  if (!ev) {                                                     // a stream without a registered event: one event per thread and device, as before
+    static thread_local hipEvent_t tev = nullptr; static thread_local int ev_dev = -1;
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (!tev || ev_dev != dev) {
+      if (tev) (void)hipEventDestroy(tev);
+      tev = nullptr;
+      const hipError_t c = hipEventCreateWithFlags(&tev, hipEventBlockingSync | hipEventDisableTiming);
+      if (c != hipSuccess) { tev = nullptr; (void)hipGetLastError(); return hipStreamSynchronize(st); }
+      ev_dev = dev;
+    }
+    ev = tev;
   }
-  // (an event belongs to the device that was current when it was made: a thread that trims the cache of a context on ANOTHER device — the allocator's
-  //  out-of-memory path — records into a foreign stream; that, like any other failure here, falls back to the plain wait)
+  // (two threads never wait for the same context at once: a context is driven by one host thread at a time, include/metamaps_hip.h)
   if (hipEventRecord(ev, st) != hipSuccess) { (void)hipGetLastError(); return hipStreamSynchronize(st); }
   const hipError_t w = hipEventSynchronize(ev);
   if (w != hipSuccess) { (void)hipGetLastError(); return hipStreamSynchronize(st); }
@@ -535,6 +562,7 @@ struct mm_ctx {
   void aux_ready() {
     if (aux_stream) return;
     MM_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+    mm::stream_event_register(aux_stream);
     MM_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     MM_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
   }

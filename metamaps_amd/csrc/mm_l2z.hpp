@@ -48,7 +48,8 @@ namespace mm {
 #ifndef L2Z_RING
 #define L2Z_RING 128
 #endif
-constexpr int L2Z_QCAP = L2Z_RING;                                   // ring of compacted (hash, entry) pairs waiting for the search (4 + 2 bytes each): eight words are added at a time, 64 taken
+__host__ __device__ constexpr int l2z_qcap(int nwq) { return nwq == 2 ? L2Z_RING : 2 * L2Z_RING; }   // (long-read classes: two searches per lane at a time, see dense2)
+constexpr int L2Z_QCAP_ = L2Z_RING;                                   // ring of compacted (hash, entry) pairs waiting for the search (4 + 2 bytes each): eight words are added at a time, 64 taken
 #ifndef L2Z_WAVES_10K
 #define L2Z_WAVES_10K 6                                         // waves per SIMD the 10 kb class is compiled for
 #endif
@@ -61,26 +62,32 @@ __host__ __device__ inline size_t l2z_mask_bytes(int nwq) { return (((size_t)(64
 __host__ __device__ inline size_t l2z_list_bytes(int nwq) { return (size_t)(64 * 64 * nwq) * 4; }
 // bits of the membership table: at least 8 per sketch hash, at least 2^15
 __host__ __device__ inline int l2z_bloom_log2(int smax) { int b = 15; while (((size_t)1 << b) < (size_t)8 * (size_t)smax && b < 19) ++b; return b; }
-constexpr int L2Z_BAND = 128;                                  // ranks of a band (two per lane)
+// ranks of a band: 128 for the 10 kb class (+-3.4 standard deviations of the best window's pivot around its expectation there), 512 for the long-read
+// classes (the deviation grows with the square root of the sketch: ~47 ranks at 13 000 hashes)
+__host__ __device__ constexpr int l2z_band(int nwq) { return nwq == 2 ? 128 : 512; }
 // Where the pivot of the best window lies against the two estimates of it, measured on the bench batch (tools/l2z_pivot_hist.py): against the one from
 // pass A's matched counts -11 +- 19 ranks, against the one predicted from L1's seed hits +7 +- 19.  The band is centred there; the reference rank of
 // the prefix masks and the bound sits ~2.3 sigma above the centre (lower: tighter bound but more blocks whose bound is not valid; 10 / 20 / 32 above
 // the first estimate measured 381 / 281 / 236 million windows scored per bench step).
-#ifndef L2Z_CENTRE_OFF
-#define L2Z_CENTRE_OFF (-11)
+// In units of the hypergeometric deviation sigma = sqrt(s p (1 - p)^2), p = s / (s + window-only hashes) (15.7 ranks for the bench's 10 kb reads): centre at
+// the estimate - 0.7 sigma (from the matched counts) / + 0.43 sigma (predicted), reference rank 3.5 sigma above the centre (2.0 / 2.75 / 3.5: 215 / 149 / 122 million windows scored on 20 000 reads of 20-50 kb, 276 / 234 / 236 on the 10 kb bench batch).
+#ifndef L2Z_CENTRE_SIG
+#define L2Z_CENTRE_SIG (-0.70f)
 #endif
-#ifndef L2Z_CENTRE_OFF_PRED
-#define L2Z_CENTRE_OFF_PRED 7
+#ifndef L2Z_CENTRE_SIG_PRED
+#define L2Z_CENTRE_SIG_PRED 0.43f
 #endif
-#ifndef L2Z_REF_ABOVE
-#define L2Z_REF_ABOVE 43                                        // reference rank: centre + this
+#ifndef L2Z_REF_SIG
+#define L2Z_REF_SIG 3.5f
 #endif
 // per-wave LDS: the first entry's position of every word (pass A writes, the e_min searches read) | a region used by pass A as
 // {ring of (hash, entry) pairs, matched bits of the current group of 64 words} and afterwards as {band gap counters / prefixes, the band's
 // hashes, band presence bits, slide scratch}
-constexpr int L2Z_XA_BYTES = L2Z_QCAP * 6 + 64 * 8, L2Z_XB_BYTES = L2Z_BAND * 4 * 2 + 16 + L2_SCRATCH_BYTES;
-constexpr int L2Z_X_BYTES = (L2Z_XA_BYTES > L2Z_XB_BYTES ? L2Z_XA_BYTES : L2Z_XB_BYTES) + 64;   // (+ eight phase clocks at its end)
-__host__ __device__ inline size_t l2z_wave_bytes(int nwq) { return ((((size_t)(64 * nwq + 1) * 4) + 15) & ~(size_t)15) + L2Z_X_BYTES; }
+__host__ __device__ constexpr int l2z_x_bytes(int nwq) {
+  const int xa = l2z_qcap(nwq) * 6 + 64 * 8, xb = l2z_band(nwq) * 4 * 2 + l2z_band(nwq) / 8 + L2_SCRATCH_BYTES;
+  return (xa > xb ? xa : xb) + 64;                               // (+ eight phase clocks at its end)
+}
+__host__ __device__ inline size_t l2z_wave_bytes(int nwq) { return ((((size_t)(64 * nwq + 1) * 4) + 15) & ~(size_t)15) + (size_t)l2z_x_bytes(nwq); }
 __host__ __device__ inline size_t l2z_shared_bytes(int smax, int nwq, bool qlds, int bbl) {
   return ((size_t)1 << (bbl - 3)) + l2_tpart_bytes(nwq) + (qlds ? l2_qpart_bytes(smax) : 0);
 }
@@ -143,6 +150,8 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
            const int32_t* __restrict__ cand_hint /* seed hits inside each candidate (l1_wave_kernel; 0: none): what the best window's matched count will be */) {
   extern __shared__ __align__(16) uint32_t lds[];
   constexpr int NW = 64 * NWQ, CAP = 64 * NW, NW1 = NW + 1;
+  constexpr int QCAP = l2z_qcap(NWQ);
+  constexpr int BAND = l2z_band(NWQ), BPL = BAND / 64;            // ranks of a band, ranks per lane
   constexpr int TBITS = l2_tbits(NWQ), tshift = 32 - TBITS;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint32_t* const BL = lds;                                      // membership bits of the sketch, keyed by the low hash bits (MurmurHash3's finaliser: uniform)
@@ -277,14 +286,14 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
   uint16_t* const pLo = pAll + NW1;
   uint16_t* const pA = pLo + NW1;
   int* const W0 = (int*)wbase;                                   // wpos of the first entry of every word
-  uint8_t* const xb_ = wbase + (l2z_wave_bytes(NWQ) - L2Z_X_BYTES);
+  uint8_t* const xb_ = wbase + (l2z_wave_bytes(NWQ) - l2z_x_bytes(NWQ));
   uint32_t* const RQh = (uint32_t*)xb_;                          // pass A: the ring's hashes ...
-  uint16_t* const RQj = (uint16_t*)(xb_ + L2Z_QCAP * 4);         // ... and entry numbers
-  uint64_t* const mL = (uint64_t*)(xb_ + L2Z_QCAP * 6);          // pass A: matched bits of the current group of 64 words
+  uint16_t* const RQj = (uint16_t*)(xb_ + QCAP * 4);         // ... and entry numbers
+  uint64_t* const mL = (uint64_t*)(xb_ + QCAP * 6);          // pass A: matched bits of the current group of 64 words
   uint32_t* const zc = (uint32_t*)xb_;                           // afterwards: gap counters of the band, then their inclusive prefixes
-  uint32_t* const BQ = zc + L2Z_BAND;                            // Q[zb .. zb + 128), 0xffffffff from rank s on
-  uint32_t* const pmw = BQ + L2Z_BAND;                           // matched ranks of the band present in the window (128 bits)
-  int* const tst = (int*)(pmw + 4);
+  uint32_t* const BQ = zc + BAND;                            // Q[zb .. zb + 128), 0xffffffff from rank s on
+  uint32_t* const pmw = BQ + BAND;                           // matched ranks of the band present in the window (128 bits)
+  int* const tst = (int*)(pmw + BAND / 32);
   uint8_t* const fdel = (uint8_t*)(tst + 64);
   uint8_t* const fadd = fdel + 64;
 
@@ -317,13 +326,18 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
   int zb = 0, r_ref = 0;                                         // band start; reference rank of the prefix masks (inside the band)
   uint32_t tau_ref = 0, tau_bl = 0, tau_bh = 0;                  // Q[r_ref]; Q[zb - 1]; Q[min(zb + 128, s) - 1]
   bool has_bl = false;
-  const int zb_top = max(0, s - L2Z_BAND + 1);                    // highest band start: its last rank is the "R = s" sentinel
-  auto set_band = [&](int centre) {                              // first band around where the pivot is expected
-    zb = max(0, min(centre - L2Z_BAND / 2, zb_top));
-    r_ref = max(zb, min(centre + L2Z_REF_ABOVE, min(zb + L2Z_BAND, s) - 1));
+  const int zb_top = max(0, s - BAND + 1);                    // highest band start: its last rank is the "R = s" sentinel
+  auto set_band = [&](float wo_, float centre_sig) -> int {      // first band around where the pivot is expected for windows with wo_ window-only hashes; returns that estimate
+    const float pq = (float)s / ((float)s + wo_);
+    const float sigma = sqrtf((float)s * pq * (1.0f - pq) * (1.0f - pq));
+    const int est = (int)((float)s * pq);
+    const int centre = est + (int)(centre_sig * sigma);
+    zb = max(0, min(centre - BAND / 2, zb_top));
+    r_ref = max(zb, min(centre + max(8, (int)(L2Z_REF_SIG * sigma)), min(zb + BAND, s) - 1));
+    return est;
   };
   auto band_thresholds = [&]() {
-    tau_bh = (uint32_t)__builtin_amdgcn_readfirstlane((int)qat(min(zb + L2Z_BAND, s) - 1));   // (wave-uniform: compared from scalar registers)
+    tau_bh = (uint32_t)__builtin_amdgcn_readfirstlane((int)qat(min(zb + BAND, s) - 1));   // (wave-uniform: compared from scalar registers)
     has_bl = zb > 0;
     tau_bl = has_bl ? (uint32_t)__builtin_amdgcn_readfirstlane((int)qat(zb - 1)) : 0u;
     tau_ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)qat(r_ref));
@@ -336,8 +350,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
       const int span = max(pw_wpos(pos[M - 1].pw) - pw_wpos(pos[0].pw), 1);
       const float we = (float)M * (float)cnt / (float)span;
       const float wo_p = fmaxf(we - (float)hc, 0.0f);
-      r_pred = (int)((float)s * ((float)s / ((float)s + wo_p)));
-      set_band(r_pred + L2Z_CENTRE_OFF_PRED);
+      r_pred = set_band(wo_p, L2Z_CENTRE_SIG_PRED);
       band_thresholds();
       fused = true;
     }
@@ -352,7 +365,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     wave_sync();
     auto dense = [&](int n) {
       wave_sync();
-      const int slot_ = (head + lane) & (L2Z_QCAP - 1);
+      const int slot_ = (head + lane) & (QCAP - 1);
       const uint32_t eh = RQh[slot_];
       const uint32_t ej = RQj[slot_];
       const int code = classify(eh);
@@ -365,6 +378,34 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
       }
       n_ml += __popcll(hm);
       head += n;
+    };
+    // Long-read classes (the sketch is searched in global memory, five or six dependent loads of ~1 us): two ring entries per lane, their searches
+    // interleaved, so that a step of 128 entries waits as long as one of 64
+    auto dense2 = [&](int n) {
+      wave_sync();
+      const int s0 = (head + lane) & (QCAP - 1), s1 = (head + 64 + lane) & (QCAP - 1);
+      const uint32_t h0 = RQh[s0], h1 = RQh[s1];
+      const uint32_t j0_ = RQj[s0], j1_ = RQj[s1];
+      const int k0 = l2_bucket(h0, tshift), k1 = l2_bucket(h1, tshift);
+      int lo0 = T[k0], hi0 = T[k0 + 1], lo1 = T[k1], hi1 = T[k1 + 1];
+      for (int it = 0; it < tsteps; ++it) {
+        const int m0 = min((lo0 + hi0) >> 1, s - 1), m1 = min((lo1 + hi1) >> 1, s - 1);
+        const uint32_t v0 = Qg[m0], v1 = Qg[m1];
+        if (lo0 < hi0) { if (v0 < h0) lo0 = m0 + 1; else hi0 = m0; }
+        if (lo1 < hi1) { if (v1 < h1) lo1 = m1 + 1; else hi1 = m1; }
+      }
+      const uint32_t e0 = Qg[min(lo0, s - 1)], e1 = Qg[min(lo1, s - 1)];
+      const bool hit0 = lane < n && lo0 < s && e0 == h0, hit1 = 64 + lane < n && lo1 < s && e1 == h1;
+      const uint64_t hm0 = __ballot(hit0), hm1 = __ballot(hit1);
+      if (hit0) { ML[mbcnt64(hm0, n_ml)] = j0_ | ((uint32_t)lo0 << 15); const uint32_t jg = j0_ & 4095u; atomicOr(&((uint32_t*)mL)[jg >> 5], 1u << (jg & 31)); }
+      n_ml += __popcll(hm0);
+      if (hit1) { ML[mbcnt64(hm1, n_ml)] = j1_ | ((uint32_t)lo1 << 15); const uint32_t jg = j1_ & 4095u; atomicOr(&((uint32_t*)mL)[jg >> 5], 1u << (jg & 31)); }
+      n_ml += __popcll(hm1);
+      head += n;
+    };
+    auto drain = [&](bool all) {                                 // the ring down to less than a step's worth (all: empty)
+      if constexpr (QLDS) { while (tail - head >= 64) dense(64); if (all && tail > head) dense(tail - head); }
+      else { while (tail - head >= 128) dense2(128); if (all && tail > head) dense2(tail - head); }
     };
     // The eight words of a step without control flow between them: eight table reads in flight, eight ballots, the parks of the fused masks; the ring
     // takes what passed afterwards.  LAST: the step that holds the end of the stream (entries behind it are masked out there and nowhere else).
@@ -396,14 +437,14 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
           if (nf) rNF = park64(rNF, nf, wd & 63);
         }
       }
-      const bool room = tail - head + total <= L2Z_QCAP;         // (otherwise — more than a third of the entries passed the table — the ring is emptied after every word)
+      const bool room = tail - head + total <= QCAP;         // (otherwise — more than a third of the entries passed the table — the ring is emptied after every word)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        if (ps[i]) { const int sl = (mbcnt64(pmk[i]) + tail) & (L2Z_QCAP - 1); RQh[sl] = x[i].hash; RQj[sl] = (uint16_t)((wd0 + i) * 64 + lane); }
+        if (ps[i]) { const int sl = (mbcnt64(pmk[i]) + tail) & (QCAP - 1); RQh[sl] = x[i].hash; RQj[sl] = (uint16_t)((wd0 + i) * 64 + lane); }
         tail += __popcll(pmk[i]);
-        if (!room) while (tail - head >= 64) dense(64);
+        if (!room) drain(false);
       }
-      while (tail - head >= 64) dense(64);
+      drain(false);
     };
     Rec nx[8];
     load8(nx, 0);
@@ -414,7 +455,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
       if (wd0 + 8 < nwords) { load8(nx, (wd0 + 8) * 64); step(x, wd0, std::false_type{}); }
       else step(x, wd0, std::true_type{});
       if (((wd0 + 8) & 63) == 0 || wd0 + 8 >= nwords) {          // end of a group of 64 words: its matched bits are complete once the ring is empty
-        while (tail > head) dense(min(64, tail - head));
+        drain(true);
         wave_sync();
         const uint64_t reg = mL[lane];
         const int g0 = wd0 & ~63;
@@ -520,14 +561,6 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
   int fUp[2] = {0, 0}, fDn[2] = {0, 0};                          // blocks with a window whose pivot lies above / below the current band
   int zdir = 0, n_pass = 0, n_low = 0;                                      // 0: first pass, +1: bands above it, -1: bands below it
   auto flag_block = [&](int (&f)[2], int kk) { if (lane == (kk & 63)) { if (kk < 64) f[0] = 1; else f[1] = 1; } };
-  auto popc_below = [](uint64_t m0, uint64_t m1, int n) -> int {  // set bits with index < n of a 128-bit set (0 <= n <= 128)
-    if (n <= 0) return 0;
-    if (n < 64) return __popcll(m0 & ((1ull << n) - 1ull));
-    if (n == 64) return __popcll(m0);
-    if (n < 128) return __popcll(m0) + __popcll(m1 & ((1ull << (n - 64)) - 1ull));
-    return __popcll(m0) + __popcll(m1);
-  };
-
   // pass B: the masks of the band [zb, zb + 128) and its reference rank
   auto pass_low = [&]() {
     band_thresholds();
@@ -571,8 +604,8 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     close_prefix(mA, pA, carryA);
   };
   auto fill_band_hashes = [&]() {                                // the band's hashes for the rank searches of the rebuilds
-    BQ[lane] = zb + lane < s ? qat(zb + lane) : 0xffffffffu;
-    BQ[lane + 64] = zb + lane + 64 < s ? qat(zb + lane + 64) : 0xffffffffu;
+#pragma unroll
+    for (int t = 0; t < BPL; ++t) BQ[lane + 64 * t] = zb + lane + 64 * t < s ? qat(zb + lane + 64 * t) : 0xffffffffu;
     wave_sync();
   };
 
@@ -584,8 +617,9 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     ++rebuilds;
     const int cb_ref = pfx(mA, pA, ne) - pfx(mA, pA, nb);
     const int sb_ref = pfx(mLo, pLo, ne) - pfx(mLo, pLo, nb);
-    zc[lane] = 0; zc[lane + 64] = 0;
-    if (lane < 4) pmw[lane] = 0;
+#pragma unroll
+    for (int t = 0; t < BPL; ++t) zc[lane + 64 * t] = 0;
+    if (lane < BAND / 32) pmw[lane] = 0;
     wave_sync();
     int acc2 = 0;                                                // window-only at or below Q[r_ref] whose earlier occurrence lies outside the window | matched ones whose earlier occurrence lies inside << 16
     const int w_lo = nb >> 6, w_hi = (ne - 1) >> 6;
@@ -622,7 +656,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
 #pragma unroll
         for (int u = 0; u < 4; ++u) bi[u] = 0;                   // rank inside the band: number of the band's hashes below h (a matched hash finds itself)
 #pragma unroll
-        for (int st = 64; st >= 1; st >>= 1) {
+        for (int st = BAND / 2; st >= 1; st >>= 1) {
           uint32_t v[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) v[u] = BQ[bi[u] + st - 1];
@@ -656,33 +690,54 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
       }
     }
     wave_sync();
-    // inclusive prefixes of the band's gap counters (two per lane), written back in place
-    const int v0 = (int)zc[2 * lane], v1 = (int)zc[2 * lane + 1];
-    const int pre = wave_incl_scan(v0 + v1);
-    const int in0 = pre - v1, in1 = pre;
+    // inclusive prefixes of the band's gap counters (BPL consecutive ones per lane), written back in place
+    int inc[BPL];
+    {
+      int run = 0;
+#pragma unroll
+      for (int t = 0; t < BPL; ++t) { run += (int)zc[BPL * lane + t]; inc[t] = run; }
+      const int before = wave_incl_scan(run) - run;
+#pragma unroll
+      for (int t = 0; t < BPL; ++t) inc[t] += before;
+    }
     const int acc2T = __builtin_amdgcn_readlane(wave_incl_scan(acc2), 63);
     wave_sync();
-    zc[2 * lane] = (uint32_t)in0; zc[2 * lane + 1] = (uint32_t)in1;
+#pragma unroll
+    for (int t = 0; t < BPL; ++t) zc[BPL * lane + t] = (uint32_t)inc[t];
     wave_sync();
-    const uint64_t bm0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pmw[0]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pmw[1]) << 32);
-    const uint64_t bm1 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pmw[2]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pmw[3]) << 32);
+    auto band_bits = [&](int wq) -> uint64_t {                   // 64 presence bits of the band from bit 64 wq on (wave-uniform)
+      return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pmw[2 * wq]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pmw[2 * wq + 1]) << 32);
+    };
+    auto popc_below = [&](int n) -> int {                        // matched band ranks present with band index < n
+      int c_ = 0;
+#pragma unroll
+      for (int wq = 0; wq < BPL; ++wq) {
+        const int k_ = n - 64 * wq;
+        if (k_ > 0) { const uint64_t m_ = band_bits(wq); c_ += __popcll(k_ >= 64 ? m_ : (m_ & ((1ull << k_) - 1ull))); }
+      }
+      return c_;
+    };
     const int kref = r_ref - zb;
     const int cb_lo = cb_ref + (acc2T & 0xffff) - __builtin_amdgcn_readfirstlane((int)zc[kref]);          // C(zb - 1): distinct window-only hashes below the band
-    const int sb_lo = sb_ref - (acc2T >> 16) - popc_below(bm0, bm1, kref + 1);                             // distinct matched hashes below the band
+    const int sb_lo = sb_ref - (acc2T >> 16) - popc_below(kref + 1);                                       // distinct matched hashes below the band
     // pivot: first band index i with (zb + i) + C(zb + i) >= s; ranks from s on are the "R = s" sentinel
-    const int i_a = 2 * lane, i_b = 2 * lane + 1;
-    const uint64_t sa = __ballot(zb + i_a >= s || zb + i_a + cb_lo + in0 >= s), sbm = __ballot(zb + i_b >= s || zb + i_b + cb_lo + in1 >= s);
-    int Rb = L2Z_BAND;
-    if (sa | sbm) Rb = min(sa ? 2 * __builtin_ctzll(sa) : L2Z_BAND, sbm ? 2 * __builtin_ctzll(sbm) + 1 : L2Z_BAND);
+    int mine_first = BAND;
+#pragma unroll
+    for (int t = BPL - 1; t >= 0; --t) { const int i_ = BPL * lane + t; if (zb + i_ >= s || zb + i_ + cb_lo + inc[t] >= s) mine_first = i_; }
+    const int Rb = wave_min(mine_first);
     const bool below = has_bl && zb - 1 + cb_lo >= s;
-    const int zrel = below ? 0 : (Rb >= L2Z_BAND ? L2Z_BAND - 64 : max(0, min(Rb - 32, L2Z_BAND - 64)));
+    const int zrel = below ? 0 : (Rb >= BAND ? BAND - 64 : max(0, min(Rb - 32, BAND - 64)));
     z0 = zb + zrel;
     const int czl = zrel > 0 ? __builtin_amdgcn_readfirstlane((int)zc[zrel - 1]) : 0;
     cbase = cb_lo + czl;
     const int rz = z0 + lane;
     fz = rz < s ? rz + (int)zc[zrel + lane] - czl : (1 << 29);
-    sb = sb_lo + popc_below(bm0, bm1, zrel);
-    pm = zrel == 0 ? bm0 : (zrel == 64 ? bm1 : ((bm0 >> zrel) | (bm1 << (64 - zrel))));
+    sb = sb_lo + popc_below(zrel);
+    {
+      const int wq = zrel >> 6, sh = zrel & 63;
+      const uint64_t m0_ = band_bits(wq), m1_ = (sh && wq + 1 < BPL) ? band_bits(wq + 1) : 0ull;
+      pm = sh ? ((m0_ >> sh) | (m1_ << (64 - sh))) : m0_;
+    }
     Qz = BQ[zrel + lane];
     has_lo = z0 > 0;
     tau_lo = zrel > 0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)BQ[zrel - 1]) : tau_bl;
@@ -805,7 +860,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
       const bool outU = inw && pj >= 64;
       const bool outD = inw && has_lo && thr <= z0 - 1;           // (z0 - 1) + C(z0 - 1) >= s: the pivot lies below z0
       const uint64_t um = __ballot(outU), dm = __ballot(outD);
-      const bool canU = z0 + 64 < zb + L2Z_BAND, canD = z0 > zb;
+      const bool canU = z0 + 64 < zb + BAND, canD = z0 > zb;
       const uint64_t cut = (canU ? um : 0ull) | (canD ? dm : 0ull);
       const int n_vis = cut ? __builtin_ctzll(cut) : n_eval;     // windows 0 .. n_vis-1 are visited in this round
       const uint64_t vis = n_vis >= 64 ? ~0ull : ((1ull << n_vis) - 1ull);
@@ -871,20 +926,18 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     const int bkb = wave_min(key);
     const int bLb = min(bkb * bspan + bspan - 1, last_end - 1);
     const int wo = max(lane2(eLo, bkb) - bLb - ubmax, 0);
-    const float pq = (float)s / (float)(s + wo);
-    r_est = (int)((float)s * pq);
-    const int zb_p = zb;
+    const int zb_p = zb, r_ref_p = r_ref;
+    r_est = set_band((float)wo, L2Z_CENTRE_SIG);                  // (what the matched counts ask for)
     if (fused) {
       // the predicted band stands if the centre this estimate asks for lies within its middle half (or both are clamped to the same edge)
-      const int want = r_est + L2Z_CENTRE_OFF;
-      const int zb_w = max(0, min(want - L2Z_BAND / 2, zb_top));
-      masks_ready = zb_w == zb_p || (want >= zb_p + L2Z_BAND / 4 && want < zb_p + 3 * L2Z_BAND / 4);
+      const int want = zb + BAND / 2;
+      masks_ready = zb == zb_p || (want >= zb_p + BAND / 4 && want < zb_p + 3 * BAND / 4);
+      if (masks_ready) { zb = zb_p; r_ref = r_ref_p; }
     }
-    if (!masks_ready) set_band(r_est + L2Z_CENTRE_OFF);
     zb_first = zb;
   }
   while (any_pass) {
-    if (++n_pass > (s >> 6) + 4) break;                            // (cannot happen: every pass moves the band by 128 ranks in one direction)
+    if (++n_pass > (s >> 6) + 4) break;                            // (cannot happen: every pass moves the band by its width in one direction)
     if (!masks_ready) { pass_low(); ++n_low; }
     masks_ready = false;
     if (dbg_stop == 6) { release_slot(); return; }
@@ -942,15 +995,15 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     // the next band: upwards while windows asked for it, then downwards from the first one
     const bool wantU = __ballot(fUp[0] | fUp[1]) != 0ull, wantD = __ballot(fDn[0] | fDn[1]) != 0ull;
     if (zdir >= 0 && wantU && zb < zb_top) {
-      zdir = 1; zb = min(zb + L2Z_BAND, zb_top);
-      r_ref = min(zb + L2Z_BAND, s) - 1;
+      zdir = 1; zb = min(zb + BAND, zb_top);
+      r_ref = min(zb + BAND, s) - 1;
       elig[0] = fUp[0]; elig[1] = fUp[1]; fUp[0] = fUp[1] = 0;
       continue;
     }
     if (zdir >= 0) { zdir = -1; zb = zb_first; }
     if (wantD && zb > 0) {
-      zb = max(0, zb - L2Z_BAND);
-      r_ref = min(zb + L2Z_BAND, s) - 1;
+      zb = max(0, zb - BAND);
+      r_ref = min(zb + BAND, s) - 1;
       elig[0] = fDn[0]; elig[1] = fDn[1]; fDn[0] = fDn[1] = 0;
       continue;
     }

@@ -2070,7 +2070,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       };
       // the zone kernels (mm_l2z.hpp, the default; MM_L2_V1=1: l2_kernel for every class): matched list + masks per slot
       const bool v2 = !getenv("MM_L2_V1");
-      const bool v2_long = v2 && getenv("MM_L2_V2_LONG");            // the long-read classes (sketches of 3 073 .. 13 000 hashes) through the zone kernel as well: measured slower on configs[3] so far
+      const bool v2_long = v2 && !getenv("MM_L2_V1_LONG");           // (MM_L2_V1_LONG=1: the long-read classes, sketches of 3 073 .. 13 000 hashes, through l2_kernel)
       const int32_t* const cand_hint_p = cand_hint.p;
       auto lists_for = [&](size_t n_waves, int nwq) -> void* { return ctx->l2_codes_at_least(slots_of(n_waves, nwq) * l2z_list_bytes(nwq)); };
       auto zmasks_for = [&](size_t n_waves, int nwq) -> uint8_t* { return (uint8_t*)ctx->l2_masks_at_least(slots_of(n_waves, nwq) * l2z_mask_bytes(nwq)); };
@@ -2143,11 +2143,13 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
       // Both take their scratch slots from ONE pool with ONE split by XCD (a slot's traffic stays in one L2, mm_l2.hpp), sized for the larger launch.
       // MM_L2_ONE_STREAM=1: one behind the other as until round 5 (cross-check and A/B).
       {
-        const size_t n_waves = std::max(nA * 4, nS * 2);
+        // side by side both launches draw on the pool at the same time: it holds a slot for every wave of both (as far as they can be resident — slots_of
+        // caps it) so that small batches do not queue for each other's slots; one behind the other the larger launch sizes it
+        const bool side_by_side = nA && nS && !no_slots && !getenv("MM_L2_ONE_STREAM");   // (without slots the scratch is indexed by wave number of the launch: one launch at a time)
+        const size_t n_waves = side_by_side ? nA * 4 + nS * 2 : std::max(nA * 4, nS * 2);
         void* const codes = !(nA || nS) ? nullptr : v2 ? lists_for(n_waves, 2) : codes_for(n_waves, 2);
         uint8_t* const masks = !(nA || nS) ? nullptr : v2 ? zmasks_for(n_waves, 2) : masks_for(n_waves, 2);
         const int n_slots = (int)slots_of(n_waves, 2);
-        const bool side_by_side = nA && nS && !no_slots && !getenv("MM_L2_ONE_STREAM");   // (without slots the scratch is indexed by wave number of the launch: one launch at a time)
         hipStream_t st_small = st;
         if (side_by_side) {
           ctx->aux_ready();

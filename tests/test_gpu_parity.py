@@ -178,6 +178,24 @@ def test_l2_launches_side_by_side_give_the_same_records(ctx, mini, monkeypatch):
         for k_ in env:
             monkeypatch.delenv(k_)
     assert np.array_equal(out["side_by_side"][0], out["one_stream"][0]) and out["side_by_side"][1] == out["one_stream"][1] and out["one_stream"][2] > 100
+    # tiny batches (a handful of waves per launch, far below the slot pool's cap): the pool is sized for the waves of BOTH launches, and with a
+    # pool of eight slots (MM_L2_SLOTS, one per XCD) every wave of both launches queues for a slot — the records are the big batch's, read by read
+    full = ctx.map_batch(idx, R, 16, 8); full.add_qualities(16)
+    off_f, rec_f = full.fetch(); off_f, rec_f = off_f.copy(), rec_f.copy(); full.close()
+    for env in ({}, {"MM_L2_SLOTS": "8"}):
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        for first in (0, 7, 19):
+            sub = ctx.seqset(reads[first:first + 3])
+            Ms = ctx.map_batch(idx, sub, 16, 8); Ms.add_qualities(16)
+            o, r = Ms.fetch()
+            for i in range(3):
+                want = rec_f[off_f[first + i]:off_f[first + i + 1]].copy(); got = r[o[i]:o[i + 1]].copy()
+                want["read"] = 0; got["read"] = 0                   # (the read number is the batch's)
+                assert want.tobytes() == got.tobytes(), (env, first, i)
+            Ms.close(); sub.close()
+        for k_ in env:
+            monkeypatch.delenv(k_)
     idx.close(); R.close(); S.close()
 
 
@@ -1030,8 +1048,8 @@ def test_zone_kernel_equals_rank_code_kernel(ctx, monkeypatch):
     """K5 runs as the zone kernel (mm_l2z.hpp: membership through a bit table + compaction, window states from threshold masks of a band of
     128 ranks, the band predicted from L1's seed-hit count) by default; l2_kernel (a rank code per streamed entry, MM_L2_V1=1) is the same
     algorithm in its first form.  Reads of 1-60 kb on a repeat-rich reference (duplicate hashes inside windows, DP/DN flags): the default, the zone
-    kernel without the predicted band (MM_L2_NO_FUSE: the band's masks from a second pass), the zone kernel for the long-read classes too
-    (MM_L2_V2_LONG), both with a lowered saturation of the duplicate distances (MM_DUP_SAT: the scan fall-back), and l2_kernel must give
+    kernel without the predicted band (MM_L2_NO_FUSE: the band's masks from a second pass), the zone kernel for the 10 kb class only
+    (MM_L2_V1_LONG), both with a lowered saturation of the duplicate distances (MM_DUP_SAT: the scan fall-back), and l2_kernel must give
     identical records; the L2 tuples of every candidate are compared as well."""
     res = {}
     for sat in ("default", "40"):
@@ -1042,7 +1060,7 @@ def test_zone_kernel_equals_rank_code_kernel(ctx, monkeypatch):
         reads, _ = ctx.synth_reads(ref, seed=41, n_reads=4000, read_len=60_000, read_len_min=1_000, sub_rate=0.04, ins_rate=0.03, del_rate=0.05, frac_random=0.05, n_abundant=43)
         idx = ctx.index(ref, 16, 8)
         monkeypatch.delenv("MM_DUP_SAT", raising=False)
-        for mode, env in (("zone", {}), ("zone_two_pass", {"MM_L2_NO_FUSE": "1"}), ("zone_long", {"MM_L2_V2_LONG": "1"}), ("zone_long_two_pass", {"MM_L2_V2_LONG": "1", "MM_L2_NO_FUSE": "1"}),
+        for mode, env in (("zone", {}), ("zone_two_pass", {"MM_L2_NO_FUSE": "1"}), ("zone_short", {"MM_L2_V1_LONG": "1"}), ("zone_short_two_pass", {"MM_L2_V1_LONG": "1", "MM_L2_NO_FUSE": "1"}),
                           ("rank_codes", {"MM_L2_V1": "1"})):
             for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
             M = ctx.map_batch(idx, reads, 16, 8)
@@ -1053,7 +1071,7 @@ def test_zone_kernel_equals_rank_code_kernel(ctx, monkeypatch):
             for k_ in env: monkeypatch.delenv(k_)
         base = res[(sat, "rank_codes")]
         assert base[3]["n_candidates"] > 10_000 and base[3]["n_mappings"] > 5_000
-        for mode in ("zone", "zone_two_pass", "zone_long", "zone_long_two_pass"):
+        for mode in ("zone", "zone_two_pass", "zone_short", "zone_short_two_pass"):
             got = res[(sat, mode)]
             assert np.array_equal(base[0], got[0]) and np.array_equal(base[1], got[1]), (sat, mode)
             acc = base[2][:, 5] == 1

@@ -61,6 +61,32 @@ inline void append_g6(std::string& out, double x) {
   out.append(buf, (size_t)n);
 }
 
+// strtod of a text append_g6 wrote (digits, optional fraction, optional e+-XX), without strtod: at most 15 significant digits and a decimal
+// exponent within +-22 make mantissa and power of ten exact doubles, whose product or quotient is then correctly rounded (Clinger's fast path) —
+// the same double strtod returns.  false: not of that shape (the caller takes strtod).
+inline bool parse_g6_text(const char* s, size_t n, double* out) {
+  size_t i = 0; bool neg = false;
+  if (i < n && s[i] == '-') { neg = true; ++i; }
+  unsigned long long m = 0; int nd = 0, frac = 0; bool any = false;
+  for (; i < n && s[i] >= '0' && s[i] <= '9'; ++i) { m = m * 10 + (unsigned)(s[i] - '0'); if (m) ++nd; any = true; }
+  if (i < n && s[i] == '.') { ++i; for (; i < n && s[i] >= '0' && s[i] <= '9'; ++i) { m = m * 10 + (unsigned)(s[i] - '0'); if (m) ++nd; ++frac; any = true; } }
+  if (!any || nd > 15) return false;
+  int e = 0;
+  if (i < n && (s[i] == 'e' || s[i] == 'E')) {
+    ++i; bool eneg = false;
+    if (i < n && (s[i] == '+' || s[i] == '-')) { eneg = s[i] == '-'; ++i; }
+    if (i >= n) return false;
+    for (; i < n && s[i] >= '0' && s[i] <= '9'; ++i) { e = e * 10 + (s[i] - '0'); if (e > 400) return false; }
+    if (eneg) e = -e;
+  }
+  if (i != n) return false;
+  const int e10 = e - frac;
+  if (e10 > 22 || e10 < -22) return false;
+  const double v = e10 >= 0 ? (double)m * ff_pow10(e10) : (double)m / ff_pow10(-e10);
+  *out = neg ? -v : v;
+  return true;
+}
+
 // appends snprintf("%f", x) (= std::to_string(x)); the fast path covers [0, 1], the range of a posterior
 inline void append_f6(std::string& out, double x) {
   if (x >= 0 && x <= 1 && !std::signbit(x)) {

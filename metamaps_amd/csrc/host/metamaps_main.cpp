@@ -202,15 +202,28 @@ std::vector<int> device_list(const Options& o, bool check = true) {   // --gpus 
 // batch, and a table that was theirs (thread_local) was rebuilt — 0.8 MB cleared, every pair formatted again — by every one of them for every batch:
 // 19 ms per batch of 85 000 lines, the whole of a worker's "finish" time.
 struct FormatCache {
-  struct Pair { uint64_t key; char ids[16], corr[16]; uint8_t n_ids, n_corr; };
+  struct Pair { uint64_t key; char ids[16], corr[16]; uint8_t n_ids, n_corr; double ident; };   // ident: the printed identity read back / 100 (what classify parses, fEM.h:264)
   static constexpr size_t CB = 1 << 14;
   std::vector<Pair> slots; int k = -1;
-  void prepare(int k_now) { if (slots.size() != CB || k != k_now) { slots.assign(CB, Pair{~0ull, {0}, {0}, 0, 0}); k = k_now; } }
+  void prepare(int k_now) { if (slots.size() != CB || k != k_now) { slots.assign(CB, Pair{~0ull, {0}, {0}, 0, 0, 0.0}); k = k_now; } }
 };
+// A mapping line as `classify` sees it once it has tokenised the file (fEM.h:234-275): where the line lies in the text, and the values of the fields it reads
+// — identity and mapping quality as the PRINTED text parses, not as the floats they were printed from.  `mapDirectly --then-classify` keeps these beside the
+// text it writes, so that classify in the same process neither reads the file back nor tokenises it.
+struct LineMeta { uint32_t beg, ls /* the blank before field 14, relative to beg */, n /* length without the newline */; int32_t contig /* index into the reference's contigs */, len, start; double ident, mapq; };
+static double mapq_as_classify_reads_it(const char* p, size_t n) {
+  double v;
+  if (parse_g6_text(p, n, &v)) return v;
+  const std::string t(p, n);
+  errno = 0; v = strtod(t.c_str(), nullptr);
+  if (errno == ERANGE) v = t.find("e-") != std::string::npos ? 0.0 : v;   // (std::stod throws on a denormal; the reference then takes 0, fEM.h:269-275 — an overflow cannot be printed by this program)
+  return v;
+}
 static void format_range(const std::vector<std::string>& names, const std::vector<int>& lens, const std::vector<int64_t>& off,
                          const std::vector<mm_map_record>& rec, const std::vector<std::string>& cname, const std::vector<int>& clen, int k, size_t r0, size_t r1, std::string& out,
-                         FormatCache& fc) {
+                         FormatCache& fc, std::vector<LineMeta>* meta) {
   out.clear();
+  if (meta) { meta->clear(); meta->reserve((size_t)(off[r1] - off[r0])); }
   out.reserve((size_t)(off[r1] - off[r0]) * 160);
   // no printf anywhere on the line (fast_format.hpp) — 4.2 M lines took 2 s of the mapping phase of a million reads
   using Pair = FormatCache::Pair;
@@ -228,11 +241,13 @@ static void format_range(const std::vector<std::string>& names, const std::vecto
         tmp.clear(); append_g6(tmp, (double)id);                   // operator<<(float): %g with 6 significant digits; printed, then re-parsed (mapWrap.h:237)
         P.n_ids = (uint8_t)tmp.size(); memcpy(P.ids, tmp.data(), tmp.size());
         const double reported = strtod(tmp.c_str(), nullptr) / 100.0;
+        P.ident = reported;
         const float corrected = std::exp(-(1 - reported));        // mapWrap.h:311
         tmp.clear(); append_g6(tmp, (double)(corrected * 100));
         P.n_corr = (uint8_t)tmp.size(); memcpy(P.corr, tmp.data(), tmp.size());
         P.key = key;
       }
+      const size_t line_beg = out.size();
       out += names[r];
       out += ' '; append_int(out, len); out += " 0 "; append_int(out, len - 1); out += ' '; out += x.strand == 1 ? '+' : '-'; out += ' ';
       out += cname[(size_t)x.ref_contig];
@@ -241,27 +256,31 @@ static void format_range(const std::vector<std::string>& names, const std::vecto
       out += ' '; out.append(P.ids, P.n_ids);
       out += ' '; append_int(out, x.shared); out += ' '; append_int(out, x.sketch);
       out += ' '; out.append(P.corr, P.n_corr);
+      const size_t ls = out.size();
       out += ' '; append_g6(out, x.mapq);                          // :318-320
+      if (meta) meta->push_back(LineMeta{(uint32_t)line_beg, (uint32_t)(ls - line_beg), (uint32_t)(out.size() - line_beg), (int32_t)x.ref_contig, (int32_t)len, (int32_t)x.ref_start,
+                                         P.ident, mapq_as_classify_reads_it(out.data() + ls + 1, out.size() - ls - 1)});
       out += '\n';
     }
   }
 }
 // the mapping lines of a batch (mapWrap.h:300-323): ranges of reads formatted by a few threads, joined in read order
 void format_records(const std::vector<std::string>& names, const std::vector<int>& lens, const std::vector<int64_t>& off,
-                    const std::vector<mm_map_record>& rec, const std::vector<std::string>& cname, const std::vector<int>& clen, int k, std::string& out) {
+                    const std::vector<mm_map_record>& rec, const std::vector<std::string>& cname, const std::vector<int>& clen, int k, std::string& out, std::vector<LineMeta>* meta) {
   const size_t n = names.size();
   const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, mm::cpu_budget() / 4), rec.size() / 10000 + 1}));   // (a quarter of the CPU budget per worker: four workers rarely format at the same moment)
   static thread_local std::vector<FormatCache> caches(8);          // (the calling thread's: a worker of mapDirectly formats batch after batch)
-  if (T == 1) { format_range(names, lens, off, rec, cname, clen, k, 0, n, out, caches[0]); return; }
+  if (T == 1) { format_range(names, lens, off, rec, cname, clen, k, 0, n, out, caches[0], meta); return; }
   std::vector<size_t> cut(T + 1, n);
   cut[0] = 0;
   { size_t t = 1; for (size_t r = 0; r < n && t < T; ++r) if ((uint64_t)off[r] >= (uint64_t)rec.size() * t / T) cut[t++] = r; }
   static thread_local std::vector<std::string> part_store(8);      // (kept with their capacity: fresh text buffers are page faults, batch after batch)
   std::vector<std::string>& part = part_store;
   FormatCache* const fcs = caches.data();
+  static thread_local std::vector<std::vector<LineMeta>> meta_store(8);
   const auto q0 = std::chrono::steady_clock::now();
   std::vector<double> took(T, 0.0);
-  auto timed = [&](size_t t) { const auto a = std::chrono::steady_clock::now(); format_range(names, lens, off, rec, cname, clen, k, cut[t], cut[t + 1], part[t], fcs[t]);
+  auto timed = [&](size_t t) { const auto a = std::chrono::steady_clock::now(); format_range(names, lens, off, rec, cname, clen, k, cut[t], cut[t + 1], part[t], fcs[t], meta ? &meta_store[t] : nullptr);
                                took[t] = std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
   static thread_local TaskPool helpers(7);                         // (task_pool.hpp: the calling worker's own helpers, there from batch to batch)
   const auto q1 = q0;
@@ -269,7 +288,11 @@ void format_records(const std::vector<std::string>& names, const std::vector<int
   const auto q2 = std::chrono::steady_clock::now();
   size_t total = 0; for (size_t t = 0; t < T; ++t) total += part[t].size();
   out.clear(); out.reserve(total);
-  for (size_t t = 0; t < T; ++t) out += part[t];
+  if (meta) { meta->clear(); meta->reserve(rec.size()); }
+  for (size_t t = 0; t < T; ++t) {
+    if (meta) for (LineMeta lm : meta_store[t]) { lm.beg += (uint32_t)out.size(); meta->push_back(lm); }
+    out += part[t];
+  }
   if (getenv("MM_CLI_FORMAT_TRACE")) {
     const auto q3 = std::chrono::steady_clock::now();
     double mx = 0; for (double x : took) mx = std::max(mx, x);
@@ -280,8 +303,12 @@ void format_records(const std::vector<std::string>& names, const std::vector<int
 
 // (defined behind map_mode; `mapDirectly --then-classify DBDIR` runs it in-process on the files it has just written)
 enum class EmReduce { None, Rccl, Host };
+struct KeptLines {                                               // the mapping lines of one output prefix as mapDirectly wrote them, batch after batch, with their parsed fields
+  struct Part { const char* text; const LineMeta* meta; size_t n_lines; const int64_t* off; size_t n_reads; };
+  std::vector<Part> parts; const std::vector<std::string>* cname = nullptr;
+};
 int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::string& mapped, const std::string& db, size_t minReadsU,
-                 const std::function<void()>& leave_now, const std::function<void()>& need_devices);
+                 const std::function<void()>& leave_now, const std::function<void()>& need_devices, const KeptLines* kept = nullptr);
 
 // One run of mapDirectly / index / mapAgainstIndex.  The state every stage shares lives in the object; the stages are its methods, in the order run()
 // calls them: parameters -> devices -> reference (parsed, packed, uploaded) or stored index -> chunk plan -> placement of the chunk indexes
@@ -314,7 +341,10 @@ struct MapRun {
   mm_map_params mp{};
   std::vector<int32_t> chunk_base;
   // what a worker hands to the writer: the finished text of one batch
-  struct Done { size_t file = 0; std::vector<std::string> names; std::vector<int> lens; std::vector<int64_t> off; std::string text; double t_mapq = 0, t_fetch = 0, t_format = 0; };
+  struct Done { size_t file = 0; std::vector<std::string> names; std::vector<int> lens; std::vector<int64_t> off; std::string text; std::vector<LineMeta> meta; double t_mapq = 0, t_fetch = 0, t_format = 0; };
+  // --then-classify: the batches of every query file as they were written, in order (text + the parsed fields of every line): what classify takes instead of the file
+  const bool keep_lines = o.v.count("then-classify") && !getenv("MM_CLI_CLASSIFY_FROM_FILE");
+  std::vector<std::vector<std::unique_ptr<Done>>> kept;
   // the writer: batches in input order -> PREFIX, .meta.unmappedReadsLengths, .meta, .parameters of every query file (mapWrap.h:34-213)
   struct Writer {
     std::mutex m; std::condition_variable cv; std::map<size_t, std::unique_ptr<Done>> ready;
@@ -914,7 +944,7 @@ struct MapRun {
     ck(ctx, mm_mapping_fetch(m, dn->off.data(), rec.data(), (int64_t)rec.size()), "fetch");
     mm_mapping_destroy(m);
     const auto f2 = std::chrono::steady_clock::now();
-    format_records(dn->names, dn->lens, dn->off, rec, cname, clen, k, dn->text);
+    format_records(dn->names, dn->lens, dn->off, rec, cname, clen, k, dn->text, keep_lines ? &dn->meta : nullptr);
     const auto f3 = std::chrono::steady_clock::now();
     pc.add("7a mapping qualities + offsets", std::chrono::duration<double>(f1 - f0).count());
     pc.add("7b fetch records", std::chrono::duration<double>(f2 - f1).count());
@@ -945,7 +975,9 @@ struct MapRun {
           ++mapped;
         }
         out << d->text;
+        if (keep_lines) { if (kept.size() <= fi) kept.resize(fi + 1); d->names.clear(); d->names.shrink_to_fit(); kept[fi].push_back(std::move(d)); }
       }
+      if (keep_lines && kept.size() <= fi) kept.resize(fi + 1);
       std::ofstream meta(prefix + ".meta");                      // mapWrap.h:178-184
       meta << "TotalReads " << total << "\nReadsTooShort " << tooShort << "\nReadsMapped " << mapped << "\nReadsNotMapped " << notMapped << "\n";
       std::ofstream ps(prefix + ".parameters");                  // mapWrap.h:196-211
@@ -1140,7 +1172,10 @@ struct MapRun {
     const std::function<void()> leave = [&] { pc.lap("9 classify"); pc.report(); };
     for (size_t fi = 0; fi < prefixes.size(); ++fi) {
       const bool last = fi + 1 == prefixes.size();
-      classify_one(devs, reduce, prefixes[fi], o.v.at("then-classify"), minReadsU, last ? leave : std::function<void()>(), nullptr);
+      KeptLines kl; kl.cname = &cname;
+      if (keep_lines && fi < kept.size()) for (const auto& d : kept[fi]) kl.parts.push_back(KeptLines::Part{d->text.data(), d->meta.data(), d->meta.size(), d->off.data(), d->lens.size()});
+      classify_one(devs, reduce, prefixes[fi], o.v.at("then-classify"), minReadsU, last ? leave : std::function<void()>(), nullptr, keep_lines ? &kl : nullptr);
+      if (keep_lines && fi < kept.size()) kept[fi].clear();
       for (auto& d : devs) mm_comm_destroy(d.ctx);
       pc.lap("9 classify");
     }
@@ -1546,7 +1581,8 @@ struct ClassifyRun {
     ~TextBuf() { delete[] p; }
   };
   TextBuf text;
-  struct MapLine { size_t beg, last_space, end; int contig; long long len; size_t start, stop; double ident, mapq; };   // [beg, end): the line; last_space: the blank before field 14
+  struct MapLine { const char* p; uint32_t last_space, n; int contig; long long len; size_t start, stop; double ident, mapq; };   // [p, p + n): the line; p + last_space: the blank before field 14
+  const KeptLines* kept = nullptr;                                // mapDirectly --then-classify: the lines in memory (no file is read)
   std::vector<MapLine> lines; std::vector<int64_t> off{0};       // read r owns lines [off[r], off[r+1])
   std::vector<std::string> contig_id; std::unordered_map<std::string, int> contig_index;
   size_t NRD = 0;
@@ -1625,7 +1661,7 @@ struct ClassifyRun {
           if (nf < 14) die("File " + mapped + " has lines with fewer than 14 fields - is this a mappings file generated by MetaMap?");
           if (fe[0] - fb[0] != cur_len || memcmp(T0 + fb[0], T0 + cur_beg, cur_len) != 0) { P.starts.push_back((int64_t)P.lines.size()); cur_beg = fb[0]; cur_len = fe[0] - fb[0]; }
           MapLine L{};
-          L.beg = p; L.end = e; L.last_space = fb[13] - 1;
+          L.p = T0 + p; L.n = (uint32_t)(e - p); L.last_space = (uint32_t)(fb[13] - 1 - p);
           std::string cid(T0 + fb[5], fe[5] - fb[5]);
           auto it = P.cix.find(cid);
           if (it == P.cix.end()) { it = P.cix.emplace(cid, (int)P.cid.size()).first; P.cid.push_back(cid); }
@@ -1749,22 +1785,22 @@ struct ClassifyRun {
         Out& O = outs[t];
         const size_t r0 = rcut[t], r1 = rcut[t + 1];
         if (r1 <= r0) return;
-        O.em.reserve((lines[(size_t)off[r1] - 1].end - lines[(size_t)off[r0]].beg) + ((size_t)off[r1] - (size_t)off[r0]) * 4 + 64);
+        { size_t bytes = 0; for (size_t i = (size_t)off[r0]; i < (size_t)off[r1]; ++i) bytes += lines[i].n + 5; O.em.reserve(bytes + 64); }
         char num[64];
         for (size_t r = r0; r < r1; ++r) {                         // fEM.h:684-779
           for (size_t i = (size_t)off[r]; i < (size_t)off[r + 1]; ++i) {   // the line with field 14 replaced by std::to_string(posterior) (:705)
-            O.em.append(text.c_str() + lines[i].beg, lines[i].last_space + 1 - lines[i].beg);
+            O.em.append(lines[i].p, (size_t)lines[i].last_space + 1);
             append_f6(O.em, post[i]);
             O.em += '\n';
           }
           const size_t b = (size_t)best[r];
           const MapLine& B = lines[b];
           const std::string& cg = contig_id[(size_t)B.contig];
-          const size_t rid_end = (size_t)((const char*)memchr(text.c_str() + B.beg, ' ', B.end - B.beg) - text.c_str());
+          const size_t rid_len = (size_t)((const char*)memchr(B.p, ' ', B.n) - B.p);
           O.li += "EqualCoverageUnit\t"; O.li += cg; O.li += '\t';
           snprintf(num, sizeof num, "%zu\t%g\t%lld\n", r, B.ident, B.len); O.li += num;                  // :711
-          O.r2.append(text.c_str() + B.beg, rid_end - B.beg); O.r2 += '\t'; O.r2 += taxa[(size_t)taxon[b]]; O.r2 += '\n';
-          O.kr.append(text.c_str() + B.beg, rid_end - B.beg); O.kr += '\t'; O.kr += tax_nonx[(size_t)taxon[b]];
+          O.r2.append(B.p, rid_len); O.r2 += '\t'; O.r2 += taxa[(size_t)taxon[b]]; O.r2 += '\n';
+          O.kr.append(B.p, rid_len); O.kr += '\t'; O.kr += tax_nonx[(size_t)taxon[b]];
           snprintf(num, sizeof num, "\t%g\n", post[b]); O.kr += num;
         }
       };
@@ -1830,9 +1866,30 @@ struct ClassifyRun {
     pc.lap("c8 evidence of unknown species + contig coverage");
     if (leave_now && !getenv("MM_CLI_FULL_TEARDOWN")) { emf.close(); r2t.close(); kr.close(); li.close(); pc.report(); leave_now(); finish_fast(); }   // (a GB of vectors and strings: nothing left to do with them)
   }
+  // mapDirectly --then-classify: the lines are in memory with their fields parsed (LineMeta) — what read_file + tokenise produce from the file, without the
+  // file: read boundaries from the batches' offsets (reads without mappings have no lines), contig IDs interned in the order of their first line
+  void adopt() {
+    size_t total = 0; for (const auto& P : kept->parts) total += P.n_lines;
+    lines.resize(total);
+    off.clear();
+    std::vector<int> intern(kept->cname->size(), -1);
+    size_t at = 0;
+    for (const auto& P : kept->parts) {
+      for (size_t r = 0; r < P.n_reads; ++r) if (P.off[r + 1] > P.off[r]) off.push_back((int64_t)at + P.off[r]);
+      for (size_t i = 0; i < P.n_lines; ++i) {
+        const LineMeta& m = P.meta[i];
+        int& ci = intern[(size_t)m.contig];
+        if (ci < 0) { ci = (int)contig_id.size(); contig_id.push_back((*kept->cname)[(size_t)m.contig]); contig_index.emplace(contig_id.back(), ci); }
+        lines[at + i] = MapLine{P.text + m.beg, m.ls, m.n, ci, (long long)m.len, (size_t)m.start, (size_t)((long long)m.start + m.len - 1), m.ident, m.mapq};
+      }
+      at += P.n_lines;
+    }
+    if (off.empty()) off.push_back(0);
+    if (!lines.empty()) off.push_back((int64_t)lines.size());
+    NRD = off.size() - 1;
+  }
   int run() {
-    read_file();
-    tokenise();
+    if (kept) adopt(); else { read_file(); tokenise(); }
     read_tables();
     pc.lap("c1 read mappings + taxonInfo");
     tax = std::make_unique<Taxonomy>(db + "/taxonomy");
@@ -1847,8 +1904,9 @@ struct ClassifyRun {
 };
 
 int classify_one(const std::vector<Dev>& devs, EmReduce reduce, const std::string& mapped, const std::string& db, size_t minReadsU,
-                 const std::function<void()>& leave_now, const std::function<void()>& need_devices) {
+                 const std::function<void()>& leave_now, const std::function<void()>& need_devices, const KeptLines* kept) {
   ClassifyRun run(devs, reduce, mapped, db, minReadsU, leave_now, need_devices);
+  run.kept = kept;
   return run.run();
 }
 

@@ -4,10 +4,18 @@
 #include <cstdlib>
 #include <random>
 
+static long n_fast_parse = 0;
 static int check_g(double x) {
   char ref[64]; snprintf(ref, sizeof ref, "%g", x);
   std::string s; append_g6(s, x);
   if (s != ref) { printf("MISMATCH %%g %.17g: fast '%s' printf '%s'\n", x, s.c_str(), ref); return 1; }
+  // the text read back (what `classify` parses with strtod): parse_g6_text either declines or returns strtod's double, bit for bit
+  double back = 0;
+  if (parse_g6_text(s.data(), s.size(), &back)) {
+    ++n_fast_parse;
+    const double want = strtod(s.c_str(), nullptr);
+    if (memcmp(&back, &want, sizeof back) != 0) { printf("MISMATCH parse '%s': fast %.17g strtod %.17g\n", s.c_str(), back, want); return 1; }
+  }
   return 0;
 }
 static int check_f(double x) {
@@ -44,6 +52,7 @@ int main(int argc, char** argv) {
     if (check_u(0) || check_u(~0ull) || check_u(0xffffffffull) || check_u(0x100000000ull) || check_i(0) || check_i(-1) || check_i(-0x7fffffffffffffffLL - 1) || check_i(0x7fffffffffffffffLL)) return 1;
     for (long i = 0; i < n; ++i) { const int bits = 1 + (int)(rng() % 64); const unsigned long long v = rng() >> (64 - bits); if (check_u(v) || check_i((long long)v)) return 1; cnt += 2; }
   }
+  if (n_fast_parse < cnt / 8) { printf("parse_g6_text declined too often: %ld of %ld\n", n_fast_parse, cnt); return 1; }
   printf("ok %ld\n", cnt);
   return 0;
 }

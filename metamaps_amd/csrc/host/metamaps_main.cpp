@@ -268,7 +268,8 @@ static void format_range(const std::vector<std::string>& names, const std::vecto
 void format_records(const std::vector<std::string>& names, const std::vector<int>& lens, const std::vector<int64_t>& off,
                     const std::vector<mm_map_record>& rec, const std::vector<std::string>& cname, const std::vector<int>& clen, int k, std::string& out, std::vector<LineMeta>* meta) {
   const size_t n = names.size();
-  const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(1u, mm::cpu_budget() / 4), rec.size() / 10000 + 1}));   // (a quarter of the CPU budget per worker: four workers rarely format at the same moment)
+  static const size_t per_part = getenv("MM_CLI_FORMAT_PART") ? (size_t)std::max(1, atoi(getenv("MM_CLI_FORMAT_PART"))) : 10000;   // (tests: several parts for small batches too)
+  const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::max(per_part < 10000 ? 8u : 1u, mm::cpu_budget() / 4), rec.size() / per_part + 1}));   // (a quarter of the CPU budget per worker: four workers rarely format at the same moment)
   static thread_local std::vector<FormatCache> caches(8);          // (the calling thread's: a worker of mapDirectly formats batch after batch)
   if (T == 1) { format_range(names, lens, off, rec, cname, clen, k, 0, n, out, caches[0], meta); return; }
   std::vector<size_t> cut(T + 1, n);
@@ -278,9 +279,10 @@ void format_records(const std::vector<std::string>& names, const std::vector<int
   std::vector<std::string>& part = part_store;
   FormatCache* const fcs = caches.data();
   static thread_local std::vector<std::vector<LineMeta>> meta_store(8);
+  std::vector<std::vector<LineMeta>>& metas = meta_store;        // (the CALLING thread's: the helpers below must not name the thread_local themselves)
   const auto q0 = std::chrono::steady_clock::now();
   std::vector<double> took(T, 0.0);
-  auto timed = [&](size_t t) { const auto a = std::chrono::steady_clock::now(); format_range(names, lens, off, rec, cname, clen, k, cut[t], cut[t + 1], part[t], fcs[t], meta ? &meta_store[t] : nullptr);
+  auto timed = [&](size_t t) { const auto a = std::chrono::steady_clock::now(); format_range(names, lens, off, rec, cname, clen, k, cut[t], cut[t + 1], part[t], fcs[t], meta ? &metas[t] : nullptr);
                                took[t] = std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
   static thread_local TaskPool helpers(7);                         // (task_pool.hpp: the calling worker's own helpers, there from batch to batch)
   const auto q1 = q0;
@@ -290,7 +292,7 @@ void format_records(const std::vector<std::string>& names, const std::vector<int
   out.clear(); out.reserve(total);
   if (meta) { meta->clear(); meta->reserve(rec.size()); }
   for (size_t t = 0; t < T; ++t) {
-    if (meta) for (LineMeta lm : meta_store[t]) { lm.beg += (uint32_t)out.size(); meta->push_back(lm); }
+    if (meta) for (LineMeta lm : metas[t]) { lm.beg += (uint32_t)out.size(); meta->push_back(lm); }
     out += part[t];
   }
   if (getenv("MM_CLI_FORMAT_TRACE")) {

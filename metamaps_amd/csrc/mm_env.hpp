@@ -101,6 +101,7 @@ inline const EnvSwitch* env_table(size_t* n) {
     {"MM_EM_SPLIT", "unset", "test", "with MM_EM_RESIDENT: the phases as launches all the same (cross-check)"},
     {"MM_EM_GRID", "256 (128 resident)", "tuning", "workgroups of the EM kernels"},
     {"MM_EM_BARRIER_TICKS", "2 s", "test", "time-out of the resident kernel's grid barrier before it hands the run to the launch path"},
+    {"MM_CLI_FORMAT_PART", "10000", "test", "mapping records per formatter thread of a batch (the text of a batch is formatted in up to eight parts and joined)"},
     {"MM_CLI_CLASSIFY_FROM_FILE", "unset", "test", "mapDirectly --then-classify reads PREFIX back and tokenises it (as `classify` does) instead of taking the lines it has just formatted from memory"},
     {"MM_EM_ORDER", "file", "debug", "\"count\": reads by mapping count for the thread-per-read E step (measurement aid)"},
     {"MM_EM_DBG", "0", "debug", "E-step variants of the round-4 measurements (tools/em_latency.py)"},

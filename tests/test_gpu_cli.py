@@ -85,9 +85,9 @@ def test_cli_then_classify_in_one_process_writes_the_same_files(tmp_path, device
         for suf in ("", ".meta", ".meta.unmappedReadsLengths") + CLASSIFY_SUFFIXES:
             assert open(a + suf, "rb").read() == open(b + suf, "rb").read(), suf
         assert os.path.getsize(a + ".EM.WIMP") > 200
-    # the in-process classify takes the lines it formatted from memory (text + parsed fields per batch); in batches of 64 reads (several parts per file)
+    # the in-process classify takes the lines it formatted from memory (text + parsed fields per batch); in batches of 64 reads (several parts per file), with the text of a batch formatted by several threads (MM_CLI_FORMAT_PART)
     # and with the file read back instead (MM_CLI_CLASSIFY_FROM_FILE=1, what round 5 did) the files are the same again
-    for tag, env in (("small_batches", {"MM_CLI_BATCH_READS": "64"}), ("from_file", {"MM_CLI_CLASSIFY_FROM_FILE": "1"})):
+    for tag, env in (("small_batches", {"MM_CLI_BATCH_READS": "64"}), ("from_file", {"MM_CLI_CLASSIFY_FROM_FILE": "1"}), ("format_parts", {"MM_CLI_FORMAT_PART": "40"})):
         alt = [str(tmp_path / f"{tag}_a"), str(tmp_path / f"{tag}_b")]
         p = subprocess.run([CLI, "mapDirectly", "--all", "-r", db.fasta, "-q", q, "-o", ",".join(alt), "--then-classify", db.dir, "--minreads", "3"] + dev,
                            capture_output=True, timeout=900, env=dict(os.environ, **env))

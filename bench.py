@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_MEASURED_GBS = 6300.0   # what a streaming read of K5's access pattern (46 KB runs from ~6 000 waves) reaches on this part: tools/ubench/stream46k, docs/history.md section 6
-TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r05_traffic.json", "r04_traffic.json")]   # the newest committed PMC summary that exists
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json")]   # the newest committed PMC summary that exists
 
 
 def parse_args():
@@ -669,9 +669,9 @@ def roofline_block(args, R):
     """The `roofline` object of the bench line.  One regime per field:
       *_alone         the kernel's launches of ONE step with the GPU to itself — HIP events on the worker's stream around the launches, in the two steps
                       right behind the timed region whose mapping sections hold the lock to their end (the durations `rocprofv3 --kernel-trace --stats`
-                      shows for this command with --serialise-map: profiles/r05_kernel_stats.txt); algorithmic bytes from THAT step's counters
+                      shows for this command with --serialise-map: profiles/r06_kernel_stats.txt); algorithmic bytes from THAT step's counters
       *_timed_region  the same events inside the timed region, averaged over its steps: two worker contexts share the GPU there, so a launch also
-                      waits for and runs beside the other step's kernels (profiles/r05_kernel_stats_default_cmd.txt); bytes averaged over the same steps
+                      waits for and runs beside the other step's kernels (profiles/r06_kernel_stats_default_cmd.txt); bytes averaged over the same steps
     Algorithmic bytes per launch follow SURVEY.md section 8 D3 (B_map = ceil(L/4) + 8 s + 8 H + 8 sum M + 32 O per read):
       K1 minimizer stage   ceil(L/4)            the packed bases it reads (what it writes, 8 B per minimizer, is not part of D3; VALU-bound)
       K3 seed filter       8 (s + H)            one probe per sketch hash + every seed hit of the kept lists
@@ -691,15 +691,16 @@ def roofline_block(args, R):
     kern = {
         "K1": entry("minimizer_kernel<2> + jstar_kernel + compact_tiles_kernel (the stage: mm_map_stats.ms_minimizer)", st_a["ms_minimizer"], st_a["bases_long_enough"] / 4.0,
                     agg["ms_mz"] / nl, agg["bases"] / 4.0 / nl, ["mm::minimizer_kernel<2>"],
-                    "VALU: two MurmurHash3 x64-128 per position = sixteen 64-bit multiplies (profiles/r05_sq_counters.txt: 97 percent of the issue slots); the HBM fraction is not its limit.  "
+                    "VALU: two MurmurHash3 x64-128 per position = sixteen 64-bit multiplies (profiles/r06_sq_counters.txt: 97 percent of the issue slots); the HBM fraction is not its limit.  "
                     "D3 counts only the packed bases it reads: the 8-byte records it writes (2.1 GB per step, twice: staged, then compacted) are what traffic_over_algorithmic shows"),
         "K3": entry("seed_filter_stream_kernel<false> (mm_map_stats.ms_hit_filter)", st_a["ms_hit_filter"], 8.0 * (st_a["sum_hits"] + st_a["sum_sketch"]),
                     agg["ms_hf"] / nl, 8.0 * agg["hf_units"] / nl, ["mm::seed_filter_stream_kernel<false>"],
                     "two things (DESIGN.md section 7): what a CU executes per read (the time follows the CUs at work: profiles/r05_sf_grid_sweep.txt; VALU 37 percent, LDS atomics, 13 barriers) and the memory side's rate "
                     "of random 64-byte requests - table sector, list pieces, survivors: 5.3e8 per launch (FETCH_SIZE) against 47e9 requests/s over a 90 GB footprint, which 64 CUs reach alone (profiles/r05_randread_cus.txt)"),
-        "K5": entry("l2_kernel<true,u8,4,2> + l2_kernel<true,u8,2,2> (the launch pair of a step: mm_map_stats.ms_l2)", st_a["ms_l2"], 8.0 * st_a["sum_l2_stream_entries"],
-                    agg["ms_l2"] / nl, 8.0 * agg["l2_stream"] / nl, ["mm::l2_kernel<true, unsigned char, 4, 2>", "mm::l2_kernel<true, unsigned char, 2, 2>"],
-                    "VALU: 2.8 wave-instructions per streamed entry, 87 percent of the issue slots (profiles/r05_sq_counters.txt); phase shares: profiles/r05_l2_phases.txt"),
+        "K5": entry("l2z_kernel<4,2,true> + l2z_kernel<2,2,true> (the zone kernel's launch pair of a step: mm_map_stats.ms_l2)", st_a["ms_l2"], 8.0 * st_a["sum_l2_stream_entries"],
+                    agg["ms_l2"] / nl, 8.0 * agg["l2_stream"] / nl, ["mm::l2z_kernel<4, 2, true>", "mm::l2z_kernel<2, 2, true>"],
+                    "instruction issue: 1.8 VALU + 1.5 scalar wave-instructions per streamed entry (l2_kernel, round 5: 2.8 + 1.3), VALU 62 percent busy (profiles/r06_sq_counters.txt); the stream is read once "
+                    "(the band's threshold masks come out of pass A); phase shares: profiles/r06_l2_phases.txt"),
     }
     dom = max(kern, key=lambda kk: kern[kk]["ms_alone"])
     d = kern[dom]
@@ -712,9 +713,9 @@ def roofline_block(args, R):
             "whole_step": {"d3_bytes": d3, "algorithmic_bytes": d3_sum, "ms_per_step": R["ms_step"], "achieved": d3_sum / (R["ms_step"] * 1e-3) / 1e9,
                            "frac": d3_sum / (R["ms_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "note": "all D3 bytes of one step (counters of the step measured alone) over the timed region's ms_per_step: what the pipeline as a whole moves per second"},
-            "how_to_recompute": "frac = kernels.K.algorithmic_bytes / (kernels.K.ms_alone * 1e-3) / 1e9 / peak; ms_alone agrees with the avg_ms column of profiles/r05_kernel_stats.txt "
+            "how_to_recompute": "frac = kernels.K.algorithmic_bytes / (kernels.K.ms_alone * 1e-3) / 1e9 / peak; ms_alone agrees with the avg_ms column of profiles/r06_kernel_stats.txt "
                                 "(K5: the sum of its two launches — that profile runs them one behind the other, MM_L2_ONE_STREAM=1; by default they run side by side on two streams and ms_alone is the time of the pair, "
-                                "within 0.1 ms of the sum at this batch size; K1: minimizer_kernel<2> + compact_tiles_kernel + jstar_kernel), ms_timed_region with profiles/r05_kernel_stats_default_cmd.txt; "
+                                "within 0.1 ms of the sum at this batch size; K1: minimizer_kernel<2> + compact_tiles_kernel + jstar_kernel), ms_timed_region with profiles/r06_kernel_stats_default_cmd.txt; "
                                 "the bytes follow from config.per_step (counters of the last timed step; the step measured alone maps another batch: kernels.K.algorithmic_bytes is its own)"}
 
 

@@ -48,7 +48,7 @@ namespace mm {
 #ifndef L2Z_RING
 #define L2Z_RING 128
 #endif
-__host__ __device__ constexpr int l2z_qcap(int nwq) { return nwq == 2 ? L2Z_RING : 2 * L2Z_RING; }   // (long-read classes: two searches per lane at a time, see dense2)
+__host__ __device__ constexpr int l2z_qcap(bool qlds) { return qlds ? L2Z_RING : 2 * L2Z_RING; }   // (sketch searched in global memory: two searches per lane at a time, see dense2)
 constexpr int L2Z_QCAP_ = L2Z_RING;                                   // ring of compacted (hash, entry) pairs waiting for the search (4 + 2 bytes each): eight words are added at a time, 64 taken
 #ifndef L2Z_WAVES_10K
 #define L2Z_WAVES_10K 6                                         // waves per SIMD the 10 kb class is compiled for
@@ -83,15 +83,15 @@ __host__ __device__ constexpr int l2z_band(int nwq) { return nwq == 2 ? 128 : 51
 // per-wave LDS: the first entry's position of every word (pass A writes, the e_min searches read) | a region used by pass A as
 // {ring of (hash, entry) pairs, matched bits of the current group of 64 words} and afterwards as {band gap counters / prefixes, the band's
 // hashes, band presence bits, slide scratch}
-__host__ __device__ constexpr int l2z_x_bytes(int nwq) {
-  const int xa = l2z_qcap(nwq) * 6 + 64 * 8, xb = l2z_band(nwq) * 4 * 2 + l2z_band(nwq) / 8 + L2_SCRATCH_BYTES;
+__host__ __device__ constexpr int l2z_x_bytes(int nwq, bool qlds) {
+  const int xa = l2z_qcap(qlds) * 6 + 64 * 8, xb = l2z_band(nwq) * 4 * 2 + l2z_band(nwq) / 8 + L2_SCRATCH_BYTES;
   return (xa > xb ? xa : xb) + 64;                               // (+ eight phase clocks at its end)
 }
-__host__ __device__ inline size_t l2z_wave_bytes(int nwq) { return ((((size_t)(64 * nwq + 1) * 4) + 15) & ~(size_t)15) + (size_t)l2z_x_bytes(nwq); }
+__host__ __device__ inline size_t l2z_wave_bytes(int nwq, bool qlds) { return ((((size_t)(64 * nwq + 1) * 4) + 15) & ~(size_t)15) + (size_t)l2z_x_bytes(nwq, qlds); }
 __host__ __device__ inline size_t l2z_shared_bytes(int smax, int nwq, bool qlds, int bbl) {
   return ((size_t)1 << (bbl - 3)) + l2_tpart_bytes(nwq) + (qlds ? l2_qpart_bytes(smax) : 0);
 }
-__host__ __device__ inline size_t l2z_lds_bytes(int smax, int nwq, bool qlds, int bbl, int waves) { return l2z_shared_bytes(smax, nwq, qlds, bbl) + (size_t)waves * l2z_wave_bytes(nwq); }
+__host__ __device__ inline size_t l2z_lds_bytes(int smax, int nwq, bool qlds, int bbl, int waves) { return l2z_shared_bytes(smax, nwq, qlds, bbl) + (size_t)waves * l2z_wave_bytes(nwq, qlds); }
 
 // number of leading lanes whose (ascending, unsigned) arr lies below v
 __device__ inline int rank_search_u(uint32_t arr, uint32_t v) {
@@ -150,7 +150,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
            const int32_t* __restrict__ cand_hint /* seed hits inside each candidate (l1_wave_kernel; 0: none): what the best window's matched count will be */) {
   extern __shared__ __align__(16) uint32_t lds[];
   constexpr int NW = 64 * NWQ, CAP = 64 * NW, NW1 = NW + 1;
-  constexpr int QCAP = l2z_qcap(NWQ);
+  constexpr int QCAP = l2z_qcap(QLDS);
   constexpr int BAND = l2z_band(NWQ), BPL = BAND / 64;            // ranks of a band, ranks per lane
   constexpr int TBITS = l2_tbits(NWQ), tshift = 32 - TBITS;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -159,7 +159,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
   uint16_t* const T = (uint16_t*)((uint8_t*)lds + ((size_t)1 << (bbl - 3)));
   int* const tmaxp = (int*)(T + ((l2_tsize(NWQ) + 1) & ~1));
   uint32_t* const QL = (uint32_t*)((uint8_t*)T + l2_tpart_bytes(NWQ));   // (QLDS only)
-  uint8_t* const wbase = (uint8_t*)lds + l2z_shared_bytes(smax, NWQ, QLDS, bbl) + (size_t)wave * l2z_wave_bytes(NWQ);
+  uint8_t* const wbase = (uint8_t*)lds + l2z_shared_bytes(smax, NWQ, QLDS, bbl) + (size_t)wave * l2z_wave_bytes(NWQ, QLDS);
   const int64_t c0 = (int64_t)grp_cand0[blockIdx.x];
   const int r = cand_read[c0];                                   // every wave of the workgroup serves this read
   const int s = sk_n[r];
@@ -251,7 +251,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
 
   // phase clocks (MM_L2_PHASES): setup, passA, bounds, rebuild, slide, passB, vote — kept in LDS so that they cost no registers when off
   const bool prof = (dbg_flags & 0x100) != 0;
-  long long* const tphL = (long long*)(wbase + l2z_wave_bytes(NWQ) - 64);
+  long long* const tphL = (long long*)(wbase + l2z_wave_bytes(NWQ, QLDS) - 64);
   long long tmark = 0;
   if (prof) { if (lane < 8) tphL[lane] = 0; tmark = clock64(); }
   auto lap = [&](int ph) { if (prof) { const long long now = clock64(); if (lane == 0) tphL[ph] += now - tmark; tmark = now; } };
@@ -286,7 +286,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
   uint16_t* const pLo = pAll + NW1;
   uint16_t* const pA = pLo + NW1;
   int* const W0 = (int*)wbase;                                   // wpos of the first entry of every word
-  uint8_t* const xb_ = wbase + (l2z_wave_bytes(NWQ) - l2z_x_bytes(NWQ));
+  uint8_t* const xb_ = wbase + (l2z_wave_bytes(NWQ, QLDS) - l2z_x_bytes(NWQ, QLDS));
   uint32_t* const RQh = (uint32_t*)xb_;                          // pass A: the ring's hashes ...
   uint16_t* const RQj = (uint16_t*)(xb_ + QCAP * 4);         // ... and entry numbers
   uint64_t* const mL = (uint64_t*)(xb_ + QCAP * 6);          // pass A: matched bits of the current group of 64 words

@@ -2167,10 +2167,19 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
             MM_KERNEL_CHECK();
           }
           if (nS) {
-            const size_t lds = l2z_lds_bytes(smA, 2, true, bbl, 2);
-            set_lds((const void*)l2z_kernel<2, 2, true>, lds);
-            l2z_kernel<2, 2, true><<<dim3((unsigned)nS), dim3(128), lds, st_small>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p,
-                M->accept_min.p, P.k, P.w, smA, bbl, M->l2.p, counters.p, d_gS0.p, d_gSn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)codes, masks, slot_flags_p, n_slots, cand_hint_p);
+            // groups of one or two candidates: a two-wave workgroup with the sketch in LDS holds 20 KB for two waves (16 waves per CU); with the sketch left
+            // in global memory (the default; MM_L2_SMALL_QLDS=1: in LDS) it holds 10 KB and the CU its 24 waves
+            if (getenv("MM_L2_SMALL_QLDS")) {
+              const size_t lds = l2z_lds_bytes(smA, 2, true, bbl, 2);
+              set_lds((const void*)l2z_kernel<2, 2, true>, lds);
+              l2z_kernel<2, 2, true><<<dim3((unsigned)nS), dim3(128), lds, st_small>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p,
+                  M->accept_min.p, P.k, P.w, smA, bbl, M->l2.p, counters.p, d_gS0.p, d_gSn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)codes, masks, slot_flags_p, n_slots, cand_hint_p);
+            } else {
+              const size_t lds = l2z_lds_bytes(smA, 2, false, bbl, 2);
+              set_lds((const void*)l2z_kernel<2, 2, false>, lds);
+              l2z_kernel<2, 2, false><<<dim3((unsigned)nS), dim3(128), lds, st_small>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p,
+                  M->accept_min.p, P.k, P.w, smA, bbl, M->l2.p, counters.p, d_gS0.p, d_gSn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)codes, masks, slot_flags_p, n_slots, cand_hint_p);
+            }
             MM_KERNEL_CHECK();
           }
         } else {

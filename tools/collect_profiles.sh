@@ -14,6 +14,7 @@ timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ou
 python tools/summarize_profiles.py $out
 # K5 phase clocks on the bench batch (10^5 x 10 kb), the probed-list distribution and the random-request ceiling (round 5)
 timeout 600 python tools/l2_long_phases.py 10000 10000 100000 > $out/l2_phases.txt 2>&1
+if [ -n "$EXTRAS" ]; then   # (round 5's K3 studies: the probed-list distribution, the random-request ceiling, the CU sweep, LDS rates, K3's phase clocks)
 timeout 600 python tools/probed_lists.py > $out/probed_lists.json 2> /dev/null
 (for s in 2m 16m 128m 40; do ./tools/ubench/randread $s; done) > $out/randread.txt 2>&1
 # what bounds K3 (round 5): its time against the CUs at work, the random-request ceiling by CUs / waves / loads in flight, LDS instruction rates, its phase clocks
@@ -21,3 +22,6 @@ timeout 600 python tools/sf_grid_sweep.py > $out/sf_grid_sweep.txt 2>&1
 timeout 300 ./tools/ubench/randread_cus 90 > $out/randread_cus.txt 2>&1
 timeout 300 ./tools/ubench/lds_rates > $out/lds_rates.txt 2>&1
 (MM_SF_PROF=1 SHAPE=community ITERS=1 timeout 600 python tools/stage_ms.py 2>&1 | grep "MM_SF_PROF\|ms_hit_filter" | tail -3) > $out/sf_phases.txt 2>&1
+fi
+timeout 600 python tools/l2z_stops.py > $out/l2z_stops.txt 2>&1
+timeout 600 python tools/l2z_pivot_hist.py 10000 10000 20000 > $out/l2z_pivot_hist.txt 2>&1

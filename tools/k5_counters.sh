@@ -14,10 +14,15 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(int)
 for row in csv.DictReader(open(sys.argv[1])):
     k = row["Kernel_Name"].split("(")[0].replace("void ", "")
-    if "l2_kernel" in k or "l2z_kernel" in k:
+    if "l2_kernel" in k or "l2z_kernel" in k or "seed_filter_stream" in k or "minimizer_kernel<2>" in k:
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[(k, row["Counter_Name"])] += 1
 for k in acc:
     for c, v in acc[k].items(): print(f"  {k[:50]:50s} {c:24s} {v:.6g}  ({cnt[(k, c)]} launches)")
 PY
 done
+python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/k5c_VALUBusy_SALUBusy_MemUnitBusy.json").read().strip().splitlines()[-1])
+print("per_step", json.dumps(d["config"]["per_step"]))
+PY
 rm -rf gpurun_out/k5c

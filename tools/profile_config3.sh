@@ -35,7 +35,7 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(int)
 for row in csv.DictReader(open(sys.argv[1])):
     k = row["Kernel_Name"].split("(")[0].replace("void ", "")
-    if any(t in k for t in ("l2_", "seed_filter", "probe_kernel", "hit_filter", "minimizer_kernel<2>", "sketch_", "sort_hits")):
+    if any(t in k for t in ("l2_", "l2z_", "seed_filter", "probe_kernel", "hit_filter", "minimizer_kernel<2>", "sketch_", "sort_hits")):
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[(k, row["Counter_Name"])] += 1
 for k in acc:
     for c, v in acc[k].items(): print(f"  {k[:60]:60s} {c:24s} {v:.6g}  ({cnt[(k, c)]} launches)")

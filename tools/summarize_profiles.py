@@ -42,10 +42,10 @@ with open(os.path.join(out, "pmc_hbm_traffic.txt"), "w") as w:
         w.write(f"{k:<62} {fe[k][0]:>8} {fe[k][1]:>14.0f} {fetch_corr(k):>5.0f} {fe[k][1]*1024*fetch_corr(k)/1e9:>10.2f} {wr.get(k,[0,0])[1]:>14.0f} {wr.get(k,[0,0])[1]*1024/1e9:>9.2f}\n")
 traffic = {}
 for k in fe:
-    if "l2_kernel" in k or "hit_filter_kernel<false>" in k or "seed_filter" in k or "minimizer_kernel<2>" in k:
+    if "l2_kernel" in k or "l2z_kernel" in k or "hit_filter_kernel<false>" in k or "seed_filter" in k or "minimizer_kernel<2>" in k:
         traffic[k] = (fe[k][1] * 1024 * fetch_corr(k) + wr.get(k, [0, 0])[1] * 1024) / max(fe[k][0], 1)
 json.dump({"shape": "community", "reads": 100000, "read_len": 10000,
-           "source": "profiles/r05_pmc_hbm_traffic.txt (FETCH_SIZE*1024*corr + WRITE_SIZE*1024 per launch, separate rocprofv3 --pmc passes; corr = 1 for the kernels that read "
+           "source": "profiles/r06_pmc_hbm_traffic.txt (FETCH_SIZE*1024*corr + WRITE_SIZE*1024 per launch, separate rocprofv3 --pmc passes; corr = 1 for the kernels that read "
                      "random pieces of <= 64 bytes, 2 for streaming kernels: profiles/r01_fetch_size_calibration.txt; tools/collect_profiles.sh)",
            "by_kernel": traffic}, open(os.path.join(out, "traffic_by_kernel.json"), "w"), indent=1)
 print(open(os.path.join(out, "kernel_stats.txt")).read()[:3000])

@@ -8,7 +8,7 @@ out=gpurun_out/profiles; rm -rf $out; mkdir -p $out
 FLAGS="--no-cpu-baseline --no-other-shape --no-e2e-full"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 6 --warmup 3 $FLAGS > $out/bench_stats_run.json 2> $out/stats.err
 # (MM_L2_ONE_STREAM=1: K5's two launches one behind the other, so that each duration is that of a kernel that owns the GPU and the pair is their sum; by default they run side by side)
-MM_L2_ONE_STREAM=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_serialised -- python bench.py --steps 6 --warmup 2 --serialise-map --workers 3 $FLAGS > /dev/null 2> $out/stats_serialised.err
+MM_L2_ONE_STREAM=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_serialised -- python bench.py --steps 6 --warmup 2 --workers 1 $FLAGS > /dev/null 2> $out/stats_serialised.err
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python bench.py --steps 1 --warmup 0 --workers 1 --distinct-batches 1 $FLAGS > /dev/null 2> $out/fetch.err
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python bench.py --steps 1 --warmup 0 --workers 1 --distinct-batches 1 $FLAGS > /dev/null 2> $out/write.err
 python tools/summarize_profiles.py $out
@@ -25,3 +25,6 @@ timeout 300 ./tools/ubench/lds_rates > $out/lds_rates.txt 2>&1
 fi
 timeout 600 python tools/l2z_stops.py > $out/l2z_stops.txt 2>&1
 timeout 600 python tools/l2z_pivot_hist.py 10000 10000 20000 > $out/l2z_pivot_hist.txt 2>&1
+# instruction counts, busy cycles, waits of the three big kernels (one bench step each set, K5's launches one behind the other)
+bash tools/k5_counters.sh > $out/sq_counters.txt 2>&1
+tail -70 $out/sq_counters.txt

@@ -10,12 +10,12 @@ def short(name):
     return n[:60]
 
 for sub, name, what in (("stats", "kernel_stats_default_cmd.txt", "python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-other-shape --no-e2e-full   (the default scheduling: three worker contexts, the kernels of their steps share the GPU, so a kernel's duration includes what it waits for and runs beside"),
-                        ("stats_serialised", "kernel_stats.txt", "MM_L2_ONE_STREAM=1 python bench.py --steps 6 --warmup 2 --serialise-map --workers 3 --no-cpu-baseline --no-other-shape --no-e2e-full   (mapping sections serialised and K5's two launches one behind the other: the durations of kernels that own the GPU")):
+                        ("stats_serialised", "kernel_stats.txt", "MM_L2_ONE_STREAM=1 python bench.py --steps 6 --warmup 2 --workers 1 --no-cpu-baseline --no-other-shape --no-e2e-full   (ONE worker context and K5's two launches one behind the other: every duration is that of a kernel that owns the GPU")):
     fs = glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True)
     if not fs: continue
     rows = list(csv.DictReader(open(fs[0])))
     with open(os.path.join(out, name), "w") as w:
-        w.write(f"# rocprofv3 --kernel-trace --stats -- {what}; setup kernels: index build, synthetic data; per-step kernels: 2 warm-up + 6 timed steps (a different read batch each) + 2 with the lock held to the end + 2 + 6 on one batch repeated + one per further worker context)\n")
+        w.write(f"# rocprofv3 --kernel-trace --stats -- {what}; setup kernels: index build, synthetic data; per-step kernels: warm-up + timed steps (a different read batch each) + the steps behind the timed region (lock held to the end, one batch repeated)\n")
         w.write(f"{'calls':>7} {'total_ms':>12} {'avg_ms':>12} {'%':>7}  kernel\n")
         for r in rows:
             w.write(f"{int(r['Calls']):>7} {float(r['TotalDurationNs'])/1e6:>12.3f} {float(r['AverageNs'])/1e6:>12.3f} {float(r['Percentage']):>7.3f}  {short(r['Name'])}\n")

@@ -131,6 +131,70 @@ __device__ inline uint64_t park64(uint64_t reg, uint64_t val, int l) {
 }
 __device__ inline int mbcnt64(uint64_t m, int base = 0) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)base)); }   // base + set bits of m below this lane
 
+// Pass B as a pass of its own — the masks of a band from a second reading of the stream.  Rare (a band that was not predicted, or the next band up /
+// down: 0.3 % of the bench's candidates), so it is a function the kernel CALLS: inlined, its 40 registers of stream words in flight were live ranges the
+// allocator made room for by spilling ~47 of the kernel's registers around the band loop of EVERY candidate (25 KB of scratch traffic each).
+struct L2ZPassB { const Rec* pos; int M, nmax, nwords; uint32_t tau_bh, tau_ref, tau_bl; int has_bl; const uint64_t* mAll; uint64_t* mLo; uint64_t* mA; uint64_t* mZ; uint64_t* mX; uint16_t* pLo; uint16_t* pA; };
+__device__ __attribute__((noinline)) void l2z_pass_b(const L2ZPassB& a) {
+  const int lane = threadIdx.x & 63;
+  const int last_end = __builtin_amdgcn_readfirstlane(a.M);
+  auto load8 = [&](Rec (&x)[8], int base) {
+    if (base + 512 <= last_end) {
+      const Rec* __restrict__ pp = a.pos + base + lane;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = pp[64 * i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = a.pos[min(base + lane + 64 * i, a.nmax)];
+    }
+  };
+  auto valid_mask = [&](int chunk_base) -> uint64_t {
+    const int nv = last_end - chunk_base;
+    return nv >= 64 ? ~0ull : (nv <= 0 ? 0ull : (1ull << nv) - 1ull);
+  };
+  // (the arguments are wave-uniform; loaded through a pointer the compiler cannot know that)
+  const int nwords = __builtin_amdgcn_readfirstlane(a.nwords);
+  const uint32_t tau_bh = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tau_bh), tau_ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tau_ref), tau_bl = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tau_bl);
+  const bool has_bl = __builtin_amdgcn_readfirstlane(a.has_bl) != 0;
+  int carryLo = 0, carryA = 0;
+  // per word four ballots, each parked in lane (word & 63) of a register pair; the masks are combined 64 words at a time
+  uint64_t rRef = 0, rBH = 0, rBL = 0, rNF = 0;                  // at or below Q[r_ref] | at or below the band's top | at or below Q[zb - 1] | an earlier occurrence exists (rare)
+  Rec nx[8];
+  load8(nx, 0);
+  for (int wd0 = 0; wd0 < nwords; wd0 += 8) {
+    Rec x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = nx[i];
+    if (wd0 + 8 < nwords) load8(nx, (wd0 + 8) * 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int wd = wd0 + i;
+      if (wd >= nwords) continue;
+      uint64_t le_bh = __ballot(x[i].hash <= tau_bh);
+      if (wd0 + 8 >= nwords) le_bh &= valid_mask(wd * 64);
+      const uint64_t le_ref = __ballot(x[i].hash <= tau_ref);
+      const uint64_t nf = __ballot((x[i].pw & PW_DP) != 0u);
+      park64x3(rBH, le_bh, rRef, le_ref, rBL, has_bl ? __ballot(x[i].hash <= tau_bl) : 0ull, wd & 63);
+      if (nf) rNF = park64(rNF, nf, wd & 63);
+    }
+    if (((wd0 + 8) & 63) == 0 || wd0 + 8 >= nwords) {
+      const int g0 = wd0 & ~63;
+      const uint64_t regAll = a.mAll[g0 + lane];
+      rRef &= rBH;
+      const uint64_t rLo = rRef & regAll, rA = rRef & ~regAll & ~rNF;
+      const int cl = __popcll(rLo), ca = __popcll(rA);
+      const int exl = carryLo + wave_excl_scan(cl, lane), exa = carryA + wave_excl_scan(ca, lane);
+      a.mLo[g0 + lane] = rLo; a.pLo[g0 + lane] = (uint16_t)exl;
+      a.mA[g0 + lane] = rA; a.pA[g0 + lane] = (uint16_t)exa;
+      a.mZ[g0 + lane] = rBH & ~rBL; a.mX[g0 + lane] = rBH & rNF;
+      carryLo = __builtin_amdgcn_readlane(exl, 63) + __builtin_amdgcn_readlane(cl, 63);
+      carryA = __builtin_amdgcn_readlane(exa, 63) + __builtin_amdgcn_readlane(ca, 63);
+      rRef = rBH = rBL = rNF = 0;
+    }
+  }
+  if ((nwords & 63) == 0 && lane == 0) { a.mLo[nwords] = 0; a.pLo[nwords] = (uint16_t)carryLo; a.mA[nwords] = 0; a.pA[nwords] = (uint16_t)carryA; }
+}
+
 // WAVES: candidates of ONE read per workgroup (they share the bit table, the bucket table and — QLDS — the sketch).  NWQ: 64 NWQ mask words,
 // i.e. candidates of up to 4096 NWQ streamed entries (larger ones go to `big_list`: the host runs them through l2_kernel).
 // QLDS: the sorted sketch lives in LDS (10 kb class); otherwise the few entries that pass the bit table search it in global memory.
@@ -561,47 +625,11 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
   int fUp[2] = {0, 0}, fDn[2] = {0, 0};                          // blocks with a window whose pivot lies above / below the current band
   int zdir = 0, n_pass = 0, n_low = 0;                                      // 0: first pass, +1: bands above it, -1: bands below it
   auto flag_block = [&](int (&f)[2], int kk) { if (lane == (kk & 63)) { if (kk < 64) f[0] = 1; else f[1] = 1; } };
-  // pass B: the masks of the band [zb, zb + 128) and its reference rank
+  // pass B: the masks of the band and its reference rank from a second reading of the stream (l2z_pass_b above)
   auto pass_low = [&]() {
     band_thresholds();
-    int carryLo = 0, carryA = 0;
-    // per word four ballots, each parked in lane (word & 63) of a register pair; the masks are combined 64 words at a time
-    uint64_t rRef = 0, rBH = 0, rBL = 0, rNF = 0;                // at or below Q[r_ref] | at or below the band's top | at or below Q[zb - 1] | an earlier occurrence exists (rare)
-    Rec nx[8];
-    load8(nx, 0);
-    for (int wd0 = 0; wd0 < nwords; wd0 += 8) {
-      Rec x[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = nx[i];
-      if (wd0 + 8 < nwords) load8(nx, (wd0 + 8) * 64);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int wd = wd0 + i;
-        if (wd >= nwords) continue;
-        uint64_t le_bh = __ballot(x[i].hash <= tau_bh);
-        if (wd0 + 8 >= nwords) le_bh &= valid_mask(wd * 64);
-        const uint64_t le_ref = __ballot(x[i].hash <= tau_ref);
-        const uint64_t nf = __ballot((x[i].pw & PW_DP) != 0u);
-        park64x3(rBH, le_bh, rRef, le_ref, rBL, has_bl ? __ballot(x[i].hash <= tau_bl) : 0ull, wd & 63);
-        if (nf) rNF = park64(rNF, nf, wd & 63);
-      }
-      if (((wd0 + 8) & 63) == 0 || wd0 + 8 >= nwords) {
-        const int g0 = wd0 & ~63;
-        const uint64_t regAll = mAll[g0 + lane];
-        rRef &= rBH;
-        const uint64_t rLo = rRef & regAll, rA = rRef & ~regAll & ~rNF;
-        const int cl = __popcll(rLo), ca = __popcll(rA);
-        const int exl = carryLo + wave_excl_scan(cl, lane), exa = carryA + wave_excl_scan(ca, lane);
-        mLo[g0 + lane] = rLo; pLo[g0 + lane] = (uint16_t)exl;
-        mA[g0 + lane] = rA; pA[g0 + lane] = (uint16_t)exa;
-        mZ[g0 + lane] = rBH & ~rBL; mX[g0 + lane] = rBH & rNF;
-        carryLo = __builtin_amdgcn_readlane(exl, 63) + __builtin_amdgcn_readlane(cl, 63);
-        carryA = __builtin_amdgcn_readlane(exa, 63) + __builtin_amdgcn_readlane(ca, 63);
-        rRef = rBH = rBL = rNF = 0;
-      }
-    }
-    close_prefix(mLo, pLo, carryLo);
-    close_prefix(mA, pA, carryA);
+    const L2ZPassB pb{pos, M, nmax, nwords, tau_bh, tau_ref, tau_bl, has_bl ? 1 : 0, mAll, mLo, mA, mZ, mX, pLo, pA};
+    l2z_pass_b(pb);
   };
   auto fill_band_hashes = [&]() {                                // the band's hashes for the rank searches of the rebuilds
 #pragma unroll

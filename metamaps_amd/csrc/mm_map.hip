@@ -1931,11 +1931,12 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   M->cand_read.alloc((size_t)std::max<int64_t>(ncand, 1));
   M->l2.alloc((size_t)std::max<int64_t>(ncand, 1));
   DBuf<int32_t> cand_hint((size_t)std::max<int64_t>(ncand, 1));   // seed hits inside each candidate (l1_wave_kernel): the zone kernel's prediction of its band
-  if (l1_serial || getenv("MM_L2_NO_FUSE")) cand_hint.zero(st);    // (0: no prediction, the masks of the band come from a second pass over the stream)
+  const bool no_hint = l1_serial || getenv("MM_L2_NO_FUSE");
+  if (no_hint) cand_hint.zero(st);                               // (0: no prediction, the masks of the band come from a second pass over the stream)
   M->rec_off.alloc((size_t)n + 1);
   if (ncand > 0) {
     if (l1_serial) l1_scan_kernel<true><<<dim3(rblk), dim3(128), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, nullptr, M->cand_off.p, M->cand.p, M->cand_read.p);
-    else l1_wave_kernel<true><<<dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, nullptr, M->cand_off.p, M->cand.p, M->cand_read.p, cand_hint.p);
+    else l1_wave_kernel<true><<<dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st>>>(M->hits.p, M->read_hit_off.p, M->d_read_len.p, M->min_hits.p, n, nullptr, M->cand_off.p, M->cand.p, M->cand_read.p, no_hint ? nullptr : cand_hint.p);
     MM_KERNEL_CHECK();
     T.end(t_l1);
     // ---- K5/K6

@@ -556,8 +556,17 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
   while (((nwords + (1 << bwl) - 1) >> bwl) > L2_NBLK_MAX) ++bwl;
   const int nblk = (nwords + (1 << bwl) - 1) >> bwl;
   const int bspan = 64 << bwl;
-  int eLo[2] = {last_end, last_end}, eHi[2] = {0, 0}, ub_all[2] = {-1, -1}, ub2[2] = {-1, -1};
-  auto lane2 = [&](const int (&v)[2], int kk) -> int { return __builtin_amdgcn_readlane(kk < 64 ? v[0] : v[1], kk & 63); };
+  // Per block (128 at most): e_min of its first window start and its bound live in LDS — where W0 lay, which is done with once the searches below are —
+  // and the three flags per block in the slide's spare scratch words.  (As lane-distributed registers, two blocks per lane, these seven arrays were live
+  // through the whole sweep, and the allocator spilled ~36 registers around it for every candidate.)
+  uint16_t* const eLoL = (uint16_t*)W0;                          // [128]
+  uint16_t* const ub2L = eLoL + 128;                             // [128] bound + 1 (0: no bound / not eligible)
+  uint32_t* const fUpW = (uint32_t*)tst;                         // [4] blocks with a window whose pivot lies above the current band
+  uint32_t* const fDnW = fUpW + 4;                               // [4] ... below it
+  uint32_t* const eligW = fDnW + 4;                              // [4] blocks this pass may visit
+  auto e_of = [&](int kk) -> int { return __builtin_amdgcn_readfirstlane((int)eLoL[kk]); };
+  auto ub_of = [&](int kk) -> int { return __builtin_amdgcn_readfirstlane((int)ub2L[kk]) - 1; };
+  int ubmax = -1, wo_est = 0;
   {
     int tg[2], lo[2], hi[2];
 #pragma unroll
@@ -593,6 +602,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
         lo[qq] = min(lo[qq] + adv * step, hi[qq]);
       }
     }
+    int eLo[2], eHi[2], ub_all[2];
     eLo[0] = lane < nblk ? lo[0] : last_end;
     eLo[1] = lane + 64 < nblk ? lo[1] : last_end;
     // per block: largest window [bF, eHi), smallest window [bL, eLo)   (lane l owns blocks l and l+64)
@@ -609,8 +619,18 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
         if (eLo[q] < last_end) ub_all[q] = pfx(mAll, pAll, eHi[q]) - pfx(mAll, pAll, bF);
       } else eLo[q] = eHi[q] = last_end;
     }
+    ubmax = wave_max(max(ub_all[0], ub_all[1]));
+    // the block with the most matched entries has the fewest window-only ones: what its smallest window holds besides them
+    const int key = max(ub_all[0], ub_all[1]) == ubmax ? ((ub_all[0] == ubmax) ? lane : lane + 64) : 1 << 20;
+    const int bkb = wave_min(key);
+    const int bLb = min(bkb * bspan + bspan - 1, last_end - 1);
+    const int eb = __builtin_amdgcn_readlane(bkb < 64 ? eLo[0] : eLo[1], bkb & 63);
+    wo_est = max(eb - bLb - ubmax, 0);
+    wave_sync();                                                 // (W0 has been read for the last time)
+    eLoL[lane] = (uint16_t)eLo[0]; eLoL[lane + 64] = (uint16_t)eLo[1];
+    if (lane < 4) { fUpW[lane] = 0; fDnW[lane] = 0; eligW[lane] = 0xffffffffu; }
+    wave_sync();
   }
-  const int ubmax = wave_max(max(ub_all[0], ub_all[1]));
   lap(2);
   if (dbg_stop == 3) { release_slot(); return; }
 
@@ -622,9 +642,8 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
   bool has_lo = false;
   int best = 0, bestR = 0, beg_pos = 0, last_pos = 0, opt_b = 0, opt_e = 0, last_b = 0;
   unsigned long long evals = 0, rebuilds = 0, rounds = 0;
-  int fUp[2] = {0, 0}, fDn[2] = {0, 0};                          // blocks with a window whose pivot lies above / below the current band
   int zdir = 0, n_pass = 0, n_low = 0;                                      // 0: first pass, +1: bands above it, -1: bands below it
-  auto flag_block = [&](int (&f)[2], int kk) { if (lane == (kk & 63)) { if (kk < 64) f[0] = 1; else f[1] = 1; } };
+  auto flag_block = [&](uint32_t* f, int kk) { if (lane == 0) atomicOr(&f[kk >> 5], 1u << (kk & 31)); };
   // pass B: the masks of the band and its reference rank from a second reading of the stream (l2z_pass_b above)
   auto pass_low = [&]() {
     band_thresholds();
@@ -895,8 +914,8 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
       const uint64_t fu = canU ? 0ull : (um & vis), fd = canD ? 0ull : (dm & vis);
       if ((fu && zdir >= 0) || (fd && zdir <= 0)) {
         const int bk2 = (b + 63 >= blk_end && bk + 1 < nblk) ? bk + 1 : bk;
-        if (fu && zdir >= 0) { flag_block(fUp, bk); flag_block(fUp, bk2); }
-        if (fd && zdir <= 0) { flag_block(fDn, bk); flag_block(fDn, bk2); }
+        if (fu && zdir >= 0) { flag_block(fUpW, bk); flag_block(fUpW, bk2); }
+        if (fd && zdir <= 0) { flag_block(fDnW, bk); flag_block(fDnW, bk2); }
       }
       const bool scored = lane < n_vis && !outU && !outD;
       const int sh_j = scored ? sb_j + __popcll(pm_j & ((1ull << (pj & 63)) - 1ull)) : -1;
@@ -929,7 +948,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
       b += dn; e += an;
       while (b >= blk_end) {                                     // entered the next block: does its bound still pass?
         ++bk;
-        if (bk >= nblk || (stage == 1 && bk == j0) || lane2(ub2, bk) < max(best, amin)) { run_stop = true; break; }
+        if (bk >= nblk || (stage == 1 && bk == j0) || ub_of(bk) < max(best, amin)) { run_stop = true; break; }
         blk_end += bspan;
       }
       if (run_stop) break;
@@ -947,13 +966,8 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
   if (dbg_stop == 9) { release_slot(); return; }
   bool any_pass = ubmax >= amin;                                 // otherwise no window can reach the acceptance threshold
   bool masks_ready = false;                                      // the band's masks came out of pass A
-  int elig[2] = {1, 1};
   if (any_pass) {
-    // the same estimate from what pass A found: the block with the most matched entries has the fewest window-only ones
-    const int key = max(ub_all[0], ub_all[1]) == ubmax ? ((ub_all[0] == ubmax) ? lane : lane + 64) : 1 << 20;
-    const int bkb = wave_min(key);
-    const int bLb = min(bkb * bspan + bspan - 1, last_end - 1);
-    const int wo = max(lane2(eLo, bkb) - bLb - ubmax, 0);
+    const int wo = wo_est;
     const int zb_p = zb, r_ref_p = r_ref;
     r_est = set_band((float)wo, L2Z_CENTRE_SIG);                  // (what the matched counts ask for)
     if (fused) {
@@ -972,17 +986,23 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     fill_band_hashes();
     lap(5);
     if (dbg_stop == 7) { release_slot(); return; }
+    wave_sync();
+    int ub2[2];
     for (int q = 0; q < 2; ++q) {
       const int bq = lane + 64 * q;
       int u = -1;
-      if (bq < nblk && eLo[q] < last_end && elig[q]) {
+      const int eLo_q = bq < nblk ? (int)eLoL[bq] : last_end;
+      if (bq < nblk && eLo_q < last_end && ((eligW[bq >> 5] >> (bq & 31)) & 1u)) {
         const int bF = bq * bspan, bL = min(bF + bspan - 1, last_end - 1);
-        const int a = eLo[q] > bL ? pfx(mA, pA, eLo[q]) - pfx(mA, pA, bL) : 0;
+        const int eHi_q = (bL + 1 < last_end && bq + 1 < nblk) ? (int)eLoL[bq + 1] : last_end;   // largest window of the block: up to e_min of the next block's start
+        const int a = eLo_q > bL ? pfx(mA, pA, eLo_q) - pfx(mA, pA, bL) : 0;
         // r_ref + a >= s: every window of the block has its pivot at or below r_ref, so it shares at most the matched entries at or below Q[r_ref]
-        u = (r_ref + a >= s) ? pfx(mLo, pLo, eHi[q]) - pfx(mLo, pLo, bF) : ub_all[q];
+        u = (r_ref + a >= s) ? pfx(mLo, pLo, eHi_q) - pfx(mLo, pLo, bF) : pfx(mAll, pAll, eHi_q) - pfx(mAll, pAll, bF);
       }
       ub2[q] = u;
     }
+    ub2L[lane] = (uint16_t)(ub2[0] + 1); ub2L[lane + 64] = (uint16_t)(ub2[1] + 1);
+    wave_sync();
     int bkmax = 0, done_hi = nblk;
     if (zdir == 0) {
       // the sweep starts a little before the block with the largest bound, so that the maximum is known early and
@@ -991,7 +1011,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
       const int key2 = max(ub2[0], ub2[1]) == u2max ? ((ub2[0] == u2max) ? lane : lane + 64) : 1 << 20;
       bkmax = wave_min(key2);
       j0 = bkmax;
-      while (j0 > 0 && bkmax - j0 < 3 && 100 * lane2(ub2, j0 - 1) >= 95 * u2max) --j0;
+      while (j0 > 0 && bkmax - j0 < 3 && 100 * ub_of(j0 - 1) >= 95 * u2max) --j0;
       stage = 0; bk = j0;
     } else { stage = 1; j0 = -1; bk = 0; }
     lap(2);
@@ -1003,14 +1023,14 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
       for (;;) {
         if (stage == 1 && bk == j0) bk = done_hi;
         if (bk >= nblk) { if (stage == 0) { done_hi = nblk; stage = 1; bk = 0; continue; } break; }
-        if (lane2(ub2, bk) >= max(best, amin)) { found = true; break; }
+        if (ub_of(bk) >= max(best, amin)) { found = true; break; }
         if (stage == 0 && bk >= bkmax) { done_hi = bk + 1; stage = 1; bk = 0; continue; }
         ++bk;
       }
       if (!found) break;
       const int nb = bk * bspan;
       blk_end = nb + bspan; run_stop = false;
-      b = nb; e = lane2(eLo, bk); pending_rebuild = true;
+      b = nb; e = e_of(bk); pending_rebuild = true;
       lap(2);
       block_slide();
       lap(4);
@@ -1021,18 +1041,19 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
       }
     }
     // the next band: upwards while windows asked for it, then downwards from the first one
-    const bool wantU = __ballot(fUp[0] | fUp[1]) != 0ull, wantD = __ballot(fDn[0] | fDn[1]) != 0ull;
+    wave_sync();
+    const bool wantU = __ballot(lane < 4 && fUpW[lane & 3] != 0u) != 0ull, wantD = __ballot(lane < 4 && fDnW[lane & 3] != 0u) != 0ull;
     if (zdir >= 0 && wantU && zb < zb_top) {
       zdir = 1; zb = min(zb + BAND, zb_top);
       r_ref = min(zb + BAND, s) - 1;
-      elig[0] = fUp[0]; elig[1] = fUp[1]; fUp[0] = fUp[1] = 0;
+      if (lane < 4) { eligW[lane] = fUpW[lane]; fUpW[lane] = 0; }
       continue;
     }
     if (zdir >= 0) { zdir = -1; zb = zb_first; }
     if (wantD && zb > 0) {
       zb = max(0, zb - BAND);
       r_ref = min(zb + BAND, s) - 1;
-      elig[0] = fDn[0]; elig[1] = fDn[1]; fDn[0] = fDn[1] = 0;
+      if (lane < 4) { eligW[lane] = fDnW[lane]; fDnW[lane] = 0; }
       continue;
     }
     break;

@@ -233,7 +233,17 @@ __global__ void __launch_bounds__(MZ_THREADS) __attribute__((amdgpu_waves_per_eu
     // is a funnel shift of (w0,w1,w2); its reverse complement is the byte-swapped complement words
     const uint64_t* f64 = (const uint64_t*)fwd;
     const uint64_t* c64 = (const uint64_t*)cmp;
-    for (int g = tid; g * 8 < np; g += MZ_THREADS) {
+    // The tile's own 2 048 positions are exactly one group of eight per thread.  The halo in front of them (16 positions at w = 8) would be two more groups
+    // — a second trip through this loop for the whole first wavefront with two lanes at work (a sixth of the kernel's instructions); it is hashed
+    // position by position instead, a lane each, by the byte-wise form of the same hash.
+    const int hb8 = P0 > H0 ? (P0 - H0) : 0;                      // positions of the halo (a multiple of 8)
+    for (int j = tid; j < hb8; j += MZ_THREADS) {
+      const uint32_t hf = murmur_bytes<false>(fwd + j, 16);
+      const uint32_t hb = murmur_bytes<true>(cmp + j + 15, 16);
+      hsh[j] = hf < hb ? hf : hb;
+      flg[j] = (uint8_t)((hf != hb ? 1 : 0) | (hf < hb ? 2 : 0));
+    }
+    for (int g = (hb8 >> 3) + tid; g * 8 < np; g += MZ_THREADS) {
       const uint64_t w0 = f64[g], w1 = f64[g + 1], w2 = f64[g + 2];
       const uint64_t c0 = c64[g], c1 = c64[g + 1], c2 = c64[g + 2];
       uint32_t hq[8]; uint64_t fq = 0;
@@ -268,7 +278,20 @@ __global__ void __launch_bounds__(MZ_THREADS) __attribute__((amdgpu_waves_per_eu
   if (w <= 9) {
     // eight consecutive positions per thread: the 16 (hash, flag) pairs they can look at are read once with vector loads and
     // the eight arg-mins are found in registers (same scan order: from the position itself down, strictly smaller wins)
-    for (int g = tid; g * 8 < np; g += MZ_THREADS) {
+    // (as above: the few evaluated positions of the halo — w - 1 of them — are taken one per lane by the plain scan, the tile's own 2 048 are one group per thread)
+    const int hb8 = P0 > H0 ? (P0 - H0) : 0;
+    for (int j = jeval0 + tid; j < hb8; j += MZ_THREADS) {
+      uint16_t c = 0xFFFF;
+      if (flg[j] & 1) {
+        uint32_t best = hsh[j]; int bj = j;
+        const int qlo = max(j - w + 1, 0);
+        for (int q = j - 1; q >= qlo; --q)
+          if ((flg[q] & 1) && hsh[q] < best) { best = hsh[q]; bj = q; }
+        c = (uint16_t)bj;
+      }
+      cps[j] = c;
+    }
+    for (int g = (hb8 >> 3) + tid; g * 8 < np; g += MZ_THREADS) {
       uint32_t h[16]; uint8_t f[16];
       {
         const uint4 a = g ? *reinterpret_cast<const uint4*>(hsh + 8 * g - 8) : make_uint4(0, 0, 0, 0);

@@ -367,6 +367,28 @@ __global__ void __launch_bounds__(MZ_THREADS) __attribute__((amdgpu_waves_per_eu
   const int js = jstar[s];
   const int j0 = (P0 - H0) + tid * (MZ_TILE / MZ_THREADS);
   uint32_t mask = 0;
+  static_assert(MZ_TILE / MZ_THREADS == 8, "eight positions per thread");
+  // Nearly always all eight positions and the one before them are non-symmetric: the previous evaluated position is then simply the one before, and the
+  // flags and window minima of the nine come with three loads.  Anything else (symmetric k-mers, the first window, the end of the sequence) takes the
+  // position-by-position form below.
+  bool fast = false;
+  if (w >= 2 && j0 + 8 <= np && H0 + j0 - 1 >= w - 1 && j0 >= 1) {   // (w = 1: a window holds no earlier position)
+    const uint2 fw = *reinterpret_cast<const uint2*>(flg + j0);
+    const uint32_t fprev = flg[j0 - 1];
+    fast = (fw.x & fw.y & 0x01010101u) == 0x01010101u && (fprev & 1u);
+    if (fast) {
+      const uint4 cw = *reinterpret_cast<const uint4*>(cps + j0);   // eight 16-bit positions of the minima
+      const uint32_t cprev = cps[j0 - 1];
+      const uint32_t c[9] = {cprev, cw.x & 0xffffu, cw.x >> 16, cw.y & 0xffffu, cw.y >> 16, cw.z & 0xffffu, cw.z >> 16, cw.w & 0xffffu, cw.w >> 16};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int p = H0 + j0 + i;
+        const bool emit = c[i] != c[i + 1] && !(p > w - 1 && p < js);
+        mask |= (emit ? 1u : 0u) << i;
+      }
+    }
+  }
+  if (!fast) {
 #pragma unroll
   for (int i = 0; i < MZ_TILE / MZ_THREADS; ++i) {
     int j = j0 + i, p = H0 + j;
@@ -378,6 +400,7 @@ __global__ void __launch_bounds__(MZ_THREADS) __attribute__((amdgpu_waves_per_eu
       if (p > w - 1 && p < js) emit = false;
       if (emit) mask |= 1u << i;
     }
+  }
   }
   const uint32_t cnt = __popc(mask);
   uint64_t tot;

@@ -78,7 +78,7 @@ __host__ __device__ constexpr int l2z_band(int nwq) { return nwq == 2 ? 128 : 51
 #define L2Z_CENTRE_SIG_PRED 0.43f
 #endif
 #ifndef L2Z_REF_SIG
-#define L2Z_REF_SIG 3.5f
+#define L2Z_REF_SIG (NWQ == 2 ? 3.0f : 4.5f)                     // (measured, ms of K5 on the 10 kb bench batch / on 20 000 reads of 20-50 kb: 3.0 11.58 / 11.59, 3.5 11.58 / 10.88, 4.5 11.76 / 10.27)
 #endif
 // per-wave LDS: the first entry's position of every word (pass A writes, the e_min searches read) | a region used by pass A as
 // {ring of (hash, entry) pairs, matched bits of the current group of 64 words} and afterwards as {band gap counters / prefixes, the band's

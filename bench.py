@@ -697,8 +697,8 @@ def roofline_block(args, R):
                     agg["ms_hf"] / nl, 8.0 * agg["hf_units"] / nl, ["mm::seed_filter_stream_kernel<false>"],
                     "two things (DESIGN.md section 7): what a CU executes per read (the time follows the CUs at work: profiles/r05_sf_grid_sweep.txt; VALU 37 percent, LDS atomics, 13 barriers) and the memory side's rate "
                     "of random 64-byte requests - table sector, list pieces, survivors: 5.3e8 per launch (FETCH_SIZE) against 47e9 requests/s over a 90 GB footprint, which 64 CUs reach alone (profiles/r05_randread_cus.txt)"),
-        "K5": entry("l2z_kernel<4,2,true> + l2z_kernel<2,2,true> (the zone kernel's launch pair of a step: mm_map_stats.ms_l2)", st_a["ms_l2"], 8.0 * st_a["sum_l2_stream_entries"],
-                    agg["ms_l2"] / nl, 8.0 * agg["l2_stream"] / nl, ["mm::l2z_kernel<4, 2, true>", "mm::l2z_kernel<2, 2, true>"],
+        "K5": entry("l2z_kernel<4,2,true> + l2z_kernel<2,2,false> (the zone kernel's launch pair of a step: mm_map_stats.ms_l2)", st_a["ms_l2"], 8.0 * st_a["sum_l2_stream_entries"],
+                    agg["ms_l2"] / nl, 8.0 * agg["l2_stream"] / nl, ["mm::l2z_kernel<4, 2, true>", "mm::l2z_kernel<2, 2, false>"],
                     "instruction issue: 1.8 VALU + 1.5 scalar wave-instructions per streamed entry (l2_kernel, round 5: 2.8 + 1.3), VALU 62 percent busy (profiles/r06_sq_counters.txt); the stream is read once "
                     "(the band's threshold masks come out of pass A); phase shares: profiles/r06_l2_phases.txt"),
     }

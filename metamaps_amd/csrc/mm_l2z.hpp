@@ -641,7 +641,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
   uint32_t Qz = 0xffffffffu, tau_lo = 0, tau_hi = 0;            // Q[z0 + lane]; Q[z0 - 1]; Q[min(z0 + 64, s) - 1]
   bool has_lo = false;
   int best = 0, bestR = 0, beg_pos = 0, last_pos = 0, opt_b = 0, opt_e = 0, last_b = 0;
-  unsigned long long evals = 0, rebuilds = 0, rounds = 0;
+  uint32_t evals = 0, rebuilds = 0, rounds = 0;                   // (diagnostics of the result record: 32 bits there too)
   int zdir = 0, n_pass = 0, n_low = 0;                                      // 0: first pass, +1: bands above it, -1: bands below it
   auto flag_block = [&](uint32_t* f, int kk) { if (lane == 0) atomicOr(&f[kk >> 5], 1u << (kk & 31)); };
   // pass B: the masks of the band and its reference rank from a second reading of the stream (l2z_pass_b above)
@@ -878,6 +878,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
       const int thr = s - cbase_j;
       auto pivot_of = [&]() -> int { return rank_search(fz, thr); };
       int pj = pivot_of();
+      int pc = pj;                                                // the lane's pivot under the zone events applied so far
       uint64_t pm_j = pm;
       uint64_t zE = __ballot(vE && !loE), zB = __ballot(vB && !loB);   // zone events in step order (each one changes the windows after its step)
       const uint64_t mEm = __ballot(mE), mBm = __ballot(mB);
@@ -896,9 +897,14 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
           pm ^= bit;
           if (lane > kk) pm_j ^= bit;
         } else {
+          // fz[r] = r + C(r) is strictly increasing and the event moves it by one from rank zi on: the first rank that reaches the lane's threshold
+          // moves by one rank at most (mm_l2_core.hpp, l2_wonly_event) — one look at the neighbour instead of a search of seven steps
           fz += (lane >= zi) ? sign : 0;
-          const int p2 = pivot_of();
-          if (lane > kk) pj = p2;
+          const int at = sign > 0 ? pc - 1 : pc;
+          const int fv = __shfl(fz, min(max(at, 0), 63), 64);
+          if (sign > 0) { if (pc > 0 && fv >= thr) --pc; }
+          else { if (pc < 64 && fv < thr) ++pc; }
+          if (lane > kk) pj = pc;
         }
       }
       // A window whose pivot left the zone: the zone is re-centred there if the band still holds the pivot (the windows before it are
@@ -939,7 +945,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
           if (b + __builtin_amdgcn_readlane(dj, j1) < opt_b) set_first();
           if (b + __builtin_amdgcn_readlane(dj, jl) > last_b) set_last();
         }
-        evals += (unsigned long long)__popcll(__ballot(scored));
+        evals += (uint32_t)__popcll(__ballot(scored));
       }
       // state of window n_vis
       int dn, an;
@@ -988,8 +994,11 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     if (dbg_stop == 7) { release_slot(); return; }
     wave_sync();
     int ub2[2];
+    int lane_b = lane;
+    asm volatile("" : "+v"(lane_b));                            // (a lane number the compiler cannot see through: everything below that depends on the lane alone was hoisted out of the band
+                                                                 //  loop — which runs once for nine candidates in ten — and kept in scratch: 29 stores per candidate, 5.7 GB per batch)
     for (int q = 0; q < 2; ++q) {
-      const int bq = lane + 64 * q;
+      const int bq = lane_b + 64 * q;
       int u = -1;
       const int eLo_q = bq < nblk ? (int)eLoL[bq] : last_end;
       if (bq < nblk && eLo_q < last_end && ((eligW[bq >> 5] >> (bq & 31)) & 1u)) {
@@ -1001,14 +1010,14 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
       }
       ub2[q] = u;
     }
-    ub2L[lane] = (uint16_t)(ub2[0] + 1); ub2L[lane + 64] = (uint16_t)(ub2[1] + 1);
+    ub2L[lane_b] = (uint16_t)(ub2[0] + 1); ub2L[lane_b + 64] = (uint16_t)(ub2[1] + 1);
     wave_sync();
     int bkmax = 0, done_hi = nblk;
     if (zdir == 0) {
       // the sweep starts a little before the block with the largest bound, so that the maximum is known early and
       // the rest (left flank afterwards, right flank on the way) is pruned against it
       const int u2max = wave_max(max(ub2[0], ub2[1]));
-      const int key2 = max(ub2[0], ub2[1]) == u2max ? ((ub2[0] == u2max) ? lane : lane + 64) : 1 << 20;
+      const int key2 = max(ub2[0], ub2[1]) == u2max ? ((ub2[0] == u2max) ? lane_b : lane_b + 64) : 1 << 20;
       bkmax = wave_min(key2);
       j0 = bkmax;
       while (j0 > 0 && bkmax - j0 < 3 && 100 * ub_of(j0 - 1) >= 95 * u2max) --j0;
@@ -1109,7 +1118,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     o.contig = contig; o.mean_pos = (beg_pos + last_pos) / 2;    // :537
     o.shared = best; o.strand = strand; o.accepted = accepted; o.pad = n_low;   // (pad: passes over the stream beyond the first, a diagnostic summed by l2_stats_kernel)
     o.opt_beg = first0 + opt_b; o.opt_end = first0 + opt_e;
-    o.n_stream = (uint32_t)M; o.n_evals = (uint32_t)evals; o.n_rebuilds = (uint32_t)rebuilds; o.pad2 = (uint32_t)rounds;
+    o.n_stream = (uint32_t)M; o.n_evals = evals; o.n_rebuilds = rebuilds; o.pad2 = rounds;
     if (dbg_flags & 0x400) { o.mean_pos = bestR - ((dbg_flags & 0x800) ? r_pred : r_est); o.shared = n_low; }   // MM_L2Z_DBG: where the pivot of the best window lay against the estimate (results are then meaningless)
     out[c] = o;
     lap(6);

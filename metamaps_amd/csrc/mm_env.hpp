@@ -91,7 +91,7 @@ inline const EnvSwitch* env_table(size_t* n) {
     {"MM_L2_NO_SLOTS", "unset", "test", "K5 scratch indexed by wave number of the launch instead of per-XCD slots taken and given back"},
     {"MM_L2_SLOTS", "auto (resident waves)", "tuning", "number of K5 scratch slots"},
     {"MM_L2_STOP", "0", "debug", "K5 leaves after phase n WITHOUT RESULTS (tools/l2_stop.py)"},
-    {"MM_L2_PHASES", "unset", "debug", "K5 phase clocks into its counters (tools/l2_long_phases.py)"},
+    {"MM_L2_PHASES", "unset", "debug", "K5 phase clocks into its counters (tools/l2_long_phases.py; the zone kernel has them in a build with -DL2Z_CLOCKS only)"},
     {"MM_MZ_DBG", "0", "debug", "K1 leaves after step n WITHOUT RESULTS (tools/stage_ms.py)"},
     {"MM_SF_DBG", "0", "debug", "fused seed filter leaves after phase n WITHOUT RESULTS (tools/sf_dbg.py)"},
     {"MM_HF_DBG", "0", "debug", "two-pass filter leaves after phase n WITHOUT RESULTS"},

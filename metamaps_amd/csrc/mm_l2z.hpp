@@ -313,8 +313,13 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     return;
   }
 
-  // phase clocks (MM_L2_PHASES): setup, passA, bounds, rebuild, slide, passB, vote — kept in LDS so that they cost no registers when off
+  // phase clocks (MM_L2_PHASES, builds with -DL2Z_CLOCKS): setup, passA, bounds, rebuild, slide, passB, vote — in LDS.  Compiled out otherwise: as a run-time
+  // switch they cost the kernel 0.26 of 9.9 ms (a branch per lap inside the slide, the clock's registers live across it)
+#ifdef L2Z_CLOCKS
   const bool prof = (dbg_flags & 0x100) != 0;
+#else
+  constexpr bool prof = false;                                   // (the clocks cost the slide two scalar registers, a branch per lap and the spills that go with them: a build with -DL2Z_CLOCKS has them)
+#endif
   long long* const tphL = (long long*)(wbase + l2z_wave_bytes(NWQ, QLDS) - 64);
   long long tmark = 0;
   if (prof) { if (lane < 8) tphL[lane] = 0; tmark = clock64(); }

@@ -13,6 +13,7 @@ timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ou
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python bench.py --steps 1 --warmup 0 --workers 1 --distinct-batches 1 $FLAGS > /dev/null 2> $out/write.err
 python tools/summarize_profiles.py $out
 # K5 phase clocks on the bench batch (10^5 x 10 kb), the probed-list distribution and the random-request ceiling (round 5)
+# (the zone kernel's clocks: build them in before calling gpurun — tools/ab_build.sh clocks "-DL2Z_CLOCKS")
 timeout 600 python tools/l2_long_phases.py 10000 10000 100000 > $out/l2_phases.txt 2>&1
 if [ -n "$EXTRAS" ]; then   # (round 5's K3 studies: the probed-list distribution, the random-request ceiling, the CU sweep, LDS rates, K3's phase clocks)
 timeout 600 python tools/probed_lists.py > $out/probed_lists.json 2> /dev/null

@@ -1,8 +1,14 @@
 """K5 phase clocks (MM_L2_PHASES) and stage times for reads of one length band against the bench's community index:
-   python tools/l2_long_phases.py LO HI N   (defaults 32000 50000 20000)"""
+   python tools/l2_long_phases.py LO HI N   (defaults 32000 50000 20000)
+The zone kernel carries its clocks only in a build with -DL2Z_CLOCKS (`tools/ab_build.sh clocks "-DL2Z_CLOCKS"` -> _ab/clocks/, picked up here when it exists;
+without it the zone kernel's clocks read 0 and only the stage times and counts below are meaningful)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if not os.environ.get("MM_LIB_PATH") and os.path.exists(os.path.join(ROOT, "_ab", "clocks", "libmetamaps_hip.so")):
+    os.environ["MM_LIB_PATH"] = os.path.join(ROOT, "_ab", "clocks", "libmetamaps_hip.so")
+    print("(library: _ab/clocks/libmetamaps_hip.so, the build with the zone kernel's phase clocks)", flush=True)
 import bench
 from metamaps_amd import capi
 

@@ -99,7 +99,7 @@ inline const EnvSwitch* env_table(size_t* n) {
     // ---- library: EM and exchange (mm_post.hip, mm_api.hip)
     {"MM_EM_FORCE_COLLECTIVE", "unset", "test", "a one-rank communicator keeps P1-P3' | ncclAllReduce | finalize instead of the plain loop (how one GPU drives the multi-rank path)"},
     {"MM_EM_RESIDENT", "unset", "tuning", "EM as one resident kernel with grid barriers instead of one launch per phase (measured: slower, DESIGN.md section 4)"},
-    {"MM_EM_SPLIT", "unset", "test", "with MM_EM_RESIDENT: the phases as launches all the same (cross-check)"},
+    {"MM_EM_SPLIT", "unset", "test", "with MM_EM_RESIDENT: the phases as launches all the same (cross-check); 2: P2 and P3 in one launch (measured slower than a launch per phase)"},
     {"MM_EM_GRID", "256 (128 resident)", "tuning", "workgroups of the EM kernels"},
     {"MM_EM_BARRIER_TICKS", "2 s", "test", "time-out of the resident kernel's grid barrier before it hands the run to the launch path"},
     {"MM_CLI_FORMAT_PART", "10000", "test", "mapping records per formatter thread of a batch (the text of a batch is formatted in up to eight parts and joined)"},

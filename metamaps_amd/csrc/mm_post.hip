@@ -610,6 +610,26 @@ __global__ void __launch_bounds__(256) em_p1_kernel(EmLoop a) { __shared__ doubl
 __global__ void __launch_bounds__(256) em_p2_kernel(EmLoop a) { if (a.ctrl[1]) return; em_p2(a, blockIdx.x, gridDim.x); }
 template <bool LOCAL>
 __global__ void __launch_bounds__(256) em_p3_kernel(EmLoop a, int n_wg) { __shared__ double sh[256]; if (a.ctrl[1]) return; em_p3<LOCAL>(a, n_wg, sh); }
+// P2 and P3 in one launch (round 6, MM_EM_SPLIT=2): the workgroup that finishes its items last runs P3 — the hand-over of the resident kernel's second barrier
+// (arrive, agent-scope release / acquire) without anybody waiting, so it needs no co-residency.  An iteration is then two launches (with several ranks: kernel A',
+// this one, the all-reduce and kernel B) instead of three (five).  bar[2]: workgroups done with P2; the last one puts it back to zero.
+// NOT the default: it measured slower than the launch it saves (see em_run).
+template <bool LOCAL>
+__global__ void __launch_bounds__(256) em_p23_kernel(EmLoop a) {
+  __shared__ double sh[256];
+  __shared__ int s_last;
+  if (a.ctrl[1]) return;
+  em_p2(a, blockIdx.x, gridDim.x);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int last = __hip_atomic_fetch_add(&a.bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == gridDim.x;
+    if (last) { __threadfence(); __hip_atomic_store(&a.bar[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    s_last = last;
+  }
+  __syncthreads();
+  if (s_last) em_p3<LOCAL>(a, (int)gridDim.x, sh);
+}
 // kernel B of a multi-rank iteration: normalise the all-reduced sums (fEM.h:606-615; fixed-shape sum over the taxa, the same on every
 // rank), log-likelihood trace, stop rule (:624-639)
 __global__ void __launch_bounds__(256) em_finalize_kernel(const double* __restrict__ partial, int32_t n_taxa, double* __restrict__ f, long long* __restrict__ ctrl,
@@ -721,6 +741,10 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
   // than three launches on one stream do.
   const bool force_split = getenv("MM_EM_RESIDENT") == nullptr || getenv("MM_EM_SPLIT") != nullptr;
   bool split = force_split || ctx->em_split;
+  // MM_EM_SPLIT=2: P2 and P3 in one launch (em_p23_kernel).  Measured in round 6 (tools/em_latency.py, idle GPU): 48.4 us per iteration against 34.7 with a launch
+  // per phase — 256 agent-scope releases (an L2 write-back each) and the arrival counter cost more than the launch they save.  Kept as the record of that.
+  const bool three_launches = !(getenv("MM_EM_SPLIT") && atoi(getenv("MM_EM_SPLIT")) == 2);
+  if (force_split) E->bar.zero(st);                              // (bar[2]: em_p23_kernel's arrival count)
   // a communicator of ONE rank has nothing to exchange: the run is the resident kernel, as without a communicator (MM_EM_FORCE_COLLECTIVE=1
   // keeps kernel A | ncclAllReduce | kernel B also then: how the tests drive the collective path on a one-GPU box)
   const bool collective = ctx->comm && (ctx->comm_size > 1 || getenv("MM_EM_FORCE_COLLECTIVE") != nullptr);
@@ -755,10 +779,14 @@ int em_run(mm_em* E, const double* f0, int max_iter, double* f_out, double* ll_t
           E->bar.zero(st);
           em_loop_kernel<true><<<grid, blk, 0, st>>>(a);
           MM_KERNEL_CHECK();
-        } else {
+        } else if (three_launches) {
           em_p1_kernel<<<grid, blk, 0, st>>>(a); MM_KERNEL_CHECK();
           em_p2_kernel<<<grid, blk, 0, st>>>(a); MM_KERNEL_CHECK();
           if (collective) em_p3_kernel<true><<<dim3(1), blk, 0, st>>>(a, E->n_wg); else em_p3_kernel<false><<<dim3(1), blk, 0, st>>>(a, E->n_wg);
+          MM_KERNEL_CHECK();
+        } else {
+          em_p1_kernel<<<grid, blk, 0, st>>>(a); MM_KERNEL_CHECK();
+          if (collective) em_p23_kernel<true><<<grid, blk, 0, st>>>(a); else em_p23_kernel<false><<<grid, blk, 0, st>>>(a);
           MM_KERNEL_CHECK();
         }
         if (collective) {                                        // fEM.h:583-600, across GPUs instead of OpenMP threads

@@ -227,6 +227,8 @@ def test_em_resident_kernel_equals_its_phases_as_launches(n_reads, n_taxa, monke
         assert f_a[1] == f_a[2] and f_a[1] > 0                    # the twins
     f_b, ll_b, best_b = run(G)                                    # the default form: one launch per phase
     assert np.array_equal(f_a, f_b) and np.array_equal(ll_a, ll_b) and np.array_equal(best_a, best_b)
+    f_3, ll_3, best_3 = run({"MM_EM_SPLIT": "2", **G})            # P1 | P2 + P3 (the workgroup that finishes its items last runs P3: measured slower, kept as the record)
+    assert np.array_equal(f_a, f_3) and np.array_equal(ll_a, ll_3) and np.array_equal(best_a, best_3)
     f_c, ll_c, best_c = run({"MM_EM_RESIDENT": "1", "MM_EM_BARRIER_TICKS": "1", **G})
     assert np.array_equal(f_a, f_c) and np.array_equal(ll_a, ll_c)
     f_0, ll_0, _ = run({})                                        # the default grid
@@ -239,7 +241,7 @@ def test_em_resident_kernel_equals_its_phases_as_launches(n_reads, n_taxa, monke
         assert len(ll_g) == len(ll_a) and np.allclose(ll_g, ll_a, rtol=1e-12, atol=0) and np.allclose(f_g, f_a, rtol=1e-10, atol=1e-300)
         if T > 4:
             assert f_g[1] == f_g[2]
-    for env in ({}, {"MM_EM_RESIDENT": "1"}, {"MM_EM_RESIDENT": "1", "MM_EM_BARRIER_TICKS": "1"}):
+    for env in ({}, {"MM_EM_SPLIT": "2"}, {"MM_EM_RESIDENT": "1"}, {"MM_EM_RESIDENT": "1", "MM_EM_BARRIER_TICKS": "1"}):
         f_m, ll_m, _ = run(env, comm=True)
         assert len(ll_m) == len(ll_a) and np.allclose(ll_m, ll_a, rtol=1e-12, atol=0) and np.allclose(f_m, f_a, rtol=1e-10, atol=1e-300)
         if T > 4:

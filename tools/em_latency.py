@@ -31,8 +31,9 @@ def main():
     off, taxon, mapq, inv, T = problem(n_reads)
     print(f"{n_reads} reads, {len(taxon)} mappings, {T} taxa, largest taxon {np.bincount(taxon).max()} mappings")
     f0 = np.full(T, 1.0 / T)
-    variants = [("launch per phase (default)", {}), ("thread-per-read P1", {"MM_EM_DBG": "3"}), ("resident grid 128", {"MM_EM_RESIDENT": "1"}), ("resident grid 64", {"MM_EM_GRID": "64", "MM_EM_RESIDENT": "1"}), ("resident grid 256", {"MM_EM_GRID": "256", "MM_EM_RESIDENT": "1"}), ("launches, grid 256", {"MM_EM_GRID": "256"}), ("launches, grid 1024", {"MM_EM_GRID": "1024"}),
+    variants = [("launch per phase (default)", {}), ("P1 | P2+P3 in one launch", {"MM_EM_SPLIT": "2"}), ("thread-per-read P1", {"MM_EM_DBG": "3"}), ("resident grid 128", {"MM_EM_RESIDENT": "1"}), ("resident grid 64", {"MM_EM_GRID": "64", "MM_EM_RESIDENT": "1"}), ("resident grid 256", {"MM_EM_GRID": "256", "MM_EM_RESIDENT": "1"}), ("launches, grid 256", {"MM_EM_GRID": "256"}), ("launches, grid 1024", {"MM_EM_GRID": "1024"}),
                 ("collective, one rank", {"MM_EM_FORCE_COLLECTIVE": "1", "_comm": "1"}),
+                ("collective, P2+P3 in one launch", {"MM_EM_FORCE_COLLECTIVE": "1", "MM_EM_SPLIT": "2", "_comm": "1"}),
                 ("collective, kernel A resident", {"MM_EM_FORCE_COLLECTIVE": "1", "MM_EM_RESIDENT": "1", "_comm": "1"})]
     for name, env in variants:
         for k in ("MM_EM_GRID", "MM_EM_SPLIT", "MM_EM_FORCE_COLLECTIVE", "MM_EM_ORDER", "MM_EM_DBG", "MM_EM_RESIDENT"):

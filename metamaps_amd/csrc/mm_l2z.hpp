@@ -236,26 +236,38 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
   if (((int)counters[11] & 0xff) == 10) { if (threadIdx.x < 64 * WAVES && (int)(threadIdx.x >> 6) < grp_n[blockIdx.x] && lane == 0) { L2Result z{}; out[c0 + (threadIdx.x >> 6)] = z; } return; }   // MM_L2_STOP=10: nothing at all (what the launches and the grouping cost)
   for (int i = threadIdx.x; i <= (int)bm; i += 64 * WAVES) BL[i] = 0;
   if (threadIdx.x == 0) *tmaxp = 0;
+  // (the sketch into LDS with coalesced, independent loads: the table loop below walked a thread's run of ranks with one dependent global load per rank,
+  //  nine round trips per workgroup before its first wave could start)
+  if constexpr (QLDS) {
+    for (int i = threadIdx.x; i < s; i += 64 * WAVES) QL[i] = Qg[i];
+    if (threadIdx.x < L2_QPAD) QL[s + threadIdx.x] = 0xffffffffu;
+  }
   __syncthreads();
   // T[b] = first rank whose bucket is >= b (every entry written exactly once, as in l2_kernel).  A thread takes a run of consecutive ranks, so that
   // the bucket of a hash is computed once (the float arithmetic of l2_bucket is most of this set-up) and its predecessor's is at hand.
   {
     const int per = (s + 64 * WAVES) / (64 * WAVES);             // ranks 0 .. s: s + 1 table steps
     const int i0 = (int)threadIdx.x * per, i1 = min(i0 + per, s + 1);
-    int bprev = (i0 > 0 && i0 <= s) ? l2_bucket(Qg[i0 - 1], tshift) : -1;
-    for (int i = i0; i < i1; ++i) {
-      int hi = 1 << TBITS;
-      if (i < s) {
-        const uint32_t h = Qg[i];
-        if constexpr (QLDS) QL[i] = h;
-        atomicOr(&BL[(h >> 5) & bm], (1u << (h & 31)) | (1u << ((h >> 20) & 31)));   // two bits of one word: one LDS read per test, ~2 % false positives at 15 bits per hash
-        hi = l2_bucket(h, tshift);
+    int bprev = (i0 > 0 && i0 <= s) ? l2_bucket(qat(i0 - 1), tshift) : -1;
+    for (int ib = i0; ib < i1; ib += 8) {                        // eight ranks per step: their hashes in flight together
+      uint32_t hh[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) hh[u] = qat(max(min(ib + u, s - 1), 0));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = ib + u;
+        if (i >= i1) break;
+        int hi = 1 << TBITS;
+        if (i < s) {
+          const uint32_t h = hh[u];
+          atomicOr(&BL[(h >> 5) & bm], (1u << (h & 31)) | (1u << ((h >> 20) & 31)));   // two bits of one word: one LDS read per test, ~2 % false positives at 15 bits per hash
+          hi = l2_bucket(h, tshift);
+        }
+        for (int bb = bprev + 1; bb <= hi; ++bb) T[bb] = (uint16_t)i;
+        bprev = hi;
       }
-      for (int bb = bprev + 1; bb <= hi; ++bb) T[bb] = (uint16_t)i;
-      bprev = hi;
     }
   }
-  if constexpr (QLDS) { if (threadIdx.x < L2_QPAD) QL[s + threadIdx.x] = 0xffffffffu; }
   __syncthreads();
   {
     int tm = 0;
@@ -426,6 +438,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
   }
 
   // ---- pass A: membership.  Bit table per entry; what passes it goes through the ring and is searched, 64 at a time --------------
+  if (dbg_stop == 11) { release_slot(); return; }                 // (the wave's preamble alone: range searches, scratch slot, band prediction)
   int n_ml = 0;
   {
     int head = 0, tail = 0, carry = 0, carryLo = 0, carryA = 0;

@@ -1,4 +1,4 @@
-"""K5 kernel time when the zone kernel leaves after a phase (MM_L2_STOP=n: 1 set-up, 2 pass A, 3 e_min + first bounds, 4 pass B + second bounds,
+"""K5 kernel time when the zone kernel leaves after a phase (MM_L2_STOP=n: 10 nothing, 1 set-up, 11 the waves' preamble, 2 pass A, 3 e_min + first bounds, 4 pass B + second bounds,
 8 first window state, 5 sweep, 0 everything), bench batch: python tools/l2z_stops.py [LO HI N]"""
 import os, sys
 import numpy as np

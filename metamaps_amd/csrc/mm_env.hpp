@@ -86,6 +86,7 @@ inline const EnvSwitch* env_table(size_t* n) {
     {"MM_L2_V1_LONG", "unset", "test", "the long-read classes (sketches of 3 073 .. 13 000 hashes) through l2_kernel, the 10 kb class through the zone kernel"},
     {"MM_L2_SMALL_QLDS", "unset", "tuning", "zone kernel, two-wave workgroups (groups of one or two candidates): the sketch in LDS as in the four-wave workgroups instead of searched in global memory"},
     {"MM_L2_NO_FUSE", "unset", "test", "zone kernel without the band predicted from L1's seed-hit count: its masks always come from a second pass over the stream"},
+    {"MM_L2_NO_RANGES", "unset", "test", "the zone kernel's waves search their candidates' index ranges themselves (until round 6) instead of taking them from l2_ranges_kernel (cross-check)"},
     {"MM_L2Z_DBG", "unset", "debug", "zone kernel writes pivot-minus-estimate and its pass count INSTEAD OF RESULTS (tools/l2z_pivot_hist.py; 2: against the predicted estimate)"},
     {"MM_L2_ONE_STREAM", "unset", "test", "the two launches of K5's 10 kb class one behind the other on the context's stream instead of side by side (auxiliary stream)"},
     {"MM_L2_NO_SLOTS", "unset", "test", "K5 scratch indexed by wave number of the launch instead of per-XCD slots taken and given back"},

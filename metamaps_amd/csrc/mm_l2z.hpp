@@ -211,7 +211,8 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
            int32_t* __restrict__ big_list, unsigned int* __restrict__ big_n /* more than 4096 NWQ streamed entries */,
            uint8_t* __restrict__ amb_used, uint32_t* __restrict__ ml_buf /* 4096 NWQ words per slot */, uint8_t* __restrict__ mask_buf /* l2z_mask_bytes(NWQ) per slot */,
            unsigned int* __restrict__ slot_flags, int n_slots,
-           const int32_t* __restrict__ cand_hint /* seed hits inside each candidate (l1_wave_kernel; 0: none): what the best window's matched count will be */) {
+           const int32_t* __restrict__ cand_hint /* seed hits inside each candidate (l1_wave_kernel; 0: none): what the best window's matched count will be */,
+           const int64_t* __restrict__ cand_rng /* optional: [first, behind-last) index entry of each candidate's stream (l2_ranges_kernel) */) {
   extern __shared__ __align__(16) uint32_t lds[];
   constexpr int NW = 64 * NWQ, CAP = 64 * NW, NW1 = NW + 1;
   constexpr int QCAP = l2z_qcap(QLDS);
@@ -305,8 +306,12 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     if (lane == 0) { L2Result z{}; out[c] = z; ovf_list[atomicAdd(ovf_n, 1u)] = (int32_t)c; }
     return;
   }
-  const int64_t first0 = contig_lower_bound_wpos(I, contig, rs, lane);                // searchIndex, :466
-  const int64_t last0 = max(first0, contig_lower_bound_wpos(I, contig, re + len, lane));   // :477
+  int64_t first0, last0;
+  if (cand_rng) { first0 = cand_rng[2 * c]; last0 = cand_rng[2 * c + 1]; }   // (made for all candidates at once: mm_map.hip, l2_ranges_kernel)
+  else {
+    first0 = contig_lower_bound_wpos(I, contig, rs, lane);                // searchIndex, :466
+    last0 = max(first0, contig_lower_bound_wpos(I, contig, re + len, lane));   // :477
+  }
   if (last0 - first0 > (int64_t)CAP) {                           // (merged candidates over long repeats)
     if (lane == 0) { L2Result z{}; out[c] = z; big_list[atomicAdd(big_n, 1u)] = (int32_t)c; }
     return;
@@ -1094,12 +1099,13 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
     accepted = 1;
     int votes = 0, amb_votes = 0;
     const int i0 = pfx(mAll, pAll, opt_b), i1 = pfx(mAll, pAll, opt_e);
-    for (int ib = i0; ib < i1; ib += 256) {                      // four batches of 64 matched entries per step: their three dependent loads each in flight together
-      uint32_t ew[4], sq[4], pwj[4]; bool cnt_it[4]; int jv[4];
+    constexpr int VB = 8;                                        // (the best window of a 10 kb read holds 600-900 matched entries: two steps instead of four)
+    for (int ib = i0; ib < i1; ib += 64 * VB) {                  // VB batches of 64 matched entries per step: their three dependent loads each in flight together
+      uint32_t ew[VB], sq[VB], pwj[VB]; bool cnt_it[VB]; int jv[VB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int i = ib + 64 * u + lane; ew[u] = i < i1 ? ML[i] : 0xffffffffu; }
+      for (int u = 0; u < VB; ++u) { const int i = ib + 64 * u + lane; ew[u] = i < i1 ? ML[i] : 0xffffffffu; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < VB; ++u) {
         const int rk = (int)((ew[u] >> 15) & 0x7fffu);
         jv[u] = (int)(ew[u] & 0x7fffu);
         cnt_it[u] = ew[u] != 0xffffffffu && rk < bestR;
@@ -1107,7 +1113,7 @@ l2z_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restr
         pwj[u] = cnt_it[u] ? pos[jv[u]].pw : 0u;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < VB; ++u) {
         if (ib + 64 * u >= i1) continue;                         // (wave-uniform)
         const bool unres = (sq[u] & 2u) && amb_used != nullptr;
         const int contrib = cnt_it[u] ? (((sq[u] & 1u) ? 1 : -1) * pw_strand(pwj[u])) : 0;

@@ -1259,6 +1259,30 @@ __global__ void __launch_bounds__(256) l2_group_unpack_kernel(const uint64_t* __
   g0[p] = (int32_t)(val[g] >> 32); gn[p] = (int32_t)(uint32_t)val[g];
 }
 
+// The streamed range of every candidate (computeMap.hpp:466, :477) — first index entry at or beyond the candidate's start, first at or beyond its end + read length —
+// one thread per candidate, both searches interleaved.  The zone kernel's waves did these searches themselves, one behind the other: eight dependent round trips in
+// front of every candidate's stream (directory, bucket bounds, two 64-ary probes, twice).  Same lower bounds as contig_lower_bound_wpos (mm_l2.hpp).
+__global__ void __launch_bounds__(256) l2_ranges_kernel(IndexView I, const int32_t* __restrict__ cand, const int32_t* __restrict__ cand_read, const int32_t* __restrict__ read_len,
+                                                        int64_t n, int64_t* __restrict__ rng) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  const int contig = cand[3 * c], rs = cand[3 * c + 1], re = cand[3 * c + 2];
+  const int len = read_len[cand_read[c]];
+  const int64_t cbeg = (int64_t)I.cstart[contig];
+  const uint64_t d0 = I.dir_off[contig], nb = I.dir_off[contig + 1] - d0 - 1;
+  const int t0 = rs, t1 = re + len;
+  const uint64_t b0 = min((uint64_t)max(t0, 0) >> I.dir_shift, nb - 1), b1 = min((uint64_t)max(t1, 0) >> I.dir_shift, nb - 1);
+  int64_t lo0 = cbeg + (int64_t)I.dir[d0 + b0], hi0 = cbeg + (int64_t)I.dir[d0 + b0 + 1];
+  int64_t lo1 = cbeg + (int64_t)I.dir[d0 + b1], hi1 = cbeg + (int64_t)I.dir[d0 + b1 + 1];
+  while (lo0 < hi0 || lo1 < hi1) {
+    const int64_t m0 = lo0 < hi0 ? (lo0 + hi0) >> 1 : lo0, m1 = lo1 < hi1 ? (lo1 + hi1) >> 1 : lo1;
+    const uint32_t p0 = I.pos[min(m0, I.N - 1)].pw, p1 = I.pos[min(m1, I.N - 1)].pw;
+    if (lo0 < hi0) { if (pw_wpos(p0) < t0) lo0 = m0 + 1; else hi0 = m0; }
+    if (lo1 < hi1) { if (pw_wpos(p1) < t1) lo1 = m1 + 1; else hi1 = m1; }
+  }
+  rng[2 * c] = lo0; rng[2 * c + 1] = max(lo0, lo1);
+}
+
 __global__ void __launch_bounds__(256) l2_stats_kernel(const L2Result* __restrict__ l2, int64_t n, unsigned long long* __restrict__ counters) {
   __shared__ unsigned long long acc[5];
   if (threadIdx.x < 5) acc[threadIdx.x] = 0;
@@ -1931,6 +1955,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
   M->cand_read.alloc((size_t)std::max<int64_t>(ncand, 1));
   M->l2.alloc((size_t)std::max<int64_t>(ncand, 1));
   DBuf<int32_t> cand_hint((size_t)std::max<int64_t>(ncand, 1));   // seed hits inside each candidate (l1_wave_kernel): the zone kernel's prediction of its band
+  DBuf<int64_t> cand_rng;                                        // [first, behind-last) index entry of each candidate's stream (l2_ranges_kernel)
   const bool no_hint = l1_serial || getenv("MM_L2_NO_FUSE");
   if (no_hint) cand_hint.zero(st);                               // (0: no prediction, the masks of the band come from a second pass over the stream)
   M->rec_off.alloc((size_t)n + 1);
@@ -1940,6 +1965,11 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
     MM_KERNEL_CHECK();
     T.end(t_l1);
     // ---- K5/K6
+    if (!getenv("MM_L2_NO_RANGES")) {                            // (MM_L2_NO_RANGES=1: the zone kernel's waves search their ranges themselves, as until round 6)
+      cand_rng.alloc(2 * (size_t)ncand);
+      l2_ranges_kernel<<<dim3((unsigned)ceil_div(ncand, 256)), dim3(256), 0, st>>>(IV, M->cand.p, M->cand_read.p, M->d_read_len.p, ncand, cand_rng.p);
+      MM_KERNEL_CHECK();
+    }
     MM_REQUIRE(ncand < (1LL << 31), MM_ERR_LIMIT, "more than 2^31 L1 candidates in one batch");
     const int smax = M->smax;
     const char* full_env = getenv("MM_L2_FULL");                 // cross-check switch: evaluate every window
@@ -2164,7 +2194,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
             const size_t lds = l2z_lds_bytes(smA, 2, true, bbl, 4);
             set_lds((const void*)l2z_kernel<4, 2, true>, lds);
             l2z_kernel<4, 2, true><<<dim3((unsigned)nA), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p,
-                M->accept_min.p, P.k, P.w, smA, bbl, M->l2.p, counters.p, d_gA0.p, d_gAn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)codes, masks, slot_flags_p, n_slots, cand_hint_p);
+                M->accept_min.p, P.k, P.w, smA, bbl, M->l2.p, counters.p, d_gA0.p, d_gAn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)codes, masks, slot_flags_p, n_slots, cand_hint_p, cand_rng.p);
             MM_KERNEL_CHECK();
           }
           if (nS) {
@@ -2174,12 +2204,12 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
               const size_t lds = l2z_lds_bytes(smA, 2, true, bbl, 2);
               set_lds((const void*)l2z_kernel<2, 2, true>, lds);
               l2z_kernel<2, 2, true><<<dim3((unsigned)nS), dim3(128), lds, st_small>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p,
-                  M->accept_min.p, P.k, P.w, smA, bbl, M->l2.p, counters.p, d_gS0.p, d_gSn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)codes, masks, slot_flags_p, n_slots, cand_hint_p);
+                  M->accept_min.p, P.k, P.w, smA, bbl, M->l2.p, counters.p, d_gS0.p, d_gSn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)codes, masks, slot_flags_p, n_slots, cand_hint_p, cand_rng.p);
             } else {
               const size_t lds = l2z_lds_bytes(smA, 2, false, bbl, 2);
               set_lds((const void*)l2z_kernel<2, 2, false>, lds);
               l2z_kernel<2, 2, false><<<dim3((unsigned)nS), dim3(128), lds, st_small>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p,
-                  M->accept_min.p, P.k, P.w, smA, bbl, M->l2.p, counters.p, d_gS0.p, d_gSn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)codes, masks, slot_flags_p, n_slots, cand_hint_p);
+                  M->accept_min.p, P.k, P.w, smA, bbl, M->l2.p, counters.p, d_gS0.p, d_gSn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)codes, masks, slot_flags_p, n_slots, cand_hint_p, cand_rng.p);
             }
             MM_KERNEL_CHECK();
           }
@@ -2212,7 +2242,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           const size_t lds = l2z_lds_bytes(smB, 8, false, bbl, 4);
           set_lds((const void*)l2z_kernel<4, 8, false>, lds);
           l2z_kernel<4, 8, false><<<dim3((unsigned)gB0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p,
-              M->accept_min.p, P.k, P.w, smB, bbl, M->l2.p, counters.p, d_gB0.p, d_gBn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)lists_for(gB0.size() * 4, 8), zmasks_for(gB0.size() * 4, 8), slot_flags_p, (int)slots_of(gB0.size() * 4), cand_hint_p);
+              M->accept_min.p, P.k, P.w, smB, bbl, M->l2.p, counters.p, d_gB0.p, d_gBn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)lists_for(gB0.size() * 4, 8), zmasks_for(gB0.size() * 4, 8), slot_flags_p, (int)slots_of(gB0.size() * 4), cand_hint_p, cand_rng.p);
           MM_KERNEL_CHECK();
         } else {
           const size_t lds = l2_lds_bytes<uint8_t>(smB, true, 4, 8);
@@ -2231,7 +2261,7 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
           const size_t lds = l2z_lds_bytes(smD, 8, false, bbl, 4);
           set_lds((const void*)l2z_kernel<4, 8, false>, lds);
           l2z_kernel<4, 8, false><<<dim3((unsigned)gD0.size()), dim3(256), lds, st>>>(IV, M->cand.p, M->cand_read.p, M->sk_hash.p, M->sk_strand.p, M->mz.off.p, M->sk_n.p, M->d_read_len.p,
-              M->accept_min.p, P.k, P.w, smD, bbl, M->l2.p, counters.p, d_gD0.p, d_gDn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)lists_for(gD0.size() * 4, 8), zmasks_for(gD0.size() * 4, 8), slot_flags_p, (int)slots_of(gD0.size() * 4), cand_hint_p);
+              M->accept_min.p, P.k, P.w, smD, bbl, M->l2.p, counters.p, d_gD0.p, d_gDn.p, ovf.p, ovf_n.p, big.p, big_n.p, amb_used_p, (uint32_t*)lists_for(gD0.size() * 4, 8), zmasks_for(gD0.size() * 4, 8), slot_flags_p, (int)slots_of(gD0.size() * 4), cand_hint_p, cand_rng.p);
           MM_KERNEL_CHECK();
         } else {
           const size_t lds = l2_lds_bytes<uint8_t>(smD, true, 4, 8);

@@ -1049,7 +1049,7 @@ def test_zone_kernel_equals_rank_code_kernel(ctx, monkeypatch):
     128 ranks, the band predicted from L1's seed-hit count) by default; l2_kernel (a rank code per streamed entry, MM_L2_V1=1) is the same
     algorithm in its first form.  Reads of 1-60 kb on a repeat-rich reference (duplicate hashes inside windows, DP/DN flags): the default, the zone
     kernel without the predicted band (MM_L2_NO_FUSE: the band's masks from a second pass), the zone kernel for the 10 kb class only
-    (MM_L2_V1_LONG), both with a lowered saturation of the duplicate distances (MM_DUP_SAT: the scan fall-back), and l2_kernel must give
+    (MM_L2_V1_LONG), the zone kernel searching its index ranges itself (MM_L2_NO_RANGES; by default l2_ranges_kernel makes them for all candidates at once), all with a lowered saturation of the duplicate distances (MM_DUP_SAT: the scan fall-back), and l2_kernel must give
     identical records; the L2 tuples of every candidate are compared as well."""
     res = {}
     for sat in ("default", "40"):
@@ -1061,7 +1061,7 @@ def test_zone_kernel_equals_rank_code_kernel(ctx, monkeypatch):
         idx = ctx.index(ref, 16, 8)
         monkeypatch.delenv("MM_DUP_SAT", raising=False)
         for mode, env in (("zone", {}), ("zone_two_pass", {"MM_L2_NO_FUSE": "1"}), ("zone_short", {"MM_L2_V1_LONG": "1"}), ("zone_short_two_pass", {"MM_L2_V1_LONG": "1", "MM_L2_NO_FUSE": "1"}),
-                          ("rank_codes", {"MM_L2_V1": "1"})):
+                          ("zone_own_ranges", {"MM_L2_NO_RANGES": "1"}), ("rank_codes", {"MM_L2_V1": "1"})):
             for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
             M = ctx.map_batch(idx, reads, 16, 8)
             off, rec = M.fetch()
@@ -1071,7 +1071,7 @@ def test_zone_kernel_equals_rank_code_kernel(ctx, monkeypatch):
             for k_ in env: monkeypatch.delenv(k_)
         base = res[(sat, "rank_codes")]
         assert base[3]["n_candidates"] > 10_000 and base[3]["n_mappings"] > 5_000
-        for mode in ("zone", "zone_two_pass", "zone_short", "zone_short_two_pass"):
+        for mode in ("zone", "zone_two_pass", "zone_short", "zone_short_two_pass", "zone_own_ranges"):
             got = res[(sat, mode)]
             assert np.array_equal(base[0], got[0]) and np.array_equal(base[1], got[1]), (sat, mode)
             acc = base[2][:, 5] == 1

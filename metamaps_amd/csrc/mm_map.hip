@@ -960,12 +960,15 @@ __global__ void __launch_bounds__(SF_THREADS) __attribute__((amdgpu_waves_per_eu
           L.alive[tid] = al;
         }
         lapp(10);                                                  // (alive)
-        // the next read's home sectors: in flight from here to the top of the next iteration
+        lds_barrier();
+        lapp(4);
+        // The next read's home sectors: in flight from here to the top of the next iteration.  Issued BEHIND the barrier that publishes alive[] (round 6; until then in front
+        // of it): the look-ups leave a CU at the rate its address path takes them (2 816 sectors, the kernel's bound), and a wave whose eleven are out goes on to
+        // the bit tests instead of waiting at the barrier for the last wave's — the step 38.9-39.5 -> 36.4-38.2 ms in turns on one box, this kernel 12.6-13.1 -> 11.9-12.6 ms
+        // (profiles/r06_ab_k3_barrier_first.txt).
         issue_lookups();
         lapp(11);                                                  // (hashes arrived, look-ups issued)
         next_issued = true;
-        lds_barrier();
-        lapp(4);
         // ---- phase 2: bit tests over the parked codes (seed_filter_kernel, phase 2)
         uint64_t* const dst = stage + stage_base;
         uint16_t* const sv = reinterpret_cast<uint16_t*>(L.cnt);   // (2 x 8 256 slots: stage_cap = 1024 + 2 x sketch size <= 6 656, unless the test hook MM_HF_STAGE_CAP says otherwise)
@@ -1745,8 +1748,8 @@ void map_batch(mm_ctx* ctx, const mm_index* I, const mm_seqset* reads, const mm_
         fprintf(stderr, "MM_SF_PROF share of cycles: zero+top %.3f | next head + resolve %.3f | scan %.3f | lists+count %.3f | window sums+alive+issue %.3f | phase 2 %.3f | survivors+end %.3f | total %.3g cycles over %d workgroups\n",
                 h[0] / tot, (h[1] + h[7]) / tot, h[2] / tot, (h[3] + h[8]) / tot, (h[4] + h[9] + h[10] + h[11]) / tot, (h[5] + h[12]) / tot, h[6] / tot, tot, sf_grid);
         fprintf(stderr, "MM_SF_PROF in detail: top %.3f | first answers + second probes issued %.3f, their answers %.3f | scan %.3f | pieces loaded, counted, parked %.3f, next hashes asked for + barrier %.3f | "
-                        "window sums %.3f, alive %.3f, hashes there + look-ups issued %.3f, barrier %.3f | bit tests + slots %.3f, barrier %.3f | survivors+end %.3f\n",
-                h[0] / tot, h[7] / tot, h[1] / tot, h[2] / tot, h[8] / tot, h[3] / tot, h[9] / tot, h[10] / tot, h[11] / tot, h[4] / tot, h[12] / tot, h[5] / tot, h[6] / tot);
+                        "window sums %.3f, alive %.3f, barrier %.3f, hashes there + look-ups issued %.3f | bit tests + slots %.3f, barrier %.3f | survivors+end %.3f\n",
+                h[0] / tot, h[7] / tot, h[1] / tot, h[2] / tot, h[8] / tot, h[3] / tot, h[9] / tot, h[10] / tot, h[4] / tot, h[11] / tot, h[12] / tot, h[5] / tot, h[6] / tot);
       }
     }
   }

@@ -51,7 +51,9 @@ namespace mm {
 __host__ __device__ constexpr int l2z_qcap(bool qlds) { return qlds ? L2Z_RING : 2 * L2Z_RING; }   // (sketch searched in global memory: two searches per lane at a time, see dense2)
 constexpr int L2Z_QCAP_ = L2Z_RING;                                   // ring of compacted (hash, entry) pairs waiting for the search (4 + 2 bytes each): eight words are added at a time, 64 taken
 #ifndef L2Z_WAVES_10K
-#define L2Z_WAVES_10K 6                                         // waves per SIMD the 10 kb class is compiled for
+#define L2Z_WAVES_10K 5                                         // waves per SIMD the 10 kb class is compiled for (96 registers).  6 (80 registers) was the better choice while the band loop
+                                                                // kept hoisted values in scratch (12.99 against 13.35 ms); without them 5 is: 9.87 + 1.87 -> 9.70 + 1.74 ms, the step - 0.3 ms
+                                                                // (4: 11.15 + 1.83, 7: 10.75 + 2.20; profiles/r06_ab_k5_waves.txt)
 #endif
 #ifndef L2Z_WAVES_LONG
 #define L2Z_WAVES_LONG 4

@@ -46,7 +46,7 @@ TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r06_traffic.json",
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 12; --config 4: 4 passes, --config 5: 2 passes of ~20 s)")   # (three worker contexts take the steps in turn: a timed region of three steps would be one round of them, no steady state)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 36, --config 3: 12; --config 4: 4 passes, --config 5: 2 passes of ~20 s)")   # (three worker contexts take the steps in turn: a timed region of three steps would be one round of them, no steady state)
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 3; --config 4: 1, --config 5: 0)")
     # workload: BASELINE configs[1] shape; scale knobs exist so that smaller boxes / quick checks can run
     ap.add_argument("--shape", choices=("community", "uniform"), default=os.environ.get("MM_BENCH_SHAPE", "community"))
@@ -115,7 +115,9 @@ def build_reference(ctx, args, shape):
 def default_steps(args):
     """K / W when the caller names none: enough steps for a steady state of three workers, few passes where a pass is seconds"""
     if args.steps is None:
-        args.steps = {4: 4, 5: 2}.get(args.config, 12)
+        # 36 steps of ~37 ms: the three worker contexts start the timed region together and finish it together — ~17 ms of fill and drain, which twelve steps carried as
+        # 1.4 ms each (tools/alloc_probe.sh, MM_BENCH_STEP_LOG: 39.7 ms per step over 12 steps, 37.5-37.9 over 36, 36.9 over 60 on one box)
+        args.steps = {3: 12, 4: 4, 5: 2}.get(args.config, 36)
     if args.warmup is None:
         args.warmup = {4: 1, 5: 0}.get(args.config, 3)
 
@@ -265,6 +267,10 @@ def main():
             post, best = em.posteriors(f)
             em.close()
             tt.append(time.perf_counter())
+            if os.environ.get("MM_BENCH_STEP_LOG"):                  # per step: worker, batch, host sections and the device's stage times (which step of the timed region is long, and where)
+                print(f"STEPLOG ticket {ticket} worker {wi} batch {ticket % B}: start {tt[0] * 1e3:.1f} map_batch {(tt[1] - tt[0]) * 1e3:.1f} mapq+fetch {(tt[2] - tt[1]) * 1e3:.1f} "
+                      f"em {(tt[3] - tt[2]) * 1e3:.1f} post {(tt[4] - tt[3]) * 1e3:.1f} end {tt[4] * 1e3:.1f} | device ms: K1 {st['ms_minimizer']:.1f} K2 {st['ms_sketch']:.1f} K3 {st['ms_probe_gather']:.1f} "
+                      f"sort {st['ms_sort_hits']:.1f} L1 {st['ms_l1_scan']:.1f} K5 {st['ms_l2']:.1f} total {st['ms_total']:.1f} | cands {st['n_candidates']} em_iters {len(lls)}", file=sys.stderr, flush=True)
             with agg_lock:
                 agg["host_ms"] = {"map_batch": (tt[1] - tt[0]) * 1e3, "mapq_fetch": (tt[2] - tt[1]) * 1e3, "em_prepare_iterate": (tt[3] - tt[2]) * 1e3,
                                   "posteriors": (tt[4] - tt[3]) * 1e3}
@@ -297,9 +303,11 @@ def main():
         agg.update({"ms_l2": 0.0, "ms_hf": 0.0, "ms_mz": 0.0, "launches": 0, "l2_stream": 0, "hf_units": 0, "bases": 0, "done_t": []})
         barrier()
         t0 = time.perf_counter()
+        if os.environ.get("MM_ALLOC_TRACE"): print(f"MM_ALLOC_TRACE (bench) timed region starts at {time.time() * 1e3:.1f} ms", file=sys.stderr, flush=True)
         run_steps(steps, sched)
         barrier()
         dt = time.perf_counter() - t0
+        if os.environ.get("MM_ALLOC_TRACE"): print(f"MM_ALLOC_TRACE (bench) timed region ends at {time.time() * 1e3:.1f} ms", file=sys.stderr, flush=True)
         if os.environ.get("MM_BENCH_RANK_LOG"):                       # tools/scale_check.sh: what every rank saw
             nr, rk = ctx.comm_info()
             print(f"RANKLOG rank {rank}/{world}: RCCL communicator of {nr} ranks (this one {rk}), {steps} steps in {dt * 1e3:.1f} ms, "

@@ -200,7 +200,7 @@ struct DevAlloc {
     // driver has seen freed is cleared when it is handed out again — 1 ms per 27 MB, up to seconds when a large region is due
     // (MM_ALLOC_TRACE, round 3: one 738 MB allocation of a bench step took 2.0 s).  With headroom the buffers of the first batches also
     // serve the later ones, and a process in steady state does not go to the driver at all.
-    if (it != cache.end() && it->first <= want + want / 4 + (want >= ((size_t)64 << 20) ? want * 7 / 20 : 0)) {
+    if (it != cache.end() && it->first <= want + want / 4 + (want >= ((size_t)256 << 10) ? want * 7 / 20 : 0)) {
       void* p = it->second; *got = it->first; cached_bytes -= it->first; cache.erase(it); return p;
     }
     }
@@ -216,17 +216,27 @@ struct DevAlloc {
         if (fr > tot / 5) ask = round_up(want + want / 4);
         refuse = fr < want + RUNTIME_RESERVE;
       }
+    } else if (want >= ((size_t)256 << 10)) {
+      // buffers of 256 KiB .. 64 MiB — per-read and per-candidate arrays — get the same quarter of headroom (no driver query: they cannot fill a device): without it every batch
+      // with a few per cent more candidates than its worker context had seen went to the driver for ~50 blocks (round 6, tools/alloc_probe.sh: 141 driver allocations, 1.3 GB,
+      // inside the bench's twelve timed steps)
+      static const bool mid_headroom = getenv("MM_ALLOC_NO_MID_HEADROOM") == nullptr;
+      if (mid_headroom) ask = round_up(want + want / 4);
     }
     void* p = nullptr;
     static const bool trace = getenv("MM_ALLOC_TRACE") != nullptr;     // every block that comes from the driver, with its cost
     static const bool use_slabs = getenv("MM_NO_SLABS") == nullptr;
     if (use_slabs && !eager && !in_build && want >= SLAB_FROM_BYTES) {
-      if (void* q = slab_piece(device, ask)) { *got = SlabSet::granules(ask); if (trace) fprintf(stderr, "MM_ALLOC_TRACE slab piece %zu bytes\n", *got); return q; }
+      const auto ts0 = std::chrono::steady_clock::now();
+      if (void* q = slab_piece(device, ask)) { *got = SlabSet::granules(ask); if (trace) fprintf(stderr, "MM_ALLOC_TRACE slab piece %zu bytes %.3f ms at %.1f ms\n", *got,
+                                                                                               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count(),
+                                                                                               std::chrono::duration<double, std::milli>(std::chrono::system_clock::now().time_since_epoch()).count()); return q; }
     }
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = refuse ? hipErrorOutOfMemory : dev_malloc(&p, ask);
     size_t granted = ask;
-    if (trace) fprintf(stderr, "MM_ALLOC_TRACE hipMalloc %zu bytes %.3f ms\n", ask, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (trace) fprintf(stderr, "MM_ALLOC_TRACE hipMalloc %zu bytes %.3f ms at %.1f ms\n", ask, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                       std::chrono::duration<double, std::milli>(std::chrono::system_clock::now().time_since_epoch()).count());
     if (e == hipErrorOutOfMemory) {
       if (trace) { int dv0 = 0; (void)hipGetDevice(&dv0); fprintf(stderr, "MM_ALLOC_TRACE out of memory at a request of %zu bytes (%zu bytes pooled)\n", want, big_pool_bytes(dv0)); }
       (void)hipGetLastError(); int dv = 0; (void)hipGetDevice(&dv);

@@ -54,6 +54,7 @@ inline const EnvSwitch* env_table(size_t* n) {
     {"MM_INDEX_PRETRIM", "unset", "test", "a device-filling index build hands the pool back before it starts (round-4 mid-round behaviour)"},
     {"MM_INDEX_NO_PRETRIM", "unset", "test", "... and does not even trim the context's own cache"},
     {"MM_ALLOC_TRACE", "unset", "debug", "every block that comes from the driver, with its cost, on stderr"},
+    {"MM_ALLOC_NO_MID_HEADROOM", "unset", "test", "device buffers of 256 KiB .. 64 MiB are asked for without the quarter of headroom that lets later, slightly larger batches reuse them (round 5 behaviour)"},
     {"MM_CTX_TRACE", "unset", "debug", "phases of mm_ctx_create (HIP initialisation, stream, allocator) on stderr"},
     {"MM_HOST_TIMING", "unset", "debug", "host-side sections of mm_map_batch and of the index build on stderr"},
     {"MM_PACK_SCALAR", "unset", "test", "mm_seqset_upload packs bases with the byte-table loop only (cross-check of the AVX2 path, host_pack.cpp)"},

@@ -6,7 +6,7 @@ strand, some random, some with N — every mapping record must equal the oracle'
 Round 2: MM_FUZZ_SEEDS=2500 MM_FUZZ_LONG_SEEDS=300 and, with MM_FUZZ_SEED_BASE=100000, 2000 + 250 more ran clean on an MI355X
 (66 minutes together); round 5's tree: MM_FUZZ_SEEDS=1500 MM_FUZZ_LONG_SEEDS=150 MM_FUZZ_SEED_BASE=500000 clean in 16 minutes
 and, on the rewritten seed filter, 2000 + 200 at base 700000 and 200 + 600 at base 900000 (profiles/r05_fuzz_campaign.txt); round 6's final tree (zone kernel, range kernel, K3's barrier placement):
-MM_FUZZ_SEEDS=1500 MM_FUZZ_LONG_SEEDS=150 MM_FUZZ_SEED_BASE=700000, 1650 cases clean in 15 minutes; the suite keeps 24 + 6 seeds."""
+MM_FUZZ_SEEDS=1500 MM_FUZZ_LONG_SEEDS=150 MM_FUZZ_SEED_BASE=700000, 1650 cases clean in 15 minutes, and 1500 + 200 at base 1100000 (new seeds) in 15; the suite keeps 24 + 6 seeds."""
 import os
 
 import numpy as np
